@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- text-line images/sec of the full CRNN-OCR train step on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run, one rank/GPU)
+
+A "step" = forward (train mode: batch statistics, dropout) + CTC loss + backward + [RCCL all-reduce of the
+flat fp32 gradient buffer] + global-norm clip + Adam + BatchNorm moving-statistics update on one synthetic
+batch that is already resident in HBM.  Workload = BASELINE.json configs[1]: 100x32x1 images, batch 256 per
+GPU, max_len 23, time_dense_size 128, n_units 256 (LSTM), Adam(1e-4, beta1 .5, clipnorm 5).  Weak scaling
+(global batch 256*N).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "crnn-ocr-lite_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def pointwise_gemm_roofline(eng, iters=5):
+    """Dominant kernel = gemm_f32_kernel<128,false,true> (NN fp32 MFMA GEMM: the pointwise 1x1 convs b2..b7,
+    dense1 and the RNN input projections).  Re-issue exactly those launches of one step on the live buffers,
+    bracketed by events on the stream they run on, and report flops / time."""
+    import ctypes
+    from crnn_mi355x.engine import _ptr, _stream
+    lib = eng.lib
+    B, T = eng.B, eng.T
+    cfgs = []
+    h, w, cin = eng.cfg.imgh + 4, eng.cfg.imgw + 4, 1
+    blocks = [(64, 1, 1), (128, 1, 1), (256, 2, 2), (256, 1, 1), (512, 1, 2), (512, 1, 1), (512, 1, 1)]
+    for i, (co, ph, pw) in enumerate(blocks, 1):
+        M = B * h * w
+        if co > 64:
+            cfgs.append((eng.ws_tensor("a%d" % i), eng.params[eng.layout["b%d_pw" % i][0]:], eng.ws_tensor("q%d" % i), M, co, cin))
+        h, w, cin = h // ph, w // pw, co
+    feat = w * cin
+    TB = T * B
+    scratch = eng.ws_tensor("gemm_scratch")
+    cfgs.append((eng.ws_tensor("x7"), eng.params[eng.layout["dense1_w"][0]:], eng.ws_tensor("gA"), TB, eng.cfg.tds, feat))
+    u, G = eng.cfg.units, 4 * eng.cfg.units
+    for n, src, k in (("rnn1f_w", "dn1", eng.cfg.tds), ("rnn1b_w", "dn1", eng.cfg.tds), ("rnn2f_w", "r1", u), ("rnn2b_w", "r1", u)):
+        cfgs.append((eng.ws_tensor(src), eng.params[eng.layout[n][0]:], eng.ws_tensor("gB"), TB, G, k))
+    flops = sum(2.0 * M * N * K for _, _, _, M, N, K in cfgs)
+    times = []
+    for it in range(iters + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for A, Bm, C, M, N, K in cfgs:
+            lib.crnn_gemm_f32(0, _ptr(A), _ptr(Bm), _ptr(C), M, N, K, K, N, N, None, 0, 0, 0, _ptr(scratch), 128 * 1024 * 1024, _stream())
+        e1.record()
+        torch.cuda.synchronize()
+        if it:
+            times.append(e0.elapsed_time(e1) * 1e-3)
+    t = float(np.median(times))
+    ach = flops / t / 1e12
+    return {"bound": "mfma", "kernel": "gemm_f32_kernel (fp32 MFMA 32x32x2, pointwise 1x1 convs + dense1 + RNN input GEMMs)",
+            "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+            "launches": len(cfgs), "avg_launch_ms": round(1e3 * t / len(cfgs), 4), "flops_per_step_set": flops, "traffic": None}
+
+
+def cpu_baseline(seconds_target=15.0):
+    """The CPU restatement (oracle, 'port') timed on this box's host cores on a bounded sample of the same
+    workload: full fp32 train step (forward, CTC, backward, clip, Adam) at batch 16."""
+    from oracle import model as M
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    cfg = M.Config()
+    Bc = 16
+    p, bn = M.init_params(cfg, seed=1, dtype=np.float32)
+    x, lab, il, ll = M.synthetic_batch(cfg, Bc, seed=0)
+    opt = M.Adam(lr=1e-4, beta_1=0.5, clipnorm=5.0)
+    n, t0 = 0, time.time()
+    while True:
+        loss, lb, g, c = M.loss_and_grads(cfg, p, bn, x, lab, il, ll)
+        p = opt.step(p, {k: g[k] for k in p})
+        n += 1
+        if time.time() - t0 > seconds_target or n >= 4:
+            break
+    dt = time.time() - t0
+    return {"value": round(n * Bc / dt, 2), "unit": "images/sec", "cores": int(cores), "kind": "port",
+            "sample": "%d full train steps at batch %d (NumPy fp32 restatement of the Keras/TF graph, %d BLAS threads; "
+                      "not Keras-TF itself, which is absent from the image)" % (n, Bc, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE configs[1]: 256)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+
+    from oracle import model as M   # only for the synthetic batch / init recipe and the cpu_baseline leg
+    from crnn_mi355x.engine import Engine
+    from crnn_mi355x.optimizers import Adam
+    from crnn_mi355x.parallel import GradAllReduce
+
+    B = args.batch
+    cfg = M.Config()
+    p, bn = M.init_params(cfg, seed=1, dtype=np.float32)         # identical weights on every rank
+    x, lab, il, ll = M.synthetic_batch(cfg, B, seed=rank)        # rank r draws its own shard
+    eng = Engine(B, dropout=True)
+    eng.set_params(p, bn)
+    xd = torch.from_numpy(x).cuda()
+    labd = torch.from_numpy(lab.astype(np.int32)).cuda(); ild = torch.from_numpy(il.astype(np.int32)).cuda()
+    lld = torch.from_numpy(ll.astype(np.int32)).cuda()
+    opt = Adam(lr=1e-4, beta_1=0.5, beta_2=0.999, clipnorm=5)
+    allreduce = GradAllReduce(eng, dist, world) if world > 1 else None
+
+    it = 0
+    for _ in range(args.warmup):
+        eng.train_step(xd, labd, ild, lld, opt, it, allreduce=allreduce); it += 1
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = eng.train_step(xd, labd, ild, lld, opt, it, allreduce=allreduce); it += 1
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    last_loss = float(loss.mean().item())
+
+    if rank == 0:
+        res = {
+            "metric": "text-line images/sec (train step)", "value": round(world * B * args.steps / dt, 1), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 100x32x1 text lines, batch %d/GPU, max_len 23, time_dense_size 128, "
+                                   "n_units 256 BiLSTM, STN on, dropout on, CTC, Adam(1e-4,b1=.5,clipnorm 5), fp32 MFMA" % B,
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": round(last_loss, 4)},
+        }
+        if not args.no_roofline:
+            res["roofline"] = pointwise_gemm_roofline(eng)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

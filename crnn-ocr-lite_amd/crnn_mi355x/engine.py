@@ -1,0 +1,200 @@
+"""Device-side engine: owns the flat parameter / gradient / optimizer-state buffers and the workspace
+(torch tensors = device memory + streams only) and drives libcrnn_mi355x through its C ABI.
+
+This is what the Keras engine + TensorFlow session were for the reference (Model.fit_generator ->
+train_on_batch, train.py:201; Model.predict_generator, predict.py:166).  No CPU fallback exists.
+"""
+import ctypes
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import native
+from .native import check, crnn_config
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Engine:
+    def __init__(self, batch, imgh=100, imgw=32, num_classes=38, max_len=23, time_dense_size=128, n_units=256,
+                 gru=False, stn=True, dropout=True, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("the CRNN hot path needs an AMD GPU (gfx950); there is no CPU fallback")
+        self.lib = native.lib()
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self.cfg = crnn_config(batch, imgh, imgw, num_classes, max_len, time_dense_size, n_units, int(bool(gru)),
+                               int(bool(stn)), int(bool(dropout)))
+        self._c = ctypes.byref(self.cfg)
+        nbytes = self.lib.crnn_workspace_bytes(self._c)
+        if nbytes == 0:
+            raise native.CrnnError("unsupported CRNN configuration (units %% 64, classes <= 64, max_len <= 31, LSTM only)")
+        self.T = self.lib.crnn_time_steps(self._c)
+        self.B, self.C = batch, num_classes
+        self.n_total = self.lib.crnn_params_total(self._c)
+        self.bn_total = self.lib.crnn_bn_total(self._c)
+        self.layout = OrderedDict()
+        name = ctypes.create_string_buffer(64)
+        off, size, ndim = ctypes.c_long(), ctypes.c_long(), ctypes.c_int()
+        dims = (ctypes.c_int * 4)()
+        for i in range(self.lib.crnn_num_params(self._c)):
+            check(self.lib.crnn_param_info(self._c, i, name, 64, ctypes.byref(off), ctypes.byref(size), ctypes.byref(ndim), dims))
+            self.layout[name.value.decode()] = (off.value, size.value, tuple(dims[:ndim.value]))
+        self.bn_layout = OrderedDict()
+        boff, bch, bcnt = ctypes.c_int(), ctypes.c_int(), ctypes.c_long()
+        for i in range(14):
+            check(self.lib.crnn_bn_info(self._c, i, name, 64, ctypes.byref(boff), ctypes.byref(bch), ctypes.byref(bcnt)))
+            self.bn_layout[name.value.decode()] = (boff.value, bch.value, bcnt.value)
+        dev = self.device
+        self.params = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
+        self.bn_mean = torch.zeros(self.bn_total, dtype=torch.float32, device=dev)
+        self.bn_var = torch.ones(self.bn_total, dtype=torch.float32, device=dev)
+        self.ws_bytes = nbytes
+        self.ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+        self.y_pred = torch.empty((batch, self.T, num_classes), dtype=torch.float32, device=dev)
+        self.loss = torch.zeros(batch, dtype=torch.float32, device=dev)
+        self.norm = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.norm_scratch = torch.zeros(1024, dtype=torch.float64, device=dev)
+        self.opt_state = {}
+
+    # ---- parameters -------------------------------------------------------------------------------------
+    def set_params(self, p, bn=None):
+        """p: {name: ndarray} in the oracle/Keras naming (oracle.model.Config.param_shapes)."""
+        flat = np.zeros(self.n_total, dtype=np.float32)
+        for name, (off, size, dims) in self.layout.items():
+            a = np.asarray(p[name], dtype=np.float32)
+            assert a.size == size, (name, a.shape, dims)
+            flat[off:off + size] = a.reshape(-1)
+        self.params.copy_(torch.from_numpy(flat))
+        if bn is not None:
+            m = np.zeros(self.bn_total, np.float32); v = np.ones(self.bn_total, np.float32)
+            for name, (off, ch, _) in self.bn_layout.items():
+                m[off:off + ch] = bn[name + "_mean"]; v[off:off + ch] = bn[name + "_var"]
+            self.bn_mean.copy_(torch.from_numpy(m)); self.bn_var.copy_(torch.from_numpy(v))
+
+    def _unflatten(self, flat):
+        flat = flat.detach().cpu().numpy()
+        return OrderedDict((n, flat[o:o + s].reshape(d).copy()) for n, (o, s, d) in self.layout.items())
+
+    def get_params(self):
+        return self._unflatten(self.params)
+
+    def get_grads(self):
+        return self._unflatten(self.grads)
+
+    def get_bn(self):
+        m, v = self.bn_mean.cpu().numpy(), self.bn_var.cpu().numpy()
+        out = OrderedDict()
+        for name, (off, ch, _) in self.bn_layout.items():
+            out[name + "_mean"] = m[off:off + ch].copy(); out[name + "_var"] = v[off:off + ch].copy()
+        return out
+
+    def ws_tensor(self, name):
+        off, cnt = ctypes.c_long(), ctypes.c_long()
+        check(self.lib.crnn_ws_tensor(self._c, name.encode(), ctypes.byref(off), ctypes.byref(cnt)), "ws_tensor " + name)
+        return self.ws[off.value:off.value + cnt.value]
+
+    # ---- hot path -----------------------------------------------------------------------------------------
+    def _as_input(self, x):
+        if not torch.is_tensor(x):
+            x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        x = x.to(self.device, dtype=torch.float32, non_blocking=True).contiguous()
+        assert x.numel() == self.B * self.cfg.imgh * self.cfg.imgw, "batch shape mismatch"
+        return x
+
+    def forward(self, x, train=False, seed=0):
+        """x (B,imgh,imgw,1) -> y_pred (B,T,C) device tensor (softmax)."""
+        x = self._as_input(x)
+        self._x = x
+        check(self.lib.crnn_forward(self._c, _ptr(self.params), _ptr(self.bn_mean), _ptr(self.bn_var), _ptr(x), _ptr(self.ws),
+                                    self.ws_bytes, _ptr(self.y_pred), int(train), int(seed), _stream()), "forward")
+        return self.y_pred
+
+    def _as_i32(self, a):
+        if not torch.is_tensor(a):
+            a = torch.from_numpy(np.ascontiguousarray(np.asarray(a).reshape(-1), dtype=np.int32))
+        return a.to(self.device, dtype=torch.int32).contiguous()
+
+    def backward(self, labels, input_length, label_length, seed=0):
+        """CTC + backward after forward(train=True).  Returns per-sample loss (device tensor, B)."""
+        self._lab = self._as_i32(labels); self._il = self._as_i32(input_length); self._ll = self._as_i32(label_length)
+        check(self.lib.crnn_backward(self._c, _ptr(self.params), _ptr(self.grads), _ptr(self._x), _ptr(self._lab), _ptr(self._il),
+                                     _ptr(self._ll), _ptr(self.ws), self.ws_bytes, _ptr(self.loss), int(seed), _stream()), "backward")
+        return self.loss
+
+    def bn_update(self):
+        check(self.lib.crnn_bn_update(self._c, _ptr(self.bn_mean), _ptr(self.bn_var), _ptr(self.ws), self.ws_bytes, _stream()), "bn_update")
+
+    def global_norm(self, clipnorm):
+        check(self.lib.crnn_global_norm(_ptr(self.grads), self.n_total, float(clipnorm or 0.0), _ptr(self.norm_scratch), _ptr(self.norm),
+                                        _stream()), "global_norm")
+        return self.norm
+
+    def adam_step(self, lr, beta_1, beta_2, epsilon, clipnorm, iteration):
+        """Keras 2.2.2 Adam; `iteration` is 0-based."""
+        st = self.opt_state
+        if "m" not in st:
+            st["m"] = torch.zeros_like(self.params); st["v"] = torch.zeros_like(self.params)
+        self.global_norm(clipnorm)
+        t = iteration + 1
+        lr_t = lr * math.sqrt(1.0 - beta_2 ** t) / (1.0 - beta_1 ** t)
+        check(self.lib.crnn_adam_step(_ptr(self.params), _ptr(self.grads), _ptr(st["m"]), _ptr(st["v"]), self.n_total, lr_t, beta_1,
+                                      beta_2, epsilon, _ptr(self.norm), _stream()), "adam")
+
+    def sgd_step(self, lr, decay, momentum, nesterov, clipnorm, iteration):
+        st = self.opt_state
+        if "vel" not in st:
+            st["vel"] = torch.zeros_like(self.params)
+        self.global_norm(clipnorm)
+        lr_i = lr / (1.0 + decay * iteration)
+        check(self.lib.crnn_sgd_step(_ptr(self.params), _ptr(self.grads), _ptr(st["vel"]), self.n_total, lr_i, momentum, int(nesterov),
+                                     _ptr(self.norm), _stream()), "sgd")
+
+    def train_step(self, x, labels, input_length, label_length, opt, iteration, seed=None, allreduce=None):
+        """forward(train) -> CTC -> backward -> [all-reduce] -> clip -> optimizer -> BN moving stats."""
+        seed = iteration if seed is None else seed
+        self.forward(x, train=True, seed=seed)
+        loss = self.backward(labels, input_length, label_length, seed=seed)
+        if allreduce is not None:
+            allreduce(self.grads)
+        opt.apply(self, iteration)
+        self.bn_update()
+        return loss
+
+    # ---- decoding -----------------------------------------------------------------------------------------
+    def greedy_decode(self, y=None, input_length=None):
+        y = self.y_pred if y is None else y
+        B, T, C = y.shape
+        out = torch.empty((B, T), dtype=torch.int32, device=self.device); ln = torch.empty(B, dtype=torch.int32, device=self.device)
+        il = self._as_i32(input_length) if input_length is not None else None
+        check(self.lib.crnn_ctc_greedy_decode(_ptr(y), _ptr(il), _ptr(out), _ptr(ln), B, T, C, _stream()), "greedy")
+        return out, ln
+
+    def beam_decode(self, y=None, beam_width=10, merge_repeated=True, input_length=None):
+        y = self.y_pred if y is None else y
+        return beam_decode(y, beam_width, merge_repeated, input_length)
+
+
+def beam_decode(y, beam_width=10, merge_repeated=True, input_length=None):
+    """y (B,T,C) softmax (device tensor or ndarray) -> (labels (B,T) int32 padded -1, lengths, scores)."""
+    lib = native.lib()
+    if not torch.is_tensor(y):
+        y = torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32)).cuda()
+    y = y.contiguous().float()
+    B, T, C = y.shape
+    out = torch.empty((B, T), dtype=torch.int32, device=y.device); ln = torch.empty(B, dtype=torch.int32, device=y.device)
+    sc = torch.empty(B, dtype=torch.float32, device=y.device)
+    il = None
+    if input_length is not None:
+        il = torch.as_tensor(np.asarray(input_length).reshape(-1).astype(np.int32)).to(y.device)
+    check(lib.crnn_ctc_beam_decode(_ptr(y), _ptr(il), _ptr(out), _ptr(ln), _ptr(sc), B, T, C, int(beam_width), int(bool(merge_repeated)),
+                                   _stream()), "beam_decode")
+    return out, ln, sc

@@ -1,0 +1,97 @@
+"""ctypes binding of libcrnn_mi355x.so (the C ABI declared in include/crnn_mi355x.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or fails to load, importing
+`lib()` raises.  Build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950).
+"""
+import ctypes
+import os
+import re
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(HERE)                      # crnn-ocr-lite_amd/
+REPO_ROOT = os.path.dirname(PKG_ROOT)
+HEADER = os.path.join(REPO_ROOT, "include", "crnn_mi355x.h")
+CSRC = os.path.join(PKG_ROOT, "csrc")
+LIB_PATH = os.path.join(PKG_ROOT, "libcrnn_mi355x.so")
+SOURCES = ["gemm.hip", "conv.hip", "stn.hip", "rnn.hip", "ctc.hip", "beam.hip", "optim.hip", "model.hip"]
+
+
+class crnn_config(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in
+                ("batch", "imgh", "imgw", "num_classes", "max_len", "tds", "units", "gru", "stn", "dropout")]
+
+
+_CTYPE = [("crnn_stream_t", ctypes.c_void_p), ("size_t", ctypes.c_size_t), ("uint64_t", ctypes.c_uint64),
+          ("uint32_t", ctypes.c_uint32), ("long", ctypes.c_long), ("int", ctypes.c_int), ("float", ctypes.c_float),
+          ("double", ctypes.c_double)]
+
+
+def _ctype_of(decl):
+    decl = decl.strip()
+    if "*" in decl:
+        return ctypes.c_void_p
+    for key, ct in _CTYPE:
+        if re.search(r"\b%s\b" % key, decl):
+            return ct
+    raise ValueError("cannot map C type: %r" % decl)
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [argtypes])} for every function declared in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"typedef\s+struct\s*\{.*?\}\s*\w+\s*;", " ", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(int|long|size_t)\s+(crnn_\w+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        argtypes = [] if args.strip() in ("", "void") else [_ctype_of(a) for a in args.split(",")]
+        out[name] = ({"int": ctypes.c_int, "long": ctypes.c_long, "size_t": ctypes.c_size_t}[ret], argtypes)
+    return out
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into crnn-ocr-lite_amd/libcrnn_mi355x.so (in-tree)."""
+    objs = []
+    inc = os.path.join(REPO_ROOT, "include")
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        deps = [src, os.path.join(CSRC, "common.h"), HEADER]
+        if not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps):
+            cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", inc, "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    if not os.path.exists(LIB_PATH) or any(os.path.getmtime(o) > os.path.getmtime(LIB_PATH) for o in objs):
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH])
+    return LIB_PATH
+
+
+_LIB = None
+
+
+def lib():
+    """Load the library and attach argtypes/restypes from the header.  Raises if it is missing."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libcrnn_mi355x.so not built (%s); run `python __graft_entry__.py` "
+                               "-- there is no CPU fallback for the CRNN hot path" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (ret, args) in parse_header().items():
+            fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = ret, args
+        _LIB = L
+    return _LIB
+
+
+class CrnnError(RuntimeError):
+    pass
+
+
+def check(code, what=""):
+    if code != 0:
+        kind = {-2: "bad argument", -3: "unsupported configuration"}.get(code, "hipError_t" if code > 0 else "error")
+        raise CrnnError("libcrnn_mi355x %s failed: %d (%s)" % (what, code, kind))

@@ -1,0 +1,52 @@
+"""Data parallelism for the train step (new work: the reference is single-device).
+
+One process per GPU; the batch dimension is sharded (each rank draws its own images); the only exchange per
+step is ONE all-reduce of the flat fp32 gradient buffer (13.1 MB for the LSTM variant) through
+torch.distributed -- backend "nccl" = RCCL over xGMI on ROCm -- followed by the identical global-norm clip +
+Adam on every rank, so the weights stay bit-identical across ranks.  BatchNorm uses per-replica batch
+statistics (what Keras' multi_gpu_model would have done); the moving statistics are averaged on demand
+(`sync_bn_stats`, e.g. before a checkpoint).
+"""
+import torch
+
+
+def allreduce_mean_(flat, dist, world, scale_fn=None):
+    """In-place mean of `flat` over all ranks (sum all-reduce, then x 1/world)."""
+    if world <= 1:
+        return flat
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if scale_fn is not None:
+        scale_fn(flat, 1.0 / world)
+    else:
+        flat.mul_(1.0 / world)
+    return flat
+
+
+class GradAllReduce:
+    """Callable handed to Engine.train_step: averages engine.grads across ranks after backward."""
+
+    def __init__(self, engine, dist, world):
+        self.engine, self.dist, self.world = engine, dist, world
+
+    def _scale(self, t, s):
+        from .native import check
+        from .engine import _ptr, _stream
+        check(self.engine.lib.crnn_scale(_ptr(t), t.numel(), float(s), _stream()), "scale")
+
+    def __call__(self, grads):
+        allreduce_mean_(grads, self.dist, self.world, self._scale if grads.is_cuda else None)
+
+
+def sync_bn_stats(engine, dist, world):
+    """Average the BatchNorm moving statistics over ranks (checkpoint time)."""
+    if world > 1:
+        for t in (engine.bn_mean, engine.bn_var):
+            allreduce_mean_(t, dist, world)
+
+
+def shard(n_items, rank, world):
+    """Contiguous shard [lo, hi) of n_items for this rank (last rank takes the remainder)."""
+    per = n_items // world
+    lo = rank * per
+    hi = n_items if rank == world - 1 else lo + per
+    return lo, hi

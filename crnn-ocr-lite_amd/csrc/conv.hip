@@ -1,0 +1,586 @@
+// Depthwise-separable conv stack kernels (utils.py:43-56, 64-70), NHWC, fp32.
+//   depthwise 3x3 'same' (fwd, data-grad = same kernel with flipped taps, weight-grad) with the
+//   (TH+2) x (W+2) x 32-channel halo tile staged in LDS, 16 B/lane channel-vectorised HBM access and
+//   the BatchNorm batch statistics (sum, sum-of-squares) produced as a deterministic per-tile partial;
+//   BatchNorm finalize / apply(+ReLU6 +MaxPool +Dropout) / backward (two-pass reduce + apply);
+//   generic column reductions.
+// All kernels are HBM-bandwidth bound; the pointwise 1x1 convs go through gemm.hip.
+#include "common.h"
+
+#define BN_EPS 1e-3f
+
+// ---------------------------------------------------------------------------------------------
+// depthwise 3x3, C % 32 == 0 : LDS halo tile
+// grid.x = C/32, grid.y = B * ceil(H/TH); block 256 = 8 channel-quads x 32 pixel threads
+// mode 0: out = conv(x, k) (flip=1 -> taps flipped = data gradient), optional stats partials
+// mode 1: weight gradient partials: dk[tap][c] += x[shifted] * g[center]
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void dwconv_tile_kernel(const float* __restrict__ x, const float* __restrict__ k,
+                                                          const float* __restrict__ g, float* __restrict__ out,
+                                                          float* __restrict__ partials, int B, int H, int W, int C,
+                                                          int TH, int flip) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float4* tile = reinterpret_cast<float4*>(smem);
+  const int tid = threadIdx.x, c4 = tid & 7, pt = tid >> 3;
+  const int cc0 = blockIdx.x * 32;
+  const int nHb = (H + TH - 1) / TH;
+  const int b = blockIdx.y / nHb, h0 = (blockIdx.y % nHb) * TH;
+  const int Wt = W + 2;
+  const int n4 = (TH + 2) * Wt * 8;
+  for (int i = tid; i < n4; i += 256) {
+    int ci = i & 7, pix = i >> 3;
+    int ly = pix / Wt, lx = pix - ly * Wt;
+    int gh = h0 + ly - 1, gw = lx - 1;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gh >= 0 && gh < H && gw >= 0 && gw < W)
+      v = *reinterpret_cast<const float4*>(&x[(((long)b * H + gh) * W + gw) * C + cc0 + 4 * ci]);
+    tile[i] = v;
+  }
+  float4 kw[9];
+  if (MODE == 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      int ts = flip ? 8 - t : t;
+      kw[t] = *reinterpret_cast<const float4*>(&k[ts * C + cc0 + 4 * c4]);
+    }
+  }
+  __syncthreads();
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), ss = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 dk[9];
+  if (MODE == 1) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dk[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int npix = TH * W;
+  for (int p = pt; p < npix; p += 32) {
+    int ly = p / W, lx = p - ly * W;
+    int gh = h0 + ly;
+    if (gh >= H) break;
+    long o = (((long)b * H + gh) * W + lx) * C + cc0 + 4 * c4;
+    if (MODE == 0) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          float4 v = tile[((ly + i) * Wt + lx + j) * 8 + c4];
+          float4 w = kw[i * 3 + j];
+          a.x = fmaf(v.x, w.x, a.x); a.y = fmaf(v.y, w.y, a.y); a.z = fmaf(v.z, w.z, a.z); a.w = fmaf(v.w, w.w, a.w);
+        }
+      *reinterpret_cast<float4*>(&out[o]) = a;
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+      ss.x = fmaf(a.x, a.x, ss.x); ss.y = fmaf(a.y, a.y, ss.y); ss.z = fmaf(a.z, a.z, ss.z); ss.w = fmaf(a.w, a.w, ss.w);
+    } else {
+      float4 gv = *reinterpret_cast<const float4*>(&g[o]);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          float4 v = tile[((ly + i) * Wt + lx + j) * 8 + c4];
+          float4& d = dk[i * 3 + j];
+          d.x = fmaf(v.x, gv.x, d.x); d.y = fmaf(v.y, gv.y, d.y); d.z = fmaf(v.z, gv.z, d.z); d.w = fmaf(v.w, gv.w, d.w);
+        }
+    }
+  }
+  if (partials == nullptr) return;
+  __syncthreads();  // tile no longer needed: reuse LDS for the cross-pixel-thread reduction
+  float4* red = reinterpret_cast<float4*>(smem);
+  if (MODE == 0) {
+    red[(0 * 32 + pt) * 8 + c4] = s;
+    red[(1 * 32 + pt) * 8 + c4] = ss;
+    __syncthreads();
+    if (tid < 16) {
+      int ci = tid & 7, v = tid >> 3;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int r = 0; r < 32; ++r) { float4 t = red[(v * 32 + r) * 8 + ci]; a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
+      *reinterpret_cast<float4*>(&partials[((long)blockIdx.y * 2 + v) * C + cc0 + 4 * ci]) = a;
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) red[(t * 32 + pt) * 8 + c4] = dk[t];
+    __syncthreads();
+    if (tid < 72) {
+      int ci = tid & 7, t = tid >> 3;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int r = 0; r < 32; ++r) { float4 v = red[(t * 32 + r) * 8 + ci]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+      *reinterpret_cast<float4*>(&partials[((long)blockIdx.y * 9 + t) * C + cc0 + 4 * ci]) = a;
+    }
+  }
+}
+
+// generic fallback (any C, e.g. the C=1 first block): one thread per output element
+template <int MODE>
+__global__ void dwconv_naive_kernel(const float* __restrict__ x, const float* __restrict__ k, const float* __restrict__ g,
+                                    float* __restrict__ out, int B, int H, int W, int C, int flip) {
+  if (MODE == 0) {
+    long total = (long)B * H * W * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+      int c = (int)(i % C); long pix = i / C;
+      int w = (int)(pix % W); long r = pix / W; int h = (int)(r % H); long b = r / H;
+      float a = 0.f;
+      for (int ii = 0; ii < 3; ++ii)
+        for (int j = 0; j < 3; ++j) {
+          int gh = h + ii - 1, gw = w + j - 1;
+          if (gh >= 0 && gh < H && gw >= 0 && gw < W) {
+            int t = ii * 3 + j; if (flip) t = 8 - t;
+            a = fmaf(x[((b * H + gh) * W + gw) * C + c], k[t * C + c], a);
+          }
+        }
+      out[i] = a;
+    }
+  } else {
+    // weight gradient, tiny tensors only: one block per (tap, channel), block-wide reduction
+    int t = blockIdx.x / C, c = blockIdx.x % C;
+    int ii = t / 3, j = t % 3;
+    float a = 0.f;
+    long npix = (long)B * H * W;
+    for (long p = threadIdx.x; p < npix; p += blockDim.x) {
+      int w = (int)(p % W); long r = p / W; int h = (int)(r % H); long b = r / H;
+      int gh = h + ii - 1, gw = w + j - 1;
+      if (gh >= 0 && gh < H && gw >= 0 && gw < W) a = fmaf(x[((b * H + gh) * W + gw) * C + c], g[p * C + c], a);
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) out[t * C + c] = red[0];
+  }
+}
+
+static int dw_pick_th(int W, size_t* lds) {
+  int TH = 8;
+  for (;;) {
+    size_t tile = (size_t)(TH + 2) * (W + 2) * 128;
+    size_t red = (size_t)9 * 32 * 128;  // weight-grad reduction scratch
+    *lds = tile > red ? tile : red;
+    if (*lds <= 64 * 1024 || TH == 1) return TH;
+    TH >>= 1;
+  }
+}
+
+// number of row-band tiles (= partial rows) the tiled kernels produce for a (B,H,W) map
+extern "C" int crnn_dwconv_num_tiles(int B, int H, int W) {
+  size_t lds; int TH = dw_pick_th(W, &lds);
+  return B * cdiv(H, TH);
+}
+
+// out = dwconv3x3(x, k[9][C]); flip=1 gives the data gradient.  If `stat_partials` != null (C%32==0
+// only) it receives [num_tiles][2][C] (sum, sumsq) partial BatchNorm statistics of `out`.
+extern "C" int crnn_dwconv3x3_fwd(const float* x, const float* k, float* out, float* stat_partials, int B, int H, int W,
+                                  int C, int flip, hipStream_t stream) {
+  if (C % 32 == 0) {
+    size_t lds; int TH = dw_pick_th(W, &lds);
+    if (lds > 64 * 1024) return CRNN_ERR_UNSUPPORTED;
+    dim3 grid(C / 32, B * cdiv(H, TH));
+    hipLaunchKernelGGL(dwconv_tile_kernel<0>, grid, dim3(256), lds, stream, x, k, nullptr, out, stat_partials, B, H, W, C, TH, flip);
+  } else {
+    if (stat_partials) return CRNN_ERR_UNSUPPORTED;
+    long total = (long)B * H * W * C;
+    int blocks = cdiv(total, 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(dwconv_naive_kernel<0>, dim3(blocks), dim3(256), 0, stream, x, k, nullptr, out, B, H, W, C, flip);
+  }
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Column reductions over a row-major [M][C] matrix -> partials [nchunk][NV][C]
+// NV=1: sum; NV=2: sum and sum of squares.  Deterministic (fixed chunking, fixed order).
+// ---------------------------------------------------------------------------------------------
+template <int VEC, int NV>
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ x, float* __restrict__ partials, long M,
+                                                        int C, int ld, int CW, int rows_per_chunk) {
+  // CW = power of two >= min(C/VEC, 256); thread -> (cl = tid % CW, rt = tid / CW)
+  __shared__ float red[2][256 * VEC];
+  const int tid = threadIdx.x, cl = tid % CW, rt = tid / CW, RT = 256 / CW;
+  const long r0 = (long)blockIdx.x * rows_per_chunk;
+  long r1 = r0 + rows_per_chunk; if (r1 > M) r1 = M;
+  const int CL = C / VEC;
+  for (int cb = 0; cb < CL; cb += CW) {
+    int c = cb + cl;
+    float s[VEC], q[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    if (c < CL) {
+      for (long r = r0 + rt; r < r1; r += RT) {
+        if (VEC == 4) {
+          float4 v = *reinterpret_cast<const float4*>(&x[r * ld + 4 * c]);
+          s[0] += v.x; s[1 % VEC] += v.y; s[2 % VEC] += v.z; s[3 % VEC] += v.w;
+          if (NV == 2) { q[0] = fmaf(v.x, v.x, q[0]); q[1 % VEC] = fmaf(v.y, v.y, q[1 % VEC]); q[2 % VEC] = fmaf(v.z, v.z, q[2 % VEC]); q[3 % VEC] = fmaf(v.w, v.w, q[3 % VEC]); }
+        } else {
+          float v = x[r * ld + c];
+          s[0] += v;
+          if (NV == 2) q[0] = fmaf(v, v, q[0]);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { red[0][tid * VEC + e] = s[e]; if (NV == 2) red[1][tid * VEC + e] = q[e]; }
+    __syncthreads();
+    if (rt == 0 && c < CL) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float a = 0.f, b2 = 0.f;
+        for (int r = 0; r < RT; ++r) { a += red[0][(r * CW + cl) * VEC + e]; if (NV == 2) b2 += red[1][(r * CW + cl) * VEC + e]; }
+        partials[((long)blockIdx.x * NV + 0) * C + c * VEC + e] = a;
+        if (NV == 2) partials[((long)blockIdx.x * NV + 1) * C + c * VEC + e] = b2;
+      }
+    }
+  }
+}
+
+static inline int pow2_ge(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+extern "C" int crnn_colreduce_chunks(long M) { long rpc = 1024; if (M < 4096) rpc = 64; return cdiv(M, rpc); }
+
+// partials [crnn_colreduce_chunks(M)][nv][C]
+extern "C" int crnn_colreduce(const float* x, float* partials, long M, int C, int ld, int nv, hipStream_t stream) {
+  if (nv != 1 && nv != 2) return CRNN_ERR_ARG;
+  int rpc = (M < 4096) ? 64 : 1024;
+  int chunks = cdiv(M, rpc);
+  bool vec = (C % 4 == 0) && (ld % 4 == 0) && ((((uintptr_t)x) & 15) == 0);
+  int CL = vec ? C / 4 : C;
+  int CW = pow2_ge(CL < 256 ? CL : 256);
+  if (vec) {
+    if (nv == 1) hipLaunchKernelGGL((colreduce_kernel<4, 1>), dim3(chunks), dim3(256), 0, stream, x, partials, M, C, ld, CW, rpc);
+    else hipLaunchKernelGGL((colreduce_kernel<4, 2>), dim3(chunks), dim3(256), 0, stream, x, partials, M, C, ld, CW, rpc);
+  } else {
+    if (nv == 1) hipLaunchKernelGGL((colreduce_kernel<1, 1>), dim3(chunks), dim3(256), 0, stream, x, partials, M, C, ld, CW, rpc);
+    else hipLaunchKernelGGL((colreduce_kernel<1, 2>), dim3(chunks), dim3(256), 0, stream, x, partials, M, C, ld, CW, rpc);
+  }
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+
+// out[i] = scale * sum_p partials[p][i], i < n  (double accumulation)
+__global__ void partials_sum_kernel(const float* __restrict__ partials, int nparts, int n, float* __restrict__ out, float scale) {
+  // blockDim = (32, 8): 32 consecutive outputs x 8 part-lanes
+  __shared__ double red[8][32];
+  int i = blockIdx.x * 32 + threadIdx.x;
+  double a = 0.0;
+  if (i < n)
+    for (int p = threadIdx.y; p < nparts; p += 8) a += (double)partials[(long)p * n + i];
+  red[threadIdx.y][threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.y == 0 && i < n) {
+    double s = 0.0;
+    for (int r = 0; r < 8; ++r) s += red[r][threadIdx.x];
+    out[i] = (float)(s * scale);
+  }
+}
+
+extern "C" int crnn_partials_sum(const float* partials, int nparts, int n, float* out, float scale, hipStream_t stream) {
+  hipLaunchKernelGGL(partials_sum_kernel, dim3(cdiv(n, 32)), dim3(32, 8), 0, stream, partials, nparts, n, out, scale);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+
+// weight gradient of the depthwise conv: dk[9][C] = sum x[shifted] * g.  scratch: [num_tiles][9][C]
+extern "C" int crnn_dwconv3x3_wgrad(const float* x, const float* g, float* dk, float* scratch, int B, int H, int W, int C,
+                                    hipStream_t stream) {
+  if (C % 32 == 0) {
+    size_t lds; int TH = dw_pick_th(W, &lds);
+    if (lds > 64 * 1024) return CRNN_ERR_UNSUPPORTED;
+    int ntiles = B * cdiv(H, TH);
+    dim3 grid(C / 32, ntiles);
+    hipLaunchKernelGGL(dwconv_tile_kernel<1>, grid, dim3(256), lds, stream, x, nullptr, g, nullptr, scratch, B, H, W, C, TH, 0);
+    CRNN_LAUNCH_CHECK();
+    return crnn_partials_sum(scratch, ntiles, 9 * C, dk, 1.f, stream);
+  }
+  hipLaunchKernelGGL(dwconv_naive_kernel<1>, dim3(9 * C), dim3(256), 0, stream, x, nullptr, g, dk, B, H, W, C, 0);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm (axis=-1, eps=1e-3): statistics finalize.  bnstate = [mean | var | scale | shift] (4*C)
+// ---------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* __restrict__ partials, int nparts, int C, double inv_n,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ bnstate) {
+  __shared__ double red[2][8][32];
+  int c = blockIdx.x * 32 + threadIdx.x;
+  double s = 0.0, q = 0.0;
+  if (c < C)
+    for (int p = threadIdx.y; p < nparts; p += 8) {
+      s += (double)partials[((long)p * 2 + 0) * C + c];
+      q += (double)partials[((long)p * 2 + 1) * C + c];
+    }
+  red[0][threadIdx.y][threadIdx.x] = s; red[1][threadIdx.y][threadIdx.x] = q;
+  __syncthreads();
+  if (threadIdx.y == 0 && c < C) {
+    s = 0.0; q = 0.0;
+    for (int r = 0; r < 8; ++r) { s += red[0][r][threadIdx.x]; q += red[1][r][threadIdx.x]; }
+    double mean = s * inv_n;
+    double var = q * inv_n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float inv = (float)(1.0 / sqrt(var + (double)BN_EPS));
+    float sc = gamma[c] * inv;
+    bnstate[c] = (float)mean; bnstate[C + c] = (float)var;
+    bnstate[2 * C + c] = sc; bnstate[3 * C + c] = beta[c] - (float)mean * sc;
+  }
+}
+
+// inference mode: scale/shift from the moving statistics
+__global__ void bn_infer_state_kernel(const float* __restrict__ mmean, const float* __restrict__ mvar,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta, int C,
+                                      float* __restrict__ bnstate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    float sc = gamma[c] / sqrtf(mvar[c] + BN_EPS);
+    bnstate[c] = mmean[c]; bnstate[C + c] = mvar[c];
+    bnstate[2 * C + c] = sc; bnstate[3 * C + c] = beta[c] - mmean[c] * sc;
+  }
+}
+
+extern "C" int crnn_bn_finalize(const float* partials, int nparts, int C, long n, const float* gamma, const float* beta,
+                                float* bnstate, hipStream_t stream) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(32, 8), 0, stream, partials, nparts, C, 1.0 / (double)n, gamma, beta, bnstate);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+
+extern "C" int crnn_bn_infer_state(const float* mmean, const float* mvar, const float* gamma, const float* beta, int C,
+                                   float* bnstate, hipStream_t stream) {
+  hipLaunchKernelGGL(bn_infer_state_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, mmean, mvar, gamma, beta, C, bnstate);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// y = Dropout(MaxPool(ReLU6(x*scale+shift)))   (utils.py:45-56).  ph=pw=1: no pooling; rate=0: no dropout.
+// x [B,H,W,C] -> y [B,H/ph,W/pw,C]
+// ---------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ void bn_act_pool_drop_kernel(const float* __restrict__ x, const float* __restrict__ bnstate,
+                                        float* __restrict__ y, int B, int H, int W, int C, int ph, int pw, float rate,
+                                        uint64_t seed, uint32_t layer) {
+  const int Ho = H / ph, Wo = W / pw, CL = C / VEC;
+  const long total = (long)B * Ho * Wo * CL;
+  const float inv_keep = rate > 0.f ? 1.f / (1.f - rate) : 1.f;
+  const float* sc = bnstate + 2 * C; const float* sh = bnstate + 3 * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int cl = (int)(i % CL); long pix = i / CL;
+    int wo = (int)(pix % Wo); long r = pix / Wo; int ho = (int)(r % Ho); long b = r / Ho;
+    float m[VEC], s[VEC], t[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { m[e] = -INFINITY; s[e] = sc[cl * VEC + e]; t[e] = sh[cl * VEC + e]; }
+    for (int ii = 0; ii < ph; ++ii)
+      for (int j = 0; j < pw; ++j) {
+        const float* p = &x[(((long)b * H + ho * ph + ii) * W + wo * pw + j) * C + cl * VEC];
+        float v[VEC];
+        if (VEC == 4) { float4 q = *reinterpret_cast<const float4*>(p); v[0] = q.x; v[1 % VEC] = q.y; v[2 % VEC] = q.z; v[3 % VEC] = q.w; }
+        else v[0] = p[0];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) m[e] = fmaxf(m[e], relu6f(fmaf(v[e], s[e], t[e])));
+      }
+    long obase = pix * C + cl * VEC;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) m[e] *= drop_scale(seed, layer, (uint64_t)(obase + e), rate, inv_keep);
+    if (VEC == 4) *reinterpret_cast<float4*>(&y[obase]) = make_float4(m[0], m[1 % VEC], m[2 % VEC], m[3 % VEC]);
+    else y[obase] = m[0];
+  }
+}
+
+extern "C" int crnn_bn_act_pool_drop(const float* x, const float* bnstate, float* y, int B, int H, int W, int C, int ph,
+                                     int pw, float rate, uint64_t seed, uint32_t layer, hipStream_t stream) {
+  long total = (long)B * (H / ph) * (W / pw) * C;
+  if (C % 4 == 0) {
+    int blocks = cdiv(total / 4, 256); if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bn_act_pool_drop_kernel<4>, dim3(blocks), dim3(256), 0, stream, x, bnstate, y, B, H, W, C, ph, pw, rate, seed, layer);
+  } else {
+    int blocks = cdiv(total, 256); if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bn_act_pool_drop_kernel<1>, dim3(blocks), dim3(256), 0, stream, x, bnstate, y, B, H, W, C, ph, pw, rate, seed, layer);
+  }
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm backward (train mode).  x = pre-BN tensor [B,H,W,C]; the upstream gradient arrives as
+// g [B,H/ph,W/pw,C] w.r.t. Dropout(MaxPool(ReLU6(BN(x)))) and is routed on the fly:
+//   gy = [first-argmax of the pool window] * g * dropmask * [0 < relu6(bn(x)) < 6]
+// pass 1 (reduce): partials [chunk][2][C] = (sum gy, sum gy*xhat)
+// pass 2 (apply):  dx = scale * (gy - c1 - xhat*c2),   c1 = sum(gy)/n, c2 = sum(gy*xhat)/n
+// ---------------------------------------------------------------------------------------------
+struct BnBwdArgs {
+  const float* x; const float* g; const float* bnstate; const float* gamma;
+  int B, H, W, C, ph, pw; float rate; uint64_t seed; uint32_t layer;
+};
+
+__device__ __forceinline__ float bn_gy(const BnBwdArgs& a, long b, int h, int w, int c, float xv, float sc, float sh) {
+  const int Ho = a.H / a.ph, Wo = a.W / a.pw;
+  int ho = h / a.ph, wo = w / a.pw;
+  if (ho >= Ho || wo >= Wo) return 0.f;
+  float y = relu6f(fmaf(xv, sc, sh));
+  if (a.ph * a.pw > 1) {
+    int si = h - ho * a.ph, sj = w - wo * a.pw;
+    for (int ii = 0; ii < a.ph; ++ii)
+      for (int j = 0; j < a.pw; ++j) {
+        if (ii == si && j == sj) continue;
+        float o = relu6f(fmaf(a.x[(((long)b * a.H + ho * a.ph + ii) * a.W + wo * a.pw + j) * a.C + c], sc, sh));
+        bool earlier = (ii < si) || (ii == si && j < sj);
+        if (earlier ? (o >= y) : (o > y)) return 0.f;  // not the first maximum
+      }
+  }
+  if (!(y > 0.f && y < 6.f)) return 0.f;
+  long oidx = (((long)b * Ho + ho) * Wo + wo) * a.C + c;
+  float inv_keep = a.rate > 0.f ? 1.f / (1.f - a.rate) : 1.f;
+  return a.g[oidx] * drop_scale(a.seed, a.layer, (uint64_t)oidx, a.rate, inv_keep);
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a, float* __restrict__ partials,
+                                                     const float* __restrict__ coef, float* __restrict__ dx, int CW,
+                                                     int rows_per_chunk) {
+  // rows = pixels (b,h,w); thread -> (c = cb + tid % CW, rt = tid / CW)
+  __shared__ float red[2][256];
+  const int tid = threadIdx.x, cl = tid % CW, rt = tid / CW, RT = 256 / CW;
+  const long M = (long)a.B * a.H * a.W;
+  const long r0 = (long)blockIdx.x * rows_per_chunk;
+  long r1 = r0 + rows_per_chunk; if (r1 > M) r1 = M;
+  const float* mean = a.bnstate; const float* var = a.bnstate + a.C;
+  const float* scp = a.bnstate + 2 * a.C; const float* shp = a.bnstate + 3 * a.C;
+  for (int cb = 0; cb < a.C; cb += CW) {
+    int c = cb + cl;
+    float s = 0.f, q = 0.f;
+    if (c < a.C) {
+      float sc = scp[c], sh = shp[c], mu = mean[c], inv = 1.0f / sqrtf(var[c] + BN_EPS);
+      float c1 = 0.f, c2 = 0.f;
+      if (PASS == 2) { c1 = coef[c]; c2 = coef[a.C + c]; }
+      for (long r = r0 + rt; r < r1; r += RT) {
+        int w = (int)(r % a.W); long rr = r / a.W; int h = (int)(rr % a.H); long b = rr / a.H;
+        float xv = a.x[r * a.C + c];
+        float gy = bn_gy(a, b, h, w, c, xv, sc, sh);
+        float xh = (xv - mu) * inv;
+        if (PASS == 1) { s += gy; q = fmaf(gy, xh, q); }
+        else dx[r * a.C + c] = sc * (gy - c1 - xh * c2);
+      }
+    }
+    if (PASS == 1) {
+      __syncthreads();
+      red[0][tid] = s; red[1][tid] = q;
+      __syncthreads();
+      if (rt == 0 && c < a.C) {
+        float s2 = 0.f, q2 = 0.f;
+        for (int r = 0; r < RT; ++r) { s2 += red[0][r * CW + cl]; q2 += red[1][r * CW + cl]; }
+        partials[((long)blockIdx.x * 2 + 0) * a.C + c] = s2;
+        partials[((long)blockIdx.x * 2 + 1) * a.C + c] = q2;
+      }
+    }
+  }
+}
+
+// dgamma = sum gy*xhat, dbeta = sum gy; coef = [c1 | c2]
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nparts, int C, double inv_n,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+  __shared__ double red[2][8][32];
+  int c = blockIdx.x * 32 + threadIdx.x;
+  double s = 0.0, q = 0.0;
+  if (c < C)
+    for (int p = threadIdx.y; p < nparts; p += 8) {
+      s += (double)partials[((long)p * 2 + 0) * C + c];
+      q += (double)partials[((long)p * 2 + 1) * C + c];
+    }
+  red[0][threadIdx.y][threadIdx.x] = s; red[1][threadIdx.y][threadIdx.x] = q;
+  __syncthreads();
+  if (threadIdx.y == 0 && c < C) {
+    s = 0.0; q = 0.0;
+    for (int r = 0; r < 8; ++r) { s += red[0][r][threadIdx.x]; q += red[1][r][threadIdx.x]; }
+    dbeta[c] = (float)s; dgamma[c] = (float)q;
+    coef[c] = (float)(s * inv_n); coef[C + c] = (float)(q * inv_n);
+  }
+}
+
+extern "C" int crnn_bn_bwd_chunks(long M) { return cdiv(M, 512); }
+
+// Full BN backward through Dropout/MaxPool/ReLU6: writes dx [B,H,W,C], dgamma[C], dbeta[C].
+// scratch_partials: [crnn_bn_bwd_chunks(B*H*W)][2][C]; coef: [2*C].
+extern "C" int crnn_bn_bwd(const float* x, const float* g, const float* bnstate, const float* gamma, float* dx,
+                           float* dgamma, float* dbeta, float* scratch_partials, float* coef, int B, int H, int W, int C,
+                           int ph, int pw, float rate, uint64_t seed, uint32_t layer, hipStream_t stream) {
+  BnBwdArgs a{x, g, bnstate, gamma, B, H, W, C, ph, pw, rate, seed, layer};
+  long M = (long)B * H * W;
+  int chunks = cdiv(M, 512);
+  int CW = pow2_ge(C < 256 ? C : 256);
+  hipLaunchKernelGGL(bn_bwd_kernel<1>, dim3(chunks), dim3(256), 0, stream, a, scratch_partials, nullptr, nullptr, CW, 512);
+  CRNN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(32, 8), 0, stream, scratch_partials, chunks, C, 1.0 / (double)M, dgamma, dbeta, coef);
+  CRNN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_kernel<2>, dim3(chunks), dim3(256), 0, stream, a, nullptr, coef, dx, CW, 512);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small elementwise helpers
+// ---------------------------------------------------------------------------------------------
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) o[i] = a[i] + b[i];
+}
+extern "C" int crnn_add(const float* a, const float* b, float* o, long n, hipStream_t stream) {
+  int blocks = cdiv(n, 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(add_kernel, dim3(blocks), dim3(256), 0, stream, a, b, o, n);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+
+// y[r*ldy + c] = x[r*ldx + c] * dropmask(idx = r*C + c)   (rows x C view, strided)
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long rows, int C, int ldx, int ldy,
+                               float rate, uint64_t seed, uint32_t layer) {
+  long n = rows * C;
+  float inv_keep = rate > 0.f ? 1.f / (1.f - rate) : 1.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long r = i / C; int c = (int)(i % C);
+    y[r * ldy + c] = x[r * ldx + c] * drop_scale(seed, layer, (uint64_t)i, rate, inv_keep);
+  }
+}
+extern "C" int crnn_dropout(const float* x, float* y, long rows, int C, int ldx, int ldy, float rate, uint64_t seed,
+                            uint32_t layer, hipStream_t stream) {
+  long n = rows * C;
+  int blocks = cdiv(n, 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(256), 0, stream, x, y, rows, C, ldx, ldy, rate, seed, layer);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+
+// materialise the multiplier (0 or 1/(1-rate)) that dropout site `layer` applies -- test hook
+__global__ void dropout_mask_kernel(float* __restrict__ m, long n, float rate, uint64_t seed, uint32_t layer) {
+  float inv_keep = rate > 0.f ? 1.f / (1.f - rate) : 1.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    m[i] = drop_scale(seed, layer, (uint64_t)i, rate, inv_keep);
+}
+extern "C" int crnn_dropout_mask(float* m, long n, float rate, uint64_t seed, uint32_t layer, hipStream_t stream) {
+  int blocks = cdiv(n, 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks), dim3(256), 0, stream, m, n, rate, seed, layer);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+
+// g_out[perm(r)][c] = g[r][c] * [y[r][c] > 0]      (backward of ReLU, and of Dropout∘ReLU when y is the
+// dropped activation: the 1/(1-p) factor is passed as `scale`).  permP as in the GEMM epilogue.
+__global__ void relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ g, float* __restrict__ go,
+                                long rows, int C, float scale, int permP) {
+  long n = rows * C;
+  long Q = permP ? rows / permP : 0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long r = i / C; int c = (int)(i % C);
+    long orow = permP ? (r % permP) * Q + r / permP : r;
+    go[orow * C + c] = (y[i] > 0.f) ? g[i] * scale : 0.f;
+  }
+}
+extern "C" int crnn_relu_bwd(const float* y, const float* g, float* go, long rows, int C, float scale, int permP,
+                             hipStream_t stream) {
+  long n = rows * C;
+  int blocks = cdiv(n, 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks), dim3(256), 0, stream, y, g, go, rows, C, scale, permP);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+
+// a = ReLU6(x*scale+shift) (the pointwise conv's input; kept for its weight gradient)
+extern "C" int crnn_bn_act(const float* x, const float* bnstate, float* y, long M, int C, hipStream_t stream) {
+  return crnn_bn_act_pool_drop(x, bnstate, y, 1, 1, (int)M, C, 1, 1, 0.f, 0, 0, stream);
+}

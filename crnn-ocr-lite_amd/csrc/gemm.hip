@@ -1,0 +1,257 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact f32, == an fmaf chain).
+//
+// One kernel template serves every matmul-shaped op of the CRNN hot path:
+//   NN  C[M,N] = A[M,K]  * B[K,N]      pointwise 1x1 conv fwd (utils.py:47), Dense fwd (utils.py:74,85,253,256),
+//                                      RNN input GEMM, STN im2col convs (utils.py:249,251)
+//   NT  C[M,N] = A[M,K]  * Bt[N,K]^T   data gradients (dX = dY * W^T)
+//   TN  C[M,N] = At[K,M]^T * B[K,N]    weight gradients (dW = X^T * dY), reduction over the huge row
+//                                      dimension split across workgroups (deterministic 2-stage sum)
+// 128 x {128,64} x 32 block tile, 4 waves (64 lanes each), each wave owns 2x2 / 1x2 MFMA 32x32
+// accumulators.  Operands are staged through LDS; "row-major-in-k" operands are stored
+// [rows][BK+4] and read as ds_read_b128 (conflict-free: 144-B row stride), "k-major" operands are
+// stored [BK][rows] and read as ds_read_b32.  The k order inside a BK chunk is permuted
+// (k = 8*kk8 + 4*half + e) identically for A and B so one b128 read feeds four MFMAs.
+// Workgroup ids are remapped so that tiles sharing the same A rows run on the same XCD (L2).
+#include "common.h"
+
+#define GBK 32
+#define GLDM (GBK + 4)
+
+struct GemmParams {
+  const float* A; const float* B; float* C;
+  int M, N, K;
+  int lda, ldb, ldc;
+  const float* bias;
+  int act;         // 0 none, 1 relu
+  int accumulate;  // C += result
+  int permP;       // 0: none; else out_row = (m % P) * (M / P) + m / P
+  int klen;        // K range per split (blockIdx.y); nsplit = gridDim.y
+  int vecA, vecB;  // 16-byte vector loads legal for the operand
+  int tilesN;
+};
+
+template <bool KM, int ROWS>
+__device__ __forceinline__ void load_tile(const float* __restrict__ X, int ld, int row0, int nrows_total,
+                                          int k0, int kend, int vec, int tid, float4 (&r)[ROWS / 32]) {
+  // ROWS x GBK tile -> ROWS*8 float4 -> ROWS/32 per thread (256 threads)
+#pragma unroll
+  for (int it = 0; it < ROWS / 32; ++it) {
+    int idx = tid + it * 256;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!KM) {
+      int row = idx >> 3, k4 = idx & 7;
+      int gr = row0 + row, gk = k0 + 4 * k4;
+      if (gr < nrows_total && gk < kend) {
+        const float* p = X + (long)gr * ld + gk;
+        if (vec) v = *reinterpret_cast<const float4*>(p);
+        else {
+          v.x = p[0];
+          if (gk + 1 < kend) v.y = p[1];
+          if (gk + 2 < kend) v.z = p[2];
+          if (gk + 3 < kend) v.w = p[3];
+        }
+      }
+    } else {
+      int krow = idx / (ROWS / 4), c4 = idx % (ROWS / 4);
+      int gk = k0 + krow, gc = row0 + 4 * c4;
+      if (gk < kend && gc < nrows_total) {
+        const float* p = X + (long)gk * ld + gc;
+        if (vec) v = *reinterpret_cast<const float4*>(p);
+        else {
+          v.x = p[0];
+          if (gc + 1 < nrows_total) v.y = p[1];
+          if (gc + 2 < nrows_total) v.z = p[2];
+          if (gc + 3 < nrows_total) v.w = p[3];
+        }
+      }
+    }
+    r[it] = v;
+  }
+}
+
+template <bool KM, int ROWS>
+__device__ __forceinline__ void store_tile(float* Xs, int tid, const float4 (&r)[ROWS / 32]) {
+#pragma unroll
+  for (int it = 0; it < ROWS / 32; ++it) {
+    int idx = tid + it * 256;
+    if (!KM) {
+      int row = idx >> 3, k4 = idx & 7;
+      *reinterpret_cast<float4*>(&Xs[row * GLDM + 4 * k4]) = r[it];
+    } else {
+      int krow = idx / (ROWS / 4), c4 = idx % (ROWS / 4);
+      *reinterpret_cast<float4*>(&Xs[krow * ROWS + 4 * c4]) = r[it];
+    }
+  }
+}
+
+template <bool KM, int ROWS>
+__device__ __forceinline__ void read_frag(const float* Xs, int r0, int kk8, int half, int l31, float (&f)[4]) {
+  if (!KM) {
+    float4 v = *reinterpret_cast<const float4*>(&Xs[(r0 + l31) * GLDM + kk8 * 8 + 4 * half]);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = Xs[(kk8 * 8 + 4 * half + e) * ROWS + r0 + l31];
+  }
+}
+
+template <int BN, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+  constexpr int BM = 128;
+  constexpr int WAVES_N = (BN == 128) ? 2 : 1;
+  constexpr int WM = (BN == 128) ? 64 : 32;  // rows per wave
+  constexpr int TM = WM / 32, TN = 2;        // MFMA tiles per wave (wave covers WM x 64)
+  __shared__ __attribute__((aligned(16))) float As[BM * GLDM];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * GLDM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * 64;
+
+  // XCD-aware bijective remap of the tile id (blocks b, b+8, ... share an L2)
+  int nwg = gridDim.x, bid = blockIdx.x;
+  int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  const int tm = lid / p.tilesN, tn = lid % p.tilesN;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int kbeg = blockIdx.y * p.klen;
+  const int kend = min(p.K, kbeg + p.klen);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float4 ra[BM / 32], rb[BN / 32];
+  load_tile<A_KM, BM>(p.A, p.lda, m0, p.M, kbeg, kend, p.vecA, tid, ra);
+  load_tile<B_KM, BN>(p.B, p.ldb, n0, p.N, kbeg, kend, p.vecB, tid, rb);
+
+  for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+    store_tile<A_KM, BM>(As, tid, ra);
+    store_tile<B_KM, BN>(Bs, tid, rb);
+    __syncthreads();
+    if (k0 + GBK < kend) {  // prefetch the next chunk; in flight during the MFMAs below
+      load_tile<A_KM, BM>(p.A, p.lda, m0, p.M, k0 + GBK, kend, p.vecA, tid, ra);
+      load_tile<B_KM, BN>(p.B, p.ldb, n0, p.N, k0 + GBK, kend, p.vecB, tid, rb);
+    }
+#pragma unroll
+    for (int kk8 = 0; kk8 < 4; ++kk8) {
+      float fa[TM][4], fb[TN][4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) read_frag<A_KM, BM>(As, wm0 + i * 32, kk8, half, l31, fa[i]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) read_frag<B_KM, BN>(Bs, wn0 + j * 32, kk8, half, l31, fb[j]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  const bool split = gridDim.y > 1;
+  float* Cout = split ? p.C + (long)blockIdx.y * p.M * p.N : p.C;
+  const int ldc = split ? p.N : p.ldc;
+  const int Q = p.permP ? p.M / p.permP : 0;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      int gn = n0 + wn0 + j * 32 + l31;
+      float bv = (!split && p.bias && gn < p.N) ? p.bias[gn] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int gm = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (gm < p.M && gn < p.N) {
+          float v = acc[i][j][e];
+          int orow = gm;
+          if (!split) {
+            v += bv;
+            if (p.act == 1) v = fmaxf(v, 0.f);
+            if (p.permP) orow = (gm % p.permP) * Q + gm / p.permP;
+            if (p.accumulate) v += Cout[(long)orow * ldc + gn];
+          }
+          Cout[(long)orow * ldc + gn] = v;
+        }
+      }
+    }
+}
+
+// second stage of a split reduction: C = act(sum_z part[z] + bias) (+ C)
+__global__ void gemm_splitk_reduce_kernel(const float* __restrict__ part, int nsplit, GemmParams p) {
+  long total = (long)p.M * p.N;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += part[(long)z * total + i];
+    int m = (int)(i / p.N), n = (int)(i % p.N);
+    if (p.bias) s += p.bias[n];
+    if (p.act == 1) s = fmaxf(s, 0.f);
+    int orow = m;
+    if (p.permP) orow = (m % p.permP) * (p.M / p.permP) + m / p.permP;
+    float* dst = p.C + (long)orow * p.ldc + n;
+    if (p.accumulate) s += *dst;
+    *dst = s;
+  }
+}
+
+static inline int aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// mode: 0 = NN, 1 = NT, 2 = TN.  `scratch` (scratch_bytes) is needed only when the reduction is split
+// (mode 2 with few output tiles); pass nullptr/0 to forbid splitting.
+extern "C" int crnn_gemm_f32(int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
+                             int ldc, const float* bias, int act, int accumulate, int permP, float* scratch,
+                             size_t scratch_bytes, hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return CRNN_ERR_ARG;
+  if (permP && (M % permP) != 0) return CRNN_ERR_ARG;
+  GemmParams p;
+  p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.bias = bias; p.act = act; p.accumulate = accumulate; p.permP = permP;
+  const bool a_km = (mode == 2), b_km = (mode != 1);
+  // contiguous extent of each operand: A: K (m-major) or M (k-major); B: N (k-major) or K (n-major)
+  p.vecA = aligned16(A) && (lda % 4 == 0) && ((a_km ? M : K) % 4 == 0);
+  p.vecB = aligned16(B) && (ldb % 4 == 0) && ((b_km ? N : K) % 4 == 0);
+  const int BN = (N <= 64) ? 64 : 128;
+  const int tilesM = cdiv(M, 128), tilesN = cdiv(N, BN);
+  p.tilesN = tilesN;
+  int tiles = tilesM * tilesN;
+  int nsplit = 1;
+  if (scratch && tiles < 256 && K >= 2048) {
+    nsplit = cdiv(1024, tiles);
+    int maxs = K / 512; if (maxs < 1) maxs = 1;
+    if (nsplit > maxs) nsplit = maxs;
+    size_t per = (size_t)M * N * sizeof(float);
+    size_t fit = scratch_bytes / per;
+    if ((size_t)nsplit > fit) nsplit = (int)fit;
+    if (nsplit < 1) nsplit = 1;
+  }
+  int klen = cdiv(K, nsplit);
+  klen = ((klen + GBK - 1) / GBK) * GBK;
+  nsplit = cdiv(K, klen);
+  p.klen = klen;
+  GemmParams pk = p;
+  if (nsplit > 1) pk.C = scratch;
+  dim3 grid(tiles, nsplit), block(256);
+#define LAUNCH(BNV, AK, BKM) hipLaunchKernelGGL((gemm_f32_kernel<BNV, AK, BKM>), grid, block, 0, stream, pk)
+  if (BN == 128) {
+    if (mode == 0) LAUNCH(128, false, true); else if (mode == 1) LAUNCH(128, false, false); else LAUNCH(128, true, true);
+  } else {
+    if (mode == 0) LAUNCH(64, false, true); else if (mode == 1) LAUNCH(64, false, false); else LAUNCH(64, true, true);
+  }
+#undef LAUNCH
+  CRNN_LAUNCH_CHECK();
+  if (nsplit > 1) {
+    long total = (long)M * N;
+    int blocks = cdiv(total, 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, scratch, nsplit, p);
+    CRNN_LAUNCH_CHECK();
+  }
+  return CRNN_OK;
+}

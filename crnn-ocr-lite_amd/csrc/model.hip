@@ -1,0 +1,452 @@
+// Host-side driver of the CRNN-OCR hot path: parameter layout (Keras weight order), workspace plan,
+// and the forward / backward kernel chains on one HIP stream.  Mirrors the graph of utils.py:58-96
+// (CRNN.get_model) + utils.py:247-258 (STN) + utils.py:98-103 (CTC Lambda); no allocation, no sync.
+#include "common.h"
+#include "crnn_mi355x.h"
+#include <string.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct BlockSpec { int cout, ph, pw; };
+const BlockSpec kBlocks[7] = {{64, 1, 1}, {128, 1, 1}, {256, 2, 2}, {256, 1, 1}, {512, 1, 2}, {512, 1, 1}, {512, 1, 1}};
+const float kDropBlock = 0.1f, kDropDense1 = 0.4f, kDropRnn = 0.2f;  // utils.py:56,75,83
+const uint32_t kLayerDense1 = 8, kLayerRnn = 9;
+
+struct Tensor { std::string name; long off; long size; int ndim; int dims[4]; };
+
+struct Dims {
+  int B, H0, W0, Hp, Wp, T, feat, C, L, tds, u, G, stn_flat;
+  int Hs1, Ws1, Ho1, Wo1, Hs2, Ws2, Ho2, Wo2;  // STN locnet maps
+  int bh[8], bw[8], bc[8];                      // input map of block i (1-based), bc[0] = 1
+};
+
+Dims make_dims(const crnn_config* c) {
+  Dims d;
+  d.B = c->batch; d.H0 = c->imgh; d.W0 = c->imgw; d.Hp = d.H0 + 4; d.Wp = d.W0 + 4;
+  d.C = c->num_classes; d.L = c->max_len; d.tds = c->tds; d.u = c->units; d.G = (c->gru ? 3 : 4) * c->units;
+  d.Hs1 = d.H0 / 2; d.Ws1 = d.W0 / 2; d.Ho1 = d.Hs1 - 4; d.Wo1 = d.Ws1 - 4;
+  d.Hs2 = d.Ho1 / 2; d.Ws2 = d.Wo1 / 2; d.Ho2 = d.Hs2 - 4; d.Wo2 = d.Ws2 - 4;
+  d.stn_flat = d.Ho2 * d.Wo2 * 20;
+  int h = d.Hp, w = d.Wp, ch = 1;
+  for (int i = 1; i <= 7; ++i) {
+    d.bh[i] = h; d.bw[i] = w; d.bc[i - 1] = ch;
+    h /= kBlocks[i - 1].ph; w /= kBlocks[i - 1].pw; ch = kBlocks[i - 1].cout;
+  }
+  d.bc[7] = ch;
+  d.T = h; d.feat = w * ch;
+  return d;
+}
+
+long pad4(long n) { return (n + 3) & ~3L; }
+
+struct Layout {
+  std::vector<Tensor> params;
+  long total = 0;
+  void add(const std::string& n, std::initializer_list<int> dims) {
+    Tensor t; t.name = n; t.off = total; t.ndim = (int)dims.size(); t.size = 1;
+    int i = 0; for (int v : dims) { t.dims[i++] = v; t.size *= v; }
+    for (; i < 4; ++i) t.dims[i] = 1;
+    params.push_back(t); total += pad4(t.size);
+  }
+  long off(const std::string& n) const { for (auto& t : params) if (t.name == n) return t.off; return -1; }
+};
+
+Layout make_layout(const crnn_config* c) {
+  Dims d = make_dims(c);
+  Layout L;
+  L.add("stn_c1_k", {5, 5, 1, 20}); L.add("stn_c1_b", {20});
+  L.add("stn_c2_k", {5, 5, 20, 20}); L.add("stn_c2_b", {20});
+  L.add("stn_d1_w", {d.stn_flat, 50}); L.add("stn_d1_b", {50});
+  L.add("stn_d2_w", {50, 6}); L.add("stn_d2_b", {6});
+  for (int i = 1; i <= 7; ++i) {
+    std::string p = "b" + std::to_string(i);
+    int ci = d.bc[i - 1], co = d.bc[i];
+    L.add(p + "_dw", {3, 3, ci}); L.add(p + "_bn1_g", {ci}); L.add(p + "_bn1_b", {ci});
+    L.add(p + "_pw", {ci, co}); L.add(p + "_bn2_g", {co}); L.add(p + "_bn2_b", {co});
+  }
+  L.add("dense1_w", {d.feat, d.tds}); L.add("dense1_b", {d.tds});
+  for (int l = 1; l <= 2; ++l)
+    for (const char* dir : {"f", "b"}) {
+      std::string p = "rnn" + std::to_string(l) + dir;
+      L.add(p + "_w", {l == 1 ? d.tds : d.u, d.G}); L.add(p + "_u", {d.u, d.G}); L.add(p + "_b", {d.G});
+    }
+  L.add("dense2_w", {2 * d.u, d.C}); L.add("dense2_b", {d.C});
+  return L;
+}
+
+// ---------------------------------------------------------------------------------------------------
+struct Plan {
+  std::vector<Tensor> t;
+  long total = 0;
+  long add(const std::string& n, long count) {
+    Tensor x; x.name = n; x.off = total; x.size = count; x.ndim = 1; x.dims[0] = x.dims[1] = x.dims[2] = x.dims[3] = 1;
+    t.push_back(x); total += (count + 63) & ~63L;  // 256-byte aligned
+    return x.off;
+  }
+  long off(const std::string& n) const { for (auto& x : t) if (x.name == n) return x.off; return -1; }
+  long cnt(const std::string& n) const { for (auto& x : t) if (x.name == n) return x.size; return -1; }
+};
+
+long lmax(long a, long b) { return a > b ? a : b; }
+
+Plan make_plan(const crnn_config* c) {
+  Dims d = make_dims(c);
+  Plan P;
+  const long B = d.B;
+  // BatchNorm state blocks [mean|var|scale|shift] first: their offsets must stay small (int) for crnn_bn_update
+  for (int i = 1; i <= 7; ++i) {
+    P.add("bn1s" + std::to_string(i), 4L * d.bc[i - 1]);
+    P.add("bn2s" + std::to_string(i), 4L * d.bc[i]);
+  }
+  // STN locnet
+  P.add("pool1", B * d.Hs1 * d.Ws1);
+  P.add("col1", B * d.Ho1 * d.Wo1 * 25);
+  P.add("c1", B * d.Ho1 * d.Wo1 * 20);
+  P.add("pool2", B * d.Hs2 * d.Ws2 * 20);
+  P.add("col2", B * d.Ho2 * d.Wo2 * 500);
+  P.add("flat", B * d.stn_flat);
+  P.add("fc1", B * 50);
+  P.add("theta", B * 6);
+  P.add("x0", B * d.Hp * d.Wp);
+  long maxact = 0, maxparts = 0;
+  for (int i = 1; i <= 7; ++i) {
+    std::string p = std::to_string(i);
+    long M = B * d.bh[i] * d.bw[i];
+    int ci = d.bc[i - 1], co = d.bc[i];
+    long Mo = B * (d.bh[i] / kBlocks[i - 1].ph) * (d.bw[i] / kBlocks[i - 1].pw);
+    P.add("d" + p, M * ci); P.add("a" + p, M * ci); P.add("q" + p, M * co); P.add("x" + p, Mo * co);
+    maxact = lmax(maxact, M * co);
+    long tiles = crnn_dwconv_num_tiles(d.B, d.bh[i], d.bw[i]);
+    maxparts = lmax(maxparts, tiles * 9L * ci);
+    maxparts = lmax(maxparts, (long)crnn_colreduce_chunks(M) * 2L * lmax(ci, co));
+    maxparts = lmax(maxparts, (long)crnn_bn_bwd_chunks(M) * 2L * lmax(ci, co));
+  }
+  const long TB = (long)d.T * B;
+  P.add("dn1", TB * d.tds);
+  for (int l = 1; l <= 2; ++l) {
+    std::string p = std::to_string(l);
+    for (const char* dir : {"f", "b"}) {
+      P.add("xw" + p + dir, TB * d.G); P.add("cs" + p + dir, TB * d.u); P.add("gt" + p + dir, TB * d.G);
+      P.add("ut" + p + dir, (long)d.G * d.u); P.add("dz" + p + dir, TB * d.G);
+    }
+  }
+  P.add("h1f", TB * d.u); P.add("h1b", TB * d.u); P.add("r1", TB * d.u);
+  P.add("h2", TB * 2 * d.u); P.add("r2d", TB * 2 * d.u);
+  P.add("logits", TB * d.C); P.add("ypred", TB * d.C);
+  // backward
+  P.add("dlogits", TB * d.C); P.add("dr2", TB * 2 * d.u); P.add("dr1", TB * d.u);
+  P.add("dcf", B * d.u); P.add("dcb", B * d.u);
+  P.add("ddn1", TB * d.tds); P.add("gbm", TB * d.tds);
+  maxact = lmax(maxact, TB * d.feat);
+  P.add("gA", maxact); P.add("gB", maxact);
+  P.add("dtheta", B * 6); P.add("dfc1", B * 50); P.add("dflat", B * d.stn_flat);
+  P.add("dcol2", B * d.Ho2 * d.Wo2 * 500); P.add("dpool2", B * d.Hs2 * d.Ws2 * 20); P.add("dc1", B * d.Ho1 * d.Wo1 * 20);
+  maxparts = lmax(maxparts, (long)crnn_colreduce_chunks(TB) * lmax(d.G, lmax(d.tds, d.C)));
+  maxparts = lmax(maxparts, (long)crnn_colreduce_chunks(B * d.Ho1 * d.Wo1) * 64);
+  P.add("partials", maxparts);
+  P.add("coef", 2 * 1024);
+  P.add("gemm_scratch", 32L * 1024 * 1024);  // 128 MiB of split-reduction partials
+  return P;
+}
+
+const size_t kGemmScratchBytes = 128UL * 1024 * 1024;
+
+struct Ctx {
+  const crnn_config* cfg; Dims d; Layout L; Plan P;
+  const float* params; float* grads; float* ws; hipStream_t s;
+  const float* p(const std::string& n) const { return params + L.off(n); }
+  float* g(const std::string& n) const { return grads + L.off(n); }
+  float* w(const std::string& n) const { return ws + P.off(n); }
+  float* scratch() const { return ws + P.off("gemm_scratch"); }
+};
+
+int gemm(const Ctx& c, int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+         const float* bias = nullptr, int act = 0, int acc = 0, int perm = 0) {
+  return crnn_gemm_f32(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, c.scratch(), kGemmScratchBytes, c.s);
+}
+
+int colsum(const Ctx& c, const float* x, long M, int C, int ld, float* out) {
+  CRNN_TRY(crnn_colreduce(x, c.w("partials"), M, C, ld, 1, c.s));
+  return crnn_partials_sum(c.w("partials"), crnn_colreduce_chunks(M), C, out, 1.f, c.s);
+}
+
+int check_cfg(const crnn_config* c) {
+  if (!c || c->batch <= 0) return CRNN_ERR_ARG;
+  if (c->gru) return CRNN_ERR_UNSUPPORTED;  // GRU cell: next milestone
+  if (c->units < 64 || c->units % 64) return CRNN_ERR_UNSUPPORTED;
+  if (c->num_classes > 64 || c->num_classes < 2) return CRNN_ERR_UNSUPPORTED;
+  if (2 * c->max_len + 1 > 64) return CRNN_ERR_UNSUPPORTED;
+  if (c->tds % 4) return CRNN_ERR_UNSUPPORTED;
+  Dims d = make_dims(c);
+  if (c->stn && (d.Ho2 < 1 || d.Wo2 < 1)) return CRNN_ERR_UNSUPPORTED;
+  if (d.T < 3 || d.feat < 1) return CRNN_ERR_UNSUPPORTED;
+  return 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+extern "C" int crnn_num_params(const crnn_config* cfg) { return (int)make_layout(cfg).params.size(); }
+extern "C" long crnn_params_total(const crnn_config* cfg) { return make_layout(cfg).total; }
+extern "C" int crnn_param_info(const crnn_config* cfg, int idx, char* name, int name_cap, long* offset, long* size,
+                               int* ndim, int* dims) {
+  Layout L = make_layout(cfg);
+  if (idx < 0 || idx >= (int)L.params.size()) return CRNN_ERR_ARG;
+  const Tensor& t = L.params[idx];
+  if (name && name_cap > 0) { strncpy(name, t.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+  if (offset) *offset = t.off;
+  if (size) *size = t.size;
+  if (ndim) *ndim = t.ndim;
+  if (dims) for (int i = 0; i < 4; ++i) dims[i] = t.dims[i];
+  return 0;
+}
+extern "C" int crnn_time_steps(const crnn_config* cfg) { return make_dims(cfg).T; }
+extern "C" int crnn_bn_total(const crnn_config* cfg) {
+  Dims d = make_dims(cfg); int n = 0;
+  for (int i = 1; i <= 7; ++i) n += d.bc[i - 1] + d.bc[i];
+  return n;
+}
+// idx 0..13: b1_bn1, b1_bn2, b2_bn1, ...
+extern "C" int crnn_bn_info(const crnn_config* cfg, int idx, char* name, int name_cap, int* offset, int* channels, long* count) {
+  if (idx < 0 || idx >= 14) return CRNN_ERR_ARG;
+  Dims d = make_dims(cfg);
+  int off = 0;
+  for (int k = 0; k < idx; ++k) { int i = k / 2 + 1; off += (k % 2 == 0) ? d.bc[i - 1] : d.bc[i]; }
+  int i = idx / 2 + 1;
+  if (name && name_cap > 0) snprintf(name, name_cap, "b%d_bn%d", i, idx % 2 + 1);
+  if (offset) *offset = off;
+  if (channels) *channels = (idx % 2 == 0) ? d.bc[i - 1] : d.bc[i];
+  if (count) *count = (long)d.B * d.bh[i] * d.bw[i];
+  return 0;
+}
+extern "C" size_t crnn_workspace_bytes(const crnn_config* cfg) {
+  if (check_cfg(cfg)) return 0;
+  return (size_t)make_plan(cfg).total * sizeof(float);
+}
+extern "C" int crnn_ws_tensor(const crnn_config* cfg, const char* name, long* offset, long* count) {
+  Plan P = make_plan(cfg);
+  long o = P.off(name);
+  if (o < 0) return CRNN_ERR_ARG;
+  if (offset) *offset = o;
+  if (count) *count = P.cnt(name);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const float* bn_mean, const float* bn_var,
+                            const float* x, float* ws, size_t ws_bytes, float* y_pred, int train, uint64_t seed,
+                            hipStream_t stream) {
+  CRNN_TRY(check_cfg(cfg));
+  Ctx c{cfg, make_dims(cfg), make_layout(cfg), make_plan(cfg), params, nullptr, ws, stream};
+  if (ws_bytes < (size_t)c.P.total * sizeof(float)) return CRNN_ERR_ARG;
+  const Dims& d = c.d;
+  const int B = d.B;
+  // ---- spatial transformer (utils.py:247-258) + ZeroPadding2D (utils.py:63)
+  if (cfg->stn) {
+    CRNN_TRY(crnn_maxpool_fwd(x, c.w("pool1"), B, d.H0, d.W0, 1, 2, 2, stream));
+    CRNN_TRY(crnn_im2col(c.w("pool1"), c.w("col1"), B, d.Hs1, d.Ws1, 1, 5, stream));
+    int R1 = B * d.Ho1 * d.Wo1;
+    CRNN_TRY(gemm(c, 0, c.w("col1"), c.p("stn_c1_k"), c.w("c1"), R1, 20, 25, 25, 20, 20, c.p("stn_c1_b")));
+    CRNN_TRY(crnn_maxpool_fwd(c.w("c1"), c.w("pool2"), B, d.Ho1, d.Wo1, 20, 2, 2, stream));
+    CRNN_TRY(crnn_im2col(c.w("pool2"), c.w("col2"), B, d.Hs2, d.Ws2, 20, 5, stream));
+    int R2 = B * d.Ho2 * d.Wo2;
+    CRNN_TRY(gemm(c, 0, c.w("col2"), c.p("stn_c2_k"), c.w("flat"), R2, 20, 500, 500, 20, 20, c.p("stn_c2_b")));
+    CRNN_TRY(gemm(c, 0, c.w("flat"), c.p("stn_d1_w"), c.w("fc1"), B, 50, d.stn_flat, d.stn_flat, 50, 50, c.p("stn_d1_b"), 1));
+    CRNN_TRY(gemm(c, 0, c.w("fc1"), c.p("stn_d2_w"), c.w("theta"), B, 6, 50, 50, 6, 6, c.p("stn_d2_b")));
+    CRNN_TRY(crnn_sampler_fwd(x, c.w("theta"), c.w("x0"), B, d.H0, d.W0, 2, stream));
+  } else {
+    CRNN_TRY(crnn_pad_copy(x, c.w("x0"), B, d.H0, d.W0, 2, stream));
+  }
+  // ---- 7 depthwise-separable blocks (utils.py:43-56, 64-70)
+  const float* in = c.w("x0");
+  int bn_off = 0;
+  for (int i = 1; i <= 7; ++i) {
+    std::string p = std::to_string(i), bp = "b" + p;
+    const int H = d.bh[i], W = d.bw[i], ci = d.bc[i - 1], co = d.bc[i];
+    const long M = (long)B * H * W;
+    float* dd = c.w("d" + p); float* aa = c.w("a" + p); float* qq = c.w("q" + p); float* xo = c.w("x" + p);
+    float* s1 = c.w("bn1s" + p); float* s2 = c.w("bn2s" + p);
+    float* parts = c.w("partials");
+    if (ci % 32 == 0) {
+      CRNN_TRY(crnn_dwconv3x3_fwd(in, c.p(bp + "_dw"), dd, train ? parts : nullptr, B, H, W, ci, 0, stream));
+      if (train) CRNN_TRY(crnn_bn_finalize(parts, crnn_dwconv_num_tiles(B, H, W), ci, M, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), s1, stream));
+    } else {
+      CRNN_TRY(crnn_dwconv3x3_fwd(in, c.p(bp + "_dw"), dd, nullptr, B, H, W, ci, 0, stream));
+      if (train) {
+        CRNN_TRY(crnn_colreduce(dd, parts, M, ci, ci, 2, stream));
+        CRNN_TRY(crnn_bn_finalize(parts, crnn_colreduce_chunks(M), ci, M, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), s1, stream));
+      }
+    }
+    if (!train) CRNN_TRY(crnn_bn_infer_state(bn_mean + bn_off, bn_var + bn_off, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), ci, s1, stream));
+    bn_off += ci;
+    CRNN_TRY(crnn_bn_act(dd, s1, aa, M, ci, stream));
+    CRNN_TRY(gemm(c, 0, aa, c.p(bp + "_pw"), qq, (int)M, co, ci, ci, co, co));
+    if (train) {
+      CRNN_TRY(crnn_colreduce(qq, parts, M, co, co, 2, stream));
+      CRNN_TRY(crnn_bn_finalize(parts, crnn_colreduce_chunks(M), co, M, c.p(bp + "_bn2_g"), c.p(bp + "_bn2_b"), s2, stream));
+    } else {
+      CRNN_TRY(crnn_bn_infer_state(bn_mean + bn_off, bn_var + bn_off, c.p(bp + "_bn2_g"), c.p(bp + "_bn2_b"), co, s2, stream));
+    }
+    bn_off += co;
+    CRNN_TRY(crnn_bn_act_pool_drop(qq, s2, xo, B, H, W, co, kBlocks[i - 1].ph, kBlocks[i - 1].pw, (train && cfg->dropout) ? kDropBlock : 0.f, seed, (uint32_t)i, stream));
+    in = xo;
+  }
+  // ---- Reshape + dense1 (relu) + Dropout(.4) (utils.py:72-75); output time-major [T][B][tds]
+  const int T = d.T, TB = T * B, u = d.u, G = d.G;
+  CRNN_TRY(gemm(c, 0, in, c.p("dense1_w"), c.w("dn1"), TB, d.tds, d.feat, d.feat, d.tds, d.tds, c.p("dense1_b"), 1, 0, T));
+  if (train && cfg->dropout) CRNN_TRY(crnn_dropout(c.w("dn1"), c.w("dn1"), TB, d.tds, d.tds, d.tds, kDropDense1, seed, kLayerDense1, stream));
+  // ---- 2 x Bidirectional(LSTM) (utils.py:78-79)
+  for (const char* n : {"1f", "1b", "2f", "2b"})
+    CRNN_TRY(crnn_transpose(c.p(std::string("rnn") + n + "_u"), c.w(std::string("ut") + n), u, G, stream));
+  CRNN_TRY(gemm(c, 0, c.w("dn1"), c.p("rnn1f_w"), c.w("xw1f"), TB, G, d.tds, d.tds, G, G, c.p("rnn1f_b")));
+  CRNN_TRY(gemm(c, 0, c.w("dn1"), c.p("rnn1b_w"), c.w("xw1b"), TB, G, d.tds, d.tds, G, G, c.p("rnn1b_b")));
+  CRNN_TRY(crnn_lstm_fwd(c.w("xw1f"), c.w("xw1b"), c.w("ut1f"), c.w("ut1b"), c.w("h1f"), c.w("h1b"), u, c.w("cs1f"), c.w("cs1b"),
+                         c.w("gt1f"), c.w("gt1b"), T, B, u, stream));
+  CRNN_TRY(crnn_add(c.w("h1f"), c.w("h1b"), c.w("r1"), (long)TB * u, stream));  // merge_mode='sum'
+  CRNN_TRY(gemm(c, 0, c.w("r1"), c.p("rnn2f_w"), c.w("xw2f"), TB, G, u, u, G, G, c.p("rnn2f_b")));
+  CRNN_TRY(gemm(c, 0, c.w("r1"), c.p("rnn2b_w"), c.w("xw2b"), TB, G, u, u, G, G, c.p("rnn2b_b")));
+  CRNN_TRY(crnn_lstm_fwd(c.w("xw2f"), c.w("xw2b"), c.w("ut2f"), c.w("ut2b"), c.w("h2"), c.w("h2") + u, 2 * u, c.w("cs2f"), c.w("cs2b"),
+                         c.w("gt2f"), c.w("gt2b"), T, B, u, stream));      // merge_mode='concat'
+  const float* r2 = c.w("h2");
+  if (train) {  // Dropout(.2) (utils.py:83)
+    CRNN_TRY(crnn_dropout(c.w("h2"), c.w("r2d"), TB, 2 * u, 2 * u, 2 * u, cfg->dropout ? kDropRnn : 0.f, seed, kLayerRnn, stream));
+    r2 = c.w("r2d");
+  }
+  // ---- dense2 + softmax (utils.py:85-86); back to batch-major [B][T][C]
+  CRNN_TRY(gemm(c, 0, r2, c.p("dense2_w"), c.w("logits"), TB, d.C, 2 * u, 2 * u, d.C, d.C, c.p("dense2_b"), 0, 0, B));
+  CRNN_TRY(crnn_softmax_rows(c.w("logits"), c.w("ypred"), TB, d.C, stream));
+  if (y_pred && y_pred != c.w("ypred")) {
+    hipError_t e = hipMemcpyAsync(y_pred, c.w("ypred"), (size_t)TB * d.C * sizeof(float), hipMemcpyDeviceToDevice, stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  return CRNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+static int lstm_layer_bwd(const Ctx& c, int layer, const float* xin, int ldx, int din, const float* hf, const float* hb, int ldh,
+                          const float* doutf, const float* doutb, int ldo, float* dxin) {
+  const Dims& d = c.d;
+  const int T = d.T, B = d.B, TB = T * B, u = d.u, G = d.G;
+  std::string l = std::to_string(layer);
+  float* dzf = c.w("dz" + l + "f"); float* dzb = c.w("dz" + l + "b");
+  CRNN_TRY(crnn_lstm_bwd(c.p("rnn" + l + "f_u"), c.p("rnn" + l + "b_u"), c.w("cs" + l + "f"), c.w("cs" + l + "b"), c.w("gt" + l + "f"),
+                         c.w("gt" + l + "b"), doutf, doutb, ldo, dzf, dzb, c.w("dcf"), c.w("dcb"), T, B, u, c.s));
+  // dW = X^T dZ ; dU = Hprev^T dZ ; db = colsum(dZ) ; dX = dZf Wf^T + dZb Wb^T
+  CRNN_TRY(gemm(c, 2, xin, dzf, c.g("rnn" + l + "f_w"), din, G, TB, ldx, G, G));
+  CRNN_TRY(gemm(c, 2, xin, dzb, c.g("rnn" + l + "b_w"), din, G, TB, ldx, G, G));
+  const int K1 = (T - 1) * B;
+  // forward direction: h_{t-1} pairs with dz_t ; backward direction: h_{t+1} pairs with dz_t
+  CRNN_TRY(gemm(c, 2, hf, dzf + (long)B * G, c.g("rnn" + l + "f_u"), u, G, K1, ldh, G, G));
+  CRNN_TRY(gemm(c, 2, hb + (long)B * ldh, dzb, c.g("rnn" + l + "b_u"), u, G, K1, ldh, G, G));
+  CRNN_TRY(colsum(c, dzf, TB, G, G, c.g("rnn" + l + "f_b")));
+  CRNN_TRY(colsum(c, dzb, TB, G, G, c.g("rnn" + l + "b_b")));
+  CRNN_TRY(gemm(c, 1, dzf, c.p("rnn" + l + "f_w"), dxin, TB, din, G, G, G, din));
+  CRNN_TRY(gemm(c, 1, dzb, c.p("rnn" + l + "b_w"), dxin, TB, din, G, G, G, din, nullptr, 0, 1));
+  return CRNN_OK;
+}
+
+extern "C" int crnn_backward(const crnn_config* cfg, const float* params, float* grads, const float* x, const int* labels,
+                             const int* input_length, const int* label_length, float* ws, size_t ws_bytes, float* loss,
+                             uint64_t seed, hipStream_t stream) {
+  CRNN_TRY(check_cfg(cfg));
+  Ctx c{cfg, make_dims(cfg), make_layout(cfg), make_plan(cfg), params, grads, ws, stream};
+  if (ws_bytes < (size_t)c.P.total * sizeof(float)) return CRNN_ERR_ARG;
+  const Dims& d = c.d;
+  const int B = d.B, T = d.T, TB = T * B, u = d.u;
+  hipError_t e = hipMemsetAsync(grads, 0, (size_t)c.L.total * sizeof(float), stream);
+  if (e != hipSuccess) return (int)e;
+  // ---- CTC (utils.py:98-103): loss per sample + d mean(loss)/d logits (time-major)
+  CRNN_TRY(crnn_ctc_loss_grad(c.w("ypred"), labels, input_length, label_length, loss, c.w("dlogits"), B, T, d.C, d.L, 2, 1.0f / (float)B, stream));
+  // ---- dense2
+  const float* r2 = c.w("r2d");
+  CRNN_TRY(gemm(c, 2, r2, c.w("dlogits"), c.g("dense2_w"), 2 * u, d.C, TB, 2 * u, d.C, d.C));
+  CRNN_TRY(colsum(c, c.w("dlogits"), TB, d.C, d.C, c.g("dense2_b")));
+  CRNN_TRY(gemm(c, 1, c.w("dlogits"), c.p("dense2_w"), c.w("dr2"), TB, 2 * u, d.C, d.C, d.C, 2 * u));
+  if (cfg->dropout) CRNN_TRY(crnn_dropout(c.w("dr2"), c.w("dr2"), TB, 2 * u, 2 * u, 2 * u, kDropRnn, seed, kLayerRnn, stream));
+  // ---- Bidirectional LSTM x2
+  CRNN_TRY(lstm_layer_bwd(c, 2, c.w("r1"), u, u, c.w("h2"), c.w("h2") + u, 2 * u, c.w("dr2"), c.w("dr2") + u, 2 * u, c.w("dr1")));
+  CRNN_TRY(lstm_layer_bwd(c, 1, c.w("dn1"), d.tds, d.tds, c.w("h1f"), c.w("h1b"), u, c.w("dr1"), c.w("dr1"), u, c.w("ddn1")));
+  // ---- Dropout(.4) + relu of dense1, rows back to batch-major
+  CRNN_TRY(crnn_relu_bwd(c.w("dn1"), c.w("ddn1"), c.w("gbm"), TB, d.tds, cfg->dropout ? 1.0f / (1.0f - kDropDense1) : 1.0f, B, stream));
+  const float* feat = c.w("x7");
+  CRNN_TRY(gemm(c, 2, feat, c.w("gbm"), c.g("dense1_w"), d.feat, d.tds, TB, d.feat, d.tds, d.tds));
+  CRNN_TRY(colsum(c, c.w("gbm"), TB, d.tds, d.tds, c.g("dense1_b")));
+  float* gA = c.w("gA"); float* gB = c.w("gB");
+  CRNN_TRY(gemm(c, 1, c.w("gbm"), c.p("dense1_w"), gA, TB, d.feat, d.tds, d.tds, d.tds, d.feat));
+  // ---- conv stack
+  for (int i = 7; i >= 1; --i) {
+    std::string p = std::to_string(i), bp = "b" + p;
+    const int H = d.bh[i], W = d.bw[i], ci = d.bc[i - 1], co = d.bc[i];
+    const long M = (long)B * H * W;
+    CRNN_TRY(crnn_bn_bwd(c.w("q" + p), gA, c.w("bn2s" + p), c.p(bp + "_bn2_g"), gB, c.g(bp + "_bn2_g"), c.g(bp + "_bn2_b"), c.w("partials"),
+                         c.w("coef"), B, H, W, co, kBlocks[i - 1].ph, kBlocks[i - 1].pw, cfg->dropout ? kDropBlock : 0.f, seed, (uint32_t)i, stream));
+    CRNN_TRY(gemm(c, 2, c.w("a" + p), gB, c.g(bp + "_pw"), ci, co, (int)M, ci, co, co));
+    CRNN_TRY(gemm(c, 1, gB, c.p(bp + "_pw"), gA, (int)M, ci, co, co, co, ci));
+    CRNN_TRY(crnn_bn_bwd(c.w("d" + p), gA, c.w("bn1s" + p), c.p(bp + "_bn1_g"), gB, c.g(bp + "_bn1_g"), c.g(bp + "_bn1_b"), c.w("partials"),
+                         c.w("coef"), B, H, W, ci, 1, 1, 0.f, 0, 0, stream));
+    const float* xin = (i == 1) ? c.w("x0") : c.w("x" + std::to_string(i - 1));
+    CRNN_TRY(crnn_dwconv3x3_wgrad(xin, gB, c.g(bp + "_dw"), c.w("partials"), B, H, W, ci, stream));
+    if (i > 1 || cfg->stn) CRNN_TRY(crnn_dwconv3x3_fwd(gB, c.p(bp + "_dw"), gA, nullptr, B, H, W, ci, 1, stream));
+  }
+  // ---- spatial transformer
+  if (cfg->stn) {
+    CRNN_TRY(crnn_sampler_bwd(x, c.w("theta"), gA, c.w("dtheta"), B, d.H0, d.W0, 2, stream));
+    CRNN_TRY(gemm(c, 2, c.w("fc1"), c.w("dtheta"), c.g("stn_d2_w"), 50, 6, B, 50, 6, 6));
+    CRNN_TRY(colsum(c, c.w("dtheta"), B, 6, 6, c.g("stn_d2_b")));
+    CRNN_TRY(gemm(c, 1, c.w("dtheta"), c.p("stn_d2_w"), c.w("dfc1"), B, 50, 6, 6, 6, 50));
+    CRNN_TRY(crnn_relu_bwd(c.w("fc1"), c.w("dfc1"), c.w("dfc1"), B, 50, 1.f, 0, stream));
+    CRNN_TRY(gemm(c, 2, c.w("flat"), c.w("dfc1"), c.g("stn_d1_w"), d.stn_flat, 50, B, d.stn_flat, 50, 50));
+    CRNN_TRY(colsum(c, c.w("dfc1"), B, 50, 50, c.g("stn_d1_b")));
+    CRNN_TRY(gemm(c, 1, c.w("dfc1"), c.p("stn_d1_w"), c.w("dflat"), B, d.stn_flat, 50, 50, 50, d.stn_flat));
+    const int R2 = B * d.Ho2 * d.Wo2, R1 = B * d.Ho1 * d.Wo1;
+    CRNN_TRY(gemm(c, 2, c.w("col2"), c.w("dflat"), c.g("stn_c2_k"), 500, 20, R2, 500, 20, 20));
+    CRNN_TRY(colsum(c, c.w("dflat"), R2, 20, 20, c.g("stn_c2_b")));
+    CRNN_TRY(gemm(c, 1, c.w("dflat"), c.p("stn_c2_k"), c.w("dcol2"), R2, 500, 20, 20, 20, 500));
+    CRNN_TRY(crnn_col2im(c.w("dcol2"), c.w("dpool2"), B, d.Hs2, d.Ws2, 20, 5, stream));
+    CRNN_TRY(crnn_maxpool_bwd(c.w("c1"), c.w("dpool2"), c.w("dc1"), B, d.Ho1, d.Wo1, 20, 2, 2, stream));
+    CRNN_TRY(gemm(c, 2, c.w("col1"), c.w("dc1"), c.g("stn_c1_k"), 25, 20, R1, 25, 20, 20));
+    CRNN_TRY(colsum(c, c.w("dc1"), R1, 20, 20, c.g("stn_c1_b")));
+  }
+  return CRNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// BatchNorm moving statistics (momentum .99): m <- .99 m + .01 mean ;
+// v <- .99 v + .01 var * n/(n-1) * n/(n-(1+eps))   (TF fused-BN Bessel correction x Keras 2.2.2 factor)
+struct BnTable { int state_off[14]; int C[14]; int cum[15]; float count[14]; };
+__global__ void bn_moving_kernel(BnTable tab, float* __restrict__ mmean, float* __restrict__ mvar, const float* __restrict__ ws,
+                                 int total, float momentum, float eps) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int k = 0;
+  while (k < 13 && i >= tab.cum[k + 1]) ++k;
+  int ch = i - tab.cum[k];
+  float n = tab.count[k];
+  float mean = ws[tab.state_off[k] + ch], var = ws[tab.state_off[k] + tab.C[k] + ch];
+  float vhat = var * (n / (n - 1.f)) * (n / (n - (1.f + eps)));
+  mmean[i] = momentum * mmean[i] + (1.f - momentum) * mean;
+  mvar[i] = momentum * mvar[i] + (1.f - momentum) * vhat;
+}
+
+extern "C" int crnn_bn_update(const crnn_config* cfg, float* bn_mean, float* bn_var, float* ws, size_t ws_bytes, hipStream_t stream) {
+  CRNN_TRY(check_cfg(cfg));
+  Dims d = make_dims(cfg);
+  Plan P = make_plan(cfg);
+  if (ws_bytes < (size_t)P.total * sizeof(float)) return CRNN_ERR_ARG;
+  BnTable tab;
+  int k = 0, cum = 0;
+  for (int i = 1; i <= 7; ++i)
+    for (int j = 1; j <= 2; ++j, ++k) {
+      int C = (j == 1) ? d.bc[i - 1] : d.bc[i];
+      tab.state_off[k] = (int)P.off(std::string("bn") + (j == 1 ? "1s" : "2s") + std::to_string(i));
+      tab.C[k] = C; tab.cum[k] = cum; tab.count[k] = (float)((long)d.B * d.bh[i] * d.bw[i]);
+      cum += C;
+    }
+  tab.cum[14] = cum;
+  hipLaunchKernelGGL(bn_moving_kernel, dim3(cdiv(cum, 256)), dim3(256), 0, stream, tab, bn_mean, bn_var, ws, cum, 0.99f, 1e-3f);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}

@@ -1,0 +1,174 @@
+// Bidirectional LSTM recurrence (Keras 2.2.2 LSTMCell: hard_sigmoid gates, tanh, gate order i,f,c,o;
+// utils.py:77-79), time-major [T][B][.] internally.
+//
+// One launch per timestep, both directions in the same launch (blockIdx.z).  The per-step work is the
+// recurrent gate GEMM  z[B,4u] = h_{t-1}[B,u] * U[u,4u]  on the matrix cores (v_mfma_f32_16x16x4_f32),
+// with the gate non-linearities / cell update fused as its epilogue.  A workgroup owns a 16(batch) x
+// 16(units) x 4(gates) output tile so the whole cell update is thread-local; its 4 waves split K and
+// combine through LDS.  Operands are read straight from L2 (U is 1 MB/direction and shared by every
+// workgroup) as 16-byte loads along K: lane (r,q) loads k = kb+4q..4q+3 and feeds 4 MFMAs, i.e. MFMA e
+// covers k in {kb+e, kb+4+e, kb+8+e, kb+12+e} for both operands.
+// The input projection x*W+b for all timesteps is hoisted into one big GEMM (gemm.hip).
+// Backward (BPTT) mirrors it: dh_{t-1} = dz_t * U^T as the per-step GEMM, the gate-gradient math as its
+// epilogue; dW/dU/dx/db are whole-sequence GEMMs afterwards.
+#include "common.h"
+
+struct LstmDir {
+  const float* xw;   // [T][B][4u]  x*W + b
+  const float* wt;   // fwd: U^T [4u][u] ; bwd: U [u][4u]
+  float* h; int ldh; // h(t,b,j) = h[(t*B+b)*ldh + j]
+  float* c;          // [T][B][u]
+  float* gates;      // [T][B][4u] activated i,f,g,o
+  const float* dout; int ldo;  // bwd: upstream gradient w.r.t. h, same indexing as h
+  float* dz;         // bwd: [T][B][4u] pre-activation gradients
+  float* dc;         // bwd: [B][u] cell-gradient carry
+};
+
+__global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmDir d0, LstmDir d1, int s, int T, int B, int u) {
+  __shared__ float red[4][4][256];
+  const LstmDir d = blockIdx.z ? d1 : d0;
+  const int dir = blockIdx.z;
+  const int t = dir ? T - 1 - s : s, tp = dir ? t + 1 : t - 1;
+  const int b0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  f32x4 acc[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (s > 0) {
+    const int kw = u >> 2, kbeg = wave * kw;
+    const bool valid = (b0 + r) < B;
+    const float* hrow = d.h + ((long)tp * B + (valid ? b0 + r : 0)) * d.ldh;
+    for (int kb = kbeg; kb < kbeg + kw; kb += 16) {
+      float4 a4 = valid ? *reinterpret_cast<const float4*>(hrow + kb + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 b4 = *reinterpret_cast<const float4*>(d.wt + ((long)(g * u + j0 + r)) * u + kb + 4 * q);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc[g], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wave][g][(q * 4 + e) * 16 + r] = acc[g][e];  // C/D: row = 4q+e, col = r
+  __syncthreads();
+  const int row = tid >> 4, col = tid & 15, b = b0 + row, j = j0 + col;
+  if (b < B) {
+    float z[4];
+    const float* xw = d.xw + ((long)t * B + b) * 4 * u;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      z[g] = ((red[0][g][tid] + red[1][g][tid]) + (red[2][g][tid] + red[3][g][tid])) + xw[g * u + j];
+    float ig = hard_sigmoid(z[0]), fg = hard_sigmoid(z[1]), gg = tanhf(z[2]), og = hard_sigmoid(z[3]);
+    float cprev = (s > 0) ? d.c[((long)tp * B + b) * u + j] : 0.f;
+    float cn = fg * cprev + ig * gg;
+    float hn = og * tanhf(cn);
+    float* gt = d.gates + ((long)t * B + b) * 4 * u;
+    gt[j] = ig; gt[u + j] = fg; gt[2 * u + j] = gg; gt[3 * u + j] = og;
+    d.c[((long)t * B + b) * u + j] = cn;
+    d.h[((long)t * B + b) * d.ldh + j] = hn;
+  }
+}
+
+// sb = 0..T-1 counts backward steps; the time handled is the (T-1-sb)-th in processing order
+__global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmDir d0, LstmDir d1, int sb, int T, int B, int u) {
+  __shared__ float red[4][256];
+  const LstmDir d = blockIdx.z ? d1 : d0;
+  const int dir = blockIdx.z;
+  const int sp = T - 1 - sb;                       // processing index of this time in the forward pass
+  const int t = dir ? T - 1 - sp : sp;
+  const int tnext = dir ? t - 1 : t + 1;           // processed after t in forward order (already back-propagated)
+  const int tprev = dir ? t + 1 : t - 1;           // processed before t in forward order
+  const int b0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int K = 4 * u;
+  if (sb > 0) {
+    const int kw = K >> 2, kbeg = wave * kw;
+    const bool valid = (b0 + r) < B;
+    const float* arow = d.dz + ((long)tnext * B + (valid ? b0 + r : 0)) * K;
+    const float* brow = d.wt + (long)(j0 + r) * K;
+    for (int kb = kbeg; kb < kbeg + kw; kb += 16) {
+      float4 a4 = valid ? *reinterpret_cast<const float4*>(arow + kb + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 b4 = *reinterpret_cast<const float4*>(brow + kb + 4 * q);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[wave][(q * 4 + e) * 16 + r] = acc[e];
+  __syncthreads();
+  const int row = tid >> 4, col = tid & 15, b = b0 + row, j = j0 + col;
+  if (b < B) {
+    float dh = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + d.dout[((long)t * B + b) * d.ldo + j];
+    const float* gt = d.gates + ((long)t * B + b) * K;
+    float ig = gt[j], fg = gt[u + j], gg = gt[2 * u + j], og = gt[3 * u + j];
+    float ct = d.c[((long)t * B + b) * u + j];
+    float cprev = (sp > 0) ? d.c[((long)tprev * B + b) * u + j] : 0.f;
+    float dcin = (sb > 0) ? d.dc[(long)b * u + j] : 0.f;
+    float tc = tanhf(ct);
+    float dov = dh * tc;
+    float dct = dh * og * (1.f - tc * tc) + dcin;
+    float* dz = d.dz + ((long)t * B + b) * K;
+    dz[j] = dct * gg * hs_grad_from_out(ig);
+    dz[u + j] = dct * cprev * hs_grad_from_out(fg);
+    dz[2 * u + j] = dct * ig * (1.f - gg * gg);
+    dz[3 * u + j] = dov * hs_grad_from_out(og);
+    d.dc[(long)b * u + j] = dct * fg;
+  }
+}
+
+static int check_units(int u) { return (u >= 64 && u % 64 == 0) ? 0 : CRNN_ERR_UNSUPPORTED; }
+
+// Forward recurrence of one Bidirectional(LSTM) layer (both directions).  Pointers per direction d in
+// {0: forward-in-time, 1: backward-in-time}: xw[d] [T][B][4u], ut[d] = U^T [4u][u], h[d] (row stride ldh),
+// c[d] [T][B][u], gates[d] [T][B][4u].  T launches on `stream`.
+extern "C" int crnn_lstm_fwd(const float* xw0, const float* xw1, const float* ut0, const float* ut1, float* h0, float* h1,
+                             int ldh, float* c0, float* c1, float* g0, float* g1, int T, int B, int u, hipStream_t stream) {
+  CRNN_TRY(check_units(u));
+  if (ldh % 4 != 0) return CRNN_ERR_ARG;
+  LstmDir a{xw0, ut0, h0, ldh, c0, g0, nullptr, 0, nullptr, nullptr};
+  LstmDir b{xw1, ut1, h1, ldh, c1, g1, nullptr, 0, nullptr, nullptr};
+  dim3 grid(u / 16, cdiv(B, 16), 2);
+  for (int s = 0; s < T; ++s) {
+    hipLaunchKernelGGL(lstm_fwd_step_kernel, grid, dim3(256), 0, stream, a, b, s, T, B, u);
+  }
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+
+// BPTT of one Bidirectional(LSTM) layer: fills dz[d] [T][B][4u] (gradients w.r.t. the gate pre-activations)
+// from dout[d] (gradient w.r.t. h, row stride ldo).  u_[d] = U [u][4u]; dc[d] = [B][u] scratch.
+extern "C" int crnn_lstm_bwd(const float* u0, const float* u1, const float* c0, const float* c1, const float* g0,
+                             const float* g1, const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1,
+                             float* dc0, float* dc1, int T, int B, int u, hipStream_t stream) {
+  CRNN_TRY(check_units(u));
+  LstmDir a{nullptr, u0, nullptr, 0, const_cast<float*>(c0), const_cast<float*>(g0), dout0, ldo, dz0, dc0};
+  LstmDir b{nullptr, u1, nullptr, 0, const_cast<float*>(c1), const_cast<float*>(g1), dout1, ldo, dz1, dc1};
+  dim3 grid(u / 16, cdiv(B, 16), 2);
+  for (int sb = 0; sb < T; ++sb) {
+    hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, dim3(256), 0, stream, a, b, sb, T, B, u);
+  }
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+
+// out[c][r] = in[r][c]  (U -> U^T once per weight update; tiny)
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
+  __shared__ float tile[32][33];
+  int c = blockIdx.x * 32 + threadIdx.x, r = blockIdx.y * 32 + threadIdx.y;
+  for (int k = 0; k < 32; k += 8) if (r + k < R && c < C) tile[threadIdx.y + k][threadIdx.x] = in[(long)(r + k) * C + c];
+  __syncthreads();
+  int oc = blockIdx.y * 32 + threadIdx.x, orow = blockIdx.x * 32 + threadIdx.y;
+  for (int k = 0; k < 32; k += 8) if (orow + k < C && oc < R) out[(long)(orow + k) * R + oc] = tile[threadIdx.x][threadIdx.y + k];
+}
+extern "C" int crnn_transpose(const float* in, float* out, int R, int C, hipStream_t stream) {
+  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(32, 8), 0, stream, in, out, R, C);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}

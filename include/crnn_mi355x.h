@@ -1,0 +1,149 @@
+/* libcrnn_mi355x.so -- C ABI of the MI355X-native (gfx950) CRNN-OCR hot path.
+ *
+ * The reference (gasparian/CRNN-OCR-lite) has no native code / FFI: its hot path is the Keras graph built
+ * by utils.py:58-96 and driven by Model.fit_generator (train.py:201) / predict_generator (predict.py:166),
+ * plus K.ctc_decode (utils.py:353).  This header is the seam a maintainer binds (ctypes) instead of the
+ * Keras/TensorFlow calls; each entry point names the reference code it replaces.
+ *
+ * Conventions: every function returns 0 on success, a positive hipError_t or a negative library code
+ * (-2 bad argument, -3 unsupported configuration).  No C++ exception crosses the ABI.  All tensor arguments
+ * are caller-owned DEVICE pointers (fp32 unless noted), NHWC / row-major contiguous unless a leading
+ * dimension is given.  Every launch is asynchronous on `stream`; nothing allocates or synchronises.
+ * One host thread per GPU process; no global mutable state.
+ */
+#ifndef CRNN_MI355X_H
+#define CRNN_MI355X_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* crnn_stream_t; /* hipStream_t (torch.cuda.current_stream().cuda_stream) */
+
+/* ---- model description: CRNN(num_classes, max_string_len, shape=(imgh,imgw,1), time_dense_size, GRU, n_units)
+ *      (utils.py:34-41) + per-process batch size ---- */
+typedef struct {
+  int batch;        /* images per step on this GPU */
+  int imgh, imgw;   /* 100 x 32: axis-1 = text width/time axis (utils.py:60) */
+  int num_classes;  /* len(lexicon)+1 = 38; blank = num_classes-1 */
+  int max_len;      /* max_string_len (labels row length) */
+  int tds;          /* time_dense_size */
+  int units;        /* n_units (multiple of 64) */
+  int gru;          /* 0 = LSTM (utils.py:78-79), 1 = GRU (utils.py:81-82) */
+  int stn;          /* 1 = spatial transformer enabled (utils.py:62) */
+  int dropout;      /* 1 = Dropout(.1/.4/.2) active in train mode (utils.py:56,75,83); 0 = off (parity runs) */
+} crnn_config;
+
+/* ---- parameter / statistics layout (Keras weight order) -------------------------------------- */
+int  crnn_num_params(const crnn_config* cfg);                 /* number of trainable tensors */
+long crnn_params_total(const crnn_config* cfg);               /* floats in the flat buffer (16-B padded tensors) */
+int  crnn_param_info(const crnn_config* cfg, int idx, char* name, int name_cap, long* offset, long* size,
+                     int* ndim, int* dims /* [4] */);
+int  crnn_bn_total(const crnn_config* cfg);                   /* channels over all 14 BatchNorm layers (3969) */
+int  crnn_bn_info(const crnn_config* cfg, int idx, char* name, int name_cap, int* offset, int* channels, long* count);
+int  crnn_time_steps(const crnn_config* cfg);                 /* T = (imgh+4)/2 (utils.py:72) */
+
+/* ---- workspace (activations kept for the backward pass + scratch) ------------------------------------------ */
+size_t crnn_workspace_bytes(const crnn_config* cfg);
+/* named view into the workspace (float offset, element count) -- for parity tests / debugging */
+int  crnn_ws_tensor(const crnn_config* cfg, const char* name, long* offset, long* count);
+
+/* ---- whole-path drivers ------------------------------------------------------------------------------------- */
+/* Forward of the predictor sub-model (utils.py:308-312; Model.predict_generator, predict.py:166):
+ * x [B,imgh,imgw,1] -> y_pred [B,T,num_classes] softmax.  train=1: batch statistics + dropout(seed)
+ * (learning_phase=1), activations kept in ws for crnn_backward; train=0: moving statistics, no dropout. */
+int crnn_forward(const crnn_config* cfg, const float* params, const float* bn_mean, const float* bn_var,
+                 const float* x, float* ws, size_t ws_bytes, float* y_pred, int train, uint64_t seed,
+                 crnn_stream_t stream);
+/* CTC loss (utils.py:98-103) + full backward of the graph after a train=1 crnn_forward on the same ws.
+ * labels [B,max_len] int32 (blank-padded), input_length/label_length [B] int32 (Readf batch contract,
+ * utils.py:485-500).  loss [B] = per-sample CTC cost (the model's 'ctc' output); grads (flat, same layout as
+ * params) = d mean(loss) / d params  (model.compile(loss={'ctc': y_pred}), train.py:192). */
+int crnn_backward(const crnn_config* cfg, const float* params, float* grads, const float* x, const int* labels,
+                  const int* input_length, const int* label_length, float* ws, size_t ws_bytes, float* loss,
+                  uint64_t seed, crnn_stream_t stream);
+/* BatchNorm moving-average update from the batch statistics left in ws by a train=1 forward (momentum .99) */
+int crnn_bn_update(const crnn_config* cfg, float* bn_mean, float* bn_var, float* ws, size_t ws_bytes,
+                   crnn_stream_t stream);
+
+/* ---- optimizers (keras.optimizers.Adam / SGD with clipnorm, train.py:187-190) ------------------------------ */
+/* norm_out[0] = global L2 norm of g, norm_out[1] = clip multiplier; scratch >= 4096 bytes */
+int crnn_global_norm(const float* g, long n, float clipnorm, void* scratch, float* norm_out, crnn_stream_t stream);
+int crnn_adam_step(float* p, const float* g, float* m, float* v, long n, float lr_t, float beta1, float beta2,
+                   float eps, const float* norm_out, crnn_stream_t stream);
+int crnn_sgd_step(float* p, const float* g, float* vel, long n, float lr, float momentum, int nesterov,
+                  const float* norm_out, crnn_stream_t stream);
+int crnn_scale(float* x, long n, float s, crnn_stream_t stream);
+
+/* ---- decoding (DecodeCTCPred.decode -> K.ctc_decode, utils.py:347-357) ------------------------------------- */
+/* y [B,T,C] softmax; out [B,T] int32 padded with -1; out_len [B]; input_len may be NULL (= T) */
+int crnn_ctc_greedy_decode(const float* y, const int* input_len, int* out, int* out_len, int B, int T, int C,
+                           crnn_stream_t stream);
+/* tf.nn.ctc_beam_search_decoder(beam_width <= 16, top_paths=1, merge_repeated); scores [B] = log-score of the
+ * best beam (sum of max-shifted log-probs, as TF r1.8 accumulates it).  State lives in LDS: no workspace. */
+int crnn_ctc_beam_decode(const float* y, const int* input_len, int* out, int* out_len, float* scores, int B, int T,
+                         int C, int beam_width, int merge_repeated, crnn_stream_t stream);
+
+/* ---- individual operators (unit-tested one by one; the drivers above chain them) --------------------------- */
+/* mode 0: C=A[M,K]*B[K,N]; 1: C=A[M,K]*Bt[N,K]^T; 2: C=At[K,M]^T*B[K,N].  bias[N]|NULL, act 0|1(relu),
+ * accumulate: C+=, permP: out_row=(m%P)*(M/P)+m/P (0=off), scratch: split-reduction partials (may be NULL) */
+int crnn_gemm_f32(int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                  const float* bias, int act, int accumulate, int permP, float* scratch, size_t scratch_bytes,
+                  crnn_stream_t stream);
+/* DepthwiseConv2D 3x3 'same' (utils.py:44): k [9][C]; flip=1 = data gradient; stat_partials [tiles][2][C] */
+int crnn_dwconv_num_tiles(int B, int H, int W);
+int crnn_dwconv3x3_fwd(const float* x, const float* k, float* out, float* stat_partials, int B, int H, int W, int C,
+                       int flip, crnn_stream_t stream);
+int crnn_dwconv3x3_wgrad(const float* x, const float* g, float* dk, float* scratch, int B, int H, int W, int C,
+                         crnn_stream_t stream);
+/* column reductions of a [M][C] matrix (sum / sum+sumsq) and their second stage */
+int crnn_colreduce_chunks(long M);
+int crnn_colreduce(const float* x, float* partials, long M, int C, int ld, int nv, crnn_stream_t stream);
+int crnn_partials_sum(const float* partials, int nparts, int n, float* out, float scale, crnn_stream_t stream);
+/* BatchNormalization(axis=-1, eps 1e-3) (utils.py:45,48): bnstate = [mean|var|scale|shift] */
+int crnn_bn_finalize(const float* partials, int nparts, int C, long n, const float* gamma, const float* beta,
+                     float* bnstate, crnn_stream_t stream);
+int crnn_bn_infer_state(const float* mmean, const float* mvar, const float* gamma, const float* beta, int C,
+                        float* bnstate, crnn_stream_t stream);
+int crnn_bn_act(const float* x, const float* bnstate, float* y, long M, int C, crnn_stream_t stream);
+/* y = Dropout(MaxPool(ReLU6(BN(x))))  (utils.py:45-56) */
+int crnn_bn_act_pool_drop(const float* x, const float* bnstate, float* y, int B, int H, int W, int C, int ph, int pw,
+                          float rate, uint64_t seed, uint32_t layer, crnn_stream_t stream);
+int crnn_bn_bwd_chunks(long M);
+int crnn_bn_bwd(const float* x, const float* g, const float* bnstate, const float* gamma, float* dx, float* dgamma,
+                float* dbeta, float* scratch_partials, float* coef, int B, int H, int W, int C, int ph, int pw,
+                float rate, uint64_t seed, uint32_t layer, crnn_stream_t stream);
+int crnn_add(const float* a, const float* b, float* o, long n, crnn_stream_t stream);
+int crnn_dropout(const float* x, float* y, long rows, int C, int ldx, int ldy, float rate, uint64_t seed,
+                 uint32_t layer, crnn_stream_t stream);
+int crnn_dropout_mask(float* m, long n, float rate, uint64_t seed, uint32_t layer, crnn_stream_t stream);
+int crnn_relu_bwd(const float* y, const float* g, float* go, long rows, int C, float scale, int permP,
+                  crnn_stream_t stream);
+/* spatial transformer pieces (utils.py:116-258) */
+int crnn_maxpool_fwd(const float* x, float* y, int B, int H, int W, int C, int ph, int pw, crnn_stream_t stream);
+int crnn_maxpool_bwd(const float* x, const float* gy, float* gx, int B, int H, int W, int C, int ph, int pw,
+                     crnn_stream_t stream);
+int crnn_im2col(const float* x, float* col, int B, int H, int W, int C, int K, crnn_stream_t stream);
+int crnn_col2im(const float* dcol, float* dx, int B, int H, int W, int C, int K, crnn_stream_t stream);
+int crnn_sampler_fwd(const float* img, const float* theta, float* out, int B, int H, int W, int pad,
+                     crnn_stream_t stream);
+int crnn_sampler_bwd(const float* img, const float* theta, const float* gout, float* dtheta, int B, int H, int W,
+                     int pad, crnn_stream_t stream);
+int crnn_pad_copy(const float* img, float* out, int B, int H, int W, int pad, crnn_stream_t stream);
+/* Bidirectional LSTM recurrence (utils.py:78-79), time-major */
+int crnn_lstm_fwd(const float* xw0, const float* xw1, const float* ut0, const float* ut1, float* h0, float* h1, int ldh,
+                  float* c0, float* c1, float* g0, float* g1, int T, int B, int u, crnn_stream_t stream);
+int crnn_lstm_bwd(const float* u0, const float* u1, const float* c0, const float* c1, const float* g0, const float* g1,
+                  const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1, float* dc0, float* dc1, int T,
+                  int B, int u, crnn_stream_t stream);
+int crnn_transpose(const float* in, float* out, int R, int C, crnn_stream_t stream);
+/* softmax + CTC (utils.py:86, 98-103) */
+int crnn_softmax_rows(const float* z, float* p, long rows, int C, crnn_stream_t stream);
+int crnn_ctc_loss_grad(const float* y, const int* labels, const int* input_len, const int* label_len, float* loss,
+                       float* dlogits, int B, int T, int C, int Lmax, int skip, float grad_scale, crnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

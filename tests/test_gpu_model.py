@@ -1,0 +1,167 @@
+"""-m gpu parity of the whole hot path (forward, CTC, backward, optimizer, BN statistics, decode)
+through the C ABI against the CPU oracle on the same seeded inputs.
+
+Tolerances (north_star): fp32 logits within 1e-3, CTC loss within 1e-3, greedy indices bit-exact;
+gradients within 1e-3 of each tensor's max magnitude."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops, ctc, model as M
+from crnn_mi355x.engine import Engine
+
+pytestmark = pytest.mark.gpu
+
+
+def masks_from_engine(eng, cfg, seed):
+    """Fetch the dropout multipliers the device RNG applies and convert them to the oracle's keep-masks."""
+    from gpu_util import L, P, S, ok, zeros, host
+    B, T = eng.B, eng.T
+    masks = {}
+    h, w = cfg.Hp, cfg.Wp
+    for i, (cout, pool) in enumerate(M.BLOCKS, 1):
+        if pool:
+            h, w = h // pool[0], w // pool[1]
+        m = zeros(B * h * w * cout)
+        ok(L().crnn_dropout_mask(P(m), m.numel(), M.DROP_BLOCK, seed, i, S()))
+        masks[f"b{i}"] = (host(m).reshape(B, h, w, cout) > 0).astype(np.float64)
+    m = zeros(T * B * cfg.tds)
+    ok(L().crnn_dropout_mask(P(m), m.numel(), M.DROP_DENSE1, seed, 8, S()))
+    masks["dense1"] = (host(m).reshape(T, B, cfg.tds).transpose(1, 0, 2) > 0).astype(np.float64)
+    m = zeros(T * B * 2 * cfg.u)
+    ok(L().crnn_dropout_mask(P(m), m.numel(), M.DROP_RNN, seed, 9, S()))
+    masks["rnn"] = (host(m).reshape(T, B, 2 * cfg.u).transpose(1, 0, 2) > 0).astype(np.float64)
+    return masks
+
+
+def layer_report(eng, cfg, c, B):
+    """max |device - oracle| for every saved intermediate (name -> (err, scale))."""
+    T = eng.T
+    rep = {}
+
+    def cmp(name, ref, tm=False):
+        t = eng.ws_tensor(name).cpu().numpy().astype(np.float64)
+        ref = np.asarray(ref, dtype=np.float64)
+        if tm:
+            ref = np.swapaxes(ref, 0, 1)
+        t = t[:ref.size].reshape(ref.shape)
+        rep[name] = (float(np.abs(t - ref).max()), float(np.abs(ref).max()))
+
+    if eng.cfg.stn:
+        for n in ("pool1", "c1", "pool2", "flat", "fc1", "theta"):
+            cmp(n, c[n].reshape(B, -1))
+    cmp("x0", ops.zeropad_fwd(c["xs"], 2))
+    for i in range(1, 8):
+        cmp(f"d{i}", c[f"d{i}"]); cmp(f"a{i}", c[f"a{i}"]); cmp(f"q{i}", c[f"q{i}"])
+    cmp("x7", c["conv_out"])
+    cmp("dn1", c["rnn_in"], tm=True)
+    cmp("h1f", c["rnn1f"][3], tm=True); cmp("h1b", c["rnn1b"][3], tm=True)
+    cmp("h2", c["rnn_out"], tm=True)
+    cmp("logits", c["logits"]); cmp("ypred", c["y_pred"])
+    return rep
+
+
+def run_case(B, imgh, imgw, u, tds, max_len, stn, dropout, seed=3, num_classes=38):
+    cfg = M.Config(imgh=imgh, imgw=imgw, num_classes=num_classes, max_len=max_len, time_dense_size=tds, n_units=u)
+    p, bn = M.init_params(cfg, seed=7, dtype=np.float64)
+    p = M.randomize_params(cfg, p)
+    x, lab, il, ll = M.synthetic_batch(cfg, B, seed=1, dtype=np.float64)
+    eng = Engine(B, imgh, imgw, num_classes, max_len, tds, u, gru=False, stn=stn, dropout=dropout)
+    eng.set_params(p, bn)
+    masks = masks_from_engine(eng, cfg, seed) if dropout else None
+    # ---- device
+    yd = eng.forward(x.astype(np.float32), train=True, seed=seed).cpu().numpy()
+    loss_d = eng.backward(lab, il, ll, seed=seed).cpu().numpy()
+    gd = eng.get_grads()
+    # ---- oracle
+    loss, loss_b, g, c = M.loss_and_grads(cfg, p, bn, x, lab, il, ll, masks=masks, stn=stn)
+    rep = layer_report(eng, cfg, c, B)
+    return cfg, eng, p, bn, (x, lab, il, ll), yd, loss_d, gd, c, loss_b, g, rep
+
+
+def check_case(res, tag):
+    cfg, eng, p, bn, batch, yd, loss_d, gd, c, loss_b, g, rep = res
+    bad = {k: v for k, v in rep.items() if v[0] > 1e-3 * max(1.0, v[1])}
+    assert not bad, f"{tag}: intermediates off: {bad}"
+    assert np.abs(c["logits"] - eng.ws_tensor("logits").cpu().numpy().reshape(c["logits"].shape)).max() < 1e-3
+    assert np.abs(yd - c["y_pred"]).max() < 1e-4
+    assert np.abs(loss_d - loss_b).max() < 1e-3, (loss_d, loss_b)
+    worst = {}
+    for k in p:
+        scale = max(np.abs(g[k]).max(), 1e-6)
+        err = np.abs(gd[k] - g[k]).max()
+        if err > 1e-3 * scale + 1e-7:
+            worst[k] = (err, scale)
+    assert not worst, f"{tag}: gradient mismatch {worst}"
+
+
+def test_small_model_no_dropout():
+    check_case(run_case(B=5, imgh=40, imgw=32, u=64, tds=32, max_len=6, stn=True, dropout=False), "small")
+
+
+def test_small_model_with_device_dropout_masks():
+    check_case(run_case(B=4, imgh=40, imgw=32, u=64, tds=32, max_len=6, stn=True, dropout=True), "small+dropout")
+
+
+def test_small_model_stn_disabled():
+    check_case(run_case(B=3, imgh=40, imgw=32, u=64, tds=32, max_len=6, stn=False, dropout=False), "nostn")
+
+
+def test_config1_shape_full_model_step_and_decode():
+    """BASELINE config 1 shape (100x32, max_len 23, tds 128, n_units 256) at a small batch: forward, loss, grads,
+    one Adam(1e-4, beta1 .5, clipnorm 5) step, BN moving statistics, inference forward and decoders."""
+    res = run_case(B=6, imgh=100, imgw=32, u=256, tds=128, max_len=23, stn=True, dropout=False)
+    check_case(res, "config1")
+    cfg, eng, p, bn, (x, lab, il, ll), yd, loss_d, gd, c, loss_b, g, rep = res
+    # optimizer + BN update
+    eng.adam_step(1e-4, 0.5, 0.999, 1e-7, 5.0, iteration=0)
+    eng.bn_update()
+    opt = M.Adam(lr=1e-4, beta_1=0.5, beta_2=0.999, epsilon=1e-7, clipnorm=5.0)
+    p_ref = opt.step({k: v.copy() for k, v in p.items()}, g)
+    pd = eng.get_params()
+    for k in p:
+        assert np.abs(pd[k] - p_ref[k]).max() < 2e-6 + 1e-5 * np.abs(p_ref[k]).max(), k
+    bn_ref = M.bn_update(cfg, {k: v.copy() for k, v in bn.items()}, c)
+    bnd = eng.get_bn()
+    for k in bn_ref:
+        assert np.abs(bnd[k] - bn_ref[k]).max() < 1e-4 * max(1.0, np.abs(bn_ref[k]).max()), k
+    # inference-mode forward with the updated weights/statistics; greedy indices bit-exact; beam vs oracle
+    y_inf = eng.forward(x.astype(np.float32), train=False).cpu().numpy()
+    y_ref, _ = M.forward(cfg, p_ref, bn_ref, x, train=False)
+    assert np.abs(y_inf - y_ref).max() < 1e-4
+    out, ln = eng.greedy_decode()
+    ref, rl = ctc.ctc_greedy_decode(y_ref)
+    assert np.array_equal(out.cpu().numpy(), ref) and np.array_equal(ln.cpu().numpy(), rl)
+    assert np.array_equal(np.argmax(y_inf, -1), np.argmax(y_ref, -1))
+    bo, bl, bs = eng.beam_decode(beam_width=10)
+    ro, rl2, rs_ = ctc.ctc_beam_decode(y_inf, beam_width=10)
+    assert np.array_equal(bo.cpu().numpy(), ro) and np.array_equal(bl.cpu().numpy(), rl2)
+
+
+def test_iam_shape_forward_loss():
+    """BASELINE config 3 shape: height 32, width 200 (T=102, CTC 100 steps), max_len 21, STN on."""
+    res = run_case(B=3, imgh=200, imgw=32, u=128, tds=64, max_len=21, stn=True, dropout=False)
+    check_case(res, "iam")
+
+
+def test_train_steps_are_deterministic_and_loss_decreases():
+    cfg = M.Config()
+    B = 16
+    p, bn = M.init_params(cfg, seed=1, dtype=np.float32)
+    x, lab, il, ll = M.synthetic_batch(cfg, B, seed=0)
+    from crnn_mi355x.optimizers import Adam
+    losses = []
+    for rep in range(2):
+        eng = Engine(B, dropout=True)
+        eng.set_params(p, bn)
+        opt = Adam(lr=1e-3, beta_1=0.5, beta_2=0.999, clipnorm=5)
+        ls = []
+        for it in range(12):
+            ls.append(float(eng.train_step(x, lab, il, ll, opt, it).mean().item()))
+        losses.append(ls)
+        final = eng.params.clone()
+        if rep == 0:
+            first = final
+    assert losses[0] == losses[1], "train step is not run-to-run deterministic"
+    assert torch.equal(first, final)
+    assert np.isfinite(losses[0]).all() and losses[0][-1] < losses[0][0]
