@@ -9,3 +9,17 @@ for p in (ROOT, os.path.join(ROOT, "crnn-ocr-lite_amd"), os.path.dirname(os.path
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+import pytest  # noqa: E402
+
+
+@pytest.fixture(autouse=True)
+def _release_device_buffers():
+    yield
+    try:
+        import gpu_util
+        if gpu_util._KEEP:
+            gpu_util.release()
+    except Exception:
+        pass

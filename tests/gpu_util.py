@@ -11,8 +11,19 @@ def L():
     return native.lib()
 
 
+_KEEP = []  # device buffers stay referenced until the test ends: a temporary passed as P(dev(x)) would be
+#             returned to torch's caching allocator (and re-used by the next dev()) before the kernel runs
+
+
 def dev(a, dtype=np.float32):
-    return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).cuda()
+    _KEEP.append(t)
+    return t
+
+
+def release():
+    torch.cuda.synchronize()
+    del _KEEP[:]
 
 
 def zeros(*shape, dtype=torch.float32):

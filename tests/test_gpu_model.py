@@ -61,6 +61,58 @@ def layer_report(eng, cfg, c, B):
     return rep
 
 
+def device_cache(eng, cfg, p, x, B, c_ref):
+    """Oracle cache rebuilt from the DEVICE's forward state (fp32 -> fp64).
+
+    ReLU6 / ReLU / hard-sigmoid gates and max-pool arg-maxima are discontinuous: with ~1e7 activations per
+    step a handful sit within fp32 round-off of a threshold, and each such flip moves a per-channel gradient
+    sum by a few percent.  The forward pass is checked layer by layer against the pure oracle
+    (`layer_report`); the backward pass is checked against the oracle's backward evaluated on the device's own
+    forward state, so both sides take identical gate decisions."""
+    T = eng.T
+    f64 = lambda name: eng.ws_tensor(name).cpu().numpy().astype(np.float64)
+    c = {"x": x, "stats": {}}
+    if eng.cfg.stn:
+        for n in ("pool1", "c1", "pool2", "flat", "fc1", "theta"):
+            c[n] = f64(n).reshape(c_ref[n].shape)
+        c["c2"] = c["flat"].reshape(c_ref["c2"].shape)
+    h, w, cin = cfg.Hp, cfg.Wp, 1
+    prev = f64("x0").reshape(B, h, w, 1)
+    c["xs"] = prev[:, 2:-2, 2:-2, :]
+    for i, (cout, pool) in enumerate(M.BLOCKS, 1):
+        c[f"in{i}"] = prev
+        c[f"d{i}"] = f64(f"d{i}").reshape(B, h, w, cin)
+        c[f"a{i}"] = f64(f"a{i}").reshape(B, h, w, cin)
+        c[f"q{i}"] = f64(f"q{i}").reshape(B, h, w, cout)
+        s1, s2 = f64(f"bn1s{i}"), f64(f"bn2s{i}")
+        n = B * h * w
+        c["stats"][f"b{i}_bn1"] = (s1[:cin], s1[cin:2 * cin], n)
+        c["stats"][f"b{i}_bn2"] = (s2[:cout], s2[cout:2 * cout], n)
+        # r = relu6(fma(q, scale, shift)): exact product + one rounding, as the device's fmaf computes it
+        y = (c[f"q{i}"] * s2[2 * cout:3 * cout] + s2[3 * cout:4 * cout]).astype(np.float32).astype(np.float64)
+        c[f"r{i}"] = np.minimum(np.maximum(y, 0), 6)
+        if pool:
+            h, w = h // pool[0], w // pool[1]
+        prev = f64(f"x{i}").reshape(B, h, w, cout)
+        cin = cout
+    c["conv_out"] = prev
+    c["feat"] = prev.reshape(B, cfg.T, cfg.feat)
+    tm = lambda a, k: np.ascontiguousarray(a.reshape(T, B, k).transpose(1, 0, 2))
+    c["dense1"] = tm(f64("dn1"), cfg.tds)
+    c["rnn_in"] = c["dense1"]
+    u, G = cfg.u, 4 * cfg.u
+    h2 = tm(f64("h2"), 2 * u)
+    r1 = tm(f64("r1"), u)
+    for name, xin, H in (("rnn1f", c["rnn_in"], tm(f64("h1f"), u)), ("rnn1b", c["rnn_in"], tm(f64("h1b"), u)),
+                         ("rnn2f", r1, h2[..., :u]), ("rnn2b", r1, h2[..., u:])):
+        l, d = name[3], name[4]
+        c[name] = (xin, p[name + "_w"], p[name + "_u"], H, tm(f64(f"cs{l}{d}"), u), tm(f64(f"gt{l}{d}"), G), d == "b")
+    c["rnn_out"] = h2
+    c["dense2_in"] = tm(f64("r2d"), 2 * u)
+    c["y_pred"] = f64("ypred").reshape(B, T, cfg.num_classes)
+    return c
+
+
 def run_case(B, imgh, imgw, u, tds, max_len, stn, dropout, seed=3, num_classes=38):
     cfg = M.Config(imgh=imgh, imgw=imgw, num_classes=num_classes, max_len=max_len, time_dense_size=tds, n_units=u)
     p, bn = M.init_params(cfg, seed=7, dtype=np.float64)
@@ -73,26 +125,42 @@ def run_case(B, imgh, imgw, u, tds, max_len, stn, dropout, seed=3, num_classes=3
     yd = eng.forward(x.astype(np.float32), train=True, seed=seed).cpu().numpy()
     loss_d = eng.backward(lab, il, ll, seed=seed).cpu().numpy()
     gd = eng.get_grads()
-    # ---- oracle
+    # ---- pure oracle (fp64): forward parity, loss parity, and a flip-tolerant look at the gradients
     loss, loss_b, g, c = M.loss_and_grads(cfg, p, bn, x, lab, il, ll, masks=masks, stn=stn)
     rep = layer_report(eng, cfg, c, B)
-    return cfg, eng, p, bn, (x, lab, il, ll), yd, loss_d, gd, c, loss_b, g, rep
+    # ---- oracle backward on the device's forward state: exact gradient parity
+    cdev = device_cache(eng, cfg, p, x, B, c)
+    _, gy = ctc.ctc_loss_and_grad(cdev["y_pred"], lab, il, ll)
+    if masks is not None:   # dense1 holds the dropped activation on the device: its mask is already applied
+        masks_dev = dict(masks)
+    else:
+        masks_dev = None
+    gdev = M.backward(cfg, p, cdev, gy / B, masks=masks_dev, stn=stn)
+    return cfg, eng, p, bn, (x, lab, il, ll), yd, loss_d, gd, c, loss_b, g, rep, gdev
 
 
 def check_case(res, tag):
-    cfg, eng, p, bn, batch, yd, loss_d, gd, c, loss_b, g, rep = res
+    cfg, eng, p, bn, batch, yd, loss_d, gd, c, loss_b, g, rep, gdev = res
     bad = {k: v for k, v in rep.items() if v[0] > 1e-3 * max(1.0, v[1])}
     assert not bad, f"{tag}: intermediates off: {bad}"
     assert np.abs(c["logits"] - eng.ws_tensor("logits").cpu().numpy().reshape(c["logits"].shape)).max() < 1e-3
     assert np.abs(yd - c["y_pred"]).max() < 1e-4
-    assert np.abs(loss_d - loss_b).max() < 1e-3, (loss_d, loss_b)
+    assert np.all(np.abs(loss_d - loss_b) < 1e-3 + 1e-5 * np.abs(loss_b)), (loss_d, loss_b)
     worst = {}
     for k in p:
-        scale = max(np.abs(g[k]).max(), 1e-6)
-        err = np.abs(gd[k] - g[k]).max()
+        scale = max(np.abs(gdev[k]).max(), 1e-6)
+        err = np.abs(gd[k] - gdev[k]).max()
         if err > 1e-3 * scale + 1e-7:
-            worst[k] = (err, scale)
-    assert not worst, f"{tag}: gradient mismatch {worst}"
+            worst[k] = (err / scale)
+    assert not worst, f"{tag}: gradient mismatch vs oracle-on-device-state {worst}"
+    # pure fp64 oracle: identical up to a handful of threshold flips => the typical (median) entry agrees
+    loose = {}
+    for k in p:
+        scale = max(np.abs(g[k]).max(), 1e-6)
+        med = np.median(np.abs(gd[k] - g[k])) / scale
+        if med > 2e-3:
+            loose[k] = med
+    assert not loose, f"{tag}: gradients far from the pure oracle {loose}"
 
 
 def test_small_model_no_dropout():
@@ -112,12 +180,12 @@ def test_config1_shape_full_model_step_and_decode():
     one Adam(1e-4, beta1 .5, clipnorm 5) step, BN moving statistics, inference forward and decoders."""
     res = run_case(B=6, imgh=100, imgw=32, u=256, tds=128, max_len=23, stn=True, dropout=False)
     check_case(res, "config1")
-    cfg, eng, p, bn, (x, lab, il, ll), yd, loss_d, gd, c, loss_b, g, rep = res
+    cfg, eng, p, bn, (x, lab, il, ll), yd, loss_d, gd, c, loss_b, g, rep, gdev = res
     # optimizer + BN update
     eng.adam_step(1e-4, 0.5, 0.999, 1e-7, 5.0, iteration=0)
     eng.bn_update()
     opt = M.Adam(lr=1e-4, beta_1=0.5, beta_2=0.999, epsilon=1e-7, clipnorm=5.0)
-    p_ref = opt.step({k: v.copy() for k, v in p.items()}, g)
+    p_ref = opt.step({k: v.copy() for k, v in p.items()}, gdev)
     pd = eng.get_params()
     for k in p:
         assert np.abs(pd[k] - p_ref[k]).max() < 2e-6 + 1e-5 * np.abs(p_ref[k]).max(), k
