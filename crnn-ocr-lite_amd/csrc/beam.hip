@@ -1,14 +1,17 @@
-// CTC beam-search decoding, one 64-lane wavefront per sample, everything resident in LDS.
+// CTC beam-search decoding, one 64-lane wavefront per sample; beam state lives in registers (lane i = beam
+// entry i = TopN slot i), classes map to lanes for the expansion, the prefix-node table sits in LDS.
+//
 // Restates tf.nn.ctc_beam_search_decoder (TF r1.8 ctc_beam_search.h; reached by the reference through
-// K.ctc_decode(greedy=False, beam_width, top_paths=1), utils.py:353): prefix trie with (blank,label,total)
-// log-probabilities per node, parent contribution only while the parent is still in the beam, children of a
-// beam entry offered unless already in the beam, top-`beam_width` kept, merge_repeated applied to the final
-// label sequence.  Flat-beam formulation that is exactly equivalent to the trie walk (ties aside):
-//   * node identity = (parent node, label), kept in an LDS node table so a prefix that drops out of the beam
-//     and re-enters later reuses its node (its descendants see it as their parent again);
-//   * the sequential "push, evict the bottom" of the TopN container == top-N selection over
-//     {re-scored beam entries} U {offered children}, earlier insertion winning ties.
-// Lanes = classes for the expansion (C <= 64), lanes = beam slots for the per-entry update.
+// K.ctc_decode(greedy=False, beam_width, top_paths=1), utils.py:353) EXACTLY, including the order-dependent side
+// effects of its sequential "grow new leaves" loop:
+//   * entries are visited in descending previous-score order, their children in label order;
+//   * a child is offered only if it is not currently in the beam; an accepted child evicts the current bottom;
+//   * an entry that has been evicted earlier in the same step and is then re-offered by its parent fails the
+//     candidate test and gets its old probabilities reset -- so it no longer expands when its own turn comes.
+// A prefix trie is replaced by node identity = (parent node, label) in an LDS table, so a prefix that drops out
+// and re-enters later is the same node again (its descendants regain their parent term).  The per-entry loop over
+// the 37 children only iterates over "events" (labels that can enter the beam, or that name an existing entry),
+// found with one wave ballot; every decision inside it is wave-uniform.
 #include "common.h"
 
 #define BEAM_MAX 16
@@ -22,152 +25,162 @@ __device__ __forceinline__ float blse(float a, float b) {
   return m + log1pf(expf(n - m));
 }
 
-struct BeamSet {  // one beam (<= BEAM_MAX entries) in LDS
-  int node[BEAM_MAX], par[BEAM_MAX], lab[BEAM_MAX];
-  float ob[BEAM_MAX], ol[BEAM_MAX], ot[BEAM_MAX], nb[BEAM_MAX], nl[BEAM_MAX], nt[BEAM_MAX];
-};
+// (min value, its lane) over lanes < cnt; ties -> lowest lane.  Result is wave-uniform.
+__device__ __forceinline__ void wave_argmin(float v, int lane, int cnt, float& mv, int& ml) {
+  mv = (lane < cnt) ? v : INFINITY; ml = lane;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(mv, o, 64); int ol = __shfl_xor(ml, o, 64);
+    if (ov < mv || (ov == mv && ol < ml)) { mv = ov; ml = ol; }
+  }
+}
 
 __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ y, const int* __restrict__ input_len,
                                                       int* __restrict__ out, int* __restrict__ out_len,
                                                       float* __restrict__ scores, int T, int C, int bw, int merge_repeated,
                                                       int nmax) {
   extern __shared__ int smem_i[];
-  int* nodes = smem_i;                                        // [nmax] ((parent+1)<<8)|(label+1)
-  float* cand = reinterpret_cast<float*>(nodes + nmax);       // [(BEAM_MAX+1)][64]
-  float* inp = cand + (BEAM_MAX + 1) * 64;                    // [64]
-  int* pick_row = reinterpret_cast<int*>(inp + 64);           // [BEAM_MAX]
-  int* pick_lane = pick_row + BEAM_MAX;
-  float* pick_val = reinterpret_cast<float*>(pick_lane + BEAM_MAX);
-  BeamSet* sets = reinterpret_cast<BeamSet*>(pick_val + BEAM_MAX);  // [2]
+  int* nodes = smem_i;                                   // [nmax] ((parent+1)<<8)|(label+1); node 0 = root
+  int* s_ref = nodes + nmax;                             // [BEAM_MAX] sorted leaves: branch index or -1
+  int* s_par = s_ref + BEAM_MAX;                         // parent branch index of a new child
+  int* s_lab = s_par + BEAM_MAX;
+  float* s_val = reinterpret_cast<float*>(s_lab + BEAM_MAX);
   const int b = blockIdx.x, lane = threadIdx.x, blank = C - 1;
   int Tb = input_len ? input_len[b] : T; if (Tb > T) Tb = T; if (Tb < 0) Tb = 0;
 
-  BeamSet* cur = &sets[0]; BeamSet* nxt = &sets[1];
+  // beam entry `lane` (valid for lane < n)
+  int b_node = 0, b_par = -1, b_lab = -1, b_act = 0;
+  float b_ob = BNEG, b_ol = BNEG, b_ot = BNEG, b_nb = 0.f, b_nl = BNEG, b_nt = 0.f;
+  // TopN slot `lane` (valid for lane < nle)
+  float l_v = BNEG; int l_ref = -1, l_par = -1, l_lab = -1;
   int n = 1, nnodes = 1;
-  if (lane == 0) {
-    nodes[0] = 0;  // root: parent -1, label -1
-    cur->node[0] = 0; cur->par[0] = -1; cur->lab[0] = -1;
-    cur->ob[0] = cur->ol[0] = cur->ot[0] = BNEG;
-    cur->nb[0] = 0.f; cur->nl[0] = BNEG; cur->nt[0] = 0.f;
-  }
+  if (lane == 0) nodes[0] = 0;
   __syncthreads();
 
   for (int t = 0; t < Tb; ++t) {
     float lg = (lane < C) ? logf(y[((long)b * T + t) * C + lane] + BEAM_EPS) : BNEG;
-    float mx = wave_max(lg);
-    inp[lane] = lg - mx;
-    // ---- oldp <- newp for every beam entry
-    if (lane < n) { cur->ob[lane] = cur->nb[lane]; cur->ol[lane] = cur->nl[lane]; cur->ot[lane] = cur->nt[lane]; }
-    __syncthreads();
-    // ---- re-score the entries that stay (TF: second loop of Step)
-    if (lane < n) {
-      int nd = cur->node[lane], par = cur->par[lane], lab = cur->lab[lane];
-      float nlv = BNEG;
-      if (nd != 0) {
-        nlv = cur->ol[lane];
-        for (int j = 0; j < n; ++j)
-          if (cur->node[j] == par) {  // parent still in the beam (Active)
-            int plab = (nodes[par] & 255) - 1;
-            nlv = blse(nlv, (lab == plab) ? cur->ob[j] : cur->ot[j]);
+    const float inp = lg - wave_max(lg);                 // lane = class
+    const float inp_blank = __shfl(inp, blank, 64);
+    // ---- oldp <- newp; re-score the entries (parent term only while the parent is in the beam)
+    b_ob = b_nb; b_ol = b_nl; b_ot = b_nt;
+    {
+      float prev = BNEG; bool found = false;
+      for (int j = 0; j < n; ++j) {
+        int nj = __shfl(b_node, j, 64), lj = __shfl(b_lab, j, 64);
+        float obj = __shfl(b_ob, j, 64), otj = __shfl(b_ot, j, 64);
+        if (lane < n && b_node != 0 && nj == b_par) { found = true; prev = (b_lab == lj) ? obj : otj; }
+      }
+      float in_lab = __shfl(inp, b_lab & 63, 64);
+      if (lane < n) {
+        float nl = BNEG;
+        if (b_node != 0) {
+          nl = found ? blse(b_ol, prev) : b_ol;
+          nl = (nl == BNEG) ? BNEG : nl + in_lab;
+        }
+        b_nb = b_ot + inp_blank; b_nl = nl; b_nt = blse(b_nb, nl);
+      }
+    }
+    // ---- TopN <- all entries
+    int nle = n;
+    l_v = b_nt; l_ref = lane; l_par = -1; l_lab = -1; b_act = (lane < n) ? 1 : 0;
+    float bval; int bslot;
+    wave_argmin(l_v, lane, nle, bval, bslot);
+    // ---- grow new leaves, entry by entry
+    for (int bi = 0; bi < n; ++bi) {
+      const float bot = __shfl(b_ot, bi, 64), bob = __shfl(b_ob, bi, 64);
+      const int blab = __shfl(b_lab, bi, 64), bnode = __shfl(b_node, bi, 64);
+      if (!(bot > BNEG && (nle < bw || bot > bval))) continue;
+      const float prev = (lane == blab) ? bob : bot;
+      const float v = (lane < blank && prev > BNEG) ? inp + prev : BNEG;     // lane = child label
+      int cb = -1;
+      for (int j = 0; j < n; ++j) {
+        int pj = __shfl(b_par, j, 64), lj = __shfl(b_lab, j, 64);
+        if (pj == bnode && lj == lane) cb = j;                                  // this child is beam entry j
+      }
+      const bool ev = (lane < blank) && (cb >= 0 || (v > BNEG && (nle < bw || v > bval)));
+      unsigned long long mask = __ballot(ev);
+      while (mask) {
+        const int c = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        const float vc = __shfl(v, c, 64);
+        const int ccb = __shfl(cb, c, 64);
+        if (ccb >= 0 && __shfl(b_act, ccb, 64)) continue;                       // child already in the beam
+        if (vc > BNEG && (nle < bw || vc > bval)) {
+          int slot;
+          if (nle == bw) {                                                      // evict the bottom
+            slot = bslot;
+            int k = __shfl(l_ref, bslot, 64);
+            if (k >= 0 && lane == k) b_act = 0;
+          } else {
+            slot = nle++;
           }
-        nlv = (nlv == BNEG) ? BNEG : nlv + inp[lab];
-      }
-      float nbv = cur->ot[lane] + inp[blank];
-      cur->nb[lane] = nbv; cur->nl[lane] = nlv; cur->nt[lane] = blse(nbv, nlv);
-    }
-    __syncthreads();
-    // ---- offer children: row i+1 = children of entry i, column = label; row 0 = the entries themselves
-    cand[lane] = (lane < n) ? cur->nt[lane] : BNEG;
-    for (int i = 0; i < n; ++i) {
-      float v = BNEG;
-      if (lane < blank) {
-        bool active = false;
-        int nd = cur->node[i];
-        for (int j = 0; j < n; ++j) active |= (cur->par[j] == nd && cur->lab[j] == lane);
-        if (!active) {
-          float prev = (lane == cur->lab[i]) ? cur->ob[i] : cur->ot[i];
-          v = (prev == BNEG) ? BNEG : inp[lane] + prev;
+          if (lane == slot) { l_v = vc; l_ref = -1; l_par = bi; l_lab = c; }
+          wave_argmin(l_v, lane, nle, bval, bslot);
+        } else if (ccb >= 0 && lane == ccb) {                                   // re-offered, rejected: reset oldp
+          b_ob = b_ol = b_ot = BNEG;
         }
       }
-      cand[(i + 1) * 64 + lane] = v;
+    }
+    // ---- new beam = TopN sorted by descending score (ties: lower slot first)
+    int rank = 0;
+    for (int j = 0; j < nle; ++j) {
+      float vj = __shfl(l_v, j, 64);
+      if (vj > l_v || (vj == l_v && j < lane)) ++rank;
     }
     __syncthreads();
-    // ---- keep the top bw (value desc; ties: smaller row, then smaller lane = earlier insertion)
-    int newn = 0;
-    for (int r = 0; r < bw; ++r) {
-      float best = BNEG; int brow = 0;
-      for (int row = 0; row <= n; ++row) { float v = cand[row * 64 + lane]; if (v > best) { best = v; brow = row; } }
-      int key = brow * 64 + lane;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        float ov = __shfl_xor(best, o, 64); int ok = __shfl_xor(key, o, 64);
-        if (ov > best || (ov == best && ok < key)) { best = ov; key = ok; }
+    if (lane < nle) { s_ref[rank] = l_ref; s_par[rank] = l_par; s_lab[rank] = l_lab; s_val[rank] = l_v; }
+    __syncthreads();
+    int r_ref = -1, r_par = 0, r_lab = 0; float r_val = BNEG;
+    if (lane < nle) { r_ref = s_ref[lane]; r_par = s_par[lane]; r_lab = s_lab[lane]; r_val = s_val[lane]; }
+    // surviving entries: copy from their old lane; new children: parent node from the parent's lane
+    const int src = (r_ref >= 0) ? r_ref : (r_par & 63);
+    int g_node = __shfl(b_node, src, 64), g_par = __shfl(b_par, src, 64), g_lab = __shfl(b_lab, src, 64);
+    float g_nb = __shfl(b_nb, src, 64), g_nl = __shfl(b_nl, src, 64), g_nt = __shfl(b_nt, src, 64);
+    int new_node = g_node, new_par = g_par, new_lab = g_lab;
+    float new_nb = g_nb, new_nl = g_nl, new_nt = g_nt;
+    const bool is_new = (lane < nle) && (r_ref < 0);
+    if (is_new) { new_par = g_node; new_lab = r_lab; new_nb = BNEG; new_nl = r_val; new_nt = r_val; new_node = -1; }
+    // resolve node ids of the new children one at a time (re-entering prefix -> reuse its node)
+    unsigned long long nm = __ballot(is_new);
+    while (nm) {
+      const int r = __ffsll((long long)nm) - 1;
+      nm &= nm - 1;
+      const int packed = ((__shfl(new_par, r, 64) + 1) << 8) | (__shfl(new_lab, r, 64) + 1);
+      int found = -1;
+      for (int base = 1; base < nnodes; base += 64) {
+        int idx = base + lane;
+        bool hit = (idx < nnodes) && (nodes[idx] == packed);
+        unsigned long long m = __ballot(hit);
+        if (m) { found = base + __ffsll((long long)m) - 1; break; }
       }
-      if (best == BNEG) break;
-      if (lane == (key & 63)) cand[key] = BNEG;
-      if (lane == 0) { pick_row[r] = key >> 6; pick_lane[r] = key & 63; pick_val[r] = best; }
-      ++newn;
-      __syncthreads();
-    }
-    __syncthreads();
-    // ---- build the new beam in pick order (already descending)
-    for (int r = 0; r < newn; ++r) {
-      int row = pick_row[r], pl = pick_lane[r];
-      if (row == 0) {
-        if (lane == 0) {
-          nxt->node[r] = cur->node[pl]; nxt->par[r] = cur->par[pl]; nxt->lab[r] = cur->lab[pl];
-          nxt->ob[r] = cur->ob[pl]; nxt->ol[r] = cur->ol[pl]; nxt->ot[r] = cur->ot[pl];
-          nxt->nb[r] = cur->nb[pl]; nxt->nl[r] = cur->nl[pl]; nxt->nt[r] = cur->nt[pl];
-        }
-      } else {
-        int parent = cur->node[row - 1];
-        int packed = ((parent + 1) << 8) | (pl + 1);
-        int found = -1;
-        for (int base = 1; base < nnodes; base += 64) {  // re-entering prefix? reuse its node
-          int idx = base + lane;
-          bool hit = (idx < nnodes) && (nodes[idx] == packed);
-          unsigned long long m = __ballot(hit);
-          if (m) { found = base + __ffsll((long long)m) - 1; break; }
-        }
-        if (found < 0) {
-          found = nnodes;
-          if (nnodes < nmax) { if (lane == 0) nodes[nnodes] = packed; ++nnodes; }
-        }
-        if (lane == 0) {
-          float v = pick_val[r];
-          nxt->node[r] = found; nxt->par[r] = parent; nxt->lab[r] = pl;
-          nxt->ob[r] = nxt->ol[r] = nxt->ot[r] = BNEG;
-          nxt->nb[r] = BNEG; nxt->nl[r] = v; nxt->nt[r] = v;
-        }
+      if (found < 0) {
+        found = nnodes;
+        if (nnodes < nmax) { if (lane == 0) nodes[nnodes] = packed; ++nnodes; }
         __syncthreads();
       }
+      if (lane == r) new_node = found;
     }
-    __syncthreads();
-    BeamSet* tmp = cur; cur = nxt; nxt = tmp;
-    n = newn;
+    b_node = new_node; b_par = new_par; b_lab = new_lab; b_nb = new_nb; b_nl = new_nl; b_nt = new_nt;
+    n = nle;
   }
-  // ---- best path = slot 0; walk to the root, merge_repeated on the collapsed sequence, reverse
+  // ---- best path = entry 0; walk to the root, merge_repeated on the collapsed sequence, reverse
   for (int i = lane; i < T; i += 64) out[(long)b * T + i] = -1;
+  const int best_node = __shfl(b_node, 0, 64);
+  const float best_score = __shfl(b_nt, 0, 64);
   __syncthreads();
   if (lane == 0) {
-    int len = 0;
-    if (n > 0) {
-      int nd = cur->node[0], prev = -1;
-      // labels are emitted leaf->root straight into `out`, then flipped in place
-      while (nd != 0) {
-        int pk = nodes[nd];
-        int lab = (pk & 255) - 1;
-        if (!merge_repeated || lab != prev) out[(long)b * T + len++] = lab;
-        prev = lab;
-        nd = (pk >> 8) - 1;
-      }
-      for (int i = 0; i < len / 2; ++i) {
-        int a = out[(long)b * T + i]; out[(long)b * T + i] = out[(long)b * T + len - 1 - i]; out[(long)b * T + len - 1 - i] = a;
-      }
-      scores[b] = cur->nt[0];
-    } else {
-      scores[b] = 0.f;
+    int len = 0, nd = best_node, prev = -1;
+    while (nd != 0) {                       // labels are emitted leaf->root straight into `out`, then flipped
+      int pk = nodes[nd];
+      int lab = (pk & 255) - 1;
+      if (!merge_repeated || lab != prev) out[(long)b * T + len++] = lab;
+      prev = lab;
+      nd = (pk >> 8) - 1;
     }
+    for (int i = 0; i < len / 2; ++i) {
+      int a = out[(long)b * T + i]; out[(long)b * T + i] = out[(long)b * T + len - 1 - i]; out[(long)b * T + len - 1 - i] = a;
+    }
+    scores[b] = best_score;
     out_len[b] = len;
   }
 }
@@ -176,7 +189,7 @@ extern "C" int crnn_ctc_beam_decode(const float* y, const int* input_len, int* o
                                     int C, int beam_width, int merge_repeated, hipStream_t stream) {
   if (C > 64 || C < 2 || beam_width < 1 || beam_width > BEAM_MAX) return CRNN_ERR_UNSUPPORTED;
   int nmax = 1 + T * beam_width;
-  size_t lds = (size_t)nmax * 4 + (size_t)(BEAM_MAX + 1) * 64 * 4 + 64 * 4 + BEAM_MAX * 12 + 2 * sizeof(BeamSet) + 64;
+  size_t lds = (size_t)nmax * 4 + BEAM_MAX * 16 + 64;
   if (lds > 64 * 1024) return CRNN_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(ctc_beam_kernel, dim3(B), dim3(64), lds, stream, y, input_len, out, out_len, scores, T, C, beam_width, merge_repeated, nmax);
   CRNN_LAUNCH_CHECK();
