@@ -1,0 +1,421 @@
+"""The reference's model-facing Python surface, re-hosted on the HIP engine.
+
+Same names / signatures / return types as utils.py (CRNN, init_predictor, load_custom_model, save_model_json,
+load_model_custom, ctc_lambda_func, BilinearInterpolation, STN) and the subset of the Keras `Model` API that
+train.py / predict.py / EarlyStoppingIter actually touch (compile, fit_generator, predict_generator,
+evaluate_generator, get/set_weights, load/save_weights, save, to_json, summary, stop_training, get_layer,
+input).  The model is not a graph of Python layer objects: `get_model()` returns a handle whose train /
+predict steps are single calls into libcrnn_mi355x (forward + CTC + backward + optimizer as HIP kernels).
+
+Storage: Keras `.h5` needs h5py (absent) -> weights are written as NumPy .npz *under the reference's file
+names* (final_weights.h5 etc. contain an npz archive); the list order is Keras' weight order so an
+h5 importer can be added without touching anything else.
+"""
+import ctypes
+import json
+import os
+import time
+from collections import OrderedDict
+
+import numpy as np
+
+from . import native
+from .init import initial_parameters
+
+BLOCK_FILTERS = (64, 128, 256, 256, 512, 512, 512)
+BLOCK_POOL = (None, None, (2, 2), None, (1, 2), None, None)
+
+
+def _cfg_struct(batch, shape, num_classes, max_len, tds, units, gru, stn=True, dropout=True):
+    return native.crnn_config(int(batch), int(shape[0]), int(shape[1]), int(num_classes), int(max_len), int(tds), int(units),
+                              int(bool(gru)), int(bool(stn)), int(bool(dropout)))
+
+
+def param_layout(cfg):
+    """{name: (offset, size, dims)} from the C ABI (host-only call, no GPU needed)."""
+    lib = native.lib()
+    c = ctypes.byref(cfg)
+    name = ctypes.create_string_buffer(64)
+    off, size, ndim = ctypes.c_long(), ctypes.c_long(), ctypes.c_int()
+    dims = (ctypes.c_int * 4)()
+    out = OrderedDict()
+    for i in range(lib.crnn_num_params(c)):
+        native.check(lib.crnn_param_info(c, i, name, 64, ctypes.byref(off), ctypes.byref(size), ctypes.byref(ndim), dims))
+        out[name.value.decode()] = (off.value, size.value, tuple(dims[:ndim.value]))
+    return out
+
+
+class _Tensor:
+    """Symbolic stand-in for `model.input` / `layer.output` (only identity matters to the callers)."""
+
+    def __init__(self, name, shape):
+        self.name, self.shape = name, shape
+
+    def __repr__(self):
+        return "<tensor %s %s>" % (self.name, self.shape)
+
+
+class _Layer:
+    def __init__(self, name, output):
+        self.name, self.output = name, output
+
+
+class History:
+    def __init__(self):
+        self.history = {}
+        self.epoch = []
+
+
+class CRNN:
+    """utils.py:32-96 -- same constructor; `get_model()` returns the trainable 4-input model whose single output
+    is the per-sample CTC cost ('ctc')."""
+
+    def __init__(self, num_classes=97, max_string_len=23, shape=(40, 40, 1), time_dense_size=128, GRU=False, n_units=256):
+        self.num_classes = num_classes
+        self.shape = shape
+        self.max_string_len = max_string_len
+        self.n_units = n_units
+        self.GRU = GRU
+        self.time_dense_size = time_dense_size
+
+    def get_model(self):
+        self.pooling_counter_h, self.pooling_counter_w = 0, 0
+        for pool in BLOCK_POOL:                      # utils.py:50-55
+            if pool is not None:
+                self.pooling_counter_h += int(pool[0] == 2)
+                self.pooling_counter_w += int(pool[1] == 2)
+        return Model(dict(num_classes=self.num_classes, max_string_len=self.max_string_len, shape=tuple(self.shape),
+                          time_dense_size=self.time_dense_size, GRU=bool(self.GRU), n_units=self.n_units))
+
+
+class Model:
+    def __init__(self, config, predictor=False, share=None):
+        self.config = dict(config)
+        self.predictor = predictor
+        self.stop_training = False
+        self.optimizer = None
+        self._iterations = 0
+        sh = self.config["shape"]
+        self._T = (sh[0] + 4) // 2
+        if share is not None:                        # predictor view of an existing model: same weights/engine
+            self._state = share._state
+        else:
+            cfg = _cfg_struct(1, sh, self.config["num_classes"], self.config["max_string_len"], self.config["time_dense_size"],
+                              self.config["n_units"], self.config["GRU"])
+            layout = param_layout(cfg)
+            p = initial_parameters(layout, self.config["n_units"], self.config["GRU"])
+            bn = OrderedDict()
+            cin = 1
+            for i, co in enumerate(BLOCK_FILTERS, 1):
+                for j, ch in ((1, cin), (2, co)):
+                    bn["b%d_bn%d_mean" % (i, j)] = np.zeros(ch, np.float32)
+                    bn["b%d_bn%d_var" % (i, j)] = np.ones(ch, np.float32)
+                cin = co
+            self._state = {"params": p, "bn": bn, "engine": None, "layout": layout}
+        C = self.config["num_classes"]
+        self.input = [_Tensor("the_input", (None,) + tuple(sh)), _Tensor("the_labels", (None, self.config["max_string_len"])),
+                      _Tensor("input_length", (None, 1)), _Tensor("label_length", (None, 1))]
+        self._layers = OrderedDict((n, _Layer(n, _Tensor(n, s))) for n, s in (
+            ("the_input", (None,) + tuple(sh)), ("softmax", (None, self._T, C)), ("ctc", (None, 1))))
+
+    # ---- engine management --------------------------------------------------------------------------------
+    def _engine(self, batch, dropout=True):
+        from .engine import Engine
+        st = self._state
+        eng = st["engine"]
+        if eng is None or eng.B != batch:
+            if eng is not None:
+                self._pull()
+            c = self.config
+            eng = Engine(batch, c["shape"][0], c["shape"][1], c["num_classes"], c["max_string_len"], c["time_dense_size"], c["n_units"],
+                         gru=c["GRU"], stn=True, dropout=dropout)
+            eng.set_params(st["params"], st["bn"])
+            st["engine"] = eng
+        return eng
+
+    def _pull(self):
+        """device -> host copies of weights and BN statistics."""
+        eng = self._state["engine"]
+        if eng is not None:
+            self._state["params"] = eng.get_params()
+            self._state["bn"] = eng.get_bn()
+
+    def _push(self):
+        eng = self._state["engine"]
+        if eng is not None:
+            eng.set_params(self._state["params"], self._state["bn"])
+
+    # ---- Keras weight list (SURVEY A.9 order, 94 tensors for either cell) ---------------------------------------
+    def _weight_index(self):
+        idx = [("p", n) for n in ("stn_c1_k", "stn_c1_b", "stn_c2_k", "stn_c2_b", "stn_d1_w", "stn_d1_b", "stn_d2_w", "stn_d2_b")]
+        for i in range(1, 8):
+            b = "b%d" % i
+            idx += [("p", b + "_dw"), ("p", b + "_bn1_g"), ("p", b + "_bn1_b"), ("s", b + "_bn1_mean"), ("s", b + "_bn1_var"),
+                    ("p", b + "_pw"), ("p", b + "_bn2_g"), ("p", b + "_bn2_b"), ("s", b + "_bn2_mean"), ("s", b + "_bn2_var")]
+        idx += [("p", "dense1_w"), ("p", "dense1_b")]
+        for l in (1, 2):
+            for d in ("f", "b"):
+                idx += [("p", "rnn%d%s_%s" % (l, d, k)) for k in ("w", "u", "b")]
+        idx += [("p", "dense2_w"), ("p", "dense2_b")]
+        return idx
+
+    @staticmethod
+    def _keras_shape(name, a):
+        if name.endswith("_dw"):
+            return a.reshape(a.shape + (1,))                 # (3,3,C,1)
+        if name.endswith("_pw"):
+            return a.reshape((1, 1) + a.shape)               # (1,1,Cin,Cout)
+        return a
+
+    def get_weights(self):
+        self._pull()
+        st = self._state
+        return [self._keras_shape(n, np.array(st["params"][n] if k == "p" else st["bn"][n])) for k, n in self._weight_index()]
+
+    def set_weights(self, weights):
+        st = self._state
+        idx = self._weight_index()
+        if len(weights) != len(idx):
+            raise ValueError("expected %d weight arrays, got %d" % (len(idx), len(weights)))
+        for (k, n), w in zip(idx, weights):
+            tgt = st["params"] if k == "p" else st["bn"]
+            tgt[n] = np.asarray(w, dtype=np.float32).reshape(tgt[n].shape)
+        self._push()
+
+    def save_weights(self, path):
+        ws = self.get_weights()
+        with open(path, "wb") as f:
+            np.savez(f, **{"w%03d" % i: w for i, w in enumerate(ws)})
+
+    def load_weights(self, path):
+        with np.load(path) as z:
+            self.set_weights([z["w%03d" % i] for i in range(len(z.files))])
+
+    def save(self, path):
+        """Keras `model.save` (architecture + weights; optimizer state is not resumed by the reference either)."""
+        ws = self.get_weights()
+        with open(path, "wb") as f:
+            np.savez(f, model_json=np.array(self.to_json()), **{"w%03d" % i: w for i, w in enumerate(ws)})
+
+    def to_json(self):
+        return json.dumps({"class_name": "Model", "backend": "crnn_mi355x", "keras_version": "2.2.2-compatible surface",
+                           "config": {"crnn": {k: (list(v) if isinstance(v, tuple) else v) for k, v in self.config.items()},
+                                      "predictor": self.predictor}})
+
+    def count_params(self):
+        trainable = sum(int(np.prod(d)) for _, _, d in self._state["layout"].values())
+        return trainable, sum(v.size for v in self._state["bn"].values())
+
+    def summary(self, print_fn=None):
+        pr = print_fn or print
+        pr("_" * 65)
+        pr("%-34s %-20s %s" % ("Layer (type)", "Shape", "Param #"))
+        pr("=" * 65)
+        for n, (_, size, dims) in self._state["layout"].items():
+            pr("%-34s %-20s %d" % (n, str(tuple(dims)), size))
+        tr, nt = self.count_params()
+        pr("=" * 65)
+        pr("Total params: {:,}".format(tr + nt))
+        pr("Trainable params: {:,}".format(tr))
+        pr("Non-trainable params: {:,}".format(nt))
+        pr("_" * 65)
+
+    def get_layer(self, name):
+        return self._layers[name]
+
+    # ---- training / inference ---------------------------------------------------------------------------------
+    def compile(self, loss=None, optimizer=None, **kwargs):
+        """loss={'ctc': lambda y_true, y_pred: y_pred} in the reference (train.py:192): the model output already
+        is the CTC cost, so the training loss is its batch mean -- that is what the engine differentiates."""
+        self.optimizer = optimizer
+        self._iterations = 0
+
+    @staticmethod
+    def _unpack(batch):
+        inputs = batch[0] if isinstance(batch, (tuple, list)) else batch
+        if isinstance(inputs, dict):
+            return inputs["the_input"], inputs.get("the_labels"), inputs.get("input_length"), inputs.get("label_length")
+        return inputs, None, None, None
+
+    def _dist(self):
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                return dist, dist.get_world_size()
+        except Exception:
+            pass
+        return None, 1
+
+    def train_on_batch(self, x, labels, input_length, label_length):
+        if self.optimizer is None:
+            raise RuntimeError("compile(optimizer=...) first")
+        eng = self._engine(len(x))
+        dist, world = self._dist()
+        allreduce = None
+        if world > 1:
+            from .parallel import GradAllReduce
+            allreduce = GradAllReduce(eng, dist, world)
+        loss = eng.train_step(x, labels, input_length, label_length, self.optimizer, self._iterations, allreduce=allreduce)
+        self._iterations += 1
+        return float(loss.mean().item())
+
+    def test_on_batch(self, x, labels, input_length, label_length):
+        """learning_phase=0 forward + CTC cost (validation loss)."""
+        import torch
+        from .engine import _ptr, _stream
+        eng = self._engine(len(x))
+        y = eng.forward(x, train=False)
+        lab, il, ll = eng._as_i32(labels), eng._as_i32(input_length), eng._as_i32(label_length)
+        scratch = eng.ws_tensor("dlogits")
+        native.check(eng.lib.crnn_ctc_loss_grad(_ptr(y), _ptr(lab), _ptr(il), _ptr(ll), _ptr(eng.loss), _ptr(scratch), eng.B, eng.T, eng.C,
+                                                self.config["max_string_len"], 2, 0.0, _stream()), "ctc")
+        return float(eng.loss.mean().item())
+
+    def predict_on_batch(self, x):
+        eng = self._engine(len(x))
+        return eng.forward(x, train=False).cpu().numpy()
+
+    def fit_generator(self, generator, steps_per_epoch=None, epochs=1, validation_data=None, validation_steps=None,
+                      shuffle=False, verbose=1, callbacks=None, **kwargs):
+        H = History()
+        callbacks = list(callbacks or [])
+        for cb in callbacks:
+            cb.set_model(self)
+            cb.on_train_begin({})
+        self.stop_training = False
+        for epoch in range(epochs):
+            t0 = time.time()
+            run, nimg = 0.0, 0
+            for step in range(steps_per_epoch):
+                x, lab, il, ll = self._unpack(next(generator))
+                loss = self.train_on_batch(x, lab, il, ll)
+                run += loss; nimg += len(x)
+                logs = {"loss": loss, "batch": step, "size": len(x)}
+                for cb in callbacks:
+                    cb.on_batch_end(step, logs)
+                if verbose and (step + 1 == steps_per_epoch or (step + 1) % max(1, steps_per_epoch // 20) == 0):
+                    print("\r%d/%d - loss: %.4f - %.0f img/s" % (step + 1, steps_per_epoch, run / (step + 1), nimg / max(time.time() - t0, 1e-9)),
+                          end="", flush=True)
+                if self.stop_training:
+                    break
+            logs = {"loss": run / max(1, step + 1)}
+            if validation_data is not None and validation_steps:
+                logs["val_loss"] = self.evaluate_generator(validation_data, validation_steps)
+            if verbose:
+                print("\nEpoch %d/%d - %ds - %s" % (epoch + 1, epochs, time.time() - t0, " - ".join("%s: %.4f" % kv for kv in logs.items())))
+            H.epoch.append(epoch)
+            for k, v in logs.items():
+                H.history.setdefault(k, []).append(v)
+            for cb in callbacks:
+                cb.on_epoch_end(epoch, logs)
+            if self.stop_training:
+                break
+        for cb in callbacks:
+            cb.on_train_end({})
+        return H
+
+    def evaluate_generator(self, generator, steps):
+        tot = 0.0
+        for _ in range(steps):
+            x, lab, il, ll = self._unpack(next(generator))
+            tot += self.test_on_batch(x, lab, il, ll)
+        return tot / max(1, steps)
+
+    def predict_generator(self, generator, steps, **kwargs):
+        """-> ndarray (steps*B, T, num_classes) float32 softmax (predict.py:166)."""
+        outs = []
+        for _ in range(steps):
+            x, _, _, _ = self._unpack(next(generator))
+            outs.append(self.predict_on_batch(x))
+        return np.concatenate(outs, 0)
+
+
+def init_predictor(model):
+    """utils.py:308-312: the softmax sub-model sharing the trained weights."""
+    return Model(model.config, predictor=True, share=model)
+
+
+def model_from_json(text, custom_objects=None):
+    cfg = json.loads(text)["config"]
+    crnn = cfg["crnn"]
+    crnn["shape"] = tuple(crnn["shape"])
+    return Model(crnn, predictor=cfg.get("predictor", False))
+
+
+def save_model_json(model, save_path, model_name):
+    """utils.py:530-533"""
+    with open(save_path + '/' + model_name + "/model.json", "w") as f:
+        f.write(model.to_json())
+
+
+def load_custom_model(model_path, model_name='/model.json', weights="/final_weights.h5"):
+    """utils.py:323-329"""
+    with open(model_path + model_name, 'r') as f:
+        model = model_from_json(f.read())
+    model.load_weights(model_path + weights)
+    return model
+
+
+def load_model_custom(path, weights="model"):
+    """utils.py:300-306"""
+    return load_custom_model(path, '/model.json', "/%s.h5" % weights)
+
+
+def ctc_lambda_func(args):
+    """utils.py:98-103 on arrays: per-sample CTC cost of y_pred[:, 2:, :] (HIP kernel)."""
+    import torch
+    from .engine import _ptr, _stream
+    y_pred, labels, input_length, label_length = args
+    y = torch.from_numpy(np.ascontiguousarray(y_pred, dtype=np.float32)).cuda()
+    B, T, C = y.shape
+    lab = torch.from_numpy(np.ascontiguousarray(labels, dtype=np.int32)).cuda()
+    il = torch.from_numpy(np.ascontiguousarray(np.asarray(input_length).reshape(-1), dtype=np.int32)).cuda()
+    ll = torch.from_numpy(np.ascontiguousarray(np.asarray(label_length).reshape(-1), dtype=np.int32)).cuda()
+    loss = torch.empty(B, dtype=torch.float32, device="cuda")
+    scratch = torch.empty(T * B * C, dtype=torch.float32, device="cuda")
+    native.check(native.lib().crnn_ctc_loss_grad(_ptr(y), _ptr(lab), _ptr(il), _ptr(ll), _ptr(loss), _ptr(scratch), B, T, C, lab.shape[1], 2, 0.0,
+                                                 _stream()), "ctc")
+    return loss.cpu().numpy().reshape(B, 1)
+
+
+class BilinearInterpolation:
+    """utils.py:116-237 as a callable on arrays: layer([image (B,H,W,1), theta (B,6)]) -> (B,H,W,1)."""
+
+    def __init__(self, output_size=(100, 32), **kwargs):
+        self.output_size = output_size
+
+    def compute_output_shape(self, input_shapes):
+        return (None, self.output_size[0], self.output_size[1], input_shapes[0][-1])
+
+    def get_config(self):
+        return {"output_size": self.output_size}
+
+    def __call__(self, tensors, mask=None):
+        import torch
+        from .engine import _ptr, _stream
+        X, theta = tensors
+        X = np.asarray(X, dtype=np.float32)
+        B, H, W, Cc = X.shape
+        if Cc != 1 or (H, W) != tuple(self.output_size):
+            raise native.CrnnError("the HIP sampler handles single-channel maps with output_size == input size")
+        xd = torch.from_numpy(np.ascontiguousarray(X)).cuda()
+        td = torch.from_numpy(np.ascontiguousarray(np.asarray(theta, dtype=np.float32).reshape(B, 6))).cuda()
+        out = torch.empty((B, H, W), dtype=torch.float32, device="cuda")
+        native.check(native.lib().crnn_sampler_fwd(_ptr(xd), _ptr(td), _ptr(out), B, H, W, 0, _stream()), "sampler")
+        return out.cpu().numpy()[..., None]
+
+    call = __call__
+
+
+def get_initial_weights(output_size):
+    """utils.py:239-245"""
+    b = np.zeros((2, 3), dtype='float32')
+    b[0, 0] = 1
+    b[1, 1] = 1
+    return [np.zeros((output_size, 6), dtype='float32'), b.flatten()]
+
+
+def STN(image, sampling_size=(100, 32)):
+    """utils.py:247-258 builds the localisation net + sampler as Keras layers; in this build the spatial
+    transformer is part of the fused model (csrc/stn.hip + model.hip) and cannot be instantiated stand-alone."""
+    raise NotImplementedError("STN is built into CRNN(...).get_model(); use BilinearInterpolation for the sampler alone")
