@@ -148,6 +148,37 @@ __global__ void dwconv_naive_kernel(const float* __restrict__ x, const float* __
   }
 }
 
+// single-channel weight gradient: partials[blk][9]
+__global__ __launch_bounds__(256) void dwconv_wgrad_c1_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                              float* __restrict__ partials, int B, int H, int W) {
+  __shared__ float red[9][256];
+  float acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+  const long npix = (long)B * H * W;
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < npix; p += (long)gridDim.x * 256L) {
+    int w = (int)(p % W); long r = p / W; int h = (int)(r % H);
+    float gv = g[p];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        int gh = h + i - 1, gw = w + j - 1;
+        if (gh >= 0 && gh < H && gw >= 0 && gw < W) acc[i * 3 + j] = fmaf(x[p + (long)(i - 1) * W + (j - 1)], gv, acc[i * 3 + j]);
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) red[t][threadIdx.x] = acc[t];
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if (threadIdx.x < s2)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) red[t][threadIdx.x] += red[t][threadIdx.x + s2];
+    __syncthreads();
+  }
+  if (threadIdx.x < 9) partials[(long)blockIdx.x * 9 + threadIdx.x] = red[threadIdx.x][0];
+}
+
 static int dw_pick_th(int W, size_t* lds) {
   int TH = 8;
   for (;;) {
@@ -233,12 +264,14 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
 
 static inline int pow2_ge(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
-extern "C" int crnn_colreduce_chunks(long M) { long rpc = 1024; if (M < 4096) rpc = 64; return cdiv(M, rpc); }
+// rows per chunk: aim for >= ~512 chunks (fills 256 CUs), between 16 and 1024 rows each
+static inline int colreduce_rpc(long M) { long r = 1024; while (r > 16 && M / r < 512) r >>= 1; return (int)r; }
+extern "C" int crnn_colreduce_chunks(long M) { return cdiv(M, colreduce_rpc(M)); }
 
 // partials [crnn_colreduce_chunks(M)][nv][C]
 extern "C" int crnn_colreduce(const float* x, float* partials, long M, int C, int ld, int nv, hipStream_t stream) {
   if (nv != 1 && nv != 2) return CRNN_ERR_ARG;
-  int rpc = (M < 4096) ? 64 : 1024;
+  int rpc = colreduce_rpc(M);
   int chunks = cdiv(M, rpc);
   bool vec = (C % 4 == 0) && (ld % 4 == 0) && ((((uintptr_t)x) & 15) == 0);
   int CL = vec ? C / 4 : C;
@@ -256,23 +289,23 @@ extern "C" int crnn_colreduce(const float* x, float* partials, long M, int C, in
 
 // out[i] = scale * sum_p partials[p][i], i < n  (double accumulation)
 __global__ void partials_sum_kernel(const float* __restrict__ partials, int nparts, int n, float* __restrict__ out, float scale) {
-  // blockDim = (32, 8): 32 consecutive outputs x 8 part-lanes
-  __shared__ double red[8][32];
+  // blockDim = (32, 32): 32 consecutive outputs x 32 part-lanes
+  __shared__ double red[32][32];
   int i = blockIdx.x * 32 + threadIdx.x;
   double a = 0.0;
   if (i < n)
-    for (int p = threadIdx.y; p < nparts; p += 8) a += (double)partials[(long)p * n + i];
+    for (int p = threadIdx.y; p < nparts; p += 32) a += (double)partials[(long)p * n + i];
   red[threadIdx.y][threadIdx.x] = a;
   __syncthreads();
   if (threadIdx.y == 0 && i < n) {
     double s = 0.0;
-    for (int r = 0; r < 8; ++r) s += red[r][threadIdx.x];
+    for (int r = 0; r < 32; ++r) s += red[r][threadIdx.x];
     out[i] = (float)(s * scale);
   }
 }
 
 extern "C" int crnn_partials_sum(const float* partials, int nparts, int n, float* out, float scale, hipStream_t stream) {
-  hipLaunchKernelGGL(partials_sum_kernel, dim3(cdiv(n, 32)), dim3(32, 8), 0, stream, partials, nparts, n, out, scale);
+  hipLaunchKernelGGL(partials_sum_kernel, dim3(cdiv(n, 32)), dim3(32, 32), 0, stream, partials, nparts, n, out, scale);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
@@ -289,6 +322,13 @@ extern "C" int crnn_dwconv3x3_wgrad(const float* x, const float* g, float* dk, f
     CRNN_LAUNCH_CHECK();
     return crnn_partials_sum(scratch, ntiles, 9 * C, dk, 1.f, stream);
   }
+  if (C == 1) {  // first block: one channel, B*H*W pixels -> per-block partials [nblk][9], then the 2nd stage
+    long npix = (long)B * H * W;
+    int nblk = cdiv(npix, 2048); if (nblk > 1024) nblk = 1024;
+    hipLaunchKernelGGL(dwconv_wgrad_c1_kernel, dim3(nblk), dim3(256), 0, stream, x, g, scratch, B, H, W);
+    CRNN_LAUNCH_CHECK();
+    return crnn_partials_sum(scratch, nblk, 9, dk, 1.f, stream);
+  }
   hipLaunchKernelGGL(dwconv_naive_kernel<1>, dim3(9 * C), dim3(256), 0, stream, x, nullptr, g, dk, B, H, W, C, 0);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
@@ -300,11 +340,11 @@ extern "C" int crnn_dwconv3x3_wgrad(const float* x, const float* g, float* dk, f
 __global__ void bn_finalize_kernel(const float* __restrict__ partials, int nparts, int C, double inv_n,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ bnstate) {
-  __shared__ double red[2][8][32];
+  __shared__ double red[2][32][32];
   int c = blockIdx.x * 32 + threadIdx.x;
   double s = 0.0, q = 0.0;
   if (c < C)
-    for (int p = threadIdx.y; p < nparts; p += 8) {
+    for (int p = threadIdx.y; p < nparts; p += 32) {
       s += (double)partials[((long)p * 2 + 0) * C + c];
       q += (double)partials[((long)p * 2 + 1) * C + c];
     }
@@ -312,7 +352,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partials, int npart
   __syncthreads();
   if (threadIdx.y == 0 && c < C) {
     s = 0.0; q = 0.0;
-    for (int r = 0; r < 8; ++r) { s += red[0][r][threadIdx.x]; q += red[1][r][threadIdx.x]; }
+    for (int r = 0; r < 32; ++r) { s += red[0][r][threadIdx.x]; q += red[1][r][threadIdx.x]; }
     double mean = s * inv_n;
     double var = q * inv_n - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -337,7 +377,7 @@ __global__ void bn_infer_state_kernel(const float* __restrict__ mmean, const flo
 
 extern "C" int crnn_bn_finalize(const float* partials, int nparts, int C, long n, const float* gamma, const float* beta,
                                 float* bnstate, hipStream_t stream) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(32, 8), 0, stream, partials, nparts, C, 1.0 / (double)n, gamma, beta, bnstate);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(32, 32), 0, stream, partials, nparts, C, 1.0 / (double)n, gamma, beta, bnstate);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
@@ -404,70 +444,124 @@ extern "C" int crnn_bn_act_pool_drop(const float* x, const float* bnstate, float
 //   gy = [first-argmax of the pool window] * g * dropmask * [0 < relu6(bn(x)) < 6]
 // pass 1 (reduce): partials [chunk][2][C] = (sum gy, sum gy*xhat)
 // pass 2 (apply):  dx = scale * (gy - c1 - xhat*c2),   c1 = sum(gy)/n, c2 = sum(gy*xhat)/n
+// Threads: VEC channels per thread (16-byte accesses when C % 4 == 0), CW channel-threads x 256/CW
+// row-threads; rows = pixels.  POOL=false (ph=pw=1) needs no per-element index arithmetic at all.
 // ---------------------------------------------------------------------------------------------
 struct BnBwdArgs {
   const float* x; const float* g; const float* bnstate; const float* gamma;
   int B, H, W, C, ph, pw; float rate; uint64_t seed; uint32_t layer;
 };
 
-__device__ __forceinline__ float bn_gy(const BnBwdArgs& a, long b, int h, int w, int c, float xv, float sc, float sh) {
-  const int Ho = a.H / a.ph, Wo = a.W / a.pw;
-  int ho = h / a.ph, wo = w / a.pw;
-  if (ho >= Ho || wo >= Wo) return 0.f;
-  float y = relu6f(fmaf(xv, sc, sh));
-  if (a.ph * a.pw > 1) {
+template <int VEC>
+struct VecF { float v[VEC]; };
+
+template <int VEC>
+__device__ __forceinline__ VecF<VEC> vload(const float* p) {
+  VecF<VEC> r;
+  if (VEC == 4) { float4 q = *reinterpret_cast<const float4*>(p); r.v[0] = q.x; r.v[1 % VEC] = q.y; r.v[2 % VEC] = q.z; r.v[3 % VEC] = q.w; }
+  else r.v[0] = p[0];
+  return r;
+}
+template <int VEC>
+__device__ __forceinline__ void vstore(float* p, const VecF<VEC>& r) {
+  if (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1 % VEC], r.v[2 % VEC], r.v[3 % VEC]);
+  else p[0] = r.v[0];
+}
+
+// gy for VEC consecutive channels starting at c0 of pixel row r
+template <int VEC, bool POOL>
+__device__ __forceinline__ VecF<VEC> bn_gy_vec(const BnBwdArgs& a, long r, int c0, const VecF<VEC>& xv, const VecF<VEC>& sc,
+                                               const VecF<VEC>& sh, float inv_keep) {
+  VecF<VEC> out, y;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) y.v[e] = relu6f(fmaf(xv.v[e], sc.v[e], sh.v[e]));
+  long oidx;
+  bool arg[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) arg[e] = true;
+  if (!POOL) {
+    oidx = r * a.C + c0;
+  } else {
+    const int Ho = a.H / a.ph, Wo = a.W / a.pw;
+    int w = (int)(r % a.W); long rr = r / a.W; int h = (int)(rr % a.H); long b = rr / a.H;
+    int ho = h / a.ph, wo = w / a.pw;
+    if (ho >= Ho || wo >= Wo) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) out.v[e] = 0.f;
+      return out;
+    }
     int si = h - ho * a.ph, sj = w - wo * a.pw;
     for (int ii = 0; ii < a.ph; ++ii)
       for (int j = 0; j < a.pw; ++j) {
         if (ii == si && j == sj) continue;
-        float o = relu6f(fmaf(a.x[(((long)b * a.H + ho * a.ph + ii) * a.W + wo * a.pw + j) * a.C + c], sc, sh));
+        VecF<VEC> o = vload<VEC>(&a.x[(((long)b * a.H + ho * a.ph + ii) * a.W + wo * a.pw + j) * a.C + c0]);
         bool earlier = (ii < si) || (ii == si && j < sj);
-        if (earlier ? (o >= y) : (o > y)) return 0.f;  // not the first maximum
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float oy = relu6f(fmaf(o.v[e], sc.v[e], sh.v[e]));
+          if (earlier ? (oy >= y.v[e]) : (oy > y.v[e])) arg[e] = false;   // not the first maximum
+        }
       }
+    oidx = (((long)b * Ho + ho) * Wo + wo) * a.C + c0;
   }
-  if (!(y > 0.f && y < 6.f)) return 0.f;
-  long oidx = (((long)b * Ho + ho) * Wo + wo) * a.C + c;
-  float inv_keep = a.rate > 0.f ? 1.f / (1.f - a.rate) : 1.f;
-  return a.g[oidx] * drop_scale(a.seed, a.layer, (uint64_t)oidx, a.rate, inv_keep);
+  VecF<VEC> gv = vload<VEC>(&a.g[oidx]);
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    bool live = arg[e] && (y.v[e] > 0.f) && (y.v[e] < 6.f);
+    out.v[e] = live ? gv.v[e] * drop_scale(a.seed, a.layer, (uint64_t)(oidx + e), a.rate, inv_keep) : 0.f;
+  }
+  return out;
 }
 
-template <int PASS>
+template <int PASS, int VEC, bool POOL>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a, float* __restrict__ partials,
                                                      const float* __restrict__ coef, float* __restrict__ dx, int CW,
                                                      int rows_per_chunk) {
-  // rows = pixels (b,h,w); thread -> (c = cb + tid % CW, rt = tid / CW)
-  __shared__ float red[2][256];
+  __shared__ float red[2][256 * VEC];
   const int tid = threadIdx.x, cl = tid % CW, rt = tid / CW, RT = 256 / CW;
   const long M = (long)a.B * a.H * a.W;
   const long r0 = (long)blockIdx.x * rows_per_chunk;
   long r1 = r0 + rows_per_chunk; if (r1 > M) r1 = M;
-  const float* mean = a.bnstate; const float* var = a.bnstate + a.C;
-  const float* scp = a.bnstate + 2 * a.C; const float* shp = a.bnstate + 3 * a.C;
-  for (int cb = 0; cb < a.C; cb += CW) {
-    int c = cb + cl;
-    float s = 0.f, q = 0.f;
-    if (c < a.C) {
-      float sc = scp[c], sh = shp[c], mu = mean[c], inv = 1.0f / sqrtf(var[c] + BN_EPS);
-      float c1 = 0.f, c2 = 0.f;
-      if (PASS == 2) { c1 = coef[c]; c2 = coef[a.C + c]; }
+  const int CL = a.C / VEC;
+  const float inv_keep = a.rate > 0.f ? 1.f / (1.f - a.rate) : 1.f;
+  for (int cb = 0; cb < CL; cb += CW) {
+    const int c = cb + cl, c0 = c * VEC;
+    VecF<VEC> s, q;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { s.v[e] = 0.f; q.v[e] = 0.f; }
+    if (c < CL) {
+      VecF<VEC> mu = vload<VEC>(a.bnstate + c0), var = vload<VEC>(a.bnstate + a.C + c0);
+      VecF<VEC> sc = vload<VEC>(a.bnstate + 2 * a.C + c0), sh = vload<VEC>(a.bnstate + 3 * a.C + c0);
+      VecF<VEC> inv, c1, c2;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { inv.v[e] = 1.0f / sqrtf(var.v[e] + BN_EPS); c1.v[e] = 0.f; c2.v[e] = 0.f; }
+      if (PASS == 2) { c1 = vload<VEC>(coef + c0); c2 = vload<VEC>(coef + a.C + c0); }
       for (long r = r0 + rt; r < r1; r += RT) {
-        int w = (int)(r % a.W); long rr = r / a.W; int h = (int)(rr % a.H); long b = rr / a.H;
-        float xv = a.x[r * a.C + c];
-        float gy = bn_gy(a, b, h, w, c, xv, sc, sh);
-        float xh = (xv - mu) * inv;
-        if (PASS == 1) { s += gy; q = fmaf(gy, xh, q); }
-        else dx[r * a.C + c] = sc * (gy - c1 - xh * c2);
+        VecF<VEC> xv = vload<VEC>(&a.x[r * a.C + c0]);
+        VecF<VEC> gy = bn_gy_vec<VEC, POOL>(a, r, c0, xv, sc, sh, inv_keep);
+        VecF<VEC> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float xh = (xv.v[e] - mu.v[e]) * inv.v[e];
+          if (PASS == 1) { s.v[e] += gy.v[e]; q.v[e] = fmaf(gy.v[e], xh, q.v[e]); }
+          else o.v[e] = sc.v[e] * (gy.v[e] - c1.v[e] - xh * c2.v[e]);
+        }
+        if (PASS == 2) vstore<VEC>(&dx[r * a.C + c0], o);
       }
     }
     if (PASS == 1) {
       __syncthreads();
-      red[0][tid] = s; red[1][tid] = q;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { red[0][tid * VEC + e] = s.v[e]; red[1][tid * VEC + e] = q.v[e]; }
       __syncthreads();
-      if (rt == 0 && c < a.C) {
-        float s2 = 0.f, q2 = 0.f;
-        for (int r = 0; r < RT; ++r) { s2 += red[0][r * CW + cl]; q2 += red[1][r * CW + cl]; }
-        partials[((long)blockIdx.x * 2 + 0) * a.C + c] = s2;
-        partials[((long)blockIdx.x * 2 + 1) * a.C + c] = q2;
+      if (rt == 0 && c < CL) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float s2 = 0.f, q2 = 0.f;
+          for (int r = 0; r < RT; ++r) { s2 += red[0][(r * CW + cl) * VEC + e]; q2 += red[1][(r * CW + cl) * VEC + e]; }
+          partials[((long)blockIdx.x * 2 + 0) * a.C + c0 + e] = s2;
+          partials[((long)blockIdx.x * 2 + 1) * a.C + c0 + e] = q2;
+        }
       }
     }
   }
@@ -476,11 +570,11 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a, float* __restr
 // dgamma = sum gy*xhat, dbeta = sum gy; coef = [c1 | c2]
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nparts, int C, double inv_n,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
-  __shared__ double red[2][8][32];
+  __shared__ double red[2][32][32];
   int c = blockIdx.x * 32 + threadIdx.x;
   double s = 0.0, q = 0.0;
   if (c < C)
-    for (int p = threadIdx.y; p < nparts; p += 8) {
+    for (int p = threadIdx.y; p < nparts; p += 32) {
       s += (double)partials[((long)p * 2 + 0) * C + c];
       q += (double)partials[((long)p * 2 + 1) * C + c];
     }
@@ -488,13 +582,29 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int n
   __syncthreads();
   if (threadIdx.y == 0 && c < C) {
     s = 0.0; q = 0.0;
-    for (int r = 0; r < 8; ++r) { s += red[0][r][threadIdx.x]; q += red[1][r][threadIdx.x]; }
+    for (int r = 0; r < 32; ++r) { s += red[0][r][threadIdx.x]; q += red[1][r][threadIdx.x]; }
     dbeta[c] = (float)s; dgamma[c] = (float)q;
     coef[c] = (float)(s * inv_n); coef[C + c] = (float)(q * inv_n);
   }
 }
 
-extern "C" int crnn_bn_bwd_chunks(long M) { return cdiv(M, 512); }
+static inline int bn_bwd_rows_per_chunk(long M) { return M >= (1L << 19) ? 256 : (M >= (1L << 15) ? 64 : 16); }
+extern "C" int crnn_bn_bwd_chunks(long M) { return cdiv(M, bn_bwd_rows_per_chunk(M)); }
+
+template <int VEC, bool POOL>
+static int bn_bwd_launch(const BnBwdArgs& a, float* dx, float* dgamma, float* dbeta, float* parts, float* coef, hipStream_t stream) {
+  const long M = (long)a.B * a.H * a.W;
+  const int rpc = bn_bwd_rows_per_chunk(M), chunks = cdiv(M, rpc);
+  const int CL = a.C / VEC;
+  const int CW = pow2_ge(CL < 256 ? CL : 256);
+  hipLaunchKernelGGL((bn_bwd_kernel<1, VEC, POOL>), dim3(chunks), dim3(256), 0, stream, a, parts, nullptr, nullptr, CW, rpc);
+  CRNN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(a.C, 32)), dim3(32, 32), 0, stream, parts, chunks, a.C, 1.0 / (double)M, dgamma, dbeta, coef);
+  CRNN_LAUNCH_CHECK();
+  hipLaunchKernelGGL((bn_bwd_kernel<2, VEC, POOL>), dim3(chunks), dim3(256), 0, stream, a, nullptr, coef, dx, CW, rpc);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
 
 // Full BN backward through Dropout/MaxPool/ReLU6: writes dx [B,H,W,C], dgamma[C], dbeta[C].
 // scratch_partials: [crnn_bn_bwd_chunks(B*H*W)][2][C]; coef: [2*C].
@@ -502,16 +612,12 @@ extern "C" int crnn_bn_bwd(const float* x, const float* g, const float* bnstate,
                            float* dgamma, float* dbeta, float* scratch_partials, float* coef, int B, int H, int W, int C,
                            int ph, int pw, float rate, uint64_t seed, uint32_t layer, hipStream_t stream) {
   BnBwdArgs a{x, g, bnstate, gamma, B, H, W, C, ph, pw, rate, seed, layer};
-  long M = (long)B * H * W;
-  int chunks = cdiv(M, 512);
-  int CW = pow2_ge(C < 256 ? C : 256);
-  hipLaunchKernelGGL(bn_bwd_kernel<1>, dim3(chunks), dim3(256), 0, stream, a, scratch_partials, nullptr, nullptr, CW, 512);
-  CRNN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(32, 8), 0, stream, scratch_partials, chunks, C, 1.0 / (double)M, dgamma, dbeta, coef);
-  CRNN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_kernel<2>, dim3(chunks), dim3(256), 0, stream, a, nullptr, coef, dx, CW, 512);
-  CRNN_LAUNCH_CHECK();
-  return CRNN_OK;
+  const bool pool = (ph * pw) > 1;
+  const bool vec = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)g | (uintptr_t)dx | (uintptr_t)bnstate | (uintptr_t)coef) & 15) == 0);
+  if (vec) return pool ? bn_bwd_launch<4, true>(a, dx, dgamma, dbeta, scratch_partials, coef, stream)
+                       : bn_bwd_launch<4, false>(a, dx, dgamma, dbeta, scratch_partials, coef, stream);
+  return pool ? bn_bwd_launch<1, true>(a, dx, dgamma, dbeta, scratch_partials, coef, stream)
+              : bn_bwd_launch<1, false>(a, dx, dgamma, dbeta, scratch_partials, coef, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
