@@ -1,0 +1,203 @@
+"""CPU tests (no GPU): the host-side mirror of the reference's Python surface against the golden vectors
+generated from the reference itself (tests/golden/helpers_golden.json), the C-ABI library's symbol table and
+layout functions, the data generator's batch contract, and the world_size-2 data-parallel reduction (gloo)."""
+import ctypes
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import utils as U  # crnn-ocr-lite_amd/utils.py (drop-in for the reference's module)
+from crnn_mi355x import native
+from crnn_mi355x.surface import param_layout, _cfg_struct
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "helpers_golden.json")))
+
+
+def _reader(batch_size=4):
+    classes = {ch: i for i, ch in enumerate(U.get_lexicon())}
+    return U.Readf(img_size=(100, 32, 1), max_len=23, normed=True, batch_size=batch_size, classes=classes), classes
+
+
+def test_lexicon_targets_blank_matrices_norm_match_reference():
+    assert U.get_lexicon() == GOLD["lexicon"]
+    reader, classes = _reader()
+    for word, ids in GOLD["make_target"].items():
+        w = word if word == "Zz9_-" else word.lower()
+        assert [int(v) for v in reader.make_target(w)] == ids
+    X, Y, il, ll = reader.get_blank_matrices()
+    g = GOLD["blank_matrices"]
+    assert list(X.shape) == g["X_shape"] and str(X.dtype) == g["X_dtype"]
+    assert Y.tolist() == g["Y"] and str(Y.dtype) == g["Y_dtype"]
+    assert il.tolist() == g["input_length"] and ll.tolist() == g["label_length"]
+    out = U.norm(np.array(GOLD["norm_in"]), reader.mean, reader.std)
+    assert str(out.dtype) == GOLD["norm_dtype"]
+    np.testing.assert_array_equal(out, np.array(GOLD["norm_out"], dtype=np.float32))
+    assert U.parse_mjsynth("/data/mj", ["./2425/1/115_Lube_45484.jpg 45484\n", "./1/2/3_a_1.jpg 1"]) == GOLD["parse_mjsynth"]
+
+
+def test_edit_distances_and_label_text_match_reference():
+    for a, b, d in GOLD["levenshtein"]:
+        assert U.levenshtein(a, b) == d and isinstance(U.levenshtein(a, b), float)
+    pairs = [(a, b) for a, b, _ in GOLD["levenshtein"] if b]
+    assert U.edit_distance([a for a, _ in pairs], [b for _, b in pairs]) == pytest.approx(GOLD["edit_distance"], rel=1e-12)
+    assert U.normalized_edit_distance([a for a, _ in pairs], [b for _, b in pairs]) == pytest.approx(GOLD["normalized_edit_distance"], rel=1e-12)
+    inv = {i: ch for i, ch in enumerate(U.get_lexicon())}
+    dec = U.DecodeCTCPred(top_paths=1, beam_width=10, inverse_classes=inv)
+    for labels, text in GOLD["labels_to_text"]:
+        assert dec.labels_to_text(labels) == text
+    for labels, text in GOLD["labels_to_text_fn"]:
+        assert U.labels_to_text(labels, inv) == text
+    W, b = U.get_initial_weights(50)
+    assert list(W.shape) == GOLD["initial_weights"]["W_shape"] and np.abs(W).max() == 0 and b.tolist() == GOLD["initial_weights"]["b"]
+
+
+def test_early_stopping_iter_trace_matches_reference():
+    g = GOLD["early_stopping"]
+
+    class _M:
+        stop_training = False
+        w = 0
+
+        def get_weights(self):
+            return self.w
+
+        def set_weights(self, w):
+            self.w = w
+
+    es = U.EarlyStoppingIter(monitor="loss", min_delta=g["min_delta"], patience=g["patience"], restore_best_weights=True, mode="auto")
+    es.set_model(_M())
+    es.on_train_begin()
+    trace = []
+    for i, l in enumerate(g["losses"]):
+        es.model.w = i
+        es.on_batch_end(i, {"loss": l})
+        trace.append([bool(es.model.stop_training), float(es.best), int(es.stopped_iter)])
+        if es.model.stop_training:
+            break
+    assert trace == g["trace"] and es.model.w == g["final_weights"]
+
+
+def test_library_exports_every_declared_symbol_and_layout_is_keras_order():
+    decl = native.parse_header()
+    assert len(decl) >= 40
+    lib = ctypes.CDLL(native.LIB_PATH)          # loads without a GPU
+    missing = [n for n in decl if not hasattr(lib, n)]
+    assert not missing, missing
+    cfg = _cfg_struct(64, (100, 32, 1), 38, 23, 128, 256, False)
+    lay = param_layout(cfg)
+    names = list(lay)
+    assert names[:8] == ["stn_c1_k", "stn_c1_b", "stn_c2_k", "stn_c2_b", "stn_d1_w", "stn_d1_b", "stn_d2_w", "stn_d2_b"]
+    assert names[-2:] == ["dense2_w", "dense2_b"] and len(names) == 66
+    assert sum(int(np.prod(d)) for _, _, d in lay.values()) == 3282865      # LSTM variant
+    assert all(off % 4 == 0 for off, _, _ in lay.values())                    # 16-byte aligned tensors
+    L = native.lib()
+    assert L.crnn_bn_total(ctypes.byref(cfg)) == 3969 and L.crnn_time_steps(ctypes.byref(cfg)) == 52
+    cfg200 = _cfg_struct(8, (200, 32, 1), 38, 21, 128, 256, False)
+    assert L.crnn_time_steps(ctypes.byref(cfg200)) == 102 and param_layout(cfg200)["stn_d1_w"][2] == (1760, 50)
+    assert L.crnn_workspace_bytes(ctypes.byref(cfg)) > 0
+    bad = _cfg_struct(8, (100, 32, 1), 38, 23, 128, 100, False)               # units not a multiple of 64
+    assert L.crnn_workspace_bytes(ctypes.byref(bad)) == 0
+
+
+def test_model_surface_weights_roundtrip_without_gpu(tmp_path):
+    init_model = U.CRNN(num_classes=38, shape=(100, 32, 1), max_string_len=23, time_dense_size=128, n_units=256)
+    model = init_model.get_model()
+    assert (init_model.pooling_counter_h, init_model.pooling_counter_w) == (1, 2)   # downsample_factor = 2 (train.py:202)
+    ws = model.get_weights()
+    assert len(ws) == 94 and ws[8].shape == (3, 3, 1, 1) and ws[13].shape == (1, 1, 1, 64)
+    assert model.count_params() == (3282865, 7938)
+    np.testing.assert_array_equal(ws[7], [1, 0, 0, 0, 1, 0])                         # identity STN (utils.py:239-245)
+    assert np.abs(ws[6]).max() == 0
+    os.makedirs(tmp_path / "m")
+    U.save_model_json(model, str(tmp_path), "m")
+    model.save_weights(str(tmp_path / "m" / "final_weights.h5"))
+    m2 = U.load_custom_model(str(tmp_path / "m"))
+    for a, b in zip(ws, m2.get_weights()):
+        np.testing.assert_array_equal(a, b)
+    pred = U.init_predictor(m2)
+    assert pred.predictor and pred.get_layer("softmax").output.shape == (None, 52, 38)
+    lines = []
+    model.summary(print_fn=lines.append)
+    assert any("Total params: 3,290,803" in l for l in lines)                        # LSTM total incl. BN statistics
+
+
+def _write_png(path, w, h, seed):
+    from PIL import Image
+    rs = np.random.RandomState(seed)
+    a = np.full((h, w), 230, np.uint8)
+    a[h // 3: 2 * h // 3, w // 5: 4 * w // 5] = rs.randint(0, 60, size=(2 * h // 3 - h // 3, 4 * w // 5 - w // 5))
+    Image.fromarray(a).save(path)
+
+
+def test_readf_generator_contract_and_first_pass_tail(tmp_path):
+    words = ["hello", "world", "ab", "q9z", "seven"]
+    names = []
+    for i, wd in enumerate(words):
+        p = str(tmp_path / ("%d_%s_%d.png" % (i, wd, i)))
+        _write_png(p, 60 + 7 * i, 24, i)
+        names.append(p)
+    np.random.seed(0)
+    reader, classes = _reader(batch_size=2)
+    gen = reader.run_generator(names, downsample_factor=2)
+    b1, o1 = next(gen)
+    assert set(b1) == {"the_input", "the_labels", "input_length", "label_length", "source_str"} and o1["ctc"].shape == (2,)
+    assert b1["the_input"].shape == (2, 100, 32, 1) and b1["the_input"].dtype == np.float64
+    assert b1["input_length"].ravel().tolist() == [50.0, 50.0] and b1["label_length"].ravel().tolist() == [5.0, 5.0]
+    assert b1["the_labels"][0, :5].tolist() == [classes[c] for c in "hello"] and b1["the_labels"][0, 5] == 37
+    assert list(b1["source_str"]) == ["hello", "world"]
+    next(gen)
+    b3, _ = next(gen)                      # tail of the first pass: full-size arrays, one fresh row
+    assert list(b3["source_str"]) == ["seven"] and b3["the_input"].shape == (2, 100, 32, 1)
+    b4, _ = next(gen)                      # second pass continues filling the same arrays (counter never resets)
+    assert list(b4["source_str"]) == ["seven", "hello"]
+    x = b1["the_input"]
+    assert abs(float(x.mean())) < 4 and np.isfinite(x).all()
+    img, word = U.open_img(names[0], (100, 32, 1), p=0.)
+    assert img.shape == (100, 32) and img.dtype == np.uint8 and word == "hello"
+    assert (img > 127).mean() < 0.5        # bright background was inverted (utils.py:402-405)
+
+
+def _dp_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "crnn-ocr-lite_amd"))
+    from crnn_mi355x.parallel import allreduce_mean_, shard
+    from oracle import model as M
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = M.Config(imgh=36, imgw=32, num_classes=7, max_len=4, time_dense_size=12, n_units=8)
+    p, bn = M.init_params(cfg, seed=5, dtype=np.float64)
+    x, lab, il, ll = M.synthetic_batch(cfg, 4, seed=2, dtype=np.float64)
+    lo, hi = shard(4, rank, world)
+    # per-replica BatchNorm statistics (no SyncBN): each rank differentiates its own shard
+    _, _, g, _ = M.loss_and_grads(cfg, p, bn, x[lo:hi], lab[lo:hi], il[lo:hi], ll[lo:hi])
+    flat = torch.from_numpy(np.concatenate([g[k].ravel() for k in p]))
+    allreduce_mean_(flat, dist, world)
+    q.put((rank, flat.numpy().copy(), (lo, hi)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_allreduce_world2_gloo():
+    import torch.multiprocessing as mp
+    from oracle import model as M
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=180) for _ in range(2)], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(60)
+    np.testing.assert_array_equal(res[0][1], res[1][1])           # identical averaged gradient on both ranks
+    assert res[0][2] == (0, 2) and res[1][2] == (2, 4)
+    cfg = M.Config(imgh=36, imgw=32, num_classes=7, max_len=4, time_dense_size=12, n_units=8)
+    p, bn = M.init_params(cfg, seed=5, dtype=np.float64)
+    x, lab, il, ll = M.synthetic_batch(cfg, 4, seed=2, dtype=np.float64)
+    gs = [M.loss_and_grads(cfg, p, bn, x[a:b], lab[a:b], il[a:b], ll[a:b])[2] for a, b in ((0, 2), (2, 4))]
+    ref = np.concatenate([(0.5 * (gs[0][k] + gs[1][k])).ravel() for k in p])
+    np.testing.assert_allclose(res[0][1], ref, rtol=1e-12, atol=1e-15)
