@@ -35,7 +35,7 @@ class Engine:
         self._c = ctypes.byref(self.cfg)
         nbytes = self.lib.crnn_workspace_bytes(self._c)
         if nbytes == 0:
-            raise native.CrnnError("unsupported CRNN configuration (units %% 64, classes <= 64, max_len <= 31, LSTM only)")
+            raise native.CrnnError("unsupported CRNN configuration (n_units % 64 == 0, classes <= 64, max_len <= 31 required)")
         self.T = self.lib.crnn_time_steps(self._c)
         self.B, self.C = batch, num_classes
         self.n_total = self.lib.crnn_params_total(self._c)

@@ -138,7 +138,7 @@ Plan make_plan(const crnn_config* c) {
   P.add("logits", TB * d.C); P.add("ypred", TB * d.C);
   // backward
   P.add("dlogits", TB * d.C); P.add("dr2", TB * 2 * d.u); P.add("dr1", TB * d.u);
-  P.add("dcf", B * d.u); P.add("dcb", B * d.u);
+  P.add("dcf", B * d.u); P.add("dcb", B * d.u); P.add("dhpf", B * d.u); P.add("dhpb", B * d.u);
   P.add("ddn1", TB * d.tds); P.add("gbm", TB * d.tds);
   maxact = lmax(maxact, TB * d.feat);
   P.add("gA", maxact); P.add("gB", maxact);
@@ -175,7 +175,6 @@ int colsum(const Ctx& c, const float* x, long M, int C, int ld, float* out) {
 
 int check_cfg(const crnn_config* c) {
   if (!c || c->batch <= 0) return CRNN_ERR_ARG;
-  if (c->gru) return CRNN_ERR_UNSUPPORTED;  // GRU cell: next milestone
   if (c->units < 64 || c->units % 64) return CRNN_ERR_UNSUPPORTED;
   if (c->num_classes > 64 || c->num_classes < 2) return CRNN_ERR_UNSUPPORTED;
   if (2 * c->max_len + 1 > 64) return CRNN_ERR_UNSUPPORTED;
@@ -303,13 +302,21 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
     CRNN_TRY(crnn_transpose(c.p(std::string("rnn") + n + "_u"), c.w(std::string("ut") + n), u, G, stream));
   CRNN_TRY(gemm(c, 0, c.w("dn1"), c.p("rnn1f_w"), c.w("xw1f"), TB, G, d.tds, d.tds, G, G, c.p("rnn1f_b")));
   CRNN_TRY(gemm(c, 0, c.w("dn1"), c.p("rnn1b_w"), c.w("xw1b"), TB, G, d.tds, d.tds, G, G, c.p("rnn1b_b")));
-  CRNN_TRY(crnn_lstm_fwd(c.w("xw1f"), c.w("xw1b"), c.w("ut1f"), c.w("ut1b"), c.w("h1f"), c.w("h1b"), u, c.w("cs1f"), c.w("cs1b"),
-                         c.w("gt1f"), c.w("gt1b"), T, B, u, stream));
+  if (cfg->gru)   // "cs" holds r*h_prev for the GRU (cell state for the LSTM)
+    CRNN_TRY(crnn_gru_fwd(c.w("xw1f"), c.w("xw1b"), c.w("ut1f"), c.w("ut1b"), c.w("h1f"), c.w("h1b"), u, c.w("gt1f"), c.w("gt1b"),
+                          c.w("cs1f"), c.w("cs1b"), T, B, u, stream));
+  else
+    CRNN_TRY(crnn_lstm_fwd(c.w("xw1f"), c.w("xw1b"), c.w("ut1f"), c.w("ut1b"), c.w("h1f"), c.w("h1b"), u, c.w("cs1f"), c.w("cs1b"),
+                           c.w("gt1f"), c.w("gt1b"), T, B, u, stream));
   CRNN_TRY(crnn_add(c.w("h1f"), c.w("h1b"), c.w("r1"), (long)TB * u, stream));  // merge_mode='sum'
   CRNN_TRY(gemm(c, 0, c.w("r1"), c.p("rnn2f_w"), c.w("xw2f"), TB, G, u, u, G, G, c.p("rnn2f_b")));
   CRNN_TRY(gemm(c, 0, c.w("r1"), c.p("rnn2b_w"), c.w("xw2b"), TB, G, u, u, G, G, c.p("rnn2b_b")));
-  CRNN_TRY(crnn_lstm_fwd(c.w("xw2f"), c.w("xw2b"), c.w("ut2f"), c.w("ut2b"), c.w("h2"), c.w("h2") + u, 2 * u, c.w("cs2f"), c.w("cs2b"),
-                         c.w("gt2f"), c.w("gt2b"), T, B, u, stream));      // merge_mode='concat'
+  if (cfg->gru)
+    CRNN_TRY(crnn_gru_fwd(c.w("xw2f"), c.w("xw2b"), c.w("ut2f"), c.w("ut2b"), c.w("h2"), c.w("h2") + u, 2 * u, c.w("gt2f"), c.w("gt2b"),
+                          c.w("cs2f"), c.w("cs2b"), T, B, u, stream));
+  else
+    CRNN_TRY(crnn_lstm_fwd(c.w("xw2f"), c.w("xw2b"), c.w("ut2f"), c.w("ut2b"), c.w("h2"), c.w("h2") + u, 2 * u, c.w("cs2f"), c.w("cs2b"),
+                           c.w("gt2f"), c.w("gt2b"), T, B, u, stream));    // merge_mode='concat'
   const float* r2 = c.w("h2");
   if (train) {  // Dropout(.2) (utils.py:83)
     CRNN_TRY(crnn_dropout(c.w("h2"), c.w("r2d"), TB, 2 * u, 2 * u, 2 * u, cfg->dropout ? kDropRnn : 0.f, seed, kLayerRnn, stream));
@@ -332,15 +339,24 @@ static int lstm_layer_bwd(const Ctx& c, int layer, const float* xin, int ldx, in
   const int T = d.T, B = d.B, TB = T * B, u = d.u, G = d.G;
   std::string l = std::to_string(layer);
   float* dzf = c.w("dz" + l + "f"); float* dzb = c.w("dz" + l + "b");
-  CRNN_TRY(crnn_lstm_bwd(c.p("rnn" + l + "f_u"), c.p("rnn" + l + "b_u"), c.w("cs" + l + "f"), c.w("cs" + l + "b"), c.w("gt" + l + "f"),
-                         c.w("gt" + l + "b"), doutf, doutb, ldo, dzf, dzb, c.w("dcf"), c.w("dcb"), T, B, u, c.s));
+  if (c.cfg->gru)
+    CRNN_TRY(crnn_gru_bwd(c.p("rnn" + l + "f_u"), c.p("rnn" + l + "b_u"), hf, hb, ldh, c.w("gt" + l + "f"), c.w("gt" + l + "b"), doutf, doutb,
+                          ldo, dzf, dzb, c.w("dcf"), c.w("dcb"), c.w("dhpf"), c.w("dhpb"), T, B, u, c.s));
+  else
+    CRNN_TRY(crnn_lstm_bwd(c.p("rnn" + l + "f_u"), c.p("rnn" + l + "b_u"), c.w("cs" + l + "f"), c.w("cs" + l + "b"), c.w("gt" + l + "f"),
+                           c.w("gt" + l + "b"), doutf, doutb, ldo, dzf, dzb, c.w("dcf"), c.w("dcb"), T, B, u, c.s));
   // dW = X^T dZ ; dU = Hprev^T dZ ; db = colsum(dZ) ; dX = dZf Wf^T + dZb Wb^T
   CRNN_TRY(gemm(c, 2, xin, dzf, c.g("rnn" + l + "f_w"), din, G, TB, ldx, G, G));
   CRNN_TRY(gemm(c, 2, xin, dzb, c.g("rnn" + l + "b_w"), din, G, TB, ldx, G, G));
   const int K1 = (T - 1) * B;
   // forward direction: h_{t-1} pairs with dz_t ; backward direction: h_{t+1} pairs with dz_t
-  CRNN_TRY(gemm(c, 2, hf, dzf + (long)B * G, c.g("rnn" + l + "f_u"), u, G, K1, ldh, G, G));
-  CRNN_TRY(gemm(c, 2, hb + (long)B * ldh, dzb, c.g("rnn" + l + "b_u"), u, G, K1, ldh, G, G));
+  const int Nh = c.cfg->gru ? 2 * u : G;   // GRU: only the z,r columns see h_prev; the candidate sees r*h_prev
+  CRNN_TRY(gemm(c, 2, hf, dzf + (long)B * G, c.g("rnn" + l + "f_u"), u, Nh, K1, ldh, G, G));
+  CRNN_TRY(gemm(c, 2, hb + (long)B * ldh, dzb, c.g("rnn" + l + "b_u"), u, Nh, K1, ldh, G, G));
+  if (c.cfg->gru) {
+    CRNN_TRY(gemm(c, 2, c.w("cs" + l + "f"), dzf + 2 * u, c.g("rnn" + l + "f_u") + 2 * u, u, u, TB, u, G, G));
+    CRNN_TRY(gemm(c, 2, c.w("cs" + l + "b"), dzb + 2 * u, c.g("rnn" + l + "b_u") + 2 * u, u, u, TB, u, G, G));
+  }
   CRNN_TRY(colsum(c, dzf, TB, G, G, c.g("rnn" + l + "f_b")));
   CRNN_TRY(colsum(c, dzb, TB, G, G, c.g("rnn" + l + "b_b")));
   CRNN_TRY(gemm(c, 1, dzf, c.p("rnn" + l + "f_w"), dxin, TB, din, G, G, G, din));

@@ -158,6 +158,177 @@ extern "C" int crnn_lstm_bwd(const float* u0, const float* u1, const float* c0, 
   return CRNN_OK;
 }
 
+// =====================================================================================================
+// Bidirectional GRU (Keras 2.2.2 GRUCell, reset_after=False, gate order z,r,h; utils.py:81-82 -- the cell
+// train.py really builds):  z = hs(xWz + h Uz), r = hs(xWr + h Ur), hh = tanh(xWh + (r*h) Uh),
+// h' = z*h + (1-z)*hh.  The candidate needs r first, so a timestep is two dependent MFMA step-GEMMs:
+//   fwd  K1: [z|r] tile  = h_{t-1} * U[:, 0:2u]      epilogue: gates z,r ; rh = r*h_{t-1}
+//        K2: hh tile     = rh * U[:, 2u:3u]          epilogue: hh, h_t
+//   bwd  KB: dh_t        = dout_t + dhp + [dz|dr]_{t+1} * U[:, 0:2u]^T    epilogue: dz_t, dhh_t
+//        KA: d(rh)_t     = dhh_t * U[:, 2u:3u]^T                          epilogue: dr_t ; dhp = dh_t*z + d(rh)*r
+// Same 16x16 tile / 4-wave split-K / 16-byte L2 streaming structure as the LSTM kernels above.
+// =====================================================================================================
+struct GruDir {
+  const float* xw;    // [T][B][3u]
+  const float* w;     // fwd: U^T [3u][u] ; bwd: U [u][3u]
+  float* h; int ldh;  // h(t,b,j)
+  float* gates;       // [T][B][3u] z, r, hh
+  float* rh;          // [T][B][u]  r * h_prev (kept for dU_h)
+  const float* dout; int ldo;
+  float* dz;          // [T][B][3u]
+  float* dh;          // [B][u] gradient w.r.t. h_t of the step in flight
+  float* dhp;         // [B][u] dh*z + d(rh)*r carried to the previous step
+};
+
+// acc[g] (16x16 tile, C/D layout) = sum_k A[b0+r][k] * Brow_g[j0+r'][k] over this wave's K slice; reduced
+// across the 4 waves into red[.][g][256] (row-major 16x16).  arow/brow are this lane's row pointers.
+template <int NG>
+__device__ __forceinline__ void step_tile_gemm(const float* arow, bool valid, const float* (&brow)[NG], int K, bool skip,
+                                               float (*red)[NG][256], int wave, int r, int q) {
+  f32x4 acc[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (!skip) {
+    const int kw = K >> 2, kbeg = wave * kw;
+    for (int kb = kbeg; kb < kbeg + kw; kb += 16) {
+      float4 a4 = valid ? *reinterpret_cast<const float4*>(arow + kb + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        float4 b4 = *reinterpret_cast<const float4*>(brow[g] + kb + 4 * q);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc[g], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wave][g][(q * 4 + e) * 16 + r] = acc[g][e];
+  __syncthreads();
+}
+
+#define STEP_IDS()                                                                                   \
+  const int b0 = blockIdx.y * 16, j0 = blockIdx.x * 16;                                              \
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;       \
+  const int row = tid >> 4, col = tid & 15, b = b0 + row, j = j0 + col;                              \
+  const bool valid = (b0 + r) < B;                                                                   \
+  const int ar = valid ? b0 + r : 0
+
+__global__ __launch_bounds__(256) void gru_fwd_zr_kernel(GruDir d0, GruDir d1, int s, int T, int B, int u) {
+  __shared__ float red[4][2][256];
+  const GruDir d = blockIdx.z ? d1 : d0;
+  const int dir = blockIdx.z, t = dir ? T - 1 - s : s, tp = dir ? t + 1 : t - 1;
+  STEP_IDS();
+  const float* arow = d.h + ((long)(s > 0 ? tp : t) * B + ar) * d.ldh;
+  const float* brow[2] = {d.w + (long)(j0 + r) * u, d.w + (long)(u + j0 + r) * u};
+  step_tile_gemm<2>(arow, valid, brow, u, s == 0, red, wave, r, q);
+  if (b < B) {
+    const float* xw = d.xw + ((long)t * B + b) * 3 * u;
+    float zz = ((red[0][0][tid] + red[1][0][tid]) + (red[2][0][tid] + red[3][0][tid])) + xw[j];
+    float rr = ((red[0][1][tid] + red[1][1][tid]) + (red[2][1][tid] + red[3][1][tid])) + xw[u + j];
+    float zg = hard_sigmoid(zz), rg = hard_sigmoid(rr);
+    float hprev = (s > 0) ? d.h[((long)tp * B + b) * d.ldh + j] : 0.f;
+    float* gt = d.gates + ((long)t * B + b) * 3 * u;
+    gt[j] = zg; gt[u + j] = rg;
+    d.rh[((long)t * B + b) * u + j] = rg * hprev;
+  }
+}
+
+__global__ __launch_bounds__(256) void gru_fwd_h_kernel(GruDir d0, GruDir d1, int s, int T, int B, int u) {
+  __shared__ float red[4][1][256];
+  const GruDir d = blockIdx.z ? d1 : d0;
+  const int dir = blockIdx.z, t = dir ? T - 1 - s : s, tp = dir ? t + 1 : t - 1;
+  STEP_IDS();
+  const float* arow = d.rh + ((long)t * B + ar) * u;
+  const float* brow[1] = {d.w + (long)(2 * u + j0 + r) * u};
+  step_tile_gemm<1>(arow, valid, brow, u, s == 0, red, wave, r, q);
+  if (b < B) {
+    float* gt = d.gates + ((long)t * B + b) * 3 * u;
+    float pre = ((red[0][0][tid] + red[1][0][tid]) + (red[2][0][tid] + red[3][0][tid])) + d.xw[((long)t * B + b) * 3 * u + 2 * u + j];
+    float hh = tanhf(pre), zg = gt[j];
+    float hprev = (s > 0) ? d.h[((long)tp * B + b) * d.ldh + j] : 0.f;
+    gt[2 * u + j] = hh;
+    d.h[((long)t * B + b) * d.ldh + j] = zg * hprev + (1.f - zg) * hh;
+  }
+}
+
+__global__ __launch_bounds__(256) void gru_bwd_b_kernel(GruDir d0, GruDir d1, int sb, int T, int B, int u) {
+  __shared__ float red[4][1][256];
+  const GruDir d = blockIdx.z ? d1 : d0;
+  const int dir = blockIdx.z, sp = T - 1 - sb, t = dir ? T - 1 - sp : sp;
+  const int tnext = dir ? t - 1 : t + 1, tprev = dir ? t + 1 : t - 1;
+  STEP_IDS();
+  const float* arow = d.dz + ((long)(sb > 0 ? tnext : t) * B + ar) * 3 * u;
+  const float* brow[1] = {d.w + (long)(j0 + r) * 3 * u};
+  step_tile_gemm<1>(arow, valid, brow, 2 * u, sb == 0, red, wave, r, q);
+  if (b < B) {
+    float dh = d.dout[((long)t * B + b) * d.ldo + j];
+    if (sb > 0) dh += ((red[0][0][tid] + red[1][0][tid]) + (red[2][0][tid] + red[3][0][tid])) + d.dhp[(long)b * u + j];
+    const float* gt = d.gates + ((long)t * B + b) * 3 * u;
+    float zg = gt[j], hh = gt[2 * u + j];
+    float hprev = (sp > 0) ? d.h[((long)tprev * B + b) * d.ldh + j] : 0.f;
+    float* dz = d.dz + ((long)t * B + b) * 3 * u;
+    dz[j] = dh * (hprev - hh) * hs_grad_from_out(zg);
+    dz[2 * u + j] = dh * (1.f - zg) * (1.f - hh * hh);
+    d.dh[(long)b * u + j] = dh;
+  }
+}
+
+__global__ __launch_bounds__(256) void gru_bwd_a_kernel(GruDir d0, GruDir d1, int sb, int T, int B, int u) {
+  __shared__ float red[4][1][256];
+  const GruDir d = blockIdx.z ? d1 : d0;
+  const int dir = blockIdx.z, sp = T - 1 - sb, t = dir ? T - 1 - sp : sp;
+  const int tprev = dir ? t + 1 : t - 1;
+  STEP_IDS();
+  const float* arow = d.dz + ((long)t * B + ar) * 3 * u + 2 * u;
+  const float* brow[1] = {d.w + (long)(j0 + r) * 3 * u + 2 * u};
+  step_tile_gemm<1>(arow, valid, brow, u, false, red, wave, r, q);
+  if (b < B) {
+    float drh = (red[0][0][tid] + red[1][0][tid]) + (red[2][0][tid] + red[3][0][tid]);
+    const float* gt = d.gates + ((long)t * B + b) * 3 * u;
+    float zg = gt[j], rg = gt[u + j];
+    float hprev = (sp > 0) ? d.h[((long)tprev * B + b) * d.ldh + j] : 0.f;
+    d.dz[((long)t * B + b) * 3 * u + u + j] = drh * hprev * hs_grad_from_out(rg);
+    d.dhp[(long)b * u + j] = d.dh[(long)b * u + j] * zg + drh * rg;
+  }
+}
+
+// Forward recurrence of one Bidirectional(GRU) layer.  xw[d] [T][B][3u] (x*W+b), ut[d] = U^T [3u][u], h[d] (row
+// stride ldh), gates[d] [T][B][3u], rh[d] [T][B][u].  2T launches.
+extern "C" int crnn_gru_fwd(const float* xw0, const float* xw1, const float* ut0, const float* ut1, float* h0, float* h1,
+                            int ldh, float* g0, float* g1, float* rh0, float* rh1, int T, int B, int u, hipStream_t stream) {
+  CRNN_TRY(check_units(u));
+  if (ldh % 4 != 0) return CRNN_ERR_ARG;
+  GruDir a{xw0, ut0, h0, ldh, g0, rh0, nullptr, 0, nullptr, nullptr, nullptr};
+  GruDir b{xw1, ut1, h1, ldh, g1, rh1, nullptr, 0, nullptr, nullptr, nullptr};
+  dim3 grid(u / 16, cdiv(B, 16), 2);
+  for (int s = 0; s < T; ++s) {
+    hipLaunchKernelGGL(gru_fwd_zr_kernel, grid, dim3(256), 0, stream, a, b, s, T, B, u);
+    hipLaunchKernelGGL(gru_fwd_h_kernel, grid, dim3(256), 0, stream, a, b, s, T, B, u);
+  }
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+
+// BPTT of one Bidirectional(GRU) layer: fills dz[d] [T][B][3u] (gradients w.r.t. the z, r, hh pre-activations).
+// u_[d] = U [u][3u]; h[d] as in the forward; dh[d], dhp[d] = [B][u] scratch.
+extern "C" int crnn_gru_bwd(const float* u0, const float* u1, const float* h0, const float* h1, int ldh, const float* g0,
+                            const float* g1, const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1,
+                            float* dh0, float* dh1, float* dhp0, float* dhp1, int T, int B, int u, hipStream_t stream) {
+  CRNN_TRY(check_units(u));
+  GruDir a{nullptr, u0, const_cast<float*>(h0), ldh, const_cast<float*>(g0), nullptr, dout0, ldo, dz0, dh0, dhp0};
+  GruDir b{nullptr, u1, const_cast<float*>(h1), ldh, const_cast<float*>(g1), nullptr, dout1, ldo, dz1, dh1, dhp1};
+  dim3 grid(u / 16, cdiv(B, 16), 2);
+  for (int sb = 0; sb < T; ++sb) {
+    hipLaunchKernelGGL(gru_bwd_b_kernel, grid, dim3(256), 0, stream, a, b, sb, T, B, u);
+    hipLaunchKernelGGL(gru_bwd_a_kernel, grid, dim3(256), 0, stream, a, b, sb, T, B, u);
+  }
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+
 // out[c][r] = in[r][c]  (U -> U^T once per weight update; tiny)
 __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
   __shared__ float tile[32][33];

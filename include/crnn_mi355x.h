@@ -137,6 +137,12 @@ int crnn_lstm_fwd(const float* xw0, const float* xw1, const float* ut0, const fl
 int crnn_lstm_bwd(const float* u0, const float* u1, const float* c0, const float* c1, const float* g0, const float* g1,
                   const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1, float* dc0, float* dc1, int T,
                   int B, int u, crnn_stream_t stream);
+/* Bidirectional GRU recurrence (utils.py:81-82; reset_after=False), time-major; gates = z,r,hh; rh = r*h_prev */
+int crnn_gru_fwd(const float* xw0, const float* xw1, const float* ut0, const float* ut1, float* h0, float* h1, int ldh,
+                 float* g0, float* g1, float* rh0, float* rh1, int T, int B, int u, crnn_stream_t stream);
+int crnn_gru_bwd(const float* u0, const float* u1, const float* h0, const float* h1, int ldh, const float* g0,
+                 const float* g1, const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1, float* dh0,
+                 float* dh1, float* dhp0, float* dhp1, int T, int B, int u, crnn_stream_t stream);
 int crnn_transpose(const float* in, float* out, int R, int C, crnn_stream_t stream);
 /* softmax + CTC (utils.py:86, 98-103) */
 int crnn_softmax_rows(const float* z, float* p, long rows, int C, crnn_stream_t stream);

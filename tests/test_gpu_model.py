@@ -100,25 +100,28 @@ def device_cache(eng, cfg, p, x, B, c_ref):
     tm = lambda a, k: np.ascontiguousarray(a.reshape(T, B, k).transpose(1, 0, 2))
     c["dense1"] = tm(f64("dn1"), cfg.tds)
     c["rnn_in"] = c["dense1"]
-    u, G = cfg.u, 4 * cfg.u
+    u, G = cfg.u, cfg.ng * cfg.u
     h2 = tm(f64("h2"), 2 * u)
     r1 = tm(f64("r1"), u)
     for name, xin, H in (("rnn1f", c["rnn_in"], tm(f64("h1f"), u)), ("rnn1b", c["rnn_in"], tm(f64("h1b"), u)),
                          ("rnn2f", r1, h2[..., :u]), ("rnn2b", r1, h2[..., u:])):
         l, d = name[3], name[4]
-        c[name] = (xin, p[name + "_w"], p[name + "_u"], H, tm(f64(f"cs{l}{d}"), u), tm(f64(f"gt{l}{d}"), G), d == "b")
+        if cfg.gru:
+            c[name] = (xin, p[name + "_w"], p[name + "_u"], H, tm(f64(f"gt{l}{d}"), G), d == "b")
+        else:
+            c[name] = (xin, p[name + "_w"], p[name + "_u"], H, tm(f64(f"cs{l}{d}"), u), tm(f64(f"gt{l}{d}"), G), d == "b")
     c["rnn_out"] = h2
     c["dense2_in"] = tm(f64("r2d"), 2 * u)
     c["y_pred"] = f64("ypred").reshape(B, T, cfg.num_classes)
     return c
 
 
-def run_case(B, imgh, imgw, u, tds, max_len, stn, dropout, seed=3, num_classes=38):
-    cfg = M.Config(imgh=imgh, imgw=imgw, num_classes=num_classes, max_len=max_len, time_dense_size=tds, n_units=u)
+def run_case(B, imgh, imgw, u, tds, max_len, stn, dropout, seed=3, num_classes=38, gru=False):
+    cfg = M.Config(imgh=imgh, imgw=imgw, num_classes=num_classes, max_len=max_len, time_dense_size=tds, n_units=u, gru=gru)
     p, bn = M.init_params(cfg, seed=7, dtype=np.float64)
     p = M.randomize_params(cfg, p)
     x, lab, il, ll = M.synthetic_batch(cfg, B, seed=1, dtype=np.float64)
-    eng = Engine(B, imgh, imgw, num_classes, max_len, tds, u, gru=False, stn=stn, dropout=dropout)
+    eng = Engine(B, imgh, imgw, num_classes, max_len, tds, u, gru=gru, stn=stn, dropout=dropout)
     eng.set_params(p, bn)
     masks = masks_from_engine(eng, cfg, seed) if dropout else None
     # ---- device
@@ -179,6 +182,15 @@ def test_small_model_no_dropout():
 
 def test_small_model_with_device_dropout_masks():
     check_case(run_case(B=4, imgh=40, imgw=32, u=64, tds=32, max_len=6, stn=True, dropout=True), "small+dropout")
+
+
+def test_small_gru_model_with_dropout():
+    """The GRU variant is what the reference's train.py actually builds."""
+    check_case(run_case(B=4, imgh=40, imgw=32, u=64, tds=32, max_len=6, stn=True, dropout=True, gru=True), "small-gru")
+
+
+def test_config1_shape_gru_model():
+    check_case(run_case(B=4, imgh=100, imgw=32, u=256, tds=128, max_len=23, stn=True, dropout=False, gru=True), "config1-gru")
 
 
 def test_small_model_stn_disabled():

@@ -253,6 +253,44 @@ def test_bilstm_fwd_bwd(B, T, u, din):
         assert_close(dzh.reshape(B * T, G).sum(0), db, rtol=2e-4, atol=1e-4, what=f"db dir{d}")
 
 
+@pytest.mark.parametrize("B,T,u,din", [(5, 7, 64, 24), (20, 5, 128, 40)])
+def test_bigru_fwd_bwd(B, T, u, din):
+    rs = np.random.RandomState(B + T + 1)
+    x = rs.normal(size=(B, T, din))
+    G = 3 * u
+    Wt = [rs.normal(size=(din, G)) * 0.3 for _ in range(2)]
+    U = [rs.normal(size=(u, G)) * 0.15 for _ in range(2)]
+    bb = [rs.normal(size=G) * 0.2 for _ in range(2)]
+    Hs, caches = [], []
+    for d in range(2):
+        h, c = ops.gru_fwd(x, Wt[d], U[d], bb[d], reverse=(d == 1))
+        Hs.append(h); caches.append(c)
+    tm = lambda a: np.ascontiguousarray(np.swapaxes(a, 0, 1))
+    xw = [dev(tm(x @ Wt[d] + bb[d])) for d in range(2)]
+    ut = [dev(U[d].T) for d in range(2)]
+    hcat = zeros(T, B, 2 * u); gt = [zeros(T, B, G) for _ in range(2)]; rh = [zeros(T, B, u) for _ in range(2)]
+    ok(L().crnn_gru_fwd(P(xw[0]), P(xw[1]), P(ut[0]), P(ut[1]), P(hcat), ctypes.c_void_p(hcat.data_ptr() + 4 * u), 2 * u, P(gt[0]), P(gt[1]),
+                        P(rh[0]), P(rh[1]), T, B, u, S()))
+    hh = host(hcat)
+    for d in range(2):
+        assert_close(hh[:, :, d * u:(d + 1) * u], tm(Hs[d]), rtol=1e-4, atol=1e-5, what=f"h dir{d}")
+        assert_close(host(gt[d]), tm(caches[d][4]), rtol=1e-4, atol=1e-5, what=f"gates dir{d}")
+    gH = rs.normal(size=(B, T, 2 * u))
+    gd = dev(tm(gH))
+    dz = [zeros(T, B, G) for _ in range(2)]; dh = [zeros(B, u) for _ in range(2)]; dhp = [zeros(B, u) for _ in range(2)]
+    Ud = [dev(U[d]) for d in range(2)]
+    ok(L().crnn_gru_bwd(P(Ud[0]), P(Ud[1]), P(hcat), ctypes.c_void_p(hcat.data_ptr() + 4 * u), 2 * u, P(gt[0]), P(gt[1]), P(gd),
+                        ctypes.c_void_p(gd.data_ptr() + 4 * u), 2 * u, P(dz[0]), P(dz[1]), P(dh[0]), P(dh[1]), P(dhp[0]), P(dhp[1]), T, B, u, S()))
+    for d in range(2):
+        dx, dW, dU, db = ops.gru_bwd(caches[d], gH[..., d * u:(d + 1) * u])
+        dzh = np.swapaxes(host(dz[d]).astype(np.float64), 0, 1)
+        assert_close(dzh @ Wt[d].T, dx, rtol=2e-4, atol=1e-5, what=f"dx dir{d}")
+        assert_close(x.reshape(B * T, -1).T @ dzh.reshape(B * T, G), dW, rtol=2e-4, atol=1e-4, what=f"dW dir{d}")
+        assert_close(dzh.reshape(B * T, G).sum(0), db, rtol=2e-4, atol=1e-4, what=f"db dir{d}")
+        rhh = np.swapaxes(host(rh[d]).astype(np.float64), 0, 1)
+        assert_close(rhh.reshape(B * T, u).T @ dzh.reshape(B * T, G)[:, 2 * u:], dU[:, 2 * u:], rtol=2e-4, atol=1e-4, what=f"dUh dir{d}")
+
+
 # ------------------------------------------------------------------------------------------------ softmax / CTC / decode
 def _ctc_case(B, T, C, Lmax, seed, short=False):
     rs = np.random.RandomState(seed)
