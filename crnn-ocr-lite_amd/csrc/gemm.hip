@@ -185,12 +185,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     }
 }
 
-// second stage of a split reduction: C = act(sum_z part[z] + bias) (+ C)
-__global__ void gemm_splitk_reduce_kernel(const float* __restrict__ part, int nsplit, GemmParams p) {
-  long total = (long)p.M * p.N;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int z = 0; z < nsplit; ++z) s += part[(long)z * total + i];
+// second stage of a split reduction: C = act(sum_z part[z] + bias) (+ C).  blockDim (32,8): 32 consecutive
+// outputs x 8 split-lanes, fixed summation order (deterministic).
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, int nsplit, GemmParams p) {
+  __shared__ float red[8][32];
+  const long total = (long)p.M * p.N;
+  const long i = (long)blockIdx.x * 32 + threadIdx.x;
+  float s = 0.f;
+  if (i < total)
+    for (int z = threadIdx.y; z < nsplit; z += 8) s += part[(long)z * total + i];
+  red[threadIdx.y][threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.y == 0 && i < total) {
+    s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) +
+        ((red[4][threadIdx.x] + red[5][threadIdx.x]) + (red[6][threadIdx.x] + red[7][threadIdx.x]));
     int m = (int)(i / p.N), n = (int)(i % p.N);
     if (p.bias) s += p.bias[n];
     if (p.act == 1) s = fmaxf(s, 0.f);
@@ -249,8 +257,7 @@ extern "C" int crnn_gemm_f32(int mode, const float* A, const float* B, float* C,
   CRNN_LAUNCH_CHECK();
   if (nsplit > 1) {
     long total = (long)M * N;
-    int blocks = cdiv(total, 256); if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, scratch, nsplit, p);
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(cdiv(total, 32)), dim3(32, 8), 0, stream, scratch, nsplit, p);
     CRNN_LAUNCH_CHECK();
   }
   return CRNN_OK;
