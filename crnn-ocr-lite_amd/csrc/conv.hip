@@ -567,6 +567,96 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a, float* __restr
   }
 }
 
+// Pooled variant (H % ph == 0, W % pw == 0): one thread owns a whole pool window x VEC channels, so every
+// pre-BN value is read exactly once per pass and the arg-max is found once per window.
+template <int PASS, int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_pool_kernel(BnBwdArgs a, float* __restrict__ partials,
+                                                          const float* __restrict__ coef, float* __restrict__ dx, int CW,
+                                                          int rows_per_chunk) {
+  __shared__ float red[2][256 * VEC];
+  const int tid = threadIdx.x, cl = tid % CW, rt = tid / CW, RT = 256 / CW;
+  const int Ho = a.H / a.ph, Wo = a.W / a.pw;
+  const long Mo = (long)a.B * Ho * Wo;
+  const long r0 = (long)blockIdx.x * rows_per_chunk;
+  long r1 = r0 + rows_per_chunk; if (r1 > Mo) r1 = Mo;
+  const int CL = a.C / VEC;
+  const float inv_keep = a.rate > 0.f ? 1.f / (1.f - a.rate) : 1.f;
+  const int nwin = a.ph * a.pw;   // <= 4
+  for (int cb = 0; cb < CL; cb += CW) {
+    const int c = cb + cl, c0 = c * VEC;
+    VecF<VEC> s, q;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { s.v[e] = 0.f; q.v[e] = 0.f; }
+    if (c < CL) {
+      VecF<VEC> mu = vload<VEC>(a.bnstate + c0), var = vload<VEC>(a.bnstate + a.C + c0);
+      VecF<VEC> sc = vload<VEC>(a.bnstate + 2 * a.C + c0), sh = vload<VEC>(a.bnstate + 3 * a.C + c0);
+      VecF<VEC> inv, c1, c2;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { inv.v[e] = 1.0f / sqrtf(var.v[e] + BN_EPS); c1.v[e] = 0.f; c2.v[e] = 0.f; }
+      if (PASS == 2) { c1 = vload<VEC>(coef + c0); c2 = vload<VEC>(coef + a.C + c0); }
+      for (long r = r0 + rt; r < r1; r += RT) {
+        int wo = (int)(r % Wo); long rr = r / Wo; int ho = (int)(rr % Ho); long b = rr / Ho;
+        const long oidx = r * a.C + c0;
+        VecF<VEC> gv = vload<VEC>(&a.g[oidx]);
+        VecF<VEC> xw[4];
+        float best[VEC]; int arg[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { best[e] = -1.f; arg[e] = 0; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (k < nwin) {
+            int ii = k / a.pw, j = k - ii * a.pw;
+            xw[k] = vload<VEC>(&a.x[(((long)b * a.H + ho * a.ph + ii) * a.W + wo * a.pw + j) * a.C + c0]);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              float y = relu6f(fmaf(xw[k].v[e], sc.v[e], sh.v[e]));
+              if (y > best[e]) { best[e] = y; arg[e] = k; }   // strict '>' keeps the FIRST maximum (scan order)
+            }
+          }
+        }
+        float gsel[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          bool live = (best[e] > 0.f) && (best[e] < 6.f);
+          gsel[e] = live ? gv.v[e] * drop_scale(a.seed, a.layer, (uint64_t)(oidx + e), a.rate, inv_keep) : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (k < nwin) {
+            VecF<VEC> o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              float gy = (arg[e] == k) ? gsel[e] : 0.f;
+              float xh = (xw[k].v[e] - mu.v[e]) * inv.v[e];
+              if (PASS == 1) { s.v[e] += gy; q.v[e] = fmaf(gy, xh, q.v[e]); }
+              else o.v[e] = sc.v[e] * (gy - c1.v[e] - xh * c2.v[e]);
+            }
+            if (PASS == 2) {
+              int ii = k / a.pw, j = k - ii * a.pw;
+              vstore<VEC>(&dx[(((long)b * a.H + ho * a.ph + ii) * a.W + wo * a.pw + j) * a.C + c0], o);
+            }
+          }
+        }
+      }
+    }
+    if (PASS == 1) {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { red[0][tid * VEC + e] = s.v[e]; red[1][tid * VEC + e] = q.v[e]; }
+      __syncthreads();
+      if (rt == 0 && c < CL) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float s2 = 0.f, q2 = 0.f;
+          for (int r = 0; r < RT; ++r) { s2 += red[0][(r * CW + cl) * VEC + e]; q2 += red[1][(r * CW + cl) * VEC + e]; }
+          partials[((long)blockIdx.x * 2 + 0) * a.C + c0 + e] = s2;
+          partials[((long)blockIdx.x * 2 + 1) * a.C + c0 + e] = q2;
+        }
+      }
+    }
+  }
+}
+
 // dgamma = sum gy*xhat, dbeta = sum gy; coef = [c1 | c2]
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nparts, int C, double inv_n,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
@@ -588,20 +678,26 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int n
   }
 }
 
-static inline int bn_bwd_rows_per_chunk(long M) { return M >= (1L << 19) ? 256 : (M >= (1L << 15) ? 64 : 16); }
+static inline int bn_bwd_rows_per_chunk(long M) { return M >= (1L << 19) ? 1024 : (M >= (1L << 17) ? 256 : (M >= (1L << 15) ? 64 : 16)); }
 extern "C" int crnn_bn_bwd_chunks(long M) { return cdiv(M, bn_bwd_rows_per_chunk(M)); }
 
 template <int VEC, bool POOL>
 static int bn_bwd_launch(const BnBwdArgs& a, float* dx, float* dgamma, float* dbeta, float* parts, float* coef, hipStream_t stream) {
   const long M = (long)a.B * a.H * a.W;
-  const int rpc = bn_bwd_rows_per_chunk(M), chunks = cdiv(M, rpc);
   const int CL = a.C / VEC;
   const int CW = pow2_ge(CL < 256 ? CL : 256);
-  hipLaunchKernelGGL((bn_bwd_kernel<1, VEC, POOL>), dim3(chunks), dim3(256), 0, stream, a, parts, nullptr, nullptr, CW, rpc);
+  const bool window = POOL && (a.H % a.ph == 0) && (a.W % a.pw == 0) && (a.ph * a.pw <= 4);
+  // chunking is over pooled pixels for the window kernel (same number of chunks as partial rows allocated:
+  // crnn_bn_bwd_chunks(M) >= chunks used here)
+  const long rows = window ? M / (a.ph * a.pw) : M;
+  const int rpc = bn_bwd_rows_per_chunk(M), chunks = cdiv(rows, rpc);
+  if (window) hipLaunchKernelGGL((bn_bwd_pool_kernel<1, VEC>), dim3(chunks), dim3(256), 0, stream, a, parts, nullptr, nullptr, CW, rpc);
+  else hipLaunchKernelGGL((bn_bwd_kernel<1, VEC, POOL>), dim3(chunks), dim3(256), 0, stream, a, parts, nullptr, nullptr, CW, rpc);
   CRNN_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(a.C, 32)), dim3(32, 32), 0, stream, parts, chunks, a.C, 1.0 / (double)M, dgamma, dbeta, coef);
   CRNN_LAUNCH_CHECK();
-  hipLaunchKernelGGL((bn_bwd_kernel<2, VEC, POOL>), dim3(chunks), dim3(256), 0, stream, a, nullptr, coef, dx, CW, rpc);
+  if (window) hipLaunchKernelGGL((bn_bwd_pool_kernel<2, VEC>), dim3(chunks), dim3(256), 0, stream, a, nullptr, coef, dx, CW, rpc);
+  else hipLaunchKernelGGL((bn_bwd_kernel<2, VEC, POOL>), dim3(chunks), dim3(256), 0, stream, a, nullptr, coef, dx, CW, rpc);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }

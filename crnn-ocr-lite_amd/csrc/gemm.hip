@@ -27,6 +27,7 @@ struct GemmParams {
   int permP;       // 0: none; else out_row = (m % P) * (M / P) + m / P
   int klen;        // K range per split (blockIdx.y); nsplit = gridDim.y
   int vecA, vecB;  // 16-byte vector loads legal for the operand
+  int vecC;        // 16-byte stores legal for C (and the split scratch)
   int tilesN;
 };
 
@@ -101,8 +102,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   constexpr int WAVES_N = (BN == 128) ? 2 : 1;
   constexpr int WM = (BN == 128) ? 64 : 32;  // rows per wave
   constexpr int TM = WM / 32, TN = 2;        // MFMA tiles per wave (wave covers WM x 64)
-  __shared__ __attribute__((aligned(16))) float As[BM * GLDM];
-  __shared__ __attribute__((aligned(16))) float Bs[BN * GLDM];
+  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * GLDM];
+  float* As = smem;
+  float* Bs = smem + BM * GLDM;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -161,28 +163,54 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   float* Cout = split ? p.C + (long)blockIdx.y * p.M * p.N : p.C;
   const int ldc = split ? p.N : p.ldc;
   const int Q = p.permP ? p.M / p.permP : 0;
+  // ---- epilogue: stage the accumulators through LDS (two 64-row halves) so that every lane stores 16
+  // contiguous bytes (512 B per output row per wave) instead of 64 separate 4-byte-per-lane stores.
+  constexpr int CLD = BN + 4;                      // padded row stride of the staged C half-tile
+  constexpr int ROWS_PER_IT = 256 / (BN / 4);      // rows covered by the 256 threads per store iteration
+  const bool vecC = p.vecC && !((ldc & 3) | (n0 & 3));
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int hp = 0; hp < 2; ++hp) {
+    if (wm0 >= 64 * hp && wm0 < 64 * hp + 64) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      int gn = n0 + wn0 + j * 32 + l31;
-      float bv = (!split && p.bias && gn < p.N) ? p.bias[gn] : 0.f;
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        int gm = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-        if (gm < p.M && gn < p.N) {
-          float v = acc[i][j][e];
-          int orow = gm;
-          if (!split) {
-            v += bv;
-            if (p.act == 1) v = fmaxf(v, 0.f);
-            if (p.permP) orow = (gm % p.permP) * Q + gm / p.permP;
-            if (p.accumulate) v += Cout[(long)orow * ldc + gn];
-          }
-          Cout[(long)orow * ldc + gn] = v;
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            smem[(wm0 - 64 * hp + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half) * CLD + wn0 + j * 32 + l31] = acc[i][j][e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 64 / ROWS_PER_IT; ++it) {
+      const int rl = it * ROWS_PER_IT + tid / (BN / 4), c4 = tid % (BN / 4);
+      const int gm = m0 + 64 * hp + rl, gn = n0 + 4 * c4;
+      if (gm < p.M && gn < p.N) {
+        float4 v = *reinterpret_cast<const float4*>(&smem[rl * CLD + 4 * c4]);
+        int orow = gm;
+        if (!split && p.permP) orow = (gm % p.permP) * Q + gm / p.permP;
+        float* dst = Cout + (long)orow * ldc + gn;
+        float vv[4] = {v.x, v.y, v.z, v.w};
+        if (!split) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (gn + e < p.N) {
+              if (p.bias) vv[e] += p.bias[gn + e];
+              if (p.act == 1) vv[e] = fmaxf(vv[e], 0.f);
+            }
+        }
+        if (vecC && gn + 3 < p.N) {
+          float4 o = make_float4(vv[0], vv[1], vv[2], vv[3]);
+          if (!split && p.accumulate) { float4 c = *reinterpret_cast<const float4*>(dst); o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
+          *reinterpret_cast<float4*>(dst) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (gn + e < p.N) dst[e] = vv[e] + ((!split && p.accumulate) ? dst[e] : 0.f);
         }
       }
     }
+    __syncthreads();
+  }
 }
 
 // second stage of a split reduction: C = act(sum_z part[z] + bias) (+ C).  blockDim (32,8): 32 consecutive
@@ -226,6 +254,7 @@ extern "C" int crnn_gemm_f32(int mode, const float* A, const float* B, float* C,
   // contiguous extent of each operand: A: K (m-major) or M (k-major); B: N (k-major) or K (n-major)
   p.vecA = aligned16(A) && (lda % 4 == 0) && ((a_km ? M : K) % 4 == 0);
   p.vecB = aligned16(B) && (ldb % 4 == 0) && ((b_km ? N : K) % 4 == 0);
+  p.vecC = aligned16(C) && (ldc % 4 == 0) && (N % 4 == 0) && (!scratch || aligned16(scratch));
   const int BN = (N <= 64) ? 64 : 128;
   const int tilesM = cdiv(M, 128), tilesN = cdiv(N, BN);
   p.tilesN = tilesN;
