@@ -234,7 +234,24 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { s[e] = 0.f; q[e] = 0.f; }
     if (c < CL) {
-      for (long r = r0 + rt; r < r1; r += RT) {
+      long r = r0 + rt;
+      if (VEC == 4) {  // 4 rows in flight per thread (independent 16-byte loads)
+        for (; r + 3L * RT < r1; r += 4L * RT) {
+          float4 v0 = *reinterpret_cast<const float4*>(&x[r * ld + 4 * c]);
+          float4 v1 = *reinterpret_cast<const float4*>(&x[(r + RT) * ld + 4 * c]);
+          float4 v2 = *reinterpret_cast<const float4*>(&x[(r + 2L * RT) * ld + 4 * c]);
+          float4 v3 = *reinterpret_cast<const float4*>(&x[(r + 3L * RT) * ld + 4 * c]);
+          s[0] += (v0.x + v1.x) + (v2.x + v3.x); s[1 % VEC] += (v0.y + v1.y) + (v2.y + v3.y);
+          s[2 % VEC] += (v0.z + v1.z) + (v2.z + v3.z); s[3 % VEC] += (v0.w + v1.w) + (v2.w + v3.w);
+          if (NV == 2) {
+            q[0] += (v0.x * v0.x + v1.x * v1.x) + (v2.x * v2.x + v3.x * v3.x);
+            q[1 % VEC] += (v0.y * v0.y + v1.y * v1.y) + (v2.y * v2.y + v3.y * v3.y);
+            q[2 % VEC] += (v0.z * v0.z + v1.z * v1.z) + (v2.z * v2.z + v3.z * v3.z);
+            q[3 % VEC] += (v0.w * v0.w + v1.w * v1.w) + (v2.w * v2.w + v3.w * v3.w);
+          }
+        }
+      }
+      for (; r < r1; r += RT) {
         if (VEC == 4) {
           float4 v = *reinterpret_cast<const float4*>(&x[r * ld + 4 * c]);
           s[0] += v.x; s[1 % VEC] += v.y; s[2 % VEC] += v.z; s[3 % VEC] += v.w;
@@ -678,8 +695,14 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int n
   }
 }
 
-static inline int bn_bwd_rows_per_chunk(long M) { return M >= (1L << 19) ? 1024 : (M >= (1L << 17) ? 256 : (M >= (1L << 15) ? 64 : 16)); }
-extern "C" int crnn_bn_bwd_chunks(long M) { return cdiv(M, bn_bwd_rows_per_chunk(M)); }
+// rows per chunk: largest power of two <= 1024 that still yields >= 1024 chunks (>= 16 rows)
+static inline int bn_bwd_rows_per_chunk(long rows) { long r = 1024; while (r > 16 && rows / r < 1024) r >>= 1; return (int)r; }
+// upper bound on the number of partial rows for a [M][C] BN backward (pooled variants iterate over M/2 or M/4 windows)
+extern "C" int crnn_bn_bwd_chunks(long M) {
+  int best = 0;
+  for (int div = 1; div <= 4; div *= 2) { int c = cdiv(M / div, bn_bwd_rows_per_chunk(M / div)); if (c > best) best = c; }
+  return best;
+}
 
 template <int VEC, bool POOL>
 static int bn_bwd_launch(const BnBwdArgs& a, float* dx, float* dgamma, float* dbeta, float* parts, float* coef, hipStream_t stream) {
@@ -690,7 +713,7 @@ static int bn_bwd_launch(const BnBwdArgs& a, float* dx, float* dgamma, float* db
   // chunking is over pooled pixels for the window kernel (same number of chunks as partial rows allocated:
   // crnn_bn_bwd_chunks(M) >= chunks used here)
   const long rows = window ? M / (a.ph * a.pw) : M;
-  const int rpc = bn_bwd_rows_per_chunk(M), chunks = cdiv(rows, rpc);
+  const int rpc = bn_bwd_rows_per_chunk(rows), chunks = cdiv(rows, rpc);
   if (window) hipLaunchKernelGGL((bn_bwd_pool_kernel<1, VEC>), dim3(chunks), dim3(256), 0, stream, a, parts, nullptr, nullptr, CW, rpc);
   else hipLaunchKernelGGL((bn_bwd_kernel<1, VEC, POOL>), dim3(chunks), dim3(256), 0, stream, a, parts, nullptr, nullptr, CW, rpc);
   CRNN_LAUNCH_CHECK();
