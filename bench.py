@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE configs[1]: 256)")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="fp32 = parity mode (fp32 MFMA); bf16 = GEMM products in bf16, fp32 accumulate/storage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -127,7 +129,7 @@ def main():
     cfg = M.Config()
     p, bn = M.init_params(cfg, seed=1, dtype=np.float32)         # identical weights on every rank
     x, lab, il, ll = M.synthetic_batch(cfg, B, seed=rank)        # rank r draws its own shard
-    eng = Engine(B, dropout=True)
+    eng = Engine(B, dropout=True, precision=args.precision)
     eng.set_params(p, bn)
     xd = torch.from_numpy(x).cuda()
     labd = torch.from_numpy(lab.astype(np.int32)).cuda(); ild = torch.from_numpy(il.astype(np.int32)).cuda()
@@ -159,9 +161,9 @@ def main():
         res = {
             "metric": "text-line images/sec (train step)", "value": round(world * B * args.steps / dt, 1), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 100x32x1 text lines, batch %d/GPU, max_len 23, time_dense_size 128, "
-                                   "n_units 256 BiLSTM, STN on, dropout on, CTC, Adam(1e-4,b1=.5,clipnorm 5), fp32 MFMA" % B,
+                                   "n_units 256 BiLSTM, STN on, dropout on, CTC, Adam(1e-4,b1=.5,clipnorm 5), %s" % (B, "fp32 MFMA" if args.precision == "fp32" else "bf16 MFMA products / fp32 accumulate+storage"),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": round(last_loss, 4)},
         }
         if not args.no_roofline:

@@ -25,13 +25,16 @@ def _stream():
 
 class Engine:
     def __init__(self, batch, imgh=100, imgw=32, num_classes=38, max_len=23, time_dense_size=128, n_units=256,
-                 gru=False, stn=True, dropout=True, device=None):
+                 gru=False, stn=True, dropout=True, device=None, precision="fp32"):
         if not torch.cuda.is_available():
             raise RuntimeError("the CRNN hot path needs an AMD GPU (gfx950); there is no CPU fallback")
         self.lib = native.lib()
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.cfg = crnn_config(batch, imgh, imgw, num_classes, max_len, time_dense_size, n_units, int(bool(gru)),
-                               int(bool(stn)), int(bool(dropout)))
+                               int(bool(stn)), int(bool(dropout)), int(precision == "bf16"))
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' (parity mode) or 'bf16' (bf16 MFMA products, fp32 accumulate/storage)")
+        self.precision = precision
         self._c = ctypes.byref(self.cfg)
         nbytes = self.lib.crnn_workspace_bytes(self._c)
         if nbytes == 0:

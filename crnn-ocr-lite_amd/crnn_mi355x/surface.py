@@ -26,9 +26,9 @@ BLOCK_FILTERS = (64, 128, 256, 256, 512, 512, 512)
 BLOCK_POOL = (None, None, (2, 2), None, (1, 2), None, None)
 
 
-def _cfg_struct(batch, shape, num_classes, max_len, tds, units, gru, stn=True, dropout=True):
+def _cfg_struct(batch, shape, num_classes, max_len, tds, units, gru, stn=True, dropout=True, mfma_bf16=False):
     return native.crnn_config(int(batch), int(shape[0]), int(shape[1]), int(num_classes), int(max_len), int(tds), int(units),
-                              int(bool(gru)), int(bool(stn)), int(bool(dropout)))
+                              int(bool(gru)), int(bool(stn)), int(bool(dropout)), int(bool(mfma_bf16)))
 
 
 def param_layout(cfg):
@@ -128,7 +128,7 @@ class Model:
                 self._pull()
             c = self.config
             eng = Engine(batch, c["shape"][0], c["shape"][1], c["num_classes"], c["max_string_len"], c["time_dense_size"], c["n_units"],
-                         gru=c["GRU"], stn=True, dropout=dropout)
+                         gru=c["GRU"], stn=True, dropout=dropout, precision=os.environ.get("CRNN_PRECISION", "fp32"))
             eng.set_params(st["params"], st["bn"])
             st["engine"] = eng
         return eng

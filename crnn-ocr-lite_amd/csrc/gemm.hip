@@ -291,3 +291,5 @@ extern "C" int crnn_gemm_f32(int mode, const float* A, const float* B, float* C,
   }
   return CRNN_OK;
 }
+
+#include "gemm_bf16.inc"

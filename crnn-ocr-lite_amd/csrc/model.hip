@@ -163,8 +163,16 @@ struct Ctx {
   float* scratch() const { return ws + P.off("gemm_scratch"); }
 };
 
+// GEMMs of the conv stack / dense layers / RNN input projections: bf16 products when cfg->mfma_bf16
 int gemm(const Ctx& c, int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
          const float* bias = nullptr, int act = 0, int acc = 0, int perm = 0) {
+  if (c.cfg->mfma_bf16)
+    return crnn_gemm_bf16(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, c.scratch(), kGemmScratchBytes, c.s);
+  return crnn_gemm_f32(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, c.scratch(), kGemmScratchBytes, c.s);
+}
+// always-fp32 GEMM (spatial-transformer localisation net: tiny, and theta is precision-sensitive)
+int gemm32(const Ctx& c, int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+           const float* bias = nullptr, int act = 0, int acc = 0, int perm = 0) {
   return crnn_gemm_f32(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, c.scratch(), kGemmScratchBytes, c.s);
 }
 
@@ -248,13 +256,13 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
     CRNN_TRY(crnn_maxpool_fwd(x, c.w("pool1"), B, d.H0, d.W0, 1, 2, 2, stream));
     CRNN_TRY(crnn_im2col(c.w("pool1"), c.w("col1"), B, d.Hs1, d.Ws1, 1, 5, stream));
     int R1 = B * d.Ho1 * d.Wo1;
-    CRNN_TRY(gemm(c, 0, c.w("col1"), c.p("stn_c1_k"), c.w("c1"), R1, 20, 25, 25, 20, 20, c.p("stn_c1_b")));
+    CRNN_TRY(gemm32(c, 0, c.w("col1"), c.p("stn_c1_k"), c.w("c1"), R1, 20, 25, 25, 20, 20, c.p("stn_c1_b")));
     CRNN_TRY(crnn_maxpool_fwd(c.w("c1"), c.w("pool2"), B, d.Ho1, d.Wo1, 20, 2, 2, stream));
     CRNN_TRY(crnn_im2col(c.w("pool2"), c.w("col2"), B, d.Hs2, d.Ws2, 20, 5, stream));
     int R2 = B * d.Ho2 * d.Wo2;
-    CRNN_TRY(gemm(c, 0, c.w("col2"), c.p("stn_c2_k"), c.w("flat"), R2, 20, 500, 500, 20, 20, c.p("stn_c2_b")));
-    CRNN_TRY(gemm(c, 0, c.w("flat"), c.p("stn_d1_w"), c.w("fc1"), B, 50, d.stn_flat, d.stn_flat, 50, 50, c.p("stn_d1_b"), 1));
-    CRNN_TRY(gemm(c, 0, c.w("fc1"), c.p("stn_d2_w"), c.w("theta"), B, 6, 50, 50, 6, 6, c.p("stn_d2_b")));
+    CRNN_TRY(gemm32(c, 0, c.w("col2"), c.p("stn_c2_k"), c.w("flat"), R2, 20, 500, 500, 20, 20, c.p("stn_c2_b")));
+    CRNN_TRY(gemm32(c, 0, c.w("flat"), c.p("stn_d1_w"), c.w("fc1"), B, 50, d.stn_flat, d.stn_flat, 50, 50, c.p("stn_d1_b"), 1));
+    CRNN_TRY(gemm32(c, 0, c.w("fc1"), c.p("stn_d2_w"), c.w("theta"), B, 6, 50, 50, 6, 6, c.p("stn_d2_b")));
     CRNN_TRY(crnn_sampler_fwd(x, c.w("theta"), c.w("x0"), B, d.H0, d.W0, 2, stream));
   } else {
     CRNN_TRY(crnn_pad_copy(x, c.w("x0"), B, d.H0, d.W0, 2, stream));
@@ -410,20 +418,20 @@ extern "C" int crnn_backward(const crnn_config* cfg, const float* params, float*
   // ---- spatial transformer
   if (cfg->stn) {
     CRNN_TRY(crnn_sampler_bwd(x, c.w("theta"), gA, c.w("dtheta"), B, d.H0, d.W0, 2, stream));
-    CRNN_TRY(gemm(c, 2, c.w("fc1"), c.w("dtheta"), c.g("stn_d2_w"), 50, 6, B, 50, 6, 6));
+    CRNN_TRY(gemm32(c, 2, c.w("fc1"), c.w("dtheta"), c.g("stn_d2_w"), 50, 6, B, 50, 6, 6));
     CRNN_TRY(colsum(c, c.w("dtheta"), B, 6, 6, c.g("stn_d2_b")));
-    CRNN_TRY(gemm(c, 1, c.w("dtheta"), c.p("stn_d2_w"), c.w("dfc1"), B, 50, 6, 6, 6, 50));
+    CRNN_TRY(gemm32(c, 1, c.w("dtheta"), c.p("stn_d2_w"), c.w("dfc1"), B, 50, 6, 6, 6, 50));
     CRNN_TRY(crnn_relu_bwd(c.w("fc1"), c.w("dfc1"), c.w("dfc1"), B, 50, 1.f, 0, stream));
-    CRNN_TRY(gemm(c, 2, c.w("flat"), c.w("dfc1"), c.g("stn_d1_w"), d.stn_flat, 50, B, d.stn_flat, 50, 50));
+    CRNN_TRY(gemm32(c, 2, c.w("flat"), c.w("dfc1"), c.g("stn_d1_w"), d.stn_flat, 50, B, d.stn_flat, 50, 50));
     CRNN_TRY(colsum(c, c.w("dfc1"), B, 50, 50, c.g("stn_d1_b")));
-    CRNN_TRY(gemm(c, 1, c.w("dfc1"), c.p("stn_d1_w"), c.w("dflat"), B, d.stn_flat, 50, 50, 50, d.stn_flat));
+    CRNN_TRY(gemm32(c, 1, c.w("dfc1"), c.p("stn_d1_w"), c.w("dflat"), B, d.stn_flat, 50, 50, 50, d.stn_flat));
     const int R2 = B * d.Ho2 * d.Wo2, R1 = B * d.Ho1 * d.Wo1;
-    CRNN_TRY(gemm(c, 2, c.w("col2"), c.w("dflat"), c.g("stn_c2_k"), 500, 20, R2, 500, 20, 20));
+    CRNN_TRY(gemm32(c, 2, c.w("col2"), c.w("dflat"), c.g("stn_c2_k"), 500, 20, R2, 500, 20, 20));
     CRNN_TRY(colsum(c, c.w("dflat"), R2, 20, 20, c.g("stn_c2_b")));
-    CRNN_TRY(gemm(c, 1, c.w("dflat"), c.p("stn_c2_k"), c.w("dcol2"), R2, 500, 20, 20, 20, 500));
+    CRNN_TRY(gemm32(c, 1, c.w("dflat"), c.p("stn_c2_k"), c.w("dcol2"), R2, 500, 20, 20, 20, 500));
     CRNN_TRY(crnn_col2im(c.w("dcol2"), c.w("dpool2"), B, d.Hs2, d.Ws2, 20, 5, stream));
     CRNN_TRY(crnn_maxpool_bwd(c.w("c1"), c.w("dpool2"), c.w("dc1"), B, d.Ho1, d.Wo1, 20, 2, 2, stream));
-    CRNN_TRY(gemm(c, 2, c.w("col1"), c.w("dc1"), c.g("stn_c1_k"), 25, 20, R1, 25, 20, 20));
+    CRNN_TRY(gemm32(c, 2, c.w("col1"), c.w("dc1"), c.g("stn_c1_k"), 25, 20, R1, 25, 20, 20));
     CRNN_TRY(colsum(c, c.w("dc1"), R1, 20, 20, c.g("stn_c1_b")));
   }
   return CRNN_OK;

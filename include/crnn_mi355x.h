@@ -33,6 +33,8 @@ typedef struct {
   int gru;          /* 0 = LSTM (utils.py:78-79), 1 = GRU (utils.py:81-82) */
   int stn;          /* 1 = spatial transformer enabled (utils.py:62) */
   int dropout;      /* 1 = Dropout(.1/.4/.2) active in train mode (utils.py:56,75,83); 0 = off (parity runs) */
+  int mfma_bf16;    /* 0 = fp32 MFMA everywhere (parity mode); 1 = conv-stack / dense / RNN-input GEMMs multiply in bf16
+                       (operands rounded while staged into LDS, fp32 accumulate, fp32 tensors in HBM) */
 } crnn_config;
 
 /* ---- parameter / statistics layout (Keras weight order) -------------------------------------- */
@@ -91,6 +93,10 @@ int crnn_ctc_beam_decode(const float* y, const int* input_len, int* out, int* ou
 int crnn_gemm_f32(int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                   const float* bias, int act, int accumulate, int permP, float* scratch, size_t scratch_bytes,
                   crnn_stream_t stream);
+/* same contract, products in bf16 on v_mfma_f32_32x32x16_bf16 (fp32 accumulate, fp32 operands/result in HBM) */
+int crnn_gemm_bf16(int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                   const float* bias, int act, int accumulate, int permP, float* scratch, size_t scratch_bytes,
+                   crnn_stream_t stream);
 /* DepthwiseConv2D 3x3 'same' (utils.py:44): k [9][C]; flip=1 = data gradient; stat_partials [tiles][2][C] */
 int crnn_dwconv_num_tiles(int B, int H, int W);
 int crnn_dwconv3x3_fwd(const float* x, const float* k, float* out, float* stat_partials, int B, int H, int W, int C,

@@ -9,6 +9,7 @@ L = native.lib()
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 S = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 B = 256
+FN = L.crnn_gemm_bf16 if '--bf16' in sys.argv else L.crnn_gemm_f32
 scr = torch.empty(32 * 1024 * 1024, device="cuda")
 shapes = []
 h, w, cin = 104, 36, 1
@@ -27,7 +28,7 @@ for name, mode, M, N, K in shapes:
     else: A = torch.randn(K, M, device="cuda"); Bm = torch.randn(K, N, device="cuda"); lda, ldb = M, N
     C = torch.empty(M, N, device="cuda")
     def run():
-        r = L.crnn_gemm_f32(mode, P(A), P(Bm), P(C), M, N, K, lda, ldb, N, None, 0, 0, 0, P(scr), 128 * 1024 * 1024, S())
+        r = FN(mode, P(A), P(Bm), P(C), M, N, K, lda, ldb, N, None, 0, 0, 0, P(scr), 128 * 1024 * 1024, S())
         assert r == 0
     for _ in range(2): run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -255,3 +255,26 @@ def test_train_steps_are_deterministic_and_loss_decreases():
     assert losses[0] == losses[1], "train step is not run-to-run deterministic"
     assert torch.equal(first, final)
     assert np.isfinite(losses[0]).all() and losses[0][-1] < losses[0][0]
+
+
+def test_bf16_mfma_mode_tracks_the_fp32_oracle():
+    """Fast mode (crnn_config.mfma_bf16): GEMM products in bf16, everything else fp32.  Not a parity mode: the
+    forward must stay within bf16 round-off of the oracle and the gradients must point the same way."""
+    cfg = M.Config()
+    B = 8
+    p, bn = M.init_params(cfg, seed=7, dtype=np.float64)
+    p = M.randomize_params(cfg, p)
+    x, lab, il, ll = M.synthetic_batch(cfg, B, seed=1, dtype=np.float64)
+    eng = Engine(B, dropout=False, precision="bf16")
+    eng.set_params(p, bn)
+    yd = eng.forward(x.astype(np.float32), train=True, seed=0).cpu().numpy()
+    loss_d = eng.backward(lab, il, ll, seed=0).cpu().numpy()
+    gd = eng.get_grads()
+    loss, loss_b, g, c = M.loss_and_grads(cfg, p, bn, x, lab, il, ll)
+    err_y = np.abs(yd - c["y_pred"]).max()
+    agree = (np.argmax(yd, -1) == np.argmax(c["y_pred"], -1)).mean()
+    rel_loss = np.abs(loss_d - loss_b).max() / np.abs(loss_b).max()
+    cos = {k: float((gd[k].ravel() @ g[k].ravel()) / (np.linalg.norm(gd[k]) * np.linalg.norm(g[k]) + 1e-30)) for k in p if g[k].size >= 512}
+    print(f"[bf16] max|dy|={err_y:.3e} argmax agreement={agree:.4f} rel loss err={rel_loss:.3e} min grad cosine={min(cos.values()):.4f}")
+    assert err_y < 5e-2 and agree > 0.97 and rel_loss < 2e-2
+    assert min(cos.values()) > 0.98, {k: v for k, v in cos.items() if v < 0.99}

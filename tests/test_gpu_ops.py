@@ -69,6 +69,37 @@ def test_gemm_split_reduction_large_k():
     assert_close(host(C3), ref, rtol=2e-4, what="NN split+epilogue")
 
 
+def _bf16_round(a):
+    """round-to-nearest-even to bfloat16, returned as float64 (what v_cvt_pk_bf16_f32 does to the staged operands)"""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.view(np.float32).astype(np.float64)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(300, 130, 70), (128, 64, 64), (1000, 38, 512), (77, 20, 25), (513, 257, 129), (260, 1, 64),
+                                   (64, 128, 5000)])
+def test_gemm_bf16_mode_equals_fp32_accumulation_of_bf16_rounded_operands(mode, shape):
+    Mm, N, K = shape
+    rs = np.random.RandomState(Mm + N + K + mode)
+    A = rs.normal(size=(Mm, K)).astype(np.float32); B = rs.normal(size=(K, N)).astype(np.float32)
+    ref = _bf16_round(A) @ _bf16_round(B)
+    if mode == 0:
+        Ad, Bd, lda, ldb = dev(A), dev(B), K, N
+    elif mode == 1:
+        Ad, Bd, lda, ldb = dev(A), dev(B.T), K, K
+    else:
+        Ad, Bd, lda, ldb = dev(A.T), dev(B), Mm, N
+    C = zeros(Mm, N); scr = zeros(16 * 1024 * 1024)
+    bias = rs.normal(size=N)
+    ok(L().crnn_gemm_bf16(mode, P(Ad), P(Bd), P(C), Mm, N, K, lda, ldb, N, P(dev(bias)), 1, 0, 0, P(scr), 64 * 1024 * 1024, S()))
+    assert_close(host(C), np.maximum(ref + bias, 0), rtol=2e-5, atol=1e-4, what="bf16 products, fp32 accumulate")
+    # and it is within bf16 round-off of the exact product
+    ok(L().crnn_gemm_bf16(mode, P(Ad), P(Bd), P(C), Mm, N, K, lda, ldb, N, None, 0, 0, 0, P(scr), 64 * 1024 * 1024, S()))
+    exact = A.astype(np.float64) @ B.astype(np.float64)
+    assert np.abs(host(C) - exact).max() < 2.0 ** -7 * np.sqrt(K) * 4
+
+
 # ------------------------------------------------------------------------------------------------ depthwise conv
 @pytest.mark.parametrize("shape", [(3, 20, 12, 64), (2, 9, 7, 32), (2, 13, 36, 128), (2, 10, 6, 1), (1, 5, 9, 96)])
 def test_dwconv_fwd_flip_wgrad_stats(shape):
