@@ -24,16 +24,54 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (not the 2:1-sparsity figure)
 PEAK_HBM_GBS = 8000.0
 
 
-def pointwise_gemm_roofline(eng, iters=5):
-    """Dominant kernel = gemm_f32_kernel<128,false,true> (NN fp32 MFMA GEMM: the pointwise 1x1 convs b2..b7,
-    dense1 and the RNN input projections).  Re-issue exactly those launches of one step on the live buffers,
-    bracketed by events on the stream they run on, and report flops / time."""
-    import ctypes
+def depthwise_roofline(eng, iters=5):
+    """Dominant kernel of the step (rocprofv3: largest total time) = dwconv_tile_kernel<0>: the depthwise 3x3 of
+    blocks 2..7, forward (with the BatchNorm-statistics epilogue) and data-gradient (flipped taps) = 12 launches per
+    step.  HBM-bound.  Re-issue exactly those launches on the live buffers between events on the launch stream.
+    Algorithmic bytes per launch = read H*W*C + write H*W*C fp32 per image, weights negligible."""
     from crnn_mi355x.engine import _ptr, _stream
     lib = eng.lib
+    B = eng.B
+    blocks = [(64, 1, 1), (128, 1, 1), (256, 2, 2), (256, 1, 1), (512, 1, 2), (512, 1, 1), (512, 1, 1)]
+    h, w, cin = eng.cfg.imgh + 4, eng.cfg.imgw + 4, 1
+    launches, nbytes = [], 0.0
+    parts = eng.ws_tensor("partials")
+    for i, (co, ph, pw) in enumerate(blocks, 1):
+        if i >= 2:
+            k = eng.params[eng.layout["b%d_dw" % i][0]:]
+            launches.append((eng.ws_tensor("x%d" % (i - 1)), k, eng.ws_tensor("d%d" % i), parts, h, w, cin, 0))   # forward
+            launches.append((eng.ws_tensor("gB"), k, eng.ws_tensor("gA"), None, h, w, cin, 1))                    # data gradient
+            nbytes += 2 * (2.0 * B * h * w * cin * 4)
+        h, w, cin = h // ph, w // pw, co
+    times = []
+    for it in range(iters + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for x, k, o, pt, hh, ww, cc, flip in launches:
+            lib.crnn_dwconv3x3_fwd(_ptr(x), _ptr(k), _ptr(o), _ptr(pt), B, hh, ww, cc, flip, _stream())
+        e1.record()
+        torch.cuda.synchronize()
+        if it:
+            times.append(e0.elapsed_time(e1) * 1e-3)
+    t = float(np.median(times))
+    ach = nbytes / t / 1e9
+    return {"bound": "hbm", "kernel": "dwconv_tile_kernel<0> (depthwise 3x3 fwd + data-gradient, blocks 2-7, LDS halo tiles)",
+            "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
+            "launches": len(launches), "avg_launch_ms": round(1e3 * t / len(launches), 4),
+            "algorithmic_bytes_per_launch_set": nbytes, "traffic": None}
+
+
+def pointwise_gemm_roofline(eng, iters=5):
+    """Secondary: the NN GEMM family (pointwise 1x1 convs b2..b7 fwd, dense1, RNN input projections) of one step on the
+    live buffers: flops / time against the MFMA peak of the active mode."""
+    from crnn_mi355x.engine import _ptr, _stream
+    lib = eng.lib
+    fn = lib.crnn_gemm_bf16 if eng.precision == "bf16" else lib.crnn_gemm_f32
+    peak = PEAK_BF16_MFMA_TFLOPS if eng.precision == "bf16" else PEAK_F32_MFMA_TFLOPS
     B, T = eng.B, eng.T
     cfgs = []
     h, w, cin = eng.cfg.imgh + 4, eng.cfg.imgw + 4, 1
@@ -56,16 +94,16 @@ def pointwise_gemm_roofline(eng, iters=5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for A, Bm, C, M, N, K in cfgs:
-            lib.crnn_gemm_f32(0, _ptr(A), _ptr(Bm), _ptr(C), M, N, K, K, N, N, None, 0, 0, 0, _ptr(scratch), 128 * 1024 * 1024, _stream())
+            fn(0, _ptr(A), _ptr(Bm), _ptr(C), M, N, K, K, N, N, None, 0, 0, 0, _ptr(scratch), 128 * 1024 * 1024, _stream())
         e1.record()
         torch.cuda.synchronize()
         if it:
             times.append(e0.elapsed_time(e1) * 1e-3)
     t = float(np.median(times))
     ach = flops / t / 1e12
-    return {"bound": "mfma", "kernel": "gemm_f32_kernel (fp32 MFMA 32x32x2, pointwise 1x1 convs + dense1 + RNN input GEMMs)",
-            "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-            "launches": len(cfgs), "avg_launch_ms": round(1e3 * t / len(cfgs), 4), "flops_per_step_set": flops, "traffic": None}
+    return {"bound": "mfma", "kernel": "gemm_%s_kernel<128,false,true> (pointwise 1x1 convs fwd + dense1 + RNN input GEMMs)" % ("bf16" if eng.precision == "bf16" else "f32"),
+            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "launches": len(cfgs), "avg_launch_ms": round(1e3 * t / len(cfgs), 4), "flops_per_launch_set": flops}
 
 
 def cpu_baseline(seconds_target=15.0):
@@ -101,7 +139,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE configs[1]: 256)")
-    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="bf16",
                     help="fp32 = parity mode (fp32 MFMA); bf16 = GEMM products in bf16, fp32 accumulate/storage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -167,7 +205,8 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": round(last_loss, 4)},
         }
         if not args.no_roofline:
-            res["roofline"] = pointwise_gemm_roofline(eng)
+            res["roofline"] = depthwise_roofline(eng)
+            res["gemm_roofline"] = pointwise_gemm_roofline(eng)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

@@ -28,14 +28,24 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const float* __restric
   const int b = blockIdx.y / nHb, h0 = (blockIdx.y % nHb) * TH;
   const int Wt = W + 2;
   const int n4 = (TH + 2) * Wt * 8;
-  for (int i = tid; i < n4; i += 256) {
-    int ci = i & 7, pix = i >> 3;
-    int ly = pix / Wt, lx = pix - ly * Wt;
-    int gh = h0 + ly - 1, gw = lx - 1;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (gh >= 0 && gh < H && gw >= 0 && gw < W)
-      v = *reinterpret_cast<const float4*>(&x[(((long)b * H + gh) * W + gw) * C + cc0 + 4 * ci]);
-    tile[i] = v;
+  // halo-tile fill: 4 independent 16-byte loads in flight per thread before the LDS writes
+  for (int base = tid; base < n4; base += 1024) {
+    float4 v[4];
+#pragma unroll
+    for (int uu = 0; uu < 4; ++uu) {
+      int i = base + uu * 256;
+      int ci = i & 7, pix = i >> 3;
+      int ly = pix / Wt, lx = pix - ly * Wt;
+      int gh = h0 + ly - 1, gw = lx - 1;
+      v[uu] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < n4 && gh >= 0 && gh < H && gw >= 0 && gw < W)
+        v[uu] = *reinterpret_cast<const float4*>(&x[(((long)b * H + gh) * W + gw) * C + cc0 + 4 * ci]);
+    }
+#pragma unroll
+    for (int uu = 0; uu < 4; ++uu) {
+      int i = base + uu * 256;
+      if (i < n4) tile[i] = v[uu];
+    }
   }
   float4 kw[9];
   if (MODE == 0) {
@@ -53,6 +63,9 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const float* __restric
     for (int t = 0; t < 9; ++t) dk[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const int npix = TH * W;
+  float4 gnext = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (MODE == 1 && pt < npix && h0 + pt / W < H)
+    gnext = *reinterpret_cast<const float4*>(&g[(((long)b * H + h0 + pt / W) * W + (pt % W)) * C + cc0 + 4 * c4]);
   for (int p = pt; p < npix; p += 32) {
     int ly = p / W, lx = p - ly * W;
     int gh = h0 + ly;
@@ -72,7 +85,11 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const float* __restric
       s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
       ss.x = fmaf(a.x, a.x, ss.x); ss.y = fmaf(a.y, a.y, ss.y); ss.z = fmaf(a.z, a.z, ss.z); ss.w = fmaf(a.w, a.w, ss.w);
     } else {
-      float4 gv = *reinterpret_cast<const float4*>(&g[o]);
+      float4 gv = gnext;
+      {  // prefetch the upstream gradient of this thread's next pixel
+        int pn = p + 32, lyn = pn / W, lxn = pn - lyn * W;
+        if (pn < npix && h0 + lyn < H) gnext = *reinterpret_cast<const float4*>(&g[(((long)b * H + h0 + lyn) * W + lxn) * C + cc0 + 4 * c4]);
+      }
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
