@@ -6,6 +6,7 @@
 //   generic column reductions.
 // All kernels are HBM-bandwidth bound; the pointwise 1x1 convs go through gemm.hip.
 #include "common.h"
+#include <stdlib.h>
 
 #define BN_EPS 1e-3f
 
@@ -197,7 +198,9 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_c1_kernel(const float* __res
 }
 
 static int dw_pick_th(int W, size_t* lds) {
-  int TH = 8;
+  static int th_env = -1;   // experiment hook: CRNN_DW_TH overrides the tile height
+  if (th_env < 0) { const char* e = getenv("CRNN_DW_TH"); th_env = e ? atoi(e) : 0; }
+  int TH = th_env > 0 ? th_env : 8;
   for (;;) {
     size_t tile = (size_t)(TH + 2) * (W + 2) * 128;
     size_t red = (size_t)9 * 32 * 128;  // weight-grad reduction scratch
