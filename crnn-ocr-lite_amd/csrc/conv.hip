@@ -197,22 +197,25 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_c1_kernel(const float* __res
   if (threadIdx.x < 9) partials[(long)blockIdx.x * 9 + threadIdx.x] = red[threadIdx.x][0];
 }
 
-static int dw_pick_th(int W, size_t* lds) {
+// Tile height: as tall as a ~48 KiB halo tile allows (3 workgroups per CU), then balanced over the bands of H.
+static int dw_pick_th2(int H, int W, size_t* lds) {
   static int th_env = -1;   // experiment hook: CRNN_DW_TH overrides the tile height
   if (th_env < 0) { const char* e = getenv("CRNN_DW_TH"); th_env = e ? atoi(e) : 0; }
-  int TH = th_env > 0 ? th_env : 8;
-  for (;;) {
-    size_t tile = (size_t)(TH + 2) * (W + 2) * 128;
-    size_t red = (size_t)9 * 32 * 128;  // weight-grad reduction scratch
-    *lds = tile > red ? tile : red;
-    if (*lds <= 64 * 1024 || TH == 1) return TH;
-    TH >>= 1;
-  }
+  const size_t red = (size_t)9 * 32 * 128;  // weight-grad reduction scratch
+  int thmax = (int)(49152 / ((size_t)(W + 2) * 128)) - 2;
+  if (thmax < 1) thmax = 1;
+  if (thmax > H) thmax = H;
+  int nb = (H + thmax - 1) / thmax;
+  int TH = (H + nb - 1) / nb;
+  if (th_env > 0) TH = th_env;
+  size_t tile = (size_t)(TH + 2) * (W + 2) * 128;
+  *lds = tile > red ? tile : red;
+  return TH;
 }
 
 // number of row-band tiles (= partial rows) the tiled kernels produce for a (B,H,W) map
 extern "C" int crnn_dwconv_num_tiles(int B, int H, int W) {
-  size_t lds; int TH = dw_pick_th(W, &lds);
+  size_t lds; int TH = dw_pick_th2(H, W, &lds);
   return B * cdiv(H, TH);
 }
 
@@ -221,8 +224,12 @@ extern "C" int crnn_dwconv_num_tiles(int B, int H, int W) {
 extern "C" int crnn_dwconv3x3_fwd(const float* x, const float* k, float* out, float* stat_partials, int B, int H, int W,
                                   int C, int flip, hipStream_t stream) {
   if (C % 32 == 0) {
-    size_t lds; int TH = dw_pick_th(W, &lds);
-    if (lds > 64 * 1024) return CRNN_ERR_UNSUPPORTED;
+    size_t lds; int TH = dw_pick_th2(H, W, &lds);
+    if (lds > 160 * 1024) return CRNN_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024) {
+      static bool attr0 = false;
+      if (!attr0) { hipFuncSetAttribute((const void*)dwconv_tile_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr0 = true; }
+    }
     dim3 grid(C / 32, B * cdiv(H, TH));
     hipLaunchKernelGGL(dwconv_tile_kernel<0>, grid, dim3(256), lds, stream, x, k, nullptr, out, stat_partials, B, H, W, C, TH, flip);
   } else {
@@ -351,8 +358,12 @@ extern "C" int crnn_partials_sum(const float* partials, int nparts, int n, float
 extern "C" int crnn_dwconv3x3_wgrad(const float* x, const float* g, float* dk, float* scratch, int B, int H, int W, int C,
                                     hipStream_t stream) {
   if (C % 32 == 0) {
-    size_t lds; int TH = dw_pick_th(W, &lds);
-    if (lds > 64 * 1024) return CRNN_ERR_UNSUPPORTED;
+    size_t lds; int TH = dw_pick_th2(H, W, &lds);
+    if (lds > 160 * 1024) return CRNN_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024) {
+      static bool attr1 = false;
+      if (!attr1) { hipFuncSetAttribute((const void*)dwconv_tile_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
+    }
     int ntiles = B * cdiv(H, TH);
     dim3 grid(C / 32, ntiles);
     hipLaunchKernelGGL(dwconv_tile_kernel<1>, grid, dim3(256), lds, stream, x, nullptr, g, nullptr, scratch, B, H, W, C, TH, 0);

@@ -13,6 +13,58 @@
 // epilogue; dW/dU/dx/db are whole-sequence GEMMs afterwards.
 #include "common.h"
 
+// ----------------------------------------------------------------------------------------------------------
+// Shared step-GEMM tile: acc[g] (16x16, MFMA C/D layout) = sum_k A[b0+r][k] * Brow_g[j0+r'][k] over this wave's
+// quarter of K, then reduced across the 4 waves into red[.][g][256] (row-major 16x16).  arow / brow are this
+// lane's row pointers (k contiguous).  The loads of PD k-chunks (16 k each) are all issued before their MFMAs, so
+// a wave pays the L2 latency once per group instead of once per chunk (the step kernels are latency-bound).
+// ----------------------------------------------------------------------------------------------------------
+template <int NG, int PD>
+__device__ __forceinline__ void step_tile_gemm(const float* arow, bool valid, const float* (&brow)[NG], int K, bool skip,
+                                               float (*red)[NG][256], int wave, int r, int q) {
+  f32x4 acc[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (!skip) {
+    const int kw = K >> 2, kbeg = wave * kw, kend = kbeg + kw;
+    int kb = kbeg;
+    for (; kb + 16 * PD <= kend; kb += 16 * PD) {
+      float4 a4[PD], b4[NG][PD];
+#pragma unroll
+      for (int c = 0; c < PD; ++c) {
+        a4[c] = valid ? *reinterpret_cast<const float4*>(arow + kb + 16 * c + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) b4[g][c] = *reinterpret_cast<const float4*>(brow[g] + kb + 16 * c + 4 * q);
+      }
+#pragma unroll
+      for (int c = 0; c < PD; ++c)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].x, b4[g][c].x, acc[g], 0, 0, 0);
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].y, b4[g][c].y, acc[g], 0, 0, 0);
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].z, b4[g][c].z, acc[g], 0, 0, 0);
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].w, b4[g][c].w, acc[g], 0, 0, 0);
+        }
+    }
+    for (; kb < kend; kb += 16) {
+      float4 a4 = valid ? *reinterpret_cast<const float4*>(arow + kb + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        float4 b4 = *reinterpret_cast<const float4*>(brow[g] + kb + 4 * q);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc[g], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wave][g][(q * 4 + e) * 16 + r] = acc[g][e];  // C/D: row = 4q+e, col = r
+  __syncthreads();
+}
+
 struct LstmDir {
   const float* xw;   // [T][B][4u]  x*W + b
   const float* wt;   // fwd: U^T [4u][u] ; bwd: U [u][4u]
@@ -31,30 +83,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmDir d0, LstmDir 
   const int t = dir ? T - 1 - s : s, tp = dir ? t + 1 : t - 1;
   const int b0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
-  f32x4 acc[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (s > 0) {
-    const int kw = u >> 2, kbeg = wave * kw;
+  {
     const bool valid = (b0 + r) < B;
-    const float* hrow = d.h + ((long)tp * B + (valid ? b0 + r : 0)) * d.ldh;
-    for (int kb = kbeg; kb < kbeg + kw; kb += 16) {
-      float4 a4 = valid ? *reinterpret_cast<const float4*>(hrow + kb + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float4 b4 = *reinterpret_cast<const float4*>(d.wt + ((long)(g * u + j0 + r)) * u + kb + 4 * q);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc[g], 0, 0, 0);
-      }
-    }
+    const float* arow = d.h + ((long)(s > 0 ? tp : t) * B + (valid ? b0 + r : 0)) * d.ldh;
+    const float* brow[4] = {d.wt + (long)(j0 + r) * u, d.wt + (long)(u + j0 + r) * u, d.wt + (long)(2 * u + j0 + r) * u,
+                            d.wt + (long)(3 * u + j0 + r) * u};
+    step_tile_gemm<4, 4>(arow, valid, brow, u, s == 0, red, wave, r, q);
   }
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) red[wave][g][(q * 4 + e) * 16 + r] = acc[g][e];  // C/D: row = 4q+e, col = r
-  __syncthreads();
   const int row = tid >> 4, col = tid & 15, b = b0 + row, j = j0 + col;
   if (b < B) {
     float z[4];
@@ -75,7 +110,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmDir d0, LstmDir 
 
 // sb = 0..T-1 counts backward steps; the time handled is the (T-1-sb)-th in processing order
 __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmDir d0, LstmDir d1, int sb, int T, int B, int u) {
-  __shared__ float red[4][256];
+  __shared__ float red4[4][1][256];
+  float (*red)[256] = reinterpret_cast<float (*)[256]>(red4);
   const LstmDir d = blockIdx.z ? d1 : d0;
   const int dir = blockIdx.z;
   const int sp = T - 1 - sb;                       // processing index of this time in the forward pass
@@ -84,25 +120,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmDir d0, LstmDir 
   const int tprev = dir ? t + 1 : t - 1;           // processed before t in forward order
   const int b0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
-  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int K = 4 * u;
-  if (sb > 0) {
-    const int kw = K >> 2, kbeg = wave * kw;
+  {
     const bool valid = (b0 + r) < B;
-    const float* arow = d.dz + ((long)tnext * B + (valid ? b0 + r : 0)) * K;
-    const float* brow = d.wt + (long)(j0 + r) * K;
-    for (int kb = kbeg; kb < kbeg + kw; kb += 16) {
-      float4 a4 = valid ? *reinterpret_cast<const float4*>(arow + kb + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 b4 = *reinterpret_cast<const float4*>(brow + kb + 4 * q);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc, 0, 0, 0);
-    }
+    const float* arow = d.dz + ((long)(sb > 0 ? tnext : t) * B + (valid ? b0 + r : 0)) * K;
+    const float* brow[1] = {d.wt + (long)(j0 + r) * K};
+    step_tile_gemm<1, 8>(arow, valid, brow, K, sb == 0, red4, wave, r, q);
   }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) red[wave][(q * 4 + e) * 16 + r] = acc[e];
-  __syncthreads();
   const int row = tid >> 4, col = tid & 15, b = b0 + row, j = j0 + col;
   if (b < B) {
     float dh = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + d.dout[((long)t * B + b) * d.ldo + j];
@@ -180,35 +204,6 @@ struct GruDir {
   float* dhp;         // [B][u] dh*z + d(rh)*r carried to the previous step
 };
 
-// acc[g] (16x16 tile, C/D layout) = sum_k A[b0+r][k] * Brow_g[j0+r'][k] over this wave's K slice; reduced
-// across the 4 waves into red[.][g][256] (row-major 16x16).  arow/brow are this lane's row pointers.
-template <int NG>
-__device__ __forceinline__ void step_tile_gemm(const float* arow, bool valid, const float* (&brow)[NG], int K, bool skip,
-                                               float (*red)[NG][256], int wave, int r, int q) {
-  f32x4 acc[NG];
-#pragma unroll
-  for (int g = 0; g < NG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (!skip) {
-    const int kw = K >> 2, kbeg = wave * kw;
-    for (int kb = kbeg; kb < kbeg + kw; kb += 16) {
-      float4 a4 = valid ? *reinterpret_cast<const float4*>(arow + kb + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        float4 b4 = *reinterpret_cast<const float4*>(brow[g] + kb + 4 * q);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc[g], 0, 0, 0);
-      }
-    }
-  }
-#pragma unroll
-  for (int g = 0; g < NG; ++g)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) red[wave][g][(q * 4 + e) * 16 + r] = acc[g][e];
-  __syncthreads();
-}
-
 #define STEP_IDS()                                                                                   \
   const int b0 = blockIdx.y * 16, j0 = blockIdx.x * 16;                                              \
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;       \
@@ -223,7 +218,7 @@ __global__ __launch_bounds__(256) void gru_fwd_zr_kernel(GruDir d0, GruDir d1, i
   STEP_IDS();
   const float* arow = d.h + ((long)(s > 0 ? tp : t) * B + ar) * d.ldh;
   const float* brow[2] = {d.w + (long)(j0 + r) * u, d.w + (long)(u + j0 + r) * u};
-  step_tile_gemm<2>(arow, valid, brow, u, s == 0, red, wave, r, q);
+  step_tile_gemm<2, 4>(arow, valid, brow, u, s == 0, red, wave, r, q);
   if (b < B) {
     const float* xw = d.xw + ((long)t * B + b) * 3 * u;
     float zz = ((red[0][0][tid] + red[1][0][tid]) + (red[2][0][tid] + red[3][0][tid])) + xw[j];
@@ -243,7 +238,7 @@ __global__ __launch_bounds__(256) void gru_fwd_h_kernel(GruDir d0, GruDir d1, in
   STEP_IDS();
   const float* arow = d.rh + ((long)t * B + ar) * u;
   const float* brow[1] = {d.w + (long)(2 * u + j0 + r) * u};
-  step_tile_gemm<1>(arow, valid, brow, u, s == 0, red, wave, r, q);
+  step_tile_gemm<1, 4>(arow, valid, brow, u, s == 0, red, wave, r, q);
   if (b < B) {
     float* gt = d.gates + ((long)t * B + b) * 3 * u;
     float pre = ((red[0][0][tid] + red[1][0][tid]) + (red[2][0][tid] + red[3][0][tid])) + d.xw[((long)t * B + b) * 3 * u + 2 * u + j];
@@ -262,7 +257,7 @@ __global__ __launch_bounds__(256) void gru_bwd_b_kernel(GruDir d0, GruDir d1, in
   STEP_IDS();
   const float* arow = d.dz + ((long)(sb > 0 ? tnext : t) * B + ar) * 3 * u;
   const float* brow[1] = {d.w + (long)(j0 + r) * 3 * u};
-  step_tile_gemm<1>(arow, valid, brow, 2 * u, sb == 0, red, wave, r, q);
+  step_tile_gemm<1, 8>(arow, valid, brow, 2 * u, sb == 0, red, wave, r, q);
   if (b < B) {
     float dh = d.dout[((long)t * B + b) * d.ldo + j];
     if (sb > 0) dh += ((red[0][0][tid] + red[1][0][tid]) + (red[2][0][tid] + red[3][0][tid])) + d.dhp[(long)b * u + j];
@@ -284,7 +279,7 @@ __global__ __launch_bounds__(256) void gru_bwd_a_kernel(GruDir d0, GruDir d1, in
   STEP_IDS();
   const float* arow = d.dz + ((long)t * B + ar) * 3 * u + 2 * u;
   const float* brow[1] = {d.w + (long)(j0 + r) * 3 * u + 2 * u};
-  step_tile_gemm<1>(arow, valid, brow, u, false, red, wave, r, q);
+  step_tile_gemm<1, 4>(arow, valid, brow, u, false, red, wave, r, q);
   if (b < B) {
     float drh = (red[0][0][tid] + red[1][0][tid]) + (red[2][0][tid] + red[3][0][tid]);
     const float* gt = d.gates + ((long)t * B + b) * 3 * u;
