@@ -59,10 +59,21 @@ def depthwise_roofline(eng, iters=5):
             times.append(e0.elapsed_time(e1) * 1e-3)
     t = float(np.median(times))
     ach = nbytes / t / 1e9
+    # HBM bytes of the same launch set from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected by
+    # scripts/gpu_pmc.sh at batch 256 and committed under profiles/; FETCH_SIZE x2 per the gfx950 note in the guide)
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_dwconv.json")))
+        if B == pmc["batch"] and (eng.cfg.imgh, eng.cfg.imgw) == (100, 32):
+            sh = pmc["shapes"]
+            traffic = 2 * sh["104x36x64"]["hbm_bytes_per_launch"] + 2 * sh["104x36x128"]["hbm_bytes_per_launch"] \
+                + 8 * sh["52x18x256|52x9x512"]["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     return {"bound": "hbm", "kernel": "dwconv_tile_kernel<0> (depthwise 3x3 fwd + data-gradient, blocks 2-7, LDS halo tiles)",
             "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
             "launches": len(launches), "avg_launch_ms": round(1e3 * t / len(launches), 4),
-            "algorithmic_bytes_per_launch_set": nbytes, "traffic": None}
+            "algorithmic_bytes_per_launch_set": nbytes, "traffic": traffic}
 
 
 def pointwise_gemm_roofline(eng, iters=5):
