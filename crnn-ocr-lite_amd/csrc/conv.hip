@@ -9,6 +9,9 @@
 #include <stdlib.h>
 
 #define BN_EPS 1e-3f
+#ifndef DW_NT
+#define DW_NT 256   // threads per depthwise workgroup (8 channel-quads x DW_NT/8 pixel threads)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // depthwise 3x3, C % 32 == 0 : LDS halo tile
@@ -16,8 +19,8 @@
 // mode 0: out = conv(x, k) (flip=1 -> taps flipped = data gradient), optional stats partials
 // mode 1: weight gradient partials: dk[tap][c] += x[shifted] * g[center]
 // ---------------------------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(256) void dwconv_tile_kernel(const float* __restrict__ x, const float* __restrict__ k,
+template <int MODE, int NT>
+__global__ __launch_bounds__(NT) void dwconv_tile_kernel(const float* __restrict__ x, const float* __restrict__ k,
                                                           const float* __restrict__ g, float* __restrict__ out,
                                                           float* __restrict__ partials, int B, int H, int W, int C,
                                                           int TH, int flip) {
@@ -30,11 +33,11 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const float* __restric
   const int Wt = W + 2;
   const int n4 = (TH + 2) * Wt * 8;
   // halo-tile fill: 4 independent 16-byte loads in flight per thread before the LDS writes
-  for (int base = tid; base < n4; base += 1024) {
+  for (int base = tid; base < n4; base += 4 * NT) {
     float4 v[4];
 #pragma unroll
     for (int uu = 0; uu < 4; ++uu) {
-      int i = base + uu * 256;
+      int i = base + uu * NT;
       int ci = i & 7, pix = i >> 3;
       int ly = pix / Wt, lx = pix - ly * Wt;
       int gh = h0 + ly - 1, gw = lx - 1;
@@ -44,7 +47,7 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const float* __restric
     }
 #pragma unroll
     for (int uu = 0; uu < 4; ++uu) {
-      int i = base + uu * 256;
+      int i = base + uu * NT;
       if (i < n4) tile[i] = v[uu];
     }
   }
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const float* __restric
   float4 gnext = make_float4(0.f, 0.f, 0.f, 0.f);
   if (MODE == 1 && pt < npix && h0 + pt / W < H)
     gnext = *reinterpret_cast<const float4*>(&g[(((long)b * H + h0 + pt / W) * W + (pt % W)) * C + cc0 + 4 * c4]);
-  for (int p = pt; p < npix; p += 32) {
+  for (int p = pt; p < npix; p += NT / 8) {
     int ly = p / W, lx = p - ly * W;
     int gh = h0 + ly;
     if (gh >= H) break;
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const float* __restric
     } else {
       float4 gv = gnext;
       {  // prefetch the upstream gradient of this thread's next pixel
-        int pn = p + 32, lyn = pn / W, lxn = pn - lyn * W;
+        int pn = p + NT / 8, lyn = pn / W, lxn = pn - lyn * W;
         if (pn < npix && h0 + lyn < H) gnext = *reinterpret_cast<const float4*>(&g[(((long)b * H + h0 + lyn) * W + lxn) * C + cc0 + 4 * c4]);
       }
 #pragma unroll
@@ -105,23 +108,23 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const float* __restric
   __syncthreads();  // tile no longer needed: reuse LDS for the cross-pixel-thread reduction
   float4* red = reinterpret_cast<float4*>(smem);
   if (MODE == 0) {
-    red[(0 * 32 + pt) * 8 + c4] = s;
-    red[(1 * 32 + pt) * 8 + c4] = ss;
+    red[(0 * (NT / 8) + pt) * 8 + c4] = s;
+    red[(1 * (NT / 8) + pt) * 8 + c4] = ss;
     __syncthreads();
     if (tid < 16) {
       int ci = tid & 7, v = tid >> 3;
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int r = 0; r < 32; ++r) { float4 t = red[(v * 32 + r) * 8 + ci]; a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
+      for (int r = 0; r < NT / 8; ++r) { float4 t = red[(v * (NT / 8) + r) * 8 + ci]; a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
       *reinterpret_cast<float4*>(&partials[((long)blockIdx.y * 2 + v) * C + cc0 + 4 * ci]) = a;
     }
   } else {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) red[(t * 32 + pt) * 8 + c4] = dk[t];
+    for (int t = 0; t < 9; ++t) red[(t * (NT / 8) + pt) * 8 + c4] = dk[t];
     __syncthreads();
     if (tid < 72) {
       int ci = tid & 7, t = tid >> 3;
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int r = 0; r < 32; ++r) { float4 v = red[(t * 32 + r) * 8 + ci]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+      for (int r = 0; r < NT / 8; ++r) { float4 v = red[(t * (NT / 8) + r) * 8 + ci]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
       *reinterpret_cast<float4*>(&partials[((long)blockIdx.y * 9 + t) * C + cc0 + 4 * ci]) = a;
     }
   }
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_c1_kernel(const float* __res
 static int dw_pick_th2(int H, int W, size_t* lds) {
   static int th_env = -1;   // experiment hook: CRNN_DW_TH overrides the tile height
   if (th_env < 0) { const char* e = getenv("CRNN_DW_TH"); th_env = e ? atoi(e) : 0; }
-  const size_t red = (size_t)9 * 32 * 128;  // weight-grad reduction scratch
+  const size_t red = (size_t)9 * (DW_NT / 8) * 128;  // weight-grad reduction scratch
   int thmax = (int)(49152 / ((size_t)(W + 2) * 128)) - 2;
   if (thmax < 1) thmax = 1;
   if (thmax > H) thmax = H;
@@ -228,10 +231,10 @@ extern "C" int crnn_dwconv3x3_fwd(const float* x, const float* k, float* out, fl
     if (lds > 160 * 1024) return CRNN_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
       static bool attr0 = false;
-      if (!attr0) { hipFuncSetAttribute((const void*)dwconv_tile_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr0 = true; }
+      if (!attr0) { hipFuncSetAttribute((const void*)dwconv_tile_kernel<0, DW_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr0 = true; }
     }
     dim3 grid(C / 32, B * cdiv(H, TH));
-    hipLaunchKernelGGL(dwconv_tile_kernel<0>, grid, dim3(256), lds, stream, x, k, nullptr, out, stat_partials, B, H, W, C, TH, flip);
+    hipLaunchKernelGGL((dwconv_tile_kernel<0, DW_NT>), grid, dim3(DW_NT), lds, stream, x, k, nullptr, out, stat_partials, B, H, W, C, TH, flip);
   } else {
     if (stat_partials) return CRNN_ERR_UNSUPPORTED;
     long total = (long)B * H * W * C;
@@ -362,11 +365,11 @@ extern "C" int crnn_dwconv3x3_wgrad(const float* x, const float* g, float* dk, f
     if (lds > 160 * 1024) return CRNN_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
       static bool attr1 = false;
-      if (!attr1) { hipFuncSetAttribute((const void*)dwconv_tile_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
+      if (!attr1) { hipFuncSetAttribute((const void*)dwconv_tile_kernel<1, DW_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
     }
     int ntiles = B * cdiv(H, TH);
     dim3 grid(C / 32, ntiles);
-    hipLaunchKernelGGL(dwconv_tile_kernel<1>, grid, dim3(256), lds, stream, x, nullptr, g, nullptr, scratch, B, H, W, C, TH, 0);
+    hipLaunchKernelGGL((dwconv_tile_kernel<1, DW_NT>), grid, dim3(DW_NT), lds, stream, x, nullptr, g, nullptr, scratch, B, H, W, C, TH, 0);
     CRNN_LAUNCH_CHECK();
     return crnn_partials_sum(scratch, ntiles, 9 * C, dk, 1.f, stream);
   }

@@ -1,0 +1,59 @@
+"""-m gpu end-to-end test of the drop-in surface: the reference's train.py / predict.py command lines (same flags)
+on a small synthetic image folder -- Readf generator, CRNN(...).get_model(), compile, fit_generator with
+ModelCheckpoint + EarlyStoppingIter, artefact files, load_custom_model, init_predictor, predict_generator,
+DecodeCTCPred (HIP beam search), edit-distance report and prediction.csv."""
+import os
+import pickle
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "crnn-ocr-lite_amd")
+
+
+def _make_dataset(folder, n=48, seed=0):
+    from PIL import Image, ImageDraw
+    rs = np.random.RandomState(seed)
+    alphabet = "abcdefghij0123"
+    for i in range(n):
+        word = "".join(rs.choice(list(alphabet), size=rs.randint(2, 6)))
+        img = Image.new("L", (20 + 12 * len(word), 28), color=235)
+        ImageDraw.Draw(img).text((4, 6), word, fill=20)
+        img.save(os.path.join(folder, "%d_%s_%d.png" % (i, word, i)))
+
+
+def test_train_then_predict_cli_roundtrip(tmp_path, capsys):
+    sys.path.insert(0, PKG)
+    import train as train_cli
+    import predict as predict_cli
+    data = tmp_path / "data"; out = tmp_path / "out"
+    os.makedirs(data); os.makedirs(out)
+    _make_dataset(str(data))
+    np.random.seed(0)
+    train_cli.main(["--path", str(data), "--save_path", str(out), "--model_name", "m1", "--nbepochs", "2", "--norm", "--opt", "adam",
+                    "--lr", "0.001", "--batch_size", "8", "--n_units", "64", "--time_dense_size", "32", "--early_stopping", "1000",
+                    "--G", "0"])
+    mdir = out / "m1"
+    for f in ("arguments.txt", "model.json", "model_summary.txt", "checkpoint_weights.h5", "final_weights.h5", "final_model.h5",
+              "loss_history.pickle.dat"):
+        assert (mdir / f).exists(), f
+    hist = pickle.load(open(mdir / "loss_history.pickle.dat", "rb"))
+    assert len(hist["loss"]) == 2 and len(hist["val_loss"]) == 2 and np.isfinite(hist["loss"]).all() and np.isfinite(hist["val_loss"]).all()
+    assert hist["loss"][1] < hist["loss"][0]
+    assert "Total params" in open(mdir / "model_summary.txt").read()
+    res = tmp_path / "res"; os.makedirs(res)
+    # max_len must match the trained model (the reference reads it from the CLI too, predict.py:65)
+    import json
+    max_len = json.load(open(mdir / "model.json"))["config"]["crnn"]["max_string_len"]
+    predict_cli.main(["--model_path", str(mdir), "--image_path", str(data), "--result_path", str(res), "--validate", "--train_portion", "0.5",
+                      "--batch_size", "8", "--max_len", str(max_len), "--G", "0"])
+    text = capsys.readouterr().out
+    assert "mean edit distance" in text and "predictions decoded" in text
+    import pandas as pd
+    df = pd.read_csv(res / "prediction.csv")
+    assert len(df) == 24 and set(df.columns) >= {"fname", "prediction"}
+    assert all(isinstance(p, str) or (isinstance(p, float) and np.isnan(p)) for p in df["prediction"])
