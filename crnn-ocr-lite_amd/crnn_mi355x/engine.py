@@ -31,9 +31,10 @@ class Engine:
         self.lib = native.lib()
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.cfg = crnn_config(batch, imgh, imgw, num_classes, max_len, time_dense_size, n_units, int(bool(gru)),
-                               int(bool(stn)), int(bool(dropout)), int(precision == "bf16"))
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' (parity mode) or 'bf16' (bf16 MFMA products, fp32 accumulate/storage)")
+                               int(bool(stn)), int(bool(dropout)), {"fp32": 0, "bf16": 1, "bf16s": 2}.get(precision, 0))
+        if precision not in ("fp32", "bf16", "bf16s"):
+            raise ValueError("precision must be 'fp32' (parity mode), 'bf16' (bf16 MFMA products, fp32 tensors) or "
+                             "'bf16s' (bf16 MFMA products + bf16 conv-stack tensors in HBM)")
         self.precision = precision
         self._c = ctypes.byref(self.cfg)
         nbytes = self.lib.crnn_workspace_bytes(self._c)
@@ -101,8 +102,11 @@ class Engine:
         return out
 
     def ws_tensor(self, name):
-        off, cnt = ctypes.c_long(), ctypes.c_long()
-        check(self.lib.crnn_ws_tensor(self._c, name.encode(), ctypes.byref(off), ctypes.byref(cnt)), "ws_tensor " + name)
+        """Named view into the workspace, in its storage type (torch.float32 or torch.bfloat16)."""
+        off, cnt, dt = ctypes.c_long(), ctypes.c_long(), ctypes.c_int()
+        check(self.lib.crnn_ws_tensor_info(self._c, name.encode(), ctypes.byref(off), ctypes.byref(cnt), ctypes.byref(dt)), "ws_tensor " + name)
+        if dt.value == 1:
+            return self.ws[off.value:off.value + (cnt.value + 1) // 2].view(torch.bfloat16)[:cnt.value]
         return self.ws[off.value:off.value + cnt.value]
 
     # ---- hot path -----------------------------------------------------------------------------------------

@@ -19,9 +19,9 @@
 // mode 0: out = conv(x, k) (flip=1 -> taps flipped = data gradient), optional stats partials
 // mode 1: weight gradient partials: dk[tap][c] += x[shifted] * g[center]
 // ---------------------------------------------------------------------------------------------
-template <int MODE, int NT>
-__global__ __launch_bounds__(NT) void dwconv_tile_kernel(const float* __restrict__ x, const float* __restrict__ k,
-                                                          const float* __restrict__ g, float* __restrict__ out,
+template <int MODE, int NT, typename T>
+__global__ __launch_bounds__(NT) void dwconv_tile_kernel(const T* __restrict__ x, const float* __restrict__ k,
+                                                          const T* __restrict__ g, T* __restrict__ out,
                                                           float* __restrict__ partials, int B, int H, int W, int C,
                                                           int TH, int flip) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(NT) void dwconv_tile_kernel(const float* __restrict
       int gh = h0 + ly - 1, gw = lx - 1;
       v[uu] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (i < n4 && gh >= 0 && gh < H && gw >= 0 && gw < W)
-        v[uu] = *reinterpret_cast<const float4*>(&x[(((long)b * H + gh) * W + gw) * C + cc0 + 4 * ci]);
+        v[uu] = ld4(&x[(((long)b * H + gh) * W + gw) * C + cc0 + 4 * ci]);
     }
 #pragma unroll
     for (int uu = 0; uu < 4; ++uu) {
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(NT) void dwconv_tile_kernel(const float* __restrict
   const int npix = TH * W;
   float4 gnext = make_float4(0.f, 0.f, 0.f, 0.f);
   if (MODE == 1 && pt < npix && h0 + pt / W < H)
-    gnext = *reinterpret_cast<const float4*>(&g[(((long)b * H + h0 + pt / W) * W + (pt % W)) * C + cc0 + 4 * c4]);
+    gnext = ld4(&g[(((long)b * H + h0 + pt / W) * W + (pt % W)) * C + cc0 + 4 * c4]);
   for (int p = pt; p < npix; p += NT / 8) {
     int ly = p / W, lx = p - ly * W;
     int gh = h0 + ly;
@@ -85,14 +85,14 @@ __global__ __launch_bounds__(NT) void dwconv_tile_kernel(const float* __restrict
           float4 w = kw[i * 3 + j];
           a.x = fmaf(v.x, w.x, a.x); a.y = fmaf(v.y, w.y, a.y); a.z = fmaf(v.z, w.z, a.z); a.w = fmaf(v.w, w.w, a.w);
         }
-      *reinterpret_cast<float4*>(&out[o]) = a;
+      st4(&out[o], a);
       s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
       ss.x = fmaf(a.x, a.x, ss.x); ss.y = fmaf(a.y, a.y, ss.y); ss.z = fmaf(a.z, a.z, ss.z); ss.w = fmaf(a.w, a.w, ss.w);
     } else {
       float4 gv = gnext;
       {  // prefetch the upstream gradient of this thread's next pixel
         int pn = p + NT / 8, lyn = pn / W, lxn = pn - lyn * W;
-        if (pn < npix && h0 + lyn < H) gnext = *reinterpret_cast<const float4*>(&g[(((long)b * H + h0 + lyn) * W + lxn) * C + cc0 + 4 * c4]);
+        if (pn < npix && h0 + lyn < H) gnext = ld4(&g[(((long)b * H + h0 + lyn) * W + lxn) * C + cc0 + 4 * c4]);
       }
 #pragma unroll
       for (int i = 0; i < 3; ++i)
@@ -224,33 +224,43 @@ extern "C" int crnn_dwconv_num_tiles(int B, int H, int W) {
 
 // out = dwconv3x3(x, k[9][C]); flip=1 gives the data gradient.  If `stat_partials` != null (C%32==0
 // only) it receives [num_tiles][2][C] (sum, sumsq) partial BatchNorm statistics of `out`.
-extern "C" int crnn_dwconv3x3_fwd(const float* x, const float* k, float* out, float* stat_partials, int B, int H, int W,
-                                  int C, int flip, hipStream_t stream) {
-  if (C % 32 == 0) {
-    size_t lds; int TH = dw_pick_th2(H, W, &lds);
-    if (lds > 160 * 1024) return CRNN_ERR_UNSUPPORTED;
-    if (lds > 64 * 1024) {
-      static bool attr0 = false;
-      if (!attr0) { hipFuncSetAttribute((const void*)dwconv_tile_kernel<0, DW_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr0 = true; }
-    }
-    dim3 grid(C / 32, B * cdiv(H, TH));
-    hipLaunchKernelGGL((dwconv_tile_kernel<0, DW_NT>), grid, dim3(DW_NT), lds, stream, x, k, nullptr, out, stat_partials, B, H, W, C, TH, flip);
-  } else {
-    if (stat_partials) return CRNN_ERR_UNSUPPORTED;
-    long total = (long)B * H * W * C;
-    int blocks = cdiv(total, 256); if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(dwconv_naive_kernel<0>, dim3(blocks), dim3(256), 0, stream, x, k, nullptr, out, B, H, W, C, flip);
-  }
+// dtype: storage of x/out (CRNN_F32 | CRNN_BF16); arithmetic and statistics are fp32 either way.
+template <typename T>
+static int dwconv_fwd_launch(const T* x, const float* k, T* out, float* stat_partials, int B, int H, int W, int C, int flip,
+                             hipStream_t stream) {
+  size_t lds; int TH = dw_pick_th2(H, W, &lds);
+  if (lds > 160 * 1024) return CRNN_ERR_UNSUPPORTED;
+  if (lds > 64 * 1024) hipFuncSetAttribute((const void*)dwconv_tile_kernel<0, DW_NT, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  dim3 grid(C / 32, B * cdiv(H, TH));
+  hipLaunchKernelGGL((dwconv_tile_kernel<0, DW_NT, T>), grid, dim3(DW_NT), lds, stream, x, k, (const T*)nullptr, out, stat_partials, B, H, W, C, TH, flip);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
+}
+
+extern "C" int crnn_dwconv3x3_fwd_ex(const void* x, const float* k, void* out, float* stat_partials, int B, int H, int W,
+                                     int C, int flip, int dtype, hipStream_t stream) {
+  if (C % 32 == 0) {
+    if (dtype == CRNN_BF16) return dwconv_fwd_launch<bf16_t>((const bf16_t*)x, k, (bf16_t*)out, stat_partials, B, H, W, C, flip, stream);
+    return dwconv_fwd_launch<float>((const float*)x, k, (float*)out, stat_partials, B, H, W, C, flip, stream);
+  }
+  if (stat_partials || dtype != CRNN_F32) return CRNN_ERR_UNSUPPORTED;
+  long total = (long)B * H * W * C;
+  int blocks = cdiv(total, 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(dwconv_naive_kernel<0>, dim3(blocks), dim3(256), 0, stream, (const float*)x, k, nullptr, (float*)out, B, H, W, C, flip);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+extern "C" int crnn_dwconv3x3_fwd(const float* x, const float* k, float* out, float* stat_partials, int B, int H, int W,
+                                  int C, int flip, hipStream_t stream) {
+  return crnn_dwconv3x3_fwd_ex(x, k, out, stat_partials, B, H, W, C, flip, CRNN_F32, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
 // Column reductions over a row-major [M][C] matrix -> partials [nchunk][NV][C]
 // NV=1: sum; NV=2: sum and sum of squares.  Deterministic (fixed chunking, fixed order).
 // ---------------------------------------------------------------------------------------------
-template <int VEC, int NV>
-__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ x, float* __restrict__ partials, long M,
+template <int VEC, int NV, typename T>
+__global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ x, float* __restrict__ partials, long M,
                                                         int C, int ld, int CW, int rows_per_chunk) {
   // CW = power of two >= min(C/VEC, 256); thread -> (cl = tid % CW, rt = tid / CW)
   __shared__ float red[2][256 * VEC];
@@ -267,10 +277,10 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
       long r = r0 + rt;
       if (VEC == 4) {  // 4 rows in flight per thread (independent 16-byte loads)
         for (; r + 3L * RT < r1; r += 4L * RT) {
-          float4 v0 = *reinterpret_cast<const float4*>(&x[r * ld + 4 * c]);
-          float4 v1 = *reinterpret_cast<const float4*>(&x[(r + RT) * ld + 4 * c]);
-          float4 v2 = *reinterpret_cast<const float4*>(&x[(r + 2L * RT) * ld + 4 * c]);
-          float4 v3 = *reinterpret_cast<const float4*>(&x[(r + 3L * RT) * ld + 4 * c]);
+          float4 v0 = ld4(&x[r * ld + 4 * c]);
+          float4 v1 = ld4(&x[(r + RT) * ld + 4 * c]);
+          float4 v2 = ld4(&x[(r + 2L * RT) * ld + 4 * c]);
+          float4 v3 = ld4(&x[(r + 3L * RT) * ld + 4 * c]);
           s[0] += (v0.x + v1.x) + (v2.x + v3.x); s[1 % VEC] += (v0.y + v1.y) + (v2.y + v3.y);
           s[2 % VEC] += (v0.z + v1.z) + (v2.z + v3.z); s[3 % VEC] += (v0.w + v1.w) + (v2.w + v3.w);
           if (NV == 2) {
@@ -283,11 +293,11 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
       }
       for (; r < r1; r += RT) {
         if (VEC == 4) {
-          float4 v = *reinterpret_cast<const float4*>(&x[r * ld + 4 * c]);
+          float4 v = ld4(&x[r * ld + 4 * c]);
           s[0] += v.x; s[1 % VEC] += v.y; s[2 % VEC] += v.z; s[3 % VEC] += v.w;
           if (NV == 2) { q[0] = fmaf(v.x, v.x, q[0]); q[1 % VEC] = fmaf(v.y, v.y, q[1 % VEC]); q[2 % VEC] = fmaf(v.z, v.z, q[2 % VEC]); q[3 % VEC] = fmaf(v.w, v.w, q[3 % VEC]); }
         } else {
-          float v = x[r * ld + c];
+          float v = ld1(&x[r * ld + c]);
           s[0] += v;
           if (NV == 2) q[0] = fmaf(v, v, q[0]);
         }
@@ -315,23 +325,31 @@ static inline int pow2_ge(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 static inline int colreduce_rpc(long M) { long r = 1024; while (r > 16 && M / r < 512) r >>= 1; return (int)r; }
 extern "C" int crnn_colreduce_chunks(long M) { return cdiv(M, colreduce_rpc(M)); }
 
-// partials [crnn_colreduce_chunks(M)][nv][C]
-extern "C" int crnn_colreduce(const float* x, float* partials, long M, int C, int ld, int nv, hipStream_t stream) {
-  if (nv != 1 && nv != 2) return CRNN_ERR_ARG;
+// partials [crnn_colreduce_chunks(M)][nv][C]; dtype = storage of x
+template <typename T>
+static int colreduce_launch(const T* x, float* partials, long M, int C, int ld, int nv, hipStream_t stream) {
   int rpc = colreduce_rpc(M);
   int chunks = cdiv(M, rpc);
   bool vec = (C % 4 == 0) && (ld % 4 == 0) && ((((uintptr_t)x) & 15) == 0);
   int CL = vec ? C / 4 : C;
   int CW = pow2_ge(CL < 256 ? CL : 256);
   if (vec) {
-    if (nv == 1) hipLaunchKernelGGL((colreduce_kernel<4, 1>), dim3(chunks), dim3(256), 0, stream, x, partials, M, C, ld, CW, rpc);
-    else hipLaunchKernelGGL((colreduce_kernel<4, 2>), dim3(chunks), dim3(256), 0, stream, x, partials, M, C, ld, CW, rpc);
+    if (nv == 1) hipLaunchKernelGGL((colreduce_kernel<4, 1, T>), dim3(chunks), dim3(256), 0, stream, x, partials, M, C, ld, CW, rpc);
+    else hipLaunchKernelGGL((colreduce_kernel<4, 2, T>), dim3(chunks), dim3(256), 0, stream, x, partials, M, C, ld, CW, rpc);
   } else {
-    if (nv == 1) hipLaunchKernelGGL((colreduce_kernel<1, 1>), dim3(chunks), dim3(256), 0, stream, x, partials, M, C, ld, CW, rpc);
-    else hipLaunchKernelGGL((colreduce_kernel<1, 2>), dim3(chunks), dim3(256), 0, stream, x, partials, M, C, ld, CW, rpc);
+    if (nv == 1) hipLaunchKernelGGL((colreduce_kernel<1, 1, T>), dim3(chunks), dim3(256), 0, stream, x, partials, M, C, ld, CW, rpc);
+    else hipLaunchKernelGGL((colreduce_kernel<1, 2, T>), dim3(chunks), dim3(256), 0, stream, x, partials, M, C, ld, CW, rpc);
   }
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
+}
+extern "C" int crnn_colreduce_ex(const void* x, float* partials, long M, int C, int ld, int nv, int dtype, hipStream_t stream) {
+  if (nv != 1 && nv != 2) return CRNN_ERR_ARG;
+  if (dtype == CRNN_BF16) return colreduce_launch<bf16_t>((const bf16_t*)x, partials, M, C, ld, nv, stream);
+  return colreduce_launch<float>((const float*)x, partials, M, C, ld, nv, stream);
+}
+extern "C" int crnn_colreduce(const float* x, float* partials, long M, int C, int ld, int nv, hipStream_t stream) {
+  return crnn_colreduce_ex(x, partials, M, C, ld, nv, CRNN_F32, stream);
 }
 
 // out[i] = scale * sum_p partials[p][i], i < n  (double accumulation)
@@ -358,31 +376,39 @@ extern "C" int crnn_partials_sum(const float* partials, int nparts, int n, float
 }
 
 // weight gradient of the depthwise conv: dk[9][C] = sum x[shifted] * g.  scratch: [num_tiles][9][C]
-extern "C" int crnn_dwconv3x3_wgrad(const float* x, const float* g, float* dk, float* scratch, int B, int H, int W, int C,
-                                    hipStream_t stream) {
+template <typename T>
+static int dwconv_wgrad_launch(const T* x, const T* g, float* dk, float* scratch, int B, int H, int W, int C, hipStream_t stream) {
+  size_t lds; int TH = dw_pick_th2(H, W, &lds);
+  if (lds > 160 * 1024) return CRNN_ERR_UNSUPPORTED;
+  if (lds > 64 * 1024) hipFuncSetAttribute((const void*)dwconv_tile_kernel<1, DW_NT, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  int ntiles = B * cdiv(H, TH);
+  dim3 grid(C / 32, ntiles);
+  hipLaunchKernelGGL((dwconv_tile_kernel<1, DW_NT, T>), grid, dim3(DW_NT), lds, stream, x, (const float*)nullptr, g, (T*)nullptr, scratch, B, H, W, C, TH, 0);
+  CRNN_LAUNCH_CHECK();
+  return crnn_partials_sum(scratch, ntiles, 9 * C, dk, 1.f, stream);
+}
+
+extern "C" int crnn_dwconv3x3_wgrad_ex(const void* x, const void* g, float* dk, float* scratch, int B, int H, int W, int C,
+                                       int dtype, hipStream_t stream) {
   if (C % 32 == 0) {
-    size_t lds; int TH = dw_pick_th2(H, W, &lds);
-    if (lds > 160 * 1024) return CRNN_ERR_UNSUPPORTED;
-    if (lds > 64 * 1024) {
-      static bool attr1 = false;
-      if (!attr1) { hipFuncSetAttribute((const void*)dwconv_tile_kernel<1, DW_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
-    }
-    int ntiles = B * cdiv(H, TH);
-    dim3 grid(C / 32, ntiles);
-    hipLaunchKernelGGL((dwconv_tile_kernel<1, DW_NT>), grid, dim3(DW_NT), lds, stream, x, nullptr, g, nullptr, scratch, B, H, W, C, TH, 0);
-    CRNN_LAUNCH_CHECK();
-    return crnn_partials_sum(scratch, ntiles, 9 * C, dk, 1.f, stream);
+    if (dtype == CRNN_BF16) return dwconv_wgrad_launch<bf16_t>((const bf16_t*)x, (const bf16_t*)g, dk, scratch, B, H, W, C, stream);
+    return dwconv_wgrad_launch<float>((const float*)x, (const float*)g, dk, scratch, B, H, W, C, stream);
   }
+  if (dtype != CRNN_F32) return CRNN_ERR_UNSUPPORTED;
   if (C == 1) {  // first block: one channel, B*H*W pixels -> per-block partials [nblk][9], then the 2nd stage
     long npix = (long)B * H * W;
     int nblk = cdiv(npix, 2048); if (nblk > 1024) nblk = 1024;
-    hipLaunchKernelGGL(dwconv_wgrad_c1_kernel, dim3(nblk), dim3(256), 0, stream, x, g, scratch, B, H, W);
+    hipLaunchKernelGGL(dwconv_wgrad_c1_kernel, dim3(nblk), dim3(256), 0, stream, (const float*)x, (const float*)g, scratch, B, H, W);
     CRNN_LAUNCH_CHECK();
     return crnn_partials_sum(scratch, nblk, 9, dk, 1.f, stream);
   }
-  hipLaunchKernelGGL(dwconv_naive_kernel<1>, dim3(9 * C), dim3(256), 0, stream, x, nullptr, g, dk, B, H, W, C, 0);
+  hipLaunchKernelGGL(dwconv_naive_kernel<1>, dim3(9 * C), dim3(256), 0, stream, (const float*)x, nullptr, (const float*)g, dk, B, H, W, C, 0);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
+}
+extern "C" int crnn_dwconv3x3_wgrad(const float* x, const float* g, float* dk, float* scratch, int B, int H, int W, int C,
+                                    hipStream_t stream) {
+  return crnn_dwconv3x3_wgrad_ex(x, g, dk, scratch, B, H, W, C, CRNN_F32, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -444,9 +470,9 @@ extern "C" int crnn_bn_infer_state(const float* mmean, const float* mvar, const 
 // y = Dropout(MaxPool(ReLU6(x*scale+shift)))   (utils.py:45-56).  ph=pw=1: no pooling; rate=0: no dropout.
 // x [B,H,W,C] -> y [B,H/ph,W/pw,C]
 // ---------------------------------------------------------------------------------------------
-template <int VEC>
-__global__ void bn_act_pool_drop_kernel(const float* __restrict__ x, const float* __restrict__ bnstate,
-                                        float* __restrict__ y, int B, int H, int W, int C, int ph, int pw, float rate,
+template <int VEC, typename TI, typename TO>
+__global__ void bn_act_pool_drop_kernel(const TI* __restrict__ x, const float* __restrict__ bnstate,
+                                        TO* __restrict__ y, int B, int H, int W, int C, int ph, int pw, float rate,
                                         uint64_t seed, uint32_t layer) {
   const int Ho = H / ph, Wo = W / pw, CL = C / VEC;
   const long total = (long)B * Ho * Wo * CL;
@@ -460,33 +486,46 @@ __global__ void bn_act_pool_drop_kernel(const float* __restrict__ x, const float
     for (int e = 0; e < VEC; ++e) { m[e] = -INFINITY; s[e] = sc[cl * VEC + e]; t[e] = sh[cl * VEC + e]; }
     for (int ii = 0; ii < ph; ++ii)
       for (int j = 0; j < pw; ++j) {
-        const float* p = &x[(((long)b * H + ho * ph + ii) * W + wo * pw + j) * C + cl * VEC];
+        const TI* p = &x[(((long)b * H + ho * ph + ii) * W + wo * pw + j) * C + cl * VEC];
         float v[VEC];
-        if (VEC == 4) { float4 q = *reinterpret_cast<const float4*>(p); v[0] = q.x; v[1 % VEC] = q.y; v[2 % VEC] = q.z; v[3 % VEC] = q.w; }
-        else v[0] = p[0];
+        if (VEC == 4) { float4 q = ld4(p); v[0] = q.x; v[1 % VEC] = q.y; v[2 % VEC] = q.z; v[3 % VEC] = q.w; }
+        else v[0] = ld1(p);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) m[e] = fmaxf(m[e], relu6f(fmaf(v[e], s[e], t[e])));
       }
     long obase = pix * C + cl * VEC;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) m[e] *= drop_scale(seed, layer, (uint64_t)(obase + e), rate, inv_keep);
-    if (VEC == 4) *reinterpret_cast<float4*>(&y[obase]) = make_float4(m[0], m[1 % VEC], m[2 % VEC], m[3 % VEC]);
-    else y[obase] = m[0];
+    if (VEC == 4) st4(&y[obase], make_float4(m[0], m[1 % VEC], m[2 % VEC], m[3 % VEC]));
+    else st1(&y[obase], m[0]);
   }
 }
 
-extern "C" int crnn_bn_act_pool_drop(const float* x, const float* bnstate, float* y, int B, int H, int W, int C, int ph,
-                                     int pw, float rate, uint64_t seed, uint32_t layer, hipStream_t stream) {
+template <typename TI, typename TO>
+static int bn_act_launch(const TI* x, const float* bnstate, TO* y, int B, int H, int W, int C, int ph, int pw, float rate, uint64_t seed,
+                         uint32_t layer, hipStream_t stream) {
   long total = (long)B * (H / ph) * (W / pw) * C;
   if (C % 4 == 0) {
     int blocks = cdiv(total / 4, 256); if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(bn_act_pool_drop_kernel<4>, dim3(blocks), dim3(256), 0, stream, x, bnstate, y, B, H, W, C, ph, pw, rate, seed, layer);
+    hipLaunchKernelGGL((bn_act_pool_drop_kernel<4, TI, TO>), dim3(blocks), dim3(256), 0, stream, x, bnstate, y, B, H, W, C, ph, pw, rate, seed, layer);
   } else {
     int blocks = cdiv(total, 256); if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(bn_act_pool_drop_kernel<1>, dim3(blocks), dim3(256), 0, stream, x, bnstate, y, B, H, W, C, ph, pw, rate, seed, layer);
+    hipLaunchKernelGGL((bn_act_pool_drop_kernel<1, TI, TO>), dim3(blocks), dim3(256), 0, stream, x, bnstate, y, B, H, W, C, ph, pw, rate, seed, layer);
   }
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
+}
+// dt_in / dt_out: storage of x / y
+extern "C" int crnn_bn_act_pool_drop_ex(const void* x, const float* bnstate, void* y, int B, int H, int W, int C, int ph,
+                                        int pw, float rate, uint64_t seed, uint32_t layer, int dt_in, int dt_out, hipStream_t stream) {
+  if (dt_in == CRNN_BF16 && dt_out == CRNN_BF16) return bn_act_launch((const bf16_t*)x, bnstate, (bf16_t*)y, B, H, W, C, ph, pw, rate, seed, layer, stream);
+  if (dt_in == CRNN_BF16) return bn_act_launch((const bf16_t*)x, bnstate, (float*)y, B, H, W, C, ph, pw, rate, seed, layer, stream);
+  if (dt_out == CRNN_BF16) return bn_act_launch((const float*)x, bnstate, (bf16_t*)y, B, H, W, C, ph, pw, rate, seed, layer, stream);
+  return bn_act_launch((const float*)x, bnstate, (float*)y, B, H, W, C, ph, pw, rate, seed, layer, stream);
+}
+extern "C" int crnn_bn_act_pool_drop(const float* x, const float* bnstate, float* y, int B, int H, int W, int C, int ph,
+                                     int pw, float rate, uint64_t seed, uint32_t layer, hipStream_t stream) {
+  return crnn_bn_act_pool_drop_ex(x, bnstate, y, B, H, W, C, ph, pw, rate, seed, layer, CRNN_F32, CRNN_F32, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -498,30 +537,31 @@ extern "C" int crnn_bn_act_pool_drop(const float* x, const float* bnstate, float
 // Threads: VEC channels per thread (16-byte accesses when C % 4 == 0), CW channel-threads x 256/CW
 // row-threads; rows = pixels.  POOL=false (ph=pw=1) needs no per-element index arithmetic at all.
 // ---------------------------------------------------------------------------------------------
-struct BnBwdArgs {
-  const float* x; const float* g; const float* bnstate; const float* gamma;
+template <typename T>
+struct BnBwdArgsT {
+  const T* x; const T* g; const float* bnstate; const float* gamma;
   int B, H, W, C, ph, pw; float rate; uint64_t seed; uint32_t layer;
 };
 
 template <int VEC>
 struct VecF { float v[VEC]; };
 
-template <int VEC>
-__device__ __forceinline__ VecF<VEC> vload(const float* p) {
+template <int VEC, typename T>
+__device__ __forceinline__ VecF<VEC> vload(const T* p) {
   VecF<VEC> r;
-  if (VEC == 4) { float4 q = *reinterpret_cast<const float4*>(p); r.v[0] = q.x; r.v[1 % VEC] = q.y; r.v[2 % VEC] = q.z; r.v[3 % VEC] = q.w; }
-  else r.v[0] = p[0];
+  if (VEC == 4) { float4 q = ld4(p); r.v[0] = q.x; r.v[1 % VEC] = q.y; r.v[2 % VEC] = q.z; r.v[3 % VEC] = q.w; }
+  else r.v[0] = ld1(p);
   return r;
 }
-template <int VEC>
-__device__ __forceinline__ void vstore(float* p, const VecF<VEC>& r) {
-  if (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1 % VEC], r.v[2 % VEC], r.v[3 % VEC]);
-  else p[0] = r.v[0];
+template <int VEC, typename T>
+__device__ __forceinline__ void vstore(T* p, const VecF<VEC>& r) {
+  if (VEC == 4) st4(p, make_float4(r.v[0], r.v[1 % VEC], r.v[2 % VEC], r.v[3 % VEC]));
+  else st1(p, r.v[0]);
 }
 
 // gy for VEC consecutive channels starting at c0 of pixel row r
-template <int VEC, bool POOL>
-__device__ __forceinline__ VecF<VEC> bn_gy_vec(const BnBwdArgs& a, long r, int c0, const VecF<VEC>& xv, const VecF<VEC>& sc,
+template <int VEC, bool POOL, typename T>
+__device__ __forceinline__ VecF<VEC> bn_gy_vec(const BnBwdArgsT<T>& a, long r, int c0, const VecF<VEC>& xv, const VecF<VEC>& sc,
                                                const VecF<VEC>& sh, float inv_keep) {
   VecF<VEC> out, y;
 #pragma unroll
@@ -564,9 +604,9 @@ __device__ __forceinline__ VecF<VEC> bn_gy_vec(const BnBwdArgs& a, long r, int c
   return out;
 }
 
-template <int PASS, int VEC, bool POOL>
-__global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a, float* __restrict__ partials,
-                                                     const float* __restrict__ coef, float* __restrict__ dx, int CW,
+template <int PASS, int VEC, bool POOL, typename T>
+__global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgsT<T> a, float* __restrict__ partials,
+                                                     const float* __restrict__ coef, T* __restrict__ dx, int CW,
                                                      int rows_per_chunk) {
   __shared__ float red[2][256 * VEC];
   const int tid = threadIdx.x, cl = tid % CW, rt = tid / CW, RT = 256 / CW;
@@ -589,7 +629,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a, float* __restr
       if (PASS == 2) { c1 = vload<VEC>(coef + c0); c2 = vload<VEC>(coef + a.C + c0); }
       for (long r = r0 + rt; r < r1; r += RT) {
         VecF<VEC> xv = vload<VEC>(&a.x[r * a.C + c0]);
-        VecF<VEC> gy = bn_gy_vec<VEC, POOL>(a, r, c0, xv, sc, sh, inv_keep);
+        VecF<VEC> gy = bn_gy_vec<VEC, POOL, T>(a, r, c0, xv, sc, sh, inv_keep);
         VecF<VEC> o;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
@@ -620,9 +660,9 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a, float* __restr
 
 // Pooled variant (H % ph == 0, W % pw == 0): one thread owns a whole pool window x VEC channels, so every
 // pre-BN value is read exactly once per pass and the arg-max is found once per window.
-template <int PASS, int VEC>
-__global__ __launch_bounds__(256) void bn_bwd_pool_kernel(BnBwdArgs a, float* __restrict__ partials,
-                                                          const float* __restrict__ coef, float* __restrict__ dx, int CW,
+template <int PASS, int VEC, typename T>
+__global__ __launch_bounds__(256) void bn_bwd_pool_kernel(BnBwdArgsT<T> a, float* __restrict__ partials,
+                                                          const float* __restrict__ coef, T* __restrict__ dx, int CW,
                                                           int rows_per_chunk) {
   __shared__ float red[2][256 * VEC];
   const int tid = threadIdx.x, cl = tid % CW, rt = tid / CW, RT = 256 / CW;
@@ -738,39 +778,53 @@ extern "C" int crnn_bn_bwd_chunks(long M) {
   return best;
 }
 
-template <int VEC, bool POOL>
-static int bn_bwd_launch(const BnBwdArgs& a, float* dx, float* dgamma, float* dbeta, float* parts, float* coef, hipStream_t stream) {
+template <int VEC, bool POOL, typename T>
+static int bn_bwd_launch(const BnBwdArgsT<T>& a, T* dx, float* dgamma, float* dbeta, float* parts, float* coef, hipStream_t stream) {
   const long M = (long)a.B * a.H * a.W;
   const int CL = a.C / VEC;
   const int CW = pow2_ge(CL < 256 ? CL : 256);
   const bool window = POOL && (a.H % a.ph == 0) && (a.W % a.pw == 0) && (a.ph * a.pw <= 4);
-  // chunking is over pooled pixels for the window kernel (same number of chunks as partial rows allocated:
-  // crnn_bn_bwd_chunks(M) >= chunks used here)
   const long rows = window ? M / (a.ph * a.pw) : M;
   const int rpc = bn_bwd_rows_per_chunk(rows), chunks = cdiv(rows, rpc);
-  if (window) hipLaunchKernelGGL((bn_bwd_pool_kernel<1, VEC>), dim3(chunks), dim3(256), 0, stream, a, parts, nullptr, nullptr, CW, rpc);
-  else hipLaunchKernelGGL((bn_bwd_kernel<1, VEC, POOL>), dim3(chunks), dim3(256), 0, stream, a, parts, nullptr, nullptr, CW, rpc);
+  if (window) hipLaunchKernelGGL((bn_bwd_pool_kernel<1, VEC, T>), dim3(chunks), dim3(256), 0, stream, a, parts, (const float*)nullptr, (T*)nullptr, CW, rpc);
+  else hipLaunchKernelGGL((bn_bwd_kernel<1, VEC, POOL, T>), dim3(chunks), dim3(256), 0, stream, a, parts, (const float*)nullptr, (T*)nullptr, CW, rpc);
   CRNN_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(a.C, 32)), dim3(32, 32), 0, stream, parts, chunks, a.C, 1.0 / (double)M, dgamma, dbeta, coef);
   CRNN_LAUNCH_CHECK();
-  if (window) hipLaunchKernelGGL((bn_bwd_pool_kernel<2, VEC>), dim3(chunks), dim3(256), 0, stream, a, nullptr, coef, dx, CW, rpc);
-  else hipLaunchKernelGGL((bn_bwd_kernel<2, VEC, POOL>), dim3(chunks), dim3(256), 0, stream, a, nullptr, coef, dx, CW, rpc);
+  if (window) hipLaunchKernelGGL((bn_bwd_pool_kernel<2, VEC, T>), dim3(chunks), dim3(256), 0, stream, a, (float*)nullptr, coef, dx, CW, rpc);
+  else hipLaunchKernelGGL((bn_bwd_kernel<2, VEC, POOL, T>), dim3(chunks), dim3(256), 0, stream, a, (float*)nullptr, coef, dx, CW, rpc);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
 
+template <typename T>
+static int bn_bwd_typed(const T* x, const T* g, const float* bnstate, const float* gamma, T* dx, float* dgamma, float* dbeta,
+                        float* scratch_partials, float* coef, int B, int H, int W, int C, int ph, int pw, float rate, uint64_t seed,
+                        uint32_t layer, hipStream_t stream) {
+  BnBwdArgsT<T> a{x, g, bnstate, gamma, B, H, W, C, ph, pw, rate, seed, layer};
+  const bool pool = (ph * pw) > 1;
+  const bool vec = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)g | (uintptr_t)dx | (uintptr_t)bnstate | (uintptr_t)coef) & 15) == 0);
+  if (vec) return pool ? bn_bwd_launch<4, true, T>(a, dx, dgamma, dbeta, scratch_partials, coef, stream)
+                       : bn_bwd_launch<4, false, T>(a, dx, dgamma, dbeta, scratch_partials, coef, stream);
+  return pool ? bn_bwd_launch<1, true, T>(a, dx, dgamma, dbeta, scratch_partials, coef, stream)
+              : bn_bwd_launch<1, false, T>(a, dx, dgamma, dbeta, scratch_partials, coef, stream);
+}
+
 // Full BN backward through Dropout/MaxPool/ReLU6: writes dx [B,H,W,C], dgamma[C], dbeta[C].
-// scratch_partials: [crnn_bn_bwd_chunks(B*H*W)][2][C]; coef: [2*C].
+// scratch_partials: [crnn_bn_bwd_chunks(B*H*W)][2][C]; coef: [2*C].  dtype = storage of x, g and dx.
+extern "C" int crnn_bn_bwd_ex(const void* x, const void* g, const float* bnstate, const float* gamma, void* dx,
+                              float* dgamma, float* dbeta, float* scratch_partials, float* coef, int B, int H, int W, int C,
+                              int ph, int pw, float rate, uint64_t seed, uint32_t layer, int dtype, hipStream_t stream) {
+  if (dtype == CRNN_BF16)
+    return bn_bwd_typed<bf16_t>((const bf16_t*)x, (const bf16_t*)g, bnstate, gamma, (bf16_t*)dx, dgamma, dbeta, scratch_partials, coef, B, H, W,
+                                C, ph, pw, rate, seed, layer, stream);
+  return bn_bwd_typed<float>((const float*)x, (const float*)g, bnstate, gamma, (float*)dx, dgamma, dbeta, scratch_partials, coef, B, H, W, C,
+                             ph, pw, rate, seed, layer, stream);
+}
 extern "C" int crnn_bn_bwd(const float* x, const float* g, const float* bnstate, const float* gamma, float* dx,
                            float* dgamma, float* dbeta, float* scratch_partials, float* coef, int B, int H, int W, int C,
                            int ph, int pw, float rate, uint64_t seed, uint32_t layer, hipStream_t stream) {
-  BnBwdArgs a{x, g, bnstate, gamma, B, H, W, C, ph, pw, rate, seed, layer};
-  const bool pool = (ph * pw) > 1;
-  const bool vec = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)g | (uintptr_t)dx | (uintptr_t)bnstate | (uintptr_t)coef) & 15) == 0);
-  if (vec) return pool ? bn_bwd_launch<4, true>(a, dx, dgamma, dbeta, scratch_partials, coef, stream)
-                       : bn_bwd_launch<4, false>(a, dx, dgamma, dbeta, scratch_partials, coef, stream);
-  return pool ? bn_bwd_launch<1, true>(a, dx, dgamma, dbeta, scratch_partials, coef, stream)
-              : bn_bwd_launch<1, false>(a, dx, dgamma, dbeta, scratch_partials, coef, stream);
+  return crnn_bn_bwd_ex(x, g, bnstate, gamma, dx, dgamma, dbeta, scratch_partials, coef, B, H, W, C, ph, pw, rate, seed, layer, CRNN_F32, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

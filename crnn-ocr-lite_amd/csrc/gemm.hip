@@ -28,6 +28,7 @@ struct GemmParams {
   int klen;        // K range per split (blockIdx.y); nsplit = gridDim.y
   int vecA, vecB;  // 16-byte vector loads legal for the operand
   int vecC;        // 16-byte stores legal for C (and the split scratch)
+  int dtA, dtB, dtC;  // storage of the operands / result (CRNN_F32 | CRNN_BF16); the fp32 kernel requires all CRNN_F32
   int tilesN;
 };
 
@@ -232,9 +233,15 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
     if (p.act == 1) s = fmaxf(s, 0.f);
     int orow = m;
     if (p.permP) orow = (m % p.permP) * (p.M / p.permP) + m / p.permP;
-    float* dst = p.C + (long)orow * p.ldc + n;
-    if (p.accumulate) s += *dst;
-    *dst = s;
+    if (p.dtC == CRNN_BF16) {
+      bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + (long)orow * p.ldc + n;
+      if (p.accumulate) s += ld1(dst);
+      st1(dst, s);
+    } else {
+      float* dst = p.C + (long)orow * p.ldc + n;
+      if (p.accumulate) s += *dst;
+      *dst = s;
+    }
   }
 }
 
@@ -250,6 +257,7 @@ extern "C" int crnn_gemm_f32(int mode, const float* A, const float* B, float* C,
   GemmParams p;
   p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.bias = bias; p.act = act; p.accumulate = accumulate; p.permP = permP;
+  p.dtA = p.dtB = p.dtC = CRNN_F32;
   const bool a_km = (mode == 2), b_km = (mode != 1);
   // contiguous extent of each operand: A: K (m-major) or M (k-major); B: N (k-major) or K (n-major)
   p.vecA = aligned16(A) && (lda % 4 == 0) && ((a_km ? M : K) % 4 == 0);

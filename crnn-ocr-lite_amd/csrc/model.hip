@@ -15,7 +15,7 @@ const BlockSpec kBlocks[7] = {{64, 1, 1}, {128, 1, 1}, {256, 2, 2}, {256, 1, 1},
 const float kDropBlock = 0.1f, kDropDense1 = 0.4f, kDropRnn = 0.2f;  // utils.py:56,75,83
 const uint32_t kLayerDense1 = 8, kLayerRnn = 9;
 
-struct Tensor { std::string name; long off; long size; int ndim; int dims[4]; };
+struct Tensor { std::string name; long off; long size; int ndim; int dims[4]; int dtype = CRNN_F32; };
 
 struct Dims {
   int B, H0, W0, Hp, Wp, T, feat, C, L, tds, u, G, stn_flat;
@@ -81,11 +81,14 @@ Layout make_layout(const crnn_config* c) {
 struct Plan {
   std::vector<Tensor> t;
   long total = 0;
-  long add(const std::string& n, long count) {
-    Tensor x; x.name = n; x.off = total; x.size = count; x.ndim = 1; x.dims[0] = x.dims[1] = x.dims[2] = x.dims[3] = 1;
-    t.push_back(x); total += (count + 63) & ~63L;  // 256-byte aligned
+  // `count` elements of `dtype`; offsets/total are in floats (a bf16 tensor occupies count/2 floats)
+  long add(const std::string& n, long count, int dtype = CRNN_F32) {
+    Tensor x; x.name = n; x.off = total; x.size = count; x.ndim = 1; x.dims[0] = x.dims[1] = x.dims[2] = x.dims[3] = 1; x.dtype = dtype;
+    long floats = (dtype == CRNN_BF16) ? (count + 1) / 2 : count;
+    t.push_back(x); total += (floats + 63) & ~63L;  // 256-byte aligned
     return x.off;
   }
+  int dt(const std::string& n) const { for (auto& x : t) if (x.name == n) return x.dtype; return CRNN_F32; }
   long off(const std::string& n) const { for (auto& x : t) if (x.name == n) return x.off; return -1; }
   long cnt(const std::string& n) const { for (auto& x : t) if (x.name == n) return x.size; return -1; }
 };
@@ -117,7 +120,10 @@ Plan make_plan(const crnn_config* c) {
     long M = B * d.bh[i] * d.bw[i];
     int ci = d.bc[i - 1], co = d.bc[i];
     long Mo = B * (d.bh[i] / kBlocks[i - 1].ph) * (d.bw[i] / kBlocks[i - 1].pw);
-    P.add("d" + p, M * ci); P.add("a" + p, M * ci); P.add("q" + p, M * co); P.add("x" + p, Mo * co);
+    // storage mode 2 (bf16 tensors): every conv-stack tensor with >= 4 channels is kept as bf16
+    const int sdt_in = (c->mfma_bf16 == 2 && ci % 4 == 0) ? CRNN_BF16 : CRNN_F32;
+    const int sdt_out = (c->mfma_bf16 == 2) ? CRNN_BF16 : CRNN_F32;
+    P.add("d" + p, M * ci, sdt_in); P.add("a" + p, M * ci, sdt_in); P.add("q" + p, M * co, sdt_out); P.add("x" + p, Mo * co, sdt_out);
     maxact = lmax(maxact, M * co);
     long tiles = crnn_dwconv_num_tiles(d.B, d.bh[i], d.bw[i]);
     maxparts = lmax(maxparts, tiles * 9L * ci);
@@ -141,6 +147,7 @@ Plan make_plan(const crnn_config* c) {
   P.add("dcf", B * d.u); P.add("dcb", B * d.u); P.add("dhpf", B * d.u); P.add("dhpb", B * d.u);
   P.add("ddn1", TB * d.tds); P.add("gbm", TB * d.tds);
   maxact = lmax(maxact, TB * d.feat);
+  // gradient ping-pong buffers: sized for fp32, hold bf16 tensors in storage mode 2
   P.add("gA", maxact); P.add("gB", maxact);
   P.add("dtheta", B * 6); P.add("dfc1", B * 50); P.add("dflat", B * d.stn_flat);
   P.add("dcol2", B * d.Ho2 * d.Wo2 * 500); P.add("dpool2", B * d.Hs2 * d.Ws2 * 20); P.add("dc1", B * d.Ho1 * d.Wo1 * 20);
@@ -160,6 +167,8 @@ struct Ctx {
   const float* p(const std::string& n) const { return params + L.off(n); }
   float* g(const std::string& n) const { return grads + L.off(n); }
   float* w(const std::string& n) const { return ws + P.off(n); }
+  int dt(const std::string& n) const { return P.dt(n); }
+  int gdt() const { return cfg->mfma_bf16 == 2 ? CRNN_BF16 : CRNN_F32; }   // storage of the conv-stack gradients
   float* scratch() const { return ws + P.off("gemm_scratch"); }
 };
 
@@ -169,6 +178,14 @@ int gemm(const Ctx& c, int mode, const float* A, const float* B, float* C, int M
   if (c.cfg->mfma_bf16)
     return crnn_gemm_bf16(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, c.scratch(), kGemmScratchBytes, c.s);
   return crnn_gemm_f32(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, c.scratch(), kGemmScratchBytes, c.s);
+}
+// GEMM with explicit operand / result storage types (storage mode 2); falls back to the plain entry points otherwise
+int gemm_t(const Ctx& c, int mode, const float* A, int dtA, const float* B, int dtB, float* C, int dtC, int M, int N, int K, int lda,
+           int ldb, int ldc, const float* bias = nullptr, int act = 0, int acc = 0, int perm = 0) {
+  if (c.cfg->mfma_bf16 == 2)
+    return crnn_gemm_bf16_ex(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, c.scratch(), kGemmScratchBytes, dtA, dtB, dtC, c.s);
+  if (dtA != CRNN_F32 || dtB != CRNN_F32 || dtC != CRNN_F32) return CRNN_ERR_ARG;
+  return gemm(c, mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm);
 }
 // always-fp32 GEMM (spatial-transformer localisation net: tiny, and theta is precision-sensitive)
 int gemm32(const Ctx& c, int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
@@ -184,6 +201,7 @@ int colsum(const Ctx& c, const float* x, long M, int C, int ld, float* out) {
 int check_cfg(const crnn_config* c) {
   if (!c || c->batch <= 0) return CRNN_ERR_ARG;
   if (c->units < 64 || c->units % 64) return CRNN_ERR_UNSUPPORTED;
+  if (c->mfma_bf16 < 0 || c->mfma_bf16 > 2) return CRNN_ERR_ARG;
   if (c->num_classes > 64 || c->num_classes < 2) return CRNN_ERR_UNSUPPORTED;
   if (2 * c->max_len + 1 > 64) return CRNN_ERR_UNSUPPORTED;
   if (c->tds % 4) return CRNN_ERR_UNSUPPORTED;
@@ -233,6 +251,15 @@ extern "C" size_t crnn_workspace_bytes(const crnn_config* cfg) {
   if (check_cfg(cfg)) return 0;
   return (size_t)make_plan(cfg).total * sizeof(float);
 }
+extern "C" int crnn_ws_tensor_info(const crnn_config* cfg, const char* name, long* offset, long* count, int* dtype) {
+  Plan P = make_plan(cfg);
+  long o = P.off(name);
+  if (o < 0) return CRNN_ERR_ARG;
+  if (offset) *offset = o;
+  if (count) *count = P.cnt(name);
+  if (dtype) *dtype = P.dt(name);
+  return 0;
+}
 extern "C" int crnn_ws_tensor(const crnn_config* cfg, const char* name, long* offset, long* count) {
   Plan P = make_plan(cfg);
   long o = P.off(name);
@@ -277,33 +304,35 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
     float* dd = c.w("d" + p); float* aa = c.w("a" + p); float* qq = c.w("q" + p); float* xo = c.w("x" + p);
     float* s1 = c.w("bn1s" + p); float* s2 = c.w("bn2s" + p);
     float* parts = c.w("partials");
+    const int dtd = c.dt("d" + p), dtq = c.dt("q" + p);
     if (ci % 32 == 0) {
-      CRNN_TRY(crnn_dwconv3x3_fwd(in, c.p(bp + "_dw"), dd, train ? parts : nullptr, B, H, W, ci, 0, stream));
+      CRNN_TRY(crnn_dwconv3x3_fwd_ex(in, c.p(bp + "_dw"), dd, train ? parts : nullptr, B, H, W, ci, 0, dtd, stream));
       if (train) CRNN_TRY(crnn_bn_finalize(parts, crnn_dwconv_num_tiles(B, H, W), ci, M, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), s1, stream));
     } else {
-      CRNN_TRY(crnn_dwconv3x3_fwd(in, c.p(bp + "_dw"), dd, nullptr, B, H, W, ci, 0, stream));
+      CRNN_TRY(crnn_dwconv3x3_fwd_ex(in, c.p(bp + "_dw"), dd, nullptr, B, H, W, ci, 0, dtd, stream));
       if (train) {
-        CRNN_TRY(crnn_colreduce(dd, parts, M, ci, ci, 2, stream));
+        CRNN_TRY(crnn_colreduce_ex(dd, parts, M, ci, ci, 2, dtd, stream));
         CRNN_TRY(crnn_bn_finalize(parts, crnn_colreduce_chunks(M), ci, M, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), s1, stream));
       }
     }
     if (!train) CRNN_TRY(crnn_bn_infer_state(bn_mean + bn_off, bn_var + bn_off, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), ci, s1, stream));
     bn_off += ci;
-    CRNN_TRY(crnn_bn_act(dd, s1, aa, M, ci, stream));
-    CRNN_TRY(gemm(c, 0, aa, c.p(bp + "_pw"), qq, (int)M, co, ci, ci, co, co));
+    CRNN_TRY(crnn_bn_act_pool_drop_ex(dd, s1, aa, 1, 1, (int)M, ci, 1, 1, 0.f, 0, 0, dtd, dtd, stream));
+    CRNN_TRY(gemm_t(c, 0, aa, dtd, c.p(bp + "_pw"), CRNN_F32, qq, dtq, (int)M, co, ci, ci, co, co));
     if (train) {
-      CRNN_TRY(crnn_colreduce(qq, parts, M, co, co, 2, stream));
+      CRNN_TRY(crnn_colreduce_ex(qq, parts, M, co, co, 2, dtq, stream));
       CRNN_TRY(crnn_bn_finalize(parts, crnn_colreduce_chunks(M), co, M, c.p(bp + "_bn2_g"), c.p(bp + "_bn2_b"), s2, stream));
     } else {
       CRNN_TRY(crnn_bn_infer_state(bn_mean + bn_off, bn_var + bn_off, c.p(bp + "_bn2_g"), c.p(bp + "_bn2_b"), co, s2, stream));
     }
     bn_off += co;
-    CRNN_TRY(crnn_bn_act_pool_drop(qq, s2, xo, B, H, W, co, kBlocks[i - 1].ph, kBlocks[i - 1].pw, (train && cfg->dropout) ? kDropBlock : 0.f, seed, (uint32_t)i, stream));
+    CRNN_TRY(crnn_bn_act_pool_drop_ex(qq, s2, xo, B, H, W, co, kBlocks[i - 1].ph, kBlocks[i - 1].pw, (train && cfg->dropout) ? kDropBlock : 0.f, seed,
+                                      (uint32_t)i, dtq, c.dt("x" + p), stream));
     in = xo;
   }
   // ---- Reshape + dense1 (relu) + Dropout(.4) (utils.py:72-75); output time-major [T][B][tds]
   const int T = d.T, TB = T * B, u = d.u, G = d.G;
-  CRNN_TRY(gemm(c, 0, in, c.p("dense1_w"), c.w("dn1"), TB, d.tds, d.feat, d.feat, d.tds, d.tds, c.p("dense1_b"), 1, 0, T));
+  CRNN_TRY(gemm_t(c, 0, in, c.dt("x7"), c.p("dense1_w"), CRNN_F32, c.w("dn1"), CRNN_F32, TB, d.tds, d.feat, d.feat, d.tds, d.tds, c.p("dense1_b"), 1, 0, T));
   if (train && cfg->dropout) CRNN_TRY(crnn_dropout(c.w("dn1"), c.w("dn1"), TB, d.tds, d.tds, d.tds, kDropDense1, seed, kLayerDense1, stream));
   // ---- 2 x Bidirectional(LSTM) (utils.py:78-79)
   for (const char* n : {"1f", "1b", "2f", "2b"})
@@ -396,24 +425,25 @@ extern "C" int crnn_backward(const crnn_config* cfg, const float* params, float*
   // ---- Dropout(.4) + relu of dense1, rows back to batch-major
   CRNN_TRY(crnn_relu_bwd(c.w("dn1"), c.w("ddn1"), c.w("gbm"), TB, d.tds, cfg->dropout ? 1.0f / (1.0f - kDropDense1) : 1.0f, B, stream));
   const float* feat = c.w("x7");
-  CRNN_TRY(gemm(c, 2, feat, c.w("gbm"), c.g("dense1_w"), d.feat, d.tds, TB, d.feat, d.tds, d.tds));
+  CRNN_TRY(gemm_t(c, 2, feat, c.dt("x7"), c.w("gbm"), CRNN_F32, c.g("dense1_w"), CRNN_F32, d.feat, d.tds, TB, d.feat, d.tds, d.tds));
   CRNN_TRY(colsum(c, c.w("gbm"), TB, d.tds, d.tds, c.g("dense1_b")));
   float* gA = c.w("gA"); float* gB = c.w("gB");
-  CRNN_TRY(gemm(c, 1, c.w("gbm"), c.p("dense1_w"), gA, TB, d.feat, d.tds, d.tds, d.tds, d.feat));
+  CRNN_TRY(gemm_t(c, 1, c.w("gbm"), CRNN_F32, c.p("dense1_w"), CRNN_F32, gA, c.gdt(), TB, d.feat, d.tds, d.tds, d.tds, d.feat));
   // ---- conv stack
   for (int i = 7; i >= 1; --i) {
     std::string p = std::to_string(i), bp = "b" + p;
     const int H = d.bh[i], W = d.bw[i], ci = d.bc[i - 1], co = d.bc[i];
     const long M = (long)B * H * W;
-    CRNN_TRY(crnn_bn_bwd(c.w("q" + p), gA, c.w("bn2s" + p), c.p(bp + "_bn2_g"), gB, c.g(bp + "_bn2_g"), c.g(bp + "_bn2_b"), c.w("partials"),
-                         c.w("coef"), B, H, W, co, kBlocks[i - 1].ph, kBlocks[i - 1].pw, cfg->dropout ? kDropBlock : 0.f, seed, (uint32_t)i, stream));
-    CRNN_TRY(gemm(c, 2, c.w("a" + p), gB, c.g(bp + "_pw"), ci, co, (int)M, ci, co, co));
-    CRNN_TRY(gemm(c, 1, gB, c.p(bp + "_pw"), gA, (int)M, ci, co, co, co, ci));
-    CRNN_TRY(crnn_bn_bwd(c.w("d" + p), gA, c.w("bn1s" + p), c.p(bp + "_bn1_g"), gB, c.g(bp + "_bn1_g"), c.g(bp + "_bn1_b"), c.w("partials"),
-                         c.w("coef"), B, H, W, ci, 1, 1, 0.f, 0, 0, stream));
+    const int dtd = c.dt("d" + p), dtq = c.dt("q" + p);   // dtq == storage of the incoming gradient (gdt)
+    CRNN_TRY(crnn_bn_bwd_ex(c.w("q" + p), gA, c.w("bn2s" + p), c.p(bp + "_bn2_g"), gB, c.g(bp + "_bn2_g"), c.g(bp + "_bn2_b"), c.w("partials"),
+                            c.w("coef"), B, H, W, co, kBlocks[i - 1].ph, kBlocks[i - 1].pw, cfg->dropout ? kDropBlock : 0.f, seed, (uint32_t)i, dtq, stream));
+    CRNN_TRY(gemm_t(c, 2, c.w("a" + p), dtd, gB, dtq, c.g(bp + "_pw"), CRNN_F32, ci, co, (int)M, ci, co, co));
+    CRNN_TRY(gemm_t(c, 1, gB, dtq, c.p(bp + "_pw"), CRNN_F32, gA, dtd, (int)M, ci, co, co, co, ci));
+    CRNN_TRY(crnn_bn_bwd_ex(c.w("d" + p), gA, c.w("bn1s" + p), c.p(bp + "_bn1_g"), gB, c.g(bp + "_bn1_g"), c.g(bp + "_bn1_b"), c.w("partials"),
+                            c.w("coef"), B, H, W, ci, 1, 1, 0.f, 0, 0, dtd, stream));
     const float* xin = (i == 1) ? c.w("x0") : c.w("x" + std::to_string(i - 1));
-    CRNN_TRY(crnn_dwconv3x3_wgrad(xin, gB, c.g(bp + "_dw"), c.w("partials"), B, H, W, ci, stream));
-    if (i > 1 || cfg->stn) CRNN_TRY(crnn_dwconv3x3_fwd(gB, c.p(bp + "_dw"), gA, nullptr, B, H, W, ci, 1, stream));
+    CRNN_TRY(crnn_dwconv3x3_wgrad_ex(xin, gB, c.g(bp + "_dw"), c.w("partials"), B, H, W, ci, dtd, stream));
+    if (i > 1 || cfg->stn) CRNN_TRY(crnn_dwconv3x3_fwd_ex(gB, c.p(bp + "_dw"), gA, nullptr, B, H, W, ci, 1, dtd, stream));
   }
   // ---- spatial transformer
   if (cfg->stn) {

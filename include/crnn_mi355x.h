@@ -34,7 +34,8 @@ typedef struct {
   int stn;          /* 1 = spatial transformer enabled (utils.py:62) */
   int dropout;      /* 1 = Dropout(.1/.4/.2) active in train mode (utils.py:56,75,83); 0 = off (parity runs) */
   int mfma_bf16;    /* 0 = fp32 MFMA everywhere (parity mode); 1 = conv-stack / dense / RNN-input GEMMs multiply in bf16
-                       (operands rounded while staged into LDS, fp32 accumulate, fp32 tensors in HBM) */
+                       (operands rounded while staged into LDS, fp32 accumulate, fp32 tensors in HBM); 2 = as 1 and the
+                       conv-stack activations / gradients are stored as bf16 in HBM (statistics, RNN, CTC, optimizer fp32) */
 } crnn_config;
 
 /* ---- parameter / statistics layout (Keras weight order) -------------------------------------- */
@@ -50,6 +51,8 @@ int  crnn_time_steps(const crnn_config* cfg);                 /* T = (imgh+4)/2 
 size_t crnn_workspace_bytes(const crnn_config* cfg);
 /* named view into the workspace (float offset, element count) -- for parity tests / debugging */
 int  crnn_ws_tensor(const crnn_config* cfg, const char* name, long* offset, long* count);
+/* same + storage type of the tensor (0 = fp32, 1 = bf16; offset stays in floats, count in elements) */
+int  crnn_ws_tensor_info(const crnn_config* cfg, const char* name, long* offset, long* count, int* dtype);
 
 /* ---- whole-path drivers ------------------------------------------------------------------------------------- */
 /* Forward of the predictor sub-model (utils.py:308-312; Model.predict_generator, predict.py:166):
@@ -97,6 +100,20 @@ int crnn_gemm_f32(int mode, const float* A, const float* B, float* C, int M, int
 int crnn_gemm_bf16(int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                    const float* bias, int act, int accumulate, int permP, float* scratch, size_t scratch_bytes,
                    crnn_stream_t stream);
+/* storage-typed variants (dt*: 0 = fp32, 1 = bf16 tensors in HBM; arithmetic stays fp32 / bf16-MFMA with fp32 accumulate) */
+int crnn_gemm_bf16_ex(int mode, const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                      const float* bias, int act, int accumulate, int permP, float* scratch, size_t scratch_bytes, int dtA,
+                      int dtB, int dtC, crnn_stream_t stream);
+int crnn_dwconv3x3_fwd_ex(const void* x, const float* k, void* out, float* stat_partials, int B, int H, int W, int C, int flip,
+                          int dtype, crnn_stream_t stream);
+int crnn_dwconv3x3_wgrad_ex(const void* x, const void* g, float* dk, float* scratch, int B, int H, int W, int C, int dtype,
+                            crnn_stream_t stream);
+int crnn_colreduce_ex(const void* x, float* partials, long M, int C, int ld, int nv, int dtype, crnn_stream_t stream);
+int crnn_bn_act_pool_drop_ex(const void* x, const float* bnstate, void* y, int B, int H, int W, int C, int ph, int pw, float rate,
+                             uint64_t seed, uint32_t layer, int dt_in, int dt_out, crnn_stream_t stream);
+int crnn_bn_bwd_ex(const void* x, const void* g, const float* bnstate, const float* gamma, void* dx, float* dgamma, float* dbeta,
+                   float* scratch_partials, float* coef, int B, int H, int W, int C, int ph, int pw, float rate, uint64_t seed,
+                   uint32_t layer, int dtype, crnn_stream_t stream);
 /* DepthwiseConv2D 3x3 'same' (utils.py:44): k [9][C]; flip=1 = data gradient; stat_partials [tiles][2][C] */
 int crnn_dwconv_num_tiles(int B, int H, int W);
 int crnn_dwconv3x3_fwd(const float* x, const float* k, float* out, float* stat_partials, int B, int H, int W, int C,

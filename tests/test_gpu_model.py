@@ -40,7 +40,7 @@ def layer_report(eng, cfg, c, B):
     rep = {}
 
     def cmp(name, ref, tm=False):
-        t = eng.ws_tensor(name).cpu().numpy().astype(np.float64)
+        t = eng.ws_tensor(name).float().cpu().numpy().astype(np.float64)
         ref = np.asarray(ref, dtype=np.float64)
         if tm:
             ref = np.swapaxes(ref, 0, 1)
@@ -70,7 +70,7 @@ def device_cache(eng, cfg, p, x, B, c_ref):
     (`layer_report`); the backward pass is checked against the oracle's backward evaluated on the device's own
     forward state, so both sides take identical gate decisions."""
     T = eng.T
-    f64 = lambda name: eng.ws_tensor(name).cpu().numpy().astype(np.float64)
+    f64 = lambda name: eng.ws_tensor(name).float().cpu().numpy().astype(np.float64)
     c = {"x": x, "stats": {}}
     if eng.cfg.stn:
         for n in ("pool1", "c1", "pool2", "flat", "fc1", "theta"):
@@ -146,7 +146,7 @@ def check_case(res, tag):
     cfg, eng, p, bn, batch, yd, loss_d, gd, c, loss_b, g, rep, gdev = res
     bad = {k: v for k, v in rep.items() if v[0] > 1e-3 * max(1.0, v[1])}
     assert not bad, f"{tag}: intermediates off: {bad}"
-    assert np.abs(c["logits"] - eng.ws_tensor("logits").cpu().numpy().reshape(c["logits"].shape)).max() < 1e-3
+    assert np.abs(c["logits"] - eng.ws_tensor("logits").float().cpu().numpy().reshape(c["logits"].shape)).max() < 1e-3
     assert np.abs(yd - c["y_pred"]).max() < 1e-4
     assert np.all(np.abs(loss_d - loss_b) < 1e-3 + 1e-5 * np.abs(loss_b)), (loss_d, loss_b)
     worst = {}
@@ -162,7 +162,7 @@ def check_case(res, tag):
     for i in range(1, 8):
         for key, dev_name in ((f"a{i}", f"a{i}"),):
             a_ref = c[key]
-            a_dev = eng.ws_tensor(dev_name).cpu().numpy().reshape(a_ref.shape)
+            a_dev = eng.ws_tensor(dev_name).float().cpu().numpy().reshape(a_ref.shape)
             flips += int((((a_ref > 0) & (a_ref < 6)) != ((a_dev > 0) & (a_dev < 6))).sum())
     loose = {}
     for k in p:
@@ -257,15 +257,16 @@ def test_train_steps_are_deterministic_and_loss_decreases():
     assert np.isfinite(losses[0]).all() and losses[0][-1] < losses[0][0]
 
 
-def test_bf16_mfma_mode_tracks_the_fp32_oracle():
-    """Fast mode (crnn_config.mfma_bf16): GEMM products in bf16, everything else fp32.  Not a parity mode: the
-    forward must stay within bf16 round-off of the oracle and the gradients must point the same way."""
+@pytest.mark.parametrize("precision", ["bf16", "bf16s"])
+def test_bf16_mfma_mode_tracks_the_fp32_oracle(precision):
+    """Fast modes: 'bf16' = GEMM products in bf16 (fp32 tensors); 'bf16s' = additionally bf16 conv-stack tensors in HBM.
+    Not parity modes: the forward must stay within bf16 round-off of the oracle and the gradients must point the same way."""
     cfg = M.Config()
     B = 8
     p, bn = M.init_params(cfg, seed=7, dtype=np.float64)
     p = M.randomize_params(cfg, p)
     x, lab, il, ll = M.synthetic_batch(cfg, B, seed=1, dtype=np.float64)
-    eng = Engine(B, dropout=False, precision="bf16")
+    eng = Engine(B, dropout=False, precision=precision)
     eng.set_params(p, bn)
     yd = eng.forward(x.astype(np.float32), train=True, seed=0).cpu().numpy()
     loss_d = eng.backward(lab, il, ll, seed=0).cpu().numpy()
@@ -275,24 +276,24 @@ def test_bf16_mfma_mode_tracks_the_fp32_oracle():
     agree = (np.argmax(yd, -1) == np.argmax(c["y_pred"], -1)).mean()
     rel_loss = np.abs(loss_d - loss_b).max() / np.abs(loss_b).max()
     cos = {k: float((gd[k].ravel() @ g[k].ravel()) / (np.linalg.norm(gd[k]) * np.linalg.norm(g[k]) + 1e-30)) for k in p if g[k].size >= 512}
-    print(f"[bf16] max|dy|={err_y:.3e} argmax agreement={agree:.4f} rel loss err={rel_loss:.3e} grad cosines: "
+    print(f"[{precision}] max|dy|={err_y:.3e} argmax agreement={agree:.4f} rel loss err={rel_loss:.3e} grad cosines: "
           + " ".join(f"{k}:{v:.3f}" for k, v in cos.items()))
-    assert err_y < 5e-2 and agree > 0.97 and rel_loss < 2e-2
+    assert err_y < 5e-2 and agree > (0.97 if precision == "bf16" else 0.93) and rel_loss < 2e-2
     # bf16 products perturb ~1 % of the ReLU6 / pool decisions (cf. DESIGN.md "threshold flips"), so the gradients
     # of the lower layers are noisy copies of the fp64 ones; the top of the network must still agree closely
     for k in ("dense2_w", "rnn2f_w", "rnn2b_u", "rnn1f_w", "dense1_w"):
-        assert cos[k] > 0.97, (k, cos[k])
-    assert min(cos.values()) > 0.5, cos
+        assert cos[k] > (0.97 if precision == "bf16" else 0.95), (k, cos[k])
+    assert min(cos.values()) > (0.5 if precision == "bf16" else 0.3), cos
     # what matters for the fast mode: optimisation behaves like the fp32 mode
     from crnn_mi355x.optimizers import Adam
     p32, bn32 = M.init_params(cfg, seed=1, dtype=np.float32)
     xb, labb, ilb, llb = M.synthetic_batch(cfg, 32, seed=0)
     curves = {}
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", precision):
         e = Engine(32, dropout=True, precision=prec)
         e.set_params(p32, bn32)
         opt = Adam(lr=1e-3, beta_1=0.5, beta_2=0.999, clipnorm=5)
         curves[prec] = [float(e.train_step(xb, labb, ilb, llb, opt, it).mean().item()) for it in range(25)]
-    print("[bf16] loss curves fp32 vs bf16:", [round(v, 2) for v in curves["fp32"][::6]], [round(v, 2) for v in curves["bf16"][::6]])
-    assert curves["bf16"][-1] < 0.75 * curves["bf16"][0]
-    assert abs(curves["bf16"][-1] - curves["fp32"][-1]) < 0.1 * curves["fp32"][-1]
+    print(f"[{precision}] loss curves fp32 vs {precision}:", [round(v, 2) for v in curves["fp32"][::6]], [round(v, 2) for v in curves[precision][::6]])
+    assert curves[precision][-1] < 0.75 * curves[precision][0]
+    assert abs(curves[precision][-1] - curves["fp32"][-1]) < 0.1 * curves["fp32"][-1]

@@ -413,3 +413,82 @@ def test_adam_sgd_clipnorm():
             ok(L().crnn_sgd_step(P(pd), P(gd), P(vel), n, 1e-2 / (1 + 1e-6 * it), 0.9, 1, P(norm), S()))
             opt.step(po, {"w": g})
         assert_close(host(pd), po["w"], rtol=1e-5, atol=1e-6, what="sgd")
+
+
+# ------------------------------------------------------------------------------------------------ bf16 storage variants
+def _to_bf16_dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda().to(torch.bfloat16)
+
+
+def _f(t):
+    return t.float().cpu().numpy().astype(np.float64)
+
+
+def test_bf16_storage_dwconv_bn_chain():
+    """Storage-typed kernels (dtype=1): inputs/outputs are bf16 tensors, arithmetic fp32.  Reference = the oracle on the
+    bf16-rounded inputs; outputs agree to one bf16 rounding (2^-8 relative)."""
+    rs = np.random.RandomState(3)
+    B, H, W, C = 2, 13, 18, 64
+    x = _bf16_round(rs.normal(size=(B, H, W, C))); k = rs.normal(size=(3, 3, C)); g = _bf16_round(rs.normal(size=(B, H, W, C)))
+    xd, gd = _to_bf16_dev(x), _to_bf16_dev(g)
+    _KEEP = [xd, gd]
+    out = torch.zeros(B, H, W, C, dtype=torch.bfloat16, device="cuda")
+    nt = L().crnn_dwconv_num_tiles(B, H, W)
+    parts = zeros(nt, 2, C)
+    ok(L().crnn_dwconv3x3_fwd_ex(P(xd), P(dev(k)), P(out), P(parts), B, H, W, C, 0, 1, S()))
+    ref = ops.dwconv_fwd(x, k)
+    assert_close(_f(out), ref, rtol=2.0 ** -8, atol=2e-2, what="dw fwd bf16")
+    assert_close(host(parts).sum(0)[0], ref.sum((0, 1, 2)), rtol=1e-4, atol=1e-2, what="stats from fp32 values")
+    dk = zeros(9, C); scr = zeros(nt * 9 * C)
+    ok(L().crnn_dwconv3x3_wgrad_ex(P(xd), P(gd), P(dk), P(scr), B, H, W, C, 1, S()))
+    assert_close(host(dk).reshape(3, 3, C), ops.dwconv_bwd(x, k, g)[1], rtol=1e-4, atol=1e-3, what="dw wgrad bf16 in, fp32 out")
+    # BN statistics + apply + pool on a bf16 tensor, bf16 result
+    gamma = 1 + 0.3 * rs.normal(size=C); beta = 0.5 * rs.normal(size=C) + 1.0
+    Mr = B * H * W
+    ch = L().crnn_colreduce_chunks(Mr); cp = zeros(ch, 2, C)
+    ok(L().crnn_colreduce_ex(P(xd), P(cp), Mr, C, C, 2, 1, S()))
+    st = zeros(4 * C)
+    ok(L().crnn_bn_finalize(P(cp), ch, C, Mr, P(dev(gamma)), P(dev(beta)), P(st), S()))
+    y_bn, mean, var = ops.bn_train_fwd(x, gamma, beta)
+    assert_close(host(st)[:C], mean, what="mean"); assert_close(host(st)[C:2 * C], var, what="var")
+    Hq, Wq = (H // 1), (W // 2)
+    y = torch.zeros(B, Hq, Wq, C, dtype=torch.bfloat16, device="cuda")
+    ok(L().crnn_bn_act_pool_drop_ex(P(xd), P(st), P(y), B, H, W, C, 1, 2, 0.0, 0, 0, 1, 1, S()))
+    r = ops.relu6_fwd(y_bn)
+    assert_close(_f(y), ops.maxpool_fwd(r, 1, 2), rtol=2.0 ** -8, atol=2e-2, what="bn+relu6+pool bf16")
+    # BN backward with bf16 x / g / dx
+    gp = _bf16_round(rs.normal(size=(B, Hq, Wq, C)))
+    gpd = _to_bf16_dev(gp)
+    dx = torch.zeros(B, H, W, C, dtype=torch.bfloat16, device="cuda"); dgm = zeros(C); dbt = zeros(C)
+    pp = zeros(L().crnn_bn_bwd_chunks(Mr), 2, C); coef = zeros(2 * C)
+    ok(L().crnn_bn_bwd_ex(P(xd), P(gpd), P(st), P(dev(gamma)), P(dx), P(dgm), P(dbt), P(pp), P(coef), B, H, W, C, 1, 2, 0.0, 0, 0, 1, S()))
+    gr = ops.relu6_bwd_from_out(r, ops.maxpool_bwd(r, gp, 1, 2))
+    dx_ref, dg_ref, db_ref = ops.bn_train_bwd(x, gamma, mean, var, gr)
+    assert_close(host(dgm), dg_ref, rtol=1e-3, atol=1e-2, what="dgamma"); assert_close(host(dbt), db_ref, rtol=1e-3, atol=1e-2, what="dbeta")
+    assert_close(_f(dx), dx_ref, rtol=2.0 ** -7, atol=2e-2, what="dx bf16")
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_gemm_bf16_storage_operands_and_result(mode):
+    rs = np.random.RandomState(40 + mode)
+    Mm, N, K = 300, 136, 200
+    A = _bf16_round(rs.normal(size=(Mm, K))); B = _bf16_round(rs.normal(size=(K, N)))
+    ref = A @ B
+    if mode == 0:
+        Ad, Bd, lda, ldb = _to_bf16_dev(A), _to_bf16_dev(B), K, N
+    elif mode == 1:
+        Ad, Bd, lda, ldb = _to_bf16_dev(A), _to_bf16_dev(B.T), K, K
+    else:
+        Ad, Bd, lda, ldb = _to_bf16_dev(A.T), _to_bf16_dev(B), Mm, N
+    scr = zeros(16 * 1024 * 1024)
+    C32 = zeros(Mm, N)
+    ok(L().crnn_gemm_bf16_ex(mode, P(Ad), P(Bd), P(C32), Mm, N, K, lda, ldb, N, None, 0, 0, 0, P(scr), 64 * 1024 * 1024, 1, 1, 0, S()))
+    assert_close(host(C32), ref, rtol=2e-5, atol=1e-4, what="bf16 operands, fp32 result")
+    C16 = torch.zeros(Mm, N, dtype=torch.bfloat16, device="cuda")
+    ok(L().crnn_gemm_bf16_ex(mode, P(Ad), P(Bd), P(C16), Mm, N, K, lda, ldb, N, None, 0, 0, 0, P(scr), 64 * 1024 * 1024, 1, 1, 1, S()))
+    assert_close(_f(C16), ref, rtol=2.0 ** -8, atol=1e-3, what="bf16 result")
+    # mixed: fp32 A (activations) x bf16 B, accumulate into a bf16 C
+    A32 = dev(A) if mode != 2 else dev(A.T)
+    C0 = _bf16_round(rs.normal(size=(Mm, N))); Cacc = _to_bf16_dev(C0)
+    ok(L().crnn_gemm_bf16_ex(mode, P(A32), P(Bd), P(Cacc), Mm, N, K, lda, ldb, N, None, 0, 1, 0, P(scr), 64 * 1024 * 1024, 0, 1, 1, S()))
+    assert_close(_f(Cacc), ref + C0, rtol=2.0 ** -7, atol=1e-2, what="accumulate into bf16")
