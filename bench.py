@@ -39,20 +39,22 @@ def depthwise_roofline(eng, iters=5):
     blocks = [(64, 1, 1), (128, 1, 1), (256, 2, 2), (256, 1, 1), (512, 1, 2), (512, 1, 1), (512, 1, 1)]
     h, w, cin = eng.cfg.imgh + 4, eng.cfg.imgw + 4, 1
     launches, nbytes = [], 0.0
+    esz = 2 if eng.precision == "bf16s" else 4          # storage bytes per element of the conv-stack tensors
+    dtype = 1 if eng.precision == "bf16s" else 0
     parts = eng.ws_tensor("partials")
     for i, (co, ph, pw) in enumerate(blocks, 1):
         if i >= 2:
             k = eng.params[eng.layout["b%d_dw" % i][0]:]
             launches.append((eng.ws_tensor("x%d" % (i - 1)), k, eng.ws_tensor("d%d" % i), parts, h, w, cin, 0))   # forward
             launches.append((eng.ws_tensor("gB"), k, eng.ws_tensor("gA"), None, h, w, cin, 1))                    # data gradient
-            nbytes += 2 * (2.0 * B * h * w * cin * 4)
+            nbytes += 2 * (2.0 * B * h * w * cin * esz)
         h, w, cin = h // ph, w // pw, co
     times = []
     for it in range(iters + 1):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for x, k, o, pt, hh, ww, cc, flip in launches:
-            lib.crnn_dwconv3x3_fwd(_ptr(x), _ptr(k), _ptr(o), _ptr(pt), B, hh, ww, cc, flip, _stream())
+            lib.crnn_dwconv3x3_fwd_ex(_ptr(x), _ptr(k), _ptr(o), _ptr(pt), B, hh, ww, cc, flip, dtype, _stream())
         e1.record()
         torch.cuda.synchronize()
         if it:
@@ -64,7 +66,7 @@ def depthwise_roofline(eng, iters=5):
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_dwconv.json")))
-        if B == pmc["batch"] and (eng.cfg.imgh, eng.cfg.imgw) == (100, 32):
+        if B == pmc["batch"] and (eng.cfg.imgh, eng.cfg.imgw) == (100, 32) and esz == 4:
             sh = pmc["shapes"]
             traffic = 2 * sh["104x36x64"]["hbm_bytes_per_launch"] + 2 * sh["104x36x128"]["hbm_bytes_per_launch"] \
                 + 8 * sh["52x18x256|52x9x512"]["hbm_bytes_per_launch"]
@@ -81,8 +83,9 @@ def pointwise_gemm_roofline(eng, iters=5):
     live buffers: flops / time against the MFMA peak of the active mode."""
     from crnn_mi355x.engine import _ptr, _stream
     lib = eng.lib
-    fn = lib.crnn_gemm_bf16 if eng.precision == "bf16" else lib.crnn_gemm_f32
-    peak = PEAK_BF16_MFMA_TFLOPS if eng.precision == "bf16" else PEAK_F32_MFMA_TFLOPS
+    bf = eng.precision != "fp32"
+    peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
+    sdt = 1 if eng.precision == "bf16s" else 0
     B, T = eng.B, eng.T
     cfgs = []
     h, w, cin = eng.cfg.imgh + 4, eng.cfg.imgw + 4, 1
@@ -90,29 +93,32 @@ def pointwise_gemm_roofline(eng, iters=5):
     for i, (co, ph, pw) in enumerate(blocks, 1):
         M = B * h * w
         if co > 64:
-            cfgs.append((eng.ws_tensor("a%d" % i), eng.params[eng.layout["b%d_pw" % i][0]:], eng.ws_tensor("q%d" % i), M, co, cin))
+            cfgs.append((eng.ws_tensor("a%d" % i), eng.params[eng.layout["b%d_pw" % i][0]:], eng.ws_tensor("q%d" % i), M, co, cin, sdt, sdt))
         h, w, cin = h // ph, w // pw, co
     feat = w * cin
     TB = T * B
     scratch = eng.ws_tensor("gemm_scratch")
-    cfgs.append((eng.ws_tensor("x7"), eng.params[eng.layout["dense1_w"][0]:], eng.ws_tensor("gA"), TB, eng.cfg.tds, feat))
+    cfgs.append((eng.ws_tensor("x7"), eng.params[eng.layout["dense1_w"][0]:], eng.ws_tensor("gA"), TB, eng.cfg.tds, feat, sdt, 0))
     u, G = eng.cfg.units, 4 * eng.cfg.units
     for n, src, k in (("rnn1f_w", "dn1", eng.cfg.tds), ("rnn1b_w", "dn1", eng.cfg.tds), ("rnn2f_w", "r1", u), ("rnn2b_w", "r1", u)):
-        cfgs.append((eng.ws_tensor(src), eng.params[eng.layout[n][0]:], eng.ws_tensor("gB"), TB, G, k))
-    flops = sum(2.0 * M * N * K for _, _, _, M, N, K in cfgs)
+        cfgs.append((eng.ws_tensor(src), eng.params[eng.layout[n][0]:], eng.ws_tensor("gB"), TB, G, k, 0, 0))
+    flops = sum(2.0 * M * N * K for _, _, _, M, N, K, _, _ in cfgs)
     times = []
     for it in range(iters + 1):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for A, Bm, C, M, N, K in cfgs:
-            fn(0, _ptr(A), _ptr(Bm), _ptr(C), M, N, K, K, N, N, None, 0, 0, 0, _ptr(scratch), 128 * 1024 * 1024, _stream())
+        for A, Bm, C, M, N, K, dta, dtc in cfgs:
+            if bf:
+                lib.crnn_gemm_bf16_ex(0, _ptr(A), _ptr(Bm), _ptr(C), M, N, K, K, N, N, None, 0, 0, 0, _ptr(scratch), 128 * 1024 * 1024, dta, 0, dtc, _stream())
+            else:
+                lib.crnn_gemm_f32(0, _ptr(A), _ptr(Bm), _ptr(C), M, N, K, K, N, N, None, 0, 0, 0, _ptr(scratch), 128 * 1024 * 1024, _stream())
         e1.record()
         torch.cuda.synchronize()
         if it:
             times.append(e0.elapsed_time(e1) * 1e-3)
     t = float(np.median(times))
     ach = flops / t / 1e12
-    return {"bound": "mfma", "kernel": "gemm_%s_kernel<128,false,true> (pointwise 1x1 convs fwd + dense1 + RNN input GEMMs)" % ("bf16" if eng.precision == "bf16" else "f32"),
+    return {"bound": "mfma", "kernel": "gemm_%s_kernel<128,false,true> (pointwise 1x1 convs fwd + dense1 + RNN input GEMMs)" % ("bf16" if bf else "f32"),
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "launches": len(cfgs), "avg_launch_ms": round(1e3 * t / len(cfgs), 4), "flops_per_launch_set": flops}
 
@@ -212,7 +218,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 100x32x1 text lines, batch %d/GPU, max_len 23, time_dense_size 128, "
-                                   "n_units 256 BiLSTM, STN on, dropout on, CTC, Adam(1e-4,b1=.5,clipnorm 5), %s" % (B, "fp32 MFMA" if args.precision == "fp32" else "bf16 MFMA products / fp32 accumulate+storage"),
+                                   "n_units 256 BiLSTM, STN on, dropout on, CTC, Adam(1e-4,b1=.5,clipnorm 5), %s" % (B, {"fp32": "fp32 MFMA", "bf16": "bf16 MFMA products / fp32 accumulate+storage",
+                                       "bf16s": "bf16 MFMA products, bf16 conv-stack tensors in HBM, fp32 accumulate/statistics/RNN/optimizer"}[args.precision]),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": round(last_loss, 4)},
         }
         if not args.no_roofline:
