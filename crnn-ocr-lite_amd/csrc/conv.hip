@@ -32,21 +32,26 @@ __global__ __launch_bounds__(NT) void dwconv_tile_kernel(const T* __restrict__ x
   const int b = blockIdx.y / nHb, h0 = (blockIdx.y % nHb) * TH;
   const int Wt = W + 2;
   const int n4 = (TH + 2) * Wt * 8;
-  // halo-tile fill: 4 independent 16-byte loads in flight per thread before the LDS writes
-  for (int base = tid; base < n4; base += 4 * NT) {
-    float4 v[4];
+  // halo-tile fill: all of this thread's loads (<= 12 x 16 bytes) are issued before the first LDS write, so the
+  // workgroup pays the HBM latency once (the kernel is latency-bound, not bandwidth-bound: see DESIGN.md)
+  for (int base = tid; base < n4; base += 12 * NT) {
+    float4 v[12];
+    // (ly, lx) of this thread's first element, then stepped by NT/8 pixels per load: no per-load integer division
+    int pix0 = base >> 3;
+    int fy = pix0 / Wt, fx = pix0 - fy * Wt;
+    const int ci = tid & 7;
 #pragma unroll
-    for (int uu = 0; uu < 4; ++uu) {
+    for (int uu = 0; uu < 12; ++uu) {
       int i = base + uu * NT;
-      int ci = i & 7, pix = i >> 3;
-      int ly = pix / Wt, lx = pix - ly * Wt;
-      int gh = h0 + ly - 1, gw = lx - 1;
+      int gh = h0 + fy - 1, gw = fx - 1;
       v[uu] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (i < n4 && gh >= 0 && gh < H && gw >= 0 && gw < W)
         v[uu] = ld4(&x[(((long)b * H + gh) * W + gw) * C + cc0 + 4 * ci]);
+      fx += NT / 8;
+      while (fx >= Wt) { fx -= Wt; ++fy; }
     }
 #pragma unroll
-    for (int uu = 0; uu < 4; ++uu) {
+    for (int uu = 0; uu < 12; ++uu) {
       int i = base + uu * NT;
       if (i < n4) tile[i] = v[uu];
     }
@@ -70,8 +75,8 @@ __global__ __launch_bounds__(NT) void dwconv_tile_kernel(const T* __restrict__ x
   float4 gnext = make_float4(0.f, 0.f, 0.f, 0.f);
   if (MODE == 1 && pt < npix && h0 + pt / W < H)
     gnext = ld4(&g[(((long)b * H + h0 + pt / W) * W + (pt % W)) * C + cc0 + 4 * c4]);
+  int ly = pt / W, lx = pt - (pt / W) * W;   // stepped incrementally below (no division per pixel)
   for (int p = pt; p < npix; p += NT / 8) {
-    int ly = p / W, lx = p - ly * W;
     int gh = h0 + ly;
     if (gh >= H) break;
     long o = (((long)b * H + gh) * W + lx) * C + cc0 + 4 * c4;
@@ -91,7 +96,8 @@ __global__ __launch_bounds__(NT) void dwconv_tile_kernel(const T* __restrict__ x
     } else {
       float4 gv = gnext;
       {  // prefetch the upstream gradient of this thread's next pixel
-        int pn = p + NT / 8, lyn = pn / W, lxn = pn - lyn * W;
+        int pn = p + NT / 8, lyn = ly, lxn = lx + NT / 8;
+        while (lxn >= W) { lxn -= W; ++lyn; }
         if (pn < npix && h0 + lyn < H) gnext = ld4(&g[(((long)b * H + h0 + lyn) * W + lxn) * C + cc0 + 4 * c4]);
       }
 #pragma unroll
@@ -103,6 +109,8 @@ __global__ __launch_bounds__(NT) void dwconv_tile_kernel(const T* __restrict__ x
           d.x = fmaf(v.x, gv.x, d.x); d.y = fmaf(v.y, gv.y, d.y); d.z = fmaf(v.z, gv.z, d.z); d.w = fmaf(v.w, gv.w, d.w);
         }
     }
+    lx += NT / 8;
+    while (lx >= W) { lx -= W; ++ly; }
   }
   if (partials == nullptr) return;
   __syncthreads();  // tile no longer needed: reuse LDS for the cross-pixel-thread reduction
