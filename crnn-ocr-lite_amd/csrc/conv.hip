@@ -19,39 +19,57 @@
 // mode 0: out = conv(x, k) (flip=1 -> taps flipped = data gradient), optional stats partials
 // mode 1: weight gradient partials: dk[tap][c] += x[shifted] * g[center]
 // ---------------------------------------------------------------------------------------------
+// raw 4-channel vector of the storage type (what sits in HBM and in the LDS tile) and its fp32 view
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { typedef float4 type; };
+template <> struct Raw4<bf16_t> { typedef uint2 type; };
+__device__ __forceinline__ float4 ldraw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ uint2 ldraw(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+__device__ __forceinline__ float4 cvt4(float4 v) { return v; }
+__device__ __forceinline__ float4 cvt4(uint2 u) {
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void zero4(float4& v) { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void zero4(uint2& v) { v = make_uint2(0u, 0u); }
+
+// A workgroup handles TH rows x full width x one 128-BYTE channel slab (32 fp32 or 64 bf16 channels): every
+// pixel's slab is one full 128-B HBM segment in either storage type.  CL = lanes per pixel (4 channels each).
 template <int MODE, int NT, typename T>
 __global__ __launch_bounds__(NT) void dwconv_tile_kernel(const T* __restrict__ x, const float* __restrict__ k,
                                                           const T* __restrict__ g, T* __restrict__ out,
                                                           float* __restrict__ partials, int B, int H, int W, int C,
                                                           int TH, int flip) {
+  typedef typename Raw4<T>::type V;
+  constexpr int CL = 128 / sizeof(V);         // 8 (fp32) or 16 (bf16)
+  constexpr int PT = NT / CL;                 // pixel threads
+  constexpr int MAXLD = 49152 / (NT * sizeof(V));   // loads per thread for a full 48 KiB tile: 12 or 24
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float4* tile = reinterpret_cast<float4*>(smem);
-  const int tid = threadIdx.x, c4 = tid & 7, pt = tid >> 3;
-  const int cc0 = blockIdx.x * 32;
+  V* tile = reinterpret_cast<V*>(smem);
+  const int tid = threadIdx.x, c4 = tid & (CL - 1), pt = tid / CL;
+  const int cc0 = blockIdx.x * (4 * CL);
   const int nHb = (H + TH - 1) / TH;
   const int b = blockIdx.y / nHb, h0 = (blockIdx.y % nHb) * TH;
   const int Wt = W + 2;
-  const int n4 = (TH + 2) * Wt * 8;
-  // halo-tile fill: all of this thread's loads (<= 12 x 16 bytes) are issued before the first LDS write, so the
-  // workgroup pays the HBM latency once (the kernel is latency-bound, not bandwidth-bound: see DESIGN.md)
-  for (int base = tid; base < n4; base += 12 * NT) {
-    float4 v[12];
-    // (ly, lx) of this thread's first element, then stepped by NT/8 pixels per load: no per-load integer division
-    int pix0 = base >> 3;
+  const int n4 = (TH + 2) * Wt * CL;
+  // halo-tile fill: all of this thread's loads are issued before the first LDS write (one HBM latency per
+  // workgroup); (fy, fx) are stepped incrementally: no per-load integer division
+  for (int base = tid; base < n4; base += MAXLD * NT) {
+    V v[MAXLD];
+    int pix0 = base / CL;
     int fy = pix0 / Wt, fx = pix0 - fy * Wt;
-    const int ci = tid & 7;
 #pragma unroll
-    for (int uu = 0; uu < 12; ++uu) {
+    for (int uu = 0; uu < MAXLD; ++uu) {
       int i = base + uu * NT;
       int gh = h0 + fy - 1, gw = fx - 1;
-      v[uu] = make_float4(0.f, 0.f, 0.f, 0.f);
+      zero4(v[uu]);
       if (i < n4 && gh >= 0 && gh < H && gw >= 0 && gw < W)
-        v[uu] = ld4(&x[(((long)b * H + gh) * W + gw) * C + cc0 + 4 * ci]);
-      fx += NT / 8;
+        v[uu] = ldraw(&x[(((long)b * H + gh) * W + gw) * C + cc0 + 4 * c4]);
+      fx += PT;
       while (fx >= Wt) { fx -= Wt; ++fy; }
     }
 #pragma unroll
-    for (int uu = 0; uu < 12; ++uu) {
+    for (int uu = 0; uu < MAXLD; ++uu) {
       int i = base + uu * NT;
       if (i < n4) tile[i] = v[uu];
     }
@@ -76,7 +94,7 @@ __global__ __launch_bounds__(NT) void dwconv_tile_kernel(const T* __restrict__ x
   if (MODE == 1 && pt < npix && h0 + pt / W < H)
     gnext = ld4(&g[(((long)b * H + h0 + pt / W) * W + (pt % W)) * C + cc0 + 4 * c4]);
   int ly = pt / W, lx = pt - (pt / W) * W;   // stepped incrementally below (no division per pixel)
-  for (int p = pt; p < npix; p += NT / 8) {
+  for (int p = pt; p < npix; p += PT) {
     int gh = h0 + ly;
     if (gh >= H) break;
     long o = (((long)b * H + gh) * W + lx) * C + cc0 + 4 * c4;
@@ -86,7 +104,7 @@ __global__ __launch_bounds__(NT) void dwconv_tile_kernel(const T* __restrict__ x
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          float4 v = tile[((ly + i) * Wt + lx + j) * 8 + c4];
+          float4 v = cvt4(tile[((ly + i) * Wt + lx + j) * CL + c4]);
           float4 w = kw[i * 3 + j];
           a.x = fmaf(v.x, w.x, a.x); a.y = fmaf(v.y, w.y, a.y); a.z = fmaf(v.z, w.z, a.z); a.w = fmaf(v.w, w.w, a.w);
         }
@@ -96,7 +114,7 @@ __global__ __launch_bounds__(NT) void dwconv_tile_kernel(const T* __restrict__ x
     } else {
       float4 gv = gnext;
       {  // prefetch the upstream gradient of this thread's next pixel
-        int pn = p + NT / 8, lyn = ly, lxn = lx + NT / 8;
+        int pn = p + PT, lyn = ly, lxn = lx + PT;
         while (lxn >= W) { lxn -= W; ++lyn; }
         if (pn < npix && h0 + lyn < H) gnext = ld4(&g[(((long)b * H + h0 + lyn) * W + lxn) * C + cc0 + 4 * c4]);
       }
@@ -104,35 +122,35 @@ __global__ __launch_bounds__(NT) void dwconv_tile_kernel(const T* __restrict__ x
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          float4 v = tile[((ly + i) * Wt + lx + j) * 8 + c4];
+          float4 v = cvt4(tile[((ly + i) * Wt + lx + j) * CL + c4]);
           float4& d = dk[i * 3 + j];
           d.x = fmaf(v.x, gv.x, d.x); d.y = fmaf(v.y, gv.y, d.y); d.z = fmaf(v.z, gv.z, d.z); d.w = fmaf(v.w, gv.w, d.w);
         }
     }
-    lx += NT / 8;
+    lx += PT;
     while (lx >= W) { lx -= W; ++ly; }
   }
   if (partials == nullptr) return;
   __syncthreads();  // tile no longer needed: reuse LDS for the cross-pixel-thread reduction
   float4* red = reinterpret_cast<float4*>(smem);
   if (MODE == 0) {
-    red[(0 * (NT / 8) + pt) * 8 + c4] = s;
-    red[(1 * (NT / 8) + pt) * 8 + c4] = ss;
+    red[(0 * PT + pt) * CL + c4] = s;
+    red[(1 * PT + pt) * CL + c4] = ss;
     __syncthreads();
-    if (tid < 16) {
-      int ci = tid & 7, v = tid >> 3;
+    if (tid < 2 * CL) {
+      int ci = tid & (CL - 1), v = tid / CL;
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int r = 0; r < NT / 8; ++r) { float4 t = red[(v * (NT / 8) + r) * 8 + ci]; a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
+      for (int r = 0; r < PT; ++r) { float4 t = red[(v * PT + r) * CL + ci]; a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
       *reinterpret_cast<float4*>(&partials[((long)blockIdx.y * 2 + v) * C + cc0 + 4 * ci]) = a;
     }
   } else {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) red[(t * (NT / 8) + pt) * 8 + c4] = dk[t];
+    for (int t = 0; t < 9; ++t) red[(t * PT + pt) * CL + c4] = dk[t];
     __syncthreads();
-    if (tid < 72) {
-      int ci = tid & 7, t = tid >> 3;
+    if (tid < 9 * CL) {
+      int ci = tid & (CL - 1), t = tid / CL;
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int r = 0; r < NT / 8; ++r) { float4 v = red[(t * (NT / 8) + r) * 8 + ci]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+      for (int r = 0; r < PT; ++r) { float4 v = red[(t * PT + r) * CL + ci]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
       *reinterpret_cast<float4*>(&partials[((long)blockIdx.y * 9 + t) * C + cc0 + 4 * ci]) = a;
     }
   }
@@ -239,7 +257,9 @@ static int dwconv_fwd_launch(const T* x, const float* k, T* out, float* stat_par
   size_t lds; int TH = dw_pick_th2(H, W, &lds);
   if (lds > 160 * 1024) return CRNN_ERR_UNSUPPORTED;
   if (lds > 64 * 1024) hipFuncSetAttribute((const void*)dwconv_tile_kernel<0, DW_NT, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  dim3 grid(C / 32, B * cdiv(H, TH));
+  const int slab = 128 / (int)sizeof(T);   // channels per workgroup: 32 (fp32) or 64 (bf16)
+  if (C % slab) return CRNN_ERR_UNSUPPORTED;
+  dim3 grid(C / slab, B * cdiv(H, TH));
   hipLaunchKernelGGL((dwconv_tile_kernel<0, DW_NT, T>), grid, dim3(DW_NT), lds, stream, x, k, (const T*)nullptr, out, stat_partials, B, H, W, C, TH, flip);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
@@ -390,7 +410,9 @@ static int dwconv_wgrad_launch(const T* x, const T* g, float* dk, float* scratch
   if (lds > 160 * 1024) return CRNN_ERR_UNSUPPORTED;
   if (lds > 64 * 1024) hipFuncSetAttribute((const void*)dwconv_tile_kernel<1, DW_NT, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   int ntiles = B * cdiv(H, TH);
-  dim3 grid(C / 32, ntiles);
+  const int slab = 128 / (int)sizeof(T);
+  if (C % slab) return CRNN_ERR_UNSUPPORTED;
+  dim3 grid(C / slab, ntiles);
   hipLaunchKernelGGL((dwconv_tile_kernel<1, DW_NT, T>), grid, dim3(DW_NT), lds, stream, x, (const float*)nullptr, g, (T*)nullptr, scratch, B, H, W, C, TH, 0);
   CRNN_LAUNCH_CHECK();
   return crnn_partials_sum(scratch, ntiles, 9 * C, dk, 1.f, stream);

@@ -9,21 +9,23 @@ L = native.lib()
 P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 S = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 B = 256
+BF = '--bf16' in sys.argv
+DT = torch.bfloat16 if BF else torch.float32
 tot = 0; totb = 0
 for (h, w, c) in [(104, 36, 64), (104, 36, 128), (52, 18, 256), (52, 18, 256), (52, 9, 512), (52, 9, 512)]:
-    x = torch.randn(B, h, w, c, device="cuda"); k = torch.randn(9, c, device="cuda"); o = torch.empty_like(x)
+    x = torch.randn(B, h, w, c, device="cuda").to(DT); k = torch.randn(9, c, device="cuda"); o = torch.empty_like(x)
     nt = L.crnn_dwconv_num_tiles(B, h, w)
     parts = torch.empty(nt * 9 * c, device="cuda"); dk = torch.empty(9, c, device="cuda")
-    for name, fn in (("fwd+stats", lambda: L.crnn_dwconv3x3_fwd(P(x), P(k), P(o), P(parts), B, h, w, c, 0, S())),
-                     ("dgrad", lambda: L.crnn_dwconv3x3_fwd(P(x), P(k), P(o), None, B, h, w, c, 1, S())),
-                     ("wgrad", lambda: L.crnn_dwconv3x3_wgrad(P(x), P(o), P(dk), P(parts), B, h, w, c, S()))):
+    for name, fn in (("fwd+stats", lambda: L.crnn_dwconv3x3_fwd_ex(P(x), P(k), P(o), P(parts), B, h, w, c, 0, int(BF), S())),
+                     ("dgrad", lambda: L.crnn_dwconv3x3_fwd_ex(P(x), P(k), P(o), None, B, h, w, c, 1, int(BF), S())),
+                     ("wgrad", lambda: L.crnn_dwconv3x3_wgrad_ex(P(x), P(o), P(dk), P(parts), B, h, w, c, int(BF), S()))):
         for _ in range(2): fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5): fn()
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
-        by = 2.0 * x.numel() * 4
+        by = 2.0 * x.numel() * x.element_size()
         if name != "wgrad": tot += ms; totb += by
         print("%dx%dx%d %-9s %.3f ms  %.2f TB/s" % (h, w, c, name, ms, by / ms / 1e9))
 print("fwd+dgrad total %.3f ms  %.2f TB/s" % (tot, totb / tot / 1e9))
