@@ -86,6 +86,8 @@ def pointwise_gemm_roofline(eng, iters=5):
     bf = eng.precision != "fp32"
     peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
     sdt = 1 if eng.precision == "bf16s" else 0
+    wsrc = eng.ws_tensor("pbf") if bf else eng.params      # bf16 modes read the weights from their bf16 shadow
+    W = lambda name: wsrc[eng.layout[name][0]:]
     B, T = eng.B, eng.T
     cfgs = []
     h, w, cin = eng.cfg.imgh + 4, eng.cfg.imgw + 4, 1
@@ -93,15 +95,15 @@ def pointwise_gemm_roofline(eng, iters=5):
     for i, (co, ph, pw) in enumerate(blocks, 1):
         M = B * h * w
         if co > 64:
-            cfgs.append((eng.ws_tensor("a%d" % i), eng.params[eng.layout["b%d_pw" % i][0]:], eng.ws_tensor("q%d" % i), M, co, cin, sdt, sdt))
+            cfgs.append((eng.ws_tensor("a%d" % i), W("b%d_pw" % i), eng.ws_tensor("q%d" % i), M, co, cin, sdt, sdt))
         h, w, cin = h // ph, w // pw, co
     feat = w * cin
     TB = T * B
     scratch = eng.ws_tensor("gemm_scratch")
-    cfgs.append((eng.ws_tensor("x7"), eng.params[eng.layout["dense1_w"][0]:], eng.ws_tensor("gA"), TB, eng.cfg.tds, feat, sdt, 0))
+    cfgs.append((eng.ws_tensor("x7"), W("dense1_w"), eng.ws_tensor("gA"), TB, eng.cfg.tds, feat, sdt, 0))
     u, G = eng.cfg.units, 4 * eng.cfg.units
     for n, src, k in (("rnn1f_w", "dn1", eng.cfg.tds), ("rnn1b_w", "dn1", eng.cfg.tds), ("rnn2f_w", "r1", u), ("rnn2b_w", "r1", u)):
-        cfgs.append((eng.ws_tensor(src), eng.params[eng.layout[n][0]:], eng.ws_tensor("gB"), TB, G, k, 0, 0))
+        cfgs.append((eng.ws_tensor(src), W(n), eng.ws_tensor("gB"), TB, G, k, 0, 0))
     flops = sum(2.0 * M * N * K for _, _, _, M, N, K, _, _ in cfgs)
     times = []
     for it in range(iters + 1):
@@ -109,7 +111,7 @@ def pointwise_gemm_roofline(eng, iters=5):
         e0.record()
         for A, Bm, C, M, N, K, dta, dtc in cfgs:
             if bf:
-                lib.crnn_gemm_bf16_ex(0, _ptr(A), _ptr(Bm), _ptr(C), M, N, K, K, N, N, None, 0, 0, 0, _ptr(scratch), 128 * 1024 * 1024, dta, 0, dtc, _stream())
+                lib.crnn_gemm_bf16_ex(0, _ptr(A), _ptr(Bm), _ptr(C), M, N, K, K, N, N, None, 0, 0, 0, _ptr(scratch), 128 * 1024 * 1024, dta, 1, dtc, _stream())
             else:
                 lib.crnn_gemm_f32(0, _ptr(A), _ptr(Bm), _ptr(C), M, N, K, K, N, N, None, 0, 0, 0, _ptr(scratch), 128 * 1024 * 1024, _stream())
         e1.record()

@@ -13,6 +13,7 @@
 // (k = 8*kk8 + 4*half + e) identically for A and B so one b128 read feeds four MFMAs.
 // Workgroup ids are remapped so that tiles sharing the same A rows run on the same XCD (L2).
 #include "common.h"
+#include <stdlib.h>
 
 #define GBK 32
 #define GLDM (GBK + 4)

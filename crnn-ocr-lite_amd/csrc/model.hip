@@ -154,6 +154,7 @@ Plan make_plan(const crnn_config* c) {
   maxparts = lmax(maxparts, (long)crnn_colreduce_chunks(TB) * lmax(d.G, lmax(d.tds, d.C)));
   maxparts = lmax(maxparts, (long)crnn_colreduce_chunks(B * d.Ho1 * d.Wo1) * 64);
   P.add("partials", maxparts);
+  P.add("pbf", make_layout(c).total, CRNN_BF16);   // bf16 shadow of the parameter buffer (GEMM B operands in the bf16 modes)
   P.add("coef", 2 * 1024);
   P.add("gemm_scratch", 32L * 1024 * 1024);  // 128 MiB of split-reduction partials
   return P;
@@ -172,18 +173,32 @@ struct Ctx {
   float* scratch() const { return ws + P.off("gemm_scratch"); }
 };
 
+// In the bf16 modes a weight operand (B of the NN / NT GEMMs, i.e. a pointer into the parameter buffer) is read from
+// the bf16 shadow copy refreshed at the start of every forward: half the L2->LDS bytes, identical rounding (RNE).
+const float* weight_operand(const Ctx& c, int mode, const float* B, int* dtB) {
+  if (c.cfg->mfma_bf16 && mode != 2 && B >= c.params && B < c.params + c.L.total) {
+    *dtB = CRNN_BF16;
+    return reinterpret_cast<const float*>(reinterpret_cast<const bf16_t*>(c.ws + c.P.off("pbf")) + (B - c.params));
+  }
+  return B;
+}
 // GEMMs of the conv stack / dense layers / RNN input projections: bf16 products when cfg->mfma_bf16
 int gemm(const Ctx& c, int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
          const float* bias = nullptr, int act = 0, int acc = 0, int perm = 0) {
-  if (c.cfg->mfma_bf16)
-    return crnn_gemm_bf16(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, c.scratch(), kGemmScratchBytes, c.s);
+  if (c.cfg->mfma_bf16) {
+    int dtB = CRNN_F32;
+    B = weight_operand(c, mode, B, &dtB);
+    return crnn_gemm_bf16_ex(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, c.scratch(), kGemmScratchBytes, CRNN_F32, dtB, CRNN_F32, c.s);
+  }
   return crnn_gemm_f32(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, c.scratch(), kGemmScratchBytes, c.s);
 }
 // GEMM with explicit operand / result storage types (storage mode 2); falls back to the plain entry points otherwise
 int gemm_t(const Ctx& c, int mode, const float* A, int dtA, const float* B, int dtB, float* C, int dtC, int M, int N, int K, int lda,
            int ldb, int ldc, const float* bias = nullptr, int act = 0, int acc = 0, int perm = 0) {
-  if (c.cfg->mfma_bf16 == 2)
+  if (c.cfg->mfma_bf16 == 2) {
+    B = weight_operand(c, mode, B, &dtB);
     return crnn_gemm_bf16_ex(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, c.scratch(), kGemmScratchBytes, dtA, dtB, dtC, c.s);
+  }
   if (dtA != CRNN_F32 || dtB != CRNN_F32 || dtC != CRNN_F32) return CRNN_ERR_ARG;
   return gemm(c, mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm);
 }
@@ -278,6 +293,7 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
   if (ws_bytes < (size_t)c.P.total * sizeof(float)) return CRNN_ERR_ARG;
   const Dims& d = c.d;
   const int B = d.B;
+  if (cfg->mfma_bf16) CRNN_TRY(crnn_convert_f32_to_bf16(params, c.ws + c.P.off("pbf"), c.L.total, stream));
   // ---- spatial transformer (utils.py:247-258) + ZeroPadding2D (utils.py:63)
   if (cfg->stn) {
     CRNN_TRY(crnn_maxpool_fwd(x, c.w("pool1"), B, d.H0, d.W0, 1, 2, 2, stream));

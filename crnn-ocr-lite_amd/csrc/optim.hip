@@ -87,3 +87,15 @@ extern "C" int crnn_scale(float* x, long n, float s, hipStream_t stream) {
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
+
+// bf16 shadow of a flat fp32 buffer (round-to-nearest-even), 4 elements per thread; n % 4 == 0
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long n4) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) st4(y + 4 * i, ld4(x + 4 * i));
+}
+extern "C" int crnn_convert_f32_to_bf16(const float* x, void* y, long n, hipStream_t stream) {
+  if (n % 4) return CRNN_ERR_ARG;
+  int blocks = cdiv(n / 4, 256); if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(blocks), dim3(256), 0, stream, x, (bf16_t*)y, n / 4);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}

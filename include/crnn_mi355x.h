@@ -80,6 +80,8 @@ int crnn_adam_step(float* p, const float* g, float* m, float* v, long n, float l
 int crnn_sgd_step(float* p, const float* g, float* vel, long n, float lr, float momentum, int nesterov,
                   const float* norm_out, crnn_stream_t stream);
 int crnn_scale(float* x, long n, float s, crnn_stream_t stream);
+/* y (bf16) = round-to-nearest-even(x); n % 4 == 0 */
+int crnn_convert_f32_to_bf16(const float* x, void* y, long n, crnn_stream_t stream);
 
 /* ---- decoding (DecodeCTCPred.decode -> K.ctc_decode, utils.py:347-357) ------------------------------------- */
 /* y [B,T,C] softmax; out [B,T] int32 padded with -1; out_len [B]; input_len may be NULL (= T) */

@@ -10,6 +10,8 @@ P = lambda t: ctypes.c_void_p(t.data_ptr())
 S = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 B = 256
 FN = L.crnn_gemm_bf16 if '--bf16' in sys.argv else L.crnn_gemm_f32
+BFS = '--bf16s' in sys.argv
+WBF = '--wbf16' in sys.argv   # weights (B operand of NN/NT) stored as bf16 too
 scr = torch.empty(32 * 1024 * 1024, device="cuda")
 shapes = []
 h, w, cin = 104, 36, 1
@@ -27,8 +29,15 @@ for name, mode, M, N, K in shapes:
     elif mode == 1: A = torch.randn(M, K, device="cuda"); Bm = torch.randn(N, K, device="cuda"); lda, ldb = K, K
     else: A = torch.randn(K, M, device="cuda"); Bm = torch.randn(K, N, device="cuda"); lda, ldb = M, N
     C = torch.empty(M, N, device="cuda")
+    if BFS:
+        A = A.to(torch.bfloat16)
+        if mode == 2 or WBF: Bm = Bm.to(torch.bfloat16)
+        else: C = C.to(torch.bfloat16)
     def run():
-        r = FN(mode, P(A), P(Bm), P(C), M, N, K, lda, ldb, N, None, 0, 0, 0, P(scr), 128 * 1024 * 1024, S())
+        if BFS:
+            r = L.crnn_gemm_bf16_ex(mode, P(A), P(Bm), P(C), M, N, K, lda, ldb, N, None, 0, 0, 0, P(scr), 128 * 1024 * 1024, 1, int(mode == 2 or WBF), int(mode != 2), S())
+        else:
+            r = FN(mode, P(A), P(Bm), P(C), M, N, K, lda, ldb, N, None, 0, 0, 0, P(scr), 128 * 1024 * 1024, S())
         assert r == 0
     for _ in range(2): run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
