@@ -158,7 +158,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE configs[1]: 256)")
-    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16s"], default="bf16",
+    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16s"], default="bf16s",
                     help="fp32 = parity mode (fp32 MFMA); bf16 = GEMM products in bf16, fp32 accumulate/storage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

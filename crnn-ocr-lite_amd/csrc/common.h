@@ -30,20 +30,45 @@ __device__ __forceinline__ float relu6f(float v) { return fminf(fmaxf(v, 0.f), 6
 __device__ __forceinline__ float hard_sigmoid(float z) { return fminf(fmaxf(0.2f * z + 0.5f, 0.f), 1.f); }
 __device__ __forceinline__ float hs_grad_from_out(float a) { return (a > 0.f && a < 1.f) ? 0.2f : 0.f; }
 
-// Counter-based dropout RNG: keep-decision for element `idx` of dropout site `layer` in step
-// `seed`.  murmur3-style 64->32 finaliser; the backward pass recomputes it (no mask tensor).
-__device__ __host__ __forceinline__ uint32_t crnn_hash(uint64_t seed, uint32_t layer, uint64_t idx) {
-  uint64_t x = idx + 0x9E3779B97F4A7C15ull * (seed + 1) + ((uint64_t)layer << 56);
+// Counter-based dropout RNG: murmur3-style 64-bit finaliser of (step seed, dropout site, group), one hash
+// per group of 4 consecutive elements; element idx takes 16-bit lane (idx & 3) of the hash of group idx >> 2
+// and is kept when lane >= floor(rate * 65536).  The backward pass recomputes it (no mask tensor).
+__device__ __host__ __forceinline__ uint64_t crnn_hash(uint64_t seed, uint32_t layer, uint64_t group) {
+  uint64_t x = group + 0x9E3779B97F4A7C15ull * (seed + 1) + ((uint64_t)layer << 56);
   x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
   x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
   x ^= x >> 33;
-  return (uint32_t)x;
+  return x;
 }
 // returns the multiplier applied to the activation: 0 or 1/(1-rate); rate<=0 => 1
 __device__ __forceinline__ float drop_scale(uint64_t seed, uint32_t layer, uint64_t idx, float rate, float inv_keep) {
   if (rate <= 0.f) return 1.f;
-  float u = (float)(crnn_hash(seed, layer, idx) >> 8) * (1.0f / 16777216.0f);
-  return (u >= rate) ? inv_keep : 0.f;
+  uint32_t lane = (uint32_t)(crnn_hash(seed, layer, idx >> 2) >> (16 * (idx & 3))) & 0xffffu;
+  return (lane >= (uint32_t)(rate * 65536.f)) ? inv_keep : 0.f;
+}
+// multipliers of N consecutive elements idx0 .. idx0+N-1; one hash per aligned group of 4 when idx0 % 4 == 0
+template <int N>
+__device__ __forceinline__ void drop_scale_vec(uint64_t seed, uint32_t layer, uint64_t idx0, float rate, float inv_keep, float* out) {
+  if (rate <= 0.f) {
+#pragma unroll
+    for (int e = 0; e < N; ++e) out[e] = 1.f;
+    return;
+  }
+  if (N % 4 == 0) {
+    const uint32_t thr = (uint32_t)(rate * 65536.f);
+#pragma unroll
+    for (int gq = 0; gq < N / 4; ++gq) {
+      uint64_t h = crnn_hash(seed, layer, (idx0 >> 2) + gq);
+      uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 32);
+      out[(4 * gq + 0) % N] = ((lo & 0xffffu) >= thr) ? inv_keep : 0.f;
+      out[(4 * gq + 1) % N] = ((lo >> 16) >= thr) ? inv_keep : 0.f;
+      out[(4 * gq + 2) % N] = ((hi & 0xffffu) >= thr) ? inv_keep : 0.f;
+      out[(4 * gq + 3) % N] = ((hi >> 16) >= thr) ? inv_keep : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < N; ++e) out[e] = drop_scale(seed, layer, idx0 + e, rate, inv_keep);
+  }
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -77,6 +102,19 @@ __device__ __forceinline__ float4 ld4(const bf16_t* p) {
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
   *reinterpret_cast<uint2*>(p) = make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w));
+}
+struct float8 { float4 lo, hi; };
+__device__ __forceinline__ float8 ld8(const float* p) { float8 r; r.lo = ld4(p); r.hi = ld4(p + 4); return r; }
+__device__ __forceinline__ float8 ld8(const bf16_t* p) {   // one 16-byte load
+  uint4 u = *reinterpret_cast<const uint4*>(p);
+  float8 r;
+  r.lo = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+  r.hi = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u));
+  return r;
+}
+__device__ __forceinline__ void st8(float* p, const float8& v) { st4(p, v.lo); st4(p + 4, v.hi); }
+__device__ __forceinline__ void st8(bf16_t* p, const float8& v) {
+  *reinterpret_cast<uint4*>(p) = make_uint4(pack2_bf16(v.lo.x, v.lo.y), pack2_bf16(v.lo.z, v.lo.w), pack2_bf16(v.hi.x, v.hi.y), pack2_bf16(v.hi.z, v.hi.w));
 }
 __device__ __forceinline__ float ld1(const float* p) { return *p; }
 __device__ __forceinline__ float ld1(const bf16_t* p) { return __uint_as_float(((unsigned)*p) << 16); }

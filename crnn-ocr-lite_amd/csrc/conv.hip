@@ -256,7 +256,7 @@ static int dwconv_fwd_launch(const T* x, const float* k, T* out, float* stat_par
                              hipStream_t stream) {
   size_t lds; int TH = dw_pick_th2(H, W, &lds);
   if (lds > 160 * 1024) return CRNN_ERR_UNSUPPORTED;
-  if (lds > 64 * 1024) hipFuncSetAttribute((const void*)dwconv_tile_kernel<0, DW_NT, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_tile_kernel<0, DW_NT, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const int slab = 128 / (int)sizeof(T);   // channels per workgroup: 32 (fp32) or 64 (bf16)
   if (C % slab) return CRNN_ERR_UNSUPPORTED;
   dim3 grid(C / slab, B * cdiv(H, TH));
@@ -283,6 +283,41 @@ extern "C" int crnn_dwconv3x3_fwd(const float* x, const float* k, float* out, fl
   return crnn_dwconv3x3_fwd_ex(x, k, out, stat_partials, B, H, W, C, flip, CRNN_F32, stream);
 }
 
+// VEC consecutive channels of one pixel, widened to fp32 (VEC = 1, 4 or 8; 8 = one 16-byte access of bf16 storage)
+template <int VEC>
+struct VecF { float v[VEC]; };
+
+template <int VEC, typename T>
+__device__ __forceinline__ VecF<VEC> vload(const T* p) {
+  VecF<VEC> r;
+  if (VEC == 8) {
+    float8 q = ld8(p);
+    r.v[0] = q.lo.x; r.v[1 % VEC] = q.lo.y; r.v[2 % VEC] = q.lo.z; r.v[3 % VEC] = q.lo.w;
+    r.v[4 % VEC] = q.hi.x; r.v[5 % VEC] = q.hi.y; r.v[6 % VEC] = q.hi.z; r.v[7 % VEC] = q.hi.w;
+  } else if (VEC == 4) {
+    float4 q = ld4(p); r.v[0] = q.x; r.v[1 % VEC] = q.y; r.v[2 % VEC] = q.z; r.v[3 % VEC] = q.w;
+  } else {
+    r.v[0] = ld1(p);
+  }
+  return r;
+}
+template <int VEC, typename T>
+__device__ __forceinline__ void vstore(T* p, const VecF<VEC>& r) {
+  if (VEC == 8) {
+    float8 q;
+    q.lo = make_float4(r.v[0], r.v[1 % VEC], r.v[2 % VEC], r.v[3 % VEC]);
+    q.hi = make_float4(r.v[4 % VEC], r.v[5 % VEC], r.v[6 % VEC], r.v[7 % VEC]);
+    st8(p, q);
+  } else if (VEC == 4) {
+    st4(p, make_float4(r.v[0], r.v[1 % VEC], r.v[2 % VEC], r.v[3 % VEC]));
+  } else {
+    st1(p, r.v[0]);
+  }
+}
+// widest vector the storage type moves in one 16-byte access
+template <typename T> struct VecMax { static const int value = 4; };
+template <> struct VecMax<bf16_t> { static const int value = 8; };
+
 // ---------------------------------------------------------------------------------------------
 // Column reductions over a row-major [M][C] matrix -> partials [nchunk][NV][C]
 // NV=1: sum; NV=2: sum and sum of squares.  Deterministic (fixed chunking, fixed order).
@@ -303,32 +338,23 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ x,
     for (int e = 0; e < VEC; ++e) { s[e] = 0.f; q[e] = 0.f; }
     if (c < CL) {
       long r = r0 + rt;
-      if (VEC == 4) {  // 4 rows in flight per thread (independent 16-byte loads)
+      if (VEC > 1) {  // 4 rows in flight per thread (independent 16-byte loads)
         for (; r + 3L * RT < r1; r += 4L * RT) {
-          float4 v0 = ld4(&x[r * ld + 4 * c]);
-          float4 v1 = ld4(&x[(r + RT) * ld + 4 * c]);
-          float4 v2 = ld4(&x[(r + 2L * RT) * ld + 4 * c]);
-          float4 v3 = ld4(&x[(r + 3L * RT) * ld + 4 * c]);
-          s[0] += (v0.x + v1.x) + (v2.x + v3.x); s[1 % VEC] += (v0.y + v1.y) + (v2.y + v3.y);
-          s[2 % VEC] += (v0.z + v1.z) + (v2.z + v3.z); s[3 % VEC] += (v0.w + v1.w) + (v2.w + v3.w);
-          if (NV == 2) {
-            q[0] += (v0.x * v0.x + v1.x * v1.x) + (v2.x * v2.x + v3.x * v3.x);
-            q[1 % VEC] += (v0.y * v0.y + v1.y * v1.y) + (v2.y * v2.y + v3.y * v3.y);
-            q[2 % VEC] += (v0.z * v0.z + v1.z * v1.z) + (v2.z * v2.z + v3.z * v3.z);
-            q[3 % VEC] += (v0.w * v0.w + v1.w * v1.w) + (v2.w * v2.w + v3.w * v3.w);
+          VecF<VEC> v0 = vload<VEC>(&x[r * ld + VEC * c]);
+          VecF<VEC> v1 = vload<VEC>(&x[(r + RT) * ld + VEC * c]);
+          VecF<VEC> v2 = vload<VEC>(&x[(r + 2L * RT) * ld + VEC * c]);
+          VecF<VEC> v3 = vload<VEC>(&x[(r + 3L * RT) * ld + VEC * c]);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            s[e] += (v0.v[e] + v1.v[e]) + (v2.v[e] + v3.v[e]);
+            if (NV == 2) q[e] += (v0.v[e] * v0.v[e] + v1.v[e] * v1.v[e]) + (v2.v[e] * v2.v[e] + v3.v[e] * v3.v[e]);
           }
         }
       }
       for (; r < r1; r += RT) {
-        if (VEC == 4) {
-          float4 v = ld4(&x[r * ld + 4 * c]);
-          s[0] += v.x; s[1 % VEC] += v.y; s[2 % VEC] += v.z; s[3 % VEC] += v.w;
-          if (NV == 2) { q[0] = fmaf(v.x, v.x, q[0]); q[1 % VEC] = fmaf(v.y, v.y, q[1 % VEC]); q[2 % VEC] = fmaf(v.z, v.z, q[2 % VEC]); q[3 % VEC] = fmaf(v.w, v.w, q[3 % VEC]); }
-        } else {
-          float v = ld1(&x[r * ld + c]);
-          s[0] += v;
-          if (NV == 2) q[0] = fmaf(v, v, q[0]);
-        }
+        VecF<VEC> v = vload<VEC>(&x[r * ld + VEC * c]);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { s[e] += v.v[e]; if (NV == 2) q[e] = fmaf(v.v[e], v.v[e], q[e]); }
       }
     }
     __syncthreads();
@@ -354,20 +380,21 @@ static inline int colreduce_rpc(long M) { long r = 1024; while (r > 16 && M / r 
 extern "C" int crnn_colreduce_chunks(long M) { return cdiv(M, colreduce_rpc(M)); }
 
 // partials [crnn_colreduce_chunks(M)][nv][C]; dtype = storage of x
+template <int VEC, typename T>
+static void colreduce_go(const T* x, float* partials, long M, int C, int ld, int nv, int chunks, int rpc, hipStream_t stream) {
+  const int CL = C / VEC, CW = pow2_ge(CL < 256 ? CL : 256);
+  if (nv == 1) hipLaunchKernelGGL((colreduce_kernel<VEC, 1, T>), dim3(chunks), dim3(256), 0, stream, x, partials, M, C, ld, CW, rpc);
+  else hipLaunchKernelGGL((colreduce_kernel<VEC, 2, T>), dim3(chunks), dim3(256), 0, stream, x, partials, M, C, ld, CW, rpc);
+}
 template <typename T>
 static int colreduce_launch(const T* x, float* partials, long M, int C, int ld, int nv, hipStream_t stream) {
   int rpc = colreduce_rpc(M);
   int chunks = cdiv(M, rpc);
-  bool vec = (C % 4 == 0) && (ld % 4 == 0) && ((((uintptr_t)x) & 15) == 0);
-  int CL = vec ? C / 4 : C;
-  int CW = pow2_ge(CL < 256 ? CL : 256);
-  if (vec) {
-    if (nv == 1) hipLaunchKernelGGL((colreduce_kernel<4, 1, T>), dim3(chunks), dim3(256), 0, stream, x, partials, M, C, ld, CW, rpc);
-    else hipLaunchKernelGGL((colreduce_kernel<4, 2, T>), dim3(chunks), dim3(256), 0, stream, x, partials, M, C, ld, CW, rpc);
-  } else {
-    if (nv == 1) hipLaunchKernelGGL((colreduce_kernel<1, 1, T>), dim3(chunks), dim3(256), 0, stream, x, partials, M, C, ld, CW, rpc);
-    else hipLaunchKernelGGL((colreduce_kernel<1, 2, T>), dim3(chunks), dim3(256), 0, stream, x, partials, M, C, ld, CW, rpc);
-  }
+  const int VM = VecMax<T>::value;
+  const bool al = ((((uintptr_t)x) & 15) == 0);
+  if (VM == 8 && al && (C % 8 == 0) && (ld % 8 == 0)) colreduce_go<VecMax<T>::value, T>(x, partials, M, C, ld, nv, chunks, rpc, stream);
+  else if (al && (C % 4 == 0) && (ld % 4 == 0)) colreduce_go<4, T>(x, partials, M, C, ld, nv, chunks, rpc, stream);
+  else colreduce_go<1, T>(x, partials, M, C, ld, nv, chunks, rpc, stream);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
@@ -380,25 +407,37 @@ extern "C" int crnn_colreduce(const float* x, float* partials, long M, int C, in
   return crnn_colreduce_ex(x, partials, M, C, ld, nv, CRNN_F32, stream);
 }
 
-// out[i] = scale * sum_p partials[p][i], i < n  (double accumulation)
-__global__ void partials_sum_kernel(const float* __restrict__ partials, int nparts, int n, float* __restrict__ out, float scale) {
-  // blockDim = (32, 32): 32 consecutive outputs x 32 part-lanes
-  __shared__ double red[32][32];
-  int i = blockIdx.x * 32 + threadIdx.x;
+// Second-stage reductions run as (RED_CH outputs) x (RED_PL part-lanes) blocks: each lane adds every RED_PL-th
+// partial in double, four independent loads in flight; lanes are then combined in a fixed order (deterministic).
+#define RED_CH 16
+#define RED_PL 64
+__device__ __forceinline__ double part_lane_sum(const float* __restrict__ base, long stride, int nparts, int lane) {
   double a = 0.0;
-  if (i < n)
-    for (int p = threadIdx.y; p < nparts; p += 32) a += (double)partials[(long)p * n + i];
-  red[threadIdx.y][threadIdx.x] = a;
+  int p = lane;
+  for (; p + 3 * RED_PL < nparts; p += 4 * RED_PL) {
+    float v0 = base[(long)p * stride], v1 = base[(long)(p + RED_PL) * stride];
+    float v2 = base[(long)(p + 2 * RED_PL) * stride], v3 = base[(long)(p + 3 * RED_PL) * stride];
+    a += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+  }
+  for (; p < nparts; p += RED_PL) a += (double)base[(long)p * stride];
+  return a;
+}
+
+// out[i] = scale * sum_p partials[p][i], i < n  (double accumulation)
+__global__ __launch_bounds__(RED_CH * RED_PL) void partials_sum_kernel(const float* __restrict__ partials, int nparts, int n, float* __restrict__ out, float scale) {
+  __shared__ double red[RED_PL][RED_CH];
+  int i = blockIdx.x * RED_CH + threadIdx.x;
+  red[threadIdx.y][threadIdx.x] = (i < n) ? part_lane_sum(partials + i, n, nparts, threadIdx.y) : 0.0;
   __syncthreads();
   if (threadIdx.y == 0 && i < n) {
     double s = 0.0;
-    for (int r = 0; r < 32; ++r) s += red[r][threadIdx.x];
+    for (int r = 0; r < RED_PL; ++r) s += red[r][threadIdx.x];
     out[i] = (float)(s * scale);
   }
 }
 
 extern "C" int crnn_partials_sum(const float* partials, int nparts, int n, float* out, float scale, hipStream_t stream) {
-  hipLaunchKernelGGL(partials_sum_kernel, dim3(cdiv(n, 32)), dim3(32, 32), 0, stream, partials, nparts, n, out, scale);
+  hipLaunchKernelGGL(partials_sum_kernel, dim3(cdiv(n, RED_CH)), dim3(RED_CH, RED_PL), 0, stream, partials, nparts, n, out, scale);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
@@ -408,7 +447,7 @@ template <typename T>
 static int dwconv_wgrad_launch(const T* x, const T* g, float* dk, float* scratch, int B, int H, int W, int C, hipStream_t stream) {
   size_t lds; int TH = dw_pick_th2(H, W, &lds);
   if (lds > 160 * 1024) return CRNN_ERR_UNSUPPORTED;
-  if (lds > 64 * 1024) hipFuncSetAttribute((const void*)dwconv_tile_kernel<1, DW_NT, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_tile_kernel<1, DW_NT, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   int ntiles = B * cdiv(H, TH);
   const int slab = 128 / (int)sizeof(T);
   if (C % slab) return CRNN_ERR_UNSUPPORTED;
@@ -444,22 +483,17 @@ extern "C" int crnn_dwconv3x3_wgrad(const float* x, const float* g, float* dk, f
 // ---------------------------------------------------------------------------------------------
 // BatchNorm (axis=-1, eps=1e-3): statistics finalize.  bnstate = [mean | var | scale | shift] (4*C)
 // ---------------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const float* __restrict__ partials, int nparts, int C, double inv_n,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ bnstate) {
-  __shared__ double red[2][32][32];
-  int c = blockIdx.x * 32 + threadIdx.x;
-  double s = 0.0, q = 0.0;
-  if (c < C)
-    for (int p = threadIdx.y; p < nparts; p += 32) {
-      s += (double)partials[((long)p * 2 + 0) * C + c];
-      q += (double)partials[((long)p * 2 + 1) * C + c];
-    }
-  red[0][threadIdx.y][threadIdx.x] = s; red[1][threadIdx.y][threadIdx.x] = q;
+__global__ __launch_bounds__(RED_CH * RED_PL) void bn_finalize_kernel(const float* __restrict__ partials, int nparts, int C, double inv_n,
+                                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                      float* __restrict__ bnstate) {
+  __shared__ double red[2][RED_PL][RED_CH];
+  int c = blockIdx.x * RED_CH + threadIdx.x;
+  red[0][threadIdx.y][threadIdx.x] = (c < C) ? part_lane_sum(partials + c, 2L * C, nparts, threadIdx.y) : 0.0;
+  red[1][threadIdx.y][threadIdx.x] = (c < C) ? part_lane_sum(partials + C + c, 2L * C, nparts, threadIdx.y) : 0.0;
   __syncthreads();
   if (threadIdx.y == 0 && c < C) {
-    s = 0.0; q = 0.0;
-    for (int r = 0; r < 32; ++r) { s += red[0][r][threadIdx.x]; q += red[1][r][threadIdx.x]; }
+    double s = 0.0, q = 0.0;
+    for (int r = 0; r < RED_PL; ++r) { s += red[0][r][threadIdx.x]; q += red[1][r][threadIdx.x]; }
     double mean = s * inv_n;
     double var = q * inv_n - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -484,7 +518,7 @@ __global__ void bn_infer_state_kernel(const float* __restrict__ mmean, const flo
 
 extern "C" int crnn_bn_finalize(const float* partials, int nparts, int C, long n, const float* gamma, const float* beta,
                                 float* bnstate, hipStream_t stream) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(32, 32), 0, stream, partials, nparts, C, 1.0 / (double)n, gamma, beta, bnstate);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, RED_CH)), dim3(RED_CH, RED_PL), 0, stream, partials, nparts, C, 1.0 / (double)n, gamma, beta, bnstate);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
@@ -510,38 +544,46 @@ __global__ void bn_act_pool_drop_kernel(const TI* __restrict__ x, const float* _
   const float* sc = bnstate + 2 * C; const float* sh = bnstate + 3 * C;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     int cl = (int)(i % CL); long pix = i / CL;
-    int wo = (int)(pix % Wo); long r = pix / Wo; int ho = (int)(r % Ho); long b = r / Ho;
-    float m[VEC], s[VEC], t[VEC];
+    VecF<VEC> m, s = vload<VEC>(sc + cl * VEC), t = vload<VEC>(sh + cl * VEC);
+    if (ph * pw == 1) {
+      VecF<VEC> v = vload<VEC>(&x[pix * C + cl * VEC]);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) { m[e] = -INFINITY; s[e] = sc[cl * VEC + e]; t[e] = sh[cl * VEC + e]; }
-    for (int ii = 0; ii < ph; ++ii)
-      for (int j = 0; j < pw; ++j) {
-        const TI* p = &x[(((long)b * H + ho * ph + ii) * W + wo * pw + j) * C + cl * VEC];
-        float v[VEC];
-        if (VEC == 4) { float4 q = ld4(p); v[0] = q.x; v[1 % VEC] = q.y; v[2 % VEC] = q.z; v[3 % VEC] = q.w; }
-        else v[0] = ld1(p);
+      for (int e = 0; e < VEC; ++e) m.v[e] = relu6f(fmaf(v.v[e], s.v[e], t.v[e]));
+    } else {
+      int wo = (int)(pix % Wo); long r = pix / Wo; int ho = (int)(r % Ho); long b = r / Ho;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) m[e] = fmaxf(m[e], relu6f(fmaf(v[e], s[e], t[e])));
-      }
+      for (int e = 0; e < VEC; ++e) m.v[e] = -INFINITY;
+      for (int ii = 0; ii < ph; ++ii)
+        for (int j = 0; j < pw; ++j) {
+          VecF<VEC> v = vload<VEC>(&x[(((long)b * H + ho * ph + ii) * W + wo * pw + j) * C + cl * VEC]);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) m.v[e] = fmaxf(m.v[e], relu6f(fmaf(v.v[e], s.v[e], t.v[e])));
+        }
+    }
     long obase = pix * C + cl * VEC;
+    float dm[VEC];
+    drop_scale_vec<VEC>(seed, layer, (uint64_t)obase, rate, inv_keep, dm);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) m[e] *= drop_scale(seed, layer, (uint64_t)(obase + e), rate, inv_keep);
-    if (VEC == 4) st4(&y[obase], make_float4(m[0], m[1 % VEC], m[2 % VEC], m[3 % VEC]));
-    else st1(&y[obase], m[0]);
+    for (int e = 0; e < VEC; ++e) m.v[e] *= dm[e];
+    vstore<VEC>(&y[obase], m);
   }
 }
 
+template <int VEC, typename TI, typename TO>
+static void bn_act_go(const TI* x, const float* bnstate, TO* y, int B, int H, int W, int C, int ph, int pw, float rate, uint64_t seed,
+                      uint32_t layer, hipStream_t stream) {
+  long total = (long)B * (H / ph) * (W / pw) * C;
+  int blocks = cdiv(total / VEC, 256); if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL((bn_act_pool_drop_kernel<VEC, TI, TO>), dim3(blocks), dim3(256), 0, stream, x, bnstate, y, B, H, W, C, ph, pw, rate, seed, layer);
+}
 template <typename TI, typename TO>
 static int bn_act_launch(const TI* x, const float* bnstate, TO* y, int B, int H, int W, int C, int ph, int pw, float rate, uint64_t seed,
                          uint32_t layer, hipStream_t stream) {
-  long total = (long)B * (H / ph) * (W / pw) * C;
-  if (C % 4 == 0) {
-    int blocks = cdiv(total / 4, 256); if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL((bn_act_pool_drop_kernel<4, TI, TO>), dim3(blocks), dim3(256), 0, stream, x, bnstate, y, B, H, W, C, ph, pw, rate, seed, layer);
-  } else {
-    int blocks = cdiv(total, 256); if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL((bn_act_pool_drop_kernel<1, TI, TO>), dim3(blocks), dim3(256), 0, stream, x, bnstate, y, B, H, W, C, ph, pw, rate, seed, layer);
-  }
+  const bool al = ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)bnstate) & 15) == 0);
+  const int VM = (VecMax<TI>::value == 8 && VecMax<TO>::value == 8) ? 8 : 4;
+  if (VM == 8 && al && C % 8 == 0) bn_act_go<(VecMax<TI>::value == 8 && VecMax<TO>::value == 8) ? 8 : 4>(x, bnstate, y, B, H, W, C, ph, pw, rate, seed, layer, stream);
+  else if (al && C % 4 == 0) bn_act_go<4>(x, bnstate, y, B, H, W, C, ph, pw, rate, seed, layer, stream);
+  else bn_act_go<1>(x, bnstate, y, B, H, W, C, ph, pw, rate, seed, layer, stream);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
@@ -572,22 +614,6 @@ struct BnBwdArgsT {
   const T* x; const T* g; const float* bnstate; const float* gamma;
   int B, H, W, C, ph, pw; float rate; uint64_t seed; uint32_t layer;
 };
-
-template <int VEC>
-struct VecF { float v[VEC]; };
-
-template <int VEC, typename T>
-__device__ __forceinline__ VecF<VEC> vload(const T* p) {
-  VecF<VEC> r;
-  if (VEC == 4) { float4 q = ld4(p); r.v[0] = q.x; r.v[1 % VEC] = q.y; r.v[2 % VEC] = q.z; r.v[3 % VEC] = q.w; }
-  else r.v[0] = ld1(p);
-  return r;
-}
-template <int VEC, typename T>
-__device__ __forceinline__ void vstore(T* p, const VecF<VEC>& r) {
-  if (VEC == 4) st4(p, make_float4(r.v[0], r.v[1 % VEC], r.v[2 % VEC], r.v[3 % VEC]));
-  else st1(p, r.v[0]);
-}
 
 // gy for VEC consecutive channels starting at c0 of pixel row r
 template <int VEC, bool POOL, typename T>
@@ -626,10 +652,12 @@ __device__ __forceinline__ VecF<VEC> bn_gy_vec(const BnBwdArgsT<T>& a, long r, i
     oidx = (((long)b * Ho + ho) * Wo + wo) * a.C + c0;
   }
   VecF<VEC> gv = vload<VEC>(&a.g[oidx]);
+  float dm[VEC];
+  drop_scale_vec<VEC>(a.seed, a.layer, (uint64_t)oidx, a.rate, inv_keep, dm);
 #pragma unroll
   for (int e = 0; e < VEC; ++e) {
     bool live = arg[e] && (y.v[e] > 0.f) && (y.v[e] < 6.f);
-    out.v[e] = live ? gv.v[e] * drop_scale(a.seed, a.layer, (uint64_t)(oidx + e), a.rate, inv_keep) : 0.f;
+    out.v[e] = live ? gv.v[e] * dm[e] : 0.f;
   }
   return out;
 }
@@ -657,7 +685,27 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgsT<T> a, float* __r
 #pragma unroll
       for (int e = 0; e < VEC; ++e) { inv.v[e] = 1.0f / sqrtf(var.v[e] + BN_EPS); c1.v[e] = 0.f; c2.v[e] = 0.f; }
       if (PASS == 2) { c1 = vload<VEC>(coef + c0); c2 = vload<VEC>(coef + a.C + c0); }
-      for (long r = r0 + rt; r < r1; r += RT) {
+      long r = r0 + rt;
+      for (; r + RT < r1; r += 2L * RT) {   // two rows in flight (independent loads)
+        VecF<VEC> xa = vload<VEC>(&a.x[r * a.C + c0]);
+        VecF<VEC> xb = vload<VEC>(&a.x[(r + RT) * a.C + c0]);
+        VecF<VEC> ga = bn_gy_vec<VEC, POOL, T>(a, r, c0, xa, sc, sh, inv_keep);
+        VecF<VEC> gb = bn_gy_vec<VEC, POOL, T>(a, r + RT, c0, xb, sc, sh, inv_keep);
+        VecF<VEC> oa, ob;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float ha = (xa.v[e] - mu.v[e]) * inv.v[e], hb = (xb.v[e] - mu.v[e]) * inv.v[e];
+          if (PASS == 1) {
+            s.v[e] += ga.v[e]; q.v[e] = fmaf(ga.v[e], ha, q.v[e]);
+            s.v[e] += gb.v[e]; q.v[e] = fmaf(gb.v[e], hb, q.v[e]);
+          } else {
+            oa.v[e] = sc.v[e] * (ga.v[e] - c1.v[e] - ha * c2.v[e]);
+            ob.v[e] = sc.v[e] * (gb.v[e] - c1.v[e] - hb * c2.v[e]);
+          }
+        }
+        if (PASS == 2) { vstore<VEC>(&dx[r * a.C + c0], oa); vstore<VEC>(&dx[(r + RT) * a.C + c0], ob); }
+      }
+      for (; r < r1; r += RT) {
         VecF<VEC> xv = vload<VEC>(&a.x[r * a.C + c0]);
         VecF<VEC> gy = bn_gy_vec<VEC, POOL, T>(a, r, c0, xv, sc, sh, inv_keep);
         VecF<VEC> o;
@@ -735,11 +783,12 @@ __global__ __launch_bounds__(256) void bn_bwd_pool_kernel(BnBwdArgsT<T> a, float
             }
           }
         }
-        float gsel[VEC];
+        float gsel[VEC], dm[VEC];
+        drop_scale_vec<VEC>(a.seed, a.layer, (uint64_t)oidx, a.rate, inv_keep, dm);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           bool live = (best[e] > 0.f) && (best[e] < 6.f);
-          gsel[e] = live ? gv.v[e] * drop_scale(a.seed, a.layer, (uint64_t)(oidx + e), a.rate, inv_keep) : 0.f;
+          gsel[e] = live ? gv.v[e] * dm[e] : 0.f;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -779,21 +828,16 @@ __global__ __launch_bounds__(256) void bn_bwd_pool_kernel(BnBwdArgsT<T> a, float
 }
 
 // dgamma = sum gy*xhat, dbeta = sum gy; coef = [c1 | c2]
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nparts, int C, double inv_n,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
-  __shared__ double red[2][32][32];
-  int c = blockIdx.x * 32 + threadIdx.x;
-  double s = 0.0, q = 0.0;
-  if (c < C)
-    for (int p = threadIdx.y; p < nparts; p += 32) {
-      s += (double)partials[((long)p * 2 + 0) * C + c];
-      q += (double)partials[((long)p * 2 + 1) * C + c];
-    }
-  red[0][threadIdx.y][threadIdx.x] = s; red[1][threadIdx.y][threadIdx.x] = q;
+__global__ __launch_bounds__(RED_CH * RED_PL) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nparts, int C, double inv_n,
+                                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+  __shared__ double red[2][RED_PL][RED_CH];
+  int c = blockIdx.x * RED_CH + threadIdx.x;
+  red[0][threadIdx.y][threadIdx.x] = (c < C) ? part_lane_sum(partials + c, 2L * C, nparts, threadIdx.y) : 0.0;
+  red[1][threadIdx.y][threadIdx.x] = (c < C) ? part_lane_sum(partials + C + c, 2L * C, nparts, threadIdx.y) : 0.0;
   __syncthreads();
   if (threadIdx.y == 0 && c < C) {
-    s = 0.0; q = 0.0;
-    for (int r = 0; r < 32; ++r) { s += red[0][r][threadIdx.x]; q += red[1][r][threadIdx.x]; }
+    double s = 0.0, q = 0.0;
+    for (int r = 0; r < RED_PL; ++r) { s += red[0][r][threadIdx.x]; q += red[1][r][threadIdx.x]; }
     dbeta[c] = (float)s; dgamma[c] = (float)q;
     coef[c] = (float)(s * inv_n); coef[C + c] = (float)(q * inv_n);
   }
@@ -819,7 +863,7 @@ static int bn_bwd_launch(const BnBwdArgsT<T>& a, T* dx, float* dgamma, float* db
   if (window) hipLaunchKernelGGL((bn_bwd_pool_kernel<1, VEC, T>), dim3(chunks), dim3(256), 0, stream, a, parts, (const float*)nullptr, (T*)nullptr, CW, rpc);
   else hipLaunchKernelGGL((bn_bwd_kernel<1, VEC, POOL, T>), dim3(chunks), dim3(256), 0, stream, a, parts, (const float*)nullptr, (T*)nullptr, CW, rpc);
   CRNN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(a.C, 32)), dim3(32, 32), 0, stream, parts, chunks, a.C, 1.0 / (double)M, dgamma, dbeta, coef);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(a.C, RED_CH)), dim3(RED_CH, RED_PL), 0, stream, parts, chunks, a.C, 1.0 / (double)M, dgamma, dbeta, coef);
   CRNN_LAUNCH_CHECK();
   if (window) hipLaunchKernelGGL((bn_bwd_pool_kernel<2, VEC, T>), dim3(chunks), dim3(256), 0, stream, a, (float*)nullptr, coef, dx, CW, rpc);
   else hipLaunchKernelGGL((bn_bwd_kernel<2, VEC, POOL, T>), dim3(chunks), dim3(256), 0, stream, a, (float*)nullptr, coef, dx, CW, rpc);
@@ -833,7 +877,11 @@ static int bn_bwd_typed(const T* x, const T* g, const float* bnstate, const floa
                         uint32_t layer, hipStream_t stream) {
   BnBwdArgsT<T> a{x, g, bnstate, gamma, B, H, W, C, ph, pw, rate, seed, layer};
   const bool pool = (ph * pw) > 1;
-  const bool vec = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)g | (uintptr_t)dx | (uintptr_t)bnstate | (uintptr_t)coef) & 15) == 0);
+  const bool al = ((((uintptr_t)x | (uintptr_t)g | (uintptr_t)dx | (uintptr_t)bnstate | (uintptr_t)coef) & 15) == 0);
+  const bool vec = (C % 4 == 0) && al;
+  if (VecMax<T>::value == 8 && al && C % 8 == 0)
+    return pool ? bn_bwd_launch<VecMax<T>::value, true, T>(a, dx, dgamma, dbeta, scratch_partials, coef, stream)
+                : bn_bwd_launch<VecMax<T>::value, false, T>(a, dx, dgamma, dbeta, scratch_partials, coef, stream);
   if (vec) return pool ? bn_bwd_launch<4, true, T>(a, dx, dgamma, dbeta, scratch_partials, coef, stream)
                        : bn_bwd_launch<4, false, T>(a, dx, dgamma, dbeta, scratch_partials, coef, stream);
   return pool ? bn_bwd_launch<1, true, T>(a, dx, dgamma, dbeta, scratch_partials, coef, stream)

@@ -19,51 +19,67 @@
 // lane's row pointers (k contiguous).  The loads of PD k-chunks (16 k each) are all issued before their MFMAs, so
 // a wave pays the L2 latency once per group instead of once per chunk (the step kernels are latency-bound).
 // ----------------------------------------------------------------------------------------------------------
-template <int NG, int PD>
-__device__ __forceinline__ void step_tile_gemm(const float* arow, bool valid, const float* (&brow)[NG], int K, bool skip,
-                                               float (*red)[NG][256], int wave, int r, int q) {
-  f32x4 acc[NG];
+template <int NG, int PD, int MT = 1>
+__device__ __forceinline__ void step_tile_gemm(const float* (&arow)[MT], const bool (&valid)[MT], const float* (&brow)[NG], int K, bool skip,
+                                               float (*red)[MT * NG][256], int wave, int r, int q) {
+  // MT batch tiles (16 rows each) share every B fragment: the recurrent weights are read once per MT*16 batch rows
+  f32x4 acc[MT][NG];
 #pragma unroll
-  for (int g = 0; g < NG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[m][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (!skip) {
     const int kw = K >> 2, kbeg = wave * kw, kend = kbeg + kw;
     int kb = kbeg;
     for (; kb + 16 * PD <= kend; kb += 16 * PD) {
-      float4 a4[PD], b4[NG][PD];
+      float4 a4[MT][PD], b4[NG][PD];
 #pragma unroll
       for (int c = 0; c < PD; ++c) {
-        a4[c] = valid ? *reinterpret_cast<const float4*>(arow + kb + 16 * c + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          a4[m][c] = valid[m] ? *reinterpret_cast<const float4*>(arow[m] + kb + 16 * c + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int g = 0; g < NG; ++g) b4[g][c] = *reinterpret_cast<const float4*>(brow[g] + kb + 16 * c + 4 * q);
       }
 #pragma unroll
       for (int c = 0; c < PD; ++c)
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].x, b4[g][c].x, acc[g], 0, 0, 0);
-          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].y, b4[g][c].y, acc[g], 0, 0, 0);
-          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].z, b4[g][c].z, acc[g], 0, 0, 0);
-          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].w, b4[g][c].w, acc[g], 0, 0, 0);
-        }
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m][c].x, b4[g][c].x, acc[m][g], 0, 0, 0);
+            acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m][c].y, b4[g][c].y, acc[m][g], 0, 0, 0);
+            acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m][c].z, b4[g][c].z, acc[m][g], 0, 0, 0);
+            acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m][c].w, b4[g][c].w, acc[m][g], 0, 0, 0);
+          }
     }
     for (; kb < kend; kb += 16) {
-      float4 a4 = valid ? *reinterpret_cast<const float4*>(arow + kb + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 a4[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a4[m] = valid[m] ? *reinterpret_cast<const float4*>(arow[m] + kb + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         float4 b4 = *reinterpret_cast<const float4*>(brow[g] + kb + 4 * q);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc[g], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m].x, b4.x, acc[m][g], 0, 0, 0);
+          acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m].y, b4.y, acc[m][g], 0, 0, 0);
+          acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m].z, b4.z, acc[m][g], 0, 0, 0);
+          acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m].w, b4.w, acc[m][g], 0, 0, 0);
+        }
       }
     }
   }
 #pragma unroll
-  for (int g = 0; g < NG; ++g)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) red[wave][g][(q * 4 + e) * 16 + r] = acc[g][e];  // C/D: row = 4q+e, col = r
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wave][m * NG + g][(q * 4 + e) * 16 + r] = acc[m][g][e];  // C/D: row = 4q+e, col = r
   __syncthreads();
 }
+
+#define LSTM_MT 1   // batch tiles (x16 rows) per workgroup in the LSTM step kernels
 
 struct LstmDir {
   const float* xw;   // [T][B][4u]  x*W + b
@@ -77,73 +93,106 @@ struct LstmDir {
 };
 
 __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmDir d0, LstmDir d1, int s, int T, int B, int u) {
-  __shared__ float red[4][4][256];
+  __shared__ float red[4][LSTM_MT * 4][256];
   const LstmDir d = blockIdx.z ? d1 : d0;
   const int dir = blockIdx.z;
   const int t = dir ? T - 1 - s : s, tp = dir ? t + 1 : t - 1;
-  const int b0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+  const int b0 = blockIdx.y * (16 * LSTM_MT), j0 = blockIdx.x * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  float xwv[LSTM_MT][4], cpv[LSTM_MT];   // epilogue operands, requested before the GEMM so their latency overlaps it
+#pragma unroll
+  for (int m = 0; m < LSTM_MT; ++m) {
+    const int b = b0 + 16 * m + (tid >> 4), j = j0 + (tid & 15);
+    const bool ok = b < B;
+    const float* xw = d.xw + ((long)t * B + (ok ? b : 0)) * 4 * u;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) xwv[m][g] = xw[g * u + j];
+    cpv[m] = (s > 0) ? d.c[((long)tp * B + (ok ? b : 0)) * u + j] : 0.f;
+  }
   {
-    const bool valid = (b0 + r) < B;
-    const float* arow = d.h + ((long)(s > 0 ? tp : t) * B + (valid ? b0 + r : 0)) * d.ldh;
+    bool valid[LSTM_MT]; const float* arow[LSTM_MT];
+#pragma unroll
+    for (int m = 0; m < LSTM_MT; ++m) {
+      valid[m] = (b0 + 16 * m + r) < B;
+      arow[m] = d.h + ((long)(s > 0 ? tp : t) * B + (valid[m] ? b0 + 16 * m + r : 0)) * d.ldh;
+    }
     const float* brow[4] = {d.wt + (long)(j0 + r) * u, d.wt + (long)(u + j0 + r) * u, d.wt + (long)(2 * u + j0 + r) * u,
                             d.wt + (long)(3 * u + j0 + r) * u};
-    step_tile_gemm<4, 4>(arow, valid, brow, u, s == 0, red, wave, r, q);
+    step_tile_gemm<4, 4, LSTM_MT>(arow, valid, brow, u, s == 0, red, wave, r, q);
   }
-  const int row = tid >> 4, col = tid & 15, b = b0 + row, j = j0 + col;
-  if (b < B) {
-    float z[4];
-    const float* xw = d.xw + ((long)t * B + b) * 4 * u;
+  const int row = tid >> 4, col = tid & 15, j = j0 + col;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      z[g] = ((red[0][g][tid] + red[1][g][tid]) + (red[2][g][tid] + red[3][g][tid])) + xw[g * u + j];
-    float ig = hard_sigmoid(z[0]), fg = hard_sigmoid(z[1]), gg = tanhf(z[2]), og = hard_sigmoid(z[3]);
-    float cprev = (s > 0) ? d.c[((long)tp * B + b) * u + j] : 0.f;
-    float cn = fg * cprev + ig * gg;
-    float hn = og * tanhf(cn);
-    float* gt = d.gates + ((long)t * B + b) * 4 * u;
-    gt[j] = ig; gt[u + j] = fg; gt[2 * u + j] = gg; gt[3 * u + j] = og;
-    d.c[((long)t * B + b) * u + j] = cn;
-    d.h[((long)t * B + b) * d.ldh + j] = hn;
+  for (int m = 0; m < LSTM_MT; ++m) {
+    const int b = b0 + 16 * m + row;
+    if (b < B) {
+      float z[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        z[g] = ((red[0][m * 4 + g][tid] + red[1][m * 4 + g][tid]) + (red[2][m * 4 + g][tid] + red[3][m * 4 + g][tid])) + xwv[m][g];
+      float ig = hard_sigmoid(z[0]), fg = hard_sigmoid(z[1]), gg = tanhf(z[2]), og = hard_sigmoid(z[3]);
+      float cn = fg * cpv[m] + ig * gg;
+      float hn = og * tanhf(cn);
+      float* gt = d.gates + ((long)t * B + b) * 4 * u;
+      gt[j] = ig; gt[u + j] = fg; gt[2 * u + j] = gg; gt[3 * u + j] = og;
+      d.c[((long)t * B + b) * u + j] = cn;
+      d.h[((long)t * B + b) * d.ldh + j] = hn;
+    }
   }
 }
 
 // sb = 0..T-1 counts backward steps; the time handled is the (T-1-sb)-th in processing order
 __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmDir d0, LstmDir d1, int sb, int T, int B, int u) {
-  __shared__ float red4[4][1][256];
-  float (*red)[256] = reinterpret_cast<float (*)[256]>(red4);
+  __shared__ float red[4][LSTM_MT][256];
   const LstmDir d = blockIdx.z ? d1 : d0;
   const int dir = blockIdx.z;
   const int sp = T - 1 - sb;                       // processing index of this time in the forward pass
   const int t = dir ? T - 1 - sp : sp;
   const int tnext = dir ? t - 1 : t + 1;           // processed after t in forward order (already back-propagated)
   const int tprev = dir ? t + 1 : t - 1;           // processed before t in forward order
-  const int b0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+  const int b0 = blockIdx.y * (16 * LSTM_MT), j0 = blockIdx.x * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
   const int K = 4 * u;
-  {
-    const bool valid = (b0 + r) < B;
-    const float* arow = d.dz + ((long)(sb > 0 ? tnext : t) * B + (valid ? b0 + r : 0)) * K;
-    const float* brow[1] = {d.wt + (long)(j0 + r) * K};
-    step_tile_gemm<1, 8>(arow, valid, brow, K, sb == 0, red4, wave, r, q);
+  float gv[LSTM_MT][4], ctv[LSTM_MT], cpv[LSTM_MT], dcv[LSTM_MT], dov[LSTM_MT];   // epilogue operands, requested before the GEMM
+#pragma unroll
+  for (int m = 0; m < LSTM_MT; ++m) {
+    const int b = b0 + 16 * m + (tid >> 4), j = j0 + (tid & 15);
+    const long bb = (b < B) ? b : 0;
+    const float* gt = d.gates + ((long)t * B + bb) * K;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gv[m][g] = gt[g * u + j];
+    ctv[m] = d.c[((long)t * B + bb) * u + j];
+    cpv[m] = (sp > 0) ? d.c[((long)tprev * B + bb) * u + j] : 0.f;
+    dcv[m] = (sb > 0) ? d.dc[bb * u + j] : 0.f;
+    dov[m] = d.dout[((long)t * B + bb) * d.ldo + j];
   }
-  const int row = tid >> 4, col = tid & 15, b = b0 + row, j = j0 + col;
-  if (b < B) {
-    float dh = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + d.dout[((long)t * B + b) * d.ldo + j];
-    const float* gt = d.gates + ((long)t * B + b) * K;
-    float ig = gt[j], fg = gt[u + j], gg = gt[2 * u + j], og = gt[3 * u + j];
-    float ct = d.c[((long)t * B + b) * u + j];
-    float cprev = (sp > 0) ? d.c[((long)tprev * B + b) * u + j] : 0.f;
-    float dcin = (sb > 0) ? d.dc[(long)b * u + j] : 0.f;
-    float tc = tanhf(ct);
-    float dov = dh * tc;
-    float dct = dh * og * (1.f - tc * tc) + dcin;
-    float* dz = d.dz + ((long)t * B + b) * K;
-    dz[j] = dct * gg * hs_grad_from_out(ig);
-    dz[u + j] = dct * cprev * hs_grad_from_out(fg);
-    dz[2 * u + j] = dct * ig * (1.f - gg * gg);
-    dz[3 * u + j] = dov * hs_grad_from_out(og);
-    d.dc[(long)b * u + j] = dct * fg;
+  {
+    bool valid[LSTM_MT]; const float* arow[LSTM_MT];
+#pragma unroll
+    for (int m = 0; m < LSTM_MT; ++m) {
+      valid[m] = (b0 + 16 * m + r) < B;
+      arow[m] = d.dz + ((long)(sb > 0 ? tnext : t) * B + (valid[m] ? b0 + 16 * m + r : 0)) * K;
+    }
+    const float* brow[1] = {d.wt + (long)(j0 + r) * K};
+    step_tile_gemm<1, 8, LSTM_MT>(arow, valid, brow, K, sb == 0, red, wave, r, q);
+  }
+  const int row = tid >> 4, col = tid & 15, j = j0 + col;
+#pragma unroll
+  for (int m = 0; m < LSTM_MT; ++m) {
+    const int b = b0 + 16 * m + row;
+    if (b < B) {
+      float dh = ((red[0][m][tid] + red[1][m][tid]) + (red[2][m][tid] + red[3][m][tid])) + dov[m];
+      float ig = gv[m][0], fg = gv[m][1], gg = gv[m][2], og = gv[m][3];
+      float ct = ctv[m], cprev = cpv[m], dcin = dcv[m];
+      float tc = tanhf(ct);
+      float dog = dh * tc;
+      float dct = dh * og * (1.f - tc * tc) + dcin;
+      float* dz = d.dz + ((long)t * B + b) * K;
+      dz[j] = dct * gg * hs_grad_from_out(ig);
+      dz[u + j] = dct * cprev * hs_grad_from_out(fg);
+      dz[2 * u + j] = dct * ig * (1.f - gg * gg);
+      dz[3 * u + j] = dog * hs_grad_from_out(og);
+      d.dc[(long)b * u + j] = dct * fg;
+    }
   }
 }
 
@@ -158,7 +207,7 @@ extern "C" int crnn_lstm_fwd(const float* xw0, const float* xw1, const float* ut
   if (ldh % 4 != 0) return CRNN_ERR_ARG;
   LstmDir a{xw0, ut0, h0, ldh, c0, g0, nullptr, 0, nullptr, nullptr};
   LstmDir b{xw1, ut1, h1, ldh, c1, g1, nullptr, 0, nullptr, nullptr};
-  dim3 grid(u / 16, cdiv(B, 16), 2);
+  dim3 grid(u / 16, cdiv(B, 16 * LSTM_MT), 2);
   for (int s = 0; s < T; ++s) {
     hipLaunchKernelGGL(lstm_fwd_step_kernel, grid, dim3(256), 0, stream, a, b, s, T, B, u);
   }
@@ -174,7 +223,7 @@ extern "C" int crnn_lstm_bwd(const float* u0, const float* u1, const float* c0, 
   CRNN_TRY(check_units(u));
   LstmDir a{nullptr, u0, nullptr, 0, const_cast<float*>(c0), const_cast<float*>(g0), dout0, ldo, dz0, dc0};
   LstmDir b{nullptr, u1, nullptr, 0, const_cast<float*>(c1), const_cast<float*>(g1), dout1, ldo, dz1, dc1};
-  dim3 grid(u / 16, cdiv(B, 16), 2);
+  dim3 grid(u / 16, cdiv(B, 16 * LSTM_MT), 2);
   for (int sb = 0; sb < T; ++sb) {
     hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, dim3(256), 0, stream, a, b, sb, T, B, u);
   }
@@ -208,15 +257,16 @@ struct GruDir {
   const int b0 = blockIdx.y * 16, j0 = blockIdx.x * 16;                                              \
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;       \
   const int row = tid >> 4, col = tid & 15, b = b0 + row, j = j0 + col;                              \
-  const bool valid = (b0 + r) < B;                                                                   \
-  const int ar = valid ? b0 + r : 0
+  const bool valid1 = (b0 + r) < B;                                                                  \
+  const bool valid[1] = {valid1};                                                                    \
+  const int ar = valid1 ? b0 + r : 0
 
 __global__ __launch_bounds__(256) void gru_fwd_zr_kernel(GruDir d0, GruDir d1, int s, int T, int B, int u) {
   __shared__ float red[4][2][256];
   const GruDir d = blockIdx.z ? d1 : d0;
   const int dir = blockIdx.z, t = dir ? T - 1 - s : s, tp = dir ? t + 1 : t - 1;
   STEP_IDS();
-  const float* arow = d.h + ((long)(s > 0 ? tp : t) * B + ar) * d.ldh;
+  const float* arow[1] = {d.h + ((long)(s > 0 ? tp : t) * B + ar) * d.ldh};
   const float* brow[2] = {d.w + (long)(j0 + r) * u, d.w + (long)(u + j0 + r) * u};
   step_tile_gemm<2, 4>(arow, valid, brow, u, s == 0, red, wave, r, q);
   if (b < B) {
@@ -236,7 +286,7 @@ __global__ __launch_bounds__(256) void gru_fwd_h_kernel(GruDir d0, GruDir d1, in
   const GruDir d = blockIdx.z ? d1 : d0;
   const int dir = blockIdx.z, t = dir ? T - 1 - s : s, tp = dir ? t + 1 : t - 1;
   STEP_IDS();
-  const float* arow = d.rh + ((long)t * B + ar) * u;
+  const float* arow[1] = {d.rh + ((long)t * B + ar) * u};
   const float* brow[1] = {d.w + (long)(2 * u + j0 + r) * u};
   step_tile_gemm<1, 4>(arow, valid, brow, u, s == 0, red, wave, r, q);
   if (b < B) {
@@ -255,7 +305,7 @@ __global__ __launch_bounds__(256) void gru_bwd_b_kernel(GruDir d0, GruDir d1, in
   const int dir = blockIdx.z, sp = T - 1 - sb, t = dir ? T - 1 - sp : sp;
   const int tnext = dir ? t - 1 : t + 1, tprev = dir ? t + 1 : t - 1;
   STEP_IDS();
-  const float* arow = d.dz + ((long)(sb > 0 ? tnext : t) * B + ar) * 3 * u;
+  const float* arow[1] = {d.dz + ((long)(sb > 0 ? tnext : t) * B + ar) * 3 * u};
   const float* brow[1] = {d.w + (long)(j0 + r) * 3 * u};
   step_tile_gemm<1, 8>(arow, valid, brow, 2 * u, sb == 0, red, wave, r, q);
   if (b < B) {
@@ -277,7 +327,7 @@ __global__ __launch_bounds__(256) void gru_bwd_a_kernel(GruDir d0, GruDir d1, in
   const int dir = blockIdx.z, sp = T - 1 - sb, t = dir ? T - 1 - sp : sp;
   const int tprev = dir ? t + 1 : t - 1;
   STEP_IDS();
-  const float* arow = d.dz + ((long)t * B + ar) * 3 * u + 2 * u;
+  const float* arow[1] = {d.dz + ((long)t * B + ar) * 3 * u + 2 * u};
   const float* brow[1] = {d.w + (long)(j0 + r) * 3 * u + 2 * u};
   step_tile_gemm<1, 4>(arow, valid, brow, u, false, red, wave, r, q);
   if (b < B) {
