@@ -6,7 +6,8 @@ import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 adam = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("adam_kernel")]
-k = int(sys.argv[2]) if len(sys.argv) > 2 else len(adam) - 2
+args = [a for a in sys.argv[2:] if not a.startswith("--")]
+k = int(args[0]) if args else len(adam) - 2
 seg = rows[adam[k] + 1: adam[k + 1] + 1]
 t0 = int(seg[0]["Start_Timestamp"]); prev = t0
 busy = 0; agg = {}
