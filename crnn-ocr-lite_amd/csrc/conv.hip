@@ -13,146 +13,249 @@
 #define DW_NT 256   // threads per depthwise workgroup (8 channel-quads x DW_NT/8 pixel threads)
 #endif
 
+// VEC consecutive channels of one pixel, widened to fp32 (VEC = 1, 4 or 8; 8 = one 16-byte access of bf16 storage)
+template <int VEC>
+struct VecF { float v[VEC]; };
+
+template <int VEC, typename T>
+__device__ __forceinline__ VecF<VEC> vload(const T* p) {
+  VecF<VEC> r;
+  if (VEC == 8) {
+    float8 q = ld8(p);
+    r.v[0] = q.lo.x; r.v[1 % VEC] = q.lo.y; r.v[2 % VEC] = q.lo.z; r.v[3 % VEC] = q.lo.w;
+    r.v[4 % VEC] = q.hi.x; r.v[5 % VEC] = q.hi.y; r.v[6 % VEC] = q.hi.z; r.v[7 % VEC] = q.hi.w;
+  } else if (VEC == 4) {
+    float4 q = ld4(p); r.v[0] = q.x; r.v[1 % VEC] = q.y; r.v[2 % VEC] = q.z; r.v[3 % VEC] = q.w;
+  } else {
+    r.v[0] = ld1(p);
+  }
+  return r;
+}
+template <int VEC, typename T>
+__device__ __forceinline__ void vstore(T* p, const VecF<VEC>& r) {
+  if (VEC == 8) {
+    float8 q;
+    q.lo = make_float4(r.v[0], r.v[1 % VEC], r.v[2 % VEC], r.v[3 % VEC]);
+    q.hi = make_float4(r.v[4 % VEC], r.v[5 % VEC], r.v[6 % VEC], r.v[7 % VEC]);
+    st8(p, q);
+  } else if (VEC == 4) {
+    st4(p, make_float4(r.v[0], r.v[1 % VEC], r.v[2 % VEC], r.v[3 % VEC]));
+  } else {
+    st1(p, r.v[0]);
+  }
+}
+// widest vector the storage type moves in one 16-byte access
+template <typename T> struct VecMax { static const int value = 4; };
+template <> struct VecMax<bf16_t> { static const int value = 8; };
+
 // ---------------------------------------------------------------------------------------------
 // depthwise 3x3, C % 32 == 0 : LDS halo tile
 // grid.x = C/32, grid.y = B * ceil(H/TH); block 256 = 8 channel-quads x 32 pixel threads
 // mode 0: out = conv(x, k) (flip=1 -> taps flipped = data gradient), optional stats partials
 // mode 1: weight gradient partials: dk[tap][c] += x[shifted] * g[center]
 // ---------------------------------------------------------------------------------------------
-// raw 4-channel vector of the storage type (what sits in HBM and in the LDS tile) and its fp32 view
-template <typename T> struct Raw4;
-template <> struct Raw4<float> { typedef float4 type; };
-template <> struct Raw4<bf16_t> { typedef uint2 type; };
-__device__ __forceinline__ float4 ldraw(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ uint2 ldraw(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
-__device__ __forceinline__ float4 cvt4(float4 v) { return v; }
-__device__ __forceinline__ float4 cvt4(uint2 u) {
-  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
-                     __uint_as_float(u.y & 0xffff0000u));
+// raw channel vector of the storage type (what sits in HBM and in the LDS tile): 4 fp32 (16 B) or DW_BF16_VN bf16
+#ifndef DW_BF16_VN
+#define DW_BF16_VN 4
+#endif
+template <typename T> struct RawV;
+template <> struct RawV<float> { typedef float4 type; static const int N = 4; };
+#if DW_BF16_VN == 8
+template <> struct RawV<bf16_t> { typedef uint4 type; static const int N = 8; };
+#else
+template <> struct RawV<bf16_t> { typedef uint2 type; static const int N = 4; };
+#endif
+template <typename V, typename T> __device__ __forceinline__ V ldraw(const T* p) { return *reinterpret_cast<const V*>(p); }
+__device__ __forceinline__ void widen(const float4& v, float (&f)[4]) { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
+__device__ __forceinline__ void widen(const uint2& u, float (&f)[4]) {
+  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
 }
-__device__ __forceinline__ void zero4(float4& v) { v = make_float4(0.f, 0.f, 0.f, 0.f); }
-__device__ __forceinline__ void zero4(uint2& v) { v = make_uint2(0u, 0u); }
+__device__ __forceinline__ void widen(const uint4& u, float (&f)[8]) {
+  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ void zerov(float4& v) { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void zerov(uint2& v) { v = make_uint2(0u, 0u); }
+__device__ __forceinline__ void zerov(uint4& v) { v = make_uint4(0u, 0u, 0u, 0u); }
+__device__ __forceinline__ void narrow_store(float* p, const float (&f)[4]) { st4(p, make_float4(f[0], f[1], f[2], f[3])); }
+__device__ __forceinline__ void narrow_store(bf16_t* p, const float (&f)[4]) { st4(p, make_float4(f[0], f[1], f[2], f[3])); }
+__device__ __forceinline__ void narrow_store(bf16_t* p, const float (&f)[8]) {
+  *reinterpret_cast<uint4*>(p) = make_uint4(pack2_bf16(f[0], f[1]), pack2_bf16(f[2], f[3]), pack2_bf16(f[4], f[5]), pack2_bf16(f[6], f[7]));
+}
+// sum over the pixel-threads of a wave that share a channel lane (lanes l, l^CL, l^2CL, ...), fixed order
+template <int CL>
+__device__ __forceinline__ float pixlane_sum(float v) {
+#pragma unroll
+  for (int o = CL; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
 
 // A workgroup handles TH rows x full width x one 128-BYTE channel slab (32 fp32 or 64 bf16 channels): every
-// pixel's slab is one full 128-B HBM segment in either storage type.  CL = lanes per pixel (4 channels each).
+// pixel's slab is one full 128-B HBM segment in either storage type (CL lanes x sizeof(V) bytes).
+// Each thread produces PXB horizontally adjacent pixels per step: the 3 x (PXB+2) window is read from LDS and widened
+// once and feeds all PXB outputs (5 LDS vectors per output at PXB = 3 instead of 9).
+#define DW_PXB 3   // fp32 storage; bf16 storage (8 channels per lane, 72 weight registers) uses 2
 template <int MODE, int NT, typename T>
-__global__ __launch_bounds__(NT) void dwconv_tile_kernel(const T* __restrict__ x, const float* __restrict__ k,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void dwconv_tile_kernel(const T* __restrict__ x, const float* __restrict__ k,
                                                           const T* __restrict__ g, T* __restrict__ out,
                                                           float* __restrict__ partials, int B, int H, int W, int C,
-                                                          int TH, int flip) {
-  typedef typename Raw4<T>::type V;
-  constexpr int CL = 128 / sizeof(V);         // 8 (fp32) or 16 (bf16)
+                                                          int TH, int TW, int flip) {
+  typedef typename RawV<T>::type V;
+  constexpr int VN = RawV<T>::N;              // channels per lane
+  constexpr int CL = 128 / sizeof(V);         // lanes per pixel (the 128-B slab)
   constexpr int PT = NT / CL;                 // pixel threads
-  constexpr int MAXLD = 49152 / (NT * sizeof(V));   // loads per thread for a full 48 KiB tile: 12 or 24
+  constexpr int MAXLD = 49152 / (NT * sizeof(V));   // loads per thread for a full 48 KiB tile
   extern __shared__ __attribute__((aligned(16))) float smem[];
   V* tile = reinterpret_cast<V*>(smem);
   const int tid = threadIdx.x, c4 = tid & (CL - 1), pt = tid / CL;
-  const int cc0 = blockIdx.x * (4 * CL);
-  const int nHb = (H + TH - 1) / TH;
-  const int b = blockIdx.y / nHb, h0 = (blockIdx.y % nHb) * TH;
-  const int Wt = W + 2;
-  const int n4 = (TH + 2) * Wt * CL;
-  // halo-tile fill: all of this thread's loads are issued before the first LDS write (one HBM latency per
-  // workgroup); (fy, fx) are stepped incrementally: no per-load integer division
-  for (int base = tid; base < n4; base += MAXLD * NT) {
-    V v[MAXLD];
-    int pix0 = base / CL;
-    int fy = pix0 / Wt, fx = pix0 - fy * Wt;
+  const int cc0 = blockIdx.x * (VN * CL);
+  const int nHb = (H + TH - 1) / TH, nWb = (W + TW - 1) / TW;
+  const int wb = blockIdx.y % nWb, hb = (blockIdx.y / nWb) % nHb, b = blockIdx.y / (nWb * nHb);
+  const int h0 = hb * TH, w0 = wb * TW;
+  const int Wt = TW + 2;
+  // halo-tile fill with 16-byte loads (8 lanes per pixel slab, whatever the compute vector is); all of this thread's
+  // loads are issued before the first LDS write (one HBM latency per workgroup).  32-bit offsets inside the image,
+  // (fy, fx) stepped without division or branches.
+  {
+    constexpr int FL = 8, FPT = NT / FL;                  // fill lanes per pixel, fill pixel-threads
+    constexpr int FMAX = 49152 / (NT * 16);               // loads per thread for a full 48 KiB tile
+    constexpr int FE = 16 / sizeof(T);                    // elements per 16-byte load
+    uint4* tile16 = reinterpret_cast<uint4*>(smem);
+    const T* xb = x + (long)b * H * W * C + cc0 + FE * (tid & (FL - 1));
+    const int n16 = (TH + 2) * Wt * FL;
+    const int dfy = FPT / Wt, dfx = FPT - dfy * Wt;
+    for (int base = tid; base < n16; base += FMAX * NT) {
+      uint4 v[FMAX];
+      int pix0 = base / FL;
+      int fy = pix0 / Wt, fx = pix0 - fy * Wt;
 #pragma unroll
-    for (int uu = 0; uu < MAXLD; ++uu) {
-      int i = base + uu * NT;
-      int gh = h0 + fy - 1, gw = fx - 1;
-      zero4(v[uu]);
-      if (i < n4 && gh >= 0 && gh < H && gw >= 0 && gw < W)
-        v[uu] = ldraw(&x[(((long)b * H + gh) * W + gw) * C + cc0 + 4 * c4]);
-      fx += PT;
-      while (fx >= Wt) { fx -= Wt; ++fy; }
-    }
+      for (int uu = 0; uu < FMAX; ++uu) {
+        int i = base + uu * NT;
+        int gh = h0 + fy - 1, gw = w0 + fx - 1;
+        v[uu] = make_uint4(0u, 0u, 0u, 0u);
+        if (i < n16 && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
+          v[uu] = *reinterpret_cast<const uint4*>(xb + (gh * W + gw) * C);
+        fx += dfx; fy += dfy;
+        if (fx >= Wt) { fx -= Wt; ++fy; }
+      }
 #pragma unroll
-    for (int uu = 0; uu < MAXLD; ++uu) {
-      int i = base + uu * NT;
-      if (i < n4) tile[i] = v[uu];
+      for (int uu = 0; uu < FMAX; ++uu) {
+        int i = base + uu * NT;
+        if (i < n16) tile16[i] = v[uu];
+      }
     }
   }
-  float4 kw[9];
+  float kw[9][VN];
   if (MODE == 0) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       int ts = flip ? 8 - t : t;
-      kw[t] = *reinterpret_cast<const float4*>(&k[ts * C + cc0 + 4 * c4]);
+      VecF<VN> w = vload<VN>(&k[ts * C + cc0 + VN * c4]);
+#pragma unroll
+      for (int e = 0; e < VN; ++e) kw[t][e] = w.v[e];
     }
   }
   __syncthreads();
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), ss = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 dk[9];
+  float s[VN], ss[VN], dk[9][VN];
+#pragma unroll
+  for (int e = 0; e < VN; ++e) { s[e] = 0.f; ss[e] = 0.f; }
   if (MODE == 1) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) dk[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int e = 0; e < VN; ++e) dk[t][e] = 0.f;
   }
-  const int npix = TH * W;
-  float4 gnext = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (MODE == 1 && pt < npix && h0 + pt / W < H)
-    gnext = ld4(&g[(((long)b * H + h0 + pt / W) * W + (pt % W)) * C + cc0 + 4 * c4]);
-  int ly = pt / W, lx = pt - (pt / W) * W;   // stepped incrementally below (no division per pixel)
-  for (int p = pt; p < npix; p += PT) {
-    int gh = h0 + ly;
+  constexpr int PXB = DW_PXB;
+  const int gpr = (TW + PXB - 1) / PXB;        // pixel groups per tile row
+  const int npg = TH * gpr;
+  const int dly = PT / gpr, dlg = PT - dly * gpr;
+  int ly = pt / gpr, lg = pt - ly * gpr;       // stepped incrementally below
+  const T* gb = g + (long)b * H * W * C + cc0 + VN * c4;
+  T* ob = out + (long)b * H * W * C + cc0 + VN * c4;
+  for (int pg = pt; pg < npg; pg += PT) {
+    const int lx = lg * PXB;
+    const int gh = h0 + ly;
     if (gh >= H) break;
-    long o = (((long)b * H + gh) * W + lx) * C + cc0 + 4 * c4;
-    if (MODE == 0) {
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int o = (gh * W + w0 + lx) * C;
+    float gv[PXB][VN];
+    if (MODE == 1) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          float4 v = cvt4(tile[((ly + i) * Wt + lx + j) * CL + c4]);
-          float4 w = kw[i * 3 + j];
-          a.x = fmaf(v.x, w.x, a.x); a.y = fmaf(v.y, w.y, a.y); a.z = fmaf(v.z, w.z, a.z); a.w = fmaf(v.w, w.w, a.w);
-        }
-      st4(&out[o], a);
-      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
-      ss.x = fmaf(a.x, a.x, ss.x); ss.y = fmaf(a.y, a.y, ss.y); ss.z = fmaf(a.z, a.z, ss.z); ss.w = fmaf(a.w, a.w, ss.w);
-    } else {
-      float4 gv = gnext;
-      {  // prefetch the upstream gradient of this thread's next pixel
-        int pn = p + PT, lyn = ly, lxn = lx + PT;
-        while (lxn >= W) { lxn -= W; ++lyn; }
-        if (pn < npix && h0 + lyn < H) gnext = ld4(&g[(((long)b * H + h0 + lyn) * W + lxn) * C + cc0 + 4 * c4]);
+      for (int e = 0; e < PXB; ++e) {
+        V gr; zerov(gr);
+        if (lx + e < TW && w0 + lx + e < W) gr = ldraw<V>(gb + o + e * C);
+        widen(gr, gv[e]);
       }
+    }
+    float a[PXB][VN];
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
+    for (int e = 0; e < PXB; ++e)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          float4 v = cvt4(tile[((ly + i) * Wt + lx + j) * CL + c4]);
-          float4& d = dk[i * 3 + j];
-          d.x = fmaf(v.x, gv.x, d.x); d.y = fmaf(v.y, gv.y, d.y); d.z = fmaf(v.z, gv.z, d.z); d.w = fmaf(v.w, gv.w, d.w);
+      for (int c = 0; c < VN; ++c) a[e][c] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float r[PXB + 2][VN];   // (the last group of a ragged row reads past the row end: those outputs are discarded)
+#pragma unroll
+      for (int j = 0; j < PXB + 2; ++j) widen(tile[((ly + i) * Wt + lx + j) * CL + c4], r[j]);
+#pragma unroll
+      for (int e = 0; e < PXB; ++e)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int c = 0; c < VN; ++c) {
+            if (MODE == 0) a[e][c] = fmaf(r[e + j][c], kw[i * 3 + j][c], a[e][c]);
+            else dk[i * 3 + j][c] = fmaf(r[e + j][c], gv[e][c], dk[i * 3 + j][c]);
+          }
+      __builtin_amdgcn_sched_barrier(0);   // one window row at a time: keeps the live set under the 3-waves/SIMD budget
+    }
+    if (MODE == 0) {
+#pragma unroll
+      for (int e = 0; e < PXB; ++e)
+        if (lx + e < TW && w0 + lx + e < W) {
+          narrow_store(ob + o + e * C, a[e]);
+          if (partials != nullptr) {
+#pragma unroll
+            for (int c = 0; c < VN; ++c) { s[c] += a[e][c]; ss[c] = fmaf(a[e][c], a[e][c], ss[c]); }
+          }
         }
     }
-    lx += PT;
-    while (lx >= W) { lx -= W; ++ly; }
+    lg += dlg; ly += dly;
+    if (lg >= gpr) { lg -= gpr; ++ly; }
   }
   if (partials == nullptr) return;
-  __syncthreads();  // tile no longer needed: reuse LDS for the cross-pixel-thread reduction
-  float4* red = reinterpret_cast<float4*>(smem);
+  // per-tile partials: the 8 pixel-threads of each wave are combined with lane shuffles, the NT/64 waves through LDS
+  __syncthreads();  // tile no longer needed
+  constexpr int NW = NT / 64, NV = (MODE == 0) ? 2 : 9;
+  float* red = smem;   // [NW][NV][CL][VN]
+  const int wave = tid >> 6, lane = tid & 63;
   if (MODE == 0) {
-    red[(0 * PT + pt) * CL + c4] = s;
-    red[(1 * PT + pt) * CL + c4] = ss;
-    __syncthreads();
-    if (tid < 2 * CL) {
-      int ci = tid & (CL - 1), v = tid / CL;
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int r = 0; r < PT; ++r) { float4 t = red[(v * PT + r) * CL + ci]; a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
-      *reinterpret_cast<float4*>(&partials[((long)blockIdx.y * 2 + v) * C + cc0 + 4 * ci]) = a;
+#pragma unroll
+    for (int e = 0; e < VN; ++e) { s[e] = pixlane_sum<CL>(s[e]); ss[e] = pixlane_sum<CL>(ss[e]); }
+    if (lane < CL) {
+#pragma unroll
+      for (int e = 0; e < VN; ++e) { red[((wave * NV + 0) * CL + c4) * VN + e] = s[e]; red[((wave * NV + 1) * CL + c4) * VN + e] = ss[e]; }
     }
   } else {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) red[(t * PT + pt) * CL + c4] = dk[t];
-    __syncthreads();
-    if (tid < 9 * CL) {
-      int ci = tid & (CL - 1), t = tid / CL;
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int r = 0; r < PT; ++r) { float4 v = red[(t * PT + r) * CL + ci]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
-      *reinterpret_cast<float4*>(&partials[((long)blockIdx.y * 9 + t) * C + cc0 + 4 * ci]) = a;
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int e = 0; e < VN; ++e) dk[t][e] = pixlane_sum<CL>(dk[t][e]);
+    if (lane < CL) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < VN; ++e) red[((wave * NV + t) * CL + c4) * VN + e] = dk[t][e];
     }
+  }
+  __syncthreads();
+  for (int i = tid; i < NV * CL * VN; i += NT) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) a += red[w * NV * CL * VN + i];
+    int v = i / (CL * VN), cch = i % (CL * VN);
+    partials[((long)blockIdx.y * NV + v) * C + cc0 + cch] = a;
   }
 }
 
@@ -226,26 +329,38 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_c1_kernel(const float* __res
   if (threadIdx.x < 9) partials[(long)blockIdx.x * 9 + threadIdx.x] = red[threadIdx.x][0];
 }
 
-// Tile height: as tall as a ~48 KiB halo tile allows (3 workgroups per CU), then balanced over the bands of H.
-static int dw_pick_th2(int H, int W, size_t* lds) {
-  static int th_env = -1;   // experiment hook: CRNN_DW_TH overrides the tile height
+// Tile = TH rows x TW columns of one 128-byte channel slab.  TW splits W into ceil(W/64) equal column tiles (the CRNN
+// maps are at most 36 wide: full-width tiles), TH is as tall as a 48 KiB halo tile allows (3 workgroups per CU) and
+// then balanced over the bands of H.
+struct DwTile { int TH, TW, nHb, nWb; size_t lds; };
+static DwTile dw_pick_tile(int H, int W) {
+  static int th_env = -1, tw_env = -1;   // experiment hooks: CRNN_DW_TH / CRNN_DW_TW override the tile
   if (th_env < 0) { const char* e = getenv("CRNN_DW_TH"); th_env = e ? atoi(e) : 0; }
-  const size_t red = (size_t)9 * (DW_NT / 8) * 128;  // weight-grad reduction scratch
-  int thmax = (int)(49152 / ((size_t)(W + 2) * 128)) - 2;
+  if (tw_env < 0) { const char* e = getenv("CRNN_DW_TW"); tw_env = e ? atoi(e) : 0; }
+  DwTile t;
+  t.nWb = cdiv(W, 64);
+  t.TW = cdiv(W, t.nWb);
+  if (tw_env > 0) t.TW = tw_env;
+  t.nWb = cdiv(W, t.TW);
+  static int lds_env = -1;               // CRNN_DW_LDS: halo-tile budget in bytes (default 48 KiB)
+  if (lds_env < 0) { const char* e = getenv("CRNN_DW_LDS"); lds_env = e ? atoi(e) : 49152; }
+  int thmax = (int)((size_t)lds_env / ((size_t)(t.TW + 2) * 128)) - 2;
   if (thmax < 1) thmax = 1;
   if (thmax > H) thmax = H;
-  int nb = (H + thmax - 1) / thmax;
-  int TH = (H + nb - 1) / nb;
-  if (th_env > 0) TH = th_env;
-  size_t tile = (size_t)(TH + 2) * (W + 2) * 128;
-  *lds = tile > red ? tile : red;
-  return TH;
+  int nb = cdiv(H, thmax);
+  t.TH = cdiv(H, nb);
+  if (th_env > 0) t.TH = th_env;
+  t.nHb = cdiv(H, t.TH);
+  const size_t red = (size_t)(DW_NT / 64) * 9 * 64 * 4;  // weight-grad cross-wave reduction scratch (<= 64 channels per slab)
+  size_t tile = (size_t)(t.TH + 2) * (t.TW + 2) * 128 + 128 * DW_PXB;   // + slack for the ragged last pixel group
+  t.lds = tile > red ? tile : red;
+  return t;
 }
 
-// number of row-band tiles (= partial rows) the tiled kernels produce for a (B,H,W) map
+// number of tiles (= partial rows) the tiled kernels produce for a (B,H,W) map
 extern "C" int crnn_dwconv_num_tiles(int B, int H, int W) {
-  size_t lds; int TH = dw_pick_th2(H, W, &lds);
-  return B * cdiv(H, TH);
+  DwTile t = dw_pick_tile(H, W);
+  return B * t.nHb * t.nWb;
 }
 
 // out = dwconv3x3(x, k[9][C]); flip=1 gives the data gradient.  If `stat_partials` != null (C%32==0
@@ -254,13 +369,13 @@ extern "C" int crnn_dwconv_num_tiles(int B, int H, int W) {
 template <typename T>
 static int dwconv_fwd_launch(const T* x, const float* k, T* out, float* stat_partials, int B, int H, int W, int C, int flip,
                              hipStream_t stream) {
-  size_t lds; int TH = dw_pick_th2(H, W, &lds);
-  if (lds > 160 * 1024) return CRNN_ERR_UNSUPPORTED;
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_tile_kernel<0, DW_NT, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  DwTile t = dw_pick_tile(H, W);
+  if (t.lds > 160 * 1024) return CRNN_ERR_UNSUPPORTED;
+  if (t.lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_tile_kernel<0, DW_NT, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const int slab = 128 / (int)sizeof(T);   // channels per workgroup: 32 (fp32) or 64 (bf16)
   if (C % slab) return CRNN_ERR_UNSUPPORTED;
-  dim3 grid(C / slab, B * cdiv(H, TH));
-  hipLaunchKernelGGL((dwconv_tile_kernel<0, DW_NT, T>), grid, dim3(DW_NT), lds, stream, x, k, (const T*)nullptr, out, stat_partials, B, H, W, C, TH, flip);
+  dim3 grid(C / slab, B * t.nHb * t.nWb);
+  hipLaunchKernelGGL((dwconv_tile_kernel<0, DW_NT, T>), grid, dim3(DW_NT), t.lds, stream, x, k, (const T*)nullptr, out, stat_partials, B, H, W, C, t.TH, t.TW, flip);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
@@ -282,41 +397,6 @@ extern "C" int crnn_dwconv3x3_fwd(const float* x, const float* k, float* out, fl
                                   int C, int flip, hipStream_t stream) {
   return crnn_dwconv3x3_fwd_ex(x, k, out, stat_partials, B, H, W, C, flip, CRNN_F32, stream);
 }
-
-// VEC consecutive channels of one pixel, widened to fp32 (VEC = 1, 4 or 8; 8 = one 16-byte access of bf16 storage)
-template <int VEC>
-struct VecF { float v[VEC]; };
-
-template <int VEC, typename T>
-__device__ __forceinline__ VecF<VEC> vload(const T* p) {
-  VecF<VEC> r;
-  if (VEC == 8) {
-    float8 q = ld8(p);
-    r.v[0] = q.lo.x; r.v[1 % VEC] = q.lo.y; r.v[2 % VEC] = q.lo.z; r.v[3 % VEC] = q.lo.w;
-    r.v[4 % VEC] = q.hi.x; r.v[5 % VEC] = q.hi.y; r.v[6 % VEC] = q.hi.z; r.v[7 % VEC] = q.hi.w;
-  } else if (VEC == 4) {
-    float4 q = ld4(p); r.v[0] = q.x; r.v[1 % VEC] = q.y; r.v[2 % VEC] = q.z; r.v[3 % VEC] = q.w;
-  } else {
-    r.v[0] = ld1(p);
-  }
-  return r;
-}
-template <int VEC, typename T>
-__device__ __forceinline__ void vstore(T* p, const VecF<VEC>& r) {
-  if (VEC == 8) {
-    float8 q;
-    q.lo = make_float4(r.v[0], r.v[1 % VEC], r.v[2 % VEC], r.v[3 % VEC]);
-    q.hi = make_float4(r.v[4 % VEC], r.v[5 % VEC], r.v[6 % VEC], r.v[7 % VEC]);
-    st8(p, q);
-  } else if (VEC == 4) {
-    st4(p, make_float4(r.v[0], r.v[1 % VEC], r.v[2 % VEC], r.v[3 % VEC]));
-  } else {
-    st1(p, r.v[0]);
-  }
-}
-// widest vector the storage type moves in one 16-byte access
-template <typename T> struct VecMax { static const int value = 4; };
-template <> struct VecMax<bf16_t> { static const int value = 8; };
 
 // ---------------------------------------------------------------------------------------------
 // Column reductions over a row-major [M][C] matrix -> partials [nchunk][NV][C]
@@ -445,14 +525,14 @@ extern "C" int crnn_partials_sum(const float* partials, int nparts, int n, float
 // weight gradient of the depthwise conv: dk[9][C] = sum x[shifted] * g.  scratch: [num_tiles][9][C]
 template <typename T>
 static int dwconv_wgrad_launch(const T* x, const T* g, float* dk, float* scratch, int B, int H, int W, int C, hipStream_t stream) {
-  size_t lds; int TH = dw_pick_th2(H, W, &lds);
-  if (lds > 160 * 1024) return CRNN_ERR_UNSUPPORTED;
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_tile_kernel<1, DW_NT, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  int ntiles = B * cdiv(H, TH);
+  DwTile t = dw_pick_tile(H, W);
+  if (t.lds > 160 * 1024) return CRNN_ERR_UNSUPPORTED;
+  if (t.lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_tile_kernel<1, DW_NT, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  int ntiles = B * t.nHb * t.nWb;
   const int slab = 128 / (int)sizeof(T);
   if (C % slab) return CRNN_ERR_UNSUPPORTED;
   dim3 grid(C / slab, ntiles);
-  hipLaunchKernelGGL((dwconv_tile_kernel<1, DW_NT, T>), grid, dim3(DW_NT), lds, stream, x, (const float*)nullptr, g, (T*)nullptr, scratch, B, H, W, C, TH, 0);
+  hipLaunchKernelGGL((dwconv_tile_kernel<1, DW_NT, T>), grid, dim3(DW_NT), t.lds, stream, x, (const float*)nullptr, g, (T*)nullptr, scratch, B, H, W, C, t.TH, t.TW, 0);
   CRNN_LAUNCH_CHECK();
   return crnn_partials_sum(scratch, ntiles, 9 * C, dk, 1.f, stream);
 }

@@ -79,6 +79,26 @@ __device__ __forceinline__ void step_tile_gemm(const float* (&arow)[MT], const b
   __syncthreads();
 }
 
+// XCD-aware placement of the step tiles.  Workgroup id -> XCD is id % 8, and an XCD's L2 does not keep the
+// recurrent operands across launches, so every step each XCD refetches whatever its tiles touch.  The 8 XCDs are
+// therefore arranged as SJ column groups x (8/SJ) batch groups: an XCD only ever sees 1/SJ of the recurrent
+// weights and SJ/8 of the state rows (e.g. 20 MB -> 6 MB of L2 fills per LSTM forward step at u = 256, B = 256).
+__host__ __device__ inline int cdiv_i(int a, int b) { return (a + b - 1) / b; }
+struct StepTile { int dir, bt, jt; };
+__host__ __device__ inline int step_grid(int gx, int gy, int SJ) { return 8 * 2 * cdiv_i(gy, 8 / SJ) * (gx / SJ); }
+__device__ __forceinline__ StepTile step_tile_map(int gx, int gy, int SJ) {
+  const int id = blockIdx.x, xcd = id & 7, loc = id >> 3;
+  const int jpg = gx / SJ, bpg = cdiv_i(gy, 8 / SJ);
+  const int xj = xcd % SJ, xb = xcd / SJ;
+  StepTile t;
+  t.jt = xj * jpg + loc % jpg;
+  const int rest = loc / jpg;
+  t.bt = xb * bpg + rest % bpg;
+  t.dir = rest / bpg;
+  return t;
+}
+static inline int step_sj(int gx) { return (gx % 4 == 0) ? 4 : (gx % 2 == 0 ? 2 : 1); }
+
 #define LSTM_MT 1   // batch tiles (x16 rows) per workgroup in the LSTM step kernels
 
 struct LstmDir {
@@ -92,12 +112,14 @@ struct LstmDir {
   float* dc;         // bwd: [B][u] cell-gradient carry
 };
 
-__global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmDir d0, LstmDir d1, int s, int T, int B, int u) {
+__global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmDir d0, LstmDir d1, int s, int T, int B, int u, int SJ) {
   __shared__ float red[4][LSTM_MT * 4][256];
-  const LstmDir d = blockIdx.z ? d1 : d0;
-  const int dir = blockIdx.z;
+  const StepTile st = step_tile_map(u / 16, cdiv_i(B, 16 * LSTM_MT), SJ);
+  if (st.bt * 16 * LSTM_MT >= B) return;
+  const LstmDir d = st.dir ? d1 : d0;
+  const int dir = st.dir;
   const int t = dir ? T - 1 - s : s, tp = dir ? t + 1 : t - 1;
-  const int b0 = blockIdx.y * (16 * LSTM_MT), j0 = blockIdx.x * 16;
+  const int b0 = st.bt * (16 * LSTM_MT), j0 = st.jt * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
   float xwv[LSTM_MT][4], cpv[LSTM_MT];   // epilogue operands, requested before the GEMM so their latency overlaps it
 #pragma unroll
@@ -141,15 +163,17 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmDir d0, LstmDir 
 }
 
 // sb = 0..T-1 counts backward steps; the time handled is the (T-1-sb)-th in processing order
-__global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmDir d0, LstmDir d1, int sb, int T, int B, int u) {
+__global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmDir d0, LstmDir d1, int sb, int T, int B, int u, int SJ) {
   __shared__ float red[4][LSTM_MT][256];
-  const LstmDir d = blockIdx.z ? d1 : d0;
-  const int dir = blockIdx.z;
+  const StepTile st = step_tile_map(u / 16, cdiv_i(B, 16 * LSTM_MT), SJ);
+  if (st.bt * 16 * LSTM_MT >= B) return;
+  const LstmDir d = st.dir ? d1 : d0;
+  const int dir = st.dir;
   const int sp = T - 1 - sb;                       // processing index of this time in the forward pass
   const int t = dir ? T - 1 - sp : sp;
   const int tnext = dir ? t - 1 : t + 1;           // processed after t in forward order (already back-propagated)
   const int tprev = dir ? t + 1 : t - 1;           // processed before t in forward order
-  const int b0 = blockIdx.y * (16 * LSTM_MT), j0 = blockIdx.x * 16;
+  const int b0 = st.bt * (16 * LSTM_MT), j0 = st.jt * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
   const int K = 4 * u;
   float gv[LSTM_MT][4], ctv[LSTM_MT], cpv[LSTM_MT], dcv[LSTM_MT], dov[LSTM_MT];   // epilogue operands, requested before the GEMM
@@ -207,9 +231,10 @@ extern "C" int crnn_lstm_fwd(const float* xw0, const float* xw1, const float* ut
   if (ldh % 4 != 0) return CRNN_ERR_ARG;
   LstmDir a{xw0, ut0, h0, ldh, c0, g0, nullptr, 0, nullptr, nullptr};
   LstmDir b{xw1, ut1, h1, ldh, c1, g1, nullptr, 0, nullptr, nullptr};
-  dim3 grid(u / 16, cdiv(B, 16 * LSTM_MT), 2);
+  const int SJ = step_sj(u / 16);
+  dim3 grid(step_grid(u / 16, cdiv(B, 16 * LSTM_MT), SJ));
   for (int s = 0; s < T; ++s) {
-    hipLaunchKernelGGL(lstm_fwd_step_kernel, grid, dim3(256), 0, stream, a, b, s, T, B, u);
+    hipLaunchKernelGGL(lstm_fwd_step_kernel, grid, dim3(256), 0, stream, a, b, s, T, B, u, SJ);
   }
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
@@ -223,9 +248,10 @@ extern "C" int crnn_lstm_bwd(const float* u0, const float* u1, const float* c0, 
   CRNN_TRY(check_units(u));
   LstmDir a{nullptr, u0, nullptr, 0, const_cast<float*>(c0), const_cast<float*>(g0), dout0, ldo, dz0, dc0};
   LstmDir b{nullptr, u1, nullptr, 0, const_cast<float*>(c1), const_cast<float*>(g1), dout1, ldo, dz1, dc1};
-  dim3 grid(u / 16, cdiv(B, 16 * LSTM_MT), 2);
+  const int SJ = step_sj(u / 16) > 2 ? 2 : step_sj(u / 16);   // the dz rows (4u wide) outweigh the weights here: favour batch groups
+  dim3 grid(step_grid(u / 16, cdiv(B, 16 * LSTM_MT), SJ));
   for (int sb = 0; sb < T; ++sb) {
-    hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, dim3(256), 0, stream, a, b, sb, T, B, u);
+    hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, dim3(256), 0, stream, a, b, sb, T, B, u, SJ);
   }
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
@@ -253,18 +279,22 @@ struct GruDir {
   float* dhp;         // [B][u] dh*z + d(rh)*r carried to the previous step
 };
 
+#define STEP_TILE()                                                                                  \
+  const StepTile st = step_tile_map(u / 16, cdiv_i(B, 16), SJ);                                      \
+  if (st.bt * 16 >= B) return
 #define STEP_IDS()                                                                                   \
-  const int b0 = blockIdx.y * 16, j0 = blockIdx.x * 16;                                              \
+  const int b0 = st.bt * 16, j0 = st.jt * 16;                                                        \
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;       \
   const int row = tid >> 4, col = tid & 15, b = b0 + row, j = j0 + col;                              \
   const bool valid1 = (b0 + r) < B;                                                                  \
   const bool valid[1] = {valid1};                                                                    \
   const int ar = valid1 ? b0 + r : 0
 
-__global__ __launch_bounds__(256) void gru_fwd_zr_kernel(GruDir d0, GruDir d1, int s, int T, int B, int u) {
+__global__ __launch_bounds__(256) void gru_fwd_zr_kernel(GruDir d0, GruDir d1, int s, int T, int B, int u, int SJ) {
   __shared__ float red[4][2][256];
-  const GruDir d = blockIdx.z ? d1 : d0;
-  const int dir = blockIdx.z, t = dir ? T - 1 - s : s, tp = dir ? t + 1 : t - 1;
+  STEP_TILE();
+  const GruDir d = st.dir ? d1 : d0;
+  const int dir = st.dir, t = dir ? T - 1 - s : s, tp = dir ? t + 1 : t - 1;
   STEP_IDS();
   const float* arow[1] = {d.h + ((long)(s > 0 ? tp : t) * B + ar) * d.ldh};
   const float* brow[2] = {d.w + (long)(j0 + r) * u, d.w + (long)(u + j0 + r) * u};
@@ -281,10 +311,11 @@ __global__ __launch_bounds__(256) void gru_fwd_zr_kernel(GruDir d0, GruDir d1, i
   }
 }
 
-__global__ __launch_bounds__(256) void gru_fwd_h_kernel(GruDir d0, GruDir d1, int s, int T, int B, int u) {
+__global__ __launch_bounds__(256) void gru_fwd_h_kernel(GruDir d0, GruDir d1, int s, int T, int B, int u, int SJ) {
   __shared__ float red[4][1][256];
-  const GruDir d = blockIdx.z ? d1 : d0;
-  const int dir = blockIdx.z, t = dir ? T - 1 - s : s, tp = dir ? t + 1 : t - 1;
+  STEP_TILE();
+  const GruDir d = st.dir ? d1 : d0;
+  const int dir = st.dir, t = dir ? T - 1 - s : s, tp = dir ? t + 1 : t - 1;
   STEP_IDS();
   const float* arow[1] = {d.rh + ((long)t * B + ar) * u};
   const float* brow[1] = {d.w + (long)(2 * u + j0 + r) * u};
@@ -299,10 +330,11 @@ __global__ __launch_bounds__(256) void gru_fwd_h_kernel(GruDir d0, GruDir d1, in
   }
 }
 
-__global__ __launch_bounds__(256) void gru_bwd_b_kernel(GruDir d0, GruDir d1, int sb, int T, int B, int u) {
+__global__ __launch_bounds__(256) void gru_bwd_b_kernel(GruDir d0, GruDir d1, int sb, int T, int B, int u, int SJ) {
   __shared__ float red[4][1][256];
-  const GruDir d = blockIdx.z ? d1 : d0;
-  const int dir = blockIdx.z, sp = T - 1 - sb, t = dir ? T - 1 - sp : sp;
+  STEP_TILE();
+  const GruDir d = st.dir ? d1 : d0;
+  const int dir = st.dir, sp = T - 1 - sb, t = dir ? T - 1 - sp : sp;
   const int tnext = dir ? t - 1 : t + 1, tprev = dir ? t + 1 : t - 1;
   STEP_IDS();
   const float* arow[1] = {d.dz + ((long)(sb > 0 ? tnext : t) * B + ar) * 3 * u};
@@ -321,10 +353,11 @@ __global__ __launch_bounds__(256) void gru_bwd_b_kernel(GruDir d0, GruDir d1, in
   }
 }
 
-__global__ __launch_bounds__(256) void gru_bwd_a_kernel(GruDir d0, GruDir d1, int sb, int T, int B, int u) {
+__global__ __launch_bounds__(256) void gru_bwd_a_kernel(GruDir d0, GruDir d1, int sb, int T, int B, int u, int SJ) {
   __shared__ float red[4][1][256];
-  const GruDir d = blockIdx.z ? d1 : d0;
-  const int dir = blockIdx.z, sp = T - 1 - sb, t = dir ? T - 1 - sp : sp;
+  STEP_TILE();
+  const GruDir d = st.dir ? d1 : d0;
+  const int dir = st.dir, sp = T - 1 - sb, t = dir ? T - 1 - sp : sp;
   const int tprev = dir ? t + 1 : t - 1;
   STEP_IDS();
   const float* arow[1] = {d.dz + ((long)t * B + ar) * 3 * u + 2 * u};
@@ -348,10 +381,11 @@ extern "C" int crnn_gru_fwd(const float* xw0, const float* xw1, const float* ut0
   if (ldh % 4 != 0) return CRNN_ERR_ARG;
   GruDir a{xw0, ut0, h0, ldh, g0, rh0, nullptr, 0, nullptr, nullptr, nullptr};
   GruDir b{xw1, ut1, h1, ldh, g1, rh1, nullptr, 0, nullptr, nullptr, nullptr};
-  dim3 grid(u / 16, cdiv(B, 16), 2);
+  const int SJ = step_sj(u / 16);
+  dim3 grid(step_grid(u / 16, cdiv(B, 16), SJ));
   for (int s = 0; s < T; ++s) {
-    hipLaunchKernelGGL(gru_fwd_zr_kernel, grid, dim3(256), 0, stream, a, b, s, T, B, u);
-    hipLaunchKernelGGL(gru_fwd_h_kernel, grid, dim3(256), 0, stream, a, b, s, T, B, u);
+    hipLaunchKernelGGL(gru_fwd_zr_kernel, grid, dim3(256), 0, stream, a, b, s, T, B, u, SJ);
+    hipLaunchKernelGGL(gru_fwd_h_kernel, grid, dim3(256), 0, stream, a, b, s, T, B, u, SJ);
   }
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
@@ -365,10 +399,11 @@ extern "C" int crnn_gru_bwd(const float* u0, const float* u1, const float* h0, c
   CRNN_TRY(check_units(u));
   GruDir a{nullptr, u0, const_cast<float*>(h0), ldh, const_cast<float*>(g0), nullptr, dout0, ldo, dz0, dh0, dhp0};
   GruDir b{nullptr, u1, const_cast<float*>(h1), ldh, const_cast<float*>(g1), nullptr, dout1, ldo, dz1, dh1, dhp1};
-  dim3 grid(u / 16, cdiv(B, 16), 2);
+  const int SJ = step_sj(u / 16) > 2 ? 2 : step_sj(u / 16);
+  dim3 grid(step_grid(u / 16, cdiv(B, 16), SJ));
   for (int sb = 0; sb < T; ++sb) {
-    hipLaunchKernelGGL(gru_bwd_b_kernel, grid, dim3(256), 0, stream, a, b, sb, T, B, u);
-    hipLaunchKernelGGL(gru_bwd_a_kernel, grid, dim3(256), 0, stream, a, b, sb, T, B, u);
+    hipLaunchKernelGGL(gru_bwd_b_kernel, grid, dim3(256), 0, stream, a, b, sb, T, B, u, SJ);
+    hipLaunchKernelGGL(gru_bwd_a_kernel, grid, dim3(256), 0, stream, a, b, sb, T, B, u, SJ);
   }
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;

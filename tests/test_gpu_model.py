@@ -295,5 +295,7 @@ def test_bf16_mfma_mode_tracks_the_fp32_oracle(precision):
         opt = Adam(lr=1e-3, beta_1=0.5, beta_2=0.999, clipnorm=5)
         curves[prec] = [float(e.train_step(xb, labb, ilb, llb, opt, it).mean().item()) for it in range(25)]
     print(f"[{precision}] loss curves fp32 vs {precision}:", [round(v, 2) for v in curves["fp32"][::6]], [round(v, 2) for v in curves[precision][::6]])
-    assert curves[precision][-1] < 0.75 * curves[precision][0]
-    assert abs(curves[precision][-1] - curves["fp32"][-1]) < 0.1 * curves["fp32"][-1]
+    # single steps at lr 1e-3 with dropout are bumpy (both modes): compare the level of the last steps, not one sample
+    tail = {k: float(np.mean(v[-6:])) for k, v in curves.items()}
+    assert tail[precision] < 0.75 * curves[precision][0]
+    assert abs(tail[precision] - tail["fp32"]) < 0.1 * tail["fp32"], (curves["fp32"][-6:], curves[precision][-6:])
