@@ -505,14 +505,18 @@ __device__ __forceinline__ double part_lane_sum(const float* __restrict__ base, 
 
 // out[i] = scale * sum_p partials[p][i], i < n  (double accumulation)
 __global__ __launch_bounds__(RED_CH * RED_PL) void partials_sum_kernel(const float* __restrict__ partials, int nparts, int n, float* __restrict__ out, float scale) {
+  // gridDim.y > 1: blockIdx.y reduces its own contiguous chunk of the partial rows into out[blockIdx.y][n]
   __shared__ double red[RED_PL][RED_CH];
+  const int chunk = (nparts + gridDim.y - 1) / gridDim.y;
+  const int p0 = blockIdx.y * chunk;
+  const int np = min(chunk, nparts - p0);
   int i = blockIdx.x * RED_CH + threadIdx.x;
-  red[threadIdx.y][threadIdx.x] = (i < n) ? part_lane_sum(partials + i, n, nparts, threadIdx.y) : 0.0;
+  red[threadIdx.y][threadIdx.x] = (i < n && np > 0) ? part_lane_sum(partials + (long)p0 * n + i, n, np, threadIdx.y) : 0.0;
   __syncthreads();
   if (threadIdx.y == 0 && i < n) {
     double s = 0.0;
     for (int r = 0; r < RED_PL; ++r) s += red[r][threadIdx.x];
-    out[i] = (float)(s * scale);
+    out[(long)blockIdx.y * n + i] = (float)(s * scale);
   }
 }
 
@@ -601,6 +605,16 @@ extern "C" int crnn_bn_finalize(const float* partials, int nparts, int C, long n
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, RED_CH)), dim3(RED_CH, RED_PL), 0, stream, partials, nparts, C, 1.0 / (double)n, gamma, beta, bnstate);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
+}
+// Same, for long partial lists (one row per GEMM tile): a first launch folds the rows into CRNN_BN_FOLD_ROWS chunk
+// sums (scratch: CRNN_BN_FOLD_ROWS * 2 * C floats) with hundreds of workgroups, the finalize then reads those.
+#define CRNN_BN_FOLD_ROWS 32
+extern "C" int crnn_bn_finalize_folded(const float* partials, int nparts, int C, long n, const float* gamma, const float* beta,
+                                       float* bnstate, float* scratch, hipStream_t stream) {
+  if (nparts <= 1024 || scratch == nullptr) return crnn_bn_finalize(partials, nparts, C, n, gamma, beta, bnstate, stream);
+  hipLaunchKernelGGL(partials_sum_kernel, dim3(cdiv(2 * C, RED_CH), CRNN_BN_FOLD_ROWS), dim3(RED_CH, RED_PL), 0, stream, partials, nparts, 2 * C, scratch, 1.f);
+  CRNN_LAUNCH_CHECK();
+  return crnn_bn_finalize(scratch, CRNN_BN_FOLD_ROWS, C, n, gamma, beta, bnstate, stream);
 }
 
 extern "C" int crnn_bn_infer_state(const float* mmean, const float* mvar, const float* gamma, const float* beta, int C,

@@ -31,7 +31,54 @@ struct GemmParams {
   int vecC;        // 16-byte stores legal for C (and the split scratch)
   int dtA, dtB, dtC;  // storage of the operands / result (CRNN_F32 | CRNN_BF16); the fp32 kernel requires all CRNN_F32
   int tilesN;
+  float* stats;    // optional [tilesM][2][N]: per-tile column sums / sums of squares of the result as stored (BatchNorm statistics)
 };
+
+// ---- statistics epilogue: per-tile column sums / sums of squares of the result as it will be stored, taken straight
+// from the MFMA accumulators (a lane owns one column of each 32x32 block: 16 rows x TM blocks per column block), then
+// combined across the two lane halves (shuffle) and the waves stacked along M (LDS), all in a fixed order.
+typedef float f32x16_stats __attribute__((ext_vector_type(16)));
+template <int TM, int TN>
+__device__ __forceinline__ void tile_stats_regs(const f32x16_stats (&acc)[TM][TN], int row_base, int M, int dtC, int half,
+                                                float (&ssum)[TN], float (&ssq)[TN]) {
+  const bool full = row_base + TM * 32 <= M;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v = acc[i][j][e];
+        if (dtC == CRNN_BF16) v = __uint_as_float(pack2_bf16(v, 0.f) << 16);   // the value the consumer reads back
+        if (!full && row_base + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half >= M) v = 0.f;
+        if (e & 1) { s1 += v; q1 = fmaf(v, v, q1); } else { s0 += v; q0 = fmaf(v, v, q0); }
+      }
+    float sv = s0 + s1, qv = q0 + q1;
+    sv += __shfl_xor(sv, 32, 64); qv += __shfl_xor(qv, 32, 64);
+    ssum[j] = sv; ssq[j] = qv;
+  }
+}
+// smem: [2][WAVES_M][BN]; lanes of half 0 deposit their wave's column sums, then one thread per (stat, column) adds the waves
+template <int BN, int TN, int WAVES_M>
+__device__ __forceinline__ void tile_stats_finish(float* smem, float* stats, int tm, int n0, int N, int tid, int wmi, int wn0,
+                                                  int half, int l31, const float (&ssum)[TN], const float (&ssq)[TN]) {
+  if (half == 0) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      smem[(0 * WAVES_M + wmi) * BN + wn0 + j * 32 + l31] = ssum[j];
+      smem[(1 * WAVES_M + wmi) * BN + wn0 + j * 32 + l31] = ssq[j];
+    }
+  }
+  __syncthreads();
+  if (tid < 2 * BN) {
+    const int v = tid / BN, c = tid % BN;
+    float a = 0.f;
+#pragma unroll
+    for (int q = 0; q < WAVES_M; ++q) a += smem[(v * WAVES_M + q) * BN + c];
+    if (n0 + c < N) stats[((long)tm * 2 + v) * N + n0 + c] = a;
+  }
+}
 
 template <bool KM, int ROWS>
 __device__ __forceinline__ void load_tile(const float* __restrict__ X, int ld, int row0, int nrows_total,
@@ -170,6 +217,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   constexpr int CLD = BN + 4;                      // padded row stride of the staged C half-tile
   constexpr int ROWS_PER_IT = 256 / (BN / 4);      // rows covered by the 256 threads per store iteration
   const bool vecC = p.vecC && !((ldc & 3) | (n0 & 3));
+  float st_sum[TN], st_sq[TN];
+  if (p.stats) tile_stats_regs<TM, TN>(acc, m0 + wm0, p.M, CRNN_F32, half, st_sum, st_sq);
 #pragma unroll
   for (int hp = 0; hp < 2; ++hp) {
     if (wm0 >= 64 * hp && wm0 < 64 * hp + 64) {
@@ -213,6 +262,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     }
     __syncthreads();
   }
+  if (p.stats) tile_stats_finish<BN, TN, 4 / WAVES_N>(smem, p.stats, tm, n0, p.N, tid, wave / WAVES_N, wn0, half, l31, st_sum, st_sq);
 }
 
 // second stage of a split reduction: C = act(sum_z part[z] + bias) (+ C).  blockDim (32,8): 32 consecutive
@@ -250,12 +300,14 @@ static inline int aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; 
 
 // mode: 0 = NN, 1 = NT, 2 = TN.  `scratch` (scratch_bytes) is needed only when the reduction is split
 // (mode 2 with few output tiles); pass nullptr/0 to forbid splitting.
-extern "C" int crnn_gemm_f32(int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
-                             int ldc, const float* bias, int act, int accumulate, int permP, float* scratch,
-                             size_t scratch_bytes, hipStream_t stream) {
+static int gemm_f32_impl(int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
+                         int ldc, const float* bias, int act, int accumulate, int permP, float* scratch,
+                         size_t scratch_bytes, float* stats, hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0) return CRNN_ERR_ARG;
   if (permP && (M % permP) != 0) return CRNN_ERR_ARG;
+  if (stats && (bias || act || accumulate || permP || scratch)) return CRNN_ERR_ARG;   // statistics of the plain product only
   GemmParams p;
+  p.stats = stats;
   p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.bias = bias; p.act = act; p.accumulate = accumulate; p.permP = permP;
   p.dtA = p.dtB = p.dtC = CRNN_F32;
@@ -301,4 +353,21 @@ extern "C" int crnn_gemm_f32(int mode, const float* A, const float* B, float* C,
   return CRNN_OK;
 }
 
+extern "C" int crnn_gemm_f32(int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
+                             int ldc, const float* bias, int act, int accumulate, int permP, float* scratch,
+                             size_t scratch_bytes, hipStream_t stream) {
+  return gemm_f32_impl(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, accumulate, permP, scratch, scratch_bytes, nullptr, stream);
+}
+
 #include "gemm_bf16.inc"
+
+// ---- pointwise 1x1 convolution = GEMM over the pixels, with the next BatchNorm's statistics from the epilogue
+extern "C" int crnn_pwconv_stat_rows(long M) { return cdiv(M, 128); }
+extern "C" int crnn_pwconv_fwd(const void* a, const void* w, void* q, long M, int N, int K, float* stat_partials,
+                               int bf16_products, int dt_a, int dt_w, int dt_q, hipStream_t stream) {
+  if (M <= 0 || M > 0x7fffffffL) return CRNN_ERR_ARG;
+  if (bf16_products)
+    return gemm_bf16_impl(0, a, w, q, (int)M, N, K, K, N, N, nullptr, 0, 0, 0, nullptr, 0, dt_a, dt_w, dt_q, stat_partials, stream);
+  if (dt_a != CRNN_F32 || dt_w != CRNN_F32 || dt_q != CRNN_F32) return CRNN_ERR_ARG;
+  return gemm_f32_impl(0, (const float*)a, (const float*)w, (float*)q, (int)M, N, K, K, N, N, nullptr, 0, 0, 0, nullptr, 0, stat_partials, stream);
+}

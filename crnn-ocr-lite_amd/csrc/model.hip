@@ -128,6 +128,7 @@ Plan make_plan(const crnn_config* c) {
     long tiles = crnn_dwconv_num_tiles(d.B, d.bh[i], d.bw[i]);
     maxparts = lmax(maxparts, tiles * 9L * ci);
     maxparts = lmax(maxparts, (long)crnn_colreduce_chunks(M) * 2L * lmax(ci, co));
+    maxparts = lmax(maxparts, (long)crnn_pwconv_stat_rows(M) * 2L * co);
     maxparts = lmax(maxparts, (long)crnn_bn_bwd_chunks(M) * 2L * lmax(ci, co));
   }
   const long TB = (long)d.T * B;
@@ -156,6 +157,7 @@ Plan make_plan(const crnn_config* c) {
   P.add("partials", maxparts);
   P.add("pbf", make_layout(c).total, CRNN_BF16);   // bf16 shadow of the parameter buffer (GEMM B operands in the bf16 modes)
   P.add("coef", 2 * 1024);
+  P.add("fold", 32 * 2 * 1024);   // chunk sums of long BatchNorm partial lists (crnn_bn_finalize_folded)
   P.add("gemm_scratch", 32L * 1024 * 1024);  // 128 MiB of split-reduction partials
   return P;
 }
@@ -323,7 +325,7 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
     const int dtd = c.dt("d" + p), dtq = c.dt("q" + p);
     if (ci % 32 == 0) {
       CRNN_TRY(crnn_dwconv3x3_fwd_ex(in, c.p(bp + "_dw"), dd, train ? parts : nullptr, B, H, W, ci, 0, dtd, stream));
-      if (train) CRNN_TRY(crnn_bn_finalize(parts, crnn_dwconv_num_tiles(B, H, W), ci, M, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), s1, stream));
+      if (train) CRNN_TRY(crnn_bn_finalize_folded(parts, crnn_dwconv_num_tiles(B, H, W), ci, M, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), s1, c.w("fold"), stream));
     } else {
       CRNN_TRY(crnn_dwconv3x3_fwd_ex(in, c.p(bp + "_dw"), dd, nullptr, B, H, W, ci, 0, dtd, stream));
       if (train) {
@@ -334,10 +336,13 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
     if (!train) CRNN_TRY(crnn_bn_infer_state(bn_mean + bn_off, bn_var + bn_off, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), ci, s1, stream));
     bn_off += ci;
     CRNN_TRY(crnn_bn_act_pool_drop_ex(dd, s1, aa, 1, 1, (int)M, ci, 1, 1, 0.f, 0, 0, dtd, dtd, stream));
-    CRNN_TRY(gemm_t(c, 0, aa, dtd, c.p(bp + "_pw"), CRNN_F32, qq, dtq, (int)M, co, ci, ci, co, co));
+    {  // pointwise conv; in training its epilogue also produces the batch statistics of the BatchNorm that follows
+      int dtw = CRNN_F32;
+      const float* wq = weight_operand(c, 0, c.p(bp + "_pw"), &dtw);
+      CRNN_TRY(crnn_pwconv_fwd(aa, wq, qq, M, co, ci, train ? parts : nullptr, cfg->mfma_bf16 ? 1 : 0, dtd, dtw, dtq, stream));
+    }
     if (train) {
-      CRNN_TRY(crnn_colreduce_ex(qq, parts, M, co, co, 2, dtq, stream));
-      CRNN_TRY(crnn_bn_finalize(parts, crnn_colreduce_chunks(M), co, M, c.p(bp + "_bn2_g"), c.p(bp + "_bn2_b"), s2, stream));
+      CRNN_TRY(crnn_bn_finalize_folded(parts, crnn_pwconv_stat_rows(M), co, M, c.p(bp + "_bn2_g"), c.p(bp + "_bn2_b"), s2, c.w("fold"), stream));
     } else {
       CRNN_TRY(crnn_bn_infer_state(bn_mean + bn_off, bn_var + bn_off, c.p(bp + "_bn2_g"), c.p(bp + "_bn2_b"), co, s2, stream));
     }

@@ -106,6 +106,14 @@ int crnn_gemm_bf16(int mode, const float* A, const float* B, float* C, int M, in
 int crnn_gemm_bf16_ex(int mode, const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                       const float* bias, int act, int accumulate, int permP, float* scratch, size_t scratch_bytes, int dtA,
                       int dtB, int dtC, crnn_stream_t stream);
+/* Pointwise 1x1 convolution (reference utils.py:49, Conv2D(1x1, no bias)) as one GEMM over the pixels:
+ * q[M][N] = a[M][K] * w[K][N].  stat_partials (may be NULL) receives [crnn_pwconv_stat_rows(M)][2][N] per-tile column
+ * sums / sums of squares of q AS STORED (i.e. after rounding to dt_q): the batch statistics of the BatchNorm that
+ * follows (utils.py:50), produced by the GEMM epilogue instead of a separate pass over q.  Deterministic.
+ * bf16_products: 0 = fp32 MFMA (all dt_* must be 0), 1 = bf16 MFMA products with fp32 accumulation. */
+int crnn_pwconv_stat_rows(long M);
+int crnn_pwconv_fwd(const void* a, const void* w, void* q, long M, int N, int K, float* stat_partials, int bf16_products,
+                    int dt_a, int dt_w, int dt_q, crnn_stream_t stream);
 int crnn_dwconv3x3_fwd_ex(const void* x, const float* k, void* out, float* stat_partials, int B, int H, int W, int C, int flip,
                           int dtype, crnn_stream_t stream);
 int crnn_dwconv3x3_wgrad_ex(const void* x, const void* g, float* dk, float* scratch, int B, int H, int W, int C, int dtype,
@@ -129,6 +137,10 @@ int crnn_partials_sum(const float* partials, int nparts, int n, float* out, floa
 /* BatchNormalization(axis=-1, eps 1e-3) (utils.py:45,48): bnstate = [mean|var|scale|shift] */
 int crnn_bn_finalize(const float* partials, int nparts, int C, long n, const float* gamma, const float* beta,
                      float* bnstate, crnn_stream_t stream);
+/* same result for long partial lists (e.g. one row per GEMM tile): folds the rows into 32 chunk sums first;
+ * scratch: 32 * 2 * C floats (NULL or nparts <= 1024: plain crnn_bn_finalize) */
+int crnn_bn_finalize_folded(const float* partials, int nparts, int C, long n, const float* gamma, const float* beta,
+                            float* bnstate, float* scratch, crnn_stream_t stream);
 int crnn_bn_infer_state(const float* mmean, const float* mvar, const float* gamma, const float* beta, int C,
                         float* bnstate, crnn_stream_t stream);
 int crnn_bn_act(const float* x, const float* bnstate, float* y, long M, int C, crnn_stream_t stream);

@@ -492,3 +492,41 @@ def test_gemm_bf16_storage_operands_and_result(mode):
     C0 = _bf16_round(rs.normal(size=(Mm, N))); Cacc = _to_bf16_dev(C0)
     ok(L().crnn_gemm_bf16_ex(mode, P(A32), P(Bd), P(Cacc), Mm, N, K, lda, ldb, N, None, 0, 1, 0, P(scr), 64 * 1024 * 1024, 0, 1, 1, S()))
     assert_close(_f(Cacc), ref + C0, rtol=2.0 ** -7, atol=1e-2, what="accumulate into bf16")
+
+
+@pytest.mark.parametrize("case", ["fp32", "bf16", "bf16s"])
+def test_pwconv_fwd_with_statistics_epilogue(case):
+    """crnn_pwconv_fwd: q = a @ w plus the per-tile (sum, sum of squares) of q as stored (utils.py:49-50)."""
+    rs = np.random.RandomState(77)
+    Mm, N, K = 128 * 5 + 37, 192, 64          # ragged last row tile, two column tiles of 128 (second one half empty)
+    A = rs.normal(size=(Mm, K)); W = rs.normal(size=(K, N)) * 0.2
+    rows = L().crnn_pwconv_stat_rows(Mm)
+    assert rows == 6
+    parts = zeros(rows, 2, N)
+    if case == "fp32":
+        Ad, Wd, Q = dev(A), dev(W), zeros(Mm, N)
+        ok(L().crnn_pwconv_fwd(P(Ad), P(Wd), P(Q), Mm, N, K, P(parts), 0, 0, 0, 0, S()))
+        q = host(Q); ref = A.astype(np.float32).astype(np.float64) @ W.astype(np.float32).astype(np.float64)
+        assert_close(q, ref, rtol=1e-5, atol=1e-5, what="pwconv fp32")
+    else:
+        A = _bf16_round(A); W = _bf16_round(W)
+        ref = A @ W
+        Wd = _to_bf16_dev(W)
+        if case == "bf16":
+            Ad, Q = dev(A), zeros(Mm, N)
+            ok(L().crnn_pwconv_fwd(P(Ad), P(Wd), P(Q), Mm, N, K, P(parts), 1, 0, 1, 0, S()))
+            q = host(Q)
+            assert_close(q, ref, rtol=2e-5, atol=1e-4, what="pwconv bf16 products")
+        else:
+            Ad = _to_bf16_dev(A); Q = torch.zeros(Mm, N, dtype=torch.bfloat16, device="cuda")
+            ok(L().crnn_pwconv_fwd(P(Ad), P(Wd), P(Q), Mm, N, K, P(parts), 1, 1, 1, 1, S()))
+            q = _f(Q)
+            assert_close(q, ref, rtol=2.0 ** -8, atol=1e-3, what="pwconv bf16 storage")
+    pr = host(parts).astype(np.float64)
+    q64 = q.astype(np.float64)
+    # the statistics are those of the STORED values, tile by tile (128 rows each)
+    for t in range(rows):
+        blk = q64[128 * t: 128 * (t + 1)]
+        assert_close(pr[t, 0], blk.sum(0), rtol=1e-5, atol=1e-3, what="tile %d sum" % t)
+        assert_close(pr[t, 1], (blk * blk).sum(0), rtol=1e-5, atol=1e-3, what="tile %d sumsq" % t)
+    # statistics are refused together with bias / accumulate-style epilogues? (plain product only) -> covered by the ABI contract
