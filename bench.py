@@ -61,15 +61,16 @@ def depthwise_roofline(eng, iters=5):
             times.append(e0.elapsed_time(e1) * 1e-3)
     t = float(np.median(times))
     ach = nbytes / t / 1e9
-    # HBM bytes of the same launch set from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected by
-    # scripts/gpu_pmc.sh at batch 256 and committed under profiles/; FETCH_SIZE x2 per the gfx950 note in the guide)
+    # HBM bytes of the same launch set from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE as separate
+    # counter-only runs over scripts/dw_bench.py at batch 256 -- scripts/gpu_round.sh -- folded by scripts/pmc_summary.py
+    # and committed under profiles/; FETCH_SIZE x2 per the gfx950 note in MI355X_MICROARCH.md)
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_dwconv.json")))
-        if B == pmc["batch"] and (eng.cfg.imgh, eng.cfg.imgw) == (100, 32) and esz == 4:
-            sh = pmc["shapes"]
+        if B == pmc["batch"] and (eng.cfg.imgh, eng.cfg.imgw) == (100, 32):
+            sh = pmc["modes"]["bf16" if esz == 2 else "fp32"]["shapes"]
             traffic = 2 * sh["104x36x64"]["hbm_bytes_per_launch"] + 2 * sh["104x36x128"]["hbm_bytes_per_launch"] \
-                + 8 * sh["52x18x256|52x9x512"]["hbm_bytes_per_launch"]
+                + 4 * sh["52x18x256"]["hbm_bytes_per_launch"] + 4 * sh["52x9x512"]["hbm_bytes_per_launch"]
     except Exception:
         pass
     return {"bound": "hbm", "kernel": "dwconv_tile_kernel<0> (depthwise 3x3 fwd + data-gradient, blocks 2-7, LDS halo tiles)",
