@@ -321,9 +321,11 @@ static int gemm_f32_impl(int mode, const float* A, const float* B, float* C, int
   p.tilesN = tilesN;
   int tiles = tilesM * tilesN;
   int nsplit = 1;
-  if (scratch && tiles < 256 && K >= 2048) {
-    nsplit = cdiv(1024, tiles);
-    int maxs = K / 512; if (maxs < 1) maxs = 1;
+  static int split_target = -1;   // CRNN_SPLIT_WGS: workgroups a split reduction aims for
+  if (split_target < 0) { const char* e = getenv("CRNN_SPLIT_WGS"); split_target = e ? atoi(e) : 768; }   // 3 resident workgroups per CU
+  if (scratch && ((tiles < 256 && K >= 2048) || (tiles <= 16 && K >= 512))) {
+    nsplit = cdiv(split_target, tiles);
+    int maxs = K / (K >= 2048 ? 512 : 128); if (maxs < 1) maxs = 1;
     if (nsplit > maxs) nsplit = maxs;
     size_t per = (size_t)M * N * sizeof(float);
     size_t fit = scratch_bytes / per;
