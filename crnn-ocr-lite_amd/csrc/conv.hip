@@ -857,19 +857,23 @@ __global__ __launch_bounds__(256) void bn_bwd_pool_kernel(BnBwdArgsT<T> a, float
 #pragma unroll
       for (int e = 0; e < VEC; ++e) { inv.v[e] = 1.0f / sqrtf(var.v[e] + BN_EPS); c1.v[e] = 0.f; c2.v[e] = 0.f; }
       if (PASS == 2) { c1 = vload<VEC>(coef + c0); c2 = vload<VEC>(coef + a.C + c0); }
-      for (long r = r0 + rt; r < r1; r += RT) {
+      // one pool window per step; pass 1 (reduce only) keeps two windows' loads in flight
+      auto load_window = [&](long r, VecF<VEC>& gv, VecF<VEC> (&xw)[4], long& xbase) {
         int wo = (int)(r % Wo); long rr = r / Wo; int ho = (int)(rr % Ho); long b = rr / Ho;
+        gv = vload<VEC>(&a.g[r * a.C + c0]);
+        xbase = (((long)b * a.H + ho * a.ph) * a.W + wo * a.pw) * a.C + c0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < nwin) { int ii = k / a.pw, j = k - ii * a.pw; xw[k] = vload<VEC>(&a.x[xbase + ((long)ii * a.W + j) * a.C]); }
+      };
+      auto do_window = [&](long r, const VecF<VEC>& gv, const VecF<VEC> (&xw)[4], long xbase) {
         const long oidx = r * a.C + c0;
-        VecF<VEC> gv = vload<VEC>(&a.g[oidx]);
-        VecF<VEC> xw[4];
         float best[VEC]; int arg[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { best[e] = -1.f; arg[e] = 0; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           if (k < nwin) {
-            int ii = k / a.pw, j = k - ii * a.pw;
-            xw[k] = vload<VEC>(&a.x[(((long)b * a.H + ho * a.ph + ii) * a.W + wo * a.pw + j) * a.C + c0]);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
               float y = relu6f(fmaf(xw[k].v[e], sc.v[e], sh.v[e]));
@@ -897,10 +901,25 @@ __global__ __launch_bounds__(256) void bn_bwd_pool_kernel(BnBwdArgsT<T> a, float
             }
             if (PASS == 2) {
               int ii = k / a.pw, j = k - ii * a.pw;
-              vstore<VEC>(&dx[(((long)b * a.H + ho * a.ph + ii) * a.W + wo * a.pw + j) * a.C + c0], o);
+              vstore<VEC>(&dx[xbase + ((long)ii * a.W + j) * a.C], o);
             }
           }
         }
+      };
+      long r = r0 + rt;
+      if (PASS == 1) {
+        for (; r + RT < r1; r += 2L * RT) {
+          VecF<VEC> ga, gb, xa[4], xb[4]; long ba, bb;
+          load_window(r, ga, xa, ba);
+          load_window(r + RT, gb, xb, bb);
+          do_window(r, ga, xa, ba);
+          do_window(r + RT, gb, xb, bb);
+        }
+      }
+      for (; r < r1; r += RT) {
+        VecF<VEC> gv, xw[4]; long xbase;
+        load_window(r, gv, xw, xbase);
+        do_window(r, gv, xw, xbase);
       }
     }
     if (PASS == 1) {

@@ -265,20 +265,31 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   if (p.stats) tile_stats_finish<BN, TN, 4 / WAVES_N>(smem, p.stats, tm, n0, p.N, tid, wave / WAVES_N, wn0, half, l31, st_sum, st_sq);
 }
 
-// second stage of a split reduction: C = act(sum_z part[z] + bias) (+ C).  blockDim (32,8): 32 consecutive
-// outputs x 8 split-lanes, fixed summation order (deterministic).
-__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, int nsplit, GemmParams p) {
-  __shared__ float red[8][32];
+// second stage of a split reduction: C = act(sum_z part[z] + bias) (+ C); fixed summation order (deterministic).
+template <int LY>
+__global__ __launch_bounds__(32 * LY) void gemm_splitk_reduce_kernel(const float* __restrict__ part, int nsplit, GemmParams p) {
+  // blockDim (32, LY): 32 consecutive outputs x LY split-lanes (8 for short split lists, 32 for long ones), four
+  // independent loads in flight per lane
+  __shared__ float red[LY][33];
   const long total = (long)p.M * p.N;
   const long i = (long)blockIdx.x * 32 + threadIdx.x;
   float s = 0.f;
-  if (i < total)
-    for (int z = threadIdx.y; z < nsplit; z += 8) s += part[(long)z * total + i];
+  if (i < total) {
+    int z = threadIdx.y;
+    for (; z + 3 * LY < nsplit; z += 4 * LY) {
+      float v0 = part[(long)z * total + i], v1 = part[(long)(z + LY) * total + i];
+      float v2 = part[(long)(z + 2 * LY) * total + i], v3 = part[(long)(z + 3 * LY) * total + i];
+      s += (v0 + v1) + (v2 + v3);
+    }
+    for (; z < nsplit; z += LY) s += part[(long)z * total + i];
+  }
   red[threadIdx.y][threadIdx.x] = s;
   __syncthreads();
   if (threadIdx.y == 0 && i < total) {
-    s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) +
-        ((red[4][threadIdx.x] + red[5][threadIdx.x]) + (red[6][threadIdx.x] + red[7][threadIdx.x]));
+    s = 0.f;
+#pragma unroll
+    for (int r = 0; r < LY; r += 4)
+      s += (red[r][threadIdx.x] + red[r + 1][threadIdx.x]) + (red[r + 2][threadIdx.x] + red[r + 3][threadIdx.x]);
     int m = (int)(i / p.N), n = (int)(i % p.N);
     if (p.bias) s += p.bias[n];
     if (p.act == 1) s = fmaxf(s, 0.f);
@@ -349,7 +360,8 @@ static int gemm_f32_impl(int mode, const float* A, const float* B, float* C, int
   CRNN_LAUNCH_CHECK();
   if (nsplit > 1) {
     long total = (long)M * N;
-    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(cdiv(total, 32)), dim3(32, 8), 0, stream, scratch, nsplit, p);
+    if (nsplit > 32) hipLaunchKernelGGL(gemm_splitk_reduce_kernel<32>, dim3(cdiv(total, 32)), dim3(32, 32), 0, stream, scratch, nsplit, p);
+    else hipLaunchKernelGGL(gemm_splitk_reduce_kernel<8>, dim3(cdiv(total, 32)), dim3(32, 8), 0, stream, scratch, nsplit, p);
     CRNN_LAUNCH_CHECK();
   }
   return CRNN_OK;
