@@ -137,6 +137,22 @@ class Engine:
                                      _ptr(self._ll), _ptr(self.ws), self.ws_bytes, _ptr(self.loss), int(seed), _stream()), "backward")
         return self.loss
 
+    def backward_top(self, labels, input_length, label_length, seed=0):
+        """First backward stage: CTC, dense2, recurrent layers, dense1 -> grads[grad_split:] are final."""
+        self._lab = self._as_i32(labels); self._il = self._as_i32(input_length); self._ll = self._as_i32(label_length)
+        check(self.lib.crnn_backward_top(self._c, _ptr(self.params), _ptr(self.grads), _ptr(self._lab), _ptr(self._il), _ptr(self._ll),
+                                         _ptr(self.ws), self.ws_bytes, _ptr(self.loss), int(seed), _stream()), "backward_top")
+        return self.loss
+
+    def backward_bottom(self, seed=0):
+        """Second backward stage: conv stack + spatial transformer -> grads[:grad_split]."""
+        check(self.lib.crnn_backward_bottom(self._c, _ptr(self.params), _ptr(self.grads), _ptr(self._x), _ptr(self.ws), self.ws_bytes,
+                                            int(seed), _stream()), "backward_bottom")
+
+    @property
+    def grad_split(self):
+        return int(self.lib.crnn_grad_split_offset(self._c))
+
     def bn_update(self):
         check(self.lib.crnn_bn_update(self._c, _ptr(self.bn_mean), _ptr(self.bn_var), _ptr(self.ws), self.ws_bytes, _stream()), "bn_update")
 
@@ -169,9 +185,18 @@ class Engine:
         """forward(train) -> CTC -> backward -> [all-reduce] -> clip -> optimizer -> BN moving stats."""
         seed = iteration if seed is None else seed
         self.forward(x, train=True, seed=seed)
-        loss = self.backward(labels, input_length, label_length, seed=seed)
-        if allreduce is not None:
-            allreduce(self.grads)
+        if allreduce is not None and getattr(allreduce, "overlap", False):
+            # the upper layers' gradients (tail of the flat buffer) are exchanged while the conv stack is still in backward
+            loss = self.backward_top(labels, input_length, label_length, seed=seed)
+            split = self.grad_split
+            allreduce.start(self.grads[split:])
+            self.backward_bottom(seed=seed)
+            allreduce.start(self.grads[:split])
+            allreduce.finish(self.grads)
+        else:
+            loss = self.backward(labels, input_length, label_length, seed=seed)
+            if allreduce is not None:
+                allreduce(self.grads)
         opt.apply(self, iteration)
         self.bn_update()
         return loss

@@ -23,10 +23,16 @@ def allreduce_mean_(flat, dist, world, scale_fn=None):
 
 
 class GradAllReduce:
-    """Callable handed to Engine.train_step: averages engine.grads across ranks after backward."""
+    """Handed to Engine.train_step: averages engine.grads across ranks.
 
-    def __init__(self, engine, dist, world):
-        self.engine, self.dist, self.world = engine, dist, world
+    overlap=True (default): two asynchronous all-reduces -- `start(view)` is called once the upper layers' gradients
+    are final (the collective then runs on RCCL's stream concurrently with the conv-stack backward that the engine
+    keeps launching on the compute stream) and once more for the rest; `finish` joins both and applies 1/world.
+    overlap=False: one blocking all-reduce of the whole buffer after backward (`__call__`)."""
+
+    def __init__(self, engine, dist, world, overlap=True):
+        self.engine, self.dist, self.world, self.overlap = engine, dist, world, overlap
+        self._pending = []
 
     def _scale(self, t, s):
         from .native import check
@@ -35,6 +41,20 @@ class GradAllReduce:
 
     def __call__(self, grads):
         allreduce_mean_(grads, self.dist, self.world, self._scale if grads.is_cuda else None)
+
+    def start(self, view):
+        if self.world > 1 and view.numel():
+            self._pending.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self, grads):
+        for w in self._pending:
+            w.wait()            # the compute stream waits for the collective; the host does not block
+        self._pending = []
+        if self.world > 1:
+            if grads.is_cuda:
+                self._scale(grads, 1.0 / self.world)
+            else:
+                grads.mul_(1.0 / self.world)
 
 
 def sync_bn_stats(engine, dist, world):

@@ -422,12 +422,42 @@ static int lstm_layer_bwd(const Ctx& c, int layer, const float* xin, int ldx, in
   return CRNN_OK;
 }
 
+// The backward runs in two stages so that a data-parallel host can start the gradient all-reduce of the upper
+// layers (dense1, the recurrent layers, dense2: the tail of the flat buffer, ~77 % of its bytes) while the
+// conv-stack / STN stage is still running.
+namespace {
+int backward_top(const Ctx& c, const int* labels, const int* input_length, const int* label_length, float* loss, uint64_t seed);
+int backward_bottom(const Ctx& c, const float* x, uint64_t seed);
+}
+extern "C" long crnn_grad_split_offset(const crnn_config* cfg) { return make_layout(cfg).off("dense1_w"); }
+extern "C" int crnn_backward_top(const crnn_config* cfg, const float* params, float* grads, const int* labels,
+                                 const int* input_length, const int* label_length, float* ws, size_t ws_bytes, float* loss,
+                                 uint64_t seed, hipStream_t stream) {
+  CRNN_TRY(check_cfg(cfg));
+  Ctx c{cfg, make_dims(cfg), make_layout(cfg), make_plan(cfg), params, grads, ws, stream};
+  if (ws_bytes < (size_t)c.P.total * sizeof(float)) return CRNN_ERR_ARG;
+  return backward_top(c, labels, input_length, label_length, loss, seed);
+}
+extern "C" int crnn_backward_bottom(const crnn_config* cfg, const float* params, float* grads, const float* x, float* ws,
+                                    size_t ws_bytes, uint64_t seed, hipStream_t stream) {
+  CRNN_TRY(check_cfg(cfg));
+  Ctx c{cfg, make_dims(cfg), make_layout(cfg), make_plan(cfg), params, grads, ws, stream};
+  if (ws_bytes < (size_t)c.P.total * sizeof(float)) return CRNN_ERR_ARG;
+  return backward_bottom(c, x, seed);
+}
 extern "C" int crnn_backward(const crnn_config* cfg, const float* params, float* grads, const float* x, const int* labels,
                              const int* input_length, const int* label_length, float* ws, size_t ws_bytes, float* loss,
                              uint64_t seed, hipStream_t stream) {
   CRNN_TRY(check_cfg(cfg));
   Ctx c{cfg, make_dims(cfg), make_layout(cfg), make_plan(cfg), params, grads, ws, stream};
   if (ws_bytes < (size_t)c.P.total * sizeof(float)) return CRNN_ERR_ARG;
+  CRNN_TRY(backward_top(c, labels, input_length, label_length, loss, seed));
+  return backward_bottom(c, x, seed);
+}
+
+namespace {
+int backward_top(const Ctx& c, const int* labels, const int* input_length, const int* label_length, float* loss, uint64_t seed) {
+  const crnn_config* cfg = c.cfg; float* grads = c.grads; hipStream_t stream = c.s;
   const Dims& d = c.d;
   const int B = d.B, T = d.T, TB = T * B, u = d.u;
   hipError_t e = hipMemsetAsync(grads, 0, (size_t)c.L.total * sizeof(float), stream);
@@ -450,6 +480,14 @@ extern "C" int crnn_backward(const crnn_config* cfg, const float* params, float*
   CRNN_TRY(colsum(c, c.w("gbm"), TB, d.tds, d.tds, c.g("dense1_b")));
   float* gA = c.w("gA"); float* gB = c.w("gB");
   CRNN_TRY(gemm_t(c, 1, c.w("gbm"), CRNN_F32, c.p("dense1_w"), CRNN_F32, gA, c.gdt(), TB, d.feat, d.tds, d.tds, d.tds, d.feat));
+  return CRNN_OK;
+}
+
+int backward_bottom(const Ctx& c, const float* x, uint64_t seed) {
+  const crnn_config* cfg = c.cfg; hipStream_t stream = c.s;
+  const Dims& d = c.d;
+  const int B = d.B;
+  float* gA = c.w("gA"); float* gB = c.w("gB");   // gA holds d loss / d x7 (written by backward_top)
   // ---- conv stack
   for (int i = 7; i >= 1; --i) {
     std::string p = std::to_string(i), bp = "b" + p;
@@ -487,6 +525,7 @@ extern "C" int crnn_backward(const crnn_config* cfg, const float* params, float*
   }
   return CRNN_OK;
 }
+}  // namespace
 
 // ---------------------------------------------------------------------------------------------------
 // BatchNorm moving statistics (momentum .99): m <- .99 m + .01 mean ;

@@ -68,6 +68,15 @@ int crnn_forward(const crnn_config* cfg, const float* params, const float* bn_me
 int crnn_backward(const crnn_config* cfg, const float* params, float* grads, const float* x, const int* labels,
                   const int* input_length, const int* label_length, float* ws, size_t ws_bytes, float* loss,
                   uint64_t seed, crnn_stream_t stream);
+/* The same backward in two stages, for data-parallel hosts that overlap the gradient exchange with compute:
+ * crnn_backward_top = CTC, dense2, recurrent layers, dense1 (zeroes grads first; fills grads[crnn_grad_split_offset..]),
+ * crnn_backward_bottom = conv stack + spatial transformer (fills grads[0..crnn_grad_split_offset)).  Calling top then
+ * bottom on one stream == crnn_backward. */
+long crnn_grad_split_offset(const crnn_config* cfg);
+int crnn_backward_top(const crnn_config* cfg, const float* params, float* grads, const int* labels, const int* input_length,
+                      const int* label_length, float* ws, size_t ws_bytes, float* loss, uint64_t seed, crnn_stream_t stream);
+int crnn_backward_bottom(const crnn_config* cfg, const float* params, float* grads, const float* x, float* ws, size_t ws_bytes,
+                         uint64_t seed, crnn_stream_t stream);
 /* BatchNorm moving-average update from the batch statistics left in ws by a train=1 forward (momentum .99) */
 int crnn_bn_update(const crnn_config* cfg, float* bn_mean, float* bn_var, float* ws, size_t ws_bytes,
                    crnn_stream_t stream);

@@ -302,3 +302,28 @@ def test_bf16_mfma_mode_tracks_the_fp32_oracle(precision):
     tail = {k: float(np.mean(v[-6:])) for k, v in curves.items()}
     assert tail[precision] < 0.8 * curves[precision][0]
     assert abs(tail[precision] - tail["fp32"]) < 0.1 * tail["fp32"], (curves["fp32"][-6:], curves[precision][-6:])
+
+
+def test_two_stage_backward_equals_single_call():
+    """crnn_backward_top + crnn_backward_bottom (the form a data-parallel host overlaps with the all-reduce) must give
+    the very same gradient buffer and loss as crnn_backward."""
+    cfg = M.Config()
+    B = 4
+    p, bn = M.init_params(cfg, seed=3, dtype=np.float32)
+    p = M.randomize_params(cfg, p)
+    x, lab, il, ll = M.synthetic_batch(cfg, B, seed=5)
+    for precision in ("fp32", "bf16s"):
+        eng = Engine(B, dropout=True, precision=precision)
+        eng.set_params(p, bn)
+        eng.forward(x, train=True, seed=11)
+        loss1 = eng.backward(lab, il, ll, seed=11).clone(); g1 = eng.grads.clone()
+        eng.grads.fill_(float("nan"))
+        eng.forward(x, train=True, seed=11)
+        loss2 = eng.backward_top(lab, il, ll, seed=11).clone()
+        split = eng.grad_split
+        top_done = eng.grads[split:].clone()
+        eng.backward_bottom(seed=11)
+        assert 0 < split < eng.grads.numel()
+        assert torch.equal(loss1, loss2)
+        assert torch.equal(eng.grads, g1), precision
+        assert torch.equal(top_done, g1[split:]), "upper-layer gradients must be final after the first stage"

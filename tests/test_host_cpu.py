@@ -175,7 +175,14 @@ def _dp_worker(rank, world, port, q):
     # per-replica BatchNorm statistics (no SyncBN): each rank differentiates its own shard
     _, _, g, _ = M.loss_and_grads(cfg, p, bn, x[lo:hi], lab[lo:hi], il[lo:hi], ll[lo:hi])
     flat = torch.from_numpy(np.concatenate([g[k].ravel() for k in p]))
+    staged = flat.clone()
     allreduce_mean_(flat, dist, world)
+    # the overlapped form used by Engine.train_step: tail of the buffer first (asynchronously), then the head, then join
+    from crnn_mi355x.parallel import GradAllReduce
+    ar = GradAllReduce(None, dist, world, overlap=True)
+    split = staged.numel() // 3
+    ar.start(staged[split:]); ar.start(staged[:split]); ar.finish(staged)
+    assert torch.equal(staged, flat), "two-stage all-reduce differs from the single one"
     q.put((rank, flat.numpy().copy(), (lo, hi)))
     dist.barrier()
     dist.destroy_process_group()
