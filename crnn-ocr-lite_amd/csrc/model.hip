@@ -423,7 +423,7 @@ static int lstm_layer_bwd(const Ctx& c, int layer, const float* xin, int ldx, in
 }
 
 // The backward runs in two stages so that a data-parallel host can start the gradient all-reduce of the upper
-// layers (dense1, the recurrent layers, dense2: the tail of the flat buffer, ~77 % of its bytes) while the
+// layers (dense1, the recurrent layers, dense2: the tail of the flat buffer, 75 % of its bytes) while the
 // conv-stack / STN stage is still running.
 namespace {
 int backward_top(const Ctx& c, const int* labels, const int* input_length, const int* label_length, float* loss, uint64_t seed);
