@@ -335,11 +335,52 @@ def init_predictor(model):
     return Model(model.config, predictor=True, share=model)
 
 
+def crnn_config_from_keras_json(cfg):
+    """Architecture facts of a Keras-2.2.2 `model.json` written by the reference (`save_model_json`, utils.py:530-533;
+    e.g. models/OCR_mjsynth_FULL_2/model.json) -> the CRNN(...) constructor arguments.  Only the graph CRNN.get_model
+    builds (utils.py:58-96) is accepted: anything else raises ValueError instead of silently building a different net."""
+    layers = cfg["layers"]
+    by_name = {l["name"]: l for l in layers}
+    kinds = [l["class_name"] for l in layers]
+
+    def need(cond, what):
+        if not cond:
+            raise ValueError("model.json is not the CRNN-OCR-lite graph: " + what)
+
+    for n in ("the_input", "dense1", "dense2"):
+        need(n in by_name, "layer %r missing" % n)
+    shape = tuple(int(v) for v in by_name["the_input"]["config"]["batch_input_shape"][1:])
+    need(len(shape) == 3 and shape[2] == 1, "the_input must be (H, W, 1)")
+    need(kinds.count("DepthwiseConv2D") == len(BLOCK_FILTERS), "expected %d depthwise-separable blocks" % len(BLOCK_FILTERS))
+    pw = [int(l["config"]["filters"]) for l in layers if l["class_name"] == "Conv2D" and list(l["config"].get("kernel_size", [])) == [1, 1]]
+    need(pw == list(BLOCK_FILTERS), "pointwise filters %r != %r" % (pw, list(BLOCK_FILTERS)))
+    birnn = [l for l in layers if l["class_name"] == "Bidirectional"]
+    need(len(birnn) == 2, "expected two Bidirectional layers")
+    cells = {l["config"]["layer"]["class_name"] for l in birnn}
+    need(len(cells) == 1 and cells <= {"GRU", "LSTM"}, "recurrent cells %r" % sorted(cells))
+    need([l["config"].get("merge_mode") for l in birnn] == ["sum", "concat"], "merge modes must be sum, concat (utils.py:77-82)")
+    units = {int(l["config"]["layer"]["config"]["units"]) for l in birnn}
+    need(len(units) == 1, "both recurrent layers must have the same width")
+    for l in birnn:
+        need(l["config"]["layer"]["config"].get("recurrent_activation", "hard_sigmoid") == "hard_sigmoid", "recurrent_activation")
+    max_len = int(by_name["the_labels"]["config"]["batch_input_shape"][1]) if "the_labels" in by_name else 23
+    return dict(num_classes=int(by_name["dense2"]["config"]["units"]), max_string_len=max_len, shape=shape,
+                time_dense_size=int(by_name["dense1"]["config"]["units"]), GRU=(cells == {"GRU"}), n_units=units.pop())
+
+
 def model_from_json(text, custom_objects=None):
-    cfg = json.loads(text)["config"]
-    crnn = cfg["crnn"]
-    crnn["shape"] = tuple(crnn["shape"])
-    return Model(crnn, predictor=cfg.get("predictor", False))
+    """Accepts this package's own `to_json` and the reference's Keras-2.2.2 `model.json` artefacts."""
+    top = json.loads(text)
+    cfg = top["config"]
+    if "crnn" in cfg:
+        crnn = cfg["crnn"]
+        crnn["shape"] = tuple(crnn["shape"])
+        return Model(crnn, predictor=cfg.get("predictor", False))
+    if "layers" in cfg:
+        crnn = crnn_config_from_keras_json(cfg)
+        predictor = not any(l["name"] == "ctc" for l in cfg["layers"])      # init_predictor's sub-model has no loss head
+        return Model(crnn, predictor=predictor)
+    raise ValueError("unrecognised model.json")
 
 
 def save_model_json(model, save_path, model_name):

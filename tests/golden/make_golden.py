@@ -174,6 +174,32 @@ def main():
     }
     with open(os.path.join(OUT, "helpers_golden.json"), "w") as f:
         json.dump(golden, f, indent=1)
+
+    # ---- the Keras-2.2.2 model.json artefacts the reference ships (models/*/model.json): keep the architecture
+    # facts a loader needs (layer class / name / units / shapes; data, not code) + what its arguments.txt and
+    # model_summary.txt say, as the known answers for crnn_mi355x.surface.model_from_json
+    keep = ("batch_input_shape", "units", "filters", "kernel_size", "pool_size", "padding", "rate", "merge_mode", "activation",
+            "axis", "momentum", "epsilon", "output_size", "depth_multiplier", "use_bias", "max_value")
+    arts = {}
+    for name in sorted(os.listdir(os.path.join(os.path.dirname(REF), "models"))):
+        mj = json.load(open(os.path.join(os.path.dirname(REF), "models", name, "model.json")))
+        layers = []
+        for l in mj["config"]["layers"]:
+            cfg = {k: l["config"][k] for k in keep if k in l["config"]}
+            if l["class_name"] == "Bidirectional":
+                inner = l["config"]["layer"]
+                cfg["layer"] = {"class_name": inner["class_name"],
+                                "config": {k: inner["config"][k] for k in ("units", "activation", "recurrent_activation", "return_sequences",
+                                                                           "implementation", "reset_after") if k in inner["config"]}}
+            layers.append({"class_name": l["class_name"], "name": l["name"], "config": cfg})
+        summary = open(os.path.join(os.path.dirname(REF), "models", name, "model_summary.txt")).read()
+        counts = {k: int(v.replace(",", "")) for k, v in
+                  __import__("re").findall(r"(Total params|Trainable params|Non-trainable params): ([0-9,]+)", summary)}
+        arts[name] = {"model_json": {"class_name": mj["class_name"], "keras_version": mj["keras_version"], "backend": mj["backend"],
+                                     "config": {"name": mj["config"].get("name"), "layers": layers}},
+                      "param_counts": counts}
+    with open(os.path.join(OUT, "keras_model_json.json"), "w") as f:
+        json.dump(arts, f, indent=0)
     print("wrote", os.listdir(OUT))
 
 

@@ -208,3 +208,28 @@ def test_data_parallel_gradient_allreduce_world2_gloo():
     gs = [M.loss_and_grads(cfg, p, bn, x[a:b], lab[a:b], il[a:b], ll[a:b])[2] for a, b in ((0, 2), (2, 4))]
     ref = np.concatenate([(0.5 * (gs[0][k] + gs[1][k])).ravel() for k in p])
     np.testing.assert_allclose(res[0][1], ref, rtol=1e-12, atol=1e-15)
+
+
+def test_reference_keras_model_json_artefacts_load_as_the_same_architecture():
+    """the Keras-2.2.2 model.json files the reference ships (facts kept in tests/golden/
+    keras_model_json.json by make_golden.py) must build the very architecture their model_summary.txt counts."""
+    arts = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "keras_model_json.json")))
+    assert set(arts) == {"OCR_IAM_ver1", "OCR_Stickies_ver1", "OCR_mjsynth_FULL_2"}
+    for name, art in arts.items():
+        m = U.model_from_json(json.dumps(art["model_json"]))
+        c = m.config
+        assert c["GRU"] is True and c["n_units"] == 256 and c["time_dense_size"] == 128 and c["num_classes"] == 38, (name, c)
+        assert tuple(c["shape"]) == (100, 32, 1)
+        assert c["max_string_len"] == (21 if name == "OCR_IAM_ver1" else c["max_string_len"])
+        trainable, non_trainable = m.count_params()
+        assert trainable == art["param_counts"]["Trainable params"] == 2823089
+        assert non_trainable == art["param_counts"]["Non-trainable params"] == 7938
+        assert not m.predictor
+    # a graph that is not CRNN.get_model's is refused, not silently rebuilt
+    bad = json.loads(json.dumps(arts["OCR_mjsynth_FULL_2"]["model_json"]))
+    bad["config"]["layers"] = [l for l in bad["config"]["layers"] if l["class_name"] != "DepthwiseConv2D"][:-1]
+    with pytest.raises(ValueError):
+        U.model_from_json(json.dumps(bad))
+    # this package's own to_json still round-trips
+    own = U.CRNN(num_classes=38, shape=(100, 32, 1), GRU=False, max_string_len=23).get_model()
+    assert U.model_from_json(own.to_json()).config == own.config
