@@ -79,6 +79,11 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libcrnn_mi355x.so not built (%s); run `python __graft_entry__.py` "
                                "-- there is no CPU fallback for the CRNN hot path" % LIB_PATH)
+        # The library must bind to the SAME HIP runtime as PyTorch (streams and device pointers cross the boundary):
+        # torch ships its own libamdhip64 under torch/lib with the same SONAME as /opt/rocm's, and whichever is loaded
+        # first serves both -- so torch goes first.  Loading this .so before torch would pull in a second runtime and
+        # every launch on a torch stream would fail with hipErrorNoDevice.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (ret, args) in parse_header().items():
             fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol

@@ -95,6 +95,7 @@ class Model:
         self.stop_training = False
         self.optimizer = None
         self._iterations = 0
+        self._prefetched = None          # batch drawn ahead of time by fit_generator (kept across epochs)
         sh = self.config["shape"]
         self._T = (sh[0] + 4) // 2
         if share is not None:                        # predictor view of an existing model: same weights/engine
@@ -230,6 +231,13 @@ class Model:
         self.optimizer = optimizer
         self._iterations = 0
 
+    def _snapshot(self, batch):
+        """Readf re-yields the SAME arrays it keeps filling (utils.py:468,495-511): copy what a step needs before the
+        generator is advanced again."""
+        x, lab, il, ll = self._unpack(batch)
+        cp = lambda a: None if a is None else np.array(a, copy=True)
+        return np.asarray(x, dtype=np.float32).copy(), cp(lab), cp(il), cp(ll)
+
     @staticmethod
     def _unpack(batch):
         inputs = batch[0] if isinstance(batch, (tuple, list)) else batch
@@ -246,7 +254,8 @@ class Model:
             pass
         return None, 1
 
-    def train_on_batch(self, x, labels, input_length, label_length):
+    def _train_on_batch_async(self, x, labels, input_length, label_length):
+        """Enqueue one train step; returns the batch-mean loss as a DEVICE scalar (no host synchronisation)."""
         if self.optimizer is None:
             raise RuntimeError("compile(optimizer=...) first")
         eng = self._engine(len(x))
@@ -257,7 +266,10 @@ class Model:
             allreduce = GradAllReduce(eng, dist, world)
         loss = eng.train_step(x, labels, input_length, label_length, self.optimizer, self._iterations, allreduce=allreduce)
         self._iterations += 1
-        return float(loss.mean().item())
+        return loss.mean()
+
+    def train_on_batch(self, x, labels, input_length, label_length):
+        return float(self._train_on_batch_async(x, labels, input_length, label_length).item())
 
     def test_on_batch(self, x, labels, input_length, label_length):
         """learning_phase=0 forward + CTC cost (validation loss)."""
@@ -287,8 +299,14 @@ class Model:
             t0 = time.time()
             run, nimg = 0.0, 0
             for step in range(steps_per_epoch):
-                x, lab, il, ll = self._unpack(next(generator))
-                loss = self.train_on_batch(x, lab, il, ll)
+                # the step is enqueued first, then the NEXT batch is drawn from the generator (host decode / augmentation)
+                # while the GPU works, and only then is the loss read back (the one host sync per step Keras has too)
+                if self._prefetched is None:
+                    self._prefetched = self._snapshot(next(generator))
+                x, lab, il, ll = self._prefetched
+                loss_dev = self._train_on_batch_async(x, lab, il, ll)
+                self._prefetched = self._snapshot(next(generator))
+                loss = float(loss_dev.item())
                 run += loss; nimg += len(x)
                 logs = {"loss": loss, "batch": step, "size": len(x)}
                 for cb in callbacks:

@@ -57,3 +57,17 @@ def test_train_then_predict_cli_roundtrip(tmp_path, capsys):
     df = pd.read_csv(res / "prediction.csv")
     assert len(df) == 24 and set(df.columns) >= {"fname", "prediction"}
     assert all(isinstance(p, str) or (isinstance(p, float) and np.isnan(p)) for p in df["prediction"])
+
+
+def test_drop_in_import_order_fresh_process():
+    """A user script does `from utils import *` first (as the reference's train.py does) and never imports torch itself:
+    the library must still bind to PyTorch's HIP runtime (crnn_mi355x.native.lib imports torch before dlopen) -- run the
+    host-inclusive fit benchmark in a fresh interpreter."""
+    import json
+    import subprocess
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, PKG]))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fit_bench.py"), "--batch", "8", "--steps", "3", "--precision", "fp32"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["steps"] == 3 and np.isfinite(res["loss"]) and res["images_per_sec"] > 0
