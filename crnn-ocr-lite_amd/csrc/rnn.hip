@@ -99,6 +99,59 @@ __device__ __forceinline__ StepTile step_tile_map(int gx, int gy, int SJ) {
 }
 static inline int step_sj(int gx) { return (gx % 4 == 0) ? 4 : (gx % 2 == 0 ? 2 : 1); }
 
+// bf16-MFMA variant for the throughput modes: the recurrent weights come from a bf16 copy (half the L2 bytes), the
+// fp32 state rows are rounded to bf16 while they are packed (v_cvt_pk_bf16_f32) and one v_mfma_f32_16x16x32_bf16
+// covers 32 k (8 of the fp32 MFMAs).  Lane (r,q) holds k = kb+8q..8q+7 of row r for both operands.  Requires the
+// wave's K quarter to be a multiple of 32.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8_t pack8_bf16(const float4& lo, const float4& hi) {
+  uint4 w = make_uint4(pack2_bf16(lo.x, lo.y), pack2_bf16(lo.z, lo.w), pack2_bf16(hi.x, hi.y), pack2_bf16(hi.z, hi.w));
+  return __builtin_bit_cast(bf16x8_t, w);
+}
+template <int NG, int PD, int MT = 1>
+__device__ __forceinline__ void step_tile_gemm_bf16(const float* (&arow)[MT], const bool (&valid)[MT], const bf16_t* (&brow)[NG], int K, bool skip,
+                                                    float (*red)[MT * NG][256], int wave, int r, int q) {
+  f32x4 acc[MT][NG];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[m][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (!skip) {
+    const int kw = K >> 2, kbeg = wave * kw, kend = kbeg + kw;
+    for (int kb = kbeg; kb < kend; kb += 32 * PD) {
+      float4 alo[MT][PD], ahi[MT][PD]; uint4 b8[NG][PD];
+#pragma unroll
+      for (int c = 0; c < PD; ++c) {
+        const int k = kb + 32 * c + 8 * q;
+        const bool in = kb + 32 * c < kend;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          alo[m][c] = (valid[m] && in) ? *reinterpret_cast<const float4*>(arow[m] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+          ahi[m][c] = (valid[m] && in) ? *reinterpret_cast<const float4*>(arow[m] + k + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) b8[g][c] = in ? *reinterpret_cast<const uint4*>(brow[g] + k) : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int c = 0; c < PD; ++c)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const bf16x8_t av = pack8_bf16(alo[m][c], ahi[m][c]);
+#pragma unroll
+          for (int g = 0; g < NG; ++g)
+            acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8_t, b8[g][c]), acc[m][g], 0, 0, 0);
+        }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wave][m * NG + g][(q * 4 + e) * 16 + r] = acc[m][g][e];  // C/D: row = 4q+e, col = r
+  __syncthreads();
+}
+
 #define LSTM_MT 1   // batch tiles (x16 rows) per workgroup in the LSTM step kernels
 
 struct LstmDir {
@@ -112,6 +165,7 @@ struct LstmDir {
   float* dc;         // bwd: [B][u] cell-gradient carry
 };
 
+template <bool WBF>
 __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmDir d0, LstmDir d1, int s, int T, int B, int u, int SJ) {
   __shared__ float red[4][LSTM_MT * 4][256];
   const StepTile st = step_tile_map(u / 16, cdiv_i(B, 16 * LSTM_MT), SJ);
@@ -138,9 +192,15 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmDir d0, LstmDir 
       valid[m] = (b0 + 16 * m + r) < B;
       arow[m] = d.h + ((long)(s > 0 ? tp : t) * B + (valid[m] ? b0 + 16 * m + r : 0)) * d.ldh;
     }
-    const float* brow[4] = {d.wt + (long)(j0 + r) * u, d.wt + (long)(u + j0 + r) * u, d.wt + (long)(2 * u + j0 + r) * u,
-                            d.wt + (long)(3 * u + j0 + r) * u};
-    step_tile_gemm<4, 4, LSTM_MT>(arow, valid, brow, u, s == 0, red, wave, r, q);
+    if constexpr (WBF) {
+      const bf16_t* wb = reinterpret_cast<const bf16_t*>(d.wt);
+      const bf16_t* brow[4] = {wb + (long)(j0 + r) * u, wb + (long)(u + j0 + r) * u, wb + (long)(2 * u + j0 + r) * u, wb + (long)(3 * u + j0 + r) * u};
+      step_tile_gemm_bf16<4, 2, LSTM_MT>(arow, valid, brow, u, s == 0, red, wave, r, q);
+    } else {
+      const float* brow[4] = {d.wt + (long)(j0 + r) * u, d.wt + (long)(u + j0 + r) * u, d.wt + (long)(2 * u + j0 + r) * u,
+                              d.wt + (long)(3 * u + j0 + r) * u};
+      step_tile_gemm<4, 4, LSTM_MT>(arow, valid, brow, u, s == 0, red, wave, r, q);
+    }
   }
   const int row = tid >> 4, col = tid & 15, j = j0 + col;
 #pragma unroll
@@ -163,6 +223,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmDir d0, LstmDir 
 }
 
 // sb = 0..T-1 counts backward steps; the time handled is the (T-1-sb)-th in processing order
+template <bool WBF>
 __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmDir d0, LstmDir d1, int sb, int T, int B, int u, int SJ) {
   __shared__ float red[4][LSTM_MT][256];
   const StepTile st = step_tile_map(u / 16, cdiv_i(B, 16 * LSTM_MT), SJ);
@@ -196,8 +257,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmDir d0, LstmDir 
       valid[m] = (b0 + 16 * m + r) < B;
       arow[m] = d.dz + ((long)(sb > 0 ? tnext : t) * B + (valid[m] ? b0 + 16 * m + r : 0)) * K;
     }
-    const float* brow[1] = {d.wt + (long)(j0 + r) * K};
-    step_tile_gemm<1, 8, LSTM_MT>(arow, valid, brow, K, sb == 0, red, wave, r, q);
+    if constexpr (WBF) {
+      const bf16_t* brow[1] = {reinterpret_cast<const bf16_t*>(d.wt) + (long)(j0 + r) * K};
+      step_tile_gemm_bf16<1, 4, LSTM_MT>(arow, valid, brow, K, sb == 0, red, wave, r, q);
+    } else {
+      const float* brow[1] = {d.wt + (long)(j0 + r) * K};
+      step_tile_gemm<1, 8, LSTM_MT>(arow, valid, brow, K, sb == 0, red, wave, r, q);
+    }
   }
   const int row = tid >> 4, col = tid & 15, j = j0 + col;
 #pragma unroll
@@ -225,36 +291,49 @@ static int check_units(int u) { return (u >= 64 && u % 64 == 0) ? 0 : CRNN_ERR_U
 // Forward recurrence of one Bidirectional(LSTM) layer (both directions).  Pointers per direction d in
 // {0: forward-in-time, 1: backward-in-time}: xw[d] [T][B][4u], ut[d] = U^T [4u][u], h[d] (row stride ldh),
 // c[d] [T][B][u], gates[d] [T][B][4u].  T launches on `stream`.
-extern "C" int crnn_lstm_fwd(const float* xw0, const float* xw1, const float* ut0, const float* ut1, float* h0, float* h1,
-                             int ldh, float* c0, float* c1, float* g0, float* g1, int T, int B, int u, hipStream_t stream) {
+extern "C" int crnn_lstm_fwd_ex(const float* xw0, const float* xw1, const void* ut0, const void* ut1, float* h0, float* h1,
+                                int ldh, float* c0, float* c1, float* g0, float* g1, int T, int B, int u, int dt_u, hipStream_t stream) {
   CRNN_TRY(check_units(u));
   if (ldh % 4 != 0) return CRNN_ERR_ARG;
-  LstmDir a{xw0, ut0, h0, ldh, c0, g0, nullptr, 0, nullptr, nullptr};
-  LstmDir b{xw1, ut1, h1, ldh, c1, g1, nullptr, 0, nullptr, nullptr};
+  if (dt_u == CRNN_BF16 && (u % 128 != 0 || ((uintptr_t)ut0 | (uintptr_t)ut1) & 15)) return CRNN_ERR_UNSUPPORTED;   // 32-wide bf16 MFMA per K quarter
+  LstmDir a{xw0, (const float*)ut0, h0, ldh, c0, g0, nullptr, 0, nullptr, nullptr};
+  LstmDir b{xw1, (const float*)ut1, h1, ldh, c1, g1, nullptr, 0, nullptr, nullptr};
   const int SJ = step_sj(u / 16);
   dim3 grid(step_grid(u / 16, cdiv(B, 16 * LSTM_MT), SJ));
   for (int s = 0; s < T; ++s) {
-    hipLaunchKernelGGL(lstm_fwd_step_kernel, grid, dim3(256), 0, stream, a, b, s, T, B, u, SJ);
+    if (dt_u == CRNN_BF16) hipLaunchKernelGGL(lstm_fwd_step_kernel<true>, grid, dim3(256), 0, stream, a, b, s, T, B, u, SJ);
+    else hipLaunchKernelGGL(lstm_fwd_step_kernel<false>, grid, dim3(256), 0, stream, a, b, s, T, B, u, SJ);
   }
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
+extern "C" int crnn_lstm_fwd(const float* xw0, const float* xw1, const float* ut0, const float* ut1, float* h0, float* h1,
+                             int ldh, float* c0, float* c1, float* g0, float* g1, int T, int B, int u, hipStream_t stream) {
+  return crnn_lstm_fwd_ex(xw0, xw1, ut0, ut1, h0, h1, ldh, c0, c1, g0, g1, T, B, u, CRNN_F32, stream);
+}
 
 // BPTT of one Bidirectional(LSTM) layer: fills dz[d] [T][B][4u] (gradients w.r.t. the gate pre-activations)
 // from dout[d] (gradient w.r.t. h, row stride ldo).  u_[d] = U [u][4u]; dc[d] = [B][u] scratch.
-extern "C" int crnn_lstm_bwd(const float* u0, const float* u1, const float* c0, const float* c1, const float* g0,
-                             const float* g1, const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1,
-                             float* dc0, float* dc1, int T, int B, int u, hipStream_t stream) {
+extern "C" int crnn_lstm_bwd_ex(const void* u0, const void* u1, const float* c0, const float* c1, const float* g0,
+                                const float* g1, const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1,
+                                float* dc0, float* dc1, int T, int B, int u, int dt_u, hipStream_t stream) {
   CRNN_TRY(check_units(u));
-  LstmDir a{nullptr, u0, nullptr, 0, const_cast<float*>(c0), const_cast<float*>(g0), dout0, ldo, dz0, dc0};
-  LstmDir b{nullptr, u1, nullptr, 0, const_cast<float*>(c1), const_cast<float*>(g1), dout1, ldo, dz1, dc1};
+  if (dt_u == CRNN_BF16 && (u % 32 != 0 || ((uintptr_t)u0 | (uintptr_t)u1) & 15)) return CRNN_ERR_UNSUPPORTED;
+  LstmDir a{nullptr, (const float*)u0, nullptr, 0, const_cast<float*>(c0), const_cast<float*>(g0), dout0, ldo, dz0, dc0};
+  LstmDir b{nullptr, (const float*)u1, nullptr, 0, const_cast<float*>(c1), const_cast<float*>(g1), dout1, ldo, dz1, dc1};
   const int SJ = step_sj(u / 16) > 2 ? 2 : step_sj(u / 16);   // the dz rows (4u wide) outweigh the weights here: favour batch groups
   dim3 grid(step_grid(u / 16, cdiv(B, 16 * LSTM_MT), SJ));
   for (int sb = 0; sb < T; ++sb) {
-    hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, dim3(256), 0, stream, a, b, sb, T, B, u, SJ);
+    if (dt_u == CRNN_BF16) hipLaunchKernelGGL(lstm_bwd_step_kernel<true>, grid, dim3(256), 0, stream, a, b, sb, T, B, u, SJ);
+    else hipLaunchKernelGGL(lstm_bwd_step_kernel<false>, grid, dim3(256), 0, stream, a, b, sb, T, B, u, SJ);
   }
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
+}
+extern "C" int crnn_lstm_bwd(const float* u0, const float* u1, const float* c0, const float* c1, const float* g0,
+                             const float* g1, const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1,
+                             float* dc0, float* dc1, int T, int B, int u, hipStream_t stream) {
+  return crnn_lstm_bwd_ex(u0, u1, c0, c1, g0, g1, dout0, dout1, ldo, dz0, dz1, dc0, dc1, T, B, u, CRNN_F32, stream);
 }
 
 // =====================================================================================================
@@ -409,17 +488,22 @@ extern "C" int crnn_gru_bwd(const float* u0, const float* u1, const float* h0, c
   return CRNN_OK;
 }
 
-// out[c][r] = in[r][c]  (U -> U^T once per weight update; tiny)
-__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
+// out[c][r] = in[r][c]  (U -> U^T once per weight update; tiny); TO = float or bf16_t
+template <typename TO>
+__global__ void transpose_kernel(const float* __restrict__ in, TO* __restrict__ out, int R, int C) {
   __shared__ float tile[32][33];
   int c = blockIdx.x * 32 + threadIdx.x, r = blockIdx.y * 32 + threadIdx.y;
   for (int k = 0; k < 32; k += 8) if (r + k < R && c < C) tile[threadIdx.y + k][threadIdx.x] = in[(long)(r + k) * C + c];
   __syncthreads();
   int oc = blockIdx.y * 32 + threadIdx.x, orow = blockIdx.x * 32 + threadIdx.y;
-  for (int k = 0; k < 32; k += 8) if (orow + k < C && oc < R) out[(long)(orow + k) * R + oc] = tile[threadIdx.x][threadIdx.y + k];
+  for (int k = 0; k < 32; k += 8) if (orow + k < C && oc < R) st1(&out[(long)(orow + k) * R + oc], tile[threadIdx.x][threadIdx.y + k]);
 }
-extern "C" int crnn_transpose(const float* in, float* out, int R, int C, hipStream_t stream) {
-  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(32, 8), 0, stream, in, out, R, C);
+extern "C" int crnn_transpose_ex(const float* in, void* out, int R, int C, int dt_out, hipStream_t stream) {
+  if (dt_out == CRNN_BF16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(32, 8), 0, stream, in, (bf16_t*)out, R, C);
+  else hipLaunchKernelGGL(transpose_kernel<float>, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(32, 8), 0, stream, in, (float*)out, R, C);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
+}
+extern "C" int crnn_transpose(const float* in, float* out, int R, int C, hipStream_t stream) {
+  return crnn_transpose_ex(in, out, R, C, CRNN_F32, stream);
 }

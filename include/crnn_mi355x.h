@@ -183,6 +183,13 @@ int crnn_lstm_fwd(const float* xw0, const float* xw1, const float* ut0, const fl
 int crnn_lstm_bwd(const float* u0, const float* u1, const float* c0, const float* c1, const float* g0, const float* g1,
                   const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1, float* dc0, float* dc1, int T,
                   int B, int u, crnn_stream_t stream);
+/* same, dt_u = storage of the recurrent weights ut* / u* (0 = fp32; 1 = bf16: the per-step products then run on
+ * v_mfma_f32_16x16x32_bf16 with the fp32 state rounded to bf16 as it is packed, fp32 accumulation; needs u % 128 == 0) */
+int crnn_lstm_fwd_ex(const float* xw0, const float* xw1, const void* ut0, const void* ut1, float* h0, float* h1, int ldh,
+                     float* c0, float* c1, float* g0, float* g1, int T, int B, int u, int dt_u, crnn_stream_t stream);
+int crnn_lstm_bwd_ex(const void* u0, const void* u1, const float* c0, const float* c1, const float* g0, const float* g1,
+                     const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1, float* dc0, float* dc1, int T,
+                     int B, int u, int dt_u, crnn_stream_t stream);
 /* Bidirectional GRU recurrence (utils.py:81-82; reset_after=False), time-major; gates = z,r,hh; rh = r*h_prev */
 int crnn_gru_fwd(const float* xw0, const float* xw1, const float* ut0, const float* ut1, float* h0, float* h1, int ldh,
                  float* g0, float* g1, float* rh0, float* rh1, int T, int B, int u, crnn_stream_t stream);
@@ -190,6 +197,7 @@ int crnn_gru_bwd(const float* u0, const float* u1, const float* h0, const float*
                  const float* g1, const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1, float* dh0,
                  float* dh1, float* dhp0, float* dhp1, int T, int B, int u, crnn_stream_t stream);
 int crnn_transpose(const float* in, float* out, int R, int C, crnn_stream_t stream);
+int crnn_transpose_ex(const float* in, void* out, int R, int C, int dt_out, crnn_stream_t stream);   /* dt_out 1: bf16 result */
 /* softmax + CTC (utils.py:86, 98-103) */
 int crnn_softmax_rows(const float* z, float* p, long rows, int C, crnn_stream_t stream);
 int crnn_ctc_loss_grad(const float* y, const int* labels, const int* input_len, const int* label_len, float* loss,
