@@ -139,7 +139,9 @@ __global__ __launch_bounds__(64) void ctc_loss_grad_kernel(const float* __restri
 
 extern "C" int crnn_ctc_loss_grad(const float* y, const int* labels, const int* input_len, const int* label_len, float* loss,
                                   float* dlogits, int B, int T, int C, int Lmax, int skip, float grad_scale, hipStream_t stream) {
-  if (C > 64 || T <= skip) return CRNN_ERR_UNSUPPORTED;
+  if (C > 64 || C < 2 || T <= skip) return CRNN_ERR_UNSUPPORTED;
+  if (Lmax < 0 || 2 * Lmax + 1 > 64) return CRNN_ERR_UNSUPPORTED;   // the extended label (2L+1 states) lives on the 64 lanes of one wavefront
+  if (B <= 0) return CRNN_ERR_ARG;
   size_t lds = ((size_t)(T - skip) * C + (size_t)(T - skip) * 64 + 64) * sizeof(float);
   if (lds > 64 * 1024) return CRNN_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(ctc_loss_grad_kernel, dim3(B), dim3(64), lds, stream, y, labels, input_len, label_len, loss, dlogits, B, T, C, Lmax, skip, grad_scale);

@@ -327,3 +327,36 @@ def test_two_stage_backward_equals_single_call():
         assert torch.equal(loss1, loss2)
         assert torch.equal(eng.grads, g1), precision
         assert torch.equal(top_done, g1[split:]), "upper-layer gradients must be final after the first stage"
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16s"])
+def test_full_size_batch256_properties(precision):
+    """BASELINE configs[1] size (batch 256): properties that do not need the (slow) CPU oracle at this size --
+    (1) inference is per-image: the first 8 images of the batch give the same posteriors when run alone at batch 8
+        (fp32: to fp32 round-off; bf16s: to bf16 round-off, different tiles round the same sums differently) and, in
+        fp32, the same greedy indices;
+    (2) the greedy decode equals arg-max / collapse-repeats / drop-blank applied to the device posteriors (bit-exact);
+    (3) the posteriors are normalised, the per-sample CTC loss is finite and positive, the train step is deterministic."""
+    cfg = M.Config()
+    B = 256
+    p, bn = M.init_params(cfg, seed=2, dtype=np.float32)
+    p = M.randomize_params(cfg, p)
+    x, lab, il, ll = M.synthetic_batch(cfg, B, seed=9)
+    big = Engine(B, dropout=True, precision=precision); big.set_params(p, bn)
+    yb = big.forward(x, train=False).clone()
+    small = Engine(8, dropout=True, precision=precision); small.set_params(p, bn)
+    ys = small.forward(x[:8], train=False)
+    tol = 2e-5 if precision == "fp32" else 3e-2
+    assert float((yb[:8] - ys).abs().max()) < tol
+    gb, lb = big.greedy_decode(yb); gs, ls = small.greedy_decode(ys)
+    if precision == "fp32":
+        assert torch.equal(gb[:8], gs) and torch.equal(lb[:8], ls)
+    yh = yb.cpu().numpy()
+    ref, rl = ctc.ctc_greedy_decode(yh, np.full(B, yh.shape[1]))
+    assert np.array_equal(gb.cpu().numpy(), ref) and np.array_equal(lb.cpu().numpy(), rl)
+    assert np.abs(yh.sum(-1) - 1).max() < 1e-5
+    big.forward(x, train=True, seed=4); l1 = big.backward(lab, il, ll, seed=4).clone(); g1 = big.grads.clone()
+    big.forward(x, train=True, seed=4); l2 = big.backward(lab, il, ll, seed=4)
+    assert torch.equal(l1, l2) and torch.equal(g1, big.grads)
+    lh = l1.cpu().numpy()
+    assert np.isfinite(lh).all() and (lh > 0).all() and np.isfinite(g1.cpu().numpy()).all()

@@ -574,3 +574,45 @@ def test_bilstm_bf16_recurrent_weights_track_the_fp64_cell():
         assert np.percentile(err, 99) < 1e-2 * np.abs(ref).max(), (d, np.percentile(err, 99), np.abs(ref).max())
     # unsupported widths are refused, not silently computed in another precision
     assert L().crnn_lstm_fwd_ex(P(xw[0]), P(xw[1]), P(ut[0]), P(ut[1]), P(hcat), P(hcat), 2 * u, P(cs[0]), P(cs[1]), P(gt[0]), P(gt[1]), T, B, 64, 1, S()) == -3
+
+
+def test_ctc_and_decoders_at_the_size_limits_and_with_empty_labels():
+    """Edge cases of the decode / loss kernels: the largest alphabet (64 classes) and label (31) the library accepts, a long
+    IAM-like sequence (T = 102), empty labels (label_length = 0), a one-step input, and out-of-range sizes refused."""
+    B, T, C, Lmax = 7, 102, 64, 31
+    rs = np.random.RandomState(123)
+    logits = rs.normal(size=(B, T, C)) * 2.5
+    y = ops.softmax_fwd(logits)
+    ll = np.array([31, 0, 1, 17, 0, 31, 5])
+    labels = np.full((B, Lmax), C - 1, dtype=np.int64)
+    for b in range(B):
+        labels[b, :ll[b]] = rs.randint(0, C - 1, size=ll[b])
+    labels[5, :31] = 7                                    # 31 repeats need 61 frames: feasible only for T-2 >= 61
+    il = np.array([T - 2, T - 2, 3, 60, 1, T - 2, T - 2], dtype=np.int64)
+    loss_ref, gy = ctc.ctc_loss_and_grad(y, labels, il, ll)
+    gl_ref = ops.softmax_bwd(y, gy / B)
+    yd = dev(y)
+    loss = zeros(B); dl = zeros(T, B, C)
+    ok(L().crnn_ctc_loss_grad(P(yd), P(dev(labels, np.int32)), P(dev(il, np.int32)), P(dev(ll, np.int32)), P(loss), P(dl), B, T, C, Lmax, 2,
+                              1.0 / B, S()))
+    lh = host(loss)
+    assert np.array_equal(np.isfinite(lh), np.isfinite(loss_ref))
+    fin = np.isfinite(loss_ref)
+    assert_close(lh[fin], loss_ref[fin], rtol=1e-4, atol=1e-3, what="ctc loss at C=64, L=31, T=102")
+    assert_close(np.swapaxes(host(dl), 0, 1), gl_ref, rtol=1e-3, atol=2e-6, what="dlogits")
+    # decoders on the same posteriors (float32 as the model emits them)
+    yp = y.astype(np.float32)
+    ilf = np.array([T, 1, 2, 60, T, 33, T])
+    ref, rl = ctc.ctc_greedy_decode(yp, ilf)
+    out = zeros(B, T, dtype=torch.int32); ln = zeros(B, dtype=torch.int32)
+    ok(L().crnn_ctc_greedy_decode(P(dev(yp)), P(dev(ilf, np.int32)), P(out), P(ln), B, T, C, S()))
+    assert np.array_equal(host(out), ref) and np.array_equal(host(ln), rl)
+    bref, brl, bsc = ctc.ctc_beam_decode(yp, beam_width=16, merge_repeated=True, input_length=ilf)
+    out = zeros(B, T, dtype=torch.int32); ln = zeros(B, dtype=torch.int32); sc = zeros(B)
+    ok(L().crnn_ctc_beam_decode(P(dev(yp)), P(dev(ilf, np.int32)), P(out), P(ln), P(sc), B, T, C, 16, 1, S()))
+    assert np.array_equal(host(ln), brl) and np.array_equal(host(out), bref)
+    assert_close(host(sc), bsc, rtol=1e-4, atol=1e-3, what="beam score")
+    # limits are enforced, not overrun
+    assert L().crnn_ctc_beam_decode(P(dev(yp)), None, P(out), P(ln), P(sc), B, T, C, 17, 1, S()) != 0      # beam wider than 16
+    assert L().crnn_ctc_loss_grad(P(yd), P(dev(labels, np.int32)), P(dev(il, np.int32)), P(dev(ll, np.int32)), P(loss), P(dl), B, T, C, 32, 2,
+                                  1.0 / B, S()) != 0                                                          # 2*32+1 > 64 lanes
