@@ -93,26 +93,33 @@ def pointwise_gemm_roofline(eng, iters=5):
     cfgs = []
     h, w, cin = eng.cfg.imgh + 4, eng.cfg.imgw + 4, 1
     blocks = [(64, 1, 1), (128, 1, 1), (256, 2, 2), (256, 1, 1), (512, 1, 2), (512, 1, 1), (512, 1, 1)]
+    pwT = eng.ws_tensor("pwT") if bf else None         # bf16 W^T copies the forward reads in the bf16 modes (NT GEMM)
+    toff = 0
     for i, (co, ph, pw) in enumerate(blocks, 1):
         M = B * h * w
         if co > 64:
-            cfgs.append((eng.ws_tensor("a%d" % i), W("b%d_pw" % i), eng.ws_tensor("q%d" % i), M, co, cin, sdt, sdt))
+            if bf:
+                cfgs.append((eng.ws_tensor("a%d" % i), pwT[toff:], eng.ws_tensor("q%d" % i), M, co, cin, sdt, sdt, 1))
+                toff += cin * co
+            else:
+                cfgs.append((eng.ws_tensor("a%d" % i), W("b%d_pw" % i), eng.ws_tensor("q%d" % i), M, co, cin, sdt, sdt, 0))
         h, w, cin = h // ph, w // pw, co
     feat = w * cin
     TB = T * B
     scratch = eng.ws_tensor("gemm_scratch")
-    cfgs.append((eng.ws_tensor("x7"), W("dense1_w"), eng.ws_tensor("gA"), TB, eng.cfg.tds, feat, sdt, 0))
+    cfgs.append((eng.ws_tensor("x7"), W("dense1_w"), eng.ws_tensor("gA"), TB, eng.cfg.tds, feat, sdt, 0, 0))
     u, G = eng.cfg.units, 4 * eng.cfg.units
     for n, src, k in (("rnn1f_w", "dn1", eng.cfg.tds), ("rnn1b_w", "dn1", eng.cfg.tds), ("rnn2f_w", "r1", u), ("rnn2b_w", "r1", u)):
-        cfgs.append((eng.ws_tensor(src), W(n), eng.ws_tensor("gB"), TB, G, k, 0, 0))
-    flops = sum(2.0 * M * N * K for _, _, _, M, N, K, _, _ in cfgs)
+        cfgs.append((eng.ws_tensor(src), W(n), eng.ws_tensor("gB"), TB, G, k, 0, 0, 0))
+    flops = sum(2.0 * M * N * K for _, _, _, M, N, K, _, _, _ in cfgs)
     times = []
     for it in range(iters + 1):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for A, Bm, C, M, N, K, dta, dtc in cfgs:
+        for A, Bm, C, M, N, K, dta, dtc, wt in cfgs:
             if bf:
-                lib.crnn_gemm_bf16_ex(0, _ptr(A), _ptr(Bm), _ptr(C), M, N, K, K, N, N, None, 0, 0, 0, _ptr(scratch), 128 * 1024 * 1024, dta, 1, dtc, _stream())
+                lib.crnn_gemm_bf16_ex(1 if wt else 0, _ptr(A), _ptr(Bm), _ptr(C), M, N, K, K, K if wt else N, N, None, 0, 0, 0, _ptr(scratch),
+                                      128 * 1024 * 1024, dta, 1, dtc, _stream())
             else:
                 lib.crnn_gemm_f32(0, _ptr(A), _ptr(Bm), _ptr(C), M, N, K, K, N, N, None, 0, 0, 0, _ptr(scratch), 128 * 1024 * 1024, _stream())
         e1.record()

@@ -378,10 +378,13 @@ extern "C" int crnn_gemm_f32(int mode, const float* A, const float* B, float* C,
 // ---- pointwise 1x1 convolution = GEMM over the pixels, with the next BatchNorm's statistics from the epilogue
 extern "C" int crnn_pwconv_stat_rows(long M) { return cdiv(M, 128); }
 extern "C" int crnn_pwconv_fwd(const void* a, const void* w, void* q, long M, int N, int K, float* stat_partials,
-                               int bf16_products, int dt_a, int dt_w, int dt_q, hipStream_t stream) {
+                               int bf16_products, int dt_a, int dt_w, int dt_q, int w_transposed, hipStream_t stream) {
   if (M <= 0 || M > 0x7fffffffL) return CRNN_ERR_ARG;
+  // w_transposed: the weights are given as W^T [N][K] (both operands then contiguous along the reduction: the staging
+  // needs no k-pair interleave and the fragments are single 16-byte LDS reads)
+  const int mode = w_transposed ? 1 : 0, ldw = w_transposed ? K : N;
   if (bf16_products)
-    return gemm_bf16_impl(0, a, w, q, (int)M, N, K, K, N, N, nullptr, 0, 0, 0, nullptr, 0, dt_a, dt_w, dt_q, stat_partials, stream);
+    return gemm_bf16_impl(mode, a, w, q, (int)M, N, K, K, ldw, N, nullptr, 0, 0, 0, nullptr, 0, dt_a, dt_w, dt_q, stat_partials, stream);
   if (dt_a != CRNN_F32 || dt_w != CRNN_F32 || dt_q != CRNN_F32) return CRNN_ERR_ARG;
-  return gemm_f32_impl(0, (const float*)a, (const float*)w, (float*)q, (int)M, N, K, K, N, N, nullptr, 0, 0, 0, nullptr, 0, stat_partials, stream);
+  return gemm_f32_impl(mode, (const float*)a, (const float*)w, (float*)q, (int)M, N, K, K, ldw, N, nullptr, 0, 0, 0, nullptr, 0, stat_partials, stream);
 }

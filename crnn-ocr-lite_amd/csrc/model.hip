@@ -155,6 +155,8 @@ Plan make_plan(const crnn_config* c) {
   maxparts = lmax(maxparts, (long)crnn_colreduce_chunks(TB) * lmax(d.G, lmax(d.tds, d.C)));
   maxparts = lmax(maxparts, (long)crnn_colreduce_chunks(B * d.Ho1 * d.Wo1) * 64);
   P.add("partials", maxparts);
+  { long pw = 0; for (int i = 2; i <= 7; ++i) pw += (long)d.bc[i - 1] * d.bc[i];
+    P.add("pwT", pw, CRNN_BF16); }   // bf16 W^T copies of the pointwise-conv weights (bf16 modes)
   P.add("pbf", make_layout(c).total, CRNN_BF16);   // bf16 shadow of the parameter buffer (GEMM B operands in the bf16 modes)
   P.add("coef", 2 * 1024);
   P.add("fold", 32 * 2 * 1024);   // chunk sums of long BatchNorm partial lists (crnn_bn_finalize_folded)
@@ -312,6 +314,18 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
   } else {
     CRNN_TRY(crnn_pad_copy(x, c.w("x0"), B, d.H0, d.W0, 2, stream));
   }
+  // bf16 modes: W^T (bf16) copies of the pointwise weights of blocks 2..7, one launch
+  long pwT_off[8]; for (int i = 0; i < 8; ++i) pwT_off[i] = -1;
+  if (cfg->mfma_bf16) {
+    long in_off[8], out_off[8]; int R[8], Cc[8]; int n = 0; long acc = 0;
+    for (int i = 2; i <= 7; ++i) {
+      const int ci = d.bc[i - 1], co = d.bc[i];
+      if (ci % 8 || co % 8) continue;
+      in_off[n] = c.L.off("b" + std::to_string(i) + "_pw"); out_off[n] = acc; R[n] = ci; Cc[n] = co;
+      pwT_off[i] = acc; acc += (long)ci * co; ++n;
+    }
+    if (n) CRNN_TRY(crnn_transpose_batch(params, c.w("pwT"), n, in_off, out_off, R, Cc, CRNN_BF16, stream));
+  }
   // ---- 7 depthwise-separable blocks (utils.py:43-56, 64-70)
   const float* in = c.w("x0");
   int bn_off = 0;
@@ -337,9 +351,13 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
     bn_off += ci;
     CRNN_TRY(crnn_bn_act_pool_drop_ex(dd, s1, aa, 1, 1, (int)M, ci, 1, 1, 0.f, 0, 0, dtd, dtd, stream));
     {  // pointwise conv; in training its epilogue also produces the batch statistics of the BatchNorm that follows
-      int dtw = CRNN_F32;
+      int dtw = CRNN_F32, wt = 0;
       const float* wq = weight_operand(c, 0, c.p(bp + "_pw"), &dtw);
-      CRNN_TRY(crnn_pwconv_fwd(aa, wq, qq, M, co, ci, train ? parts : nullptr, cfg->mfma_bf16 ? 1 : 0, dtd, dtw, dtq, stream));
+      if (cfg->mfma_bf16 && pwT_off[i] >= 0) {   // bf16 W^T copy made above: both operands contiguous along the reduction
+        wq = reinterpret_cast<const float*>(reinterpret_cast<const bf16_t*>(c.w("pwT")) + pwT_off[i]);
+        dtw = CRNN_BF16; wt = 1;
+      }
+      CRNN_TRY(crnn_pwconv_fwd(aa, wq, qq, M, co, ci, train ? parts : nullptr, cfg->mfma_bf16 ? 1 : 0, dtd, dtw, dtq, wt, stream));
     }
     if (train) {
       CRNN_TRY(crnn_bn_finalize_folded(parts, crnn_pwconv_stat_rows(M), co, M, c.p(bp + "_bn2_g"), c.p(bp + "_bn2_b"), s2, c.w("fold"), stream));

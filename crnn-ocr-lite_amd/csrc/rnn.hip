@@ -507,3 +507,34 @@ extern "C" int crnn_transpose_ex(const float* in, void* out, int R, int C, int d
 extern "C" int crnn_transpose(const float* in, float* out, int R, int C, hipStream_t stream) {
   return crnn_transpose_ex(in, out, R, C, CRNN_F32, stream);
 }
+
+// several small transposes in one launch (blockIdx.z = matrix): the W^T copies of the pointwise-conv weights
+struct TransTable { long in_off[8], out_off[8]; int R[8], C[8]; };
+template <typename TO>
+__global__ void transpose_batch_kernel(const float* __restrict__ src, TO* __restrict__ dst, TransTable tab) {
+  __shared__ float tile[32][33];
+  const int z = blockIdx.z, R = tab.R[z], C = tab.C[z];
+  const float* in = src + tab.in_off[z]; TO* out = dst + tab.out_off[z];
+  if (blockIdx.x * 32 >= C || blockIdx.y * 32 >= R) return;
+  int c = blockIdx.x * 32 + threadIdx.x, r = blockIdx.y * 32 + threadIdx.y;
+  for (int k = 0; k < 32; k += 8) if (r + k < R && c < C) tile[threadIdx.y + k][threadIdx.x] = in[(long)(r + k) * C + c];
+  __syncthreads();
+  int oc = blockIdx.y * 32 + threadIdx.x, orow = blockIdx.x * 32 + threadIdx.y;
+  for (int k = 0; k < 32; k += 8) if (orow + k < C && oc < R) st1(&out[(long)(orow + k) * R + oc], tile[threadIdx.x][threadIdx.y + k]);
+}
+extern "C" int crnn_transpose_batch(const float* src, void* dst, int n, const long* in_off, const long* out_off, const int* R, const int* C,
+                                    int dt_out, hipStream_t stream) {
+  if (n <= 0 || n > 8) return CRNN_ERR_ARG;
+  TransTable tab; int maxR = 0, maxC = 0;
+  for (int i = 0; i < 8; ++i) {
+    int j = i < n ? i : 0;
+    tab.in_off[i] = in_off[j]; tab.out_off[i] = out_off[j]; tab.R[i] = R[j]; tab.C[i] = C[j];
+    if (R[j] > maxR) maxR = R[j];
+    if (C[j] > maxC) maxC = C[j];
+  }
+  dim3 grid(cdiv(maxC, 32), cdiv(maxR, 32), n);
+  if (dt_out == CRNN_BF16) hipLaunchKernelGGL(transpose_batch_kernel<bf16_t>, grid, dim3(32, 8), 0, stream, src, (bf16_t*)dst, tab);
+  else hipLaunchKernelGGL(transpose_batch_kernel<float>, grid, dim3(32, 8), 0, stream, src, (float*)dst, tab);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}

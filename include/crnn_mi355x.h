@@ -122,7 +122,11 @@ int crnn_gemm_bf16_ex(int mode, const void* A, const void* B, void* C, int M, in
  * bf16_products: 0 = fp32 MFMA (all dt_* must be 0), 1 = bf16 MFMA products with fp32 accumulation. */
 int crnn_pwconv_stat_rows(long M);
 int crnn_pwconv_fwd(const void* a, const void* w, void* q, long M, int N, int K, float* stat_partials, int bf16_products,
-                    int dt_a, int dt_w, int dt_q, crnn_stream_t stream);
+                    int dt_a, int dt_w, int dt_q, int w_transposed /* 1: w is W^T [N][K] */, crnn_stream_t stream);
+/* n (<= 8) independent matrix transposes in one launch: out[i] [C_i][R_i] = in[i]^T, in[i] = src + in_off[i] (fp32
+ * elements), out[i] = dst + out_off[i] (elements of dt_out: 0 fp32 | 1 bf16) */
+int crnn_transpose_batch(const float* src, void* dst, int n, const long* in_off, const long* out_off, const int* R, const int* C,
+                         int dt_out, crnn_stream_t stream);
 int crnn_dwconv3x3_fwd_ex(const void* x, const float* k, void* out, float* stat_partials, int B, int H, int W, int C, int flip,
                           int dtype, crnn_stream_t stream);
 int crnn_dwconv3x3_wgrad_ex(const void* x, const void* g, float* dk, float* scratch, int B, int H, int W, int C, int dtype,

@@ -505,7 +505,7 @@ def test_pwconv_fwd_with_statistics_epilogue(case):
     parts = zeros(rows, 2, N)
     if case == "fp32":
         Ad, Wd, Q = dev(A), dev(W), zeros(Mm, N)
-        ok(L().crnn_pwconv_fwd(P(Ad), P(Wd), P(Q), Mm, N, K, P(parts), 0, 0, 0, 0, S()))
+        ok(L().crnn_pwconv_fwd(P(Ad), P(Wd), P(Q), Mm, N, K, P(parts), 0, 0, 0, 0, 0, S()))
         q = host(Q); ref = A.astype(np.float32).astype(np.float64) @ W.astype(np.float32).astype(np.float64)
         assert_close(q, ref, rtol=1e-5, atol=1e-5, what="pwconv fp32")
     else:
@@ -514,14 +514,22 @@ def test_pwconv_fwd_with_statistics_epilogue(case):
         Wd = _to_bf16_dev(W)
         if case == "bf16":
             Ad, Q = dev(A), zeros(Mm, N)
-            ok(L().crnn_pwconv_fwd(P(Ad), P(Wd), P(Q), Mm, N, K, P(parts), 1, 0, 1, 0, S()))
+            ok(L().crnn_pwconv_fwd(P(Ad), P(Wd), P(Q), Mm, N, K, P(parts), 1, 0, 1, 0, 0, S()))
             q = host(Q)
             assert_close(q, ref, rtol=2e-5, atol=1e-4, what="pwconv bf16 products")
         else:
             Ad = _to_bf16_dev(A); Q = torch.zeros(Mm, N, dtype=torch.bfloat16, device="cuda")
-            ok(L().crnn_pwconv_fwd(P(Ad), P(Wd), P(Q), Mm, N, K, P(parts), 1, 1, 1, 1, S()))
+            ok(L().crnn_pwconv_fwd(P(Ad), P(Wd), P(Q), Mm, N, K, P(parts), 1, 1, 1, 1, 0, S()))
             q = _f(Q)
             assert_close(q, ref, rtol=2.0 ** -8, atol=1e-3, what="pwconv bf16 storage")
+            # the transposed-weight form (W^T made by crnn_transpose_batch) must give the very same stored result
+            WT = torch.zeros(N, K, dtype=torch.bfloat16, device="cuda"); Q2 = torch.zeros_like(Q); parts2 = zeros(rows, 2, N)
+            off = (ctypes.c_long * 1)(0); rr = (ctypes.c_int * 1)(K); cc = (ctypes.c_int * 1)(N)
+            ok(L().crnn_transpose_batch(P(dev(W)), P(WT), 1, off, off, rr, cc, 1, S()))
+            assert torch.equal(WT, Wd.t().contiguous())
+            ok(L().crnn_pwconv_fwd(P(Ad), P(WT), P(Q2), Mm, N, K, P(parts2), 1, 1, 1, 1, 1, S()))
+            assert_close(_f(Q2), q, rtol=2.0 ** -8, atol=1e-3, what="pwconv with W^T")
+            assert_close(host(parts2), host(parts), rtol=1e-3, atol=1e-2, what="stats with W^T")
     pr = host(parts).astype(np.float64)
     q64 = q.astype(np.float64)
     # the statistics are those of the STORED values, tile by tile (128 rows each)
