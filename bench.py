@@ -28,7 +28,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (not the 2:1-sparsity fig
 PEAK_HBM_GBS = 8000.0
 
 
-def depthwise_roofline(eng, iters=5):
+def depthwise_roofline(eng, iters=15):
     """Dominant kernel of the step (rocprofv3: largest total time) = dwconv_tile_kernel<0>: the depthwise 3x3 of
     blocks 2..7, forward (with the BatchNorm-statistics epilogue) and data-gradient (flipped taps) = 12 launches per
     step.  HBM-bound.  Re-issue exactly those launches on the live buffers between events on the launch stream.
