@@ -108,7 +108,7 @@ def pointwise_gemm_roofline(eng, iters=5):
     TB = T * B
     scratch = eng.ws_tensor("gemm_scratch")
     cfgs.append((eng.ws_tensor("x7"), W("dense1_w"), eng.ws_tensor("gA"), TB, eng.cfg.tds, feat, sdt, 0, 0))
-    u, G = eng.cfg.units, 4 * eng.cfg.units
+    u, G = eng.cfg.units, (3 if eng.cfg.gru else 4) * eng.cfg.units
     for n, src, k in (("rnn1f_w", "dn1", eng.cfg.tds), ("rnn1b_w", "dn1", eng.cfg.tds), ("rnn2f_w", "r1", u), ("rnn2b_w", "r1", u)):
         cfgs.append((eng.ws_tensor(src), W(n), eng.ws_tensor("gB"), TB, G, k, 0, 0, 0))
     flops = sum(2.0 * M * N * K for _, _, _, M, N, K, _, _, _ in cfgs)
@@ -168,6 +168,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE configs[1]: 256)")
     ap.add_argument("--precision", choices=["fp32", "bf16", "bf16s"], default="bf16s",
                     help="fp32 = parity mode (fp32 MFMA); bf16 = GEMM products in bf16, fp32 accumulate/storage")
+    ap.add_argument("--gru", action="store_true", help="GRU recurrence (what the reference's train.py really builds, SURVEY F3) instead of "
+                    "the LSTM BASELINE.json names")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -196,10 +198,10 @@ def main():
     from crnn_mi355x.parallel import GradAllReduce
 
     B = args.batch
-    cfg = M.Config()
+    cfg = M.Config(gru=args.gru)
     p, bn = M.init_params(cfg, seed=1, dtype=np.float32)         # identical weights on every rank
     x, lab, il, ll = M.synthetic_batch(cfg, B, seed=rank)        # rank r draws its own shard
-    eng = Engine(B, dropout=True, precision=args.precision)
+    eng = Engine(B, dropout=True, precision=args.precision, gru=args.gru)
     eng.set_params(p, bn)
     xd = torch.from_numpy(x).cuda()
     labd = torch.from_numpy(lab.astype(np.int32)).cuda(); ild = torch.from_numpy(il.astype(np.int32)).cuda()
@@ -233,7 +235,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 100x32x1 text lines, batch %d/GPU, max_len 23, time_dense_size 128, "
-                                   "n_units 256 BiLSTM, STN on, dropout on, CTC, Adam(1e-4,b1=.5,clipnorm 5), %s" % (B, {"fp32": "fp32 MFMA", "bf16": "bf16 MFMA products / fp32 accumulate+storage",
+                                   "n_units 256 %s, STN on, dropout on, CTC, Adam(1e-4,b1=.5,clipnorm 5), %s" % (B, "BiGRU" if args.gru else "BiLSTM", {"fp32": "fp32 MFMA", "bf16": "bf16 MFMA products / fp32 accumulate+storage",
                                        "bf16s": "bf16 MFMA products, bf16 conv-stack tensors in HBM, fp32 accumulate/statistics/RNN/optimizer"}[args.precision]),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": round(last_loss, 4)},
         }
