@@ -374,15 +374,15 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
   CRNN_TRY(gemm_t(c, 0, in, c.dt("x7"), c.p("dense1_w"), CRNN_F32, c.w("dn1"), CRNN_F32, TB, d.tds, d.feat, d.feat, d.tds, d.tds, c.p("dense1_b"), 1, 0, T));
   if (train && cfg->dropout) CRNN_TRY(crnn_dropout(c.w("dn1"), c.w("dn1"), TB, d.tds, d.tds, d.tds, kDropDense1, seed, kLayerDense1, stream));
   // ---- 2 x Bidirectional(LSTM) (utils.py:78-79)
-  // bf16 modes: the LSTM's recurrent products run on the bf16 MFMA from a bf16 U^T (u % 128 == 0); GRU / parity mode: fp32
-  const int dtu = (cfg->mfma_bf16 && !cfg->gru && u % 128 == 0) ? CRNN_BF16 : CRNN_F32;
+  // bf16 modes: the recurrent products run on the bf16 MFMA from a bf16 U^T (u % 128 == 0); parity mode: fp32
+  const int dtu = (cfg->mfma_bf16 && u % 128 == 0) ? CRNN_BF16 : CRNN_F32;
   for (const char* n : {"1f", "1b", "2f", "2b"})
     CRNN_TRY(crnn_transpose_ex(c.p(std::string("rnn") + n + "_u"), c.w(std::string("ut") + n), u, G, dtu, stream));
   CRNN_TRY(gemm(c, 0, c.w("dn1"), c.p("rnn1f_w"), c.w("xw1f"), TB, G, d.tds, d.tds, G, G, c.p("rnn1f_b")));
   CRNN_TRY(gemm(c, 0, c.w("dn1"), c.p("rnn1b_w"), c.w("xw1b"), TB, G, d.tds, d.tds, G, G, c.p("rnn1b_b")));
   if (cfg->gru)   // "cs" holds r*h_prev for the GRU (cell state for the LSTM)
-    CRNN_TRY(crnn_gru_fwd(c.w("xw1f"), c.w("xw1b"), c.w("ut1f"), c.w("ut1b"), c.w("h1f"), c.w("h1b"), u, c.w("gt1f"), c.w("gt1b"),
-                          c.w("cs1f"), c.w("cs1b"), T, B, u, stream));
+    CRNN_TRY(crnn_gru_fwd_ex(c.w("xw1f"), c.w("xw1b"), c.w("ut1f"), c.w("ut1b"), c.w("h1f"), c.w("h1b"), u, c.w("gt1f"), c.w("gt1b"),
+                             c.w("cs1f"), c.w("cs1b"), T, B, u, dtu, stream));
   else
     CRNN_TRY(crnn_lstm_fwd_ex(c.w("xw1f"), c.w("xw1b"), c.w("ut1f"), c.w("ut1b"), c.w("h1f"), c.w("h1b"), u, c.w("cs1f"), c.w("cs1b"),
                               c.w("gt1f"), c.w("gt1b"), T, B, u, dtu, stream));
@@ -390,8 +390,8 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
   CRNN_TRY(gemm(c, 0, c.w("r1"), c.p("rnn2f_w"), c.w("xw2f"), TB, G, u, u, G, G, c.p("rnn2f_b")));
   CRNN_TRY(gemm(c, 0, c.w("r1"), c.p("rnn2b_w"), c.w("xw2b"), TB, G, u, u, G, G, c.p("rnn2b_b")));
   if (cfg->gru)
-    CRNN_TRY(crnn_gru_fwd(c.w("xw2f"), c.w("xw2b"), c.w("ut2f"), c.w("ut2b"), c.w("h2"), c.w("h2") + u, 2 * u, c.w("gt2f"), c.w("gt2b"),
-                          c.w("cs2f"), c.w("cs2b"), T, B, u, stream));
+    CRNN_TRY(crnn_gru_fwd_ex(c.w("xw2f"), c.w("xw2b"), c.w("ut2f"), c.w("ut2b"), c.w("h2"), c.w("h2") + u, 2 * u, c.w("gt2f"), c.w("gt2b"),
+                             c.w("cs2f"), c.w("cs2b"), T, B, u, dtu, stream));
   else
     CRNN_TRY(crnn_lstm_fwd_ex(c.w("xw2f"), c.w("xw2b"), c.w("ut2f"), c.w("ut2b"), c.w("h2"), c.w("h2") + u, 2 * u, c.w("cs2f"), c.w("cs2b"),
                               c.w("gt2f"), c.w("gt2b"), T, B, u, dtu, stream));    // merge_mode='concat'
@@ -417,10 +417,13 @@ static int lstm_layer_bwd(const Ctx& c, int layer, const float* xin, int ldx, in
   const int T = d.T, B = d.B, TB = T * B, u = d.u, G = d.G;
   std::string l = std::to_string(layer);
   float* dzf = c.w("dz" + l + "f"); float* dzb = c.w("dz" + l + "b");
-  if (c.cfg->gru)
-    CRNN_TRY(crnn_gru_bwd(c.p("rnn" + l + "f_u"), c.p("rnn" + l + "b_u"), hf, hb, ldh, c.w("gt" + l + "f"), c.w("gt" + l + "b"), doutf, doutb,
-                          ldo, dzf, dzb, c.w("dcf"), c.w("dcb"), c.w("dhpf"), c.w("dhpb"), T, B, u, c.s));
-  else
+  if (c.cfg->gru) {
+    int dtu = CRNN_F32;
+    const float* uf = c.p("rnn" + l + "f_u"); const float* ub = c.p("rnn" + l + "b_u");
+    if (c.cfg->mfma_bf16 && u % 128 == 0) { uf = weight_operand(c, 0, uf, &dtu); ub = weight_operand(c, 0, ub, &dtu); }
+    CRNN_TRY(crnn_gru_bwd_ex(uf, ub, hf, hb, ldh, c.w("gt" + l + "f"), c.w("gt" + l + "b"), doutf, doutb,
+                             ldo, dzf, dzb, c.w("dcf"), c.w("dcb"), c.w("dhpf"), c.w("dhpb"), T, B, u, dtu, c.s));
+  } else
   {
     // bf16 modes: U [u][4u] is read from the bf16 shadow of the parameter buffer (refreshed by the forward)
     int dtu = CRNN_F32;

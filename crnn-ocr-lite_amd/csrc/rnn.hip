@@ -369,6 +369,7 @@ struct GruDir {
   const bool valid[1] = {valid1};                                                                    \
   const int ar = valid1 ? b0 + r : 0
 
+template <bool WBF>
 __global__ __launch_bounds__(256) void gru_fwd_zr_kernel(GruDir d0, GruDir d1, int s, int T, int B, int u, int SJ) {
   __shared__ float red[4][2][256];
   STEP_TILE();
@@ -376,8 +377,14 @@ __global__ __launch_bounds__(256) void gru_fwd_zr_kernel(GruDir d0, GruDir d1, i
   const int dir = st.dir, t = dir ? T - 1 - s : s, tp = dir ? t + 1 : t - 1;
   STEP_IDS();
   const float* arow[1] = {d.h + ((long)(s > 0 ? tp : t) * B + ar) * d.ldh};
-  const float* brow[2] = {d.w + (long)(j0 + r) * u, d.w + (long)(u + j0 + r) * u};
-  step_tile_gemm<2, 4>(arow, valid, brow, u, s == 0, red, wave, r, q);
+  if constexpr (WBF) {
+    const bf16_t* wb = reinterpret_cast<const bf16_t*>(d.w);
+    const bf16_t* brow[2] = {wb + (long)(j0 + r) * u, wb + (long)(u + j0 + r) * u};
+    step_tile_gemm_bf16<2, 2>(arow, valid, brow, u, s == 0, red, wave, r, q);
+  } else {
+    const float* brow[2] = {d.w + (long)(j0 + r) * u, d.w + (long)(u + j0 + r) * u};
+    step_tile_gemm<2, 4>(arow, valid, brow, u, s == 0, red, wave, r, q);
+  }
   if (b < B) {
     const float* xw = d.xw + ((long)t * B + b) * 3 * u;
     float zz = ((red[0][0][tid] + red[1][0][tid]) + (red[2][0][tid] + red[3][0][tid])) + xw[j];
@@ -390,6 +397,7 @@ __global__ __launch_bounds__(256) void gru_fwd_zr_kernel(GruDir d0, GruDir d1, i
   }
 }
 
+template <bool WBF>
 __global__ __launch_bounds__(256) void gru_fwd_h_kernel(GruDir d0, GruDir d1, int s, int T, int B, int u, int SJ) {
   __shared__ float red[4][1][256];
   STEP_TILE();
@@ -397,8 +405,13 @@ __global__ __launch_bounds__(256) void gru_fwd_h_kernel(GruDir d0, GruDir d1, in
   const int dir = st.dir, t = dir ? T - 1 - s : s, tp = dir ? t + 1 : t - 1;
   STEP_IDS();
   const float* arow[1] = {d.rh + ((long)t * B + ar) * u};
-  const float* brow[1] = {d.w + (long)(2 * u + j0 + r) * u};
-  step_tile_gemm<1, 4>(arow, valid, brow, u, s == 0, red, wave, r, q);
+  if constexpr (WBF) {
+    const bf16_t* brow[1] = {reinterpret_cast<const bf16_t*>(d.w) + (long)(2 * u + j0 + r) * u};
+    step_tile_gemm_bf16<1, 2>(arow, valid, brow, u, s == 0, red, wave, r, q);
+  } else {
+    const float* brow[1] = {d.w + (long)(2 * u + j0 + r) * u};
+    step_tile_gemm<1, 4>(arow, valid, brow, u, s == 0, red, wave, r, q);
+  }
   if (b < B) {
     float* gt = d.gates + ((long)t * B + b) * 3 * u;
     float pre = ((red[0][0][tid] + red[1][0][tid]) + (red[2][0][tid] + red[3][0][tid])) + d.xw[((long)t * B + b) * 3 * u + 2 * u + j];
@@ -409,6 +422,7 @@ __global__ __launch_bounds__(256) void gru_fwd_h_kernel(GruDir d0, GruDir d1, in
   }
 }
 
+template <bool WBF>
 __global__ __launch_bounds__(256) void gru_bwd_b_kernel(GruDir d0, GruDir d1, int sb, int T, int B, int u, int SJ) {
   __shared__ float red[4][1][256];
   STEP_TILE();
@@ -417,8 +431,13 @@ __global__ __launch_bounds__(256) void gru_bwd_b_kernel(GruDir d0, GruDir d1, in
   const int tnext = dir ? t - 1 : t + 1, tprev = dir ? t + 1 : t - 1;
   STEP_IDS();
   const float* arow[1] = {d.dz + ((long)(sb > 0 ? tnext : t) * B + ar) * 3 * u};
-  const float* brow[1] = {d.w + (long)(j0 + r) * 3 * u};
-  step_tile_gemm<1, 8>(arow, valid, brow, 2 * u, sb == 0, red, wave, r, q);
+  if constexpr (WBF) {
+    const bf16_t* brow[1] = {reinterpret_cast<const bf16_t*>(d.w) + (long)(j0 + r) * 3 * u};
+    step_tile_gemm_bf16<1, 4>(arow, valid, brow, 2 * u, sb == 0, red, wave, r, q);
+  } else {
+    const float* brow[1] = {d.w + (long)(j0 + r) * 3 * u};
+    step_tile_gemm<1, 8>(arow, valid, brow, 2 * u, sb == 0, red, wave, r, q);
+  }
   if (b < B) {
     float dh = d.dout[((long)t * B + b) * d.ldo + j];
     if (sb > 0) dh += ((red[0][0][tid] + red[1][0][tid]) + (red[2][0][tid] + red[3][0][tid])) + d.dhp[(long)b * u + j];
@@ -432,6 +451,7 @@ __global__ __launch_bounds__(256) void gru_bwd_b_kernel(GruDir d0, GruDir d1, in
   }
 }
 
+template <bool WBF>
 __global__ __launch_bounds__(256) void gru_bwd_a_kernel(GruDir d0, GruDir d1, int sb, int T, int B, int u, int SJ) {
   __shared__ float red[4][1][256];
   STEP_TILE();
@@ -440,8 +460,13 @@ __global__ __launch_bounds__(256) void gru_bwd_a_kernel(GruDir d0, GruDir d1, in
   const int tprev = dir ? t + 1 : t - 1;
   STEP_IDS();
   const float* arow[1] = {d.dz + ((long)t * B + ar) * 3 * u + 2 * u};
-  const float* brow[1] = {d.w + (long)(j0 + r) * 3 * u + 2 * u};
-  step_tile_gemm<1, 4>(arow, valid, brow, u, false, red, wave, r, q);
+  if constexpr (WBF) {
+    const bf16_t* brow[1] = {reinterpret_cast<const bf16_t*>(d.w) + (long)(j0 + r) * 3 * u + 2 * u};
+    step_tile_gemm_bf16<1, 2>(arow, valid, brow, u, false, red, wave, r, q);
+  } else {
+    const float* brow[1] = {d.w + (long)(j0 + r) * 3 * u + 2 * u};
+    step_tile_gemm<1, 4>(arow, valid, brow, u, false, red, wave, r, q);
+  }
   if (b < B) {
     float drh = (red[0][0][tid] + red[1][0][tid]) + (red[2][0][tid] + red[3][0][tid]);
     const float* gt = d.gates + ((long)t * B + b) * 3 * u;
@@ -454,38 +479,59 @@ __global__ __launch_bounds__(256) void gru_bwd_a_kernel(GruDir d0, GruDir d1, in
 
 // Forward recurrence of one Bidirectional(GRU) layer.  xw[d] [T][B][3u] (x*W+b), ut[d] = U^T [3u][u], h[d] (row
 // stride ldh), gates[d] [T][B][3u], rh[d] [T][B][u].  2T launches.
-extern "C" int crnn_gru_fwd(const float* xw0, const float* xw1, const float* ut0, const float* ut1, float* h0, float* h1,
-                            int ldh, float* g0, float* g1, float* rh0, float* rh1, int T, int B, int u, hipStream_t stream) {
+extern "C" int crnn_gru_fwd_ex(const float* xw0, const float* xw1, const void* ut0, const void* ut1, float* h0, float* h1,
+                               int ldh, float* g0, float* g1, float* rh0, float* rh1, int T, int B, int u, int dt_u, hipStream_t stream) {
   CRNN_TRY(check_units(u));
   if (ldh % 4 != 0) return CRNN_ERR_ARG;
-  GruDir a{xw0, ut0, h0, ldh, g0, rh0, nullptr, 0, nullptr, nullptr, nullptr};
-  GruDir b{xw1, ut1, h1, ldh, g1, rh1, nullptr, 0, nullptr, nullptr, nullptr};
+  if (dt_u == CRNN_BF16 && (u % 128 != 0 || ((uintptr_t)ut0 | (uintptr_t)ut1) & 15)) return CRNN_ERR_UNSUPPORTED;
+  GruDir a{xw0, (const float*)ut0, h0, ldh, g0, rh0, nullptr, 0, nullptr, nullptr, nullptr};
+  GruDir b{xw1, (const float*)ut1, h1, ldh, g1, rh1, nullptr, 0, nullptr, nullptr, nullptr};
   const int SJ = step_sj(u / 16);
   dim3 grid(step_grid(u / 16, cdiv(B, 16), SJ));
   for (int s = 0; s < T; ++s) {
-    hipLaunchKernelGGL(gru_fwd_zr_kernel, grid, dim3(256), 0, stream, a, b, s, T, B, u, SJ);
-    hipLaunchKernelGGL(gru_fwd_h_kernel, grid, dim3(256), 0, stream, a, b, s, T, B, u, SJ);
+    if (dt_u == CRNN_BF16) {
+      hipLaunchKernelGGL(gru_fwd_zr_kernel<true>, grid, dim3(256), 0, stream, a, b, s, T, B, u, SJ);
+      hipLaunchKernelGGL(gru_fwd_h_kernel<true>, grid, dim3(256), 0, stream, a, b, s, T, B, u, SJ);
+    } else {
+      hipLaunchKernelGGL(gru_fwd_zr_kernel<false>, grid, dim3(256), 0, stream, a, b, s, T, B, u, SJ);
+      hipLaunchKernelGGL(gru_fwd_h_kernel<false>, grid, dim3(256), 0, stream, a, b, s, T, B, u, SJ);
+    }
   }
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
+extern "C" int crnn_gru_fwd(const float* xw0, const float* xw1, const float* ut0, const float* ut1, float* h0, float* h1,
+                            int ldh, float* g0, float* g1, float* rh0, float* rh1, int T, int B, int u, hipStream_t stream) {
+  return crnn_gru_fwd_ex(xw0, xw1, ut0, ut1, h0, h1, ldh, g0, g1, rh0, rh1, T, B, u, CRNN_F32, stream);
+}
 
 // BPTT of one Bidirectional(GRU) layer: fills dz[d] [T][B][3u] (gradients w.r.t. the z, r, hh pre-activations).
 // u_[d] = U [u][3u]; h[d] as in the forward; dh[d], dhp[d] = [B][u] scratch.
-extern "C" int crnn_gru_bwd(const float* u0, const float* u1, const float* h0, const float* h1, int ldh, const float* g0,
-                            const float* g1, const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1,
-                            float* dh0, float* dh1, float* dhp0, float* dhp1, int T, int B, int u, hipStream_t stream) {
+extern "C" int crnn_gru_bwd_ex(const void* u0, const void* u1, const float* h0, const float* h1, int ldh, const float* g0,
+                               const float* g1, const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1,
+                               float* dh0, float* dh1, float* dhp0, float* dhp1, int T, int B, int u, int dt_u, hipStream_t stream) {
   CRNN_TRY(check_units(u));
-  GruDir a{nullptr, u0, const_cast<float*>(h0), ldh, const_cast<float*>(g0), nullptr, dout0, ldo, dz0, dh0, dhp0};
-  GruDir b{nullptr, u1, const_cast<float*>(h1), ldh, const_cast<float*>(g1), nullptr, dout1, ldo, dz1, dh1, dhp1};
+  if (dt_u == CRNN_BF16 && (u % 128 != 0 || ((uintptr_t)u0 | (uintptr_t)u1) & 15)) return CRNN_ERR_UNSUPPORTED;
+  GruDir a{nullptr, (const float*)u0, const_cast<float*>(h0), ldh, const_cast<float*>(g0), nullptr, dout0, ldo, dz0, dh0, dhp0};
+  GruDir b{nullptr, (const float*)u1, const_cast<float*>(h1), ldh, const_cast<float*>(g1), nullptr, dout1, ldo, dz1, dh1, dhp1};
   const int SJ = step_sj(u / 16) > 2 ? 2 : step_sj(u / 16);
   dim3 grid(step_grid(u / 16, cdiv(B, 16), SJ));
   for (int sb = 0; sb < T; ++sb) {
-    hipLaunchKernelGGL(gru_bwd_b_kernel, grid, dim3(256), 0, stream, a, b, sb, T, B, u, SJ);
-    hipLaunchKernelGGL(gru_bwd_a_kernel, grid, dim3(256), 0, stream, a, b, sb, T, B, u, SJ);
+    if (dt_u == CRNN_BF16) {
+      hipLaunchKernelGGL(gru_bwd_b_kernel<true>, grid, dim3(256), 0, stream, a, b, sb, T, B, u, SJ);
+      hipLaunchKernelGGL(gru_bwd_a_kernel<true>, grid, dim3(256), 0, stream, a, b, sb, T, B, u, SJ);
+    } else {
+      hipLaunchKernelGGL(gru_bwd_b_kernel<false>, grid, dim3(256), 0, stream, a, b, sb, T, B, u, SJ);
+      hipLaunchKernelGGL(gru_bwd_a_kernel<false>, grid, dim3(256), 0, stream, a, b, sb, T, B, u, SJ);
+    }
   }
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
+}
+extern "C" int crnn_gru_bwd(const float* u0, const float* u1, const float* h0, const float* h1, int ldh, const float* g0,
+                            const float* g1, const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1,
+                            float* dh0, float* dh1, float* dhp0, float* dhp1, int T, int B, int u, hipStream_t stream) {
+  return crnn_gru_bwd_ex(u0, u1, h0, h1, ldh, g0, g1, dout0, dout1, ldo, dz0, dz1, dh0, dh1, dhp0, dhp1, T, B, u, CRNN_F32, stream);
 }
 
 // out[c][r] = in[r][c]  (U -> U^T once per weight update; tiny); TO = float or bf16_t

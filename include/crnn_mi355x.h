@@ -200,6 +200,12 @@ int crnn_gru_fwd(const float* xw0, const float* xw1, const float* ut0, const flo
 int crnn_gru_bwd(const float* u0, const float* u1, const float* h0, const float* h1, int ldh, const float* g0,
                  const float* g1, const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1, float* dh0,
                  float* dh1, float* dhp0, float* dhp1, int T, int B, int u, crnn_stream_t stream);
+/* dt_u as for crnn_lstm_*_ex (1 = bf16 recurrent weights, products on the bf16 MFMA; u % 128 == 0) */
+int crnn_gru_fwd_ex(const float* xw0, const float* xw1, const void* ut0, const void* ut1, float* h0, float* h1, int ldh,
+                    float* g0, float* g1, float* rh0, float* rh1, int T, int B, int u, int dt_u, crnn_stream_t stream);
+int crnn_gru_bwd_ex(const void* u0, const void* u1, const float* h0, const float* h1, int ldh, const float* g0,
+                    const float* g1, const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1, float* dh0,
+                    float* dh1, float* dhp0, float* dhp1, int T, int B, int u, int dt_u, crnn_stream_t stream);
 int crnn_transpose(const float* in, float* out, int R, int C, crnn_stream_t stream);
 int crnn_transpose_ex(const float* in, void* out, int R, int C, int dt_out, crnn_stream_t stream);   /* dt_out 1: bf16 result */
 /* softmax + CTC (utils.py:86, 98-103) */

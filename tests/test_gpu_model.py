@@ -360,3 +360,28 @@ def test_full_size_batch256_properties(precision):
     assert torch.equal(l1, l2) and torch.equal(g1, big.grads)
     lh = l1.cpu().numpy()
     assert np.isfinite(lh).all() and (lh > 0).all() and np.isfinite(g1.cpu().numpy()).all()
+
+
+def test_bf16s_gru_variant_tracks_the_fp32_oracle():
+    """The GRU recurrence (what the reference's train.py builds) in the throughput mode: recurrent products on the bf16
+    MFMA from bf16 U copies.  Same acceptance as the LSTM variant: forward within bf16 round-off, gradients of the upper
+    layers pointing the same way as the fp64 oracle's."""
+    cfg = M.Config(gru=True)
+    B = 8
+    p, bn = M.init_params(cfg, seed=17, dtype=np.float64)
+    p = M.randomize_params(cfg, p)
+    x, lab, il, ll = M.synthetic_batch(cfg, B, seed=3, dtype=np.float64)
+    eng = Engine(B, dropout=False, precision="bf16s", gru=True)
+    eng.set_params(p, bn)
+    yd = eng.forward(x.astype(np.float32), train=True, seed=0).cpu().numpy()
+    loss_d = eng.backward(lab, il, ll, seed=0).cpu().numpy()
+    gd = eng.get_grads()
+    loss, loss_b, g, c = M.loss_and_grads(cfg, p, bn, x, lab, il, ll)
+    agree = (np.argmax(yd, -1) == np.argmax(c["y_pred"], -1)).mean()
+    rel_loss = np.abs(loss_d - loss_b).max() / np.abs(loss_b).max()
+    cos = {k: float((gd[k].ravel() @ g[k].ravel()) / (np.linalg.norm(gd[k]) * np.linalg.norm(g[k]) + 1e-30)) for k in p if g[k].size >= 512}
+    print("[bf16s gru] max|dy|=%.3e agreement=%.4f rel loss err=%.3e" % (np.abs(yd - c["y_pred"]).max(), agree, rel_loss),
+          " ".join("%s:%.3f" % kv for kv in cos.items() if kv[0].startswith(("rnn", "dense"))))
+    assert np.abs(yd - c["y_pred"]).max() < 5e-2 and agree > 0.93 and rel_loss < 2e-2
+    for k in ("dense2_w", "rnn2f_w", "rnn2b_u", "rnn1f_u", "rnn1f_w", "dense1_w"):
+        assert cos[k] > 0.95, (k, cos[k])
