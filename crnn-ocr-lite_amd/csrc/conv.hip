@@ -1,16 +1,17 @@
-// Depthwise-separable conv stack kernels (utils.py:43-56, 64-70), NHWC, fp32.
-//   depthwise 3x3 'same' (fwd, data-grad = same kernel with flipped taps, weight-grad) with the
-//   (TH+2) x (W+2) x 32-channel halo tile staged in LDS, 16 B/lane channel-vectorised HBM access and
-//   the BatchNorm batch statistics (sum, sum-of-squares) produced as a deterministic per-tile partial;
-//   BatchNorm finalize / apply(+ReLU6 +MaxPool +Dropout) / backward (two-pass reduce + apply);
-//   generic column reductions.
+// Depthwise-separable conv stack kernels (utils.py:43-56, 64-70), NHWC; tensors stored as fp32 or bf16 (CRNN_F32 /
+// CRNN_BF16, chosen per call), arithmetic and statistics always fp32.
+//   depthwise 3x3 'same' (fwd, data-grad = same kernel with flipped taps, weight-grad): the (TH+2) x (TW+2) halo tile of
+//   one 128-byte channel slab is staged in LDS with 16-byte loads, each thread produces 3 adjacent pixels from one 3x5
+//   window, and the BatchNorm batch statistics (or the 9 tap gradients) leave as a deterministic per-tile partial;
+//   BatchNorm finalize / apply(+ReLU6 +MaxPool +Dropout) / backward (two-pass reduce + apply), 16-byte vectors;
+//   generic column reductions and the second-stage (double) reductions.
 // All kernels are HBM-bandwidth bound; the pointwise 1x1 convs go through gemm.hip.
 #include "common.h"
 #include <stdlib.h>
 
 #define BN_EPS 1e-3f
 #ifndef DW_NT
-#define DW_NT 256   // threads per depthwise workgroup (8 channel-quads x DW_NT/8 pixel threads)
+#define DW_NT 256   // threads per depthwise workgroup
 #endif
 
 // VEC consecutive channels of one pixel, widened to fp32 (VEC = 1, 4 or 8; 8 = one 16-byte access of bf16 storage)
