@@ -103,7 +103,10 @@ template <int MODE, int NT, typename T>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void dwconv_tile_kernel(const T* __restrict__ x, const float* __restrict__ k,
                                                           const T* __restrict__ g, T* __restrict__ out,
                                                           float* __restrict__ partials, int B, int H, int W, int C,
-                                                          int TH, int TW, int flip) {
+                                                          int TH, int TW, int flip, const float* __restrict__ bnstate) {
+  // MODE 0: out = conv (+ statistics partials)   MODE 1: weight-gradient partials
+  // MODE 2: out = ReLU6(conv * scale + shift) with bnstate = [mean|var|scale|shift] (inference: BatchNorm folded in)
+  constexpr bool FWD = (MODE != 1);
   typedef typename RawV<T>::type V;
   constexpr int VN = RawV<T>::N;              // channels per lane
   constexpr int CL = 128 / sizeof(V);         // lanes per pixel (the 128-B slab)
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void dw
     }
   }
   float kw[9][VN];
-  if (MODE == 0) {
+  if (FWD) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       int ts = flip ? 8 - t : t;
@@ -158,6 +161,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void dw
 #pragma unroll
       for (int e = 0; e < VN; ++e) kw[t][e] = w.v[e];
     }
+  }
+  float bsc[VN], bsh[VN];
+  if (MODE == 2) {
+    VecF<VN> v1 = vload<VN>(&bnstate[2 * C + cc0 + VN * c4]), v2 = vload<VN>(&bnstate[3 * C + cc0 + VN * c4]);
+#pragma unroll
+    for (int e = 0; e < VN; ++e) { bsc[e] = v1.v[e]; bsh[e] = v2.v[e]; }
   }
   __syncthreads();
   float s[VN], ss[VN], dk[9][VN];
@@ -206,15 +215,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void dw
         for (int j = 0; j < 3; ++j)
 #pragma unroll
           for (int c = 0; c < VN; ++c) {
-            if (MODE == 0) a[e][c] = fmaf(r[e + j][c], kw[i * 3 + j][c], a[e][c]);
+            if (FWD) a[e][c] = fmaf(r[e + j][c], kw[i * 3 + j][c], a[e][c]);
             else dk[i * 3 + j][c] = fmaf(r[e + j][c], gv[e][c], dk[i * 3 + j][c]);
           }
       __builtin_amdgcn_sched_barrier(0);   // one window row at a time: keeps the live set under the 3-waves/SIMD budget
     }
-    if (MODE == 0) {
+    if (FWD) {
 #pragma unroll
       for (int e = 0; e < PXB; ++e)
         if (lx + e < TW && w0 + lx + e < W) {
+          if (MODE == 2) {
+#pragma unroll
+            for (int c = 0; c < VN; ++c) a[e][c] = relu6f(fmaf(a[e][c], bsc[c], bsh[c]));
+          }
           narrow_store(ob + o + e * C, a[e]);
           if (partials != nullptr) {
 #pragma unroll
@@ -225,13 +238,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void dw
     lg += dlg; ly += dly;
     if (lg >= gpr) { lg -= gpr; ++ly; }
   }
-  if (partials == nullptr) return;
+  if (partials == nullptr || MODE == 2) return;
   // per-tile partials: the 8 pixel-threads of each wave are combined with lane shuffles, the NT/64 waves through LDS
   __syncthreads();  // tile no longer needed
-  constexpr int NW = NT / 64, NV = (MODE == 0) ? 2 : 9;
+  constexpr int NW = NT / 64, NV = FWD ? 2 : 9;
   float* red = smem;   // [NW][NV][CL][VN]
   const int wave = tid >> 6, lane = tid & 63;
-  if (MODE == 0) {
+  if (FWD) {
 #pragma unroll
     for (int e = 0; e < VN; ++e) { s[e] = pixlane_sum<CL>(s[e]); ss[e] = pixlane_sum<CL>(ss[e]); }
     if (lane < CL) {
@@ -369,14 +382,15 @@ extern "C" int crnn_dwconv_num_tiles(int B, int H, int W) {
 // dtype: storage of x/out (CRNN_F32 | CRNN_BF16); arithmetic and statistics are fp32 either way.
 template <typename T>
 static int dwconv_fwd_launch(const T* x, const float* k, T* out, float* stat_partials, int B, int H, int W, int C, int flip,
-                             hipStream_t stream) {
+                             hipStream_t stream, const float* bnstate = nullptr) {
   DwTile t = dw_pick_tile(H, W);
   if (t.lds > 160 * 1024) return CRNN_ERR_UNSUPPORTED;
   if (t.lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_tile_kernel<0, DW_NT, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const int slab = 128 / (int)sizeof(T);   // channels per workgroup: 32 (fp32) or 64 (bf16)
   if (C % slab) return CRNN_ERR_UNSUPPORTED;
   dim3 grid(C / slab, B * t.nHb * t.nWb);
-  hipLaunchKernelGGL((dwconv_tile_kernel<0, DW_NT, T>), grid, dim3(DW_NT), t.lds, stream, x, k, (const T*)nullptr, out, stat_partials, B, H, W, C, t.TH, t.TW, flip);
+  if (bnstate) hipLaunchKernelGGL((dwconv_tile_kernel<2, DW_NT, T>), grid, dim3(DW_NT), t.lds, stream, x, k, (const T*)nullptr, out, (float*)nullptr, B, H, W, C, t.TH, t.TW, flip, bnstate);
+  else hipLaunchKernelGGL((dwconv_tile_kernel<0, DW_NT, T>), grid, dim3(DW_NT), t.lds, stream, x, k, (const T*)nullptr, out, stat_partials, B, H, W, C, t.TH, t.TW, flip, (const float*)nullptr);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
@@ -393,6 +407,14 @@ extern "C" int crnn_dwconv3x3_fwd_ex(const void* x, const float* k, void* out, f
   hipLaunchKernelGGL(dwconv_naive_kernel<0>, dim3(blocks), dim3(256), 0, stream, (const float*)x, k, nullptr, (float*)out, B, H, W, C, flip);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
+}
+// Inference form: out = ReLU6(BatchNorm(dwconv3x3(x, k))) with the normalisation folded into the conv's epilogue
+// (bnstate = [mean|var|scale|shift] from crnn_bn_infer_state); C % (128 / sizeof(storage)) == 0 only.
+extern "C" int crnn_dwconv3x3_bn_relu6_fwd(const void* x, const float* k, const float* bnstate, void* out, int B, int H, int W, int C,
+                                           int dtype, hipStream_t stream) {
+  if (!bnstate) return CRNN_ERR_ARG;
+  if (dtype == CRNN_BF16) return dwconv_fwd_launch<bf16_t>((const bf16_t*)x, k, (bf16_t*)out, nullptr, B, H, W, C, 0, stream, bnstate);
+  return dwconv_fwd_launch<float>((const float*)x, k, (float*)out, nullptr, B, H, W, C, 0, stream, bnstate);
 }
 extern "C" int crnn_dwconv3x3_fwd(const float* x, const float* k, float* out, float* stat_partials, int B, int H, int W,
                                   int C, int flip, hipStream_t stream) {
@@ -537,7 +559,7 @@ static int dwconv_wgrad_launch(const T* x, const T* g, float* dk, float* scratch
   const int slab = 128 / (int)sizeof(T);
   if (C % slab) return CRNN_ERR_UNSUPPORTED;
   dim3 grid(C / slab, ntiles);
-  hipLaunchKernelGGL((dwconv_tile_kernel<1, DW_NT, T>), grid, dim3(DW_NT), t.lds, stream, x, (const float*)nullptr, g, (T*)nullptr, scratch, B, H, W, C, t.TH, t.TW, 0);
+  hipLaunchKernelGGL((dwconv_tile_kernel<1, DW_NT, T>), grid, dim3(DW_NT), t.lds, stream, x, (const float*)nullptr, g, (T*)nullptr, scratch, B, H, W, C, t.TH, t.TW, 0, (const float*)nullptr);
   CRNN_LAUNCH_CHECK();
   return crnn_partials_sum(scratch, ntiles, 9 * C, dk, 1.f, stream);
 }

@@ -32,6 +32,7 @@ struct GemmParams {
   int dtA, dtB, dtC;  // storage of the operands / result (CRNN_F32 | CRNN_BF16); the fp32 kernel requires all CRNN_F32
   int tilesN;
   float* stats;    // optional [tilesM][2][N]: per-tile column sums / sums of squares of the result as stored (BatchNorm statistics)
+  const float* cscale; const float* cshift;   // optional per-column epilogue  C = ReLU6(C * cscale[n] + cshift[n])  (inference BatchNorm folded in)
 };
 
 // ---- statistics epilogue: per-tile column sums / sums of squares of the result as it will be stored, taken straight
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             if (gn + e < p.N) {
               if (p.bias) vv[e] += p.bias[gn + e];
               if (p.act == 1) vv[e] = fmaxf(vv[e], 0.f);
+              if (p.cscale) vv[e] = relu6f(fmaf(vv[e], p.cscale[gn + e], p.cshift[gn + e]));
             }
         }
         if (vecC && gn + 3 < p.N) {
@@ -313,12 +315,13 @@ static inline int aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; 
 // (mode 2 with few output tiles); pass nullptr/0 to forbid splitting.
 static int gemm_f32_impl(int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
                          int ldc, const float* bias, int act, int accumulate, int permP, float* scratch,
-                         size_t scratch_bytes, float* stats, hipStream_t stream) {
+                         size_t scratch_bytes, float* stats, hipStream_t stream, const float* cscale = nullptr, const float* cshift = nullptr) {
   if (M <= 0 || N <= 0 || K <= 0) return CRNN_ERR_ARG;
   if (permP && (M % permP) != 0) return CRNN_ERR_ARG;
-  if (stats && (bias || act || accumulate || permP || scratch)) return CRNN_ERR_ARG;   // statistics of the plain product only
+  if (stats && (bias || act || accumulate || permP || scratch || cscale)) return CRNN_ERR_ARG;   // statistics of the plain product only
+  if (cscale && (scratch || accumulate || !cshift)) return CRNN_ERR_ARG;                          // no split reduction with the folded BatchNorm
   GemmParams p;
-  p.stats = stats;
+  p.stats = stats; p.cscale = cscale; p.cshift = cshift;
   p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.bias = bias; p.act = act; p.accumulate = accumulate; p.permP = permP;
   p.dtA = p.dtB = p.dtC = CRNN_F32;
@@ -378,13 +381,16 @@ extern "C" int crnn_gemm_f32(int mode, const float* A, const float* B, float* C,
 // ---- pointwise 1x1 convolution = GEMM over the pixels, with the next BatchNorm's statistics from the epilogue
 extern "C" int crnn_pwconv_stat_rows(long M) { return cdiv(M, 128); }
 extern "C" int crnn_pwconv_fwd(const void* a, const void* w, void* q, long M, int N, int K, float* stat_partials,
-                               int bf16_products, int dt_a, int dt_w, int dt_q, int w_transposed, hipStream_t stream) {
+                               const float* out_bnstate, int bf16_products, int dt_a, int dt_w, int dt_q, int w_transposed,
+                               hipStream_t stream) {
   if (M <= 0 || M > 0x7fffffffL) return CRNN_ERR_ARG;
   // w_transposed: the weights are given as W^T [N][K] (both operands then contiguous along the reduction: the staging
   // needs no k-pair interleave and the fragments are single 16-byte LDS reads)
   const int mode = w_transposed ? 1 : 0, ldw = w_transposed ? K : N;
+  // out_bnstate ([mean|var|scale|shift] of the BatchNorm after the conv, inference): q = ReLU6(product * scale + shift)
+  const float* cs = out_bnstate ? out_bnstate + 2L * N : nullptr; const float* ch = out_bnstate ? out_bnstate + 3L * N : nullptr;
   if (bf16_products)
-    return gemm_bf16_impl(mode, a, w, q, (int)M, N, K, K, ldw, N, nullptr, 0, 0, 0, nullptr, 0, dt_a, dt_w, dt_q, stat_partials, stream);
+    return gemm_bf16_impl(mode, a, w, q, (int)M, N, K, K, ldw, N, nullptr, 0, 0, 0, nullptr, 0, dt_a, dt_w, dt_q, stat_partials, stream, cs, ch);
   if (dt_a != CRNN_F32 || dt_w != CRNN_F32 || dt_q != CRNN_F32) return CRNN_ERR_ARG;
-  return gemm_f32_impl(mode, (const float*)a, (const float*)w, (float*)q, (int)M, N, K, K, ldw, N, nullptr, 0, 0, 0, nullptr, 0, stat_partials, stream);
+  return gemm_f32_impl(mode, (const float*)a, (const float*)w, (float*)q, (int)M, N, K, K, ldw, N, nullptr, 0, 0, 0, nullptr, 0, stat_partials, stream, cs, ch);
 }

@@ -337,35 +337,56 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
     float* s1 = c.w("bn1s" + p); float* s2 = c.w("bn2s" + p);
     float* parts = c.w("partials");
     const int dtd = c.dt("d" + p), dtq = c.dt("q" + p);
-    if (ci % 32 == 0) {
-      CRNN_TRY(crnn_dwconv3x3_fwd_ex(in, c.p(bp + "_dw"), dd, train ? parts : nullptr, B, H, W, ci, 0, dtd, stream));
-      if (train) CRNN_TRY(crnn_bn_finalize_folded(parts, crnn_dwconv_num_tiles(B, H, W), ci, M, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), s1, c.w("fold"), stream));
+    const int ph = kBlocks[i - 1].ph, pw = kBlocks[i - 1].pw;
+    const int slab = (dtd == CRNN_BF16) ? 64 : 32;
+    if (!train) {
+      // inference (learning_phase 0): the BatchNorm scale/shift are known up front, so BN + ReLU6 fold into the
+      // epilogue of the conv that feeds them -- the depthwise kernel writes `a` directly and, when the block has no
+      // pooling, the pointwise GEMM writes the block output directly: two passes per block instead of four
+      CRNN_TRY(crnn_bn_infer_state(bn_mean + bn_off, bn_var + bn_off, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), ci, s1, stream));
+      bn_off += ci;
+      if (ci % slab == 0) {
+        CRNN_TRY(crnn_dwconv3x3_bn_relu6_fwd(in, c.p(bp + "_dw"), s1, aa, B, H, W, ci, dtd, stream));
+      } else {
+        CRNN_TRY(crnn_dwconv3x3_fwd_ex(in, c.p(bp + "_dw"), dd, nullptr, B, H, W, ci, 0, dtd, stream));
+        CRNN_TRY(crnn_bn_act_pool_drop_ex(dd, s1, aa, 1, 1, (int)M, ci, 1, 1, 0.f, 0, 0, dtd, dtd, stream));
+      }
+      CRNN_TRY(crnn_bn_infer_state(bn_mean + bn_off, bn_var + bn_off, c.p(bp + "_bn2_g"), c.p(bp + "_bn2_b"), co, s2, stream));
+      bn_off += co;
+      int dtw = CRNN_F32, wt = 0;
+      const float* wq = weight_operand(c, 0, c.p(bp + "_pw"), &dtw);
+      if (cfg->mfma_bf16 && pwT_off[i] >= 0) {
+        wq = reinterpret_cast<const float*>(reinterpret_cast<const bf16_t*>(c.w("pwT")) + pwT_off[i]);
+        dtw = CRNN_BF16; wt = 1;
+      }
+      const bool fold = (ph * pw == 1) && (c.dt("x" + p) == dtq);
+      CRNN_TRY(crnn_pwconv_fwd(aa, wq, fold ? xo : qq, M, co, ci, nullptr, fold ? s2 : nullptr, cfg->mfma_bf16 ? 1 : 0, dtd, dtw, dtq, wt, stream));
+      if (!fold) CRNN_TRY(crnn_bn_act_pool_drop_ex(qq, s2, xo, B, H, W, co, ph, pw, 0.f, seed, (uint32_t)i, dtq, c.dt("x" + p), stream));
+      in = xo;
+      continue;
+    }
+    if (ci % 32 == 0 && ci % slab == 0) {
+      CRNN_TRY(crnn_dwconv3x3_fwd_ex(in, c.p(bp + "_dw"), dd, parts, B, H, W, ci, 0, dtd, stream));
+      CRNN_TRY(crnn_bn_finalize_folded(parts, crnn_dwconv_num_tiles(B, H, W), ci, M, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), s1, c.w("fold"), stream));
     } else {
       CRNN_TRY(crnn_dwconv3x3_fwd_ex(in, c.p(bp + "_dw"), dd, nullptr, B, H, W, ci, 0, dtd, stream));
-      if (train) {
-        CRNN_TRY(crnn_colreduce_ex(dd, parts, M, ci, ci, 2, dtd, stream));
-        CRNN_TRY(crnn_bn_finalize(parts, crnn_colreduce_chunks(M), ci, M, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), s1, stream));
-      }
+      CRNN_TRY(crnn_colreduce_ex(dd, parts, M, ci, ci, 2, dtd, stream));
+      CRNN_TRY(crnn_bn_finalize(parts, crnn_colreduce_chunks(M), ci, M, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), s1, stream));
     }
-    if (!train) CRNN_TRY(crnn_bn_infer_state(bn_mean + bn_off, bn_var + bn_off, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), ci, s1, stream));
     bn_off += ci;
     CRNN_TRY(crnn_bn_act_pool_drop_ex(dd, s1, aa, 1, 1, (int)M, ci, 1, 1, 0.f, 0, 0, dtd, dtd, stream));
-    {  // pointwise conv; in training its epilogue also produces the batch statistics of the BatchNorm that follows
+    {  // pointwise conv; its epilogue also produces the batch statistics of the BatchNorm that follows
       int dtw = CRNN_F32, wt = 0;
       const float* wq = weight_operand(c, 0, c.p(bp + "_pw"), &dtw);
       if (cfg->mfma_bf16 && pwT_off[i] >= 0) {   // bf16 W^T copy made above: both operands contiguous along the reduction
         wq = reinterpret_cast<const float*>(reinterpret_cast<const bf16_t*>(c.w("pwT")) + pwT_off[i]);
         dtw = CRNN_BF16; wt = 1;
       }
-      CRNN_TRY(crnn_pwconv_fwd(aa, wq, qq, M, co, ci, train ? parts : nullptr, cfg->mfma_bf16 ? 1 : 0, dtd, dtw, dtq, wt, stream));
+      CRNN_TRY(crnn_pwconv_fwd(aa, wq, qq, M, co, ci, parts, nullptr, cfg->mfma_bf16 ? 1 : 0, dtd, dtw, dtq, wt, stream));
     }
-    if (train) {
-      CRNN_TRY(crnn_bn_finalize_folded(parts, crnn_pwconv_stat_rows(M), co, M, c.p(bp + "_bn2_g"), c.p(bp + "_bn2_b"), s2, c.w("fold"), stream));
-    } else {
-      CRNN_TRY(crnn_bn_infer_state(bn_mean + bn_off, bn_var + bn_off, c.p(bp + "_bn2_g"), c.p(bp + "_bn2_b"), co, s2, stream));
-    }
+    CRNN_TRY(crnn_bn_finalize_folded(parts, crnn_pwconv_stat_rows(M), co, M, c.p(bp + "_bn2_g"), c.p(bp + "_bn2_b"), s2, c.w("fold"), stream));
     bn_off += co;
-    CRNN_TRY(crnn_bn_act_pool_drop_ex(qq, s2, xo, B, H, W, co, kBlocks[i - 1].ph, kBlocks[i - 1].pw, (train && cfg->dropout) ? kDropBlock : 0.f, seed,
+    CRNN_TRY(crnn_bn_act_pool_drop_ex(qq, s2, xo, B, H, W, co, ph, pw, cfg->dropout ? kDropBlock : 0.f, seed,
                                       (uint32_t)i, dtq, c.dt("x" + p), stream));
     in = xo;
   }

@@ -116,13 +116,20 @@ int crnn_gemm_bf16_ex(int mode, const void* A, const void* B, void* C, int M, in
                       const float* bias, int act, int accumulate, int permP, float* scratch, size_t scratch_bytes, int dtA,
                       int dtB, int dtC, crnn_stream_t stream);
 /* Pointwise 1x1 convolution (reference utils.py:49, Conv2D(1x1, no bias)) as one GEMM over the pixels:
- * q[M][N] = a[M][K] * w[K][N].  stat_partials (may be NULL) receives [crnn_pwconv_stat_rows(M)][2][N] per-tile column
- * sums / sums of squares of q AS STORED (i.e. after rounding to dt_q): the batch statistics of the BatchNorm that
- * follows (utils.py:50), produced by the GEMM epilogue instead of a separate pass over q.  Deterministic.
+ * q[M][N] = a[M][K] * w[K][N] (w_transposed = 1: w is given as W^T [N][K]).
+ * Training: stat_partials (may be NULL) receives [crnn_pwconv_stat_rows(M)][2][N] per-tile column sums / sums of
+ * squares of q AS STORED (i.e. after rounding to dt_q): the batch statistics of the BatchNorm that follows
+ * (utils.py:50), produced by the GEMM epilogue instead of a separate pass over q.  Deterministic.
+ * Inference: out_bnstate (may be NULL; [mean|var|scale|shift] from crnn_bn_infer_state) folds that BatchNorm and the
+ * ReLU6 after it (utils.py:50-51) into the epilogue: q = ReLU6(product * scale + shift).  Not both at once.
  * bf16_products: 0 = fp32 MFMA (all dt_* must be 0), 1 = bf16 MFMA products with fp32 accumulation. */
 int crnn_pwconv_stat_rows(long M);
-int crnn_pwconv_fwd(const void* a, const void* w, void* q, long M, int N, int K, float* stat_partials, int bf16_products,
-                    int dt_a, int dt_w, int dt_q, int w_transposed /* 1: w is W^T [N][K] */, crnn_stream_t stream);
+int crnn_pwconv_fwd(const void* a, const void* w, void* q, long M, int N, int K, float* stat_partials, const float* out_bnstate,
+                    int bf16_products, int dt_a, int dt_w, int dt_q, int w_transposed, crnn_stream_t stream);
+/* Depthwise 3x3 with the inference BatchNorm + ReLU6 after it (utils.py:44-46) folded into the epilogue:
+ * out = ReLU6(dwconv3x3(x, k) * scale + shift); C must be a multiple of 32 (fp32 storage) / 64 (bf16 storage). */
+int crnn_dwconv3x3_bn_relu6_fwd(const void* x, const float* k, const float* bnstate, void* out, int B, int H, int W, int C,
+                                int dtype, crnn_stream_t stream);
 /* n (<= 8) independent matrix transposes in one launch: out[i] [C_i][R_i] = in[i]^T, in[i] = src + in_off[i] (fp32
  * elements), out[i] = dst + out_off[i] (elements of dt_out: 0 fp32 | 1 bf16) */
 int crnn_transpose_batch(const float* src, void* dst, int n, const long* in_off, const long* out_off, const int* R, const int* C,

@@ -505,7 +505,7 @@ def test_pwconv_fwd_with_statistics_epilogue(case):
     parts = zeros(rows, 2, N)
     if case == "fp32":
         Ad, Wd, Q = dev(A), dev(W), zeros(Mm, N)
-        ok(L().crnn_pwconv_fwd(P(Ad), P(Wd), P(Q), Mm, N, K, P(parts), 0, 0, 0, 0, 0, S()))
+        ok(L().crnn_pwconv_fwd(P(Ad), P(Wd), P(Q), Mm, N, K, P(parts), None, 0, 0, 0, 0, 0, S()))
         q = host(Q); ref = A.astype(np.float32).astype(np.float64) @ W.astype(np.float32).astype(np.float64)
         assert_close(q, ref, rtol=1e-5, atol=1e-5, what="pwconv fp32")
     else:
@@ -514,12 +514,12 @@ def test_pwconv_fwd_with_statistics_epilogue(case):
         Wd = _to_bf16_dev(W)
         if case == "bf16":
             Ad, Q = dev(A), zeros(Mm, N)
-            ok(L().crnn_pwconv_fwd(P(Ad), P(Wd), P(Q), Mm, N, K, P(parts), 1, 0, 1, 0, 0, S()))
+            ok(L().crnn_pwconv_fwd(P(Ad), P(Wd), P(Q), Mm, N, K, P(parts), None, 1, 0, 1, 0, 0, S()))
             q = host(Q)
             assert_close(q, ref, rtol=2e-5, atol=1e-4, what="pwconv bf16 products")
         else:
             Ad = _to_bf16_dev(A); Q = torch.zeros(Mm, N, dtype=torch.bfloat16, device="cuda")
-            ok(L().crnn_pwconv_fwd(P(Ad), P(Wd), P(Q), Mm, N, K, P(parts), 1, 1, 1, 1, 0, S()))
+            ok(L().crnn_pwconv_fwd(P(Ad), P(Wd), P(Q), Mm, N, K, P(parts), None, 1, 1, 1, 1, 0, S()))
             q = _f(Q)
             assert_close(q, ref, rtol=2.0 ** -8, atol=1e-3, what="pwconv bf16 storage")
             # the transposed-weight form (W^T made by crnn_transpose_batch) must give the very same stored result
@@ -527,7 +527,7 @@ def test_pwconv_fwd_with_statistics_epilogue(case):
             off = (ctypes.c_long * 1)(0); rr = (ctypes.c_int * 1)(K); cc = (ctypes.c_int * 1)(N)
             ok(L().crnn_transpose_batch(P(dev(W)), P(WT), 1, off, off, rr, cc, 1, S()))
             assert torch.equal(WT, Wd.t().contiguous())
-            ok(L().crnn_pwconv_fwd(P(Ad), P(WT), P(Q2), Mm, N, K, P(parts2), 1, 1, 1, 1, 1, S()))
+            ok(L().crnn_pwconv_fwd(P(Ad), P(WT), P(Q2), Mm, N, K, P(parts2), None, 1, 1, 1, 1, 1, S()))
             assert_close(_f(Q2), q, rtol=2.0 ** -8, atol=1e-3, what="pwconv with W^T")
             assert_close(host(parts2), host(parts), rtol=1e-3, atol=1e-2, what="stats with W^T")
     pr = host(parts).astype(np.float64)
@@ -624,3 +624,47 @@ def test_ctc_and_decoders_at_the_size_limits_and_with_empty_labels():
     assert L().crnn_ctc_beam_decode(P(dev(yp)), None, P(out), P(ln), P(sc), B, T, C, 17, 1, S()) != 0      # beam wider than 16
     assert L().crnn_ctc_loss_grad(P(yd), P(dev(labels, np.int32)), P(dev(il, np.int32)), P(dev(ll, np.int32)), P(loss), P(dl), B, T, C, 32, 2,
                                   1.0 / B, S()) != 0                                                          # 2*32+1 > 64 lanes
+
+
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+def test_inference_epilogues_fold_batchnorm_and_relu6(storage):
+    """Inference forms (BN scale/shift known up front): crnn_dwconv3x3_bn_relu6_fwd and crnn_pwconv_fwd(out_bnstate)
+    must equal conv -> BatchNorm(inference) -> ReLU6 done as separate oracle steps (utils.py:44-51)."""
+    rs = np.random.RandomState(5)
+    B, H, W, C, N = 3, 13, 9, 64, 128
+    bf = storage == "bf16"
+    x = rs.normal(size=(B, H, W, C)); k = rs.normal(size=(3, 3, C)) * 0.4
+    if bf:
+        x = _bf16_round(x)
+    gam, bet = rs.uniform(0.5, 1.5, C), rs.normal(size=C) * 0.3
+    mm, mv = rs.normal(size=C) * 0.2, rs.uniform(0.5, 2.0, C)
+    st = zeros(4 * C)
+    ok(L().crnn_bn_infer_state(P(dev(mm)), P(dev(mv)), P(dev(gam)), P(dev(bet)), C, P(st), S()))
+    ref_d = ops.dwconv_fwd(x, k)
+    ref_a = ops.relu6_fwd(ops.bn_infer_fwd(ref_d, gam, bet, mm, mv))
+    xd = _to_bf16_dev(x) if bf else dev(x)
+    out = torch.zeros(B, H, W, C, dtype=torch.bfloat16 if bf else torch.float32, device="cuda")
+    ok(L().crnn_dwconv3x3_bn_relu6_fwd(P(xd), P(dev(k.reshape(9, C))), P(st), P(out), B, H, W, C, int(bf), S()))
+    got = _f(out) if bf else host(out)
+    assert_close(got, ref_a, rtol=2.0 ** -8 if bf else 1e-5, atol=2e-2 if bf else 1e-5, what="dw + folded BN + ReLU6")
+    # pointwise conv with the folded BatchNorm + ReLU6 of its output
+    a = got.reshape(-1, C).astype(np.float64)                 # what the next layer really reads
+    Wp = rs.normal(size=(C, N)) * 0.2
+    if bf:
+        Wp = _bf16_round(Wp)
+    g2, b2 = rs.uniform(0.5, 1.5, N), rs.normal(size=N) * 0.3
+    m2, v2 = rs.normal(size=N) * 0.2, rs.uniform(0.5, 2.0, N)
+    st2 = zeros(4 * N)
+    ok(L().crnn_bn_infer_state(P(dev(m2)), P(dev(v2)), P(dev(g2)), P(dev(b2)), N, P(st2), S()))
+    ref_x = ops.relu6_fwd(ops.bn_infer_fwd((a @ Wp).reshape(B, H, W, N), g2, b2, m2, v2)).reshape(-1, N)
+    M_ = a.shape[0]
+    if bf:
+        q = torch.zeros(M_, N, dtype=torch.bfloat16, device="cuda")
+        ok(L().crnn_pwconv_fwd(P(out), P(_to_bf16_dev(Wp)), P(q), M_, N, C, None, P(st2), 1, 1, 1, 1, 0, S()))
+        assert_close(_f(q), ref_x, rtol=2.0 ** -7, atol=3e-2, what="pw + folded BN + ReLU6 (bf16)")
+    else:
+        q = zeros(M_, N)
+        ok(L().crnn_pwconv_fwd(P(out), P(dev(Wp)), P(q), M_, N, C, None, P(st2), 0, 0, 0, 0, 0, S()))
+        assert_close(host(q), ref_x, rtol=1e-4, atol=1e-4, what="pw + folded BN + ReLU6 (fp32)")
+    # statistics and the folded BatchNorm are mutually exclusive
+    assert L().crnn_pwconv_fwd(P(out), P(dev(Wp)), P(q), M_, N, C, P(zeros(8, 2, N)), P(st2), 0, 0, 0, 0, 0, S()) != 0
