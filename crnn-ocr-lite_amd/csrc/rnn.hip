@@ -152,7 +152,8 @@ __device__ __forceinline__ void step_tile_gemm_bf16(const float* (&arow)[MT], co
   __syncthreads();
 }
 
-#define LSTM_MT 1   // batch tiles (x16 rows) per workgroup in the LSTM step kernels
+// MT = batch tiles (x16 rows) per workgroup in the LSTM step kernels: 1 while the step is latency-bound (<= 1 workgroup
+// per CU), 2 for large batches where the recurrent weights' L2 traffic per batch row matters (inference at batch 1024)
 
 struct LstmDir {
   const float* xw;   // [T][B][4u]  x*W + b
@@ -165,19 +166,19 @@ struct LstmDir {
   float* dc;         // bwd: [B][u] cell-gradient carry
 };
 
-template <bool WBF>
+template <bool WBF, int MT>
 __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmDir d0, LstmDir d1, int s, int T, int B, int u, int SJ) {
-  __shared__ float red[4][LSTM_MT * 4][256];
-  const StepTile st = step_tile_map(u / 16, cdiv_i(B, 16 * LSTM_MT), SJ);
-  if (st.bt * 16 * LSTM_MT >= B) return;
+  __shared__ float red[4][MT * 4][256];
+  const StepTile st = step_tile_map(u / 16, cdiv_i(B, 16 * MT), SJ);
+  if (st.bt * 16 * MT >= B) return;
   const LstmDir d = st.dir ? d1 : d0;
   const int dir = st.dir;
   const int t = dir ? T - 1 - s : s, tp = dir ? t + 1 : t - 1;
-  const int b0 = st.bt * (16 * LSTM_MT), j0 = st.jt * 16;
+  const int b0 = st.bt * (16 * MT), j0 = st.jt * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
-  float xwv[LSTM_MT][4], cpv[LSTM_MT];   // epilogue operands, requested before the GEMM so their latency overlaps it
+  float xwv[MT][4], cpv[MT];   // epilogue operands, requested before the GEMM so their latency overlaps it
 #pragma unroll
-  for (int m = 0; m < LSTM_MT; ++m) {
+  for (int m = 0; m < MT; ++m) {
     const int b = b0 + 16 * m + (tid >> 4), j = j0 + (tid & 15);
     const bool ok = b < B;
     const float* xw = d.xw + ((long)t * B + (ok ? b : 0)) * 4 * u;
@@ -186,25 +187,25 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmDir d0, LstmDir 
     cpv[m] = (s > 0) ? d.c[((long)tp * B + (ok ? b : 0)) * u + j] : 0.f;
   }
   {
-    bool valid[LSTM_MT]; const float* arow[LSTM_MT];
+    bool valid[MT]; const float* arow[MT];
 #pragma unroll
-    for (int m = 0; m < LSTM_MT; ++m) {
+    for (int m = 0; m < MT; ++m) {
       valid[m] = (b0 + 16 * m + r) < B;
       arow[m] = d.h + ((long)(s > 0 ? tp : t) * B + (valid[m] ? b0 + 16 * m + r : 0)) * d.ldh;
     }
     if constexpr (WBF) {
       const bf16_t* wb = reinterpret_cast<const bf16_t*>(d.wt);
       const bf16_t* brow[4] = {wb + (long)(j0 + r) * u, wb + (long)(u + j0 + r) * u, wb + (long)(2 * u + j0 + r) * u, wb + (long)(3 * u + j0 + r) * u};
-      step_tile_gemm_bf16<4, 2, LSTM_MT>(arow, valid, brow, u, s == 0, red, wave, r, q);
+      step_tile_gemm_bf16<4, 2, MT>(arow, valid, brow, u, s == 0, red, wave, r, q);
     } else {
       const float* brow[4] = {d.wt + (long)(j0 + r) * u, d.wt + (long)(u + j0 + r) * u, d.wt + (long)(2 * u + j0 + r) * u,
                               d.wt + (long)(3 * u + j0 + r) * u};
-      step_tile_gemm<4, 4, LSTM_MT>(arow, valid, brow, u, s == 0, red, wave, r, q);
+      step_tile_gemm<4, 4, MT>(arow, valid, brow, u, s == 0, red, wave, r, q);
     }
   }
   const int row = tid >> 4, col = tid & 15, j = j0 + col;
 #pragma unroll
-  for (int m = 0; m < LSTM_MT; ++m) {
+  for (int m = 0; m < MT; ++m) {
     const int b = b0 + 16 * m + row;
     if (b < B) {
       float z[4];
@@ -223,23 +224,23 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmDir d0, LstmDir 
 }
 
 // sb = 0..T-1 counts backward steps; the time handled is the (T-1-sb)-th in processing order
-template <bool WBF>
+template <bool WBF, int MT>
 __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmDir d0, LstmDir d1, int sb, int T, int B, int u, int SJ) {
-  __shared__ float red[4][LSTM_MT][256];
-  const StepTile st = step_tile_map(u / 16, cdiv_i(B, 16 * LSTM_MT), SJ);
-  if (st.bt * 16 * LSTM_MT >= B) return;
+  __shared__ float red[4][MT][256];
+  const StepTile st = step_tile_map(u / 16, cdiv_i(B, 16 * MT), SJ);
+  if (st.bt * 16 * MT >= B) return;
   const LstmDir d = st.dir ? d1 : d0;
   const int dir = st.dir;
   const int sp = T - 1 - sb;                       // processing index of this time in the forward pass
   const int t = dir ? T - 1 - sp : sp;
   const int tnext = dir ? t - 1 : t + 1;           // processed after t in forward order (already back-propagated)
   const int tprev = dir ? t + 1 : t - 1;           // processed before t in forward order
-  const int b0 = st.bt * (16 * LSTM_MT), j0 = st.jt * 16;
+  const int b0 = st.bt * (16 * MT), j0 = st.jt * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
   const int K = 4 * u;
-  float gv[LSTM_MT][4], ctv[LSTM_MT], cpv[LSTM_MT], dcv[LSTM_MT], dov[LSTM_MT];   // epilogue operands, requested before the GEMM
+  float gv[MT][4], ctv[MT], cpv[MT], dcv[MT], dov[MT];   // epilogue operands, requested before the GEMM
 #pragma unroll
-  for (int m = 0; m < LSTM_MT; ++m) {
+  for (int m = 0; m < MT; ++m) {
     const int b = b0 + 16 * m + (tid >> 4), j = j0 + (tid & 15);
     const long bb = (b < B) ? b : 0;
     const float* gt = d.gates + ((long)t * B + bb) * K;
@@ -251,23 +252,23 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmDir d0, LstmDir 
     dov[m] = d.dout[((long)t * B + bb) * d.ldo + j];
   }
   {
-    bool valid[LSTM_MT]; const float* arow[LSTM_MT];
+    bool valid[MT]; const float* arow[MT];
 #pragma unroll
-    for (int m = 0; m < LSTM_MT; ++m) {
+    for (int m = 0; m < MT; ++m) {
       valid[m] = (b0 + 16 * m + r) < B;
       arow[m] = d.dz + ((long)(sb > 0 ? tnext : t) * B + (valid[m] ? b0 + 16 * m + r : 0)) * K;
     }
     if constexpr (WBF) {
       const bf16_t* brow[1] = {reinterpret_cast<const bf16_t*>(d.wt) + (long)(j0 + r) * K};
-      step_tile_gemm_bf16<1, 4, LSTM_MT>(arow, valid, brow, K, sb == 0, red, wave, r, q);
+      step_tile_gemm_bf16<1, 4, MT>(arow, valid, brow, K, sb == 0, red, wave, r, q);
     } else {
       const float* brow[1] = {d.wt + (long)(j0 + r) * K};
-      step_tile_gemm<1, 8, LSTM_MT>(arow, valid, brow, K, sb == 0, red, wave, r, q);
+      step_tile_gemm<1, 8, MT>(arow, valid, brow, K, sb == 0, red, wave, r, q);
     }
   }
   const int row = tid >> 4, col = tid & 15, j = j0 + col;
 #pragma unroll
-  for (int m = 0; m < LSTM_MT; ++m) {
+  for (int m = 0; m < MT; ++m) {
     const int b = b0 + 16 * m + row;
     if (b < B) {
       float dh = ((red[0][m][tid] + red[1][m][tid]) + (red[2][m][tid] + red[3][m][tid])) + dov[m];
@@ -299,10 +300,16 @@ extern "C" int crnn_lstm_fwd_ex(const float* xw0, const float* xw1, const void* 
   LstmDir a{xw0, (const float*)ut0, h0, ldh, c0, g0, nullptr, 0, nullptr, nullptr};
   LstmDir b{xw1, (const float*)ut1, h1, ldh, c1, g1, nullptr, 0, nullptr, nullptr};
   const int SJ = step_sj(u / 16);
-  dim3 grid(step_grid(u / 16, cdiv(B, 16 * LSTM_MT), SJ));
+  const int MT = (B >= 512) ? 2 : 1;
+  dim3 grid(step_grid(u / 16, cdiv(B, 16 * MT), SJ));
   for (int s = 0; s < T; ++s) {
-    if (dt_u == CRNN_BF16) hipLaunchKernelGGL(lstm_fwd_step_kernel<true>, grid, dim3(256), 0, stream, a, b, s, T, B, u, SJ);
-    else hipLaunchKernelGGL(lstm_fwd_step_kernel<false>, grid, dim3(256), 0, stream, a, b, s, T, B, u, SJ);
+    if (dt_u == CRNN_BF16) {
+      if (MT == 2) hipLaunchKernelGGL((lstm_fwd_step_kernel<true, 2>), grid, dim3(256), 0, stream, a, b, s, T, B, u, SJ);
+      else hipLaunchKernelGGL((lstm_fwd_step_kernel<true, 1>), grid, dim3(256), 0, stream, a, b, s, T, B, u, SJ);
+    } else {
+      if (MT == 2) hipLaunchKernelGGL((lstm_fwd_step_kernel<false, 2>), grid, dim3(256), 0, stream, a, b, s, T, B, u, SJ);
+      else hipLaunchKernelGGL((lstm_fwd_step_kernel<false, 1>), grid, dim3(256), 0, stream, a, b, s, T, B, u, SJ);
+    }
   }
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
@@ -322,10 +329,16 @@ extern "C" int crnn_lstm_bwd_ex(const void* u0, const void* u1, const float* c0,
   LstmDir a{nullptr, (const float*)u0, nullptr, 0, const_cast<float*>(c0), const_cast<float*>(g0), dout0, ldo, dz0, dc0};
   LstmDir b{nullptr, (const float*)u1, nullptr, 0, const_cast<float*>(c1), const_cast<float*>(g1), dout1, ldo, dz1, dc1};
   const int SJ = step_sj(u / 16) > 2 ? 2 : step_sj(u / 16);   // the dz rows (4u wide) outweigh the weights here: favour batch groups
-  dim3 grid(step_grid(u / 16, cdiv(B, 16 * LSTM_MT), SJ));
+  const int MT = (B >= 512) ? 2 : 1;
+  dim3 grid(step_grid(u / 16, cdiv(B, 16 * MT), SJ));
   for (int sb = 0; sb < T; ++sb) {
-    if (dt_u == CRNN_BF16) hipLaunchKernelGGL(lstm_bwd_step_kernel<true>, grid, dim3(256), 0, stream, a, b, sb, T, B, u, SJ);
-    else hipLaunchKernelGGL(lstm_bwd_step_kernel<false>, grid, dim3(256), 0, stream, a, b, sb, T, B, u, SJ);
+    if (dt_u == CRNN_BF16) {
+      if (MT == 2) hipLaunchKernelGGL((lstm_bwd_step_kernel<true, 2>), grid, dim3(256), 0, stream, a, b, sb, T, B, u, SJ);
+      else hipLaunchKernelGGL((lstm_bwd_step_kernel<true, 1>), grid, dim3(256), 0, stream, a, b, sb, T, B, u, SJ);
+    } else {
+      if (MT == 2) hipLaunchKernelGGL((lstm_bwd_step_kernel<false, 2>), grid, dim3(256), 0, stream, a, b, sb, T, B, u, SJ);
+      else hipLaunchKernelGGL((lstm_bwd_step_kernel<false, 1>), grid, dim3(256), 0, stream, a, b, sb, T, B, u, SJ);
+    }
   }
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;

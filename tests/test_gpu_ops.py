@@ -240,7 +240,7 @@ def test_sampler_bwd_maxpool_im2col():
 
 
 # ------------------------------------------------------------------------------------------------ LSTM
-@pytest.mark.parametrize("B,T,u,din", [(5, 7, 64, 24), (33, 6, 128, 40)])
+@pytest.mark.parametrize("B,T,u,din", [(5, 7, 64, 24), (33, 6, 128, 40), (520, 3, 64, 8)])   # 520: two batch tiles per workgroup, ragged
 def test_bilstm_fwd_bwd(B, T, u, din):
     rs = np.random.RandomState(B + T)
     x = rs.normal(size=(B, T, din))
