@@ -51,7 +51,12 @@ __global__ __launch_bounds__(64) void ctc_loss_grad_kernel(const float* __restri
   float* lsm = sm;               // [Tmax][C]
   float* alpha = sm + (T - skip) * C;  // [Tmax][64]
   float* ab = alpha + (T - skip) * 64; // [64] scratch
-  const float* yb = y + ((long)b * T + skip) * C;
+  float* ys = ab + 64;                 // [Tmax][C] this sample's posteriors (one coalesced read instead of one exposed
+                                       // global-load latency per time step: a sample is a single wavefront, nothing hides it)
+  const float* yg = y + ((long)b * T + skip) * C;
+  for (int i = lane; i < Tb * C; i += 64) ys[i] = yg[i];
+  __syncthreads();
+  const float* yb = ys;
 
   // zero gradient rows outside the valid window (and everything if the sample is degenerate)
   for (int t = 0; t < T; ++t) {
@@ -100,6 +105,12 @@ __global__ __launch_bounds__(64) void ctc_loss_grad_kernel(const float* __restri
     for (int t = skip; t < skip + Tb; ++t) if (lane < C) dlogits[((long)t * B + b) * C + lane] = 0.f;
     return;
   }
+  // which extended-label states carry class `lane` (bit s set <=> ext_s == lane)
+  unsigned long long occ_mask = 0ull;
+  for (int s2 = 0; s2 < S; ++s2) {
+    int e2 = __shfl(ext, s2, 64);
+    if (e2 == lane) occ_mask |= 1ull << s2;
+  }
   // beta (includes the emission at t, like alpha) + gradient, t descending
   int extn2 = __shfl_down(ext, 2, 64);
   const bool can_skip_b = (s + 2 < S) && (ext != blank) && (ext != extn2);
@@ -114,20 +125,22 @@ __global__ __launch_bounds__(64) void ctc_loss_grad_kernel(const float* __restri
       if (can_skip_b) v = lse2(v, b2);
       bt = (s < S && v != NEG_INF) ? v + lsm[t * C + ext] : NEG_INF;
     }
-    // ab[s] = alpha_t(s) + beta_t(s)  (both contain lsm[t][ext] once)
+    // state lane s: w_s = exp(alpha_t(s) + beta_t(s) - lsm[t][ext_s] - ll)  (alpha and beta both contain the emission once):
+    // one exp per lane here instead of one per (class, state) pair in the class loop below -- a sample is a single
+    // wavefront, so the longest per-lane chain (the blank class: L+1 states) is the critical path
     __syncthreads();
-    ab[s] = (s < S) ? alpha[t * 64 + s] + bt : NEG_INF;
+    {
+      float v = (s < S) ? alpha[t * 64 + s] + bt : NEG_INF;
+      ab[s] = (v != NEG_INF) ? expf(v - lsm[t * C + ext] - ll) : 0.f;
+    }
     __syncthreads();
-    // lane k: gz_k = softmax(z)_k - sum_{s: ext_s = k} exp(ab_s - lsm_k - ll); then chain to the logits
+    // lane k: gz_k = softmax(z)_k - sum_{s: ext_s = k} exp(ab_s - lsm_k - ll); then chain to the logits.
+    // occ_mask = the states whose symbol is this lane's class (built once per sample): visited in ascending s
     float gyk = 0.f, pk = 0.f;
     if (lane < C) {
       float l = lsm[t * C + lane];
       float occ = 0.f;
-      for (int s2 = 0; s2 < S; ++s2) {
-        int e2 = (s2 & 1) ? labels[(long)b * Lmax + (s2 >> 1)] : blank;
-        float v = ab[s2];
-        if (e2 == lane && v != NEG_INF) occ += expf(v - l - ll);
-      }
+      for (unsigned long long m = occ_mask; m; m &= m - 1) occ += ab[__ffsll((long long)m) - 1];
       float gz = expf(l) - occ;
       pk = yb[t * C + lane];
       gyk = gz / (pk + CTC_EPS);          // d loss / d y_pred[t][k]
@@ -142,8 +155,9 @@ extern "C" int crnn_ctc_loss_grad(const float* y, const int* labels, const int* 
   if (C > 64 || C < 2 || T <= skip) return CRNN_ERR_UNSUPPORTED;
   if (Lmax < 0 || 2 * Lmax + 1 > 64) return CRNN_ERR_UNSUPPORTED;   // the extended label (2L+1 states) lives on the 64 lanes of one wavefront
   if (B <= 0) return CRNN_ERR_ARG;
-  size_t lds = ((size_t)(T - skip) * C + (size_t)(T - skip) * 64 + 64) * sizeof(float);
-  if (lds > 64 * 1024) return CRNN_ERR_UNSUPPORTED;
+  size_t lds = (2 * (size_t)(T - skip) * C + (size_t)(T - skip) * 64 + 64) * sizeof(float);
+  if (lds > 160 * 1024) return CRNN_ERR_UNSUPPORTED;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)ctc_loss_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(ctc_loss_grad_kernel, dim3(B), dim3(64), lds, stream, y, labels, input_len, label_len, loss, dlogits, B, T, C, Lmax, skip, grad_scale);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
