@@ -385,7 +385,11 @@ static int dwconv_fwd_launch(const T* x, const float* k, T* out, float* stat_par
                              hipStream_t stream, const float* bnstate = nullptr) {
   DwTile t = dw_pick_tile(H, W);
   if (t.lds > 160 * 1024) return CRNN_ERR_UNSUPPORTED;
-  if (t.lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_tile_kernel<0, DW_NT, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (t.lds > 48 * 1024) {   // more dynamic LDS than the default launch limit: raise it to exactly what this tile needs
+    hipError_t e = hipFuncSetAttribute((const void*)dwconv_tile_kernel<0, DW_NT, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds);
+    if (e != hipSuccess) return (int)e;
+    if (bnstate) { e = hipFuncSetAttribute((const void*)dwconv_tile_kernel<2, DW_NT, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds); if (e != hipSuccess) return (int)e; }
+  }
   const int slab = 128 / (int)sizeof(T);   // channels per workgroup: 32 (fp32) or 64 (bf16)
   if (C % slab) return CRNN_ERR_UNSUPPORTED;
   dim3 grid(C / slab, B * t.nHb * t.nWb);
@@ -554,7 +558,10 @@ template <typename T>
 static int dwconv_wgrad_launch(const T* x, const T* g, float* dk, float* scratch, int B, int H, int W, int C, hipStream_t stream) {
   DwTile t = dw_pick_tile(H, W);
   if (t.lds > 160 * 1024) return CRNN_ERR_UNSUPPORTED;
-  if (t.lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_tile_kernel<1, DW_NT, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (t.lds > 48 * 1024) {   // more dynamic LDS than the default launch limit: raise it to exactly what this tile needs
+    hipError_t e = hipFuncSetAttribute((const void*)dwconv_tile_kernel<1, DW_NT, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds);
+    if (e != hipSuccess) return (int)e;
+  }
   int ntiles = B * t.nHb * t.nWb;
   const int slab = 128 / (int)sizeof(T);
   if (C % slab) return CRNN_ERR_UNSUPPORTED;
