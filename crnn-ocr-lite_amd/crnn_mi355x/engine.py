@@ -112,7 +112,15 @@ class Engine:
     # ---- hot path -----------------------------------------------------------------------------------------
     def _as_input(self, x):
         if not torch.is_tensor(x):
-            x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+            # Readf's batches start as np.empty (utils.py:448) and the short tail batch of a pass is yielded with
+            # whatever those unused rows contain: rows that are not finite in fp32 are zeroed instead of poisoning
+            # the batch statistics of every other image (the values are undefined in the reference as well)
+            with np.errstate(over="ignore", invalid="ignore"):
+                x = np.ascontiguousarray(x, dtype=np.float32)
+            bad = ~np.isfinite(x)
+            if bad.any():
+                x = np.where(bad, np.float32(0), x)
+            x = torch.from_numpy(x)
         x = x.to(self.device, dtype=torch.float32, non_blocking=True).contiguous()
         assert x.numel() == self.B * self.cfg.imgh * self.cfg.imgw, "batch shape mismatch"
         return x
