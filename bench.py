@@ -8,6 +8,9 @@ flat fp32 gradient buffer] + global-norm clip + Adam + BatchNorm moving-statisti
 batch that is already resident in HBM.  Workload = BASELINE.json configs[1]: 100x32x1 images, batch 256 per
 GPU, max_len 23, time_dense_size 128, n_units 256 (LSTM), Adam(1e-4, beta1 .5, clipnorm 5).  Weak scaling
 (global batch 256*N).  Rank 0 prints ONE JSON line.
+
+The timed path is the product only (crnn_mi355x over libcrnn_mi355x.so: weights from crnn_mi355x.init, synthetic batch
+generated here); `oracle/` is imported by the `cpu_baseline` leg alone, where it IS the thing being timed.
 """
 import argparse
 import json
@@ -133,6 +136,19 @@ def pointwise_gemm_roofline(eng, iters=5):
             "launches": len(cfgs), "avg_launch_ms": round(1e3 * t / len(cfgs), 4), "flops_per_launch_set": flops}
 
 
+def synthetic_batch(B, seed, imgh=100, imgw=32, max_len=23, num_classes=38, T=52):
+    """SURVEY 8d synthetic inputs: uint8 noise images normalised like Readf (utils.py:415-416, train.py mean/std),
+    label lengths ~ U{1..max_len}, labels ~ U{0..36} padded with the blank (37), input_length = T - 2."""
+    rs = np.random.RandomState(seed)
+    x = ((rs.randint(0, 256, (B, imgh, imgw, 1)).astype(np.float32) - 118.24236953981779) / 36.72835353999682).astype(np.float32)
+    blank = num_classes - 1
+    ll = rs.randint(1, max_len + 1, size=B)
+    labels = np.full((B, max_len), blank, dtype=np.int64)
+    for b in range(B):
+        labels[b, :ll[b]] = rs.randint(0, blank, size=ll[b])
+    return x, labels, np.full(B, T - 2, dtype=np.int64), ll.astype(np.int64)
+
+
 def cpu_baseline(seconds_target=15.0):
     """The CPU restatement (oracle, 'port') timed on this box's host cores on a bounded sample of the same
     workload: full fp32 train step (forward, CTC, backward, clip, Adam) at batch 16."""
@@ -192,17 +208,15 @@ def main():
     else:
         torch.cuda.set_device(0)
 
-    from oracle import model as M   # only for the synthetic batch / init recipe and the cpu_baseline leg
     from crnn_mi355x.engine import Engine
+    from crnn_mi355x.init import initial_parameters
     from crnn_mi355x.optimizers import Adam
     from crnn_mi355x.parallel import GradAllReduce
 
     B = args.batch
-    cfg = M.Config(gru=args.gru)
-    p, bn = M.init_params(cfg, seed=1, dtype=np.float32)         # identical weights on every rank
-    x, lab, il, ll = M.synthetic_batch(cfg, B, seed=rank)        # rank r draws its own shard
     eng = Engine(B, dropout=True, precision=args.precision, gru=args.gru)
-    eng.set_params(p, bn)
+    eng.set_params(initial_parameters(eng.layout, eng.cfg.units, args.gru, seed=1))   # Keras-family init, identical on every rank
+    x, lab, il, ll = synthetic_batch(B, seed=rank, T=eng.T)      # rank r draws its own shard
     xd = torch.from_numpy(x).cuda()
     labd = torch.from_numpy(lab.astype(np.int32)).cuda(); ild = torch.from_numpy(il.astype(np.int32)).cuda()
     lld = torch.from_numpy(ll.astype(np.int32)).cuda()

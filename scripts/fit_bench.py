@@ -13,11 +13,10 @@ ap.add_argument("--precision", default="bf16s")
 args = ap.parse_args()
 os.environ["CRNN_PRECISION"] = args.precision
 import utils as U
-from oracle import model as M
+from bench import synthetic_batch
 
 B = args.batch
-cfg = M.Config()
-x, lab, il, ll = M.synthetic_batch(cfg, B, seed=0)
+x, lab, il, ll = synthetic_batch(B, seed=0)
 X = x.astype(np.float64)                                   # Readf batches are float64 (utils.py:446-452)
 inputs = {"the_input": X, "the_labels": lab.astype(np.int64), "input_length": il.reshape(-1, 1).astype(np.int64),
           "label_length": ll.reshape(-1, 1).astype(np.int64), "source_str": np.array(["x"] * B)}

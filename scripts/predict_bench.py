@@ -16,16 +16,19 @@ ap.add_argument("--precision", default="bf16s")
 ap.add_argument("--cpu-sample", type=int, default=32)
 args = ap.parse_args()
 
-from oracle import model as M, ctc as OC          # synthetic batch / init recipe, and the CPU beam baseline
 from crnn_mi355x.engine import Engine
+from crnn_mi355x.init import initial_parameters
+from bench import synthetic_batch
 
 B = args.batch
-cfg = M.Config()
-p, bn = M.init_params(cfg, seed=1, dtype=np.float32)
-p = M.randomize_params(cfg, p)                    # non-degenerate posteriors (identity-STN / zero-bias init decodes to "")
-x, lab, il, ll = M.synthetic_batch(cfg, B, seed=0)
 eng = Engine(B, dropout=False, precision=args.precision)
-eng.set_params(p, bn)
+p = initial_parameters(eng.layout, eng.cfg.units, False, seed=1)
+rs = np.random.RandomState(2)
+for k in p:                                        # non-degenerate posteriors: the identity-STN / zero-bias init decodes to ""
+    if k.endswith(("_b", "_g")) or k == "stn_d2_w":
+        p[k] = (p[k] + rs.normal(size=p[k].shape) * (0.02 if k.startswith("stn_d2") else 0.3)).astype(np.float32)
+eng.set_params(p)
+x, lab, il, ll = synthetic_batch(B, seed=0, T=eng.T)
 xd = torch.from_numpy(x).cuda()
 
 
@@ -48,7 +51,9 @@ b50, b90 = timed(beam, args.iters)
 g50, _ = timed(greedy, args.iters)
 t50, t90 = timed(both, args.iters)
 
-# CPU restatement of TF's beam search on a bounded sample of the same posteriors, one thread
+# CPU restatement of TF's beam search (the oracle: only this baseline leg uses it) on a bounded sample of the same
+# posteriors, one thread
+from oracle import ctc as OC
 y = state["y"].float().cpu().numpy()
 n = min(args.cpu_sample, B)
 t0 = time.perf_counter()
