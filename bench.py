@@ -184,6 +184,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE configs[1]: 256)")
     ap.add_argument("--precision", choices=["fp32", "bf16", "bf16s"], default="bf16s",
                     help="fp32 = parity mode (fp32 MFMA); bf16 = GEMM products in bf16, fp32 accumulate/storage")
+    ap.add_argument("--imgh", type=int, default=100, help="image length (the time axis); 200 = the IAM shape of BASELINE configs[2]")
+    ap.add_argument("--max-len", type=int, default=23, help="label capacity; 21 for the IAM shape")
     ap.add_argument("--gru", action="store_true", help="GRU recurrence (what the reference's train.py really builds, SURVEY F3) instead of "
                     "the LSTM BASELINE.json names")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -214,9 +216,9 @@ def main():
     from crnn_mi355x.parallel import GradAllReduce
 
     B = args.batch
-    eng = Engine(B, dropout=True, precision=args.precision, gru=args.gru)
+    eng = Engine(B, imgh=args.imgh, max_len=args.max_len, dropout=True, precision=args.precision, gru=args.gru)
     eng.set_params(initial_parameters(eng.layout, eng.cfg.units, args.gru, seed=1))   # Keras-family init, identical on every rank
-    x, lab, il, ll = synthetic_batch(B, seed=rank, T=eng.T)      # rank r draws its own shard
+    x, lab, il, ll = synthetic_batch(B, seed=rank, imgh=args.imgh, max_len=args.max_len, T=eng.T)   # rank r draws its own shard
     xd = torch.from_numpy(x).cuda()
     labd = torch.from_numpy(lab.astype(np.int32)).cuda(); ild = torch.from_numpy(il.astype(np.int32)).cuda()
     lld = torch.from_numpy(ll.astype(np.int32)).cuda()
@@ -248,9 +250,11 @@ def main():
             "metric": "text-line images/sec (train step)", "value": round(world * B * args.steps / dt, 1), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 100x32x1 text lines, batch %d/GPU, max_len 23, time_dense_size 128, "
-                                   "n_units 256 %s, STN on, dropout on, CTC, Adam(1e-4,b1=.5,clipnorm 5), %s" % (B, "BiGRU" if args.gru else "BiLSTM", {"fp32": "fp32 MFMA", "bf16": "bf16 MFMA products / fp32 accumulate+storage",
-                                       "bf16s": "bf16 MFMA products, bf16 conv-stack tensors in HBM, fp32 accumulate/statistics/RNN/optimizer"}[args.precision]),
+            "config": {"workload": "BASELINE configs[%d]: %dx32x1 text lines, batch %d/GPU, max_len %d, time_dense_size 128, n_units 256 %s, "
+                                   "STN on, dropout on, CTC, Adam(1e-4,b1=.5,clipnorm 5), %s" % (
+                                       1 if args.imgh == 100 else 2, args.imgh, B, args.max_len, "BiGRU" if args.gru else "BiLSTM",
+                                       {"fp32": "fp32 MFMA", "bf16": "bf16 MFMA products / fp32 accumulate+storage",
+                                        "bf16s": "bf16 MFMA products, bf16 conv-stack tensors in HBM, fp32 accumulate/statistics/RNN/optimizer"}[args.precision]),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": round(last_loss, 4)},
         }
         if not args.no_roofline:
