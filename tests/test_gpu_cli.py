@@ -73,3 +73,23 @@ def test_drop_in_import_order_fresh_process():
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads(out.stdout.strip().splitlines()[-1])
     assert res["steps"] == 3 and np.isfinite(res["loss"]) and res["images_per_sec"] > 0
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """The N>1 form of bench.py exactly as the driver launches it (torch.distributed.run, one process per rank): two ranks
+    share this box's single GPU and exchange gradients over gloo instead of RCCL (CRNN_DIST_BACKEND) -- everything else
+    (staged backward, asynchronous bucketed all-reduce, barrier, max-over-ranks timing, rank-0 JSON line) is the real path."""
+    import json
+    import subprocess
+    env = dict(os.environ, CRNN_DIST_BACKEND="gloo", PYTHONPATH=os.pathsep.join([ROOT, PKG]))
+    port = 29600 + os.getpid() % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "16",
+           "--no-roofline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                     # rank 0 only
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 32 and res["config"]["parallelism"] == "dp2"
+    assert res["scaling"] == "weak" and res["value"] > 0 and np.isfinite(res["config"]["final_loss"])
