@@ -577,6 +577,18 @@ int backward_bottom(const Ctx& c, const float* x, uint64_t seed) {
 }
 }  // namespace
 
+extern "C" int crnn_train_step_adam(const crnn_config* cfg, float* params, float* grads, float* m, float* v, float* bn_mean, float* bn_var,
+                                    const float* x, const int* labels, const int* input_length, const int* label_length, float* ws,
+                                    size_t ws_bytes, float* y_pred, float* loss, void* norm_scratch, float* norm_out, float lr_t,
+                                    float beta1, float beta2, float eps, float clipnorm, uint64_t seed, hipStream_t stream) {
+  CRNN_TRY(crnn_forward(cfg, params, bn_mean, bn_var, x, ws, ws_bytes, y_pred, 1, seed, stream));
+  CRNN_TRY(crnn_backward(cfg, params, grads, x, labels, input_length, label_length, ws, ws_bytes, loss, seed, stream));
+  const long n = make_layout(cfg).total;
+  CRNN_TRY(crnn_global_norm(grads, n, clipnorm, norm_scratch, norm_out, stream));
+  CRNN_TRY(crnn_adam_step(params, grads, m, v, n, lr_t, beta1, beta2, eps, norm_out, stream));
+  return crnn_bn_update(cfg, bn_mean, bn_var, ws, ws_bytes, stream);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // BatchNorm moving statistics (momentum .99): m <- .99 m + .01 mean ;
 // v <- .99 v + .01 var * n/(n-1) * n/(n-(1+eps))   (TF fused-BN Bessel correction x Keras 2.2.2 factor)

@@ -81,6 +81,16 @@ int crnn_backward_bottom(const crnn_config* cfg, const float* params, float* gra
 int crnn_bn_update(const crnn_config* cfg, float* bn_mean, float* bn_var, float* ws, size_t ws_bytes,
                    crnn_stream_t stream);
 
+/* One whole single-GPU train step on one stream, what Keras' train_on_batch does for this model (train.py:201-209):
+ * crnn_forward(train=1) -> crnn_backward -> crnn_global_norm(clipnorm) -> crnn_adam_step -> crnn_bn_update.
+ * m, v: Adam moments (same layout as params); lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) is computed by the caller
+ * (Keras 2.2.2 form, t = 1-based iteration); norm_scratch >= 4096 bytes, norm_out 2 floats (global norm, clip factor).
+ * Data-parallel hosts call the stages themselves (crnn_backward_top / _bottom around their all-reduce). */
+int crnn_train_step_adam(const crnn_config* cfg, float* params, float* grads, float* m, float* v, float* bn_mean, float* bn_var,
+                         const float* x, const int* labels, const int* input_length, const int* label_length, float* ws,
+                         size_t ws_bytes, float* y_pred, float* loss, void* norm_scratch, float* norm_out, float lr_t, float beta1,
+                         float beta2, float eps, float clipnorm, uint64_t seed, crnn_stream_t stream);
+
 /* ---- optimizers (keras.optimizers.Adam / SGD with clipnorm, train.py:187-190) ------------------------------ */
 /* norm_out[0] = global L2 norm of g, norm_out[1] = clip multiplier; scratch >= 4096 bytes */
 int crnn_global_norm(const float* g, long n, float clipnorm, void* scratch, float* norm_out, crnn_stream_t stream);

@@ -385,3 +385,30 @@ def test_bf16s_gru_variant_tracks_the_fp32_oracle():
     assert np.abs(yd - c["y_pred"]).max() < 5e-2 and agree > 0.93 and rel_loss < 2e-2
     for k in ("dense2_w", "rnn2f_w", "rnn2b_u", "rnn1f_u", "rnn1f_w", "dense1_w"):
         assert cos[k] > 0.95, (k, cos[k])
+
+
+def test_c_train_step_driver_equals_the_staged_python_step():
+    """crnn_train_step_adam (forward -> backward -> clip -> Adam -> BN moving statistics in one C call) must leave exactly
+    the state Engine.train_step leaves when it chains the same entry points from Python."""
+    import math
+    from crnn_mi355x.engine import _ptr, _stream
+    from crnn_mi355x.native import check
+    from crnn_mi355x.optimizers import Adam
+    cfg = M.Config()
+    B = 4
+    p, bn = M.init_params(cfg, seed=5, dtype=np.float32)
+    p = M.randomize_params(cfg, p)
+    x, lab, il, ll = M.synthetic_batch(cfg, B, seed=6)
+    a = Engine(B, dropout=True, precision="fp32"); a.set_params(p, bn)
+    b = Engine(B, dropout=True, precision="fp32"); b.set_params(p, bn)
+    opt = Adam(lr=1e-4, beta_1=0.5, beta_2=0.999, clipnorm=5)
+    la = a.train_step(x, lab, il, ll, opt, iteration=0, seed=3).clone()
+    xd = b._as_input(x); labd, ild, lld = b._as_i32(lab), b._as_i32(il), b._as_i32(ll)
+    mom, vel = torch.zeros_like(b.params), torch.zeros_like(b.params)
+    lr_t = 1e-4 * math.sqrt(1.0 - 0.999) / (1.0 - 0.5)
+    check(b.lib.crnn_train_step_adam(b._c, _ptr(b.params), _ptr(b.grads), _ptr(mom), _ptr(vel), _ptr(b.bn_mean), _ptr(b.bn_var), _ptr(xd),
+                                     _ptr(labd), _ptr(ild), _ptr(lld), _ptr(b.ws), b.ws_bytes, _ptr(b.y_pred), _ptr(b.loss),
+                                     _ptr(b.norm_scratch), _ptr(b.norm), lr_t, 0.5, 0.999, 1e-7, 5.0, 3, _stream()), "train_step_adam")
+    assert torch.equal(la, b.loss) and torch.equal(a.params, b.params)
+    assert torch.equal(a.bn_mean, b.bn_mean) and torch.equal(a.bn_var, b.bn_var)
+    assert torch.equal(a.opt_state["m"], mom) and torch.equal(a.opt_state["v"], vel)
