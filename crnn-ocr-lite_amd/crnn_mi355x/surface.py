@@ -95,7 +95,7 @@ class Model:
         self.stop_training = False
         self.optimizer = None
         self._iterations = 0
-        self._prefetched = None          # batch drawn ahead of time by fit_generator (kept across epochs)
+        self._prefetched = None          # (generator, batch) drawn ahead of time by fit_generator (kept across epochs)
         sh = self.config["shape"]
         self._T = (sh[0] + 4) // 2
         if share is not None:                        # predictor view of an existing model: same weights/engine
@@ -301,11 +301,11 @@ class Model:
             for step in range(steps_per_epoch):
                 # the step is enqueued first, then the NEXT batch is drawn from the generator (host decode / augmentation)
                 # while the GPU works, and only then is the loss read back (the one host sync per step Keras has too)
-                if self._prefetched is None:
-                    self._prefetched = self._snapshot(next(generator))
-                x, lab, il, ll = self._prefetched
+                if self._prefetched is None or self._prefetched[0] is not generator:   # a batch drawn ahead belongs to ITS generator
+                    self._prefetched = (generator, self._snapshot(next(generator)))
+                x, lab, il, ll = self._prefetched[1]
                 loss_dev = self._train_on_batch_async(x, lab, il, ll)
-                self._prefetched = self._snapshot(next(generator))
+                self._prefetched = (generator, self._snapshot(next(generator)))
                 loss = float(loss_dev.item())
                 run += loss; nimg += len(x)
                 logs = {"loss": loss, "batch": step, "size": len(x)}
