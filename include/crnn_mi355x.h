@@ -141,7 +141,8 @@ int crnn_pwconv_fwd(const void* a, const void* w, void* q, long M, int N, int K,
 int crnn_dwconv3x3_bn_relu6_fwd(const void* x, const float* k, const float* bnstate, void* out, int B, int H, int W, int C,
                                 int dtype, crnn_stream_t stream);
 /* n (<= 8) independent matrix transposes in one launch: out[i] [C_i][R_i] = in[i]^T, in[i] = src + in_off[i] (fp32
- * elements), out[i] = dst + out_off[i] (elements of dt_out: 0 fp32 | 1 bf16) */
+ * elements), out[i] = dst + out_off[i] (elements of dt_out: 0 fp32 | 1 bf16).  src / dst are device pointers; the four
+ * descriptor arrays (in_off, out_off, R, C) are HOST arrays of n entries, copied into the kernel arguments. */
 int crnn_transpose_batch(const float* src, void* dst, int n, const long* in_off, const long* out_off, const int* R, const int* C,
                          int dt_out, crnn_stream_t stream);
 int crnn_dwconv3x3_fwd_ex(const void* x, const float* k, void* out, float* stat_partials, int B, int H, int W, int C, int flip,
