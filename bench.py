@@ -115,6 +115,8 @@ def pointwise_gemm_roofline(eng, iters=5):
     for n, src, k in (("rnn1f_w", "dn1", eng.cfg.tds), ("rnn1b_w", "dn1", eng.cfg.tds), ("rnn2f_w", "r1", u), ("rnn2b_w", "r1", u)):
         cfgs.append((eng.ws_tensor(src), W(n), eng.ws_tensor("gB"), TB, G, k, 0, 0, 0))
     flops = sum(2.0 * M * N * K for _, _, _, M, N, K, _, _, _ in cfgs)
+    # algorithmic HBM bytes of the same launches: A read + C written once, in their storage types (weights negligible)
+    hbm_bytes = sum(M * K * (2.0 if dta else 4.0) + M * N * (2.0 if dtc else 4.0) for _, _, _, M, N, K, dta, dtc, _ in cfgs)
     times = []
     for it in range(iters + 1):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -133,7 +135,10 @@ def pointwise_gemm_roofline(eng, iters=5):
     ach = flops / t / 1e12
     return {"bound": "mfma", "kernel": "gemm_%s_kernel<128,false,true> (pointwise 1x1 convs fwd + dense1 + RNN input GEMMs)" % ("bf16" if bf else "f32"),
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "launches": len(cfgs), "avg_launch_ms": round(1e3 * t / len(cfgs), 4), "flops_per_launch_set": flops}
+            "launches": len(cfgs), "avg_launch_ms": round(1e3 * t / len(cfgs), 4), "flops_per_launch_set": flops,
+            # with bf16 tensors every one of these GEMMs sits below the 312 FLOP/B ridge: the binding roof is HBM
+            "hbm_bytes_per_launch_set": hbm_bytes, "hbm_achieved_GBps": round(hbm_bytes / t / 1e9, 1),
+            "hbm_frac": round(hbm_bytes / t / 1e9 / PEAK_HBM_GBS, 4)}
 
 
 def synthetic_batch(B, seed, imgh=100, imgw=32, max_len=23, num_classes=38, T=52):
