@@ -124,9 +124,9 @@ def pointwise_gemm_roofline(eng, iters=5):
         for A, Bm, C, M, N, K, dta, dtc, wt in cfgs:
             if bf:
                 lib.crnn_gemm_bf16_ex(1 if wt else 0, _ptr(A), _ptr(Bm), _ptr(C), M, N, K, K, K if wt else N, N, None, 0, 0, 0, _ptr(scratch),
-                                      128 * 1024 * 1024, dta, 1, dtc, _stream())
+                                      64 * 1024 * 1024, dta, 1, dtc, _stream())
             else:
-                lib.crnn_gemm_f32(0, _ptr(A), _ptr(Bm), _ptr(C), M, N, K, K, N, N, None, 0, 0, 0, _ptr(scratch), 128 * 1024 * 1024, _stream())
+                lib.crnn_gemm_f32(0, _ptr(A), _ptr(Bm), _ptr(C), M, N, K, K, N, N, None, 0, 0, 0, _ptr(scratch), 64 * 1024 * 1024, _stream())
         e1.record()
         torch.cuda.synchronize()
         if it:

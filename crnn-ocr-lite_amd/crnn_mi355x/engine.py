@@ -5,6 +5,7 @@ This is what the Keras engine + TensorFlow session were for the reference (Model
 train_on_batch, train.py:201; Model.predict_generator, predict.py:166).  No CPU fallback exists.
 """
 import ctypes
+import os
 import math
 from collections import OrderedDict
 
@@ -68,6 +69,10 @@ class Engine:
         self.norm = torch.zeros(2, dtype=torch.float32, device=dev)
         self.norm_scratch = torch.zeros(1024, dtype=torch.float64, device=dev)
         self.opt_state = {}
+        # side-stream schedule of the backward (crnn_backward_ex): measured 1 % SLOWER than the serial one at batch 256 (the
+        # GEMMs crowd the latency-critical BPTT launches), so it is opt-in: CRNN_RNN_OVERLAP=1
+        self.overlap_rnn_wgrad = os.environ.get("CRNN_RNN_OVERLAP", "0") == "1"
+        self._aux_stream = None
 
     # ---- parameters -------------------------------------------------------------------------------------
     def set_params(self, p, bn=None):
@@ -141,15 +146,16 @@ class Engine:
     def backward(self, labels, input_length, label_length, seed=0):
         """CTC + backward after forward(train=True).  Returns per-sample loss (device tensor, B)."""
         self._lab = self._as_i32(labels); self._il = self._as_i32(input_length); self._ll = self._as_i32(label_length)
-        check(self.lib.crnn_backward(self._c, _ptr(self.params), _ptr(self.grads), _ptr(self._x), _ptr(self._lab), _ptr(self._il),
-                                     _ptr(self._ll), _ptr(self.ws), self.ws_bytes, _ptr(self.loss), int(seed), _stream()), "backward")
+        check(self.lib.crnn_backward_ex(self._c, _ptr(self.params), _ptr(self.grads), _ptr(self._x), _ptr(self._lab), _ptr(self._il),
+                                        _ptr(self._ll), _ptr(self.ws), self.ws_bytes, _ptr(self.loss), int(seed), _stream(), self._aux()),
+              "backward")
         return self.loss
 
     def backward_top(self, labels, input_length, label_length, seed=0):
         """First backward stage: CTC, dense2, recurrent layers, dense1 -> grads[grad_split:] are final."""
         self._lab = self._as_i32(labels); self._il = self._as_i32(input_length); self._ll = self._as_i32(label_length)
-        check(self.lib.crnn_backward_top(self._c, _ptr(self.params), _ptr(self.grads), _ptr(self._lab), _ptr(self._il), _ptr(self._ll),
-                                         _ptr(self.ws), self.ws_bytes, _ptr(self.loss), int(seed), _stream()), "backward_top")
+        check(self.lib.crnn_backward_top_ex(self._c, _ptr(self.params), _ptr(self.grads), _ptr(self._lab), _ptr(self._il), _ptr(self._ll),
+                                            _ptr(self.ws), self.ws_bytes, _ptr(self.loss), int(seed), _stream(), self._aux()), "backward_top")
         return self.loss
 
     def backward_bottom(self, seed=0):
@@ -160,6 +166,14 @@ class Engine:
     @property
     def grad_split(self):
         return int(self.lib.crnn_grad_split_offset(self._c))
+
+    def _aux(self):
+        """Second stream for the weight-gradient GEMMs that overlap the BPTT chains (None: serial schedule)."""
+        if not self.overlap_rnn_wgrad:
+            return None
+        if self._aux_stream is None:
+            self._aux_stream = torch.cuda.Stream(device=self.device)
+        return ctypes.c_void_p(self._aux_stream.cuda_stream)
 
     def bn_update(self):
         check(self.lib.crnn_bn_update(self._c, _ptr(self.bn_mean), _ptr(self.bn_var), _ptr(self.ws), self.ws_bytes, _stream()), "bn_update")

@@ -160,11 +160,13 @@ Plan make_plan(const crnn_config* c) {
   P.add("pbf", make_layout(c).total, CRNN_BF16);   // bf16 shadow of the parameter buffer (GEMM B operands in the bf16 modes)
   P.add("coef", 2 * 1024);
   P.add("fold", 32 * 2 * 1024);   // chunk sums of long BatchNorm partial lists (crnn_bn_finalize_folded)
-  P.add("gemm_scratch", 32L * 1024 * 1024);  // 128 MiB of split-reduction partials
+  P.add("gemm_scratch", 16L * 1024 * 1024);   // 64 MiB of split-reduction partials (main stream)
+  P.add("gemm_scratch2", 16L * 1024 * 1024);  // the same for the side stream of the backward
+  P.add("partials2", lmax((long)crnn_colreduce_chunks(TB) * lmax(d.G, lmax(d.tds, d.C)), 1024));
   return P;
 }
 
-const size_t kGemmScratchBytes = 128UL * 1024 * 1024;
+const size_t kGemmScratchBytes = 64UL * 1024 * 1024;
 
 struct Ctx {
   const crnn_config* cfg; Dims d; Layout L; Plan P;
@@ -174,7 +176,9 @@ struct Ctx {
   float* w(const std::string& n) const { return ws + P.off(n); }
   int dt(const std::string& n) const { return P.dt(n); }
   int gdt() const { return cfg->mfma_bf16 == 2 ? CRNN_BF16 : CRNN_F32; }   // storage of the conv-stack gradients
-  float* scratch() const { return ws + P.off("gemm_scratch"); }
+  bool side = false;   // side-stream context: its own split-reduction scratch and reduction partials
+  float* scratch() const { return ws + P.off(side ? "gemm_scratch2" : "gemm_scratch"); }
+  float* partials() const { return ws + P.off(side ? "partials2" : "partials"); }
 };
 
 // In the bf16 modes a weight operand (B of the NN / NT GEMMs, i.e. a pointer into the parameter buffer) is read from
@@ -213,8 +217,8 @@ int gemm32(const Ctx& c, int mode, const float* A, const float* B, float* C, int
 }
 
 int colsum(const Ctx& c, const float* x, long M, int C, int ld, float* out) {
-  CRNN_TRY(crnn_colreduce(x, c.w("partials"), M, C, ld, 1, c.s));
-  return crnn_partials_sum(c.w("partials"), crnn_colreduce_chunks(M), C, out, 1.f, c.s);
+  CRNN_TRY(crnn_colreduce(x, c.partials(), M, C, ld, 1, c.s));
+  return crnn_partials_sum(c.partials(), crnn_colreduce_chunks(M), C, out, 1.f, c.s);
 }
 
 int check_cfg(const crnn_config* c) {
@@ -432,28 +436,30 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
 }
 
 // ---------------------------------------------------------------------------------------------------
-static int lstm_layer_bwd(const Ctx& c, int layer, const float* xin, int ldx, int din, const float* hf, const float* hb, int ldh,
-                          const float* doutf, const float* doutb, int ldo, float* dxin) {
+// One Bidirectional layer's backward in three pieces so that the caller can put the weight-gradient GEMMs on a second
+// stream: (1) the BPTT chain (T dependent step launches, latency-bound), (2) dW/dU/db from the finished dz (throughput
+// work nobody downstream of the chain waits for), (3) dX = dZ W^T (what the layer below needs).
+static int rnn_bwd_chain(const Ctx& c, int layer, const float* hf, const float* hb, int ldh, const float* doutf, const float* doutb, int ldo) {
+  const Dims& d = c.d;
+  const int T = d.T, B = d.B, u = d.u;
+  std::string l = std::to_string(layer);
+  float* dzf = c.w("dz" + l + "f"); float* dzb = c.w("dz" + l + "b");
+  // bf16 modes: U is read from the bf16 shadow of the parameter buffer (refreshed by the forward)
+  int dtu = CRNN_F32;
+  const float* uf = c.p("rnn" + l + "f_u"); const float* ub = c.p("rnn" + l + "b_u");
+  if (c.cfg->mfma_bf16 && u % 128 == 0) { uf = weight_operand(c, 0, uf, &dtu); ub = weight_operand(c, 0, ub, &dtu); }
+  if (c.cfg->gru)
+    return crnn_gru_bwd_ex(uf, ub, hf, hb, ldh, c.w("gt" + l + "f"), c.w("gt" + l + "b"), doutf, doutb,
+                           ldo, dzf, dzb, c.w("dcf"), c.w("dcb"), c.w("dhpf"), c.w("dhpb"), T, B, u, dtu, c.s);
+  return crnn_lstm_bwd_ex(uf, ub, c.w("cs" + l + "f"), c.w("cs" + l + "b"), c.w("gt" + l + "f"),
+                          c.w("gt" + l + "b"), doutf, doutb, ldo, dzf, dzb, c.w("dcf"), c.w("dcb"), T, B, u, dtu, c.s);
+}
+static int rnn_bwd_wgrads(const Ctx& c, int layer, const float* xin, int ldx, int din, const float* hf, const float* hb, int ldh) {
   const Dims& d = c.d;
   const int T = d.T, B = d.B, TB = T * B, u = d.u, G = d.G;
   std::string l = std::to_string(layer);
   float* dzf = c.w("dz" + l + "f"); float* dzb = c.w("dz" + l + "b");
-  if (c.cfg->gru) {
-    int dtu = CRNN_F32;
-    const float* uf = c.p("rnn" + l + "f_u"); const float* ub = c.p("rnn" + l + "b_u");
-    if (c.cfg->mfma_bf16 && u % 128 == 0) { uf = weight_operand(c, 0, uf, &dtu); ub = weight_operand(c, 0, ub, &dtu); }
-    CRNN_TRY(crnn_gru_bwd_ex(uf, ub, hf, hb, ldh, c.w("gt" + l + "f"), c.w("gt" + l + "b"), doutf, doutb,
-                             ldo, dzf, dzb, c.w("dcf"), c.w("dcb"), c.w("dhpf"), c.w("dhpb"), T, B, u, dtu, c.s));
-  } else
-  {
-    // bf16 modes: U [u][4u] is read from the bf16 shadow of the parameter buffer (refreshed by the forward)
-    int dtu = CRNN_F32;
-    const float* uf = c.p("rnn" + l + "f_u"); const float* ub = c.p("rnn" + l + "b_u");
-    if (c.cfg->mfma_bf16 && u % 128 == 0) { uf = weight_operand(c, 0, uf, &dtu); ub = weight_operand(c, 0, ub, &dtu); }
-    CRNN_TRY(crnn_lstm_bwd_ex(uf, ub, c.w("cs" + l + "f"), c.w("cs" + l + "b"), c.w("gt" + l + "f"),
-                              c.w("gt" + l + "b"), doutf, doutb, ldo, dzf, dzb, c.w("dcf"), c.w("dcb"), T, B, u, dtu, c.s));
-  }
-  // dW = X^T dZ ; dU = Hprev^T dZ ; db = colsum(dZ) ; dX = dZf Wf^T + dZb Wb^T
+  // dW = X^T dZ ; dU = Hprev^T dZ ; db = colsum(dZ)
   CRNN_TRY(gemm(c, 2, xin, dzf, c.g("rnn" + l + "f_w"), din, G, TB, ldx, G, G));
   CRNN_TRY(gemm(c, 2, xin, dzb, c.g("rnn" + l + "b_w"), din, G, TB, ldx, G, G));
   const int K1 = (T - 1) * B;
@@ -466,27 +472,36 @@ static int lstm_layer_bwd(const Ctx& c, int layer, const float* xin, int ldx, in
     CRNN_TRY(gemm(c, 2, c.w("cs" + l + "b"), dzb + 2 * u, c.g("rnn" + l + "b_u") + 2 * u, u, u, TB, u, G, G));
   }
   CRNN_TRY(colsum(c, dzf, TB, G, G, c.g("rnn" + l + "f_b")));
-  CRNN_TRY(colsum(c, dzb, TB, G, G, c.g("rnn" + l + "b_b")));
-  CRNN_TRY(gemm(c, 1, dzf, c.p("rnn" + l + "f_w"), dxin, TB, din, G, G, G, din));
-  CRNN_TRY(gemm(c, 1, dzb, c.p("rnn" + l + "b_w"), dxin, TB, din, G, G, G, din, nullptr, 0, 1));
-  return CRNN_OK;
+  return colsum(c, dzb, TB, G, G, c.g("rnn" + l + "b_b"));
+}
+static int rnn_bwd_dx(const Ctx& c, int layer, int din, float* dxin) {
+  const Dims& d = c.d;
+  const int TB = d.T * d.B, G = d.G;
+  std::string l = std::to_string(layer);
+  CRNN_TRY(gemm(c, 1, c.w("dz" + l + "f"), c.p("rnn" + l + "f_w"), dxin, TB, din, G, G, G, din));
+  return gemm(c, 1, c.w("dz" + l + "b"), c.p("rnn" + l + "b_w"), dxin, TB, din, G, G, G, din, nullptr, 0, 1);
 }
 
 // The backward runs in two stages so that a data-parallel host can start the gradient all-reduce of the upper
 // layers (dense1, the recurrent layers, dense2: the tail of the flat buffer, 75 % of its bytes) while the
 // conv-stack / STN stage is still running.
 namespace {
-int backward_top(const Ctx& c, const int* labels, const int* input_length, const int* label_length, float* loss, uint64_t seed);
+int backward_top(const Ctx& c, const int* labels, const int* input_length, const int* label_length, float* loss, uint64_t seed, hipStream_t aux);
 int backward_bottom(const Ctx& c, const float* x, uint64_t seed);
 }
 extern "C" long crnn_grad_split_offset(const crnn_config* cfg) { return make_layout(cfg).off("dense1_w"); }
-extern "C" int crnn_backward_top(const crnn_config* cfg, const float* params, float* grads, const int* labels,
-                                 const int* input_length, const int* label_length, float* ws, size_t ws_bytes, float* loss,
-                                 uint64_t seed, hipStream_t stream) {
+extern "C" int crnn_backward_top_ex(const crnn_config* cfg, const float* params, float* grads, const int* labels,
+                                    const int* input_length, const int* label_length, float* ws, size_t ws_bytes, float* loss,
+                                    uint64_t seed, hipStream_t stream, hipStream_t aux_stream) {
   CRNN_TRY(check_cfg(cfg));
   Ctx c{cfg, make_dims(cfg), make_layout(cfg), make_plan(cfg), params, grads, ws, stream};
   if (ws_bytes < (size_t)c.P.total * sizeof(float)) return CRNN_ERR_ARG;
-  return backward_top(c, labels, input_length, label_length, loss, seed);
+  return backward_top(c, labels, input_length, label_length, loss, seed, aux_stream == stream ? nullptr : aux_stream);
+}
+extern "C" int crnn_backward_top(const crnn_config* cfg, const float* params, float* grads, const int* labels,
+                                 const int* input_length, const int* label_length, float* ws, size_t ws_bytes, float* loss,
+                                 uint64_t seed, hipStream_t stream) {
+  return crnn_backward_top_ex(cfg, params, grads, labels, input_length, label_length, ws, ws_bytes, loss, seed, stream, nullptr);
 }
 extern "C" int crnn_backward_bottom(const crnn_config* cfg, const float* params, float* grads, const float* x, float* ws,
                                     size_t ws_bytes, uint64_t seed, hipStream_t stream) {
@@ -501,28 +516,73 @@ extern "C" int crnn_backward(const crnn_config* cfg, const float* params, float*
   CRNN_TRY(check_cfg(cfg));
   Ctx c{cfg, make_dims(cfg), make_layout(cfg), make_plan(cfg), params, grads, ws, stream};
   if (ws_bytes < (size_t)c.P.total * sizeof(float)) return CRNN_ERR_ARG;
-  CRNN_TRY(backward_top(c, labels, input_length, label_length, loss, seed));
+  CRNN_TRY(backward_top(c, labels, input_length, label_length, loss, seed, nullptr));
+  return backward_bottom(c, x, seed);
+}
+extern "C" int crnn_backward_ex(const crnn_config* cfg, const float* params, float* grads, const float* x, const int* labels,
+                                const int* input_length, const int* label_length, float* ws, size_t ws_bytes, float* loss,
+                                uint64_t seed, hipStream_t stream, hipStream_t aux_stream) {
+  CRNN_TRY(check_cfg(cfg));
+  Ctx c{cfg, make_dims(cfg), make_layout(cfg), make_plan(cfg), params, grads, ws, stream};
+  if (ws_bytes < (size_t)c.P.total * sizeof(float)) return CRNN_ERR_ARG;
+  CRNN_TRY(backward_top(c, labels, input_length, label_length, loss, seed, aux_stream == stream ? nullptr : aux_stream));
   return backward_bottom(c, x, seed);
 }
 
 namespace {
-int backward_top(const Ctx& c, const int* labels, const int* input_length, const int* label_length, float* loss, uint64_t seed) {
+// aux != nullptr: a second stream takes the weight-gradient GEMMs that nothing on the critical path waits for (dense2's
+// during the layer-2 BPTT chain, layer 2's during the layer-1 chain).  The chains are T dependent launches of a few
+// microseconds each and leave the GPU almost idle; the GEMMs fill it.  Only the aux stream touches the split-reduction
+// scratch and the reduction partials between the fork and the join, and every gradient tensor still has a single
+// writer in a fixed order, so the result is bit-identical to the serial schedule.
+struct ForkJoin {
+  // The three events are created once per host thread and reused by every call (recording an event again while an earlier
+  // wait on it is still queued is well defined: the wait captured the earlier record); nothing is created or destroyed
+  // on the step's path.
+  hipStream_t main, aux; int n = 0; bool on;
+  ForkJoin(hipStream_t m, hipStream_t a) : main(m), aux(a), on(a != nullptr) {}
+  static int event(int i, hipEvent_t* out) {
+    static thread_local hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    if (!ev[i]) { hipError_t r = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming); if (r != hipSuccess) return (int)r; }
+    *out = ev[i];
+    return CRNN_OK;
+  }
+  int link(hipStream_t from, hipStream_t to) {   // `to` continues after everything enqueued on `from` so far
+    if (!on) return CRNN_OK;
+    hipEvent_t e; CRNN_TRY(event(n++, &e));
+    hipError_t r = hipEventRecord(e, from); if (r != hipSuccess) return (int)r;
+    r = hipStreamWaitEvent(to, e, 0); return r == hipSuccess ? CRNN_OK : (int)r;
+  }
+  int fork() { return link(main, aux); }
+  int join() { return link(aux, main); }
+};
+
+int backward_top(const Ctx& c, const int* labels, const int* input_length, const int* label_length, float* loss, uint64_t seed, hipStream_t aux) {
   const crnn_config* cfg = c.cfg; float* grads = c.grads; hipStream_t stream = c.s;
   const Dims& d = c.d;
   const int B = d.B, T = d.T, TB = T * B, u = d.u;
+  ForkJoin fj(stream, aux);
+  Ctx ca = c; if (aux) { ca.s = aux; ca.side = true; }   // same tensors, side stream, its own reduction scratch
   hipError_t e = hipMemsetAsync(grads, 0, (size_t)c.L.total * sizeof(float), stream);
   if (e != hipSuccess) return (int)e;
   // ---- CTC (utils.py:98-103): loss per sample + d mean(loss)/d logits (time-major)
   CRNN_TRY(crnn_ctc_loss_grad(c.w("ypred"), labels, input_length, label_length, loss, c.w("dlogits"), B, T, d.C, d.L, 2, 1.0f / (float)B, stream));
-  // ---- dense2
+  // ---- dense2: weight / bias gradients on the side stream, the data gradient feeds the recurrent layers
   const float* r2 = c.w("r2d");
-  CRNN_TRY(gemm(c, 2, r2, c.w("dlogits"), c.g("dense2_w"), 2 * u, d.C, TB, 2 * u, d.C, d.C));
-  CRNN_TRY(colsum(c, c.w("dlogits"), TB, d.C, d.C, c.g("dense2_b")));
+  CRNN_TRY(fj.fork());
+  CRNN_TRY(gemm(ca, 2, r2, c.w("dlogits"), c.g("dense2_w"), 2 * u, d.C, TB, 2 * u, d.C, d.C));
+  CRNN_TRY(colsum(ca, c.w("dlogits"), TB, d.C, d.C, c.g("dense2_b")));
   CRNN_TRY(gemm(c, 1, c.w("dlogits"), c.p("dense2_w"), c.w("dr2"), TB, 2 * u, d.C, d.C, d.C, 2 * u));
   if (cfg->dropout) CRNN_TRY(crnn_dropout(c.w("dr2"), c.w("dr2"), TB, 2 * u, 2 * u, 2 * u, kDropRnn, seed, kLayerRnn, stream));
-  // ---- Bidirectional LSTM x2
-  CRNN_TRY(lstm_layer_bwd(c, 2, c.w("r1"), u, u, c.w("h2"), c.w("h2") + u, 2 * u, c.w("dr2"), c.w("dr2") + u, 2 * u, c.w("dr1")));
-  CRNN_TRY(lstm_layer_bwd(c, 1, c.w("dn1"), d.tds, d.tds, c.w("h1f"), c.w("h1b"), u, c.w("dr1"), c.w("dr1"), u, c.w("ddn1")));
+  // ---- Bidirectional LSTM / GRU x2
+  CRNN_TRY(rnn_bwd_chain(c, 2, c.w("h2"), c.w("h2") + u, 2 * u, c.w("dr2"), c.w("dr2") + u, 2 * u));
+  CRNN_TRY(fj.fork());                               // dz of layer 2 is complete: its weight gradients go to the side stream
+  CRNN_TRY(rnn_bwd_wgrads(ca, 2, c.w("r1"), u, u, c.w("h2"), c.w("h2") + u, 2 * u));
+  CRNN_TRY(rnn_bwd_dx(c, 2, u, c.w("dr1")));
+  CRNN_TRY(rnn_bwd_chain(c, 1, c.w("h1f"), c.w("h1b"), u, c.w("dr1"), c.w("dr1"), u));
+  CRNN_TRY(fj.join());                               // the scratch buffers are the main stream's again
+  CRNN_TRY(rnn_bwd_wgrads(c, 1, c.w("dn1"), d.tds, d.tds, c.w("h1f"), c.w("h1b"), u));
+  CRNN_TRY(rnn_bwd_dx(c, 1, d.tds, c.w("ddn1")));
   // ---- Dropout(.4) + relu of dense1, rows back to batch-major
   CRNN_TRY(crnn_relu_bwd(c.w("dn1"), c.w("ddn1"), c.w("gbm"), TB, d.tds, cfg->dropout ? 1.0f / (1.0f - kDropDense1) : 1.0f, B, stream));
   const float* feat = c.w("x7");

@@ -77,6 +77,16 @@ int crnn_backward_top(const crnn_config* cfg, const float* params, float* grads,
                       const int* label_length, float* ws, size_t ws_bytes, float* loss, uint64_t seed, crnn_stream_t stream);
 int crnn_backward_bottom(const crnn_config* cfg, const float* params, float* grads, const float* x, float* ws, size_t ws_bytes,
                          uint64_t seed, crnn_stream_t stream);
+/* Same results, with a caller-owned second stream (aux_stream, NULL = serial): the weight-gradient GEMMs of dense2 and of the
+ * upper recurrent layer run there while the BPTT chains (2 x T dependent launches of a few microseconds, GPU almost
+ * idle) run on `stream`; events fork / join the two inside the call, everything is complete on `stream` order-wise when
+ * the call's last kernel is.  Bit-identical to the serial schedule. */
+int crnn_backward_top_ex(const crnn_config* cfg, const float* params, float* grads, const int* labels, const int* input_length,
+                         const int* label_length, float* ws, size_t ws_bytes, float* loss, uint64_t seed, crnn_stream_t stream,
+                         crnn_stream_t aux_stream);
+int crnn_backward_ex(const crnn_config* cfg, const float* params, float* grads, const float* x, const int* labels,
+                     const int* input_length, const int* label_length, float* ws, size_t ws_bytes, float* loss, uint64_t seed,
+                     crnn_stream_t stream, crnn_stream_t aux_stream);
 /* BatchNorm moving-average update from the batch statistics left in ws by a train=1 forward (momentum .99) */
 int crnn_bn_update(const crnn_config* cfg, float* bn_mean, float* bn_var, float* ws, size_t ws_bytes,
                    crnn_stream_t stream);

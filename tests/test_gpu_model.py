@@ -412,3 +412,28 @@ def test_c_train_step_driver_equals_the_staged_python_step():
     assert torch.equal(la, b.loss) and torch.equal(a.params, b.params)
     assert torch.equal(a.bn_mean, b.bn_mean) and torch.equal(a.bn_var, b.bn_var)
     assert torch.equal(a.opt_state["m"], mom) and torch.equal(a.opt_state["v"], vel)
+
+
+def test_side_stream_weight_gradients_equal_the_serial_schedule():
+    """crnn_backward_ex with a second stream (weight-gradient GEMMs of dense2 / the upper recurrent layer overlapping the BPTT
+    chains) must be bit-identical to the serial schedule, LSTM and GRU, fp32 and bf16s."""
+    for gru in (False, True):
+        cfg = M.Config(gru=gru)
+        B = 8
+        p, bn = M.init_params(cfg, seed=21, dtype=np.float32)
+        p = M.randomize_params(cfg, p)
+        x, lab, il, ll = M.synthetic_batch(cfg, B, seed=22)
+        for precision in ("fp32", "bf16s"):
+            eng = Engine(B, dropout=True, precision=precision, gru=gru)
+            eng.set_params(p, bn)
+            res = {}
+            for overlap in (False, True):
+                eng.overlap_rnn_wgrad = overlap
+                eng.grads.fill_(float("nan"))
+                eng.forward(x, train=True, seed=2)
+                loss = eng.backward(lab, il, ll, seed=2).clone()
+                torch.cuda.synchronize()
+                res[overlap] = (loss, eng.grads.clone())
+            assert torch.equal(res[False][0], res[True][0])
+            assert torch.equal(res[False][1], res[True][1]), (gru, precision)
+            assert torch.isfinite(res[True][1]).all()
