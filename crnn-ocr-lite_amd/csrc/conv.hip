@@ -1118,3 +1118,117 @@ extern "C" int crnn_relu_bwd(const float* y, const float* g, float* go, long row
 extern "C" int crnn_bn_act(const float* x, const float* bnstate, float* y, long M, int C, hipStream_t stream) {
   return crnn_bn_act_pool_drop(x, bnstate, y, 1, 1, (int)M, C, 1, 1, 0.f, 0, 0, stream);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Pointwise conv with ONE input channel (block 1: 1 -> 64, utils.py:64): an outer product, not a GEMM.
+//   fwd   q[m][c] = a[m] * w[c]                 (+ per-128-row-tile column statistics of q as stored)
+//   dgrad da[m]   = sum_c dq[m][c] * w[c]
+//   wgrad dw[c]   = sum_m a[m] * dq[m][c]        (partials per 1024-row chunk, then crnn_partials_sum)
+// a / da are fp32 (one channel is never stored as bf16), q / dq fp32 or bf16, N % 8 == 0, N <= 256.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pw1_fwd_kernel(const float* __restrict__ a, const float* __restrict__ w, T* __restrict__ q,
+                                                      float* __restrict__ stats, long M, int N) {
+  // one workgroup per 128-row tile (= one statistics row); thread = (8-column group, row lane)
+  __shared__ float red[2][256 * 8];
+  const int CG = N / 8, RT = 256 / CG, tid = threadIdx.x, cg = tid % CG, rt = tid / CG;
+  const long r0 = (long)blockIdx.x * 128;
+  float wv[8], s[8], ss[8];
+  VecF<8> wl = vload<8>(w + 8 * cg);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { wv[e] = wl.v[e]; s[e] = 0.f; ss[e] = 0.f; }
+  if (rt < RT)
+    for (int r = rt; r < 128 && r0 + r < M; r += RT) {
+      const float av = a[r0 + r];
+      VecF<8> o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o.v[e] = av * wv[e];
+      vstore<8>(&q[(r0 + r) * N + 8 * cg], o);
+      if (stats) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float v = o.v[e];
+          if (sizeof(T) == 2) v = __uint_as_float(pack2_bf16(v, 0.f) << 16);   // the value the consumer reads back
+          s[e] += v; ss[e] = fmaf(v, v, ss[e]);
+        }
+      }
+    }
+  if (!stats) return;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[0][tid * 8 + e] = s[e]; red[1][tid * 8 + e] = ss[e]; }
+  __syncthreads();
+  if (tid < 2 * N) {
+    const int v = tid / N, c = tid % N;
+    float acc = 0.f;
+    for (int r = 0; r < RT; ++r) acc += red[v][(r * CG + c / 8) * 8 + (c & 7)];
+    stats[((long)blockIdx.x * 2 + v) * N + c] = acc;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void pw1_dgrad_kernel(const T* __restrict__ dq, const float* __restrict__ w, float* __restrict__ da, long M, int N) {
+  // CG lanes per row (8 columns each), rows = 256 / CG per pass; lanes of a row are combined with shuffles
+  const int CG = N / 8, tid = threadIdx.x, cg = tid % CG;
+  VecF<8> wl = vload<8>(w + 8 * cg);
+  const long rows_per_block = 256 / CG;
+  for (long r = (long)blockIdx.x * rows_per_block + tid / CG; r < M; r += (long)gridDim.x * rows_per_block) {
+    VecF<8> g = vload<8>(&dq[r * N + 8 * cg]);
+    float acc = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc = fmaf(g.v[e], wl.v[e], acc);
+    for (int o = 1; o < CG; o <<= 1) acc += __shfl_xor(acc, o, 64);       // CG is a power of two <= 32 (N <= 256)
+    if (cg == 0) da[r] = acc;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void pw1_wgrad_kernel(const float* __restrict__ a, const T* __restrict__ dq, float* __restrict__ partials,
+                                                        long M, int N, int rows_per_chunk) {
+  __shared__ float red[256 * 8];
+  const int CG = N / 8, RT = 256 / CG, tid = threadIdx.x, cg = tid % CG, rt = tid / CG;
+  const long r0 = (long)blockIdx.x * rows_per_chunk;
+  long r1 = r0 + rows_per_chunk; if (r1 > M) r1 = M;
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  if (rt < RT)
+    for (long r = r0 + rt; r < r1; r += RT) {
+      const float av = a[r];
+      VecF<8> g = vload<8>(&dq[r * N + 8 * cg]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] = fmaf(av, g.v[e], s[e]);
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[tid * 8 + e] = s[e];
+  __syncthreads();
+  if (tid < N) {
+    float acc = 0.f;
+    for (int r = 0; r < RT; ++r) acc += red[(r * CG + tid / 8) * 8 + (tid & 7)];
+    partials[(long)blockIdx.x * N + tid] = acc;
+  }
+}
+static bool pw1_ok(int N, const void* q) { return N % 8 == 0 && N <= 256 && (N & (N - 1)) == 0 && ((uintptr_t)q & 15) == 0; }
+// q [M][N] = a[M] (x) w[N]; stat_partials (may be NULL): [ceil(M/128)][2][N] like crnn_pwconv_fwd
+extern "C" int crnn_pw1_fwd(const float* a, const float* w, void* q, long M, int N, float* stat_partials, int dt_q, hipStream_t stream) {
+  if (!pw1_ok(N, q) || M <= 0) return CRNN_ERR_UNSUPPORTED;
+  const int blocks = cdiv(M, 128);
+  if (dt_q == CRNN_BF16) hipLaunchKernelGGL(pw1_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, a, w, (bf16_t*)q, stat_partials, M, N);
+  else hipLaunchKernelGGL(pw1_fwd_kernel<float>, dim3(blocks), dim3(256), 0, stream, a, w, (float*)q, stat_partials, M, N);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+// da[M] = dq[M][N] . w[N];   dw[N] = sum_m a[m] * dq[m][N]  (scratch: crnn_colreduce_chunks(M) * N floats)
+extern "C" int crnn_pw1_bwd(const float* a, const float* w, const void* dq, float* da, float* dw, float* scratch, long M, int N,
+                            int dt_q, hipStream_t stream) {
+  if (!pw1_ok(N, dq) || M <= 0) return CRNN_ERR_UNSUPPORTED;
+  const int rpc = colreduce_rpc(M), chunks = cdiv(M, rpc);
+  if (dt_q == CRNN_BF16) hipLaunchKernelGGL(pw1_wgrad_kernel<bf16_t>, dim3(chunks), dim3(256), 0, stream, a, (const bf16_t*)dq, scratch, M, N, rpc);
+  else hipLaunchKernelGGL(pw1_wgrad_kernel<float>, dim3(chunks), dim3(256), 0, stream, a, (const float*)dq, scratch, M, N, rpc);
+  CRNN_LAUNCH_CHECK();
+  CRNN_TRY(crnn_partials_sum(scratch, chunks, N, dw, 1.f, stream));
+  if (da) {
+    int blocks = cdiv(M, 256 / (N / 8)); if (blocks > 8192) blocks = 8192;
+    if (dt_q == CRNN_BF16) hipLaunchKernelGGL(pw1_dgrad_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)dq, w, da, M, N);
+    else hipLaunchKernelGGL(pw1_dgrad_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)dq, w, da, M, N);
+    CRNN_LAUNCH_CHECK();
+  }
+  return CRNN_OK;
+}

@@ -363,8 +363,10 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
         wq = reinterpret_cast<const float*>(reinterpret_cast<const bf16_t*>(c.w("pwT")) + pwT_off[i]);
         dtw = CRNN_BF16; wt = 1;
       }
-      const bool fold = (ph * pw == 1) && (c.dt("x" + p) == dtq);
-      CRNN_TRY(crnn_pwconv_fwd(aa, wq, fold ? xo : qq, M, co, ci, nullptr, fold ? s2 : nullptr, cfg->mfma_bf16 ? 1 : 0, dtd, dtw, dtq, wt, stream));
+      const bool one = (ci == 1 && dtd == CRNN_F32);                      // block 1: an outer product, not a GEMM
+      const bool fold = !one && (ph * pw == 1) && (c.dt("x" + p) == dtq);
+      if (one) CRNN_TRY(crnn_pw1_fwd(aa, c.p(bp + "_pw"), qq, M, co, nullptr, dtq, stream));
+      else CRNN_TRY(crnn_pwconv_fwd(aa, wq, fold ? xo : qq, M, co, ci, nullptr, fold ? s2 : nullptr, cfg->mfma_bf16 ? 1 : 0, dtd, dtw, dtq, wt, stream));
       if (!fold) CRNN_TRY(crnn_bn_act_pool_drop_ex(qq, s2, xo, B, H, W, co, ph, pw, 0.f, seed, (uint32_t)i, dtq, c.dt("x" + p), stream));
       in = xo;
       continue;
@@ -386,7 +388,8 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
         wq = reinterpret_cast<const float*>(reinterpret_cast<const bf16_t*>(c.w("pwT")) + pwT_off[i]);
         dtw = CRNN_BF16; wt = 1;
       }
-      CRNN_TRY(crnn_pwconv_fwd(aa, wq, qq, M, co, ci, parts, nullptr, cfg->mfma_bf16 ? 1 : 0, dtd, dtw, dtq, wt, stream));
+      if (ci == 1 && dtd == CRNN_F32) CRNN_TRY(crnn_pw1_fwd(aa, c.p(bp + "_pw"), qq, M, co, parts, dtq, stream));   // block 1: outer product
+      else CRNN_TRY(crnn_pwconv_fwd(aa, wq, qq, M, co, ci, parts, nullptr, cfg->mfma_bf16 ? 1 : 0, dtd, dtw, dtq, wt, stream));
     }
     CRNN_TRY(crnn_bn_finalize_folded(parts, crnn_pwconv_stat_rows(M), co, M, c.p(bp + "_bn2_g"), c.p(bp + "_bn2_b"), s2, c.w("fold"), stream));
     bn_off += co;
@@ -606,8 +609,12 @@ int backward_bottom(const Ctx& c, const float* x, uint64_t seed) {
     const int dtd = c.dt("d" + p), dtq = c.dt("q" + p);   // dtq == storage of the incoming gradient (gdt)
     CRNN_TRY(crnn_bn_bwd_ex(c.w("q" + p), gA, c.w("bn2s" + p), c.p(bp + "_bn2_g"), gB, c.g(bp + "_bn2_g"), c.g(bp + "_bn2_b"), c.w("partials"),
                             c.w("coef"), B, H, W, co, kBlocks[i - 1].ph, kBlocks[i - 1].pw, cfg->dropout ? kDropBlock : 0.f, seed, (uint32_t)i, dtq, stream));
-    CRNN_TRY(gemm_t(c, 2, c.w("a" + p), dtd, gB, dtq, c.g(bp + "_pw"), CRNN_F32, ci, co, (int)M, ci, co, co));
-    CRNN_TRY(gemm_t(c, 1, gB, dtq, c.p(bp + "_pw"), CRNN_F32, gA, dtd, (int)M, ci, co, co, co, ci));
+    if (ci == 1 && dtd == CRNN_F32) {   // block 1: outer-product weight / data gradients
+      CRNN_TRY(crnn_pw1_bwd(c.w("a" + p), c.p(bp + "_pw"), gB, gA, c.g(bp + "_pw"), c.w("partials"), M, co, dtq, stream));
+    } else {
+      CRNN_TRY(gemm_t(c, 2, c.w("a" + p), dtd, gB, dtq, c.g(bp + "_pw"), CRNN_F32, ci, co, (int)M, ci, co, co));
+      CRNN_TRY(gemm_t(c, 1, gB, dtq, c.p(bp + "_pw"), CRNN_F32, gA, dtd, (int)M, ci, co, co, co, ci));
+    }
     CRNN_TRY(crnn_bn_bwd_ex(c.w("d" + p), gA, c.w("bn1s" + p), c.p(bp + "_bn1_g"), gB, c.g(bp + "_bn1_g"), c.g(bp + "_bn1_b"), c.w("partials"),
                             c.w("coef"), B, H, W, ci, 1, 1, 0.f, 0, 0, dtd, stream));
     const float* xin = (i == 1) ? c.w("x0") : c.w("x" + std::to_string(i - 1));

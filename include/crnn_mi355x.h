@@ -146,6 +146,13 @@ int crnn_gemm_bf16_ex(int mode, const void* A, const void* B, void* C, int M, in
 int crnn_pwconv_stat_rows(long M);
 int crnn_pwconv_fwd(const void* a, const void* w, void* q, long M, int N, int K, float* stat_partials, const float* out_bnstate,
                     int bf16_products, int dt_a, int dt_w, int dt_q, int w_transposed, crnn_stream_t stream);
+/* The same pointwise conv for ONE input channel (block 1: Conv2D(64, 1x1) on the single-channel depthwise output,
+ * utils.py:64 / 49): an outer product q[m][c] = a[m] * w[c], its data gradient da[m] = dq[m] . w and weight gradient
+ * dw[c] = sum_m a[m] dq[m][c].  a / da fp32; q / dq fp32 (dt_q 0) or bf16 (1); N a power of two, 8 <= N <= 256.
+ * stat_partials as for crnn_pwconv_fwd; scratch: crnn_colreduce_chunks(M) * N floats; da may be NULL. */
+int crnn_pw1_fwd(const float* a, const float* w, void* q, long M, int N, float* stat_partials, int dt_q, crnn_stream_t stream);
+int crnn_pw1_bwd(const float* a, const float* w, const void* dq, float* da, float* dw, float* scratch, long M, int N, int dt_q,
+                 crnn_stream_t stream);
 /* Depthwise 3x3 with the inference BatchNorm + ReLU6 after it (utils.py:44-46) folded into the epilogue:
  * out = ReLU6(dwconv3x3(x, k) * scale + shift); C must be a multiple of 32 (fp32 storage) / 64 (bf16 storage). */
 int crnn_dwconv3x3_bn_relu6_fwd(const void* x, const float* k, const float* bnstate, void* out, int B, int H, int W, int C,

@@ -668,3 +668,32 @@ def test_inference_epilogues_fold_batchnorm_and_relu6(storage):
         assert_close(host(q), ref_x, rtol=1e-4, atol=1e-4, what="pw + folded BN + ReLU6 (fp32)")
     # statistics and the folded BatchNorm are mutually exclusive
     assert L().crnn_pwconv_fwd(P(out), P(dev(Wp)), P(q), M_, N, C, P(zeros(8, 2, N)), P(st2), 0, 0, 0, 0, 0, S()) != 0
+
+
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+def test_single_channel_pointwise_conv_outer_product_kernels(storage):
+    """crnn_pw1_fwd / crnn_pw1_bwd (block 1: one input channel) against the plain matrix form."""
+    rs = np.random.RandomState(8)
+    Mm, N = 128 * 3 + 45, 64
+    bf = storage == "bf16"
+    a = rs.normal(size=Mm); w = rs.normal(size=N) * 0.5
+    ref = np.outer(a.astype(np.float32).astype(np.float64), w.astype(np.float32).astype(np.float64))
+    rows = L().crnn_pwconv_stat_rows(Mm)
+    parts = zeros(rows, 2, N)
+    q = torch.zeros(Mm, N, dtype=torch.bfloat16 if bf else torch.float32, device="cuda")
+    ok(L().crnn_pw1_fwd(P(dev(a)), P(dev(w)), P(q), Mm, N, P(parts), int(bf), S()))
+    got = _f(q) if bf else host(q)
+    assert_close(got, ref, rtol=2.0 ** -8 if bf else 1e-6, atol=1e-6, what="outer product")
+    pr = host(parts).astype(np.float64); g64 = got.astype(np.float64)
+    for t in range(rows):
+        blk = g64[128 * t: 128 * (t + 1)]
+        assert_close(pr[t, 0], blk.sum(0), rtol=1e-5, atol=1e-4, what="tile sum"); assert_close(pr[t, 1], (blk * blk).sum(0), rtol=1e-5, atol=1e-4, what="tile sumsq")
+    dq = rs.normal(size=(Mm, N))
+    if bf:
+        dq = _bf16_round(dq)
+    dqd = _to_bf16_dev(dq) if bf else dev(dq)
+    da = zeros(Mm); dw = zeros(N); scr = zeros(L().crnn_colreduce_chunks(Mm) * N)
+    ok(L().crnn_pw1_bwd(P(dev(a)), P(dev(w)), P(dqd), P(da), P(dw), P(scr), Mm, N, int(bf), S()))
+    assert_close(host(da), dq @ w.astype(np.float32).astype(np.float64), rtol=1e-5, atol=1e-5, what="da")
+    assert_close(host(dw), a.astype(np.float32).astype(np.float64) @ dq, rtol=1e-5, atol=1e-4, what="dw")
+    assert L().crnn_pw1_fwd(P(dev(a)), P(dev(w)), P(q), Mm, 48, None, int(bf), S()) == -3        # N must be a power of two
