@@ -21,11 +21,13 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
 // gx[b,h,w,c] = gy[b,h/ph,w/pw,c] if (h,w) is the FIRST maximum of its window (scan order) else 0
 __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gx, int B,
                                    int H, int W, int C, int ph, int pw) {
-  int Ho = H / ph, Wo = W / pw;
-  long total = (long)B * H * W * C;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int c = (int)(i % C); long pix = i / C;
-    int w = (int)(pix % W); long r = pix / W; int h = (int)(r % H); long b = r / H;
+  // 32-bit index arithmetic (the launcher refuses tensors of 2^31 elements or more): 64-bit div/mod chains cost more
+  // than the memory traffic of these small localisation-net tensors
+  const int Ho = H / ph, Wo = W / pw;
+  const int total = B * H * W * C;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int c = i % C, pix = i / C;
+    int w = pix % W, r = pix / W, h = r % H, b = r / H;
     int ho = h / ph, wo = w / pw;
     float out = 0.f;
     if (ho < Ho && wo < Wo) {
@@ -54,7 +56,8 @@ extern "C" int crnn_maxpool_fwd(const float* x, float* y, int B, int H, int W, i
 }
 extern "C" int crnn_maxpool_bwd(const float* x, const float* gy, float* gx, int B, int H, int W, int C, int ph, int pw, hipStream_t s) {
   long total = (long)B * H * W * C;
-  int blocks = cdiv(total, 256); if (blocks > 4096) blocks = 4096;
+  if (total >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;   // 32-bit index arithmetic
+  int blocks = cdiv(total, 256); if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks), dim3(256), 0, s, x, gy, gx, B, H, W, C, ph, pw);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
@@ -62,29 +65,29 @@ extern "C" int crnn_maxpool_bwd(const float* x, const float* gy, float* gx, int 
 
 // ---- im2col / col2im for a KxK 'valid' stride-1 conv; column = (i*K + j)*C + c (HWIO order) -------
 __global__ void im2col_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int H, int W, int C, int K) {
-  int Ho = H - K + 1, Wo = W - K + 1;
-  int KKC = K * K * C;
-  long total = (long)B * Ho * Wo * KKC;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int q = (int)(i % KKC); long row = i / KKC;
-    int c = q % C; int ij = q / C; int j = ij % K, ii = ij / K;
-    int wo = (int)(row % Wo); long r = row / Wo; int ho = (int)(r % Ho); long b = r / Ho;
+  const int Ho = H - K + 1, Wo = W - K + 1;
+  const int KKC = K * K * C;
+  const int total = B * Ho * Wo * KKC;             // < 2^31 (checked by the launcher)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int q = i % KKC, row = i / KKC;
+    int c = q % C, ij = q / C, j = ij % K, ii = ij / K;
+    int wo = row % Wo, r = row / Wo, ho = r % Ho, b = r / Ho;
     col[i] = x[((b * H + ho + ii) * W + wo + j) * C + c];
   }
 }
 __global__ void col2im_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int B, int H, int W, int C, int K) {
-  int Ho = H - K + 1, Wo = W - K + 1;
-  int KKC = K * K * C;
-  long total = (long)B * H * W * C;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int c = (int)(i % C); long pix = i / C;
-    int w = (int)(pix % W); long r = pix / W; int h = (int)(r % H); long b = r / H;
+  const int Ho = H - K + 1, Wo = W - K + 1;
+  const int KKC = K * K * C;
+  const int total = B * H * W * C;                 // dcol has < 2^31 elements too (checked by the launcher)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int c = i % C, pix = i / C;
+    int w = pix % W, r = pix / W, h = r % H, b = r / H;
     float a = 0.f;
     for (int ii = 0; ii < K; ++ii) {
       int ho = h - ii; if (ho < 0 || ho >= Ho) continue;
       for (int j = 0; j < K; ++j) {
         int wo = w - j; if (wo < 0 || wo >= Wo) continue;
-        a += dcol[((b * Ho + ho) * Wo + wo) * (long)KKC + (ii * K + j) * C + c];
+        a += dcol[((b * Ho + ho) * Wo + wo) * KKC + (ii * K + j) * C + c];
       }
     }
     dx[i] = a;
@@ -92,6 +95,7 @@ __global__ void col2im_kernel(const float* __restrict__ dcol, float* __restrict_
 }
 extern "C" int crnn_im2col(const float* x, float* col, int B, int H, int W, int C, int K, hipStream_t s) {
   long total = (long)B * (H - K + 1) * (W - K + 1) * K * K * C;
+  if (total >= (1L << 31) || (long)B * H * W * C >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;   // 32-bit index arithmetic
   int blocks = cdiv(total, 256); if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(im2col_kernel, dim3(blocks), dim3(256), 0, s, x, col, B, H, W, C, K);
   CRNN_LAUNCH_CHECK();
@@ -99,6 +103,7 @@ extern "C" int crnn_im2col(const float* x, float* col, int B, int H, int W, int 
 }
 extern "C" int crnn_col2im(const float* dcol, float* dx, int B, int H, int W, int C, int K, hipStream_t s) {
   long total = (long)B * H * W * C;
+  if (total >= (1L << 31) || (long)B * (H - K + 1) * (W - K + 1) * K * K * C >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;
   int blocks = cdiv(total, 256); if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(col2im_kernel, dim3(blocks), dim3(256), 0, s, dcol, dx, B, H, W, C, K);
   CRNN_LAUNCH_CHECK();
