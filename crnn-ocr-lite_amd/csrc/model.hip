@@ -106,10 +106,8 @@ Plan make_plan(const crnn_config* c) {
   }
   // STN locnet
   P.add("pool1", B * d.Hs1 * d.Ws1);
-  P.add("col1", B * d.Ho1 * d.Wo1 * 25);
   P.add("c1", B * d.Ho1 * d.Wo1 * 20);
   P.add("pool2", B * d.Hs2 * d.Ws2 * 20);
-  P.add("col2", B * d.Ho2 * d.Wo2 * 500);
   P.add("flat", B * d.stn_flat);
   P.add("fc1", B * 50);
   P.add("theta", B * 6);
@@ -151,9 +149,13 @@ Plan make_plan(const crnn_config* c) {
   // gradient ping-pong buffers: sized for fp32, hold bf16 tensors in storage mode 2
   P.add("gA", maxact); P.add("gB", maxact);
   P.add("dtheta", B * 6); P.add("dfc1", B * 50); P.add("dflat", B * d.stn_flat);
-  P.add("dcol2", B * d.Ho2 * d.Wo2 * 500); P.add("dpool2", B * d.Hs2 * d.Ws2 * 20); P.add("dc1", B * d.Ho1 * d.Wo1 * 20);
+  P.add("dpool2", B * d.Hs2 * d.Ws2 * 20); P.add("dc1", B * d.Ho1 * d.Wo1 * 20);
   maxparts = lmax(maxparts, (long)crnn_colreduce_chunks(TB) * lmax(d.G, lmax(d.tds, d.C)));
   maxparts = lmax(maxparts, (long)crnn_colreduce_chunks(B * d.Ho1 * d.Wo1) * 64);
+  if (c->stn) {
+    maxparts = lmax(maxparts, ((long)crnn_loc_conv_wgrad_chunks(d.B, d.Hs1, d.Ws1) + 1) * (25L * 20 + 20));
+    maxparts = lmax(maxparts, ((long)crnn_loc_conv_wgrad_chunks(d.B, d.Hs2, d.Ws2) + 1) * (25L * 20 * 20 + 20));
+  }
   P.add("partials", maxparts);
   { long pw = 0; for (int i = 2; i <= 7; ++i) pw += (long)d.bc[i - 1] * d.bc[i];
     P.add("pwT", pw, CRNN_BF16); }   // bf16 W^T copies of the pointwise-conv weights (bf16 modes)
@@ -305,15 +307,11 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
   // ---- spatial transformer (utils.py:247-258) + ZeroPadding2D (utils.py:63)
   if (cfg->stn) {
     CRNN_TRY(crnn_maxpool_fwd(x, c.w("pool1"), B, d.H0, d.W0, 1, 2, 2, stream));
-    CRNN_TRY(crnn_im2col(c.w("pool1"), c.w("col1"), B, d.Hs1, d.Ws1, 1, 5, stream));
-    int R1 = B * d.Ho1 * d.Wo1;
-    CRNN_TRY(gemm32(c, 0, c.w("col1"), c.p("stn_c1_k"), c.w("c1"), R1, 20, 25, 25, 20, 20, c.p("stn_c1_b")));
+    CRNN_TRY(crnn_loc_conv_fwd(c.w("pool1"), c.p("stn_c1_k"), c.p("stn_c1_b"), c.w("c1"), B, d.Hs1, d.Ws1, 1, stream));
     CRNN_TRY(crnn_maxpool_fwd(c.w("c1"), c.w("pool2"), B, d.Ho1, d.Wo1, 20, 2, 2, stream));
-    CRNN_TRY(crnn_im2col(c.w("pool2"), c.w("col2"), B, d.Hs2, d.Ws2, 20, 5, stream));
-    int R2 = B * d.Ho2 * d.Wo2;
-    CRNN_TRY(gemm32(c, 0, c.w("col2"), c.p("stn_c2_k"), c.w("flat"), R2, 20, 500, 500, 20, 20, c.p("stn_c2_b")));
-    CRNN_TRY(gemm32(c, 0, c.w("flat"), c.p("stn_d1_w"), c.w("fc1"), B, 50, d.stn_flat, d.stn_flat, 50, 50, c.p("stn_d1_b"), 1));
-    CRNN_TRY(gemm32(c, 0, c.w("fc1"), c.p("stn_d2_w"), c.w("theta"), B, 6, 50, 50, 6, 6, c.p("stn_d2_b")));
+    CRNN_TRY(crnn_loc_conv_fwd(c.w("pool2"), c.p("stn_c2_k"), c.p("stn_c2_b"), c.w("flat"), B, d.Hs2, d.Ws2, 20, stream));
+    CRNN_TRY(crnn_loc_fc_fwd(c.w("flat"), c.p("stn_d1_w"), c.p("stn_d1_b"), c.p("stn_d2_w"), c.p("stn_d2_b"), c.w("fc1"), c.w("theta"), B,
+                             d.stn_flat, stream));
     CRNN_TRY(crnn_sampler_fwd(x, c.w("theta"), c.w("x0"), B, d.H0, d.W0, 2, stream));
   } else {
     CRNN_TRY(crnn_pad_copy(x, c.w("x0"), B, d.H0, d.W0, 2, stream));
@@ -624,21 +622,12 @@ int backward_bottom(const Ctx& c, const float* x, uint64_t seed) {
   // ---- spatial transformer
   if (cfg->stn) {
     CRNN_TRY(crnn_sampler_bwd(x, c.w("theta"), gA, c.w("dtheta"), B, d.H0, d.W0, 2, stream));
-    CRNN_TRY(gemm32(c, 2, c.w("fc1"), c.w("dtheta"), c.g("stn_d2_w"), 50, 6, B, 50, 6, 6));
-    CRNN_TRY(colsum(c, c.w("dtheta"), B, 6, 6, c.g("stn_d2_b")));
-    CRNN_TRY(gemm32(c, 1, c.w("dtheta"), c.p("stn_d2_w"), c.w("dfc1"), B, 50, 6, 6, 6, 50));
-    CRNN_TRY(crnn_relu_bwd(c.w("fc1"), c.w("dfc1"), c.w("dfc1"), B, 50, 1.f, 0, stream));
-    CRNN_TRY(gemm32(c, 2, c.w("flat"), c.w("dfc1"), c.g("stn_d1_w"), d.stn_flat, 50, B, d.stn_flat, 50, 50));
-    CRNN_TRY(colsum(c, c.w("dfc1"), B, 50, 50, c.g("stn_d1_b")));
-    CRNN_TRY(gemm32(c, 1, c.w("dfc1"), c.p("stn_d1_w"), c.w("dflat"), B, d.stn_flat, 50, 50, 50, d.stn_flat));
-    const int R2 = B * d.Ho2 * d.Wo2, R1 = B * d.Ho1 * d.Wo1;
-    CRNN_TRY(gemm32(c, 2, c.w("col2"), c.w("dflat"), c.g("stn_c2_k"), 500, 20, R2, 500, 20, 20));
-    CRNN_TRY(colsum(c, c.w("dflat"), R2, 20, 20, c.g("stn_c2_b")));
-    CRNN_TRY(gemm32(c, 1, c.w("dflat"), c.p("stn_c2_k"), c.w("dcol2"), R2, 500, 20, 20, 20, 500));
-    CRNN_TRY(crnn_col2im(c.w("dcol2"), c.w("dpool2"), B, d.Hs2, d.Ws2, 20, 5, stream));
+    CRNN_TRY(crnn_loc_fc_bwd(c.w("flat"), c.w("fc1"), c.w("dtheta"), c.p("stn_d1_w"), c.p("stn_d2_w"), c.w("dfc1"), c.w("dflat"),
+                             c.g("stn_d1_w"), c.g("stn_d1_b"), c.g("stn_d2_w"), c.g("stn_d2_b"), B, d.stn_flat, stream));
+    CRNN_TRY(crnn_loc_conv_wgrad(c.w("pool2"), c.w("dflat"), c.g("stn_c2_k"), c.g("stn_c2_b"), c.w("partials"), B, d.Hs2, d.Ws2, 20, stream));
+    CRNN_TRY(crnn_loc_conv_dgrad(c.w("dflat"), c.p("stn_c2_k"), c.w("dpool2"), B, d.Hs2, d.Ws2, stream));
     CRNN_TRY(crnn_maxpool_bwd(c.w("c1"), c.w("dpool2"), c.w("dc1"), B, d.Ho1, d.Wo1, 20, 2, 2, stream));
-    CRNN_TRY(gemm32(c, 2, c.w("col1"), c.w("dc1"), c.g("stn_c1_k"), 25, 20, R1, 25, 20, 20));
-    CRNN_TRY(colsum(c, c.w("dc1"), R1, 20, 20, c.g("stn_c1_b")));
+    CRNN_TRY(crnn_loc_conv_wgrad(c.w("pool1"), c.w("dc1"), c.g("stn_c1_k"), c.g("stn_c1_b"), c.w("partials"), B, d.Hs1, d.Ws1, 1, stream));
   }
   return CRNN_OK;
 }

@@ -216,6 +216,21 @@ int crnn_sampler_fwd(const float* img, const float* theta, float* out, int B, in
 int crnn_sampler_bwd(const float* img, const float* theta, const float* gout, float* dtheta, int B, int H, int W,
                      int pad, crnn_stream_t stream);
 int crnn_pad_copy(const float* img, float* out, int B, int H, int W, int pad, crnn_stream_t stream);
+/* Localisation net of the spatial transformer (utils.py:248-256) as direct kernels -- weights in LDS, no im2col:
+ * 5x5 'valid' convolution with 20 filters, NHWC fp32, Cin = 1 (first conv) or 20 (second), kernel [5][5][Cin][20];
+ * forward (+bias, linear), weight/bias gradient (scratch: crnn_loc_conv_wgrad_chunks(B,H,W) * (25*Cin*20 + 20) floats, plus one
+ * more row when db != dk + 25*Cin*20), data gradient (Cin = 20 only; the first conv's input needs none). */
+int crnn_loc_conv_fwd(const float* x, const float* k, const float* bias, float* y, int B, int H, int W, int Cin, crnn_stream_t stream);
+int crnn_loc_conv_wgrad_chunks(int B, int H, int W);
+int crnn_loc_conv_wgrad(const float* x, const float* gy, float* dk, float* db, float* scratch, int B, int H, int W, int Cin,
+                        crnn_stream_t stream);
+int crnn_loc_conv_dgrad(const float* gy, const float* k, float* dx, int B, int H, int W, crnn_stream_t stream);
+/* its two dense layers fused: fc1 = relu(flat W1 + b1) [F -> 50], theta = fc1 W2 + b2 [50 -> 6]; and their backward:
+ * dfc1 / dflat per image, dW1 [F][50], db1, dW2 [50][6], db2 summed over the batch in image order (deterministic) */
+int crnn_loc_fc_fwd(const float* flat, const float* w1, const float* b1, const float* w2, const float* b2, float* fc1, float* theta,
+                    int B, int F, crnn_stream_t stream);
+int crnn_loc_fc_bwd(const float* flat, const float* fc1, const float* dtheta, const float* w1, const float* w2, float* dfc1,
+                    float* dflat, float* dw1, float* db1, float* dw2, float* db2, int B, int F, crnn_stream_t stream);
 /* Bidirectional LSTM recurrence (utils.py:78-79), time-major */
 int crnn_lstm_fwd(const float* xw0, const float* xw1, const float* ut0, const float* ut1, float* h0, float* h1, int ldh,
                   float* c0, float* c1, float* g0, float* g1, int T, int B, int u, crnn_stream_t stream);

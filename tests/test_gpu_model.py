@@ -207,12 +207,13 @@ def test_config1_shape_full_model_step_and_decode():
     eng.adam_step(1e-4, 0.5, 0.999, 1e-7, 5.0, iteration=0)
     eng.bn_update()
     opt = M.Adam(lr=1e-4, beta_1=0.5, beta_2=0.999, epsilon=1e-7, clipnorm=5.0)
-    p_ref = opt.step({k: v.copy() for k, v in p.items()}, gdev)
+    # the optimizer arithmetic is checked on the DEVICE's own gradient (gd; its parity with the oracle's is asserted by
+    # check_case above): the first Adam step moves a weight by ~lr*g/(|g|+eps'), so feeding the oracle's gradient instead
+    # would turn fp32 summation-order noise on near-zero gradient elements into differences of several % of lr
+    p_ref = opt.step({k: v.copy() for k, v in p.items()}, {k: gd[k].astype(np.float64) for k in gd})
     pd = eng.get_params()
     for k in p:
-        # the first Adam step moves every weight by ~lr*g/(|g|+eps'): elements whose gradient is within the fp32 noise of
-        # zero move by a different fraction of lr -> absolute slack of 5 % of lr = 1e-4
-        assert np.abs(pd[k] - p_ref[k]).max() < 5e-6 + 1e-5 * np.abs(p_ref[k]).max(), k
+        assert np.abs(pd[k] - p_ref[k]).max() < 2e-7 + 2e-6 * np.abs(p_ref[k]).max(), k
     bn_ref = M.bn_update(cfg, {k: v.copy() for k, v in bn.items()}, c)
     bnd = eng.get_bn()
     for k in bn_ref:

@@ -697,3 +697,54 @@ def test_single_channel_pointwise_conv_outer_product_kernels(storage):
     assert_close(host(da), dq @ w.astype(np.float32).astype(np.float64), rtol=1e-5, atol=1e-5, what="da")
     assert_close(host(dw), a.astype(np.float32).astype(np.float64) @ dq, rtol=1e-5, atol=1e-4, what="dw")
     assert L().crnn_pw1_fwd(P(dev(a)), P(dev(w)), P(q), Mm, 48, None, int(bf), S()) == -3        # N must be a power of two
+
+
+@pytest.mark.parametrize("cin,H,W", [(1, 50, 16), (20, 23, 6), (20, 9, 7)])
+def test_localisation_net_direct_conv_kernels(cin, H, W):
+    """crnn_loc_conv_fwd / _wgrad / _dgrad: the 5x5 'valid' convolutions of the spatial transformer's localisation net
+    (utils.py:248-252) against the im2col restatement."""
+    rs = np.random.RandomState(cin + H)
+    B = 7
+    x = rs.normal(size=(B, H, W, cin)); k = rs.normal(size=(5, 5, cin, 20)) * 0.2; b = rs.normal(size=20) * 0.1
+    ref = ops.conv_valid_fwd(x, k, b)
+    y = zeros(B, H - 4, W - 4, 20)
+    ok(L().crnn_loc_conv_fwd(P(dev(x)), P(dev(k)), P(dev(b)), P(y), B, H, W, cin, S()))
+    assert_close(host(y), ref, rtol=1e-5, atol=1e-5, what="conv fwd")
+    gy = rs.normal(size=ref.shape)
+    dx_ref, dk_ref, db_ref = ops.conv_valid_bwd(x, k, gy)
+    chunks = L().crnn_loc_conv_wgrad_chunks(B, H, W)
+    grads = zeros(25 * cin * 20 + 20)                       # [dk | db] adjacent, as in the parameter layout
+    scr = zeros((chunks + 1) * (25 * cin * 20 + 20))
+    ok(L().crnn_loc_conv_wgrad(P(dev(x)), P(dev(gy)), P(grads), ctypes.c_void_p(grads.data_ptr() + 4 * 25 * cin * 20), P(scr), B, H, W, cin, S()))
+    g = host(grads)
+    assert_close(g[:25 * cin * 20].reshape(k.shape), dk_ref, rtol=1e-4, atol=1e-4, what="dk")
+    assert_close(g[25 * cin * 20:], db_ref, rtol=1e-4, atol=1e-4, what="db")
+    # separate dk / db buffers take the copy path
+    dk2 = zeros(25 * cin * 20); db2 = zeros(20)
+    ok(L().crnn_loc_conv_wgrad(P(dev(x)), P(dev(gy)), P(dk2), P(db2), P(scr), B, H, W, cin, S()))
+    assert_close(host(dk2).reshape(k.shape), dk_ref, rtol=1e-4, atol=1e-4, what="dk (split)"); assert_close(host(db2), db_ref, rtol=1e-4, atol=1e-4, what="db (split)")
+    if cin == 20:
+        dx = zeros(B, H, W, cin)
+        ok(L().crnn_loc_conv_dgrad(P(dev(gy)), P(dev(k)), P(dx), B, H, W, S()))
+        assert_close(host(dx), dx_ref, rtol=1e-4, atol=1e-5, what="dx")
+    assert L().crnn_loc_conv_fwd(P(dev(x)), P(dev(k)), P(dev(b)), P(y), B, H, W, 3, S()) == -3
+
+
+@pytest.mark.parametrize("B,F", [(12, 760), (3, 80)])
+def test_localisation_net_dense_kernels(B, F):
+    """crnn_loc_fc_fwd / crnn_loc_fc_bwd: Dense(50, relu) -> Dense(6) (utils.py:254-255) and their gradients."""
+    rs = np.random.RandomState(B)
+    flat = rs.normal(size=(B, F)); w1 = rs.normal(size=(F, 50)) * 0.1; b1 = rs.normal(size=50) * 0.1
+    w2 = rs.normal(size=(50, 6)) * 0.3; b2 = rs.normal(size=6)
+    pre = ops.dense_fwd(flat, w1, b1); h = np.maximum(pre, 0); th = ops.dense_fwd(h, w2, b2)
+    fc1 = zeros(B, 50); theta = zeros(B, 6)
+    ok(L().crnn_loc_fc_fwd(P(dev(flat)), P(dev(w1)), P(dev(b1)), P(dev(w2)), P(dev(b2)), P(fc1), P(theta), B, F, S()))
+    assert_close(host(fc1), h, rtol=1e-5, atol=1e-5, what="fc1"); assert_close(host(theta), th, rtol=1e-5, atol=1e-5, what="theta")
+    dth = rs.normal(size=(B, 6))
+    dh, dw2_ref, db2_ref = ops.dense_bwd(h, w2, dth)
+    dpre = dh * (pre > 0)
+    dflat_ref, dw1_ref, db1_ref = ops.dense_bwd(flat, w1, dpre)
+    dfc1 = zeros(B, 50); dflat = zeros(B, F); dw1 = zeros(F, 50); db1 = zeros(50); dw2 = zeros(50, 6); db2 = zeros(6)
+    ok(L().crnn_loc_fc_bwd(P(dev(flat)), P(fc1), P(dev(dth)), P(dev(w1)), P(dev(w2)), P(dfc1), P(dflat), P(dw1), P(db1), P(dw2), P(db2), B, F, S()))
+    for got, ref, nm in ((dfc1, dpre, "dfc1"), (dflat, dflat_ref, "dflat"), (dw1, dw1_ref, "dW1"), (db1, db1_ref, "db1"), (dw2, dw2_ref, "dW2"), (db2, db2_ref, "db2")):
+        assert_close(host(got), ref, rtol=1e-4, atol=1e-5, what=nm)
