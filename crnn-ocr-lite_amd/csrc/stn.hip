@@ -21,29 +21,24 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
 // gx[b,h,w,c] = gy[b,h/ph,w/pw,c] if (h,w) is the FIRST maximum of its window (scan order) else 0
 __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gx, int B,
                                    int H, int W, int C, int ph, int pw) {
-  // 32-bit index arithmetic (the launcher refuses tensors of 2^31 elements or more): 64-bit div/mod chains cost more
-  // than the memory traffic of these small localisation-net tensors
+  // one thread per pooling window and channel: reads the window once, routes gy to its FIRST maximum (scan order) and
+  // zeroes the rest; rows / columns beyond the last full window were zeroed by the launcher.  32-bit index arithmetic
+  // (the launcher refuses tensors of 2^31 elements or more).
   const int Ho = H / ph, Wo = W / pw;
-  const int total = B * H * W * C;
+  const int total = B * Ho * Wo * C;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     int c = i % C, pix = i / C;
-    int w = pix % W, r = pix / W, h = r % H, b = r / H;
-    int ho = h / ph, wo = w / pw;
-    float out = 0.f;
-    if (ho < Ho && wo < Wo) {
-      float v = x[i];
-      int si = h - ho * ph, sj = w - wo * pw;
-      bool is_arg = true;
-      for (int ii = 0; ii < ph && is_arg; ++ii)
-        for (int j = 0; j < pw; ++j) {
-          if (ii == si && j == sj) continue;
-          float o = x[((b * H + ho * ph + ii) * W + wo * pw + j) * C + c];
-          bool earlier = (ii < si) || (ii == si && j < sj);
-          if (earlier ? (o >= v) : (o > v)) { is_arg = false; break; }
-        }
-      if (is_arg) out = gy[((b * Ho + ho) * Wo + wo) * C + c];
-    }
-    gx[i] = out;
+    int wo = pix % Wo, r = pix / Wo, ho = r % Ho, b = r / Ho;
+    const int base = ((b * H + ho * ph) * W + wo * pw) * C + c;
+    float best = x[base]; int arg = 0;
+    for (int ii = 0; ii < ph; ++ii)
+      for (int j = 0; j < pw; ++j) {
+        float v = x[base + (ii * W + j) * C];
+        if (v > best) { best = v; arg = ii * pw + j; }          // strict '>' keeps the first maximum
+      }
+    const float g = gy[i];
+    for (int ii = 0; ii < ph; ++ii)
+      for (int j = 0; j < pw; ++j) gx[base + (ii * W + j) * C] = (ii * pw + j == arg) ? g : 0.f;
   }
 }
 
@@ -57,7 +52,12 @@ extern "C" int crnn_maxpool_fwd(const float* x, float* y, int B, int H, int W, i
 extern "C" int crnn_maxpool_bwd(const float* x, const float* gy, float* gx, int B, int H, int W, int C, int ph, int pw, hipStream_t s) {
   long total = (long)B * H * W * C;
   if (total >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;   // 32-bit index arithmetic
-  int blocks = cdiv(total, 256); if (blocks > 8192) blocks = 8192;
+  if (H % ph || W % pw) {                                  // elements outside every window get no gradient
+    hipError_t e = hipMemsetAsync(gx, 0, (size_t)total * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+  }
+  const long windows = (long)B * (H / ph) * (W / pw) * C;
+  int blocks = cdiv(windows, 256); if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks), dim3(256), 0, s, x, gy, gx, B, H, W, C, ph, pw);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void loc_fc_bwd_data_kernel(const float* __res
 // images staged through LDS in chunks of LOC_IC; a block owns LOC_RB rows r of one of two problems:
 //   blocks [0, nb1):  L = flat [B][F] (+ a virtual all-ones row F -> db1), R = dfc1 [B][50]  -> dW1 [F][50], db1
 //   last block:       L = fc1 [B][50] (+ ones row -> db2),                R = dtheta [B][6] -> dW2 [50][6], db2
-#define LOC_RB 16
+#define LOC_RB 8
 #define LOC_IC 64
 __global__ __launch_bounds__(256) void loc_fc_bwd_weights_kernel(const float* __restrict__ flat, const float* __restrict__ fc1, const float* __restrict__ dfc1,
                                                                  const float* __restrict__ dtheta, float* __restrict__ dw1, float* __restrict__ db1,
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void loc_fc_bwd_weights_kernel(const float* __
   const int nlim = second ? LOC_H1 : F;                              // index of the virtual ones-row
   const float* Lm = second ? fc1 : flat; const int ldl = second ? LOC_H1 : F;
   const float* Rm = second ? dtheta : dfc1;
-  // outputs of this thread: o = tid, tid + 256, ... < nr * nc  (<= 4 per thread: 16*50 = 800, 51*6 = 306)
+  // outputs of this thread: o = tid, tid + 256, ... < nr * nc  (<= 4 per thread: 8*50 = 400, 51*6 = 306)
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   for (int i0 = 0; i0 < B; i0 += LOC_IC) {
     const int ni = min(LOC_IC, B - i0);
