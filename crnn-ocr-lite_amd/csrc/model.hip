@@ -402,8 +402,18 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
   // ---- 2 x Bidirectional(LSTM) (utils.py:78-79)
   // bf16 modes: the recurrent products run on the bf16 MFMA from a bf16 U^T (u % 128 == 0); parity mode: fp32
   const int dtu = (cfg->mfma_bf16 && u % 128 == 0) ? CRNN_BF16 : CRNN_F32;
-  for (const char* n : {"1f", "1b", "2f", "2b"})
-    CRNN_TRY(crnn_transpose_ex(c.p(std::string("rnn") + n + "_u"), c.w(std::string("ut") + n), u, G, dtu, stream));
+  {  // U -> U^T for the four recurrences, one launch
+    long in_off[4], out_off[4]; int R[4], Cc[4]; int n = 0;
+    const char* names[4] = {"1f", "1b", "2f", "2b"};
+    const long esz = (dtu == CRNN_BF16) ? 2 : 4;
+    for (const char* nm : names) {
+      in_off[n] = c.L.off(std::string("rnn") + nm + "_u");
+      // element offset of ut<nm> from ut1f in the destination type (the workspace offsets are in floats)
+      out_off[n] = (c.P.off(std::string("ut") + nm) - c.P.off("ut1f")) * 4 / esz;
+      R[n] = u; Cc[n] = G; ++n;
+    }
+    CRNN_TRY(crnn_transpose_batch(params, c.w("ut1f"), 4, in_off, out_off, R, Cc, dtu, stream));
+  }
   CRNN_TRY(gemm(c, 0, c.w("dn1"), c.p("rnn1f_w"), c.w("xw1f"), TB, G, d.tds, d.tds, G, G, c.p("rnn1f_b")));
   CRNN_TRY(gemm(c, 0, c.w("dn1"), c.p("rnn1b_w"), c.w("xw1b"), TB, G, d.tds, d.tds, G, G, c.p("rnn1b_b")));
   if (cfg->gru)   // "cs" holds r*h_prev for the GRU (cell state for the LSTM)
