@@ -193,6 +193,13 @@ def test_config1_shape_gru_model():
     check_case(run_case(B=4, imgh=100, imgw=32, u=256, tds=128, max_len=23, stn=True, dropout=False, gru=True), "config1-gru")
 
 
+def test_odd_shape_model_wide_image_small_alphabet():
+    """A shape none of the reference's configurations use: 60 x 48 images (maps 64x52 -> 32x26 -> 32x13, so the depthwise
+    tiles, the pooled BN backward and the localisation net all see odd extents), 20 classes, max_len 10, 128 units
+    (bf16-capable width), dropout on."""
+    check_case(run_case(B=5, imgh=60, imgw=48, u=128, tds=64, max_len=10, stn=True, dropout=True, num_classes=20), "odd-shape")
+
+
 def test_small_model_stn_disabled():
     check_case(run_case(B=3, imgh=40, imgw=32, u=64, tds=32, max_len=6, stn=False, dropout=False), "nostn")
 
