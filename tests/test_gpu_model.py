@@ -197,7 +197,17 @@ def test_odd_shape_model_wide_image_small_alphabet():
     """A shape none of the reference's configurations use: 60 x 48 images (maps 64x52 -> 32x26 -> 32x13, so the depthwise
     tiles, the pooled BN backward and the localisation net all see odd extents), 20 classes, max_len 10, 128 units
     (bf16-capable width), dropout on."""
-    check_case(run_case(B=5, imgh=60, imgw=48, u=128, tds=64, max_len=10, stn=True, dropout=True, num_classes=20), "odd-shape")
+    res = run_case(B=5, imgh=60, imgw=48, u=128, tds=64, max_len=10, stn=True, dropout=True, num_classes=20)
+    check_case(res, "odd-shape")
+    # the throughput mode at the same shape: close to the fp32 engine's posteriors, finite deterministic gradients
+    cfg, eng32, p, bn, (x, lab, il, ll), yd = res[0], res[1], res[2], res[3], res[4], res[5]
+    eng = Engine(5, 60, 48, 20, 10, 64, 128, stn=True, dropout=True, precision="bf16s")
+    eng.set_params(p, bn)
+    y16 = eng.forward(x.astype(np.float32), train=True, seed=3).cpu().numpy()
+    assert np.abs(y16 - yd).max() < 5e-2
+    l1 = eng.backward(lab, il, ll, seed=3).clone(); g1 = eng.grads.clone()
+    eng.forward(x.astype(np.float32), train=True, seed=3); l2 = eng.backward(lab, il, ll, seed=3)
+    assert torch.equal(l1, l2) and torch.equal(g1, eng.grads) and torch.isfinite(g1).all()
 
 
 def test_small_model_stn_disabled():
