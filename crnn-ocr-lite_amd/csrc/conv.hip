@@ -191,11 +191,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void dw
     if (gh >= H) break;
     const int o = (gh * W + w0 + lx) * C;
     float gv[PXB][VN];
+    bool pv[PXB];                                // pixel e of this group exists (the last group of a row may be ragged)
+#pragma unroll
+    for (int e = 0; e < PXB; ++e) pv[e] = (lx + e < TW) && (w0 + lx + e < W);
     if (MODE == 1) {
 #pragma unroll
       for (int e = 0; e < PXB; ++e) {
         V gr; zerov(gr);
-        if (lx + e < TW && w0 + lx + e < W) gr = ldraw<V>(gb + o + e * C);
+        if (pv[e]) gr = ldraw<V>(gb + o + e * C);
         widen(gr, gv[e]);
       }
     }
@@ -216,14 +219,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void dw
 #pragma unroll
           for (int c = 0; c < VN; ++c) {
             if (FWD) a[e][c] = fmaf(r[e + j][c], kw[i * 3 + j][c], a[e][c]);
-            else dk[i * 3 + j][c] = fmaf(r[e + j][c], gv[e][c], dk[i * 3 + j][c]);
+            else if (pv[e]) dk[i * 3 + j][c] = fmaf(r[e + j][c], gv[e][c], dk[i * 3 + j][c]);   // (a ragged group's window may hold LDS garbage: 0 * NaN)
           }
       __builtin_amdgcn_sched_barrier(0);   // one window row at a time: keeps the live set under the 3-waves/SIMD budget
     }
     if (FWD) {
 #pragma unroll
       for (int e = 0; e < PXB; ++e)
-        if (lx + e < TW && w0 + lx + e < W) {
+        if (pv[e]) {
           if (MODE == 2) {
 #pragma unroll
             for (int c = 0; c < VN; ++c) a[e][c] = relu6f(fmaf(a[e][c], bsc[c], bsh[c]));
