@@ -468,6 +468,31 @@ def test_bf16_storage_dwconv_bn_chain():
     assert_close(_f(dx), dx_ref, rtol=2.0 ** -7, atol=2e-2, what="dx bf16")
 
 
+@pytest.mark.parametrize("shape", [(2, 30, 26, 64), (2, 12, 52, 128), (1, 9, 7, 64), (1, 6, 70, 64)])
+def test_bf16_dwconv_ragged_width_after_nan_filled_lds(shape):
+    """Widths that are not a multiple of the kernel's 3-pixel group: the last group of a row is ragged, and its window
+    reads LDS the tile fill never wrote.  A NaN-input launch first leaves NaN patterns in LDS; the weight gradient, the
+    forward and the statistics of the next launch must not see them (regression: 0 * NaN in the wgrad accumulators)."""
+    B, H, W, C = shape
+    rs = np.random.RandomState(sum(shape))
+    x = _bf16_round(rs.normal(size=shape)); k = rs.normal(size=(3, 3, C)); g = _bf16_round(rs.normal(size=shape))
+    xd, gd, kd = _to_bf16_dev(x), _to_bf16_dev(g), dev(k)
+    nt = L().crnn_dwconv_num_tiles(B, H, W)
+    poison = torch.full((8, 64, 64, C), float("nan"), dtype=torch.bfloat16, device="cuda")
+    pout = torch.zeros_like(poison)
+    for trial in range(3):
+        ok(L().crnn_dwconv3x3_fwd_ex(P(poison), P(kd), P(pout), None, 8, 64, 64, C, 0, 1, S()))
+        dk = zeros(9, C); scr = zeros(nt * 9 * C)
+        ok(L().crnn_dwconv3x3_wgrad_ex(P(xd), P(gd), P(dk), P(scr), B, H, W, C, 1, S()))
+        assert_close(host(dk).reshape(3, 3, C), ops.dwconv_bwd(x, k, g)[1], rtol=1e-4, atol=1e-3, what="wgrad trial %d" % trial)
+        ok(L().crnn_dwconv3x3_fwd_ex(P(poison), P(kd), P(pout), None, 8, 64, 64, C, 0, 1, S()))
+        out = torch.zeros(B, H, W, C, dtype=torch.bfloat16, device="cuda"); parts = zeros(nt, 2, C)
+        ok(L().crnn_dwconv3x3_fwd_ex(P(xd), P(kd), P(out), P(parts), B, H, W, C, 0, 1, S()))
+        ref = ops.dwconv_fwd(x, k)
+        assert_close(_f(out), ref, rtol=2.0 ** -8, atol=2e-2, what="fwd trial %d" % trial)
+        assert_close(host(parts).sum(0)[0], ref.sum((0, 1, 2)), rtol=1e-4, atol=1e-2, what="stats trial %d" % trial)
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_gemm_bf16_storage_operands_and_result(mode):
     rs = np.random.RandomState(40 + mode)
