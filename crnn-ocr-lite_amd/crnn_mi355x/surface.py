@@ -7,9 +7,11 @@ evaluate_generator, get/set_weights, load/save_weights, save, to_json, summary, 
 input).  The model is not a graph of Python layer objects: `get_model()` returns a handle whose train /
 predict steps are single calls into libcrnn_mi355x (forward + CTC + backward + optimizer as HIP kernels).
 
-Storage: Keras `.h5` needs h5py (absent) -> weights are written as NumPy .npz *under the reference's file
-names* (final_weights.h5 etc. contain an npz archive); the list order is Keras' weight order so an
-h5 importer can be added without touching anything else.
+Storage: `save_weights` / `save` / `load_weights` read and write real HDF5 files in the layout Keras 2.2.2 uses
+(`layer_names` / `weight_names` attributes, one group per layer, one contiguous float32 dataset per weight; `save` puts
+them under `/model_weights` next to a `model_config` attribute) through the package's own HDF5 subset (hdf5.py; h5py is
+not importable here).  Paths ending in `.npz` -- and archives written by earlier revisions under `.h5` names -- are
+NumPy archives in Keras' weight order.
 """
 import ctypes
 import json
@@ -19,7 +21,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from . import native
+from . import hdf5, native
 from .init import initial_parameters
 
 BLOCK_FILTERS = (64, 128, 256, 256, 512, 512, 512)
@@ -96,6 +98,7 @@ class Model:
         self.optimizer = None
         self._iterations = 0
         self._prefetched = None          # (generator, batch) drawn ahead of time by fit_generator (kept across epochs)
+        self._keras_json = None          # the Keras model.json this model was built from (layer names for HDF5 files)
         sh = self.config["shape"]
         self._T = (sh[0] + 4) // 2
         if share is not None:                        # predictor view of an existing model: same weights/engine
@@ -183,22 +186,127 @@ class Model:
             tgt[n] = np.asarray(w, dtype=np.float32).reshape(tgt[n].shape)
         self._push()
 
+    # ---- Keras HDF5 layout (keras/engine/saving.py of 2.2.2: save_weights_to_hdf5_group / load_weights_from_hdf5_group) ----
+    def _keras_layers(self):
+        """[(layer name, [(weight name, ('p'|'s', engine tensor name))])] for every layer of the Keras graph, in
+        `model.layers` order.  Names come from the Keras model.json this model was built from, else they are the names a
+        fresh Keras session gives CRNN.get_model() (= those in the reference's models/*/model.json)."""
+        widx = iter(self._weight_index())
+        take = lambda names: [(n, next(widx)) for n in names]
+        if self._keras_json is not None:
+            specs, nbi = [], 0
+            for l in self._keras_json["config"]["layers"]:
+                if l["class_name"] == "Bidirectional":
+                    nbi += 1
+                    inner = l["config"]["layer"]
+                    extra = inner["config"].get("name") or "%s_%d" % (inner["class_name"].lower(), nbi)
+                else:
+                    extra = bool(l["config"].get("use_bias", True))
+                specs.append((l["class_name"], l["name"], extra))
+        else:
+            cell = "gru" if self.config["GRU"] else "lstm"
+            specs = [("InputLayer", "the_input", None), ("MaxPooling2D", "max_pooling2d_1", None), ("Conv2D", "conv2d_1", True),
+                     ("MaxPooling2D", "max_pooling2d_2", None), ("Conv2D", "conv2d_2", True), ("Flatten", "flatten_1", None),
+                     ("Dense", "dense_1", None), ("Activation", "activation_1", None), ("Dense", "dense_2", None),
+                     ("BilinearInterpolation", "bilinear_interpolation_1", None), ("ZeroPadding2D", "zero_padding2d_1", None)]
+            npool = 2
+            for i in range(1, 8):
+                specs += [("DepthwiseConv2D", "depthwise_conv2d_%d" % i, None), ("BatchNormalization", "batch_normalization_%d" % (2 * i - 1), None),
+                          ("ReLU", "re_lu_%d" % (2 * i - 1), None), ("Conv2D", "conv2d_%d" % (i + 2), False),
+                          ("BatchNormalization", "batch_normalization_%d" % (2 * i), None), ("ReLU", "re_lu_%d" % (2 * i), None)]
+                if BLOCK_POOL[i - 1]:
+                    npool += 1
+                    specs.append(("MaxPooling2D", "max_pooling2d_%d" % npool, None))
+                specs.append(("Dropout", "dropout_%d" % i, None))
+            specs += [("Reshape", "reshape", None), ("Dense", "dense1", None), ("Dropout", "dropout_8", None),
+                      ("Bidirectional", "bidirectional_1", cell + "_1"), ("Bidirectional", "bidirectional_2", cell + "_2"),
+                      ("Dropout", "dropout_9", None), ("Dense", "dense2", None), ("Activation", "softmax", None)]
+            if not self.predictor:
+                specs += [("InputLayer", "the_labels", None), ("InputLayer", "input_length", None), ("InputLayer", "label_length", None),
+                          ("Lambda", "ctc", None)]
+        out = []
+        for kind, name, inner in specs:
+            if kind == "Conv2D":
+                # the two localisation convolutions carry a bias, the pointwise ones do not (utils.py:46-53,249-251)
+                w = take([name + "/kernel:0", name + "/bias:0"] if inner else [name + "/kernel:0"])
+            elif kind == "DepthwiseConv2D":
+                w = take([name + "/depthwise_kernel:0"])
+            elif kind == "BatchNormalization":
+                w = take([name + "/" + k + ":0" for k in ("gamma", "beta", "moving_mean", "moving_variance")])
+            elif kind == "Dense":
+                w = take([name + "/kernel:0", name + "/bias:0"])
+            elif kind == "Bidirectional":
+                w = take(["%s/%s_%s/%s:0" % (name, d, inner, k) for d in ("forward", "backward") for k in ("kernel", "recurrent_kernel", "bias")])
+            else:
+                w = []
+            out.append((name, w))
+        if next(widx, None) is not None:
+            raise ValueError("Keras layer list does not cover every weight of the model")
+        return out
+
+    def _weights_group(self, group):
+        """Fill `group` the way `save_weights_to_hdf5_group` does."""
+        self._pull()
+        st = self._state
+        layers = self._keras_layers()
+        group.attrs["layer_names"] = np.array([n.encode("utf8") for n, _ in layers])
+        group.attrs["backend"] = b"tensorflow"
+        group.attrs["keras_version"] = b"2.2.2"
+        for lname, ws in layers:
+            g = group.create_group(lname)
+            g.attrs["weight_names"] = np.array([n.encode("utf8") for n, _ in ws]) if ws else np.zeros((0,), np.float64)
+            for wname, (kind, key) in ws:
+                g.create_dataset(wname, self._keras_shape(key, np.asarray(st["params"][key] if kind == "p" else st["bn"][key], np.float32)))
+        return group
+
+    @staticmethod
+    def _attr_list(attrs, name):
+        """Keras splits attributes above 64 KB into name0, name1, ... (`load_attributes_from_hdf5_group`)."""
+        if name in attrs:
+            vals = attrs[name]
+        else:
+            vals, k = [], 0
+            while "%s%d" % (name, k) in attrs:
+                vals.extend(attrs["%s%d" % (name, k)]); k += 1
+        return [v.decode("utf8") if isinstance(v, bytes) else str(v) for v in np.asarray(vals).ravel().tolist()]
+
+    def _load_hdf5(self, path):
+        root = hdf5.read(path)
+        if "layer_names" not in root.attrs and "layer_names0" not in root.attrs and "model_weights" in root:
+            root = root["model_weights"]                          # a `model.save` file
+        weights = []
+        for lname in self._attr_list(root.attrs, "layer_names"):
+            g = root[lname]
+            weights += [g[w].value for w in self._attr_list(g.attrs, "weight_names")]
+        self.set_weights(weights)
+
     def save_weights(self, path):
-        ws = self.get_weights()
-        with open(path, "wb") as f:
-            np.savez(f, **{"w%03d" % i: w for i, w in enumerate(ws)})
+        if str(path).endswith(".npz"):
+            with open(path, "wb") as f:
+                np.savez(f, **{"w%03d" % i: w for i, w in enumerate(self.get_weights())})
+        else:
+            hdf5.write(path, self._weights_group(hdf5.Group()))
 
     def load_weights(self, path):
-        with np.load(path) as z:
-            self.set_weights([z["w%03d" % i] for i in range(len(z.files))])
+        if hdf5.is_hdf5(path):
+            self._load_hdf5(path)
+        else:
+            with np.load(path) as z:
+                self.set_weights([z["w%03d" % i] for i in range(len([k for k in z.files if k.startswith("w")]))])
 
     def save(self, path):
-        """Keras `model.save` (architecture + weights; optimizer state is not resumed by the reference either)."""
-        ws = self.get_weights()
-        with open(path, "wb") as f:
-            np.savez(f, model_json=np.array(self.to_json()), **{"w%03d" % i: w for i, w in enumerate(ws)})
+        """Keras `model.save`: `model_config` + `/model_weights` (the reference never resumes optimizer state: train.py
+        re-compiles, so no `optimizer_weights` group is written)."""
+        root = hdf5.Group()
+        root.attrs["keras_version"] = b"2.2.2"
+        root.attrs["backend"] = b"tensorflow"
+        root.attrs["model_config"] = self.to_json().encode("utf8")
+        self._weights_group(root.create_group("model_weights"))
+        hdf5.write(path, root)
 
     def to_json(self):
+        if self._keras_json is not None:
+            return json.dumps(self._keras_json)
         return json.dumps({"class_name": "Model", "backend": "crnn_mi355x", "keras_version": "2.2.2-compatible surface",
                            "config": {"crnn": {k: (list(v) if isinstance(v, tuple) else v) for k, v in self.config.items()},
                                       "predictor": self.predictor}})
@@ -397,7 +505,9 @@ def model_from_json(text, custom_objects=None):
     if "layers" in cfg:
         crnn = crnn_config_from_keras_json(cfg)
         predictor = not any(l["name"] == "ctc" for l in cfg["layers"])      # init_predictor's sub-model has no loss head
-        return Model(crnn, predictor=predictor)
+        model = Model(crnn, predictor=predictor)
+        model._keras_json = top
+        return model
     raise ValueError("unrecognised model.json")
 
 
