@@ -33,6 +33,10 @@ struct GemmParams {
   int tilesN;
   float* stats;    // optional [tilesM][2][N]: per-tile column sums / sums of squares of the result as stored (BatchNorm statistics)
   const float* cscale; const float* cshift;   // optional per-column epilogue  C = ReLU6(C * cscale[n] + cshift[n])  (inference BatchNorm folded in)
+  // optional producer prologue on A (bf16 kernel, bf16 A): the operand the MFMA sees is ReLU6(A * ascale[ch] + ashift[ch])
+  // rounded to bf16, ch = the reduction index (modes 0/1) or the A row (mode 2): the BatchNorm + ReLU6 between a depthwise
+  // and a pointwise convolution, applied while the tile is staged instead of in a pass of its own
+  const float* ascale; const float* ashift;
 };
 
 // ---- statistics epilogue: per-tile column sums / sums of squares of the result as it will be stored, taken straight
@@ -321,7 +325,7 @@ static int gemm_f32_impl(int mode, const float* A, const float* B, float* C, int
   if (stats && (bias || act || accumulate || permP || scratch || cscale)) return CRNN_ERR_ARG;   // statistics of the plain product only
   if (cscale && (scratch || accumulate || !cshift)) return CRNN_ERR_ARG;                          // no split reduction with the folded BatchNorm
   GemmParams p;
-  p.stats = stats; p.cscale = cscale; p.cshift = cshift;
+  p.stats = stats; p.cscale = cscale; p.cshift = cshift; p.ascale = nullptr; p.ashift = nullptr;
   p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.bias = bias; p.act = act; p.accumulate = accumulate; p.permP = permP;
   p.dtA = p.dtB = p.dtC = CRNN_F32;
@@ -393,4 +397,21 @@ extern "C" int crnn_pwconv_fwd(const void* a, const void* w, void* q, long M, in
     return gemm_bf16_impl(mode, a, w, q, (int)M, N, K, K, ldw, N, nullptr, 0, 0, 0, nullptr, 0, dt_a, dt_w, dt_q, stat_partials, stream, cs, ch);
   if (dt_a != CRNN_F32 || dt_w != CRNN_F32 || dt_q != CRNN_F32) return CRNN_ERR_ARG;
   return gemm_f32_impl(mode, (const float*)a, (const float*)w, (float*)q, (int)M, N, K, K, ldw, N, nullptr, 0, 0, 0, nullptr, 0, stat_partials, stream, cs, ch);
+}
+
+// The same convolution fed by the PRE-BatchNorm depthwise output d (bf16): the operand is ReLU6(BN(d)) (utils.py:45-46),
+// formed per element while the tile is staged (GemmParams::ascale/ashift), so the activated tensor is never written.
+extern "C" int crnn_pwconv_bnrelu6_fwd(const void* d, const float* in_bnstate, const void* w, void* q, long M, int N, int K,
+                                       float* stat_partials, int dt_q, int w_transposed, hipStream_t stream) {
+  if (M <= 0 || M > 0x7fffffffL || !in_bnstate) return CRNN_ERR_ARG;
+  const int mode = w_transposed ? 1 : 0, ldw = w_transposed ? K : N;
+  return gemm_bf16_impl(mode, d, w, q, (int)M, N, K, K, ldw, N, nullptr, 0, 0, 0, nullptr, 0, CRNN_BF16, CRNN_BF16, dt_q, stat_partials, stream,
+                        nullptr, nullptr, in_bnstate + 2L * K, in_bnstate + 3L * K);
+}
+// ... and its weight gradient dw[K][N] = ReLU6(BN(d))^T [K][M] * g[M][N] (fp32 result; g bf16)
+extern "C" int crnn_pwconv_bnrelu6_wgrad(const void* d, const float* in_bnstate, const void* g, float* dw, long M, int N, int K,
+                                         float* scratch, size_t scratch_bytes, hipStream_t stream) {
+  if (M <= 0 || M > 0x7fffffffL || !in_bnstate) return CRNN_ERR_ARG;
+  return gemm_bf16_impl(2, d, g, dw, K, N, (int)M, K, N, N, nullptr, 0, 0, 0, scratch, scratch_bytes, CRNN_BF16, CRNN_BF16, CRNN_F32, nullptr, stream,
+                        nullptr, nullptr, in_bnstate + 2L * K, in_bnstate + 3L * K);
 }

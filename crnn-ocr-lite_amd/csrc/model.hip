@@ -212,6 +212,14 @@ int gemm_t(const Ctx& c, int mode, const float* A, int dtA, const float* B, int 
   if (dtA != CRNN_F32 || dtB != CRNN_F32 || dtC != CRNN_F32) return CRNN_ERR_ARG;
   return gemm(c, mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm);
 }
+// Training with bf16 conv-stack tensors: the BatchNorm + ReLU6 between a block's depthwise and pointwise convolutions is
+// applied by the pointwise GEMMs themselves (forward and weight gradient) while they stage the operand; the activated
+// tensor `a` is not written (one read + one write pass per block less).  CRNN_FUSE_DW_BN=0 keeps the two-pass path.
+bool fuse_dw_bn(const crnn_config* cfg, int dtd, int dtq, int ci) {
+  const char* e = getenv("CRNN_FUSE_DW_BN");   // (read per call: the parity test flips it between two steps)
+  const int env = e ? atoi(e) : 1;
+  return env && cfg->mfma_bf16 == 2 && dtd == CRNN_BF16 && dtq == CRNN_BF16 && ci % 8 == 0 && ci <= 512;
+}
 // always-fp32 GEMM (spatial-transformer localisation net: tiny, and theta is precision-sensitive)
 int gemm32(const Ctx& c, int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
            const float* bias = nullptr, int act = 0, int acc = 0, int perm = 0) {
@@ -378,7 +386,8 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
       CRNN_TRY(crnn_bn_finalize(parts, crnn_colreduce_chunks(M), ci, M, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), s1, stream));
     }
     bn_off += ci;
-    CRNN_TRY(crnn_bn_act_pool_drop_ex(dd, s1, aa, 1, 1, (int)M, ci, 1, 1, 0.f, 0, 0, dtd, dtd, stream));
+    const bool fuse_a = fuse_dw_bn(cfg, dtd, dtq, ci);                  // BN + ReLU6 applied while the GEMM stages its operand
+    if (!fuse_a) CRNN_TRY(crnn_bn_act_pool_drop_ex(dd, s1, aa, 1, 1, (int)M, ci, 1, 1, 0.f, 0, 0, dtd, dtd, stream));
     {  // pointwise conv; its epilogue also produces the batch statistics of the BatchNorm that follows
       int dtw = CRNN_F32, wt = 0;
       const float* wq = weight_operand(c, 0, c.p(bp + "_pw"), &dtw);
@@ -387,6 +396,7 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
         dtw = CRNN_BF16; wt = 1;
       }
       if (ci == 1 && dtd == CRNN_F32) CRNN_TRY(crnn_pw1_fwd(aa, c.p(bp + "_pw"), qq, M, co, parts, dtq, stream));   // block 1: outer product
+      else if (fuse_a) CRNN_TRY(crnn_pwconv_bnrelu6_fwd(dd, s1, wq, qq, M, co, ci, parts, dtq, wt, stream));
       else CRNN_TRY(crnn_pwconv_fwd(aa, wq, qq, M, co, ci, parts, nullptr, cfg->mfma_bf16 ? 1 : 0, dtd, dtw, dtq, wt, stream));
     }
     CRNN_TRY(crnn_bn_finalize_folded(parts, crnn_pwconv_stat_rows(M), co, M, c.p(bp + "_bn2_g"), c.p(bp + "_bn2_b"), s2, c.w("fold"), stream));
@@ -620,7 +630,9 @@ int backward_bottom(const Ctx& c, const float* x, uint64_t seed) {
     if (ci == 1 && dtd == CRNN_F32) {   // block 1: outer-product weight / data gradients
       CRNN_TRY(crnn_pw1_bwd(c.w("a" + p), c.p(bp + "_pw"), gB, gA, c.g(bp + "_pw"), c.w("partials"), M, co, dtq, stream));
     } else {
-      CRNN_TRY(gemm_t(c, 2, c.w("a" + p), dtd, gB, dtq, c.g(bp + "_pw"), CRNN_F32, ci, co, (int)M, ci, co, co));
+      if (fuse_dw_bn(cfg, dtd, dtq, ci))   // the activated tensor was never written: re-form it from d while staging (as the forward did)
+        CRNN_TRY(crnn_pwconv_bnrelu6_wgrad(c.w("d" + p), c.w("bn1s" + p), gB, c.g(bp + "_pw"), M, co, ci, c.scratch(), kGemmScratchBytes, stream));
+      else CRNN_TRY(gemm_t(c, 2, c.w("a" + p), dtd, gB, dtq, c.g(bp + "_pw"), CRNN_F32, ci, co, (int)M, ci, co, co));
       CRNN_TRY(gemm_t(c, 1, gB, dtq, c.p(bp + "_pw"), CRNN_F32, gA, dtd, (int)M, ci, co, co, co, ci));
     }
     CRNN_TRY(crnn_bn_bwd_ex(c.w("d" + p), gA, c.w("bn1s" + p), c.p(bp + "_bn1_g"), gB, c.g(bp + "_bn1_g"), c.g(bp + "_bn1_b"), c.w("partials"),

@@ -146,6 +146,17 @@ int crnn_gemm_bf16_ex(int mode, const void* A, const void* B, void* C, int M, in
 int crnn_pwconv_stat_rows(long M);
 int crnn_pwconv_fwd(const void* a, const void* w, void* q, long M, int N, int K, float* stat_partials, const float* out_bnstate,
                     int bf16_products, int dt_a, int dt_w, int dt_q, int w_transposed, crnn_stream_t stream);
+/* Producer-fused form for training with bf16 conv-stack tensors: `d` is the depthwise output BEFORE its BatchNorm
+ * (utils.py:44) and in_bnstate = [mean|var|scale|shift] of that BatchNorm (crnn_bn_finalize*); the GEMM applies
+ * a = ReLU6(d * scale + shift) (utils.py:45-46), rounded to bf16 exactly as crnn_bn_act_pool_drop_ex would store it,
+ * while it stages the operand -- the activated tensor `a` is never materialised (forward and weight gradient):
+ *   fwd  : q[M][N] = a[M][K] * w     (+ stat_partials as for crnn_pwconv_fwd; w bf16, [K][N] or W^T [N][K])
+ *   wgrad: dw[K][N] (fp32) = a^T * g[M][N]   (g bf16; scratch for the split reduction as for crnn_gemm_bf16_ex)
+ * d, w, g are bf16; K % 8 == 0, K <= 512.  Results are bit-identical to the two-pass path. */
+int crnn_pwconv_bnrelu6_fwd(const void* d, const float* in_bnstate, const void* w, void* q, long M, int N, int K,
+                            float* stat_partials, int dt_q, int w_transposed, crnn_stream_t stream);
+int crnn_pwconv_bnrelu6_wgrad(const void* d, const float* in_bnstate, const void* g, float* dw, long M, int N, int K,
+                              float* scratch, size_t scratch_bytes, crnn_stream_t stream);
 /* The same pointwise conv for ONE input channel (block 1: Conv2D(64, 1x1) on the single-channel depthwise output,
  * utils.py:64 / 49): an outer product q[m][c] = a[m] * w[c], its data gradient da[m] = dq[m] . w and weight gradient
  * dw[c] = sum_m a[m] dq[m][c].  a / da fp32; q / dq fp32 (dt_q 0) or bf16 (1); N a power of two, 8 <= N <= 256.

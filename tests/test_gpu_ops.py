@@ -493,6 +493,47 @@ def test_bf16_dwconv_ragged_width_after_nan_filled_lds(shape):
         assert_close(host(parts).sum(0)[0], ref.sum((0, 1, 2)), rtol=1e-4, atol=1e-2, what="stats trial %d" % trial)
 
 
+@pytest.mark.parametrize("shape", [(3000, 128, 64, 1), (1111, 64, 256, 1), (2049, 256, 128, 0), (520, 512, 512, 1)])
+def test_pwconv_with_producer_bn_relu6_matches_the_two_pass_path(shape):
+    """crnn_pwconv_bnrelu6_fwd / _wgrad apply ReLU6(BN(d)) while the GEMM stages its operand; the result must be
+    bit-identical to materialising a = ReLU6(BN(d)) with crnn_bn_act_pool_drop_ex (bf16) and running the plain GEMMs --
+    output tensor, BatchNorm statistics partials and weight gradient -- and within bf16 round-off of the fp64 oracle."""
+    M, N, K, wt = shape
+    rs = np.random.RandomState(M + N)
+    d = _bf16_round(rs.normal(size=(M, K)) * 2.0)
+    scale = rs.normal(size=K); shift = rs.normal(size=K) + 1.0
+    w = _bf16_round(rs.normal(size=(K, N)) / np.sqrt(K)); g = _bf16_round(rs.normal(size=(M, N)))
+    st = dev(np.concatenate([np.zeros(K), np.ones(K), scale, shift]))
+    dd, gd = _to_bf16_dev(d), _to_bf16_dev(g)
+    wd = _to_bf16_dev(w.T.copy() if wt else w)
+    _KEEP = [dd, gd, wd]
+    # two-pass reference on the device
+    a = torch.zeros(M, K, dtype=torch.bfloat16, device="cuda")
+    ok(L().crnn_bn_act_pool_drop_ex(P(dd), P(st), P(a), 1, 1, M, K, 1, 1, 0.0, 0, 0, 1, 1, S()))
+    rows = L().crnn_pwconv_stat_rows(M)
+    q0 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda"); p0 = zeros(rows, 2, N)
+    ok(L().crnn_pwconv_fwd(P(a), P(wd), P(q0), M, N, K, P(p0), None, 1, 1, 1, 1, wt, S()))
+    scr = zeros(16 * 1024 * 1024)
+    dw0 = zeros(K, N)
+    ok(L().crnn_gemm_bf16_ex(2, P(a), P(gd), P(dw0), K, N, M, K, N, N, None, 0, 0, 0, P(scr), 64 * 1024 * 1024, 1, 1, 0, S()))
+    # fused
+    q1 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda"); p1 = zeros(rows, 2, N)
+    ok(L().crnn_pwconv_bnrelu6_fwd(P(dd), P(st), P(wd), P(q1), M, N, K, P(p1), 1, wt, S()))
+    dw1 = zeros(K, N)
+    scr.fill_(float("nan"))
+    ok(L().crnn_pwconv_bnrelu6_wgrad(P(dd), P(st), P(gd), P(dw1), M, N, K, P(scr), 64 * 1024 * 1024, S()))
+    assert torch.equal(q0, q1), "forward differs from the two-pass path"
+    assert torch.equal(p0, p1), "statistics partials differ"
+    assert torch.equal(dw0, dw1), "weight gradient differs"
+    # and against the oracle arithmetic (a rounded to bf16, fp32 accumulation)
+    a_ref = _bf16_round(np.clip(d * scale + shift, 0.0, 6.0))
+    assert_close(_f(a), a_ref, rtol=2.0 ** -8, atol=1e-6, what="a")
+    assert_close(_f(q1), _f(a).astype(np.float64) @ w, rtol=2.0 ** -7, atol=2e-2, what="q")
+    assert_close(host(dw1), _f(a).astype(np.float64).T @ g, rtol=1e-3, atol=2e-2 * np.sqrt(M / 1000.0), what="dw")
+    # contract: a missing BatchNorm state is refused
+    assert L().crnn_pwconv_bnrelu6_fwd(P(dd), None, P(wd), P(q1), M, N, K, None, 1, wt, S()) != 0
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_gemm_bf16_storage_operands_and_result(mode):
     rs = np.random.RandomState(40 + mode)
