@@ -879,38 +879,48 @@ __global__ __launch_bounds__(256) void bn_bwd_pool_kernel(BnBwdArgsT<T> a, float
   const float inv_keep = a.rate > 0.f ? 1.f / (1.f - a.rate) : 1.f;
   const int nwin = a.ph * a.pw;   // <= 4
   for (int cb = 0; cb < CL; cb += CW) {
-    const int c = cb + cl, c0 = c * VEC;
+    const int c = cb + cl, c0i = c * VEC;
     VecF<VEC> s, q;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { s.v[e] = 0.f; q.v[e] = 0.f; }
     if (c < CL) {
-      VecF<VEC> mu = vload<VEC>(a.bnstate + c0), var = vload<VEC>(a.bnstate + a.C + c0);
-      VecF<VEC> sc = vload<VEC>(a.bnstate + 2 * a.C + c0), sh = vload<VEC>(a.bnstate + 3 * a.C + c0);
+      VecF<VEC> mu = vload<VEC>(a.bnstate + c0i), var = vload<VEC>(a.bnstate + a.C + c0i);
+      VecF<VEC> sc = vload<VEC>(a.bnstate + 2 * a.C + c0i), sh = vload<VEC>(a.bnstate + 3 * a.C + c0i);
       VecF<VEC> inv, c1, c2;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) { inv.v[e] = 1.0f / sqrtf(var.v[e] + BN_EPS); c1.v[e] = 0.f; c2.v[e] = 0.f; }
-      if (PASS == 2) { c1 = vload<VEC>(coef + c0); c2 = vload<VEC>(coef + a.C + c0); }
+      if (PASS == 2) { c1 = vload<VEC>(coef + c0i); c2 = vload<VEC>(coef + a.C + c0i); }
       // one pool window per step; pass 1 (reduce only) keeps two windows' loads in flight
       auto load_window = [&](long r, VecF<VEC>& gv, VecF<VEC> (&xw)[4], long& xbase) {
         int wo = (int)(r % Wo); long rr = r / Wo; int ho = (int)(rr % Ho); long b = rr / Ho;
-        gv = vload<VEC>(&a.g[r * a.C + c0]);
-        xbase = (((long)b * a.H + ho * a.ph) * a.W + wo * a.pw) * a.C + c0;
+        gv = vload<VEC>(&a.g[r * a.C + c0i]);
+        xbase = (((long)b * a.H + ho * a.ph) * a.W + wo * a.pw) * a.C + c0i;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if (k < nwin) { int ii = k / a.pw, j = k - ii * a.pw; xw[k] = vload<VEC>(&a.x[xbase + ((long)ii * a.W + j) * a.C]); }
       };
-      auto do_window = [&](long r, const VecF<VEC>& gv, const VecF<VEC> (&xw)[4], long xbase) {
-        const long oidx = r * a.C + c0;
-        float best[VEC]; int arg[VEC];
+      // These two kernels are VALU-bound (SQ counters: ~3 resident waves/SIMD each 27-34 % VALU-active), so the window is
+      // processed with as few operations as the arithmetic allows: only the arg-max position carries gradient, hence
+      //   pass 1: sum gy = gsel, sum gy*xhat = gsel * xhat(x at the arg-max)            (x tracked alongside the maximum)
+      //   pass 2: dx_k = scale*(gy_k - c1 - xhat_k*c2) = fma(cx, x_k, c0) + [k == arg] * scale*gsel
+      //           with the per-channel constants cx = -scale*c2*inv, c0 = -scale*c1 - cx*mu.
+      VecF<VEC> cx, c0;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) { best[e] = -1.f; arg[e] = 0; }
+      for (int e = 0; e < VEC; ++e) { cx.v[e] = -sc.v[e] * c2.v[e] * inv.v[e]; c0.v[e] = -sc.v[e] * c1.v[e] - cx.v[e] * mu.v[e]; }
+      auto do_window = [&](long r, const VecF<VEC>& gv, const VecF<VEC> (&xw)[4], long xbase) {
+        const long oidx = r * a.C + c0i;
+        float best[VEC], xs[VEC]; int arg[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { best[e] = -1.f; xs[e] = 0.f; arg[e] = 0; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           if (k < nwin) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
               float y = relu6f(fmaf(xw[k].v[e], sc.v[e], sh.v[e]));
-              if (y > best[e]) { best[e] = y; arg[e] = k; }   // strict '>' keeps the FIRST maximum (scan order)
+              const bool up = y > best[e];                      // strict '>' keeps the FIRST maximum (scan order)
+              best[e] = up ? y : best[e];
+              if (PASS == 1) xs[e] = up ? xw[k].v[e] : xs[e]; else arg[e] = up ? k : arg[e];
             }
           }
         }
@@ -921,18 +931,21 @@ __global__ __launch_bounds__(256) void bn_bwd_pool_kernel(BnBwdArgsT<T> a, float
           bool live = (best[e] > 0.f) && (best[e] < 6.f);
           gsel[e] = live ? gv.v[e] * dm[e] : 0.f;
         }
+        if (PASS == 1) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (k < nwin) {
-            VecF<VEC> o;
+          for (int e = 0; e < VEC; ++e) {
+            s.v[e] += gsel[e];
+            q.v[e] = fmaf(gsel[e], (xs[e] - mu.v[e]) * inv.v[e], q.v[e]);
+          }
+        } else {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-              float gy = (arg[e] == k) ? gsel[e] : 0.f;
-              float xh = (xw[k].v[e] - mu.v[e]) * inv.v[e];
-              if (PASS == 1) { s.v[e] += gy; q.v[e] = fmaf(gy, xh, q.v[e]); }
-              else o.v[e] = sc.v[e] * (gy - c1.v[e] - xh * c2.v[e]);
-            }
-            if (PASS == 2) {
+          for (int e = 0; e < VEC; ++e) gsel[e] *= sc.v[e];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (k < nwin) {
+              VecF<VEC> o;
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) o.v[e] = fmaf(cx.v[e], xw[k].v[e], c0.v[e]) + ((arg[e] == k) ? gsel[e] : 0.f);
               int ii = k / a.pw, j = k - ii * a.pw;
               vstore<VEC>(&dx[xbase + ((long)ii * a.W + j) * a.C], o);
             }
@@ -965,8 +978,8 @@ __global__ __launch_bounds__(256) void bn_bwd_pool_kernel(BnBwdArgsT<T> a, float
         for (int e = 0; e < VEC; ++e) {
           float s2 = 0.f, q2 = 0.f;
           for (int r = 0; r < RT; ++r) { s2 += red[0][(r * CW + cl) * VEC + e]; q2 += red[1][(r * CW + cl) * VEC + e]; }
-          partials[((long)blockIdx.x * 2 + 0) * a.C + c0 + e] = s2;
-          partials[((long)blockIdx.x * 2 + 1) * a.C + c0 + e] = q2;
+          partials[((long)blockIdx.x * 2 + 0) * a.C + c0i + e] = s2;
+          partials[((long)blockIdx.x * 2 + 1) * a.C + c0i + e] = q2;
         }
       }
     }
