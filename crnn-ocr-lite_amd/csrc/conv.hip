@@ -533,6 +533,40 @@ __device__ __forceinline__ double part_lane_sum(const float* __restrict__ base, 
   return a;
 }
 
+// two interleaved sums (sum / sum-of-products rows of one partials array): eight independent loads in flight
+__device__ __forceinline__ void part_lane_sum2(const float* __restrict__ b0, const float* __restrict__ b1, long stride, int nparts, int lane,
+                                               double& s0, double& s1) {
+  double a = 0.0, b = 0.0;
+  int p = lane;
+  for (; p + 3 * RED_PL < nparts; p += 4 * RED_PL) {
+    const long o0 = (long)p * stride, o1 = (long)(p + RED_PL) * stride, o2 = (long)(p + 2 * RED_PL) * stride, o3 = (long)(p + 3 * RED_PL) * stride;
+    float v0 = b0[o0], v1 = b0[o1], v2 = b0[o2], v3 = b0[o3];
+    float w0 = b1[o0], w1 = b1[o1], w2 = b1[o2], w3 = b1[o3];
+    a += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+    b += ((double)w0 + (double)w1) + ((double)w2 + (double)w3);
+  }
+  for (; p < nparts; p += RED_PL) { a += (double)b0[(long)p * stride]; b += (double)b1[(long)p * stride]; }
+  s0 = a; s1 = b;
+}
+// lanes -> one value per output, fixed two-level order (8 groups of 8 lanes): red[2][RED_PL][RED_CH], result valid for y == 0
+__device__ __forceinline__ void lanes_sum2(double (&red)[2][RED_PL][RED_CH], double& s, double& q) {
+  static_assert(RED_PL == 64, "two-level lane reduction is written for 64 part-lanes");
+  __syncthreads();
+  const int x = threadIdx.x, y = threadIdx.y;
+  if (y < 8) {
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { a += red[0][y * 8 + r][x]; b += red[1][y * 8 + r][x]; }
+    red[0][y * 8][x] = a; red[1][y * 8][x] = b;      // (only this thread reads rows y*8 .. y*8+7)
+  }
+  __syncthreads();
+  s = 0.0; q = 0.0;
+  if (y == 0) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { s += red[0][r * 8][x]; q += red[1][r * 8][x]; }
+  }
+}
+
 // out[i] = scale * sum_p partials[p][i], i < n  (double accumulation)
 __global__ __launch_bounds__(RED_CH * RED_PL) void partials_sum_kernel(const float* __restrict__ partials, int nparts, int n, float* __restrict__ out, float scale) {
   // gridDim.y > 1: blockIdx.y reduces its own contiguous chunk of the partial rows into out[blockIdx.y][n]
@@ -605,12 +639,11 @@ __global__ __launch_bounds__(RED_CH * RED_PL) void bn_finalize_kernel(const floa
                                                                       float* __restrict__ bnstate) {
   __shared__ double red[2][RED_PL][RED_CH];
   int c = blockIdx.x * RED_CH + threadIdx.x;
-  red[0][threadIdx.y][threadIdx.x] = (c < C) ? part_lane_sum(partials + c, 2L * C, nparts, threadIdx.y) : 0.0;
-  red[1][threadIdx.y][threadIdx.x] = (c < C) ? part_lane_sum(partials + C + c, 2L * C, nparts, threadIdx.y) : 0.0;
-  __syncthreads();
+  double s = 0.0, q = 0.0;
+  if (c < C) part_lane_sum2(partials + c, partials + C + c, 2L * C, nparts, threadIdx.y, s, q);
+  red[0][threadIdx.y][threadIdx.x] = s; red[1][threadIdx.y][threadIdx.x] = q;
+  lanes_sum2(red, s, q);
   if (threadIdx.y == 0 && c < C) {
-    double s = 0.0, q = 0.0;
-    for (int r = 0; r < RED_PL; ++r) { s += red[0][r][threadIdx.x]; q += red[1][r][threadIdx.x]; }
     double mean = s * inv_n;
     double var = q * inv_n - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -991,12 +1024,11 @@ __global__ __launch_bounds__(RED_CH * RED_PL) void bn_bwd_finalize_kernel(const 
                                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
   __shared__ double red[2][RED_PL][RED_CH];
   int c = blockIdx.x * RED_CH + threadIdx.x;
-  red[0][threadIdx.y][threadIdx.x] = (c < C) ? part_lane_sum(partials + c, 2L * C, nparts, threadIdx.y) : 0.0;
-  red[1][threadIdx.y][threadIdx.x] = (c < C) ? part_lane_sum(partials + C + c, 2L * C, nparts, threadIdx.y) : 0.0;
-  __syncthreads();
+  double s = 0.0, q = 0.0;
+  if (c < C) part_lane_sum2(partials + c, partials + C + c, 2L * C, nparts, threadIdx.y, s, q);
+  red[0][threadIdx.y][threadIdx.x] = s; red[1][threadIdx.y][threadIdx.x] = q;
+  lanes_sum2(red, s, q);
   if (threadIdx.y == 0 && c < C) {
-    double s = 0.0, q = 0.0;
-    for (int r = 0; r < RED_PL; ++r) { s += red[0][r][threadIdx.x]; q += red[1][r][threadIdx.x]; }
     dbeta[c] = (float)s; dgamma[c] = (float)q;
     coef[c] = (float)(s * inv_n); coef[C + c] = (float)(q * inv_n);
   }
