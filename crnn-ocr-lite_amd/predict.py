@@ -29,6 +29,8 @@ def build_parser():
     parser.add_argument('--mjsynth', action='store_true')
     parser.add_argument('--imgh', type=int, default=100)
     parser.add_argument('--imgW', type=int, default=32)
+    parser.add_argument('--workers', type=int, default=0,
+                        help='image decoding processes feeding the generator (0 = the reference\'s single-threaded loader)')
     return parser
 
 
@@ -57,7 +59,7 @@ def main(argv=None):
             fnames = fnames[int(len(fnames) * args.train_portion):]
     if args.num_instances is not None:
         fnames = fnames[np.random.randint(0, len(fnames), min(args.num_instances, len(fnames)))]
-    reader = U.Readf(img_size=img_size, normed=True, batch_size=args.batch_size, transform_p=0., classes=classes, max_len=args.max_len)
+    reader = U.Readf(img_size=img_size, normed=True, batch_size=args.batch_size, transform_p=0., classes=classes, max_len=args.max_len, workers=args.workers)
     length = len(fnames)
     bboxs = {}
     if args.boxes is not None:

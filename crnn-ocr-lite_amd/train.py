@@ -43,6 +43,8 @@ def build_parser():
     parser.add_argument('--GRU', action='store_true')
     parser.add_argument('--imgh', type=int, default=100)
     parser.add_argument('--imgW', type=int, default=32)
+    parser.add_argument('--workers', type=int, default=0,
+                        help='image decoding processes feeding the generator (0 = the reference\'s single-threaded loader)')
     return parser
 
 
@@ -86,7 +88,7 @@ def main(argv=None):
     train = train[lo:hi]
 
     reader = U.Readf(img_size=(args.imgh, args.imgW, 1), normed=args.norm, batch_size=args.batch_size, classes=classes,
-                     max_len=max_len, transform_p=0.7)
+                     max_len=max_len, transform_p=0.7, workers=args.workers, seed=args.random_state)
     print(" [INFO] Number of classes: {}; Max. string length: {} ".format(len(classes) + 1, max_len))
     init_model = U.CRNN(num_classes=len(classes) + 1, shape=(args.imgh, args.imgW, 1), GRU=args.GRU,
                         time_dense_size=args.time_dense_size, n_units=args.n_units, max_string_len=max_len)

@@ -233,3 +233,73 @@ def test_reference_keras_model_json_artefacts_load_as_the_same_architecture():
     # this package's own to_json still round-trips
     own = U.CRNN(num_classes=38, shape=(100, 32, 1), GRU=False, max_string_len=23).get_model()
     assert U.model_from_json(own.to_json()).config == own.config
+
+
+# ------------------------------------------------------------------------------------------------ parallel loader
+def _write_images(folder, n, seed=0):
+    from PIL import Image
+    rs = np.random.RandomState(seed)
+    words = ["hello", "world", "overfilled", "cellist", "amd", "ocr", "keras", "x"]
+    names = []
+    for i in range(n):
+        a = (rs.rand(20 + i % 9, 40 + 7 * (i % 11), 3) * 255).astype(np.uint8)
+        path = os.path.join(str(folder), "%d_%s_%d.png" % (i, words[i % len(words)], i))
+        Image.fromarray(a).save(path)
+        names.append(path)
+    return names
+
+
+def _take(gen, n):
+    out = []
+    for _ in range(n):
+        inputs, _ = next(gen)
+        out.append({k: np.array(v) for k, v in inputs.items()})
+    return out
+
+
+def test_modal_value_fast_path_equals_unique_argmax():
+    from crnn_mi355x import data as D
+    rs = np.random.RandomState(1)
+    for trial in range(50):
+        a = rs.randint(0, 1 + trial % 7 * 40, size=(rs.randint(1, 30), rs.randint(1, 30))).astype(np.uint8 if trial % 2 else np.int64)
+        vals, counts = np.unique(a, return_counts=True)
+        assert D._modal_value(a) == vals[np.argmax(counts)]
+    assert D._modal_value(np.where(np.zeros((3, 3)) > 1, 255, 0)) == 0
+
+
+def test_worker_processes_yield_the_serial_loaders_batches(tmp_path):
+    """Readf(workers=N): same visiting order, same arrays.  Without random padding (predict.py uses transform_p=0) the
+    batches are identical to the single-threaded loop, short first-pass tail and wrap-around included; with random
+    padding they depend only on `seed`, not on the worker count; page + bounding-box inputs go through the same path."""
+    import utils as U
+    names = _write_images(tmp_path, 37)
+    classes = {c: i for i, c in enumerate(U.get_lexicon())}
+    kw = dict(img_size=(100, 32, 1), max_len=23, normed=True, batch_size=8, classes=classes)
+    serial = _take(U.Readf(transform_p=0., **kw).run_generator(names), 7)          # 4 full + tail of 5 + wrap
+    par = U.Readf(transform_p=0., workers=2, chunk=5, **kw)
+    got = _take(par.run_generator(names), 7)
+    par.close()
+    for i, (a, b) in enumerate(zip(serial, got)):
+        rows = 5 if i == 4 else 8            # the first-pass tail re-yields full-size arrays whose last rows are np.empty garbage
+        for k in a:
+            assert np.array_equal(a[k][:rows], b[k][:rows]), (i, k)
+    # random padding: reproducible per seed across worker counts, different across seeds
+    runs = []
+    for workers, seed in ((2, 5), (3, 5), (2, 6)):
+        r = U.Readf(transform_p=0.7, workers=workers, seed=seed, chunk=4, **kw)
+        runs.append(_take(r.run_generator(names), 3))
+        r.close()
+    assert all(np.array_equal(a["the_input"], b["the_input"]) for a, b in zip(runs[0], runs[1]))
+    assert any(not np.array_equal(a["the_input"], b["the_input"]) for a, b in zip(runs[0], runs[2]))
+    # pages with word boxes (predict.py --validate on IAM-style annotations): (word, x0, y0, x1, y1) crops
+    from PIL import Image
+    page = str(tmp_path / "page.png")
+    Image.fromarray((np.random.RandomState(3).rand(120, 300, 3) * 255).astype(np.uint8)).save(page)
+    boxes = {page: [("ab", 5, 5, 40, 90), (None, 50, 10, 100, 200), ("xyz", 10, 100, 60, 280)]}
+    s2 = _take(U.Readf(transform_p=0., **dict(kw, batch_size=3)).run_generator([page], bboxs=boxes), 2)
+    p2r = U.Readf(transform_p=0., workers=2, **dict(kw, batch_size=3))
+    p2 = _take(p2r.run_generator([page], bboxs=boxes), 2)
+    p2r.close()
+    for a, b in zip(s2, p2):
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
