@@ -29,9 +29,10 @@ def main():
         g = r.run_generator(names)
         next(g)
         t = time.time(); k = 0
-        while time.time() - t < 4.0:
+        while time.time() - t < 3.0:
             next(g); k += 256
         out["images_per_sec"]["workers=%d" % w] = round(k / (time.time() - t), 1)
+        print("workers=%d: %.0f img/s" % (w, out["images_per_sec"]["workers=%d" % w]), file=sys.stderr, flush=True)
         r.close()
     print(json.dumps(out))
 
