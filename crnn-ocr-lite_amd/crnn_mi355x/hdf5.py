@@ -132,13 +132,19 @@ class _Reader:
                 raise NotImplementedError("HDF5 offsets/lengths of %d/%d bytes" % (b[start + 13], b[start + 14]))
             p = start + (24 if ver == 0 else 28)
             self.base = self.u64(p)
+            self._check_eof(self.u64(p + 16))
             return self.u64(p + 32 + 8) + self.base      # root symbol-table entry: object header address
         if ver in (2, 3):
             if b[start + 9] != 8 or b[start + 10] != 8:
                 raise NotImplementedError("HDF5 offsets/lengths of %d/%d bytes" % (b[start + 9], b[start + 10]))
             self.base = self.u64(start + 12)
+            self._check_eof(self.u64(start + 28))
             return self.u64(start + 36) + self.base
         raise NotImplementedError("HDF5 superblock version %d" % ver)
+
+    def _check_eof(self, eof):
+        if eof != UNDEF and eof + self.base > len(self.b):
+            raise ValueError("truncated HDF5 file: %d bytes, the superblock records %d" % (len(self.b), eof + self.base))
 
     # ---- object headers -> [(type, flags, data)]
     def messages(self, addr):
@@ -457,8 +463,11 @@ def read(path_or_bytes):
     else:
         with open(path_or_bytes, "rb") as f:
             buf = f.read()
-    r = _Reader(buf)
-    return r.node(r.root)
+    try:
+        r = _Reader(buf)
+        return r.node(r.root)
+    except (struct.error, IndexError, zlib.error, UnicodeDecodeError, RecursionError) as e:   # truncated / corrupted file
+        raise ValueError("corrupt or truncated HDF5 file: %s" % e) from e
 
 
 def is_hdf5(path):
