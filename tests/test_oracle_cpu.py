@@ -4,6 +4,7 @@ cross-checked against an independent torch-autograd mirror.  No GPU needed."""
 import itertools
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -174,3 +175,22 @@ def test_bn_moving_update_formula():
     m, v = ops.bn_moving_update(np.zeros(2), np.ones(2), np.array([1., 2.]), np.array([4., 9.]), 100.0)
     np.testing.assert_allclose(m, [.01, .02])
     np.testing.assert_allclose(v, .99 + .01 * np.array([4., 9.]) * (100 / 99) * (100 / (100 - 1.001)))
+
+
+def test_oracle_matches_its_committed_snapshot():
+    """The oracle checks every GPU parity test; tests/golden/oracle_snapshot.npz (make_oracle_snapshot.py) pins the
+    oracle itself: posteriors, losses, gradient norms / leading entries, decodes and an Adam step of two tiny models."""
+    sys.path.insert(0, GOLD)
+    import make_oracle_snapshot as S
+    want = np.load(os.path.join(GOLD, "oracle_snapshot.npz"))
+    got = S.snapshot()
+    assert sorted(got) == sorted(want.files)
+    for k in want.files:
+        a, b = np.asarray(got[k]), want[k]
+        assert a.shape == b.shape, k
+        if b.dtype.kind in "US":
+            assert a.tolist() == b.tolist(), k
+        elif b.dtype.kind in "iu":
+            assert np.array_equal(a, b), k
+        else:
+            assert np.allclose(a, b, rtol=1e-9, atol=1e-12), (k, float(np.abs(a - b).max()))
