@@ -181,6 +181,23 @@ def cpu_baseline(seconds_target=15.0):
                       "not Keras-TF itself, which is absent from the image)" % (n, Bc, cores)}
 
 
+def self_launch(n):
+    """Spawn n ranks of this script (same argv) under torch.distributed.run on this node and relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    if os.environ.get("CRNN_DIST_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < n:
+        print("bench.py: --gpus %d needs %d visible GPUs for RCCL, found %d" % (n, n, torch.cuda.device_count()), file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,8 +214,13 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's world size wins" % (args.gpus, world), file=sys.stderr)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:

@@ -26,7 +26,9 @@ def _stream():
 
 class Engine:
     def __init__(self, batch, imgh=100, imgw=32, num_classes=38, max_len=23, time_dense_size=128, n_units=256,
-                 gru=False, stn=True, dropout=True, device=None, precision="fp32"):
+                 gru=False, stn=True, dropout=True, device=None, precision="fp32", share=None):
+        """share: another Engine of the same architecture (any batch size) whose parameter / gradient / BatchNorm / optimizer-
+        state tensors this one adopts (only the workspace and the batch-shaped outputs are its own)."""
         if not torch.cuda.is_available():
             raise RuntimeError("the CRNN hot path needs an AMD GPU (gfx950); there is no CPU fallback")
         self.lib = native.lib()
@@ -58,17 +60,22 @@ class Engine:
             check(self.lib.crnn_bn_info(self._c, i, name, 64, ctypes.byref(boff), ctypes.byref(bch), ctypes.byref(bcnt)))
             self.bn_layout[name.value.decode()] = (boff.value, bch.value, bcnt.value)
         dev = self.device
-        self.params = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
-        self.grads = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
-        self.bn_mean = torch.zeros(self.bn_total, dtype=torch.float32, device=dev)
-        self.bn_var = torch.ones(self.bn_total, dtype=torch.float32, device=dev)
+        if share is not None:
+            if share.n_total != self.n_total or share.bn_total != self.bn_total or list(share.layout.items()) != list(self.layout.items()):
+                raise ValueError("Engine(share=...) needs the same architecture")
+            self.params, self.grads, self.bn_mean, self.bn_var = share.params, share.grads, share.bn_mean, share.bn_var
+        else:
+            self.params = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
+            self.grads = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
+            self.bn_mean = torch.zeros(self.bn_total, dtype=torch.float32, device=dev)
+            self.bn_var = torch.ones(self.bn_total, dtype=torch.float32, device=dev)
         self.ws_bytes = nbytes
         self.ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
         self.y_pred = torch.empty((batch, self.T, num_classes), dtype=torch.float32, device=dev)
         self.loss = torch.zeros(batch, dtype=torch.float32, device=dev)
         self.norm = torch.zeros(2, dtype=torch.float32, device=dev)
         self.norm_scratch = torch.zeros(1024, dtype=torch.float64, device=dev)
-        self.opt_state = {}
+        self.opt_state = share.opt_state if share is not None else {}     # Adam m/v or SGD velocity: survives a batch-size change
         # side-stream schedule of the backward (crnn_backward_ex): measured 1 % SLOWER than the serial one at batch 256 (the
         # GEMMs crowd the latency-critical BPTT launches), so it is opt-in: CRNN_RNN_OVERLAP=1
         self.overlap_rnn_wgrad = os.environ.get("CRNN_RNN_OVERLAP", "0") == "1"
@@ -143,9 +150,29 @@ class Engine:
             a = torch.from_numpy(np.ascontiguousarray(np.asarray(a).reshape(-1), dtype=np.int32))
         return a.to(self.device, dtype=torch.int32).contiguous()
 
+    def _ctc_inputs(self, labels, input_length, label_length):
+        """Host-side validation of the CTC inputs (the kernel indexes LDS with the label ids): labels (B, max_len) with
+        0 <= id < num_classes, 0 <= label_length <= max_len, input_length <= T - 2.  Device tensors are trusted (checking
+        them would force a synchronisation in the hot loop); NumPy batches from Readf are checked."""
+        if not torch.is_tensor(labels):
+            lab = np.asarray(labels)
+            if lab.size != self.B * self.cfg.max_len:
+                raise ValueError("the_labels must be (batch=%d, max_len=%d), got %r" % (self.B, self.cfg.max_len, lab.shape))
+            if lab.size and (lab.min() < 0 or lab.max() >= self.C):
+                raise ValueError("label ids must be in [0, %d) (blank = %d), got [%d, %d]" % (self.C, self.C - 1, lab.min(), lab.max()))
+        if not torch.is_tensor(label_length):
+            ll = np.asarray(label_length)
+            if ll.size != self.B or (ll.size and (ll.min() < 0 or ll.max() > self.cfg.max_len)):
+                raise ValueError("label_length must be (batch,) with values in [0, max_len=%d]" % self.cfg.max_len)
+        if not torch.is_tensor(input_length):
+            il = np.asarray(input_length)
+            if il.size != self.B or (il.size and (il.min() < 0 or il.max() > self.T - 2)):
+                raise ValueError("input_length must be (batch,) with values in [0, T-2=%d]" % (self.T - 2))
+        self._lab = self._as_i32(labels); self._il = self._as_i32(input_length); self._ll = self._as_i32(label_length)
+
     def backward(self, labels, input_length, label_length, seed=0):
         """CTC + backward after forward(train=True).  Returns per-sample loss (device tensor, B)."""
-        self._lab = self._as_i32(labels); self._il = self._as_i32(input_length); self._ll = self._as_i32(label_length)
+        self._ctc_inputs(labels, input_length, label_length)
         check(self.lib.crnn_backward_ex(self._c, _ptr(self.params), _ptr(self.grads), _ptr(self._x), _ptr(self._lab), _ptr(self._il),
                                         _ptr(self._ll), _ptr(self.ws), self.ws_bytes, _ptr(self.loss), int(seed), _stream(), self._aux()),
               "backward")
@@ -153,7 +180,7 @@ class Engine:
 
     def backward_top(self, labels, input_length, label_length, seed=0):
         """First backward stage: CTC, dense2, recurrent layers, dense1 -> grads[grad_split:] are final."""
-        self._lab = self._as_i32(labels); self._il = self._as_i32(input_length); self._ll = self._as_i32(label_length)
+        self._ctc_inputs(labels, input_length, label_length)
         check(self.lib.crnn_backward_top_ex(self._c, _ptr(self.params), _ptr(self.grads), _ptr(self._lab), _ptr(self._il), _ptr(self._ll),
                                             _ptr(self.ws), self.ws_bytes, _ptr(self.loss), int(seed), _stream(), self._aux()), "backward_top")
         return self.loss

@@ -58,15 +58,28 @@ class GradAllReduce:
 
 
 def sync_bn_stats(engine, dist, world):
-    """Average the BatchNorm moving statistics over ranks (checkpoint time)."""
+    """Average the BatchNorm moving statistics over ranks.  Policy (SURVEY 8e "document the choice"): batch statistics stay
+    per replica inside a step (no SyncBN, what Keras' multi_gpu_model would do); the MOVING statistics -- which only the
+    inference / validation forward and the saved weight files read -- are averaged over ranks at the end of every epoch
+    (before validation and ModelCheckpoint) and at the end of training (before final_weights.h5), so every rank validates
+    with, and rank 0 saves, the same numbers.  A collective: every rank must call it."""
     if world > 1:
         for t in (engine.bn_mean, engine.bn_var):
             allreduce_mean_(t, dist, world)
 
 
+def broadcast_state(engine, dist, world, src=0):
+    """Make every rank start from rank `src`'s weights and BatchNorm moving statistics (a freshly built model draws its
+    initial weights from OS entropy per process; identical replicas are what makes `all-reduce + same Adam step` keep
+    the weights bit-identical afterwards).  A collective: every rank must call it."""
+    if world > 1:
+        for t in (engine.params, engine.bn_mean, engine.bn_var):
+            dist.broadcast(t, src)
+
+
 def shard(n_items, rank, world):
-    """Contiguous shard [lo, hi) of n_items for this rank (last rank takes the remainder)."""
+    """Contiguous shard [lo, hi) of n_items for this rank.  Every rank gets the SAME number of items (the remainder
+    n_items % world is dropped) so that all ranks run the same number of steps -- and therefore issue the same
+    number of collectives -- per epoch."""
     per = n_items // world
-    lo = rank * per
-    hi = n_items if rank == world - 1 else lo + per
-    return lo, hi
+    return rank * per, rank * per + per

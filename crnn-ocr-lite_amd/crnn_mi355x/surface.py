@@ -124,18 +124,36 @@ class Model:
 
     # ---- engine management --------------------------------------------------------------------------------
     def _engine(self, batch, dropout=True):
+        """Engine for this batch size.  Engines differ only in their workspace: the parameter, gradient, BatchNorm and
+        optimizer-state tensors are shared between them, so a short tail batch or a validation pass with another batch size
+        neither resets Adam's moments nor round-trips the weights through the host.  The three most recent sizes are kept."""
         from .engine import Engine
         st = self._state
-        eng = st["engine"]
-        if eng is None or eng.B != batch:
-            if eng is not None:
-                self._pull()
+        engines = st.setdefault("engines", OrderedDict())
+        eng = engines.get(batch)
+        if eng is None:
+            base = st["engine"]
             c = self.config
             eng = Engine(batch, c["shape"][0], c["shape"][1], c["num_classes"], c["max_string_len"], c["time_dense_size"], c["n_units"],
-                         gru=c["GRU"], stn=True, dropout=dropout, precision=os.environ.get("CRNN_PRECISION", "fp32"))
-            eng.set_params(st["params"], st["bn"])
-            st["engine"] = eng
+                         gru=c["GRU"], stn=True, dropout=dropout, precision=os.environ.get("CRNN_PRECISION", "fp32"), share=base)
+            if base is None:
+                eng.set_params(st["params"], st["bn"])
+                self._dp_broadcast(eng)
+            engines[batch] = eng
+            while len(engines) > 3:
+                engines.popitem(last=False)
+        else:
+            engines.move_to_end(batch)
+        st["engine"] = eng
         return eng
+
+    def _dp_broadcast(self, eng):
+        """Data parallel: every rank adopts rank 0's weights / BN statistics (a fresh model is initialised from OS entropy
+        per process; crnn_mi355x.parallel.broadcast_state)."""
+        dist, world = self._dist()
+        if world > 1:
+            from .parallel import broadcast_state
+            broadcast_state(eng, dist, world)
 
     def _pull(self):
         """device -> host copies of weights and BN statistics."""
@@ -148,6 +166,7 @@ class Model:
         eng = self._state["engine"]
         if eng is not None:
             eng.set_params(self._state["params"], self._state["bn"])
+            self._dp_broadcast(eng)
 
     # ---- Keras weight list (SURVEY A.9 order, 94 tensors for either cell) ---------------------------------------
     def _weight_index(self):
@@ -338,6 +357,9 @@ class Model:
         is the CTC cost, so the training loss is its batch mean -- that is what the engine differentiates."""
         self.optimizer = optimizer
         self._iterations = 0
+        eng = self._state.get("engine")
+        if eng is not None:
+            eng.opt_state.clear()            # a new optimizer starts from zero moments (shared dict: cleared for every engine)
 
     def _snapshot(self, batch):
         """Readf re-yields the SAME arrays it keeps filling (utils.py:468,495-511): copy what a step needs before the
@@ -403,6 +425,7 @@ class Model:
             cb.set_model(self)
             cb.on_train_begin({})
         self.stop_training = False
+        dist, world = self._dist()
         for epoch in range(epochs):
             t0 = time.time()
             run, nimg = 0.0, 0
@@ -414,6 +437,11 @@ class Model:
                 x, lab, il, ll = self._prefetched[1]
                 loss_dev = self._train_on_batch_async(x, lab, il, ll)
                 self._prefetched = (generator, self._snapshot(next(generator)))
+                if world > 1:
+                    # every rank logs (and EarlyStoppingIter monitors) the GLOBAL batch-mean loss, so all ranks take the same
+                    # stop / restore decisions and keep issuing the same collectives
+                    dist.all_reduce(loss_dev, op=dist.ReduceOp.SUM)
+                    loss_dev = loss_dev / world
                 loss = float(loss_dev.item())
                 run += loss; nimg += len(x)
                 logs = {"loss": loss, "batch": step, "size": len(x)}
@@ -425,6 +453,7 @@ class Model:
                 if self.stop_training:
                     break
             logs = {"loss": run / max(1, step + 1)}
+            self._dp_sync_bn()                # moving statistics averaged over ranks before validation / checkpoints
             if validation_data is not None and validation_steps:
                 logs["val_loss"] = self.evaluate_generator(validation_data, validation_steps)
             if verbose:
@@ -439,6 +468,13 @@ class Model:
         for cb in callbacks:
             cb.on_train_end({})
         return H
+
+    def _dp_sync_bn(self):
+        dist, world = self._dist()
+        eng = self._state.get("engine")
+        if world > 1 and eng is not None:
+            from .parallel import sync_bn_stats
+            sync_bn_stats(eng, dist, world)
 
     def evaluate_generator(self, generator, steps):
         tot = 0.0

@@ -6,8 +6,9 @@
 
 Differences from the reference, on purpose: `--GRU` / `--norm` mean what they say (the reference's
 `from utils import *` shadows both, SURVEY F3: it always builds GRU and always normalises); `--G` selects the
-HIP device(s) via HIP_VISIBLE_DEVICES; under torchrun every rank trains on its own shard of the file list and
-gradients are averaged with one RCCL all-reduce per step.
+HIP device(s) via HIP_VISIBLE_DEVICES; under torchrun every rank trains on its own (equal-sized) shard of the file list,
+starts from rank 0's weights (broadcast), averages gradients with RCCL all-reduces each step, monitors the global
+batch-mean loss (so early stopping agrees across ranks) and averages the BatchNorm moving statistics at every epoch end.
 """
 import argparse
 import os
@@ -56,8 +57,14 @@ def main(argv=None):
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local_rank)
+        backend = os.environ.get("CRNN_DIST_BACKEND", "nccl")     # "nccl" = RCCL over xGMI; "gloo" only to exercise DP on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     elif args.G not in ("", "-1"):
         os.environ.setdefault("HIP_VISIBLE_DEVICES", args.G)
 
@@ -84,7 +91,7 @@ def main(argv=None):
         train, val = train[:cut], train[cut:]
     max_len = max(U.get_lengths(train).values())
     print(' [INFO] %d train and %d validation images loaded ' % (len(train), len(val)))
-    lo, hi = shard(len(train), rank, world)
+    lo, hi = shard(len(train), rank, world)    # equal shards: every rank runs the same number of steps (= collectives) per epoch
     train = train[lo:hi]
 
     reader = U.Readf(img_size=(args.imgh, args.imgW, 1), normed=args.norm, batch_size=args.batch_size, classes=classes,
@@ -125,6 +132,10 @@ def main(argv=None):
         model.save_weights(out_dir + "/final_weights.h5")
         model.save(out_dir + "/final_model.h5")
         print(" [INFO] Models and history saved! ")
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

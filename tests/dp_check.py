@@ -1,0 +1,92 @@
+"""Run under torch.distributed.run (one process per rank; `CRNN_DIST_BACKEND` = nccl (RCCL) | gloo): data-parallel train steps
+of the HIP engine on per-rank shards, then checks that
+
+  * every rank ends with bit-identical parameters, BatchNorm moving statistics (after sync_bn_stats) and Adam state,
+    although every rank STARTED from different random weights (broadcast_state makes rank 0's win);
+  * those parameters equal a single-process step that applies the same optimizer to the mean of the per-shard gradients.
+
+Prints "DP_CHECK OK ..." on rank 0.  Used by tests/test_gpu_cli.py (gloo on one GPU always; nccl when >= 2 GPUs are visible).
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "crnn-ocr-lite_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local)
+    backend = os.environ.get("CRNN_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
+    from bench import synthetic_batch
+    from crnn_mi355x.engine import Engine
+    from crnn_mi355x.init import initial_parameters
+    from crnn_mi355x.optimizers import Adam
+    from crnn_mi355x.parallel import GradAllReduce, broadcast_state, sync_bn_stats
+
+    B, steps = 8, 3
+    precision = os.environ.get("CRNN_PRECISION", "fp32")
+    kw = dict(imgh=40, max_len=6, time_dense_size=32, n_units=64, dropout=False, precision=precision)
+    eng = Engine(B, **kw)
+    eng.set_params(initial_parameters(eng.layout, 64, False, seed=100 + rank))       # DIFFERENT weights per rank ...
+    broadcast_state(eng, dist, world)                                                # ... until rank 0's are adopted
+    start = eng.params.clone()
+    opt = Adam(lr=1e-3, beta_1=0.5, beta_2=0.999, clipnorm=5)
+    ar = GradAllReduce(eng, dist, world)
+    shards = [synthetic_batch(B, seed=r, imgh=40, max_len=6, T=eng.T) for r in range(world)]
+    x, lab, il, ll = shards[rank]
+    for it in range(steps):
+        eng.train_step(x, lab, il, ll, opt, it, allreduce=ar)
+    sync_bn_stats(eng, dist, world)
+    torch.cuda.synchronize()
+
+    def gathered(t):
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t.contiguous())
+        return out
+
+    for name, t in (("params", eng.params), ("bn_mean", eng.bn_mean), ("bn_var", eng.bn_var), ("adam_m", eng.opt_state["m"]),
+                    ("adam_v", eng.opt_state["v"])):
+        parts = gathered(t)
+        for r in range(1, world):
+            assert torch.equal(parts[0], parts[r]), "%s differs between rank 0 and rank %d" % (name, r)
+    assert not torch.equal(start, eng.params), "the steps did not move the weights"
+    if rank == 0:
+        # single-process reference: same start, per-shard gradients evaluated one after the other, their mean, same optimizer
+        ref = Engine(B, **kw)
+        ref.params.copy_(start)
+        opt2 = Adam(lr=1e-3, beta_1=0.5, beta_2=0.999, clipnorm=5)
+        for it in range(steps):
+            acc = torch.zeros_like(ref.grads)
+            for r in range(world):
+                xs, ls, ils, lls = shards[r]
+                ref.forward(xs, train=True, seed=it)
+                ref.backward(ls, ils, lls, seed=it)
+                acc += ref.grads                       # world = 2: (g0 + g1) is the all-reduce's sum bit for bit
+            ref.grads.copy_(acc)
+            ar._scale(ref.grads, 1.0 / world)
+            opt2.apply(ref, it)
+        torch.cuda.synchronize()
+        if world == 2:
+            assert torch.equal(ref.params, eng.params), "DP step != single-process step on the mean gradient (max diff %g)" % float(
+                (ref.params - eng.params).abs().max())
+        else:
+            assert torch.allclose(ref.params, eng.params, rtol=1e-5, atol=1e-7)
+        print("DP_CHECK OK world=%d backend=%s precision=%s" % (world, backend, precision), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

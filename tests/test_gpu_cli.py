@@ -93,3 +93,61 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 32 and res["config"]["parallelism"] == "dp2"
     assert res["scaling"] == "weak" and res["value"] > 0 and np.isfinite(res["config"]["final_loss"])
+
+
+def _torchrun(script_args, backend, nproc=2, timeout=900):
+    import subprocess
+    env = dict(os.environ, CRNN_DIST_BACKEND=backend, PYTHONPATH=os.pathsep.join([ROOT, PKG]), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29900 + os.getpid() % 300 + (7 if backend == "nccl" else 0)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + script_args
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+
+
+def test_data_parallel_step_equals_single_process_step_gloo():
+    """Two ranks (sharing this box's GPU, gradients over gloo): ranks that start from different weights end bit-identical
+    (broadcast_state), and equal to one process applying Adam to the mean of the two shard gradients (tests/dp_check.py)."""
+    out = _torchrun([os.path.join(ROOT, "tests", "dp_check.py")], "gloo")
+    assert out.returncode == 0 and "DP_CHECK OK world=2" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+def test_data_parallel_step_equals_single_process_step_rccl():
+    """The same over RCCL (backend "nccl"), one rank per GPU -- needs >= 2 visible GPUs."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs for RCCL (the gloo variant covers the logic on one GPU)")
+    out = _torchrun([os.path.join(ROOT, "tests", "dp_check.py")], "nccl")
+    assert out.returncode == 0 and "DP_CHECK OK world=2 backend=nccl" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver calls --gpus 1) must itself start 2 ranks and print
+    ONE JSON line with n_gpus 2: over RCCL when 2 GPUs are visible, else both ranks on this GPU over gloo."""
+    import json
+    import subprocess
+    import torch
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    env = dict(os.environ, CRNN_DIST_BACKEND=backend, PYTHONPATH=os.pathsep.join([ROOT, PKG]))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "16",
+                          "--no-roofline"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 32 and res["value"] > 0
+
+
+def test_train_cli_two_ranks_keep_identical_weights(tmp_path):
+    """torchrun train.py (2 ranks, gloo on this GPU): unequal file counts per rank are trimmed to equal shards, early stopping
+    monitors the global loss, so both ranks finish (no hang) and rank 0 writes the artefacts."""
+    data = tmp_path / "data"; out = tmp_path / "out"
+    os.makedirs(data); os.makedirs(out)
+    _make_dataset(str(data), n=51)
+    res = _torchrun([os.path.join(PKG, "train.py"), "--path", str(data), "--save_path", str(out), "--model_name", "dp", "--nbepochs", "2",
+                     "--norm", "--opt", "adam", "--lr", "0.001", "--batch_size", "8", "--n_units", "64", "--time_dense_size", "32",
+                     "--early_stopping", "2", "--G", "0"], "gloo")
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    for f in ("model.json", "final_weights.h5", "loss_history.pickle.dat"):
+        assert (out / "dp" / f).exists(), f

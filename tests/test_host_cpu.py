@@ -183,9 +183,45 @@ def _dp_worker(rank, world, port, q):
     split = staged.numel() // 3
     ar.start(staged[split:]); ar.start(staged[:split]); ar.finish(staged)
     assert torch.equal(staged, flat), "two-stage all-reduce differs from the single one"
+    # replicas that start from different weights adopt rank 0's; moving statistics are averaged on demand
+    from types import SimpleNamespace
+    from crnn_mi355x.parallel import broadcast_state, sync_bn_stats
+    fake = SimpleNamespace(params=torch.full((5,), float(rank + 1)), bn_mean=torch.full((3,), float(rank)), bn_var=torch.full((3,), 1.0 + rank))
+    broadcast_state(fake, dist, world)
+    assert torch.equal(fake.params, torch.full((5,), 1.0)) and torch.equal(fake.bn_mean, torch.zeros(3)) and torch.equal(fake.bn_var, torch.ones(3))
+    fake.bn_mean += rank; fake.bn_var += 2 * rank
+    sync_bn_stats(fake, dist, world)
+    assert torch.allclose(fake.bn_mean, torch.full((3,), 0.5)) and torch.allclose(fake.bn_var, torch.full((3,), 2.0))
     q.put((rank, flat.numpy().copy(), (lo, hi)))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_shards_are_equal_sized_so_every_rank_issues_the_same_collectives():
+    from crnn_mi355x.parallel import shard
+    assert [shard(51, r, 2) for r in range(2)] == [(0, 25), (25, 50)]
+    assert [shard(8, r, 8) for r in range(8)] == [(r, r + 1) for r in range(8)]
+    assert shard(10, 0, 1) == (0, 10)
+    sizes = {hi - lo for lo, hi in (shard(1003, r, 8) for r in range(8))}
+    assert sizes == {125}
+
+
+def test_bench_gpus_flag_self_launches_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` outside a launcher re-executes itself under torch.distributed.run with N processes."""
+    import importlib
+    import subprocess
+    bench = importlib.import_module("bench")
+    seen = {}
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setenv("CRNN_DIST_BACKEND", "gloo")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    assert bench.self_launch(4) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setenv("CRNN_DIST_BACKEND", "nccl")
+    assert bench.self_launch(4) == 2          # no GPUs here: refuses instead of silently running one rank
 
 
 def test_data_parallel_gradient_allreduce_world2_gloo():
