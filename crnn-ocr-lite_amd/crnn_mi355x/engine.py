@@ -26,15 +26,17 @@ def _stream():
 
 class Engine:
     def __init__(self, batch, imgh=100, imgw=32, num_classes=38, max_len=23, time_dense_size=128, n_units=256,
-                 gru=False, stn=True, dropout=True, device=None, precision="fp32", share=None):
+                 gru=False, stn=True, dropout=True, device=None, precision="fp32", share=None, flags=None):
         """share: another Engine of the same architecture (any batch size) whose parameter / gradient / BatchNorm / optimizer-
-        state tensors this one adopts (only the workspace and the batch-shaped outputs are its own)."""
+        state tensors this one adopts (only the workspace and the batch-shaped outputs are its own).
+        flags: bit set of native.FLAG_* (schedule A/B switches with identical numerics; default: $CRNN_FLAGS or 0)."""
         if not torch.cuda.is_available():
             raise RuntimeError("the CRNN hot path needs an AMD GPU (gfx950); there is no CPU fallback")
         self.lib = native.lib()
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.cfg = crnn_config(batch, imgh, imgw, num_classes, max_len, time_dense_size, n_units, int(bool(gru)),
-                               int(bool(stn)), int(bool(dropout)), {"fp32": 0, "bf16": 1, "bf16s": 2}.get(precision, 0))
+                               int(bool(stn)), int(bool(dropout)), {"fp32": 0, "bf16": 1, "bf16s": 2}.get(precision, 0),
+                               int(os.environ.get("CRNN_FLAGS", "0")) if flags is None else int(flags))
         if precision not in ("fp32", "bf16", "bf16s"):
             raise ValueError("precision must be 'fp32' (parity mode), 'bf16' (bf16 MFMA products, fp32 tensors) or "
                              "'bf16s' (bf16 MFMA products + bf16 conv-stack tensors in HBM)")

@@ -14,12 +14,15 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 HEADER = os.path.join(REPO_ROOT, "include", "crnn_mi355x.h")
 CSRC = os.path.join(PKG_ROOT, "csrc")
 LIB_PATH = os.path.join(PKG_ROOT, "libcrnn_mi355x.so")
-SOURCES = ["gemm.hip", "conv.hip", "stn.hip", "rnn.hip", "ctc.hip", "beam.hip", "optim.hip", "model.hip"]
+SOURCES = ["gemm.hip", "conv.hip", "stn.hip", "rnn.hip", "rnn_persist.hip", "ctc.hip", "beam.hip", "optim.hip", "model.hip"]
 
 
 class crnn_config(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in
-                ("batch", "imgh", "imgw", "num_classes", "max_len", "tds", "units", "gru", "stn", "dropout", "mfma_bf16")]
+                ("batch", "imgh", "imgw", "num_classes", "max_len", "tds", "units", "gru", "stn", "dropout", "mfma_bf16", "flags")]
+
+
+FLAG_RNN_STEP_KERNELS = 1      # CRNN_FLAG_RNN_STEP_KERNELS
 
 
 _CTYPE = [("crnn_stream_t", ctypes.c_void_p), ("size_t", ctypes.c_size_t), ("uint64_t", ctypes.c_uint64),
@@ -57,7 +60,7 @@ def build(verbose=False):
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
-        deps = [src, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_bf16.inc"), HEADER]
+        deps = [src, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "rnn_cell.h"), os.path.join(CSRC, "gemm_bf16.inc"), HEADER]
         if not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps):
             cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", inc, "-c", src, "-o", obj]
             if verbose:

@@ -95,6 +95,13 @@ struct Plan {
 
 long lmax(long a, long b) { return a > b ? a : b; }
 
+// storage of the recurrent weights the recurrences multiply with: bf16 copies in the bf16 modes (u % 128 == 0), else fp32
+int rnn_dtu(const crnn_config* c) { return (c->mfma_bf16 && c->units % 128 == 0) ? CRNN_BF16 : CRNN_F32; }
+// LSTM recurrences as persistent one-launch-per-layer kernels (rnn_persist.hip) unless switched off or unsupported
+bool rnn_persist(const crnn_config* c) {
+  return !c->gru && !(c->flags & CRNN_FLAG_RNN_STEP_KERNELS) && crnn_lstm_persist_supported(c->units, rnn_dtu(c)) == 0;
+}
+
 Plan make_plan(const crnn_config* c) {
   Dims d = make_dims(c);
   Plan P;
@@ -165,6 +172,7 @@ Plan make_plan(const crnn_config* c) {
   P.add("gemm_scratch", 16L * 1024 * 1024);   // 64 MiB of split-reduction partials (main stream)
   P.add("gemm_scratch2", 16L * 1024 * 1024);  // the same for the side stream of the backward
   P.add("partials2", lmax((long)crnn_colreduce_chunks(TB) * lmax(d.G, lmax(d.tds, d.C)), 1024));
+  if (rnn_persist(c)) P.add("rnnx", (long)((crnn_lstm_persist_xbuf_bytes(d.T, d.B, d.u, rnn_dtu(c)) + 3) / 4));   // h_t / dz_t exchange tiles
   return P;
 }
 
@@ -411,7 +419,9 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
   if (train && cfg->dropout) CRNN_TRY(crnn_dropout(c.w("dn1"), c.w("dn1"), TB, d.tds, d.tds, d.tds, kDropDense1, seed, kLayerDense1, stream));
   // ---- 2 x Bidirectional(LSTM) (utils.py:78-79)
   // bf16 modes: the recurrent products run on the bf16 MFMA from a bf16 U^T (u % 128 == 0); parity mode: fp32
-  const int dtu = (cfg->mfma_bf16 && u % 128 == 0) ? CRNN_BF16 : CRNN_F32;
+  const int dtu = rnn_dtu(cfg);
+  const bool persist = rnn_persist(cfg);
+  const size_t xbytes = persist ? crnn_lstm_persist_xbuf_bytes(T, B, u, dtu) : 0;
   {  // U -> U^T for the four recurrences, one launch
     long in_off[4], out_off[4]; int R[4], Cc[4]; int n = 0;
     const char* names[4] = {"1f", "1b", "2f", "2b"};
@@ -429,6 +439,9 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
   if (cfg->gru)   // "cs" holds r*h_prev for the GRU (cell state for the LSTM)
     CRNN_TRY(crnn_gru_fwd_ex(c.w("xw1f"), c.w("xw1b"), c.w("ut1f"), c.w("ut1b"), c.w("h1f"), c.w("h1b"), u, c.w("gt1f"), c.w("gt1b"),
                              c.w("cs1f"), c.w("cs1b"), T, B, u, dtu, stream));
+  else if (persist)
+    CRNN_TRY(crnn_lstm_fwd_persist(c.w("xw1f"), c.w("xw1b"), c.w("ut1f"), c.w("ut1b"), c.w("h1f"), c.w("h1b"), u, c.w("cs1f"), c.w("cs1b"),
+                                   c.w("gt1f"), c.w("gt1b"), T, B, u, dtu, c.w("rnnx"), xbytes, 0, 0, stream));
   else
     CRNN_TRY(crnn_lstm_fwd_ex(c.w("xw1f"), c.w("xw1b"), c.w("ut1f"), c.w("ut1b"), c.w("h1f"), c.w("h1b"), u, c.w("cs1f"), c.w("cs1b"),
                               c.w("gt1f"), c.w("gt1b"), T, B, u, dtu, stream));
@@ -438,6 +451,9 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
   if (cfg->gru)
     CRNN_TRY(crnn_gru_fwd_ex(c.w("xw2f"), c.w("xw2b"), c.w("ut2f"), c.w("ut2b"), c.w("h2"), c.w("h2") + u, 2 * u, c.w("gt2f"), c.w("gt2b"),
                              c.w("cs2f"), c.w("cs2b"), T, B, u, dtu, stream));
+  else if (persist)
+    CRNN_TRY(crnn_lstm_fwd_persist(c.w("xw2f"), c.w("xw2b"), c.w("ut2f"), c.w("ut2b"), c.w("h2"), c.w("h2") + u, 2 * u, c.w("cs2f"), c.w("cs2b"),
+                                   c.w("gt2f"), c.w("gt2b"), T, B, u, dtu, c.w("rnnx"), xbytes, 0, 0, stream));    // merge_mode='concat'
   else
     CRNN_TRY(crnn_lstm_fwd_ex(c.w("xw2f"), c.w("xw2b"), c.w("ut2f"), c.w("ut2b"), c.w("h2"), c.w("h2") + u, 2 * u, c.w("cs2f"), c.w("cs2b"),
                               c.w("gt2f"), c.w("gt2b"), T, B, u, dtu, stream));    // merge_mode='concat'
@@ -472,6 +488,9 @@ static int rnn_bwd_chain(const Ctx& c, int layer, const float* hf, const float* 
   if (c.cfg->gru)
     return crnn_gru_bwd_ex(uf, ub, hf, hb, ldh, c.w("gt" + l + "f"), c.w("gt" + l + "b"), doutf, doutb,
                            ldo, dzf, dzb, c.w("dcf"), c.w("dcb"), c.w("dhpf"), c.w("dhpb"), T, B, u, dtu, c.s);
+  if (rnn_persist(c.cfg) && !(((uintptr_t)uf | (uintptr_t)ub) & 15))
+    return crnn_lstm_bwd_persist(uf, ub, c.w("cs" + l + "f"), c.w("cs" + l + "b"), c.w("gt" + l + "f"), c.w("gt" + l + "b"), doutf, doutb, ldo,
+                                 dzf, dzb, T, B, u, dtu, c.w("rnnx"), crnn_lstm_persist_xbuf_bytes(T, B, u, dtu), 0, 0, c.s);
   return crnn_lstm_bwd_ex(uf, ub, c.w("cs" + l + "f"), c.w("cs" + l + "b"), c.w("gt" + l + "f"),
                           c.w("gt" + l + "b"), doutf, doutb, ldo, dzf, dzb, c.w("dcf"), c.w("dcb"), T, B, u, dtu, c.s);
 }

@@ -12,6 +12,7 @@
 // Backward (BPTT) mirrors it: dh_{t-1} = dz_t * U^T as the per-step GEMM, the gate-gradient math as its
 // epilogue; dW/dU/dx/db are whole-sequence GEMMs afterwards.
 #include "common.h"
+#include "rnn_cell.h"
 
 // ----------------------------------------------------------------------------------------------------------
 // Shared step-GEMM tile: acc[g] (16x16, MFMA C/D layout) = sum_k A[b0+r][k] * Brow_g[j0+r'][k] over this wave's
@@ -212,13 +213,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmDir d0, LstmDir 
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         z[g] = ((red[0][m * 4 + g][tid] + red[1][m * 4 + g][tid]) + (red[2][m * 4 + g][tid] + red[3][m * 4 + g][tid])) + xwv[m][g];
-      float ig = hard_sigmoid(z[0]), fg = hard_sigmoid(z[1]), gg = tanhf(z[2]), og = hard_sigmoid(z[3]);
-      float cn = fg * cpv[m] + ig * gg;
-      float hn = og * tanhf(cn);
+      const LstmFwdOut o = lstm_cell_fwd(z, cpv[m]);
       float* gt = d.gates + ((long)t * B + b) * 4 * u;
-      gt[j] = ig; gt[u + j] = fg; gt[2 * u + j] = gg; gt[3 * u + j] = og;
-      d.c[((long)t * B + b) * u + j] = cn;
-      d.h[((long)t * B + b) * d.ldh + j] = hn;
+      gt[j] = o.ig; gt[u + j] = o.fg; gt[2 * u + j] = o.gg; gt[3 * u + j] = o.og;
+      d.c[((long)t * B + b) * u + j] = o.cn;
+      d.h[((long)t * B + b) * d.ldh + j] = o.hn;
     }
   }
 }
@@ -272,17 +271,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmDir d0, LstmDir 
     const int b = b0 + 16 * m + row;
     if (b < B) {
       float dh = ((red[0][m][tid] + red[1][m][tid]) + (red[2][m][tid] + red[3][m][tid])) + dov[m];
-      float ig = gv[m][0], fg = gv[m][1], gg = gv[m][2], og = gv[m][3];
-      float ct = ctv[m], cprev = cpv[m], dcin = dcv[m];
-      float tc = tanhf(ct);
-      float dog = dh * tc;
-      float dct = dh * og * (1.f - tc * tc) + dcin;
+      const LstmBwdOut o = lstm_cell_bwd(dh, gv[m][0], gv[m][1], gv[m][2], gv[m][3], ctv[m], cpv[m], dcv[m]);
       float* dz = d.dz + ((long)t * B + b) * K;
-      dz[j] = dct * gg * hs_grad_from_out(ig);
-      dz[u + j] = dct * cprev * hs_grad_from_out(fg);
-      dz[2 * u + j] = dct * ig * (1.f - gg * gg);
-      dz[3 * u + j] = dog * hs_grad_from_out(og);
-      d.dc[(long)b * u + j] = dct * fg;
+      dz[j] = o.dz[0]; dz[u + j] = o.dz[1]; dz[2 * u + j] = o.dz[2]; dz[3 * u + j] = o.dz[3];
+      d.dc[(long)b * u + j] = o.dc;
     }
   }
 }

@@ -36,7 +36,10 @@ typedef struct {
   int mfma_bf16;    /* 0 = fp32 MFMA everywhere (parity mode); 1 = conv-stack / dense / RNN-input GEMMs multiply in bf16
                        (operands rounded while staged into LDS, fp32 accumulate, fp32 tensors in HBM); 2 = as 1 and the
                        conv-stack activations / gradients are stored as bf16 in HBM (statistics, RNN, CTC, optimizer fp32) */
+  int flags;        /* bit set of CRNN_FLAG_* (0 = the default schedule); A/B switches, every variant gives the same numbers */
 } crnn_config;
+#define CRNN_FLAG_RNN_STEP_KERNELS 1  /* LSTM recurrences as one launch per timestep (crnn_lstm_*_ex) instead of the
+                                         persistent one-launch-per-layer kernels (crnn_lstm_*_persist); bit-identical */
 
 /* ---- parameter / statistics layout (Keras weight order) -------------------------------------- */
 int  crnn_num_params(const crnn_config* cfg);                 /* number of trainable tensors */
@@ -255,6 +258,24 @@ int crnn_lstm_fwd_ex(const float* xw0, const float* xw1, const void* ut0, const 
 int crnn_lstm_bwd_ex(const void* u0, const void* u1, const float* c0, const float* c1, const float* g0, const float* g1,
                      const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1, float* dc0, float* dc1, int T,
                      int B, int u, int dt_u, crnn_stream_t stream);
+/* Persistent recurrences: ONE launch per Bidirectional(LSTM) layer (utils.py:77-82) instead of T dependent step launches.
+ * A cluster of u/16 workgroups runs the chain of one 16- or 32-row batch tile of one direction; each workgroup keeps its
+ * 256x64 slice of the recurrent weights in registers (MFMA B fragments) and the cell state / cell-gradient carry in
+ * registers for all T steps; per step the cluster all-gathers h_t (forward) / dz_t (backward) through `xbuf` with
+ * write-through stores and L1-bypassing polled loads (the data is its own ready flag) and stages it through LDS as the next
+ * step's MFMA A operand.  Bit-identical to crnn_lstm_*_ex.  `xbuf`: caller-owned scratch of crnn_lstm_persist_xbuf_bytes()
+ * bytes, 16-byte aligned; after the launch the unsigned at xbuf[0] is non-zero if a bounded wait gave up (results invalid).
+ * mt = batch rows per workgroup / 16 (1 | 2), uw = 16-unit groups per workgroup (1 | 2 | 4: 256 / 512 / 1024 threads, the
+ * cluster has u/(16 uw) members); 0 = automatic.  crnn_lstm_persist_supported: 0 if (u, dt_u) has a kernel
+ * (fp32: u in {64,128,256}; bf16: u in {128,256,512}), else -3 -- use the step kernels then. */
+size_t crnn_lstm_persist_xbuf_bytes(int T, int B, int u, int dt_u);
+int crnn_lstm_persist_supported(int u, int dt_u);
+int crnn_lstm_fwd_persist(const float* xw0, const float* xw1, const void* ut0, const void* ut1, float* h0, float* h1, int ldh,
+                          float* c0, float* c1, float* g0, float* g1, int T, int B, int u, int dt_u, void* xbuf, size_t xbuf_bytes,
+                          int mt, int uw, crnn_stream_t stream);
+int crnn_lstm_bwd_persist(const void* u0, const void* u1, const float* c0, const float* c1, const float* g0, const float* g1,
+                          const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1, int T, int B, int u, int dt_u,
+                          void* xbuf, size_t xbuf_bytes, int mt, int uw, crnn_stream_t stream);
 /* Bidirectional GRU recurrence (utils.py:81-82; reset_after=False), time-major; gates = z,r,hh; rh = r*h_prev */
 int crnn_gru_fwd(const float* xw0, const float* xw1, const float* ut0, const float* ut1, float* h0, float* h1, int ldh,
                  float* g0, float* g1, float* rh0, float* rh1, int T, int B, int u, crnn_stream_t stream);

@@ -284,6 +284,95 @@ def test_bilstm_fwd_bwd(B, T, u, din):
         assert_close(dzh.reshape(B * T, G).sum(0), db, rtol=2e-4, atol=1e-4, what=f"db dir{d}")
 
 
+def _lstm_persist_case(B, T, u, bf16, mt, uw, seed):
+    """Run one Bidirectional(LSTM) layer forward + BPTT through the per-step kernels (crnn_lstm_*_ex) and through the
+    persistent ones (crnn_lstm_*_persist); returns both result sets as host arrays + the status word."""
+    rs = np.random.RandomState(seed)
+    G = 4 * u
+    U = [rs.normal(size=(u, G)) * 0.15 for _ in range(2)]
+    xw = [dev(rs.normal(size=(T, B, G)) * 0.8) for _ in range(2)]
+    gd = dev(rs.normal(size=(T, B, 2 * u)))
+    if bf16:
+        ut = [_to_bf16_dev(U[d].T) for d in range(2)]; Ud = [_to_bf16_dev(U[d]) for d in range(2)]
+    else:
+        ut = [dev(U[d].T) for d in range(2)]; Ud = [dev(U[d]) for d in range(2)]
+    dt = 1 if bf16 else 0
+    nbytes = L().crnn_lstm_persist_xbuf_bytes(T, B, u, dt)
+    xbuf = torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device="cuda")
+    out = {}
+    for kind in ("step", "persist"):
+        hcat = zeros(T, B, 2 * u); cs = [zeros(T, B, u) for _ in range(2)]; gt = [zeros(T, B, G) for _ in range(2)]
+        dz = [zeros(T, B, G) for _ in range(2)]; dc = [zeros(B, u) for _ in range(2)]
+        hb = ctypes.c_void_p(hcat.data_ptr() + 4 * u); gb = ctypes.c_void_p(gd.data_ptr() + 4 * u)
+        if kind == "step":
+            ok(L().crnn_lstm_fwd_ex(P(xw[0]), P(xw[1]), P(ut[0]), P(ut[1]), P(hcat), hb, 2 * u, P(cs[0]), P(cs[1]), P(gt[0]), P(gt[1]), T, B, u, dt, S()))
+            ok(L().crnn_lstm_bwd_ex(P(Ud[0]), P(Ud[1]), P(cs[0]), P(cs[1]), P(gt[0]), P(gt[1]), P(gd), gb, 2 * u, P(dz[0]), P(dz[1]), P(dc[0]), P(dc[1]),
+                                    T, B, u, dt, S()))
+            status = 0
+        else:
+            ok(L().crnn_lstm_fwd_persist(P(xw[0]), P(xw[1]), P(ut[0]), P(ut[1]), P(hcat), hb, 2 * u, P(cs[0]), P(cs[1]), P(gt[0]), P(gt[1]), T, B, u, dt,
+                                         P(xbuf), nbytes, mt, uw, S()))
+            status = int(xbuf[0].item())
+            ok(L().crnn_lstm_bwd_persist(P(Ud[0]), P(Ud[1]), P(cs[0]), P(cs[1]), P(gt[0]), P(gt[1]), P(gd), gb, 2 * u, P(dz[0]), P(dz[1]), T, B, u, dt,
+                                         P(xbuf), nbytes, mt, uw, S()))
+            status |= int(xbuf[0].item())
+        out[kind] = dict(h=host(hcat), c=[host(t) for t in cs], g=[host(t) for t in gt], dz=[host(t) for t in dz], status=status)
+    return out
+
+
+@pytest.mark.parametrize("B,T,u,bf16,mt,uw", [
+    (5, 7, 64, False, 0, 0), (33, 6, 128, False, 1, 1), (33, 6, 128, False, 2, 2), (70, 9, 256, False, 0, 0), (40, 5, 256, False, 2, 1),
+    (20, 9, 128, True, 0, 0), (37, 8, 256, True, 1, 1), (37, 8, 256, True, 2, 2), (37, 8, 256, True, 1, 4), (256, 52, 256, True, 0, 0),
+    (256, 52, 256, True, 1, 2), (64, 102, 256, False, 0, 0), (18, 5, 512, True, 0, 0), (600, 4, 128, True, 0, 0)])
+def test_persistent_lstm_is_bit_identical_to_the_step_kernels(B, T, u, bf16, mt, uw):
+    """One launch per layer (cluster of u/16 workgroups per batch tile, recurrent weights + cell state in registers, h_t / dz_t
+    all-gathered through device memory and staged through LDS) must reproduce the T-launch path bit for bit, forward and
+    BPTT, fp32 and bf16 recurrent products, ragged batch tiles, 16- and 32-row tiles, 256- / 512- / 1024-thread workgroups
+    (cluster sizes u/16, u/32, u/64), T up to the IAM shape's 102, a batch that needs several launches (600 rows)."""
+    r = _lstm_persist_case(B, T, u, bf16, mt, uw, seed=B + T + u)
+    a, b = r["step"], r["persist"]
+    assert b["status"] == 0, "a bounded wait of the persistent kernel gave up"
+    assert np.array_equal(a["h"], b["h"]), "h: max diff %g" % np.abs(a["h"] - b["h"]).max()
+    for d in range(2):
+        assert np.array_equal(a["c"][d], b["c"][d]), "c dir%d" % d
+        assert np.array_equal(a["g"][d], b["g"][d]), "gates dir%d" % d
+        assert np.array_equal(a["dz"][d], b["dz"][d]), "dz dir%d: max diff %g" % (d, np.abs(a["dz"][d] - b["dz"][d]).max())
+    assert np.isfinite(b["h"]).all() and np.abs(b["dz"][0]).max() > 0
+
+
+def test_persistent_lstm_repeated_launches_and_oracle():
+    """Back-to-back launches reuse (and re-poison) the same exchange buffer; the fp32 result also matches the fp64 oracle cell."""
+    B, T, u, din = 21, 11, 64, 24
+    rs = np.random.RandomState(77)
+    x = rs.normal(size=(B, T, din)); G = 4 * u
+    Wt = [rs.normal(size=(din, G)) * 0.3 for _ in range(2)]
+    U = [rs.normal(size=(u, G)) * 0.15 for _ in range(2)]
+    bb = [rs.normal(size=G) * 0.2 for _ in range(2)]
+    tm = lambda a: np.ascontiguousarray(np.swapaxes(a, 0, 1))
+    xw = [dev(tm(x @ Wt[d] + bb[d])) for d in range(2)]
+    ut = [dev(U[d].T) for d in range(2)]
+    nbytes = L().crnn_lstm_persist_xbuf_bytes(T, B, u, 0)
+    xbuf = torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device="cuda")
+    hcat = zeros(T, B, 2 * u); cs = [zeros(T, B, u) for _ in range(2)]; gt = [zeros(T, B, G) for _ in range(2)]
+    first = None
+    for rep in range(4):
+        hcat.zero_()
+        code = L().crnn_lstm_fwd_persist(P(xw[0]), P(xw[1]), P(ut[0]), P(ut[1]), P(hcat), ctypes.c_void_p(hcat.data_ptr() + 4 * u), 2 * u, P(cs[0]),
+                                         P(cs[1]), P(gt[0]), P(gt[1]), T, B, u, 0, P(xbuf), nbytes, 0, 0, S())
+        assert code == 0
+    torch.cuda.synchronize()
+    assert int(xbuf[0].item()) == 0
+    hh = host(hcat)
+    for d in range(2):
+        h, c = ops.lstm_fwd(x, Wt[d], U[d], bb[d], reverse=(d == 1))
+        assert_close(hh[:, :, d * u:(d + 1) * u], tm(h), rtol=1e-4, atol=1e-5, what=f"h dir{d}")
+        assert_close(host(cs[d]), tm(c[4]), rtol=1e-4, atol=1e-5, what=f"c dir{d}")
+    # unsupported widths / a too-small exchange buffer are refused
+    assert L().crnn_lstm_persist_supported(192, 0) == -3 and L().crnn_lstm_persist_supported(64, 1) == -3
+    assert L().crnn_lstm_fwd_persist(P(xw[0]), P(xw[1]), P(ut[0]), P(ut[1]), P(hcat), P(hcat), 2 * u, P(cs[0]), P(cs[1]), P(gt[0]), P(gt[1]), T, B, u, 0,
+                                     P(xbuf), 64, 0, 0, S()) == -2
+
+
 @pytest.mark.parametrize("B,T,u,din", [(5, 7, 64, 24), (20, 5, 128, 40)])
 def test_bigru_fwd_bwd(B, T, u, din):
     rs = np.random.RandomState(B + T + 1)
