@@ -37,6 +37,9 @@ struct GemmParams {
   // rounded to bf16, ch = the reduction index (modes 0/1) or the A row (mode 2): the BatchNorm + ReLU6 between a depthwise
   // and a pointwise convolution, applied while the tile is staged instead of in a pass of its own
   const float* ascale; const float* ashift;
+#ifdef CRNN_GEMM_EXP
+  int exp;         // ablation build only (scripts/gemm_ablate.py): 1 no C stores, 2 no MFMA, 4 B loaded once, 8 A loaded once
+#endif
 };
 
 // ---- statistics epilogue: per-tile column sums / sums of squares of the result as it will be stored, taken straight

@@ -344,9 +344,25 @@ class SGD:
 NORM_MEAN, NORM_STD = 118.24236953981779, 36.72835353999682  # utils.py:421
 
 
-def synthetic_batch(cfg, B, seed=0, dtype=np.float32):
+def variable_width_images(rs, B, imgh, imgw, wmin=40):
+    """SURVEY 8d C3 (BASELINE configs[2], IAM shape): uint8 noise "text" occupying a random prefix of wmin..imgh rows of the time
+    axis (axis 0 after the reference's rotation, utils.py:370), the rest filled with the text's modal grey value the way open_img
+    pads a short word (utils.py:372-373,379-400 with the augmentation branch off)."""
+    x = np.empty((B, imgh, imgw, 1), dtype=np.uint8)
+    for b in range(B):
+        w = int(rs.randint(min(wmin, imgh), imgh + 1))
+        text = rs.randint(0, 256, (w, imgw)).astype(np.uint8)
+        val, counts = np.unique(text, return_counts=True)
+        fill = val[np.where(counts == counts.max())[0][0]]
+        x[b, :w, :, 0] = text
+        x[b, w:, :, 0] = fill
+    return x
+
+
+def synthetic_batch(cfg, B, seed=0, dtype=np.float32, variable_width=False):
     rs = np.random.RandomState(seed)
-    x = ((rs.randint(0, 256, (B, cfg.imgh, cfg.imgw, 1)).astype(np.float32) - NORM_MEAN) / NORM_STD).astype(dtype)
+    raw = variable_width_images(rs, B, cfg.imgh, cfg.imgw) if variable_width else rs.randint(0, 256, (B, cfg.imgh, cfg.imgw, 1))
+    x = ((raw.astype(np.float32) - NORM_MEAN) / NORM_STD).astype(dtype)
     blank = cfg.num_classes - 1
     ll = rs.randint(1, cfg.max_len + 1, size=B)
     labels = np.full((B, cfg.max_len), blank, dtype=np.int64)

@@ -116,11 +116,11 @@ def device_cache(eng, cfg, p, x, B, c_ref):
     return c
 
 
-def run_case(B, imgh, imgw, u, tds, max_len, stn, dropout, seed=3, num_classes=38, gru=False):
+def run_case(B, imgh, imgw, u, tds, max_len, stn, dropout, seed=3, num_classes=38, gru=False, variable_width=False):
     cfg = M.Config(imgh=imgh, imgw=imgw, num_classes=num_classes, max_len=max_len, time_dense_size=tds, n_units=u, gru=gru)
     p, bn = M.init_params(cfg, seed=7, dtype=np.float64)
     p = M.randomize_params(cfg, p)
-    x, lab, il, ll = M.synthetic_batch(cfg, B, seed=1, dtype=np.float64)
+    x, lab, il, ll = M.synthetic_batch(cfg, B, seed=1, dtype=np.float64, variable_width=variable_width)
     eng = Engine(B, imgh, imgw, num_classes, max_len, tds, u, gru=gru, stn=stn, dropout=dropout)
     eng.set_params(p, bn)
     masks = masks_from_engine(eng, cfg, seed) if dropout else None
@@ -152,6 +152,11 @@ def check_case(res, tag):
     worst = {}
     for k in p:
         scale = max(np.abs(gdev[k]).max(), 1e-6)
+        if "_bn" in k:
+            # d(gamma) and d(beta) of one BatchNorm layer are sums over the same B*H*W terms; with few channels (block 1 has ONE) a
+            # sum that cancels to a small value would otherwise be judged against itself instead of against the size of its terms
+            # (seen on variable-width text: d(beta) = -0.68 next to d(gamma) = 7.3, fp32 round-off of the 29 k-term sum 4e-3)
+            scale = max(scale, np.abs(gdev[k[:-1] + "g"]).max(), np.abs(gdev[k[:-1] + "b"]).max())
         err = np.abs(gd[k] - gdev[k]).max()
         if err > 1e-3 * scale + 1e-7:
             worst[k] = (err / scale)
@@ -306,6 +311,71 @@ def test_iam_shape_forward_loss():
     """BASELINE config 3 shape: height 32, width 200 (T=102, CTC 100 steps), max_len 21, STN on."""
     res = run_case(B=3, imgh=200, imgw=32, u=128, tds=64, max_len=21, stn=True, dropout=False)
     check_case(res, "iam")
+
+
+def test_iam_shape_full_width_model_variable_width_text():
+    """BASELINE configs[2] at the real model width (n_units 256, time_dense_size 128) on variable-width text lines (random prefix of
+    40..200 rows of noise, the rest the modal grey value: SURVEY 8d C3, utils.py:372-400): fp32 parity of every intermediate, logits,
+    CTC loss (T = 100 steps) and gradients."""
+    res = run_case(B=2, imgh=200, imgw=32, u=256, tds=128, max_len=21, stn=True, dropout=False, variable_width=True)
+    check_case(res, "iam-full")
+
+
+def test_bf16s_inference_at_batch256_against_the_oracle_on_a_slice():
+    """The benchmarked storage mode (bf16 conv-stack tensors) at the benchmarked batch (256): inference BatchNorm makes every image
+    independent, so the first 16 posteriors can be checked against the fp64 oracle run on those 16 images alone.  Bounds are what
+    the mode honestly delivers (measured: max |dy| ~2e-2 on single time steps whose top two classes are close, mean |dy| ~3e-4,
+    per-sample CTC cost within ~3e-3 relative, >= 98 % of arg-max indices equal) -- not the 1e-3 parity tolerance, which only
+    the fp32 mode meets (test_config1_shape...)."""
+    cfg = M.Config()
+    B, n = 256, 16
+    p, bn = M.init_params(cfg, seed=2, dtype=np.float64)
+    p = M.randomize_params(cfg, p)
+    rs = np.random.RandomState(4)
+    for k in bn:     # non-trivial moving statistics
+        bn[k] = (np.abs(rs.normal(size=bn[k].shape)) * 0.5 + 0.5) if k.endswith("_var") else rs.normal(size=bn[k].shape) * 0.1
+    x, lab, il, ll = M.synthetic_batch(cfg, B, seed=9, dtype=np.float64)
+    y_ref, _ = M.forward(cfg, p, bn, x[:n], train=False)
+    loss_ref, _ = ctc.ctc_loss_and_grad(y_ref, lab[:n], il[:n], ll[:n])
+    out = {}
+    for precision in ("fp32", "bf16s"):
+        eng = Engine(B, dropout=False, precision=precision)
+        eng.set_params(p, bn)
+        y = eng.forward(x.astype(np.float32), train=False).cpu().numpy()[:n]
+        loss_d, _ = ctc.ctc_loss_and_grad(y.astype(np.float64), lab[:n], il[:n], ll[:n])
+        out[precision] = (float(np.abs(y - y_ref).max()), float(np.abs(y - y_ref).mean()), float((np.argmax(y, -1) == np.argmax(y_ref, -1)).mean()),
+                          float(np.abs(loss_d - loss_ref).max() / np.abs(loss_ref).max()))
+        print("[batch256 %s] max|dy| %.3e mean|dy| %.3e argmax agreement %.4f rel CTC-cost err %.3e" % ((precision,) + out[precision]))
+    assert out["fp32"][0] < 1e-4 and out["fp32"][2] == 1.0 and out["fp32"][3] < 1e-4
+    assert out["bf16s"][0] < 4e-2 and out["bf16s"][1] < 1e-3 and out["bf16s"][2] >= 0.98 and out["bf16s"][3] < 6e-3
+
+
+def test_predict_path_batch1024_properties():
+    """BASELINE configs[4] size: inference at batch 1024 + beam search (width 10).  Properties that need no oracle at this size:
+    per-image independence (rows 0..7 equal the same images run at batch 8, bit for bit in fp32), normalised posteriors, greedy ==
+    arg-max/collapse of the device posteriors, beam search == the CPU restatement of TF's beam search on a sample of rows, and the
+    top beam never scores below the greedy path."""
+    cfg = M.Config()
+    B = 1024
+    p, bn = M.init_params(cfg, seed=2, dtype=np.float32)
+    p = M.randomize_params(cfg, p)
+    x = M.synthetic_batch(cfg, B, seed=11)[0]
+    big = Engine(B, dropout=False); big.set_params(p, bn)
+    yb = big.forward(x, train=False).clone()
+    small = Engine(8, dropout=False); small.set_params(p, bn)
+    ys = small.forward(x[:8], train=False)
+    assert torch.allclose(yb[:8], ys, rtol=0, atol=2e-6), float((yb[:8] - ys).abs().max())
+    y = yb.cpu().numpy()
+    assert np.isfinite(y).all() and np.abs(y.sum(-1) - 1).max() < 1e-5
+    out, ln = big.greedy_decode()
+    ref, rl = ctc.ctc_greedy_decode(y)
+    assert np.array_equal(out.cpu().numpy(), ref) and np.array_equal(ln.cpu().numpy(), rl)
+    bo, bl, bs = big.beam_decode(beam_width=10)
+    bo, bl, bs = bo.cpu().numpy(), bl.cpu().numpy(), bs.cpu().numpy()
+    rows = np.r_[0:12, 500:506, 1018:1024]
+    ro, rl2, rsc = ctc.ctc_beam_decode(y[rows], beam_width=10)
+    assert np.array_equal(bo[rows], ro) and np.array_equal(bl[rows], rl2)
+    assert np.all(np.isfinite(bs)) and (bl >= 0).all() and (bl <= big.T).all()
 
 
 def test_train_steps_are_deterministic_and_loss_decreases():
