@@ -31,6 +31,8 @@ struct GemmParams {
   int vecC;        // 16-byte stores legal for C (and the split scratch)
   int dtA, dtB, dtC;  // storage of the operands / result (CRNN_F32 | CRNN_BF16); the fp32 kernel requires all CRNN_F32
   int tilesN;
+  int xsplit;      // > 0: 1-D grid of tiles * xsplit workgroups, K split xsplit-fold with split s on XCD s % 8 (all tiles of one K range
+                   // share an L2): id -> xcd = id & 7, tile = (id >> 3) % tiles, split = ((id >> 3) / tiles) * 8 + xcd.  0: 2-D grid (tile, split)
   float* stats;    // optional [tilesM][2][N]: per-tile column sums / sums of squares of the result as stored (BatchNorm statistics)
   const float* cscale; const float* cshift;   // optional per-column epilogue  C = ReLU6(C * cscale[n] + cshift[n])  (inference BatchNorm folded in)
   // optional producer prologue on A (bf16 kernel, bf16 A): the operand the MFMA sees is ReLU6(A * ascale[ch] + ashift[ch])
@@ -328,6 +330,7 @@ static int gemm_f32_impl(int mode, const float* A, const float* B, float* C, int
   if (stats && (bias || act || accumulate || permP || scratch || cscale)) return CRNN_ERR_ARG;   // statistics of the plain product only
   if (cscale && (scratch || accumulate || !cshift)) return CRNN_ERR_ARG;                          // no split reduction with the folded BatchNorm
   GemmParams p;
+  p.xsplit = 0;
   p.stats = stats; p.cscale = cscale; p.cshift = cshift; p.ascale = nullptr; p.ashift = nullptr;
   p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.bias = bias; p.act = act; p.accumulate = accumulate; p.permP = permP;

@@ -652,7 +652,15 @@ int backward_bottom(const Ctx& c, const float* x, uint64_t seed) {
       if (fuse_dw_bn(cfg, dtd, dtq, ci))   // the activated tensor was never written: re-form it from d while staging (as the forward did)
         CRNN_TRY(crnn_pwconv_bnrelu6_wgrad(c.w("d" + p), c.w("bn1s" + p), gB, c.g(bp + "_pw"), M, co, ci, c.scratch(), kGemmScratchBytes, stream));
       else CRNN_TRY(gemm_t(c, 2, c.w("a" + p), dtd, gB, dtq, c.g(bp + "_pw"), CRNN_F32, ci, co, (int)M, ci, co, co));
-      CRNN_TRY(gemm_t(c, 1, gB, dtq, c.p(bp + "_pw"), CRNN_F32, gA, dtd, (int)M, ci, co, co, co, ci));
+      // data gradient da[M][ci] = dq[M][co] . W[ci][co]^T: the persistent LDS-DMA kernel where its shape rules hold
+      int rc = CRNN_ERR_UNSUPPORTED;
+      if (cfg->mfma_bf16 == 2 && dtq == CRNN_BF16 && dtd == CRNN_BF16 && !(cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS)) {
+        int dtw = CRNN_F32;
+        const float* wsh = weight_operand(c, 1, c.p(bp + "_pw"), &dtw);
+        if (dtw == CRNN_BF16) rc = crnn_gemm_nt_bf16(gB, wsh, gA, (int)M, ci, co, stream);
+      }
+      if (rc == CRNN_ERR_UNSUPPORTED) rc = gemm_t(c, 1, gB, dtq, c.p(bp + "_pw"), CRNN_F32, gA, dtd, (int)M, ci, co, co, co, ci);
+      CRNN_TRY(rc);
     }
     CRNN_TRY(crnn_bn_bwd_ex(c.w("d" + p), gA, c.w("bn1s" + p), c.p(bp + "_bn1_g"), gB, c.g(bp + "_bn1_g"), c.g(bp + "_bn1_b"), c.w("partials"),
                             c.w("coef"), B, H, W, ci, 1, 1, 0.f, 0, 0, dtd, stream));

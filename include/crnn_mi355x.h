@@ -38,6 +38,8 @@ typedef struct {
                        conv-stack activations / gradients are stored as bf16 in HBM (statistics, RNN, CTC, optimizer fp32) */
   int flags;        /* bit set of CRNN_FLAG_* (0 = the default schedule); A/B switches, every variant gives the same numbers */
 } crnn_config;
+#define CRNN_FLAG_GEMM_TILE_KERNELS 2 /* pointwise-conv data gradients on the tile-per-workgroup GEMM (crnn_gemm_bf16_ex) instead of
+                                         the persistent LDS-DMA kernel (crnn_gemm_nt_bf16); same products, same k order */
 #define CRNN_FLAG_RNN_STEP_KERNELS 1  /* LSTM recurrences as one launch per timestep (crnn_lstm_*_ex) instead of the
                                          persistent one-launch-per-layer kernels (crnn_lstm_*_persist); bit-identical */
 
@@ -258,6 +260,13 @@ int crnn_lstm_fwd_ex(const float* xw0, const float* xw1, const void* ut0, const 
 int crnn_lstm_bwd_ex(const void* u0, const void* u1, const float* c0, const float* c1, const float* g0, const float* g1,
                      const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1, float* dc0, float* dc1, int T,
                      int B, int u, int dt_u, crnn_stream_t stream);
+/* Persistent LDS-DMA GEMM for the pointwise-convolution products (utils.py:49): Y[M][N] = X[M][K] . W[N][K]^T, all three bf16
+ * (row strides K, K, N), fp32 accumulate on v_mfma_f32_32x32x16_bf16.  One persistent workgroup per CU: two loader waves stream
+ * 64-k chunks of pixel rows (4-slot LDS ring) and weight rows (2 slots) with global_load_lds, four MFMA waves consume them and
+ * store 16 bytes per lane straight from the accumulators (weights as the MFMA A operand, v_permlane32_swap).  Requires
+ * K % 64 == 0, N % 128 == 0, 16-byte aligned pointers; else -3 (use crnn_gemm_bf16_ex). */
+int crnn_gemm_nt_bf16(const void* X, const void* W, void* Y, int M, int N, int K, crnn_stream_t stream);
+
 /* Persistent recurrences: ONE launch per Bidirectional(LSTM) layer (utils.py:77-82) instead of T dependent step launches.
  * A cluster of u/16 workgroups runs the chain of one 16- or 32-row batch tile of one direction; each workgroup keeps its
  * 256x64 slice of the recurrent weights in registers (MFMA B fragments) and the cell state / cell-gradient carry in

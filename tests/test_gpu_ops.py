@@ -695,6 +695,29 @@ def test_pwconv_fwd_with_statistics_epilogue(case):
     # statistics are refused together with bias / accumulate-style epilogues? (plain product only) -> covered by the ABI contract
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 128, 64), (1000, 256, 128), (129, 512, 256), (4097, 256, 512), (128 * 300 + 5, 128, 256), (77, 384, 192)])
+def test_persistent_nt_gemm_equals_the_tile_kernel(M, N, K):
+    """crnn_gemm_nt_bf16 (persistent workgroups, LDS-DMA ring, loader + MFMA waves, swapped MFMA operands, direct 16-byte
+    stores) against crnn_gemm_bf16_ex mode 1 on bf16 operands: same MFMA, same k order -> the very same bf16 result; and
+    against an fp64 product of the rounded operands.  Ragged M (last stripe partly empty), one and several channel passes,
+    more stripes than CUs (persistent loop), N / K that are multiples of 128 / 64 but not powers of two."""
+    rs = np.random.RandomState(M + N + K)
+    X = _bf16_round(rs.normal(size=(M, K))); W = _bf16_round(rs.normal(size=(N, K)) * 0.2)
+    Xd, Wd = _to_bf16_dev(X), _to_bf16_dev(W)
+    Y = torch.full((M + 3, N), 7.0, dtype=torch.bfloat16, device="cuda")      # rows past M must stay untouched
+    ok(L().crnn_gemm_nt_bf16(P(Xd), P(Wd), P(Y), M, N, K, S()))
+    Y2 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    ok(L().crnn_gemm_bf16_ex(1, P(Xd), P(Wd), P(Y2), M, N, K, K, K, N, None, 0, 0, 0, None, 0, 1, 1, 1, S()))
+    got, ref_dev = Y[:M].float().cpu().numpy(), Y2.float().cpu().numpy()
+    assert np.array_equal(got, ref_dev), "differs from the tile kernel: max %g" % np.abs(got - ref_dev).max()
+    assert np.all(Y[M:].float().cpu().numpy() == 7.0)
+    ref = X @ W.T
+    assert_close(got, ref, rtol=1e-2, atol=1e-2 * np.abs(ref).max(), what="nt gemm vs fp64")     # bf16 output rounding
+    # shapes outside the kernel's rules are refused (the caller falls back to crnn_gemm_bf16_ex)
+    assert L().crnn_gemm_nt_bf16(P(Xd), P(Wd), P(Y), M, 64, K, S()) == -3
+    assert L().crnn_gemm_nt_bf16(P(Xd), P(Wd), P(Y), M, N, K - 32 if K > 64 else 96, S()) == -3
+
+
 def test_bilstm_bf16_recurrent_weights_track_the_fp64_cell():
     """crnn_lstm_fwd_ex / crnn_lstm_bwd_ex with dt_u = bf16: recurrent products on the bf16 MFMA (weights stored bf16, the
     state rounded to bf16 as it is packed).  Against the fp64 cell evaluated with the SAME bf16-rounded weights the only
