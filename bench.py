@@ -53,12 +53,13 @@ def depthwise_roofline(eng, iters=15):
             launches.append((eng.ws_tensor("gB"), k, eng.ws_tensor("gA"), None, h, w, cin, 1))                    # data gradient
             nbytes += 2 * (2.0 * B * h * w * cin * esz)
         h, w, cin = h // ph, w // pw, co
+    fn = lib.crnn_dwconv3x3_fwd_ex
     times = []
     for it in range(iters + 1):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for x, k, o, pt, hh, ww, cc, flip in launches:
-            lib.crnn_dwconv3x3_fwd_ex(_ptr(x), _ptr(k), _ptr(o), _ptr(pt), B, hh, ww, cc, flip, dtype, _stream())
+            fn(_ptr(x), _ptr(k), _ptr(o), _ptr(pt), B, hh, ww, cc, flip, dtype, _stream())
         e1.record()
         torch.cuda.synchronize()
         if it:

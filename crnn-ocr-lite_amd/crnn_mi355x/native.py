@@ -24,6 +24,7 @@ class crnn_config(ctypes.Structure):
 
 FLAG_RNN_STEP_KERNELS = 1      # CRNN_FLAG_RNN_STEP_KERNELS
 FLAG_GEMM_TILE_KERNELS = 2     # CRNN_FLAG_GEMM_TILE_KERNELS
+FLAG_NO_DW_BN_FUSION = 8       # CRNN_FLAG_NO_DW_BN_FUSION
 
 
 _CTYPE = [("crnn_stream_t", ctypes.c_void_p), ("size_t", ctypes.c_size_t), ("uint64_t", ctypes.c_uint64),

@@ -26,6 +26,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Tuning knobs of the micro-benchmark / ablation builds (scripts/, -DCRNN_EXPERIMENT_HOOKS): an environment variable overrides
+// a default.  The product library is built WITHOUT the macro: the knob is the constant, nothing reads the environment and
+// there is no static state (include/crnn_mi355x.h: "no global mutable state").
+#ifdef CRNN_EXPERIMENT_HOOKS
+#include <stdlib.h>
+static inline int crnn_knob(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+static inline int crnn_knob(const char*, int dflt) { return dflt; }
+#endif
+
 __device__ __forceinline__ float relu6f(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
 __device__ __forceinline__ float hard_sigmoid(float z) { return fminf(fmaxf(0.2f * z + 0.5f, 0.f), 1.f); }
 __device__ __forceinline__ float hs_grad_from_out(float a) { return (a > 0.f && a < 1.f) ? 0.2f : 0.f; }

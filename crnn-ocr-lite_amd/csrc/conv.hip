@@ -351,16 +351,13 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_c1_kernel(const float* __res
 // then balanced over the bands of H.
 struct DwTile { int TH, TW, nHb, nWb; size_t lds; };
 static DwTile dw_pick_tile(int H, int W) {
-  static int th_env = -1, tw_env = -1;   // experiment hooks: CRNN_DW_TH / CRNN_DW_TW override the tile
-  if (th_env < 0) { const char* e = getenv("CRNN_DW_TH"); th_env = e ? atoi(e) : 0; }
-  if (tw_env < 0) { const char* e = getenv("CRNN_DW_TW"); tw_env = e ? atoi(e) : 0; }
+  const int th_env = crnn_knob("CRNN_DW_TH", 0), tw_env = crnn_knob("CRNN_DW_TW", 0);   // tile overrides (experiment builds only)
   DwTile t;
   t.nWb = cdiv(W, 64);
   t.TW = cdiv(W, t.nWb);
   if (tw_env > 0) t.TW = tw_env;
   t.nWb = cdiv(W, t.TW);
-  static int lds_env = -1;               // CRNN_DW_LDS: halo-tile budget in bytes (default 48 KiB)
-  if (lds_env < 0) { const char* e = getenv("CRNN_DW_LDS"); lds_env = e ? atoi(e) : 49152; }
+  const int lds_env = crnn_knob("CRNN_DW_LDS", 49152);                                   // halo-tile budget in bytes
   int thmax = (int)((size_t)lds_env / ((size_t)(t.TW + 2) * 128)) - 2;
   if (thmax < 1) thmax = 1;
   if (thmax > H) thmax = H;

@@ -345,8 +345,7 @@ static int gemm_f32_impl(int mode, const float* A, const float* B, float* C, int
   p.tilesN = tilesN;
   int tiles = tilesM * tilesN;
   int nsplit = 1;
-  static int split_target = -1;   // CRNN_SPLIT_WGS: workgroups a split reduction aims for
-  if (split_target < 0) { const char* e = getenv("CRNN_SPLIT_WGS"); split_target = e ? atoi(e) : 768; }   // 3 resident workgroups per CU
+  const int split_target = crnn_knob("CRNN_SPLIT_WGS", 768);   // workgroups a split reduction aims for: 3 resident per CU
   if (scratch && ((tiles < 256 && K >= 2048) || (tiles <= 16 && K >= 512))) {
     nsplit = cdiv(split_target, tiles);
     int maxs = K / (K >= 2048 ? 512 : 128); if (maxs < 1) maxs = 1;

@@ -174,8 +174,7 @@ extern "C" int crnn_gemm_nt_bf16(const void* X, const void* W, void* Y, int M, i
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
   const int grid = p.stripes < cus ? p.stripes : cus;
-  const char* v = getenv("CRNN_NT_VARIANT");     // experiment hook (bench scripts only)
-  const int variant = v ? atoi(v) : 0;
+  const int variant = crnn_knob("CRNN_NT_VARIANT", 0);   // 1: 128 channels per pass + 4 slots, 2: 128 + 3 slots (experiment builds)
   if (N % 256 == 0 && variant != 1) {
     p.nt = N / 256;
     hipLaunchKernelGGL((gemm_nt_kernel<256, 3>), dim3(grid), dim3(384), 0, stream, p);

@@ -222,11 +222,9 @@ int gemm_t(const Ctx& c, int mode, const float* A, int dtA, const float* B, int 
 }
 // Training with bf16 conv-stack tensors: the BatchNorm + ReLU6 between a block's depthwise and pointwise convolutions is
 // applied by the pointwise GEMMs themselves (forward and weight gradient) while they stage the operand; the activated
-// tensor `a` is not written (one read + one write pass per block less).  CRNN_FUSE_DW_BN=0 keeps the two-pass path.
+// tensor `a` is not written (one read + one write pass per block less).  CRNN_FLAG_NO_DW_BN_FUSION keeps the two-pass path.
 bool fuse_dw_bn(const crnn_config* cfg, int dtd, int dtq, int ci) {
-  const char* e = getenv("CRNN_FUSE_DW_BN");   // (read per call: the parity test flips it between two steps)
-  const int env = e ? atoi(e) : 1;
-  return env && cfg->mfma_bf16 == 2 && dtd == CRNN_BF16 && dtq == CRNN_BF16 && ci % 8 == 0 && ci <= 512;
+  return !(cfg->flags & CRNN_FLAG_NO_DW_BN_FUSION) && cfg->mfma_bf16 == 2 && dtd == CRNN_BF16 && dtq == CRNN_BF16 && ci % 8 == 0 && ci <= 512;
 }
 // always-fp32 GEMM (spatial-transformer localisation net: tiny, and theta is precision-sensitive)
 int gemm32(const Ctx& c, int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,

@@ -9,7 +9,8 @@
  * (-2 bad argument, -3 unsupported configuration).  No C++ exception crosses the ABI.  All tensor arguments
  * are caller-owned DEVICE pointers (fp32 unless noted), NHWC / row-major contiguous unless a leading
  * dimension is given.  Every launch is asynchronous on `stream`; nothing allocates or synchronises.
- * One host thread per GPU process; no global mutable state.
+ * One host thread per GPU process; no global mutable state: the library keeps no statics and reads no environment variable (schedule
+ * A/B switches are crnn_config.flags).
  */
 #ifndef CRNN_MI355X_H
 #define CRNN_MI355X_H
@@ -38,6 +39,8 @@ typedef struct {
                        conv-stack activations / gradients are stored as bf16 in HBM (statistics, RNN, CTC, optimizer fp32) */
   int flags;        /* bit set of CRNN_FLAG_* (0 = the default schedule); A/B switches, every variant gives the same numbers */
 } crnn_config;
+#define CRNN_FLAG_NO_DW_BN_FUSION 8   /* bf16-storage training: materialise a = ReLU6(BN(d)) in a pass of its own instead of applying it while the
+                                         pointwise GEMMs stage their operand; bit-identical */
 #define CRNN_FLAG_GEMM_TILE_KERNELS 2 /* pointwise-conv data gradients on the tile-per-workgroup GEMM (crnn_gemm_bf16_ex) instead of
                                          the persistent LDS-DMA kernel (crnn_gemm_nt_bf16); same products, same k order */
 #define CRNN_FLAG_RNN_STEP_KERNELS 1  /* LSTM recurrences as one launch per timestep (crnn_lstm_*_ex) instead of the

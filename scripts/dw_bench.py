@@ -16,8 +16,9 @@ for (h, w, c) in [(104, 36, 64), (104, 36, 128), (52, 18, 256), (52, 18, 256), (
     x = torch.randn(B, h, w, c, device="cuda").to(DT); k = torch.randn(9, c, device="cuda"); o = torch.empty_like(x)
     nt = L.crnn_dwconv_num_tiles(B, h, w)
     parts = torch.empty(nt * 9 * c, device="cuda"); dk = torch.empty(9, c, device="cuda")
-    for name, fn in (("fwd+stats", lambda: L.crnn_dwconv3x3_fwd_ex(P(x), P(k), P(o), P(parts), B, h, w, c, 0, int(BF), S())),
-                     ("dgrad", lambda: L.crnn_dwconv3x3_fwd_ex(P(x), P(k), P(o), None, B, h, w, c, 1, int(BF), S())),
+    FW = L.crnn_dwconv3x3_fwd_ex
+    for name, fn in (("fwd+stats", lambda: FW(P(x), P(k), P(o), P(parts), B, h, w, c, 0, int(BF), S())),
+                     ("dgrad", lambda: FW(P(x), P(k), P(o), None, B, h, w, c, 1, int(BF), S())),
                      ("wgrad", lambda: L.crnn_dwconv3x3_wgrad_ex(P(x), P(o), P(dk), P(parts), B, h, w, c, int(BF), S()))):
         for _ in range(2): fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -247,26 +247,30 @@ def test_step_does_not_depend_on_workspace_contents(precision, shape):
 
 
 @pytest.mark.parametrize("shape", [(5, 60, 48, 20, 10, 64, 128), (4, 100, 32, 38, 23, 128, 256)])
-def test_bf16s_producer_fused_pointwise_convs_equal_the_two_pass_path(shape, monkeypatch):
+def test_bf16s_producer_fused_pointwise_convs_equal_the_two_pass_path(shape):
     """bf16s training applies the depthwise BatchNorm + ReLU6 inside the pointwise GEMMs (forward and weight gradient);
-    CRNN_FUSE_DW_BN=0 materialises the activated tensor instead.  Same operands, same order of operations: posteriors,
-    losses and every gradient are bit-identical."""
+    crnn_config.flags bit CRNN_FLAG_NO_DW_BN_FUSION materialises the activated tensor instead.  Same operands, same order of
+    operations: posteriors, losses and every gradient are bit-identical.  The same holds for the other schedule switches: LSTM
+    recurrences as per-step launches (CRNN_FLAG_RNN_STEP_KERNELS) and the pointwise data gradients on the tile GEMM
+    (CRNN_FLAG_GEMM_TILE_KERNELS)."""
+    from crnn_mi355x import native
     B, imgh, imgw, ncls, max_len, tds, u = shape
     cfg = M.Config(imgh=imgh, imgw=imgw, max_len=max_len, time_dense_size=tds, n_units=u, num_classes=ncls)
     p, bn = M.init_params(cfg, seed=6, dtype=np.float64)
     p = M.randomize_params(cfg, p)
     x, lab, il, ll = M.synthetic_batch(cfg, B, seed=4, dtype=np.float64)
-    eng = Engine(B, imgh, imgw, ncls, max_len, tds, u, stn=True, dropout=True, precision="bf16s")
-    eng.set_params(p, bn)
     out = {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("CRNN_FUSE_DW_BN", flag)
+    for flags in (0, native.FLAG_NO_DW_BN_FUSION, native.FLAG_RNN_STEP_KERNELS | native.FLAG_GEMM_TILE_KERNELS):
+        eng = Engine(B, imgh, imgw, ncls, max_len, tds, u, stn=True, dropout=True, precision="bf16s", flags=flags)
+        eng.set_params(p, bn)
         eng.ws.fill_(float("nan")); eng.grads.zero_()
         y = eng.forward(x.astype(np.float32), train=True, seed=5).clone()
         loss = eng.backward(lab, il, ll, seed=5).clone()
-        out[flag] = (y, loss, eng.grads.clone())
-    for a, b in zip(out["0"], out["1"]):
-        assert torch.isfinite(a).all() and torch.equal(a, b)
+        out[flags] = (y, loss, eng.grads.clone())
+        del eng
+    for flags in list(out)[1:]:
+        for a, b in zip(out[0], out[flags]):
+            assert torch.isfinite(a).all() and torch.equal(a, b), flags
 
 
 def test_small_model_stn_disabled():
