@@ -394,9 +394,13 @@ def main():
                 e64 = Engine(64, imgh=args.imgh, max_len=args.max_len, dropout=True, precision=args.precision, gru=args.gru)
                 e64.set_params(initial_parameters(e64.layout, e64.cfg.units, args.gru, seed=1))
                 k64 = max(5, args.steps)
-                dt64, l64 = timed_steps(e64, mk(64, 0), Adam(lr=1e-4, beta_1=0.5, beta_2=0.999, clipnorm=5), k64, 3)
+                b64, o64 = mk(64, 0), Adam(lr=1e-4, beta_1=0.5, beta_2=0.999, clipnorm=5)
+                # three repetitions, the fastest reported (this short run right after the big engines has been seen at twice its
+                # stand-alone time in one repetition out of several; scripts/dbg_bs64.py: 3.73 ms/step stand-alone, six repetitions alike)
+                reps = [timed_steps(e64, b64, o64, k64, 3 if r == 0 else 0, it0=r * (k64 + 3))[0] for r in range(3)]
+                dt64 = min(reps)
                 res["bs64"] = {"batch": 64, "value": round(64 * k64 / dt64, 1), "unit": "images/sec", "ms_per_step": round(1e3 * dt64 / k64, 3),
-                               "dtype": res["dtype"], "steps": k64}
+                               "dtype": res["dtype"], "steps": k64, "ms_per_step_repetitions": [round(1e3 * t / k64, 3) for t in reps]}
                 del e64
                 torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:

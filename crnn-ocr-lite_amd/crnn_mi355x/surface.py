@@ -324,11 +324,11 @@ class Model:
         hdf5.write(path, root)
 
     def to_json(self):
+        """Keras-2.2.2 functional-model JSON (keras_json.model_json); a model built from a Keras model.json hands that JSON back."""
         if self._keras_json is not None:
             return json.dumps(self._keras_json)
-        return json.dumps({"class_name": "Model", "backend": "crnn_mi355x", "keras_version": "2.2.2-compatible surface",
-                           "config": {"crnn": {k: (list(v) if isinstance(v, tuple) else v) for k, v in self.config.items()},
-                                      "predictor": self.predictor}})
+        from .keras_json import model_json
+        return json.dumps(model_json(self.config, predictor=self.predictor))
 
     def count_params(self):
         trainable = sum(int(np.prod(d)) for _, _, d in self._state["layout"].values())

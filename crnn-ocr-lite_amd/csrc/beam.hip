@@ -14,7 +14,7 @@
 // found with one wave ballot; every decision inside it is wave-uniform.
 #include "common.h"
 
-#define BEAM_MAX 16
+#define BEAM_MAX 64          // one beam entry per lane
 #define BEAM_EPS 1e-7f
 #define BNEG (-INFINITY)
 

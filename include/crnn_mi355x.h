@@ -124,7 +124,7 @@ int crnn_convert_f32_to_bf16(const float* x, void* y, long n, crnn_stream_t stre
 /* y [B,T,C] softmax; out [B,T] int32 padded with -1; out_len [B]; input_len may be NULL (= T) */
 int crnn_ctc_greedy_decode(const float* y, const int* input_len, int* out, int* out_len, int B, int T, int C,
                            crnn_stream_t stream);
-/* tf.nn.ctc_beam_search_decoder(beam_width <= 16, top_paths=1, merge_repeated); scores [B] = log-score of the
+/* tf.nn.ctc_beam_search_decoder(beam_width <= 64, top_paths=1, merge_repeated); scores [B] = log-score of the
  * best beam (sum of max-shifted log-probs, as TF r1.8 accumulates it).  State lives in LDS: no workspace. */
 int crnn_ctc_beam_decode(const float* y, const int* input_len, int* out, int* out_len, float* scores, int B, int T,
                          int C, int beam_width, int merge_repeated, crnn_stream_t stream);

@@ -48,7 +48,9 @@ def test_train_then_predict_cli_roundtrip(tmp_path, capsys):
     res = tmp_path / "res"; os.makedirs(res)
     # max_len must match the trained model (the reference reads it from the CLI too, predict.py:65)
     import json
-    max_len = json.load(open(mdir / "model.json"))["config"]["crnn"]["max_string_len"]
+    mj = json.load(open(mdir / "model.json"))       # a Keras-2.2.2 functional-model JSON (crnn_mi355x.keras_json)
+    assert mj["class_name"] == "Model" and mj["keras_version"] == "2.2.2" and mj["config"]["output_layers"] == [["ctc", 0, 0]]
+    max_len = [l for l in mj["config"]["layers"] if l["name"] == "the_labels"][0]["config"]["batch_input_shape"][1]
     predict_cli.main(["--model_path", str(mdir), "--image_path", str(data), "--result_path", str(res), "--validate", "--train_portion", "0.5",
                       "--batch_size", "8", "--max_len", str(max_len), "--G", "0"])
     text = capsys.readouterr().out

@@ -266,9 +266,39 @@ def test_reference_keras_model_json_artefacts_load_as_the_same_architecture():
     bad["config"]["layers"] = [l for l in bad["config"]["layers"] if l["class_name"] != "DepthwiseConv2D"][:-1]
     with pytest.raises(ValueError):
         U.model_from_json(json.dumps(bad))
-    # this package's own to_json still round-trips
+    # this package's own to_json round-trips ...
     own = U.CRNN(num_classes=38, shape=(100, 32, 1), GRU=False, max_string_len=23).get_model()
     assert U.model_from_json(own.to_json()).config == own.config
+    # ... and IS the Keras-2.2.2 functional-model JSON of the same graph: reduced to the keys make_golden.py kept from the
+    # reference's models/*/model.json it equals those artefacts layer by layer (names, order, hyper-parameters), and it carries the
+    # structural keys Keras' model_from_json needs (inbound_nodes of every layer, input_layers, output_layers)
+    keep = ("batch_input_shape", "units", "filters", "kernel_size", "pool_size", "padding", "rate", "merge_mode", "activation",
+            "axis", "momentum", "epsilon", "output_size", "depth_multiplier", "use_bias", "max_value")
+    for name, art in arts.items():
+        ref_layers = art["model_json"]["config"]["layers"]
+        max_len = [l for l in ref_layers if l["name"] == "the_labels"][0]["config"]["batch_input_shape"][1]
+        mine = json.loads(U.CRNN(num_classes=38, shape=(100, 32, 1), GRU=True, max_string_len=max_len).get_model().to_json())
+        assert (mine["class_name"], mine["keras_version"], mine["backend"]) == ("Model", "2.2.2", "tensorflow")
+        red = []
+        for l in mine["config"]["layers"]:
+            cfg = {k: l["config"][k] for k in keep if k in l["config"]}
+            if l["class_name"] == "Bidirectional":
+                inner = l["config"]["layer"]
+                cfg["layer"] = {"class_name": inner["class_name"], "config": {k: inner["config"][k] for k in
+                                ("units", "activation", "recurrent_activation", "return_sequences", "implementation", "reset_after") if k in inner["config"]}}
+            red.append({"class_name": l["class_name"], "name": l["name"], "config": cfg})
+        assert red == ref_layers, name
+        names = {l["name"] for l in mine["config"]["layers"]}
+        for l in mine["config"]["layers"]:
+            assert l["config"]["name"] == l["name"]
+            for node in l["inbound_nodes"]:
+                assert all(src[0] in names for src in node)
+            assert (l["class_name"] == "InputLayer") == (l["inbound_nodes"] == [])
+        assert mine["config"]["input_layers"] == [[n, 0, 0] for n in ("the_input", "the_labels", "input_length", "label_length")]
+        assert mine["config"]["output_layers"] == [["ctc", 0, 0]]
+    pred = json.loads(U.init_predictor(own).to_json())
+    assert pred["config"]["output_layers"] == [["softmax", 0, 0]] and not any(l["class_name"] == "Lambda" for l in pred["config"]["layers"])
+    assert U.model_from_json(json.dumps(pred)).predictor
 
 
 # ------------------------------------------------------------------------------------------------ parallel loader
