@@ -71,7 +71,8 @@ def depthwise_roofline(eng, iters=15):
     # and committed under profiles/; FETCH_SIZE x2 per the gfx950 note in MI355X_MICROARCH.md)
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_dwconv.json")))
+        pmc_file = [f for f in ("r02_pmc_dwconv.json", "r01_pmc_dwconv.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+        pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
         if B == pmc["batch"] and (eng.cfg.imgh, eng.cfg.imgw) == (100, 32):
             sh = pmc["modes"]["bf16" if esz == 2 else "fp32"]["shapes"]
             traffic = 2 * sh["104x36x64"]["hbm_bytes_per_launch"] + 2 * sh["104x36x128"]["hbm_bytes_per_launch"] \

@@ -856,8 +856,8 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgsT<T> a, float* __r
             s.v[e] += ga.v[e]; q.v[e] = fmaf(ga.v[e], ha, q.v[e]);
             s.v[e] += gb.v[e]; q.v[e] = fmaf(gb.v[e], hb, q.v[e]);
           } else {
-            oa.v[e] = sc.v[e] * (ga.v[e] - c1.v[e] - ha * c2.v[e]);
-            ob.v[e] = sc.v[e] * (gb.v[e] - c1.v[e] - hb * c2.v[e]);
+            oa.v[e] = bn_bwd_dx_elem(sc.v[e], ga.v[e], c1.v[e], ha, c2.v[e]);
+            ob.v[e] = bn_bwd_dx_elem(sc.v[e], gb.v[e], c1.v[e], hb, c2.v[e]);
           }
         }
         if (PASS == 2) { vstore<VEC>(&dx[r * a.C + c0], oa); vstore<VEC>(&dx[(r + RT) * a.C + c0], ob); }
@@ -870,7 +870,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgsT<T> a, float* __r
         for (int e = 0; e < VEC; ++e) {
           float xh = (xv.v[e] - mu.v[e]) * inv.v[e];
           if (PASS == 1) { s.v[e] += gy.v[e]; q.v[e] = fmaf(gy.v[e], xh, q.v[e]); }
-          else o.v[e] = sc.v[e] * (gy.v[e] - c1.v[e] - xh * c2.v[e]);
+          else o.v[e] = bn_bwd_dx_elem(sc.v[e], gy.v[e], c1.v[e], xh, c2.v[e]);
         }
         if (PASS == 2) vstore<VEC>(&dx[r * a.C + c0], o);
       }
@@ -1053,6 +1053,7 @@ static int bn_bwd_launch(const BnBwdArgsT<T>& a, T* dx, float* dgamma, float* db
   CRNN_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(a.C, RED_CH)), dim3(RED_CH, RED_PL), 0, stream, parts, chunks, a.C, 1.0 / (double)M, dgamma, dbeta, coef);
   CRNN_LAUNCH_CHECK();
+  if (dx == nullptr) return CRNN_OK;   // statistics only: dgamma, dbeta and coef = [mean(gy) | mean(gy * xhat)]; the caller applies pass 2 itself
   if (window) hipLaunchKernelGGL((bn_bwd_pool_kernel<2, VEC, T>), dim3(chunks), dim3(256), 0, stream, a, (float*)nullptr, coef, dx, CW, rpc);
   else hipLaunchKernelGGL((bn_bwd_kernel<2, VEC, POOL, T>), dim3(chunks), dim3(256), 0, stream, a, (float*)nullptr, coef, dx, CW, rpc);
   CRNN_LAUNCH_CHECK();
@@ -1065,7 +1066,7 @@ static int bn_bwd_typed(const T* x, const T* g, const float* bnstate, const floa
                         uint32_t layer, hipStream_t stream) {
   BnBwdArgsT<T> a{x, g, bnstate, gamma, B, H, W, C, ph, pw, rate, seed, layer};
   const bool pool = (ph * pw) > 1;
-  const bool al = ((((uintptr_t)x | (uintptr_t)g | (uintptr_t)dx | (uintptr_t)bnstate | (uintptr_t)coef) & 15) == 0);
+  const bool al = ((((uintptr_t)x | (uintptr_t)g | (uintptr_t)dx | (uintptr_t)bnstate | (uintptr_t)coef) & 15) == 0);   // (dx may be null: statistics only)
   const bool vec = (C % 4 == 0) && al;
   if (VecMax<T>::value == 8 && al && C % 8 == 0)
     return pool ? bn_bwd_launch<VecMax<T>::value, true, T>(a, dx, dgamma, dbeta, scratch_partials, coef, stream)

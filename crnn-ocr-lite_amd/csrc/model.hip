@@ -132,6 +132,7 @@ Plan make_plan(const crnn_config* c) {
     maxact = lmax(maxact, M * co);
     long tiles = crnn_dwconv_num_tiles(d.B, d.bh[i], d.bw[i]);
     maxparts = lmax(maxparts, tiles * 9L * ci);
+    maxparts = lmax(maxparts, (long)crnn_dwconv_bwd_fused_rows(d.B, d.bh[i], d.bw[i], ci) * 9L * ci);
     maxparts = lmax(maxparts, (long)crnn_colreduce_chunks(M) * 2L * lmax(ci, co));
     maxparts = lmax(maxparts, (long)crnn_pwconv_stat_rows(M) * 2L * co);
     maxparts = lmax(maxparts, (long)crnn_bn_bwd_chunks(M) * 2L * lmax(ci, co));
@@ -660,9 +661,19 @@ int backward_bottom(const Ctx& c, const float* x, uint64_t seed) {
       if (rc == CRNN_ERR_UNSUPPORTED) rc = gemm_t(c, 1, gB, dtq, c.p(bp + "_pw"), CRNN_F32, gA, dtd, (int)M, ci, co, co, co, ci);
       CRNN_TRY(rc);
     }
+    const float* xin = (i == 1) ? c.w("x0") : c.w("x" + std::to_string(i - 1));
+    if (i > 1 && dtd == CRNN_BF16 && c.dt("x" + std::to_string(i - 1)) == CRNN_BF16 && !(cfg->flags & CRNN_FLAG_NO_DW_BWD_FUSION) &&
+        crnn_dwconv_bwd_fused_supported(H, W, ci) == CRNN_OK) {
+      // depthwise stage in one kernel: BatchNorm statistics pass, then BN-backward pass 2 + depthwise weight and data gradients together
+      CRNN_TRY(crnn_bn_bwd_ex(c.w("d" + p), gA, c.w("bn1s" + p), c.p(bp + "_bn1_g"), nullptr, c.g(bp + "_bn1_g"), c.g(bp + "_bn1_b"), c.w("partials"),
+                              c.w("coef"), B, H, W, ci, 1, 1, 0.f, 0, 0, dtd, stream));
+      CRNN_TRY(crnn_dwconv3x3_bwd_fused(c.w("d" + p), gA, c.w("bn1s" + p), c.w("coef"), xin, c.p(bp + "_dw"), gB, c.g(bp + "_dw"), c.w("partials"),
+                                        B, H, W, ci, stream));
+      float* t = gA; gA = gB; gB = t;               // the block below finds its incoming gradient in gA
+      continue;
+    }
     CRNN_TRY(crnn_bn_bwd_ex(c.w("d" + p), gA, c.w("bn1s" + p), c.p(bp + "_bn1_g"), gB, c.g(bp + "_bn1_g"), c.g(bp + "_bn1_b"), c.w("partials"),
                             c.w("coef"), B, H, W, ci, 1, 1, 0.f, 0, 0, dtd, stream));
-    const float* xin = (i == 1) ? c.w("x0") : c.w("x" + std::to_string(i - 1));
     CRNN_TRY(crnn_dwconv3x3_wgrad_ex(xin, gB, c.g(bp + "_dw"), c.w("partials"), B, H, W, ci, dtd, stream));
     if (i > 1 || cfg->stn) CRNN_TRY(crnn_dwconv3x3_fwd_ex(gB, c.p(bp + "_dw"), gA, nullptr, B, H, W, ci, 1, dtd, stream));
   }

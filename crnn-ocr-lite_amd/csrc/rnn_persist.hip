@@ -22,8 +22,8 @@
 // (s+2) % 4 after publishing step s, and drains its stores (s_waitcnt vmcnt(0)) before it publishes step s+1: whoever
 // later sees its step s+1 data -- a precondition for polling slot (s+2) % 4 -- can no longer see the stale step s-2 there.
 // Results do not depend on workgroup placement or dispatch order; a cluster's workgroups have consecutive
-// block ids and the whole grid is sized to be co-resident (<= 1024 workgroups of 256 threads).  Every spin is
-// bounded: on give-up a status word is set and the chain free-runs (wrong numbers, no hang).
+// block ids and the whole grid is sized to be co-resident.  Every spin is bounded: on give-up bit 0 of the status word
+// xbuf[0] (all ones after a clean launch) is cleared and the chain free-runs (wrong numbers, no hang).
 //
 // Numerics: bit-identical to the per-step kernels of rnn.hip in both modes -- the K split into four quarters, the
 // k order inside a quarter, the ((q0+q1)+(q2+q3)) + x combination and the cell epilogue are the same; in the bf16
@@ -80,7 +80,7 @@ __device__ __forceinline__ void gather_tile(const void* tile, int tid, unsigned*
       }
       if (__all(ok) || dead) break;
       if (++spins > kSpinLimit) {
-        if ((tid & 63) == 0) atomicOr(status, 1u);
+        if ((tid & 63) == 0) atomicAnd(status, ~1u);     // the status word starts as all ones (one fill covers it and the ring)
         dead = true;
         break;
       }
@@ -457,13 +457,11 @@ extern "C" int crnn_lstm_persist_supported(int u, int dt_u) {
 }
 
 namespace {
-int prep_xbuf(void* xbuf, size_t xbuf_bytes, size_t need_data, bool zero_status, hipStream_t stream) {
+int prep_xbuf(void* xbuf, size_t xbuf_bytes, size_t need_data, bool reset_status, hipStream_t stream) {
   if (!xbuf || xbuf_bytes < kStatusBytes + need_data || ((uintptr_t)xbuf & 15)) return CRNN_ERR_ARG;
-  if (zero_status) {
-    hipError_t e = hipMemsetAsync(xbuf, 0, kStatusBytes, stream);
-    if (e != hipSuccess) return (int)e;
-  }
-  hipError_t e = hipMemsetAsync((unsigned char*)xbuf + kStatusBytes, 0xFF, need_data, stream);
+  // one fill: the status words (all ones = no wait gave up) and the sentinel ring behind them
+  unsigned char* p = (unsigned char*)xbuf + (reset_status ? 0 : kStatusBytes);
+  hipError_t e = hipMemsetAsync(p, 0xFF, need_data + (reset_status ? kStatusBytes : 0), stream);
   return e == hipSuccess ? CRNN_OK : (int)e;
 }
 
@@ -523,8 +521,8 @@ int with_fallback(int B, int u, int mt_req, int uw_req, Try attempt) {
 }  // namespace
 
 // Forward recurrence of one Bidirectional(LSTM) layer in ONE launch.  Arguments as crnn_lstm_fwd_ex; `xbuf` is
-// caller-owned scratch of crnn_lstm_persist_xbuf_bytes() bytes (16-byte aligned); xbuf[0] (unsigned) is non-zero
-// after the launch if a bounded wait gave up (results invalid).  mt: batch rows per workgroup / 16 (1 | 2), uw: 16-unit
+// caller-owned scratch of crnn_lstm_persist_xbuf_bytes() bytes (16-byte aligned); the unsigned xbuf[0] is 0xFFFFFFFF
+// after a clean launch, anything else means a bounded wait gave up (results invalid).  mt: batch rows per workgroup / 16 (1 | 2), uw: 16-unit
 // groups per workgroup (1 | 2 | 4); 0 = automatic.
 extern "C" int crnn_lstm_fwd_persist(const float* xw0, const float* xw1, const void* ut0, const void* ut1, float* h0, float* h1,
                                      int ldh, float* c0, float* c1, float* g0, float* g1, int T, int B, int u, int dt_u,

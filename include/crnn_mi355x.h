@@ -39,6 +39,8 @@ typedef struct {
                        conv-stack activations / gradients are stored as bf16 in HBM (statistics, RNN, CTC, optimizer fp32) */
   int flags;        /* bit set of CRNN_FLAG_* (0 = the default schedule); A/B switches, every variant gives the same numbers */
 } crnn_config;
+#define CRNN_FLAG_NO_DW_BWD_FUSION 16 /* bf16-storage training: depthwise-stage backward as three kernels (BatchNorm backward pass 2, depthwise weight
+                                         gradient, depthwise data gradient) instead of crnn_dwconv3x3_bwd_fused; same data gradients bit for bit */
 #define CRNN_FLAG_NO_DW_BN_FUSION 8   /* bf16-storage training: materialise a = ReLU6(BN(d)) in a pass of its own instead of applying it while the
                                          pointwise GEMMs stage their operand; bit-identical */
 #define CRNN_FLAG_GEMM_TILE_KERNELS 2 /* pointwise-conv data gradients on the tile-per-workgroup GEMM (crnn_gemm_bf16_ex) instead of
@@ -193,6 +195,16 @@ int crnn_bn_bwd_ex(const void* x, const void* g, const float* bnstate, const flo
                    uint32_t layer, int dtype, crnn_stream_t stream);
 /* DepthwiseConv2D 3x3 'same' (utils.py:44): k [9][C]; flip=1 = data gradient; stat_partials [tiles][2][C] */
 int crnn_dwconv_num_tiles(int B, int H, int W);
+/* Backward of one depthwise stage (DepthwiseConv2D(3x3) -> BatchNormalization -> ReLU(6.), utils.py:44-46) in one kernel, bf16 storage:
+ * from d (depthwise output), da = dL/d ReLU6(BN(d)), the BatchNorm state and the coefficients coef = [mean(gy) | mean(gy*xhat)] that
+ * crnn_bn_bwd_ex(..., dx = NULL, ...) leaves (first pass + finalize only), it forms the BatchNorm-input gradient in its halo-tile fill
+ * (never written to HBM) and produces dx = dL/d(depthwise input) and dk [9][C] = dL/d(depthwise kernel): 4 tensor passes instead of
+ * the 7 of crnn_bn_bwd_ex pass 2 + crnn_dwconv3x3_wgrad_ex + crnn_dwconv3x3_fwd_ex(flip).  dx is bit-identical to that sequence.
+ * scratch: crnn_dwconv_bwd_fused_rows(B, H, W, C) * 9 * C floats.  Supported: C % 64 == 0, any W (column tiles of <= 24 pixels) (else -3). */
+int crnn_dwconv_bwd_fused_supported(int H, int W, int C);
+int crnn_dwconv_bwd_fused_rows(int B, int H, int W, int C);
+int crnn_dwconv3x3_bwd_fused(const void* d, const void* da, const float* bnstate, const float* coef, const void* xin, const float* k, void* dx,
+                             float* dk, float* scratch, int B, int H, int W, int C, crnn_stream_t stream);
 int crnn_dwconv3x3_fwd(const float* x, const float* k, float* out, float* stat_partials, int B, int H, int W, int C,
                        int flip, crnn_stream_t stream);
 int crnn_dwconv3x3_wgrad(const float* x, const float* g, float* dk, float* scratch, int B, int H, int W, int C,
@@ -276,7 +288,8 @@ int crnn_gemm_nt_bf16(const void* X, const void* W, void* Y, int M, int N, int K
  * registers for all T steps; per step the cluster all-gathers h_t (forward) / dz_t (backward) through `xbuf` with
  * write-through stores and L1-bypassing polled loads (the data is its own ready flag) and stages it through LDS as the next
  * step's MFMA A operand.  Bit-identical to crnn_lstm_*_ex.  `xbuf`: caller-owned scratch of crnn_lstm_persist_xbuf_bytes()
- * bytes, 16-byte aligned; after the launch the unsigned at xbuf[0] is non-zero if a bounded wait gave up (results invalid).
+ * bytes, 16-byte aligned; after the launch the unsigned at xbuf[0] is 0xFFFFFFFF, anything else means a bounded wait gave up
+ * (results invalid).
  * mt = batch rows per workgroup / 16 (1 | 2), uw = 16-unit groups per workgroup (1 | 2 | 4: 256 / 512 / 1024 threads, the
  * cluster has u/(16 uw) members); 0 = automatic.  crnn_lstm_persist_supported: 0 if (u, dt_u) has a kernel
  * (fp32: u in {64,128,256}; bf16: u in {128,256,512}), else -3 -- use the step kernels then. */

@@ -80,7 +80,7 @@ def main():
                 row[name + "_us"] = round(t * 1e6, 1)
                 row[name + "_us_per_step"] = round(t * 1e6 / T, 2)
                 row[name + "_mfma_frac"] = round(flops / t / peak, 4)
-            row["status"] = int(xbuf[0].item())
+            row["status"] = int(int(xbuf[0].item()) != -1)
             mode["%s%s" % (kind, "_mt%d_uw%d" % (mt, uw) if kind == "persist" else "")] = row
         res["bf16" if bf16 else "fp32"] = mode
     print(json.dumps(res))

@@ -13,7 +13,7 @@ t0 = int(seg[0]["Start_Timestamp"]); prev = t0
 busy = 0; agg = {}
 for r in seg:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
+    name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void ", "")
     name = re.sub(r"unsigned short", "bf16", name)
     grid = "%sx%sx%s" % (int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]) // int(r["Workgroup_Size_Y"]), int(r["Grid_Size_Z"]) // int(r["Workgroup_Size_Z"]))
     if "--agg" not in sys.argv:
