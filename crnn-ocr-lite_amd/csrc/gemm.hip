@@ -40,6 +40,7 @@ struct GemmParams {
   // and a pointwise convolution, applied while the tile is staged instead of in a pass of its own
   const float* ascale; const float* ashift;
 #ifdef CRNN_GEMM_EXP
+  unsigned long long* trace;   // ablation build only: s_memrealtime stamps of workgroup 300, thread 0
   int exp;         // ablation build only (scripts/gemm_ablate.py): 1 no C stores, 2 no MFMA, 4 B loaded once, 8 A loaded once
 #endif
 };

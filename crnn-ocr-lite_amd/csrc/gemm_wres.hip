@@ -1,0 +1,282 @@
+// Weights-resident bf16 GEMM for the pointwise (1x1) convolutions (utils.py:49, Conv2D(1x1)):
+//     Y[M][N] = X[M][K] . W[N][K]^T        X = pixels x channels (bf16, NHWC rows), W bf16 [N][K], Y bf16, fp32 accumulate
+// M is 10^5..10^6 pixels, N and K are 64..512 channels: the weight matrix is at most 512 KB, a CU's register file is
+// 512 KB.  The ring kernel (gemm_nt.hip) re-streams the weight rows of its pass through LDS for every 128-pixel stripe -- 2x
+// to 4x the pixel bytes -- and that L2 -> LDS traffic, not HBM and not the MFMAs, is what it runs at.  Here the weights never
+// move again after the prologue:
+//   * a workgroup owns a SLICE of 128 output channels; each of its four MFMA waves keeps 32 channels x K of W as
+//     v_mfma_f32_32x32x16_bf16 A-operand fragments in registers for the whole launch (K/4 VGPRs: 128 at K = 512);
+//   * the only stream is the pixels: one persistent workgroup per CU walks over 128-pixel stripes, two LOADER waves feed
+//     an LDS ring of R = 6 stages (128 pixels x 64 k = 16 KiB each) with global_load_lds (16 B per lane, no VGPR staging) under
+//     counted s_waitcnt vmcnt(N); up to 4 stages = 64 KiB per CU are in flight (16 MB over the chip against the ~8 MB that
+//     8 TB/s x 1 us of latency need);
+//   * the N/128 slices of one stripe run at the same time on CUs of the SAME XCD (workgroup id -> xcd = id % 8), so the
+//     stripe is read from HBM once and from that XCD's L2 by the other slices;
+//   * pixels are the MFMA B operand (D = W X^T): a lane holds 4 consecutive output channels of one pixel per register
+//     group, v_permlane32_swap pairs groups into 8 channels;
+//   * the MFMA waves do not store to global memory: issuing the 8 result stores of a stripe costs a wave ~0.8 us (the
+//     texture-address path takes ~100 cycles per 1-KiB piece next to the loaders' traffic), as much as three stages of
+//     MFMAs.  They put the bf16 stripe (128 pixels x 128 channels, 32 KiB, XOR-swizzled 16-byte chunks) into one of two LDS
+//     staging tiles with eight ds_write_b128 and go on; two STORER waves drain the tile to global memory in pieces spread
+//     over the stages of the next stripe, as fully coalesced 256-byte rows;
+//   * one raw s_barrier per stage; the loaders guarantee stage i + 1 (not just i) at barrier i, so a compute wave reads the
+//     first fragments of the next stage before it reaches the next barrier and the MFMA pipe does not drain at stage edges.
+// LDS rows are 128 B unpadded, 16-byte chunk c of row r at position c ^ ((r >> 1) & 7) (applied to the per-lane global
+// address; the LDS image stays lane-linear): conflict-free ds_read_b128 fragment reads.
+// Numerics: the same MFMA and the same k order (64-k chunks ascending, 16-k steps ascending) as gemm_nt.hip / gemm_bf16.inc --
+// results are bit-identical.
+#include "common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct WresParams {
+  const bf16_t* X; const bf16_t* W; bf16_t* Y;
+  int M, N, K;
+  int stripes;   // ceil(M / 128)
+  int S;         // channel slices of 128 (N / 128)
+  int Q;         // stripes processed concurrently per XCD (workgroups per XCD / S)
+  int nxcd;      // XCDs the grid spans (grid = nxcd * Q * S)
+#ifdef CRNN_WRES_EXP
+  unsigned long long* trace;   // ablation build only: [64 iterations][4] s_memrealtime stamps of workgroup 0's first loader wave
+  int exp;       // unused (the ablation mask is the compile-time value of CRNN_WRES_EXP: 1 no pixel loads, 2 no fragment reads, 8 no MFMAs, 4 no stores, 32 free-running loaders only)
+#endif
+};
+#ifdef CRNN_WRES_EXP   // compile-time ablation mask: run-time tests between the MFMAs would change what is being measured
+#define WRES_EXP(p, bit) ((CRNN_WRES_EXP) & (bit))
+#else
+#define WRES_EXP(p, bit) 0
+#endif
+
+constexpr int kStage = 128 * 128;           // 128 pixel rows x 64 k x 2 B
+constexpr int kR = 6;                       // ring stages
+constexpr int kOut = 128 * 256;             // one staging tile: 128 pixels x 128 channels x 2 B
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int KCH, int NLW>   // K / 64, loader waves
+__global__ __launch_bounds__(384 + 64 * NLW) void gemm_wres_kernel(WresParams p) {
+  constexpr int kIPS = 16 / NLW;            // LDS-DMA instructions per loader wave and stage
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // kR stages, then two output staging tiles
+  unsigned char* const outs = smem + kR * kStage;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // workgroup -> (xcd, slice, stripe lane): consecutive ids go to consecutive XCDs
+  const int wg = blockIdx.x;
+#ifdef CRNN_WRES_EXP
+  const int per = gridDim.x / p.nxcd;
+  const int x = WRES_EXP(p, 16) ? wg / per : wg % p.nxcd, j = WRES_EXP(p, 16) ? wg % per : wg / p.nxcd;
+#else
+  const int x = wg % p.nxcd, j = wg / p.nxcd;
+#endif
+  const int slice = j % p.S, q = j / p.S;
+  const int step = p.Q * p.nxcd;                              // stripe stride between this workgroup's iterations
+  const int first = q * p.nxcd + x;
+  const int mine = first < p.stripes ? (p.stripes - first + step - 1) / step : 0;
+  if (mine <= 0) return;
+  const int total = mine * KCH;
+
+  if (wave >= 4 + NLW) {
+    // ------------------------------------------------------------------ storer waves: drain the staged stripes, a piece per stage
+    const int sw = wave - 4 - NLW;
+    constexpr int PP = 16 / KCH;                              // store instructions per storer wave and stage (16 per stripe)
+    const int rsub = lane >> 4, c = lane & 15;
+    auto drain = [&](int stripe_it, int t0, int t1) {        // pieces t0 .. t1-1 of the stripe of iteration stripe_it
+      const unsigned char* ob = outs + (stripe_it & 1) * kOut;
+      const int m0 = (first + stripe_it * step) * 128;
+      u32x4 v[4];
+      for (int t = t0; t < t1; t += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (t + u < t1) {
+            const int r = (sw * 16 + t + u) * 4 + rsub;
+            v[u] = *reinterpret_cast<const u32x4*>(ob + r * 256 + ((c ^ (r & 15)) * 16));
+          }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (t + u < t1) {
+            const int r = (sw * 16 + t + u) * 4 + rsub;
+            if (m0 + r < p.M && !WRES_EXP(p, 4)) *reinterpret_cast<u32x4*>(p.Y + (long)(m0 + r) * p.N + slice * 128 + c * 8) = v[u];
+          }
+      }
+    };
+    for (int jb = 0; jb <= total; ++jb) {
+      __builtin_amdgcn_s_barrier();
+      if (jb >= KCH) {
+        const int done = jb / KCH - 1, t = jb % KCH;         // the stripe that completed last; its piece for this stage
+        if (jb == total) drain(done, 0, 16);                  // the last stripe: everything at once
+        else drain(done, t * PP, (t + 1) * PP);
+      }
+    }
+    return;
+  }
+  if (wave >= 4) {
+    // ------------------------------------------------------------------ loader waves: a share of every stage each
+    const int lw = wave - 4;
+    const int rsub = lane >> 3, pos = lane & 7;
+    const long ldk = p.K;
+    auto issue = [&](int lin) {
+      const int slot = lin % kR;
+      lin = lin < total ? lin : total - 1;              // past the end: re-read the last stage into an already consumed slot
+      const int it = lin / KCH, kc = lin % KCH;
+      const int r0 = (first + it * step) * 128;
+      unsigned char* dst = smem + slot * kStage;
+#pragma unroll
+      for (int jj = 0; jj < kIPS; ++jj) {
+        const int jrow = lw * kIPS + jj;
+        int row = r0 + 8 * jrow + rsub;
+        row = row < p.M ? row : p.M - 1;
+        const int c = pos ^ ((4 * jrow + (lane >> 4)) & 7);
+        if (!WRES_EXP(p, 1)) glds16(p.X + row * ldk + kc * 64 + c * 8, dst + jrow * 1024);
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < kR - 1; ++s) issue(s);
+    for (int i = 0; i < total; ++i) {
+#ifdef CRNN_WRES_EXP
+      const bool tr = p.trace && wg == 8 && lw == 0 && lane == 0 && i < 64;
+      if (tr) p.trace[i * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+#endif
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kR - 3) * kIPS) : "memory");   // stages i and i+1 have landed
+#ifdef CRNN_WRES_EXP
+      if (tr) p.trace[i * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
+      if (!WRES_EXP(p, 32)) __builtin_amdgcn_s_barrier();
+#ifdef CRNN_WRES_EXP
+      if (tr) p.trace[i * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
+      issue(i + kR - 1);                                                        // into the slot stage i-1 has just released
+#ifdef CRNN_WRES_EXP
+      if (tr) p.trace[i * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+#endif
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  // -------------------------------------------------------------------- compute waves: 32 channels x K of W in registers
+  if (WRES_EXP(p, 32)) return;
+  const int half = lane >> 5, l31 = lane & 31, sw = (l31 >> 1) & 7;
+  const int n0 = slice * 128 + wave * 32;
+  bf16x8_t wf[KCH][4];
+  {
+    const bf16_t* wrow = p.W + (long)(n0 + l31) * p.K + half * 8;
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) wf[kc][ks] = *reinterpret_cast<const bf16x8_t*>(wrow + kc * 64 + ks * 16);
+  }
+  f32x16 acc[4];
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int lrow = l31 * 128;
+  int slot = 0;
+  bf16x8_t fx[4];                                              // fragments of k-step 0 of the stage about to be multiplied
+  __builtin_amdgcn_s_barrier();                                // barrier 0: stages 0 and 1 have landed
+  {
+    const unsigned char* A = smem + lrow + ((half ^ sw) * 16);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) fx[b] = *reinterpret_cast<const bf16x8_t*>(A + b * 32 * 128);
+  }
+  for (int it = 0; it < mine; ++it) {
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc) {
+      const unsigned char* A = smem + slot * kStage + lrow;
+      slot = slot + 1 == kR ? 0 : slot + 1;
+      const unsigned char* An = smem + slot * kStage + lrow;    // next stage (landed: the loaders run one stage ahead of the barrier)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8_t nx[4];
+        const unsigned char* src = ks < 3 ? A + (((2 * (ks + 1) + half) ^ sw) * 16) : An + ((half ^ sw) * 16);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) if (!WRES_EXP(p, 2)) nx[b] = *reinterpret_cast<const bf16x8_t*>(src + b * 32 * 128);
+        // pin the order "reads of the next k-step, then this k-step's MFMAs": left alone the scheduler shares two fragment
+        // registers between all reads and the MFMA pipe waits out an LDS round trip every second MFMA
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          if (WRES_EXP(p, 8)) continue;
+          if (kc == 0 && ks == 0) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kc][ks], fx[b], zero16, 0, 0, 0);   // C = 0: no clearing pass
+          else acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kc][ks], fx[b], acc[b], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) fx[b] = nx[b];
+      }
+      if (kc + 1 < KCH) __builtin_amdgcn_s_barrier();          // releases this stage's slot; the stage after the next has landed
+    }
+    // ---- epilogue of the stripe: lane = one pixel; register group g of a 32x32 block = channels 8g + 4half + 0..3.
+    // 16-byte chunk (4 wave + 2 pr + half) of pixel row px goes to position chunk ^ (px & 15) of the staging tile
+    unsigned char* ob = outs + (it & 1) * kOut;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int px = 32 * b + l31;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const f32x16& v = acc[b];
+        unsigned g0a = pack2_bf16(v[8 * pr + 0], v[8 * pr + 1]), g0b = pack2_bf16(v[8 * pr + 2], v[8 * pr + 3]);
+        unsigned g1a = pack2_bf16(v[8 * pr + 4], v[8 * pr + 5]), g1b = pack2_bf16(v[8 * pr + 6], v[8 * pr + 7]);
+        const u32x2 sa = __builtin_amdgcn_permlane32_swap(g0a, g1a, false, false);
+        const u32x2 sb = __builtin_amdgcn_permlane32_swap(g0b, g1b, false, false);
+        *reinterpret_cast<uint4*>(ob + px * 256 + (((4 * wave + 2 * pr + half) ^ (px & 15)) * 16)) = make_uint4(sa.x, sb.x, sa.y, sb.y);
+      }
+    }
+    __builtin_amdgcn_s_barrier();                              // the stripe's last stage: also hands the staged tile to the storers
+  }
+}
+
+template <int KCH, int NLW>
+int launch_wres(const WresParams& p, int grid, hipStream_t stream) {
+  const int lds = kR * kStage + 2 * kOut;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_wres_kernel<KCH, NLW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_wres_kernel<KCH, NLW>), dim3(grid), dim3(384 + 64 * NLW), lds, stream, p);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+
+}  // namespace
+
+// 0 if crnn_gemm_wres_bf16 handles (N, K), else -3: N a multiple of 128 up to 1024, K in {64, 128, 256, 512}
+extern "C" int crnn_gemm_wres_supported(int N, int K) {
+  return (N >= 128 && N % 128 == 0 && N <= 1024 && (K == 64 || K == 128 || K == 256 || K == 512)) ? CRNN_OK : CRNN_ERR_UNSUPPORTED;
+}
+
+// Y[M][N] (bf16) = X[M][K] (bf16, row stride K) . W[N][K]^T (bf16, row stride K), weights resident in registers.
+// One persistent workgroup per CU (512 threads: 4 MFMA waves + 2 LDS-DMA loader waves + 2 storer waves, 160 KiB of LDS).
+extern "C" int crnn_gemm_wres_bf16(const void* X, const void* W, void* Y, int M, int N, int K, hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return CRNN_ERR_ARG;
+  CRNN_TRY(crnn_gemm_wres_supported(N, K));
+  if ((((uintptr_t)X | (uintptr_t)W | (uintptr_t)Y) & 15)) return CRNN_ERR_UNSUPPORTED;
+  if ((long)M * (K > N ? K : N) >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;     // 32-bit row offsets
+  WresParams p;
+  p.X = (const bf16_t*)X; p.W = (const bf16_t*)W; p.Y = (bf16_t*)Y; p.M = M; p.N = N; p.K = K;
+  p.stripes = cdiv(M, 128); p.S = N / 128;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+  p.nxcd = 8;
+  int per_xcd = cus / 8;                                       // workgroups per XCD: one per CU
+  if (per_xcd < p.S) per_xcd = p.S;
+  p.Q = per_xcd / p.S;
+  const int need = cdiv(p.stripes, p.nxcd);                    // stripe lanes that have any work
+  if (p.Q > need) p.Q = need;
+  const int grid = p.nxcd * p.Q * p.S;
+#ifdef CRNN_WRES_EXP
+  p.exp = crnn_knob("CRNN_WRES_EXP", 0);
+  { const char* e = getenv("CRNN_WRES_TRACE"); p.trace = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
+#endif
+  switch (K / 64) {
+    case 1: return launch_wres<1, 2>(p, grid, stream);
+    case 2: return launch_wres<2, 2>(p, grid, stream);
+    case 4: return launch_wres<4, 2>(p, grid, stream);
+    default: return launch_wres<8, 2>(p, grid, stream);
+  }
+}

@@ -651,12 +651,15 @@ int backward_bottom(const Ctx& c, const float* x, uint64_t seed) {
       if (fuse_dw_bn(cfg, dtd, dtq, ci))   // the activated tensor was never written: re-form it from d while staging (as the forward did)
         CRNN_TRY(crnn_pwconv_bnrelu6_wgrad(c.w("d" + p), c.w("bn1s" + p), gB, c.g(bp + "_pw"), M, co, ci, c.scratch(), kGemmScratchBytes, stream));
       else CRNN_TRY(gemm_t(c, 2, c.w("a" + p), dtd, gB, dtq, c.g(bp + "_pw"), CRNN_F32, ci, co, (int)M, ci, co, co));
-      // data gradient da[M][ci] = dq[M][co] . W[ci][co]^T: the persistent LDS-DMA kernel where its shape rules hold
+      // data gradient da[M][ci] = dq[M][co] . W[ci][co]^T: the persistent LDS-DMA kernels where their shape rules hold
       int rc = CRNN_ERR_UNSUPPORTED;
       if (cfg->mfma_bf16 == 2 && dtq == CRNN_BF16 && dtd == CRNN_BF16 && !(cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS)) {
         int dtw = CRNN_F32;
         const float* wsh = weight_operand(c, 1, c.p(bp + "_pw"), &dtw);
-        if (dtw == CRNN_BF16) rc = crnn_gemm_nt_bf16(gB, wsh, gA, (int)M, ci, co, stream);
+        if (dtw == CRNN_BF16) {
+          rc = crnn_gemm_wres_bf16(gB, wsh, gA, (int)M, ci, co, stream);       // weights resident in registers
+          if (rc == CRNN_ERR_UNSUPPORTED) rc = crnn_gemm_nt_bf16(gB, wsh, gA, (int)M, ci, co, stream);
+        }
       }
       if (rc == CRNN_ERR_UNSUPPORTED) rc = gemm_t(c, 1, gB, dtq, c.p(bp + "_pw"), CRNN_F32, gA, dtd, (int)M, ci, co, co, co, ci);
       CRNN_TRY(rc);

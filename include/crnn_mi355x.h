@@ -281,6 +281,12 @@ int crnn_lstm_bwd_ex(const void* u0, const void* u1, const float* c0, const floa
  * store 16 bytes per lane straight from the accumulators (weights as the MFMA A operand, v_permlane32_swap).  Requires
  * K % 64 == 0, N % 128 == 0, 16-byte aligned pointers; else -3 (use crnn_gemm_bf16_ex). */
 int crnn_gemm_nt_bf16(const void* X, const void* W, void* Y, int M, int N, int K, crnn_stream_t stream);
+/* The same product with the weights RESIDENT IN REGISTERS (gemm_wres.hip): a workgroup owns 128 output channels, each of its four MFMA
+ * waves holds 32 channels x K of W as MFMA operand fragments for the whole launch, only the pixel rows stream (LDS-DMA ring of 8 x 16 KiB
+ * per CU), the N/128 channel slices of a pixel stripe run on one XCD so HBM sees the stripe once.  Bit-identical to crnn_gemm_nt_bf16.
+ * Supported (else -3): N % 128 == 0, N <= 1024, K in {64, 128, 256, 512}, 16-byte aligned pointers. */
+int crnn_gemm_wres_supported(int N, int K);
+int crnn_gemm_wres_bf16(const void* X, const void* W, void* Y, int M, int N, int K, crnn_stream_t stream);
 
 /* Persistent recurrences: ONE launch per Bidirectional(LSTM) layer (utils.py:77-82) instead of T dependent step launches.
  * A cluster of u/16 workgroups runs the chain of one 16- or 32-row batch tile of one direction; each workgroup keeps its

@@ -764,6 +764,31 @@ def test_persistent_nt_gemm_equals_the_tile_kernel(M, N, K):
     assert L().crnn_gemm_nt_bf16(P(Xd), P(Wd), P(Y), M, N, K - 32 if K > 64 else 96, S()) == -3
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 128, 64), (1000, 256, 128), (129, 512, 256), (4097, 256, 512), (128 * 300 + 5, 128, 256),
+                                   (128 * 2100 + 77, 512, 512), (70000, 384, 128), (5, 1024, 64)])
+def test_weights_resident_gemm_equals_the_tile_kernel(M, N, K):
+    """crnn_gemm_wres_bf16 (weight fragments resident in registers, pixel rows through an LDS-DMA ring of 8 stages, channel
+    slices of a stripe on one XCD, fragments of the next stage read ahead of the barrier) against crnn_gemm_bf16_ex mode 1:
+    same MFMA, same k order -> the very same bf16 result; and against an fp64 product.  Ragged M, 1..8 channel slices, K of
+    1..8 stages, fewer stripes than workgroups, more stripes than the ring is deep times the grid (long persistent loops)."""
+    rs = np.random.RandomState(M + N + K)
+    X = _bf16_round(rs.normal(size=(M, K))); W = _bf16_round(rs.normal(size=(N, K)) * 0.2)
+    Xd, Wd = _to_bf16_dev(X), _to_bf16_dev(W)
+    Y = torch.full((M + 3, N), 7.0, dtype=torch.bfloat16, device="cuda")      # rows past M must stay untouched
+    assert L().crnn_gemm_wres_supported(N, K) == 0
+    for rep in range(2):                                                      # a second launch over the same ring
+        ok(L().crnn_gemm_wres_bf16(P(Xd), P(Wd), P(Y), M, N, K, S()))
+    Y2 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    ok(L().crnn_gemm_bf16_ex(1, P(Xd), P(Wd), P(Y2), M, N, K, K, K, N, None, 0, 0, 0, None, 0, 1, 1, 1, S()))
+    assert torch.equal(Y[:M], Y2), "differs from the tile kernel: max %g" % float((Y[:M].float() - Y2.float()).abs().max())
+    assert bool((Y[M:] == 7.0).all())
+    if M <= 70000:
+        ref = X @ W.T
+        assert_close(Y[:M].float().cpu().numpy(), ref, rtol=1e-2, atol=1e-2 * np.abs(ref).max(), what="wres gemm vs fp64")
+    assert L().crnn_gemm_wres_bf16(P(Xd), P(Wd), P(Y), M, 64, K, S()) == -3 and L().crnn_gemm_wres_supported(N, 192) == -3
+    assert L().crnn_gemm_wres_supported(1152, 64) == -3
+
+
 def test_bilstm_bf16_recurrent_weights_track_the_fp64_cell():
     """crnn_lstm_fwd_ex / crnn_lstm_bwd_ex with dt_u = bf16: recurrent products on the bf16 MFMA (weights stored bf16, the
     state rounded to bf16 as it is packed).  Against the fp64 cell evaluated with the SAME bf16-rounded weights the only
