@@ -395,6 +395,7 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
     bn_off += ci;
     const bool fuse_a = fuse_dw_bn(cfg, dtd, dtq, ci);                  // BN + ReLU6 applied while the GEMM stages its operand
     if (!fuse_a) CRNN_TRY(crnn_bn_act_pool_drop_ex(dd, s1, aa, 1, 1, (int)M, ci, 1, 1, 0.f, 0, 0, dtd, dtd, stream));
+    int stat_rows = crnn_pwconv_stat_rows(M);
     {  // pointwise conv; its epilogue also produces the batch statistics of the BatchNorm that follows
       int dtw = CRNN_F32, wt = 0;
       const float* wq = weight_operand(c, 0, c.p(bp + "_pw"), &dtw);
@@ -403,10 +404,18 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
         dtw = CRNN_BF16; wt = 1;
       }
       if (ci == 1 && dtd == CRNN_F32) CRNN_TRY(crnn_pw1_fwd(aa, c.p(bp + "_pw"), qq, M, co, parts, dtq, stream));   // block 1: outer product
-      else if (fuse_a) CRNN_TRY(crnn_pwconv_bnrelu6_fwd(dd, s1, wq, qq, M, co, ci, parts, dtq, wt, stream));
-      else CRNN_TRY(crnn_pwconv_fwd(aa, wq, qq, M, co, ci, parts, nullptr, cfg->mfma_bf16 ? 1 : 0, dtd, dtw, dtq, wt, stream));
+      else if (fuse_a) {
+        // weights resident in registers, IO waves transform / drain / take the statistics (gemm_wres.hip) where its shape rules hold
+        int rc = CRNN_ERR_UNSUPPORTED;
+        if (wt && dtq == CRNN_BF16 && !(cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS) && crnn_pwconv_fwd_wres_supported(M, co, ci) == CRNN_OK) {
+          rc = crnn_pwconv_bnrelu6_fwd_wres(dd, s1, wq, qq, M, co, ci, parts, stream);
+          if (rc == CRNN_OK) stat_rows = crnn_pwconv_fwd_wres_rows(M, co);
+        }
+        if (rc == CRNN_ERR_UNSUPPORTED) rc = crnn_pwconv_bnrelu6_fwd(dd, s1, wq, qq, M, co, ci, parts, dtq, wt, stream);
+        CRNN_TRY(rc);
+      } else CRNN_TRY(crnn_pwconv_fwd(aa, wq, qq, M, co, ci, parts, nullptr, cfg->mfma_bf16 ? 1 : 0, dtd, dtw, dtq, wt, stream));
     }
-    CRNN_TRY(crnn_bn_finalize_folded(parts, crnn_pwconv_stat_rows(M), co, M, c.p(bp + "_bn2_g"), c.p(bp + "_bn2_b"), s2, c.w("fold"), stream));
+    CRNN_TRY(crnn_bn_finalize_folded(parts, stat_rows, co, M, c.p(bp + "_bn2_g"), c.p(bp + "_bn2_b"), s2, c.w("fold"), stream));
     bn_off += co;
     CRNN_TRY(crnn_bn_act_pool_drop_ex(qq, s2, xo, B, H, W, co, ph, pw, cfg->dropout ? kDropBlock : 0.f, seed,
                                       (uint32_t)i, dtq, c.dt("x" + p), stream));

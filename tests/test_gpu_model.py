@@ -250,9 +250,12 @@ def test_step_does_not_depend_on_workspace_contents(precision, shape):
 def test_bf16s_producer_fused_pointwise_convs_equal_the_two_pass_path(shape):
     """bf16s training applies the depthwise BatchNorm + ReLU6 inside the pointwise GEMMs (forward and weight gradient);
     crnn_config.flags bit CRNN_FLAG_NO_DW_BN_FUSION materialises the activated tensor instead.  Same operands, same order of
-    operations: posteriors, losses and every gradient are bit-identical.  The same holds for the other schedule switches: LSTM
-    recurrences as per-step launches (CRNN_FLAG_RNN_STEP_KERNELS) and the pointwise data gradients on the tile GEMM
-    (CRNN_FLAG_GEMM_TILE_KERNELS)."""
+    operations: posteriors, losses and every gradient are bit-identical.  The same holds for the other schedule switches on the
+    tile GEMM (CRNN_FLAG_GEMM_TILE_KERNELS): LSTM recurrences as per-step launches (CRNN_FLAG_RNN_STEP_KERNELS), the unfused
+    depthwise-stage backward (CRNN_FLAG_NO_DW_BWD_FUSION; its depthwise weight gradients group their partial sums differently).
+    The default schedule runs the pointwise convolutions on the weights-resident kernels: products and data gradients are the
+    same bits, but the BatchNorm-2 statistics are summed in another order (per IO wave over the launch instead of per 128-row
+    tile), so against the tile schedule everything agrees to the bf16 storage's rounding noise, not bit for bit -- bounds below."""
     from crnn_mi355x import native
     B, imgh, imgw, ncls, max_len, tds, u = shape
     cfg = M.Config(imgh=imgh, imgw=imgw, max_len=max_len, time_dense_size=tds, n_units=u, num_classes=ncls)
@@ -260,7 +263,8 @@ def test_bf16s_producer_fused_pointwise_convs_equal_the_two_pass_path(shape):
     p = M.randomize_params(cfg, p)
     x, lab, il, ll = M.synthetic_batch(cfg, B, seed=4, dtype=np.float64)
     out = {}
-    for flags in (0, native.FLAG_NO_DW_BN_FUSION, native.FLAG_RNN_STEP_KERNELS | native.FLAG_GEMM_TILE_KERNELS, native.FLAG_NO_DW_BWD_FUSION):
+    T = native.FLAG_GEMM_TILE_KERNELS
+    for flags in (T, T | native.FLAG_NO_DW_BN_FUSION, T | native.FLAG_RNN_STEP_KERNELS, T | native.FLAG_NO_DW_BWD_FUSION, 0):
         eng = Engine(B, imgh, imgw, ncls, max_len, tds, u, stn=True, dropout=True, precision="bf16s", flags=flags)
         eng.set_params(p, bn)
         eng.ws.fill_(float("nan")); eng.grads.zero_()
@@ -269,10 +273,11 @@ def test_bf16s_producer_fused_pointwise_convs_equal_the_two_pass_path(shape):
         out[flags] = (y, loss, eng.grads.clone())
         del eng
     lay = Engine(B, imgh, imgw, ncls, max_len, tds, u, precision="bf16s").layout
-    for flags in list(out)[1:]:
-        y0, l0, g0 = out[0]; y1, l1, g1 = out[flags]
+    y0, l0, g0 = out[T]
+    for flags in list(out)[1:-1]:
+        y1, l1, g1 = out[flags]
         assert torch.isfinite(g1).all() and torch.equal(y0, y1) and torch.equal(l0, l1), flags
-        if flags != native.FLAG_NO_DW_BWD_FUSION:
+        if flags != T | native.FLAG_NO_DW_BWD_FUSION:
             assert torch.equal(g0, g1), flags
         else:
             # the fused depthwise-stage backward groups the partial sums of the depthwise weight gradients differently: those six
@@ -284,6 +289,21 @@ def test_bf16s_producer_fused_pointwise_convs_equal_the_two_pass_path(shape):
                     a, b = g0[off:off + size], g1[off:off + size]
                     assert float((a - b).abs().max()) <= 2e-4 * float(a.abs().max()) + 1e-6, name
             assert torch.equal(g0[~dw], g1[~dw])
+    # default schedule (weights-resident pointwise kernels) against the tile schedule
+    y1, l1, g1 = out[0]
+    assert torch.isfinite(g1).all()
+    dy = float((y0 - y1).abs().max()); dl = float(((l0 - l1).abs() / l0.abs().clamp_min(1.0)).max())
+    worst = ("", 0.0)
+    for name, (off, size, _) in lay.items():
+        a, b = g0[off:off + size].double(), g1[off:off + size].double()
+        e = float((a - b).norm() / (a.norm() + 1e-30))
+        if e > worst[1]: worst = (name, e)
+    glob = float((g0.double() - g1.double()).norm() / g0.double().norm())
+    print("default vs tile schedule: max |dy| %.3g, max rel dloss %.3g, gradient rel L2 %.3g, worst tensor %s %.3g" % (dy, dl, glob, worst[0], worst[1]))
+    # measured: |dy| 5e-4, dloss 3.5e-4, whole gradient 7e-2, worst single tensor 0.14 (stn_c1_b, a cancelling bias sum at the far end
+    # of the backward chain): statistics that differ in the last fp32 bits re-round a few bf16 activations, and this random-weight
+    # 4..5-sample net amplifies that like it amplifies the bf16 storage itself (bf16s against the fp64 oracle: ~5e-2, test above)
+    assert dy < 5e-3 and dl < 2e-3 and glob < 0.2 and worst[1] < 0.5, (dy, dl, glob, worst)
 
 
 def test_small_model_stn_disabled():

@@ -789,6 +789,41 @@ def test_weights_resident_gemm_equals_the_tile_kernel(M, N, K):
     assert L().crnn_gemm_wres_supported(1152, 64) == -3
 
 
+@pytest.mark.parametrize("M,N,K", [(128 * 3, 128, 64), (128 * 40, 256, 128), (128 * 700 + 0, 128, 64), (128 * 300, 512, 256), (128 * 530, 512, 512), (128, 1024, 64)])
+def test_weights_resident_forward_pointwise_equals_the_tile_kernel(M, N, K):
+    """crnn_pwconv_bnrelu6_fwd_wres (register-resident weights, IO waves applying BatchNorm + ReLU6 on the way into the LDS ring,
+    draining the staged stripes and accumulating the BatchNorm-2 statistics) against crnn_pwconv_bnrelu6_fwd (tile kernel, W^T
+    operand): q bit for bit; the statistics = the column sums / sums of squares of the stored q (fp64 reference of the device's
+    own q, and the tile kernel's partial rows summed) to fp32 summation round-off.  1..8 channel slices, 1..8 stages, stripes fewer
+    than / many times the workgroups, workgroups without a stripe (their statistics rows must be zero)."""
+    rs = np.random.RandomState(M % 9973 + N + K)
+    d = _bf16_round(rs.normal(size=(M, K)) * 2.0); W = _bf16_round(rs.normal(size=(N, K)) * 0.2)
+    mean, var = rs.normal(size=K) * 0.3, rs.uniform(0.5, 2.0, size=K)
+    scale = rs.normal(size=K) * 0.3 + 1.0; shift = rs.normal(size=K) * 0.5 + 1.0
+    st = dev(np.concatenate([mean, var, scale, shift]))
+    dd, Wd = _to_bf16_dev(d), _to_bf16_dev(W)
+    assert L().crnn_pwconv_fwd_wres_supported(M, N, K) == 0
+    rows = L().crnn_pwconv_fwd_wres_rows(M, N)
+    q1 = torch.full((M + 2, N), 7.0, dtype=torch.bfloat16, device="cuda"); parts1 = torch.full((rows, 2, N), 3.0, device="cuda")
+    for rep in range(2):
+        ok(L().crnn_pwconv_bnrelu6_fwd_wres(P(dd), P(st), P(Wd), P(q1), M, N, K, P(parts1), S()))
+    rows2 = L().crnn_pwconv_stat_rows(M)
+    q2 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda"); parts2 = zeros(rows2, 2, N)
+    ok(L().crnn_pwconv_bnrelu6_fwd(P(dd), P(st), P(Wd), P(q2), M, N, K, P(parts2), 1, 1, S()))
+    assert torch.equal(q1[:M], q2), "q differs: max %g" % float((q1[:M].float() - q2.float()).abs().max())
+    assert bool((q1[M:] == 7.0).all())
+    got = host(parts1).sum(0); tile = host(parts2).sum(0)
+    qf = q2.float().cpu().numpy().astype(np.float64)
+    ref = np.stack([qf.sum(0), (qf * qf).sum(0)])
+    assert_close(got, ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max(), what="statistics vs fp64 sums of the stored q")
+    assert_close(got, tile, rtol=2e-5, atol=2e-5 * np.abs(ref).max(), what="statistics vs the tile kernel's")
+    # against the oracle product of the transformed operand (bf16 output rounding)
+    if M <= 128 * 40:
+        a = _bf16_round(np.clip(d * scale + shift, 0.0, 6.0))
+        assert_close(q1[:M].float().cpu().numpy(), a @ W.T, rtol=1e-2, atol=1e-2 * np.abs(a @ W.T).max(), what="q vs fp64")
+    assert L().crnn_pwconv_fwd_wres_supported(M + 64, N, K) == -3 and L().crnn_pwconv_fwd_wres_supported(M, N + 64, K) == -3
+
+
 def test_bilstm_bf16_recurrent_weights_track_the_fp64_cell():
     """crnn_lstm_fwd_ex / crnn_lstm_bwd_ex with dt_u = bf16: recurrent products on the bf16 MFMA (weights stored bf16, the
     state rounded to bf16 as it is packed).  Against the fp64 cell evaluated with the SAME bf16-rounded weights the only
