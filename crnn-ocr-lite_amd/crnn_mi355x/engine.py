@@ -81,6 +81,10 @@ class Engine:
         # side-stream schedule of the backward (crnn_backward_ex): measured 1 % SLOWER than the serial one at batch 256 (the
         # GEMMs crowd the latency-critical BPTT launches), so it is opt-in: CRNN_RNN_OVERLAP=1
         self.overlap_rnn_wgrad = os.environ.get("CRNN_RNN_OVERLAP", "0") == "1"
+        # conv stack (crnn_backward_bottom_ex): the pointwise weight-gradient GEMM of each block on the side stream next to the block's
+        # bandwidth-bound kernels -- measured neutral to 0.7 % slower at batch 256 (7.97 vs 7.91 ms: both sides already fill the CUs),
+        # so also opt-in: CRNN_CONV_OVERLAP=1; bit-identical either way
+        self.overlap_conv_wgrad = os.environ.get("CRNN_CONV_OVERLAP", "0") == "1"
         self._aux_stream = None
 
     # ---- parameters -------------------------------------------------------------------------------------
@@ -174,31 +178,29 @@ class Engine:
 
     def backward(self, labels, input_length, label_length, seed=0):
         """CTC + backward after forward(train=True).  Returns per-sample loss (device tensor, B)."""
-        self._ctc_inputs(labels, input_length, label_length)
-        check(self.lib.crnn_backward_ex(self._c, _ptr(self.params), _ptr(self.grads), _ptr(self._x), _ptr(self._lab), _ptr(self._il),
-                                        _ptr(self._ll), _ptr(self.ws), self.ws_bytes, _ptr(self.loss), int(seed), _stream(), self._aux()),
-              "backward")
+        self.backward_top(labels, input_length, label_length, seed=seed)
+        self.backward_bottom(seed=seed)
         return self.loss
 
     def backward_top(self, labels, input_length, label_length, seed=0):
         """First backward stage: CTC, dense2, recurrent layers, dense1 -> grads[grad_split:] are final."""
         self._ctc_inputs(labels, input_length, label_length)
         check(self.lib.crnn_backward_top_ex(self._c, _ptr(self.params), _ptr(self.grads), _ptr(self._lab), _ptr(self._il), _ptr(self._ll),
-                                            _ptr(self.ws), self.ws_bytes, _ptr(self.loss), int(seed), _stream(), self._aux()), "backward_top")
+                                            _ptr(self.ws), self.ws_bytes, _ptr(self.loss), int(seed), _stream(), self._aux(self.overlap_rnn_wgrad)), "backward_top")
         return self.loss
 
     def backward_bottom(self, seed=0):
         """Second backward stage: conv stack + spatial transformer -> grads[:grad_split]."""
-        check(self.lib.crnn_backward_bottom(self._c, _ptr(self.params), _ptr(self.grads), _ptr(self._x), _ptr(self.ws), self.ws_bytes,
-                                            int(seed), _stream()), "backward_bottom")
+        check(self.lib.crnn_backward_bottom_ex(self._c, _ptr(self.params), _ptr(self.grads), _ptr(self._x), _ptr(self.ws), self.ws_bytes,
+                                               int(seed), _stream(), self._aux(self.overlap_conv_wgrad)), "backward_bottom")
 
     @property
     def grad_split(self):
         return int(self.lib.crnn_grad_split_offset(self._c))
 
-    def _aux(self):
-        """Second stream for the weight-gradient GEMMs that overlap the BPTT chains (None: serial schedule)."""
-        if not self.overlap_rnn_wgrad:
+    def _aux(self, on):
+        """Second stream for the weight-gradient GEMMs that run next to the backward's critical path (None: serial schedule)."""
+        if not on:
             return None
         if self._aux_stream is None:
             self._aux_stream = torch.cuda.Stream(device=self.device)

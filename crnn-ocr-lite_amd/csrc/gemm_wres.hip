@@ -315,10 +315,12 @@ __global__ __launch_bounds__(512) void gemm_wres_fwd_kernel(WresFwdParams p) {
     for (int u = 0; u < 4; ++u) {
       const int row = 32 * w + 8 * u + r8;
       u32x4 o;
+      if (WRES_EXP(p, 64)) o = buf[u]; else {
       o.x = wres_bnrelu6_pair(buf[u].x, f32x2_t{s0.x, s0.y}, f32x2_t{t0.x, t0.y});
       o.y = wres_bnrelu6_pair(buf[u].y, f32x2_t{s0.z, s0.w}, f32x2_t{t0.z, t0.w});
       o.z = wres_bnrelu6_pair(buf[u].z, f32x2_t{s1.x, s1.y}, f32x2_t{t1.x, t1.y});
       o.w = wres_bnrelu6_pair(buf[u].w, f32x2_t{s1.z, s1.w}, f32x2_t{t1.z, t1.w});
+      }
       *reinterpret_cast<u32x4*>(dst + row * 128 + ((c ^ ((row >> 1) & 7)) * 16)) = o;
     }
   };
@@ -334,10 +336,11 @@ __global__ __launch_bounds__(512) void gemm_wres_fwd_kernel(WresFwdParams p) {
     for (int t = t0; t < t1; ++t) {
       const int r = (w * 8 + t) * 4 + r4;
       const u32x4 v = *reinterpret_cast<const u32x4*>(ob + r * 256 + ((c16 ^ (r & 15)) * 16));
-      *reinterpret_cast<u32x4*>(p.Y + (m0 + r) * p.N + slice * 128 + c16 * 8) = v;
+      if (!WRES_EXP(p, 4)) *reinterpret_cast<u32x4*>(p.Y + (m0 + r) * p.N + slice * 128 + c16 * 8) = v;
       const unsigned ww[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
+        if (WRES_EXP(p, 128)) { ssum[2 * e] = __uint_as_float(ww[e]); continue; }
         const float lo = __uint_as_float(ww[e] << 16), hi = __uint_as_float(ww[e] & 0xffff0000u);
         ssum[2 * e] += lo; ssq[2 * e] = fmaf(lo, lo, ssq[2 * e]);
         ssum[2 * e + 1] += hi; ssq[2 * e + 1] = fmaf(hi, hi, ssq[2 * e + 1]);

@@ -155,7 +155,7 @@ Plan make_plan(const crnn_config* c) {
   P.add("ddn1", TB * d.tds); P.add("gbm", TB * d.tds);
   maxact = lmax(maxact, TB * d.feat);
   // gradient ping-pong buffers: sized for fp32, hold bf16 tensors in storage mode 2
-  P.add("gA", maxact); P.add("gB", maxact);
+  P.add("gA", maxact); P.add("gB", maxact); P.add("gC", maxact);   // conv-stack gradient buffers (three: a weight-gradient GEMM on the side stream may still read one)
   P.add("dtheta", B * 6); P.add("dfc1", B * 50); P.add("dflat", B * d.stn_flat);
   P.add("dpool2", B * d.Hs2 * d.Ws2 * 20); P.add("dc1", B * d.Ho1 * d.Wo1 * 20);
   maxparts = lmax(maxparts, (long)crnn_colreduce_chunks(TB) * lmax(d.G, lmax(d.tds, d.C)));
@@ -535,7 +535,7 @@ static int rnn_bwd_dx(const Ctx& c, int layer, int din, float* dxin) {
 // conv-stack / STN stage is still running.
 namespace {
 int backward_top(const Ctx& c, const int* labels, const int* input_length, const int* label_length, float* loss, uint64_t seed, hipStream_t aux);
-int backward_bottom(const Ctx& c, const float* x, uint64_t seed);
+int backward_bottom(const Ctx& c, const float* x, uint64_t seed, hipStream_t aux);
 }
 extern "C" long crnn_grad_split_offset(const crnn_config* cfg) { return make_layout(cfg).off("dense1_w"); }
 extern "C" int crnn_backward_top_ex(const crnn_config* cfg, const float* params, float* grads, const int* labels,
@@ -556,7 +556,14 @@ extern "C" int crnn_backward_bottom(const crnn_config* cfg, const float* params,
   CRNN_TRY(check_cfg(cfg));
   Ctx c{cfg, make_dims(cfg), make_layout(cfg), make_plan(cfg), params, grads, ws, stream};
   if (ws_bytes < (size_t)c.P.total * sizeof(float)) return CRNN_ERR_ARG;
-  return backward_bottom(c, x, seed);
+  return backward_bottom(c, x, seed, nullptr);
+}
+extern "C" int crnn_backward_bottom_ex(const crnn_config* cfg, const float* params, float* grads, const float* x, float* ws,
+                                       size_t ws_bytes, uint64_t seed, hipStream_t stream, hipStream_t aux_stream) {
+  CRNN_TRY(check_cfg(cfg));
+  Ctx c{cfg, make_dims(cfg), make_layout(cfg), make_plan(cfg), params, grads, ws, stream};
+  if (ws_bytes < (size_t)c.P.total * sizeof(float)) return CRNN_ERR_ARG;
+  return backward_bottom(c, x, seed, aux_stream == stream ? nullptr : aux_stream);
 }
 extern "C" int crnn_backward(const crnn_config* cfg, const float* params, float* grads, const float* x, const int* labels,
                              const int* input_length, const int* label_length, float* ws, size_t ws_bytes, float* loss,
@@ -565,7 +572,7 @@ extern "C" int crnn_backward(const crnn_config* cfg, const float* params, float*
   Ctx c{cfg, make_dims(cfg), make_layout(cfg), make_plan(cfg), params, grads, ws, stream};
   if (ws_bytes < (size_t)c.P.total * sizeof(float)) return CRNN_ERR_ARG;
   CRNN_TRY(backward_top(c, labels, input_length, label_length, loss, seed, nullptr));
-  return backward_bottom(c, x, seed);
+  return backward_bottom(c, x, seed, nullptr);
 }
 extern "C" int crnn_backward_ex(const crnn_config* cfg, const float* params, float* grads, const float* x, const int* labels,
                                 const int* input_length, const int* label_length, float* ws, size_t ws_bytes, float* loss,
@@ -574,7 +581,7 @@ extern "C" int crnn_backward_ex(const crnn_config* cfg, const float* params, flo
   Ctx c{cfg, make_dims(cfg), make_layout(cfg), make_plan(cfg), params, grads, ws, stream};
   if (ws_bytes < (size_t)c.P.total * sizeof(float)) return CRNN_ERR_ARG;
   CRNN_TRY(backward_top(c, labels, input_length, label_length, loss, seed, aux_stream == stream ? nullptr : aux_stream));
-  return backward_bottom(c, x, seed);
+  return backward_bottom(c, x, seed, aux_stream == stream ? nullptr : aux_stream);
 }
 
 namespace {
@@ -584,13 +591,14 @@ namespace {
 // scratch and the reduction partials between the fork and the join, and every gradient tensor still has a single
 // writer in a fixed order, so the result is bit-identical to the serial schedule.
 struct ForkJoin {
-  // The three events are created once per host thread and reused by every call (recording an event again while an earlier
+  // The events are created once per host thread and reused by every call (recording an event again while an earlier
   // wait on it is still queued is well defined: the wait captured the earlier record); nothing is created or destroyed
   // on the step's path.
   hipStream_t main, aux; int n = 0; bool on;
   ForkJoin(hipStream_t m, hipStream_t a) : main(m), aux(a), on(a != nullptr) {}
   static int event(int i, hipEvent_t* out) {
-    static thread_local hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    static thread_local hipEvent_t ev[24] = {};
+    if (i >= 24) return CRNN_ERR_ARG;
     if (!ev[i]) { hipError_t r = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming); if (r != hipSuccess) return (int)r; }
     *out = ev[i];
     return CRNN_OK;
@@ -603,6 +611,16 @@ struct ForkJoin {
   }
   int fork() { return link(main, aux); }
   int join() { return link(aux, main); }
+  // split form of a join: mark the side stream's progress now, make the main stream wait for that point later
+  int mark(hipEvent_t* e) {
+    if (!on) return CRNN_OK;
+    CRNN_TRY(event(n++, e));
+    hipError_t r = hipEventRecord(*e, aux); return r == hipSuccess ? CRNN_OK : (int)r;
+  }
+  int wait(hipEvent_t e) {
+    if (!on || !e) return CRNN_OK;
+    hipError_t r = hipStreamWaitEvent(main, e, 0); return r == hipSuccess ? CRNN_OK : (int)r;
+  }
 };
 
 int backward_top(const Ctx& c, const int* labels, const int* input_length, const int* label_length, float* loss, uint64_t seed, hipStream_t aux) {
@@ -641,25 +659,40 @@ int backward_top(const Ctx& c, const int* labels, const int* input_length, const
   return CRNN_OK;
 }
 
-int backward_bottom(const Ctx& c, const float* x, uint64_t seed) {
+// aux != nullptr: the pointwise weight-gradient GEMM of every block runs on the side stream next to the rest of the block's
+// backward (data-gradient GEMM, BatchNorm statistics pass, fused depthwise stage -- HBM- and VALU-bound kernels that leave the
+// matrix cores and most of the vector-memory path idle).  The GEMM reads the BatchNorm-2 input gradient of its block, so the
+// gradient buffers rotate over three allocations and the main stream waits for GEMM i before the buffer it reads is written
+// again (by the depthwise stage of block i-1).  One writer per gradient tensor, fixed order: bit-identical to the serial schedule.
+int backward_bottom(const Ctx& c, const float* x, uint64_t seed, hipStream_t aux) {
   const crnn_config* cfg = c.cfg; hipStream_t stream = c.s;
   const Dims& d = c.d;
   const int B = d.B;
-  float* gA = c.w("gA"); float* gB = c.w("gB");   // gA holds d loss / d x7 (written by backward_top)
+  ForkJoin fj(stream, aux);
+  Ctx ca = c; if (aux) { ca.s = aux; ca.side = true; }
+  float* gA = c.w("gA"); float* gB = c.w("gB"); float* gC = c.w("gC");   // gA holds d loss / d x7 (written by backward_top)
+  hipEvent_t gB_free = nullptr, gC_free = nullptr;     // side-stream GEMMs still reading gB / gC (null: none)
   // ---- conv stack
   for (int i = 7; i >= 1; --i) {
     std::string p = std::to_string(i), bp = "b" + p;
     const int H = d.bh[i], W = d.bw[i], ci = d.bc[i - 1], co = d.bc[i];
     const long M = (long)B * H * W;
     const int dtd = c.dt("d" + p), dtq = c.dt("q" + p);   // dtq == storage of the incoming gradient (gdt)
+    const bool fused_dw = i > 1 && dtd == CRNN_BF16 && c.dt("x" + std::to_string(i - 1)) == CRNN_BF16 && !(cfg->flags & CRNN_FLAG_NO_DW_BWD_FUSION) &&
+                          crnn_dwconv_bwd_fused_supported(H, W, ci) == CRNN_OK;
+    CRNN_TRY(fj.wait(gB_free)); gB_free = nullptr;        // gB is written next
     CRNN_TRY(crnn_bn_bwd_ex(c.w("q" + p), gA, c.w("bn2s" + p), c.p(bp + "_bn2_g"), gB, c.g(bp + "_bn2_g"), c.g(bp + "_bn2_b"), c.w("partials"),
                             c.w("coef"), B, H, W, co, kBlocks[i - 1].ph, kBlocks[i - 1].pw, cfg->dropout ? kDropBlock : 0.f, seed, (uint32_t)i, dtq, stream));
     if (ci == 1 && dtd == CRNN_F32) {   // block 1: outer-product weight / data gradients
       CRNN_TRY(crnn_pw1_bwd(c.w("a" + p), c.p(bp + "_pw"), gB, gA, c.g(bp + "_pw"), c.w("partials"), M, co, dtq, stream));
     } else {
+      const bool side = fj.on && fused_dw;
+      const Ctx& cw = side ? ca : c;
+      if (side) CRNN_TRY(fj.fork());
       if (fuse_dw_bn(cfg, dtd, dtq, ci))   // the activated tensor was never written: re-form it from d while staging (as the forward did)
-        CRNN_TRY(crnn_pwconv_bnrelu6_wgrad(c.w("d" + p), c.w("bn1s" + p), gB, c.g(bp + "_pw"), M, co, ci, c.scratch(), kGemmScratchBytes, stream));
-      else CRNN_TRY(gemm_t(c, 2, c.w("a" + p), dtd, gB, dtq, c.g(bp + "_pw"), CRNN_F32, ci, co, (int)M, ci, co, co));
+        CRNN_TRY(crnn_pwconv_bnrelu6_wgrad(c.w("d" + p), c.w("bn1s" + p), gB, c.g(bp + "_pw"), M, co, ci, cw.scratch(), kGemmScratchBytes, cw.s));
+      else CRNN_TRY(gemm_t(cw, 2, c.w("a" + p), dtd, gB, dtq, c.g(bp + "_pw"), CRNN_F32, ci, co, (int)M, ci, co, co));
+      if (side) CRNN_TRY(fj.mark(&gB_free));
       // data gradient da[M][ci] = dq[M][co] . W[ci][co]^T: the persistent LDS-DMA kernels where their shape rules hold
       int rc = CRNN_ERR_UNSUPPORTED;
       if (cfg->mfma_bf16 == 2 && dtq == CRNN_BF16 && dtd == CRNN_BF16 && !(cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS)) {
@@ -674,14 +707,16 @@ int backward_bottom(const Ctx& c, const float* x, uint64_t seed) {
       CRNN_TRY(rc);
     }
     const float* xin = (i == 1) ? c.w("x0") : c.w("x" + std::to_string(i - 1));
-    if (i > 1 && dtd == CRNN_BF16 && c.dt("x" + std::to_string(i - 1)) == CRNN_BF16 && !(cfg->flags & CRNN_FLAG_NO_DW_BWD_FUSION) &&
-        crnn_dwconv_bwd_fused_supported(H, W, ci) == CRNN_OK) {
+    if (fused_dw) {
       // depthwise stage in one kernel: BatchNorm statistics pass, then BN-backward pass 2 + depthwise weight and data gradients together
       CRNN_TRY(crnn_bn_bwd_ex(c.w("d" + p), gA, c.w("bn1s" + p), c.p(bp + "_bn1_g"), nullptr, c.g(bp + "_bn1_g"), c.g(bp + "_bn1_b"), c.w("partials"),
                               c.w("coef"), B, H, W, ci, 1, 1, 0.f, 0, 0, dtd, stream));
-      CRNN_TRY(crnn_dwconv3x3_bwd_fused(c.w("d" + p), gA, c.w("bn1s" + p), c.w("coef"), xin, c.p(bp + "_dw"), gB, c.g(bp + "_dw"), c.w("partials"),
+      CRNN_TRY(fj.wait(gC_free)); gC_free = nullptr;      // gC is written next
+      CRNN_TRY(crnn_dwconv3x3_bwd_fused(c.w("d" + p), gA, c.w("bn1s" + p), c.w("coef"), xin, c.p(bp + "_dw"), gC, c.g(bp + "_dw"), c.w("partials"),
                                         B, H, W, ci, stream));
-      float* t = gA; gA = gB; gB = t;               // the block below finds its incoming gradient in gA
+      // the block below finds its incoming gradient in gA, writes gB; this block's side-stream GEMM may still read the old gB
+      float* t = gA; gA = gC; gC = gB; gB = t;
+      gC_free = gB_free; gB_free = nullptr;
       continue;
     }
     CRNN_TRY(crnn_bn_bwd_ex(c.w("d" + p), gA, c.w("bn1s" + p), c.p(bp + "_bn1_g"), gB, c.g(bp + "_bn1_g"), c.g(bp + "_bn1_b"), c.w("partials"),
@@ -689,6 +724,7 @@ int backward_bottom(const Ctx& c, const float* x, uint64_t seed) {
     CRNN_TRY(crnn_dwconv3x3_wgrad_ex(xin, gB, c.g(bp + "_dw"), c.w("partials"), B, H, W, ci, dtd, stream));
     if (i > 1 || cfg->stn) CRNN_TRY(crnn_dwconv3x3_fwd_ex(gB, c.p(bp + "_dw"), gA, nullptr, B, H, W, ci, 1, dtd, stream));
   }
+  CRNN_TRY(fj.join());                                   // every weight gradient is complete in the main stream's order
   // ---- spatial transformer
   if (cfg->stn) {
     CRNN_TRY(crnn_sampler_bwd(x, c.w("theta"), gA, c.w("dtheta"), B, d.H0, d.W0, 2, stream));

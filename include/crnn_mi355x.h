@@ -94,6 +94,11 @@ int crnn_backward_bottom(const crnn_config* cfg, const float* params, float* gra
 int crnn_backward_top_ex(const crnn_config* cfg, const float* params, float* grads, const int* labels, const int* input_length,
                          const int* label_length, float* ws, size_t ws_bytes, float* loss, uint64_t seed, crnn_stream_t stream,
                          crnn_stream_t aux_stream);
+/* crnn_backward_bottom with a side stream: the pointwise weight-gradient GEMM of every block runs there, next to the block's
+ * data-gradient GEMM, BatchNorm statistics pass and fused depthwise stage on `stream` (the gradient buffers rotate over three
+ * allocations; the main stream waits for a GEMM before the buffer it reads is rewritten).  Bit-identical to the serial schedule. */
+int crnn_backward_bottom_ex(const crnn_config* cfg, const float* params, float* grads, const float* x, float* ws, size_t ws_bytes,
+                            uint64_t seed, crnn_stream_t stream, crnn_stream_t aux_stream);
 int crnn_backward_ex(const crnn_config* cfg, const float* params, float* grads, const float* x, const int* labels,
                      const int* input_length, const int* label_length, float* ws, size_t ws_bytes, float* loss, uint64_t seed,
                      crnn_stream_t stream, crnn_stream_t aux_stream);

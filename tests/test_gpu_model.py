@@ -596,8 +596,10 @@ def test_c_train_step_driver_equals_the_staged_python_step():
 
 
 def test_side_stream_weight_gradients_equal_the_serial_schedule():
-    """crnn_backward_ex with a second stream (weight-gradient GEMMs of dense2 / the upper recurrent layer overlapping the BPTT
-    chains) must be bit-identical to the serial schedule, LSTM and GRU, fp32 and bf16s."""
+    """The backward with a second stream (weight-gradient GEMMs of dense2 / the upper recurrent layer overlapping the BPTT chains,
+    crnn_backward_top_ex; the pointwise weight-gradient GEMM of every conv block next to the block's other kernels, gradient
+    buffers rotating over three allocations, crnn_backward_bottom_ex) must be bit-identical to the serial schedule, LSTM and GRU,
+    fp32 and bf16s, repeated (the rotation and the event reuse must hold from step to step)."""
     for gru in (False, True):
         cfg = M.Config(gru=gru)
         B = 8
@@ -609,7 +611,7 @@ def test_side_stream_weight_gradients_equal_the_serial_schedule():
             eng.set_params(p, bn)
             res = {}
             for overlap in (False, True):
-                eng.overlap_rnn_wgrad = overlap
+                eng.overlap_rnn_wgrad = overlap; eng.overlap_conv_wgrad = overlap
                 eng.grads.fill_(float("nan"))
                 eng.forward(x, train=True, seed=2)
                 loss = eng.backward(lab, il, ll, seed=2).clone()
@@ -618,3 +620,9 @@ def test_side_stream_weight_gradients_equal_the_serial_schedule():
             assert torch.equal(res[False][0], res[True][0])
             assert torch.equal(res[False][1], res[True][1]), (gru, precision)
             assert torch.isfinite(res[True][1]).all()
+            for rep in range(3):                                # again, back to back
+                eng.grads.fill_(float("nan"))
+                eng.forward(x, train=True, seed=2)
+                eng.backward(lab, il, ll, seed=2)
+            torch.cuda.synchronize()
+            assert torch.equal(res[False][1], eng.grads), (gru, precision, "repeat")
