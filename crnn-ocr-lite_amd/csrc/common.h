@@ -39,13 +39,19 @@ static inline int crnn_knob(const char*, int dflt) { return dflt; }
 __device__ __forceinline__ float relu6f(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
 __device__ __forceinline__ float hard_sigmoid(float z) { return fminf(fmaxf(0.2f * z + 0.5f, 0.f), 1.f); }
 __device__ __forceinline__ float hs_grad_from_out(float a) { return (a > 0.f && a < 1.f) ? 0.2f : 0.f; }
-// BatchNorm backward, second pass, one element: dx = scale * (gy - c1 - xhat * c2) with c1 = mean(gy), c2 = mean(gy * xhat).
-// One spelling (explicit fma, no compiler contraction) shared by the stand-alone pass (conv.hip) and the kernels that apply it
-// while they load their operand (conv_bwd_fused.hip), so both produce the same bits.
-__device__ __forceinline__ float bn_bwd_dx_elem(float sc, float gy, float c1, float xh, float c2) {
+// BatchNorm backward, second pass, one element: dx = scale * (gy - c1 - xhat * c2) with c1 = mean(gy), c2 = mean(gy * xhat),
+// xhat = (x - mean) * inv, evaluated as two fused multiply-adds on per-channel constants:
+//     dx = fma(x, P, fma(gy, scale, Q)),   P = -scale * c2 * inv,   Q = scale * c2 * inv * mean - scale * c1.
+// One spelling (explicit fma, no compiler contraction) shared by the stand-alone pass (conv.hip) and the kernel that applies it
+// while it fills its tiles (conv_bwd_fused.hip), so both produce the same bits; 2 instead of 5 VALU operations per element is what
+// the fused kernel (VALU-bound) cares about.
+__device__ __forceinline__ void bn_bwd_pq(float sc, float c1, float c2, float mu, float inv, float& P, float& Q) {
 #pragma clang fp contract(off)
-  return sc * fmaf(-xh, c2, gy - c1);
+  const float k = sc * c2 * inv;
+  P = -k;
+  Q = fmaf(k, mu, -(sc * c1));
 }
+__device__ __forceinline__ float bn_bwd_dx_pq(float x, float gy, float sc, float P, float Q) { return fmaf(x, P, fmaf(gy, sc, Q)); }
 
 // Counter-based dropout RNG: murmur3-style 64-bit finaliser of (step seed, dropout site, group), one hash
 // per group of 4 consecutive elements; element idx takes 16-bit lane (idx & 3) of the hash of group idx >> 2

@@ -841,7 +841,14 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgsT<T> a, float* __r
       VecF<VEC> inv, c1, c2;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) { inv.v[e] = 1.0f / sqrtf(var.v[e] + BN_EPS); c1.v[e] = 0.f; c2.v[e] = 0.f; }
-      if (PASS == 2) { c1 = vload<VEC>(coef + c0); c2 = vload<VEC>(coef + a.C + c0); }
+      VecF<VEC> Pc, Qc;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { Pc.v[e] = 0.f; Qc.v[e] = 0.f; }
+      if (PASS == 2) {
+        c1 = vload<VEC>(coef + c0); c2 = vload<VEC>(coef + a.C + c0);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) bn_bwd_pq(sc.v[e], c1.v[e], c2.v[e], mu.v[e], inv.v[e], Pc.v[e], Qc.v[e]);
+      }
       long r = r0 + rt;
       for (; r + RT < r1; r += 2L * RT) {   // two rows in flight (independent loads)
         VecF<VEC> xa = vload<VEC>(&a.x[r * a.C + c0]);
@@ -856,8 +863,8 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgsT<T> a, float* __r
             s.v[e] += ga.v[e]; q.v[e] = fmaf(ga.v[e], ha, q.v[e]);
             s.v[e] += gb.v[e]; q.v[e] = fmaf(gb.v[e], hb, q.v[e]);
           } else {
-            oa.v[e] = bn_bwd_dx_elem(sc.v[e], ga.v[e], c1.v[e], ha, c2.v[e]);
-            ob.v[e] = bn_bwd_dx_elem(sc.v[e], gb.v[e], c1.v[e], hb, c2.v[e]);
+            oa.v[e] = bn_bwd_dx_pq(xa.v[e], ga.v[e], sc.v[e], Pc.v[e], Qc.v[e]);
+            ob.v[e] = bn_bwd_dx_pq(xb.v[e], gb.v[e], sc.v[e], Pc.v[e], Qc.v[e]);
           }
         }
         if (PASS == 2) { vstore<VEC>(&dx[r * a.C + c0], oa); vstore<VEC>(&dx[(r + RT) * a.C + c0], ob); }
@@ -870,7 +877,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgsT<T> a, float* __r
         for (int e = 0; e < VEC; ++e) {
           float xh = (xv.v[e] - mu.v[e]) * inv.v[e];
           if (PASS == 1) { s.v[e] += gy.v[e]; q.v[e] = fmaf(gy.v[e], xh, q.v[e]); }
-          else o.v[e] = bn_bwd_dx_elem(sc.v[e], gy.v[e], c1.v[e], xh, c2.v[e]);
+          else o.v[e] = bn_bwd_dx_pq(xv.v[e], gy.v[e], sc.v[e], Pc.v[e], Qc.v[e]);
         }
         if (PASS == 2) vstore<VEC>(&dx[r * a.C + c0], o);
       }

@@ -71,12 +71,12 @@ __device__ __forceinline__ void fill_load(const FillGeom& g, int base, const bf1
 __device__ __forceinline__ void fill_store(const FillGeom& g, int base, const float* cst,
                                            const u32x4 (&vd)[kNCH], const u32x4 (&vg)[kNCH], const u32x4 (&vx)[kNCH], unsigned inside,
                                            u32x4* tileD16, u32x4* tileX16) {
-  float mu[8], inv[8], sc[8], sh[8], c1[8], c2[8];
+  float sc[8], sh[8], Pc[8], Qc[8];
   {
     const float* cf = cst + 9 * 64 + 8 * (threadIdx.x & (kFL - 1));
-    float* const dst[6] = {mu, inv, sc, sh, c1, c2};
+    float* const dst[4] = {sc, sh, Pc, Qc};
 #pragma unroll
-    for (int a = 0; a < 6; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int hq = 0; hq < 2; ++hq) {
         const float4 v = *reinterpret_cast<const float4*>(cf + a * 64 + 4 * hq);
@@ -101,10 +101,9 @@ __device__ __forceinline__ void fill_store(const FillGeom& g, int base, const fl
         widen8(vd[uu], xv); widen8(vg[uu], gv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float yv = relu6f(fmaf(xv[e], sc[e], sh[e]));
-          const float gy = (yv > 0.f && yv < 6.f) ? gv[e] : 0.f;
-          const float xh = (xv[e] - mu[e]) * inv[e];
-          r[e] = bn_bwd_dx_elem(sc[e], gy, c1[e], xh, c2[e]);
+          const float tv = fmaf(xv[e], sc[e], sh[e]);                   // ReLU6 passes the gradient where 0 < BN(d) < 6 (the clamp itself is not needed)
+          const float gy = (tv > 0.f && tv < 6.f) ? gv[e] : 0.f;
+          r[e] = bn_bwd_dx_pq(xv[e], gy, sc[e], Pc[e], Qc[e]);
         }
         o = u32x4{pack2_bf16(r[0], r[1]), pack2_bf16(r[2], r[3]), pack2_bf16(r[4], r[5]), pack2_bf16(r[6], r[7])};
       }
@@ -147,15 +146,19 @@ __global__ __launch_bounds__(kNT, FUSED_WPE) void dw_bwd_fused_kernel(const bf16
   const int hstart = grp * Hg, hend = min(H, hstart + Hg);
 
   // per-slab constants in LDS (read per band: no global loads whose wait would also drain the prefetch; nothing hoisted
-  // into long-lived registers): the mirrored taps [9][64], then mean | 1/sqrt(var+eps) | scale | shift | c1 | c2 [6][64]
+  // into long-lived registers): the mirrored taps [9][64], then scale | shift | P | Q [4][64] (common.h: bn_bwd_pq)
   float* cst = reinterpret_cast<float*>(smem + 2 * tile_bytes);
-  for (int i = tid; i < 15 * 64; i += kNT) {
+  for (int i = tid; i < 13 * 64; i += kNT) {
     const int a = i >> 6, ch = cc0 + (i & 63);
     float v;
     if (a < 9) v = k[(8 - a) * C + ch];
-    else if (a == 10) v = 1.0f / sqrtf(bnstate[C + ch] + BN_EPS_F);
-    else if (a < 13) v = bnstate[(a == 9 ? 0 : a - 9) * C + ch];
-    else v = coef[(a - 13) * C + ch];
+    else if (a == 9) v = bnstate[2 * C + ch];
+    else if (a == 10) v = bnstate[3 * C + ch];
+    else {
+      float P, Q;
+      bn_bwd_pq(bnstate[2 * C + ch], coef[ch], coef[C + ch], bnstate[ch], 1.0f / sqrtf(bnstate[C + ch] + BN_EPS_F), P, Q);
+      v = a == 11 ? P : Q;
+    }
     cst[i] = v;
   }
   float dk[9][kVN];
@@ -326,7 +329,7 @@ FusedGeom fused_geom(int B, int H, int W, int C) {
   g.Hg = cdiv(H, G);
   g.G = cdiv(H, g.Hg);
   g.rows = B * g.G * g.nCol;
-  g.lds = (size_t)((g.TH + 2) * row_bytes) + 15 * 64 * sizeof(float);
+  g.lds = (size_t)((g.TH + 2) * row_bytes) + 13 * 64 * sizeof(float);
   const size_t red = 4 * 9 * kCL * kVN * sizeof(float);
   if (g.lds < red) g.lds = red;
   return g;
