@@ -105,14 +105,18 @@ def pointwise_gemm_roofline(eng, iters=5):
         M = B * h * w
         if co > 64:
             if bf:
-                cfgs.append((eng.ws_tensor("a%d" % i), pwT[toff:], eng.ws_tensor("q%d" % i), M, co, cin, sdt, sdt, 1))
+                # bf16s: the step's own forward entry (BatchNorm + ReLU6 of the depthwise output applied on the way in, statistics of q
+                # taken on the way out; weights-resident kernel where its shape rules hold, else the tile GEMM) on d, not on `a`
+                fused = eng.precision == "bf16s" and not (eng.cfg.flags & 8)
+                cfgs.append((eng.ws_tensor(("d%d" if fused else "a%d") % i), pwT[toff:], eng.ws_tensor("q%d" % i), M, co, cin, sdt, sdt,
+                             ("pw", eng.ws_tensor("bn1s%d" % i)) if fused else 1))
                 toff += cin * co
             else:
                 cfgs.append((eng.ws_tensor("a%d" % i), W("b%d_pw" % i), eng.ws_tensor("q%d" % i), M, co, cin, sdt, sdt, 0))
         h, w, cin = h // ph, w // pw, co
     feat = w * cin
     TB = T * B
-    scratch = eng.ws_tensor("gemm_scratch")
+    scratch = eng.ws_tensor("gemm_scratch"); parts = eng.ws_tensor("partials")
     cfgs.append((eng.ws_tensor("x7"), W("dense1_w"), eng.ws_tensor("gA"), TB, eng.cfg.tds, feat, sdt, 0, 0))
     u, G = eng.cfg.units, (3 if eng.cfg.gru else 4) * eng.cfg.units
     for n, src, k in (("rnn1f_w", "dn1", eng.cfg.tds), ("rnn1b_w", "dn1", eng.cfg.tds), ("rnn2f_w", "r1", u), ("rnn2b_w", "r1", u)):
@@ -125,7 +129,12 @@ def pointwise_gemm_roofline(eng, iters=5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for A, Bm, C, M, N, K, dta, dtc, wt in cfgs:
-            if bf:
+            if isinstance(wt, tuple):
+                if not (eng.cfg.flags & 2) and lib.crnn_pwconv_fwd_wres_supported(M, N, K) == 0:
+                    lib.crnn_pwconv_bnrelu6_fwd_wres(_ptr(A), _ptr(wt[1]), _ptr(Bm), _ptr(C), M, N, K, _ptr(parts), _stream())
+                else:
+                    lib.crnn_pwconv_bnrelu6_fwd(_ptr(A), _ptr(wt[1]), _ptr(Bm), _ptr(C), M, N, K, _ptr(parts), 1, 1, _stream())
+            elif bf:
                 lib.crnn_gemm_bf16_ex(1 if wt else 0, _ptr(A), _ptr(Bm), _ptr(C), M, N, K, K, K if wt else N, N, None, 0, 0, 0, _ptr(scratch),
                                       64 * 1024 * 1024, dta, 1, dtc, _stream())
             else:
@@ -136,7 +145,10 @@ def pointwise_gemm_roofline(eng, iters=5):
             times.append(e0.elapsed_time(e1) * 1e-3)
     t = float(np.median(times))
     ach = flops / t / 1e12
-    return {"bound": "mfma", "kernel": "gemm_%s_kernel<128,false,true> (pointwise 1x1 convs fwd + dense1 + RNN input GEMMs)" % ("bf16" if bf else "f32"),
+    kname = ("gemm_wres_fwd_kernel (pointwise 1x1 convs fwd incl. BN+ReLU6 prologue and statistics) + gemm_bf16_kernel (dense1, RNN input GEMMs)"
+             if any(isinstance(c[8], tuple) for c in cfgs) else
+             "gemm_%s_kernel<128,false,true> (pointwise 1x1 convs fwd + dense1 + RNN input GEMMs)" % ("bf16" if bf else "f32"))
+    return {"bound": "mfma", "kernel": kname,
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "launches": len(cfgs), "avg_launch_ms": round(1e3 * t / len(cfgs), 4), "flops_per_launch_set": flops,
             # with bf16 tensors every one of these GEMMs sits below the 312 FLOP/B ridge: the binding roof is HBM
