@@ -28,7 +28,7 @@ for f in sorted(glob.glob("$OUT/pmcany_${TAG}_*/*counter_collection.csv")):
         if d not in seen: seen.add(d)
     for k, _ in seen: calls[k] = max(calls[k], sum(1 for kk, _ in seen if kk == k))
 for k, c in sorted(agg.items(), key=lambda x: -x[1].get("SQ_BUSY_CYCLES", x[1].get("GRBM_GUI_ACTIVE", 0))):
-    if "gemm" not in k and "dwconv" not in k and "bn_" not in k and "lstm" not in k: continue
+    if "gemm" not in k and "dwconv" not in k and "bn_" not in k and "lstm" not in k and "dw_bwd" not in k: continue
     print(k, "calls", calls[k])
     print("   ", "  ".join("%s=%.4g" % (n, v / max(1, calls[k])) for n, v in sorted(c.items())))
 PY
