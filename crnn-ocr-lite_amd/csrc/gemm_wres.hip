@@ -63,71 +63,77 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 // fragments, multiplies them with every 128-pixel stage the producers put into the ring (R slots at smem), and leaves each
 // finished stripe as bf16 in the staging tile outs[stripe & 1].  Barrier protocol: one s_barrier before stage 0, one after every
 // stage; at barrier i the producers have stages i and i+1 in LDS.
-template <int KCH, int R>
+template <int KCH, int R, int CB = 1, int PB = 4>   // CB 32-channel blocks per wave, PB 32-pixel blocks per stage
 __device__ __forceinline__ void wres_compute(const unsigned char* smem, unsigned char* outs, const bf16_t* __restrict__ W, int K, int n0,
                                              int wave, int lane, int mine) {
   const int half = lane >> 5, l31 = lane & 31, sw = (l31 >> 1) & 7;
-  bf16x8_t wf[KCH][4];
-  {
-    const bf16_t* wrow = W + (long)(n0 + l31) * K + half * 8;
+  constexpr int stage = PB * 32 * 128, orow = 256 * CB;      // bytes of a ring stage / of a staging-tile row (128 CB channels)
+  bf16x8_t wf[CB][KCH][4];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) {
+    const bf16_t* wrow = W + (long)(n0 + 32 * cb + l31) * K + half * 8;
 #pragma unroll
     for (int kc = 0; kc < KCH; ++kc)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) wf[kc][ks] = *reinterpret_cast<const bf16x8_t*>(wrow + kc * 64 + ks * 16);
+      for (int ks = 0; ks < 4; ++ks) wf[cb][kc][ks] = *reinterpret_cast<const bf16x8_t*>(wrow + kc * 64 + ks * 16);
   }
-  f32x16 acc[4];
+  f32x16 acc[PB][CB];
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int lrow = l31 * 128;
   int slot = 0;
-  bf16x8_t fx[4];                                              // fragments of k-step 0 of the stage about to be multiplied
+  bf16x8_t fx[PB];                                              // fragments of k-step 0 of the stage about to be multiplied
   __builtin_amdgcn_s_barrier();                                // barrier 0: stages 0 and 1 have landed
   {
     const unsigned char* A = smem + lrow + ((half ^ sw) * 16);
 #pragma unroll
-    for (int b = 0; b < 4; ++b) fx[b] = *reinterpret_cast<const bf16x8_t*>(A + b * 32 * 128);
+    for (int b = 0; b < PB; ++b) fx[b] = *reinterpret_cast<const bf16x8_t*>(A + b * 32 * 128);
   }
   for (int it = 0; it < mine; ++it) {
 #pragma unroll
     for (int kc = 0; kc < KCH; ++kc) {
-      const unsigned char* A = smem + slot * kStage + lrow;
+      const unsigned char* A = smem + slot * stage + lrow;
       slot = slot + 1 == R ? 0 : slot + 1;
-      const unsigned char* An = smem + slot * kStage + lrow;    // next stage (landed: the loaders run one stage ahead of the barrier)
+      const unsigned char* An = smem + slot * stage + lrow;    // next stage (landed: the loaders run one stage ahead of the barrier)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        bf16x8_t nx[4];
+        bf16x8_t nx[PB];
         const unsigned char* src = ks < 3 ? A + (((2 * (ks + 1) + half) ^ sw) * 16) : An + ((half ^ sw) * 16);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) if (!WRES_EXP(p, 2)) nx[b] = *reinterpret_cast<const bf16x8_t*>(src + b * 32 * 128);
+        for (int b = 0; b < PB; ++b) if (!WRES_EXP(p, 2)) nx[b] = *reinterpret_cast<const bf16x8_t*>(src + b * 32 * 128);
         // pin the order "reads of the next k-step, then this k-step's MFMAs": left alone the scheduler shares two fragment
         // registers between all reads and the MFMA pipe waits out an LDS round trip every second MFMA
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          if (WRES_EXP(p, 8)) continue;
-          if (kc == 0 && ks == 0) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kc][ks], fx[b], zero16, 0, 0, 0);   // C = 0: no clearing pass
-          else acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kc][ks], fx[b], acc[b], 0, 0, 0);
-        }
+        for (int b = 0; b < PB; ++b)
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb) {
+            if (WRES_EXP(p, 8)) continue;
+            if (kc == 0 && ks == 0) acc[b][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cb][kc][ks], fx[b], zero16, 0, 0, 0);   // C = 0: no clearing pass
+            else acc[b][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cb][kc][ks], fx[b], acc[b][cb], 0, 0, 0);
+          }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) fx[b] = nx[b];
+        for (int b = 0; b < PB; ++b) fx[b] = nx[b];
       }
       if (kc + 1 < KCH) __builtin_amdgcn_s_barrier();          // releases this stage's slot; the stage after the next has landed
     }
     // ---- epilogue of the stripe: lane = one pixel; register group g of a 32x32 block = channels 8g + 4half + 0..3.
-    // 16-byte chunk (4 wave + 2 pr + half) of pixel row px goes to position chunk ^ (px & 15) of the staging tile
-    unsigned char* ob = outs + (it & 1) * kOut;
+    // 16-byte chunk (4 (wave CB + cb) + 2 pr + half) of pixel row px goes to position chunk ^ (px & 15) of the staging tile
+    unsigned char* ob = outs + (it & 1) * (PB * 32 * orow);
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < PB; ++b) {
       const int px = 32 * b + l31;
 #pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {
-        const f32x16& v = acc[b];
-        unsigned g0a = pack2_bf16(v[8 * pr + 0], v[8 * pr + 1]), g0b = pack2_bf16(v[8 * pr + 2], v[8 * pr + 3]);
-        unsigned g1a = pack2_bf16(v[8 * pr + 4], v[8 * pr + 5]), g1b = pack2_bf16(v[8 * pr + 6], v[8 * pr + 7]);
-        const u32x2 sa = __builtin_amdgcn_permlane32_swap(g0a, g1a, false, false);
-        const u32x2 sb = __builtin_amdgcn_permlane32_swap(g0b, g1b, false, false);
-        *reinterpret_cast<uint4*>(ob + px * 256 + (((4 * wave + 2 * pr + half) ^ (px & 15)) * 16)) = make_uint4(sa.x, sb.x, sa.y, sb.y);
-      }
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const f32x16& v = acc[b][cb];
+          unsigned g0a = pack2_bf16(v[8 * pr + 0], v[8 * pr + 1]), g0b = pack2_bf16(v[8 * pr + 2], v[8 * pr + 3]);
+          unsigned g1a = pack2_bf16(v[8 * pr + 4], v[8 * pr + 5]), g1b = pack2_bf16(v[8 * pr + 6], v[8 * pr + 7]);
+          const u32x2 sa = __builtin_amdgcn_permlane32_swap(g0a, g1a, false, false);
+          const u32x2 sb = __builtin_amdgcn_permlane32_swap(g0b, g1b, false, false);
+          *reinterpret_cast<uint4*>(ob + px * orow + (((4 * (wave * CB + cb) + 2 * pr + half) ^ (px & 15)) * 16)) = make_uint4(sa.x, sb.x, sa.y, sb.y);
+        }
     }
     __builtin_amdgcn_s_barrier();                              // the stripe's last stage: also hands the staged tile to the storers
   }
@@ -263,11 +269,16 @@ __device__ __forceinline__ unsigned wres_bnrelu6_pair(unsigned w, f32x2_t s, f32
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 
-template <int KCH>
+template <int KCH, int CB, int PB>   // K / 64; 32-channel blocks per MFMA wave (workgroup = 128 CB channels); 32-pixel blocks per stage / stripe
 __global__ __launch_bounds__(512) void gemm_wres_fwd_kernel(WresFwdParams p) {
+  constexpr int stage = PB * 32 * 128, orow = 256 * CB, otile = PB * 32 * orow, NS = 128 * CB, PX = 32 * PB;
+  constexpr int CPL = PB;                                      // 16-byte stage chunks per IO lane and stage (PX rows x 8 chunks over 256 lanes)
+  // stages in flight in the IO waves' registers: 64 KiB per CU for the deep-K shapes; the K <= 128 shapes are HBM-bound with a write
+  // stream twice the read stream and run faster with 32 KiB (measured: 75 / 160 us against 85 / 178 us for blocks 2 / 3)
+  constexpr int D = (KCH >= 4 ? 16 : 8) / PB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // kRf stages | two staging tiles | scale[K] | shift[K]
-  unsigned char* const outs = smem + kRf * kStage;
-  float* const tab = reinterpret_cast<float*>(outs + 2 * kOut);
+  unsigned char* const outs = smem + kRf * stage;
+  float* const tab = reinterpret_cast<float*>(outs + 2 * otile);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = blockIdx.x;
@@ -279,41 +290,43 @@ __global__ __launch_bounds__(512) void gemm_wres_fwd_kernel(WresFwdParams p) {
   const int total = mine * KCH;
   const int srow = (q * p.nxcd + x) * 4 + (wave - 4);          // this IO wave's partial-statistics row
   if (mine <= 0) {                                             // no stripe: the statistics rows must still read as zero
-    if (p.stats && wave >= 4 && lane < 16)
+    if (p.stats && wave >= 4 && lane < 16 * CB)
       for (int e = 0; e < 8; ++e) {
-        p.stats[((long)srow * 2 + 0) * p.N + slice * 128 + lane * 8 + e] = 0.f;
-        p.stats[((long)srow * 2 + 1) * p.N + slice * 128 + lane * 8 + e] = 0.f;
+        p.stats[((long)srow * 2 + 0) * p.N + slice * NS + lane * 8 + e] = 0.f;
+        p.stats[((long)srow * 2 + 1) * p.N + slice * NS + lane * 8 + e] = 0.f;
       }
     return;
   }
   for (int i = tid; i < p.K; i += 512) { tab[i] = p.scale[i]; tab[p.K + i] = p.shift[i]; }
+  for (int i = tid; i < 2 * otile / 16; i += 512) reinterpret_cast<u32x4*>(outs)[i] = u32x4{0u, 0u, 0u, 0u};   // see stage_fast: dummy drains read zeros
   __syncthreads();
 
   if (wave < 4) {
-    wres_compute<KCH, kRf>(smem, outs, p.W, p.K, slice * 128 + wave * 32, wave, lane, mine);
+    wres_compute<KCH, kRf, CB, PB>(smem, outs, p.W, p.K, slice * NS + wave * 32 * CB, wave, lane, mine);
     return;
   }
   // ------------------------------------------------------------------------ IO waves
   const int w = wave - 4;
-  const int r8 = lane >> 3, c = lane & 7;                      // stage chunk: pixel row 32 w + 8 it + r8, 16-byte piece c (8 channels)
+  const int r8 = lane >> 3, c = lane & 7;                      // stage chunk: pixel row 8 (PB w + u) + r8, 16-byte piece c (8 channels)
   const long ldk = p.K;
-  u32x4 pf[3][4];                                              // raw chunks of the stages in flight (stage lin in buffer lin % 3)
-  auto load = [&](int lin, u32x4 (&buf)[4]) {
+  u32x4 pf[D][CPL];                                              // raw chunks of the stages in flight (stage lin in buffer lin % D)
+  auto load = [&](int lin, u32x4 (&buf)[CPL]) {
     lin = lin < total ? lin : total - 1;                       // past the end: a valid address, the data is not used
     const int it = lin / KCH, kc = lin % KCH;
-    const bf16_t* src = p.X + ((long)(first + it * step) * 128 + 32 * w + r8) * ldk + kc * 64 + c * 8;
+    const bf16_t* src = p.X + ((long)(first + it * step) * PX + 8 * PB * w + r8) * ldk + kc * 64 + c * 8;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) buf[u] = *reinterpret_cast<const u32x4*>(src + (long)(8 * u) * ldk);
+    for (int u = 0; u < CPL; ++u) buf[u] = *reinterpret_cast<const u32x4*>(src + (long)(8 * u) * ldk);
   };
-  auto write = [&](int lin, const u32x4 (&buf)[4]) {
-    if (lin >= total) return;
+  // (stages past the end are written too -- transformed junk from the clamped loads into a slot whose stage has been consumed:
+  // keeping the steady-state loop free of branches is what lets the wait-count insertion count the outstanding loads exactly)
+  auto write = [&](int lin, const u32x4 (&buf)[CPL]) {
     const int kc = lin % KCH;
     const float4 s0 = *reinterpret_cast<const float4*>(tab + kc * 64 + c * 8), s1 = *reinterpret_cast<const float4*>(tab + kc * 64 + c * 8 + 4);
     const float4 t0 = *reinterpret_cast<const float4*>(tab + p.K + kc * 64 + c * 8), t1 = *reinterpret_cast<const float4*>(tab + p.K + kc * 64 + c * 8 + 4);
-    unsigned char* dst = smem + (lin % kRf) * kStage;
+    unsigned char* dst = smem + (lin % kRf) * stage;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int row = 32 * w + 8 * u + r8;
+    for (int u = 0; u < CPL; ++u) {
+      const int row = 8 * (PB * w + u) + r8;
       u32x4 o;
       if (WRES_EXP(p, 64)) o = buf[u]; else {
       o.x = wres_bnrelu6_pair(buf[u].x, f32x2_t{s0.x, s0.y}, f32x2_t{t0.x, t0.y});
@@ -324,19 +337,23 @@ __global__ __launch_bounds__(512) void gemm_wres_fwd_kernel(WresFwdParams p) {
       *reinterpret_cast<u32x4*>(dst + row * 128 + ((c ^ ((row >> 1) & 7)) * 16)) = o;
     }
   };
-  // drain + statistics: lane = (row r4 of a group of four, 16-byte piece c16 = 8 channels); 8 pieces per IO wave and stripe
+  // drain + statistics: a staging-tile row is 16 CB pieces of 16 bytes; lane = (row rg of a group of 4 / CB, piece cN = 8 channels);
+  // 8 pieces per IO wave and stripe (PX rows x 16 CB pieces = 2048 per stripe either way)
   constexpr int PP = 8 / KCH;                                  // pieces per stage
-  const int r4 = lane >> 4, c16 = lane & 15;
+  constexpr int RG = 4 / CB;                                   // rows a wave-instruction covers
+  const int rg = lane / (16 * CB), cN = lane % (16 * CB);
   float ssum[8], ssq[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+  // stripe_it = -1 (nothing finished yet): reads staging tile 1, still all zeros (the MFMA waves first write it at the end of
+  // stripe 1), adds zeros to the statistics and stores zeros over stripe 0's rows, which this wave rewrites with the result later
   auto drain = [&](int stripe_it, int t0, int t1) {
-    const unsigned char* ob = outs + (stripe_it & 1) * kOut;
-    const long m0 = (long)(first + stripe_it * step) * 128;
+    const unsigned char* ob = outs + (stripe_it & 1) * otile;
+    const long m0 = (long)(first + (stripe_it < 0 ? 0 : stripe_it) * step) * PX;
     for (int t = t0; t < t1; ++t) {
-      const int r = (w * 8 + t) * 4 + r4;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(ob + r * 256 + ((c16 ^ (r & 15)) * 16));
-      if (!WRES_EXP(p, 4)) *reinterpret_cast<u32x4*>(p.Y + (m0 + r) * p.N + slice * 128 + c16 * 8) = v;
+      const int r = (w * 8 + t) * RG + rg;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(ob + r * orow + ((cN ^ (r & 15)) * 16));
+      if (!WRES_EXP(p, 4)) *reinterpret_cast<u32x4*>(p.Y + (m0 + r) * p.N + slice * NS + cN * 8) = v;
       const unsigned ww[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -347,33 +364,43 @@ __global__ __launch_bounds__(512) void gemm_wres_fwd_kernel(WresFwdParams p) {
       }
     }
   };
-  auto stage_step = [&](int jb, u32x4 (&buf)[4]) {            // everything an IO wave does around barrier jb; buf = buffer (jb + 2) % 3
+  auto stage_step = [&](int jb, u32x4 (&buf)[CPL]) {          // everything an IO wave does around barrier jb; buf = buffer (jb + 2) % D
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's ring writes are in LDS before the others pass the barrier
     __builtin_amdgcn_s_barrier();
-    if (jb < total) { write(jb + 2, buf); load(jb + 5, buf); }
+    if (jb < total) { write(jb + 2, buf); load(jb + 2 + D, buf); }
     if (jb >= KCH) {
       const int done = jb / KCH - 1, t = jb % KCH;
       if (jb == total) drain(done, 0, 8);                       // the last stripe: everything at once
       else drain(done, t * PP, (t + 1) * PP);
     }
   };
-  load(0, pf[0]); load(1, pf[1]); load(2, pf[2]);
-  write(0, pf[0]); load(3, pf[0]);
-  write(1, pf[1]); load(4, pf[1]);
-  for (int jb = 0; jb <= total; jb += 3) {
-    stage_step(jb, pf[2]);
-    if (jb + 1 <= total) stage_step(jb + 1, pf[0]);
-    if (jb + 2 <= total) stage_step(jb + 2, pf[1]);
+  auto stage_fast = [&](int jb, u32x4 (&buf)[CPL]) {           // the same for jb < total, straight-line: no branch between the VMEM operations
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    write(jb + 2, buf); load(jb + 2 + D, buf);
+    drain(jb / KCH - 1, (jb % KCH) * PP, (jb % KCH + 1) * PP);
+  };
+#pragma unroll
+  for (int k = 0; k < D; ++k) load(k, pf[k]);
+  write(0, pf[0]); load(D, pf[0]);
+  write(1, pf[1]); load(D + 1, pf[1]);
+  int jb = 0;
+  for (; jb + D <= total; jb += D) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) stage_fast(jb + k, pf[(k + 2) % D]);
   }
+#pragma unroll
+  for (int k = 0; k < D; ++k)
+    if (jb + k <= total) stage_step(jb + k, pf[(k + 2) % D]);
   if (p.stats) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      ssum[e] += __shfl_xor(ssum[e], 16, 64); ssum[e] += __shfl_xor(ssum[e], 32, 64);
-      ssq[e] += __shfl_xor(ssq[e], 16, 64); ssq[e] += __shfl_xor(ssq[e], 32, 64);
+      if (CB == 1) { ssum[e] += __shfl_xor(ssum[e], 16, 64); ssq[e] += __shfl_xor(ssq[e], 16, 64); }
+      ssum[e] += __shfl_xor(ssum[e], 32, 64); ssq[e] += __shfl_xor(ssq[e], 32, 64);
     }
-    if (lane < 16) {
-      float* r0 = p.stats + ((long)srow * 2 + 0) * p.N + slice * 128 + c16 * 8;
-      float* r1 = p.stats + ((long)srow * 2 + 1) * p.N + slice * 128 + c16 * 8;
+    if (lane < 16 * CB) {
+      float* r0 = p.stats + ((long)srow * 2 + 0) * p.N + slice * NS + cN * 8;
+      float* r1 = p.stats + ((long)srow * 2 + 1) * p.N + slice * NS + cN * 8;
       *reinterpret_cast<float4*>(r0) = make_float4(ssum[0], ssum[1], ssum[2], ssum[3]);
       *reinterpret_cast<float4*>(r0 + 4) = make_float4(ssum[4], ssum[5], ssum[6], ssum[7]);
       *reinterpret_cast<float4*>(r1) = make_float4(ssq[0], ssq[1], ssq[2], ssq[3]);
@@ -435,8 +462,12 @@ extern "C" int crnn_gemm_wres_bf16(const void* X, const void* W, void* Y, int M,
 }
 
 namespace {
-void wres_fwd_geom(long M, int N, WresFwdParams& p, int& grid) {
-  p.stripes = cdiv(M, 128); p.S = N / 128;
+// two shapes of the forward kernel: (CB 1, PB 4) = 128 pixels x 128 channels per workgroup; (CB 2, PB 2) = 64 pixels x 256 channels,
+// where the doubled weight fragments still fit the registers (K <= 256): half as many channel slices transform / read every pixel
+bool wres_fwd_wide(int N, int K) { return N % 256 == 0 && K <= 256 && crnn_knob("CRNN_WRES_WIDE", 1); }
+void wres_fwd_geom(long M, int N, int K, WresFwdParams& p, int& grid) {
+  const bool wide = wres_fwd_wide(N, K);
+  p.stripes = cdiv(M, wide ? 64 : 128); p.S = N / (wide ? 256 : 128);
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
   p.nxcd = 8;
@@ -447,16 +478,17 @@ void wres_fwd_geom(long M, int N, WresFwdParams& p, int& grid) {
   if (p.Q > need) p.Q = need;
   grid = p.nxcd * p.Q * p.S;
 }
-template <int KCH>
+template <int KCH, int CB, int PB>
 int launch_wres_fwd(const WresFwdParams& p, int grid, hipStream_t stream) {
-  const int lds = kRf * kStage + 2 * kOut + 2 * p.K * (int)sizeof(float);
+  constexpr int fixed = kRf * PB * 32 * 128 + 2 * PB * 32 * 256 * CB;
+  const int lds = fixed + 2 * p.K * (int)sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_wres_fwd_kernel<KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, kRf * kStage + 2 * kOut + 2 * 512 * (int)sizeof(float));
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_wres_fwd_kernel<KCH, CB, PB>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed + 2 * 512 * (int)sizeof(float));
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_wres_fwd_kernel<KCH>), dim3(grid), dim3(512), lds, stream, p);
+  hipLaunchKernelGGL((gemm_wres_fwd_kernel<KCH, CB, PB>), dim3(grid), dim3(512), lds, stream, p);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
@@ -467,15 +499,15 @@ extern "C" int crnn_pwconv_fwd_wres_supported(long M, int N, int K) {
   return (M > 0 && M % 128 == 0 && M * (long)(K > N ? K : N) < (1L << 31) && crnn_gemm_wres_supported(N, K) == CRNN_OK) ? CRNN_OK : CRNN_ERR_UNSUPPORTED;
 }
 // rows of the partial statistics [rows][2][N] the kernel writes (every row and column of that block is written)
-extern "C" int crnn_pwconv_fwd_wres_rows(long M, int N) {
-  if (M <= 0 || N < 128 || N % 128) return 0;
+extern "C" int crnn_pwconv_fwd_wres_rows(long M, int N, int K) {
+  if (crnn_pwconv_fwd_wres_supported(M, N, K) != CRNN_OK) return 0;
   WresFwdParams p; int grid;
-  wres_fwd_geom(M, N, p, grid);
+  wres_fwd_geom(M, N, K, p, grid);
   return p.Q * p.nxcd * 4;
 }
 // q[M][N] (bf16) = ReLU6(d * scale + shift)[M][K] . wT[N][K]^T with in_bnstate = [mean|var|scale|shift] of the BatchNorm on d
 // (as crnn_pwconv_bnrelu6_fwd with w_transposed = 1 and bf16 q: the same bf16 result bit for bit); stat_partials (may be NULL):
-// [crnn_pwconv_fwd_wres_rows(M, N)][2][N] column sums / sums of squares of q as stored.
+// [crnn_pwconv_fwd_wres_rows(M, N, K)][2][N] column sums / sums of squares of q as stored.
 extern "C" int crnn_pwconv_bnrelu6_fwd_wres(const void* d, const float* in_bnstate, const void* wT, void* q, long M, int N, int K,
                                             float* stat_partials, hipStream_t stream) {
   if (!in_bnstate) return CRNN_ERR_ARG;
@@ -484,11 +516,18 @@ extern "C" int crnn_pwconv_bnrelu6_fwd_wres(const void* d, const float* in_bnsta
   WresFwdParams p; int grid;
   p.X = (const bf16_t*)d; p.W = (const bf16_t*)wT; p.Y = (bf16_t*)q; p.scale = in_bnstate + 2L * K; p.shift = in_bnstate + 3L * K;
   p.stats = stat_partials; p.M = (int)M; p.N = N; p.K = K;
-  wres_fwd_geom(M, N, p, grid);
+  wres_fwd_geom(M, N, K, p, grid);
+  if (wres_fwd_wide(N, K)) {
+    switch (K / 64) {
+      case 1: return launch_wres_fwd<1, 2, 2>(p, grid, stream);
+      case 2: return launch_wres_fwd<2, 2, 2>(p, grid, stream);
+      default: return launch_wres_fwd<4, 2, 2>(p, grid, stream);
+    }
+  }
   switch (K / 64) {
-    case 1: return launch_wres_fwd<1>(p, grid, stream);
-    case 2: return launch_wres_fwd<2>(p, grid, stream);
-    case 4: return launch_wres_fwd<4>(p, grid, stream);
-    default: return launch_wres_fwd<8>(p, grid, stream);
+    case 1: return launch_wres_fwd<1, 1, 4>(p, grid, stream);
+    case 2: return launch_wres_fwd<2, 1, 4>(p, grid, stream);
+    case 4: return launch_wres_fwd<4, 1, 4>(p, grid, stream);
+    default: return launch_wres_fwd<8, 1, 4>(p, grid, stream);
   }
 }

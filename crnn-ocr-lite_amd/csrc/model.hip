@@ -409,7 +409,7 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
         int rc = CRNN_ERR_UNSUPPORTED;
         if (wt && dtq == CRNN_BF16 && !(cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS) && crnn_pwconv_fwd_wres_supported(M, co, ci) == CRNN_OK) {
           rc = crnn_pwconv_bnrelu6_fwd_wres(dd, s1, wq, qq, M, co, ci, parts, stream);
-          if (rc == CRNN_OK) stat_rows = crnn_pwconv_fwd_wres_rows(M, co);
+          if (rc == CRNN_OK) stat_rows = crnn_pwconv_fwd_wres_rows(M, co, ci);
         }
         if (rc == CRNN_ERR_UNSUPPORTED) rc = crnn_pwconv_bnrelu6_fwd(dd, s1, wq, qq, M, co, ci, parts, dtq, wt, stream);
         CRNN_TRY(rc);

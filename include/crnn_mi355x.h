@@ -296,11 +296,11 @@ int crnn_gemm_wres_bf16(const void* X, const void* W, void* Y, int M, int N, int
  * q[M][N] (bf16) = ReLU6(BN(d))[M][K] . wT[N][K]^T, in_bnstate = [mean|var|scale|shift] of that BatchNorm.  Four IO waves per workgroup
  * load the pixel stages into registers three stages ahead, apply the BatchNorm + ReLU6 (bit for bit the arithmetic of
  * crnn_pwconv_bnrelu6_fwd) on the way into the LDS ring, drain the finished bf16 stripes and accumulate their column sums / sums of
- * squares over the whole launch: stat_partials (may be NULL) = [crnn_pwconv_fwd_wres_rows(M, N)][2][N], every element written.
+ * squares over the whole launch: stat_partials (may be NULL) = [crnn_pwconv_fwd_wres_rows(M, N, K)][2][N], every element written.
  * q is bit-identical to crnn_pwconv_bnrelu6_fwd(w_transposed = 1, bf16 q); the statistics are the same sums in a different order.
  * Supported (else -3): M % 128 == 0, N % 128 == 0, N <= 1024, K in {64, 128, 256, 512}. */
 int crnn_pwconv_fwd_wres_supported(long M, int N, int K);
-int crnn_pwconv_fwd_wres_rows(long M, int N);
+int crnn_pwconv_fwd_wres_rows(long M, int N, int K);
 int crnn_pwconv_bnrelu6_fwd_wres(const void* d, const float* in_bnstate, const void* wT, void* q, long M, int N, int K, float* stat_partials,
                                  crnn_stream_t stream);
 

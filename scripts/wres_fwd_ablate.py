@@ -15,8 +15,8 @@ for name, M, N, K in shapes:
     line = "%-3s" % name
     for m in masks:
         L = libs[m]
-        L.crnn_pwconv_fwd_wres_rows.argtypes = [ctypes.c_long, ctypes.c_int]
-        rows = L.crnn_pwconv_fwd_wres_rows(M, N); parts = torch.empty(rows * 2 * N, device="cuda")
+        L.crnn_pwconv_fwd_wres_rows.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int]
+        rows = L.crnn_pwconv_fwd_wres_rows(M, N, K); parts = torch.empty(rows * 2 * N, device="cuda")
         L.crnn_pwconv_bnrelu6_fwd_wres.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         fn = lambda: L.crnn_pwconv_bnrelu6_fwd_wres(P(X), P(st), P(W), P(Y), M, N, K, P(parts), S())
         for _ in range(2): assert fn() == 0

@@ -803,7 +803,7 @@ def test_weights_resident_forward_pointwise_equals_the_tile_kernel(M, N, K):
     st = dev(np.concatenate([mean, var, scale, shift]))
     dd, Wd = _to_bf16_dev(d), _to_bf16_dev(W)
     assert L().crnn_pwconv_fwd_wres_supported(M, N, K) == 0
-    rows = L().crnn_pwconv_fwd_wres_rows(M, N)
+    rows = L().crnn_pwconv_fwd_wres_rows(M, N, K)
     q1 = torch.full((M + 2, N), 7.0, dtype=torch.bfloat16, device="cuda"); parts1 = torch.full((rows, 2, N), 3.0, device="cuda")
     for rep in range(2):
         ok(L().crnn_pwconv_bnrelu6_fwd_wres(P(dd), P(st), P(Wd), P(q1), M, N, K, P(parts1), S()))
