@@ -1,0 +1,254 @@
+// Pixel-streaming weight gradient of a pointwise (1x1) convolution whose input is the PRE-BatchNorm depthwise output
+// (utils.py:44-49, training backward):
+//     dW[K][N] = ReLU6(BN1(d))^T [K][M] . g[M][N]        d, g bf16 (NHWC rows), dW fp32, K = channels in, N = channels out
+// The reduction runs over the M = B*H*W pixels (10^5..10^6), the result is at most 512 x 512.  The tile kernel (gemm_bf16.inc,
+// mode 2) runs this as output tiles x ~48 reduction ranges with one register-staged k-chunk in flight per workgroup: every
+// 64-pixel chunk costs it a full load round trip (2.8 us per chunk for 0.25 us of MFMAs) -- it ingests ~13 B/clk/CU where the
+// L2 can deliver three times that.  Here the same decomposition is organised as a stream:
+//   * a workgroup (512 threads) owns one 128 x 128 output tile over a contiguous range of 64-pixel chunks; the 4 MFMA waves
+//     (2 x 2, 64 x 64 each: 4 accumulator blocks of v_mfma_f32_32x32x16_bf16) keep the tile in registers for the whole range;
+//   * the 4 IO waves load the d- and g-rows of the chunks three chunks ahead into registers (96 KiB per CU in flight), apply
+//     ReLU6(d * scale + shift) -> bf16 (a lane keeps the scale / shift of its 8 channels for the whole launch; the arithmetic of
+//     crnn_pwconv_bnrelu6_wgrad's prologue bit for bit) and write both operands k-major into an LDS ring of 3 stages, row stride
+//     128 + 32 bf16 so that the transposing fragment reads (two ds_read_b64_tr_b16 per fragment) are conflict-free;
+//   * one raw s_barrier per chunk; the steady-state IO loop is branch-free so the wait-count insertion counts the outstanding
+//     loads exactly instead of draining them;
+//   * all tiles of one reduction range sit on one XCD (they read the same pixel rows: HBM sees them once); ranges are
+//     contiguous, the fp32 partial tiles go to scratch [range][K][N] and a fixed-order second stage sums them (deterministic).
+// Same products as the tile kernel (bf16 operands, fp32 accumulation); the reduction is grouped differently (other range
+// boundaries), so the result agrees to fp32 summation round-off, not bit for bit.
+#include "common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+#ifndef CRNN_WG_EXP
+#define CRNN_WG_EXP 0     // compile-time ablation mask (scripts/wgrad_bench.py --ablate): 1 no transform, 2 no fragment reads / MFMAs, 4 no global loads
+#endif
+
+namespace {
+
+struct WgParams {
+  const bf16_t* D; const bf16_t* G; float* part;     // d [M][K], g [M][N], partial tiles [nsplit][K][N]
+  const float* scale; const float* shift;             // [K]
+  int M, N, K;
+  int chunks;        // M / 64
+  int TI, TJ;        // output tiles along K (rows) and N (columns)
+  int nsplit;        // reduction ranges; grid = 8 * ceil(TI * TJ * nsplit / 8) workgroups, id -> (xcd, tile, range) below
+  int per;           // chunks per range (the last range may be shorter)
+};
+
+constexpr int kLd = 128 + 32;                 // bf16 row stride of a k-major operand stage (320 B)
+constexpr int kOp = 64 * kLd * 2;             // bytes of one operand stage: 64 pixels x 160 x 2 B = 20 KiB
+constexpr int kRing = 3;
+constexpr int kD = 3;                         // chunks in flight in the IO waves' registers
+
+__device__ __forceinline__ unsigned wg_bnrelu6_pair(unsigned w, f32x2_t s, f32x2_t t) {
+  f32x2_t v;
+  v[0] = fma_unpacked(__uint_as_float(w << 16), s[0], t[0]);             // (not v_pk_fma_f32: see common.h)
+  v[1] = fma_unpacked(__uint_as_float(w & 0xffff0000u), s[1], t[1]);
+  v[0] = __builtin_amdgcn_fmed3f(v[0], 0.f, 6.f); v[1] = __builtin_amdgcn_fmed3f(v[1], 0.f, 6.f);
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+
+// fragment = the 8 bf16 (k = 16 ks + 8 half .. +7) of tile row r0 + l31, from a k-major stage (as gemm_bf16.inc read_frag_h<true>)
+__device__ __forceinline__ bf16x8_t wg_frag(const unsigned char* Xs, int r0, int ks, int half, int l31) {
+  const int li = l31 & 15;
+  const unsigned short* X = reinterpret_cast<const unsigned short*>(Xs) + (ks * 16 + 8 * half + (li >> 2)) * kLd + r0 + (l31 & 16) + (li & 3) * 4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)X);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(X + 4 * kLd));
+  const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
+  return __builtin_bit_cast(bf16x8_t, make_uint4(a.x, a.y, b.x, b.y));
+}
+
+__global__ __launch_bounds__(512) void pw_wgrad_stream_kernel(WgParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // kRing x (A stage | B stage)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // workgroup -> (xcd, local) -> (range, tile): the tiles of a range are neighbours on one XCD
+  const int wg = blockIdx.x, x = wg & 7, loc = wg >> 3;
+  const int tiles = p.TI * p.TJ;
+  const int lin = loc % tiles, rloc = loc / tiles;              // tile, range index within this XCD
+  const int split = rloc * 8 + x;
+  if (split >= p.nsplit) return;
+  const int ti = lin / p.TJ, tj = lin % p.TJ;
+  const int c0 = split * p.per;
+  const int total = min(p.per, p.chunks - c0);                  // chunks of this range (> 0 by the host's choice of nsplit)
+
+  if (wave < 4) {
+    // ------------------------------------------------------------------------ MFMA waves
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    int slot = 0;
+    for (int s = 0; s < total; ++s) {
+      __builtin_amdgcn_s_barrier();                             // stage s is in LDS; stage s-1's slot is released
+      const unsigned char* As = smem + slot * (2 * kOp);
+      const unsigned char* Bs = As + kOp;
+      slot = slot + 1 == kRing ? 0 : slot + 1;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (CRNN_WG_EXP & 2) continue;
+        bf16x8_t fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = wg_frag(As, wm * 64 + i * 32, ks, half, l31);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = wg_frag(Bs, wn * 64 + j * 32, ks, half, l31);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_barrier();                               // the IO waves' last barrier
+    // partial tile -> scratch: lane = one column, register e = row 8 (e / 4) + 4 half + (e & 3) of the 32 x 32 block
+    float* out = p.part + (long)split * p.K * p.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = ti * 128 + wm * 64 + i * 32 + 8 * (e >> 2) + 4 * half + (e & 3);
+          const int col = tj * 128 + wn * 64 + j * 32 + l31;
+          out[(long)row * p.N + col] = acc[i][j][e];
+        }
+    return;
+  }
+  // -------------------------------------------------------------------------- IO waves
+  const int w = wave - 4;
+  const int c16 = lane & 15;                                    // 16-byte piece of a 256-byte tile row: channels 8 c16 .. +7
+  const int pxl = w * 4 + (lane >> 4);                          // pixel row within a group of 16 (chunk = 4 groups)
+  f32x2_t sc[4], sh[4];
+  {
+    const float* s = p.scale + ti * 128 + c16 * 8; const float* t = p.shift + ti * 128 + c16 * 8;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sc[e] = f32x2_t{s[2 * e], s[2 * e + 1]}; sh[e] = f32x2_t{t[2 * e], t[2 * e + 1]}; }
+  }
+  const bf16_t* dbase = p.D + (long)ti * 128 + c16 * 8;
+  const bf16_t* gbase = p.G + (long)tj * 128 + c16 * 8;
+  u32x4 ra[kD][4], rg[kD][4];
+  auto load = [&](int s, u32x4 (&xa)[4], u32x4 (&xg)[4]) {
+    s = s < total ? s : total - 1;                              // past the end: a valid address, the data lands in a consumed slot
+    const long row0 = (long)(c0 + s) * 64 + pxl;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (CRNN_WG_EXP & 4) { xa[u] = u32x4{(unsigned)s, 0u, 0u, 0u}; xg[u] = xa[u]; continue; }
+      xa[u] = *reinterpret_cast<const u32x4*>(dbase + (row0 + 16 * u) * p.K);
+      xg[u] = *reinterpret_cast<const u32x4*>(gbase + (row0 + 16 * u) * p.N);
+    }
+  };
+  auto write = [&](int s, const u32x4 (&xa)[4], const u32x4 (&xg)[4]) {
+    unsigned char* As = smem + (s % kRing) * (2 * kOp);
+    unsigned char* Bs = As + kOp;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int px = pxl + 16 * u;
+      u32x4 o;
+      if (CRNN_WG_EXP & 1) o = xa[u]; else {
+      o.x = wg_bnrelu6_pair(xa[u].x, sc[0], sh[0]); o.y = wg_bnrelu6_pair(xa[u].y, sc[1], sh[1]);
+      o.z = wg_bnrelu6_pair(xa[u].z, sc[2], sh[2]); o.w = wg_bnrelu6_pair(xa[u].w, sc[3], sh[3]);
+      }
+      *reinterpret_cast<u32x4*>(As + px * (kLd * 2) + c16 * 16) = o;
+      *reinterpret_cast<u32x4*>(Bs + px * (kLd * 2) + c16 * 16) = xg[u];
+    }
+  };
+  // barrier s (s = 0 .. total): before it stage s is written; after it the slot of stage s-1 is free -> stage s+2 goes there
+  auto step = [&](int s, u32x4 (&xa)[4], u32x4 (&xg)[4]) {   // xa/xg = buffer (s + 2) % kD
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    write(s + 2, xa, xg); load(s + 2 + kD, xa, xg);
+  };
+#pragma unroll
+  for (int k = 0; k < kD; ++k) load(k, ra[k], rg[k]);
+  write(0, ra[0], rg[0]); load(kD, ra[0], rg[0]);
+  write(1, ra[1], rg[1]); load(kD + 1, ra[1], rg[1]);
+  int s = 0;
+  for (; s + kD <= total; s += kD) {
+#pragma unroll
+    for (int k = 0; k < kD; ++k) step(s + k, ra[(k + 2) % kD], rg[(k + 2) % kD]);
+  }
+#pragma unroll
+  for (int k = 0; k < kD; ++k)
+    if (s + k <= total) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (s + k < total) { write(s + k + 2, ra[(k + 2) % kD], rg[(k + 2) % kD]); load(s + k + 2 + kD, ra[(k + 2) % kD], rg[(k + 2) % kD]); }
+    }
+}
+
+// out[i] = sum_s part[s][i], s ascending in a fixed grouping (deterministic)
+__global__ __launch_bounds__(256) void pw_wgrad_sum_kernel(const float* __restrict__ part, int nsplit, long total, float* __restrict__ out) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= total) return;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+  int s = 0;
+  for (; s + 1 < nsplit; s += 2) {
+    const float4 v0 = *reinterpret_cast<const float4*>(part + (long)s * total + i), v1 = *reinterpret_cast<const float4*>(part + (long)(s + 1) * total + i);
+    a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+  }
+  if (s < nsplit) { const float4 v0 = *reinterpret_cast<const float4*>(part + (long)s * total + i); a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w; }
+  *reinterpret_cast<float4*>(out + i) = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+}
+
+void wg_geom(long M, int N, int K, WgParams& p, int& grid) {
+  p.chunks = (int)(M / 64); p.TI = K / 128; p.TJ = N / 128;
+  const int tiles = p.TI * p.TJ;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+  int ns = (cus / tiles) & ~7;                                  // one workgroup per CU, a multiple of 8 ranges (8 XCDs)
+  if (ns < 8) ns = 8;
+  while (ns > 8 && p.chunks / ns < 4 * kD) ns -= 8;             // a range is at least a few pipeline depths long
+  if (ns > p.chunks) ns = p.chunks;                             // (tiny inputs: ranges of one chunk; some of the 8 XCD lanes stay empty)
+  p.nsplit = ns;
+  p.per = cdiv(p.chunks, ns);
+  p.nsplit = cdiv(p.chunks, p.per);                             // drop empty tail ranges
+  grid = 8 * cdiv(p.nsplit, 8) * tiles;
+}
+
+}  // namespace
+
+// 0 if crnn_pwconv_bnrelu6_wgrad_stream handles the shape (whole 64-pixel chunks, K and N multiples of 128 up to 1024), else -3
+extern "C" int crnn_pwconv_wgrad_stream_supported(long M, int N, int K) {
+  return (M >= 64 && M % 64 == 0 && N >= 128 && N % 128 == 0 && K >= 128 && K % 128 == 0 && N <= 1024 && K <= 1024 &&
+          M * (long)(K > N ? K : N) < (1L << 31)) ? CRNN_OK : CRNN_ERR_UNSUPPORTED;
+}
+// bytes of scratch the call needs (the partial tiles)
+extern "C" size_t crnn_pwconv_wgrad_stream_scratch_bytes(long M, int N, int K) {
+  if (crnn_pwconv_wgrad_stream_supported(M, N, K) != CRNN_OK) return 0;
+  WgParams p; int grid; wg_geom(M, N, K, p, grid);
+  return (size_t)p.nsplit * K * N * sizeof(float);
+}
+// dw[K][N] (fp32) = ReLU6(d * scale + shift)^T [K][M] . g[M][N]; d, g bf16; in_bnstate = [mean|var|scale|shift] of the BatchNorm on d
+extern "C" int crnn_pwconv_bnrelu6_wgrad_stream(const void* d, const float* in_bnstate, const void* g, float* dw, long M, int N, int K,
+                                                float* scratch, size_t scratch_bytes, hipStream_t stream) {
+  if (!in_bnstate || !scratch) return CRNN_ERR_ARG;
+  CRNN_TRY(crnn_pwconv_wgrad_stream_supported(M, N, K));
+  if ((((uintptr_t)d | (uintptr_t)g | (uintptr_t)dw | (uintptr_t)scratch) & 15)) return CRNN_ERR_UNSUPPORTED;
+  WgParams p; int grid;
+  p.D = (const bf16_t*)d; p.G = (const bf16_t*)g; p.part = scratch; p.scale = in_bnstate + 2L * K; p.shift = in_bnstate + 3L * K;
+  p.M = (int)M; p.N = N; p.K = K;
+  wg_geom(M, N, K, p, grid);
+  if ((size_t)p.nsplit * K * N * sizeof(float) > scratch_bytes) return CRNN_ERR_UNSUPPORTED;
+  const int lds = kRing * 2 * kOp;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)pw_wgrad_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(pw_wgrad_stream_kernel, dim3(grid), dim3(512), lds, stream, p);
+  CRNN_LAUNCH_CHECK();
+  const long total = (long)K * N;
+  hipLaunchKernelGGL(pw_wgrad_sum_kernel, dim3(cdiv(total, 1024)), dim3(256), 0, stream, scratch, p.nsplit, total, dw);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}

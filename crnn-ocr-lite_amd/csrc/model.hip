@@ -689,8 +689,14 @@ int backward_bottom(const Ctx& c, const float* x, uint64_t seed, hipStream_t aux
       const bool side = fj.on && fused_dw;
       const Ctx& cw = side ? ca : c;
       if (side) CRNN_TRY(fj.fork());
-      if (fuse_dw_bn(cfg, dtd, dtq, ci))   // the activated tensor was never written: re-form it from d while staging (as the forward did)
-        CRNN_TRY(crnn_pwconv_bnrelu6_wgrad(c.w("d" + p), c.w("bn1s" + p), gB, c.g(bp + "_pw"), M, co, ci, cw.scratch(), kGemmScratchBytes, cw.s));
+      if (fuse_dw_bn(cfg, dtd, dtq, ci)) {  // the activated tensor was never written: re-form it from d while staging (as the forward did)
+        int rc = CRNN_ERR_UNSUPPORTED;        // pixel-streaming kernel (gemm_wgrad.hip) where its shape rules hold, else the tile GEMM
+        if (!(cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS) && crnn_pwconv_wgrad_stream_supported(M, co, ci) == CRNN_OK)
+          rc = crnn_pwconv_bnrelu6_wgrad_stream(c.w("d" + p), c.w("bn1s" + p), gB, c.g(bp + "_pw"), M, co, ci, cw.scratch(), kGemmScratchBytes, cw.s);
+        if (rc == CRNN_ERR_UNSUPPORTED)
+          rc = crnn_pwconv_bnrelu6_wgrad(c.w("d" + p), c.w("bn1s" + p), gB, c.g(bp + "_pw"), M, co, ci, cw.scratch(), kGemmScratchBytes, cw.s);
+        CRNN_TRY(rc);
+      }
       else CRNN_TRY(gemm_t(cw, 2, c.w("a" + p), dtd, gB, dtq, c.g(bp + "_pw"), CRNN_F32, ci, co, (int)M, ci, co, co));
       if (side) CRNN_TRY(fj.mark(&gB_free));
       // data gradient da[M][ci] = dq[M][co] . W[ci][co]^T: the persistent LDS-DMA kernels where their shape rules hold

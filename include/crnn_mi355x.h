@@ -299,6 +299,17 @@ int crnn_gemm_wres_bf16(const void* X, const void* W, void* Y, int M, int N, int
  * squares over the whole launch: stat_partials (may be NULL) = [crnn_pwconv_fwd_wres_rows(M, N, K)][2][N], every element written.
  * q is bit-identical to crnn_pwconv_bnrelu6_fwd(w_transposed = 1, bf16 q); the statistics are the same sums in a different order.
  * Supported (else -3): M % 128 == 0, N % 128 == 0, N <= 1024, K in {64, 128, 256, 512}. */
+/* The weight gradient of the same convolution as a pixel stream (gemm_wgrad.hip): dw[K][N] (fp32) = ReLU6(BN(d))^T . g, d and g bf16.
+ * A workgroup keeps one 128 x 128 output tile in its MFMA waves' registers over a contiguous range of 64-pixel chunks; its IO waves
+ * load the d / g rows three chunks ahead, apply the BatchNorm + ReLU6 (the arithmetic of crnn_pwconv_bnrelu6_wgrad bit for bit) and
+ * write both operands k-major into an LDS ring; the tiles of a range share an XCD; partial tiles [ranges][K][N] go to scratch
+ * (crnn_pwconv_wgrad_stream_scratch_bytes) and a fixed-order second stage sums them.  Deterministic; agrees with
+ * crnn_pwconv_bnrelu6_wgrad to fp32 summation round-off (other range boundaries).  Supported (else -3): M % 64 == 0, K % 128 == 0,
+ * N % 128 == 0, K, N <= 1024. */
+int crnn_pwconv_wgrad_stream_supported(long M, int N, int K);
+size_t crnn_pwconv_wgrad_stream_scratch_bytes(long M, int N, int K);
+int crnn_pwconv_bnrelu6_wgrad_stream(const void* d, const float* in_bnstate, const void* g, float* dw, long M, int N, int K, float* scratch,
+                                     size_t scratch_bytes, crnn_stream_t stream);
 int crnn_pwconv_fwd_wres_supported(long M, int N, int K);
 int crnn_pwconv_fwd_wres_rows(long M, int N, int K);
 int crnn_pwconv_bnrelu6_fwd_wres(const void* d, const float* in_bnstate, const void* wT, void* q, long M, int N, int K, float* stat_partials,

@@ -824,6 +824,41 @@ def test_weights_resident_forward_pointwise_equals_the_tile_kernel(M, N, K):
     assert L().crnn_pwconv_fwd_wres_supported(M + 64, N, K) == -3 and L().crnn_pwconv_fwd_wres_supported(M, N + 64, K) == -3
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (64 * 7, 256, 128), (64 * 1000, 128, 256), (64 * 531, 512, 512), (64 * 3000 + 64, 256, 256), (64 * 40, 1024, 128)])
+def test_streaming_pointwise_weight_gradient_equals_the_tile_kernel(M, N, K):
+    """crnn_pwconv_bnrelu6_wgrad_stream (output tile in the MFMA waves' registers, IO waves streaming BatchNorm + ReLU6-transformed d
+    rows and g rows k-major through an LDS ring, ranges of chunks per workgroup, fixed-order second stage) against
+    crnn_pwconv_bnrelu6_wgrad (tile GEMM, other range boundaries): fp32 summation round-off; and against the fp64 product of
+    the transformed operand.  One chunk in all, ranges shorter than the pipeline, ragged last range, 1..32 output tiles; repeated
+    launches give the same bits (deterministic)."""
+    rs = np.random.RandomState(M % 9973 + N + K)
+    d = _bf16_round(rs.normal(size=(M, K)) * 2.0); g = _bf16_round(rs.normal(size=(M, N)))
+    mean, var = rs.normal(size=K) * 0.3, rs.uniform(0.5, 2.0, size=K)
+    scale = rs.normal(size=K) * 0.3 + 1.0; shift = rs.normal(size=K) * 0.5 + 1.0
+    st = dev(np.concatenate([mean, var, scale, shift]))
+    dd, gd = _to_bf16_dev(d), _to_bf16_dev(g)
+    assert L().crnn_pwconv_wgrad_stream_supported(M, N, K) == 0
+    nb = L().crnn_pwconv_wgrad_stream_scratch_bytes(M, N, K)
+    assert 0 < nb <= 64 << 20
+    scratch = torch.empty(16 << 20, dtype=torch.float32, device="cuda")
+    dw1 = torch.full((K, N), 7.0, device="cuda"); dw1b = torch.full((K, N), 5.0, device="cuda")
+    ok(L().crnn_pwconv_bnrelu6_wgrad_stream(P(dd), P(st), P(gd), P(dw1), M, N, K, P(scratch), ctypes.c_size_t(scratch.numel() * 4), S()))
+    scratch.fill_(float("nan"))
+    ok(L().crnn_pwconv_bnrelu6_wgrad_stream(P(dd), P(st), P(gd), P(dw1b), M, N, K, P(scratch), ctypes.c_size_t(scratch.numel() * 4), S()))
+    assert torch.equal(dw1, dw1b)
+    dw2 = zeros(K, N)
+    ok(L().crnn_pwconv_bnrelu6_wgrad(P(dd), P(st), P(gd), P(dw2), M, N, K, P(scratch), ctypes.c_size_t(scratch.numel() * 4), S()))
+    a = _bf16_round(np.clip(d * scale + shift, 0.0, 6.0))
+    ref = a.T @ g
+    # fp32 accumulation of a NON-NEGATIVE operand (ReLU6 output) over up to ~200 k pixels: the running sums grow monotonically, the
+    # rounding errors of a chain of n chunks add up to ~n * 2^-24 of the sum (measured 1.9e-4 of the largest entry at M = 192 k)
+    tol = (2e-5 + 6e-8 * M / 64) * np.abs(ref).max()
+    assert_close(host(dw1), host(dw2), rtol=1e-4, atol=tol, what="stream vs tile kernel")
+    # (the fp64 reference rounds ReLU6(BN(d)) to bf16 from fp64, the device from its fp32 fma: a few operands differ by one bf16 ulp)
+    assert_close(host(dw1), ref, rtol=1e-4, atol=tol + 1e-3 * np.abs(ref).max(), what="stream vs fp64")
+    assert L().crnn_pwconv_wgrad_stream_supported(M + 32, N, K) == -3 and L().crnn_pwconv_wgrad_stream_supported(M, N, 64) == -3
+
+
 def test_bilstm_bf16_recurrent_weights_track_the_fp64_cell():
     """crnn_lstm_fwd_ex / crnn_lstm_bwd_ex with dt_u = bf16: recurrent products on the bf16 MFMA (weights stored bf16, the
     state rounded to bf16 as it is packed).  Against the fp64 cell evaluated with the SAME bf16-rounded weights the only
