@@ -37,6 +37,9 @@ struct WgParams {
   int TI, TJ;        // output tiles along K (rows) and N (columns)
   int nsplit;        // reduction ranges; grid = 8 * ceil(TI * TJ * nsplit / 8) workgroups, id -> (xcd, tile, range) below
   int per;           // chunks per range (the last range may be shorter)
+#ifdef CRNN_WG_TRACE
+  unsigned long long* trace;   // [2][64][4] s_memrealtime stamps of workgroup 8: IO wave 4, MFMA wave 0
+#endif
 };
 
 constexpr int kLd = 128 + 32;                 // bf16 row stride of a k-major operand stage (320 B)
@@ -62,7 +65,9 @@ __device__ __forceinline__ bf16x8_t wg_frag(const unsigned char* Xs, int r0, int
   return __builtin_bit_cast(bf16x8_t, make_uint4(a.x, a.y, b.x, b.y));
 }
 
-__global__ __launch_bounds__(512) void pw_wgrad_stream_kernel(WgParams p) {
+template <int NIO>   // IO waves (4 or 8): 16 / NIO 16-byte pieces of each operand per lane and chunk
+__global__ __launch_bounds__(256 + 64 * NIO) void pw_wgrad_stream_kernel(WgParams p) {
+  constexpr int NP = 16 / NIO;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // kRing x (A stage | B stage)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -89,7 +94,14 @@ __global__ __launch_bounds__(512) void pw_wgrad_stream_kernel(WgParams p) {
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     int slot = 0;
     for (int s = 0; s < total; ++s) {
+#ifdef CRNN_WG_TRACE
+      const bool tr = p.trace && wg == 8 && wave == 0 && lane == 0 && s < 64;
+      if (tr) p.trace[256 + s * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+#endif
       __builtin_amdgcn_s_barrier();                             // stage s is in LDS; stage s-1's slot is released
+#ifdef CRNN_WG_TRACE
+      if (tr) p.trace[256 + s * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
       const unsigned char* As = smem + slot * (2 * kOp);
       const unsigned char* Bs = As + kOp;
       slot = slot + 1 == kRing ? 0 : slot + 1;
@@ -125,7 +137,7 @@ __global__ __launch_bounds__(512) void pw_wgrad_stream_kernel(WgParams p) {
   // -------------------------------------------------------------------------- IO waves
   const int w = wave - 4;
   const int c16 = lane & 15;                                    // 16-byte piece of a 256-byte tile row: channels 8 c16 .. +7
-  const int pxl = w * 4 + (lane >> 4);                          // pixel row within a group of 16 (chunk = 4 groups)
+  const int pxl = w * 4 + (lane >> 4);                          // pixel row within a group of 4 NIO (chunk = NP groups)
   f32x2_t sc[4], sh[4];
   {
     const float* s = p.scale + ti * 128 + c16 * 8; const float* t = p.shift + ti * 128 + c16 * 8;
@@ -134,37 +146,63 @@ __global__ __launch_bounds__(512) void pw_wgrad_stream_kernel(WgParams p) {
   }
   const bf16_t* dbase = p.D + (long)ti * 128 + c16 * 8;
   const bf16_t* gbase = p.G + (long)tj * 128 + c16 * 8;
-  u32x4 ra[kD][4], rg[kD][4];
-  auto load = [&](int s, u32x4 (&xa)[4], u32x4 (&xg)[4]) {
+  u32x4 ra[kD][NP], rg[kD][NP];
+  auto load1 = [&](int s, int u, u32x4& xa, u32x4& xg) {
     s = s < total ? s : total - 1;                              // past the end: a valid address, the data lands in a consumed slot
-    const long row0 = (long)(c0 + s) * 64 + pxl;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (CRNN_WG_EXP & 4) { xa[u] = u32x4{(unsigned)s, 0u, 0u, 0u}; xg[u] = xa[u]; continue; }
-      xa[u] = *reinterpret_cast<const u32x4*>(dbase + (row0 + 16 * u) * p.K);
-      xg[u] = *reinterpret_cast<const u32x4*>(gbase + (row0 + 16 * u) * p.N);
-    }
+    const long row = (long)(c0 + s) * 64 + pxl + 4 * NIO * u;
+    if (CRNN_WG_EXP & 4) { xa = u32x4{(unsigned)s, 0u, 0u, 0u}; xg = xa; return; }
+    xa = *reinterpret_cast<const u32x4*>(dbase + row * p.K);
+    xg = *reinterpret_cast<const u32x4*>(gbase + row * p.N);
   };
-  auto write = [&](int s, const u32x4 (&xa)[4], const u32x4 (&xg)[4]) {
+  auto load = [&](int s, u32x4 (&xa)[NP], u32x4 (&xg)[NP]) {
+#pragma unroll
+    for (int u = 0; u < NP; ++u) load1(s, u, xa[u], xg[u]);
+  };
+  auto write1 = [&](int s, int u, const u32x4& xa, const u32x4& xg) {
     unsigned char* As = smem + (s % kRing) * (2 * kOp);
     unsigned char* Bs = As + kOp;
+    const int px = pxl + 4 * NIO * u;
+    u32x4 o;
+    if (CRNN_WG_EXP & 1) o = xa; else {
+      o.x = wg_bnrelu6_pair(xa.x, sc[0], sh[0]); o.y = wg_bnrelu6_pair(xa.y, sc[1], sh[1]);
+      o.z = wg_bnrelu6_pair(xa.z, sc[2], sh[2]); o.w = wg_bnrelu6_pair(xa.w, sc[3], sh[3]);
+    }
+    *reinterpret_cast<u32x4*>(As + px * (kLd * 2) + c16 * 16) = o;
+    *reinterpret_cast<u32x4*>(Bs + px * (kLd * 2) + c16 * 16) = xg;
+  };
+  auto write = [&](int s, const u32x4 (&xa)[NP], const u32x4 (&xg)[NP]) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int px = pxl + 16 * u;
-      u32x4 o;
-      if (CRNN_WG_EXP & 1) o = xa[u]; else {
-      o.x = wg_bnrelu6_pair(xa[u].x, sc[0], sh[0]); o.y = wg_bnrelu6_pair(xa[u].y, sc[1], sh[1]);
-      o.z = wg_bnrelu6_pair(xa[u].z, sc[2], sh[2]); o.w = wg_bnrelu6_pair(xa[u].w, sc[3], sh[3]);
-      }
-      *reinterpret_cast<u32x4*>(As + px * (kLd * 2) + c16 * 16) = o;
-      *reinterpret_cast<u32x4*>(Bs + px * (kLd * 2) + c16 * 16) = xg[u];
+    for (int u = 0; u < NP; ++u) write1(s, u, xa[u], xg[u]);
+  };
+  // one chunk piece at a time: transform + stage it, then refill its registers -- the two loads of a piece go out between the
+  // vector work of two pieces instead of eight in a burst (a burst stalls the wave at the texture-address queue for ~0.4 us)
+  auto write_load = [&](int sw, int sl, u32x4 (&xa)[NP], u32x4 (&xg)[NP]) {
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      write1(sw, u, xa[u], xg[u]);
+      __builtin_amdgcn_sched_barrier(0);
+      load1(sl, u, xa[u], xg[u]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   // barrier s (s = 0 .. total): before it stage s is written; after it the slot of stage s-1 is free -> stage s+2 goes there
-  auto step = [&](int s, u32x4 (&xa)[4], u32x4 (&xg)[4]) {   // xa/xg = buffer (s + 2) % kD
+  auto step = [&](int s, u32x4 (&xa)[NP], u32x4 (&xg)[NP]) {   // xa/xg = buffer (s + 2) % kD
+#ifdef CRNN_WG_TRACE
+    const bool tr = p.trace && wg == 8 && w == 0 && lane == 0 && s < 64;
+    if (tr) p.trace[s * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef CRNN_WG_TRACE
+    if (tr) p.trace[s * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
     __builtin_amdgcn_s_barrier();
-    write(s + 2, xa, xg); load(s + 2 + kD, xa, xg);
+#ifdef CRNN_WG_TRACE
+    if (tr) p.trace[s * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
+    write_load(s + 2, s + 2 + kD, xa, xg);
+#ifdef CRNN_WG_TRACE
+    if (tr) p.trace[s * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+#endif
   };
 #pragma unroll
   for (int k = 0; k < kD; ++k) load(k, ra[k], rg[k]);
@@ -237,15 +275,20 @@ extern "C" int crnn_pwconv_bnrelu6_wgrad_stream(const void* d, const float* in_b
   p.D = (const bf16_t*)d; p.G = (const bf16_t*)g; p.part = scratch; p.scale = in_bnstate + 2L * K; p.shift = in_bnstate + 3L * K;
   p.M = (int)M; p.N = N; p.K = K;
   wg_geom(M, N, K, p, grid);
+#ifdef CRNN_WG_TRACE
+  { const char* e = getenv("CRNN_WG_TRACE"); p.trace = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
+#endif
   if ((size_t)p.nsplit * K * N * sizeof(float) > scratch_bytes) return CRNN_ERR_UNSUPPORTED;
   const int lds = kRing * 2 * kOp;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)pw_wgrad_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)pw_wgrad_stream_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pw_wgrad_stream_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(pw_wgrad_stream_kernel, dim3(grid), dim3(512), lds, stream, p);
+  if (crnn_knob("CRNN_WG_NIO", 8) == 4) hipLaunchKernelGGL(pw_wgrad_stream_kernel<4>, dim3(grid), dim3(512), lds, stream, p);
+  else hipLaunchKernelGGL(pw_wgrad_stream_kernel<8>, dim3(grid), dim3(768), lds, stream, p);
   CRNN_LAUNCH_CHECK();
   const long total = (long)K * N;
   hipLaunchKernelGGL(pw_wgrad_sum_kernel, dim3(cdiv(total, 1024)), dim3(256), 0, stream, scratch, p.nsplit, total, dw);

@@ -135,7 +135,10 @@ __device__ __forceinline__ void wres_compute(const unsigned char* smem, unsigned
           *reinterpret_cast<uint4*>(ob + px * orow + (((4 * (wave * CB + cb) + 2 * pr + half) ^ (px & 15)) * 16)) = make_uint4(sa.x, sb.x, sa.y, sb.y);
         }
     }
-    __builtin_amdgcn_s_barrier();                              // the stripe's last stage: also hands the staged tile to the storers
+    // the stripe's last stage: also hands the staged tile to the storer / IO waves -- the raw barrier orders nothing by itself, the
+    // tile's ds_writes must have completed before this wave arrives (the compiler does not wait for LDS stores at s_barrier)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   }
 }
 

@@ -135,6 +135,7 @@ Plan make_plan(const crnn_config* c) {
     maxparts = lmax(maxparts, (long)crnn_dwconv_bwd_fused_rows(d.B, d.bh[i], d.bw[i], ci) * 9L * ci);
     maxparts = lmax(maxparts, (long)crnn_colreduce_chunks(M) * 2L * lmax(ci, co));
     maxparts = lmax(maxparts, (long)crnn_pwconv_stat_rows(M) * 2L * co);
+    maxparts = lmax(maxparts, (long)crnn_pwconv_fwd_wres_rows(M, co, ci) * 2L * co);   // one row per IO wave and stripe lane: more rows than tiles at small batches
     maxparts = lmax(maxparts, (long)crnn_bn_bwd_chunks(M) * 2L * lmax(ci, co));
   }
   const long TB = (long)d.T * B;

@@ -789,7 +789,8 @@ def test_weights_resident_gemm_equals_the_tile_kernel(M, N, K):
     assert L().crnn_gemm_wres_supported(1152, 64) == -3
 
 
-@pytest.mark.parametrize("M,N,K", [(128 * 3, 128, 64), (128 * 40, 256, 128), (128 * 700 + 0, 128, 64), (128 * 300, 512, 256), (128 * 530, 512, 512), (128, 1024, 64)])
+@pytest.mark.parametrize("M,N,K", [(128 * 3, 128, 64), (128 * 40, 256, 128), (128 * 700 + 0, 128, 64), (128 * 300, 512, 256), (128 * 530, 512, 512), (128, 1024, 64),
+                                   (128 * 117, 256, 128), (128 * 117, 128, 64), (128 * 1500, 256, 256)])
 def test_weights_resident_forward_pointwise_equals_the_tile_kernel(M, N, K):
     """crnn_pwconv_bnrelu6_fwd_wres (register-resident weights, IO waves applying BatchNorm + ReLU6 on the way into the LDS ring,
     draining the staged stripes and accumulating the BatchNorm-2 statistics) against crnn_pwconv_bnrelu6_fwd (tile kernel, W^T
@@ -805,8 +806,10 @@ def test_weights_resident_forward_pointwise_equals_the_tile_kernel(M, N, K):
     assert L().crnn_pwconv_fwd_wres_supported(M, N, K) == 0
     rows = L().crnn_pwconv_fwd_wres_rows(M, N, K)
     q1 = torch.full((M + 2, N), 7.0, dtype=torch.bfloat16, device="cuda"); parts1 = torch.full((rows, 2, N), 3.0, device="cuda")
-    for rep in range(2):
+    for rep in range(4):                                      # repeated: a hand-off race between the wave roles shows as run-to-run differences
         ok(L().crnn_pwconv_bnrelu6_fwd_wres(P(dd), P(st), P(Wd), P(q1), M, N, K, P(parts1), S()))
+        if rep == 0: q_first, parts_first = q1.clone(), parts1.clone()
+        else: assert torch.equal(q_first, q1) and torch.equal(parts_first, parts1), "run %d differs from run 0" % rep
     rows2 = L().crnn_pwconv_stat_rows(M)
     q2 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda"); parts2 = zeros(rows2, 2, N)
     ok(L().crnn_pwconv_bnrelu6_fwd(P(dd), P(st), P(Wd), P(q2), M, N, K, P(parts2), 1, 1, S()))
