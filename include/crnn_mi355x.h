@@ -37,14 +37,16 @@ typedef struct {
   int mfma_bf16;    /* 0 = fp32 MFMA everywhere (parity mode); 1 = conv-stack / dense / RNN-input GEMMs multiply in bf16
                        (operands rounded while staged into LDS, fp32 accumulate, fp32 tensors in HBM); 2 = as 1 and the
                        conv-stack activations / gradients are stored as bf16 in HBM (statistics, RNN, CTC, optimizer fp32) */
-  int flags;        /* bit set of CRNN_FLAG_* (0 = the default schedule); A/B switches, every variant gives the same numbers */
+  int flags;        /* bit set of CRNN_FLAG_* (0 = the default schedule); A/B switches: bit-identical results except where a flag says otherwise */
 } crnn_config;
 #define CRNN_FLAG_NO_DW_BWD_FUSION 16 /* bf16-storage training: depthwise-stage backward as three kernels (BatchNorm backward pass 2, depthwise weight
                                          gradient, depthwise data gradient) instead of crnn_dwconv3x3_bwd_fused; same data gradients bit for bit */
 #define CRNN_FLAG_NO_DW_BN_FUSION 8   /* bf16-storage training: materialise a = ReLU6(BN(d)) in a pass of its own instead of applying it while the
                                          pointwise GEMMs stage their operand; bit-identical */
-#define CRNN_FLAG_GEMM_TILE_KERNELS 2 /* pointwise-conv data gradients on the tile-per-workgroup GEMM (crnn_gemm_bf16_ex) instead of
-                                         the persistent LDS-DMA kernel (crnn_gemm_nt_bf16); same products, same k order */
+#define CRNN_FLAG_GEMM_TILE_KERNELS 2 /* every pointwise conv of the conv stack (forward, data gradient, weight gradient) on the tile-per-workgroup
+                                         GEMM (crnn_gemm_bf16_ex / crnn_pwconv_bnrelu6_*) instead of the streaming kernels (crnn_pwconv_bnrelu6_fwd_wres,
+                                         crnn_gemm_wres_bf16, crnn_pwconv_bnrelu6_wgrad_stream).  Same products and data gradients bit for bit; the
+                                         BatchNorm-2 statistics and the weight gradients are the same sums in another order (fp32 round-off) */
 #define CRNN_FLAG_RNN_STEP_KERNELS 1  /* LSTM recurrences as one launch per timestep (crnn_lstm_*_ex) instead of the
                                          persistent one-launch-per-layer kernels (crnn_lstm_*_persist); bit-identical */
 
