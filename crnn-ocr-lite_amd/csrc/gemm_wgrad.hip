@@ -37,6 +37,7 @@ struct WgParams {
   int TI, TJ;        // output tiles along K (rows) and N (columns)
   int nsplit;        // reduction ranges; grid = 8 * ceil(TI * TJ * nsplit / 8) workgroups, id -> (xcd, tile, range) below
   int per;           // chunks per range (the last range may be shorter)
+  int lda, ldg;      // row strides of D and G in elements (bf16 convs: K and N)
 #ifdef CRNN_WG_TRACE
   unsigned long long* trace;   // [2][64][4] s_memrealtime stamps of workgroup 8: IO wave 4, MFMA wave 0
 #endif
@@ -65,9 +66,11 @@ __device__ __forceinline__ bf16x8_t wg_frag(const unsigned char* Xs, int r0, int
   return __builtin_bit_cast(bf16x8_t, make_uint4(a.x, a.y, b.x, b.y));
 }
 
-template <int NIO>   // IO waves (4 or 8): 16 / NIO 16-byte pieces of each operand per lane and chunk
+// F32: both operands are fp32 tensors rounded to bf16 on the way in (v_cvt_pk_bf16_f32, RNE -- what the tile GEMM does while it stages
+// them), no BatchNorm transform: the weight gradients of the recurrent layers, dW = X^T dZ and dU = H^T dZ over the T*B rows
+template <int NIO, bool F32>   // IO waves (4 or 8): 16 / NIO 8-channel pieces of each operand per lane and chunk
 __global__ __launch_bounds__(256 + 64 * NIO) void pw_wgrad_stream_kernel(WgParams p) {
-  constexpr int NP = 16 / NIO;
+  constexpr int NP = 16 / NIO, RW = F32 ? 2 : 1;              // 16-byte registers per piece
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // kRing x (A stage | B stage)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -139,54 +142,68 @@ __global__ __launch_bounds__(256 + 64 * NIO) void pw_wgrad_stream_kernel(WgParam
   const int c16 = lane & 15;                                    // 16-byte piece of a 256-byte tile row: channels 8 c16 .. +7
   const int pxl = w * 4 + (lane >> 4);                          // pixel row within a group of 4 NIO (chunk = NP groups)
   f32x2_t sc[4], sh[4];
-  {
+  if constexpr (!F32) {
     const float* s = p.scale + ti * 128 + c16 * 8; const float* t = p.shift + ti * 128 + c16 * 8;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { sc[e] = f32x2_t{s[2 * e], s[2 * e + 1]}; sh[e] = f32x2_t{t[2 * e], t[2 * e + 1]}; }
   }
-  const bf16_t* dbase = p.D + (long)ti * 128 + c16 * 8;
-  const bf16_t* gbase = p.G + (long)tj * 128 + c16 * 8;
-  u32x4 ra[kD][NP], rg[kD][NP];
-  auto load1 = [&](int s, int u, u32x4& xa, u32x4& xg) {
+  const bf16_t* dbase = p.D + (F32 ? 2L : 1L) * ((long)ti * 128 + c16 * 8);    // (fp32 operands: the same pointers, 4-byte elements)
+  const bf16_t* gbase = p.G + (F32 ? 2L : 1L) * ((long)tj * 128 + c16 * 8);
+  u32x4 ra[kD][NP * RW], rg[kD][NP * RW];
+  auto load1 = [&](int s, int u, u32x4* xa, u32x4* xg) {       // RW registers each
     s = s < total ? s : total - 1;                              // past the end: a valid address, the data lands in a consumed slot
     const long row = (long)(c0 + s) * 64 + pxl + 4 * NIO * u;
-    if (CRNN_WG_EXP & 4) { xa = u32x4{(unsigned)s, 0u, 0u, 0u}; xg = xa; return; }
-    xa = *reinterpret_cast<const u32x4*>(dbase + row * p.K);
-    xg = *reinterpret_cast<const u32x4*>(gbase + row * p.N);
+    if (CRNN_WG_EXP & 4) { xa[0] = u32x4{(unsigned)s, 0u, 0u, 0u}; xg[0] = xa[0]; if (F32) { xa[RW - 1] = xa[0]; xg[RW - 1] = xa[0]; } return; }
+    if constexpr (F32) {
+      const float* pa = reinterpret_cast<const float*>(dbase) + row * p.lda; const float* pg = reinterpret_cast<const float*>(gbase) + row * p.ldg;
+      xa[0] = *reinterpret_cast<const u32x4*>(pa); xa[1] = *reinterpret_cast<const u32x4*>(pa + 4);
+      xg[0] = *reinterpret_cast<const u32x4*>(pg); xg[1] = *reinterpret_cast<const u32x4*>(pg + 4);
+    } else {
+      xa[0] = *reinterpret_cast<const u32x4*>(dbase + row * p.lda);
+      xg[0] = *reinterpret_cast<const u32x4*>(gbase + row * p.ldg);
+    }
   };
-  auto load = [&](int s, u32x4 (&xa)[NP], u32x4 (&xg)[NP]) {
+  auto load = [&](int s, u32x4 (&xa)[NP * RW], u32x4 (&xg)[NP * RW]) {
 #pragma unroll
-    for (int u = 0; u < NP; ++u) load1(s, u, xa[u], xg[u]);
+    for (int u = 0; u < NP; ++u) load1(s, u, &xa[u * RW], &xg[u * RW]);
   };
-  auto write1 = [&](int s, int u, const u32x4& xa, const u32x4& xg) {
+  auto round8 = [](const u32x4& lo, const u32x4& hi) {          // 8 fp32 -> 8 bf16
+    return u32x4{pack2_bf16(__uint_as_float(lo.x), __uint_as_float(lo.y)), pack2_bf16(__uint_as_float(lo.z), __uint_as_float(lo.w)),
+                 pack2_bf16(__uint_as_float(hi.x), __uint_as_float(hi.y)), pack2_bf16(__uint_as_float(hi.z), __uint_as_float(hi.w))};
+  };
+  auto write1 = [&](int s, int u, const u32x4* xa, const u32x4* xg) {
     unsigned char* As = smem + (s % kRing) * (2 * kOp);
     unsigned char* Bs = As + kOp;
     const int px = pxl + 4 * NIO * u;
-    u32x4 o;
-    if (CRNN_WG_EXP & 1) o = xa; else {
-      o.x = wg_bnrelu6_pair(xa.x, sc[0], sh[0]); o.y = wg_bnrelu6_pair(xa.y, sc[1], sh[1]);
-      o.z = wg_bnrelu6_pair(xa.z, sc[2], sh[2]); o.w = wg_bnrelu6_pair(xa.w, sc[3], sh[3]);
+    u32x4 o, og;
+    if constexpr (F32) { o = round8(xa[0], xa[1]); og = round8(xg[0], xg[1]); }
+    else {
+      og = xg[0];
+      if (CRNN_WG_EXP & 1) o = xa[0]; else {
+        o.x = wg_bnrelu6_pair(xa[0].x, sc[0], sh[0]); o.y = wg_bnrelu6_pair(xa[0].y, sc[1], sh[1]);
+        o.z = wg_bnrelu6_pair(xa[0].z, sc[2], sh[2]); o.w = wg_bnrelu6_pair(xa[0].w, sc[3], sh[3]);
+      }
     }
     *reinterpret_cast<u32x4*>(As + px * (kLd * 2) + c16 * 16) = o;
-    *reinterpret_cast<u32x4*>(Bs + px * (kLd * 2) + c16 * 16) = xg;
+    *reinterpret_cast<u32x4*>(Bs + px * (kLd * 2) + c16 * 16) = og;
   };
-  auto write = [&](int s, const u32x4 (&xa)[NP], const u32x4 (&xg)[NP]) {
+  auto write = [&](int s, const u32x4 (&xa)[NP * RW], const u32x4 (&xg)[NP * RW]) {
 #pragma unroll
-    for (int u = 0; u < NP; ++u) write1(s, u, xa[u], xg[u]);
+    for (int u = 0; u < NP; ++u) write1(s, u, &xa[u * RW], &xg[u * RW]);
   };
   // one chunk piece at a time: transform + stage it, then refill its registers -- the two loads of a piece go out between the
   // vector work of two pieces instead of eight in a burst (a burst stalls the wave at the texture-address queue for ~0.4 us)
-  auto write_load = [&](int sw, int sl, u32x4 (&xa)[NP], u32x4 (&xg)[NP]) {
+  auto write_load = [&](int sw, int sl, u32x4 (&xa)[NP * RW], u32x4 (&xg)[NP * RW]) {
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
-      write1(sw, u, xa[u], xg[u]);
+      write1(sw, u, &xa[u * RW], &xg[u * RW]);
       __builtin_amdgcn_sched_barrier(0);
-      load1(sl, u, xa[u], xg[u]);
+      load1(sl, u, &xa[u * RW], &xg[u * RW]);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
   // barrier s (s = 0 .. total): before it stage s is written; after it the slot of stage s-1 is free -> stage s+2 goes there
-  auto step = [&](int s, u32x4 (&xa)[NP], u32x4 (&xg)[NP]) {   // xa/xg = buffer (s + 2) % kD
+  auto step = [&](int s, u32x4 (&xa)[NP * RW], u32x4 (&xg)[NP * RW]) {   // xa/xg = buffer (s + 2) % kD
 #ifdef CRNN_WG_TRACE
     const bool tr = p.trace && wg == 8 && w == 0 && lane == 0 && s < 64;
     if (tr) p.trace[s * 4 + 0] = __builtin_amdgcn_s_memrealtime();
@@ -223,7 +240,7 @@ __global__ __launch_bounds__(256 + 64 * NIO) void pw_wgrad_stream_kernel(WgParam
 }
 
 // out[i] = sum_s part[s][i], s ascending in a fixed grouping (deterministic)
-__global__ __launch_bounds__(256) void pw_wgrad_sum_kernel(const float* __restrict__ part, int nsplit, long total, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void pw_wgrad_sum_kernel(const float* __restrict__ part, int nsplit, long total, float* __restrict__ out, int N, int ldc) {
   const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= total) return;
   float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
@@ -234,7 +251,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_sum_kernel(const float* __restri
     a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
   }
   if (s < nsplit) { const float4 v0 = *reinterpret_cast<const float4*>(part + (long)s * total + i); a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w; }
-  *reinterpret_cast<float4*>(out + i) = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+  *reinterpret_cast<float4*>(out + (i / N) * ldc + i % N) = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
 }
 
 void wg_geom(long M, int N, int K, WgParams& p, int& grid) {
@@ -244,7 +261,7 @@ void wg_geom(long M, int N, int K, WgParams& p, int& grid) {
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
   int ns = (cus / tiles) & ~7;                                  // one workgroup per CU, a multiple of 8 ranges (8 XCDs)
   if (ns < 8) ns = 8;
-  while (ns > 8 && p.chunks / ns < 4 * kD) ns -= 8;             // a range is at least a few pipeline depths long
+  while (ns > 8 && p.chunks / ns < 2 * kD) ns -= 8;             // a range is at least two pipeline depths long
   if (ns > p.chunks) ns = p.chunks;                             // (tiny inputs: ranges of one chunk; some of the 8 XCD lanes stay empty)
   p.nsplit = ns;
   p.per = cdiv(p.chunks, ns);
@@ -265,33 +282,58 @@ extern "C" size_t crnn_pwconv_wgrad_stream_scratch_bytes(long M, int N, int K) {
   WgParams p; int grid; wg_geom(M, N, K, p, grid);
   return (size_t)p.nsplit * K * N * sizeof(float);
 }
+namespace {
+template <bool F32>
+int wg_launch(WgParams& p, long M, float* out, int ldc, float* scratch, size_t scratch_bytes, hipStream_t stream) {
+  int grid;
+  wg_geom(M, p.N, p.K, p, grid);
+#ifdef CRNN_WG_TRACE
+  { const char* e = getenv("CRNN_WG_TRACE"); p.trace = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
+#endif
+  if ((size_t)p.nsplit * p.K * p.N * sizeof(float) > scratch_bytes) return CRNN_ERR_UNSUPPORTED;
+  const int lds = kRing * 2 * kOp;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)pw_wgrad_stream_kernel<4, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pw_wgrad_stream_kernel<8, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  if (crnn_knob("CRNN_WG_NIO", 8) == 4) hipLaunchKernelGGL((pw_wgrad_stream_kernel<4, F32>), dim3(grid), dim3(512), lds, stream, p);
+  else hipLaunchKernelGGL((pw_wgrad_stream_kernel<8, F32>), dim3(grid), dim3(768), lds, stream, p);
+  CRNN_LAUNCH_CHECK();
+  const long total = (long)p.K * p.N;
+  hipLaunchKernelGGL(pw_wgrad_sum_kernel, dim3(cdiv(total, 1024)), dim3(256), 0, stream, scratch, p.nsplit, total, out, p.N, ldc);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+}  // namespace
+
 // dw[K][N] (fp32) = ReLU6(d * scale + shift)^T [K][M] . g[M][N]; d, g bf16; in_bnstate = [mean|var|scale|shift] of the BatchNorm on d
 extern "C" int crnn_pwconv_bnrelu6_wgrad_stream(const void* d, const float* in_bnstate, const void* g, float* dw, long M, int N, int K,
                                                 float* scratch, size_t scratch_bytes, hipStream_t stream) {
   if (!in_bnstate || !scratch) return CRNN_ERR_ARG;
   CRNN_TRY(crnn_pwconv_wgrad_stream_supported(M, N, K));
   if ((((uintptr_t)d | (uintptr_t)g | (uintptr_t)dw | (uintptr_t)scratch) & 15)) return CRNN_ERR_UNSUPPORTED;
-  WgParams p; int grid;
+  WgParams p;
   p.D = (const bf16_t*)d; p.G = (const bf16_t*)g; p.part = scratch; p.scale = in_bnstate + 2L * K; p.shift = in_bnstate + 3L * K;
-  p.M = (int)M; p.N = N; p.K = K;
-  wg_geom(M, N, K, p, grid);
-#ifdef CRNN_WG_TRACE
-  { const char* e = getenv("CRNN_WG_TRACE"); p.trace = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
-#endif
-  if ((size_t)p.nsplit * K * N * sizeof(float) > scratch_bytes) return CRNN_ERR_UNSUPPORTED;
-  const int lds = kRing * 2 * kOp;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)pw_wgrad_stream_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pw_wgrad_stream_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
-  if (crnn_knob("CRNN_WG_NIO", 8) == 4) hipLaunchKernelGGL(pw_wgrad_stream_kernel<4>, dim3(grid), dim3(512), lds, stream, p);
-  else hipLaunchKernelGGL(pw_wgrad_stream_kernel<8>, dim3(grid), dim3(768), lds, stream, p);
-  CRNN_LAUNCH_CHECK();
-  const long total = (long)K * N;
-  hipLaunchKernelGGL(pw_wgrad_sum_kernel, dim3(cdiv(total, 1024)), dim3(256), 0, stream, scratch, p.nsplit, total, dw);
-  CRNN_LAUNCH_CHECK();
-  return CRNN_OK;
+  p.M = (int)M; p.N = N; p.K = K; p.lda = K; p.ldg = N;
+  return wg_launch<false>(p, M, dw, N, scratch, scratch_bytes, stream);
+}
+
+// The same stream for fp32 operands (rounded to bf16 on the way in, like crnn_gemm_bf16_ex mode 2 with fp32 A and B):
+//     C[M][N] (fp32, row stride ldc) = A^T . B,   A [K][lda >= M] fp32, B [K][ldb >= N] fp32, K = the reduction over rows.
+// The weight gradients of the recurrent layers (dW = X^T dZ, dU = H^T dZ over T*B rows).  Supported (else -3): M, N multiples of
+// 128 up to 1024, K a multiple of 64, lda / ldb / ldc multiples of 4, 16-byte aligned pointers; scratch as above.
+extern "C" int crnn_gemm_tn_stream(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, long K, float* scratch,
+                                   size_t scratch_bytes, hipStream_t stream) {
+  if (!scratch) return CRNN_ERR_ARG;
+  CRNN_TRY(crnn_pwconv_wgrad_stream_supported(K, N, M));
+  if (lda < M || ldb < N || ldc < N || ((lda | ldb | ldc) & 3)) return CRNN_ERR_UNSUPPORTED;
+  if ((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)scratch) & 15)) return CRNN_ERR_UNSUPPORTED;
+  if (K * (long)(lda > ldb ? lda : ldb) >= (1L << 30)) return CRNN_ERR_UNSUPPORTED;
+  WgParams p;
+  p.D = (const bf16_t*)A; p.G = (const bf16_t*)B; p.part = scratch; p.scale = nullptr; p.shift = nullptr;
+  p.M = (int)K; p.N = N; p.K = M; p.lda = lda; p.ldg = ldb;
+  return wg_launch<true>(p, K, C, ldc, scratch, scratch_bytes, stream);
 }

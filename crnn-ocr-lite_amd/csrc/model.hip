@@ -503,19 +503,28 @@ static int rnn_bwd_chain(const Ctx& c, int layer, const float* hf, const float* 
   return crnn_lstm_bwd_ex(uf, ub, c.w("cs" + l + "f"), c.w("cs" + l + "b"), c.w("gt" + l + "f"),
                           c.w("gt" + l + "b"), doutf, doutb, ldo, dzf, dzb, c.w("dcf"), c.w("dcb"), T, B, u, dtu, c.s);
 }
+// C[M][N] = A^T B over K rows (weight gradients of the recurrent layers): the streaming kernel in the bf16 modes where its shape
+// rules hold (gemm_wgrad.hip, fp32 operands rounded to bf16 on the way in like the tile GEMM does), else the tile GEMM
+static int gemm_tn(const Ctx& c, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc) {
+  if (c.cfg->mfma_bf16 && !(c.cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS)) {
+    const int rc = crnn_gemm_tn_stream(A, lda, B, ldb, C, ldc, M, N, K, c.scratch(), kGemmScratchBytes, c.s);
+    if (rc != CRNN_ERR_UNSUPPORTED) return rc;
+  }
+  return gemm(c, 2, A, B, C, M, N, K, lda, ldb, ldc);
+}
 static int rnn_bwd_wgrads(const Ctx& c, int layer, const float* xin, int ldx, int din, const float* hf, const float* hb, int ldh) {
   const Dims& d = c.d;
   const int T = d.T, B = d.B, TB = T * B, u = d.u, G = d.G;
   std::string l = std::to_string(layer);
   float* dzf = c.w("dz" + l + "f"); float* dzb = c.w("dz" + l + "b");
   // dW = X^T dZ ; dU = Hprev^T dZ ; db = colsum(dZ)
-  CRNN_TRY(gemm(c, 2, xin, dzf, c.g("rnn" + l + "f_w"), din, G, TB, ldx, G, G));
-  CRNN_TRY(gemm(c, 2, xin, dzb, c.g("rnn" + l + "b_w"), din, G, TB, ldx, G, G));
+  CRNN_TRY(gemm_tn(c, xin, dzf, c.g("rnn" + l + "f_w"), din, G, TB, ldx, G, G));
+  CRNN_TRY(gemm_tn(c, xin, dzb, c.g("rnn" + l + "b_w"), din, G, TB, ldx, G, G));
   const int K1 = (T - 1) * B;
   // forward direction: h_{t-1} pairs with dz_t ; backward direction: h_{t+1} pairs with dz_t
   const int Nh = c.cfg->gru ? 2 * u : G;   // GRU: only the z,r columns see h_prev; the candidate sees r*h_prev
-  CRNN_TRY(gemm(c, 2, hf, dzf + (long)B * G, c.g("rnn" + l + "f_u"), u, Nh, K1, ldh, G, G));
-  CRNN_TRY(gemm(c, 2, hb + (long)B * ldh, dzb, c.g("rnn" + l + "b_u"), u, Nh, K1, ldh, G, G));
+  CRNN_TRY(gemm_tn(c, hf, dzf + (long)B * G, c.g("rnn" + l + "f_u"), u, Nh, K1, ldh, G, G));
+  CRNN_TRY(gemm_tn(c, hb + (long)B * ldh, dzb, c.g("rnn" + l + "b_u"), u, Nh, K1, ldh, G, G));
   if (c.cfg->gru) {
     CRNN_TRY(gemm(c, 2, c.w("cs" + l + "f"), dzf + 2 * u, c.g("rnn" + l + "f_u") + 2 * u, u, u, TB, u, G, G));
     CRNN_TRY(gemm(c, 2, c.w("cs" + l + "b"), dzb + 2 * u, c.g("rnn" + l + "b_u") + 2 * u, u, u, TB, u, G, G));

@@ -312,6 +312,12 @@ int crnn_pwconv_wgrad_stream_supported(long M, int N, int K);
 size_t crnn_pwconv_wgrad_stream_scratch_bytes(long M, int N, int K);
 int crnn_pwconv_bnrelu6_wgrad_stream(const void* d, const float* in_bnstate, const void* g, float* dw, long M, int N, int K, float* scratch,
                                      size_t scratch_bytes, crnn_stream_t stream);
+/* The same stream for fp32 operands (rounded to bf16 on the way in, as crnn_gemm_bf16_ex mode 2 does): C[M][N] (fp32, row stride ldc) =
+ * A^T . B with A [K][lda >= M], B [K][ldb >= N] fp32 and the reduction over the K rows -- the weight gradients of the recurrent layers
+ * (dW = X^T dZ, dU = H^T dZ over T*B rows).  Supported (else -3): M, N multiples of 128 up to 1024, K % 64 == 0, leading dimensions
+ * multiples of 4, 16-byte aligned pointers; scratch: crnn_pwconv_wgrad_stream_scratch_bytes(K, N, M). */
+int crnn_gemm_tn_stream(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, long K, float* scratch,
+                        size_t scratch_bytes, crnn_stream_t stream);
 int crnn_pwconv_fwd_wres_supported(long M, int N, int K);
 int crnn_pwconv_fwd_wres_rows(long M, int N, int K);
 int crnn_pwconv_bnrelu6_fwd_wres(const void* d, const float* in_bnstate, const void* wT, void* q, long M, int N, int K, float* stat_partials,

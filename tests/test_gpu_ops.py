@@ -862,6 +862,31 @@ def test_streaming_pointwise_weight_gradient_equals_the_tile_kernel(M, N, K):
     assert L().crnn_pwconv_wgrad_stream_supported(M + 32, N, K) == -3 and L().crnn_pwconv_wgrad_stream_supported(M, N, 64) == -3
 
 
+@pytest.mark.parametrize("M,N,K,lda,ldb,ldc", [(128, 1024, 13312, 128, 1024, 1024), (256, 1024, 13056, 512, 1024, 1024), (256, 512, 64 * 5, 256, 1024, 1024),
+                                               (128, 128, 64, 128, 128, 128)])
+def test_streaming_tn_gemm_on_fp32_operands_equals_the_tile_kernel(M, N, K, lda, ldb, ldc):
+    """crnn_gemm_tn_stream (the weight-gradient stream on fp32 operands: rows rounded to bf16 on the way into the LDS ring) against
+    crnn_gemm_bf16_ex mode 2 with fp32 A and B (same rounding, other reduction ranges) and against the fp64 product of the
+    bf16-rounded operands: fp32 summation round-off.  The recurrent layers' shapes (T*B rows, strided H operand, partial column range of a
+    wider result), short reductions; the columns of C beyond N stay untouched; repeated launches give the same bits."""
+    rs = np.random.RandomState(M + N + K % 977)
+    A = rs.normal(size=(K, lda)); Bm = rs.normal(size=(K, ldb))
+    Ad, Bd = dev(A), dev(Bm)
+    scratch = torch.empty(16 << 20, dtype=torch.float32, device="cuda")
+    C1 = torch.full((M, ldc), 7.0, device="cuda"); C2 = torch.full((M, ldc), 7.0, device="cuda"); C3 = torch.full((M, ldc), 7.0, device="cuda")
+    ok(L().crnn_gemm_tn_stream(P(Ad), lda, P(Bd), ldb, P(C1), ldc, M, N, K, P(scratch), ctypes.c_size_t(scratch.numel() * 4), S()))
+    scratch.fill_(float("nan"))
+    ok(L().crnn_gemm_tn_stream(P(Ad), lda, P(Bd), ldb, P(C3), ldc, M, N, K, P(scratch), ctypes.c_size_t(scratch.numel() * 4), S()))
+    assert torch.equal(C1, C3)
+    ok(L().crnn_gemm_bf16_ex(2, P(Ad), P(Bd), P(C2), M, N, K, lda, ldb, ldc, None, 0, 0, 0, P(scratch), ctypes.c_size_t(scratch.numel() * 4), 0, 0, 0, S()))
+    ref = _bf16_round(A[:, :M]).T @ _bf16_round(Bm[:, :N])
+    tol = (2e-5 + 6e-8 * K / 64) * np.abs(ref).max() + 1e-5 * np.sqrt(K)
+    assert_close(host(C1)[:, :N], host(C2)[:, :N], rtol=1e-4, atol=tol, what="stream vs tile kernel")
+    assert_close(host(C1)[:, :N], ref, rtol=1e-4, atol=tol, what="stream vs fp64")
+    if ldc > N: assert bool((C1[:, N:] == 7.0).all())
+    assert L().crnn_gemm_tn_stream(P(Ad), lda, P(Bd), ldb, P(C1), ldc, M, N, K - 32, P(scratch), ctypes.c_size_t(scratch.numel() * 4), S()) == -3
+
+
 def test_bilstm_bf16_recurrent_weights_track_the_fp64_cell():
     """crnn_lstm_fwd_ex / crnn_lstm_bwd_ex with dt_u = bf16: recurrent products on the bf16 MFMA (weights stored bf16, the
     state rounded to bf16 as it is packed).  Against the fp64 cell evaluated with the SAME bf16-rounded weights the only
