@@ -70,7 +70,7 @@ __device__ __forceinline__ void fill_load(const FillGeom& g, int base, const bf1
 // the stores into the two ring tiles
 __device__ __forceinline__ void fill_store(const FillGeom& g, int base, const float* cst,
                                            const u32x4 (&vd)[kNCH], const u32x4 (&vg)[kNCH], const u32x4 (&vx)[kNCH], unsigned inside,
-                                           u32x4* tileD16, u32x4* tileX16) {
+                                           float* tileD, float* tileX) {
   float sc[8], sh[8], Pc[8], Qc[8];
   {
     const float* cf = cst + 9 * 64 + 8 * (threadIdx.x & (kFL - 1));
@@ -94,21 +94,30 @@ __device__ __forceinline__ void fill_store(const FillGeom& g, int base, const fl
       int slot = g.slot0 + fy;
       slot -= slot >= g.R ? g.R : 0;
       slot -= slot >= g.R ? g.R : 0;
-      const int li = (slot * g.Wt + fx) * kFL + f8;
-      u32x4 o = {0u, 0u, 0u, 0u};
-      if (inside & (1u << uu)) {
-        float xv[8], gv[8], r[8];
-        widen8(vd[uu], xv); widen8(vg[uu], gv);
+      const int li = ((slot * g.Wt + fx) * kFL + f8) * 8;   // float index: 64 channels x 4 B per pixel and tile
+      float r[8], xw[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { r[e] = 0.f; xw[e] = 0.f; }
+      if (inside & (1u << uu)) {                             // (outside the image both tiles hold zeros: the load address was clamped)
+        float xv[8], gv[8];
+        widen8(vd[uu], xv); widen8(vg[uu], gv); widen8(vx[uu], xw);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float tv = fmaf(xv[e], sc[e], sh[e]);                   // ReLU6 passes the gradient where 0 < BN(d) < 6 (the clamp itself is not needed)
           const float gy = (tv > 0.f && tv < 6.f) ? gv[e] : 0.f;
           r[e] = bn_bwd_dx_pq(xv[e], gy, sc[e], Pc[e], Qc[e]);
         }
-        o = u32x4{pack2_bf16(r[0], r[1]), pack2_bf16(r[2], r[3]), pack2_bf16(r[4], r[5]), pack2_bf16(r[6], r[7])};
+        // dd as the stored bf16 tensor would hold it (round to nearest even), kept as fp32 so that the gradient loops need no widening
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const unsigned w = pack2_bf16(r[e], r[e + 1]);
+          r[e] = __uint_as_float(w << 16); r[e + 1] = __uint_as_float(w & 0xffff0000u);
+        }
       }
-      tileD16[li] = o;
-      tileX16[li] = (inside & (1u << uu)) ? vx[uu] : u32x4{0u, 0u, 0u, 0u};   // zero padding (the load address was clamped)
+      *reinterpret_cast<float4*>(tileD + li) = make_float4(r[0], r[1], r[2], r[3]);
+      *reinterpret_cast<float4*>(tileD + li + 4) = make_float4(r[4], r[5], r[6], r[7]);
+      *reinterpret_cast<float4*>(tileX + li) = make_float4(xw[0], xw[1], xw[2], xw[3]);
+      *reinterpret_cast<float4*>(tileX + li + 4) = make_float4(xw[4], xw[5], xw[6], xw[7]);
     }
     fx += dfx; fy += dfy;
     if (fx >= g.Wt) { fx -= g.Wt; ++fy; }
@@ -131,11 +140,9 @@ __global__ __launch_bounds__(kNT, FUSED_WPE) void dw_bwd_fused_kernel(const bf16
                                                                       int TH, int Hg, int G, int Wc, int nCol) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int Wt = Wc + 2, R = TH + 2;
-  const int tile_bytes = R * Wt * 128;
-  u32x4* tileD16 = reinterpret_cast<u32x4*>(smem);
-  u32x4* tileX16 = reinterpret_cast<u32x4*>(smem + tile_bytes);
-  const uint2* tileD = reinterpret_cast<const uint2*>(smem);
-  const uint2* tileX = reinterpret_cast<const uint2*>(smem + tile_bytes);
+  const int tile_bytes = R * Wt * 256;                 // fp32 tiles: every value is widened once, at fill time, not once per use
+  float* tileD = reinterpret_cast<float*>(smem);
+  float* tileX = reinterpret_cast<float*>(smem + tile_bytes);
   const int tid = threadIdx.x, c4 = tid & (kCL - 1), pt = tid / kCL;
   const int cc0 = blockIdx.x * 64;
   int y = blockIdx.y;
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(kNT, FUSED_WPE) void dw_bwd_fused_kernel(const bf16
   for (int base = 0; base < fg.n16; base += kNCH * kNT) {
     u32x4 vd[kNCH], vg[kNCH], vx[kNCH]; unsigned inside;
     fill_load(fg, base, db, gb, xb, vd, vg, vx, inside);
-    fill_store(fg, base, cst, vd, vg, vx, inside, tileD16, tileX16);
+    fill_store(fg, base, cst, vd, vg, vx, inside, tileD, tileX);
   }
   __syncthreads();
   fg.n16 = TH * Wt * kFL;                              // <= kNCH * kNT by the host's choice of TH
@@ -212,7 +219,10 @@ __global__ __launch_bounds__(kNT, FUSED_WPE) void dw_bwd_fused_kernel(const bf16
           int slot = hm + ly + i; slot -= slot >= R ? R : 0;
           float r[kPXB + 2][kVN];
 #pragma unroll
-          for (int j = 0; j < kPXB + 2; ++j) widen(tileD[(slot * Wt + lx + j) * kCL + c4], r[j]);
+          for (int j = 0; j < kPXB + 2; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(tileD + ((slot * Wt + lx + j) * kCL + c4) * 4);
+            r[j][0] = v.x; r[j][1] = v.y; r[j][2] = v.z; r[j][3] = v.w;
+          }
 #pragma unroll
           for (int e = 0; e < kPXB; ++e)
 #pragma unroll
@@ -238,7 +248,8 @@ __global__ __launch_bounds__(kNT, FUSED_WPE) void dw_bwd_fused_kernel(const bf16
           int slot = hm + ly + 1; slot -= slot >= R ? R : 0;
 #pragma unroll
           for (int e = 0; e < kPXB; ++e) {
-            widen(tileD[(slot * Wt + lx + 1 + e) * kCL + c4], ddc[e]);
+            const float4 v = *reinterpret_cast<const float4*>(tileD + ((slot * Wt + lx + 1 + e) * kCL + c4) * 4);
+            ddc[e][0] = v.x; ddc[e][1] = v.y; ddc[e][2] = v.z; ddc[e][3] = v.w;
             if (lx + e >= wc) { ddc[e][0] = ddc[e][1] = ddc[e][2] = ddc[e][3] = 0.f; }
           }
         }
@@ -247,7 +258,10 @@ __global__ __launch_bounds__(kNT, FUSED_WPE) void dw_bwd_fused_kernel(const bf16
           int slot = hm + ly + i; slot -= slot >= R ? R : 0;
           float r[kPXB + 2][kVN];
 #pragma unroll
-          for (int j = 0; j < kPXB + 2; ++j) widen(tileX[(slot * Wt + lx + j) * kCL + c4], r[j]);
+          for (int j = 0; j < kPXB + 2; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(tileX + ((slot * Wt + lx + j) * kCL + c4) * 4);
+            r[j][0] = v.x; r[j][1] = v.y; r[j][2] = v.z; r[j][3] = v.w;
+          }
 #pragma unroll
           for (int e = 0; e < kPXB; ++e)
 #pragma unroll
@@ -261,7 +275,7 @@ __global__ __launch_bounds__(kNT, FUSED_WPE) void dw_bwd_fused_kernel(const bf16
     }
     if (has_next) {
       __syncthreads();                                 // the TH oldest rows are no longer read
-      fill_store(fg, 0, cst, vd, vg, vx, inside, tileD16, tileX16);
+      fill_store(fg, 0, cst, vd, vg, vx, inside, tileD, tileX);
       __syncthreads();
     }
   }
@@ -303,8 +317,8 @@ FusedGeom fused_geom(int B, int H, int W, int C) {
   g.Wc = cdiv(cdiv(W, g.nCol), kPXB) * kPXB;
   g.nCol = cdiv(W, g.Wc);
   const int gpr = g.Wc / kPXB;
-  const long row_bytes = 2L * (g.Wc + 2) * 128;      // both tiles
-  const long budget = (long)crnn_knob("CRNN_FUSED_LDS", 38 * 1024);
+  const long row_bytes = 2L * (g.Wc + 2) * 256;      // both tiles, fp32
+  const long budget = (long)crnn_knob("CRNN_FUSED_LDS", 74 * 1024);   // two workgroups per CU (the registers allow no more)
   const long base = (long)B * (C / 64) * g.nCol;
   const int gt = (int)crnn_knob("CRNN_FUSED_WGS", 2048);
   int G = (int)((gt + base - 1) / base); if (G < 1) G = 1;
@@ -322,7 +336,7 @@ FusedGeom fused_geom(int B, int H, int W, int C) {
     if (c < best) { best = c; best_th = th; }
   }
   g.TH = (int)crnn_knob("CRNN_FUSED_TH", best_th);
-  if ((g.TH + 2) * row_bytes > 64 * 1024 || g.TH * (g.Wc + 2) * kFL > kNCH * kNT || g.TH < 1) g.TH = best_th;
+  if ((g.TH + 2) * row_bytes > 78 * 1024 || g.TH * (g.Wc + 2) * kFL > kNCH * kNT || g.TH < 1) g.TH = best_th;
   if (G > cdiv(H, 2 * g.TH)) G = cdiv(H, 2 * g.TH);
   if (G < 1) G = 1;
   G = (int)crnn_knob("CRNN_FUSED_G", G);
@@ -355,7 +369,7 @@ extern "C" int crnn_dwconv3x3_bwd_fused(const void* d, const void* da, const flo
   if ((((uintptr_t)d | (uintptr_t)da | (uintptr_t)xin | (uintptr_t)dx | (uintptr_t)bnstate | (uintptr_t)coef | (uintptr_t)k) & 15)) return CRNN_ERR_UNSUPPORTED;
   if ((long)H * W * C >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;
   const FusedGeom g = fused_geom(B, H, W, C);
-  if (g.lds > 64 * 1024 || (long)g.rows > 65535) return CRNN_ERR_UNSUPPORTED;
+  if (g.lds > 80 * 1024 || (long)g.rows > 65535) return CRNN_ERR_UNSUPPORTED;
   if (g.lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)dw_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
     if (e != hipSuccess) return (int)e;
