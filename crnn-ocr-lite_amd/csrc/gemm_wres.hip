@@ -40,6 +40,7 @@ struct WresParams {
   int S;         // channel slices of 128 (N / 128)
   int Q;         // stripes processed concurrently per XCD (workgroups per XCD / S)
   int nxcd;      // XCDs the grid spans (grid = nxcd * Q * S)
+  const float* cscale; const float* cshift;   // EPI instantiation: per-output-channel epilogue Y = ReLU6(acc * cscale[n] + cshift[n])
 #ifdef CRNN_WRES_EXP
   unsigned long long* trace;   // ablation build only: [64 iterations][4] s_memrealtime stamps of workgroup 0's first loader wave
   int exp;       // unused (the ablation mask is the compile-time value of CRNN_WRES_EXP: 1 no pixel loads, 2 no fragment reads, 8 no MFMAs, 4 no stores, 32 free-running loaders only)
@@ -63,9 +64,11 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 // fragments, multiplies them with every 128-pixel stage the producers put into the ring (R slots at smem), and leaves each
 // finished stripe as bf16 in the staging tile outs[stripe & 1].  Barrier protocol: one s_barrier before stage 0, one after every
 // stage; at barrier i the producers have stages i and i+1 in LDS.
-template <int KCH, int R, int CB = 1, int PB = 4>   // CB 32-channel blocks per wave, PB 32-pixel blocks per stage
+// EPI: the result leaves as ReLU6(acc * scale[ch] + shift[ch]) (inference: the BatchNorm after the convolution folded in, one rounding
+// to bf16 as in the tile GEMM's epilogue); epi = LDS table [scale | shift] of the workgroup's 128 CB channels.
+template <int KCH, int R, int CB = 1, int PB = 4, bool EPI = false>   // CB 32-channel blocks per wave, PB 32-pixel blocks per stage
 __device__ __forceinline__ void wres_compute(const unsigned char* smem, unsigned char* outs, const bf16_t* __restrict__ W, int K, int n0,
-                                             int wave, int lane, int mine) {
+                                             int wave, int lane, int mine, const float* epi = nullptr) {
   const int half = lane >> 5, l31 = lane & 31, sw = (l31 >> 1) & 7;
   constexpr int stage = PB * 32 * 128, orow = 256 * CB;      // bytes of a ring stage / of a staging-tile row (128 CB channels)
   bf16x8_t wf[CB][KCH][4];
@@ -120,6 +123,20 @@ __device__ __forceinline__ void wres_compute(const unsigned char* smem, unsigned
     // ---- epilogue of the stripe: lane = one pixel; register group g of a 32x32 block = channels 8g + 4half + 0..3.
     // 16-byte chunk (4 (wave CB + cb) + 2 pr + half) of pixel row px goes to position chunk ^ (px & 15) of the staging tile
     unsigned char* ob = outs + (it & 1) * (PB * 32 * orow);
+    if constexpr (EPI) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int cs0 = wave * 32 * CB + 32 * cb + 8 * g + 4 * half;
+          const float4 sv = *reinterpret_cast<const float4*>(epi + cs0), tv = *reinterpret_cast<const float4*>(epi + 128 * CB + cs0);
+          const float ss[4] = {sv.x, sv.y, sv.z, sv.w}, tt[4] = {tv.x, tv.y, tv.z, tv.w};
+#pragma unroll
+          for (int b = 0; b < PB; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[b][cb][4 * g + e] = relu6f(fmaf(acc[b][cb][4 * g + e], ss[e], tt[e]));
+        }
+    }
 #pragma unroll
     for (int b = 0; b < PB; ++b) {
       const int px = 32 * b + l31;
@@ -142,11 +159,12 @@ __device__ __forceinline__ void wres_compute(const unsigned char* smem, unsigned
   }
 }
 
-template <int KCH, int NLW>   // K / 64, loader waves
+template <int KCH, int NLW, bool EPI = false>   // K / 64, loader waves, folded-BatchNorm epilogue
 __global__ __launch_bounds__(384 + 64 * NLW) void gemm_wres_kernel(WresParams p) {
   constexpr int kIPS = 16 / NLW;            // LDS-DMA instructions per loader wave and stage
+  constexpr int RR = EPI ? kR - 1 : kR;     // ring stages (the epilogue table takes the 160 KiB budget over: one stage less)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // kR stages, then two output staging tiles
-  unsigned char* const outs = smem + kR * kStage;
+  unsigned char* const outs = smem + RR * kStage;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // workgroup -> (xcd, slice, stripe lane): consecutive ids go to consecutive XCDs
@@ -163,6 +181,13 @@ __global__ __launch_bounds__(384 + 64 * NLW) void gemm_wres_kernel(WresParams p)
   const int mine = first < p.stripes ? (p.stripes - first + step - 1) / step : 0;
   if (mine <= 0) return;
   const int total = mine * KCH;
+  const float* epi = nullptr;
+  if constexpr (EPI) {                                        // the slice's epilogue scale | shift after the staging tiles
+    float* tab = reinterpret_cast<float*>(outs + 2 * kOut);
+    for (int i = tid; i < 128; i += 384 + 64 * NLW) { tab[i] = p.cscale[slice * 128 + i]; tab[128 + i] = p.cshift[slice * 128 + i]; }
+    __syncthreads();
+    epi = tab;
+  }
 
   if (wave >= 4 + NLW) {
     // ------------------------------------------------------------------ storer waves: drain the staged stripes, a piece per stage
@@ -204,7 +229,7 @@ __global__ __launch_bounds__(384 + 64 * NLW) void gemm_wres_kernel(WresParams p)
     const int rsub = lane >> 3, pos = lane & 7;
     const long ldk = p.K;
     auto issue = [&](int lin) {
-      const int slot = lin % kR;
+      const int slot = lin % RR;
       lin = lin < total ? lin : total - 1;              // past the end: re-read the last stage into an already consumed slot
       const int it = lin / KCH, kc = lin % KCH;
       const int r0 = (first + it * step) * 128;
@@ -219,13 +244,13 @@ __global__ __launch_bounds__(384 + 64 * NLW) void gemm_wres_kernel(WresParams p)
       }
     };
 #pragma unroll
-    for (int s = 0; s < kR - 1; ++s) issue(s);
+    for (int s = 0; s < RR - 1; ++s) issue(s);
     for (int i = 0; i < total; ++i) {
 #ifdef CRNN_WRES_EXP
       const bool tr = p.trace && wg == 8 && lw == 0 && lane == 0 && i < 64;
       if (tr) p.trace[i * 4 + 0] = __builtin_amdgcn_s_memrealtime();
 #endif
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kR - 3) * kIPS) : "memory");   // stages i and i+1 have landed
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RR - 3) * kIPS) : "memory");   // stages i and i+1 have landed
 #ifdef CRNN_WRES_EXP
       if (tr) p.trace[i * 4 + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -233,7 +258,7 @@ __global__ __launch_bounds__(384 + 64 * NLW) void gemm_wres_kernel(WresParams p)
 #ifdef CRNN_WRES_EXP
       if (tr) p.trace[i * 4 + 2] = __builtin_amdgcn_s_memrealtime();
 #endif
-      issue(i + kR - 1);                                                        // into the slot stage i-1 has just released
+      issue(i + RR - 1);                                                        // into the slot stage i-1 has just released
 #ifdef CRNN_WRES_EXP
       if (tr) p.trace[i * 4 + 3] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -244,7 +269,7 @@ __global__ __launch_bounds__(384 + 64 * NLW) void gemm_wres_kernel(WresParams p)
 
   // -------------------------------------------------------------------- compute waves: 32 channels x K of W in registers
   if (WRES_EXP(p, 32)) return;
-  wres_compute<KCH, kR>(smem, outs, p.W, p.K, slice * 128 + wave * 32, wave, lane, mine);
+  wres_compute<KCH, RR, 1, 4, EPI>(smem, outs, p.W, p.K, slice * 128 + wave * 32, wave, lane, mine, epi);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -412,16 +437,16 @@ __global__ __launch_bounds__(512) void gemm_wres_fwd_kernel(WresFwdParams p) {
   }
 }
 
-template <int KCH, int NLW>
+template <int KCH, int NLW, bool EPI = false>
 int launch_wres(const WresParams& p, int grid, hipStream_t stream) {
-  const int lds = kR * kStage + 2 * kOut;
+  const int lds = (EPI ? kR - 1 : kR) * kStage + 2 * kOut + (EPI ? 1024 : 0);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_wres_kernel<KCH, NLW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_wres_kernel<KCH, NLW, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_wres_kernel<KCH, NLW>), dim3(grid), dim3(384 + 64 * NLW), lds, stream, p);
+  hipLaunchKernelGGL((gemm_wres_kernel<KCH, NLW, EPI>), dim3(grid), dim3(384 + 64 * NLW), lds, stream, p);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
@@ -435,7 +460,7 @@ extern "C" int crnn_gemm_wres_supported(int N, int K) {
 
 // Y[M][N] (bf16) = X[M][K] (bf16, row stride K) . W[N][K]^T (bf16, row stride K), weights resident in registers.
 // One persistent workgroup per CU (512 threads: 4 MFMA waves + 2 LDS-DMA loader waves + 2 storer waves, 160 KiB of LDS).
-extern "C" int crnn_gemm_wres_bf16(const void* X, const void* W, void* Y, int M, int N, int K, hipStream_t stream) {
+static int gemm_wres_impl(const void* X, const void* W, void* Y, int M, int N, int K, const float* cscale, const float* cshift, hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0) return CRNN_ERR_ARG;
   CRNN_TRY(crnn_gemm_wres_supported(N, K));
   if ((((uintptr_t)X | (uintptr_t)W | (uintptr_t)Y) & 15)) return CRNN_ERR_UNSUPPORTED;
@@ -456,12 +481,32 @@ extern "C" int crnn_gemm_wres_bf16(const void* X, const void* W, void* Y, int M,
   p.exp = crnn_knob("CRNN_WRES_EXP", 0);
   { const char* e = getenv("CRNN_WRES_TRACE"); p.trace = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
 #endif
+  p.cscale = cscale; p.cshift = cshift;
+  if (cscale) {
+    switch (K / 64) {
+      case 1: return launch_wres<1, 2, true>(p, grid, stream);
+      case 2: return launch_wres<2, 2, true>(p, grid, stream);
+      case 4: return launch_wres<4, 2, true>(p, grid, stream);
+      default: return launch_wres<8, 2, true>(p, grid, stream);
+    }
+  }
   switch (K / 64) {
     case 1: return launch_wres<1, 2>(p, grid, stream);
     case 2: return launch_wres<2, 2>(p, grid, stream);
     case 4: return launch_wres<4, 2>(p, grid, stream);
     default: return launch_wres<8, 2>(p, grid, stream);
   }
+}
+extern "C" int crnn_gemm_wres_bf16(const void* X, const void* W, void* Y, int M, int N, int K, hipStream_t stream) {
+  return gemm_wres_impl(X, W, Y, M, N, K, nullptr, nullptr, stream);
+}
+// Inference forward of a pointwise convolution with the BatchNorm + ReLU6 that follows folded in (utils.py:49-51, learning_phase 0):
+// Y[M][N] (bf16) = ReLU6((X . W^T) * scale[n] + shift[n]), out_bnstate = [mean|var|scale|shift] of that BatchNorm (crnn_bn_infer_state).
+// The epilogue runs on the fp32 accumulators in the MFMA waves (one rounding to bf16): bit-identical to crnn_pwconv_fwd(out_bnstate).
+extern "C" int crnn_pwconv_fwd_wres_folded(const void* a, const void* wT, void* y, long M, int N, int K, const float* out_bnstate, hipStream_t stream) {
+  if (!out_bnstate) return CRNN_ERR_ARG;
+  if (M > 0x7fffffffL || (((uintptr_t)out_bnstate) & 15)) return CRNN_ERR_UNSUPPORTED;
+  return gemm_wres_impl(a, wT, y, (int)M, N, K, out_bnstate + 2L * N, out_bnstate + 3L * N, stream);
 }
 
 namespace {

@@ -380,7 +380,15 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
       const bool one = (ci == 1 && dtd == CRNN_F32);                      // block 1: an outer product, not a GEMM
       const bool fold = !one && (ph * pw == 1) && (c.dt("x" + p) == dtq);
       if (one) CRNN_TRY(crnn_pw1_fwd(aa, c.p(bp + "_pw"), qq, M, co, nullptr, dtq, stream));
-      else CRNN_TRY(crnn_pwconv_fwd(aa, wq, fold ? xo : qq, M, co, ci, nullptr, fold ? s2 : nullptr, cfg->mfma_bf16 ? 1 : 0, dtd, dtw, dtq, wt, stream));
+      else {
+        // bf16 tensors + W^T: the weights-resident kernel (folded BatchNorm in its MFMA waves' epilogue, or the plain product)
+        int rc = CRNN_ERR_UNSUPPORTED;
+        if (wt && dtd == CRNN_BF16 && dtq == CRNN_BF16 && dtw == CRNN_BF16 && !(cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS) && M <= 0x7fffffffL)
+          rc = fold ? crnn_pwconv_fwd_wres_folded(aa, wq, xo, M, co, ci, s2, stream) : crnn_gemm_wres_bf16(aa, wq, qq, (int)M, co, ci, stream);
+        if (rc == CRNN_ERR_UNSUPPORTED)
+          rc = crnn_pwconv_fwd(aa, wq, fold ? xo : qq, M, co, ci, nullptr, fold ? s2 : nullptr, cfg->mfma_bf16 ? 1 : 0, dtd, dtw, dtq, wt, stream);
+        CRNN_TRY(rc);
+      }
       if (!fold) CRNN_TRY(crnn_bn_act_pool_drop_ex(qq, s2, xo, B, H, W, co, ph, pw, 0.f, seed, (uint32_t)i, dtq, c.dt("x" + p), stream));
       in = xo;
       continue;

@@ -294,6 +294,10 @@ int crnn_gemm_nt_bf16(const void* X, const void* W, void* Y, int M, int N, int K
  * Supported (else -3): N % 128 == 0, N <= 1024, K in {64, 128, 256, 512}, 16-byte aligned pointers. */
 int crnn_gemm_wres_supported(int N, int K);
 int crnn_gemm_wres_bf16(const void* X, const void* W, void* Y, int M, int N, int K, crnn_stream_t stream);
+/* Inference forward of a pointwise convolution on the same kernel with the BatchNorm + ReLU6 that follows folded into the MFMA waves'
+ * epilogue: y[M][N] (bf16) = ReLU6((a . wT^T) * scale[n] + shift[n]), out_bnstate = [mean|var|scale|shift] (crnn_bn_infer_state).
+ * Bit-identical to crnn_pwconv_fwd(..., out_bnstate, ...) on bf16 tensors.  Same shape rules as crnn_gemm_wres_bf16. */
+int crnn_pwconv_fwd_wres_folded(const void* a, const void* wT, void* y, long M, int N, int K, const float* out_bnstate, crnn_stream_t stream);
 /* The forward pointwise convolution of a training block on the same weights-resident core, fed by the PRE-BatchNorm depthwise output:
  * q[M][N] (bf16) = ReLU6(BN(d))[M][K] . wT[N][K]^T, in_bnstate = [mean|var|scale|shift] of that BatchNorm.  Four IO waves per workgroup
  * load the pixel stages into registers three stages ahead, apply the BatchNorm + ReLU6 (bit for bit the arithmetic of

@@ -887,6 +887,29 @@ def test_streaming_tn_gemm_on_fp32_operands_equals_the_tile_kernel(M, N, K, lda,
     assert L().crnn_gemm_tn_stream(P(Ad), lda, P(Bd), ldb, P(C1), ldc, M, N, K - 32, P(scratch), ctypes.c_size_t(scratch.numel() * 4), S()) == -3
 
 
+@pytest.mark.parametrize("M,N,K", [(128 * 5, 128, 64), (128 * 300 + 17, 256, 256), (128 * 700, 512, 512), (100, 128, 128)])
+def test_weights_resident_inference_conv_with_folded_batchnorm_equals_the_tile_kernel(M, N, K):
+    """crnn_pwconv_fwd_wres_folded (predict path: pointwise conv with the following BatchNorm + ReLU6 applied to the fp32 accumulators
+    in the MFMA waves before the one rounding to bf16) against crnn_pwconv_fwd(out_bnstate) on the tile GEMM: bit for bit; and
+    against the fp64 evaluation.  Ragged M, 1..4 channel slices, repeated launches."""
+    rs = np.random.RandomState(M % 9973 + N + K)
+    a = _bf16_round(np.abs(rs.normal(size=(M, K))) * 1.5); W = _bf16_round(rs.normal(size=(N, K)) * 0.2)
+    scale, shift = rs.normal(size=N) * 0.3 + 1.0, rs.normal(size=N) * 0.5 + 1.0
+    st = dev(np.concatenate([rs.normal(size=N), rs.uniform(0.5, 2.0, size=N), scale, shift]))
+    ad, Wd = _to_bf16_dev(a), _to_bf16_dev(W)
+    y1 = torch.full((M + 2, N), 7.0, dtype=torch.bfloat16, device="cuda")
+    for rep in range(3):
+        ok(L().crnn_pwconv_fwd_wres_folded(P(ad), P(Wd), P(y1), M, N, K, P(st), S()))
+        if rep == 0: first = y1.clone()
+        else: assert torch.equal(first, y1)
+    y2 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    ok(L().crnn_pwconv_fwd(P(ad), P(Wd), P(y2), M, N, K, None, P(st), 1, 1, 1, 1, 1, S()))
+    assert torch.equal(y1[:M], y2), "differs from the tile kernel: max %g" % float((y1[:M].float() - y2.float()).abs().max())
+    assert bool((y1[M:] == 7.0).all())
+    ref = np.clip((a @ W.T) * scale + shift, 0.0, 6.0)
+    assert_close(y1[:M].float().cpu().numpy(), ref, rtol=1e-2, atol=2e-2, what="folded conv vs fp64")
+
+
 def test_bilstm_bf16_recurrent_weights_track_the_fp64_cell():
     """crnn_lstm_fwd_ex / crnn_lstm_bwd_ex with dt_u = bf16: recurrent products on the bf16 MFMA (weights stored bf16, the
     state rounded to bf16 as it is packed).  Against the fp64 cell evaluated with the SAME bf16-rounded weights the only
