@@ -1181,21 +1181,32 @@ extern "C" int crnn_bn_act(const float* x, const float* bnstate, float* y, long 
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void pw1_fwd_kernel(const float* __restrict__ a, const float* __restrict__ w, T* __restrict__ q,
-                                                      float* __restrict__ stats, long M, int N) {
+                                                      float* __restrict__ stats, long M, int N, const float* __restrict__ bn) {
+  // bn != null (inference): q = ReLU6(a * w * scale + shift), the BatchNorm after the convolution folded in (bn = [mean|var|scale|shift])
   // one workgroup per 128-row tile (= one statistics row); thread = (8-column group, row lane)
   __shared__ float red[2][256 * 8];
   const int CG = N / 8, RT = 256 / CG, tid = threadIdx.x, cg = tid % CG, rt = tid / CG;
   const long r0 = (long)blockIdx.x * 128;
   float wv[8], s[8], ss[8];
   VecF<8> wl = vload<8>(w + 8 * cg);
+  float bs[8], bt[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { wv[e] = wl.v[e]; s[e] = 0.f; ss[e] = 0.f; }
+  for (int e = 0; e < 8; ++e) { wv[e] = wl.v[e]; s[e] = 0.f; ss[e] = 0.f; bs[e] = 1.f; bt[e] = 0.f; }
+  if (bn) {
+    VecF<8> v1 = vload<8>(bn + 2 * N + 8 * cg), v2 = vload<8>(bn + 3 * N + 8 * cg);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bs[e] = v1.v[e]; bt[e] = v2.v[e]; }
+  }
   if (rt < RT)
     for (int r = rt; r < 128 && r0 + r < M; r += RT) {
       const float av = a[r0 + r];
       VecF<8> o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o.v[e] = av * wv[e];
+      if (bn) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.v[e] = relu6f(fmaf(o.v[e], bs[e], bt[e]));
+      }
       vstore<8>(&q[(r0 + r) * N + 8 * cg], o);
       if (stats) {
 #pragma unroll
@@ -1260,13 +1271,21 @@ __global__ __launch_bounds__(256) void pw1_wgrad_kernel(const float* __restrict_
 }
 static bool pw1_ok(int N, const void* q) { return N % 8 == 0 && N <= 256 && (N & (N - 1)) == 0 && ((uintptr_t)q & 15) == 0; }
 // q [M][N] = a[M] (x) w[N]; stat_partials (may be NULL): [ceil(M/128)][2][N] like crnn_pwconv_fwd
-extern "C" int crnn_pw1_fwd(const float* a, const float* w, void* q, long M, int N, float* stat_partials, int dt_q, hipStream_t stream) {
+static int pw1_fwd_launch(const float* a, const float* w, void* q, long M, int N, float* stat_partials, const float* bn, int dt_q, hipStream_t stream) {
   if (!pw1_ok(N, q) || M <= 0) return CRNN_ERR_UNSUPPORTED;
   const int blocks = cdiv(M, 128);
-  if (dt_q == CRNN_BF16) hipLaunchKernelGGL(pw1_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, a, w, (bf16_t*)q, stat_partials, M, N);
-  else hipLaunchKernelGGL(pw1_fwd_kernel<float>, dim3(blocks), dim3(256), 0, stream, a, w, (float*)q, stat_partials, M, N);
+  if (dt_q == CRNN_BF16) hipLaunchKernelGGL(pw1_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, a, w, (bf16_t*)q, stat_partials, M, N, bn);
+  else hipLaunchKernelGGL(pw1_fwd_kernel<float>, dim3(blocks), dim3(256), 0, stream, a, w, (float*)q, stat_partials, M, N, bn);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
+}
+extern "C" int crnn_pw1_fwd(const float* a, const float* w, void* q, long M, int N, float* stat_partials, int dt_q, hipStream_t stream) {
+  return pw1_fwd_launch(a, w, q, M, N, stat_partials, nullptr, dt_q, stream);
+}
+// inference: y = ReLU6(BN(a (x) w)) with out_bnstate = [mean|var|scale|shift] of the BatchNorm after the convolution (crnn_bn_infer_state)
+extern "C" int crnn_pw1_fwd_folded(const float* a, const float* w, void* y, long M, int N, const float* out_bnstate, int dt_y, hipStream_t stream) {
+  if (!out_bnstate) return CRNN_ERR_ARG;
+  return pw1_fwd_launch(a, w, y, M, N, nullptr, out_bnstate, dt_y, stream);
 }
 // da[M] = dq[M][N] . w[N];   dw[N] = sum_m a[m] * dq[m][N]  (scratch: crnn_colreduce_chunks(M) * N floats)
 extern "C" int crnn_pw1_bwd(const float* a, const float* w, const void* dq, float* da, float* dw, float* scratch, long M, int N,

@@ -378,8 +378,8 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
         dtw = CRNN_BF16; wt = 1;
       }
       const bool one = (ci == 1 && dtd == CRNN_F32);                      // block 1: an outer product, not a GEMM
-      const bool fold = !one && (ph * pw == 1) && (c.dt("x" + p) == dtq);
-      if (one) CRNN_TRY(crnn_pw1_fwd(aa, c.p(bp + "_pw"), qq, M, co, nullptr, dtq, stream));
+      const bool fold = (ph * pw == 1) && (c.dt("x" + p) == dtq);
+      if (one) CRNN_TRY(fold ? crnn_pw1_fwd_folded(aa, c.p(bp + "_pw"), xo, M, co, s2, dtq, stream) : crnn_pw1_fwd(aa, c.p(bp + "_pw"), qq, M, co, nullptr, dtq, stream));
       else {
         // bf16 tensors + W^T: the weights-resident kernel (folded BatchNorm in its MFMA waves' epilogue, or the plain product)
         int rc = CRNN_ERR_UNSUPPORTED;

@@ -179,6 +179,8 @@ int crnn_pwconv_bnrelu6_wgrad(const void* d, const float* in_bnstate, const void
  * dw[c] = sum_m a[m] dq[m][c].  a / da fp32; q / dq fp32 (dt_q 0) or bf16 (1); N a power of two, 8 <= N <= 256.
  * stat_partials as for crnn_pwconv_fwd; scratch: crnn_colreduce_chunks(M) * N floats; da may be NULL. */
 int crnn_pw1_fwd(const float* a, const float* w, void* q, long M, int N, float* stat_partials, int dt_q, crnn_stream_t stream);
+/* inference form: y = ReLU6((a (x) w) * scale + shift), out_bnstate = [mean|var|scale|shift] of the BatchNorm after the convolution */
+int crnn_pw1_fwd_folded(const float* a, const float* w, void* y, long M, int N, const float* out_bnstate, int dt_y, crnn_stream_t stream);
 int crnn_pw1_bwd(const float* a, const float* w, const void* dq, float* da, float* dw, float* scratch, long M, int N, int dt_q,
                  crnn_stream_t stream);
 /* Depthwise 3x3 with the inference BatchNorm + ReLU6 after it (utils.py:44-46) folded into the epilogue:
