@@ -1067,6 +1067,13 @@ def test_single_channel_pointwise_conv_outer_product_kernels(storage):
     assert_close(host(da), dq @ w.astype(np.float32).astype(np.float64), rtol=1e-5, atol=1e-5, what="da")
     assert_close(host(dw), a.astype(np.float32).astype(np.float64) @ dq, rtol=1e-5, atol=1e-4, what="dw")
     assert L().crnn_pw1_fwd(P(dev(a)), P(dev(w)), P(q), Mm, 48, None, int(bf), S()) == -3        # N must be a power of two
+    # inference form: the BatchNorm + ReLU6 after the convolution folded in
+    scale, shift = rs.normal(size=N) * 0.3 + 1.0, rs.normal(size=N) * 0.5 + 1.0
+    st = dev(np.concatenate([rs.normal(size=N), rs.uniform(0.5, 2.0, size=N), scale, shift]))
+    y = torch.full((Mm, N), 9.0, dtype=torch.bfloat16 if bf else torch.float32, device="cuda")
+    ok(L().crnn_pw1_fwd_folded(P(dev(a)), P(dev(w)), P(y), Mm, N, P(st), int(bf), S()))
+    yref = np.clip(ref * scale.astype(np.float32) + shift.astype(np.float32), 0.0, 6.0)
+    assert_close(_f(y) if bf else host(y), yref, rtol=2.0 ** -8 if bf else 1e-6, atol=1e-5, what="folded outer product")
 
 
 @pytest.mark.parametrize("cin,H,W", [(1, 50, 16), (20, 23, 6), (20, 9, 7)])
