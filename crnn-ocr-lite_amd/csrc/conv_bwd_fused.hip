@@ -233,7 +233,7 @@ __global__ __launch_bounds__(kNT, FUSED_WPE) void dw_bwd_fused_kernel(const bf16
         const int o = ((h0 + ly) * W + w0 + lx) * C;
 #pragma unroll
         for (int e = 0; e < kPXB; ++e)
-          if (lx + e < wc) st4(ob + o + e * C, make_float4(a[e][0], a[e][1], a[e][2], a[e][3]));
+          if (lx + e < wc && (FUSED_ABL != 4 || a[e][0] == 12345.678f)) st4(ob + o + e * C, make_float4(a[e][0], a[e][1], a[e][2], a[e][3]));
         lg += dlg; ly += dly;
         if (lg >= gpr) { lg -= gpr; ++ly; }
       }

@@ -337,3 +337,148 @@ extern "C" int crnn_gemm_tn_stream(const float* A, int lda, const float* B, int 
   p.M = (int)K; p.N = N; p.K = M; p.lda = lda; p.ldg = ldb;
   return wg_launch<true>(p, K, C, ldc, scratch, scratch_bytes, stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Input gradient of a Bidirectional recurrent layer's input projections (utils.py:77-82, backward):
+//     dX[M][N] (fp32) = dZf[M][K] . Wf[N][K]^T + dZb[M][K] . Wb[N][K]^T      M = T*B rows, K = 4u (3u) gate columns, N = 128 | 256
+// dZ are fp32 tensors (rounded to bf16 on the way in, as the tile GEMM does), W the bf16 weight shadows.  The tile GEMM runs this as
+// two launches (the second accumulating into the first's result) of 104-208 tiles with a serial k-chunk chain each (38-40 us per
+// launch against an 11 us HBM floor).  Here one workgroup per 64-row stripe keeps its [64][N] result in the MFMA waves' registers over
+// the whole 2K reduction; 8 IO waves stage every 64-k chunk of the dZ rows (fp32 -> bf16) and of the weight rows (bf16) two chunks
+// ahead through registers into an LDS ring (swizzled 128-byte rows, the weights-resident kernels' fragment layout), branch-free
+// steady state; weights are the MFMA A operand so a lane ends up with 4 consecutive output columns of one row: float4 stores.
+namespace {
+
+struct NtsParams {
+  const float* A[2]; const bf16_t* W[2];    // the (dZ, W) pairs
+  float* Y;
+  int M, N, K, lda, ldw, ldy, npairs;
+};
+constexpr int kNtsRing = 3, kNtsD = 2;
+
+template <int CB>   // 32-channel blocks per MFMA wave: N = 128 CB
+__global__ __launch_bounds__(768) void gemm_nt_f32_stream_kernel(NtsParams p) {
+  constexpr int N = 128 * CB;
+  constexpr int kX = 64 * 128, kW = N * 128, kSt = kX + kW;   // bytes of a stage: 64 rows x 64 k bf16 | N weight rows x 64 k bf16
+  constexpr int WP = N * 8 / 512;                              // 16-byte weight pieces per IO lane and stage (N rows x 8 pieces over 512 lanes)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * 64;
+  const int kch = p.K / 64, total = kch * p.npairs;
+
+  if (wave < 4) {
+    const int half = lane >> 5, l31 = lane & 31, sw = (l31 >> 1) & 7;
+    f32x16 acc[2][CB];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[b][cb][e] = 0.f;
+    int slot = 0;
+    for (int s = 0; s < total; ++s) {
+      __builtin_amdgcn_s_barrier();
+      const unsigned char* Xs = smem + slot * kSt + l31 * 128;
+      const unsigned char* Ws = smem + slot * kSt + kX + (wave * 32 * CB + l31) * 128;
+      slot = slot + 1 == kNtsRing ? 0 : slot + 1;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int off = ((2 * ks + half) ^ sw) * 16;
+        bf16x8_t fx[2], fw[CB];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) fx[b] = *reinterpret_cast<const bf16x8_t*>(Xs + b * 32 * 128 + off);
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) fw[cb] = *reinterpret_cast<const bf16x8_t*>(Ws + cb * 32 * 128 + off);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb) acc[b][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[cb], fx[b], acc[b][cb], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+    // lane = one row; register group g of a block = columns 8 g + 4 half + 0..3
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float* yrow = p.Y + (long)(m0 + 32 * b + l31) * p.ldy + wave * 32 * CB + 4 * half;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(yrow + 32 * cb + 8 * g) = make_float4(acc[b][cb][4 * g], acc[b][cb][4 * g + 1], acc[b][cb][4 * g + 2], acc[b][cb][4 * g + 3]);
+    }
+    return;
+  }
+  // ---------------------------------------------------------------------------- IO waves (8): lane il = 0..511
+  const int il = tid - 256;
+  const int xr = il >> 3, xc = il & 7;                          // dZ piece: row xr (0..63), 8-k piece xc
+  u32x4 rx[kNtsD][2], rw[kNtsD][WP];
+  auto load = [&](int s, u32x4 (&ax)[2], u32x4 (&aw)[WP]) {
+    s = s < total ? s : total - 1;
+    const int pr = s / kch, kc = s - pr * kch;
+    const float* a = p.A[pr] + (long)(m0 + xr) * p.lda + kc * 64 + xc * 8;
+    ax[0] = *reinterpret_cast<const u32x4*>(a); ax[1] = *reinterpret_cast<const u32x4*>(a + 4);
+    const bf16_t* w = p.W[pr] + kc * 64 + xc * 8;
+#pragma unroll
+    for (int u = 0; u < WP; ++u) aw[u] = *reinterpret_cast<const u32x4*>(w + (long)(xr + 64 * u) * p.ldw);
+  };
+  auto write = [&](int s, const u32x4 (&ax)[2], const u32x4 (&aw)[WP]) {
+    unsigned char* st = smem + (s % kNtsRing) * kSt;
+    const u32x4 o = {pack2_bf16(__uint_as_float(ax[0].x), __uint_as_float(ax[0].y)), pack2_bf16(__uint_as_float(ax[0].z), __uint_as_float(ax[0].w)),
+                     pack2_bf16(__uint_as_float(ax[1].x), __uint_as_float(ax[1].y)), pack2_bf16(__uint_as_float(ax[1].z), __uint_as_float(ax[1].w))};
+    *reinterpret_cast<u32x4*>(st + xr * 128 + ((xc ^ ((xr >> 1) & 7)) * 16)) = o;
+#pragma unroll
+    for (int u = 0; u < WP; ++u) {
+      const int r = xr + 64 * u;
+      *reinterpret_cast<u32x4*>(st + kX + r * 128 + ((xc ^ ((r >> 1) & 7)) * 16)) = aw[u];
+    }
+  };
+  auto step = [&](int s, u32x4 (&ax)[2], u32x4 (&aw)[WP]) {     // buffer (s + 1) % kNtsD
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    write(s + 1, ax, aw); load(s + 1 + kNtsD, ax, aw);
+  };
+  // barrier s: stage s is written before it; after it the slot of stage s-1 is free; stage s+1 goes into slot (s+1) % 3, which held
+  // stage s-2 -- released at barrier s-1
+  load(0, rx[0], rw[0]); load(1, rx[1], rw[1]);
+  write(0, rx[0], rw[0]); load(2, rx[0], rw[0]);
+  int s = 0;
+  for (; s + kNtsD <= total; s += kNtsD) {
+#pragma unroll
+    for (int k = 0; k < kNtsD; ++k) step(s + k, rx[(k + 1) % kNtsD], rw[(k + 1) % kNtsD]);
+  }
+#pragma unroll
+  for (int k = 0; k < kNtsD; ++k)
+    if (s + k <= total) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (s + k < total) { write(s + k + 1, rx[(k + 1) % kNtsD], rw[(k + 1) % kNtsD]); load(s + k + 1 + kNtsD, rx[(k + 1) % kNtsD], rw[(k + 1) % kNtsD]); }
+    }
+}
+
+}  // namespace
+
+// Y[M][N] (fp32, row stride ldy) = A0[M][K] . W0[N][K]^T (+ A1 . W1^T when A1 != NULL); A fp32 (row stride lda), W bf16 (row stride ldw).
+// Supported (else -3): M % 64 == 0, N in {128, 256}, K % 64 == 0, leading dimensions multiples of 8, 16-byte aligned pointers.
+extern "C" int crnn_gemm_nt_f32_stream(const float* A0, const void* W0, const float* A1, const void* W1, float* Y, int M, int N, int K, int lda,
+                                       int ldw, int ldy, hipStream_t stream) {
+  if (M <= 0 || K <= 0 || !A0 || !W0 || !Y || ((A1 != nullptr) != (W1 != nullptr))) return CRNN_ERR_ARG;
+  if (M % 64 || (N != 128 && N != 256) || K % 64 || ((lda | ldw | ldy) & 7) || lda < K || ldw < K || ldy < N) return CRNN_ERR_UNSUPPORTED;
+  if ((((uintptr_t)A0 | (uintptr_t)W0 | (uintptr_t)A1 | (uintptr_t)W1 | (uintptr_t)Y) & 15)) return CRNN_ERR_UNSUPPORTED;
+  if ((long)M * (lda > ldy ? lda : ldy) >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;
+  NtsParams p;
+  p.A[0] = A0; p.A[1] = A1 ? A1 : A0; p.W[0] = (const bf16_t*)W0; p.W[1] = (const bf16_t*)(W1 ? W1 : W0); p.Y = Y;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldy = ldy; p.npairs = A1 ? 2 : 1;
+  const int lds = kNtsRing * (64 * 128 + N * 128);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_f32_stream_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kNtsRing * (64 * 128 + 128 * 128));
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_f32_stream_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kNtsRing * (64 * 128 + 256 * 128));
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  if (N == 128) hipLaunchKernelGGL(gemm_nt_f32_stream_kernel<1>, dim3(M / 64), dim3(768), lds, stream, p);
+  else hipLaunchKernelGGL(gemm_nt_f32_stream_kernel<2>, dim3(M / 64), dim3(768), lds, stream, p);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}

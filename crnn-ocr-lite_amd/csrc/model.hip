@@ -544,6 +544,15 @@ static int rnn_bwd_dx(const Ctx& c, int layer, int din, float* dxin) {
   const Dims& d = c.d;
   const int TB = d.T * d.B, G = d.G;
   std::string l = std::to_string(layer);
+  if (c.cfg->mfma_bf16 && !(c.cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS)) {   // both directions in one streaming launch (gemm_wgrad.hip)
+    int dtf = CRNN_F32, dtb = CRNN_F32;
+    const float* wf = weight_operand(c, 1, c.p("rnn" + l + "f_w"), &dtf);
+    const float* wb = weight_operand(c, 1, c.p("rnn" + l + "b_w"), &dtb);
+    if (dtf == CRNN_BF16 && dtb == CRNN_BF16) {
+      const int rc = crnn_gemm_nt_f32_stream(c.w("dz" + l + "f"), wf, c.w("dz" + l + "b"), wb, dxin, TB, din, G, G, G, din, c.s);
+      if (rc != CRNN_ERR_UNSUPPORTED) return rc;
+    }
+  }
   CRNN_TRY(gemm(c, 1, c.w("dz" + l + "f"), c.p("rnn" + l + "f_w"), dxin, TB, din, G, G, G, din));
   return gemm(c, 1, c.w("dz" + l + "b"), c.p("rnn" + l + "b_w"), dxin, TB, din, G, G, G, din, nullptr, 0, 1);
 }

@@ -324,6 +324,12 @@ int crnn_pwconv_bnrelu6_wgrad_stream(const void* d, const float* in_bnstate, con
  * multiples of 4, 16-byte aligned pointers; scratch: crnn_pwconv_wgrad_stream_scratch_bytes(K, N, M). */
 int crnn_gemm_tn_stream(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, long K, float* scratch,
                         size_t scratch_bytes, crnn_stream_t stream);
+/* Input gradient of a Bidirectional layer's input projections in one streaming launch: Y[M][N] (fp32, row stride ldy) = A0[M][K] . W0[N][K]^T
+ * (+ A1 . W1^T when A1 != NULL), A fp32 (rounded to bf16 on the way in), W bf16; one workgroup per 64-row stripe keeps its result in the
+ * MFMA waves' registers over the whole reduction.  Supported (else -3): M % 64 == 0, N in {128, 256}, K % 64 == 0, leading dimensions
+ * multiples of 8, 16-byte aligned pointers. */
+int crnn_gemm_nt_f32_stream(const float* A0, const void* W0, const float* A1, const void* W1, float* Y, int M, int N, int K, int lda, int ldw,
+                            int ldy, crnn_stream_t stream);
 int crnn_pwconv_fwd_wres_supported(long M, int N, int K);
 int crnn_pwconv_fwd_wres_rows(long M, int N, int K);
 int crnn_pwconv_bnrelu6_fwd_wres(const void* d, const float* in_bnstate, const void* wT, void* q, long M, int N, int K, float* stat_partials,

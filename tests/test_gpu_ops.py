@@ -910,6 +910,29 @@ def test_weights_resident_inference_conv_with_folded_batchnorm_equals_the_tile_k
     assert_close(y1[:M].float().cpu().numpy(), ref, rtol=1e-2, atol=2e-2, what="folded conv vs fp64")
 
 
+@pytest.mark.parametrize("M,N,K,two", [(13312, 128, 1024, True), (13312, 256, 1024, True), (64 * 3, 256, 768, True), (64, 128, 64, False), (64 * 9, 128, 128, False)])
+def test_streaming_nt_gemm_of_the_recurrent_input_gradient_equals_the_tile_kernel(M, N, K, two):
+    """crnn_gemm_nt_f32_stream (dX = dZf Wf^T + dZb Wb^T in one launch: result of a 64-row stripe in the MFMA waves' registers over both
+    reductions, fp32 dZ rounded to bf16 and bf16 weight rows staged through registers into an LDS ring) against two crnn_gemm_bf16_ex
+    mode-1 launches (the second accumulating) and the fp64 product of the rounded operands: fp32 summation round-off.  The layers'
+    shapes, GRU's 3u columns, one pair, one chunk; repeated launches give the same bits."""
+    rs = np.random.RandomState(M % 997 + N + K)
+    A0, A1 = rs.normal(size=(M, K)), rs.normal(size=(M, K)); W0, W1 = _bf16_round(rs.normal(size=(N, K)) * 0.2), _bf16_round(rs.normal(size=(N, K)) * 0.2)
+    A0d, A1d, W0d, W1d = dev(A0), dev(A1), _to_bf16_dev(W0), _to_bf16_dev(W1)
+    Y1 = torch.full((M, N), 7.0, device="cuda"); Y3 = torch.full((M, N), 5.0, device="cuda")
+    ok(L().crnn_gemm_nt_f32_stream(P(A0d), P(W0d), P(A1d) if two else None, P(W1d) if two else None, P(Y1), M, N, K, K, K, N, S()))
+    ok(L().crnn_gemm_nt_f32_stream(P(A0d), P(W0d), P(A1d) if two else None, P(W1d) if two else None, P(Y3), M, N, K, K, K, N, S()))
+    assert torch.equal(Y1, Y3)
+    Y2 = zeros(M, N); scr = zeros(16 << 20)
+    ok(L().crnn_gemm_bf16_ex(1, P(A0d), P(W0d), P(Y2), M, N, K, K, K, N, None, 0, 0, 0, P(scr), ctypes.c_size_t(scr.numel() * 4), 0, 1, 0, S()))
+    if two: ok(L().crnn_gemm_bf16_ex(1, P(A1d), P(W1d), P(Y2), M, N, K, K, K, N, None, 0, 1, 0, P(scr), ctypes.c_size_t(scr.numel() * 4), 0, 1, 0, S()))
+    ref = _bf16_round(A0) @ W0.T + (_bf16_round(A1) @ W1.T if two else 0.0)
+    tol = 2e-5 * np.abs(ref).max() + 1e-6 * np.sqrt(K)
+    assert_close(host(Y1), host(Y2), rtol=1e-4, atol=tol, what="stream vs tile kernel")
+    assert_close(host(Y1), ref, rtol=1e-4, atol=tol, what="stream vs fp64")
+    assert L().crnn_gemm_nt_f32_stream(P(A0d), P(W0d), None, None, P(Y1), M, 192, K, K, K, 192, S()) == -3
+
+
 def test_bilstm_bf16_recurrent_weights_track_the_fp64_cell():
     """crnn_lstm_fwd_ex / crnn_lstm_bwd_ex with dt_u = bf16: recurrent products on the bf16 MFMA (weights stored bf16, the
     state rounded to bf16 as it is packed).  Against the fp64 cell evaluated with the SAME bf16-rounded weights the only
