@@ -933,6 +933,44 @@ def test_streaming_nt_gemm_of_the_recurrent_input_gradient_equals_the_tile_kerne
     assert L().crnn_gemm_nt_f32_stream(P(A0d), P(W0d), None, None, P(Y1), M, 192, K, K, K, 192, S()) == -3
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_streaming_pointwise_kernels_on_random_shapes(seed):
+    """The three streaming pointwise-conv kernels on drawn shapes (stripe counts around the grid size, 1..8 channel slices, every K,
+    ragged last ranges): forward (q bit for bit, statistics to round-off), data gradient (bit for bit), weight gradient (round-off),
+    each against the tile GEMM entry points it replaces; repeated launches bit-identical."""
+    rs = np.random.RandomState(1000 + seed)
+    K = int(rs.choice([64, 128, 256, 512])); N = 128 * int(rs.randint(1, 5)); M = 128 * int(rs.randint(1, 900))
+    d = _bf16_round(rs.normal(size=(M, K)) * 2.0); W = _bf16_round(rs.normal(size=(N, K)) * 0.2); g = _bf16_round(rs.normal(size=(M, N)))
+    st = dev(np.concatenate([rs.normal(size=K) * 0.3, rs.uniform(0.5, 2.0, size=K), rs.normal(size=K) * 0.3 + 1.0, rs.normal(size=K) * 0.5 + 1.0]))
+    dd, Wd, gd = _to_bf16_dev(d), _to_bf16_dev(W), _to_bf16_dev(g)
+    scratch = torch.empty(16 << 20, dtype=torch.float32, device="cuda"); nb = ctypes.c_size_t(scratch.numel() * 4)
+    # forward
+    rows = L().crnn_pwconv_fwd_wres_rows(M, N, K)
+    q1 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda"); q1b = torch.zeros_like(q1); p1 = zeros(rows, 2, N); p1b = zeros(rows, 2, N)
+    ok(L().crnn_pwconv_bnrelu6_fwd_wres(P(dd), P(st), P(Wd), P(q1), M, N, K, P(p1), S()))
+    ok(L().crnn_pwconv_bnrelu6_fwd_wres(P(dd), P(st), P(Wd), P(q1b), M, N, K, P(p1b), S()))
+    q2 = torch.zeros_like(q1); p2 = zeros(L().crnn_pwconv_stat_rows(M), 2, N)
+    ok(L().crnn_pwconv_bnrelu6_fwd(P(dd), P(st), P(Wd), P(q2), M, N, K, P(p2), 1, 1, S()))
+    assert torch.equal(q1, q2) and torch.equal(q1, q1b) and torch.equal(p1, p1b), (M, N, K)
+    t1, t2 = host(p1).sum(0), host(p2).sum(0)
+    assert_close(t1, t2, rtol=3e-5, atol=3e-5 * np.abs(t2).max(), what="forward statistics %r" % ((M, N, K),))
+    # data gradient: da[M][K] = g[M][N] . Wt[K][N]^T
+    Wt = _to_bf16_dev(np.ascontiguousarray(W.T))
+    if L().crnn_gemm_wres_supported(K, N) == 0:
+        a1 = torch.zeros(M, K, dtype=torch.bfloat16, device="cuda"); a2 = torch.zeros_like(a1)
+        ok(L().crnn_gemm_wres_bf16(P(gd), P(Wt), P(a1), M, K, N, S()))
+        ok(L().crnn_gemm_bf16_ex(1, P(gd), P(Wt), P(a2), M, K, N, N, N, K, None, 0, 0, 0, None, 0, 1, 1, 1, S()))
+        assert torch.equal(a1, a2), (M, N, K)
+    # weight gradient
+    if L().crnn_pwconv_wgrad_stream_supported(M, N, K) == 0:
+        w1 = zeros(K, N); w1b = zeros(K, N); w2 = zeros(K, N)
+        ok(L().crnn_pwconv_bnrelu6_wgrad_stream(P(dd), P(st), P(gd), P(w1), M, N, K, P(scratch), nb, S()))
+        ok(L().crnn_pwconv_bnrelu6_wgrad_stream(P(dd), P(st), P(gd), P(w1b), M, N, K, P(scratch), nb, S()))
+        ok(L().crnn_pwconv_bnrelu6_wgrad(P(dd), P(st), P(gd), P(w2), M, N, K, P(scratch), nb, S()))
+        assert torch.equal(w1, w1b)
+        assert_close(host(w1), host(w2), rtol=1e-4, atol=(2e-5 + 6e-8 * M / 64) * np.abs(host(w2)).max(), what="weight gradient %r" % ((M, N, K),))
+
+
 def test_bilstm_bf16_recurrent_weights_track_the_fp64_cell():
     """crnn_lstm_fwd_ex / crnn_lstm_bwd_ex with dt_u = bf16: recurrent products on the bf16 MFMA (weights stored bf16, the
     state rounded to bf16 as it is packed).  Against the fp64 cell evaluated with the SAME bf16-rounded weights the only
