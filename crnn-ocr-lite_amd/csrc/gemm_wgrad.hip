@@ -352,7 +352,8 @@ namespace {
 struct NtsParams {
   const float* A[2]; const bf16_t* W[2];    // the (dZ, W) pairs
   float* Y;
-  int M, N, K, lda, ldw, ldy, npairs;
+  const float* bias;                        // optional [N total]: added to the finished sums (fp32), as the tile GEMM's epilogue does
+  int M, N, K, lda, ldw, ldy, npairs;       // N = columns per workgroup (128 CB); blockIdx.y selects the column slab
 };
 constexpr int kNtsRing = 3, kNtsD = 2;
 
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(768) void gemm_nt_f32_stream_kernel(NtsParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m0 = blockIdx.x * 64;
+  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * N;          // row stripe, column slab (weight rows n0 .. n0 + N - 1)
   const int kch = p.K / 64, total = kch * p.npairs;
 
   if (wave < 4) {
@@ -400,12 +401,16 @@ __global__ __launch_bounds__(768) void gemm_nt_f32_stream_kernel(NtsParams p) {
     // lane = one row; register group g of a block = columns 8 g + 4 half + 0..3
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      float* yrow = p.Y + (long)(m0 + 32 * b + l31) * p.ldy + wave * 32 * CB + 4 * half;
+      const int col0 = n0 + wave * 32 * CB + 4 * half;
+      float* yrow = p.Y + (long)(m0 + 32 * b + l31) * p.ldy + col0;
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<float4*>(yrow + 32 * cb + 8 * g) = make_float4(acc[b][cb][4 * g], acc[b][cb][4 * g + 1], acc[b][cb][4 * g + 2], acc[b][cb][4 * g + 3]);
+        for (int g = 0; g < 4; ++g) {
+          float4 v = make_float4(acc[b][cb][4 * g], acc[b][cb][4 * g + 1], acc[b][cb][4 * g + 2], acc[b][cb][4 * g + 3]);
+          if (p.bias) { const float4 bv = *reinterpret_cast<const float4*>(p.bias + col0 + 32 * cb + 8 * g); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+          *reinterpret_cast<float4*>(yrow + 32 * cb + 8 * g) = v;
+        }
     }
     return;
   }
@@ -420,7 +425,7 @@ __global__ __launch_bounds__(768) void gemm_nt_f32_stream_kernel(NtsParams p) {
     ax[0] = *reinterpret_cast<const u32x4*>(a); ax[1] = *reinterpret_cast<const u32x4*>(a + 4);
     const bf16_t* w = p.W[pr] + kc * 64 + xc * 8;
 #pragma unroll
-    for (int u = 0; u < WP; ++u) aw[u] = *reinterpret_cast<const u32x4*>(w + (long)(xr + 64 * u) * p.ldw);
+    for (int u = 0; u < WP; ++u) aw[u] = *reinterpret_cast<const u32x4*>(w + (long)(n0 + xr + 64 * u) * p.ldw);
   };
   auto write = [&](int s, const u32x4 (&ax)[2], const u32x4 (&aw)[WP]) {
     unsigned char* st = smem + (s % kNtsRing) * kSt;
@@ -458,18 +463,20 @@ __global__ __launch_bounds__(768) void gemm_nt_f32_stream_kernel(NtsParams p) {
 
 }  // namespace
 
-// Y[M][N] (fp32, row stride ldy) = A0[M][K] . W0[N][K]^T (+ A1 . W1^T when A1 != NULL); A fp32 (row stride lda), W bf16 (row stride ldw).
-// Supported (else -3): M % 64 == 0, N in {128, 256}, K % 64 == 0, leading dimensions multiples of 8, 16-byte aligned pointers.
-extern "C" int crnn_gemm_nt_f32_stream(const float* A0, const void* W0, const float* A1, const void* W1, float* Y, int M, int N, int K, int lda,
-                                       int ldw, int ldy, hipStream_t stream) {
-  if (M <= 0 || K <= 0 || !A0 || !W0 || !Y || ((A1 != nullptr) != (W1 != nullptr))) return CRNN_ERR_ARG;
-  if (M % 64 || (N != 128 && N != 256) || K % 64 || ((lda | ldw | ldy) & 7) || lda < K || ldw < K || ldy < N) return CRNN_ERR_UNSUPPORTED;
-  if ((((uintptr_t)A0 | (uintptr_t)W0 | (uintptr_t)A1 | (uintptr_t)W1 | (uintptr_t)Y) & 15)) return CRNN_ERR_UNSUPPORTED;
-  if ((long)M * (lda > ldy ? lda : ldy) >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;
+// Y[M][N] (fp32, row stride ldy) = A0[M][K] . W0[N][K]^T (+ A1 . W1^T when A1 != NULL) (+ bias[N]); A fp32 (row stride lda), W bf16 (row stride
+// ldw).  Supported (else -3): M % 64 == 0, N % 128 == 0 (column slabs of 256, or of 128 when N % 256 != 0), K % 64 == 0, leading dimensions
+// multiples of 8, 16-byte aligned pointers.
+extern "C" int crnn_gemm_nt_f32_stream_bias(const float* A0, const void* W0, const float* A1, const void* W1, float* Y, const float* bias, int M, int N,
+                                            int K, int lda, int ldw, int ldy, hipStream_t stream) {
+  if (M <= 0 || K <= 0 || N <= 0 || !A0 || !W0 || !Y || ((A1 != nullptr) != (W1 != nullptr))) return CRNN_ERR_ARG;
+  if (M % 64 || N % 128 || K % 64 || ((lda | ldw | ldy) & 7) || lda < K || ldw < K || ldy < N) return CRNN_ERR_UNSUPPORTED;
+  if ((((uintptr_t)A0 | (uintptr_t)W0 | (uintptr_t)A1 | (uintptr_t)W1 | (uintptr_t)Y | (uintptr_t)bias) & 15)) return CRNN_ERR_UNSUPPORTED;
+  if ((long)M * (lda > ldy ? lda : ldy) >= (1L << 31) || N > 65535 * 128) return CRNN_ERR_UNSUPPORTED;
+  const int slab = (N % 256 == 0) ? 256 : 128;
   NtsParams p;
-  p.A[0] = A0; p.A[1] = A1 ? A1 : A0; p.W[0] = (const bf16_t*)W0; p.W[1] = (const bf16_t*)(W1 ? W1 : W0); p.Y = Y;
-  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldy = ldy; p.npairs = A1 ? 2 : 1;
-  const int lds = kNtsRing * (64 * 128 + N * 128);
+  p.A[0] = A0; p.A[1] = A1 ? A1 : A0; p.W[0] = (const bf16_t*)W0; p.W[1] = (const bf16_t*)(W1 ? W1 : W0); p.Y = Y; p.bias = bias;
+  p.M = M; p.N = slab; p.K = K; p.lda = lda; p.ldw = ldw; p.ldy = ldy; p.npairs = A1 ? 2 : 1;
+  const int lds = kNtsRing * (64 * 128 + slab * 128);
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_f32_stream_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kNtsRing * (64 * 128 + 128 * 128));
@@ -477,8 +484,13 @@ extern "C" int crnn_gemm_nt_f32_stream(const float* A0, const void* W0, const fl
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  if (N == 128) hipLaunchKernelGGL(gemm_nt_f32_stream_kernel<1>, dim3(M / 64), dim3(768), lds, stream, p);
-  else hipLaunchKernelGGL(gemm_nt_f32_stream_kernel<2>, dim3(M / 64), dim3(768), lds, stream, p);
+  if (slab == 128) hipLaunchKernelGGL(gemm_nt_f32_stream_kernel<1>, dim3(M / 64, N / slab), dim3(768), lds, stream, p);
+  else hipLaunchKernelGGL(gemm_nt_f32_stream_kernel<2>, dim3(M / 64, N / slab), dim3(768), lds, stream, p);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
+}
+extern "C" int crnn_gemm_nt_f32_stream(const float* A0, const void* W0, const float* A1, const void* W1, float* Y, int M, int N, int K, int lda,
+                                       int ldw, int ldy, hipStream_t stream) {
+  if (N != 128 && N != 256) return (M <= 0 || K <= 0) ? CRNN_ERR_ARG : CRNN_ERR_UNSUPPORTED;
+  return crnn_gemm_nt_f32_stream_bias(A0, W0, A1, W1, Y, nullptr, M, N, K, lda, ldw, ldy, stream);
 }

@@ -145,6 +145,7 @@ Plan make_plan(const crnn_config* c) {
     for (const char* dir : {"f", "b"}) {
       P.add("xw" + p + dir, TB * d.G); P.add("cs" + p + dir, TB * d.u); P.add("gt" + p + dir, TB * d.G);
       P.add("ut" + p + dir, (long)d.G * d.u); P.add("dz" + p + dir, TB * d.G);
+      P.add("wt" + p + dir, (long)d.G * (l == 1 ? d.tds : d.u));   // bf16 W^T of the input projection (streaming xw kernel), oversized by 2
     }
   }
   P.add("h1f", TB * d.u); P.add("h1b", TB * d.u); P.add("r1", TB * d.u);
@@ -439,8 +440,10 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
   const int dtu = rnn_dtu(cfg);
   const bool persist = rnn_persist(cfg);
   const size_t xbytes = persist ? crnn_lstm_persist_xbuf_bytes(T, B, u, dtu) : 0;
-  {  // U -> U^T for the four recurrences, one launch
-    long in_off[4], out_off[4]; int R[4], Cc[4]; int n = 0;
+  // bf16 U^T: the input projections stream too (64-row stripes of X against a bf16 W^T through LDS, gemm_wgrad.hip) unless the tile schedule is asked for
+  const bool xw_stream = dtu == CRNN_BF16 && !(cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS) && TB % 64 == 0 && G % 128 == 0 && d.tds % 64 == 0 && u % 64 == 0;
+  {  // U -> U^T for the four recurrences (and W -> W^T for the streamed input projections), one launch
+    long in_off[8], out_off[8]; int R[8], Cc[8]; int n = 0;
     const char* names[4] = {"1f", "1b", "2f", "2b"};
     const long esz = (dtu == CRNN_BF16) ? 2 : 4;
     for (const char* nm : names) {
@@ -449,10 +452,22 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
       out_off[n] = (c.P.off(std::string("ut") + nm) - c.P.off("ut1f")) * 4 / esz;
       R[n] = u; Cc[n] = G; ++n;
     }
-    CRNN_TRY(crnn_transpose_batch(params, c.w("ut1f"), 4, in_off, out_off, R, Cc, dtu, stream));
+    if (xw_stream)
+      for (const char* nm : names) {
+        in_off[n] = c.L.off(std::string("rnn") + nm + "_w");
+        out_off[n] = (c.P.off(std::string("wt") + nm) - c.P.off("ut1f")) * 4 / esz;
+        R[n] = nm[0] == '1' ? d.tds : u; Cc[n] = G; ++n;
+      }
+    CRNN_TRY(crnn_transpose_batch(params, c.w("ut1f"), n, in_off, out_off, R, Cc, dtu, stream));
   }
-  CRNN_TRY(gemm(c, 0, c.w("dn1"), c.p("rnn1f_w"), c.w("xw1f"), TB, G, d.tds, d.tds, G, G, c.p("rnn1f_b")));
-  CRNN_TRY(gemm(c, 0, c.w("dn1"), c.p("rnn1b_w"), c.w("xw1b"), TB, G, d.tds, d.tds, G, G, c.p("rnn1b_b")));
+  auto xw = [&](const float* xin, int din, const char* nm) -> int {
+    const std::string s(nm);
+    if (xw_stream)
+      return crnn_gemm_nt_f32_stream_bias(xin, c.w("wt" + s), nullptr, nullptr, c.w("xw" + s), c.p("rnn" + s + "_b"), TB, G, din, din, din, G, stream);
+    return gemm(c, 0, xin, c.p("rnn" + s + "_w"), c.w("xw" + s), TB, G, din, din, G, G, c.p("rnn" + s + "_b"));
+  };
+  CRNN_TRY(xw(c.w("dn1"), d.tds, "1f"));
+  CRNN_TRY(xw(c.w("dn1"), d.tds, "1b"));
   if (cfg->gru)   // "cs" holds r*h_prev for the GRU (cell state for the LSTM)
     CRNN_TRY(crnn_gru_fwd_ex(c.w("xw1f"), c.w("xw1b"), c.w("ut1f"), c.w("ut1b"), c.w("h1f"), c.w("h1b"), u, c.w("gt1f"), c.w("gt1b"),
                              c.w("cs1f"), c.w("cs1b"), T, B, u, dtu, stream));
@@ -463,8 +478,8 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
     CRNN_TRY(crnn_lstm_fwd_ex(c.w("xw1f"), c.w("xw1b"), c.w("ut1f"), c.w("ut1b"), c.w("h1f"), c.w("h1b"), u, c.w("cs1f"), c.w("cs1b"),
                               c.w("gt1f"), c.w("gt1b"), T, B, u, dtu, stream));
   CRNN_TRY(crnn_add(c.w("h1f"), c.w("h1b"), c.w("r1"), (long)TB * u, stream));  // merge_mode='sum'
-  CRNN_TRY(gemm(c, 0, c.w("r1"), c.p("rnn2f_w"), c.w("xw2f"), TB, G, u, u, G, G, c.p("rnn2f_b")));
-  CRNN_TRY(gemm(c, 0, c.w("r1"), c.p("rnn2b_w"), c.w("xw2b"), TB, G, u, u, G, G, c.p("rnn2b_b")));
+  CRNN_TRY(xw(c.w("r1"), u, "2f"));
+  CRNN_TRY(xw(c.w("r1"), u, "2b"));
   if (cfg->gru)
     CRNN_TRY(crnn_gru_fwd_ex(c.w("xw2f"), c.w("xw2b"), c.w("ut2f"), c.w("ut2b"), c.w("h2"), c.w("h2") + u, 2 * u, c.w("gt2f"), c.w("gt2b"),
                              c.w("cs2f"), c.w("cs2b"), T, B, u, dtu, stream));

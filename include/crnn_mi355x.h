@@ -330,6 +330,10 @@ int crnn_gemm_tn_stream(const float* A, int lda, const float* B, int ldb, float*
  * multiples of 8, 16-byte aligned pointers. */
 int crnn_gemm_nt_f32_stream(const float* A0, const void* W0, const float* A1, const void* W1, float* Y, int M, int N, int K, int lda, int ldw,
                             int ldy, crnn_stream_t stream);
+/* The same kernel over column slabs of a wider result, with an optional bias added to the finished sums: Y[M][N] = A0 . W0[N][K]^T (+ A1 . W1^T)
+ * (+ bias[N]); N % 128 == 0.  The recurrent layers' input projections xw = X W + b from the bf16 W^T copies. */
+int crnn_gemm_nt_f32_stream_bias(const float* A0, const void* W0, const float* A1, const void* W1, float* Y, const float* bias, int M, int N, int K,
+                                 int lda, int ldw, int ldy, crnn_stream_t stream);
 int crnn_pwconv_fwd_wres_supported(long M, int N, int K);
 int crnn_pwconv_fwd_wres_rows(long M, int N, int K);
 int crnn_pwconv_bnrelu6_fwd_wres(const void* d, const float* in_bnstate, const void* wT, void* q, long M, int N, int K, float* stat_partials,

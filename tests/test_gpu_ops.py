@@ -933,6 +933,28 @@ def test_streaming_nt_gemm_of_the_recurrent_input_gradient_equals_the_tile_kerne
     assert L().crnn_gemm_nt_f32_stream(P(A0d), P(W0d), None, None, P(Y1), M, 192, K, K, K, 192, S()) == -3
 
 
+@pytest.mark.parametrize("M,N,K,bias", [(8192, 1024, 128, True), (8192, 1024, 256, True), (64 * 5, 384, 64, True), (64 * 3, 768, 192, False), (64, 128, 64, True)])
+def test_streaming_input_projection_equals_the_tile_kernel(M, N, K, bias):
+    """crnn_gemm_nt_f32_stream_bias (xw = X W + b of the recurrent layers from the bf16 W^T copy: column slabs of 256, or 128 when
+    N % 256 != 0, bias added to the finished fp32 sums) against crnn_gemm_bf16_ex mode 0 on the fp32 [K][N] weights (same bf16 rounding
+    of both operands, bias in the epilogue) and the fp64 product of the rounded operands.  The layers' shapes (G = 4u = 1024, din = 128 /
+    256), the GRU's 3u columns, a single stripe; the surrounding memory stays untouched; repeated launches give the same bits."""
+    rs = np.random.RandomState(M % 997 + N + K)
+    A = rs.normal(size=(M, K)); W = _bf16_round(rs.normal(size=(K, N)) * 0.2); b = rs.normal(size=(N,)) if bias else None
+    Ad, Wd, WTd = dev(A), dev(W), _to_bf16_dev(np.ascontiguousarray(W.T)); bd = dev(b) if bias else None
+    Y1 = torch.full((M + 1, N), 7.0, device="cuda"); Y3 = torch.full((M, N), 5.0, device="cuda")
+    ok(L().crnn_gemm_nt_f32_stream_bias(P(Ad), P(WTd), None, None, P(Y1), P(bd) if bias else None, M, N, K, K, K, N, S()))
+    ok(L().crnn_gemm_nt_f32_stream_bias(P(Ad), P(WTd), None, None, P(Y3), P(bd) if bias else None, M, N, K, K, K, N, S()))
+    assert torch.equal(Y1[:M], Y3) and bool((Y1[M:] == 7.0).all())
+    Y2 = zeros(M, N); scr = zeros(16 << 20)
+    ok(L().crnn_gemm_bf16_ex(0, P(Ad), P(Wd), P(Y2), M, N, K, K, N, N, P(bd) if bias else None, 0, 0, 0, P(scr), ctypes.c_size_t(scr.numel() * 4), 0, 0, 0, S()))
+    ref = _bf16_round(A) @ W + (b if bias else 0.0)
+    tol = 2e-5 * np.abs(ref).max() + 1e-6 * np.sqrt(K)
+    assert_close(host(Y3), host(Y2), rtol=1e-4, atol=tol, what="stream vs tile kernel")
+    assert_close(host(Y3), ref, rtol=1e-4, atol=tol, what="stream vs fp64")
+    assert L().crnn_gemm_nt_f32_stream_bias(P(Ad), P(WTd), None, None, P(Y3), None, M, 192, K, K, K, 192, S()) == -3
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_streaming_pointwise_kernels_on_random_shapes(seed):
     """The three streaming pointwise-conv kernels on drawn shapes (stripe counts around the grid size, 1..8 channel slices, every K,
