@@ -33,33 +33,43 @@ PEAK_HBM_GBS = 8000.0
 
 
 def depthwise_roofline(eng, iters=15):
-    """Dominant kernel of the step (rocprofv3: largest total time) = dwconv_tile_kernel<0>: the depthwise 3x3 of
-    blocks 2..7, forward (with the BatchNorm-statistics epilogue) and data-gradient (flipped taps) = 12 launches per
-    step.  HBM-bound.  Re-issue exactly those launches on the live buffers between events on the launch stream.
-    Algorithmic bytes per launch = read H*W*C + write H*W*C fp32 per image, weights negligible."""
+    """The HBM-bound kernel north_star singles out: the depthwise 3x3 of blocks 2..7.  bf16s (the headline mode): the six forward
+    launches of a step (each with the BatchNorm-statistics epilogue) exactly as the step issues them -- dw_fwd_stream_kernel where its
+    shape rule holds (every block of the CRNN), dwconv_tile_kernel<0> otherwise or under CRNN_FLAG_DW_TILE_KERNEL; the data gradient
+    lives in the fused depthwise-stage backward (dw_bwd_roofline).  fp32 / bf16 modes: dwconv_tile_kernel<0> forward + data gradient
+    (flipped taps) = 12 launches.  Re-issued on the live buffers between events on the launch stream.  Algorithmic bytes per launch
+    = read H*W*C + write H*W*C elements per image in the storage type, weights negligible."""
     from crnn_mi355x.engine import _ptr, _stream
     lib = eng.lib
     B = eng.B
     blocks = [(64, 1, 1), (128, 1, 1), (256, 2, 2), (256, 1, 1), (512, 1, 2), (512, 1, 1), (512, 1, 1)]
     h, w, cin = eng.cfg.imgh + 4, eng.cfg.imgw + 4, 1
     launches, nbytes = [], 0.0
-    esz = 2 if eng.precision == "bf16s" else 4          # storage bytes per element of the conv-stack tensors
-    dtype = 1 if eng.precision == "bf16s" else 0
+    bf16s = eng.precision == "bf16s"
+    esz = 2 if bf16s else 4          # storage bytes per element of the conv-stack tensors
+    dtype = 1 if bf16s else 0
     parts = eng.ws_tensor("partials")
+    nstream = 0
     for i, (co, ph, pw) in enumerate(blocks, 1):
         if i >= 2:
             k = eng.params[eng.layout["b%d_dw" % i][0]:]
-            launches.append((eng.ws_tensor("x%d" % (i - 1)), k, eng.ws_tensor("d%d" % i), parts, h, w, cin, 0))   # forward
-            launches.append((eng.ws_tensor("gB"), k, eng.ws_tensor("gA"), None, h, w, cin, 1))                    # data gradient
-            nbytes += 2 * (2.0 * B * h * w * cin * esz)
+            st = bf16s and not (eng.cfg.flags & 32) and lib.crnn_dwconv_fwd_stream_supported(B, h, w, cin) == 0
+            nstream += int(st)
+            launches.append((eng.ws_tensor("x%d" % (i - 1)), k, eng.ws_tensor("d%d" % i), parts, h, w, cin, 0, st))   # forward
+            nbytes += 2.0 * B * h * w * cin * esz
+            if not bf16s:
+                launches.append((eng.ws_tensor("gB"), k, eng.ws_tensor("gA"), None, h, w, cin, 1, False))            # data gradient
+                nbytes += 2.0 * B * h * w * cin * esz
         h, w, cin = h // ph, w // pw, co
-    fn = lib.crnn_dwconv3x3_fwd_ex
     times = []
     for it in range(iters + 1):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for x, k, o, pt, hh, ww, cc, flip in launches:
-            fn(_ptr(x), _ptr(k), _ptr(o), _ptr(pt), B, hh, ww, cc, flip, dtype, _stream())
+        for x, k, o, pt, hh, ww, cc, flip, st in launches:
+            if st:
+                lib.crnn_dwconv3x3_fwd_stream(_ptr(x), _ptr(k), _ptr(o), _ptr(pt), None, B, hh, ww, cc, flip, _stream())
+            else:
+                lib.crnn_dwconv3x3_fwd_ex(_ptr(x), _ptr(k), _ptr(o), _ptr(pt), B, hh, ww, cc, flip, dtype, _stream())
         e1.record()
         torch.cuda.synchronize()
         if it:
@@ -67,19 +77,29 @@ def depthwise_roofline(eng, iters=15):
     t = float(np.median(times))
     ach = nbytes / t / 1e9
     # HBM bytes of the same launch set from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE as separate
-    # counter-only runs over scripts/dw_bench.py at batch 256 -- scripts/gpu_round.sh -- folded by scripts/pmc_summary.py
+    # counter-only runs over scripts/dw_bench.py at batch 256 -- scripts/gpu_round2.sh -- folded by scripts/pmc_summary.py
     # and committed under profiles/; FETCH_SIZE x2 per the gfx950 note in MI355X_MICROARCH.md)
     traffic = None
     try:
         pmc_file = [f for f in ("r02_pmc_dwconv.json", "r01_pmc_dwconv.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
         pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
         if B == pmc["batch"] and (eng.cfg.imgh, eng.cfg.imgw) == (100, 32):
-            sh = pmc["modes"]["bf16" if esz == 2 else "fp32"]["shapes"]
-            traffic = 2 * sh["104x36x64"]["hbm_bytes_per_launch"] + 2 * sh["104x36x128"]["hbm_bytes_per_launch"] \
-                + 4 * sh["52x18x256"]["hbm_bytes_per_launch"] + 4 * sh["52x9x512"]["hbm_bytes_per_launch"]
+            if nstream == len(launches):
+                sh = pmc["stream"]["shapes"]
+                traffic = sh["104x36x64"]["hbm_bytes_per_launch"] + sh["104x36x128"]["hbm_bytes_per_launch"] \
+                    + 2 * sh["52x18x256"]["hbm_bytes_per_launch"] + 2 * sh["52x9x512"]["hbm_bytes_per_launch"]
+            elif nstream == 0:
+                sh = pmc["modes"]["bf16" if esz == 2 else "fp32"]["shapes"]
+                per = len(launches) // 6
+                traffic = per * (sh["104x36x64"]["hbm_bytes_per_launch"] + sh["104x36x128"]["hbm_bytes_per_launch"]
+                                 + 2 * sh["52x18x256"]["hbm_bytes_per_launch"] + 2 * sh["52x9x512"]["hbm_bytes_per_launch"])
     except Exception:
         pass
-    return {"bound": "hbm", "kernel": "dwconv_tile_kernel<0> (depthwise 3x3 fwd + data-gradient, blocks 2-7, LDS halo tiles)",
+    kname = ("dw_fwd_stream_kernel (depthwise 3x3 forward + BatchNorm statistics, blocks 2-7: rows streamed through an LDS ring by a loader wave)"
+             if nstream == len(launches) else
+             "dwconv_tile_kernel<0> (depthwise 3x3 fwd%s, blocks 2-7, LDS halo tiles)" % ("" if bf16s else " + data-gradient")
+             if nstream == 0 else "dw_fwd_stream_kernel + dwconv_tile_kernel<0> (depthwise 3x3 forward, blocks 2-7)")
+    return {"bound": "hbm", "kernel": kname,
             "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
             "launches": len(launches), "avg_launch_ms": round(1e3 * t / len(launches), 4),
             "algorithmic_bytes_per_launch_set": nbytes, "traffic": traffic}
@@ -155,7 +175,9 @@ def pointwise_gemm_roofline(eng, iters=5):
     cfgs.append((eng.ws_tensor("x7"), W("dense1_w"), eng.ws_tensor("gA"), TB, eng.cfg.tds, feat, sdt, 0, 0))
     u, G = eng.cfg.units, (3 if eng.cfg.gru else 4) * eng.cfg.units
     for n, src, k in (("rnn1f_w", "dn1", eng.cfg.tds), ("rnn1b_w", "dn1", eng.cfg.tds), ("rnn2f_w", "r1", u), ("rnn2b_w", "r1", u)):
-        cfgs.append((eng.ws_tensor(src), W(n), eng.ws_tensor("gB"), TB, G, k, 0, 0, 0))
+        # bf16 modes: the step's streaming kernel on the bf16 W^T copy the forward keeps (model.hip xw_stream), else the tile GEMM
+        xs = bf and u % 128 == 0 and not (eng.cfg.flags & 2) and TB % 64 == 0 and G % 128 == 0 and k % 64 == 0
+        cfgs.append((eng.ws_tensor(src), W(n), eng.ws_tensor("gB"), TB, G, k, 0, 0, ("xw", eng.ws_tensor("wt" + n[3:5])) if xs else 0))
     flops = sum(2.0 * M * N * K for _, _, _, M, N, K, _, _, _ in cfgs)
     # algorithmic HBM bytes of the same launches: A read + C written once, in their storage types (weights negligible)
     hbm_bytes = sum(M * K * (2.0 if dta else 4.0) + M * N * (2.0 if dtc else 4.0) for _, _, _, M, N, K, dta, dtc, _ in cfgs)
@@ -164,7 +186,9 @@ def pointwise_gemm_roofline(eng, iters=5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for A, Bm, C, M, N, K, dta, dtc, wt in cfgs:
-            if isinstance(wt, tuple):
+            if isinstance(wt, tuple) and wt[0] == "xw":
+                lib.crnn_gemm_nt_f32_stream_bias(_ptr(A), _ptr(wt[1]), None, None, _ptr(C), None, M, N, K, K, K, N, _stream())
+            elif isinstance(wt, tuple):
                 if not (eng.cfg.flags & 2) and lib.crnn_pwconv_fwd_wres_supported(M, N, K) == 0:
                     lib.crnn_pwconv_bnrelu6_fwd_wres(_ptr(A), _ptr(wt[1]), _ptr(Bm), _ptr(C), M, N, K, _ptr(parts), _stream())
                 else:
@@ -180,8 +204,9 @@ def pointwise_gemm_roofline(eng, iters=5):
             times.append(e0.elapsed_time(e1) * 1e-3)
     t = float(np.median(times))
     ach = flops / t / 1e12
-    kname = ("gemm_wres_fwd_kernel (pointwise 1x1 convs fwd incl. BN+ReLU6 prologue and statistics) + gemm_bf16_kernel (dense1, RNN input GEMMs)"
-             if any(isinstance(c[8], tuple) for c in cfgs) else
+    kname = ("gemm_wres_fwd_kernel (pointwise 1x1 convs fwd incl. BN+ReLU6 prologue and statistics) + gemm_bf16_kernel (dense1) + "
+             "gemm_nt_f32_stream_kernel (RNN input projections)"
+             if any(isinstance(c[8], tuple) and c[8][0] == "pw" for c in cfgs) else
              "gemm_%s_kernel<128,false,true> (pointwise 1x1 convs fwd + dense1 + RNN input GEMMs)" % ("bf16" if bf else "f32"))
     return {"bound": "mfma", "kernel": kname,
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),

@@ -14,7 +14,7 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 HEADER = os.path.join(REPO_ROOT, "include", "crnn_mi355x.h")
 CSRC = os.path.join(PKG_ROOT, "csrc")
 LIB_PATH = os.path.join(PKG_ROOT, "libcrnn_mi355x.so")
-SOURCES = ["gemm.hip", "gemm_nt.hip", "gemm_wres.hip", "gemm_wgrad.hip", "conv.hip", "conv_bwd_fused.hip", "stn.hip", "rnn.hip", "rnn_persist.hip", "ctc.hip", "beam.hip", "optim.hip", "model.hip"]
+SOURCES = ["gemm.hip", "gemm_nt.hip", "gemm_wres.hip", "gemm_wgrad.hip", "conv.hip", "conv_bwd_fused.hip", "dwconv_stream.hip", "stn.hip", "rnn.hip", "rnn_persist.hip", "ctc.hip", "beam.hip", "optim.hip", "model.hip"]
 
 
 class crnn_config(ctypes.Structure):
@@ -26,6 +26,7 @@ FLAG_RNN_STEP_KERNELS = 1      # CRNN_FLAG_RNN_STEP_KERNELS
 FLAG_GEMM_TILE_KERNELS = 2     # CRNN_FLAG_GEMM_TILE_KERNELS
 FLAG_NO_DW_BN_FUSION = 8       # CRNN_FLAG_NO_DW_BN_FUSION
 FLAG_NO_DW_BWD_FUSION = 16     # CRNN_FLAG_NO_DW_BWD_FUSION
+FLAG_DW_TILE_KERNEL = 32       # CRNN_FLAG_DW_TILE_KERNEL
 
 
 _CTYPE = [("crnn_stream_t", ctypes.c_void_p), ("size_t", ctypes.c_size_t), ("uint64_t", ctypes.c_uint64),

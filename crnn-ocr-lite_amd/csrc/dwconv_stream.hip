@@ -1,0 +1,292 @@
+// Depthwise 3x3 convolution (reference utils.py:44, DepthwiseConv2D(3x3, padding='same', no bias)) of a bf16 NHWC map as a ROW STREAM:
+//     out[n][y][x][c] = sum_{i,j} k[3i+j][c] * in[n][y+i-1][x+j-1][c]      (+ BatchNorm statistics of out, or the folded BN + ReLU6)
+//
+// The halo-tile kernel (conv.hip) alternates "fill a tile" and "compute it" inside a workgroup and relies on three workgroups per
+// CU to overlap the two; its waves are parked a third of the time.  Here one workgroup walks a band of image rows top to bottom:
+//   * a LOADER wave puts whole rows (all channels: W*C*2 contiguous bytes, 9 KiB for every block of the CRNN) into an LDS ring with
+//     global_load_lds (16 B per lane, no VGPR staging) D rows ahead, under a counted s_waitcnt vmcnt(N);
+//   * up to 9 COMPUTE waves own one 16-byte column (pixel x, 8 channels) of the row each.  The three-row window is never held: when
+//     input row r arrives it is read ONCE from LDS (x-1, x, x+1: three ds_read_b128) and contributes its taps to three running
+//     sums - output rows r-1 (taps 6..8: now complete, rounded, stored), r (taps 3..5) and r+1 (taps 0..2).  Every output is the
+//     same fp32 fma chain (tap order 0..8) as the tile kernel's: bit-identical results;
+//   * one s_barrier per row hands the row over; the ring needs D+1 slots only because nothing is re-read.
+// No halo re-reads inside a band (a band boundary re-reads 2 rows), zero padding = a 16-byte zero chunk in LDS for the row ends and
+// peeled first/last steps for the rows above and below the image.  Narrow maps run NS bands of the same image side by side in one
+// workgroup so that the step row always fills the 9 waves (block 2: 2 x 36 px x 64 ch; blocks 3-7: W*C = 4608).
+// BatchNorm statistics: per-lane fp32 sums over the band, combined over the pixel columns through LDS in a fixed order: one
+// partial row [2][C] per workgroup.
+#include "common.h"
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef CRNN_DWS_EXP
+#define CRNN_DWS_EXP 0      // experiment builds: 1 = no DMA, 2 = no stores, 4 = no fmas, 8 = nontemporal stores, 16 = nontemporal loads
+#endif
+
+struct DwsParams {
+  const unsigned char* x; const float* k; unsigned char* out; float* partials; const float* bnstate;
+  int H, W, C, HB, NS, nwgb, flip, cols, rowbytes;
+};
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, (CRNN_DWS_EXP & 16) ? 2 : 0);
+}
+__device__ __forceinline__ void widen8(const u32x4& u, float (&f)[8]) {
+  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+
+constexpr int kDwsMaxWaves = 9;     // compute waves (576 columns of 16 bytes)
+
+// NI: 1 KiB DMA instructions per step row; D: rows in flight; EPI: out = ReLU6(conv * scale + shift) (inference), no statistics
+template <int NI, int D, bool EPI>
+__global__ __launch_bounds__((kDwsMaxWaves + 1) * 64) void dw_fwd_stream_kernel(DwsParams p) {
+  constexpr int NR = D + 1, SLOT = NI * 1024;
+  static_assert((D - 1) * NI <= 63, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ncw = (int)(blockDim.x >> 6) - 1;
+  const int img = blockIdx.x / p.nwgb, wb = blockIdx.x - img * p.nwgb;
+  const int r0 = wb * p.NS * p.HB;                 // first output row of sub-band 0
+  const int steps = p.HB + 2;                      // input rows r0-1 .. r0+HB of every sub-band
+  const int zoff = NR * SLOT;                      // 16 zero bytes (the pixels left of x = 0 and right of x = W-1)
+  if (tid < 4) reinterpret_cast<unsigned*>(lds + zoff)[tid] = 0u;
+
+  if (wave == ncw) {
+    // ------------------------------------------------------------------ loader wave
+    const unsigned char* gx = p.x + (long)img * p.H * p.rowbytes;
+    int rowfirst[NI], within[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int f = i * 1024 + lane * 16;
+      int s = f / p.rowbytes, w = f - s * p.rowbytes;
+      if (s >= p.NS) { s = p.NS - 1; w = p.rowbytes - 16; }     // past the step row: re-read its last chunk (lands in the slot's unused tail)
+      rowfirst[i] = r0 + s * p.HB - 1; within[i] = w;
+    }
+    auto issue = [&](int t, int slot) {
+      t = t < steps ? t : steps - 1;                           // past the end: the last row again, into a slot nobody reads any more
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        int row = rowfirst[i] + t;
+        row = row < 0 ? 0 : (row >= p.H ? p.H - 1 : row);      // rows outside the image: any valid row (the compute waves substitute zeros)
+        if (!(CRNN_DWS_EXP & 1)) glds16(gx + (long)row * p.rowbytes + within[i], lds + slot * SLOT + i * 1024);
+      }
+    };
+#pragma unroll
+    for (int t = 0; t < D; ++t) issue(t, t);
+    int slot = D;                                              // slot of row t + D
+    for (int t = 0; t < steps; ++t) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NI) : "memory");   // row t has landed
+      __builtin_amdgcn_s_barrier();
+      issue(t + D, slot);                                      // the slot row t-1 has just released
+      slot = slot + 1 == NR ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                              // ring free: the statistics reduction may use it
+    if (!EPI && p.partials) __builtin_amdgcn_s_barrier();
+  } else {
+    // ------------------------------------------------------------------ compute waves
+    const int col = wave * 64 + lane;
+    const bool act = col < p.cols;
+    const int ccol = act ? col : p.cols - 1;                   // idle lanes of the last wave shadow the last column
+    const int cpp = p.C >> 3;                                  // 16-byte columns per pixel
+    const int pxs = ccol / cpp, oct = ccol - pxs * cpp;
+    const int sub = pxs / p.W, px = pxs - sub * p.W;
+    const int offC = ccol * 16, pitch = p.C * 2;
+    const bool hasL = px > 0, hasR = px < p.W - 1;
+    float kw[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float* kp = p.k + (long)(p.flip ? 8 - t : t) * p.C + oct * 8;
+      const float4 a = *reinterpret_cast<const float4*>(kp), b = *reinterpret_cast<const float4*>(kp + 4);
+      kw[t][0] = a.x; kw[t][1] = a.y; kw[t][2] = a.z; kw[t][3] = a.w; kw[t][4] = b.x; kw[t][5] = b.y; kw[t][6] = b.z; kw[t][7] = b.w;
+    }
+    float esc[8], esh[8];
+    if (EPI) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { esc[e] = p.bnstate[2 * p.C + oct * 8 + e]; esh[e] = p.bnstate[3 * p.C + oct * 8 + e]; }
+    }
+    float X0[8], X1[8], X2[8], s[8], ss[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { X0[e] = X1[e] = X2[e] = 0.f; s[e] = ss[e] = 0.f; }
+    const int rsub = r0 + sub * p.HB;                          // this lane's first output row
+    unsigned char* orow = p.out + ((long)img * p.H + rsub) * p.rowbytes + px * pitch + oct * 16;
+    int slot = 0;
+    // one step: input row t of the band (image row rsub - 1 + t) -> taps 6..8 of output t-2 (A: complete), 3..5 of t-1 (Bc), 0..2 of t (Cn)
+    auto step = [&](int t, float (&A)[8], float (&Bc)[8], float (&Cn)[8], bool edge) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const unsigned char* sb = lds + slot * SLOT;
+      u32x4 vL = *reinterpret_cast<const u32x4*>(hasL ? sb + offC - pitch : lds + zoff);
+      u32x4 vC = *reinterpret_cast<const u32x4*>(sb + offC);
+      u32x4 vR = *reinterpret_cast<const u32x4*>(hasR ? sb + offC + pitch : lds + zoff);
+      slot = slot + 1 == NR ? 0 : slot + 1;
+      if (edge) {
+        const int g = rsub - 1 + t;
+        if (g < 0 || g >= p.H) { vL = (u32x4)(0u); vC = (u32x4)(0u); vR = (u32x4)(0u); }
+      }
+      if (!(CRNN_DWS_EXP & 4)) {
+        float f[8];
+        widen8(vL, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { A[e] = fmaf(f[e], kw[6][e], A[e]); Bc[e] = fmaf(f[e], kw[3][e], Bc[e]); Cn[e] = fmaf(f[e], kw[0][e], 0.f); }
+        widen8(vC, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { A[e] = fmaf(f[e], kw[7][e], A[e]); Bc[e] = fmaf(f[e], kw[4][e], Bc[e]); Cn[e] = fmaf(f[e], kw[1][e], Cn[e]); }
+        widen8(vR, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { A[e] = fmaf(f[e], kw[8][e], A[e]); Bc[e] = fmaf(f[e], kw[5][e], Bc[e]); Cn[e] = fmaf(f[e], kw[2][e], Cn[e]); }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { A[e] += __uint_as_float(vL[e]); A[e + 4] += __uint_as_float(vC[e]); Bc[e] += __uint_as_float(vR[e]); }
+      }
+      if (t >= 2 && act) {
+        if (EPI) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) A[e] = relu6f(fmaf(A[e], esc[e], esh[e]));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { s[e] += A[e]; ss[e] = fmaf(A[e], A[e], ss[e]); }
+        }
+        u32x4 o;
+        o.x = pack2_bf16(A[0], A[1]); o.y = pack2_bf16(A[2], A[3]); o.z = pack2_bf16(A[4], A[5]); o.w = pack2_bf16(A[6], A[7]);
+        if (CRNN_DWS_EXP & 8) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(orow + (long)(t - 2) * p.rowbytes));
+        else if (!(CRNN_DWS_EXP & 2)) *reinterpret_cast<u32x4*>(orow + (long)(t - 2) * p.rowbytes) = o;
+      }
+    };
+    step(0, X1, X2, X0, true);
+    step(1, X2, X0, X1, false);
+    int t = 2;
+    for (; t + 3 <= steps - 1; t += 3) {          // whole groups of three that do not contain the last step
+      step(t, X0, X1, X2, false);
+      step(t + 1, X1, X2, X0, false);
+      step(t + 2, X2, X0, X1, false);
+    }
+    for (int r = 0; t < steps; ++t, ++r) {        // 1..3 remaining steps, the last one reads the row below the band
+      if (r == 0) step(t, X0, X1, X2, true);
+      else if (r == 1) step(t, X1, X2, X0, true);
+      else step(t, X2, X0, X1, true);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (!EPI && p.partials) {
+      float* red = reinterpret_cast<float*>(lds);
+      const int nthr = ncw * 64;
+      if (cpp <= 64 && (cpp & (cpp - 1)) == 0) {
+        // lanes l, l + cpp, l + 2 cpp, ... of a wave hold the same channels of different pixels: xor-shuffle them together, then one
+        // record [wave][octet][sum 8 | sumsq 8] per wave in LDS and a fixed-order sum over the waves
+        for (int o = cpp; o < 64; o <<= 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { s[e] += __shfl_xor(s[e], o, 64); ss[e] += __shfl_xor(ss[e], o, 64); }
+        }
+        if (lane < cpp) {
+          float* dst = red + (wave * cpp + lane) * 16;
+#pragma unroll
+          for (int e = 0; e < 8; e += 4) {
+            *reinterpret_cast<float4*>(dst + e) = make_float4(s[e], s[e + 1], s[e + 2], s[e + 3]);
+            *reinterpret_cast<float4*>(dst + 8 + e) = make_float4(ss[e], ss[e + 1], ss[e + 2], ss[e + 3]);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // wave w holds octets (64 w + lane) % cpp: with cpp < 64 every wave holds all of them, with cpp == 64 likewise (octet = lane)
+        for (int ch = tid; ch < 2 * p.C; ch += nthr) {
+          const int c = ch < p.C ? ch : ch - p.C;
+          const float* src = red + (c >> 3) * 16 + (ch < p.C ? 0 : 8) + (c & 7);
+          float a = 0.f;
+          for (int w = 0; w < ncw; ++w) a += src[w * cpp * 16];
+          p.partials[(long)blockIdx.x * 2 * p.C + ch] = a;
+        }
+      } else {
+        if (act) {   // [cols][16]
+#pragma unroll
+          for (int e = 0; e < 8; e += 4) {
+            *reinterpret_cast<float4*>(red + col * 16 + e) = make_float4(s[e], s[e + 1], s[e + 2], s[e + 3]);
+            *reinterpret_cast<float4*>(red + col * 16 + 8 + e) = make_float4(ss[e], ss[e + 1], ss[e + 2], ss[e + 3]);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int npx = p.NS * p.W;
+        for (int ch = tid; ch < 2 * p.C; ch += nthr) {            // ch < C: sum, else sum of squares; pixel columns in ascending order
+          const int c = ch < p.C ? ch : ch - p.C;
+          const float* src = red + (c >> 3) * 16 + (ch < p.C ? 0 : 8) + (c & 7);
+          float a = 0.f;
+          for (int q = 0; q < npx; ++q) a += src[(long)q * cpp * 16];
+          p.partials[(long)blockIdx.x * 2 * p.C + ch] = a;
+        }
+      }
+    }
+  }
+}
+
+struct DwsGeom { int NS, nwgb, HB, cols, ncw; bool ok; };
+DwsGeom dws_geom(int B, int H, int W, int C) {
+  DwsGeom g; g.ok = false; g.NS = g.nwgb = g.HB = g.cols = g.ncw = 0;
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8) return g;
+  const long rowbytes = (long)W * C * 2, cols1 = (long)W * C / 8;
+  if (cols1 > kDwsMaxWaves * 64) return g;
+  int NS = (int)(kDwsMaxWaves * 64 / cols1);
+  while (NS > 1 && H % NS) --NS;
+  if (NS * rowbytes <= 8 * 1024 || NS * rowbytes > 9 * 1024) return g;     // the 9-instruction step row only (every block of the CRNN)
+  // bands per image over workgroups: enough workgroups for the chip, bands of at least 8 rows
+  int nwgb = 1;
+#ifndef CRNN_DWS_WGS
+#define CRNN_DWS_WGS 256
+#endif
+  const int want = CRNN_DWS_WGS;
+  for (int n = 1; n <= H / NS; ++n) {
+    if ((H / NS) % n || H / NS / n < 8) continue;
+    nwgb = n;
+    if ((long)B * n >= want) break;
+  }
+  if (H % (NS * nwgb)) return g;
+  g.NS = NS; g.nwgb = nwgb; g.HB = H / (NS * nwgb); g.cols = (int)(NS * cols1); g.ncw = (g.cols + 63) / 64; g.ok = true;
+  return g;
+}
+
+#ifndef CRNN_DWS_D
+#define CRNN_DWS_D 4
+#endif
+constexpr int kDwsD = CRNN_DWS_D;     // rows in flight per workgroup (2..7 measured: 4.4 / 4.6 / 4.6 / 4.5 TB/s at 2 / 3 / 4 / 7)
+
+template <bool EPI>
+int dws_launch(const DwsParams& p, const DwsGeom& g, int B, hipStream_t stream) {
+  constexpr int lds = (kDwsD + 1) * 9 * 1024 + 64;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)dw_fwd_stream_kernel<9, kDwsD, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((dw_fwd_stream_kernel<9, kDwsD, EPI>), dim3(B * g.nwgb), dim3((g.ncw + 1) * 64), lds, stream, p);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+
+}  // namespace
+
+// CRNN_OK when crnn_dwconv3x3_fwd_stream takes the shape (bf16 storage; W*C*2 bytes per row such that a whole number of bands fills
+// the 9 KiB step row), else CRNN_ERR_UNSUPPORTED: the caller uses the halo-tile kernel (crnn_dwconv3x3_fwd_ex).
+extern "C" int crnn_dwconv_fwd_stream_supported(int B, int H, int W, int C) { return dws_geom(B, H, W, C).ok ? CRNN_OK : CRNN_ERR_UNSUPPORTED; }
+// rows [2][C] of statistics partials the launch writes (one per workgroup)
+extern "C" int crnn_dwconv_fwd_stream_rows(int B, int H, int W, int C) { DwsGeom g = dws_geom(B, H, W, C); return g.ok ? B * g.nwgb : 0; }
+// out = dwconv3x3(x, k[9][C]) on bf16 NHWC maps (flip = 1: the data gradient).  stat_partials != NULL: [rows][2][C] sums / sums of squares of
+// the fp32 results (BatchNorm batch statistics); bnstate != NULL ([mean|var|scale|shift]): out = ReLU6(conv * scale + shift) (inference), no
+// statistics.  Results bit-identical to crnn_dwconv3x3_fwd_ex / crnn_dwconv3x3_bn_relu6_fwd.
+extern "C" int crnn_dwconv3x3_fwd_stream(const void* x, const float* k, void* out, float* stat_partials, const float* bnstate, int B, int H, int W,
+                                         int C, int flip, hipStream_t stream) {
+  if (!x || !k || !out) return CRNN_ERR_ARG;
+  DwsGeom g = dws_geom(B, H, W, C);
+  if (!g.ok || (((uintptr_t)x | (uintptr_t)out | (uintptr_t)k | (uintptr_t)bnstate) & 15)) return CRNN_ERR_UNSUPPORTED;
+  if ((long)H * W * C * 2 >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;
+  DwsParams p;
+  p.x = (const unsigned char*)x; p.k = k; p.out = (unsigned char*)out; p.partials = bnstate ? nullptr : stat_partials; p.bnstate = bnstate;
+  p.H = H; p.W = W; p.C = C; p.HB = g.HB; p.NS = g.NS; p.nwgb = g.nwgb; p.flip = flip; p.cols = g.cols; p.rowbytes = W * C * 2;
+  return bnstate ? dws_launch<true>(p, g, B, stream) : dws_launch<false>(p, g, B, stream);
+}

@@ -133,6 +133,7 @@ Plan make_plan(const crnn_config* c) {
     long tiles = crnn_dwconv_num_tiles(d.B, d.bh[i], d.bw[i]);
     maxparts = lmax(maxparts, tiles * 9L * ci);
     maxparts = lmax(maxparts, (long)crnn_dwconv_bwd_fused_rows(d.B, d.bh[i], d.bw[i], ci) * 9L * ci);
+    maxparts = lmax(maxparts, (long)crnn_dwconv_fwd_stream_rows(d.B, d.bh[i], d.bw[i], ci) * 2L * ci);
     maxparts = lmax(maxparts, (long)crnn_colreduce_chunks(M) * 2L * lmax(ci, co));
     maxparts = lmax(maxparts, (long)crnn_pwconv_stat_rows(M) * 2L * co);
     maxparts = lmax(maxparts, (long)crnn_pwconv_fwd_wres_rows(M, co, ci) * 2L * co);   // one row per IO wave and stripe lane: more rows than tiles at small batches
@@ -358,13 +359,17 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
     const int dtd = c.dt("d" + p), dtq = c.dt("q" + p);
     const int ph = kBlocks[i - 1].ph, pw = kBlocks[i - 1].pw;
     const int slab = (dtd == CRNN_BF16) ? 64 : 32;
+    // bf16 maps whose rows fill the 9 KiB step row: the row-stream kernel (dwconv_stream.hip), bit-identical to the halo-tile kernel
+    const bool dws = dtd == CRNN_BF16 && !(cfg->flags & CRNN_FLAG_DW_TILE_KERNEL) && crnn_dwconv_fwd_stream_supported(B, H, W, ci) == CRNN_OK;
     if (!train) {
       // inference (learning_phase 0): the BatchNorm scale/shift are known up front, so BN + ReLU6 fold into the
       // epilogue of the conv that feeds them -- the depthwise kernel writes `a` directly and, when the block has no
       // pooling, the pointwise GEMM writes the block output directly: two passes per block instead of four
       CRNN_TRY(crnn_bn_infer_state(bn_mean + bn_off, bn_var + bn_off, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), ci, s1, stream));
       bn_off += ci;
-      if (ci % slab == 0) {
+      if (dws) {
+        CRNN_TRY(crnn_dwconv3x3_fwd_stream(in, c.p(bp + "_dw"), aa, nullptr, s1, B, H, W, ci, 0, stream));
+      } else if (ci % slab == 0) {
         CRNN_TRY(crnn_dwconv3x3_bn_relu6_fwd(in, c.p(bp + "_dw"), s1, aa, B, H, W, ci, dtd, stream));
       } else {
         CRNN_TRY(crnn_dwconv3x3_fwd_ex(in, c.p(bp + "_dw"), dd, nullptr, B, H, W, ci, 0, dtd, stream));
@@ -394,7 +399,10 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
       in = xo;
       continue;
     }
-    if (ci % 32 == 0 && ci % slab == 0) {
+    if (dws) {
+      CRNN_TRY(crnn_dwconv3x3_fwd_stream(in, c.p(bp + "_dw"), dd, parts, nullptr, B, H, W, ci, 0, stream));
+      CRNN_TRY(crnn_bn_finalize_folded(parts, crnn_dwconv_fwd_stream_rows(B, H, W, ci), ci, M, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), s1, c.w("fold"), stream));
+    } else if (ci % 32 == 0 && ci % slab == 0) {
       CRNN_TRY(crnn_dwconv3x3_fwd_ex(in, c.p(bp + "_dw"), dd, parts, B, H, W, ci, 0, dtd, stream));
       CRNN_TRY(crnn_bn_finalize_folded(parts, crnn_dwconv_num_tiles(B, H, W), ci, M, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), s1, c.w("fold"), stream));
     } else {

@@ -39,6 +39,8 @@ typedef struct {
                        conv-stack activations / gradients are stored as bf16 in HBM (statistics, RNN, CTC, optimizer fp32) */
   int flags;        /* bit set of CRNN_FLAG_* (0 = the default schedule); A/B switches: bit-identical results except where a flag says otherwise */
 } crnn_config;
+#define CRNN_FLAG_DW_TILE_KERNEL 32    /* bf16-storage modes: depthwise 3x3 forward on the halo-tile kernel (crnn_dwconv3x3_fwd_ex) instead of the row-stream
+                                        * kernel (crnn_dwconv3x3_fwd_stream); results bit-identical, BatchNorm statistics to summation round-off */
 #define CRNN_FLAG_NO_DW_BWD_FUSION 16 /* bf16-storage training: depthwise-stage backward as three kernels (BatchNorm backward pass 2, depthwise weight
                                          gradient, depthwise data gradient) instead of crnn_dwconv3x3_bwd_fused; same data gradients bit for bit */
 #define CRNN_FLAG_NO_DW_BN_FUSION 8   /* bf16-storage training: materialise a = ReLU6(BN(d)) in a pass of its own instead of applying it while the
@@ -187,6 +189,16 @@ int crnn_pw1_bwd(const float* a, const float* w, const void* dq, float* da, floa
  * out = ReLU6(dwconv3x3(x, k) * scale + shift); C must be a multiple of 32 (fp32 storage) / 64 (bf16 storage). */
 int crnn_dwconv3x3_bn_relu6_fwd(const void* x, const float* k, const float* bnstate, void* out, int B, int H, int W, int C,
                                 int dtype, crnn_stream_t stream);
+/* Depthwise 3x3 of a bf16 NHWC map as a row stream (dwconv_stream.hip): a loader wave keeps whole rows (W*C*2 contiguous bytes) in flight
+ * into an LDS ring with global_load_lds, the compute waves own a 16-byte column each and add every arriving row's taps to three running output
+ * rows (nothing is held or re-read).  stat_partials != NULL: [crnn_dwconv_fwd_stream_rows][2][C] BatchNorm partial sums of the fp32 results;
+ * bnstate != NULL ([mean|var|scale|shift]): out = ReLU6(conv * scale + shift) (inference), no statistics; flip = 1: the data gradient.
+ * Results bit-identical to crnn_dwconv3x3_fwd_ex / crnn_dwconv3x3_bn_relu6_fwd (reference utils.py:44-46).  _supported: CRNN_OK when the shape
+ * is taken (a whole number of row bands fills the 9 KiB step row: every block of the CRNN), else CRNN_ERR_UNSUPPORTED. */
+int crnn_dwconv_fwd_stream_supported(int B, int H, int W, int C);
+int crnn_dwconv_fwd_stream_rows(int B, int H, int W, int C);
+int crnn_dwconv3x3_fwd_stream(const void* x, const float* k, void* out, float* stat_partials, const float* bnstate, int B, int H, int W, int C,
+                              int flip, crnn_stream_t stream);
 /* n (<= 8) independent matrix transposes in one launch: out[i] [C_i][R_i] = in[i]^T, in[i] = src + in_off[i] (fp32
  * elements), out[i] = dst + out_off[i] (elements of dt_out: 0 fp32 | 1 bf16).  src / dst are device pointers; the four
  * descriptor arrays (in_off, out_off, R, C) are HOST arrays of n entries, copied into the kernel arguments. */

@@ -19,7 +19,9 @@ for (h, w, c) in [(104, 36, 64), (104, 36, 128), (52, 18, 256), (52, 18, 256), (
     FW = L.crnn_dwconv3x3_fwd_ex
     for name, fn in (("fwd+stats", lambda: FW(P(x), P(k), P(o), P(parts), B, h, w, c, 0, int(BF), S())),
                      ("dgrad", lambda: FW(P(x), P(k), P(o), None, B, h, w, c, 1, int(BF), S())),
-                     ("wgrad", lambda: L.crnn_dwconv3x3_wgrad_ex(P(x), P(o), P(dk), P(parts), B, h, w, c, int(BF), S()))):
+                     ("wgrad", lambda: L.crnn_dwconv3x3_wgrad_ex(P(x), P(o), P(dk), P(parts), B, h, w, c, int(BF), S())),
+                     ("fwd-stream", lambda: L.crnn_dwconv3x3_fwd_stream(P(x), P(k), P(o), P(parts), None, B, h, w, c, 0, S()))):
+        if name == "fwd-stream" and not (BF and L.crnn_dwconv_fwd_stream_supported(B, h, w, c) == 0): continue
         for _ in range(2): fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -27,6 +29,6 @@ for (h, w, c) in [(104, 36, 64), (104, 36, 128), (52, 18, 256), (52, 18, 256), (
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
         by = 2.0 * x.numel() * x.element_size()
-        if name != "wgrad": tot += ms; totb += by
+        if name in ("fwd+stats", "dgrad"): tot += ms; totb += by
         print("%dx%dx%d %-9s %.3f ms  %.2f TB/s" % (h, w, c, name, ms, by / ms / 1e9))
 print("fwd+dgrad total %.3f ms  %.2f TB/s" % (tot, totb / tot / 1e9))

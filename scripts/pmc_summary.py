@@ -40,6 +40,37 @@ for mode, esz in (("bf16", 2), ("fp32", 4)):
                         "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
                         "algorithmic_bytes_per_launch": alg, "ratio": (rd + wr) / alg}
     res["modes"][mode] = {"storage_bytes_per_element": esz, "shapes": shapes}
+# the row-stream forward (bf16 only): every shape launches the same grid, so the launches are told apart by their order in
+# dw_bench.py (7 launches = 2 warm-up + 5 timed per shape, six shapes in the order of the step)
+ORDER = ["104x36x64", "104x36x128", "52x18x256", "52x18x256", "52x9x512", "52x9x512"]
+DIMS = {n: (h, w, ch) for n, h, w, ch in SHAPES}
+try:
+    per = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        src = os.path.join(ROOT, "gpurun_out", "%s_pmc_bf16_%s" % (tag, c), "dw_counter_collection.csv")
+        rows = [(int(r["Dispatch_Id"]), float(r["Counter_Value"])) for r in csv.DictReader(open(src))
+                if "dw_fwd_stream_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c]
+        rows.sort()
+        assert len(rows) == 7 * len(ORDER), len(rows)
+        per[c] = [[v for _, v in rows[7 * i:7 * i + 7]] for i in range(len(ORDER))]
+        keep = os.path.join(ROOT, "profiles", "%s_pmc_dwstream_%s.csv" % (pref, c))
+        with open(src) as f, open(keep, "w") as g:
+            for i, line in enumerate(f):
+                if i == 0 or "dw_fwd_stream_kernel" in line:
+                    g.write(line)
+    shapes = {}
+    for i, name in enumerate(ORDER):
+        h, w, ch = DIMS[name]
+        f, wv = per["FETCH_SIZE"][i], per["WRITE_SIZE"][i]
+        rd = 2.0 * 1024 * sum(f) / len(f); wr = 1024.0 * sum(wv) / len(wv)
+        alg = 2.0 * B * h * w * ch * 2
+        shapes[name] = {"launches_sampled": len(f), "FETCH_SIZE_KB_avg": sum(f) / len(f), "WRITE_SIZE_KB_avg": sum(wv) / len(wv),
+                        "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
+                        "algorithmic_bytes_per_launch": alg, "ratio": (rd + wr) / alg}
+    res["stream"] = {"kernel": "dw_fwd_stream_kernel (forward with statistics; bf16 storage)", "storage_bytes_per_element": 2, "shapes": shapes}
+    print("stream", {k: round(v["ratio"], 3) for k, v in shapes.items()})
+except Exception as e:
+    print("no row-stream counters:", repr(e))
 out = os.path.join(ROOT, "profiles", "%s_pmc_dwconv.json" % pref)
 json.dump(res, open(out, "w"), indent=1)
 for m, d in res["modes"].items():

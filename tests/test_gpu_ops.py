@@ -559,6 +559,55 @@ def _f(t):
     return t.float().cpu().numpy().astype(np.float64)
 
 
+@pytest.mark.parametrize("B,H,W,C", [(3, 104, 36, 64), (2, 104, 36, 128), (5, 52, 18, 256), (2, 52, 9, 512), (2, 204, 36, 128), (256, 52, 9, 512),
+                                     (70, 52, 18, 256)])
+def test_row_stream_depthwise_equals_the_halo_tile_kernel(B, H, W, C):
+    """crnn_dwconv3x3_fwd_stream (rows streamed through an LDS ring by a loader wave with global_load_lds; every compute lane owns a 16-byte
+    column and adds an arriving row's taps to three running output rows) against crnn_dwconv3x3_fwd_ex / crnn_dwconv3x3_bn_relu6_fwd on the
+    same bf16 maps: the outputs bit for bit (same fp32 fma chain per output) for the forward, the flipped taps (data gradient) and the
+    folded BatchNorm + ReLU6 (inference) forms; the BatchNorm partial sums to fp32 summation round-off and against the NumPy oracle.  The
+    CRNN's blocks 2-7 (block 2 runs two row bands side by side), the IAM height, one band per workgroup (batch 256) and many (small
+    batches); memory around the output untouched; repeated launches give the same bits."""
+    assert L().crnn_dwconv_fwd_stream_supported(B, H, W, C) == 0
+    rs = np.random.RandomState(B + H + W + C)
+    x = _bf16_round(rs.normal(size=(B, H, W, C))); k = rs.normal(size=(3, 3, C))
+    xd, kd = _to_bf16_dev(x), dev(k)
+    rows = L().crnn_dwconv_fwd_stream_rows(B, H, W, C); nt = L().crnn_dwconv_num_tiles(B, H, W)
+    assert rows >= B
+    for flip in (0, 1):
+        o1 = torch.full((B * H * W * C + 64,), 7.0, dtype=torch.bfloat16, device="cuda"); o2 = torch.zeros(B * H * W * C, dtype=torch.bfloat16, device="cuda")
+        p1 = torch.full((rows + 1, 2, C), 3.0, device="cuda"); p2 = zeros(nt, 2, C)
+        ok(L().crnn_dwconv3x3_fwd_stream(P(xd), P(kd), P(o1), P(p1), None, B, H, W, C, flip, S()))
+        ok(L().crnn_dwconv3x3_fwd_ex(P(xd), P(kd), P(o2), P(p2), B, H, W, C, flip, 1, S()))
+        assert torch.equal(o1[:-64].view(torch.int16), o2.view(torch.int16)), "flip %d: max diff %g" % (flip, float((o1[:-64].float() - o2.float()).abs().max()))
+        assert bool((o1[-64:] == 7.0).all()) and bool((p1[rows] == 3.0).all())
+        a, b = host(p1[:rows]).sum(0), host(p2).sum(0)
+        assert_close(a, b, rtol=2e-5, atol=1e-5 * np.sqrt(B * H * W) * 3, what="statistics vs the tile kernel")
+        if flip == 0 and B * H * W * C <= 4e6:
+            ref = ops.dwconv_fwd(x, k)
+            assert_close(_f(o1[:-64].view(B, H, W, C)), ref, rtol=2.0 ** -8, atol=2e-2, what="vs oracle")
+            assert_close(a[0], ref.sum((0, 1, 2)), rtol=1e-4, atol=1e-2, what="sum vs oracle")
+            assert_close(a[1], (ref ** 2).sum((0, 1, 2)), rtol=1e-4, atol=1e-2, what="sum of squares vs oracle")
+        o3 = torch.zeros_like(o2); p3 = torch.zeros(rows, 2, C, device="cuda")
+        ok(L().crnn_dwconv3x3_fwd_stream(P(xd), P(kd), P(o3), P(p3), None, B, H, W, C, flip, S()))
+        assert torch.equal(o3.view(torch.int16), o2.view(torch.int16)) and torch.equal(p3, p1[:rows])
+    st = dev(np.concatenate([rs.normal(size=C), 1 + rs.uniform(size=C), 1 + 0.3 * rs.normal(size=C), 0.5 * rs.normal(size=C) + 1.0]))
+    o1 = torch.zeros(B * H * W * C, dtype=torch.bfloat16, device="cuda"); o2 = torch.zeros_like(o1)
+    ok(L().crnn_dwconv3x3_fwd_stream(P(xd), P(kd), P(o1), None, P(st), B, H, W, C, 0, S()))
+    ok(L().crnn_dwconv3x3_bn_relu6_fwd(P(xd), P(kd), P(st), P(o2), B, H, W, C, 1, S()))
+    assert torch.equal(o1.view(torch.int16), o2.view(torch.int16))
+    # plain product, no statistics
+    o1.zero_()
+    ok(L().crnn_dwconv3x3_fwd_stream(P(xd), P(kd), P(o1), None, None, B, H, W, C, 0, S()))
+    ok(L().crnn_dwconv3x3_fwd_ex(P(xd), P(kd), P(o2), None, B, H, W, C, 0, 1, S()))
+    assert torch.equal(o1.view(torch.int16), o2.view(torch.int16))
+
+
+def test_row_stream_depthwise_refuses_other_shapes():
+    for B, H, W, C in [(2, 104, 40, 128), (2, 13, 18, 64), (2, 52, 18, 252), (2, 51, 9, 256)]:
+        assert L().crnn_dwconv_fwd_stream_supported(B, H, W, C) == -3 and L().crnn_dwconv_fwd_stream_rows(B, H, W, C) == 0
+
+
 def test_bf16_storage_dwconv_bn_chain():
     """Storage-typed kernels (dtype=1): inputs/outputs are bf16 tensors, arithmetic fp32.  Reference = the oracle on the
     bf16-rounded inputs; outputs agree to one bf16 rounding (2^-8 relative)."""
