@@ -106,7 +106,8 @@ def depthwise_roofline(eng, iters=15):
 
 
 def depthwise_bwd_roofline(eng, iters=5):
-    """Secondary: the fused depthwise-stage backward (blocks 2..7, bf16s training; csrc/conv_bwd_fused.hip) on the live buffers.
+    """Secondary: the fused depthwise-stage backward (blocks 2..7, bf16s training; csrc/dwconv_bwd_stream.hip, or csrc/conv_bwd_fused.hip
+    where the stream kernel's shape rule fails / under CRNN_FLAG_DW_TILE_KERNEL) on the live buffers, as the step issues it.
     Algorithmic bytes per launch = read d, da, x + write dx = 4 x B*H*W*C elements in the storage type."""
     from crnn_mi355x.engine import _ptr, _stream
     if eng.precision != "bf16s" or (eng.cfg.flags & 16):
@@ -114,28 +115,34 @@ def depthwise_bwd_roofline(eng, iters=5):
     lib = eng.lib; B = eng.B
     blocks = [(64, 1, 1), (128, 1, 1), (256, 2, 2), (256, 1, 1), (512, 1, 2), (512, 1, 1), (512, 1, 1)]
     h, w, cin = eng.cfg.imgh + 4, eng.cfg.imgw + 4, 1
-    launches, nbytes = [], 0.0
+    launches, nbytes, nstream = [], 0.0, 0
     parts, coef = eng.ws_tensor("partials"), eng.ws_tensor("coef")
     for i, (co, ph, pw) in enumerate(blocks, 1):
         if i >= 2:
             if lib.crnn_dwconv_bwd_fused_supported(h, w, cin) != 0:
                 return None
             k = eng.params[eng.layout["b%d_dw" % i][0]:]; gk = eng.grads[eng.layout["b%d_dw" % i][0]:]
+            st = not (eng.cfg.flags & 32) and lib.crnn_dwconv_bwd_stream_supported(B, h, w, cin) == 0    # the step's own choice of kernel
+            nstream += int(st)
             launches.append((eng.ws_tensor("d%d" % i), eng.ws_tensor("gA"), eng.ws_tensor("bn1s%d" % i), coef, eng.ws_tensor("x%d" % (i - 1)), k,
-                             eng.ws_tensor("gB"), gk, parts, h, w, cin))
+                             eng.ws_tensor("gB"), gk, parts, h, w, cin, st))
             nbytes += 4 * (2.0 * B * h * w * cin)
         h, w, cin = h // ph, w // pw, co
     times = []
     for it in range(iters + 1):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for d, da, st, cf, x, k, dx, dk, pt, hh, ww, cc in launches:
-            lib.crnn_dwconv3x3_bwd_fused(_ptr(d), _ptr(da), _ptr(st), _ptr(cf), _ptr(x), _ptr(k), _ptr(dx), _ptr(dk), _ptr(pt), B, hh, ww, cc, _stream())
+        for d, da, st, cf, x, k, dx, dk, pt, hh, ww, cc, strm in launches:
+            fn = lib.crnn_dwconv3x3_bwd_stream if strm else lib.crnn_dwconv3x3_bwd_fused
+            fn(_ptr(d), _ptr(da), _ptr(st), _ptr(cf), _ptr(x), _ptr(k), _ptr(dx), _ptr(dk), _ptr(pt), B, hh, ww, cc, _stream())
         e1.record(); torch.cuda.synchronize()
         if it:
             times.append(e0.elapsed_time(e1) * 1e-3)
     t = float(np.median(times)); ach = nbytes / t / 1e9
-    return {"bound": "hbm", "kernel": "dw_bwd_fused_kernel (BatchNorm-backward pass 2 + depthwise weight and data gradients, blocks 2-7; VALU-issue-bound, DESIGN.md section 4)",
+    kname = ("dw_bwd_stream_kernel (BatchNorm-backward pass 2 + depthwise weight and data gradients, blocks 2-7: rows of d, da, x streamed through an LDS ring, "
+             "weight-gradient and data-gradient wave groups; incl. the second-stage sum of the weight-gradient partials)" if nstream == len(launches) else
+             "dw_bwd_fused_kernel (BatchNorm-backward pass 2 + depthwise weight and data gradients, blocks 2-7; VALU-issue-bound, DESIGN.md section 4)")
+    return {"bound": "hbm", "kernel": kname,
             "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "launches": len(launches),
             "avg_launch_ms": round(1e3 * t / len(launches), 4), "algorithmic_bytes_per_launch_set": nbytes}
 

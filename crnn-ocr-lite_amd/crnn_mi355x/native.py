@@ -14,7 +14,7 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 HEADER = os.path.join(REPO_ROOT, "include", "crnn_mi355x.h")
 CSRC = os.path.join(PKG_ROOT, "csrc")
 LIB_PATH = os.path.join(PKG_ROOT, "libcrnn_mi355x.so")
-SOURCES = ["gemm.hip", "gemm_nt.hip", "gemm_wres.hip", "gemm_wgrad.hip", "conv.hip", "conv_bwd_fused.hip", "dwconv_stream.hip", "stn.hip", "rnn.hip", "rnn_persist.hip", "ctc.hip", "beam.hip", "optim.hip", "model.hip"]
+SOURCES = ["gemm.hip", "gemm_nt.hip", "gemm_wres.hip", "gemm_wgrad.hip", "conv.hip", "conv_bwd_fused.hip", "dwconv_stream.hip", "dwconv_bwd_stream.hip", "stn.hip", "rnn.hip", "rnn_persist.hip", "ctc.hip", "beam.hip", "optim.hip", "model.hip"]
 
 
 class crnn_config(ctypes.Structure):

@@ -1,0 +1,383 @@
+// Backward of one depthwise stage of a conv block (bf16 storage, training) as a ROW STREAM -- the arithmetic of dw_bwd_fused_kernel
+// (conv_bwd_fused.hip: BatchNorm-backward pass 2 + depthwise weight gradient + depthwise data gradient, reference utils.py:44-46) on
+// the schedule of dw_fwd_stream_kernel (dwconv_stream.hip):
+//     dd = scale * (gy - c1 - xhat * c2),  gy = da * [0 < BN(d) < 6]           (rounded to bf16 as the stored tensor would be)
+//     dx[y][x] = sum_ij k[8 - (3i+j)] dd[y+i-1][x+j-1]                           dk[3i+j] = sum_yx xin[y+i-1][x+j-1] dd[y][x]
+// A workgroup walks a band of rows of one image and one channel range (288 16-byte columns = pixel x 8 channels); per step the LOADER
+// wave brings one row each of d, da and xin (the latter one row behind) into an LDS ring with global_load_lds, and two groups of
+// compute waves work on it:
+//   * the five DK waves own a column each: they form dd of the arriving d/da row (own column only), leave it as bf16 in a two-row LDS
+//     buffer for the other group, and add the arriving xin row (x-1, x, x+1 from LDS) times the last three dd values of their column
+//     to the 72 weight-gradient sums they keep in registers (dk[0..2] with dd[r+1], dk[3..5] with dd[r], dk[6..8] with dd[r-1]);
+//   * the five DX waves read the previous dd row (x-1, x, x+1) and run the forward stream kernel's three running output rows with the
+//     mirrored taps: every dx value is the same fp32 fma chain as in the tile kernels (bit-identical).
+// The two groups have different register sets (72 sums + 32 BatchNorm constants vs 72 taps + 24 running sums) -- one wave holding both
+// would need 260 registers -- and unequal work, so the roles are dealt over the wave slots such that every SIMD carries about the same
+// (wave w runs on SIMD w mod 4).  Nothing is re-read: 4 tensor passes of HBM traffic (+ 2 halo rows per band), one barrier per row.
+#include "common.h"
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define BN_EPS_F 1e-3f
+
+#ifndef CRNN_DBS_EXP
+#define CRNN_DBS_EXP 0      // experiment builds: 1 = no DMA, 2 = no stores, 4 = no dk fmas, 8 = no dx fmas
+#endif
+#ifndef CRNN_DBS_D
+#define CRNN_DBS_D 3
+#endif
+
+struct DbsParams {
+  const unsigned char *d, *da, *xin; unsigned char* dx; const float *bnstate, *coef, *k; float* partials;
+  int H, W, C, HB, nwgb, nsplit, cols, cppw, rowbytes;
+};
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+__device__ __forceinline__ void widen8(const u32x4& u, float (&f)[8]) {
+  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+
+constexpr int kCW = 5;                       // compute waves per group (320 columns)
+constexpr int kSub = 5 * 1024;               // one row of one tensor in a ring stage (5 DMA instructions)
+constexpr int kStageB = 3 * kSub;            // d | da | xin
+constexpr int kNI = 15;                      // DMA instructions per stage
+constexpr int kD = CRNN_DBS_D, kNR = kD + 1;
+static_assert((kD - 1) * kNI <= 63, "vmcnt is a 6-bit counter");
+constexpr int kDdOff = kNR * kStageB;        // two dd rows
+constexpr int kZOff = kDdOff + 2 * kSub;     // 16 zero bytes
+constexpr int kCstOff = kZOff + 64;          // BatchNorm constants of the workgroup's channels: scale | shift | P | Q, [4][<= 256] floats
+constexpr int kLds = kCstOff + 4 * 256 * 4;
+
+// role of wave slot w (11 waves; SIMD = w mod 4): DK work is about twice DX work per step
+//   SIMD 3: w3 w7 = DK DK;  SIMD 0: w0 w4 w8 = DK DX DX;  SIMD 1: w1 w5 w9 = DK DX DX;  SIMD 2: w2 w6 w10 = DK DX loader
+__device__ __forceinline__ int role_of(int w, int& idx) {   // 0 = DK, 1 = DX, 2 = loader; idx = index inside the group
+  if (w == 10) { idx = 0; return 2; }
+  if (w < 4) { idx = w; return 0; }
+  if (w == 7) { idx = 4; return 0; }
+  idx = w < 7 ? w - 4 : w - 5;                                // 4 5 6 8 9 -> 0 1 2 3 4
+  return 1;
+}
+
+__global__ __launch_bounds__(704) void dw_bwd_stream_kernel(DbsParams p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int gidx; const int role = role_of(wave, gidx);
+  int bid = blockIdx.x;
+  const int split = bid % p.nsplit; bid /= p.nsplit;
+  const int wb = bid % p.nwgb, img = bid / p.nwgb;
+  const int r0 = wb * p.HB;                         // first row of the band
+  const int nsteps = p.HB + 3;                      // step s: d/da row r0-1+s (s <= HB+1), xin row r0-2+s (s >= 1), dx row r0+s-3 (s >= 3)
+  const int CWb = p.C / p.nsplit * 2;               // bytes of this workgroup's channel range per pixel
+  const int c0 = split * (p.C / p.nsplit);          // first channel
+  if (tid < 4) reinterpret_cast<unsigned*>(lds + kZOff)[tid] = 0u;
+  const long imgoff = (long)img * p.H * p.rowbytes;
+
+  if (role == 2) {
+    // ------------------------------------------------------------------ loader wave
+    int goff[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      int f = i * 64 + lane; f = f < p.cols ? f : p.cols - 1;
+      const int px = f / p.cppw, o = f - px * p.cppw;
+      goff[i] = px * p.C * 2 + c0 * 2 + o * 16;
+    }
+    const unsigned char* gd = p.d + imgoff; const unsigned char* gg = p.da + imgoff; const unsigned char* gxx = p.xin + imgoff;
+    auto issue = [&](int s, int slot) {
+      s = s < nsteps ? s : nsteps - 1;
+      int rd = r0 - 1 + s; rd = rd < 0 ? 0 : (rd >= p.H ? p.H - 1 : rd);
+      int rx = r0 - 2 + s; rx = rx < 0 ? 0 : (rx >= p.H ? p.H - 1 : rx);
+      const long od = (long)rd * p.rowbytes, ox = (long)rx * p.rowbytes;
+      unsigned char* dst = lds + slot * kStageB;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        if (!(CRNN_DBS_EXP & 1)) {
+          glds16(gd + od + goff[i], dst + i * 1024);
+          glds16(gg + od + goff[i], dst + kSub + i * 1024);
+          glds16(gxx + ox + goff[i], dst + 2 * kSub + i * 1024);
+        }
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < kD; ++s) issue(s, s);
+    int slot = kD;
+    for (int s = 0; s < nsteps; ++s) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kD - 1) * kNI) : "memory");
+      __builtin_amdgcn_s_barrier();
+      issue(s + kD, slot);
+      slot = slot + 1 == kNR ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+    return;
+  }
+
+  const int col = gidx * 64 + lane;
+  const bool act = col < p.cols;
+  const int ccol = act ? col : p.cols - 1;
+  const int px = ccol / p.cppw, oct = ccol - px * p.cppw;
+  const int offC = ccol * 16;
+  const bool hasL = px > 0, hasR = px < p.W - 1;
+  const int pitch = p.cppw * 16;                    // LDS bytes between horizontally adjacent pixels
+  const int ch0 = c0 + oct * 8;
+
+  if (role == 1) {
+    // ------------------------------------------------------------------ DX waves: dx = correlation of dd with the mirrored taps
+    float kw[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float* kp = p.k + (long)(8 - t) * p.C + ch0;
+      const float4 a = *reinterpret_cast<const float4*>(kp), b = *reinterpret_cast<const float4*>(kp + 4);
+      kw[t][0] = a.x; kw[t][1] = a.y; kw[t][2] = a.z; kw[t][3] = a.w; kw[t][4] = b.x; kw[t][5] = b.y; kw[t][6] = b.z; kw[t][7] = b.w;
+    }
+    float X0[8], X1[8], X2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) X0[e] = X1[e] = X2[e] = 0.f;
+    unsigned char* orow = p.dx + imgoff + (long)r0 * p.rowbytes + px * p.C * 2 + ch0 * 2;
+    // a = arriving dd row (relative: image row r0-1+a), read one step after the DK waves wrote it
+    auto step = [&](int a, float (&A)[8], float (&Bc)[8], float (&Cn)[8]) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const unsigned char* sb = lds + kDdOff + (a & 1) * kSub;
+      const u32x4 vL = *reinterpret_cast<const u32x4*>(hasL ? sb + offC - pitch : lds + kZOff);
+      const u32x4 vC = *reinterpret_cast<const u32x4*>(sb + offC);
+      const u32x4 vR = *reinterpret_cast<const u32x4*>(hasR ? sb + offC + pitch : lds + kZOff);
+      if (!(CRNN_DBS_EXP & 8)) {
+        float f[8];
+        widen8(vL, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { A[e] = fmaf(f[e], kw[6][e], A[e]); Bc[e] = fmaf(f[e], kw[3][e], Bc[e]); Cn[e] = fmaf(f[e], kw[0][e], 0.f); }
+        widen8(vC, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { A[e] = fmaf(f[e], kw[7][e], A[e]); Bc[e] = fmaf(f[e], kw[4][e], Bc[e]); Cn[e] = fmaf(f[e], kw[1][e], Cn[e]); }
+        widen8(vR, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { A[e] = fmaf(f[e], kw[8][e], A[e]); Bc[e] = fmaf(f[e], kw[5][e], Bc[e]); Cn[e] = fmaf(f[e], kw[2][e], Cn[e]); }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { A[e] += __uint_as_float(vL[e]); A[e + 4] += __uint_as_float(vC[e]); Bc[e] += __uint_as_float(vR[e]); }
+      }
+      if (a >= 2 && act) {
+        u32x4 o;
+        o.x = pack2_bf16(A[0], A[1]); o.y = pack2_bf16(A[2], A[3]); o.z = pack2_bf16(A[4], A[5]); o.w = pack2_bf16(A[6], A[7]);
+        if (!(CRNN_DBS_EXP & 2)) *reinterpret_cast<u32x4*>(orow + (long)(a - 2) * p.rowbytes) = o;
+      }
+    };
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                  // step 0: the first dd row is being formed
+    step(0, X1, X2, X0);
+    step(1, X2, X0, X1);
+    const int last = p.HB + 1;                     // arriving rows 0 .. HB+1
+    int a = 2;
+    for (; a + 2 <= last; a += 3) {
+      step(a, X0, X1, X2);
+      step(a + 1, X1, X2, X0);
+      step(a + 2, X2, X0, X1);
+    }
+    for (int r = 0; a <= last; ++a, ++r) {
+      if (r == 0) step(a, X0, X1, X2);
+      else step(a, X1, X2, X0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+    return;
+  }
+
+  // -------------------------------------------------------------------- DK waves: dd of the arriving row, weight-gradient sums
+  // (the 72 sums leave no room for the 32 BatchNorm constants of the lane's channels: they sit in LDS and are read per step; the dd
+  // history is kept as packed bf16)
+  const int cw = p.cppw * 8;                        // channels of this workgroup
+  float* cst = reinterpret_cast<float*>(lds + kCstOff);
+  for (int i = gidx * 64 + lane; i < cw; i += kCW * 64) {
+    const int ch = c0 + i;
+    const float scv = p.bnstate[2 * p.C + ch];
+    float P, Q;
+    bn_bwd_pq(scv, p.coef[ch], p.coef[p.C + ch], p.bnstate[ch], 1.0f / sqrtf(p.bnstate[p.C + ch] + BN_EPS_F), P, Q);
+    cst[i] = scv; cst[cw + i] = p.bnstate[3 * p.C + ch]; cst[2 * cw + i] = P; cst[3 * cw + i] = Q;
+  }
+  const float* cl = cst + oct * 8;
+  float dk[9][8];
+  u32x4 H0 = (u32x4)(0u), H1 = (u32x4)(0u), H2 = (u32x4)(0u);
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dk[t][e] = 0.f;
+  int slot = 0;
+  // step s: Dn <- dd of row s (relative: image row r0-1+s); xin row s-1 (image row r0-2+s) meets Dn (taps 0..2), Dm1 (3..5), Dm2 (6..8)
+  auto step = [&](int s, u32x4& Dn, const u32x4& Dm1, const u32x4& Dm2, bool edge) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* sb = lds + slot * kStageB;
+    slot = slot + 1 == kNR ? 0 : slot + 1;
+    if (!edge || s <= p.HB + 1) {
+      const u32x4 vd = *reinterpret_cast<const u32x4*>(sb + offC);
+      const u32x4 vg = *reinterpret_cast<const u32x4*>(sb + kSub + offC);
+      float xv[8], gv[8], r[8];
+      widen8(vd, xv); widen8(vg, gv);
+#pragma unroll
+      for (int hq = 0; hq < 2; ++hq) {
+        const float4 s4 = *reinterpret_cast<const float4*>(cl + 4 * hq), h4 = *reinterpret_cast<const float4*>(cl + cw + 4 * hq);
+        const float4 p4 = *reinterpret_cast<const float4*>(cl + 2 * cw + 4 * hq), q4 = *reinterpret_cast<const float4*>(cl + 3 * cw + 4 * hq);
+        const float scq[4] = {s4.x, s4.y, s4.z, s4.w}, shq[4] = {h4.x, h4.y, h4.z, h4.w}, pq[4] = {p4.x, p4.y, p4.z, p4.w}, qq[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float tv = fmaf(xv[4 * hq + e], scq[e], shq[e]);
+          const float gy = (tv > 0.f && tv < 6.f) ? gv[4 * hq + e] : 0.f;
+          r[4 * hq + e] = bn_bwd_dx_pq(xv[4 * hq + e], gy, scq[e], pq[e], qq[e]);
+        }
+      }
+      u32x4 w;
+      w.x = pack2_bf16(r[0], r[1]); w.y = pack2_bf16(r[2], r[3]); w.z = pack2_bf16(r[4], r[5]); w.w = pack2_bf16(r[6], r[7]);
+      bool band = act;
+      if (edge) {
+        const int g = r0 - 1 + s;
+        if (g < 0 || g >= p.H) w = (u32x4)(0u);
+        band = act && s >= 1 && s <= p.HB;                     // halo rows feed dx only: their weight-gradient terms belong to the neighbour band
+      }
+      if (act) *reinterpret_cast<u32x4*>(lds + kDdOff + (s & 1) * kSub + offC) = w;
+      Dn = band ? w : (u32x4)(0u);
+    } else {
+      Dn = (u32x4)(0u);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!edge || s >= 1) {
+      const unsigned char* xb = sb + 2 * kSub;
+      u32x4 vL = *reinterpret_cast<const u32x4*>(hasL ? xb + offC - pitch : lds + kZOff);
+      u32x4 vC = *reinterpret_cast<const u32x4*>(xb + offC);
+      u32x4 vR = *reinterpret_cast<const u32x4*>(hasR ? xb + offC + pitch : lds + kZOff);
+      if (edge) {
+        const int g = r0 - 2 + s;
+        if (g < 0 || g >= p.H) { vL = (u32x4)(0u); vC = (u32x4)(0u); vR = (u32x4)(0u); }
+      }
+      if (!(CRNN_DBS_EXP & 4)) {
+        float f[8], dn[8], dm1[8], dm2[8];
+        widen8(Dn, dn); widen8(Dm1, dm1); widen8(Dm2, dm2);
+        widen8(vL, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dk[0][e] = fmaf(f[e], dn[e], dk[0][e]); dk[3][e] = fmaf(f[e], dm1[e], dk[3][e]); dk[6][e] = fmaf(f[e], dm2[e], dk[6][e]); }
+        widen8(vC, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dk[1][e] = fmaf(f[e], dn[e], dk[1][e]); dk[4][e] = fmaf(f[e], dm1[e], dk[4][e]); dk[7][e] = fmaf(f[e], dm2[e], dk[7][e]); }
+        widen8(vR, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dk[2][e] = fmaf(f[e], dn[e], dk[2][e]); dk[5][e] = fmaf(f[e], dm1[e], dk[5][e]); dk[8][e] = fmaf(f[e], dm2[e], dk[8][e]); }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dk[0][e] += __uint_as_float(vL[e] + Dn[e]); dk[1][e] += __uint_as_float(vC[e] + Dm1[e]); dk[2][e] += __uint_as_float(vR[e] + Dm2[e]); }
+      }
+    }
+  };
+  step(0, H0, H2, H1, true);
+  step(1, H1, H0, H2, true);
+  int s = 2;
+  for (; s + 2 <= p.HB; s += 3) {                   // rows 2 .. HB need no edge handling
+    step(s, H2, H1, H0, false);
+    step(s + 1, H0, H2, H1, false);
+    step(s + 2, H1, H0, H2, false);
+  }
+  for (; s < nsteps; ++s) {
+    const int m = s % 3;
+    if (m == 2) step(s, H2, H1, H0, true);
+    else if (m == 0) step(s, H0, H2, H1, true);
+    else step(s, H1, H0, H2, true);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                    // ring free
+  // weight-gradient partials of the workgroup: lanes l, l + cppw, ... of a wave hold the same channels -> xor shuffles; the five waves
+  // through LDS in a fixed order
+  float* red = reinterpret_cast<float*>(lds);       // [5 waves][9][cppw * 8]
+  for (int o = p.cppw; o < 64; o <<= 1) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dk[t][e] += __shfl_xor(dk[t][e], o, 64);
+  }
+  if (lane < p.cppw) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float* dst = red + (gidx * 9 + t) * cw + lane * 8;
+      *reinterpret_cast<float4*>(dst) = make_float4(dk[t][0], dk[t][1], dk[t][2], dk[t][3]);
+      *reinterpret_cast<float4*>(dst + 4) = make_float4(dk[t][4], dk[t][5], dk[t][6], dk[t][7]);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  {
+    // the DK waves' threads, numbered 0 .. 319 by (group index, lane)
+    const int t5 = gidx * 64 + lane;
+    const long prow = (long)(blockIdx.x / p.nsplit) * 9 * p.C;
+    for (int i = t5; i < 9 * cw; i += kCW * 64) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < kCW; ++w) a += red[w * 9 * cw + i];
+      const int t = i / cw, c = i - t * cw;
+      p.partials[prow + (long)t * p.C + c0 + c] = a;
+    }
+  }
+}
+
+struct DbsGeom { int nsplit, nwgb, HB, cols, cppw; bool ok; };
+DbsGeom dbs_geom(int B, int H, int W, int C) {
+  DbsGeom g; g.ok = false; g.nsplit = g.nwgb = g.HB = g.cols = g.cppw = 0;
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8) return g;
+  const long cols1 = (long)W * C / 8;
+  int ns = 0;
+  for (int n = 1; n <= C / 8; ++n) {
+    if ((C / 8) % n) continue;
+    if (cols1 / n <= kCW * 64) { ns = n; break; }
+  }
+  if (!ns) return g;
+  const int cols = (int)(cols1 / ns), cppw = C / 8 / ns;
+  if (cols <= 4 * 64 || (cppw & (cppw - 1)) || cppw > 32) return g;   // five full-ish waves; power-of-two columns per pixel below a wave (shuffle reduction)
+  int nwgb = 1;
+#ifndef CRNN_DBS_WGS
+#define CRNN_DBS_WGS 256
+#endif
+  for (int n = 1; n <= H; ++n) {
+    if (H % n || H / n < 8) continue;
+    nwgb = n;
+    if ((long)B * n * ns >= CRNN_DBS_WGS) break;
+  }
+  if (H % nwgb) return g;
+  g.nsplit = ns; g.nwgb = nwgb; g.HB = H / nwgb; g.cols = cols; g.cppw = cppw; g.ok = true;
+  return g;
+}
+
+}  // namespace
+
+// CRNN_OK when crnn_dwconv3x3_bwd_stream takes the shape (W * C / 8 sixteen-byte columns split over whole channel octets into
+// workgroups of 257..320 columns: every block of the CRNN), else CRNN_ERR_UNSUPPORTED -> crnn_dwconv3x3_bwd_fused.
+extern "C" int crnn_dwconv_bwd_stream_supported(int B, int H, int W, int C) { return dbs_geom(B, H, W, C).ok ? CRNN_OK : CRNN_ERR_UNSUPPORTED; }
+// rows of [9][C] weight-gradient partials the launch writes (scratch = rows * 9 * C floats)
+extern "C" int crnn_dwconv_bwd_stream_rows(int B, int H, int W, int C) { DbsGeom g = dbs_geom(B, H, W, C); return g.ok ? B * g.nwgb : 0; }
+// Same contract as crnn_dwconv3x3_bwd_fused (d, da, xin, dx: bf16 [B,H,W,C]; bnstate = [mean|var|scale|shift]; coef = [c1|c2];
+// k [9][C]; dk [9][C] out); dx bit-identical, dk to the summation order of its partial sums.
+extern "C" int crnn_dwconv3x3_bwd_stream(const void* d, const void* da, const float* bnstate, const float* coef, const void* xin, const float* k,
+                                         void* dx, float* dk, float* scratch, int B, int H, int W, int C, hipStream_t stream) {
+  if (!d || !da || !bnstate || !coef || !xin || !k || !dx || !dk || !scratch) return CRNN_ERR_ARG;
+  const DbsGeom g = dbs_geom(B, H, W, C);
+  if (!g.ok) return CRNN_ERR_UNSUPPORTED;
+  if ((((uintptr_t)d | (uintptr_t)da | (uintptr_t)xin | (uintptr_t)dx | (uintptr_t)bnstate | (uintptr_t)coef | (uintptr_t)k) & 15)) return CRNN_ERR_UNSUPPORTED;
+  if ((long)H * W * C * 2 >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;
+  DbsParams p;
+  p.d = (const unsigned char*)d; p.da = (const unsigned char*)da; p.xin = (const unsigned char*)xin; p.dx = (unsigned char*)dx;
+  p.bnstate = bnstate; p.coef = coef; p.k = k; p.partials = scratch;
+  p.H = H; p.W = W; p.C = C; p.HB = g.HB; p.nwgb = g.nwgb; p.nsplit = g.nsplit; p.cols = g.cols; p.cppw = g.cppw; p.rowbytes = W * C * 2;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)dw_bwd_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(dw_bwd_stream_kernel, dim3(B * g.nwgb * g.nsplit), dim3(704), kLds, stream, p);
+  CRNN_LAUNCH_CHECK();
+  return crnn_partials_sum(scratch, B * g.nwgb, 9 * C, dk, 1.f, stream);
+}

@@ -134,6 +134,7 @@ Plan make_plan(const crnn_config* c) {
     maxparts = lmax(maxparts, tiles * 9L * ci);
     maxparts = lmax(maxparts, (long)crnn_dwconv_bwd_fused_rows(d.B, d.bh[i], d.bw[i], ci) * 9L * ci);
     maxparts = lmax(maxparts, (long)crnn_dwconv_fwd_stream_rows(d.B, d.bh[i], d.bw[i], ci) * 2L * ci);
+    maxparts = lmax(maxparts, (long)crnn_dwconv_bwd_stream_rows(d.B, d.bh[i], d.bw[i], ci) * 9L * ci);
     maxparts = lmax(maxparts, (long)crnn_colreduce_chunks(M) * 2L * lmax(ci, co));
     maxparts = lmax(maxparts, (long)crnn_pwconv_stat_rows(M) * 2L * co);
     maxparts = lmax(maxparts, (long)crnn_pwconv_fwd_wres_rows(M, co, ci) * 2L * co);   // one row per IO wave and stripe lane: more rows than tiles at small batches
@@ -768,8 +769,14 @@ int backward_bottom(const Ctx& c, const float* x, uint64_t seed, hipStream_t aux
       CRNN_TRY(crnn_bn_bwd_ex(c.w("d" + p), gA, c.w("bn1s" + p), c.p(bp + "_bn1_g"), nullptr, c.g(bp + "_bn1_g"), c.g(bp + "_bn1_b"), c.w("partials"),
                               c.w("coef"), B, H, W, ci, 1, 1, 0.f, 0, 0, dtd, stream));
       CRNN_TRY(fj.wait(gC_free)); gC_free = nullptr;      // gC is written next
-      CRNN_TRY(crnn_dwconv3x3_bwd_fused(c.w("d" + p), gA, c.w("bn1s" + p), c.w("coef"), xin, c.p(bp + "_dw"), gC, c.g(bp + "_dw"), c.w("partials"),
-                                        B, H, W, ci, stream));
+      int rc = CRNN_ERR_UNSUPPORTED;
+      if (!(cfg->flags & CRNN_FLAG_DW_TILE_KERNEL))         // rows streamed through LDS where the shape rule holds (dwconv_bwd_stream.hip)
+        rc = crnn_dwconv3x3_bwd_stream(c.w("d" + p), gA, c.w("bn1s" + p), c.w("coef"), xin, c.p(bp + "_dw"), gC, c.g(bp + "_dw"), c.w("partials"),
+                                       B, H, W, ci, stream);
+      if (rc == CRNN_ERR_UNSUPPORTED)
+        rc = crnn_dwconv3x3_bwd_fused(c.w("d" + p), gA, c.w("bn1s" + p), c.w("coef"), xin, c.p(bp + "_dw"), gC, c.g(bp + "_dw"), c.w("partials"),
+                                      B, H, W, ci, stream);
+      CRNN_TRY(rc);
       // the block below finds its incoming gradient in gA, writes gB; this block's side-stream GEMM may still read the old gB
       float* t = gA; gA = gC; gC = gB; gB = t;
       gC_free = gB_free; gB_free = nullptr;

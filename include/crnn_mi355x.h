@@ -39,8 +39,10 @@ typedef struct {
                        conv-stack activations / gradients are stored as bf16 in HBM (statistics, RNN, CTC, optimizer fp32) */
   int flags;        /* bit set of CRNN_FLAG_* (0 = the default schedule); A/B switches: bit-identical results except where a flag says otherwise */
 } crnn_config;
-#define CRNN_FLAG_DW_TILE_KERNEL 32    /* bf16-storage modes: depthwise 3x3 forward on the halo-tile kernel (crnn_dwconv3x3_fwd_ex) instead of the row-stream
-                                        * kernel (crnn_dwconv3x3_fwd_stream); results bit-identical, BatchNorm statistics to summation round-off */
+#define CRNN_FLAG_DW_TILE_KERNEL 32    /* bf16-storage modes: depthwise 3x3 forward and fused depthwise-stage backward on the halo-tile kernels
+                                        * (crnn_dwconv3x3_fwd_ex, crnn_dwconv3x3_bwd_fused) instead of the row-stream kernels (crnn_dwconv3x3_fwd_stream,
+                                        * crnn_dwconv3x3_bwd_stream); tensors bit-identical, BatchNorm statistics / depthwise weight gradients to
+                                        * summation round-off */
 #define CRNN_FLAG_NO_DW_BWD_FUSION 16 /* bf16-storage training: depthwise-stage backward as three kernels (BatchNorm backward pass 2, depthwise weight
                                          gradient, depthwise data gradient) instead of crnn_dwconv3x3_bwd_fused; same data gradients bit for bit */
 #define CRNN_FLAG_NO_DW_BN_FUSION 8   /* bf16-storage training: materialise a = ReLU6(BN(d)) in a pass of its own instead of applying it while the
@@ -226,6 +228,16 @@ int crnn_dwconv_bwd_fused_supported(int H, int W, int C);
 int crnn_dwconv_bwd_fused_rows(int B, int H, int W, int C);
 int crnn_dwconv3x3_bwd_fused(const void* d, const void* da, const float* bnstate, const float* coef, const void* xin, const float* k, void* dx,
                              float* dk, float* scratch, int B, int H, int W, int C, crnn_stream_t stream);
+/* The same stage as a row stream (dwconv_bwd_stream.hip): a loader wave brings one row each of d, da and xin per step into an LDS ring
+ * (global_load_lds); five "DK" waves form dd of the arriving row and keep the 72 weight-gradient sums of their 16-byte column, five "DX"
+ * waves run the three running output rows of the data gradient on the dd row the others left in LDS.  Same contract and arithmetic as
+ * crnn_dwconv3x3_bwd_fused (dx bit-identical, dk to the order of its partial sums); scratch: crnn_dwconv_bwd_stream_rows() * 9 * C floats.
+ * _supported: CRNN_OK when W * C / 8 sixteen-byte columns split over whole channel octets into workgroups of 257..320 columns (every block
+ * of the CRNN), else CRNN_ERR_UNSUPPORTED. */
+int crnn_dwconv_bwd_stream_supported(int B, int H, int W, int C);
+int crnn_dwconv_bwd_stream_rows(int B, int H, int W, int C);
+int crnn_dwconv3x3_bwd_stream(const void* d, const void* da, const float* bnstate, const float* coef, const void* xin, const float* k, void* dx,
+                              float* dk, float* scratch, int B, int H, int W, int C, crnn_stream_t stream);
 int crnn_dwconv3x3_fwd(const float* x, const float* k, float* out, float* stat_partials, int B, int H, int W, int C,
                        int flip, crnn_stream_t stream);
 int crnn_dwconv3x3_wgrad(const float* x, const float* g, float* dk, float* scratch, int B, int H, int W, int C,

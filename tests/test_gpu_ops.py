@@ -126,7 +126,8 @@ def test_dwconv_fwd_flip_wgrad_stats(shape):
     assert_close(host(dk).reshape(3, 3, C), dk_ref, rtol=1e-4, atol=1e-4, what="wgrad")
 
 
-@pytest.mark.parametrize("shape", [(2, 104, 36, 128), (3, 52, 18, 256), (2, 52, 9, 512), (2, 13, 7, 64), (1, 5, 61, 64), (5, 33, 20, 128), (1, 3, 100, 64), (2, 1, 1, 64), (1, 40, 25, 64)])
+@pytest.mark.parametrize("shape", [(2, 104, 36, 128), (3, 52, 18, 256), (2, 52, 9, 512), (2, 13, 7, 64), (1, 5, 61, 64), (5, 33, 20, 128), (1, 3, 100, 64), (2, 1, 1, 64), (1, 40, 25, 64),
+                                   (3, 104, 36, 64), (2, 204, 36, 128), (40, 52, 18, 256), (128, 52, 9, 512), (2, 7, 36, 64), (1, 3, 18, 256)])
 def test_fused_depthwise_stage_backward_equals_the_three_kernel_sequence(shape):
     """crnn_dwconv3x3_bwd_fused (BatchNorm-backward pass 2 formed in the halo-tile fill, depthwise weight and data gradients from one
     pass over the tiles) against crnn_bn_bwd_ex + crnn_dwconv3x3_wgrad_ex + crnn_dwconv3x3_fwd_ex(flip=1) on bf16 tensors: the data
@@ -170,6 +171,20 @@ def test_fused_depthwise_stage_backward_equals_the_three_kernel_sequence(shape):
     assert_close(_f(dx2), dx_ref, rtol=2.0 ** -7, atol=2e-2 * np.abs(dx_ref).max(), what="dx vs oracle")
     assert_close(host(dk2).reshape(3, 3, C), dk_ref, rtol=1e-2, atol=1e-2 * np.abs(dk_ref).max(), what="dk vs oracle")
     assert L().crnn_dwconv_bwd_fused_supported(H, W, 32) == -3 and L().crnn_dwconv_bwd_fused_supported(H, W, 96) == -3
+    # the row-stream kernel of the same stage, where its shape rule holds: dx bit for bit, dk to summation round-off
+    if L().crnn_dwconv_bwd_stream_supported(B, H, W, C) == 0:
+        rows = L().crnn_dwconv_bwd_stream_rows(B, H, W, C)
+        dx3 = torch.full((B * H * W * C + 64,), 9.0, dtype=torch.bfloat16, device="cuda"); dk3 = zeros(9, C)
+        sc3 = torch.full((rows * 9 * C + 16,), 5.0, device="cuda")
+        ok(L().crnn_dwconv3x3_bwd_stream(P(dd), P(dad), P(st), P(coef2), P(xd), P(kd), P(dx3), P(dk3), P(sc3), B, H, W, C, S()))
+        assert torch.equal(dx3[:-64].view(torch.int16), dx1.reshape(-1).view(torch.int16)), "stream dx: max diff %g" % float((dx1.reshape(-1).float() - dx3[:-64].float()).abs().max())
+        assert bool((dx3[-64:] == 9.0).all()) and bool((sc3[-16:] == 5.0).all())
+        assert_close(host(dk3), host(dk1), rtol=2e-5, atol=2e-4 * np.abs(host(dk1)).max(), what="dk stream vs sequence")
+        dx4 = torch.zeros_like(dx3); dk4 = zeros(9, C)
+        ok(L().crnn_dwconv3x3_bwd_stream(P(dd), P(dad), P(st), P(coef2), P(xd), P(kd), P(dx4), P(dk4), P(sc3), B, H, W, C, S()))
+        assert torch.equal(dx4[:-64], dx3[:-64]) and torch.equal(dk3, dk4), "repeat launches differ"
+    else:
+        assert L().crnn_dwconv_bwd_stream_rows(B, H, W, C) == 0
 
 
 # ------------------------------------------------------------------------------------------------ BatchNorm chain
