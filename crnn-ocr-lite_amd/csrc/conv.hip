@@ -777,8 +777,9 @@ template <int VEC, bool POOL, typename T>
 __device__ __forceinline__ VecF<VEC> bn_gy_vec(const BnBwdArgsT<T>& a, long r, int c0, const VecF<VEC>& xv, const VecF<VEC>& sc,
                                                const VecF<VEC>& sh, float inv_keep) {
   VecF<VEC> out, y;
+  // no pooling: only 0 < y < 6 is asked of y below, which the clamp does not change (it is skipped); the window scan needs the clamped value
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) y.v[e] = relu6f(fmaf(xv.v[e], sc.v[e], sh.v[e]));
+  for (int e = 0; e < VEC; ++e) { const float t = fmaf(xv.v[e], sc.v[e], sh.v[e]); y.v[e] = POOL ? relu6f(t) : t; }
   long oidx;
   bool arg[VEC];
 #pragma unroll
@@ -946,15 +947,18 @@ __global__ __launch_bounds__(256) void bn_bwd_pool_kernel(BnBwdArgsT<T> a, float
       for (int e = 0; e < VEC; ++e) { cx.v[e] = -sc.v[e] * c2.v[e] * inv.v[e]; c0.v[e] = -sc.v[e] * c1.v[e] - cx.v[e] * mu.v[e]; }
       auto do_window = [&](long r, const VecF<VEC>& gv, const VecF<VEC> (&xw)[4], long xbase) {
         const long oidx = r * a.C + c0i;
+        // The scan runs on the UNCLAMPED BatchNorm value t: a window carries gradient only if its maximum lies in (0, 6), and then the
+        // first maximum of ReLU6(t) is the first maximum of t (values below 0 clamp to 0 < max, none reaches 6); for every other
+        // window gsel = 0 and neither xs nor arg is used.  Same bits, two VALU operations per element fewer.
         float best[VEC], xs[VEC]; int arg[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) { best[e] = -1.f; xs[e] = 0.f; arg[e] = 0; }
+        for (int e = 0; e < VEC; ++e) { best[e] = -INFINITY; xs[e] = 0.f; arg[e] = 0; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           if (k < nwin) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-              float y = relu6f(fmaf(xw[k].v[e], sc.v[e], sh.v[e]));
+              float y = fmaf(xw[k].v[e], sc.v[e], sh.v[e]);
               const bool up = y > best[e];                      // strict '>' keeps the FIRST maximum (scan order)
               best[e] = up ? y : best[e];
               if (PASS == 1) xs[e] = up ? xw[k].v[e] : xs[e]; else arg[e] = up ? k : arg[e];

@@ -24,6 +24,8 @@ timeout 200 python scripts/gemm_nt_bench.py 2>/dev/null | grep -v amdgpu > $OUT/
 timeout 200 python scripts/gemm_ablate.py 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_gemm_ablate.txt
 timeout 200 python scripts/rnn_gemm_bench.py 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_rnn_gemm_bench.txt
 timeout 100 python scripts/fused_bench.py --product-only 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_dw_bwd_fused_bench.txt
+timeout 100 python scripts/dws_bench.py 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_dw_fwd_stream_bench.txt
+timeout 100 python scripts/dbs_bench.py 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_dw_bwd_stream_bench.txt
 [ -f scripts/_trace/libwres_exp0.so ] && timeout 200 python scripts/wres_fwd_ablate.py 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_wres_fwd_ablate.txt
 [ -f scripts/_trace/libingest2.so ] && timeout 100 python scripts/experiments/ingest_probe2.py 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_ingest_probe.txt
 [ -f scripts/_trace/libingest.so ] && timeout 100 python scripts/experiments/ingest_probe.py 2>/dev/null | grep -v amdgpu >> $OUT/${TAG}_ingest_probe.txt
@@ -44,8 +46,8 @@ for mode in bf16 fp32; do
   done
 done
 cd $ROOT
-bash scripts/gpu_pmc_sq.sh ${TAG}_sq_dw scripts/dw_bench.py --bf16 2>&1 | grep dwconv > $OUT/${TAG}_pmc_sq_dwconv.txt
-bash scripts/gpu_pmc_any.sh ${TAG}_step "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAVE_CYCLES" -- bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary --no-roofline 2>&1 | grep -A1 -E "gemm_bf16_kernel|gemm_nt_kernel|gemm_wres|dw_bwd_fused|lstm_.*persist|dwconv_tile|bn_bwd" > $OUT/${TAG}_pmc_sq_step.txt
+bash scripts/gpu_pmc_sq.sh ${TAG}_sq_dw scripts/dw_bench.py --bf16 2>&1 | grep -E "dwconv|dw_fwd_stream" > $OUT/${TAG}_pmc_sq_dwconv.txt
+bash scripts/gpu_pmc_any.sh ${TAG}_step "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAVE_CYCLES" -- bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary --no-roofline 2>&1 | grep -A1 -E "gemm_bf16_kernel|gemm_nt_kernel|gemm_wres|dw_bwd_fused|dw_bwd_stream|dw_fwd_stream|pw_wgrad_stream|lstm_.*persist|dwconv_tile|bn_bwd" > $OUT/${TAG}_pmc_sq_step.txt
 find $OUT -name "*kernel_trace.csv" -size +30M -delete
 grep -E "passed|failed|error" $OUT/${TAG}_pytest_gpu.log | tail -3
 for f in bench_bf16s bench_fp32 bench_bf16 bench_iam bench_gru bench_step_kernels predict; do cut -c1-400 $OUT/${TAG}_$f.json; echo; done
