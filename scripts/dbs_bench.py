@@ -24,6 +24,7 @@ for (h, w, c) in shapes:
 variants = [("tile", L0, False), ("stream", L0, True)]
 for pth in sorted(glob.glob(os.path.join(ROOT, "scripts/_trace/libdbs_*.so"))):
     variants.append((os.path.basename(pth)[7:-3], ctypes.CDLL(pth), True))
+variants.append(("stream", L0, True))      # again, last: order effects
 iters = 6
 for name, L, stream in variants:
     ms = np.zeros((iters, len(shapes)))
