@@ -535,6 +535,14 @@ __device__ __forceinline__ void part_lane_sum2(const float* __restrict__ b0, con
                                                double& s0, double& s1) {
   double a = 0.0, b = 0.0;
   int p = lane;
+  // sixteen independent loads in flight: a lane's share of ~1900 partial rows is ~30 rows, i.e. four round trips to a remote L2 / HBM instead of eight
+  for (; p + 7 * RED_PL < nparts; p += 8 * RED_PL) {
+    float v[8], w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const long o = (long)(p + u * RED_PL) * stride; v[u] = b0[o]; w[u] = b1[o]; }
+    a += (((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3])) + (((double)v[4] + (double)v[5]) + ((double)v[6] + (double)v[7]));
+    b += (((double)w[0] + (double)w[1]) + ((double)w[2] + (double)w[3])) + (((double)w[4] + (double)w[5]) + ((double)w[6] + (double)w[7]));
+  }
   for (; p + 3 * RED_PL < nparts; p += 4 * RED_PL) {
     const long o0 = (long)p * stride, o1 = (long)(p + RED_PL) * stride, o2 = (long)(p + 2 * RED_PL) * stride, o3 = (long)(p + 3 * RED_PL) * stride;
     float v0 = b0[o0], v1 = b0[o1], v2 = b0[o2], v3 = b0[o3];

@@ -239,19 +239,32 @@ __global__ __launch_bounds__(256 + 64 * NIO) void pw_wgrad_stream_kernel(WgParam
     }
 }
 
-// out[i] = sum_s part[s][i], s ascending in a fixed grouping (deterministic)
+// out[i] = sum_s part[s][i] in a fixed grouping (deterministic): 8 split-lanes per output quad (lane l takes s = l, l + 8, ... with four
+// loads in flight), combined through LDS in lane order.  32 quads per workgroup: 256 workgroups for a 128 x 256 gradient -- the partials are
+// ingested by the whole chip instead of by 32 CUs.
 __global__ __launch_bounds__(256) void pw_wgrad_sum_kernel(const float* __restrict__ part, int nsplit, long total, float* __restrict__ out, int N, int ldc) {
-  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i >= total) return;
+  __shared__ float4 red[8][32];
+  const int q = threadIdx.x & 31, l = threadIdx.x >> 5;
+  const long i = ((long)blockIdx.x * 32 + q) * 4;
   float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-  int s = 0;
-  for (; s + 1 < nsplit; s += 2) {
-    const float4 v0 = *reinterpret_cast<const float4*>(part + (long)s * total + i), v1 = *reinterpret_cast<const float4*>(part + (long)(s + 1) * total + i);
-    a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
-    a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+  if (i < total) {
+    int s = l;
+    for (; s + 24 < nsplit; s += 32) {
+      const float4 v0 = *reinterpret_cast<const float4*>(part + (long)s * total + i), v1 = *reinterpret_cast<const float4*>(part + (long)(s + 8) * total + i);
+      const float4 v2 = *reinterpret_cast<const float4*>(part + (long)(s + 16) * total + i), v3 = *reinterpret_cast<const float4*>(part + (long)(s + 24) * total + i);
+      a0.x += v0.x + v2.x; a0.y += v0.y + v2.y; a0.z += v0.z + v2.z; a0.w += v0.w + v2.w;
+      a1.x += v1.x + v3.x; a1.y += v1.y + v3.y; a1.z += v1.z + v3.z; a1.w += v1.w + v3.w;
+    }
+    for (; s < nsplit; s += 8) { const float4 v0 = *reinterpret_cast<const float4*>(part + (long)s * total + i); a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w; }
   }
-  if (s < nsplit) { const float4 v0 = *reinterpret_cast<const float4*>(part + (long)s * total + i); a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w; }
-  *reinterpret_cast<float4*>(out + (i / N) * ldc + i % N) = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+  red[l][q] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+  __syncthreads();
+  if (l == 0 && i < total) {
+    float4 r = red[0][q];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { const float4 v = red[k][q]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+    *reinterpret_cast<float4*>(out + (i / N) * ldc + i % N) = r;
+  }
 }
 
 void wg_geom(long M, int N, int K, WgParams& p, int& grid) {
@@ -303,7 +316,7 @@ int wg_launch(WgParams& p, long M, float* out, int ldc, float* scratch, size_t s
   else hipLaunchKernelGGL((pw_wgrad_stream_kernel<8, F32>), dim3(grid), dim3(768), lds, stream, p);
   CRNN_LAUNCH_CHECK();
   const long total = (long)p.K * p.N;
-  hipLaunchKernelGGL(pw_wgrad_sum_kernel, dim3(cdiv(total, 1024)), dim3(256), 0, stream, scratch, p.nsplit, total, out, p.N, ldc);
+  hipLaunchKernelGGL(pw_wgrad_sum_kernel, dim3(cdiv(total, 128)), dim3(256), 0, stream, scratch, p.nsplit, total, out, p.N, ldc);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
