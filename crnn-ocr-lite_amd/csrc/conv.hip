@@ -859,6 +859,21 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgsT<T> a, float* __r
         for (int e = 0; e < VEC; ++e) bn_bwd_pq(sc.v[e], c1.v[e], c2.v[e], mu.v[e], inv.v[e], Pc.v[e], Qc.v[e]);
       }
       long r = r0 + rt;
+#if CRNN_BNB_ROWS4
+      if (PASS == 1 && !POOL) {
+        for (; r + 3L * RT < r1; r += 4L * RT) {   // four rows in flight: 8 independent 16-byte loads per thread
+          VecF<VEC> xr[4], gr[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) xr[u] = vload<VEC>(&a.x[(r + u * RT) * a.C + c0]);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) gr[u] = bn_gy_vec<VEC, POOL, T>(a, r + u * RT, c0, xr[u], sc, sh, inv_keep);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { s.v[e] += gr[u].v[e]; q.v[e] = fmaf(gr[u].v[e], (xr[u].v[e] - mu.v[e]) * inv.v[e], q.v[e]); }
+        }
+      }
+#endif
       for (; r + RT < r1; r += 2L * RT) {   // two rows in flight (independent loads)
         VecF<VEC> xa = vload<VEC>(&a.x[r * a.C + c0]);
         VecF<VEC> xb = vload<VEC>(&a.x[(r + RT) * a.C + c0]);
@@ -1050,8 +1065,16 @@ __global__ __launch_bounds__(RED_CH * RED_PL) void bn_bwd_finalize_kernel(const 
   }
 }
 
-// rows per chunk: largest power of two <= 1024 that still yields >= 1024 chunks (>= 16 rows)
-static inline int bn_bwd_rows_per_chunk(long rows) { long r = 1024; while (r > 16 && rows / r < 1024) r >>= 1; return (int)r; }
+// Chunking of the two BatchNorm-backward passes: rows per chunk = the largest power of two <= 1024 that still yields CRNN_BNB_MINCHUNKS
+// chunks.  256 (1-2 workgroups per CU, 468 partial rows at batch 256) measured best over 256 / 512 / 768 / 1024 / 2048
+// (scripts/bnp1_bench.py): the statistics pass itself barely cares, the finalize that reads the partial rows halves.
+#ifndef CRNN_BNB_MINCHUNKS
+#define CRNN_BNB_MINCHUNKS 256
+#endif
+#ifndef CRNN_BNB_ROWS4
+#define CRNN_BNB_ROWS4 1       // statistics pass without pooling: four rows (8 independent 16-byte loads) in flight per thread; 0 = two
+#endif
+static inline int bn_bwd_rows_per_chunk(long rows) { long r = 1024; while (r > 16 && rows / r < CRNN_BNB_MINCHUNKS) r >>= 1; return (int)r; }
 // upper bound on the number of partial rows for a [M][C] BN backward (pooled variants iterate over M/2 or M/4 windows)
 extern "C" int crnn_bn_bwd_chunks(long M) {
   int best = 0;
