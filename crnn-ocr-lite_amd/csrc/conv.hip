@@ -926,19 +926,29 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgsT<T> a, float* __r
 
 // Pooled variant (H % ph == 0, W % pw == 0): one thread owns a whole pool window x VEC channels, so every
 // pre-BN value is read exactly once per pass and the arg-max is found once per window.
-template <int PASS, int VEC, typename T>
+// PHT x PWT: the window as compile-time constants (0 x 0: run-time a.ph x a.pw) -- the window loops unroll without guards and the index
+// arithmetic has no run-time divisions: a thread decomposes its first window index once and then steps (b, ho, wo) by RT windows.
+template <int PASS, int VEC, typename T, int PHT = 0, int PWT = 0>
 __global__ __launch_bounds__(256) void bn_bwd_pool_kernel(BnBwdArgsT<T> a, float* __restrict__ partials,
                                                           const float* __restrict__ coef, T* __restrict__ dx, int CW,
                                                           int rows_per_chunk) {
   __shared__ float red[2][256 * VEC];
   const int tid = threadIdx.x, cl = tid % CW, rt = tid / CW, RT = 256 / CW;
-  const int Ho = a.H / a.ph, Wo = a.W / a.pw;
+  const int ph = PHT ? PHT : a.ph, pw = PWT ? PWT : a.pw;
+  const int Ho = a.H / ph, Wo = a.W / pw;
   const long Mo = (long)a.B * Ho * Wo;
   const long r0 = (long)blockIdx.x * rows_per_chunk;
   long r1 = r0 + rows_per_chunk; if (r1 > Mo) r1 = Mo;
   const int CL = a.C / VEC;
   const float inv_keep = a.rate > 0.f ? 1.f / (1.f - a.rate) : 1.f;
-  const int nwin = a.ph * a.pw;   // <= 4
+  const int nwin = ph * pw;       // <= 4
+  // first window of this thread: (b, ho, wo), stepped by RT windows per iteration
+  struct Pos { int b, ho, wo; };
+  auto pos_of = [&](long r) { Pos p; p.wo = (int)(r % Wo); const long rr = r / Wo; p.ho = (int)(rr % Ho); p.b = (int)(rr / Ho); return p; };
+  auto advance = [&](Pos& p, int n) {
+    p.wo += n;
+    while (p.wo >= Wo) { p.wo -= Wo; if (++p.ho == Ho) { p.ho = 0; ++p.b; } }
+  };
   for (int cb = 0; cb < CL; cb += CW) {
     const int c = cb + cl, c0i = c * VEC;
     VecF<VEC> s, q;
@@ -952,13 +962,12 @@ __global__ __launch_bounds__(256) void bn_bwd_pool_kernel(BnBwdArgsT<T> a, float
       for (int e = 0; e < VEC; ++e) { inv.v[e] = 1.0f / sqrtf(var.v[e] + BN_EPS); c1.v[e] = 0.f; c2.v[e] = 0.f; }
       if (PASS == 2) { c1 = vload<VEC>(coef + c0i); c2 = vload<VEC>(coef + a.C + c0i); }
       // one pool window per step; pass 1 (reduce only) keeps two windows' loads in flight
-      auto load_window = [&](long r, VecF<VEC>& gv, VecF<VEC> (&xw)[4], long& xbase) {
-        int wo = (int)(r % Wo); long rr = r / Wo; int ho = (int)(rr % Ho); long b = rr / Ho;
+      auto load_window = [&](long r, const Pos& p, VecF<VEC>& gv, VecF<VEC> (&xw)[4], long& xbase) {
         gv = vload<VEC>(&a.g[r * a.C + c0i]);
-        xbase = (((long)b * a.H + ho * a.ph) * a.W + wo * a.pw) * a.C + c0i;
+        xbase = (((long)p.b * a.H + p.ho * ph) * a.W + p.wo * pw) * a.C + c0i;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          if (k < nwin) { int ii = k / a.pw, j = k - ii * a.pw; xw[k] = vload<VEC>(&a.x[xbase + ((long)ii * a.W + j) * a.C]); }
+          if (k < nwin) { int ii = k / pw, j = k - ii * pw; xw[k] = vload<VEC>(&a.x[xbase + ((long)ii * a.W + j) * a.C]); }
       };
       // These two kernels are VALU-bound (SQ counters: ~3 resident waves/SIMD each 27-34 % VALU-active), so the window is
       // processed with as few operations as the arithmetic allows: only the arg-max position carries gradient, hence
@@ -1010,26 +1019,30 @@ __global__ __launch_bounds__(256) void bn_bwd_pool_kernel(BnBwdArgsT<T> a, float
               VecF<VEC> o;
 #pragma unroll
               for (int e = 0; e < VEC; ++e) o.v[e] = fmaf(cx.v[e], xw[k].v[e], c0.v[e]) + ((arg[e] == k) ? gsel[e] : 0.f);
-              int ii = k / a.pw, j = k - ii * a.pw;
+              int ii = k / pw, j = k - ii * pw;
               vstore<VEC>(&dx[xbase + ((long)ii * a.W + j) * a.C], o);
             }
           }
         }
       };
       long r = r0 + rt;
+      Pos pa = pos_of(r < r1 ? r : r0);
       if (PASS == 1) {
         for (; r + RT < r1; r += 2L * RT) {
           VecF<VEC> ga, gb, xa[4], xb[4]; long ba, bb;
-          load_window(r, ga, xa, ba);
-          load_window(r + RT, gb, xb, bb);
+          Pos pb = pa; advance(pb, RT);
+          load_window(r, pa, ga, xa, ba);
+          load_window(r + RT, pb, gb, xb, bb);
           do_window(r, ga, xa, ba);
           do_window(r + RT, gb, xb, bb);
+          pa = pb; advance(pa, RT);
         }
       }
       for (; r < r1; r += RT) {
         VecF<VEC> gv, xw[4]; long xbase;
-        load_window(r, gv, xw, xbase);
+        load_window(r, pa, gv, xw, xbase);
         do_window(r, gv, xw, xbase);
+        advance(pa, RT);
       }
     }
     if (PASS == 1) {
@@ -1090,13 +1103,18 @@ static int bn_bwd_launch(const BnBwdArgsT<T>& a, T* dx, float* dgamma, float* db
   const bool window = POOL && (a.H % a.ph == 0) && (a.W % a.pw == 0) && (a.ph * a.pw <= 4);
   const long rows = window ? M / (a.ph * a.pw) : M;
   const int rpc = bn_bwd_rows_per_chunk(rows), chunks = cdiv(rows, rpc);
-  if (window) hipLaunchKernelGGL((bn_bwd_pool_kernel<1, VEC, T>), dim3(chunks), dim3(256), 0, stream, a, parts, (const float*)nullptr, (T*)nullptr, CW, rpc);
+  const int pk = (a.ph == 2 && a.pw == 2) ? 1 : ((a.ph == 1 && a.pw == 2) ? 2 : 0);      // the CRNN's two pool shapes as compile-time windows
+  if (window && pk == 1) hipLaunchKernelGGL((bn_bwd_pool_kernel<1, VEC, T, 2, 2>), dim3(chunks), dim3(256), 0, stream, a, parts, (const float*)nullptr, (T*)nullptr, CW, rpc);
+  else if (window && pk == 2) hipLaunchKernelGGL((bn_bwd_pool_kernel<1, VEC, T, 1, 2>), dim3(chunks), dim3(256), 0, stream, a, parts, (const float*)nullptr, (T*)nullptr, CW, rpc);
+  else if (window) hipLaunchKernelGGL((bn_bwd_pool_kernel<1, VEC, T>), dim3(chunks), dim3(256), 0, stream, a, parts, (const float*)nullptr, (T*)nullptr, CW, rpc);
   else hipLaunchKernelGGL((bn_bwd_kernel<1, VEC, POOL, T>), dim3(chunks), dim3(256), 0, stream, a, parts, (const float*)nullptr, (T*)nullptr, CW, rpc);
   CRNN_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(a.C, RED_CH)), dim3(RED_CH, RED_PL), 0, stream, parts, chunks, a.C, 1.0 / (double)M, dgamma, dbeta, coef);
   CRNN_LAUNCH_CHECK();
   if (dx == nullptr) return CRNN_OK;   // statistics only: dgamma, dbeta and coef = [mean(gy) | mean(gy * xhat)]; the caller applies pass 2 itself
-  if (window) hipLaunchKernelGGL((bn_bwd_pool_kernel<2, VEC, T>), dim3(chunks), dim3(256), 0, stream, a, (float*)nullptr, coef, dx, CW, rpc);
+  if (window && pk == 1) hipLaunchKernelGGL((bn_bwd_pool_kernel<2, VEC, T, 2, 2>), dim3(chunks), dim3(256), 0, stream, a, (float*)nullptr, coef, dx, CW, rpc);
+  else if (window && pk == 2) hipLaunchKernelGGL((bn_bwd_pool_kernel<2, VEC, T, 1, 2>), dim3(chunks), dim3(256), 0, stream, a, (float*)nullptr, coef, dx, CW, rpc);
+  else if (window) hipLaunchKernelGGL((bn_bwd_pool_kernel<2, VEC, T>), dim3(chunks), dim3(256), 0, stream, a, (float*)nullptr, coef, dx, CW, rpc);
   else hipLaunchKernelGGL((bn_bwd_kernel<2, VEC, POOL, T>), dim3(chunks), dim3(256), 0, stream, a, (float*)nullptr, coef, dx, CW, rpc);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
