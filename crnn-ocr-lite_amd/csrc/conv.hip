@@ -699,33 +699,49 @@ extern "C" int crnn_bn_infer_state(const float* mmean, const float* mvar, const 
 // y = Dropout(MaxPool(ReLU6(x*scale+shift)))   (utils.py:45-56).  ph=pw=1: no pooling; rate=0: no dropout.
 // x [B,H,W,C] -> y [B,H/ph,W/pw,C]
 // ---------------------------------------------------------------------------------------------
-template <int VEC, typename TI, typename TO>
+// IDX: index type of the element counter -- unsigned (32-bit divisions: ~25 VALU instructions each) whenever the tensor has fewer than 2^31
+// vectors, long otherwise (64-bit divisions cost ~100 each, and a vector needs two to five of them against ~60 instructions of payload).
+// PHT x PWT: the pool window as compile-time constants (0 x 0: run-time ph x pw).
+template <int VEC, typename TI, typename TO, typename IDX, int PHT, int PWT>
 __global__ void bn_act_pool_drop_kernel(const TI* __restrict__ x, const float* __restrict__ bnstate,
-                                        TO* __restrict__ y, int B, int H, int W, int C, int ph, int pw, float rate,
+                                        TO* __restrict__ y, int B, int H, int W, int C, int ph_, int pw_, float rate,
                                         uint64_t seed, uint32_t layer) {
+  const int ph = PHT ? PHT : ph_, pw = PWT ? PWT : pw_;
   const int Ho = H / ph, Wo = W / pw, CL = C / VEC;
-  const long total = (long)B * Ho * Wo * CL;
+  const IDX total = (IDX)((long)B * Ho * Wo * CL);
   const float inv_keep = rate > 0.f ? 1.f / (1.f - rate) : 1.f;
   const float* sc = bnstate + 2 * C; const float* sh = bnstate + 3 * C;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int cl = (int)(i % CL); long pix = i / CL;
+  for (IDX i = (IDX)blockIdx.x * (IDX)blockDim.x + threadIdx.x; i < total; i += (IDX)gridDim.x * (IDX)blockDim.x) {
+    const int cl = (int)(i % (IDX)CL); const IDX pix = i / (IDX)CL;
     VecF<VEC> m, s = vload<VEC>(sc + cl * VEC), t = vload<VEC>(sh + cl * VEC);
     if (ph * pw == 1) {
-      VecF<VEC> v = vload<VEC>(&x[pix * C + cl * VEC]);
+      VecF<VEC> v = vload<VEC>(&x[(long)pix * C + cl * VEC]);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) m.v[e] = relu6f(fmaf(v.v[e], s.v[e], t.v[e]));
     } else {
-      int wo = (int)(pix % Wo); long r = pix / Wo; int ho = (int)(r % Ho); long b = r / Ho;
+      const int wo = (int)(pix % (IDX)Wo); const IDX r = pix / (IDX)Wo; const int ho = (int)(r % (IDX)Ho); const long b = (long)(r / (IDX)Ho);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) m.v[e] = -INFINITY;
-      for (int ii = 0; ii < ph; ++ii)
-        for (int j = 0; j < pw; ++j) {
-          VecF<VEC> v = vload<VEC>(&x[(((long)b * H + ho * ph + ii) * W + wo * pw + j) * C + cl * VEC]);
+      const long base = ((b * H + (long)ho * ph) * W + (long)wo * pw) * C + cl * VEC;
+      if (PHT) {
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) m.v[e] = fmaxf(m.v[e], relu6f(fmaf(v.v[e], s.v[e], t.v[e])));
-        }
+        for (int ii = 0; ii < (PHT ? PHT : 1); ++ii)
+#pragma unroll
+          for (int j = 0; j < (PWT ? PWT : 1); ++j) {
+            VecF<VEC> v = vload<VEC>(&x[base + ((long)ii * W + j) * C]);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) m.v[e] = fmaxf(m.v[e], relu6f(fmaf(v.v[e], s.v[e], t.v[e])));
+          }
+      } else {
+        for (int ii = 0; ii < ph; ++ii)
+          for (int j = 0; j < pw; ++j) {
+            VecF<VEC> v = vload<VEC>(&x[base + ((long)ii * W + j) * C]);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) m.v[e] = fmaxf(m.v[e], relu6f(fmaf(v.v[e], s.v[e], t.v[e])));
+          }
+      }
     }
-    long obase = pix * C + cl * VEC;
+    const long obase = (long)pix * C + cl * VEC;
     float dm[VEC];
     drop_scale_vec<VEC>(seed, layer, (uint64_t)obase, rate, inv_keep, dm);
 #pragma unroll
@@ -739,7 +755,14 @@ static void bn_act_go(const TI* x, const float* bnstate, TO* y, int B, int H, in
                       uint32_t layer, hipStream_t stream) {
   long total = (long)B * (H / ph) * (W / pw) * C;
   int blocks = cdiv(total / VEC, 256); if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL((bn_act_pool_drop_kernel<VEC, TI, TO>), dim3(blocks), dim3(256), 0, stream, x, bnstate, y, B, H, W, C, ph, pw, rate, seed, layer);
+  const bool small = total / VEC + 8192L * 256 < (1L << 31);       // the grid-stride counter stays below 2^31 + one stride: fits unsigned
+  const dim3 g(blocks), t(256);
+#define BN_ACT_LAUNCH(IDX, PHT, PWT) hipLaunchKernelGGL((bn_act_pool_drop_kernel<VEC, TI, TO, IDX, PHT, PWT>), g, t, 0, stream, x, bnstate, y, B, H, W, C, ph, pw, rate, seed, layer)
+  if (!small) BN_ACT_LAUNCH(long, 0, 0);
+  else if (ph == 2 && pw == 2) BN_ACT_LAUNCH(unsigned, 2, 2);
+  else if (ph == 1 && pw == 2) BN_ACT_LAUNCH(unsigned, 1, 2);
+  else BN_ACT_LAUNCH(unsigned, 0, 0);
+#undef BN_ACT_LAUNCH
 }
 template <typename TI, typename TO>
 static int bn_act_launch(const TI* x, const float* bnstate, TO* y, int B, int H, int W, int C, int ph, int pw, float rate, uint64_t seed,
@@ -1078,16 +1101,17 @@ __global__ __launch_bounds__(RED_CH * RED_PL) void bn_bwd_finalize_kernel(const 
   }
 }
 
-// Chunking of the two BatchNorm-backward passes: rows per chunk = the largest power of two <= 1024 that still yields CRNN_BNB_MINCHUNKS
-// chunks.  256 (1-2 workgroups per CU, 468 partial rows at batch 256) measured best over 256 / 512 / 768 / 1024 / 2048
-// (scripts/bnp1_bench.py): the statistics pass itself barely cares, the finalize that reads the partial rows halves.
+// Chunking of the two BatchNorm-backward passes: rows per chunk = the largest power of two <= 512 that still yields CRNN_BNB_MINCHUNKS
+// chunks.  256 (468 partial rows for the 52-row maps at batch 256, 1872 for the 104-row maps) measured best over 256 / 512 / 768 / 1024 /
+// 2048 (scripts/bnp1_bench.py): the statistics pass itself barely cares, the finalize that reads the partial rows halves; chunks of 1024
+// rows (936 workgroups) cost the 104-row maps 6 % in the step.
 #ifndef CRNN_BNB_MINCHUNKS
 #define CRNN_BNB_MINCHUNKS 256
 #endif
 #ifndef CRNN_BNB_ROWS4
 #define CRNN_BNB_ROWS4 1       // statistics pass without pooling: four rows (8 independent 16-byte loads) in flight per thread; 0 = two
 #endif
-static inline int bn_bwd_rows_per_chunk(long rows) { long r = 1024; while (r > 16 && rows / r < CRNN_BNB_MINCHUNKS) r >>= 1; return (int)r; }
+static inline int bn_bwd_rows_per_chunk(long rows) { long r = 512; while (r > 16 && rows / r < CRNN_BNB_MINCHUNKS) r >>= 1; return (int)r; }
 // upper bound on the number of partial rows for a [M][C] BN backward (pooled variants iterate over M/2 or M/4 windows)
 extern "C" int crnn_bn_bwd_chunks(long M) {
   int best = 0;
