@@ -102,6 +102,30 @@ def test_library_exports_every_declared_symbol_and_layout_is_keras_order():
     assert L.crnn_workspace_bytes(ctypes.byref(bad)) == 0
 
 
+def test_schedule_flags_of_the_binding_equal_the_header_and_row_stream_shape_rules():
+    """native.FLAG_* mirror the CRNN_FLAG_* macros of include/crnn_mi355x.h (the header is the contract: a drifted constant would silently
+    select another schedule), and the shape rules of the two row-stream depthwise kernels -- host arithmetic, no GPU -- accept every block of
+    the CRNN at the 100x32 and 200x32 input shapes and refuse maps whose rows do not fill the step row."""
+    import re
+    text = open(native.HEADER).read()
+    macros = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+CRNN_FLAG_(\w+)\s+(\d+)", text)}
+    ours = {k[5:]: v for k, v in vars(native).items() if k.startswith("FLAG_")}
+    assert macros == ours and len(set(macros.values())) == len(macros), (macros, ours)
+    assert all(v & (v - 1) == 0 for v in macros.values())                    # single bits
+    L = ctypes.CDLL(native.LIB_PATH)
+    for B in (1, 64, 256, 1024):
+        for H in (104, 204):
+            for (h, w, c) in [(H, 36, 64), (H, 36, 128), (H // 2, 18, 256), (H // 2, 18, 256), (H // 2, 9, 512), (H // 2, 9, 512)]:
+                assert L.crnn_dwconv_fwd_stream_supported(B, h, w, c) == 0 and L.crnn_dwconv_bwd_stream_supported(B, h, w, c) == 0, (B, h, w, c)
+                rows_f, rows_b = L.crnn_dwconv_fwd_stream_rows(B, h, w, c), L.crnn_dwconv_bwd_stream_rows(B, h, w, c)
+                assert rows_f >= B and rows_f % B == 0 and h % (rows_f // B) == 0          # whole row bands per image
+                assert rows_b >= B and rows_b % B == 0 and h % (rows_b // B) == 0
+    for (h, w, c) in [(104, 52, 64), (13, 18, 64), (52, 18, 252), (51, 9, 256), (104, 36, 1)]:
+        assert L.crnn_dwconv_fwd_stream_supported(8, h, w, c) == -3 and L.crnn_dwconv_fwd_stream_rows(8, h, w, c) == 0
+    for (h, w, c) in [(104, 52, 64), (52, 18, 252), (104, 36, 1), (8, 4, 64)]:
+        assert L.crnn_dwconv_bwd_stream_supported(8, h, w, c) == -3 and L.crnn_dwconv_bwd_stream_rows(8, h, w, c) == 0
+
+
 def test_model_surface_weights_roundtrip_without_gpu(tmp_path):
     init_model = U.CRNN(num_classes=38, shape=(100, 32, 1), max_string_len=23, time_dense_size=128, n_units=256)
     model = init_model.get_model()
