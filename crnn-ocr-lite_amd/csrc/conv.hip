@@ -1201,9 +1201,28 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
     y[r * ldy + c] = x[r * ldx + c] * drop_scale(seed, layer, (uint64_t)i, rate, inv_keep);
   }
 }
+// four consecutive elements per thread: one 16-byte load / store and ONE hash (drop_scale_vec: a hash covers an aligned group of four
+// element indices) instead of four of each; 32-bit index arithmetic.  C, ldx, ldy multiples of 4, 16-byte aligned, < 2^31 vectors.
+__global__ void dropout_vec4_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned nvec, int C4, int ldx, int ldy,
+                                    float rate, uint64_t seed, uint32_t layer) {
+  const float inv_keep = rate > 0.f ? 1.f / (1.f - rate) : 1.f;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += gridDim.x * blockDim.x) {
+    const unsigned r = i / (unsigned)C4, c4 = i - r * (unsigned)C4;
+    const float4 v = *reinterpret_cast<const float4*>(x + (long)r * ldx + 4 * c4);
+    float dm[4];
+    drop_scale_vec<4>(seed, layer, (uint64_t)i * 4, rate, inv_keep, dm);
+    *reinterpret_cast<float4*>(y + (long)r * ldy + 4 * c4) = make_float4(v.x * dm[0], v.y * dm[1], v.z * dm[2], v.w * dm[3]);
+  }
+}
 extern "C" int crnn_dropout(const float* x, float* y, long rows, int C, int ldx, int ldy, float rate, uint64_t seed,
                             uint32_t layer, hipStream_t stream) {
   long n = rows * C;
+  if (C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && n / 4 + 4096L * 256 < (1L << 31) && n > 0) {
+    int blocks = cdiv(n / 4, 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(dropout_vec4_kernel, dim3(blocks), dim3(256), 0, stream, x, y, (unsigned)(n / 4), C / 4, ldx, ldy, rate, seed, layer);
+    CRNN_LAUNCH_CHECK();
+    return CRNN_OK;
+  }
   int blocks = cdiv(n, 256); if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(256), 0, stream, x, y, rows, C, ldx, ldy, rate, seed, layer);
   CRNN_LAUNCH_CHECK();
