@@ -1,4 +1,6 @@
-// Backward of one depthwise stage of a conv block in ONE kernel (bf16 storage, training):
+// Backward of one depthwise stage of a conv block in ONE kernel (bf16 storage, training) on halo tiles -- since the end of round 2 the fallback of
+// the row-stream kernel of the same stage (dwconv_bwd_stream.hip: crnn_dwconv3x3_bwd_stream), taken for map widths that kernel refuses and under
+// CRNN_FLAG_DW_TILE_KERNEL:
 //     a = ReLU6(BatchNorm_1(d)),  d = DepthwiseConv2D(3x3)(x)          (utils.py:44-46)
 // given da = dL/da (from the pointwise data-gradient GEMM), the BatchNorm statistics / coefficients (crnn_bn_bwd_ex with
 // dx = null: first pass + finalize) it produces   dx = dL/dx   and   dk = dL/d(depthwise kernel).
