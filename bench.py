@@ -106,9 +106,9 @@ def depthwise_roofline(eng, iters=15):
     # HBM bytes of the same launch set from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE as separate
     # counter-only runs over scripts/dw_bench.py at batch 256 -- scripts/gpu_round2.sh -- folded by scripts/pmc_summary.py
     # and committed under profiles/; FETCH_SIZE x2 per the gfx950 note in MI355X_MICROARCH.md)
-    traffic = None
+    traffic, pmc_file = None, None
     try:
-        pmc_file = [f for f in ("r02_pmc_dwconv.json", "r01_pmc_dwconv.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+        pmc_file = [f for f in ("r03_pmc_dwconv.json", "r02_pmc_dwconv.json", "r01_pmc_dwconv.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
         pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
         if B == pmc["batch"] and (eng.cfg.imgh, eng.cfg.imgw) == (100, 32):
             if nstream == len(launches):
@@ -126,19 +126,22 @@ def depthwise_roofline(eng, iters=15):
              if nstream == len(launches) else
              "dwconv_tile_kernel<0> (depthwise 3x3 fwd%s, blocks 2-7, LDS halo tiles)" % ("" if bf16s else " + data-gradient")
              if nstream == 0 else "dw_fwd_stream_kernel + dwconv_tile_kernel<0> (depthwise 3x3 forward, blocks 2-7)")
-    cold = {"achieved": round(ach, 1), "frac": round(ach / PEAK_HBM_GBS, 4), "avg_launch_ms": round(1e3 * t / len(launches), 4),
-            "note": "the same launches re-issued back to back (every input last touched five launches earlier: nothing cache-resident, launch gaps included)"}
+    # HBM-roofline fraction = the COLD back-to-back figure: the six launches re-issued in a row on the live buffers, every input last
+    # touched five launches earlier (1.7 GB working set against the 256 MB last-level cache), launch gaps inside the event pair.  The
+    # in-step figure (each launch right after its producer, part of its input still in the last-level cache) is an EFFECTIVE
+    # bandwidth, reported beside it -- it is what the timed steps see, not an HBM fraction.
+    res = {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
+           "launches": len(launches), "avg_launch_ms": round(1e3 * t / len(launches), 4), "algorithmic_bytes_per_launch_set": nbytes,
+           "traffic": traffic,
+           "traffic_note": None if traffic is None else "HBM bytes per launch set from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the cold "
+                           "micro-benchmark (scripts/dw_bench.py; profiles/%s), i.e. the same cache state as `achieved`" % pmc_file,
+           "measurement": "HIP events on the launch stream around the launch set re-issued back to back on the live buffers (cold: every input "
+                          "last touched five launches earlier), median of %d repetitions" % iters}
     if in_step is not None:
-        # headline = the state the timed steps run the kernel in (this is the duration rocprofv3 reports for the kernel over the bench command)
-        return {"bound": "hbm", "kernel": kname, "achieved": in_step["achieved"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": in_step["frac"],
-                "launches": len(launches), "avg_launch_ms": in_step["avg_launch_ms"], "algorithmic_bytes_per_launch_set": nbytes, "traffic": traffic,
-                "measurement": "one HIP-event pair per launch on the launch stream, each launch issued right after the kernel that writes its input "
-                               "(previous block's BN + ReLU6 + pool + dropout), i.e. in the step's order and cache state",
-                "cold_back_to_back": cold}
-    return {"bound": "hbm", "kernel": kname,
-            "achieved": cold["achieved"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": cold["frac"],
-            "launches": len(launches), "avg_launch_ms": cold["avg_launch_ms"],
-            "algorithmic_bytes_per_launch_set": nbytes, "traffic": traffic}
+        in_step["note"] = ("effective bandwidth in the step's order and cache state: one event pair per launch, each launch issued right after the "
+                           "kernel that writes its input (previous block's BN + ReLU6 + pool + dropout); not an HBM-roofline fraction")
+        res["in_step_effective"] = in_step
+    return res
 
 
 def depthwise_bwd_roofline(eng, iters=5):
@@ -290,20 +293,82 @@ def cpu_baseline():
     """The reference's CPU path is Keras-TF (train.py with --G 0), absent from this image; what IS timed here, on this box's host
     cores, is the torch-CPU fp32 restatement of the same graph (oracle/torch_port.py: training-mode forward, CTC cost, autograd
     backward, global-norm clip, Keras-form Adam) on the metric's literal batch: 64 synthetic 100x32 images (BASELINE configs[0]).
-    Bounded sample: one step with 4 threads (the reference's own CPU setting, predict.py:88-93) and two steps with all cores."""
+    Bounded sample (about 25-30 s of CPU work): one untimed warm-up step + two timed steps with 16 threads; one warm-up + one timed
+    step with 4 threads (the reference's own CPU setting, predict.py:88-93)."""
     from oracle import torch_port as TP
     # this graph does not scale over cores on the CPU (52-step Python LSTM loops, small ops): measured on the MI355X box's host
     # (2 x EPYC 9575F, 256 logical cores) 4 / 16 / 32 / 64 threads = 6.2 / 6.5 / 6.3 / 9.1 s per step, and minutes per step with all
     # 256 -- so "all cores" is capped at 16 threads and `cores` states the threads actually used
     cores = min(os.cpu_count() or 1, 16)
-    s4, _ = TP.train_step_benchmark(batch=64, threads=4, steps=1, warmup=0)
-    sall, _ = TP.train_step_benchmark(batch=64, threads=cores, steps=2, warmup=0)
+    sall, _ = TP.train_step_benchmark(batch=64, threads=cores, steps=2, warmup=1)
+    s4, _ = TP.train_step_benchmark(batch=64, threads=4, steps=1, warmup=0)     # the allocator / thread pools are warm by now
     return {"value": round(64 / sall, 2), "unit": "images/sec", "cores": int(cores), "kind": "port",
             "threads4": {"value": round(64 / s4, 2), "unit": "images/sec", "cores": 4, "sec_per_step": round(s4, 3)},
             "sec_per_step": round(sall, 3), "host_logical_cores": os.cpu_count(),
             "sample": "torch-CPU fp32 restatement of the Keras/TF graph (oracle/torch_port.py), full train step (fwd + CTC + bwd + clip + "
-                      "Adam) at batch 64, 100x32: 2 timed steps with %d threads (more threads are slower on this graph); 1 step with 4 threads "
-                      "(the reference's CPU setting, predict.py:88-93); Keras-TF itself is not in the image" % cores}
+                      "Adam) at batch 64, 100x32: 1 warm-up + 2 timed steps with %d threads (more threads are slower on this graph); then 1 timed "
+                      "step with 4 threads (the reference's CPU setting, predict.py:88-93); a bounded sample (BASELINE.md planned 5 + 20 steps: "
+                      "that is 2.5 minutes of CPU work); Keras-TF itself is not in the image" % cores}
+
+
+def predict_leg(batch=1024, iters=20, precision="bf16s", cpu_sample=32):
+    """BASELINE configs[4] (predict.py:166-171 + utils.py:347-357): inference-only path at batch 1024 -- forward (BatchNorm moving
+    statistics, dropout off) + CTC beam search (beam_width 10, top_paths 1, merge_repeated) as the HIP wavefront kernel; p50 latency
+    per image = p50 of (forward + beam search of the whole batch) / batch.  Beside it the greedy decode and the CPU restatement of the
+    TF beam search (oracle/ctc.py, one host thread) on a bounded sample of the same posteriors."""
+    from crnn_mi355x.engine import Engine
+    from crnn_mi355x.init import initial_parameters
+    B = batch
+    eng = Engine(B, dropout=False, precision=precision)
+    p = initial_parameters(eng.layout, eng.cfg.units, False, seed=1)
+    rs = np.random.RandomState(2)
+    for k in p:                                        # non-degenerate posteriors: the identity-STN / zero-bias init decodes to ""
+        if k.endswith(("_b", "_g")) or k == "stn_d2_w":
+            p[k] = (p[k] + rs.normal(size=p[k].shape) * (0.02 if k.startswith("stn_d2") else 0.3)).astype(np.float32)
+    eng.set_params(p)
+    x, lab, il, ll = synthetic_batch(B, seed=0, T=eng.T)
+    xd = torch.from_numpy(x).cuda()
+
+    def timed(fn, n):
+        ts = []
+        for _ in range(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return float(np.median(ts)), float(np.percentile(ts, 90))
+    state = {}
+
+    def fwd(): state["y"] = eng.forward(xd, train=False)
+    def beam(): state["beam"] = eng.beam_decode(state["y"], beam_width=10)
+    def greedy(): state["greedy"] = eng.greedy_decode(state["y"])
+    def both(): fwd(); beam()
+    for _ in range(3):
+        both(); greedy()
+    f50, _ = timed(fwd, iters)
+    b50, _ = timed(beam, iters)
+    g50, _ = timed(greedy, iters)
+    t50, t90 = timed(both, iters)
+    eng.check_rnn_status()
+    out = {"workload": "BASELINE configs[4]: predict path, batch %d, 100x32x1, forward (inference BatchNorm) + CTC beam search bw=10" % B,
+           "precision": precision, "iters": iters, "forward_ms_p50": round(f50, 3), "beam_decode_ms_p50": round(b50, 3),
+           "greedy_decode_ms_p50": round(g50, 3), "forward_plus_beam_ms_p50": round(t50, 3), "forward_plus_beam_ms_p90": round(t90, 3),
+           "latency_us_per_image_p50": round(1e3 * t50 / B, 3), "images_per_sec": round(B / (t50 * 1e-3), 1)}
+    if cpu_sample:
+        # CPU restatement of TF's beam search (the oracle: only this baseline leg uses it) on a bounded sample, one thread
+        from oracle import ctc as OC
+        y = state["y"].float().cpu().numpy()
+        n = min(cpu_sample, B)
+        t0 = time.perf_counter()
+        ref = OC.ctc_beam_decode(y[:n].astype(np.float64), beam_width=10)
+        cpu_ms = 1e3 * (time.perf_counter() - t0) / n
+        o, ln, _ = [t.cpu().numpy() for t in state["beam"]]
+        agree = sum(int(ln[i] == ref[1][i] and list(o[i, :ln[i]]) == list(ref[0][i, :ref[1][i]])) for i in range(n)) / n
+        out.update({"cpu_beam_ms_per_image": round(cpu_ms, 3), "cpu_beam_sample": n, "cpu_beam_kind": "port (oracle/ctc.py, 1 thread)",
+                    "beam_agreement_with_cpu_on_sample": agree,
+                    "reference_published": "1.01 s/image for the per-image K.ctc_decode loop (reference README.md:75, unknown hardware)"})
+    del eng
+    torch.cuda.empty_cache()
+    return out
 
 
 def lstm_roofline(eng, iters=10):
@@ -467,7 +532,36 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    last_loss = float(loss.mean().item())
+    last_loss, giveups = eng.loss_and_status().tolist()
+    eng.raise_if_rnn_gave_up(giveups)       # a persistent recurrence that lost its co-residency would have produced garbage silently
+
+    dp_proof = None
+    if dist is not None:
+        # Self-proof of the N-rank run (after the timed region): the process group's own world size and backend, identical replicas
+        # (max |difference| of a parameter checksum vector gathered from every rank: 0.0 when the all-reduce + same Adam step kept the
+        # weights bit-identical), and how much of the gradient exchange is exposed (the same steps without the all-reduce, timed the
+        # same way: replicas diverge there, which is why it runs last).
+        chk = torch.stack([eng.params.double().sum(), eng.params.double().abs().sum(), (eng.params.double() ** 2).sum(),
+                           eng.bn_mean.double().sum()])
+        allchk = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(allchk, chk)
+        allchk = torch.stack(allchk)
+        spread = float((allchk.max(0).values - allchk.min(0).values).abs().max().item())
+        k2 = max(3, min(args.steps, 10))
+        dist.barrier(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            eng.train_step(xd, labd, ild, lld, opt, it, allreduce=None); it += 1
+        torch.cuda.synchronize(); dist.barrier()
+        tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ms_no_ar = 1e3 * float(tt.item()) / k2
+        dp_proof = {"dist_world_size": dist.get_world_size(), "dist_backend": dist.get_backend(), "ranks_reporting": int(allchk.shape[0]),
+                    "param_checksum_max_abs_diff_across_ranks": spread, "replicas_identical": spread == 0.0,
+                    "allreduce_bytes_per_step": int(eng.n_total * 4), "ms_per_step_without_allreduce": round(ms_no_ar, 3),
+                    "exposed_allreduce_ms": round(1e3 * dt / args.steps - ms_no_ar, 3),
+                    "note": "checksums = (sum, sum|.|, sum of squares of the flat parameter buffer; sum of the BatchNorm moving means) in fp64 "
+                            "per rank after the timed steps; exposed = ms_per_step - the same step without the gradient exchange"}
 
     if rank == 0:
         res = {
@@ -482,6 +576,8 @@ def main():
                                                  "parity tolerance: see parity_mode for the fp32 step)"}[args.precision]),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": round(last_loss, 4)},
         }
+        if dp_proof is not None:
+            res["data_parallel"] = dp_proof
         if not args.no_roofline:
             res["roofline"] = depthwise_roofline(eng)
             res["gemm_roofline"] = pointwise_gemm_roofline(eng)
@@ -492,36 +588,51 @@ def main():
             if lr is not None:
                 res["lstm_roofline"] = lr
         if world == 1 and not args.no_secondary:
-            mk = lambda bb, seed: tuple(torch.from_numpy(a if i == 0 else a.astype(np.int32)).cuda() for i, a in enumerate(
-                synthetic_batch(bb, seed=seed, imgh=args.imgh, max_len=args.max_len, T=eng.T)))
+            adam = lambda: Adam(lr=1e-4, beta_1=0.5, beta_2=0.999, clipnorm=5)
+
+            def leg(batch, steps, warm, reps=1, **kw):
+                """One more engine on the same kind of synthetic batch, timed like the headline (wall clock around `steps` steps between
+                device synchronisations); reps > 1: the MEDIAN repetition is reported, all are listed."""
+                kw = dict(dict(imgh=args.imgh, max_len=args.max_len, dropout=True, precision=args.precision, gru=args.gru), **kw)
+                e = Engine(batch, **kw)
+                e.set_params(initial_parameters(e.layout, e.cfg.units, kw["gru"], seed=1))
+                bt = tuple(torch.from_numpy(a if i == 0 else a.astype(np.int32)).cuda() for i, a in enumerate(
+                    synthetic_batch(batch, seed=0, imgh=kw["imgh"], max_len=kw["max_len"], T=e.T)))
+                o = adam()
+                ts, ls = [], None
+                for r in range(reps):
+                    t, ls = timed_steps(e, bt, o, steps, warm if r == 0 else 0, it0=r * (steps + warm))
+                    ts.append(t)
+                e.check_rnn_status()
+                del e
+                torch.cuda.empty_cache()
+                tm = float(np.median(ts))
+                out = {"batch": batch, "value": round(batch * steps / tm, 1), "unit": "images/sec", "ms_per_step": round(1e3 * tm / steps, 3),
+                       "dtype": "f32" if kw["precision"] == "fp32" else "bf16", "steps": steps, "final_loss": round(ls, 4)}
+                if reps > 1:
+                    out["ms_per_step_repetitions"] = [round(1e3 * t / steps, 3) for t in ts]
+                    out["statistic"] = "median of %d repetitions" % reps
+                return out
             if args.precision != "fp32":
                 # the parity mode (fp32 storage + fp32 MFMA: the mode in which logits / CTC loss meet the 1e-3 tolerance and arg-max is
                 # bit-exact against the oracle, tests/test_gpu_model.py) timed in the same run on the same workload
-                e32 = Engine(B, imgh=args.imgh, max_len=args.max_len, dropout=True, precision="fp32", gru=args.gru)
-                e32.set_params(initial_parameters(e32.layout, e32.cfg.units, args.gru, seed=1))
-                k32 = max(3, min(args.steps, 10))
-                dt32, l32 = timed_steps(e32, mk(B, 0), Adam(lr=1e-4, beta_1=0.5, beta_2=0.999, clipnorm=5), k32, 2)
-                res["parity_mode"] = {"value": round(B * k32 / dt32, 1), "unit": "images/sec", "ms_per_step": round(1e3 * dt32 / k32, 3), "dtype": "f32",
-                                      "steps": k32, "final_loss": round(l32, 4),
-                                      "note": "fp32 tensors + fp32 MFMA: the mode the 1e-3 logit / CTC-loss parity and bit-exact arg-max are asserted in; "
-                                              "the headline bf16 line is outside that tolerance (bf16 conv-stack tensors: softmax within 2e-3, loss 2e-3 "
-                                              "relative of the fp64 oracle)"}
-                del e32
-                torch.cuda.empty_cache()
+                res["parity_mode"] = dict(leg(B, max(3, min(args.steps, 10)), 2, precision="fp32"),
+                                          note="fp32 tensors + fp32 MFMA: the mode the 1e-3 logit / CTC-loss parity and bit-exact arg-max are asserted in; "
+                                               "the headline bf16 line is outside that tolerance (bf16 conv-stack tensors: softmax within 2e-3, loss 2e-3 "
+                                               "relative of the fp64 oracle)")
             if B != 64:
                 # the metric's literal batch size (BASELINE.json: "100x32 bs64"), same precision as the headline
-                e64 = Engine(64, imgh=args.imgh, max_len=args.max_len, dropout=True, precision=args.precision, gru=args.gru)
-                e64.set_params(initial_parameters(e64.layout, e64.cfg.units, args.gru, seed=1))
-                k64 = max(5, args.steps)
-                b64, o64 = mk(64, 0), Adam(lr=1e-4, beta_1=0.5, beta_2=0.999, clipnorm=5)
-                # three repetitions, the fastest reported (this short run right after the big engines has been seen at twice its
-                # stand-alone time in one repetition out of several; scripts/dbg_bs64.py: 3.73 ms/step stand-alone, six repetitions alike)
-                reps = [timed_steps(e64, b64, o64, k64, 3 if r == 0 else 0, it0=r * (k64 + 3))[0] for r in range(3)]
-                dt64 = min(reps)
-                res["bs64"] = {"batch": 64, "value": round(64 * k64 / dt64, 1), "unit": "images/sec", "ms_per_step": round(1e3 * dt64 / k64, 3),
-                               "dtype": res["dtype"], "steps": k64, "ms_per_step_repetitions": [round(1e3 * t / k64, 3) for t in reps]}
-                del e64
-                torch.cuda.empty_cache()
+                res["bs64"] = leg(64, max(5, args.steps), 3, reps=3)
+            if args.imgh == 100 and not args.gru and args.precision == "bf16s":
+                # BASELINE configs[2]: the IAM shape (200x32 variable-width text, max_len 21, T = 102), STN on
+                res["iam"] = dict(leg(B, max(3, min(args.steps, 10)), 2, imgh=200, max_len=21),
+                                  workload="BASELINE configs[2]: 200x32x1 variable-width text lines (random 40..200-row prefix, modal-grey padding), "
+                                           "max_len 21, T = 102, STN on, batch %d" % B)
+                # the cell the reference's train.py really builds (train.py:119 shadows :109; utils.py:80-82): BiGRU, reset_after=False
+                res["gru"] = dict(leg(B, max(3, min(args.steps, 10)), 2, gru=True),
+                                  workload="configs[1] with the GRU recurrence the reference trains (train.py:119, utils.py:80-82)")
+                # BASELINE configs[4]: predict path (predict.py:166-171), batch 1024, beam width 10
+                res["predict"] = predict_leg(1024, iters=20, precision=args.precision, cpu_sample=0 if args.no_cpu_baseline else 32)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

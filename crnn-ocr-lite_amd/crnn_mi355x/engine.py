@@ -65,6 +65,9 @@ class Engine:
         if share is not None:
             if share.n_total != self.n_total or share.bn_total != self.bn_total or list(share.layout.items()) != list(self.layout.items()):
                 raise ValueError("Engine(share=...) needs the same architecture")
+            if share.device != self.device or share.precision != precision:
+                raise ValueError("Engine(share=...) needs the same device and precision (%s/%s vs %s/%s): the parameter, gradient and "
+                                 "optimizer-state tensors are shared" % (share.device, share.precision, self.device, precision))
             self.params, self.grads, self.bn_mean, self.bn_var = share.params, share.grads, share.bn_mean, share.bn_var
         else:
             self.params = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
@@ -72,7 +75,14 @@ class Engine:
             self.bn_mean = torch.zeros(self.bn_total, dtype=torch.float32, device=dev)
             self.bn_var = torch.ones(self.bn_total, dtype=torch.float32, device=dev)
         self.ws_bytes = nbytes
-        self.ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+        # zeroed once: the sticky give-up counter of the persistent recurrences lives in it (include/crnn_mi355x.h, "rnnx") and no
+        # launch ever resets that word
+        self.ws = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+        self._rnn_giveups = None          # 1-element int32 view of that counter (None: this configuration runs the per-step kernels)
+        self._rnn_giveups_seen = 0
+        off, cnt = ctypes.c_long(), ctypes.c_long()
+        if self.lib.crnn_ws_tensor(self._c, b"rnnx", ctypes.byref(off), ctypes.byref(cnt)) == 0:
+            self._rnn_giveups = self.ws[off.value:off.value + 1].view(torch.int32)
         self.y_pred = torch.empty((batch, self.T, num_classes), dtype=torch.float32, device=dev)
         self.loss = torch.zeros(batch, dtype=torch.float32, device=dev)
         self.norm = torch.zeros(2, dtype=torch.float32, device=dev)
@@ -253,6 +263,31 @@ class Engine:
         opt.apply(self, iteration)
         self.bn_update()
         return loss
+
+    # ---- persistent-recurrence status ------------------------------------------------------------------------
+    def loss_and_status(self):
+        """Device tensor [mean CTC cost of the last step, give-up counter]: ONE small D2H copy serves the loss read-back of the
+        training loop and the status check (`raise_if_rnn_gave_up(values[1])`), no extra synchronisation."""
+        st = self._rnn_giveups.to(torch.float32) if self._rnn_giveups is not None else torch.zeros(1, device=self.device)
+        return torch.cat([self.loss.mean().reshape(1), st])
+
+    def raise_if_rnn_gave_up(self, count):
+        """count: current value of the sticky give-up counter (from loss_and_status / check_rnn_status).  A persistent recurrence
+        whose cluster was not co-resident (CUs held by another process / stream, a CU-masked device) stops waiting after a bounded
+        spin and free-runs on garbage; that must never pass silently."""
+        count = int(count)
+        if count != self._rnn_giveups_seen:
+            new = count - self._rnn_giveups_seen
+            self._rnn_giveups_seen = count
+            raise native.CrnnError("persistent LSTM/GRU recurrence gave up waiting for its workgroup cluster %d time(s): the launch was not "
+                                   "co-resident on the GPU, so the results of this step (and weights updated from it) are invalid.  Free the GPU "
+                                   "of other work, or run the per-step recurrence kernels: Engine(flags=native.FLAG_RNN_STEP_KERNELS) / "
+                                   "CRNN_FLAGS=1" % new)
+
+    def check_rnn_status(self):
+        """Synchronising check (4-byte D2H) for call sites that already wait for the device (predict, validation)."""
+        if self._rnn_giveups is not None:
+            self.raise_if_rnn_gave_up(int(self._rnn_giveups.item()))
 
     # ---- decoding -----------------------------------------------------------------------------------------
     def greedy_decode(self, y=None, input_length=None):

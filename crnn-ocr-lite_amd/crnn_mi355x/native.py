@@ -27,6 +27,8 @@ FLAG_GEMM_TILE_KERNELS = 2     # CRNN_FLAG_GEMM_TILE_KERNELS
 FLAG_NO_DW_BN_FUSION = 8       # CRNN_FLAG_NO_DW_BN_FUSION
 FLAG_NO_DW_BWD_FUSION = 16     # CRNN_FLAG_NO_DW_BWD_FUSION
 FLAG_DW_TILE_KERNEL = 32       # CRNN_FLAG_DW_TILE_KERNEL
+FLAG_RNN_LINEAR_CLUSTERS = 64  # CRNN_FLAG_RNN_LINEAR_CLUSTERS
+RNN_XCD_LOCAL = 0x100          # CRNN_RNN_XCD_LOCAL (or-ed into the uw argument of crnn_lstm_*_persist)
 
 
 _CTYPE = [("crnn_stream_t", ctypes.c_void_p), ("size_t", ctypes.c_size_t), ("uint64_t", ctypes.c_uint64),
@@ -59,18 +61,24 @@ def parse_header(path=HEADER):
 
 def build(verbose=False):
     """Compile every HIP source for gfx950 into crnn-ocr-lite_amd/libcrnn_mi355x.so (in-tree)."""
-    objs = []
+    objs, jobs = [], []
     inc = os.path.join(REPO_ROOT, "include")
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         deps = [src, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "rnn_cell.h"), os.path.join(CSRC, "gemm_bf16.inc"), HEADER]
         if not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps):
-            cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", inc, "-c", src, "-o", obj]
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.check_call(cmd)
+            jobs.append(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", inc, "-c", src, "-o", obj])
         objs.append(obj)
+    if jobs:   # translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            list(ex.map(run, jobs))
     if not os.path.exists(LIB_PATH) or any(os.path.getmtime(o) > os.path.getmtime(LIB_PATH) for o in objs):
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH])
     return LIB_PATH

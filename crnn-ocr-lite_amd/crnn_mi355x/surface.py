@@ -137,8 +137,7 @@ class Model:
             eng = Engine(batch, c["shape"][0], c["shape"][1], c["num_classes"], c["max_string_len"], c["time_dense_size"], c["n_units"],
                          gru=c["GRU"], stn=True, dropout=dropout, precision=os.environ.get("CRNN_PRECISION", "fp32"), share=base)
             if base is None:
-                eng.set_params(st["params"], st["bn"])
-                self._dp_broadcast(eng)
+                eng.set_params(st["params"], st["bn"])     # no collective here: see sync_replicas()
             engines[batch] = eng
             while len(engines) > 3:
                 engines.popitem(last=False)
@@ -147,12 +146,19 @@ class Model:
         st["engine"] = eng
         return eng
 
-    def _dp_broadcast(self, eng):
-        """Data parallel: every rank adopts rank 0's weights / BN statistics (a fresh model is initialised from OS entropy
-        per process; crnn_mi355x.parallel.broadcast_state)."""
+    def sync_replicas(self, batch=None):
+        """Data parallel, a COLLECTIVE (every rank must call it): all ranks adopt rank 0's weights / BatchNorm moving statistics
+        (a fresh model is initialised from OS entropy per process; crnn_mi355x.parallel.broadcast_state).  fit_generator calls it once
+        when it starts; nothing else in this class issues a broadcast -- building an engine lazily (the first predict / test / train
+        call) and set_weights / load_weights are rank-local, so rank-conditional user code (`if rank == 0: model.predict_on_batch(...)`,
+        `if rank == 0: model.load_weights(...)`) cannot deadlock the other ranks.  After a rank-local load_weights, call this (or
+        fit_generator) on every rank to make the replicas identical again."""
         dist, world = self._dist()
         if world > 1:
             from .parallel import broadcast_state
+            eng = self._state.get("engine")
+            if eng is None:
+                eng = self._engine(batch or 1)
             broadcast_state(eng, dist, world)
 
     def _pull(self):
@@ -165,8 +171,7 @@ class Model:
     def _push(self):
         eng = self._state["engine"]
         if eng is not None:
-            eng.set_params(self._state["params"], self._state["bn"])
-            self._dp_broadcast(eng)
+            eng.set_params(self._state["params"], self._state["bn"])     # rank-local (see sync_replicas)
 
     # ---- Keras weight list (SURVEY A.9 order, 94 tensors for either cell) ---------------------------------------
     def _weight_index(self):
@@ -394,12 +399,19 @@ class Model:
         if world > 1:
             from .parallel import GradAllReduce
             allreduce = GradAllReduce(eng, dist, world)
-        loss = eng.train_step(x, labels, input_length, label_length, self.optimizer, self._iterations, allreduce=allreduce)
+        eng.train_step(x, labels, input_length, label_length, self.optimizer, self._iterations, allreduce=allreduce)
         self._iterations += 1
-        return loss.mean()
+        return eng.loss_and_status(), eng       # [batch-mean loss, give-up counter of the persistent recurrences]
+
+    @staticmethod
+    def _read_loss(ls_dev, eng):
+        """The one host synchronisation of a step: loss and recurrence status in one D2H copy; raises if a recurrence gave up."""
+        loss, giveups = ls_dev.tolist()
+        eng.raise_if_rnn_gave_up(giveups)
+        return float(loss)
 
     def train_on_batch(self, x, labels, input_length, label_length):
-        return float(self._train_on_batch_async(x, labels, input_length, label_length).item())
+        return self._read_loss(*self._train_on_batch_async(x, labels, input_length, label_length))
 
     def test_on_batch(self, x, labels, input_length, label_length):
         """learning_phase=0 forward + CTC cost (validation loss)."""
@@ -407,15 +419,19 @@ class Model:
         from .engine import _ptr, _stream
         eng = self._engine(len(x))
         y = eng.forward(x, train=False)
-        lab, il, ll = eng._as_i32(labels), eng._as_i32(input_length), eng._as_i32(label_length)
+        eng._ctc_inputs(labels, input_length, label_length)      # host-side validation: the CTC kernel indexes LDS with the label ids
         scratch = eng.ws_tensor("dlogits")
-        native.check(eng.lib.crnn_ctc_loss_grad(_ptr(y), _ptr(lab), _ptr(il), _ptr(ll), _ptr(eng.loss), _ptr(scratch), eng.B, eng.T, eng.C,
-                                                self.config["max_string_len"], 2, 0.0, _stream()), "ctc")
-        return float(eng.loss.mean().item())
+        native.check(eng.lib.crnn_ctc_loss_grad(_ptr(y), _ptr(eng._lab), _ptr(eng._il), _ptr(eng._ll), _ptr(eng.loss), _ptr(scratch), eng.B, eng.T,
+                                                eng.C, self.config["max_string_len"], 2, 0.0, _stream()), "ctc")
+        loss, giveups = eng.loss_and_status().tolist()
+        eng.raise_if_rnn_gave_up(giveups)
+        return float(loss)
 
     def predict_on_batch(self, x):
         eng = self._engine(len(x))
-        return eng.forward(x, train=False).cpu().numpy()
+        y = eng.forward(x, train=False).cpu().numpy()
+        eng.check_rnn_status()
+        return y
 
     def fit_generator(self, generator, steps_per_epoch=None, epochs=1, validation_data=None, validation_steps=None,
                       shuffle=False, verbose=1, callbacks=None, **kwargs):
@@ -426,6 +442,11 @@ class Model:
             cb.on_train_begin({})
         self.stop_training = False
         dist, world = self._dist()
+        if world > 1:
+            # the documented collective point: replicas start from rank 0's weights (engine for the first batch's size built here)
+            if self._prefetched is None or self._prefetched[0] is not generator:
+                self._prefetched = (generator, self._snapshot(next(generator)))
+            self.sync_replicas(len(self._prefetched[1][0]))
         for epoch in range(epochs):
             t0 = time.time()
             run, nimg = 0.0, 0
@@ -435,14 +456,15 @@ class Model:
                 if self._prefetched is None or self._prefetched[0] is not generator:   # a batch drawn ahead belongs to ITS generator
                     self._prefetched = (generator, self._snapshot(next(generator)))
                 x, lab, il, ll = self._prefetched[1]
-                loss_dev = self._train_on_batch_async(x, lab, il, ll)
+                ls_dev, eng = self._train_on_batch_async(x, lab, il, ll)
                 self._prefetched = (generator, self._snapshot(next(generator)))
                 if world > 1:
                     # every rank logs (and EarlyStoppingIter monitors) the GLOBAL batch-mean loss, so all ranks take the same
-                    # stop / restore decisions and keep issuing the same collectives
-                    dist.all_reduce(loss_dev, op=dist.ReduceOp.SUM)
-                    loss_dev = loss_dev / world
-                loss = float(loss_dev.item())
+                    # stop / restore decisions and keep issuing the same collectives; the give-up counters are summed, so a
+                    # recurrence that gave up on one rank stops every rank
+                    dist.all_reduce(ls_dev, op=dist.ReduceOp.SUM)
+                    ls_dev[0] /= world
+                loss = self._read_loss(ls_dev, eng)
                 run += loss; nimg += len(x)
                 logs = {"loss": loss, "batch": step, "size": len(x)}
                 for cb in callbacks:

@@ -26,6 +26,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Kernels with more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once PER DEVICE.  The latch is a
+// per-call-site bit mask over device ordinals (atomic: launchers may be called from several host threads, one per GPU); it caches a
+// device property, it is not state of the computation.
+#include <atomic>
+static inline int crnn_lds_attr(const void* fn, int bytes, std::atomic<unsigned long long>& latch) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (latch.load(std::memory_order_acquire) & bit) return 0;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return (int)e;
+  latch.fetch_or(bit, std::memory_order_release);
+  return 0;
+}
+#define CRNN_LDS_ATTR(fn, bytes)                                              \
+  do {                                                                        \
+    static std::atomic<unsigned long long> latch__{0};                        \
+    CRNN_TRY(crnn_lds_attr((const void*)(fn), (bytes), latch__));             \
+  } while (0)
+
 // Tuning knobs of the micro-benchmark / ablation builds (scripts/, -DCRNN_EXPERIMENT_HOOKS): an environment variable overrides
 // a default.  The product library is built WITHOUT the macro: the knob is the constant, nothing reads the environment and
 // there is no static state (include/crnn_mi355x.h: "no global mutable state").

@@ -371,12 +371,7 @@ extern "C" int crnn_dwconv3x3_bwd_stream(const void* d, const void* da, const fl
   p.d = (const unsigned char*)d; p.da = (const unsigned char*)da; p.xin = (const unsigned char*)xin; p.dx = (unsigned char*)dx;
   p.bnstate = bnstate; p.coef = coef; p.k = k; p.partials = scratch;
   p.H = H; p.W = W; p.C = C; p.HB = g.HB; p.nwgb = g.nwgb; p.nsplit = g.nsplit; p.cols = g.cols; p.cppw = g.cppw; p.rowbytes = W * C * 2;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)dw_bwd_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
+  CRNN_LDS_ATTR(dw_bwd_stream_kernel, kLds);
   hipLaunchKernelGGL(dw_bwd_stream_kernel, dim3(B * g.nwgb * g.nsplit), dim3(704), kLds, stream, p);
   CRNN_LAUNCH_CHECK();
   return crnn_partials_sum(scratch, B * g.nwgb, 9 * C, dk, 1.f, stream);

@@ -258,12 +258,7 @@ constexpr int kDwsD = CRNN_DWS_D;     // rows in flight per workgroup (2..7 meas
 template <bool EPI>
 int dws_launch(const DwsParams& p, const DwsGeom& g, int B, hipStream_t stream) {
   constexpr int lds = (kDwsD + 1) * 9 * 1024 + 64;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)dw_fwd_stream_kernel<9, kDwsD, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
+  CRNN_LDS_ATTR((dw_fwd_stream_kernel<9, kDwsD, EPI>), lds);
   hipLaunchKernelGGL((dw_fwd_stream_kernel<9, kDwsD, EPI>), dim3(B * g.nwgb), dim3((g.ncw + 1) * 64), lds, stream, p);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;

@@ -305,13 +305,8 @@ int wg_launch(WgParams& p, long M, float* out, int ldc, float* scratch, size_t s
 #endif
   if ((size_t)p.nsplit * p.K * p.N * sizeof(float) > scratch_bytes) return CRNN_ERR_UNSUPPORTED;
   const int lds = kRing * 2 * kOp;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)pw_wgrad_stream_kernel<4, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pw_wgrad_stream_kernel<8, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
+  CRNN_LDS_ATTR((pw_wgrad_stream_kernel<4, F32>), lds);
+  CRNN_LDS_ATTR((pw_wgrad_stream_kernel<8, F32>), lds);
   if (crnn_knob("CRNN_WG_NIO", 8) == 4) hipLaunchKernelGGL((pw_wgrad_stream_kernel<4, F32>), dim3(grid), dim3(512), lds, stream, p);
   else hipLaunchKernelGGL((pw_wgrad_stream_kernel<8, F32>), dim3(grid), dim3(768), lds, stream, p);
   CRNN_LAUNCH_CHECK();
@@ -490,13 +485,8 @@ extern "C" int crnn_gemm_nt_f32_stream_bias(const float* A0, const void* W0, con
   p.A[0] = A0; p.A[1] = A1 ? A1 : A0; p.W[0] = (const bf16_t*)W0; p.W[1] = (const bf16_t*)(W1 ? W1 : W0); p.Y = Y; p.bias = bias;
   p.M = M; p.N = slab; p.K = K; p.lda = lda; p.ldw = ldw; p.ldy = ldy; p.npairs = A1 ? 2 : 1;
   const int lds = kNtsRing * (64 * 128 + slab * 128);
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_f32_stream_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kNtsRing * (64 * 128 + 128 * 128));
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_f32_stream_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kNtsRing * (64 * 128 + 256 * 128));
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
+  CRNN_LDS_ATTR(gemm_nt_f32_stream_kernel<1>, kNtsRing * (64 * 128 + 128 * 128));
+  CRNN_LDS_ATTR(gemm_nt_f32_stream_kernel<2>, kNtsRing * (64 * 128 + 256 * 128));
   if (slab == 128) hipLaunchKernelGGL(gemm_nt_f32_stream_kernel<1>, dim3(M / 64, N / slab), dim3(768), lds, stream, p);
   else hipLaunchKernelGGL(gemm_nt_f32_stream_kernel<2>, dim3(M / 64, N / slab), dim3(768), lds, stream, p);
   CRNN_LAUNCH_CHECK();

@@ -440,12 +440,7 @@ __global__ __launch_bounds__(512) void gemm_wres_fwd_kernel(WresFwdParams p) {
 template <int KCH, int NLW, bool EPI = false>
 int launch_wres(const WresParams& p, int grid, hipStream_t stream) {
   const int lds = (EPI ? kR - 1 : kR) * kStage + 2 * kOut + (EPI ? 1024 : 0);
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_wres_kernel<KCH, NLW, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
+  CRNN_LDS_ATTR((gemm_wres_kernel<KCH, NLW, EPI>), lds);
   hipLaunchKernelGGL((gemm_wres_kernel<KCH, NLW, EPI>), dim3(grid), dim3(384 + 64 * NLW), lds, stream, p);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
@@ -530,12 +525,7 @@ template <int KCH, int CB, int PB>
 int launch_wres_fwd(const WresFwdParams& p, int grid, hipStream_t stream) {
   constexpr int fixed = kRf * PB * 32 * 128 + 2 * PB * 32 * 256 * CB;
   const int lds = fixed + 2 * p.K * (int)sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_wres_fwd_kernel<KCH, CB, PB>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed + 2 * 512 * (int)sizeof(float));
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
+  CRNN_LDS_ATTR((gemm_wres_fwd_kernel<KCH, CB, PB>), fixed + 2 * 512 * (int)sizeof(float));
   hipLaunchKernelGGL((gemm_wres_fwd_kernel<KCH, CB, PB>), dim3(grid), dim3(512), lds, stream, p);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;

@@ -102,6 +102,9 @@ bool rnn_persist(const crnn_config* c) {
   return !c->gru && !(c->flags & CRNN_FLAG_RNN_STEP_KERNELS) && crnn_lstm_persist_supported(c->units, rnn_dtu(c)) == 0;
 }
 
+// uw argument of the persistent recurrences: automatic workgroup size, XCD-local clusters unless the linear map is asked for
+int rnn_uw(const crnn_config* c) { return (c->flags & CRNN_FLAG_RNN_LINEAR_CLUSTERS) ? 0 : CRNN_RNN_XCD_LOCAL; }
+
 Plan make_plan(const crnn_config* c) {
   Dims d = make_dims(c);
   Plan P;
@@ -482,7 +485,7 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
                              c.w("cs1f"), c.w("cs1b"), T, B, u, dtu, stream));
   else if (persist)
     CRNN_TRY(crnn_lstm_fwd_persist(c.w("xw1f"), c.w("xw1b"), c.w("ut1f"), c.w("ut1b"), c.w("h1f"), c.w("h1b"), u, c.w("cs1f"), c.w("cs1b"),
-                                   c.w("gt1f"), c.w("gt1b"), T, B, u, dtu, c.w("rnnx"), xbytes, 0, 0, stream));
+                                   c.w("gt1f"), c.w("gt1b"), T, B, u, dtu, c.w("rnnx"), xbytes, 0, rnn_uw(cfg), stream));
   else
     CRNN_TRY(crnn_lstm_fwd_ex(c.w("xw1f"), c.w("xw1b"), c.w("ut1f"), c.w("ut1b"), c.w("h1f"), c.w("h1b"), u, c.w("cs1f"), c.w("cs1b"),
                               c.w("gt1f"), c.w("gt1b"), T, B, u, dtu, stream));
@@ -494,7 +497,7 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
                              c.w("cs2f"), c.w("cs2b"), T, B, u, dtu, stream));
   else if (persist)
     CRNN_TRY(crnn_lstm_fwd_persist(c.w("xw2f"), c.w("xw2b"), c.w("ut2f"), c.w("ut2b"), c.w("h2"), c.w("h2") + u, 2 * u, c.w("cs2f"), c.w("cs2b"),
-                                   c.w("gt2f"), c.w("gt2b"), T, B, u, dtu, c.w("rnnx"), xbytes, 0, 0, stream));    // merge_mode='concat'
+                                   c.w("gt2f"), c.w("gt2b"), T, B, u, dtu, c.w("rnnx"), xbytes, 0, rnn_uw(cfg), stream));    // merge_mode='concat'
   else
     CRNN_TRY(crnn_lstm_fwd_ex(c.w("xw2f"), c.w("xw2b"), c.w("ut2f"), c.w("ut2b"), c.w("h2"), c.w("h2") + u, 2 * u, c.w("cs2f"), c.w("cs2b"),
                               c.w("gt2f"), c.w("gt2b"), T, B, u, dtu, stream));    // merge_mode='concat'
@@ -531,7 +534,7 @@ static int rnn_bwd_chain(const Ctx& c, int layer, const float* hf, const float* 
                            ldo, dzf, dzb, c.w("dcf"), c.w("dcb"), c.w("dhpf"), c.w("dhpb"), T, B, u, dtu, c.s);
   if (rnn_persist(c.cfg) && !(((uintptr_t)uf | (uintptr_t)ub) & 15))
     return crnn_lstm_bwd_persist(uf, ub, c.w("cs" + l + "f"), c.w("cs" + l + "b"), c.w("gt" + l + "f"), c.w("gt" + l + "b"), doutf, doutb, ldo,
-                                 dzf, dzb, T, B, u, dtu, c.w("rnnx"), crnn_lstm_persist_xbuf_bytes(T, B, u, dtu), 0, 0, c.s);
+                                 dzf, dzb, T, B, u, dtu, c.w("rnnx"), crnn_lstm_persist_xbuf_bytes(T, B, u, dtu), 0, rnn_uw(c.cfg), c.s);
   return crnn_lstm_bwd_ex(uf, ub, c.w("cs" + l + "f"), c.w("cs" + l + "b"), c.w("gt" + l + "f"),
                           c.w("gt" + l + "b"), doutf, doutb, ldo, dzf, dzb, c.w("dcf"), c.w("dcb"), T, B, u, dtu, c.s);
 }

@@ -22,8 +22,11 @@
 // (s+2) % 4 after publishing step s, and drains its stores (s_waitcnt vmcnt(0)) before it publishes step s+1: whoever
 // later sees its step s+1 data -- a precondition for polling slot (s+2) % 4 -- can no longer see the stale step s-2 there.
 // Results do not depend on workgroup placement or dispatch order; a cluster's workgroups have consecutive
-// block ids and the whole grid is sized to be co-resident.  Every spin is bounded: on give-up bit 0 of the status word
-// xbuf[0] (all ones after a clean launch) is cleared and the chain free-runs (wrong numbers, no hang).
+// block ids (or, with the XCD-local map, block ids congruent modulo 8: one XCD, one L2) and the whole grid is sized to be
+// co-resident.  Every spin is bounded: on give-up the chain free-runs (wrong numbers, no hang) and says so twice in the
+// first kStatusBytes of xbuf: the unsigned at byte 0 is a STICKY give-up counter that no launch ever resets (the caller
+// zeroes it once when it allocates xbuf and compares it with the value it saw last -- Engine.check_rnn_status), the
+// unsigned at byte 16 is the per-launch status word (all ones after a clean launch, bit 0 cleared on give-up).
 //
 // Numerics: bit-identical to the per-step kernels of rnn.hip in both modes -- the K split into four quarters, the
 // k order inside a quarter, the ((q0+q1)+(q2+q3)) + x combination and the cell epilogue are the same; in the bf16
@@ -42,10 +45,25 @@ constexpr size_t kStatusBytes = 65536;        // trace build: [64..) = per-step 
 #define RNN_TRACE(slot) do { if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 + 3)) \
     reinterpret_cast<unsigned long long*>(xbuf + 64)[((blockIdx.x != 0) * 128 + TRACE_STEP) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
-constexpr size_t kStatusBytes = 256;          // [0] = give-up flags; the exchange tiles follow
+constexpr size_t kStatusBytes = 256;          // byte 0: sticky give-up counter, byte 16: per-launch status; the exchange tiles follow
 #define RNN_TRACE(slot) do {} while (0)
 #endif
 constexpr unsigned kSpinLimit = 1u << 21;
+constexpr size_t kLaunchStatusOff = 16;       // the fill of every launch starts here (the counter in front of it survives)
+// cache policy of the exchange (aux bits of the buffer instructions: 1 = sc0, 16 = sc1).  Default: write-through stores and
+// L1-bypassing loads at device scope (works for any placement).  Other values exist for scripts/lstm_xcd_bench.py only.
+#ifndef CRNN_RNN_POL
+#define CRNN_RNN_POL 0
+#endif
+#if CRNN_RNN_POL == 0
+constexpr int kAuxSt = 16, kAuxLd = 16;
+#elif CRNN_RNN_POL == 1
+constexpr int kAuxSt = 0, kAuxLd = 16;
+#elif CRNN_RNN_POL == 2
+constexpr int kAuxSt = 1, kAuxLd = 1;
+#else
+constexpr int kAuxSt = 17, kAuxLd = 17;
+#endif
 constexpr int kRing = 4;                      // step slots of the exchange ring
 
 template <bool WBF> struct XE { typedef float type; };
@@ -74,13 +92,16 @@ __device__ __forceinline__ void gather_tile(const void* tile, int tid, unsigned*
       for (int i = 0; i < GRP; ++i) {
         const int idx = tid + NT * (i0 + i);
         if (i0 + i < NLD && idx < NCH) {
-          v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, idx * 16, 0, 16);   // aux 16 = sc1: served past the L1
+          v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, idx * 16, 0, kAuxLd);   // aux 16 = sc1: served past the L1
           ok &= (v[i].x != kSentinel) & (v[i].y != kSentinel) & (v[i].z != kSentinel) & (v[i].w != kSentinel);
         }
       }
       if (__all(ok) || dead) break;
       if (++spins > kSpinLimit) {
-        if ((tid & 63) == 0) atomicAnd(status, ~1u);     // the status word starts as all ones (one fill covers it and the ring)
+        if ((tid & 63) == 0) {
+          atomicAnd(status + kLaunchStatusOff / 4, ~1u);   // the per-launch word starts as all ones (one fill covers it and the ring)
+          atomicAdd(status, 1u);                           // sticky: never reset by a launch
+        }
         dead = true;
         break;
       }
@@ -92,6 +113,16 @@ __device__ __forceinline__ void gather_tile(const void* tile, int tid, unsigned*
       if (i0 + i < NLD && idx < NCH) sink(idx, v[i]);
     }
   }
+}
+
+// Workgroup -> (cluster, member).  Linear: a cluster's members have consecutive block ids, which the round-robin dispatch deals over
+// all 8 XCDs.  XCD-local (xmap): workgroup id % 8 is its XCD, so the members of a cluster are the ids congruent modulo 8 inside a
+// group of 8*NSW ids -- the whole all-gather of a chain then stays inside one XCD's L2 domain.  Needs (#clusters % 8 == 0); the
+// results do not depend on the map.
+__device__ __forceinline__ int cluster_block_id(int id, int nsw, int xmap) {
+  if (!xmap) return id;
+  const int xcd = id & 7, loc = id >> 3;
+  return ((loc / nsw) * 8 + xcd) * nsw + loc % nsw;
 }
 
 struct FwdDir {
@@ -117,7 +148,7 @@ struct BwdDir {
 // forward
 // ---------------------------------------------------------------------------------------------------------------
 template <bool WBF, int MT, int U, int UW>
-__global__ __launch_bounds__(256 * UW) void lstm_fwd_persist_kernel(FwdDir d0, FwdDir d1, int T, int B, int b_lo, int b_cnt, unsigned char* xbuf) {
+__global__ __launch_bounds__(256 * UW) void lstm_fwd_persist_kernel(FwdDir d0, FwdDir d1, int T, int B, int b_lo, int b_cnt, unsigned char* xbuf, int xmap) {
   typedef typename XE<WBF>::type E;
   constexpr int ES = sizeof(E), BT = 16 * MT, NSW = U / (16 * UW), NT = 256 * UW;
   constexpr int LDA = U + 16 / ES;                       // +16 bytes per row
@@ -129,7 +160,8 @@ __global__ __launch_bounds__(256 * UW) void lstm_fwd_persist_kernel(FwdDir d0, F
   __shared__ __attribute__((aligned(16))) E hout[UW][BT * 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
   const int gate = wave & 3, ug = wave >> 2;
-  const int sl = blockIdx.x % NSW, cl = blockIdx.x / NSW, dir = cl & 1, bt = cl >> 1;
+  const int bid = cluster_block_id(blockIdx.x, NSW, xmap);
+  const int sl = bid % NSW, cl = bid / NSW, dir = cl & 1, bt = cl >> 1;
   const int nbt = (b_cnt + BT - 1) / BT;
   const FwdDir d = dir ? d1 : d0;
   const int sg = sl * UW + ug;                           // this wave's unit group within the layer
@@ -231,7 +263,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_fwd_persist_kernel(FwdDir d0, F
         const int part = lane % CPR, rl = (lane / CPR) % 4, m = lane / (4 * CPR);
         const int eoff = (16 * m + 4 * gate + rl) * 16 + part * (16 / ES);
         const u32x4 v = *reinterpret_cast<const u32x4*>(&hout[ug][eoff]);
-        __builtin_amdgcn_raw_buffer_store_b128(v, rs, eoff * ES, 0, 16);       // sc1
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, eoff * ES, 0, kAuxSt);   // sc1
       }
     }
     RNN_TRACE(4);
@@ -249,7 +281,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_fwd_persist_kernel(FwdDir d0, F
       E* stale = xdata + (((long)dir * kRing + ((s + 2) & (kRing - 1))) * nbt + bt) * tile_elems + (long)sg * BT * 16;
       const int part = lane % CPR, rl = (lane / CPR) % 4, m = lane / (4 * CPR);
       const int eoff = (16 * m + 4 * gate + rl) * 16 + part * (16 / ES);
-      __builtin_amdgcn_raw_buffer_store_b128((u32x4){kSentinel, kSentinel, kSentinel, kSentinel}, make_rsrc(stale, BT * 16 * ES), eoff * ES, 0, 16);
+      __builtin_amdgcn_raw_buffer_store_b128((u32x4){kSentinel, kSentinel, kSentinel, kSentinel}, make_rsrc(stale, BT * 16 * ES), eoff * ES, 0, kAuxSt);
     }
 #undef TRACE_STEP
   }
@@ -259,7 +291,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_fwd_persist_kernel(FwdDir d0, F
 // backward (BPTT): dh_{t}[b, j'] = sum_k dz_{t_next}[b, k] U[j', k] + dout_t[b, j'], then the gate gradients dz_t
 // ---------------------------------------------------------------------------------------------------------------
 template <bool WBF, int MT, int U, int UW>
-__global__ __launch_bounds__(256 * UW) void lstm_bwd_persist_kernel(BwdDir d0, BwdDir d1, int T, int B, int b_lo, int b_cnt, unsigned char* xbuf) {
+__global__ __launch_bounds__(256 * UW) void lstm_bwd_persist_kernel(BwdDir d0, BwdDir d1, int T, int B, int b_lo, int b_cnt, unsigned char* xbuf, int xmap) {
   typedef typename XE<WBF>::type E;
   constexpr int ES = sizeof(E), BT = 16 * MT, NSW = U / (16 * UW), NT = 256 * UW, K = 4 * U;
   constexpr int LDA = K + 16 / ES;
@@ -271,7 +303,8 @@ __global__ __launch_bounds__(256 * UW) void lstm_bwd_persist_kernel(BwdDir d0, B
   __shared__ __attribute__((aligned(16))) E zout[UW][BT * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
   const int kq = wave & 3, ug = wave >> 2;
-  const int sl = blockIdx.x % NSW, cl = blockIdx.x / NSW, dir = cl & 1, bt = cl >> 1;
+  const int bid = cluster_block_id(blockIdx.x, NSW, xmap);
+  const int sl = bid % NSW, cl = bid / NSW, dir = cl & 1, bt = cl >> 1;
   const int nbt = (b_cnt + BT - 1) / BT;
   const BwdDir d = dir ? d1 : d0;
   const int sg = sl * UW + ug;
@@ -374,7 +407,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_bwd_persist_kernel(BwdDir d0, B
           const int part = id % CPR, rl = (id / CPR) % 4, m = id / (4 * CPR);
           const int eoff = (16 * m + 4 * kq + rl) * 64 + part * (16 / ES);
           const u32x4 v = *reinterpret_cast<const u32x4*>(&zout[ug][eoff]);
-          __builtin_amdgcn_raw_buffer_store_b128(v, rs, eoff * ES, 0, 16);
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs, eoff * ES, 0, kAuxSt);
         }
       }
     }
@@ -396,7 +429,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_bwd_persist_kernel(BwdDir d0, B
         if (id < NPUB) {
           const int part = id % CPR, rl = (id / CPR) % 4, m = id / (4 * CPR);
           const int eoff = (16 * m + 4 * kq + rl) * 64 + part * (16 / ES);
-          __builtin_amdgcn_raw_buffer_store_b128((u32x4){kSentinel, kSentinel, kSentinel, kSentinel}, rp, eoff * ES, 0, 16);
+          __builtin_amdgcn_raw_buffer_store_b128((u32x4){kSentinel, kSentinel, kSentinel, kSentinel}, rp, eoff * ES, 0, kAuxSt);
         }
       }
     }
@@ -460,13 +493,14 @@ namespace {
 int prep_xbuf(void* xbuf, size_t xbuf_bytes, size_t need_data, bool reset_status, hipStream_t stream) {
   if (!xbuf || xbuf_bytes < kStatusBytes + need_data || ((uintptr_t)xbuf & 15)) return CRNN_ERR_ARG;
   // one fill: the status words (all ones = no wait gave up) and the sentinel ring behind them
-  unsigned char* p = (unsigned char*)xbuf + (reset_status ? 0 : kStatusBytes);
-  hipError_t e = hipMemsetAsync(p, 0xFF, need_data + (reset_status ? kStatusBytes : 0), stream);
+  // (the sticky give-up counter in front of the per-launch word is never touched)
+  unsigned char* p = (unsigned char*)xbuf + (reset_status ? kLaunchStatusOff : kStatusBytes);
+  hipError_t e = hipMemsetAsync(p, 0xFF, need_data + (reset_status ? kStatusBytes - kLaunchStatusOff : 0), stream);
   return e == hipSuccess ? CRNN_OK : (int)e;
 }
 
 template <bool WBF, int MT, int U, int UW>
-int launch_fwd_v(const FwdDir& a, const FwdDir& b, int T, int B, void* xbuf, size_t xbuf_bytes, hipStream_t stream) {
+int launch_fwd_v(const FwdDir& a, const FwdDir& b, int T, int B, void* xbuf, size_t xbuf_bytes, int xreq, hipStream_t stream) {
   if constexpr (!fwd_ok(WBF, MT, U, UW)) {
     return CRNN_ERR_UNSUPPORTED;
   } else {
@@ -475,14 +509,15 @@ int launch_fwd_v(const FwdDir& a, const FwdDir& b, int T, int B, void* xbuf, siz
     for (int lo = 0; lo < B; lo += ck.rows_per_launch) {
       const int cnt = (B - lo < ck.rows_per_launch) ? B - lo : ck.rows_per_launch;
       CRNN_TRY(prep_xbuf(xbuf, xbuf_bytes, ck.xdata_bytes, lo == 0, stream));     // every slot is written once per launch: poison first
-      hipLaunchKernelGGL((lstm_fwd_persist_kernel<WBF, MT, U, UW>), dim3(2 * cdiv(cnt, BT) * NSW), dim3(256 * UW), 0, stream, a, b, T, B, lo, cnt,
-                         (unsigned char*)xbuf);
+      const int ncl = 2 * cdiv(cnt, BT);
+      hipLaunchKernelGGL((lstm_fwd_persist_kernel<WBF, MT, U, UW>), dim3(ncl * NSW), dim3(256 * UW), 0, stream, a, b, T, B, lo, cnt,
+                         (unsigned char*)xbuf, (xreq && ncl % 8 == 0) ? 1 : 0);
     }
     return CRNN_OK;
   }
 }
 template <bool WBF, int MT, int U, int UW>
-int launch_bwd_v(const BwdDir& a, const BwdDir& b, int T, int B, void* xbuf, size_t xbuf_bytes, hipStream_t stream) {
+int launch_bwd_v(const BwdDir& a, const BwdDir& b, int T, int B, void* xbuf, size_t xbuf_bytes, int xreq, hipStream_t stream) {
   if constexpr (!bwd_ok(WBF, MT, U, UW)) {
     return CRNN_ERR_UNSUPPORTED;
   } else {
@@ -491,8 +526,9 @@ int launch_bwd_v(const BwdDir& a, const BwdDir& b, int T, int B, void* xbuf, siz
     for (int lo = 0; lo < B; lo += ck.rows_per_launch) {
       const int cnt = (B - lo < ck.rows_per_launch) ? B - lo : ck.rows_per_launch;
       CRNN_TRY(prep_xbuf(xbuf, xbuf_bytes, ck.xdata_bytes, lo == 0, stream));
-      hipLaunchKernelGGL((lstm_bwd_persist_kernel<WBF, MT, U, UW>), dim3(2 * cdiv(cnt, BT) * NSW), dim3(256 * UW), 0, stream, a, b, T, B, lo, cnt,
-                         (unsigned char*)xbuf);
+      const int ncl = 2 * cdiv(cnt, BT);
+      hipLaunchKernelGGL((lstm_bwd_persist_kernel<WBF, MT, U, UW>), dim3(ncl * NSW), dim3(256 * UW), 0, stream, a, b, T, B, lo, cnt,
+                         (unsigned char*)xbuf, (xreq && ncl % 8 == 0) ? 1 : 0);
     }
     return CRNN_OK;
   }
@@ -522,23 +558,26 @@ int with_fallback(int B, int u, int mt_req, int uw_req, Try attempt) {
 
 // Forward recurrence of one Bidirectional(LSTM) layer in ONE launch.  Arguments as crnn_lstm_fwd_ex; `xbuf` is
 // caller-owned scratch of crnn_lstm_persist_xbuf_bytes() bytes (16-byte aligned); the unsigned xbuf[0] is 0xFFFFFFFF
-// after a clean launch, anything else means a bounded wait gave up (results invalid).  mt: batch rows per workgroup / 16 (1 | 2), uw: 16-unit
-// groups per workgroup (1 | 2 | 4); 0 = automatic.
+// 16-byte aligned, its first 4 bytes zeroed once by the caller after allocation); the unsigned at byte 16 is 0xFFFFFFFF after a clean launch,
+// anything else means a bounded wait gave up (results invalid), and the unsigned at byte 0 counts give-ups since the caller zeroed it.
+// mt: batch rows per workgroup / 16 (1 | 2), uw: 16-unit groups per workgroup (1 | 2 | 4); 0 = automatic.  uw_req | CRNN_RNN_XCD_LOCAL
+// (0x100) asks for the XCD-local workgroup -> cluster map (same results).
 extern "C" int crnn_lstm_fwd_persist(const float* xw0, const float* xw1, const void* ut0, const void* ut1, float* h0, float* h1,
                                      int ldh, float* c0, float* c1, float* g0, float* g1, int T, int B, int u, int dt_u,
                                      void* xbuf, size_t xbuf_bytes, int mt_req, int uw_req, hipStream_t stream) {
   CRNN_TRY(crnn_lstm_persist_supported(u, dt_u));
   if (T < 1 || B < 1 || (((uintptr_t)ut0 | (uintptr_t)ut1) & 15)) return CRNN_ERR_ARG;
   FwdDir a{xw0, ut0, h0, ldh, c0, g0}, b{xw1, ut1, h1, ldh, c1, g1};
+  const int xreq = (uw_req & CRNN_RNN_XCD_LOCAL) ? 1 : 0; uw_req &= 0xff;
   const int rc = with_fallback(B, u, mt_req, uw_req, [&](int mt, int uw) {
     if (dt_u == CRNN_BF16) {
-      if (u == 128) return DISPATCH_MT_UW(launch_fwd_v, true, 128, a, b, T, B, xbuf, xbuf_bytes, stream);
-      if (u == 256) return DISPATCH_MT_UW(launch_fwd_v, true, 256, a, b, T, B, xbuf, xbuf_bytes, stream);
-      return DISPATCH_MT_UW(launch_fwd_v, true, 512, a, b, T, B, xbuf, xbuf_bytes, stream);
+      if (u == 128) return DISPATCH_MT_UW(launch_fwd_v, true, 128, a, b, T, B, xbuf, xbuf_bytes, xreq, stream);
+      if (u == 256) return DISPATCH_MT_UW(launch_fwd_v, true, 256, a, b, T, B, xbuf, xbuf_bytes, xreq, stream);
+      return DISPATCH_MT_UW(launch_fwd_v, true, 512, a, b, T, B, xbuf, xbuf_bytes, xreq, stream);
     }
-    if (u == 64) return DISPATCH_MT_UW(launch_fwd_v, false, 64, a, b, T, B, xbuf, xbuf_bytes, stream);
-    if (u == 128) return DISPATCH_MT_UW(launch_fwd_v, false, 128, a, b, T, B, xbuf, xbuf_bytes, stream);
-    return DISPATCH_MT_UW(launch_fwd_v, false, 256, a, b, T, B, xbuf, xbuf_bytes, stream);
+    if (u == 64) return DISPATCH_MT_UW(launch_fwd_v, false, 64, a, b, T, B, xbuf, xbuf_bytes, xreq, stream);
+    if (u == 128) return DISPATCH_MT_UW(launch_fwd_v, false, 128, a, b, T, B, xbuf, xbuf_bytes, xreq, stream);
+    return DISPATCH_MT_UW(launch_fwd_v, false, 256, a, b, T, B, xbuf, xbuf_bytes, xreq, stream);
   });
   CRNN_TRY(rc);
   CRNN_LAUNCH_CHECK();
@@ -553,17 +592,38 @@ extern "C" int crnn_lstm_bwd_persist(const void* u0, const void* u1, const float
   CRNN_TRY(crnn_lstm_persist_supported(u, dt_u));
   if (T < 1 || B < 1 || (((uintptr_t)u0 | (uintptr_t)u1) & 15)) return CRNN_ERR_ARG;
   BwdDir a{u0, c0, g0, dout0, ldo, dz0}, b{u1, c1, g1, dout1, ldo, dz1};
+  const int xreq = (uw_req & CRNN_RNN_XCD_LOCAL) ? 1 : 0; uw_req &= 0xff;
   const int rc = with_fallback(B, u, mt_req, uw_req, [&](int mt, int uw) {
     if (dt_u == CRNN_BF16) {
-      if (u == 128) return DISPATCH_MT_UW(launch_bwd_v, true, 128, a, b, T, B, xbuf, xbuf_bytes, stream);
-      if (u == 256) return DISPATCH_MT_UW(launch_bwd_v, true, 256, a, b, T, B, xbuf, xbuf_bytes, stream);
-      return DISPATCH_MT_UW(launch_bwd_v, true, 512, a, b, T, B, xbuf, xbuf_bytes, stream);
+      if (u == 128) return DISPATCH_MT_UW(launch_bwd_v, true, 128, a, b, T, B, xbuf, xbuf_bytes, xreq, stream);
+      if (u == 256) return DISPATCH_MT_UW(launch_bwd_v, true, 256, a, b, T, B, xbuf, xbuf_bytes, xreq, stream);
+      return DISPATCH_MT_UW(launch_bwd_v, true, 512, a, b, T, B, xbuf, xbuf_bytes, xreq, stream);
     }
-    if (u == 64) return DISPATCH_MT_UW(launch_bwd_v, false, 64, a, b, T, B, xbuf, xbuf_bytes, stream);
-    if (u == 128) return DISPATCH_MT_UW(launch_bwd_v, false, 128, a, b, T, B, xbuf, xbuf_bytes, stream);
-    return DISPATCH_MT_UW(launch_bwd_v, false, 256, a, b, T, B, xbuf, xbuf_bytes, stream);
+    if (u == 64) return DISPATCH_MT_UW(launch_bwd_v, false, 64, a, b, T, B, xbuf, xbuf_bytes, xreq, stream);
+    if (u == 128) return DISPATCH_MT_UW(launch_bwd_v, false, 128, a, b, T, B, xbuf, xbuf_bytes, xreq, stream);
+    return DISPATCH_MT_UW(launch_bwd_v, false, 256, a, b, T, B, xbuf, xbuf_bytes, xreq, stream);
   });
   CRNN_TRY(rc);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Test hook: workgroups that pin LDS and spin on the constant 100 MHz clock (bounded) -- tests/test_gpu_ops.py uses it to
+// take the CUs away from a persistent recurrence and asserts that the give-up is reported instead of silently wrong numbers.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(64) void occupy_kernel(unsigned long long ticks, int lds_bytes) {
+  extern __shared__ unsigned char pin[];
+  if (threadIdx.x == 0) pin[lds_bytes - 1] = 1;    // the allocation is what matters
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+}  // namespace
+extern "C" int crnn_debug_occupy(int blocks, int lds_bytes, long microseconds, hipStream_t stream) {
+  if (blocks < 1 || lds_bytes < 1 || lds_bytes > 160 * 1024 || microseconds < 0 || microseconds > 30L * 1000 * 1000) return CRNN_ERR_ARG;
+  CRNN_LDS_ATTR(occupy_kernel, 160 * 1024);
+  hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(64), lds_bytes, stream, (unsigned long long)microseconds * 100ull, lds_bytes);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }

@@ -9,8 +9,10 @@
  * (-2 bad argument, -3 unsupported configuration).  No C++ exception crosses the ABI.  All tensor arguments
  * are caller-owned DEVICE pointers (fp32 unless noted), NHWC / row-major contiguous unless a leading
  * dimension is given.  Every launch is asynchronous on `stream`; nothing allocates or synchronises.
- * One host thread per GPU process; no global mutable state: the library keeps no statics and reads no environment variable (schedule
- * A/B switches are crnn_config.flags).
+ * One host thread per GPU process; no global mutable state: the library reads no environment variable (schedule A/B switches are
+ * crnn_config.flags) and keeps nothing between calls except caches of device properties -- per-device "dynamic LDS size raised" latches
+ * (atomic bit masks over device ordinals, so a second device in the same process gets its own hipFuncSetAttribute) and the thread-local
+ * events of the side-stream schedules (crnn_backward_*_ex).
  */
 #ifndef CRNN_MI355X_H
 #define CRNN_MI355X_H
@@ -51,6 +53,8 @@ typedef struct {
                                          GEMM (crnn_gemm_bf16_ex / crnn_pwconv_bnrelu6_*) instead of the streaming kernels (crnn_pwconv_bnrelu6_fwd_wres,
                                          crnn_gemm_wres_bf16, crnn_pwconv_bnrelu6_wgrad_stream).  Same products and data gradients bit for bit; the
                                          BatchNorm-2 statistics and the weight gradients are the same sums in another order (fp32 round-off) */
+#define CRNN_FLAG_RNN_LINEAR_CLUSTERS 64 /* persistent recurrences: cluster members = consecutive workgroup ids (dealt over all XCDs) instead of the
+                                         XCD-local map; bit-identical */
 #define CRNN_FLAG_RNN_STEP_KERNELS 1  /* LSTM recurrences as one launch per timestep (crnn_lstm_*_ex) instead of the
                                          persistent one-launch-per-layer kernels (crnn_lstm_*_persist); bit-identical */
 
@@ -69,6 +73,10 @@ size_t crnn_workspace_bytes(const crnn_config* cfg);
 int  crnn_ws_tensor(const crnn_config* cfg, const char* name, long* offset, long* count);
 /* same + storage type of the tensor (0 = fp32, 1 = bf16; offset stays in floats, count in elements) */
 int  crnn_ws_tensor_info(const crnn_config* cfg, const char* name, long* offset, long* count, int* dtype);
+
+/* Test hook (tests/test_gpu_ops.py: the give-up path of the persistent recurrences): `blocks` workgroups of 64 threads that each pin
+ * `lds_bytes` of LDS (<= 160 KiB: nothing else fits next to one on its CU) and spin for `microseconds` of the constant 100 MHz clock. */
+int crnn_debug_occupy(int blocks, int lds_bytes, long microseconds, crnn_stream_t stream);
 
 /* ---- whole-path drivers ------------------------------------------------------------------------------------- */
 /* Forward of the predictor sub-model (utils.py:308-312; Model.predict_generator, predict.py:166):
@@ -369,11 +377,15 @@ int crnn_pwconv_bnrelu6_fwd_wres(const void* d, const float* in_bnstate, const v
  * registers for all T steps; per step the cluster all-gathers h_t (forward) / dz_t (backward) through `xbuf` with
  * write-through stores and L1-bypassing polled loads (the data is its own ready flag) and stages it through LDS as the next
  * step's MFMA A operand.  Bit-identical to crnn_lstm_*_ex.  `xbuf`: caller-owned scratch of crnn_lstm_persist_xbuf_bytes()
- * bytes, 16-byte aligned; after the launch the unsigned at xbuf[0] is 0xFFFFFFFF, anything else means a bounded wait gave up
- * (results invalid).
+ * bytes, 16-byte aligned.  Status: the unsigned at byte 16 of xbuf is 0xFFFFFFFF after a clean launch, anything else means a
+ * bounded wait gave up (the cluster was not co-resident: results invalid); the unsigned at byte 0 is a STICKY counter of give-ups
+ * that no launch resets -- the caller zeroes it once after allocating xbuf and compares it with the last value it saw (the engine
+ * does that wherever it synchronises with the host anyway and raises; inside the workspace this is the tensor "rnnx").
  * mt = batch rows per workgroup / 16 (1 | 2), uw = 16-unit groups per workgroup (1 | 2 | 4: 256 / 512 / 1024 threads, the
- * cluster has u/(16 uw) members); 0 = automatic.  crnn_lstm_persist_supported: 0 if (u, dt_u) has a kernel
+ * cluster has u/(16 uw) members); 0 = automatic; uw | CRNN_RNN_XCD_LOCAL: the members of a cluster are the workgroup ids congruent
+ * modulo 8 (one XCD) instead of consecutive ids -- same results.  crnn_lstm_persist_supported: 0 if (u, dt_u) has a kernel
  * (fp32: u in {64,128,256}; bf16: u in {128,256,512}), else -3 -- use the step kernels then. */
+#define CRNN_RNN_XCD_LOCAL 0x100
 size_t crnn_lstm_persist_xbuf_bytes(int T, int B, int u, int dt_u);
 int crnn_lstm_persist_supported(int u, int dt_u);
 int crnn_lstm_fwd_persist(const float* xw0, const float* xw1, const void* ut0, const void* ut1, float* h0, float* h1, int ldh,

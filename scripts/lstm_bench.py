@@ -25,15 +25,24 @@ def main():
     ap.add_argument("--T", type=int, default=52)
     ap.add_argument("--units", type=int, default=256)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--pol-only", action="store_true", help="bf16, XCD-local persistent variants only (cache-policy experiment libraries)")
     args = ap.parse_args()
     L = native.lib()
+    if os.environ.get("CRNN_RNN_LIB"):      # experiment build of rnn_persist.hip alone (cache-policy variants, scripts/lstm_xcd_bench.sh)
+        alt = ctypes.CDLL(os.environ["CRNN_RNN_LIB"])
+        for n in ("crnn_lstm_fwd_persist", "crnn_lstm_bwd_persist"):
+            f = getattr(alt, n); f.restype, f.argtypes = getattr(L, n).restype, getattr(L, n).argtypes
+        class _Mix:
+            def __getattr__(self, n):
+                return getattr(alt, n) if n in ("crnn_lstm_fwd_persist", "crnn_lstm_bwd_persist") else getattr(L, n)
+        L = _Mix()
     B, T, u = args.batch, args.T, args.units
     G = 4 * u
     rs = np.random.RandomState(0)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     S = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     res = {"batch": B, "T": T, "units": u}
-    for bf16 in (True, False):
+    for bf16 in ((True,) if args.pol_only else (True, False)):
         dt = 1 if bf16 else 0
         wdt = torch.bfloat16 if bf16 else torch.float32
         U = [torch.from_numpy((rs.normal(size=(u, G)) * 0.1).astype(np.float32)).cuda() for _ in range(2)]
@@ -63,11 +72,15 @@ def main():
         flops = 2.0 * T * 2 * B * u * G
         peak = 2500e12 if bf16 else 157.3e12
         mode = {}
-        for kind, mt, uw in (("step", 0, 0), ("persist", 1, 1), ("persist", 1, 2), ("persist", 1, 4), ("persist", 2, 2), ("persist", 2, 4), ("persist", 0, 0)):
+        variants = (("persist", 0, 0x100), ("persist", 1, 0x102), ("persist", 0, 0x100)) if args.pol_only else (("step", 0, 0), ("persist", 1, 1), ("persist", 1, 2), ("persist", 1, 4), ("persist", 2, 2), ("persist", 2, 4), ("persist", 0, 0), ("persist", 0, 0x100), ("persist", 1, 0x102), ("persist", 0, 0))
+        for kind, mt, uw in variants:
             row = {}
+            xbuf[:4].zero_()            # the sticky give-up counter belongs to this variant
             for name, fn in (("fwd", fwd), ("bwd", bwd)):
                 ts = []
                 for it in range(args.iters + 3):
+                    if it == 1 and kind == "persist" and int(xbuf[0].item()) != 0:
+                        break                                   # this variant loses its hand-offs (bounded waits gave up): do not time it
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     rc = fn(kind, mt, uw)
@@ -76,12 +89,12 @@ def main():
                     assert rc == 0, (kind, mt, uw, name, rc)
                     if it >= 3:
                         ts.append(e0.elapsed_time(e1) * 1e-3)
-                t = float(np.median(ts))
+                t = float(np.median(ts)) if ts else float('nan')
                 row[name + "_us"] = round(t * 1e6, 1)
                 row[name + "_us_per_step"] = round(t * 1e6 / T, 2)
                 row[name + "_mfma_frac"] = round(flops / t / peak, 4)
-            row["status"] = int(int(xbuf[0].item()) != -1)
-            mode["%s%s" % (kind, "_mt%d_uw%d" % (mt, uw) if kind == "persist" else "")] = row
+            row["status"] = int(int(xbuf[4].item()) != -1); row["giveups"] = int(xbuf[0].item())
+            mode["%s%s" % (kind, ("_mt%d_uw%d%s" % (mt, uw & 0xff, "_xcd" if uw & 0x100 else "")) if kind == "persist" else "") + ("_again" if (kind, mt, uw) == ("persist", 0, 0) and "persist_mt0_uw0" in mode else "")] = row
         res["bf16" if bf16 else "fp32"] = mode
     print(json.dumps(res))
 

@@ -33,7 +33,7 @@ for rep in range(3):
     assert rc == 0, rc
     torch.cuda.synchronize()
 raw = xbuf[:65536 // 4].cpu().numpy().view(np.uint64)[8:]     # skip 64 bytes
-out = {"status": int(int(xbuf[0].item()) != -1)}
+out = {"status": int(int(xbuf[4].item()) != -1), "giveups": int(xbuf[0].item())}
 for wg in range(2):
     t = raw[wg * 128 * 8:(wg * 128 + T) * 8].reshape(T, 8)[:, :5].astype(np.int64) * 10     # ns
     s = slice(2, T - 1)

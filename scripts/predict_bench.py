@@ -1,13 +1,9 @@
 #!/usr/bin/env python3
-"""BASELINE configs[4]: inference-only predict path at batch 1024 -- forward (BN moving statistics,
-dropout off) + CTC beam search (beam_width 10, top_paths 1, merge_repeated) as the HIP wavefront kernel, next to the
-greedy decode and to the CPU restatement of the TF beam search (oracle/ctc.py, one thread) on a bounded sample.
-Prints one JSON line.  usage: predict_bench.py [--batch 1024] [--iters 20] [--precision bf16s]"""
-import argparse, json, os, sys, time
+"""BASELINE configs[4]: inference-only predict path at batch 1024 -- the same leg bench.py reports as `predict`
+(bench.predict_leg), stand-alone.  Prints one JSON line.  usage: predict_bench.py [--batch 1024] [--iters 20] [--precision bf16s]"""
+import argparse, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "crnn-ocr-lite_amd")]
-import numpy as np
-import torch
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1024)
@@ -16,56 +12,5 @@ ap.add_argument("--precision", default="bf16s")
 ap.add_argument("--cpu-sample", type=int, default=32)
 args = ap.parse_args()
 
-from crnn_mi355x.engine import Engine
-from crnn_mi355x.init import initial_parameters
-from bench import synthetic_batch
-
-B = args.batch
-eng = Engine(B, dropout=False, precision=args.precision)
-p = initial_parameters(eng.layout, eng.cfg.units, False, seed=1)
-rs = np.random.RandomState(2)
-for k in p:                                        # non-degenerate posteriors: the identity-STN / zero-bias init decodes to ""
-    if k.endswith(("_b", "_g")) or k == "stn_d2_w":
-        p[k] = (p[k] + rs.normal(size=p[k].shape) * (0.02 if k.startswith("stn_d2") else 0.3)).astype(np.float32)
-eng.set_params(p)
-x, lab, il, ll = synthetic_batch(B, seed=0, T=eng.T)
-xd = torch.from_numpy(x).cuda()
-
-
-def timed(fn, iters):
-    ts = []
-    for _ in range(iters):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
-    return float(np.median(ts)), float(np.percentile(ts, 90))
-
-state = {}
-def fwd(): state["y"] = eng.forward(xd, train=False)
-def beam(): state["beam"] = eng.beam_decode(state["y"], beam_width=10)
-def greedy(): state["greedy"] = eng.greedy_decode(state["y"])
-def both(): fwd(); beam()
-for _ in range(3): both(); greedy()
-f50, f90 = timed(fwd, args.iters)
-b50, b90 = timed(beam, args.iters)
-g50, _ = timed(greedy, args.iters)
-t50, t90 = timed(both, args.iters)
-
-# CPU restatement of TF's beam search (the oracle: only this baseline leg uses it) on a bounded sample of the same
-# posteriors, one thread
-from oracle import ctc as OC
-y = state["y"].float().cpu().numpy()
-n = min(args.cpu_sample, B)
-t0 = time.perf_counter()
-ref = OC.ctc_beam_decode(y[:n].astype(np.float64), beam_width=10)
-cpu_ms_per_img = 1e3 * (time.perf_counter() - t0) / n
-out, ln, sc = [t.cpu().numpy() for t in state["beam"]]
-agree = sum(int(ln[i] == ref[1][i] and list(out[i, :ln[i]]) == list(ref[0][i, :ref[1][i]])) for i in range(n)) / n
-print(json.dumps({
-    "workload": "BASELINE configs[4]: predict path, batch %d, 100x32x1, forward (inference BN) + CTC beam search bw=10" % B,
-    "precision": args.precision, "iters": args.iters,
-    "forward_ms_p50": round(f50, 3), "beam_decode_ms_p50": round(b50, 3), "greedy_decode_ms_p50": round(g50, 3),
-    "forward_plus_beam_ms_p50": round(t50, 3), "forward_plus_beam_ms_p90": round(t90, 3),
-    "latency_us_per_image_p50": round(1e3 * t50 / B, 3), "images_per_sec": round(B / (t50 * 1e-3), 1),
-    "cpu_beam_ms_per_image": round(cpu_ms_per_img, 3), "cpu_beam_sample": n, "cpu_beam_kind": "port (oracle/ctc.py, 1 thread)",
-    "beam_agreement_with_cpu_on_sample": agree}))
+from bench import predict_leg
+print(json.dumps(predict_leg(args.batch, args.iters, args.precision, args.cpu_sample)))
