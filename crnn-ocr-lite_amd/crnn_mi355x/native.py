@@ -14,7 +14,7 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 HEADER = os.path.join(REPO_ROOT, "include", "crnn_mi355x.h")
 CSRC = os.path.join(PKG_ROOT, "csrc")
 LIB_PATH = os.path.join(PKG_ROOT, "libcrnn_mi355x.so")
-SOURCES = ["gemm.hip", "gemm_nt.hip", "gemm_wres.hip", "gemm_wgrad.hip", "conv.hip", "conv_bwd_fused.hip", "dwconv_stream.hip", "dwconv_bwd_stream.hip", "stn.hip", "rnn.hip", "rnn_persist.hip", "ctc.hip", "beam.hip", "optim.hip", "model.hip"]
+SOURCES = ["gemm.hip", "gemm_nt.hip", "gemm_wres.hip", "gemm_wgrad.hip", "conv.hip", "conv_bwd_fused.hip", "dwconv_stream.hip", "dwconv_bwd_stream.hip", "stn.hip", "rnn.hip", "rnn_persist.hip", "gru_persist.hip", "ctc.hip", "beam.hip", "optim.hip", "model.hip"]
 
 
 class crnn_config(ctypes.Structure):
@@ -66,7 +66,7 @@ def build(verbose=False):
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
-        deps = [src, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "rnn_cell.h"), os.path.join(CSRC, "gemm_bf16.inc"), HEADER]
+        deps = [src, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "rnn_cell.h"), os.path.join(CSRC, "rnn_exchange.h"), os.path.join(CSRC, "gemm_bf16.inc"), HEADER]
         if not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps):
             jobs.append(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", inc, "-c", src, "-o", obj])
         objs.append(obj)

@@ -427,8 +427,12 @@ __global__ __launch_bounds__(512) void gemm_wres_fwd_kernel(WresFwdParams p) {
       ssum[e] += __shfl_xor(ssum[e], 32, 64); ssq[e] += __shfl_xor(ssq[e], 32, 64);
     }
     if (lane < 16 * CB) {
-      float* r0 = p.stats + ((long)srow * 2 + 0) * p.N + slice * NS + cN * 8;
-      float* r1 = p.stats + ((long)srow * 2 + 1) * p.N + slice * NS + cN * 8;
+      // the row addresses are formed HERE: left to itself the compiler hoists them above the stage loops and, at the 256-register
+      // ceiling of the deep-K instantiations, spills them across (an opaque copy of the lane index pins the address arithmetic)
+      int cq = cN;
+      asm volatile("" : "+v"(cq));
+      float* r0 = p.stats + ((long)srow * 2 + 0) * p.N + slice * NS + cq * 8;
+      float* r1 = p.stats + ((long)srow * 2 + 1) * p.N + slice * NS + cq * 8;
       *reinterpret_cast<float4*>(r0) = make_float4(ssum[0], ssum[1], ssum[2], ssum[3]);
       *reinterpret_cast<float4*>(r0 + 4) = make_float4(ssum[4], ssum[5], ssum[6], ssum[7]);
       *reinterpret_cast<float4*>(r1) = make_float4(ssq[0], ssq[1], ssq[2], ssq[3]);

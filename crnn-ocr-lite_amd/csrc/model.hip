@@ -97,12 +97,16 @@ long lmax(long a, long b) { return a > b ? a : b; }
 
 // storage of the recurrent weights the recurrences multiply with: bf16 copies in the bf16 modes (u % 128 == 0), else fp32
 int rnn_dtu(const crnn_config* c) { return (c->mfma_bf16 && c->units % 128 == 0) ? CRNN_BF16 : CRNN_F32; }
-// LSTM recurrences as persistent one-launch-per-layer kernels (rnn_persist.hip) unless switched off or unsupported
+// recurrences as persistent one-launch-per-layer kernels (rnn_persist.hip, gru_persist.hip) unless switched off or unsupported
 bool rnn_persist(const crnn_config* c) {
-  return !c->gru && !(c->flags & CRNN_FLAG_RNN_STEP_KERNELS) && crnn_lstm_persist_supported(c->units, rnn_dtu(c)) == 0;
+  if (c->flags & CRNN_FLAG_RNN_STEP_KERNELS) return false;
+  return (c->gru ? crnn_gru_persist_supported(c->units, rnn_dtu(c)) : crnn_lstm_persist_supported(c->units, rnn_dtu(c))) == 0;
 }
 
-// uw argument of the persistent recurrences: automatic workgroup size, XCD-local clusters unless the linear map is asked for
+// uw argument of the persistent BPTT launches: automatic workgroup size, XCD-local clusters unless the linear map is asked for.
+// Measured at B = 256, u = 256 (profiles/r03_lstm_bench.json): the backward all-gather (32 KB of dz per step and chain) is faster inside
+// one XCD (bf16 198 -> 173 us per layer, fp32 368 -> 291), the forward one (8 KB of h) is faster dealt over all XCDs (131 vs 141 us),
+// so the forward launches keep the linear map.
 int rnn_uw(const crnn_config* c) { return (c->flags & CRNN_FLAG_RNN_LINEAR_CLUSTERS) ? 0 : CRNN_RNN_XCD_LOCAL; }
 
 Plan make_plan(const crnn_config* c) {
@@ -480,24 +484,30 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
   };
   CRNN_TRY(xw(c.w("dn1"), d.tds, "1f"));
   CRNN_TRY(xw(c.w("dn1"), d.tds, "1b"));
-  if (cfg->gru)   // "cs" holds r*h_prev for the GRU (cell state for the LSTM)
+  if (cfg->gru && persist)   // "cs" holds r*h_prev for the GRU (cell state for the LSTM)
+    CRNN_TRY(crnn_gru_fwd_persist(c.w("xw1f"), c.w("xw1b"), c.w("ut1f"), c.w("ut1b"), c.w("h1f"), c.w("h1b"), u, c.w("gt1f"), c.w("gt1b"),
+                                  c.w("cs1f"), c.w("cs1b"), T, B, u, dtu, c.w("rnnx"), xbytes, 0, stream));
+  else if (cfg->gru)
     CRNN_TRY(crnn_gru_fwd_ex(c.w("xw1f"), c.w("xw1b"), c.w("ut1f"), c.w("ut1b"), c.w("h1f"), c.w("h1b"), u, c.w("gt1f"), c.w("gt1b"),
                              c.w("cs1f"), c.w("cs1b"), T, B, u, dtu, stream));
   else if (persist)
     CRNN_TRY(crnn_lstm_fwd_persist(c.w("xw1f"), c.w("xw1b"), c.w("ut1f"), c.w("ut1b"), c.w("h1f"), c.w("h1b"), u, c.w("cs1f"), c.w("cs1b"),
-                                   c.w("gt1f"), c.w("gt1b"), T, B, u, dtu, c.w("rnnx"), xbytes, 0, rnn_uw(cfg), stream));
+                                   c.w("gt1f"), c.w("gt1b"), T, B, u, dtu, c.w("rnnx"), xbytes, 0, 0, stream));
   else
     CRNN_TRY(crnn_lstm_fwd_ex(c.w("xw1f"), c.w("xw1b"), c.w("ut1f"), c.w("ut1b"), c.w("h1f"), c.w("h1b"), u, c.w("cs1f"), c.w("cs1b"),
                               c.w("gt1f"), c.w("gt1b"), T, B, u, dtu, stream));
   CRNN_TRY(crnn_add(c.w("h1f"), c.w("h1b"), c.w("r1"), (long)TB * u, stream));  // merge_mode='sum'
   CRNN_TRY(xw(c.w("r1"), u, "2f"));
   CRNN_TRY(xw(c.w("r1"), u, "2b"));
-  if (cfg->gru)
+  if (cfg->gru && persist)
+    CRNN_TRY(crnn_gru_fwd_persist(c.w("xw2f"), c.w("xw2b"), c.w("ut2f"), c.w("ut2b"), c.w("h2"), c.w("h2") + u, 2 * u, c.w("gt2f"), c.w("gt2b"),
+                                  c.w("cs2f"), c.w("cs2b"), T, B, u, dtu, c.w("rnnx"), xbytes, 0, stream));
+  else if (cfg->gru)
     CRNN_TRY(crnn_gru_fwd_ex(c.w("xw2f"), c.w("xw2b"), c.w("ut2f"), c.w("ut2b"), c.w("h2"), c.w("h2") + u, 2 * u, c.w("gt2f"), c.w("gt2b"),
                              c.w("cs2f"), c.w("cs2b"), T, B, u, dtu, stream));
   else if (persist)
     CRNN_TRY(crnn_lstm_fwd_persist(c.w("xw2f"), c.w("xw2b"), c.w("ut2f"), c.w("ut2b"), c.w("h2"), c.w("h2") + u, 2 * u, c.w("cs2f"), c.w("cs2b"),
-                                   c.w("gt2f"), c.w("gt2b"), T, B, u, dtu, c.w("rnnx"), xbytes, 0, rnn_uw(cfg), stream));    // merge_mode='concat'
+                                   c.w("gt2f"), c.w("gt2b"), T, B, u, dtu, c.w("rnnx"), xbytes, 0, 0, stream));    // merge_mode='concat'
   else
     CRNN_TRY(crnn_lstm_fwd_ex(c.w("xw2f"), c.w("xw2b"), c.w("ut2f"), c.w("ut2b"), c.w("h2"), c.w("h2") + u, 2 * u, c.w("cs2f"), c.w("cs2b"),
                               c.w("gt2f"), c.w("gt2b"), T, B, u, dtu, stream));    // merge_mode='concat'
@@ -529,6 +539,9 @@ static int rnn_bwd_chain(const Ctx& c, int layer, const float* hf, const float* 
   int dtu = CRNN_F32;
   const float* uf = c.p("rnn" + l + "f_u"); const float* ub = c.p("rnn" + l + "b_u");
   if (c.cfg->mfma_bf16 && u % 128 == 0) { uf = weight_operand(c, 0, uf, &dtu); ub = weight_operand(c, 0, ub, &dtu); }
+  if (c.cfg->gru && rnn_persist(c.cfg) && !(((uintptr_t)uf | (uintptr_t)ub) & 15))
+    return crnn_gru_bwd_persist(uf, ub, hf, hb, ldh, c.w("gt" + l + "f"), c.w("gt" + l + "b"), doutf, doutb, ldo, dzf, dzb, T, B, u, dtu,
+                                c.w("rnnx"), crnn_lstm_persist_xbuf_bytes(T, B, u, dtu), rnn_uw(c.cfg), c.s);
   if (c.cfg->gru)
     return crnn_gru_bwd_ex(uf, ub, hf, hb, ldh, c.w("gt" + l + "f"), c.w("gt" + l + "b"), doutf, doutb,
                            ldo, dzf, dzb, c.w("dcf"), c.w("dcb"), c.w("dhpf"), c.w("dhpb"), T, B, u, dtu, c.s);

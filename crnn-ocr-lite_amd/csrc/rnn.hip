@@ -394,11 +394,11 @@ __global__ __launch_bounds__(256) void gru_fwd_zr_kernel(GruDir d0, GruDir d1, i
     const float* xw = d.xw + ((long)t * B + b) * 3 * u;
     float zz = ((red[0][0][tid] + red[1][0][tid]) + (red[2][0][tid] + red[3][0][tid])) + xw[j];
     float rr = ((red[0][1][tid] + red[1][1][tid]) + (red[2][1][tid] + red[3][1][tid])) + xw[u + j];
-    float zg = hard_sigmoid(zz), rg = hard_sigmoid(rr);
     float hprev = (s > 0) ? d.h[((long)tp * B + b) * d.ldh + j] : 0.f;
+    const GruZR o = gru_cell_zr(zz, rr, hprev);
     float* gt = d.gates + ((long)t * B + b) * 3 * u;
-    gt[j] = zg; gt[u + j] = rg;
-    d.rh[((long)t * B + b) * u + j] = rg * hprev;
+    gt[j] = o.zg; gt[u + j] = o.rg;
+    d.rh[((long)t * B + b) * u + j] = o.rh;
   }
 }
 
@@ -420,10 +420,11 @@ __global__ __launch_bounds__(256) void gru_fwd_h_kernel(GruDir d0, GruDir d1, in
   if (b < B) {
     float* gt = d.gates + ((long)t * B + b) * 3 * u;
     float pre = ((red[0][0][tid] + red[1][0][tid]) + (red[2][0][tid] + red[3][0][tid])) + d.xw[((long)t * B + b) * 3 * u + 2 * u + j];
-    float hh = tanhf(pre), zg = gt[j];
+    float zg = gt[j];
     float hprev = (s > 0) ? d.h[((long)tp * B + b) * d.ldh + j] : 0.f;
-    gt[2 * u + j] = hh;
-    d.h[((long)t * B + b) * d.ldh + j] = zg * hprev + (1.f - zg) * hh;
+    const GruH o = gru_cell_h(pre, zg, hprev);
+    gt[2 * u + j] = o.hh;
+    d.h[((long)t * B + b) * d.ldh + j] = o.hn;
   }
 }
 
@@ -450,8 +451,9 @@ __global__ __launch_bounds__(256) void gru_bwd_b_kernel(GruDir d0, GruDir d1, in
     float zg = gt[j], hh = gt[2 * u + j];
     float hprev = (sp > 0) ? d.h[((long)tprev * B + b) * d.ldh + j] : 0.f;
     float* dz = d.dz + ((long)t * B + b) * 3 * u;
-    dz[j] = dh * (hprev - hh) * hs_grad_from_out(zg);
-    dz[2 * u + j] = dh * (1.f - zg) * (1.f - hh * hh);
+    const GruBwdB o = gru_cell_bwd_b(dh, zg, hh, hprev);
+    dz[j] = o.dzz;
+    dz[2 * u + j] = o.dhh;
     d.dh[(long)b * u + j] = dh;
   }
 }
@@ -477,8 +479,9 @@ __global__ __launch_bounds__(256) void gru_bwd_a_kernel(GruDir d0, GruDir d1, in
     const float* gt = d.gates + ((long)t * B + b) * 3 * u;
     float zg = gt[j], rg = gt[u + j];
     float hprev = (sp > 0) ? d.h[((long)tprev * B + b) * d.ldh + j] : 0.f;
-    d.dz[((long)t * B + b) * 3 * u + u + j] = drh * hprev * hs_grad_from_out(rg);
-    d.dhp[(long)b * u + j] = d.dh[(long)b * u + j] * zg + drh * rg;
+    const GruBwdA o = gru_cell_bwd_a(drh, d.dh[(long)b * u + j], zg, rg, hprev);
+    d.dz[((long)t * B + b) * 3 * u + u + j] = o.dzr;
+    d.dhp[(long)b * u + j] = o.dhp;
   }
 }
 

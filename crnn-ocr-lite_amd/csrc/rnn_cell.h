@@ -1,4 +1,4 @@
-// LSTM cell arithmetic shared by the per-step (rnn.hip) and persistent (rnn_persist.hip) recurrences
+// LSTM / GRU cell arithmetic shared by the per-step (rnn.hip) and persistent (rnn_persist.hip) recurrences
 // (Keras 2.2.2 LSTMCell: hard_sigmoid gates, tanh, gate order i,f,c,o; utils.py:77-79).  Floating-point contraction
 // is switched off inside these functions: every product and sum is rounded exactly as written, so two kernels that
 // call them produce bit-identical results regardless of how the compiler schedules the surrounding code.
@@ -44,5 +44,47 @@ __device__ __forceinline__ LstmBwdOut lstm_cell_bwd(float dh, float ig, float fg
   o.dz[2] = (dct * ig) * (1.f - g2);
   o.dz[3] = dog * hs_grad_from_out(og);
   o.dc = dct * fg;
+  return o;
+}
+
+// ---- GRU (Keras 2.2.2 GRUCell, reset_after=False, gate order z,r,h; utils.py:80-82), shared by the per-step kernels of rnn.hip and
+// the persistent ones of gru_persist.hip: same operations in the same order, contraction off => bit-identical results.
+struct GruZR { float zg, rg, rh; };
+// zz, rr: pre-activations (recurrent product + x W + b); rh = r * h_prev feeds the candidate's recurrent product
+__device__ __forceinline__ GruZR gru_cell_zr(float zz, float rr, float hprev) {
+#pragma clang fp contract(off)
+  GruZR o;
+  o.zg = hard_sigmoid(zz); o.rg = hard_sigmoid(rr);
+  o.rh = o.rg * hprev;
+  return o;
+}
+struct GruH { float hh, hn; };
+__device__ __forceinline__ GruH gru_cell_h(float pre, float zg, float hprev) {
+#pragma clang fp contract(off)
+  GruH o;
+  o.hh = lstm_tanh(pre);
+  const float a = zg * hprev, b = (1.f - zg) * o.hh;
+  o.hn = a + b;
+  return o;
+}
+// backward, first half: dh = gradient w.r.t. h_t -> gradients of the z and candidate pre-activations
+struct GruBwdB { float dzz, dhh; };
+__device__ __forceinline__ GruBwdB gru_cell_bwd_b(float dh, float zg, float hh, float hprev) {
+#pragma clang fp contract(off)
+  GruBwdB o;
+  const float t0 = hprev - hh;
+  o.dzz = (dh * t0) * hs_grad_from_out(zg);
+  const float t1 = 1.f - zg, t2 = hh * hh, t3 = 1.f - t2;
+  o.dhh = (dh * t1) * t3;
+  return o;
+}
+// second half: drh = gradient w.r.t. r * h_prev -> gradient of the r pre-activation and the carry to h_prev
+struct GruBwdA { float dzr, dhp; };
+__device__ __forceinline__ GruBwdA gru_cell_bwd_a(float drh, float dh, float zg, float rg, float hprev) {
+#pragma clang fp contract(off)
+  GruBwdA o;
+  o.dzr = (drh * hprev) * hs_grad_from_out(rg);
+  const float a = dh * zg, b = drh * rg;
+  o.dhp = a + b;
   return o;
 }

@@ -53,10 +53,10 @@ typedef struct {
                                          GEMM (crnn_gemm_bf16_ex / crnn_pwconv_bnrelu6_*) instead of the streaming kernels (crnn_pwconv_bnrelu6_fwd_wres,
                                          crnn_gemm_wres_bf16, crnn_pwconv_bnrelu6_wgrad_stream).  Same products and data gradients bit for bit; the
                                          BatchNorm-2 statistics and the weight gradients are the same sums in another order (fp32 round-off) */
-#define CRNN_FLAG_RNN_LINEAR_CLUSTERS 64 /* persistent recurrences: cluster members = consecutive workgroup ids (dealt over all XCDs) instead of the
-                                         XCD-local map; bit-identical */
-#define CRNN_FLAG_RNN_STEP_KERNELS 1  /* LSTM recurrences as one launch per timestep (crnn_lstm_*_ex) instead of the
-                                         persistent one-launch-per-layer kernels (crnn_lstm_*_persist); bit-identical */
+#define CRNN_FLAG_RNN_LINEAR_CLUSTERS 64 /* persistent BPTT launches: cluster members = consecutive workgroup ids (dealt over all XCDs, what the
+                                         forward launches always use) instead of the XCD-local map; bit-identical */
+#define CRNN_FLAG_RNN_STEP_KERNELS 1  /* LSTM / GRU recurrences as one (two) launch(es) per timestep (crnn_lstm_*_ex, crnn_gru_*_ex) instead of
+                                         the persistent one-launch-per-layer kernels (crnn_lstm_*_persist, crnn_gru_*_persist); bit-identical */
 
 /* ---- parameter / statistics layout (Keras weight order) -------------------------------------- */
 int  crnn_num_params(const crnn_config* cfg);                 /* number of trainable tensors */
@@ -394,6 +394,18 @@ int crnn_lstm_fwd_persist(const float* xw0, const float* xw1, const void* ut0, c
 int crnn_lstm_bwd_persist(const void* u0, const void* u1, const float* c0, const float* c1, const float* g0, const float* g1,
                           const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1, int T, int B, int u, int dt_u,
                           void* xbuf, size_t xbuf_bytes, int mt, int uw, crnn_stream_t stream);
+/* Persistent Bidirectional(GRU) recurrences (utils.py:80-82, the cell train.py:119 really builds): ONE launch per layer and pass instead of
+ * 2 T step launches, the cluster / sentinel-ring design of crnn_lstm_*_persist with two all-gathers per step (h_{t-1}, then r * h_{t-1}:
+ * the candidate's recurrent product needs r of every unit; backward: [dz|dr]_{t+1}, then dhh_t).  Bit-identical to crnn_gru_*_ex.
+ * xbuf: crnn_lstm_persist_xbuf_bytes(T, B, u, dt_u) bytes, same status words; flags: 0 or CRNN_RNN_XCD_LOCAL.
+ * crnn_gru_persist_supported: 0 if (u, dt_u) has a kernel (fp32: u in {64,128,256}; bf16: u in {128,256,512}), else -3. */
+int crnn_gru_persist_supported(int u, int dt_u);
+int crnn_gru_fwd_persist(const float* xw0, const float* xw1, const void* ut0, const void* ut1, float* h0, float* h1, int ldh,
+                         float* g0, float* g1, float* rh0, float* rh1, int T, int B, int u, int dt_u, void* xbuf, size_t xbuf_bytes,
+                         int flags, crnn_stream_t stream);
+int crnn_gru_bwd_persist(const void* u0, const void* u1, const float* h0, const float* h1, int ldh, const float* g0, const float* g1,
+                         const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1, int T, int B, int u, int dt_u,
+                         void* xbuf, size_t xbuf_bytes, int flags, crnn_stream_t stream);
 /* Bidirectional GRU recurrence (utils.py:81-82; reset_after=False), time-major; gates = z,r,hh; rh = r*h_prev */
 int crnn_gru_fwd(const float* xw0, const float* xw1, const float* ut0, const float* ut1, float* h0, float* h1, int ldh,
                  float* g0, float* g1, float* rh0, float* rh1, int T, int B, int u, crnn_stream_t stream);

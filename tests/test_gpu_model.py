@@ -308,6 +308,35 @@ def test_bf16s_producer_fused_pointwise_convs_equal_the_two_pass_path(shape):
     assert dy < 5e-3 and dl < 2e-3 and glob < 0.2 and worst[1] < 0.5, (dy, dl, glob, worst)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16s"])
+def test_gru_model_persistent_recurrences_equal_the_step_kernels(precision):
+    """GRU variant (what the reference's train.py builds): the whole train step with the persistent recurrences (default) must equal
+    the per-step-launch schedule (CRNN_FLAG_RNN_STEP_KERNELS) bit for bit -- posteriors, losses, every gradient -- and so must the
+    BPTT launches on the linear workgroup -> cluster map (CRNN_FLAG_RNN_LINEAR_CLUSTERS)."""
+    from crnn_mi355x import native
+    B, imgh, imgw, ncls, max_len, tds, u = 20, 60, 32, 38, 10, 64, 256
+    cfg = M.Config(imgh=imgh, imgw=imgw, max_len=max_len, time_dense_size=tds, n_units=u, num_classes=ncls, gru=True)
+    p, bn = M.init_params(cfg, seed=8, dtype=np.float64)
+    p = M.randomize_params(cfg, p)
+    x, lab, il, ll = M.synthetic_batch(cfg, B, seed=2, dtype=np.float64)
+    out = {}
+    for flags in (0, native.FLAG_RNN_STEP_KERNELS, native.FLAG_RNN_LINEAR_CLUSTERS):
+        eng = Engine(B, imgh, imgw, ncls, max_len, tds, u, gru=True, stn=True, dropout=True, precision=precision, flags=flags)
+        eng.set_params(p, bn)
+        eng.grads.zero_()
+        y = eng.forward(x.astype(np.float32), train=True, seed=5).clone()
+        loss = eng.backward(lab, il, ll, seed=5).clone()
+        eng.check_rnn_status()
+        assert (eng._rnn_giveups is not None) == (flags != native.FLAG_RNN_STEP_KERNELS)
+        out[flags] = (y, loss, eng.grads.clone())
+        del eng
+    y0, l0, g0 = out[0]
+    assert torch.isfinite(g0).all() and float(g0.abs().max()) > 0
+    for flags in list(out)[1:]:
+        y1, l1, g1 = out[flags]
+        assert torch.equal(y0, y1) and torch.equal(l0, l1) and torch.equal(g0, g1), flags
+
+
 def test_small_model_stn_disabled():
     check_case(run_case(B=3, imgh=40, imgw=32, u=64, tds=32, max_len=6, stn=False, dropout=False), "nostn")
 

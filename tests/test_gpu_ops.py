@@ -412,13 +412,13 @@ def test_persistent_lstm_reports_a_lost_cluster():
     from crnn_mi355x.engine import Engine
     from crnn_mi355x.native import CrnnError
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    eng = Engine(16, imgh=12, imgw=32, max_len=3, time_dense_size=64, n_units=256, dropout=False, precision="bf16s")   # T = 8: 2 clusters of 8
+    eng = Engine(16, imgh=40, imgw=32, max_len=6, time_dense_size=64, n_units=256, dropout=False, precision="bf16s")   # T = 22: 2 clusters of 8
     assert eng._rnn_giveups is not None
     from oracle import model as M
-    cfg = M.Config(imgh=12, imgw=32, max_len=3, time_dense_size=64, n_units=256)
+    cfg = M.Config(imgh=40, imgw=32, max_len=6, time_dense_size=64, n_units=256)
     p, bn = M.init_params(cfg, seed=3, dtype=np.float64)
     eng.set_params(M.randomize_params(cfg, p), bn)
-    x = np.random.RandomState(0).normal(size=(16, 12, 32, 1)).astype(np.float32)
+    x = np.random.RandomState(0).normal(size=(16, 40, 32, 1)).astype(np.float32)
     y0 = eng.forward(x, train=False).clone()
     eng.check_rnn_status()                                                     # clean run: no exception
     side = torch.cuda.Stream()
@@ -505,6 +505,94 @@ def test_bigru_fwd_bwd(B, T, u, din):
         assert_close(dzh.reshape(B * T, G).sum(0), db, rtol=2e-4, atol=1e-4, what=f"db dir{d}")
         rhh = np.swapaxes(host(rh[d]).astype(np.float64), 0, 1)
         assert_close(rhh.reshape(B * T, u).T @ dzh.reshape(B * T, G)[:, 2 * u:], dU[:, 2 * u:], rtol=2e-4, atol=1e-4, what=f"dUh dir{d}")
+
+
+def _gru_persist_case(B, T, u, bf16, flags, seed, reps=1):
+    """One Bidirectional(GRU) layer forward + BPTT through the per-step kernels (crnn_gru_*_ex: 2 T launches per pass) and through the
+    persistent ones (crnn_gru_*_persist); returns both result sets as host arrays + the status."""
+    rs = np.random.RandomState(seed)
+    G = 3 * u
+    U = [rs.normal(size=(u, G)) * 0.15 for _ in range(2)]
+    xw = [dev(rs.normal(size=(T, B, G)) * 0.8) for _ in range(2)]
+    gd = dev(rs.normal(size=(T, B, 2 * u)))
+    if bf16:
+        ut = [_to_bf16_dev(U[d].T) for d in range(2)]; Ud = [_to_bf16_dev(U[d]) for d in range(2)]
+    else:
+        ut = [dev(U[d].T) for d in range(2)]; Ud = [dev(U[d]) for d in range(2)]
+    dt = 1 if bf16 else 0
+    nbytes = L().crnn_lstm_persist_xbuf_bytes(T, B, u, dt)
+    xbuf = torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device="cuda")
+    out = {}
+    for kind in ("step", "persist"):
+        hcat = zeros(T, B, 2 * u); gt = [zeros(T, B, G) for _ in range(2)]; rh = [zeros(T, B, u) for _ in range(2)]
+        dz = [zeros(T, B, G) for _ in range(2)]; dh = [zeros(B, u) for _ in range(2)]; dhp = [zeros(B, u) for _ in range(2)]
+        hb = ctypes.c_void_p(hcat.data_ptr() + 4 * u); gb = ctypes.c_void_p(gd.data_ptr() + 4 * u)
+        status = 0
+        if kind == "step":
+            ok(L().crnn_gru_fwd_ex(P(xw[0]), P(xw[1]), P(ut[0]), P(ut[1]), P(hcat), hb, 2 * u, P(gt[0]), P(gt[1]), P(rh[0]), P(rh[1]), T, B, u, dt, S()))
+            ok(L().crnn_gru_bwd_ex(P(Ud[0]), P(Ud[1]), P(hcat), hb, 2 * u, P(gt[0]), P(gt[1]), P(gd), gb, 2 * u, P(dz[0]), P(dz[1]), P(dh[0]), P(dh[1]),
+                                   P(dhp[0]), P(dhp[1]), T, B, u, dt, S()))
+        else:
+            for _ in range(reps):       # back-to-back launches reuse (and re-poison) the same exchange ring
+                ok(L().crnn_gru_fwd_persist(P(xw[0]), P(xw[1]), P(ut[0]), P(ut[1]), P(hcat), hb, 2 * u, P(gt[0]), P(gt[1]), P(rh[0]), P(rh[1]), T, B, u, dt,
+                                            P(xbuf), nbytes, flags, S()))
+                status |= int(xbuf[4].item()) != -1
+                ok(L().crnn_gru_bwd_persist(P(Ud[0]), P(Ud[1]), P(hcat), hb, 2 * u, P(gt[0]), P(gt[1]), P(gd), gb, 2 * u, P(dz[0]), P(dz[1]), T, B, u, dt,
+                                            P(xbuf), nbytes, flags, S()))
+                status |= int(xbuf[4].item()) != -1
+            status |= int(xbuf[0].item()) != 0
+        out[kind] = dict(h=host(hcat), g=[host(t) for t in gt], rh=[host(t) for t in rh], dz=[host(t) for t in dz], status=status)
+    return out
+
+
+@pytest.mark.parametrize("B,T,u,bf16,flags", [
+    (5, 7, 64, False, 0), (33, 6, 128, False, 0), (70, 9, 256, False, 0), (20, 9, 128, True, 0), (37, 8, 256, True, 0), (256, 52, 256, True, 0),
+    (256, 52, 256, True, 0x100), (64, 102, 256, False, 0x100), (18, 5, 512, True, 0), (600, 4, 128, True, 0), (64, 9, 256, False, 0x100)])
+def test_persistent_gru_is_bit_identical_to_the_step_kernels(B, T, u, bf16, flags):
+    """One launch per layer and pass (cluster of u/32 workgroups per batch tile, recurrent weights + hidden state / gradient carry in
+    registers, two all-gathers per step through the sentinel ring) must reproduce the 2T-launch path bit for bit: forward (z, r, hh gates,
+    r*h_prev, h) and BPTT (dz), fp32 and bf16 recurrent products, ragged batch tiles, both workgroup -> cluster maps, T up to the IAM
+    shape's 102, a batch that needs several launches (600 rows)."""
+    r = _gru_persist_case(B, T, u, bf16, flags, seed=B + T + u)
+    a, b = r["step"], r["persist"]
+    assert b["status"] == 0, "a bounded wait of the persistent kernel gave up"
+    assert np.array_equal(a["h"], b["h"]), "h: max diff %g" % np.abs(a["h"] - b["h"]).max()
+    for d in range(2):
+        assert np.array_equal(a["g"][d], b["g"][d]), "gates dir%d: max diff %g" % (d, np.abs(a["g"][d] - b["g"][d]).max())
+        assert np.array_equal(a["rh"][d], b["rh"][d]), "r*h dir%d" % d
+        assert np.array_equal(a["dz"][d], b["dz"][d]), "dz dir%d: max diff %g" % (d, np.abs(a["dz"][d] - b["dz"][d]).max())
+    assert np.isfinite(b["h"]).all() and np.abs(b["dz"][0]).max() > 0 and np.abs(b["h"]).max() > 0
+
+
+def test_persistent_gru_repeated_launches_and_oracle():
+    """Four forward + BPTT launches back to back on one exchange ring stay bit-identical to the step kernels; the fp32 forward also
+    matches the fp64 oracle cell (ops.gru_fwd); unsupported widths are refused."""
+    r = _gru_persist_case(21, 11, 64, False, 0, seed=5, reps=4)
+    assert r["persist"]["status"] == 0
+    assert np.array_equal(r["step"]["h"], r["persist"]["h"]) and np.array_equal(r["step"]["dz"][1], r["persist"]["dz"][1])
+    B, T, u, din = 19, 9, 64, 24
+    rs = np.random.RandomState(78)
+    x = rs.normal(size=(B, T, din)); G = 3 * u
+    Wt = [rs.normal(size=(din, G)) * 0.3 for _ in range(2)]
+    U = [rs.normal(size=(u, G)) * 0.15 for _ in range(2)]
+    bb = [rs.normal(size=G) * 0.2 for _ in range(2)]
+    tm = lambda a: np.ascontiguousarray(np.swapaxes(a, 0, 1))
+    xw = [dev(tm(x @ Wt[d] + bb[d])) for d in range(2)]
+    ut = [dev(U[d].T) for d in range(2)]
+    nbytes = L().crnn_lstm_persist_xbuf_bytes(T, B, u, 0)
+    xbuf = torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device="cuda")
+    hcat = zeros(T, B, 2 * u); gt = [zeros(T, B, G) for _ in range(2)]; rh = [zeros(T, B, u) for _ in range(2)]
+    ok(L().crnn_gru_fwd_persist(P(xw[0]), P(xw[1]), P(ut[0]), P(ut[1]), P(hcat), ctypes.c_void_p(hcat.data_ptr() + 4 * u), 2 * u, P(gt[0]), P(gt[1]),
+                                P(rh[0]), P(rh[1]), T, B, u, 0, P(xbuf), nbytes, 0, S()))
+    hh = host(hcat)
+    assert int(xbuf[4].item()) == -1 and int(xbuf[0].item()) == 0
+    for d in range(2):
+        h, c = ops.gru_fwd(x, Wt[d], U[d], bb[d], reverse=(d == 1))
+        assert_close(hh[:, :, d * u:(d + 1) * u], tm(h), rtol=1e-4, atol=1e-5, what=f"h dir{d}")
+        assert_close(host(gt[d]), tm(c[4]), rtol=1e-4, atol=1e-5, what=f"gates dir{d}")
+    assert L().crnn_gru_persist_supported(192, 0) == -3 and L().crnn_gru_persist_supported(64, 1) == -3
+    assert L().crnn_gru_fwd_persist(P(xw[0]), P(xw[1]), P(ut[0]), P(ut[1]), P(hcat), P(hcat), 2 * u, P(gt[0]), P(gt[1]), P(rh[0]), P(rh[1]), T, B, u, 0,
+                                    P(xbuf), 64, 0, S()) == -2
 
 
 # ------------------------------------------------------------------------------------------------ softmax / CTC / decode
