@@ -1172,6 +1172,15 @@ extern "C" int crnn_bn_bwd_ex(const void* x, const void* g, const float* bnstate
   return bn_bwd_typed<float>((const float*)x, (const float*)g, bnstate, gamma, (float*)dx, dgamma, dbeta, scratch_partials, coef, B, H, W, C,
                              ph, pw, rate, seed, layer, stream);
 }
+// Second stage of a BatchNorm backward whose statistics pass ran elsewhere (crnn_gemm_wres_bf16_bnstats): partials [nparts][2][C] = partial
+// sums of gy and gy * xhat over `count` elements per channel -> dgamma, dbeta and coef = [mean(gy) | mean(gy * xhat)] (what
+// crnn_dwconv3x3_bwd_stream / crnn_dwconv3x3_bwd_fused apply).  The finalize launch of crnn_bn_bwd_ex, on its own.
+extern "C" int crnn_bn_bwd_finalize(const float* partials, int nparts, int C, long count, float* dgamma, float* dbeta, float* coef, hipStream_t stream) {
+  if (!partials || nparts < 1 || C < 1 || count < 1 || !dgamma || !dbeta || !coef) return CRNN_ERR_ARG;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, RED_CH)), dim3(RED_CH, RED_PL), 0, stream, partials, nparts, C, 1.0 / (double)count, dgamma, dbeta, coef);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
 extern "C" int crnn_bn_bwd(const float* x, const float* g, const float* bnstate, const float* gamma, float* dx,
                            float* dgamma, float* dbeta, float* scratch_partials, float* coef, int B, int H, int W, int C,
                            int ph, int pw, float rate, uint64_t seed, uint32_t layer, hipStream_t stream) {

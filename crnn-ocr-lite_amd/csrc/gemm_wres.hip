@@ -41,6 +41,11 @@ struct WresParams {
   int Q;         // stripes processed concurrently per XCD (workgroups per XCD / S)
   int nxcd;      // XCDs the grid spans (grid = nxcd * Q * S)
   const float* cscale; const float* cshift;   // EPI instantiation: per-output-channel epilogue Y = ReLU6(acc * cscale[n] + cshift[n])
+  // BNS instantiation (Y = the gradient w.r.t. a = ReLU6(BN(d)) of a depthwise-separable block): the storer waves also take the statistics
+  // of that BatchNorm's backward pass, sum(gy) and sum(gy * xhat) per channel with gy = Y where 0 < d * scale + shift < 6, from the
+  // staged stripe and the matching rows of d -- the stand-alone statistics pass (bn_bwd_kernel<1>) would read Y and d again
+  const bf16_t* D; const float* bnstate;      // d [M][N]; [mean | var | scale | shift] x N
+  float* stats;                               // [2 * Q * nxcd][2][N] partial sums, one row per storer wave and stripe lane
 #ifdef CRNN_WRES_EXP
   unsigned long long* trace;   // ablation build only: [64 iterations][4] s_memrealtime stamps of workgroup 0's first loader wave
   int exp;       // unused (the ablation mask is the compile-time value of CRNN_WRES_EXP: 1 no pixel loads, 2 no fragment reads, 8 no MFMAs, 4 no stores, 32 free-running loaders only)
@@ -159,7 +164,109 @@ __device__ __forceinline__ void wres_compute(const unsigned char* smem, unsigned
   }
 }
 
-template <int KCH, int NLW, bool EPI = false>   // K / 64, loader waves, folded-BatchNorm epilogue
+// Storer wave of the BNS instantiation.  Same drain as below (16 pieces of 4 rows x 256 bytes per wave and stripe, a share of them after
+// every stage of the next stripe), plus: the matching 16-byte chunks of d are loaded two piece steps ahead, and each drained chunk adds
+// its 8 channels' gy and gy * xhat to per-lane sums kept over the whole launch (a lane always sees the same 8 channels).  The steady
+// state is straight-line (M % 128 == 0: unguarded stores; loads past the end re-read a valid row) so that the wait-count insertion can
+// count the loads in flight across the stores.  One partial row per storer wave: the same sums as bn_bwd_kernel<1> in another order.
+template <int KCH>
+__device__ __forceinline__ void wres_store_bnstats(const WresParams& p, const unsigned char* outs, int sw, int lane, int slice, int first, int step,
+                                                   int mine, long srow) {
+  constexpr int PP = 16 / KCH;                                 // pieces per storer wave and stage
+  constexpr int PF = 2;                                        // piece steps the loads of d run ahead
+  const int rsub = lane >> 4, c = lane & 15;
+  const int ch0 = slice * 128 + c * 8;
+  const int total = mine * KCH, nps = total - KCH;             // piece steps of the steady state (stripes 0 .. mine-2)
+  float sc[8], sh[8], mu[8], inv[8], ss[8], qq[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    mu[e] = p.bnstate[ch0 + e];
+    inv[e] = 1.0f / sqrtf(p.bnstate[p.N + ch0 + e] + 1e-3f);   // BN_EPS, the spelling of bn_bwd_kernel
+    sc[e] = p.bnstate[2 * p.N + ch0 + e]; sh[e] = p.bnstate[3 * p.N + ch0 + e];
+    ss[e] = 0.f; qq[e] = 0.f;
+  }
+  auto row_of = [&](int stripe, int piece) { return (long)(first + stripe * step) * 128 + (sw * 16 + piece) * 4 + rsub; };
+  auto load_d = [&](int ps, u32x4 (&xv)[PP]) {
+    ps = ps < nps ? ps : (nps > 0 ? nps - 1 : 0);              // past the end: a valid address, the data is not used
+    const int stripe = ps / KCH, t = ps % KCH;
+#pragma unroll
+    for (int u = 0; u < PP; ++u) xv[u] = *reinterpret_cast<const u32x4*>(p.D + row_of(stripe, t * PP + u) * p.N + ch0);
+  };
+  auto accum = [&](const u32x4& gv, const u32x4& xv) {
+#pragma clang fp contract(off)
+    const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, xw[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int e = 2 * w + hf;
+        const float xx = __uint_as_float(hf ? (xw[w] & 0xffff0000u) : (xw[w] << 16));
+        const float gg = __uint_as_float(hf ? (gw[w] & 0xffff0000u) : (gw[w] << 16));
+        const float t = fmaf(xx, sc[e], sh[e]);
+        const float gy = (t > 0.f && t < 6.f) ? gg : 0.f;
+        const float xh = (xx - mu[e]) * inv[e];
+        ss[e] += gy;
+        qq[e] = fmaf(gy, xh, qq[e]);
+      }
+  };
+  auto piece_step = [&](int stripe, int t, const u32x4 (&xv)[PP]) {   // pieces t*PP .. of the finished stripe `stripe`
+    const unsigned char* ob = outs + (stripe & 1) * kOut;
+    u32x4 v[PP];
+#pragma unroll
+    for (int u = 0; u < PP; ++u) {
+      const int r = (sw * 16 + t * PP + u) * 4 + rsub;
+      v[u] = *reinterpret_cast<const u32x4*>(ob + r * 256 + ((c ^ (r & 15)) * 16));
+    }
+#pragma unroll
+    for (int u = 0; u < PP; ++u) *reinterpret_cast<u32x4*>(p.Y + row_of(stripe, t * PP + u) * p.N + ch0) = v[u];
+#pragma unroll
+    for (int u = 0; u < PP; ++u) accum(v[u], xv[u]);
+  };
+  u32x4 xb[PF][PP];
+#pragma unroll
+  for (int k = 0; k < PF; ++k) load_d(k, xb[k]);
+  for (int jb = 0; jb < KCH; ++jb) __builtin_amdgcn_s_barrier();   // barriers 0 .. KCH-1: no stripe has finished yet
+  int ps = 0;
+  for (; ps + PF <= nps; ps += PF) {
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      __builtin_amdgcn_s_barrier();
+      // a stage's arithmetic stays in its stage: hoisted above the barrier (it does not depend on the staged tile) the next stage's
+      // use of d would wait for loads issued one stage ago instead of two
+      __builtin_amdgcn_sched_barrier(0);
+      piece_step((ps + k) / KCH, (ps + k) % KCH, xb[k]);
+      load_d(ps + k + PF, xb[k]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (ps < nps) {                                              // nps odd: one more steady stage, its chunks of d are in buffer 0
+    __builtin_amdgcn_s_barrier();
+    piece_step(ps / KCH, ps % KCH, xb[0]);
+  }
+  __builtin_amdgcn_s_barrier();                                // barrier `total`: the last stripe is staged; everything at once
+  for (int t = 0; t < KCH; ++t) {
+    u32x4 xv[PP];
+    const int stripe = mine - 1;
+#pragma unroll
+    for (int u = 0; u < PP; ++u) xv[u] = *reinterpret_cast<const u32x4*>(p.D + row_of(stripe, t * PP + u) * p.N + ch0);
+    piece_step(stripe, t, xv);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    ss[e] += __shfl_xor(ss[e], 16, 64); qq[e] += __shfl_xor(qq[e], 16, 64);
+    ss[e] += __shfl_xor(ss[e], 32, 64); qq[e] += __shfl_xor(qq[e], 32, 64);
+  }
+  if (lane < 16) {
+    float* r0 = p.stats + (srow * 2 + 0) * p.N + ch0;
+    float* r1 = p.stats + (srow * 2 + 1) * p.N + ch0;
+    *reinterpret_cast<float4*>(r0) = make_float4(ss[0], ss[1], ss[2], ss[3]);
+    *reinterpret_cast<float4*>(r0 + 4) = make_float4(ss[4], ss[5], ss[6], ss[7]);
+    *reinterpret_cast<float4*>(r1) = make_float4(qq[0], qq[1], qq[2], qq[3]);
+    *reinterpret_cast<float4*>(r1 + 4) = make_float4(qq[4], qq[5], qq[6], qq[7]);
+  }
+}
+
+template <int KCH, int NLW, bool EPI = false, bool BNS = false>   // K / 64, loader waves, folded-BatchNorm epilogue, BatchNorm-backward statistics
 __global__ __launch_bounds__(384 + 64 * NLW) void gemm_wres_kernel(WresParams p) {
   constexpr int kIPS = 16 / NLW;            // LDS-DMA instructions per loader wave and stage
   constexpr int RR = EPI ? kR - 1 : kR;     // ring stages (the epilogue table takes the 160 KiB budget over: one stage less)
@@ -179,7 +286,17 @@ __global__ __launch_bounds__(384 + 64 * NLW) void gemm_wres_kernel(WresParams p)
   const int step = p.Q * p.nxcd;                              // stripe stride between this workgroup's iterations
   const int first = q * p.nxcd + x;
   const int mine = first < p.stripes ? (p.stripes - first + step - 1) / step : 0;
-  if (mine <= 0) return;
+  if (mine <= 0) {
+    if constexpr (BNS) {                                      // no stripe: this workgroup's statistics rows must still read as zero
+      if (wave >= 4 + NLW && lane < 16) {
+        const long row = (long)(q * p.nxcd + x) * 2 + (wave - 4 - NLW);
+        float4* r0 = reinterpret_cast<float4*>(p.stats + (row * 2 + 0) * p.N + slice * 128 + lane * 8);
+        float4* r1 = reinterpret_cast<float4*>(p.stats + (row * 2 + 1) * p.N + slice * 128 + lane * 8);
+        r0[0] = r0[1] = r1[0] = r1[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    return;
+  }
   const int total = mine * KCH;
   const float* epi = nullptr;
   if constexpr (EPI) {                                        // the slice's epilogue scale | shift after the staging tiles
@@ -189,6 +306,9 @@ __global__ __launch_bounds__(384 + 64 * NLW) void gemm_wres_kernel(WresParams p)
     epi = tab;
   }
 
+  if constexpr (BNS) {
+    if (wave >= 4 + NLW) { wres_store_bnstats<KCH>(p, outs, wave - 4 - NLW, lane, slice, first, step, mine, (q * p.nxcd + x) * 2 + (wave - 4 - NLW)); return; }
+  }
   if (wave >= 4 + NLW) {
     // ------------------------------------------------------------------ storer waves: drain the staged stripes, a piece per stage
     const int sw = wave - 4 - NLW;
@@ -441,11 +561,11 @@ __global__ __launch_bounds__(512) void gemm_wres_fwd_kernel(WresFwdParams p) {
   }
 }
 
-template <int KCH, int NLW, bool EPI = false>
+template <int KCH, int NLW, bool EPI = false, bool BNS = false>
 int launch_wres(const WresParams& p, int grid, hipStream_t stream) {
   const int lds = (EPI ? kR - 1 : kR) * kStage + 2 * kOut + (EPI ? 1024 : 0);
-  CRNN_LDS_ATTR((gemm_wres_kernel<KCH, NLW, EPI>), lds);
-  hipLaunchKernelGGL((gemm_wres_kernel<KCH, NLW, EPI>), dim3(grid), dim3(384 + 64 * NLW), lds, stream, p);
+  CRNN_LDS_ATTR((gemm_wres_kernel<KCH, NLW, EPI, BNS>), lds);
+  hipLaunchKernelGGL((gemm_wres_kernel<KCH, NLW, EPI, BNS>), dim3(grid), dim3(384 + 64 * NLW), lds, stream, p);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
@@ -459,13 +579,7 @@ extern "C" int crnn_gemm_wres_supported(int N, int K) {
 
 // Y[M][N] (bf16) = X[M][K] (bf16, row stride K) . W[N][K]^T (bf16, row stride K), weights resident in registers.
 // One persistent workgroup per CU (512 threads: 4 MFMA waves + 2 LDS-DMA loader waves + 2 storer waves, 160 KiB of LDS).
-static int gemm_wres_impl(const void* X, const void* W, void* Y, int M, int N, int K, const float* cscale, const float* cshift, hipStream_t stream) {
-  if (M <= 0 || N <= 0 || K <= 0) return CRNN_ERR_ARG;
-  CRNN_TRY(crnn_gemm_wres_supported(N, K));
-  if ((((uintptr_t)X | (uintptr_t)W | (uintptr_t)Y) & 15)) return CRNN_ERR_UNSUPPORTED;
-  if ((long)M * (K > N ? K : N) >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;     // 32-bit row offsets
-  WresParams p;
-  p.X = (const bf16_t*)X; p.W = (const bf16_t*)W; p.Y = (bf16_t*)Y; p.M = M; p.N = N; p.K = K;
+static int wres_geom(int M, int N, WresParams& p) {             // -> grid
   p.stripes = cdiv(M, 128); p.S = N / 128;
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
@@ -475,7 +589,22 @@ static int gemm_wres_impl(const void* X, const void* W, void* Y, int M, int N, i
   p.Q = per_xcd / p.S;
   const int need = cdiv(p.stripes, p.nxcd);                    // stripe lanes that have any work
   if (p.Q > need) p.Q = need;
-  const int grid = p.nxcd * p.Q * p.S;
+  return p.nxcd * p.Q * p.S;
+}
+static int gemm_wres_impl(const void* X, const void* W, void* Y, int M, int N, int K, const float* cscale, const float* cshift, hipStream_t stream,
+                          const void* D = nullptr, const float* bnstate = nullptr, float* stats = nullptr) {
+  if (M <= 0 || N <= 0 || K <= 0) return CRNN_ERR_ARG;
+  CRNN_TRY(crnn_gemm_wres_supported(N, K));
+  if ((((uintptr_t)X | (uintptr_t)W | (uintptr_t)Y) & 15)) return CRNN_ERR_UNSUPPORTED;
+  if ((long)M * (K > N ? K : N) >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;     // 32-bit row offsets
+  WresParams p;
+  p.X = (const bf16_t*)X; p.W = (const bf16_t*)W; p.Y = (bf16_t*)Y; p.M = M; p.N = N; p.K = K;
+  p.D = (const bf16_t*)D; p.bnstate = bnstate; p.stats = stats;
+  const int grid = wres_geom(M, N, p);
+  if (D) {                                                     // storer waves take the BatchNorm-backward statistics (K = 256 | 512 here)
+    if (K == 256) return launch_wres<4, 2, false, true>(p, grid, stream);
+    return launch_wres<8, 2, false, true>(p, grid, stream);
+  }
 #ifdef CRNN_WRES_EXP
   p.exp = crnn_knob("CRNN_WRES_EXP", 0);
   { const char* e = getenv("CRNN_WRES_TRACE"); p.trace = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
@@ -498,6 +627,28 @@ static int gemm_wres_impl(const void* X, const void* W, void* Y, int M, int N, i
 }
 extern "C" int crnn_gemm_wres_bf16(const void* X, const void* W, void* Y, int M, int N, int K, hipStream_t stream) {
   return gemm_wres_impl(X, W, Y, M, N, K, nullptr, nullptr, stream);
+}
+// crnn_gemm_wres_bf16 for the data gradient da = dq . W^T of a depthwise-separable block (utils.py:45-49 backwards) that also takes the
+// statistics pass of the BatchNorm in front of the pointwise convolution: stat_partials [crnn_gemm_wres_bnstats_rows(M, N, K)][2][N]
+// = per-channel partial sums of gy and gy * xhat, gy = da where 0 < d * scale + shift < 6 (ReLU6 gate), xhat = (d - mean) / sqrt(var + eps),
+// d [M][N] bf16 = the BatchNorm's input, bnstate = [mean | var | scale | shift] x N.  Feed them to crnn_bn_bwd_finalize.  Shapes: as
+// crnn_gemm_wres_bf16 with whole 128-row stripes (M % 128 == 0) and K in {256, 512}; -3 otherwise (run crnn_bn_bwd_ex's statistics pass).
+extern "C" int crnn_gemm_wres_bnstats_supported(long M, int N, int K) {
+  return (M > 0 && M % 128 == 0 && M <= 0x7fffffffL && M * (long)(K > N ? K : N) < (1L << 31) && (K == 256 || K == 512) &&
+          crnn_gemm_wres_supported(N, K) == CRNN_OK) ? CRNN_OK : CRNN_ERR_UNSUPPORTED;
+}
+extern "C" int crnn_gemm_wres_bnstats_rows(long M, int N, int K) {
+  if (crnn_gemm_wres_bnstats_supported(M, N, K) != CRNN_OK) return 0;
+  WresParams p;
+  wres_geom((int)M, N, p);
+  return 2 * p.Q * p.nxcd;
+}
+extern "C" int crnn_gemm_wres_bf16_bnstats(const void* X, const void* W, void* Y, long M, int N, int K, const void* d, const float* bnstate,
+                                           float* stat_partials, hipStream_t stream) {
+  if (!d || !bnstate || !stat_partials) return CRNN_ERR_ARG;
+  CRNN_TRY(crnn_gemm_wres_bnstats_supported(M, N, K));
+  if ((((uintptr_t)d | (uintptr_t)stat_partials | (uintptr_t)bnstate) & 15)) return CRNN_ERR_UNSUPPORTED;
+  return gemm_wres_impl(X, W, Y, (int)M, N, K, nullptr, nullptr, stream, d, bnstate, stat_partials);
 }
 // Inference forward of a pointwise convolution with the BatchNorm + ReLU6 that follows folded in (utils.py:49-51, learning_phase 0):
 // Y[M][N] (bf16) = ReLU6((X . W^T) * scale[n] + shift[n]), out_bnstate = [mean|var|scale|shift] of that BatchNorm (crnn_bn_infer_state).

@@ -146,6 +146,7 @@ Plan make_plan(const crnn_config* c) {
     maxparts = lmax(maxparts, (long)crnn_pwconv_stat_rows(M) * 2L * co);
     maxparts = lmax(maxparts, (long)crnn_pwconv_fwd_wres_rows(M, co, ci) * 2L * co);   // one row per IO wave and stripe lane: more rows than tiles at small batches
     maxparts = lmax(maxparts, (long)crnn_bn_bwd_chunks(M) * 2L * lmax(ci, co));
+    maxparts = lmax(maxparts, (long)crnn_gemm_wres_bnstats_rows(M, ci, co) * 2L * ci);
   }
   const long TB = (long)d.T * B;
   P.add("dn1", TB * d.tds);
@@ -747,6 +748,7 @@ int backward_bottom(const Ctx& c, const float* x, uint64_t seed, hipStream_t aux
     const int dtd = c.dt("d" + p), dtq = c.dt("q" + p);   // dtq == storage of the incoming gradient (gdt)
     const bool fused_dw = i > 1 && dtd == CRNN_BF16 && c.dt("x" + std::to_string(i - 1)) == CRNN_BF16 && !(cfg->flags & CRNN_FLAG_NO_DW_BWD_FUSION) &&
                           crnn_dwconv_bwd_fused_supported(H, W, ci) == CRNN_OK;
+    int bn1_stats_rows = 0;                               // > 0: the data-gradient GEMM left the BatchNorm-1 backward statistics in `partials`
     CRNN_TRY(fj.wait(gB_free)); gB_free = nullptr;        // gB is written next
     CRNN_TRY(crnn_bn_bwd_ex(c.w("q" + p), gA, c.w("bn2s" + p), c.p(bp + "_bn2_g"), gB, c.g(bp + "_bn2_g"), c.g(bp + "_bn2_b"), c.w("partials"),
                             c.w("coef"), B, H, W, co, kBlocks[i - 1].ph, kBlocks[i - 1].pw, cfg->dropout ? kDropBlock : 0.f, seed, (uint32_t)i, dtq, stream));
@@ -772,7 +774,13 @@ int backward_bottom(const Ctx& c, const float* x, uint64_t seed, hipStream_t aux
         int dtw = CRNN_F32;
         const float* wsh = weight_operand(c, 1, c.p(bp + "_pw"), &dtw);
         if (dtw == CRNN_BF16) {
-          rc = crnn_gemm_wres_bf16(gB, wsh, gA, (int)M, ci, co, stream);       // weights resident in registers
+          // weights resident in registers; where the fused depthwise stage follows, the storer waves also take the statistics pass of
+          // the depthwise BatchNorm's backward (they hold the finished da stripe: the stand-alone pass would read da and d again)
+          if (fused_dw && !(cfg->flags & CRNN_FLAG_NO_BN_STATS_FUSION) && crnn_gemm_wres_bnstats_supported(M, ci, co) == CRNN_OK) {
+            rc = crnn_gemm_wres_bf16_bnstats(gB, wsh, gA, M, ci, co, c.w("d" + p), c.w("bn1s" + p), c.w("partials"), stream);
+            bn1_stats_rows = (rc == CRNN_OK) ? crnn_gemm_wres_bnstats_rows(M, ci, co) : 0;
+          }
+          if (rc == CRNN_ERR_UNSUPPORTED) rc = crnn_gemm_wres_bf16(gB, wsh, gA, (int)M, ci, co, stream);
           if (rc == CRNN_ERR_UNSUPPORTED) rc = crnn_gemm_nt_bf16(gB, wsh, gA, (int)M, ci, co, stream);
         }
       }
@@ -782,8 +790,11 @@ int backward_bottom(const Ctx& c, const float* x, uint64_t seed, hipStream_t aux
     const float* xin = (i == 1) ? c.w("x0") : c.w("x" + std::to_string(i - 1));
     if (fused_dw) {
       // depthwise stage in one kernel: BatchNorm statistics pass, then BN-backward pass 2 + depthwise weight and data gradients together
-      CRNN_TRY(crnn_bn_bwd_ex(c.w("d" + p), gA, c.w("bn1s" + p), c.p(bp + "_bn1_g"), nullptr, c.g(bp + "_bn1_g"), c.g(bp + "_bn1_b"), c.w("partials"),
-                              c.w("coef"), B, H, W, ci, 1, 1, 0.f, 0, 0, dtd, stream));
+      if (bn1_stats_rows > 0)
+        CRNN_TRY(crnn_bn_bwd_finalize(c.w("partials"), bn1_stats_rows, ci, M, c.g(bp + "_bn1_g"), c.g(bp + "_bn1_b"), c.w("coef"), stream));
+      else
+        CRNN_TRY(crnn_bn_bwd_ex(c.w("d" + p), gA, c.w("bn1s" + p), c.p(bp + "_bn1_g"), nullptr, c.g(bp + "_bn1_g"), c.g(bp + "_bn1_b"), c.w("partials"),
+                                c.w("coef"), B, H, W, ci, 1, 1, 0.f, 0, 0, dtd, stream));
       CRNN_TRY(fj.wait(gC_free)); gC_free = nullptr;      // gC is written next
       int rc = CRNN_ERR_UNSUPPORTED;
       if (!(cfg->flags & CRNN_FLAG_DW_TILE_KERNEL))         // rows streamed through LDS where the shape rule holds (dwconv_bwd_stream.hip)

@@ -18,7 +18,7 @@ constexpr size_t kStatusBytes = 65536;        // trace build: [64..) = per-step 
 constexpr size_t kStatusBytes = 256;          // byte 0: sticky give-up counter, byte 16: per-launch status; the exchange tiles follow
 #define RNN_TRACE(slot) do {} while (0)
 #endif
-constexpr unsigned kSpinLimit = 1u << 21;
+constexpr unsigned long long kSpinTicks = 200ull * 1000 * 1000;   // a wait gives up after 2 s of the constant 100 MHz clock (s_memrealtime)
 constexpr size_t kLaunchStatusOff = 16;       // the fill of every launch starts here (the counter in front of it survives)
 // cache policy of the exchange (aux bits of the buffer instructions: 1 = sc0, 16 = sc1).  Default: write-through stores and
 // L1-bypassing loads at device scope (works for any placement).  Other values exist for scripts/lstm_xcd_bench.py only.
@@ -55,6 +55,7 @@ __device__ __forceinline__ void gather_tile(const void* tile, int tid, unsigned*
   for (int i0 = 0; i0 < NLD; i0 += GRP) {
     u32x4 v[GRP];
     unsigned spins = 0;
+    unsigned long long t0 = 0;
     for (;;) {
       bool ok = true;
       asm volatile("" ::: "memory");   // the tile changes under us: every pass must re-issue its loads
@@ -67,7 +68,15 @@ __device__ __forceinline__ void gather_tile(const void* tile, int tid, unsigned*
         }
       }
       if (__all(ok) || dead) break;
-      if (++spins > kSpinLimit) {
+      // bounded wait: the clock is read once per 1024 polls (a hand-off normally completes within a few), 2 s after the first reading
+      // the wave stops waiting
+      bool expired = false;
+      if ((++spins & 1023u) == 0) {
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        if (t0 == 0) t0 = now;
+        else expired = now - t0 > kSpinTicks;
+      }
+      if (expired) {
         if ((tid & 63) == 0) {
           atomicAnd(status + kLaunchStatusOff / 4, ~1u);   // the per-launch word starts as all ones (one fill covers it and the ring)
           atomicAdd(status, 1u);                           // sticky: never reset by a launch

@@ -53,6 +53,9 @@ typedef struct {
                                          GEMM (crnn_gemm_bf16_ex / crnn_pwconv_bnrelu6_*) instead of the streaming kernels (crnn_pwconv_bnrelu6_fwd_wres,
                                          crnn_gemm_wres_bf16, crnn_pwconv_bnrelu6_wgrad_stream).  Same products and data gradients bit for bit; the
                                          BatchNorm-2 statistics and the weight gradients are the same sums in another order (fp32 round-off) */
+#define CRNN_FLAG_NO_BN_STATS_FUSION 128 /* bf16-storage training: statistics pass of the depthwise BatchNorm's backward as a kernel of its own
+                                         (crnn_bn_bwd_ex) instead of inside the data-gradient GEMM (crnn_gemm_wres_bf16_bnstats); same data gradients
+                                         bit for bit, the BatchNorm-1 gradients / coefficients are the same sums in another order */
 #define CRNN_FLAG_RNN_LINEAR_CLUSTERS 64 /* persistent BPTT launches: cluster members = consecutive workgroup ids (dealt over all XCDs, what the
                                          forward launches always use) instead of the XCD-local map; bit-identical */
 #define CRNN_FLAG_RNN_STEP_KERNELS 1  /* LSTM / GRU recurrences as one (two) launch(es) per timestep (crnn_lstm_*_ex, crnn_gru_*_ex) instead of
@@ -328,6 +331,18 @@ int crnn_gemm_nt_bf16(const void* X, const void* W, void* Y, int M, int N, int K
  * Supported (else -3): N % 128 == 0, N <= 1024, K in {64, 128, 256, 512}, 16-byte aligned pointers. */
 int crnn_gemm_wres_supported(int N, int K);
 int crnn_gemm_wres_bf16(const void* X, const void* W, void* Y, int M, int N, int K, crnn_stream_t stream);
+/* The same product as the data gradient da = dq . W^T of a depthwise-separable block (utils.py:45-49 backwards), with the statistics pass of
+ * the backward of the BatchNorm in front of the pointwise convolution taken by the kernel's storer waves from the staged result and the
+ * matching rows of d (the BatchNorm's input, bf16 [M][N]; bnstate = [mean | var | scale | shift] x N): stat_partials
+ * [crnn_gemm_wres_bnstats_rows(M, N, K)][2][N] = partial sums of gy and gy * xhat, gy = da where 0 < d * scale + shift < 6.  Saves the
+ * stand-alone pass's second read of da and d.  Y bit-identical to crnn_gemm_wres_bf16; the statistics are crnn_bn_bwd_ex's sums in
+ * another order.  Shapes: M % 128 == 0, K in {256, 512}, N % 128 == 0 (-3 otherwise).  crnn_bn_bwd_finalize turns the partials into
+ * dgamma, dbeta and coef = [mean(gy) | mean(gy * xhat)] (count = M). */
+int crnn_gemm_wres_bnstats_supported(long M, int N, int K);
+int crnn_gemm_wres_bnstats_rows(long M, int N, int K);
+int crnn_gemm_wres_bf16_bnstats(const void* X, const void* W, void* Y, long M, int N, int K, const void* d, const float* bnstate,
+                                float* stat_partials, crnn_stream_t stream);
+int crnn_bn_bwd_finalize(const float* partials, int nparts, int C, long count, float* dgamma, float* dbeta, float* coef, crnn_stream_t stream);
 /* Inference forward of a pointwise convolution on the same kernel with the BatchNorm + ReLU6 that follows folded into the MFMA waves'
  * epilogue: y[M][N] (bf16) = ReLU6((a . wT^T) * scale[n] + shift[n]), out_bnstate = [mean|var|scale|shift] (crnn_bn_infer_state).
  * Bit-identical to crnn_pwconv_fwd(..., out_bnstate, ...) on bf16 tensors.  Same shape rules as crnn_gemm_wres_bf16. */

@@ -32,9 +32,10 @@ def main():
         alt = ctypes.CDLL(os.environ["CRNN_RNN_LIB"])
         for n in ("crnn_lstm_fwd_persist", "crnn_lstm_bwd_persist"):
             f = getattr(alt, n); f.restype, f.argtypes = getattr(L, n).restype, getattr(L, n).argtypes
+        base = L
         class _Mix:
             def __getattr__(self, n):
-                return getattr(alt, n) if n in ("crnn_lstm_fwd_persist", "crnn_lstm_bwd_persist") else getattr(L, n)
+                return getattr(alt, n) if n in ("crnn_lstm_fwd_persist", "crnn_lstm_bwd_persist") else getattr(base, n)
         L = _Mix()
     B, T, u = args.batch, args.T, args.units
     G = 4 * u

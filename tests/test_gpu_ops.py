@@ -423,7 +423,7 @@ def test_persistent_lstm_reports_a_lost_cluster():
     eng.check_rnn_status()                                                     # clean run: no exception
     side = torch.cuda.Stream()
     # 150 KiB of LDS per spinner block: at most one per CU and nothing with more than 10 KiB of LDS beside it (the recurrence needs 17.6)
-    ok(L().crnn_debug_occupy(cus - 2, 150 * 1024, 8 * 1000 * 1000, ctypes.c_void_p(side.cuda_stream)))
+    ok(L().crnn_debug_occupy(cus - 2, 150 * 1024, 7 * 1000 * 1000, ctypes.c_void_p(side.cuda_stream)))   # 7 s; a wait gives up after 2 s
     import time
     time.sleep(0.2)                                                            # the spinners are resident before the forward is enqueued
     eng.forward(x, train=False)
@@ -974,6 +974,56 @@ def test_weights_resident_gemm_equals_the_tile_kernel(M, N, K):
         assert_close(Y[:M].float().cpu().numpy(), ref, rtol=1e-2, atol=1e-2 * np.abs(ref).max(), what="wres gemm vs fp64")
     assert L().crnn_gemm_wres_bf16(P(Xd), P(Wd), P(Y), M, 64, K, S()) == -3 and L().crnn_gemm_wres_supported(N, 192) == -3
     assert L().crnn_gemm_wres_supported(1152, 64) == -3
+
+
+@pytest.mark.parametrize("M,N,K", [(128 * 3, 128, 256), (128 * 41, 256, 256), (128 * 300, 256, 512), (128 * 531, 512, 512), (128 * 936, 512, 512), (128 * 7488, 128, 256),
+                                   (128, 1024, 256), (128 * 9, 384, 512)])
+def test_weights_resident_data_gradient_with_batchnorm_backward_statistics(M, N, K):
+    """crnn_gemm_wres_bf16_bnstats: the data-gradient GEMM da = dq . W^T whose storer waves also take the statistics pass of the depthwise
+    BatchNorm's backward.  da must be the very bits of crnn_gemm_wres_bf16; dgamma / dbeta / coef after
+    crnn_bn_bwd_finalize must equal crnn_bn_bwd_ex's statistics pass on the same da and d up to the order of the fp32 partial sums, and an
+    fp64 evaluation of sum(gy), sum(gy * xhat) with gy = da where 0 < d * scale + shift < 6.  One stripe, fewer stripes than workgroups, odd
+    and even numbers of stripes per workgroup, 1..8 channel slices, the CRNN's own shapes (blocks 3, 6/7 at batch 256)."""
+    rs = np.random.RandomState(M % 1000 + N + K)
+    dq = _bf16_round(rs.normal(size=(M, K))); W = _bf16_round(rs.normal(size=(N, K)) * 0.1)
+    d = _bf16_round(rs.normal(size=(M, N)) * 1.5 + 0.3)
+    gamma = rs.uniform(0.5, 1.5, N); beta = rs.normal(size=N) * 0.5 + 1.0
+    mean = d.mean(0); var = d.var(0)
+    inv = 1.0 / np.sqrt(var.astype(np.float32) + np.float32(1e-3))
+    scale = (gamma * inv).astype(np.float32); shift = (beta - mean * gamma * inv).astype(np.float32)
+    bnstate = dev(np.concatenate([mean, var, scale, shift]).astype(np.float32))
+    dqd, Wd, dd = _to_bf16_dev(dq), _to_bf16_dev(W), _to_bf16_dev(d)
+    assert L().crnn_gemm_wres_bnstats_supported(M, N, K) == 0
+    rows = L().crnn_gemm_wres_bnstats_rows(M, N, K)
+    assert rows > 0
+    parts = torch.full((rows * 2 * N,), float("nan"), device="cuda")         # every row and column must be written
+    da = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    dg, db, coef = zeros(N), zeros(N), zeros(2 * N)
+    for rep in range(2):
+        ok(L().crnn_gemm_wres_bf16_bnstats(P(dqd), P(Wd), P(da), M, N, K, P(dd), P(bnstate), P(parts), S()))
+    ok(L().crnn_bn_bwd_finalize(P(parts), rows, N, M, P(dg), P(db), P(coef), S()))
+    assert bool(torch.isfinite(parts).all())
+    da0 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    ok(L().crnn_gemm_wres_bf16(P(dqd), P(Wd), P(da0), M, N, K, S()))
+    assert torch.equal(da, da0), "da differs from crnn_gemm_wres_bf16"
+    # the stand-alone statistics pass on the same tensors (B x H x W = 1 x 1 x M)
+    nch = L().crnn_bn_bwd_chunks(M)
+    parts2 = zeros(nch * 2 * N); dg2, db2, coef2 = zeros(N), zeros(N), zeros(2 * N)
+    ok(L().crnn_bn_bwd_ex(P(dd), P(da0), P(bnstate), P(dev(gamma)), None, P(dg2), P(db2), P(parts2), P(coef2), 1, 1, M, N, 1, 1, 0.0, 0, 0, 1, S()))
+    for a, b, what in ((dg, dg2, "dgamma"), (db, db2, "dbeta"), (coef, coef2, "coef")):
+        a, b = host(a).astype(np.float64), host(b).astype(np.float64)
+        assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max() + 1e-6, (what, np.abs(a - b).max(), np.abs(b).max())
+    # fp64 statistics of the device's own da
+    g = da0.float().cpu().numpy().astype(np.float64)
+    t = d.astype(np.float32) * scale + shift                                  # fp32 fma on the device; threshold ties are measure-zero here
+    live = (t > 0) & (t < 6)
+    gy = np.where(live, g, 0.0)
+    xhat = (d - mean.astype(np.float32).astype(np.float64)) * inv.astype(np.float64)
+    assert_close(host(db), gy.sum(0), rtol=1e-4, atol=1e-4 * np.abs(gy).sum(0).max(), what="dbeta vs fp64")
+    assert_close(host(dg), (gy * xhat).sum(0), rtol=1e-4, atol=1e-4 * np.abs(gy * xhat).sum(0).max(), what="dgamma vs fp64")
+    # shapes outside the rules are refused
+    assert L().crnn_gemm_wres_bnstats_supported(M + 5, N, K) == -3 and L().crnn_gemm_wres_bnstats_supported(M, N, 128) == -3
+    assert L().crnn_gemm_wres_bf16_bnstats(P(dqd), P(Wd), P(da), M, N, K, None, P(bnstate), P(parts), S()) == -2
 
 
 @pytest.mark.parametrize("M,N,K", [(128 * 3, 128, 64), (128 * 40, 256, 128), (128 * 700 + 0, 128, 64), (128 * 300, 512, 256), (128 * 530, 512, 512), (128, 1024, 64),
