@@ -71,25 +71,25 @@ __device__ __forceinline__ void load_frags(const void* w, long row_elems_off, in
   }
 }
 // a wave publishes the rows it produced (4 of the 16-row tile: rows 4 kq .. 4 kq + 3), RE elements each, from its LDS staging
-// area to its slice of an exchange tile: 16 bytes per lane, write-through
+// area to its slice of an exchange tile: 16 bytes per lane (write-through, or plain inside a verified one-XCD cluster)
 template <int RE, typename E>
-__device__ __forceinline__ void publish_rows(const E* stage, E* slice, int kq, int lane) {
+__device__ __forceinline__ void publish_rows(const E* stage, E* slice, int kq, int lane, bool local) {
   constexpr int ES = sizeof(E), CPR = RE * ES / 16;                 // 16-byte chunks per row
   const __amdgpu_buffer_rsrc_t rs = make_rsrc(slice, 16 * RE * ES);
   if (lane < 4 * CPR) {
     const int part = lane % CPR, rl = lane / CPR;
     const int eoff = (4 * kq + rl) * RE + part * (16 / ES);
     const u32x4 v = *reinterpret_cast<const u32x4*>(&stage[eoff]);
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, eoff * ES, 0, kAuxSt);
+    xstore(v, rs, eoff * ES, local);
   }
 }
 template <int RE, typename E>
-__device__ __forceinline__ void poison_rows(E* slice, int kq, int lane) {
+__device__ __forceinline__ void poison_rows(E* slice, int kq, int lane, bool local) {
   constexpr int ES = sizeof(E), CPR = RE * ES / 16;
   if (lane < 4 * CPR) {
     const int part = lane % CPR, rl = lane / CPR;
     const int eoff = (4 * kq + rl) * RE + part * (16 / ES);
-    __builtin_amdgcn_raw_buffer_store_b128((u32x4){kSentinel, kSentinel, kSentinel, kSentinel}, make_rsrc(slice, 16 * RE * ES), eoff * ES, 0, kAuxSt);
+    xstore((u32x4){kSentinel, kSentinel, kSentinel, kSentinel}, make_rsrc(slice, 16 * RE * ES), eoff * ES, local);
   }
 }
 
@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256 * UW) void gru_fwd_persist_kernel(GruFwdDir d0,
   E* xdata = reinterpret_cast<E*>(xbuf + kStatusBytes);
   const long tile_elems = (long)BT * U;
   bool dead = false;
+  const bool local = xmap && cluster_shares_xcd(xbuf, cl, sl, NSW, tid, status, dead);   // plain (L2-resident) exchange stores
   auto slot_tile = [&](int e) { return xdata + (((long)dir * kRing + (e & (kRing - 1))) * nbt + bt) * tile_elems; };
 
   // this wave's K quarter of the z, r and candidate columns j0 .. j0+15 of U (rows of U^T), resident for all T steps
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256 * UW) void gru_fwd_persist_kernel(GruFwdDir d0,
       // publish r * h_prev of this unit group (exchange 2s): the candidate product of every member waits for it
       pub[ug][row * 16 + col] = to_e<WBF>(o.rh);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the re-poisoning after the previous exchange has landed
-      publish_rows<16>(pub[ug], slot_tile(2 * s) + (long)sg * BT * 16, kq, lane);
+      publish_rows<16>(pub[ug], slot_tile(2 * s) + (long)sg * BT * 16, kq, lane, local);
     }
     if (live) {                                                      // what the backward pass reads: off the critical path
       float* gt = d.gates + ((long)t * B + b) * 3 * U;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256 * UW) void gru_fwd_persist_kernel(GruFwdDir d0,
       d.rh[((long)t * B + b) * U + j] = o.rh;
     }
     if (s > 0) {
-      poison_rows<16>(slot_tile(2 * s + 2) + (long)sg * BT * 16, kq, lane);
+      poison_rows<16>(slot_tile(2 * s + 2) + (long)sg * BT * 16, kq, lane, local);
       gather_to_As(2 * s);                                           // r * h_prev of the whole cluster
       __syncthreads();
       const f32x4 ah = quarter_chain<WBF, KQ>(As, LDA, kq * (U / 4), bh, r, q);
@@ -186,13 +187,13 @@ __global__ __launch_bounds__(256 * UW) void gru_fwd_persist_kernel(GruFwdDir d0,
     if (s + 1 < T) {
       pub[ug][row * 16 + col] = to_e<WBF>(g.hn);                     // exchange 2s+1
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      publish_rows<16>(pub[ug], slot_tile(2 * s + 1) + (long)sg * BT * 16, kq, lane);
+      publish_rows<16>(pub[ug], slot_tile(2 * s + 1) + (long)sg * BT * 16, kq, lane, local);
     }
     if (live) {
       d.gates[((long)t * B + b) * 3 * U + 2 * U + j] = g.hh;
       d.h[((long)t * B + b) * d.ldh + j] = g.hn;
     }
-    if (s + 1 < T) poison_rows<16>(slot_tile(2 * s + 3) + (long)sg * BT * 16, kq, lane);
+    if (s + 1 < T) poison_rows<16>(slot_tile(2 * s + 3) + (long)sg * BT * 16, kq, lane, local);
   }
 }
 
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(256 * UW) void gru_bwd_persist_kernel(GruBwdDir d0,
   E* xdata = reinterpret_cast<E*>(xbuf + kStatusBytes);
   const long tile_elems = (long)BT * K2;                 // slot stride (the dhh tiles use half of it)
   bool dead = false;
+  const bool local = xmap && cluster_shares_xcd(xbuf, cl, sl, NSW, tid, status, dead);   // plain (L2-resident) exchange stores
   auto slot_tile = [&](int e) { return xdata + (((long)dir * kRing + (e & (kRing - 1))) * nbt + bt) * tile_elems; };
 
   // U[j0 + r][.]: this wave's quarter of the z|r columns (K = 2u) and of the candidate columns (K = u)
@@ -263,12 +265,12 @@ __global__ __launch_bounds__(256 * UW) void gru_bwd_persist_kernel(GruBwdDir d0,
     // publish dhh_t of this unit group (exchange 2sb)
     pub[ug][row * 16 + col] = to_e<WBF>(ob.dhh);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    publish_rows<16>(pub[ug], slot_tile(2 * sb) + (long)sg * BT * 16, kq, lane);
+    publish_rows<16>(pub[ug], slot_tile(2 * sb) + (long)sg * BT * 16, kq, lane, local);
     if (live) {
       float* dz = d.dz + ((long)t * B + b) * G;
       dz[j] = ob.dzz; dz[2 * U + j] = ob.dhh;
     }
-    poison_rows<16>(slot_tile(2 * sb + 2) + (long)sg * BT * 16, kq, lane);
+    poison_rows<16>(slot_tile(2 * sb + 2) + (long)sg * BT * 16, kq, lane, local);
     gather_tile<NCH_H, NT>(slot_tile(2 * sb), tid, status, dead, [&](int idx, const u32x4& v) {
       const int e0 = idx * (16 / ES), sg2 = e0 / (BT * 16), rem = e0 % (BT * 16);
       *reinterpret_cast<u32x4*>(&As[(rem >> 4) * LDA + sg2 * 16 + (rem & 15)]) = v;
@@ -288,10 +290,10 @@ __global__ __launch_bounds__(256 * UW) void gru_bwd_persist_kernel(GruBwdDir d0,
       pub[ug][(row * 2 + 0) * 16 + col] = to_e<WBF>(ob.dzz);         // exchange 2sb+1: [dz | dr]_t
       pub[ug][(row * 2 + 1) * 16 + col] = to_e<WBF>(oa.dzr);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      publish_rows<32>(pub[ug], slot_tile(2 * sb + 1) + (long)sg * BT * 32, kq, lane);
+      publish_rows<32>(pub[ug], slot_tile(2 * sb + 1) + (long)sg * BT * 32, kq, lane, local);
     }
     if (live) d.dz[((long)t * B + b) * G + U + j] = oa.dzr;
-    if (sb + 1 < T) poison_rows<32>(slot_tile(2 * sb + 3) + (long)sg * BT * 32, kq, lane);
+    if (sb + 1 < T) poison_rows<32>(slot_tile(2 * sb + 3) + (long)sg * BT * 32, kq, lane, local);
   }
 }
 
@@ -304,7 +306,7 @@ int gru_launch_fwd(const GruFwdDir& a, const GruFwdDir& b, int T, int B, void* x
   const Chunking ck = chunking(T, B, U, 1, UW, ES, gru_lds_fwd(U, UW, ES), U);
   for (int lo = 0; lo < B; lo += ck.rows_per_launch) {
     const int cnt = (B - lo < ck.rows_per_launch) ? B - lo : ck.rows_per_launch;
-    CRNN_TRY(prep_xbuf(xbuf, xbuf_bytes, ck.xdata_bytes, lo == 0, stream));     // every slot is written per launch: poison first
+    CRNN_TRY(prep_xbuf(xbuf, xbuf_bytes, ck.xdata_bytes, stream));     // every slot is written per launch: poison first
     const int ncl = 2 * cdiv(cnt, 16);
     hipLaunchKernelGGL((gru_fwd_persist_kernel<WBF, U, UW>), dim3(ncl * NSW), dim3(256 * UW), 0, stream, a, b, T, B, lo, cnt, (unsigned char*)xbuf,
                        (xreq && ncl % 8 == 0) ? 1 : 0);
@@ -317,7 +319,7 @@ int gru_launch_bwd(const GruBwdDir& a, const GruBwdDir& b, int T, int B, void* x
   const Chunking ck = chunking(T, B, U, 1, UW, ES, gru_lds_bwd(U, UW, ES), 2 * U);
   for (int lo = 0; lo < B; lo += ck.rows_per_launch) {
     const int cnt = (B - lo < ck.rows_per_launch) ? B - lo : ck.rows_per_launch;
-    CRNN_TRY(prep_xbuf(xbuf, xbuf_bytes, ck.xdata_bytes, lo == 0, stream));
+    CRNN_TRY(prep_xbuf(xbuf, xbuf_bytes, ck.xdata_bytes, stream));
     const int ncl = 2 * cdiv(cnt, 16);
     hipLaunchKernelGGL((gru_bwd_persist_kernel<WBF, U, UW>), dim3(ncl * NSW), dim3(256 * UW), 0, stream, a, b, T, B, lo, cnt, (unsigned char*)xbuf,
                        (xreq && ncl % 8 == 0) ? 1 : 0);

@@ -103,10 +103,10 @@ bool rnn_persist(const crnn_config* c) {
   return (c->gru ? crnn_gru_persist_supported(c->units, rnn_dtu(c)) : crnn_lstm_persist_supported(c->units, rnn_dtu(c))) == 0;
 }
 
-// uw argument of the persistent BPTT launches: automatic workgroup size, XCD-local clusters unless the linear map is asked for.
-// Measured at B = 256, u = 256 (profiles/r03_lstm_bench.json): the backward all-gather (32 KB of dz per step and chain) is faster inside
-// one XCD (bf16 198 -> 173 us per layer, fp32 368 -> 291), the forward one (8 KB of h) is faster dealt over all XCDs (131 vs 141 us),
-// so the forward launches keep the linear map.
+// uw argument of the persistent recurrences: automatic workgroup size, XCD-local clusters unless the linear map is asked for.
+// Measured at B = 256, u = 256 (profiles/r03_lstm_cache_policy.txt): with the XCD-local map and, once a cluster has verified that its
+// members share an XCD, plain exchange stores the LSTM forward takes 98 us per layer (linear map + write-through stores: 131) and the
+// BPTT 142 us (198).
 int rnn_uw(const crnn_config* c) { return (c->flags & CRNN_FLAG_RNN_LINEAR_CLUSTERS) ? 0 : CRNN_RNN_XCD_LOCAL; }
 
 Plan make_plan(const crnn_config* c) {
@@ -487,13 +487,13 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
   CRNN_TRY(xw(c.w("dn1"), d.tds, "1b"));
   if (cfg->gru && persist)   // "cs" holds r*h_prev for the GRU (cell state for the LSTM)
     CRNN_TRY(crnn_gru_fwd_persist(c.w("xw1f"), c.w("xw1b"), c.w("ut1f"), c.w("ut1b"), c.w("h1f"), c.w("h1b"), u, c.w("gt1f"), c.w("gt1b"),
-                                  c.w("cs1f"), c.w("cs1b"), T, B, u, dtu, c.w("rnnx"), xbytes, 0, stream));
+                                  c.w("cs1f"), c.w("cs1b"), T, B, u, dtu, c.w("rnnx"), xbytes, rnn_uw(cfg), stream));
   else if (cfg->gru)
     CRNN_TRY(crnn_gru_fwd_ex(c.w("xw1f"), c.w("xw1b"), c.w("ut1f"), c.w("ut1b"), c.w("h1f"), c.w("h1b"), u, c.w("gt1f"), c.w("gt1b"),
                              c.w("cs1f"), c.w("cs1b"), T, B, u, dtu, stream));
   else if (persist)
     CRNN_TRY(crnn_lstm_fwd_persist(c.w("xw1f"), c.w("xw1b"), c.w("ut1f"), c.w("ut1b"), c.w("h1f"), c.w("h1b"), u, c.w("cs1f"), c.w("cs1b"),
-                                   c.w("gt1f"), c.w("gt1b"), T, B, u, dtu, c.w("rnnx"), xbytes, 0, 0, stream));
+                                   c.w("gt1f"), c.w("gt1b"), T, B, u, dtu, c.w("rnnx"), xbytes, 0, rnn_uw(cfg), stream));
   else
     CRNN_TRY(crnn_lstm_fwd_ex(c.w("xw1f"), c.w("xw1b"), c.w("ut1f"), c.w("ut1b"), c.w("h1f"), c.w("h1b"), u, c.w("cs1f"), c.w("cs1b"),
                               c.w("gt1f"), c.w("gt1b"), T, B, u, dtu, stream));
@@ -502,13 +502,13 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
   CRNN_TRY(xw(c.w("r1"), u, "2b"));
   if (cfg->gru && persist)
     CRNN_TRY(crnn_gru_fwd_persist(c.w("xw2f"), c.w("xw2b"), c.w("ut2f"), c.w("ut2b"), c.w("h2"), c.w("h2") + u, 2 * u, c.w("gt2f"), c.w("gt2b"),
-                                  c.w("cs2f"), c.w("cs2b"), T, B, u, dtu, c.w("rnnx"), xbytes, 0, stream));
+                                  c.w("cs2f"), c.w("cs2b"), T, B, u, dtu, c.w("rnnx"), xbytes, rnn_uw(cfg), stream));
   else if (cfg->gru)
     CRNN_TRY(crnn_gru_fwd_ex(c.w("xw2f"), c.w("xw2b"), c.w("ut2f"), c.w("ut2b"), c.w("h2"), c.w("h2") + u, 2 * u, c.w("gt2f"), c.w("gt2b"),
                              c.w("cs2f"), c.w("cs2b"), T, B, u, dtu, stream));
   else if (persist)
     CRNN_TRY(crnn_lstm_fwd_persist(c.w("xw2f"), c.w("xw2b"), c.w("ut2f"), c.w("ut2b"), c.w("h2"), c.w("h2") + u, 2 * u, c.w("cs2f"), c.w("cs2b"),
-                                   c.w("gt2f"), c.w("gt2b"), T, B, u, dtu, c.w("rnnx"), xbytes, 0, 0, stream));    // merge_mode='concat'
+                                   c.w("gt2f"), c.w("gt2b"), T, B, u, dtu, c.w("rnnx"), xbytes, 0, rnn_uw(cfg), stream));    // merge_mode='concat'
   else
     CRNN_TRY(crnn_lstm_fwd_ex(c.w("xw2f"), c.w("xw2b"), c.w("ut2f"), c.w("ut2b"), c.w("h2"), c.w("h2") + u, 2 * u, c.w("cs2f"), c.w("cs2b"),
                               c.w("gt2f"), c.w("gt2b"), T, B, u, dtu, stream));    // merge_mode='concat'

@@ -10,30 +10,27 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr unsigned kSentinel = 0xffffffffu;
+// Layout of xbuf: [0,4) sticky give-up counter (never reset by a launch) | [16,20) per-launch status (all ones = clean) | [kHelloOff, +kHelloBytes)
+// one word per workgroup of the launch for the XCD census | (trace build: time stamps) | the exchange ring.  Every launch fills
+// [16, end) with 0xFF first.
+constexpr size_t kLaunchStatusOff = 16;
+constexpr size_t kHelloOff = 256, kHelloBytes = 4096;     // 1024 workgroups (a launch has at most 2 per CU)
 #ifdef CRNN_RNN_TRACE
-constexpr size_t kStatusBytes = 65536;        // trace build: [64..) = per-step timestamps of two workgroups
+constexpr size_t kTraceOff = kHelloOff + kHelloBytes;
+constexpr size_t kStatusBytes = kTraceOff + 65536;        // trace build: per-step timestamps of two workgroups
 #define RNN_TRACE(slot) do { if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 + 3)) \
-    reinterpret_cast<unsigned long long*>(xbuf + 64)[((blockIdx.x != 0) * 128 + TRACE_STEP) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    reinterpret_cast<unsigned long long*>(xbuf + kTraceOff)[((blockIdx.x != 0) * 128 + TRACE_STEP) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
-constexpr size_t kStatusBytes = 256;          // byte 0: sticky give-up counter, byte 16: per-launch status; the exchange tiles follow
+constexpr size_t kStatusBytes = kHelloOff + kHelloBytes;
 #define RNN_TRACE(slot) do {} while (0)
 #endif
 constexpr unsigned long long kSpinTicks = 200ull * 1000 * 1000;   // a wait gives up after 2 s of the constant 100 MHz clock (s_memrealtime)
-constexpr size_t kLaunchStatusOff = 16;       // the fill of every launch starts here (the counter in front of it survives)
-// cache policy of the exchange (aux bits of the buffer instructions: 1 = sc0, 16 = sc1).  Default: write-through stores and
-// L1-bypassing loads at device scope (works for any placement).  Other values exist for scripts/lstm_xcd_bench.py only.
-#ifndef CRNN_RNN_POL
-#define CRNN_RNN_POL 0
-#endif
-#if CRNN_RNN_POL == 0
-constexpr int kAuxSt = 16, kAuxLd = 16;
-#elif CRNN_RNN_POL == 1
-constexpr int kAuxSt = 0, kAuxLd = 16;
-#elif CRNN_RNN_POL == 2
-constexpr int kAuxSt = 1, kAuxLd = 1;
-#else
-constexpr int kAuxSt = 17, kAuxLd = 17;
-#endif
+// Cache policy of the exchange (aux bits of the buffer instructions: 1 = sc0, 16 = sc1).  Loads always bypass the L1 (sc1: a CU's L1
+// is never refreshed by other CUs' stores).  Stores: write-through to memory (sc1) unless the cluster has verified that all its members
+// run on ONE XCD -- then plain stores (the XCD's L2 is the coherence point of its CUs): measured at B = 256, u = 256, bf16
+// (profiles/r03_lstm_cache_policy.txt) LSTM forward 131 us (linear map, sc1) / 143 (XCD-local, sc1) / 98 (XCD-local, plain), BPTT
+// 198 / 174-185 / 142; sc0 loads or stores read stale L1 lines (every wait gives up).
+constexpr int kAuxSt = 16, kAuxLd = 16, kAuxStLocal = 0;
 constexpr int kRing = 4;                      // step slots of the exchange ring
 
 template <bool WBF> struct XE { typedef float type; };
@@ -43,6 +40,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 __device__ __forceinline__ unsigned pack_e(bf16_t*, float lo, float hi) { return pack2_bf16(lo, hi); }
+// 16-byte store into an exchange tile: plain when the cluster is known to share an XCD, else write-through (device scope)
+__device__ __forceinline__ void xstore(const u32x4& v, __amdgpu_buffer_rsrc_t rs, int byte_off, bool local) {
+  if (local) __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, kAuxStLocal);
+  else __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, kAuxSt);
+}
 
 // Poll NCH 16-byte chunks of an exchange tile (chunk idx = tid + NT*i) until none carries the sentinel, then hand
 // them to `sink(idx, value)`.  Groups of <= 8 chunks per thread bound the register footprint.
@@ -104,6 +106,40 @@ __device__ __forceinline__ int cluster_block_id(int id, int nsw, int xmap) {
   return ((loc / nsw) * 8 + xcd) * nsw + loc % nsw;
 }
 
+// XCD census of a cluster (XCD-local map only): HIP promises nothing about workgroup -> XCD placement ("block b runs on XCD b % 8" is
+// an observation), so plain L2-resident stores are only used after the members have PROVED they share an XCD: every member writes its
+// HW_REG_XCC_ID (write-through) into its word of the hello table, wave 0 polls the cluster's words (L1-bypassing, bounded like every
+// wait) and the workgroup takes the verdict "all equal".  Every member sees the same words, so the cluster agrees; one hand-off
+// (about 1 us) per launch.  A member that never shows up ends the wait like any other lost hand-off (give-up counter, device-scope stores).
+__device__ __forceinline__ bool cluster_shares_xcd(unsigned char* xbuf, int cl, int sl, int nsw, int tid, unsigned* status, bool& dead) {
+  __shared__ int verdict;
+  const unsigned myx = __builtin_amdgcn_s_getreg(0x1814) & 0xfu;        // hwreg(HW_REG_XCC_ID, 0, 4)
+  if (tid < 64) {
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(xbuf + kHelloOff + (size_t)cl * nsw * 4, nsw * 4);
+    if (tid == 0) __builtin_amdgcn_raw_buffer_store_b32(myx, rs, sl * 4, 0, kAuxSt);
+    unsigned v = myx, spins = 0;
+    unsigned long long t0 = 0;
+    bool lost = false;
+    for (;;) {
+      asm volatile("" ::: "memory");
+      v = (tid < nsw) ? __builtin_amdgcn_raw_buffer_load_b32(rs, tid * 4, 0, kAuxLd) : myx;
+      if (__all(v != kSentinel)) break;
+      if ((++spins & 1023u) == 0) {
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        if (t0 == 0) t0 = now;
+        else if (now - t0 > kSpinTicks) { lost = true; break; }
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (lost && tid == 0) { atomicAnd(status + kLaunchStatusOff / 4, ~1u); atomicAdd(status, 1u); }
+    const bool same = __all(v == myx) && !lost;
+    if (tid == 0) verdict = same ? 1 : (lost ? -1 : 0);
+  }
+  __syncthreads();
+  if (verdict < 0) dead = true;
+  return verdict > 0;
+}
+
 // Workgroups that are certainly co-resident on the device: per CU as many as the LDS footprint and the thread count
 // (2048 threads, and the registers of two 256-thread workgroups / one 1024-thread workgroup) admit, at most 2.
 inline int resident_cap(size_t lds_bytes, int threads) {
@@ -126,12 +162,11 @@ inline Chunking chunking(int T, int B, int u, int mt, int uw, int es, size_t lds
   return c;
 }
 
-int prep_xbuf(void* xbuf, size_t xbuf_bytes, size_t need_data, bool reset_status, hipStream_t stream) {
+int prep_xbuf(void* xbuf, size_t xbuf_bytes, size_t need_data, hipStream_t stream) {
   if (!xbuf || xbuf_bytes < kStatusBytes + need_data || ((uintptr_t)xbuf & 15)) return CRNN_ERR_ARG;
-  // one fill: the status words (all ones = no wait gave up) and the sentinel ring behind them
-  // (the sticky give-up counter in front of the per-launch word is never touched)
-  unsigned char* p = (unsigned char*)xbuf + (reset_status ? kLaunchStatusOff : kStatusBytes);
-  hipError_t e = hipMemsetAsync(p, 0xFF, need_data + (reset_status ? kStatusBytes - kLaunchStatusOff : 0), stream);
+  // one fill per launch: the per-launch status word (all ones = no wait gave up), the hello table and the sentinel ring behind them;
+  // the sticky give-up counter in front is never touched
+  hipError_t e = hipMemsetAsync((unsigned char*)xbuf + kLaunchStatusOff, 0xFF, kStatusBytes - kLaunchStatusOff + need_data, stream);
   return e == hipSuccess ? CRNN_OK : (int)e;
 }
 

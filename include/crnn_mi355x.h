@@ -56,8 +56,8 @@ typedef struct {
 #define CRNN_FLAG_NO_BN_STATS_FUSION 128 /* bf16-storage training: statistics pass of the depthwise BatchNorm's backward as a kernel of its own
                                          (crnn_bn_bwd_ex) instead of inside the data-gradient GEMM (crnn_gemm_wres_bf16_bnstats); same data gradients
                                          bit for bit, the BatchNorm-1 gradients / coefficients are the same sums in another order */
-#define CRNN_FLAG_RNN_LINEAR_CLUSTERS 64 /* persistent BPTT launches: cluster members = consecutive workgroup ids (dealt over all XCDs, what the
-                                         forward launches always use) instead of the XCD-local map; bit-identical */
+#define CRNN_FLAG_RNN_LINEAR_CLUSTERS 64 /* persistent recurrences: cluster members = consecutive workgroup ids (dealt over all XCDs, write-through
+                                         exchange stores) instead of the XCD-local map (plain stores inside a verified one-XCD cluster); bit-identical */
 #define CRNN_FLAG_RNN_STEP_KERNELS 1  /* LSTM / GRU recurrences as one (two) launch(es) per timestep (crnn_lstm_*_ex, crnn_gru_*_ex) instead of
                                          the persistent one-launch-per-layer kernels (crnn_lstm_*_persist, crnn_gru_*_persist); bit-identical */
 
@@ -392,13 +392,14 @@ int crnn_pwconv_bnrelu6_fwd_wres(const void* d, const float* in_bnstate, const v
  * registers for all T steps; per step the cluster all-gathers h_t (forward) / dz_t (backward) through `xbuf` with
  * write-through stores and L1-bypassing polled loads (the data is its own ready flag) and stages it through LDS as the next
  * step's MFMA A operand.  Bit-identical to crnn_lstm_*_ex.  `xbuf`: caller-owned scratch of crnn_lstm_persist_xbuf_bytes()
- * bytes, 16-byte aligned.  Status: the unsigned at byte 16 of xbuf is 0xFFFFFFFF after a clean launch, anything else means a
+ * bytes, 16-byte aligned.  Status: the unsigned at byte 16 of xbuf is 0xFFFFFFFF after a clean kernel launch, anything else means a
  * bounded wait gave up (the cluster was not co-resident: results invalid); the unsigned at byte 0 is a STICKY counter of give-ups
  * that no launch resets -- the caller zeroes it once after allocating xbuf and compares it with the last value it saw (the engine
  * does that wherever it synchronises with the host anyway and raises; inside the workspace this is the tensor "rnnx").
  * mt = batch rows per workgroup / 16 (1 | 2), uw = 16-unit groups per workgroup (1 | 2 | 4: 256 / 512 / 1024 threads, the
  * cluster has u/(16 uw) members); 0 = automatic; uw | CRNN_RNN_XCD_LOCAL: the members of a cluster are the workgroup ids congruent
- * modulo 8 (one XCD) instead of consecutive ids -- same results.  crnn_lstm_persist_supported: 0 if (u, dt_u) has a kernel
+ * modulo 8 (observed: one XCD) instead of consecutive ids; each cluster then checks HW_REG_XCC_ID of all its members once per launch and,
+ * only if they agree, exchanges with plain L2-resident stores instead of write-through ones -- same results for any placement.  crnn_lstm_persist_supported: 0 if (u, dt_u) has a kernel
  * (fp32: u in {64,128,256}; bf16: u in {128,256,512}), else -3 -- use the step kernels then. */
 #define CRNN_RNN_XCD_LOCAL 0x100
 size_t crnn_lstm_persist_xbuf_bytes(int T, int B, int u, int dt_u);

@@ -25,25 +25,15 @@ def main():
     ap.add_argument("--T", type=int, default=52)
     ap.add_argument("--units", type=int, default=256)
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--pol-only", action="store_true", help="bf16, XCD-local persistent variants only (cache-policy experiment libraries)")
     args = ap.parse_args()
     L = native.lib()
-    if os.environ.get("CRNN_RNN_LIB"):      # experiment build of rnn_persist.hip alone (cache-policy variants, scripts/lstm_xcd_bench.sh)
-        alt = ctypes.CDLL(os.environ["CRNN_RNN_LIB"])
-        for n in ("crnn_lstm_fwd_persist", "crnn_lstm_bwd_persist"):
-            f = getattr(alt, n); f.restype, f.argtypes = getattr(L, n).restype, getattr(L, n).argtypes
-        base = L
-        class _Mix:
-            def __getattr__(self, n):
-                return getattr(alt, n) if n in ("crnn_lstm_fwd_persist", "crnn_lstm_bwd_persist") else getattr(base, n)
-        L = _Mix()
     B, T, u = args.batch, args.T, args.units
     G = 4 * u
     rs = np.random.RandomState(0)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     S = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     res = {"batch": B, "T": T, "units": u}
-    for bf16 in ((True,) if args.pol_only else (True, False)):
+    for bf16 in (True, False):
         dt = 1 if bf16 else 0
         wdt = torch.bfloat16 if bf16 else torch.float32
         U = [torch.from_numpy((rs.normal(size=(u, G)) * 0.1).astype(np.float32)).cuda() for _ in range(2)]
@@ -73,7 +63,7 @@ def main():
         flops = 2.0 * T * 2 * B * u * G
         peak = 2500e12 if bf16 else 157.3e12
         mode = {}
-        variants = (("persist", 0, 0x100), ("persist", 1, 0x102), ("persist", 0, 0x100)) if args.pol_only else (("step", 0, 0), ("persist", 1, 1), ("persist", 1, 2), ("persist", 1, 4), ("persist", 2, 2), ("persist", 2, 4), ("persist", 0, 0), ("persist", 0, 0x100), ("persist", 1, 0x102), ("persist", 0, 0))
+        variants = (("step", 0, 0), ("persist", 1, 1), ("persist", 1, 2), ("persist", 1, 4), ("persist", 2, 2), ("persist", 2, 4), ("persist", 0, 0), ("persist", 0, 0x100), ("persist", 1, 0x102), ("persist", 0, 0))
         for kind, mt, uw in variants:
             row = {}
             xbuf[:4].zero_()            # the sticky give-up counter belongs to this variant

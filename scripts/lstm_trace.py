@@ -15,7 +15,7 @@ lib = ctypes.CDLL(os.path.join(ROOT, "scripts", "_trace", "librnn_trace.so"))
 lib.crnn_lstm_persist_xbuf_bytes.restype = ctypes.c_size_t
 B, T, u = int(os.environ.get("B", 256)), 52, 256
 G = 4 * u
-mt = int(os.environ.get("MT", 1)); uw = int(os.environ.get("UW", 1))
+mt = int(os.environ.get("MT", 1)); uw = int(os.environ.get("UW", 1)) | (0x100 if os.environ.get("XCD", "0") == "1" else 0)   # XCD=1: XCD-local clusters
 rs = np.random.RandomState(0)
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 S = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -32,8 +32,9 @@ for rep in range(3):
                                    P(xbuf), ctypes.c_size_t(nbytes), mt, uw, S)
     assert rc == 0, rc
     torch.cuda.synchronize()
-raw = xbuf[:65536 // 4].cpu().numpy().view(np.uint64)[8:]     # skip 64 bytes
-out = {"status": int(int(xbuf[4].item()) != -1), "giveups": int(xbuf[0].item())}
+TRACE_OFF = 256 + 4096                                          # kTraceOff of rnn_exchange.h (status words + hello table)
+raw = xbuf[TRACE_OFF // 4:(TRACE_OFF + 65536) // 4].cpu().numpy().view(np.uint64)
+out = {"xcd_local": bool(uw & 0x100), "uw": uw & 0xff, "status": int(int(xbuf[4].item()) != -1), "giveups": int(xbuf[0].item())}
 for wg in range(2):
     t = raw[wg * 128 * 8:(wg * 128 + T) * 8].reshape(T, 8)[:, :5].astype(np.int64) * 10     # ns
     s = slice(2, T - 1)
