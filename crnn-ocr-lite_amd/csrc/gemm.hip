@@ -318,6 +318,44 @@ __global__ __launch_bounds__(32 * LY) void gemm_splitk_reduce_kernel(const float
     }
   }
 }
+// The same second stage for the common case -- at most 8 partial results, fp32 result, N % 4 == 0 and 16-byte aligned rows: one thread sums
+// four consecutive outputs over the splits in registers (the partial lists are 7 - 55 MB: the LDS-combining form above moved 32 outputs
+// per 256-thread workgroup and ran dense1's forward reduction at a quarter of the memory bandwidth).  Fixed order: ((p0+p1)+(p2+p3)) +
+// ((p4+p5)+(p6+p7)), absent partials count as zero.
+__global__ __launch_bounds__(256) void gemm_splitk_reduce8_kernel(const float* __restrict__ part, int nsplit, GemmParams p) {
+  const long total4 = ((long)p.M * p.N) >> 2;
+  const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i4 >= total4) return;
+  const float4* src = reinterpret_cast<const float4*>(part);
+  float4 v[8];
+#pragma unroll
+  for (int z = 0; z < 8; ++z) v[z] = z < nsplit ? src[(long)z * total4 + i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float s[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float a0 = (&v[0].x)[e], a1 = (&v[1].x)[e], a2 = (&v[2].x)[e], a3 = (&v[3].x)[e];
+    const float a4 = (&v[4].x)[e], a5 = (&v[5].x)[e], a6 = (&v[6].x)[e], a7 = (&v[7].x)[e];
+    s[e] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+  }
+  const long i = i4 << 2;
+  const int m = (int)(i / p.N), n = (int)(i % p.N);
+  if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); s[0] += b.x; s[1] += b.y; s[2] += b.z; s[3] += b.w; }
+  if (p.act == 1) { s[0] = fmaxf(s[0], 0.f); s[1] = fmaxf(s[1], 0.f); s[2] = fmaxf(s[2], 0.f); s[3] = fmaxf(s[3], 0.f); }
+  int orow = m;
+  if (p.permP) orow = (m % p.permP) * (p.M / p.permP) + m / p.permP;
+  float4* dst = reinterpret_cast<float4*>(p.C + (long)orow * p.ldc + n);
+  if (p.accumulate) { const float4 c = *dst; s[0] += c.x; s[1] += c.y; s[2] += c.z; s[3] += c.w; }
+  *dst = make_float4(s[0], s[1], s[2], s[3]);
+}
+// launches the matching second stage
+static inline void launch_splitk_reduce(const float* scratch, int nsplit, const GemmParams& p, hipStream_t stream) {
+  const long total = (long)p.M * p.N;
+  const bool vec = nsplit <= 8 && p.dtC == CRNN_F32 && (p.N & 3) == 0 && (p.ldc & 3) == 0 && !(((uintptr_t)p.C | (uintptr_t)scratch) & 15) &&
+                   (!p.bias || !((uintptr_t)p.bias & 15));
+  if (vec) hipLaunchKernelGGL(gemm_splitk_reduce8_kernel, dim3(cdiv(total >> 2, 256)), dim3(256), 0, stream, scratch, nsplit, p);
+  else if (nsplit > 32) hipLaunchKernelGGL(gemm_splitk_reduce_kernel<32>, dim3(cdiv(total, 32)), dim3(32, 32), 0, stream, scratch, nsplit, p);
+  else hipLaunchKernelGGL(gemm_splitk_reduce_kernel<8>, dim3(cdiv(total, 32)), dim3(32, 8), 0, stream, scratch, nsplit, p);
+}
 
 static inline int aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
@@ -372,9 +410,7 @@ static int gemm_f32_impl(int mode, const float* A, const float* B, float* C, int
 #undef LAUNCH
   CRNN_LAUNCH_CHECK();
   if (nsplit > 1) {
-    long total = (long)M * N;
-    if (nsplit > 32) hipLaunchKernelGGL(gemm_splitk_reduce_kernel<32>, dim3(cdiv(total, 32)), dim3(32, 32), 0, stream, scratch, nsplit, p);
-    else hipLaunchKernelGGL(gemm_splitk_reduce_kernel<8>, dim3(cdiv(total, 32)), dim3(32, 8), 0, stream, scratch, nsplit, p);
+    launch_splitk_reduce(scratch, nsplit, p, stream);
     CRNN_LAUNCH_CHECK();
   }
   return CRNN_OK;
