@@ -435,6 +435,9 @@ extern "C" int crnn_pwconv_fwd(const void* a, const void* w, void* q, long M, in
   const int mode = w_transposed ? 1 : 0, ldw = w_transposed ? K : N;
   // out_bnstate ([mean|var|scale|shift] of the BatchNorm after the conv, inference): q = ReLU6(product * scale + shift)
   const float* cs = out_bnstate ? out_bnstate + 2L * N : nullptr; const float* ch = out_bnstate ? out_bnstate + 3L * N : nullptr;
+  if (bf16_products == 2)   // fp32 tensors, fp32-accurate three-plane bf16 products (crnn_gemm_f32x3)
+    return gemm_bf16_impl(mode, a, w, q, (int)M, N, K, K, ldw, N, nullptr, 0, 0, 0, nullptr, 0, dt_a, dt_w, dt_q, stat_partials, stream, cs, ch,
+                          nullptr, nullptr, true);
   if (bf16_products)
     return gemm_bf16_impl(mode, a, w, q, (int)M, N, K, K, ldw, N, nullptr, 0, 0, 0, nullptr, 0, dt_a, dt_w, dt_q, stat_partials, stream, cs, ch);
   if (dt_a != CRNN_F32 || dt_w != CRNN_F32 || dt_q != CRNN_F32) return CRNN_ERR_ARG;

@@ -221,8 +221,14 @@ int gemm(const Ctx& c, int mode, const float* A, const float* B, float* C, int M
     B = weight_operand(c, mode, B, &dtB);
     return crnn_gemm_bf16_ex(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, c.scratch(), kGemmScratchBytes, CRNN_F32, dtB, CRNN_F32, c.s);
   }
-  return crnn_gemm_f32(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, c.scratch(), kGemmScratchBytes, c.s);
+  // parity mode: fp32 tensors; the products come from three bf16 planes per operand (fp32-level accuracy at 2.7x the matrix rate of the fp32
+  // MFMA, crnn_gemm_f32x3) unless the exact-fmaf-chain kernel is asked for
+  if (c.cfg->flags & CRNN_FLAG_FP32_MFMA_GEMMS)
+    return crnn_gemm_f32(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, c.scratch(), kGemmScratchBytes, c.s);
+  return crnn_gemm_f32x3(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, c.scratch(), kGemmScratchBytes, c.s);
 }
+// product selector of crnn_pwconv_fwd: 1 = bf16 products (bf16 modes), 2 = three-plane fp32-accurate products, 0 = fp32 MFMA
+int pw_products(const crnn_config* cfg) { return cfg->mfma_bf16 ? 1 : ((cfg->flags & CRNN_FLAG_FP32_MFMA_GEMMS) ? 0 : 2); }
 // GEMM with explicit operand / result storage types (storage mode 2); falls back to the plain entry points otherwise
 int gemm_t(const Ctx& c, int mode, const float* A, int dtA, const float* B, int dtB, float* C, int dtC, int M, int N, int K, int lda,
            int ldb, int ldc, const float* bias = nullptr, int act = 0, int acc = 0, int perm = 0) {
@@ -401,7 +407,7 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
         if (wt && dtd == CRNN_BF16 && dtq == CRNN_BF16 && dtw == CRNN_BF16 && !(cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS) && M <= 0x7fffffffL)
           rc = fold ? crnn_pwconv_fwd_wres_folded(aa, wq, xo, M, co, ci, s2, stream) : crnn_gemm_wres_bf16(aa, wq, qq, (int)M, co, ci, stream);
         if (rc == CRNN_ERR_UNSUPPORTED)
-          rc = crnn_pwconv_fwd(aa, wq, fold ? xo : qq, M, co, ci, nullptr, fold ? s2 : nullptr, cfg->mfma_bf16 ? 1 : 0, dtd, dtw, dtq, wt, stream);
+          rc = crnn_pwconv_fwd(aa, wq, fold ? xo : qq, M, co, ci, nullptr, fold ? s2 : nullptr, pw_products(cfg), dtd, dtw, dtq, wt, stream);
         CRNN_TRY(rc);
       }
       if (!fold) CRNN_TRY(crnn_bn_act_pool_drop_ex(qq, s2, xo, B, H, W, co, ph, pw, 0.f, seed, (uint32_t)i, dtq, c.dt("x" + p), stream));
@@ -440,7 +446,7 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
         }
         if (rc == CRNN_ERR_UNSUPPORTED) rc = crnn_pwconv_bnrelu6_fwd(dd, s1, wq, qq, M, co, ci, parts, dtq, wt, stream);
         CRNN_TRY(rc);
-      } else CRNN_TRY(crnn_pwconv_fwd(aa, wq, qq, M, co, ci, parts, nullptr, cfg->mfma_bf16 ? 1 : 0, dtd, dtw, dtq, wt, stream));
+      } else CRNN_TRY(crnn_pwconv_fwd(aa, wq, qq, M, co, ci, parts, nullptr, pw_products(cfg), dtd, dtw, dtq, wt, stream));
     }
     CRNN_TRY(crnn_bn_finalize_folded(parts, stat_rows, co, M, c.p(bp + "_bn2_g"), c.p(bp + "_bn2_b"), s2, c.w("fold"), stream));
     bn_off += co;

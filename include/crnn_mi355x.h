@@ -53,6 +53,9 @@ typedef struct {
                                          GEMM (crnn_gemm_bf16_ex / crnn_pwconv_bnrelu6_*) instead of the streaming kernels (crnn_pwconv_bnrelu6_fwd_wres,
                                          crnn_gemm_wres_bf16, crnn_pwconv_bnrelu6_wgrad_stream).  Same products and data gradients bit for bit; the
                                          BatchNorm-2 statistics and the weight gradients are the same sums in another order (fp32 round-off) */
+#define CRNN_FLAG_FP32_MFMA_GEMMS 256   /* parity mode (mfma_bf16 = 0): conv-stack / dense / RNN-projection GEMMs on v_mfma_f32_32x32x2_f32 (crnn_gemm_f32:
+                                         bit-equal to an fmaf chain, 157 TFLOP/s peak) instead of the three-plane bf16 products of crnn_gemm_f32x3
+                                         (fp32-level accuracy, 2.7x the matrix rate); results agree to fp32 round-off */
 #define CRNN_FLAG_NO_BN_STATS_FUSION 128 /* bf16-storage training: statistics pass of the depthwise BatchNorm's backward as a kernel of its own
                                          (crnn_bn_bwd_ex) instead of inside the data-gradient GEMM (crnn_gemm_wres_bf16_bnstats); same data gradients
                                          bit for bit, the BatchNorm-1 gradients / coefficients are the same sums in another order */
@@ -159,6 +162,12 @@ int crnn_ctc_beam_decode(const float* y, const int* input_len, int* out, int* ou
 int crnn_gemm_f32(int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                   const float* bias, int act, int accumulate, int permP, float* scratch, size_t scratch_bytes,
                   crnn_stream_t stream);
+/* The same contract with fp32-accurate products from three bf16 planes per operand: x = hi + mid + lo (bf16 each, |x - sum| <= 2^-27 |x|), a
+ * product keeps hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi (dropped terms <= 2^-26 of it), every partial product is exact in the MFMA's fp32
+ * accumulator: six v_mfma_f32_32x32x16_bf16 per k-step instead of eight four-times slower v_mfma_f32_32x32x2_f32.  Equal to crnn_gemm_f32 to
+ * fp32 round-off, not bit for bit.  What the parity mode's big GEMMs run on (CRNN_FLAG_FP32_MFMA_GEMMS switches back). */
+int crnn_gemm_f32x3(int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                    const float* bias, int act, int accumulate, int permP, float* scratch, size_t scratch_bytes, crnn_stream_t stream);
 /* same contract, products in bf16 on v_mfma_f32_32x32x16_bf16 (fp32 accumulate, fp32 operands/result in HBM) */
 int crnn_gemm_bf16(int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                    const float* bias, int act, int accumulate, int permP, float* scratch, size_t scratch_bytes,
@@ -174,7 +183,8 @@ int crnn_gemm_bf16_ex(int mode, const void* A, const void* B, void* C, int M, in
  * (utils.py:50), produced by the GEMM epilogue instead of a separate pass over q.  Deterministic.
  * Inference: out_bnstate (may be NULL; [mean|var|scale|shift] from crnn_bn_infer_state) folds that BatchNorm and the
  * ReLU6 after it (utils.py:50-51) into the epilogue: q = ReLU6(product * scale + shift).  Not both at once.
- * bf16_products: 0 = fp32 MFMA (all dt_* must be 0), 1 = bf16 MFMA products with fp32 accumulation. */
+ * bf16_products: 0 = fp32 MFMA (all dt_* must be 0), 1 = bf16 MFMA products with fp32 accumulation, 2 = fp32 tensors with fp32-accurate
+ * three-plane bf16 products (crnn_gemm_f32x3; all dt_* must be 0). */
 int crnn_pwconv_stat_rows(long M);
 int crnn_pwconv_fwd(const void* a, const void* w, void* q, long M, int N, int K, float* stat_partials, const float* out_bnstate,
                     int bf16_products, int dt_a, int dt_w, int dt_q, int w_transposed, crnn_stream_t stream);

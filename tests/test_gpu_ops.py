@@ -39,6 +39,69 @@ def test_gemm_modes(mode, shape):
     assert_close(host(C), ref + C0, what="accumulate")
 
 
+def _gemm_x3(mode, A, B, M, N, K, lda, ldb, ldc, bias=None, act=0, acc=0, perm=0, C=None, scratch_mb=64):
+    Cd = zeros(M, ldc) if C is None else C
+    scr = zeros(scratch_mb * 1024 * 1024 // 4) if scratch_mb else None
+    ok(L().crnn_gemm_f32x3(mode, P(A), P(B), P(Cd), M, N, K, lda, ldb, ldc, P(bias), act, acc, perm, P(scr),
+                           (scratch_mb * 1024 * 1024) if scratch_mb else 0, S()))
+    return Cd
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(300, 130, 70), (128, 64, 32), (1000, 38, 512), (77, 20, 25), (513, 257, 129), (4, 6, 50), (260, 1, 64), (1, 64, 900),
+                                   (1024, 256, 512), (2048, 512, 128), (640, 128, 4608)])
+def test_gemm_three_plane_products_are_fp32_accurate(mode, shape):
+    """crnn_gemm_f32x3 (the parity mode's GEMMs): fp32 operands split into three bf16 planes, six bf16 MFMAs per k-step.  Against an fp64
+    product its error must be of the order of the fp32-MFMA kernel's own (an fmaf chain), i.e. fp32 round-off -- far inside the 1e-3 /
+    1e-4 parity tolerances -- in all three operand modes, ragged and whole tiles (guarded and unguarded instantiations), K of 25 .. 4608
+    (split reductions included), with the bias / ReLU / accumulate epilogues."""
+    Mm, N, K = shape
+    rs = np.random.RandomState(Mm + N + K + mode)
+    A = rs.normal(size=(Mm, K)) * np.exp(rs.normal(size=(Mm, 1))); B = rs.normal(size=(K, N)) * np.exp(rs.normal(size=(1, N)) * 2)   # wide dynamic range
+    A = A.astype(np.float32).astype(np.float64); B = B.astype(np.float32).astype(np.float64)
+    bias = rs.normal(size=N)
+    ref = A @ B
+    mag = np.abs(A) @ np.abs(B)                                                # scale of the rounding error of every output
+    if mode == 0:
+        Ad, Bd, lda, ldb = dev(A), dev(B), K, N
+    elif mode == 1:
+        Ad, Bd, lda, ldb = dev(A), dev(B.T), K, K
+    else:
+        Ad, Bd, lda, ldb = dev(A.T), dev(B), Mm, N
+    C3 = host(_gemm_x3(mode, Ad, Bd, Mm, N, K, lda, ldb, N)).astype(np.float64)
+    C1 = host(gemm(mode, Ad, Bd, Mm, N, K, lda, ldb, N)).astype(np.float64)
+    e3 = float((np.abs(C3 - ref) / mag).max()); e1 = float((np.abs(C1 - ref) / mag).max())
+    print("x3 error %.3g of sum|a||b| (fp32 MFMA kernel: %.3g)" % (e3, e1))
+    assert e3 < 4 * e1 + 3e-7, (e3, e1)                                        # fp32 round-off: 6e-8 per operation
+    C = _gemm_x3(mode, Ad, Bd, Mm, N, K, lda, ldb, N, bias=dev(bias), act=1)
+    assert_close(host(C), np.maximum(ref + bias, 0), rtol=1e-5, atol=3e-6 * mag.max(), what="bias+relu")
+    C0 = rs.normal(size=(Mm, N))
+    C = _gemm_x3(mode, Ad, Bd, Mm, N, K, lda, ldb, N, acc=1, C=dev(C0))
+    assert_close(host(C), ref + C0, rtol=1e-5, atol=3e-6 * mag.max(), what="accumulate")
+
+
+def test_gemm_three_plane_split_reduction_permute_and_statistics():
+    rs = np.random.RandomState(3)
+    K, Mm, N = 40000, 64, 128
+    X = rs.normal(size=(K, Mm)); G = rs.normal(size=(K, N))
+    C = _gemm_x3(2, dev(X), dev(G), Mm, N, K, Mm, N, N)
+    assert_close(host(C), X.T @ G, rtol=1e-5, atol=1e-3, what="TN split")
+    A = rs.normal(size=(130, 4608)); W = rs.normal(size=(4608, 128)) * 0.02; b = rs.normal(size=128)
+    C3 = _gemm_x3(0, dev(A), dev(W), 130, 128, 4608, 4608, 128, 128, bias=dev(b), act=1, perm=10)
+    ref = np.maximum(A @ W + b, 0).reshape(13, 10, 128).transpose(1, 0, 2).reshape(130, 128)
+    assert_close(host(C3), ref, rtol=1e-5, atol=1e-5, what="NN split+epilogue")
+    # pointwise conv with the BatchNorm statistics epilogue (crnn_pwconv_fwd, product selector 2) against the fp32-MFMA path
+    M, K2, N2 = 128 * 37 + 5, 64, 128
+    a = rs.normal(size=(M, K2)); w = rs.normal(size=(K2, N2)) * 0.2
+    rows = L().crnn_pwconv_stat_rows(M)
+    q3, q1 = zeros(M, N2), zeros(M, N2); st3, st1 = zeros(rows * 2 * N2), zeros(rows * 2 * N2)
+    ok(L().crnn_pwconv_fwd(P(dev(a)), P(dev(w)), P(q3), M, N2, K2, P(st3), None, 2, 0, 0, 0, 0, S()))
+    ok(L().crnn_pwconv_fwd(P(dev(a)), P(dev(w)), P(q1), M, N2, K2, P(st1), None, 0, 0, 0, 0, 0, S()))
+    assert_close(host(q3), host(q1), rtol=1e-5, atol=2e-6 * float(np.abs(host(q1)).max()), what="pwconv x3 vs fp32")
+    s3 = host(st3).reshape(rows, 2, N2).sum(0); s1 = host(st1).reshape(rows, 2, N2).sum(0)
+    assert_close(s3, s1, rtol=1e-5, atol=1e-4 * float(np.abs(s1).max()), what="pwconv statistics")
+
+
 def test_gemm_row_permute_and_ld():
     rs = np.random.RandomState(0)
     Bn, T, K, N = 6, 5, 40, 24
@@ -423,7 +486,8 @@ def test_persistent_lstm_reports_a_lost_cluster():
     eng.check_rnn_status()                                                     # clean run: no exception
     side = torch.cuda.Stream()
     # 150 KiB of LDS per spinner block: at most one per CU and nothing with more than 10 KiB of LDS beside it (the recurrence needs 17.6)
-    ok(L().crnn_debug_occupy(cus - 2, 150 * 1024, 7 * 1000 * 1000, ctypes.c_void_p(side.cuda_stream)))   # 7 s; a wait gives up after 2 s
+    # (not ok(): that helper synchronises the device, i.e. would wait the spinners out)
+    assert L().crnn_debug_occupy(cus - 2, 150 * 1024, 7 * 1000 * 1000, ctypes.c_void_p(side.cuda_stream)) == 0   # 7 s; a wait gives up after 2 s
     import time
     time.sleep(0.2)                                                            # the spinners are resident before the forward is enqueued
     t0 = time.perf_counter()
