@@ -242,10 +242,10 @@ __global__ __launch_bounds__(256 + 64 * NIO) void pw_wgrad_stream_kernel(WgParam
 // out[i] = sum_s part[s][i] in a fixed grouping (deterministic): 8 split-lanes per output quad (lane l takes s = l, l + 8, ... with four
 // loads in flight), combined through LDS in lane order.  32 quads per workgroup: 256 workgroups for a 128 x 256 gradient -- the partials are
 // ingested by the whole chip instead of by 32 CUs.
-__global__ __launch_bounds__(256) void pw_wgrad_sum_kernel(const float* __restrict__ part, int nsplit, long total, float* __restrict__ out, int N, int ldc) {
+__device__ __forceinline__ void pw_wgrad_sum_block(const float* __restrict__ part, int nsplit, long total, float* __restrict__ out, int N, int ldc, int blk) {
   __shared__ float4 red[8][32];
   const int q = threadIdx.x & 31, l = threadIdx.x >> 5;
-  const long i = ((long)blockIdx.x * 32 + q) * 4;
+  const long i = ((long)blk * 32 + q) * 4;
   float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
   if (i < total) {
     int s = l;
@@ -265,6 +265,18 @@ __global__ __launch_bounds__(256) void pw_wgrad_sum_kernel(const float* __restri
     for (int k = 1; k < 8; ++k) { const float4 v = red[k][q]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
     *reinterpret_cast<float4*>(out + (i / N) * ldc + i % N) = r;
   }
+}
+__global__ __launch_bounds__(256) void pw_wgrad_sum_kernel(const float* __restrict__ part, int nsplit, long total, float* __restrict__ out, int N, int ldc) {
+  pw_wgrad_sum_block(part, nsplit, total, out, N, ldc, blockIdx.x);
+}
+// the second stages of several weight-gradient streams in ONE launch (crnn_wgrad_sum_batch): a workgroup finds its job by its block
+// range and runs the very code above on it -- same sums, same order, 5 us of dependent launch per job less
+struct SumBatch { crnn_sum_job job[CRNN_SUM_BATCH_MAX]; int first[CRNN_SUM_BATCH_MAX + 1]; int n; };
+__global__ __launch_bounds__(256) void pw_wgrad_sum_batch_kernel(SumBatch b) {
+  int j = 0;
+  while (j + 1 < b.n && (int)blockIdx.x >= b.first[j + 1]) ++j;
+  const crnn_sum_job& jb = b.job[j];
+  pw_wgrad_sum_block(jb.partials, jb.nsplit, jb.total, jb.out, jb.N, jb.ldc, blockIdx.x - b.first[j]);
 }
 
 void wg_geom(long M, int N, int K, WgParams& p, int& grid) {
@@ -297,7 +309,7 @@ extern "C" size_t crnn_pwconv_wgrad_stream_scratch_bytes(long M, int N, int K) {
 }
 namespace {
 template <bool F32>
-int wg_launch(WgParams& p, long M, float* out, int ldc, float* scratch, size_t scratch_bytes, hipStream_t stream) {
+int wg_launch(WgParams& p, long M, float* out, int ldc, float* scratch, size_t scratch_bytes, hipStream_t stream, crnn_sum_job* defer = nullptr) {
   int grid;
   wg_geom(M, p.N, p.K, p, grid);
 #ifdef CRNN_WG_TRACE
@@ -311,30 +323,56 @@ int wg_launch(WgParams& p, long M, float* out, int ldc, float* scratch, size_t s
   else hipLaunchKernelGGL((pw_wgrad_stream_kernel<8, F32>), dim3(grid), dim3(768), lds, stream, p);
   CRNN_LAUNCH_CHECK();
   const long total = (long)p.K * p.N;
+  if (defer) {   // the caller batches the second stage (crnn_wgrad_sum_batch); `scratch` must stay untouched until then
+    defer->partials = scratch; defer->nsplit = p.nsplit; defer->total = total; defer->out = out; defer->N = p.N; defer->ldc = ldc;
+    return CRNN_OK;
+  }
   hipLaunchKernelGGL(pw_wgrad_sum_kernel, dim3(cdiv(total, 128)), dim3(256), 0, stream, scratch, p.nsplit, total, out, p.N, ldc);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
 }  // namespace
 
+// Second stages of up to CRNN_SUM_BATCH_MAX deferred weight-gradient streams (crnn_pwconv_bnrelu6_wgrad_stream_defer / crnn_gemm_tn_stream_defer)
+// in one launch; results bit-identical to the immediate forms.
+extern "C" int crnn_wgrad_sum_batch(const crnn_sum_job* jobs, int n, hipStream_t stream) {
+  if (n <= 0) return CRNN_OK;
+  if (!jobs || n > CRNN_SUM_BATCH_MAX) return CRNN_ERR_ARG;
+  SumBatch b; b.n = n; int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!jobs[i].partials || !jobs[i].out || jobs[i].total <= 0 || (jobs[i].total & 3) || jobs[i].nsplit < 1) return CRNN_ERR_ARG;
+    b.job[i] = jobs[i]; b.first[i] = blocks; blocks += cdiv(jobs[i].total, 128);
+  }
+  for (int i = n; i < CRNN_SUM_BATCH_MAX; ++i) { b.job[i] = jobs[0]; b.first[i] = blocks; }
+  b.first[CRNN_SUM_BATCH_MAX] = blocks;
+  hipLaunchKernelGGL(pw_wgrad_sum_batch_kernel, dim3(blocks), dim3(256), 0, stream, b);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+
 // dw[K][N] (fp32) = ReLU6(d * scale + shift)^T [K][M] . g[M][N]; d, g bf16; in_bnstate = [mean|var|scale|shift] of the BatchNorm on d
-extern "C" int crnn_pwconv_bnrelu6_wgrad_stream(const void* d, const float* in_bnstate, const void* g, float* dw, long M, int N, int K,
-                                                float* scratch, size_t scratch_bytes, hipStream_t stream) {
+// `defer` (may be NULL): only the first stage runs, *defer describes the second one for crnn_wgrad_sum_batch (scratch stays live until then)
+extern "C" int crnn_pwconv_bnrelu6_wgrad_stream_defer(const void* d, const float* in_bnstate, const void* g, float* dw, long M, int N, int K,
+                                                      float* scratch, size_t scratch_bytes, crnn_sum_job* defer, hipStream_t stream) {
   if (!in_bnstate || !scratch) return CRNN_ERR_ARG;
   CRNN_TRY(crnn_pwconv_wgrad_stream_supported(M, N, K));
   if ((((uintptr_t)d | (uintptr_t)g | (uintptr_t)dw | (uintptr_t)scratch) & 15)) return CRNN_ERR_UNSUPPORTED;
   WgParams p;
   p.D = (const bf16_t*)d; p.G = (const bf16_t*)g; p.part = scratch; p.scale = in_bnstate + 2L * K; p.shift = in_bnstate + 3L * K;
   p.M = (int)M; p.N = N; p.K = K; p.lda = K; p.ldg = N;
-  return wg_launch<false>(p, M, dw, N, scratch, scratch_bytes, stream);
+  return wg_launch<false>(p, M, dw, N, scratch, scratch_bytes, stream, defer);
+}
+extern "C" int crnn_pwconv_bnrelu6_wgrad_stream(const void* d, const float* in_bnstate, const void* g, float* dw, long M, int N, int K,
+                                                float* scratch, size_t scratch_bytes, hipStream_t stream) {
+  return crnn_pwconv_bnrelu6_wgrad_stream_defer(d, in_bnstate, g, dw, M, N, K, scratch, scratch_bytes, nullptr, stream);
 }
 
 // The same stream for fp32 operands (rounded to bf16 on the way in, like crnn_gemm_bf16_ex mode 2 with fp32 A and B):
 //     C[M][N] (fp32, row stride ldc) = A^T . B,   A [K][lda >= M] fp32, B [K][ldb >= N] fp32, K = the reduction over rows.
 // The weight gradients of the recurrent layers (dW = X^T dZ, dU = H^T dZ over T*B rows).  Supported (else -3): M, N multiples of
 // 128 up to 1024, K a multiple of 64, lda / ldb / ldc multiples of 4, 16-byte aligned pointers; scratch as above.
-extern "C" int crnn_gemm_tn_stream(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, long K, float* scratch,
-                                   size_t scratch_bytes, hipStream_t stream) {
+extern "C" int crnn_gemm_tn_stream_defer(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, long K, float* scratch,
+                                         size_t scratch_bytes, crnn_sum_job* defer, hipStream_t stream) {
   if (!scratch) return CRNN_ERR_ARG;
   CRNN_TRY(crnn_pwconv_wgrad_stream_supported(K, N, M));
   if (lda < M || ldb < N || ldc < N || ((lda | ldb | ldc) & 3)) return CRNN_ERR_UNSUPPORTED;
@@ -343,7 +381,11 @@ extern "C" int crnn_gemm_tn_stream(const float* A, int lda, const float* B, int 
   WgParams p;
   p.D = (const bf16_t*)A; p.G = (const bf16_t*)B; p.part = scratch; p.scale = nullptr; p.shift = nullptr;
   p.M = (int)K; p.N = N; p.K = M; p.lda = lda; p.ldg = ldb;
-  return wg_launch<true>(p, K, C, ldc, scratch, scratch_bytes, stream);
+  return wg_launch<true>(p, K, C, ldc, scratch, scratch_bytes, stream, defer);
+}
+extern "C" int crnn_gemm_tn_stream(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, long K, float* scratch,
+                                   size_t scratch_bytes, hipStream_t stream) {
+  return crnn_gemm_tn_stream_defer(A, lda, B, ldb, C, ldc, M, N, K, scratch, scratch_bytes, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

@@ -103,6 +103,8 @@ bool rnn_persist(const crnn_config* c) {
   return (c->gru ? crnn_gru_persist_supported(c->units, rnn_dtu(c)) : crnn_lstm_persist_supported(c->units, rnn_dtu(c))) == 0;
 }
 
+size_t deferred_scratch_bytes(const crnn_config* cfg, const Dims& d);   // (defined with the deferred second stages below)
+
 // uw argument of the persistent recurrences: automatic workgroup size, XCD-local clusters unless the linear map is asked for.
 // Measured at B = 256, u = 256 (profiles/r03_lstm_cache_policy.txt): with the XCD-local map and, once a cluster has verified that its
 // members share an XCD, plain exchange stores the LSTM forward takes 98 us per layer (linear map + write-through stores: 131) and the
@@ -185,15 +187,22 @@ Plan make_plan(const crnn_config* c) {
   P.add("gemm_scratch", 16L * 1024 * 1024);   // 64 MiB of split-reduction partials (main stream)
   P.add("gemm_scratch2", 16L * 1024 * 1024);  // the same for the side stream of the backward
   P.add("partials2", lmax((long)crnn_colreduce_chunks(TB) * lmax(d.G, lmax(d.tds, d.C)), 1024));
+  if (c->mfma_bf16 && !(c->flags & (CRNN_FLAG_NO_DEFERRED_SUMS | CRNN_FLAG_GEMM_TILE_KERNELS)))
+    P.add("wgrad_scratch", (long)(deferred_scratch_bytes(c, d) / sizeof(float)) + 64);   // partial tiles of the deferred weight-gradient second stages
   if (rnn_persist(c)) P.add("rnnx", (long)((crnn_lstm_persist_xbuf_bytes(d.T, d.B, d.u, rnn_dtu(c)) + 3) / 4));   // h_t / dz_t exchange tiles
   return P;
 }
 
 const size_t kGemmScratchBytes = 64UL * 1024 * 1024;
 
+// Second stages of the streaming weight gradients, collected over a backward stage and run as one launch (crnn_wgrad_sum_batch): each
+// deferred first stage keeps its partial tiles in its own piece of the "wgrad_scratch" workspace tensor until the flush.
+struct Deferred { std::vector<crnn_sum_job> jobs; size_t used = 0, cap = 0; float* base = nullptr; };
+
 struct Ctx {
   const crnn_config* cfg; Dims d; Layout L; Plan P;
   const float* params; float* grads; float* ws; hipStream_t s;
+  Deferred* def = nullptr;   // null: every second stage right after its first stage
   const float* p(const std::string& n) const { return params + L.off(n); }
   float* g(const std::string& n) const { return grads + L.off(n); }
   float* w(const std::string& n) const { return ws + P.off(n); }
@@ -249,6 +258,35 @@ bool fuse_dw_bn(const crnn_config* cfg, int dtd, int dtq, int ci) {
 int gemm32(const Ctx& c, int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
            const float* bias = nullptr, int act = 0, int acc = 0, int perm = 0) {
   return crnn_gemm_f32(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, c.scratch(), kGemmScratchBytes, c.s);
+}
+
+int flush_deferred(const Ctx& c) {
+  if (!c.def || c.def->jobs.empty()) return CRNN_OK;
+  const int rc = crnn_wgrad_sum_batch(c.def->jobs.data(), (int)c.def->jobs.size(), c.s);
+  c.def->jobs.clear(); c.def->used = 0;
+  return rc;
+}
+// a piece of the deferred scratch for `bytes` of partial tiles (null: not deferring, or it can never fit); flushes first when full
+float* deferred_scratch(const Ctx& c, size_t bytes, int* rc) {
+  *rc = CRNN_OK;
+  if (!c.def || bytes == 0 || bytes > c.def->cap) return nullptr;
+  if (c.def->used + bytes > c.def->cap || (int)c.def->jobs.size() >= CRNN_SUM_BATCH_MAX) { *rc = flush_deferred(c); if (*rc) return nullptr; }
+  float* ptr = c.def->base + c.def->used / sizeof(float);
+  c.def->used += (bytes + 255) & ~(size_t)255;
+  return ptr;
+}
+// bytes of deferred scratch one backward stage needs at most (make_plan)
+size_t deferred_scratch_bytes(const crnn_config* cfg, const Dims& d) {
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const long TB = (long)d.T * d.B, K1 = (long)(d.T - 1) * d.B;
+  const int Nh = cfg->gru ? 2 * d.u : d.G;
+  size_t top = 0, bottom = 0;
+  for (int l = 1; l <= 2; ++l) {
+    const int din = l == 1 ? d.tds : d.u;
+    top += 2 * al(crnn_pwconv_wgrad_stream_scratch_bytes(TB, d.G, din)) + 2 * al(crnn_pwconv_wgrad_stream_scratch_bytes(K1, Nh, d.u));
+  }
+  for (int i = 2; i <= 7; ++i) bottom += al(crnn_pwconv_wgrad_stream_scratch_bytes((long)d.B * d.bh[i] * d.bw[i], d.bc[i], d.bc[i - 1]));
+  return top > bottom ? top : bottom;
 }
 
 int colsum(const Ctx& c, const float* x, long M, int C, int ld, float* out) {
@@ -562,6 +600,15 @@ static int rnn_bwd_chain(const Ctx& c, int layer, const float* hf, const float* 
 // rules hold (gemm_wgrad.hip, fp32 operands rounded to bf16 on the way in like the tile GEMM does), else the tile GEMM
 static int gemm_tn(const Ctx& c, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc) {
   if (c.cfg->mfma_bf16 && !(c.cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS)) {
+    const size_t need = c.def ? crnn_pwconv_wgrad_stream_scratch_bytes(K, N, M) : 0;
+    int rc0 = CRNN_OK;
+    if (float* sc = deferred_scratch(c, need, &rc0)) {      // first stage now, the fixed-order sum with the stage's other second stages
+      crnn_sum_job job;
+      const int rc = crnn_gemm_tn_stream_defer(A, lda, B, ldb, C, ldc, M, N, K, sc, need, &job, c.s);
+      if (rc == CRNN_OK) { c.def->jobs.push_back(job); return CRNN_OK; }
+      if (rc != CRNN_ERR_UNSUPPORTED) return rc;
+    }
+    CRNN_TRY(rc0);
     const int rc = crnn_gemm_tn_stream(A, lda, B, ldb, C, ldc, M, N, K, c.scratch(), kGemmScratchBytes, c.s);
     if (rc != CRNN_ERR_UNSUPPORTED) return rc;
   }
@@ -697,7 +744,17 @@ struct ForkJoin {
   }
 };
 
-int backward_top(const Ctx& c, const int* labels, const int* input_length, const int* label_length, float* loss, uint64_t seed, hipStream_t aux) {
+// deferred second stages: serial schedule only (a side stream's first stages could not share one flush), bf16 modes with the streaming kernels
+void deferred_setup(const Ctx& c0, Ctx& c, Deferred& def, hipStream_t aux) {
+  c = c0;
+  const long off = c0.P.off("wgrad_scratch");
+  if (aux || off < 0) return;
+  def.base = c0.ws + off; def.cap = (size_t)(c0.P.cnt("wgrad_scratch") - 64) * sizeof(float);
+  c.def = &def;
+}
+
+int backward_top(const Ctx& c0, const int* labels, const int* input_length, const int* label_length, float* loss, uint64_t seed, hipStream_t aux) {
+  Deferred def; Ctx c; deferred_setup(c0, c, def, aux);
   const crnn_config* cfg = c.cfg; float* grads = c.grads; hipStream_t stream = c.s;
   const Dims& d = c.d;
   const int B = d.B, T = d.T, TB = T * B, u = d.u;
@@ -730,7 +787,7 @@ int backward_top(const Ctx& c, const int* labels, const int* input_length, const
   CRNN_TRY(colsum(c, c.w("gbm"), TB, d.tds, d.tds, c.g("dense1_b")));
   float* gA = c.w("gA"); float* gB = c.w("gB");
   CRNN_TRY(gemm_t(c, 1, c.w("gbm"), CRNN_F32, c.p("dense1_w"), CRNN_F32, gA, c.gdt(), TB, d.feat, d.tds, d.tds, d.tds, d.feat));
-  return CRNN_OK;
+  return flush_deferred(c);                             // every gradient of this stage is final (a data-parallel host exchanges them now)
 }
 
 // aux != nullptr: the pointwise weight-gradient GEMM of every block runs on the side stream next to the rest of the block's
@@ -738,7 +795,8 @@ int backward_top(const Ctx& c, const int* labels, const int* input_length, const
 // matrix cores and most of the vector-memory path idle).  The GEMM reads the BatchNorm-2 input gradient of its block, so the
 // gradient buffers rotate over three allocations and the main stream waits for GEMM i before the buffer it reads is written
 // again (by the depthwise stage of block i-1).  One writer per gradient tensor, fixed order: bit-identical to the serial schedule.
-int backward_bottom(const Ctx& c, const float* x, uint64_t seed, hipStream_t aux) {
+int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t aux) {
+  Deferred def; Ctx c; deferred_setup(c0, c, def, aux);
   const crnn_config* cfg = c.cfg; hipStream_t stream = c.s;
   const Dims& d = c.d;
   const int B = d.B;
@@ -766,8 +824,18 @@ int backward_bottom(const Ctx& c, const float* x, uint64_t seed, hipStream_t aux
       if (side) CRNN_TRY(fj.fork());
       if (fuse_dw_bn(cfg, dtd, dtq, ci)) {  // the activated tensor was never written: re-form it from d while staging (as the forward did)
         int rc = CRNN_ERR_UNSUPPORTED;        // pixel-streaming kernel (gemm_wgrad.hip) where its shape rules hold, else the tile GEMM
-        if (!(cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS) && crnn_pwconv_wgrad_stream_supported(M, co, ci) == CRNN_OK)
-          rc = crnn_pwconv_bnrelu6_wgrad_stream(c.w("d" + p), c.w("bn1s" + p), gB, c.g(bp + "_pw"), M, co, ci, cw.scratch(), kGemmScratchBytes, cw.s);
+        if (!(cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS) && crnn_pwconv_wgrad_stream_supported(M, co, ci) == CRNN_OK) {
+          const size_t need = cw.def ? crnn_pwconv_wgrad_stream_scratch_bytes(M, co, ci) : 0;
+          int rc0 = CRNN_OK;
+          if (float* sc = deferred_scratch(cw, need, &rc0)) {
+            crnn_sum_job job;
+            rc = crnn_pwconv_bnrelu6_wgrad_stream_defer(c.w("d" + p), c.w("bn1s" + p), gB, c.g(bp + "_pw"), M, co, ci, sc, need, &job, cw.s);
+            if (rc == CRNN_OK) cw.def->jobs.push_back(job);
+          }
+          CRNN_TRY(rc0);
+          if (rc == CRNN_ERR_UNSUPPORTED)
+            rc = crnn_pwconv_bnrelu6_wgrad_stream(c.w("d" + p), c.w("bn1s" + p), gB, c.g(bp + "_pw"), M, co, ci, cw.scratch(), kGemmScratchBytes, cw.s);
+        }
         if (rc == CRNN_ERR_UNSUPPORTED)
           rc = crnn_pwconv_bnrelu6_wgrad(c.w("d" + p), c.w("bn1s" + p), gB, c.g(bp + "_pw"), M, co, ci, cw.scratch(), kGemmScratchBytes, cw.s);
         CRNN_TRY(rc);
@@ -821,6 +889,7 @@ int backward_bottom(const Ctx& c, const float* x, uint64_t seed, hipStream_t aux
     if (i > 1 || cfg->stn) CRNN_TRY(crnn_dwconv3x3_fwd_ex(gB, c.p(bp + "_dw"), gA, nullptr, B, H, W, ci, 1, dtd, stream));
   }
   CRNN_TRY(fj.join());                                   // every weight gradient is complete in the main stream's order
+  CRNN_TRY(flush_deferred(c));
   // ---- spatial transformer
   if (cfg->stn) {
     CRNN_TRY(crnn_sampler_bwd(x, c.w("theta"), gA, c.w("dtheta"), B, d.H0, d.W0, 2, stream));

@@ -53,6 +53,8 @@ typedef struct {
                                          GEMM (crnn_gemm_bf16_ex / crnn_pwconv_bnrelu6_*) instead of the streaming kernels (crnn_pwconv_bnrelu6_fwd_wres,
                                          crnn_gemm_wres_bf16, crnn_pwconv_bnrelu6_wgrad_stream).  Same products and data gradients bit for bit; the
                                          BatchNorm-2 statistics and the weight gradients are the same sums in another order (fp32 round-off) */
+#define CRNN_FLAG_NO_DEFERRED_SUMS 512   /* second stage of every streaming weight gradient right after its first stage (13 launches per step) instead of
+                                         batched at the end of each backward stage (crnn_wgrad_sum_batch); bit-identical */
 #define CRNN_FLAG_FP32_MFMA_GEMMS 256   /* parity mode (mfma_bf16 = 0): conv-stack / dense / RNN-projection GEMMs on v_mfma_f32_32x32x2_f32 (crnn_gemm_f32:
                                          bit-equal to an fmaf chain, 157 TFLOP/s peak) instead of the three-plane bf16 products of crnn_gemm_f32x3
                                          (fp32-level accuracy, 2.7x the matrix rate); results agree to fp32 round-off */
@@ -381,6 +383,17 @@ int crnn_pwconv_bnrelu6_wgrad_stream(const void* d, const float* in_bnstate, con
  * multiples of 4, 16-byte aligned pointers; scratch: crnn_pwconv_wgrad_stream_scratch_bytes(K, N, M). */
 int crnn_gemm_tn_stream(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, long K, float* scratch,
                         size_t scratch_bytes, crnn_stream_t stream);
+/* Deferred second stages.  The two streaming weight-gradient entries above are stage 1 (partial tiles into `scratch`) + stage 2 (a fixed-order
+ * sum into the gradient, ~5 us of dependent launch each, 13 per train step).  The *_defer forms run stage 1 only and describe stage 2 in
+ * *job; crnn_wgrad_sum_batch runs up to CRNN_SUM_BATCH_MAX of them in ONE launch -- the same sums in the same order, bit-identical
+ * gradients.  Each deferred call needs its own scratch until the batch has run (crnn_pwconv_wgrad_stream_scratch_bytes). */
+#define CRNN_SUM_BATCH_MAX 16
+typedef struct { const float* partials; float* out; long total; int nsplit, N, ldc; } crnn_sum_job;
+int crnn_pwconv_bnrelu6_wgrad_stream_defer(const void* d, const float* in_bnstate, const void* g, float* dw, long M, int N, int K,
+                                           float* scratch, size_t scratch_bytes, crnn_sum_job* job, crnn_stream_t stream);
+int crnn_gemm_tn_stream_defer(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, long K, float* scratch,
+                              size_t scratch_bytes, crnn_sum_job* job, crnn_stream_t stream);
+int crnn_wgrad_sum_batch(const crnn_sum_job* jobs, int n, crnn_stream_t stream);
 /* Input gradient of a Bidirectional layer's input projections in one streaming launch: Y[M][N] (fp32, row stride ldy) = A0[M][K] . W0[N][K]^T
  * (+ A1 . W1^T when A1 != NULL), A fp32 (rounded to bf16 on the way in), W bf16; one workgroup per 64-row stripe keeps its result in the
  * MFMA waves' registers over the whole reduction.  Supported (else -3): M % 64 == 0, N in {128, 256}, K % 64 == 0, leading dimensions
