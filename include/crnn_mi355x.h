@@ -425,6 +425,8 @@ int crnn_pwconv_bnrelu6_fwd_wres(const void* d, const float* in_bnstate, const v
  * only if they agree, exchanges with plain L2-resident stores instead of write-through ones -- same results for any placement.  crnn_lstm_persist_supported: 0 if (u, dt_u) has a kernel
  * (fp32: u in {64,128,256}; bf16: u in {128,256,512}), else -3 -- use the step kernels then. */
 #define CRNN_RNN_XCD_LOCAL 0x100
+#define CRNN_RNN_DEBUG_DROP_MEMBER 0x200   /* crnn_lstm_fwd_persist only, tests: the last workgroup of the grid is not launched, so its cluster loses a
+                                              member for good -- the others wait their 2 s, give up and report it (status word, sticky counter) */
 size_t crnn_lstm_persist_xbuf_bytes(int T, int B, int u, int dt_u);
 int crnn_lstm_persist_supported(int u, int dt_u);
 int crnn_lstm_fwd_persist(const float* xw0, const float* xw1, const void* ut0, const void* ut1, float* h0, float* h1, int ldh,
