@@ -390,6 +390,7 @@ def lstm_roofline(eng, iters=10):
         U = lambda n: ctypes.c_void_p(pbf.data_ptr() + 2 * eng.layout[n][0])
     else:
         U = lambda n: ctypes.c_void_p(eng.params.data_ptr() + 4 * eng.layout[n][0])
+    uwf = 0 if (cfg.flags & 64) else 0x100        # the step's own workgroup -> cluster map (XCD-local unless CRNN_FLAG_RNN_LINEAR_CLUSTERS)
     xb = W("rnnx") if persist else None
     nx = lib.crnn_lstm_persist_xbuf_bytes(T, B, u, dt) if persist else 0
     off = lambda t, e: ctypes.c_void_p(t.data_ptr() + 4 * e)
@@ -403,8 +404,8 @@ def lstm_roofline(eng, iters=10):
             g = [U("rnn%df_u" % l), U("rnn%db_u" % l), _ptr(W("cs%df" % l)), _ptr(W("cs%db" % l)), _ptr(W("gt%df" % l)), _ptr(W("gt%db" % l)), p(do0), p(do1),
                  ldh, _ptr(W("dz%df" % l)), _ptr(W("dz%db" % l))]
             if persist:
-                rc = lib.crnn_lstm_fwd_persist(*a, _ptr(xb), nx, 0, 0, _stream())
-                rc |= lib.crnn_lstm_bwd_persist(*g, T, B, u, dt, _ptr(xb), nx, 0, 0, _stream())
+                rc = lib.crnn_lstm_fwd_persist(*a, _ptr(xb), nx, 0, uwf, _stream())
+                rc |= lib.crnn_lstm_bwd_persist(*g, T, B, u, dt, _ptr(xb), nx, 0, uwf, _stream())
             else:
                 rc = lib.crnn_lstm_fwd_ex(*a, _stream())
                 rc |= lib.crnn_lstm_bwd_ex(*g, _ptr(dcf), _ptr(dcb), T, B, u, dt, _stream())
@@ -420,11 +421,42 @@ def lstm_roofline(eng, iters=10):
     flops = 2 * 2 * (2.0 * T * 2 * B * u * 4 * u)          # 2 layers x (forward + backward)
     peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
     ach = flops / t / 1e12
+    # the other half of the gate GEMM: the input projections x W + b hoisted over all T steps (four launches per forward), on the live buffers
+    G = 4 * u
+    proj = []
+    for n, src, k in (("rnn1f", "dn1", cfg.tds), ("rnn1b", "dn1", cfg.tds), ("rnn2f", "r1", u), ("rnn2b", "r1", u)):
+        proj.append((W(src), W("wt" + n[3:5]) if bf else None, W("xw" + n[3:5]), eng.params[eng.layout[n + "_w"][0]:], eng.params[eng.layout[n + "_b"][0]:], k))
+    TB = T * B
+    pt = []
+    scratch = W("gemm_scratch")
+    for it in range(iters + 2):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for xin, wt, out, wfp, bias, k in proj:
+            if bf and u % 128 == 0 and not (cfg.flags & 2) and TB % 64 == 0 and k % 64 == 0:
+                rc = lib.crnn_gemm_nt_f32_stream_bias(_ptr(xin), _ptr(wt), None, None, _ptr(out), _ptr(bias), TB, G, k, k, k, G, _stream())
+            elif bf:
+                rc = lib.crnn_gemm_bf16_ex(0, _ptr(xin), _ptr(wfp), _ptr(out), TB, G, k, k, G, G, _ptr(bias), 0, 0, 0, _ptr(scratch), 64 * 1024 * 1024, 0, 0, 0, _stream())
+            else:
+                rc = lib.crnn_gemm_f32x3(0, _ptr(xin), _ptr(wfp), _ptr(out), TB, G, k, k, G, G, _ptr(bias), 0, 0, 0, _ptr(scratch), 64 * 1024 * 1024, _stream())
+            assert rc == 0, rc
+        e1.record(); torch.cuda.synchronize()
+        if it >= 2:
+            pt.append(e0.elapsed_time(e1) * 1e-3)
+    tp = float(np.median(pt))
+    pflops = sum(2.0 * TB * k * G for *_, k in proj)
     return {"bound": "mfma", "kernel": ("lstm_fwd/bwd_persist_kernel (one launch per layer and pass: cluster of workgroups per batch tile, recurrent "
                                         "weights + cell state in registers, h/dz all-gather through a sentinel ring, LDS-staged MFMA operand)" if persist
                                         else "lstm_fwd/bwd_step_kernel (one launch per timestep)"),
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "launches": 4 if persist else 4 * T,
             "ms_per_train_step": round(1e3 * t, 4), "us_per_step": round(1e6 * t / (4 * T), 3), "flops_recurrent_gemm": flops,
+            "input_projections": {"achieved": round(pflops / tp / 1e12, 2), "unit": "TFLOP/s", "frac": round(pflops / tp / 1e12 / peak, 4), "launches": 4,
+                                  "ms": round(1e3 * tp, 4), "flops": pflops,
+                                  "note": "the hoisted half of the gate GEMM (x W + b over all T steps, forward): fp32 rows streamed once against a "
+                                          "bf16 W^T -- bound by reading the 14-27 MB of x and writing 55 MB of xw per launch, not by the matrix cores"},
+            "target_note": "north_star asks >= 40 % MFMA utilisation on the LSTM gate GEMM: the recurrent half is a chain of T dependent 268-MFLOP "
+                           "steps (0.1 us of MFMA work each against a 1.7 us cross-workgroup hand-off), the hoisted half is HBM-bound; neither can "
+                           "reach it at B = 256, T = 52 on any schedule (DESIGN.md section 4)",
             "note": "T = %d dependent steps per launch; each step's GEMM (2 x %d x %d x %d per direction) is ~0.1 us of MFMA work, the step time is "
                     "the cross-workgroup hand-off latency of h_t / dz_t" % (T, B, u, 4 * u)}
 

@@ -187,7 +187,7 @@ Plan make_plan(const crnn_config* c) {
   P.add("gemm_scratch", 16L * 1024 * 1024);   // 64 MiB of split-reduction partials (main stream)
   P.add("gemm_scratch2", 16L * 1024 * 1024);  // the same for the side stream of the backward
   P.add("partials2", lmax((long)crnn_colreduce_chunks(TB) * lmax(d.G, lmax(d.tds, d.C)), 1024));
-  if (c->mfma_bf16 && !(c->flags & (CRNN_FLAG_NO_DEFERRED_SUMS | CRNN_FLAG_GEMM_TILE_KERNELS)))
+  if (c->mfma_bf16 && (c->flags & CRNN_FLAG_DEFERRED_SUMS) && !(c->flags & CRNN_FLAG_GEMM_TILE_KERNELS))
     P.add("wgrad_scratch", (long)(deferred_scratch_bytes(c, d) / sizeof(float)) + 64);   // partial tiles of the deferred weight-gradient second stages
   if (rnn_persist(c)) P.add("rnnx", (long)((crnn_lstm_persist_xbuf_bytes(d.T, d.B, d.u, rnn_dtu(c)) + 3) / 4));   // h_t / dz_t exchange tiles
   return P;

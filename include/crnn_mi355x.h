@@ -53,8 +53,9 @@ typedef struct {
                                          GEMM (crnn_gemm_bf16_ex / crnn_pwconv_bnrelu6_*) instead of the streaming kernels (crnn_pwconv_bnrelu6_fwd_wres,
                                          crnn_gemm_wres_bf16, crnn_pwconv_bnrelu6_wgrad_stream).  Same products and data gradients bit for bit; the
                                          BatchNorm-2 statistics and the weight gradients are the same sums in another order (fp32 round-off) */
-#define CRNN_FLAG_NO_DEFERRED_SUMS 512   /* second stage of every streaming weight gradient right after its first stage (13 launches per step) instead of
-                                         batched at the end of each backward stage (crnn_wgrad_sum_batch); bit-identical */
+#define CRNN_FLAG_DEFERRED_SUMS 512      /* opt-in: second stage of every streaming weight gradient batched at the end of its backward stage
+                                         (crnn_wgrad_sum_batch: 2 launches instead of 13 per step) instead of right after its first stage;
+                                         bit-identical; measured neutral (6.583 vs 6.584 ms: the second stages are bandwidth, not launch latency) */
 #define CRNN_FLAG_FP32_MFMA_GEMMS 256   /* parity mode (mfma_bf16 = 0): conv-stack / dense / RNN-projection GEMMs on v_mfma_f32_32x32x2_f32 (crnn_gemm_f32:
                                          bit-equal to an fmaf chain, 157 TFLOP/s peak) instead of the three-plane bf16 products of crnn_gemm_f32x3
                                          (fp32-level accuracy, 2.7x the matrix rate); results agree to fp32 round-off */

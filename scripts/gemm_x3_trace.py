@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""In-kernel timeline of the three-plane GEMM (crnn_gemm_f32x3) on the parity mode's deep-K pointwise shape: s_memrealtime stamps of one
+workgroup (trace build scripts/_trace/libgemm_exp.so, -DCRNN_GEMM_EXP -DCRNN_EXPERIMENT_HOOKS).  Per chunk: planes stored | barrier |
+96 MFMAs with the next chunk's split in their shadow | barrier."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+import numpy as np, torch
+lib = ctypes.CDLL(os.path.join(ROOT, "scripts", "_trace", os.environ.get("GEMM_LIB", "libgemm_exp.so")))
+P = lambda t: ctypes.c_void_p(t.data_ptr())
+S = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+M, N, K = 119808, 512, 512
+A = torch.randn(M, K, device="cuda"); B = torch.randn(K, N, device="cuda") * 0.05; C = torch.empty(M, N, device="cuda")
+trace = torch.zeros(64, dtype=torch.int64, device="cuda")
+os.environ["CRNN_GEMM_TRACE"] = hex(trace.data_ptr())
+args = [ctypes.c_int(0), P(A), P(B), P(C), M, N, K, K, N, N, None, 0, 0, 0, None, ctypes.c_size_t(0), S()]
+lib.crnn_gemm_f32x3.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 6 + [ctypes.c_void_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+for _ in range(3):
+    rc = lib.crnn_gemm_f32x3(*args); assert rc == 0, rc
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5): lib.crnn_gemm_f32x3(*args)
+e1.record(); torch.cuda.synchronize()
+t = trace.cpu().numpy()
+t = t[t > 0]
+d = np.diff(t) * 10
+print("kernel %.1f us; stamps of workgroup 300 (ns between stamps):" % (e0.elapsed_time(e1) / 5 * 1e3))
+print(" ".join("%d" % x for x in d))

@@ -266,7 +266,7 @@ def test_bf16s_producer_fused_pointwise_convs_equal_the_two_pass_path(shape):
     x, lab, il, ll = M.synthetic_batch(cfg, B, seed=4, dtype=np.float64)
     out = {}
     T = native.FLAG_GEMM_TILE_KERNELS | native.FLAG_DW_TILE_KERNEL
-    for flags in (T, T | native.FLAG_NO_DW_BN_FUSION, T | native.FLAG_RNN_STEP_KERNELS, T | native.FLAG_NO_DW_BWD_FUSION, native.FLAG_NO_DEFERRED_SUMS,
+    for flags in (T, T | native.FLAG_NO_DW_BN_FUSION, T | native.FLAG_RNN_STEP_KERNELS, T | native.FLAG_NO_DW_BWD_FUSION, native.FLAG_DEFERRED_SUMS,
                   native.FLAG_NO_BN_STATS_FUSION, 0):
         eng = Engine(B, imgh, imgw, ncls, max_len, tds, u, stn=True, dropout=True, precision="bf16s", flags=flags)
         eng.set_params(p, bn)
@@ -284,9 +284,9 @@ def test_bf16s_producer_fused_pointwise_convs_equal_the_two_pass_path(shape):
     rel = float((ga.double() - gb.double()).norm() / ga.double().norm())
     print("BatchNorm-statistics fusion on/off: gradient rel L2 %.3g" % rel)
     assert torch.isfinite(ga).all() and rel < 5e-2, rel
-    # second stages of the streaming weight gradients batched at the end of each backward stage (default) or right after their first
-    # stages: the same sums in the same order
-    yc, lc, gc = out[native.FLAG_NO_DEFERRED_SUMS]
+    # second stages of the streaming weight gradients right after their first stages (default) or batched at the end of each backward
+    # stage (CRNN_FLAG_DEFERRED_SUMS): the same sums in the same order
+    yc, lc, gc = out[native.FLAG_DEFERRED_SUMS]
     assert torch.equal(yc, yb) and torch.equal(lc, lb) and torch.equal(gc, gb), "deferred second stages changed the gradients"
     for flags in list(out)[1:-3]:
         y1, l1, g1 = out[flags]
