@@ -438,7 +438,8 @@ def lstm_roofline(eng, iters=10):
             elif bf:
                 rc = lib.crnn_gemm_bf16_ex(0, _ptr(xin), _ptr(wfp), _ptr(out), TB, G, k, k, G, G, _ptr(bias), 0, 0, 0, _ptr(scratch), 64 * 1024 * 1024, 0, 0, 0, _stream())
             else:
-                rc = lib.crnn_gemm_f32x3(0, _ptr(xin), _ptr(wfp), _ptr(out), TB, G, k, k, G, G, _ptr(bias), 0, 0, 0, _ptr(scratch), 64 * 1024 * 1024, _stream())
+                fn = lib.crnn_gemm_f32x3 if (cfg.flags & 256) else lib.crnn_gemm_f32
+                rc = fn(0, _ptr(xin), _ptr(wfp), _ptr(out), TB, G, k, k, G, G, _ptr(bias), 0, 0, 0, _ptr(scratch), 64 * 1024 * 1024, _stream())
             assert rc == 0, rc
         e1.record(); torch.cuda.synchronize()
         if it >= 2:

@@ -349,6 +349,33 @@ def test_gru_model_persistent_recurrences_equal_the_step_kernels(precision):
         assert torch.equal(y0, y1) and torch.equal(l0, l1) and torch.equal(g0, g1), flags
 
 
+def test_parity_mode_three_plane_gemms_track_the_fp32_mfma_path():
+    """CRNN_FLAG_X3_GEMMS (opt-in): the parity mode's big GEMMs as three-plane bf16 products.  Against the default fp32-MFMA path the whole
+    train step must agree to fp32 round-off: posteriors within 1e-5, CTC costs within 1e-5 relative, identical greedy decode, gradients
+    within 1e-4 of their norm."""
+    from crnn_mi355x import native
+    B, imgh, imgw, ncls, max_len, tds, u = 8, 100, 32, 38, 23, 128, 256
+    cfg = M.Config(imgh=imgh, imgw=imgw, max_len=max_len, time_dense_size=tds, n_units=u, num_classes=ncls)
+    p, bn = M.init_params(cfg, seed=9, dtype=np.float64)
+    p = M.randomize_params(cfg, p)
+    x, lab, il, ll = M.synthetic_batch(cfg, B, seed=3, dtype=np.float64)
+    out = {}
+    for flags in (0, native.FLAG_X3_GEMMS):
+        eng = Engine(B, imgh, imgw, ncls, max_len, tds, u, stn=True, dropout=False, precision="fp32", flags=flags)
+        eng.set_params(p, bn)
+        eng.grads.zero_()
+        y = eng.forward(x.astype(np.float32), train=True, seed=1).clone()
+        loss = eng.backward(lab, il, ll, seed=1).clone()
+        dec = eng.greedy_decode()[0].clone()
+        out[flags] = (y, loss, eng.grads.clone(), dec)
+        del eng
+    (y0, l0, g0, d0), (y1, l1, g1, d1) = out[0], out[native.FLAG_X3_GEMMS]
+    dy = float((y0 - y1).abs().max()); dl = float(((l0 - l1).abs() / l0.abs().clamp_min(1.0)).max())
+    dg = float((g0.double() - g1.double()).norm() / g0.double().norm())
+    print("three-plane vs fp32 MFMA: max |dy| %.3g, max rel dloss %.3g, gradient rel L2 %.3g" % (dy, dl, dg))
+    assert torch.isfinite(g1).all() and dy < 1e-5 and dl < 1e-5 and dg < 1e-4 and torch.equal(d0, d1), (dy, dl, dg)
+
+
 def test_small_model_stn_disabled():
     check_case(run_case(B=3, imgh=40, imgw=32, u=64, tds=32, max_len=6, stn=False, dropout=False), "nostn")
 
