@@ -29,7 +29,7 @@ FLAG_NO_DW_BWD_FUSION = 16     # CRNN_FLAG_NO_DW_BWD_FUSION
 FLAG_DW_TILE_KERNEL = 32       # CRNN_FLAG_DW_TILE_KERNEL
 FLAG_RNN_LINEAR_CLUSTERS = 64  # CRNN_FLAG_RNN_LINEAR_CLUSTERS
 FLAG_NO_BN_STATS_FUSION = 128  # CRNN_FLAG_NO_BN_STATS_FUSION
-FLAG_X3_GEMMS = 256            # CRNN_FLAG_X3_GEMMS
+FLAG_F32_MFMA_GEMMS = 256      # CRNN_FLAG_F32_MFMA_GEMMS
 FLAG_DEFERRED_SUMS = 512       # CRNN_FLAG_DEFERRED_SUMS
 RNN_XCD_LOCAL = 0x100          # CRNN_RNN_XCD_LOCAL (or-ed into the uw argument of crnn_lstm_*_persist)
 

@@ -230,14 +230,14 @@ int gemm(const Ctx& c, int mode, const float* A, const float* B, float* C, int M
     B = weight_operand(c, mode, B, &dtB);
     return crnn_gemm_bf16_ex(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, c.scratch(), kGemmScratchBytes, CRNN_F32, dtB, CRNN_F32, c.s);
   }
-  // parity mode: fp32 tensors, fp32 MFMA (an fmaf chain bit for bit).  Opt-in: the products from three bf16 planes per operand (fp32-level
-  // accuracy on the 16x faster bf16 matrix path, crnn_gemm_f32x3) -- with the present kernel 1-4 % faster per step
-  if (c.cfg->flags & CRNN_FLAG_X3_GEMMS)
-    return crnn_gemm_f32x3(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, c.scratch(), kGemmScratchBytes, c.s);
-  return crnn_gemm_f32(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, c.scratch(), kGemmScratchBytes, c.s);
+  // parity mode: fp32 tensors; the products from three bf16 planes per operand (fp32-level accuracy on the 16x faster bf16 matrix path,
+  // crnn_gemm_f32x3).  CRNN_FLAG_F32_MFMA_GEMMS: fp32 MFMA (an fmaf chain bit for bit)
+  if (c.cfg->flags & CRNN_FLAG_F32_MFMA_GEMMS)
+    return crnn_gemm_f32(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, c.scratch(), kGemmScratchBytes, c.s);
+  return crnn_gemm_f32x3(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, c.scratch(), kGemmScratchBytes, c.s);
 }
-// product selector of crnn_pwconv_fwd: 1 = bf16 products (bf16 modes), 0 = fp32 MFMA, 2 = three-plane fp32-accurate products (opt-in)
-int pw_products(const crnn_config* cfg) { return cfg->mfma_bf16 ? 1 : ((cfg->flags & CRNN_FLAG_X3_GEMMS) ? 2 : 0); }
+// product selector of crnn_pwconv_fwd: 1 = bf16 products (bf16 modes), 2 = three-plane fp32-accurate products (parity mode), 0 = fp32 MFMA
+int pw_products(const crnn_config* cfg) { return cfg->mfma_bf16 ? 1 : ((cfg->flags & CRNN_FLAG_F32_MFMA_GEMMS) ? 0 : 2); }
 // GEMM with explicit operand / result storage types (storage mode 2); falls back to the plain entry points otherwise
 int gemm_t(const Ctx& c, int mode, const float* A, int dtA, const float* B, int dtB, float* C, int dtC, int M, int N, int K, int lda,
            int ldb, int ldc, const float* bias = nullptr, int act = 0, int acc = 0, int perm = 0) {

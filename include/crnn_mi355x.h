@@ -56,9 +56,9 @@ typedef struct {
 #define CRNN_FLAG_DEFERRED_SUMS 512      /* opt-in: second stage of every streaming weight gradient batched at the end of its backward stage
                                          (crnn_wgrad_sum_batch: 2 launches instead of 13 per step) instead of right after its first stage;
                                          bit-identical; measured neutral (6.583 vs 6.584 ms: the second stages are bandwidth, not launch latency) */
-#define CRNN_FLAG_X3_GEMMS 256          /* opt-in, parity mode (mfma_bf16 = 0): conv-stack / dense / RNN-projection GEMMs as three-plane bf16 products
-                                         (crnn_gemm_f32x3: fp32-level accuracy, six bf16 MFMAs per k-step) instead of v_mfma_f32_32x32x2_f32
-                                         (crnn_gemm_f32: an fmaf chain bit for bit); results agree to fp32 round-off; 1-4 % faster per step today */
+#define CRNN_FLAG_F32_MFMA_GEMMS 256    /* parity mode (mfma_bf16 = 0): conv-stack / dense / RNN-projection GEMMs on v_mfma_f32_32x32x2_f32 (crnn_gemm_f32:
+                                         an fmaf chain bit for bit) instead of three-plane bf16 products (crnn_gemm_f32x3: fp32-level accuracy, six bf16
+                                         MFMAs per k-step, 1.2-1.7x faster per GEMM); results agree to fp32 round-off */
 #define CRNN_FLAG_NO_BN_STATS_FUSION 128 /* bf16-storage training: statistics pass of the depthwise BatchNorm's backward as a kernel of its own
                                          (crnn_bn_bwd_ex) instead of inside the data-gradient GEMM (crnn_gemm_wres_bf16_bnstats); same data gradients
                                          bit for bit, the BatchNorm-1 gradients / coefficients are the same sums in another order */
@@ -168,7 +168,7 @@ int crnn_gemm_f32(int mode, const float* A, const float* B, float* C, int M, int
 /* The same contract with fp32-accurate products from three bf16 planes per operand: x = hi + mid + lo (bf16 each, |x - sum| <= 2^-27 |x|), a
  * product keeps hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi (dropped terms <= 2^-26 of it), every partial product is exact in the MFMA's fp32
  * accumulator: six v_mfma_f32_32x32x16_bf16 per k-step instead of eight four-times slower v_mfma_f32_32x32x2_f32.  Equal to crnn_gemm_f32 to
- * fp32 round-off, not bit for bit.  Opt-in for the parity mode's big GEMMs (CRNN_FLAG_X3_GEMMS). */
+ * fp32 round-off, not bit for bit.  The parity mode's GEMMs (CRNN_FLAG_F32_MFMA_GEMMS selects crnn_gemm_f32 instead). */
 int crnn_gemm_f32x3(int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                     const float* bias, int act, int accumulate, int permP, float* scratch, size_t scratch_bytes, crnn_stream_t stream);
 /* same contract, products in bf16 on v_mfma_f32_32x32x16_bf16 (fp32 accumulate, fp32 operands/result in HBM) */

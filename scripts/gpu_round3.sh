@@ -11,7 +11,7 @@ echo "pytest_gpu exit $?" > $OUT/${TAG}_summary.txt
 timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_bf16s.json 2> $OUT/${TAG}_bench.err
 echo "bench exit $?" >> $OUT/${TAG}_summary.txt
 timeout 300 python bench.py --steps 20 --warmup 5 --precision fp32 --no-cpu-baseline --no-secondary > $OUT/${TAG}_bench_fp32.json 2>> $OUT/${TAG}_bench.err
-CRNN_FLAGS=256 timeout 300 python bench.py --steps 20 --warmup 5 --precision fp32 --no-cpu-baseline --no-secondary --no-roofline > $OUT/${TAG}_bench_fp32_x3_gemms.json 2>> $OUT/${TAG}_bench.err
+CRNN_FLAGS=256 timeout 300 python bench.py --steps 20 --warmup 5 --precision fp32 --no-cpu-baseline --no-secondary --no-roofline > $OUT/${TAG}_bench_fp32_mfma_gemms.json 2>> $OUT/${TAG}_bench.err
 timeout 300 python bench.py --steps 20 --warmup 5 --precision bf16 --no-cpu-baseline --no-secondary > $OUT/${TAG}_bench_bf16.json 2>> $OUT/${TAG}_bench.err
 timeout 300 python bench.py --steps 20 --warmup 5 --imgh 200 --max-len 21 --no-cpu-baseline --no-secondary > $OUT/${TAG}_bench_iam.json 2>> $OUT/${TAG}_bench.err
 timeout 300 python bench.py --steps 20 --warmup 5 --gru --no-cpu-baseline --no-secondary > $OUT/${TAG}_bench_gru.json 2>> $OUT/${TAG}_bench.err
@@ -52,6 +52,6 @@ done
 cd $ROOT
 find $OUT -name "*kernel_trace.csv" -size +30M -delete
 grep -E "passed|failed|error" $OUT/${TAG}_pytest_gpu.log | tail -3
-for f in bench_bf16s bench_fp32 bench_fp32_x3_gemms bench_bf16 bench_iam bench_gru bench_gru_step_kernels bench_step_kernels bench_linear_clusters bench_no_bn_stats_fusion bench_deferred_sums bench_bf16s_again predict; do echo -n "$f: "; cut -c1-170 $OUT/${TAG}_$f.json; echo; done
+for f in bench_bf16s bench_fp32 bench_fp32_mfma_gemms bench_bf16 bench_iam bench_gru bench_gru_step_kernels bench_step_kernels bench_linear_clusters bench_no_bn_stats_fusion bench_deferred_sums bench_bf16s_again predict; do echo -n "$f: "; cut -c1-170 $OUT/${TAG}_$f.json; echo; done
 grep -v amdgpu $OUT/${TAG}_bench.err | tail -5
 cat $OUT/${TAG}_summary.txt

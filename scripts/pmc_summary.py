@@ -14,6 +14,9 @@ res = {"kernel": "dwconv_tile_kernel<0> (forward with statistics epilogue, and d
        "modes": {}}
 for mode, esz in (("bf16", 2), ("fp32", 4)):
     per = {}
+    if not all(os.path.exists(os.path.join(ROOT, "gpurun_out", "%s_pmc_%s_%s" % (tag, mode, c), "dw_counter_collection.csv"))
+               for c in ("FETCH_SIZE", "WRITE_SIZE")):
+        print("no %s counter passes for %s" % (mode, tag)); continue      # a round may collect one storage mode only
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         src = os.path.join(ROOT, "gpurun_out", "%s_pmc_%s_%s" % (tag, mode, c), "dw_counter_collection.csv")
         agg = collections.defaultdict(list)
@@ -32,6 +35,8 @@ for mode, esz in (("bf16", 2), ("fp32", 4)):
         slab = 128 // esz
         th = 8 if w == 36 else (13 if w == 18 else 26)
         grid = (ch // slab) * B * ceil(h / th) * 256      # threads
+        if not per["FETCH_SIZE"] or not per["WRITE_SIZE"]:
+            break                                          # this pass ran the row-stream kernels only
         key = min(per["FETCH_SIZE"], key=lambda g: abs(g - grid))
         f, wv = per["FETCH_SIZE"][key], per["WRITE_SIZE"][key]
         rd = 2.0 * 1024 * sum(f) / len(f); wr = 1024.0 * sum(wv) / len(wv)
