@@ -499,7 +499,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE configs[1]: 256)")
     ap.add_argument("--precision", choices=["fp32", "bf16", "bf16s"], default="bf16s",
-                    help="fp32 = parity mode (fp32 MFMA); bf16 = GEMM products in bf16, fp32 accumulate/storage")
+                    help="fp32 = parity mode (fp32 tensors, fp32-accurate three-plane bf16 products); bf16 = GEMM products in bf16, fp32 accumulate/storage")
     ap.add_argument("--imgh", type=int, default=100, help="image length (the time axis); 200 = the IAM shape of BASELINE configs[2]")
     ap.add_argument("--max-len", type=int, default=23, help="label capacity; 21 for the IAM shape")
     ap.add_argument("--gru", action="store_true", help="GRU recurrence (what the reference's train.py really builds, SURVEY F3) instead of "
@@ -604,7 +604,7 @@ def main():
             "config": {"workload": "BASELINE configs[%d]: %dx32x1 text lines, batch %d/GPU, max_len %d, time_dense_size 128, n_units 256 %s, "
                                    "STN on, dropout on, CTC, Adam(1e-4,b1=.5,clipnorm 5), %s" % (
                                        1 if args.imgh == 100 else 2, args.imgh, B, args.max_len, "BiGRU" if args.gru else "BiLSTM",
-                                       {"fp32": "fp32 MFMA", "bf16": "bf16 MFMA products / fp32 accumulate+storage",
+                                       {"fp32": "fp32 tensors, fp32-accurate GEMMs (three bf16 planes per operand on the bf16 MFMA)", "bf16": "bf16 MFMA products / fp32 accumulate+storage",
                                         "bf16s": "bf16 MFMA products, bf16 conv-stack tensors in HBM, fp32 accumulate/statistics/RNN/optimizer (outside the 1e-3 "
                                                  "parity tolerance: see parity_mode for the fp32 step)"}[args.precision]),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": round(last_loss, 4)},
@@ -647,10 +647,11 @@ def main():
                     out["statistic"] = "median of %d repetitions" % reps
                 return out
             if args.precision != "fp32":
-                # the parity mode (fp32 storage + fp32 MFMA: the mode in which logits / CTC loss meet the 1e-3 tolerance and arg-max is
+                # the parity mode (fp32 storage + fp32-accurate three-plane GEMMs: the mode in which logits / CTC loss meet the 1e-3 tolerance and arg-max is
                 # bit-exact against the oracle, tests/test_gpu_model.py) timed in the same run on the same workload
                 res["parity_mode"] = dict(leg(B, max(3, min(args.steps, 10)), 2, precision="fp32"),
-                                          note="fp32 tensors + fp32 MFMA: the mode the 1e-3 logit / CTC-loss parity and bit-exact arg-max are asserted in; "
+                                          note="fp32 tensors + fp32-accurate GEMMs (three bf16 planes per operand, six bf16 MFMAs per k-step; CRNN_FLAGS=256 = fp32 MFMA, 20.6 ms): "
+                                               "the mode the 1e-3 logit / CTC-loss parity and bit-exact arg-max are asserted in; "
                                                "the headline bf16 line is outside that tolerance (bf16 conv-stack tensors: softmax within 2e-3, loss 2e-3 "
                                                "relative of the fp64 oracle)")
             if B != 64:

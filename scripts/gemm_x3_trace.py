@@ -23,6 +23,7 @@ for _ in range(5): lib.crnn_gemm_f32x3(*args)
 e1.record(); torch.cuda.synchronize()
 t = trace.cpu().numpy()
 print("kernel %.1f us" % (e0.elapsed_time(e1) / 5 * 1e3))
+if t.max() == 0: sys.exit(0)      # a build without stamps: the timing only
 if os.environ.get("GEMM_LIB", "").startswith("libgemm_x3p"):
     # producer-wave kernel: 64 stamps per wave (waves 0-3 multiply, 4-7 stage); ns relative to the workgroup's first stamp
     t = t.reshape(8, 64); t0 = t[t > 0].min()
