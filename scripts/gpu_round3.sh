@@ -26,8 +26,7 @@ timeout 200 python scripts/lstm_bench.py > $OUT/${TAG}_lstm_bench.json 2>/dev/nu
 XCD=1 UW=2 timeout 100 python scripts/lstm_trace.py > $OUT/${TAG}_lstm_trace.json 2>/dev/null
 XCD=0 UW=2 timeout 100 python scripts/lstm_trace.py >> $OUT/${TAG}_lstm_trace.json 2>/dev/null
 timeout 100 python scripts/occupy_probe.py 2>&1 | grep -v amdgpu > $OUT/${TAG}_occupy_probe.txt
-[ -f scripts/_trace/libgemm_exp.so ] && timeout 100 python scripts/gemm_x3_trace.py 2>&1 | grep -v amdgpu > $OUT/${TAG}_gemm_x3_trace.txt
-[ -f scripts/_trace/libgemm_exp_nosplit.so ] && GEMM_LIB=libgemm_exp_nosplit.so timeout 100 python scripts/gemm_x3_trace.py 2>&1 | grep -v amdgpu >> $OUT/${TAG}_gemm_x3_trace.txt
+timeout 200 python scripts/gemm_x3_bench.py 2>&1 | grep -v amdgpu > $OUT/${TAG}_gemm_x3_bench.txt
 timeout 100 python scripts/dws_bench.py 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_dw_fwd_stream_bench.txt
 timeout 100 python scripts/dbs_bench.py 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_dw_bwd_stream_bench.txt
 cd /tmp && export TMPDIR=/tmp
