@@ -141,6 +141,28 @@ def depthwise_roofline(eng, iters=15):
         in_step["note"] = ("effective bandwidth in the step's order and cache state: one event pair per launch, each launch issued right after the "
                            "kernel that writes its input (previous block's BN + ReLU6 + pool + dropout); not an HBM-roofline fraction")
         res["in_step_effective"] = in_step
+    # What a plain COPY of the same bytes achieves here: the six (input, output) pairs copied back to back, same cold protocol and events.
+    # "sweep" = grid-stride copy (the resident workgroups read one window of the buffer together); "banded" = every workgroup its own
+    # contiguous band, the row-stream kernel's pattern (one image per workgroup).  Last: the copies overwrite the forward's outputs.
+    if bf16s and hasattr(lib, "crnn_debug_copy"):
+        ref = {}
+        for name, pattern in (("sweep", 0), ("banded", 1)):
+            ts = []
+            for it in range(iters + 1):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for (x, k, o, pt, hh, ww, cc, flip, st) in launches:
+                    lib.crnn_debug_copy(_ptr(x), _ptr(o), B * hh * ww * cc * esz, pattern, 256, _stream())
+                e1.record()
+                torch.cuda.synchronize()
+                if it:
+                    ts.append(e0.elapsed_time(e1) * 1e-3)
+            tc = float(np.median(ts))
+            ref[name] = {"achieved": round(nbytes / tc / 1e9, 1), "frac": round(nbytes / tc / 1e9 / PEAK_HBM_GBS, 4), "kernel_vs_copy": round(tc / t, 3)}
+        ref["note"] = ("crnn_debug_copy of the same six tensor pairs (256 workgroups x 256 threads, 16-byte accesses), timed like `achieved`: "
+                       "`sweep` = grid-stride (the practical read+write ceiling of this chip), `banded` = one contiguous band per workgroup, the "
+                       "access pattern of the row-stream kernel; kernel_vs_copy = copy time / kernel time")
+        res["copy_reference"] = ref
     return res
 
 

@@ -86,6 +86,10 @@ int  crnn_ws_tensor_info(const crnn_config* cfg, const char* name, long* offset,
 /* Test hook (tests/test_gpu_ops.py: the give-up path of the persistent recurrences): `blocks` workgroups of 64 threads that each pin
  * `lds_bytes` of LDS (<= 160 KiB: nothing else fits next to one on its CU) and spin for `microseconds` of the constant 100 MHz clock. */
 int crnn_debug_occupy(int blocks, int lds_bytes, long microseconds, crnn_stream_t stream);
+/* Measurement reference (bench.py "copy_reference"): dst[0..bytes) = src[0..bytes) (16-byte aligned, bytes % 16 == 0) by `workgroups` workgroups
+ * of 256 threads.  pattern 0: grid-stride (the resident workgroups sweep one window together); pattern 1: workgroup b copies its own
+ * contiguous 1/workgroups of the buffer -- the access pattern of the row-stream depthwise kernels (one image band per workgroup). */
+int crnn_debug_copy(const void* src, void* dst, size_t bytes, int pattern, int workgroups, crnn_stream_t stream);
 
 /* ---- whole-path drivers ------------------------------------------------------------------------------------- */
 /* Forward of the predictor sub-model (utils.py:308-312; Model.predict_generator, predict.py:166):

@@ -303,6 +303,19 @@ def test_bn_relu6_pool_dropout_fwd_bwd(shape, pool, rate):
     assert_close(host(dx), dx_ref, rtol=2e-4, atol=1e-5, what="dx")
 
 
+@pytest.mark.parametrize("pattern", [0, 1])
+def test_measurement_reference_copy_is_a_copy(pattern):
+    """crnn_debug_copy (bench.py copy_reference): both access patterns move exactly the bytes asked for, for sizes that do not divide by
+    the workgroup count or the 16 KiB iteration, and refuse misaligned requests."""
+    for nbytes, wgs in ((16, 1), (16 * 1000 + 16, 7), (9216 * 104, 256), (4 << 20, 1024)):
+        src = torch.randint(0, 256, (nbytes + 64,), dtype=torch.uint8, device="cuda")
+        dst = torch.zeros_like(src)
+        ok(L().crnn_debug_copy(P(src), P(dst), nbytes, pattern, wgs, S()))
+        assert torch.equal(dst[:nbytes], src[:nbytes]) and int(dst[nbytes:].sum()) == 0, (nbytes, wgs)
+    assert L().crnn_debug_copy(P(src), P(dst), 24, pattern, 4, S()) != 0
+    assert L().crnn_debug_copy(P(src), P(dst), 32, 2, 4, S()) != 0
+
+
 def test_bn_inference_state_and_colsum():
     rs = np.random.RandomState(5)
     C = 48
