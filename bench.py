@@ -160,7 +160,7 @@ def depthwise_roofline(eng, iters=15):
             tc = float(np.median(ts))
             ref[name] = {"achieved": round(nbytes / tc / 1e9, 1), "frac": round(nbytes / tc / 1e9 / PEAK_HBM_GBS, 4), "kernel_vs_copy": round(tc / t, 3)}
         ref["note"] = ("crnn_debug_copy of the same six tensor pairs (256 workgroups x 256 threads, 16-byte accesses), timed like `achieved`: "
-                       "`sweep` = grid-stride (the practical read+write ceiling of this chip), `banded` = one contiguous band per workgroup, the "
+                       "`sweep` = grid-stride, plain loads / stores (nontemporal ones reach 0.74-0.78: profiles/r03_copy_probe.txt), `banded` = one contiguous band per workgroup, the "
                        "access pattern of the row-stream kernel; kernel_vs_copy = copy time / kernel time")
         res["copy_reference"] = ref
     return res
