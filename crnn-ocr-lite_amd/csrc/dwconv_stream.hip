@@ -27,7 +27,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct DwsParams {
   const unsigned char* x; const float* k; unsigned char* out; float* partials; const float* bnstate;
-  int H, W, C, HB, NS, nwgb, flip, cols, rowbytes;
+  int H, W, C, HB, NS, nwgb, flip, cols, rowbytes, wmaj;
 };
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
@@ -116,6 +116,9 @@ __global__ __launch_bounds__((kDwsMaxWaves + 1) * 64) void dw_fwd_stream_kernel(
     for (int e = 0; e < 8; ++e) { X0[e] = X1[e] = X2[e] = 0.f; s[e] = ss[e] = 0.f; }
     const int rsub = r0 + sub * p.HB;                          // this lane's first output row
     unsigned char* orow = p.out + ((long)img * p.H + rsub) * p.rowbytes + px * pitch + oct * 16;
+    // window-major output (EPI only; crnn_dwconv3x3_fwd_stream_ex out_order 1): pixel (y, x) is row ((y/2) (W/2) + x/2) 4 + (y&1) 2 + (x&1) of
+    // the image -- the four pixels of a 2x2 pooling window are consecutive rows for the pointwise GEMM whose epilogue pools them
+    unsigned char* const owin = p.out + (long)img * p.H * p.rowbytes + ((px >> 1) * 4 + (px & 1)) * pitch + oct * 16;
     int slot = 0;
     // one step: input row t of the band (image row rsub - 1 + t) -> taps 6..8 of output t-2 (A: complete), 3..5 of t-1 (Bc), 0..2 of t (Cn)
     auto step = [&](int t, float (&A)[8], float (&Bc)[8], float (&Cn)[8], bool edge) {
@@ -155,8 +158,10 @@ __global__ __launch_bounds__((kDwsMaxWaves + 1) * 64) void dw_fwd_stream_kernel(
         }
         u32x4 o;
         o.x = pack2_bf16(A[0], A[1]); o.y = pack2_bf16(A[2], A[3]); o.z = pack2_bf16(A[4], A[5]); o.w = pack2_bf16(A[6], A[7]);
-        if (CRNN_DWS_EXP & 8) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(orow + (long)(t - 2) * p.rowbytes));
-        else if (!(CRNN_DWS_EXP & 2)) *reinterpret_cast<u32x4*>(orow + (long)(t - 2) * p.rowbytes) = o;
+        unsigned char* dst = orow + (long)(t - 2) * p.rowbytes;
+        if (EPI && p.wmaj) { const int y = rsub + t - 2; dst = owin + (long)(y >> 1) * 2 * p.rowbytes + (y & 1) * 2 * pitch; }
+        if (CRNN_DWS_EXP & 8) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(dst));
+        else if (!(CRNN_DWS_EXP & 2)) *reinterpret_cast<u32x4*>(dst) = o;
       }
     };
     step(0, X1, X2, X0, true);
@@ -274,16 +279,24 @@ extern "C" int crnn_dwconv_fwd_stream_rows(int B, int H, int W, int C) { DwsGeom
 // out = dwconv3x3(x, k[9][C]) on bf16 NHWC maps (flip = 1: the data gradient).  stat_partials != NULL: [rows][2][C] sums / sums of squares of
 // the fp32 results (BatchNorm batch statistics); bnstate != NULL ([mean|var|scale|shift]): out = ReLU6(conv * scale + shift) (inference), no
 // statistics.  Results bit-identical to crnn_dwconv3x3_fwd_ex / crnn_dwconv3x3_bn_relu6_fwd.
-extern "C" int crnn_dwconv3x3_fwd_stream(const void* x, const float* k, void* out, float* stat_partials, const float* bnstate, int B, int H, int W,
-                                         int C, int flip, hipStream_t stream) {
-  if (!x || !k || !out) return CRNN_ERR_ARG;
+// out_order 1 (inference form only: bnstate != NULL; H, W even): the rows of `out` are in 2x2-window-major order -- pixel (y, x) of an image is
+// its row ((y/2) (W/2) + x/2) 4 + (y&1) 2 + (x&1) -- for crnn_pwconv_fwd_wres_folded_pool(..., pool_rows = 4), whose epilogue max-pools groups of
+// four consecutive rows (MaxPooling2D((2,2)) after the pointwise conv, utils.py:52-54, without the un-pooled map ever reaching HBM).
+extern "C" int crnn_dwconv3x3_fwd_stream_ex(const void* x, const float* k, void* out, float* stat_partials, const float* bnstate, int B, int H, int W,
+                                            int C, int flip, int out_order, hipStream_t stream) {
+  if (!x || !k || !out || out_order < 0 || out_order > 1) return CRNN_ERR_ARG;
+  if (out_order && (!bnstate || (H & 1) || (W & 1))) return CRNN_ERR_ARG;
   DwsGeom g = dws_geom(B, H, W, C);
   if (!g.ok || (((uintptr_t)x | (uintptr_t)out | (uintptr_t)k | (uintptr_t)bnstate) & 15)) return CRNN_ERR_UNSUPPORTED;
   if ((long)H * W * C * 2 >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;
   DwsParams p;
   p.x = (const unsigned char*)x; p.k = k; p.out = (unsigned char*)out; p.partials = bnstate ? nullptr : stat_partials; p.bnstate = bnstate;
-  p.H = H; p.W = W; p.C = C; p.HB = g.HB; p.NS = g.NS; p.nwgb = g.nwgb; p.flip = flip; p.cols = g.cols; p.rowbytes = W * C * 2;
+  p.H = H; p.W = W; p.C = C; p.HB = g.HB; p.NS = g.NS; p.nwgb = g.nwgb; p.flip = flip; p.cols = g.cols; p.rowbytes = W * C * 2; p.wmaj = out_order;
   return bnstate ? dws_launch<true>(p, g, B, stream) : dws_launch<false>(p, g, B, stream);
+}
+extern "C" int crnn_dwconv3x3_fwd_stream(const void* x, const float* k, void* out, float* stat_partials, const float* bnstate, int B, int H, int W,
+                                         int C, int flip, hipStream_t stream) {
+  return crnn_dwconv3x3_fwd_stream_ex(x, k, out, stat_partials, bnstate, B, H, W, C, flip, 0, stream);
 }
 
 // ---- measurement reference (bench.py depthwise_roofline "copy_reference"): what a plain copy of the same bytes achieves -----------------

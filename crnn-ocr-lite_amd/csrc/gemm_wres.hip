@@ -266,7 +266,7 @@ __device__ __forceinline__ void wres_store_bnstats(const WresParams& p, const un
   }
 }
 
-template <int KCH, int NLW, bool EPI = false, bool BNS = false>   // K / 64, loader waves, folded-BatchNorm epilogue, BatchNorm-backward statistics
+template <int KCH, int NLW, bool EPI = false, bool BNS = false, int POOL = 1>   // K / 64, loader waves, folded-BatchNorm epilogue, BatchNorm-backward statistics, pooled rows
 __global__ __launch_bounds__(384 + 64 * NLW) void gemm_wres_kernel(WresParams p) {
   constexpr int kIPS = 16 / NLW;            // LDS-DMA instructions per loader wave and stage
   constexpr int RR = EPI ? kR - 1 : kR;     // ring stages (the epilogue table takes the 160 KiB budget over: one stage less)
@@ -319,6 +319,25 @@ __global__ __launch_bounds__(384 + 64 * NLW) void gemm_wres_kernel(WresParams p)
       const int m0 = (first + stripe_it * step) * 128;
       u32x4 v[4];
       for (int t = t0; t < t1; t += 4) {
+        if constexpr (POOL > 1) {
+          // MaxPooling over groups of POOL consecutive staged rows (EPI only: values in [0, 6], so bf16 bit patterns order like signed 16-bit
+          // integers and -0 is the smallest).  Four pieces = 16 rows per iteration (PP is 8 or 4 here); lane group rsub takes rows 4 rsub .. + 3
+          // of them, one row per register: the maxima are taken between registers and every store instruction still writes whole rows.
+          typedef short s16x8 __attribute__((ext_vector_type(8)));
+          const int rb = (sw * 16 + t) * 4 + 4 * rsub;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const int r = rb + u; v[u] = *reinterpret_cast<const u32x4*>(ob + r * 256 + ((c ^ (r & 15)) * 16)); }
+          const s16x8 a = __builtin_elementwise_max(__builtin_bit_cast(s16x8, v[0]), __builtin_bit_cast(s16x8, v[1]));
+          const s16x8 b = __builtin_elementwise_max(__builtin_bit_cast(s16x8, v[2]), __builtin_bit_cast(s16x8, v[3]));
+          if constexpr (POOL == 4) {
+            if (m0 + rb < p.M && !WRES_EXP(p, 4))
+              *reinterpret_cast<u32x4*>(p.Y + (long)((m0 + rb) >> 2) * p.N + slice * 128 + c * 8) = __builtin_bit_cast(u32x4, __builtin_elementwise_max(a, b));
+          } else {
+            if (m0 + rb < p.M && !WRES_EXP(p, 4)) *reinterpret_cast<u32x4*>(p.Y + (long)((m0 + rb) >> 1) * p.N + slice * 128 + c * 8) = __builtin_bit_cast(u32x4, a);
+            if (m0 + rb + 2 < p.M && !WRES_EXP(p, 4)) *reinterpret_cast<u32x4*>(p.Y + (long)(((m0 + rb) >> 1) + 1) * p.N + slice * 128 + c * 8) = __builtin_bit_cast(u32x4, b);
+          }
+          continue;
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
           if (t + u < t1) {
@@ -561,11 +580,11 @@ __global__ __launch_bounds__(512) void gemm_wres_fwd_kernel(WresFwdParams p) {
   }
 }
 
-template <int KCH, int NLW, bool EPI = false, bool BNS = false>
+template <int KCH, int NLW, bool EPI = false, bool BNS = false, int POOL = 1>
 int launch_wres(const WresParams& p, int grid, hipStream_t stream) {
   const int lds = (EPI ? kR - 1 : kR) * kStage + 2 * kOut + (EPI ? 1024 : 0);
-  CRNN_LDS_ATTR((gemm_wres_kernel<KCH, NLW, EPI, BNS>), lds);
-  hipLaunchKernelGGL((gemm_wres_kernel<KCH, NLW, EPI, BNS>), dim3(grid), dim3(384 + 64 * NLW), lds, stream, p);
+  CRNN_LDS_ATTR((gemm_wres_kernel<KCH, NLW, EPI, BNS, POOL>), lds);
+  hipLaunchKernelGGL((gemm_wres_kernel<KCH, NLW, EPI, BNS, POOL>), dim3(grid), dim3(384 + 64 * NLW), lds, stream, p);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
@@ -592,7 +611,7 @@ static int wres_geom(int M, int N, WresParams& p) {             // -> grid
   return p.nxcd * p.Q * p.S;
 }
 static int gemm_wres_impl(const void* X, const void* W, void* Y, int M, int N, int K, const float* cscale, const float* cshift, hipStream_t stream,
-                          const void* D = nullptr, const float* bnstate = nullptr, float* stats = nullptr) {
+                          const void* D = nullptr, const float* bnstate = nullptr, float* stats = nullptr, int pool = 1) {
   if (M <= 0 || N <= 0 || K <= 0) return CRNN_ERR_ARG;
   CRNN_TRY(crnn_gemm_wres_supported(N, K));
   if ((((uintptr_t)X | (uintptr_t)W | (uintptr_t)Y) & 15)) return CRNN_ERR_UNSUPPORTED;
@@ -610,6 +629,12 @@ static int gemm_wres_impl(const void* X, const void* W, void* Y, int M, int N, i
   { const char* e = getenv("CRNN_WRES_TRACE"); p.trace = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
 #endif
   p.cscale = cscale; p.cshift = cshift;
+  if (pool != 1) {      // the two pooled blocks of the CRNN: 128 -> 256 channels with MaxPooling2D((2,2)), 256 -> 512 with (1,2); pooled by the storer waves
+    if (!cscale || M % pool) return CRNN_ERR_ARG;
+    if (pool == 4 && K == 128) return launch_wres<2, 2, true, false, 4>(p, grid, stream);
+    if (pool == 2 && K == 256) return launch_wres<4, 2, true, false, 2>(p, grid, stream);
+    return CRNN_ERR_UNSUPPORTED;
+  }
   if (cscale) {
     switch (K / 64) {
       case 1: return launch_wres<1, 2, true>(p, grid, stream);
@@ -657,6 +682,22 @@ extern "C" int crnn_pwconv_fwd_wres_folded(const void* a, const void* wT, void* 
   if (!out_bnstate) return CRNN_ERR_ARG;
   if (M > 0x7fffffffL || (((uintptr_t)out_bnstate) & 15)) return CRNN_ERR_UNSUPPORTED;
   return gemm_wres_impl(a, wT, y, (int)M, N, K, out_bnstate + 2L * N, out_bnstate + 3L * N, stream);
+}
+// The same with the MaxPooling2D that follows the block's ReLU6 (utils.py:52-54) in the epilogue: y [M / pool_rows][N] = max over every group of
+// pool_rows consecutive rows of ReLU6((X . W^T) * scale + shift).  pool_rows = 2: MaxPooling2D((1,2)) on a map of even width in NHWC order;
+// pool_rows = 4: MaxPooling2D((2,2)) when the rows of X are in 2x2-window-major order (crnn_dwconv3x3_fwd_stream_ex, out_order 1).  The un-pooled
+// map is never written.  Equal to max-pooling crnn_pwconv_fwd_wres_folded's output (rounding to bf16 is monotonic).  Shapes: (K, pool_rows) =
+// (128, 4) | (256, 2) -- the CRNN's two pooled blocks --, M % pool_rows == 0; -3 otherwise.
+extern "C" int crnn_pwconv_fwd_wres_folded_pool_supported(long M, int N, int K, int pool_rows) {
+  return (M > 0 && M <= 0x7fffffffL && M % pool_rows == 0 && ((K == 128 && pool_rows == 4) || (K == 256 && pool_rows == 2)) &&
+          crnn_gemm_wres_supported(N, K) == CRNN_OK) ? CRNN_OK : CRNN_ERR_UNSUPPORTED;
+}
+extern "C" int crnn_pwconv_fwd_wres_folded_pool(const void* a, const void* wT, void* y, long M, int N, int K, const float* out_bnstate, int pool_rows,
+                                                hipStream_t stream) {
+  if (!out_bnstate) return CRNN_ERR_ARG;
+  CRNN_TRY(crnn_pwconv_fwd_wres_folded_pool_supported(M, N, K, pool_rows));
+  if ((((uintptr_t)out_bnstate) & 15)) return CRNN_ERR_UNSUPPORTED;
+  return gemm_wres_impl(a, wT, y, (int)M, N, K, out_bnstate + 2L * N, out_bnstate + 3L * N, stream, nullptr, nullptr, nullptr, pool_rows);
 }
 
 namespace {

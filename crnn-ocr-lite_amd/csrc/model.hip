@@ -420,8 +420,15 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
       // pooling, the pointwise GEMM writes the block output directly: two passes per block instead of four
       CRNN_TRY(crnn_bn_infer_state(bn_mean + bn_off, bn_var + bn_off, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), ci, s1, stream));
       bn_off += ci;
+      // a pooled block on bf16 maps: BN + ReLU6 + MaxPooling2D all in the pointwise GEMM's epilogue (groups of 2 | 4 consecutive rows); for the
+      // (2,2) window the depthwise kernel writes its rows in window-major order -- the un-pooled map q never exists
+      int pool_rows = 1;
+      if (ph * pw > 1 && cfg->mfma_bf16 && pwT_off[i] >= 0 && dtd == CRNN_BF16 && dtq == CRNN_BF16 && c.dt("x" + p) == CRNN_BF16 &&
+          !(cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS) && crnn_pwconv_fwd_wres_folded_pool_supported(M, co, ci, ph * pw) == CRNN_OK &&
+          ((ph == 1 && pw == 2 && W % 2 == 0) || (ph == 2 && pw == 2 && dws && H % 2 == 0 && W % 2 == 0)))
+        pool_rows = ph * pw;
       if (dws) {
-        CRNN_TRY(crnn_dwconv3x3_fwd_stream(in, c.p(bp + "_dw"), aa, nullptr, s1, B, H, W, ci, 0, stream));
+        CRNN_TRY(crnn_dwconv3x3_fwd_stream_ex(in, c.p(bp + "_dw"), aa, nullptr, s1, B, H, W, ci, 0, pool_rows == 4 ? 1 : 0, stream));
       } else if (ci % slab == 0) {
         CRNN_TRY(crnn_dwconv3x3_bn_relu6_fwd(in, c.p(bp + "_dw"), s1, aa, B, H, W, ci, dtd, stream));
       } else {
@@ -437,13 +444,15 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
         dtw = CRNN_BF16; wt = 1;
       }
       const bool one = (ci == 1 && dtd == CRNN_F32);                      // block 1: an outer product, not a GEMM
-      const bool fold = (ph * pw == 1) && (c.dt("x" + p) == dtq);
+      const bool fold = (ph * pw == 1 || pool_rows > 1) && (c.dt("x" + p) == dtq);
       if (one) CRNN_TRY(fold ? crnn_pw1_fwd_folded(aa, c.p(bp + "_pw"), xo, M, co, s2, dtq, stream) : crnn_pw1_fwd(aa, c.p(bp + "_pw"), qq, M, co, nullptr, dtq, stream));
       else {
         // bf16 tensors + W^T: the weights-resident kernel (folded BatchNorm in its MFMA waves' epilogue, or the plain product)
         int rc = CRNN_ERR_UNSUPPORTED;
         if (wt && dtd == CRNN_BF16 && dtq == CRNN_BF16 && dtw == CRNN_BF16 && !(cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS) && M <= 0x7fffffffL)
-          rc = fold ? crnn_pwconv_fwd_wres_folded(aa, wq, xo, M, co, ci, s2, stream) : crnn_gemm_wres_bf16(aa, wq, qq, (int)M, co, ci, stream);
+          rc = pool_rows > 1 ? crnn_pwconv_fwd_wres_folded_pool(aa, wq, xo, M, co, ci, s2, pool_rows, stream)
+               : fold ? crnn_pwconv_fwd_wres_folded(aa, wq, xo, M, co, ci, s2, stream) : crnn_gemm_wres_bf16(aa, wq, qq, (int)M, co, ci, stream);
+        if (pool_rows > 1) { CRNN_TRY(rc); in = xo; continue; }        // (its shape rules were checked above: no fallback that could read window-major rows)
         if (rc == CRNN_ERR_UNSUPPORTED)
           rc = crnn_pwconv_fwd(aa, wq, fold ? xo : qq, M, co, ci, nullptr, fold ? s2 : nullptr, pw_products(cfg), dtd, dtw, dtq, wt, stream);
         CRNN_TRY(rc);

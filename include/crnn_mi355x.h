@@ -229,6 +229,10 @@ int crnn_dwconv_fwd_stream_supported(int B, int H, int W, int C);
 int crnn_dwconv_fwd_stream_rows(int B, int H, int W, int C);
 int crnn_dwconv3x3_fwd_stream(const void* x, const float* k, void* out, float* stat_partials, const float* bnstate, int B, int H, int W, int C,
                               int flip, crnn_stream_t stream);
+/* out_order 1 (inference form only: bnstate != NULL; H, W even): the rows of `out` are in 2x2-window-major order -- pixel (y, x) of an image is its row
+ * ((y/2) (W/2) + x/2) 4 + (y&1) 2 + (x&1) -- so that crnn_pwconv_fwd_wres_folded_pool(pool_rows = 4) can pool in its epilogue.  0: NHWC. */
+int crnn_dwconv3x3_fwd_stream_ex(const void* x, const float* k, void* out, float* stat_partials, const float* bnstate, int B, int H, int W, int C,
+                                 int flip, int out_order, crnn_stream_t stream);
 /* n (<= 8) independent matrix transposes in one launch: out[i] [C_i][R_i] = in[i]^T, in[i] = src + in_off[i] (fp32
  * elements), out[i] = dst + out_off[i] (elements of dt_out: 0 fp32 | 1 bf16).  src / dst are device pointers; the four
  * descriptor arrays (in_off, out_off, R, C) are HOST arrays of n entries, copied into the kernel arguments. */
@@ -364,6 +368,13 @@ int crnn_bn_bwd_finalize(const float* partials, int nparts, int C, long count, f
  * epilogue: y[M][N] (bf16) = ReLU6((a . wT^T) * scale[n] + shift[n]), out_bnstate = [mean|var|scale|shift] (crnn_bn_infer_state).
  * Bit-identical to crnn_pwconv_fwd(..., out_bnstate, ...) on bf16 tensors.  Same shape rules as crnn_gemm_wres_bf16. */
 int crnn_pwconv_fwd_wres_folded(const void* a, const void* wT, void* y, long M, int N, int K, const float* out_bnstate, crnn_stream_t stream);
+/* ... and with the MaxPooling2D after the block's ReLU6 (utils.py:52-54) in the epilogue: y [M / pool_rows][N] = max over every group of pool_rows
+ * consecutive rows of ReLU6((a . wT^T) * scale + shift); the un-pooled map never reaches HBM.  pool_rows = 2: MaxPooling2D((1,2)) on an NHWC map of
+ * even width; pool_rows = 4: MaxPooling2D((2,2)) when the rows of `a` are in 2x2-window-major order (crnn_dwconv3x3_fwd_stream_ex, out_order 1).
+ * Equal to max-pooling crnn_pwconv_fwd_wres_folded's output.  (K, pool_rows) = (128, 4) | (256, 2), M % pool_rows == 0; -3 otherwise. */
+int crnn_pwconv_fwd_wres_folded_pool_supported(long M, int N, int K, int pool_rows);
+int crnn_pwconv_fwd_wres_folded_pool(const void* a, const void* wT, void* y, long M, int N, int K, const float* out_bnstate, int pool_rows,
+                                     crnn_stream_t stream);
 /* The forward pointwise convolution of a training block on the same weights-resident core, fed by the PRE-BatchNorm depthwise output:
  * q[M][N] (bf16) = ReLU6(BN(d))[M][K] . wT[N][K]^T, in_bnstate = [mean|var|scale|shift] of that BatchNorm.  Four IO waves per workgroup
  * load the pixel stages into registers three stages ahead, apply the BatchNorm + ReLU6 (bit for bit the arithmetic of

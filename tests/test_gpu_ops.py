@@ -1236,6 +1236,59 @@ def test_weights_resident_inference_conv_with_folded_batchnorm_equals_the_tile_k
     assert_close(y1[:M].float().cpu().numpy(), ref, rtol=1e-2, atol=2e-2, what="folded conv vs fp64")
 
 
+def _window_major(t):
+    """[B][H][W][C] -> rows in 2x2-window-major order: pixel (y, x) is row ((y/2)(W/2) + x/2) 4 + (y&1) 2 + (x&1) of its image."""
+    B, H, W, C = t.shape
+    return t.reshape(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, C).contiguous()
+
+
+@pytest.mark.parametrize("B,H,W,K,N,pool", [(2, 8, 36, 128, 256, 4), (5, 104, 36, 128, 256, 4), (3, 52, 18, 256, 512, 2), (1, 2, 18, 256, 512, 2),
+                                            (7, 6, 36, 128, 128, 4)])
+def test_weights_resident_inference_conv_pools_in_its_epilogue(B, H, W, K, N, pool):
+    """crnn_pwconv_fwd_wres_folded_pool (predict path, the CRNN's two pooled blocks: MaxPooling2D after the block's ReLU6 taken over groups of
+    2 | 4 consecutive rows in the MFMA waves' epilogue, the un-pooled map never written) equals max-pooling the output of
+    crnn_pwconv_fwd_wres_folded, value for value (rounding to bf16 is monotonic) -- for (2,2) on rows in 2x2-window-major order.  Ragged last
+    stripes, one and several channel slices, memory behind the output untouched, repeated launches, unsupported shapes refused."""
+    rs = np.random.RandomState(B * 131 + H + W + K + N)
+    M = B * H * W
+    a = torch.from_numpy(_bf16_round(np.abs(rs.normal(size=(B, H, W, K))) * 1.2).astype(np.float32)).cuda().bfloat16()
+    Wd = _to_bf16_dev(_bf16_round(rs.normal(size=(N, K)) * 0.2))
+    st = dev(np.concatenate([rs.normal(size=N), rs.uniform(0.5, 2.0, size=N), rs.normal(size=N) * 0.3 + 1.0, rs.normal(size=N) * 0.5 + 0.5]))
+    assert L().crnn_pwconv_fwd_wres_folded_pool_supported(M, N, K, pool) == 0
+    full = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    ok(L().crnn_pwconv_fwd_wres_folded(P(a), P(Wd), P(full), M, N, K, P(st), S()))
+    full = full.view(B, H, W, N).float()
+    if pool == 4:
+        ref = full.view(B, H // 2, 2, W // 2, 2, N).amax(dim=(2, 4)); ain = _window_major(a)
+    else:
+        ref = full.view(B, H, W // 2, 2, N).amax(dim=3); ain = a
+    y = torch.full((M // pool + 3, N), 7.0, dtype=torch.bfloat16, device="cuda")
+    for rep in range(2):
+        ok(L().crnn_pwconv_fwd_wres_folded_pool(P(ain), P(Wd), P(y), M, N, K, P(st), pool, S()))
+        got = y[:M // pool].float().view(ref.shape)
+        assert torch.equal(got, ref), "pooled epilogue differs: max %g" % float((got - ref).abs().max())
+        assert bool((y[M // pool:] == 7.0).all())
+    assert float(ref.max()) > 0.5 and float((ref == 0).float().mean()) < 0.9          # the comparison saw real values
+    assert L().crnn_pwconv_fwd_wres_folded_pool_supported(M, N, K, 3) == -3 and L().crnn_pwconv_fwd_wres_folded_pool_supported(M, N, 512, 2) == -3
+    assert L().crnn_pwconv_fwd_wres_folded_pool(P(ain), P(Wd), P(y), M, N, K, P(st), 6 - pool, S()) == -3
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 104, 36, 128), (3, 52, 18, 256), (2, 104, 36, 64)])
+def test_row_stream_depthwise_writes_window_major_rows(B, H, W, C):
+    """crnn_dwconv3x3_fwd_stream_ex(out_order = 1): the folded inference form with its rows in 2x2-window-major order is the NHWC result,
+    permuted -- bit for bit; the training forms refuse the order."""
+    rs = np.random.RandomState(B + H + W + C + 1)
+    xd, kd = _to_bf16_dev(_bf16_round(rs.normal(size=(B, H, W, C)))), dev(rs.normal(size=(3, 3, C)))
+    st = dev(np.concatenate([rs.normal(size=C), 1 + rs.uniform(size=C), 1 + 0.3 * rs.normal(size=C), 0.5 * rs.normal(size=C) + 1.0]))
+    o0 = torch.zeros(B, H, W, C, dtype=torch.bfloat16, device="cuda"); o1 = torch.full((B * H * W * C + 64,), 7.0, dtype=torch.bfloat16, device="cuda")
+    ok(L().crnn_dwconv3x3_fwd_stream_ex(P(xd), P(kd), P(o0), None, P(st), B, H, W, C, 0, 0, S()))
+    ok(L().crnn_dwconv3x3_fwd_stream_ex(P(xd), P(kd), P(o1), None, P(st), B, H, W, C, 0, 1, S()))
+    assert torch.equal(o1[:-64].view(B, H, W, C).view(torch.int16), _window_major(o0).view(torch.int16)) and bool((o1[-64:] == 7.0).all())
+    assert float(o0.float().abs().max()) > 0
+    parts = zeros(L().crnn_dwconv_fwd_stream_rows(B, H, W, C), 2, C)
+    assert L().crnn_dwconv3x3_fwd_stream_ex(P(xd), P(kd), P(o1), P(parts), None, B, H, W, C, 0, 1, S()) != 0
+
+
 @pytest.mark.parametrize("M,N,K,two", [(13312, 128, 1024, True), (13312, 256, 1024, True), (64 * 3, 256, 768, True), (64, 128, 64, False), (64 * 9, 128, 128, False)])
 def test_streaming_nt_gemm_of_the_recurrent_input_gradient_equals_the_tile_kernel(M, N, K, two):
     """crnn_gemm_nt_f32_stream (dX = dZf Wf^T + dZb Wb^T in one launch: result of a 64-row stripe in the MFMA waves' registers over both
