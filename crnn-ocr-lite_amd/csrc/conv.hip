@@ -694,6 +694,33 @@ extern "C" int crnn_bn_infer_state(const float* mmean, const float* mvar, const 
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
+// The same for up to CRNN_BN_INFER_BATCH_MAX BatchNorm layers in one launch (the predict path knows all of them before its first conv: 14
+// launches of ~5 us each otherwise): arrays of n device pointers / channel counts on the host; grid.y = layer.
+struct BnInferBatch { const float* mmean[CRNN_BN_INFER_BATCH_MAX]; const float* mvar[CRNN_BN_INFER_BATCH_MAX]; const float* gamma[CRNN_BN_INFER_BATCH_MAX];
+                      const float* beta[CRNN_BN_INFER_BATCH_MAX]; float* bnstate[CRNN_BN_INFER_BATCH_MAX]; int C[CRNN_BN_INFER_BATCH_MAX]; };
+__global__ void bn_infer_state_batch_kernel(BnInferBatch b) {
+  const int j = blockIdx.y, C = b.C[j], c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float mm = b.mmean[j][c], mv = b.mvar[j][c];
+    const float sc = b.gamma[j][c] / sqrtf(mv + BN_EPS);
+    float* st = b.bnstate[j];
+    st[c] = mm; st[C + c] = mv; st[2 * C + c] = sc; st[3 * C + c] = b.beta[j][c] - mm * sc;
+  }
+}
+extern "C" int crnn_bn_infer_state_batch(int n, const float* const* mmean, const float* const* mvar, const float* const* gamma, const float* const* beta,
+                                         const int* C, float* const* bnstate, hipStream_t stream) {
+  if (n < 0 || n > CRNN_BN_INFER_BATCH_MAX || (n && (!mmean || !mvar || !gamma || !beta || !C || !bnstate))) return CRNN_ERR_ARG;
+  if (n == 0) return CRNN_OK;
+  BnInferBatch b; int cmax = 0;
+  for (int j = 0; j < n; ++j) {
+    if (!mmean[j] || !mvar[j] || !gamma[j] || !beta[j] || !bnstate[j] || C[j] <= 0) return CRNN_ERR_ARG;
+    b.mmean[j] = mmean[j]; b.mvar[j] = mvar[j]; b.gamma[j] = gamma[j]; b.beta[j] = beta[j]; b.bnstate[j] = bnstate[j]; b.C[j] = C[j];
+    if (C[j] > cmax) cmax = C[j];
+  }
+  hipLaunchKernelGGL(bn_infer_state_batch_kernel, dim3(cdiv(cmax, 256), n), dim3(256), 0, stream, b);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // y = Dropout(MaxPool(ReLU6(x*scale+shift)))   (utils.py:45-56).  ph=pw=1: no pooling; rate=0: no dropout.

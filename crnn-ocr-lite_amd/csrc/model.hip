@@ -402,6 +402,18 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
   // ---- 7 depthwise-separable blocks (utils.py:43-56, 64-70)
   const float* in = c.w("x0");
   int bn_off = 0;
+  if (!train) {   // inference: every BatchNorm's [mean|var|scale|shift] is known before the first conv -- one launch for all 14
+    const float *mm[14], *mv[14], *gg[14], *bb[14]; float* st[14]; int cc[14]; int n = 0, off = 0;
+    for (int i = 1; i <= 7; ++i) {
+      const std::string bp = "b" + std::to_string(i);
+      for (int h = 0; h < 2; ++h) {
+        const int ch = h ? d.bc[i] : d.bc[i - 1];
+        mm[n] = bn_mean + off; mv[n] = bn_var + off; gg[n] = c.p(bp + (h ? "_bn2_g" : "_bn1_g")); bb[n] = c.p(bp + (h ? "_bn2_b" : "_bn1_b"));
+        st[n] = c.w((h ? "bn2s" : "bn1s") + std::to_string(i)); cc[n] = ch; off += ch; ++n;
+      }
+    }
+    CRNN_TRY(crnn_bn_infer_state_batch(n, mm, mv, gg, bb, cc, st, stream));
+  }
   for (int i = 1; i <= 7; ++i) {
     std::string p = std::to_string(i), bp = "b" + p;
     const int H = d.bh[i], W = d.bw[i], ci = d.bc[i - 1], co = d.bc[i];
@@ -418,7 +430,6 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
       // inference (learning_phase 0): the BatchNorm scale/shift are known up front, so BN + ReLU6 fold into the
       // epilogue of the conv that feeds them -- the depthwise kernel writes `a` directly and, when the block has no
       // pooling, the pointwise GEMM writes the block output directly: two passes per block instead of four
-      CRNN_TRY(crnn_bn_infer_state(bn_mean + bn_off, bn_var + bn_off, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), ci, s1, stream));
       bn_off += ci;
       // a pooled block on bf16 maps: BN + ReLU6 + MaxPooling2D all in the pointwise GEMM's epilogue (groups of 2 | 4 consecutive rows); for the
       // (2,2) window the depthwise kernel writes its rows in window-major order -- the un-pooled map q never exists
@@ -435,7 +446,6 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
         CRNN_TRY(crnn_dwconv3x3_fwd_ex(in, c.p(bp + "_dw"), dd, nullptr, B, H, W, ci, 0, dtd, stream));
         CRNN_TRY(crnn_bn_act_pool_drop_ex(dd, s1, aa, 1, 1, (int)M, ci, 1, 1, 0.f, 0, 0, dtd, dtd, stream));
       }
-      CRNN_TRY(crnn_bn_infer_state(bn_mean + bn_off, bn_var + bn_off, c.p(bp + "_bn2_g"), c.p(bp + "_bn2_b"), co, s2, stream));
       bn_off += co;
       int dtw = CRNN_F32, wt = 0;
       const float* wq = weight_operand(c, 0, c.p(bp + "_pw"), &dtw);

@@ -287,6 +287,11 @@ int crnn_bn_finalize_folded(const float* partials, int nparts, int C, long n, co
                             float* bnstate, float* scratch, crnn_stream_t stream);
 int crnn_bn_infer_state(const float* mmean, const float* mvar, const float* gamma, const float* beta, int C,
                         float* bnstate, crnn_stream_t stream);
+/* ... for n <= CRNN_BN_INFER_BATCH_MAX layers in one launch: host arrays of n device pointers (moving mean / variance, gamma, beta, bnstate out) and
+ * channel counts.  Same values as n crnn_bn_infer_state calls. */
+#define CRNN_BN_INFER_BATCH_MAX 16
+int crnn_bn_infer_state_batch(int n, const float* const* mmean, const float* const* mvar, const float* const* gamma, const float* const* beta,
+                              const int* C, float* const* bnstate, crnn_stream_t stream);
 int crnn_bn_act(const float* x, const float* bnstate, float* y, long M, int C, crnn_stream_t stream);
 /* y = Dropout(MaxPool(ReLU6(BN(x))))  (utils.py:45-56) */
 int crnn_bn_act_pool_drop(const float* x, const float* bnstate, float* y, int B, int H, int W, int C, int ph, int pw,

@@ -316,6 +316,23 @@ def test_measurement_reference_copy_is_a_copy(pattern):
     assert L().crnn_debug_copy(P(src), P(dst), 32, 2, 4, S()) != 0
 
 
+def test_bn_inference_states_in_one_launch_equal_the_single_launches():
+    """crnn_bn_infer_state_batch (the predict path's 14 BatchNorm layers in one launch) writes what n crnn_bn_infer_state calls write."""
+    rs = np.random.RandomState(5)
+    Cs = [1, 64, 64, 128, 128, 256, 512, 512, 38, 300]
+    arrs = [[dev(rs.normal(size=C)), dev(rs.uniform(0.1, 2.0, size=C)), dev(rs.normal(size=C) * 0.3 + 1.0), dev(rs.normal(size=C))] for C in Cs]
+    one = [zeros(4 * C) for C in Cs]; many = [torch.full((4 * C + 8,), 7.0, device="cuda") for C in Cs]
+    for (mm, mv, g, b), C, o in zip(arrs, Cs, one):
+        ok(L().crnn_bn_infer_state(P(mm), P(mv), P(g), P(b), C, P(o), S()))
+    n = len(Cs)
+    PA = ctypes.c_void_p * n
+    col = lambda k: PA(*[a[k].data_ptr() for a in arrs])
+    ok(L().crnn_bn_infer_state_batch(n, col(0), col(1), col(2), col(3), (ctypes.c_int * n)(*Cs), PA(*[t.data_ptr() for t in many]), S()))
+    for o, m, C in zip(one, many, Cs):
+        assert torch.equal(o, m[:4 * C]) and bool((m[4 * C:] == 7.0).all())
+    assert L().crnn_bn_infer_state_batch(17, col(0), col(1), col(2), col(3), (ctypes.c_int * n)(*Cs), PA(*[t.data_ptr() for t in many]), S()) != 0
+
+
 def test_bn_inference_state_and_colsum():
     rs = np.random.RandomState(5)
     C = 48
