@@ -25,14 +25,43 @@ __device__ __forceinline__ float blse(float a, float b) {
   return m + log1pf(expf(n - m));
 }
 
-// (min value, its lane) over lanes < cnt; ties -> lowest lane.  Result is wave-uniform.
+// Value of lane l (wave-uniform l) as a scalar: v_readlane_b32 instead of the LDS round trip of ds_bpermute_b32 -- the decoder is one wave per
+// sample, a chain of several hundred dependent cross-lane reads per time step, so their latency IS its run time.
+__device__ __forceinline__ int rl(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float rl(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// (min value, its lane) over lanes < cnt; ties -> lowest lane.  Result is wave-uniform.  The first four butterfly steps stay inside a row of
+// 16 lanes (DPP: quad permutes, half-row mirror, row mirror -- any pairing works for an idempotent reduction); beams of at most 16 entries
+// (the reference decodes with 5 or 10) never leave the row.
+template <int CTRL>
+__device__ __forceinline__ float max_dpp(float v) {
+  return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false)));
+}
+// maximum over the 64 lanes, wave-uniform: four in-row DPP steps, then the four row maxima as scalars
+__device__ __forceinline__ float wave_max64(float v) {
+  v = max_dpp<0xB1>(v); v = max_dpp<0x4E>(v); v = max_dpp<0x141>(v); v = max_dpp<0x140>(v);
+  return fmaxf(fmaxf(rl(v, 0), rl(v, 16)), fmaxf(rl(v, 32), rl(v, 48)));
+}
+template <int CTRL>
+__device__ __forceinline__ void argmin_dpp(float& mv, int& ml) {
+  const float ov = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(mv), __float_as_int(mv), CTRL, 0xf, 0xf, false));
+  const int ol = __builtin_amdgcn_update_dpp(ml, ml, CTRL, 0xf, 0xf, false);
+  if (ov < mv || (ov == mv && ol < ml)) { mv = ov; ml = ol; }
+}
 __device__ __forceinline__ void wave_argmin(float v, int lane, int cnt, float& mv, int& ml) {
   mv = (lane < cnt) ? v : INFINITY; ml = lane;
+  argmin_dpp<0xB1>(mv, ml);      // quad_perm [1,0,3,2]
+  argmin_dpp<0x4E>(mv, ml);      // quad_perm [2,3,0,1]
+  argmin_dpp<0x141>(mv, ml);     // row_half_mirror
+  argmin_dpp<0x140>(mv, ml);     // row_mirror
+  if (cnt > 16) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    float ov = __shfl_xor(mv, o, 64); int ol = __shfl_xor(ml, o, 64);
-    if (ov < mv || (ov == mv && ol < ml)) { mv = ov; ml = ol; }
+    for (int o = 16; o <= 32; o <<= 1) {
+      float ov = __shfl_xor(mv, o, 64); int ol = __shfl_xor(ml, o, 64);
+      if (ov < mv || (ov == mv && ol < ml)) { mv = ov; ml = ol; }
+    }
   }
+  mv = rl(mv, 0); ml = rl(ml, 0);
 }
 
 __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ y, const int* __restrict__ input_len,
@@ -56,18 +85,29 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
   int n = 1, nnodes = 1;
   if (lane == 0) nodes[0] = 0;
   __syncthreads();
+  // register copy of the node table, 64 nodes per register (node 64 k + lane in nd[k]): the search for a re-entering prefix compares against
+  // registers instead of walking LDS -- up to ten searches per time step, each up to nnodes / 64 dependent LDS round trips before.  Tables
+  // beyond kNodeRegs * 64 nodes (T * beam_width > 1023) keep the LDS walk.
+  constexpr int kNodeRegs = 16;
+  const bool regtab = nmax <= kNodeRegs * 64;
+  int nd[kNodeRegs];
+#pragma unroll
+  for (int k = 0; k < kNodeRegs; ++k) nd[k] = -1;
 
+  float ynext = (Tb > 0 && lane < C) ? y[(long)b * T * C + lane] : 0.f;        // the next step's posteriors are requested a step ahead
   for (int t = 0; t < Tb; ++t) {
-    float lg = (lane < C) ? logf(y[((long)b * T + t) * C + lane] + BEAM_EPS) : BNEG;
-    const float inp = lg - wave_max(lg);                 // lane = class
-    const float inp_blank = __shfl(inp, blank, 64);
+    const float ycur = ynext;
+    if (t + 1 < Tb && lane < C) ynext = y[((long)b * T + t + 1) * C + lane];
+    float lg = (lane < C) ? logf(ycur + BEAM_EPS) : BNEG;
+    const float inp = lg - wave_max64(lg);               // lane = class
+    const float inp_blank = rl(inp, blank);
     // ---- oldp <- newp; re-score the entries (parent term only while the parent is in the beam)
     b_ob = b_nb; b_ol = b_nl; b_ot = b_nt;
     {
       float prev = BNEG; bool found = false;
       for (int j = 0; j < n; ++j) {
-        int nj = __shfl(b_node, j, 64), lj = __shfl(b_lab, j, 64);
-        float obj = __shfl(b_ob, j, 64), otj = __shfl(b_ot, j, 64);
+        int nj = rl(b_node, j), lj = rl(b_lab, j);
+        float obj = rl(b_ob, j), otj = rl(b_ot, j);
         if (lane < n && b_node != 0 && nj == b_par) { found = true; prev = (b_lab == lj) ? obj : otj; }
       }
       float in_lab = __shfl(inp, b_lab & 63, 64);
@@ -87,14 +127,14 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
     wave_argmin(l_v, lane, nle, bval, bslot);
     // ---- grow new leaves, entry by entry
     for (int bi = 0; bi < n; ++bi) {
-      const float bot = __shfl(b_ot, bi, 64), bob = __shfl(b_ob, bi, 64);
-      const int blab = __shfl(b_lab, bi, 64), bnode = __shfl(b_node, bi, 64);
+      const float bot = rl(b_ot, bi), bob = rl(b_ob, bi);
+      const int blab = rl(b_lab, bi), bnode = rl(b_node, bi);
       if (!(bot > BNEG && (nle < bw || bot > bval))) continue;
       const float prev = (lane == blab) ? bob : bot;
       const float v = (lane < blank && prev > BNEG) ? inp + prev : BNEG;     // lane = child label
       int cb = -1;
       for (int j = 0; j < n; ++j) {
-        int pj = __shfl(b_par, j, 64), lj = __shfl(b_lab, j, 64);
+        int pj = rl(b_par, j), lj = rl(b_lab, j);
         if (pj == bnode && lj == lane) cb = j;                                  // this child is beam entry j
       }
       const bool ev = (lane < blank) && (cb >= 0 || (v > BNEG && (nle < bw || v > bval)));
@@ -102,14 +142,14 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
       while (mask) {
         const int c = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
-        const float vc = __shfl(v, c, 64);
-        const int ccb = __shfl(cb, c, 64);
-        if (ccb >= 0 && __shfl(b_act, ccb, 64)) continue;                       // child already in the beam
+        const float vc = rl(v, c);
+        const int ccb = rl(cb, c);
+        if (ccb >= 0 && rl(b_act, ccb)) continue;                       // child already in the beam
         if (vc > BNEG && (nle < bw || vc > bval)) {
           int slot;
           if (nle == bw) {                                                      // evict the bottom
             slot = bslot;
-            int k = __shfl(l_ref, bslot, 64);
+            int k = rl(l_ref, bslot);
             if (k >= 0 && lane == k) b_act = 0;
           } else {
             slot = nle++;
@@ -124,7 +164,7 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
     // ---- new beam = TopN sorted by descending score (ties: lower slot first)
     int rank = 0;
     for (int j = 0; j < nle; ++j) {
-      float vj = __shfl(l_v, j, 64);
+      float vj = rl(l_v, j);
       if (vj > l_v || (vj == l_v && j < lane)) ++rank;
     }
     __syncthreads();
@@ -145,17 +185,34 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
     while (nm) {
       const int r = __ffsll((long long)nm) - 1;
       nm &= nm - 1;
-      const int packed = ((__shfl(new_par, r, 64) + 1) << 8) | (__shfl(new_lab, r, 64) + 1);
+      const int packed = ((rl(new_par, r) + 1) << 8) | (rl(new_lab, r) + 1);
       int found = -1;
-      for (int base = 1; base < nnodes; base += 64) {
-        int idx = base + lane;
-        bool hit = (idx < nnodes) && (nodes[idx] == packed);
-        unsigned long long m = __ballot(hit);
-        if (m) { found = base + __ffsll((long long)m) - 1; break; }
+      if (regtab) {
+#pragma unroll
+        for (int k = 0; k < kNodeRegs; ++k) {
+          if (found < 0 && k * 64 < nnodes) {                                   // (packed > 0 = nodes[0], and unused slots hold -1: no index test needed)
+            const unsigned long long m = __ballot(nd[k] == packed);
+            if (m) found = k * 64 + __ffsll((long long)m) - 1;
+          }
+        }
+      } else {
+        for (int base = 1; base < nnodes; base += 64) {
+          int idx = base + lane;
+          bool hit = (idx < nnodes) && (nodes[idx] == packed);
+          unsigned long long m = __ballot(hit);
+          if (m) { found = base + __ffsll((long long)m) - 1; break; }
+        }
       }
       if (found < 0) {
         found = nnodes;
-        if (nnodes < nmax) { if (lane == 0) nodes[nnodes] = packed; ++nnodes; }
+        if (nnodes < nmax) {
+          if (lane == 0) nodes[nnodes] = packed;
+          if (regtab) {
+#pragma unroll
+            for (int k = 0; k < kNodeRegs; ++k) if (k == (nnodes >> 6) && lane == (nnodes & 63)) nd[k] = packed;
+          }
+          ++nnodes;
+        }
         __syncthreads();
       }
       if (lane == r) new_node = found;
@@ -165,8 +222,8 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float* __restrict__ 
   }
   // ---- best path = entry 0; walk to the root, merge_repeated on the collapsed sequence, reverse
   for (int i = lane; i < T; i += 64) out[(long)b * T + i] = -1;
-  const int best_node = __shfl(b_node, 0, 64);
-  const float best_score = __shfl(b_nt, 0, 64);
+  const int best_node = rl(b_node, 0);
+  const float best_score = rl(b_nt, 0);
   __syncthreads();
   if (lane == 0) {
     int len = 0, nd = best_node, prev = -1;
