@@ -631,6 +631,10 @@ static int gemm_wres_impl(const void* X, const void* W, void* Y, int M, int N, i
   p.cscale = cscale; p.cshift = cshift;
   if (pool != 1) {      // the two pooled blocks of the CRNN: 128 -> 256 channels with MaxPooling2D((2,2)), 256 -> 512 with (1,2); pooled by the storer waves
     if (!cscale || M % pool) return CRNN_ERR_ARG;
+#ifdef CRNN_WRES_POOL_NOEPI      // timing experiment: the pooled kernels without the BatchNorm + ReLU6 arithmetic in the MFMA waves (wrong values)
+    if (pool == 4 && K == 128) return launch_wres<2, 2, false, false, 4>(p, grid, stream);
+    if (pool == 2 && K == 256) return launch_wres<4, 2, false, false, 2>(p, grid, stream);
+#endif
     if (pool == 4 && K == 128) return launch_wres<2, 2, true, false, 4>(p, grid, stream);
     if (pool == 2 && K == 256) return launch_wres<4, 2, true, false, 2>(p, grid, stream);
     return CRNN_ERR_UNSUPPORTED;
