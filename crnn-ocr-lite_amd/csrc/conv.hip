@@ -1147,7 +1147,7 @@ extern "C" int crnn_bn_bwd_chunks(long M) {
 }
 
 template <int VEC, bool POOL, typename T>
-static int bn_bwd_launch(const BnBwdArgsT<T>& a, T* dx, float* dgamma, float* dbeta, float* parts, float* coef, hipStream_t stream) {
+static int bn_bwd_launch(const BnBwdArgsT<T>& a, T* dx, float* dgamma, float* dbeta, float* parts, float* coef, hipStream_t stream, bool apply_only = false) {
   const long M = (long)a.B * a.H * a.W;
   const int CL = a.C / VEC;
   const int CW = pow2_ge(CL < 256 ? CL : 256);
@@ -1155,6 +1155,7 @@ static int bn_bwd_launch(const BnBwdArgsT<T>& a, T* dx, float* dgamma, float* db
   const long rows = window ? M / (a.ph * a.pw) : M;
   const int rpc = bn_bwd_rows_per_chunk(rows), chunks = cdiv(rows, rpc);
   const int pk = (a.ph == 2 && a.pw == 2) ? 1 : ((a.ph == 1 && a.pw == 2) ? 2 : 0);      // the CRNN's two pool shapes as compile-time windows
+  if (!apply_only) {   // (apply_only: coef comes from elsewhere -- the statistics were taken by the kernel that produced g)
   if (window && pk == 1) hipLaunchKernelGGL((bn_bwd_pool_kernel<1, VEC, T, 2, 2>), dim3(chunks), dim3(256), 0, stream, a, parts, (const float*)nullptr, (T*)nullptr, CW, rpc);
   else if (window && pk == 2) hipLaunchKernelGGL((bn_bwd_pool_kernel<1, VEC, T, 1, 2>), dim3(chunks), dim3(256), 0, stream, a, parts, (const float*)nullptr, (T*)nullptr, CW, rpc);
   else if (window) hipLaunchKernelGGL((bn_bwd_pool_kernel<1, VEC, T>), dim3(chunks), dim3(256), 0, stream, a, parts, (const float*)nullptr, (T*)nullptr, CW, rpc);
@@ -1162,6 +1163,7 @@ static int bn_bwd_launch(const BnBwdArgsT<T>& a, T* dx, float* dgamma, float* db
   CRNN_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(a.C, RED_CH)), dim3(RED_CH, RED_PL), 0, stream, parts, chunks, a.C, 1.0 / (double)M, dgamma, dbeta, coef);
   CRNN_LAUNCH_CHECK();
+  }
   if (dx == nullptr) return CRNN_OK;   // statistics only: dgamma, dbeta and coef = [mean(gy) | mean(gy * xhat)]; the caller applies pass 2 itself
   if (window && pk == 1) hipLaunchKernelGGL((bn_bwd_pool_kernel<2, VEC, T, 2, 2>), dim3(chunks), dim3(256), 0, stream, a, (float*)nullptr, coef, dx, CW, rpc);
   else if (window && pk == 2) hipLaunchKernelGGL((bn_bwd_pool_kernel<2, VEC, T, 1, 2>), dim3(chunks), dim3(256), 0, stream, a, (float*)nullptr, coef, dx, CW, rpc);
@@ -1174,18 +1176,18 @@ static int bn_bwd_launch(const BnBwdArgsT<T>& a, T* dx, float* dgamma, float* db
 template <typename T>
 static int bn_bwd_typed(const T* x, const T* g, const float* bnstate, const float* gamma, T* dx, float* dgamma, float* dbeta,
                         float* scratch_partials, float* coef, int B, int H, int W, int C, int ph, int pw, float rate, uint64_t seed,
-                        uint32_t layer, hipStream_t stream) {
+                        uint32_t layer, hipStream_t stream, bool apply_only = false) {
   BnBwdArgsT<T> a{x, g, bnstate, gamma, B, H, W, C, ph, pw, rate, seed, layer};
   const bool pool = (ph * pw) > 1;
   const bool al = ((((uintptr_t)x | (uintptr_t)g | (uintptr_t)dx | (uintptr_t)bnstate | (uintptr_t)coef) & 15) == 0);   // (dx may be null: statistics only)
   const bool vec = (C % 4 == 0) && al;
   if (VecMax<T>::value == 8 && al && C % 8 == 0)
-    return pool ? bn_bwd_launch<VecMax<T>::value, true, T>(a, dx, dgamma, dbeta, scratch_partials, coef, stream)
-                : bn_bwd_launch<VecMax<T>::value, false, T>(a, dx, dgamma, dbeta, scratch_partials, coef, stream);
-  if (vec) return pool ? bn_bwd_launch<4, true, T>(a, dx, dgamma, dbeta, scratch_partials, coef, stream)
-                       : bn_bwd_launch<4, false, T>(a, dx, dgamma, dbeta, scratch_partials, coef, stream);
-  return pool ? bn_bwd_launch<1, true, T>(a, dx, dgamma, dbeta, scratch_partials, coef, stream)
-              : bn_bwd_launch<1, false, T>(a, dx, dgamma, dbeta, scratch_partials, coef, stream);
+    return pool ? bn_bwd_launch<VecMax<T>::value, true, T>(a, dx, dgamma, dbeta, scratch_partials, coef, stream, apply_only)
+                : bn_bwd_launch<VecMax<T>::value, false, T>(a, dx, dgamma, dbeta, scratch_partials, coef, stream, apply_only);
+  if (vec) return pool ? bn_bwd_launch<4, true, T>(a, dx, dgamma, dbeta, scratch_partials, coef, stream, apply_only)
+                       : bn_bwd_launch<4, false, T>(a, dx, dgamma, dbeta, scratch_partials, coef, stream, apply_only);
+  return pool ? bn_bwd_launch<1, true, T>(a, dx, dgamma, dbeta, scratch_partials, coef, stream, apply_only)
+              : bn_bwd_launch<1, false, T>(a, dx, dgamma, dbeta, scratch_partials, coef, stream, apply_only);
 }
 
 // Full BN backward through Dropout/MaxPool/ReLU6: writes dx [B,H,W,C], dgamma[C], dbeta[C].
@@ -1199,6 +1201,17 @@ extern "C" int crnn_bn_bwd_ex(const void* x, const void* g, const float* bnstate
   return bn_bwd_typed<float>((const float*)x, (const float*)g, bnstate, gamma, (float*)dx, dgamma, dbeta, scratch_partials, coef, B, H, W, C,
                              ph, pw, rate, seed, layer, stream);
 }
+// Pass 2 of crnn_bn_bwd_ex alone: dx = scale * (gy - coef[0..C) - xhat * coef[C..2C)) with coef = [mean(gy) | mean(gy * xhat)] from crnn_bn_bwd_finalize
+// (the statistics taken by the kernel that produced g: crnn_gemm_wres_bf16_bnstats, crnn_gemm_f32x3_bnstats).  Same arguments otherwise.
+extern "C" int crnn_bn_bwd_apply_ex(const void* x, const void* g, const float* bnstate, const float* coef, void* dx, int B, int H, int W, int C,
+                                    int ph, int pw, float rate, uint64_t seed, uint32_t layer, int dtype, hipStream_t stream) {
+  if (!x || !g || !bnstate || !coef || !dx) return CRNN_ERR_ARG;
+  if (dtype == CRNN_BF16)
+    return bn_bwd_typed<bf16_t>((const bf16_t*)x, (const bf16_t*)g, bnstate, nullptr, (bf16_t*)dx, nullptr, nullptr, nullptr, const_cast<float*>(coef), B, H, W,
+                                C, ph, pw, rate, seed, layer, stream, true);
+  return bn_bwd_typed<float>((const float*)x, (const float*)g, bnstate, nullptr, (float*)dx, nullptr, nullptr, nullptr, const_cast<float*>(coef), B, H, W, C,
+                             ph, pw, rate, seed, layer, stream, true);
+}
 // Second stage of a BatchNorm backward whose statistics pass ran elsewhere (crnn_gemm_wres_bf16_bnstats): partials [nparts][2][C] = partial
 // sums of gy and gy * xhat over `count` elements per channel -> dgamma, dbeta and coef = [mean(gy) | mean(gy * xhat)] (what
 // crnn_dwconv3x3_bwd_stream / crnn_dwconv3x3_bwd_fused apply).  The finalize launch of crnn_bn_bwd_ex, on its own.
@@ -1207,6 +1220,15 @@ extern "C" int crnn_bn_bwd_finalize(const float* partials, int nparts, int C, lo
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, RED_CH)), dim3(RED_CH, RED_PL), 0, stream, partials, nparts, C, 1.0 / (double)count, dgamma, dbeta, coef);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
+}
+// Same, for long partial lists (one row per GEMM tile row: crnn_gemm_f32x3_bnstats): rows folded into CRNN_BN_FOLD_ROWS chunk sums first
+// (scratch: CRNN_BN_FOLD_ROWS * 2 * C floats), as crnn_bn_finalize_folded does for the forward statistics.
+extern "C" int crnn_bn_bwd_finalize_folded(const float* partials, int nparts, int C, long count, float* dgamma, float* dbeta, float* coef, float* scratch,
+                                           hipStream_t stream) {
+  if (nparts <= 1024 || scratch == nullptr) return crnn_bn_bwd_finalize(partials, nparts, C, count, dgamma, dbeta, coef, stream);
+  hipLaunchKernelGGL(partials_sum_kernel, dim3(cdiv(2 * C, RED_CH), CRNN_BN_FOLD_ROWS), dim3(RED_CH, RED_PL), 0, stream, partials, nparts, 2 * C, scratch, 1.f);
+  CRNN_LAUNCH_CHECK();
+  return crnn_bn_bwd_finalize(scratch, CRNN_BN_FOLD_ROWS, C, count, dgamma, dbeta, coef, stream);
 }
 extern "C" int crnn_bn_bwd(const float* x, const float* g, const float* bnstate, const float* gamma, float* dx,
                            float* dgamma, float* dbeta, float* scratch_partials, float* coef, int B, int H, int W, int C,

@@ -39,6 +39,10 @@ struct GemmParams {
   // rounded to bf16, ch = the reduction index (modes 0/1) or the A row (mode 2): the BatchNorm + ReLU6 between a depthwise
   // and a pointwise convolution, applied while the tile is staged instead of in a pass of its own
   const float* ascale; const float* ashift;
+  // optional BatchNorm-BACKWARD statistics from the epilogue (bf16-family tile kernels, fp32 result, whole tiles): C is the gradient da that arrives at
+  // a ReLU6(BatchNorm(d)); bnpart [tilesM][2][N] = per-tile column sums of gy and gy * xhat, gy = C where 0 < d * scale + shift < 6,
+  // xhat = (d - mean) / sqrt(var + eps); bnD [M][ldd] fp32 = d, bnstate = [mean | var | scale | shift] x N
+  const float* bnD; int ldd; const float* bnstate; float* bnpart;
 #ifdef CRNN_GEMM_EXP
   unsigned long long* trace;   // ablation build only: s_memrealtime stamps of workgroup 300, thread 0
   int exp;         // ablation build only (scripts/gemm_ablate.py): 1 no C stores, 2 no MFMA, 4 B loaded once, 8 A loaded once
@@ -371,6 +375,7 @@ static int gemm_f32_impl(int mode, const float* A, const float* B, float* C, int
   GemmParams p;
   p.xsplit = 0;
   p.stats = stats; p.cscale = cscale; p.cshift = cshift; p.ascale = nullptr; p.ashift = nullptr;
+  p.bnD = nullptr; p.ldd = 0; p.bnstate = nullptr; p.bnpart = nullptr;
   p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.bias = bias; p.act = act; p.accumulate = accumulate; p.permP = permP;
   p.dtA = p.dtB = p.dtC = CRNN_F32;

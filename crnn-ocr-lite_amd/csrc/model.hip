@@ -877,6 +877,12 @@ int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t au
           if (rc == CRNN_ERR_UNSUPPORTED) rc = crnn_gemm_nt_bf16(gB, wsh, gA, (int)M, ci, co, stream);
         }
       }
+      // parity mode: the three-plane GEMM's epilogue takes the statistics pass of the depthwise BatchNorm's backward (it holds the finished da tile)
+      if (rc == CRNN_ERR_UNSUPPORTED && !fused_dw && pw_products(cfg) == 2 && dtq == CRNN_F32 && dtd == CRNN_F32 &&
+          !(cfg->flags & CRNN_FLAG_NO_BN_STATS_FUSION) && crnn_gemm_f32x3_bnstats_supported(M, ci, co) == CRNN_OK) {
+        rc = crnn_gemm_f32x3_bnstats(gB, c.p(bp + "_pw"), gA, M, ci, co, c.w("d" + p), c.w("bn1s" + p), c.w("partials"), stream);
+        bn1_stats_rows = (rc == CRNN_OK) ? crnn_gemm_f32x3_bnstats_rows(M) : 0;
+      }
       if (rc == CRNN_ERR_UNSUPPORTED) rc = gemm_t(c, 1, gB, dtq, c.p(bp + "_pw"), CRNN_F32, gA, dtd, (int)M, ci, co, co, co, ci);
       CRNN_TRY(rc);
     }
@@ -902,6 +908,10 @@ int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t au
       gC_free = gB_free; gB_free = nullptr;
       continue;
     }
+    if (bn1_stats_rows > 0) {   // statistics from the data-gradient GEMM: finalize, then pass 2 alone
+      CRNN_TRY(crnn_bn_bwd_finalize_folded(c.w("partials"), bn1_stats_rows, ci, M, c.g(bp + "_bn1_g"), c.g(bp + "_bn1_b"), c.w("coef"), c.w("fold"), stream));
+      CRNN_TRY(crnn_bn_bwd_apply_ex(c.w("d" + p), gA, c.w("bn1s" + p), c.w("coef"), gB, B, H, W, ci, 1, 1, 0.f, 0, 0, dtd, stream));
+    } else
     CRNN_TRY(crnn_bn_bwd_ex(c.w("d" + p), gA, c.w("bn1s" + p), c.p(bp + "_bn1_g"), gB, c.g(bp + "_bn1_g"), c.g(bp + "_bn1_b"), c.w("partials"),
                             c.w("coef"), B, H, W, ci, 1, 1, 0.f, 0, 0, dtd, stream));
     CRNN_TRY(crnn_dwconv3x3_wgrad_ex(xin, gB, c.g(bp + "_dw"), c.w("partials"), B, H, W, ci, dtd, stream));

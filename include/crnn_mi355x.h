@@ -369,6 +369,20 @@ int crnn_gemm_wres_bnstats_rows(long M, int N, int K);
 int crnn_gemm_wres_bf16_bnstats(const void* X, const void* W, void* Y, long M, int N, int K, const void* d, const float* bnstate,
                                 float* stat_partials, crnn_stream_t stream);
 int crnn_bn_bwd_finalize(const float* partials, int nparts, int C, long count, float* dgamma, float* dbeta, float* coef, crnn_stream_t stream);
+/* ... for long partial lists (folded into 32 chunk rows first; scratch: 32 * 2 * C floats, may be NULL for nparts <= 1024) */
+int crnn_bn_bwd_finalize_folded(const float* partials, int nparts, int C, long count, float* dgamma, float* dbeta, float* coef, float* scratch,
+                                crnn_stream_t stream);
+/* Pass 2 of crnn_bn_bwd_ex alone: dx from coef = [mean(gy) | mean(gy * xhat)] of a statistics pass that ran elsewhere (crnn_bn_bwd_finalize*). */
+int crnn_bn_bwd_apply_ex(const void* x, const void* g, const float* bnstate, const float* coef, void* dx, int B, int H, int W, int C, int ph, int pw,
+                         float rate, uint64_t seed, uint32_t layer, int dtype, crnn_stream_t stream);
+/* Parity mode: the data gradient da [M][N] = dq [M][K] . W [N][K]^T of a block's pointwise conv as three-plane products (crnn_gemm_f32x3 mode 1, bit for
+ * bit) whose epilogue also takes the statistics pass of the BatchNorm in front of the conv: stat_partials [M / 128][2][N] = per-tile column sums of gy and
+ * gy * xhat, gy = da where 0 < d * scale + shift < 6 (d [M][N] fp32 = the BatchNorm's input, bnstate = [mean|var|scale|shift] x N).  Whole tiles only
+ * (M % 128 == 0, N = 64 or a multiple of 128, K % 64 == 0, 16-byte aligned pointers); -3 otherwise (run crnn_bn_bwd_ex). */
+int crnn_gemm_f32x3_bnstats_supported(long M, int N, int K);
+int crnn_gemm_f32x3_bnstats_rows(long M);
+int crnn_gemm_f32x3_bnstats(const float* dq, const float* W, float* da, long M, int N, int K, const float* d, const float* bnstate, float* stat_partials,
+                            crnn_stream_t stream);
 /* Inference forward of a pointwise convolution on the same kernel with the BatchNorm + ReLU6 that follows folded into the MFMA waves'
  * epilogue: y[M][N] (bf16) = ReLU6((a . wT^T) * scale[n] + shift[n]), out_bnstate = [mean|var|scale|shift] (crnn_bn_infer_state).
  * Bit-identical to crnn_pwconv_fwd(..., out_bnstate, ...) on bf16 tensors.  Same shape rules as crnn_gemm_wres_bf16. */

@@ -1253,6 +1253,54 @@ def test_weights_resident_inference_conv_with_folded_batchnorm_equals_the_tile_k
     assert_close(y1[:M].float().cpu().numpy(), ref, rtol=1e-2, atol=2e-2, what="folded conv vs fp64")
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 64, 128), (128 * 9, 128, 256), (128 * 40, 256, 256), (128 * 21, 512, 512), (128 * 1500, 128, 256), (128 * 7, 64, 128)])
+def test_three_plane_data_gradient_with_batchnorm_backward_statistics(M, N, K):
+    """crnn_gemm_f32x3_bnstats (parity mode): the pointwise conv's data gradient da = dq . W^T as three-plane products whose epilogue also takes
+    the statistics pass of the depthwise BatchNorm's backward.  da must be the very bits of crnn_gemm_f32x3; dgamma / dbeta / coef after
+    crnn_bn_bwd_finalize_folded must equal crnn_bn_bwd_ex's statistics pass on the same da and d up to the order of the fp32 partial sums and an
+    fp64 evaluation; crnn_bn_bwd_apply_ex (pass 2 alone) must reproduce crnn_bn_bwd_ex's dx from the same coefficients bit for bit.  One and
+    many tile rows (beyond 1024: the folded finalize), both tile widths."""
+    rs = np.random.RandomState(M % 1000 + N + K + 7)
+    dq = rs.normal(size=(M, K)).astype(np.float32); W = (rs.normal(size=(N, K)) * 0.1).astype(np.float32)
+    d = (rs.normal(size=(M, N)) * 1.5 + 0.3).astype(np.float32)
+    gamma = rs.uniform(0.5, 1.5, N); beta = rs.normal(size=N) * 0.5 + 1.0
+    mean = d.astype(np.float64).mean(0); var = d.astype(np.float64).var(0)
+    inv = 1.0 / np.sqrt(var.astype(np.float32) + np.float32(1e-3))
+    scale = (gamma * inv).astype(np.float32); shift = (beta - mean * gamma * inv).astype(np.float32)
+    bnstate = dev(np.concatenate([mean, var, scale, shift]).astype(np.float32))
+    dqd, Wd, dd = dev(dq), dev(W), dev(d)
+    assert L().crnn_gemm_f32x3_bnstats_supported(M, N, K) == 0
+    rows = L().crnn_gemm_f32x3_bnstats_rows(M)
+    assert rows == M // 128
+    parts = torch.full((rows * 2 * N,), float("nan"), device="cuda")         # every row and column must be written
+    da = zeros(M, N); dg, db, coef = zeros(N), zeros(N), zeros(2 * N); fold = zeros(32 * 2 * N)
+    for rep in range(2):
+        ok(L().crnn_gemm_f32x3_bnstats(P(dqd), P(Wd), P(da), M, N, K, P(dd), P(bnstate), P(parts), S()))
+    assert bool(torch.isfinite(parts).all())
+    ok(L().crnn_bn_bwd_finalize_folded(P(parts), rows, N, M, P(dg), P(db), P(coef), P(fold), S()))
+    da0 = zeros(M, N); scr = zeros(16)
+    ok(L().crnn_gemm_f32x3(1, P(dqd), P(Wd), P(da0), M, N, K, K, K, N, None, 0, 0, 0, None, 0, S()))
+    assert torch.equal(da, da0), "da differs from crnn_gemm_f32x3"
+    nch = L().crnn_bn_bwd_chunks(M)
+    parts2 = zeros(nch * 2 * N); dg2, db2, coef2 = zeros(N), zeros(N), zeros(2 * N); dx2 = zeros(M, N)
+    ok(L().crnn_bn_bwd_ex(P(dd), P(da0), P(bnstate), P(dev(gamma)), P(dx2), P(dg2), P(db2), P(parts2), P(coef2), 1, 1, M, N, 1, 1, 0.0, 0, 0, 0, S()))
+    for a, b, what in ((dg, dg2, "dgamma"), (db, db2, "dbeta"), (coef, coef2, "coef")):
+        a, b = host(a).astype(np.float64), host(b).astype(np.float64)
+        assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max() + 1e-6, (what, np.abs(a - b).max(), np.abs(b).max())
+    dx1 = torch.full((M, N), 7.0, device="cuda")
+    ok(L().crnn_bn_bwd_apply_ex(P(dd), P(da0), P(bnstate), P(coef2), P(dx1), 1, 1, M, N, 1, 1, 0.0, 0, 0, 0, S()))
+    assert torch.equal(dx1, dx2), "pass 2 alone differs from crnn_bn_bwd_ex"
+    g = host(da0).astype(np.float64)
+    t = d * scale + shift
+    live = (t > 0) & (t < 6)
+    gy = np.where(live, g, 0.0)
+    xhat = (d.astype(np.float64) - mean.astype(np.float32).astype(np.float64)) * inv.astype(np.float64)
+    assert_close(host(db), gy.sum(0), rtol=1e-4, atol=1e-4 * np.abs(gy).sum(0).max(), what="dbeta vs fp64")
+    assert_close(host(dg), (gy * xhat).sum(0), rtol=1e-4, atol=1e-4 * np.abs(gy * xhat).sum(0).max(), what="dgamma vs fp64")
+    assert L().crnn_gemm_f32x3_bnstats_supported(M + 5, N, K) == -3 and L().crnn_gemm_f32x3_bnstats_supported(M, 96, K) == -3
+    assert L().crnn_gemm_f32x3_bnstats(P(dqd), P(Wd), P(da), M, N, K, None, P(bnstate), P(parts), S()) == -2
+
+
 def _window_major(t):
     """[B][H][W][C] -> rows in 2x2-window-major order: pixel (y, x) is row ((y/2)(W/2) + x/2) 4 + (y&1) 2 + (x&1) of its image."""
     B, H, W, C = t.shape
