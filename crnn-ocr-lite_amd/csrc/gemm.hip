@@ -465,3 +465,19 @@ extern "C" int crnn_pwconv_bnrelu6_wgrad(const void* d, const float* in_bnstate,
   return gemm_bf16_impl(2, d, g, dw, K, N, (int)M, K, N, N, nullptr, 0, 0, 0, scratch, scratch_bytes, CRNN_BF16, CRNN_BF16, CRNN_F32, nullptr, stream,
                         nullptr, nullptr, in_bnstate + 2L * K, in_bnstate + 3L * K);
 }
+// Parity mode (fp32 tensors, three-plane products): the same two GEMMs fed by the PRE-BatchNorm depthwise output d [M][K] fp32 -- the staging waves of
+// the three-plane kernel apply ReLU6(d * scale[ch] + shift[ch]) (the arithmetic of crnn_bn_act_pool_drop_ex, bit for bit) to the raw items before the
+// plane split, so the activated tensor is never written.  Results equal crnn_bn_act_pool_drop_ex + crnn_pwconv_fwd(bf16_products = 2) / crnn_gemm_f32x3
+// mode 2 bit for bit.  w [K][N] fp32 (K <= 512); -3 for shapes outside the kernel's rules.
+extern "C" int crnn_pwconv_bnrelu6_fwd_f32x3(const float* d, const float* in_bnstate, const float* w, float* q, long M, int N, int K,
+                                             float* stat_partials, hipStream_t stream) {
+  if (M <= 0 || M > 0x7fffffffL || !in_bnstate) return CRNN_ERR_ARG;
+  return gemm_bf16_impl(0, d, w, q, (int)M, N, K, K, N, N, nullptr, 0, 0, 0, nullptr, 0, CRNN_F32, CRNN_F32, CRNN_F32, stat_partials, stream,
+                        nullptr, nullptr, in_bnstate + 2L * K, in_bnstate + 3L * K, true);
+}
+extern "C" int crnn_pwconv_bnrelu6_wgrad_f32x3(const float* d, const float* in_bnstate, const float* g, float* dw, long M, int N, int K,
+                                               float* scratch, size_t scratch_bytes, hipStream_t stream) {
+  if (M <= 0 || M > 0x7fffffffL || !in_bnstate) return CRNN_ERR_ARG;
+  return gemm_bf16_impl(2, d, g, dw, K, N, (int)M, K, N, N, nullptr, 0, 0, 0, scratch, scratch_bytes, CRNN_F32, CRNN_F32, CRNN_F32, nullptr, stream,
+                        nullptr, nullptr, in_bnstate + 2L * K, in_bnstate + 3L * K, true);
+}

@@ -254,6 +254,10 @@ int gemm_t(const Ctx& c, int mode, const float* A, int dtA, const float* B, int 
 bool fuse_dw_bn(const crnn_config* cfg, int dtd, int dtq, int ci) {
   return !(cfg->flags & CRNN_FLAG_NO_DW_BN_FUSION) && cfg->mfma_bf16 == 2 && dtd == CRNN_BF16 && dtq == CRNN_BF16 && ci % 8 == 0 && ci <= 512;
 }
+// parity mode with three-plane GEMMs: the same fusion in the staging waves of crnn_gemm_f32x3's kernel (forward product and weight gradient)
+bool fuse_dw_bn_x3(const crnn_config* cfg, int dtd, int dtq, int ci) {
+  return !(cfg->flags & CRNN_FLAG_NO_DW_BN_FUSION) && pw_products(cfg) == 2 && dtd == CRNN_F32 && dtq == CRNN_F32 && ci % 4 == 0 && ci >= 16 && ci <= 512;
+}
 // always-fp32 GEMM (spatial-transformer localisation net: tiny, and theta is precision-sensitive)
 int gemm32(const Ctx& c, int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
            const float* bias = nullptr, int act = 0, int acc = 0, int perm = 0) {
@@ -484,7 +488,8 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
     }
     bn_off += ci;
     const bool fuse_a = fuse_dw_bn(cfg, dtd, dtq, ci);                  // BN + ReLU6 applied while the GEMM stages its operand
-    if (!fuse_a) CRNN_TRY(crnn_bn_act_pool_drop_ex(dd, s1, aa, 1, 1, (int)M, ci, 1, 1, 0.f, 0, 0, dtd, dtd, stream));
+    const bool fuse_x3 = fuse_dw_bn_x3(cfg, dtd, dtq, ci);              // ... by the staging waves of the parity mode's three-plane kernel
+    if (!fuse_a && !fuse_x3) CRNN_TRY(crnn_bn_act_pool_drop_ex(dd, s1, aa, 1, 1, (int)M, ci, 1, 1, 0.f, 0, 0, dtd, dtd, stream));
     int stat_rows = crnn_pwconv_stat_rows(M);
     {  // pointwise conv; its epilogue also produces the batch statistics of the BatchNorm that follows
       int dtw = CRNN_F32, wt = 0;
@@ -494,6 +499,7 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
         dtw = CRNN_BF16; wt = 1;
       }
       if (ci == 1 && dtd == CRNN_F32) CRNN_TRY(crnn_pw1_fwd(aa, c.p(bp + "_pw"), qq, M, co, parts, dtq, stream));   // block 1: outer product
+      else if (fuse_x3) CRNN_TRY(crnn_pwconv_bnrelu6_fwd_f32x3(dd, s1, c.p(bp + "_pw"), qq, M, co, ci, parts, stream));
       else if (fuse_a) {
         // weights resident in registers, IO waves transform / drain / take the statistics (gemm_wres.hip) where its shape rules hold
         int rc = CRNN_ERR_UNSUPPORTED;
@@ -859,6 +865,8 @@ int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t au
           rc = crnn_pwconv_bnrelu6_wgrad(c.w("d" + p), c.w("bn1s" + p), gB, c.g(bp + "_pw"), M, co, ci, cw.scratch(), kGemmScratchBytes, cw.s);
         CRNN_TRY(rc);
       }
+      else if (fuse_dw_bn_x3(cfg, dtd, dtq, ci))   // parity mode: likewise, in the three-plane kernel's staging waves
+        CRNN_TRY(crnn_pwconv_bnrelu6_wgrad_f32x3(c.w("d" + p), c.w("bn1s" + p), gB, c.g(bp + "_pw"), M, co, ci, cw.scratch(), kGemmScratchBytes, cw.s));
       else CRNN_TRY(gemm_t(cw, 2, c.w("a" + p), dtd, gB, dtq, c.g(bp + "_pw"), CRNN_F32, ci, co, (int)M, ci, co, co));
       if (side) CRNN_TRY(fj.mark(&gB_free));
       // data gradient da[M][ci] = dq[M][co] . W[ci][co]^T: the persistent LDS-DMA kernels where their shape rules hold

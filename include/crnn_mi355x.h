@@ -206,6 +206,13 @@ int crnn_pwconv_bnrelu6_fwd(const void* d, const float* in_bnstate, const void* 
                             float* stat_partials, int dt_q, int w_transposed, crnn_stream_t stream);
 int crnn_pwconv_bnrelu6_wgrad(const void* d, const float* in_bnstate, const void* g, float* dw, long M, int N, int K,
                               float* scratch, size_t scratch_bytes, crnn_stream_t stream);
+/* Parity mode (fp32 tensors, three-plane products, crnn_gemm_f32x3): the same two GEMMs fed by the PRE-BatchNorm depthwise output d [M][K] fp32; the
+ * staging waves apply ReLU6(d * scale[ch] + shift[ch]) (crnn_bn_act_pool_drop_ex's arithmetic, bit for bit) before the plane split, so the activated
+ * tensor is never written.  w [K][N] fp32, K <= 512; results equal the unfused sequence bit for bit; -3 outside the kernel's shape rules. */
+int crnn_pwconv_bnrelu6_fwd_f32x3(const float* d, const float* in_bnstate, const float* w, float* q, long M, int N, int K, float* stat_partials,
+                                  crnn_stream_t stream);
+int crnn_pwconv_bnrelu6_wgrad_f32x3(const float* d, const float* in_bnstate, const float* g, float* dw, long M, int N, int K, float* scratch,
+                                    size_t scratch_bytes, crnn_stream_t stream);
 /* The same pointwise conv for ONE input channel (block 1: Conv2D(64, 1x1) on the single-channel depthwise output,
  * utils.py:64 / 49): an outer product q[m][c] = a[m] * w[c], its data gradient da[m] = dq[m] . w and weight gradient
  * dw[c] = sum_m a[m] dq[m][c].  a / da fp32; q / dq fp32 (dt_q 0) or bf16 (1); N a power of two, 8 <= N <= 256.

@@ -1301,6 +1301,35 @@ def test_three_plane_data_gradient_with_batchnorm_backward_statistics(M, N, K):
     assert L().crnn_gemm_f32x3_bnstats(P(dqd), P(Wd), P(da), M, N, K, None, P(bnstate), P(parts), S()) == -2
 
 
+@pytest.mark.parametrize("M,K,N", [(128 * 40, 128, 256), (1000, 64, 128), (128 * 6, 512, 512), (128 * 3 + 5, 256, 64), (128 * 200, 64, 128)])
+def test_three_plane_gemms_apply_batchnorm_relu6_while_staging(M, K, N):
+    """crnn_pwconv_bnrelu6_fwd_f32x3 / crnn_pwconv_bnrelu6_wgrad_f32x3 (parity mode): the staging waves of the three-plane kernel apply
+    ReLU6(d * scale + shift) to the raw fp32 items before the plane split.  Both must equal the unfused sequence -- crnn_bn_act_pool_drop_ex,
+    then crnn_pwconv_fwd(bf16_products = 2) with its statistics / crnn_gemm_f32x3 mode 2 -- bit for bit: whole and ragged tiles, both tile
+    widths, the split reduction of the weight gradient."""
+    rs = np.random.RandomState(M % 1000 + N + K + 3)
+    d = dev((rs.normal(size=(M, K)) * 1.5 + 0.4).astype(np.float32)); w = dev((rs.normal(size=(K, N)) * 0.1).astype(np.float32))
+    g = dev(rs.normal(size=(M, N)).astype(np.float32))
+    st = dev(np.concatenate([rs.normal(size=K), rs.uniform(0.5, 2.0, size=K), rs.normal(size=K) * 0.3 + 1.0, rs.normal(size=K) * 0.5 + 0.5]).astype(np.float32))
+    a = zeros(M, K)
+    ok(L().crnn_bn_act_pool_drop_ex(P(d), P(st), P(a), 1, 1, M, K, 1, 1, 0.0, 0, 0, 0, 0, S()))
+    rows = L().crnn_pwconv_stat_rows(M)
+    q0, q1 = zeros(M, N), torch.full((M + 2, N), 7.0, device="cuda"); p0, p1 = zeros(rows, 2, N), zeros(rows, 2, N)
+    ok(L().crnn_pwconv_fwd(P(a), P(w), P(q0), M, N, K, P(p0), None, 2, 0, 0, 0, 0, S()))
+    for rep in range(2):
+        ok(L().crnn_pwconv_bnrelu6_fwd_f32x3(P(d), P(st), P(w), P(q1), M, N, K, P(p1), S()))
+    assert torch.equal(q1[:M], q0) and bool((q1[M:] == 7.0).all()), "forward differs: max %g" % float((q1[:M] - q0).abs().max())
+    assert torch.equal(p1, p0)
+    assert float(q0.abs().max()) > 0
+    scr = zeros(16 * 1024 * 1024); sb = ctypes.c_size_t(scr.numel() * 4)
+    dw0, dw1 = zeros(K, N), zeros(K, N)
+    ok(L().crnn_gemm_f32x3(2, P(a), P(g), P(dw0), K, N, M, K, N, N, None, 0, 0, 0, P(scr), sb, S()))
+    ok(L().crnn_pwconv_bnrelu6_wgrad_f32x3(P(d), P(st), P(g), P(dw1), M, N, K, P(scr), sb, S()))
+    assert torch.equal(dw1, dw0), "weight gradient differs: max %g" % float((dw1 - dw0).abs().max())
+    ref = host(a).astype(np.float64).T @ host(g).astype(np.float64)
+    assert_close(host(dw1), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max() + 1e-6, what="weight gradient vs fp64")
+
+
 def _window_major(t):
     """[B][H][W][C] -> rows in 2x2-window-major order: pixel (y, x) is row ((y/2)(W/2) + x/2) 4 + (y&1) 2 + (x&1) of its image."""
     B, H, W, C = t.shape
