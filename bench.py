@@ -208,6 +208,52 @@ def depthwise_bwd_roofline(eng, iters=5):
             "avg_launch_ms": round(1e3 * t / len(launches), 4), "algorithmic_bytes_per_launch_set": nbytes}
 
 
+def batchnorm_roofline(eng, iters=5):
+    """Secondary: the BatchNorm streaming passes of the conv stack that are kernels of their own in the bf16s step -- the block outputs' BatchNorm-2 +
+    ReLU6 + pool + dropout (forward, 7 launches) and BatchNorm-2's backward (statistics pass, finalize, apply pass: blocks 7..1) -- re-issued on the
+    live buffers.  Algorithmic bytes in the storage type: apply reads q and writes x; the backward's two passes read g and q twice and write dq."""
+    from crnn_mi355x.engine import _ptr, _stream
+    if eng.precision != "bf16s":
+        return None
+    lib = eng.lib; B = eng.B
+    blocks = [(64, 1, 1), (128, 1, 1), (256, 2, 2), (256, 1, 1), (512, 1, 2), (512, 1, 1), (512, 1, 1)]
+    h, w = eng.cfg.imgh + 4, eng.cfg.imgw + 4
+    parts, coef = eng.ws_tensor("partials"), eng.ws_tensor("coef")
+    rate = 0.1 if eng.cfg.dropout else 0.0
+    fwd, bwd, fb, bb = [], [], 0.0, 0.0
+    for i, (co, ph, pw) in enumerate(blocks, 1):
+        q, st, x = eng.ws_tensor("q%d" % i), eng.ws_tensor("bn2s%d" % i), eng.ws_tensor("x%d" % i)
+        M, Mo = B * h * w, B * (h // ph) * (w // pw)
+        gam = eng.params[eng.layout["b%d_bn2_g" % i][0]:]; dg = eng.grads[eng.layout["b%d_bn2_g" % i][0]:]; db = eng.grads[eng.layout["b%d_bn2_b" % i][0]:]
+        fwd.append((q, st, x, h, w, co, ph, pw, i)); fb += 2.0 * (M + Mo) * co
+        bwd.append((q, st, gam, dg, db, h, w, co, ph, pw, i)); bb += 2.0 * (2 * (M + Mo) + M) * co
+        h, w = h // ph, w // pw
+    gA, gB = eng.ws_tensor("gA"), eng.ws_tensor("gB")
+    res = {}
+    for name, nb, nl in (("apply", fb, len(fwd)), ("backward", bb, 2 * len(bwd))):
+        ts = []
+        for it in range(iters + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if name == "apply":
+                for q, st, x, hh, ww, cc, ph, pw, layer in fwd:
+                    lib.crnn_bn_act_pool_drop_ex(_ptr(q), _ptr(st), _ptr(x), B, hh, ww, cc, ph, pw, rate, 1234, layer, 1, 1, _stream())
+            else:
+                for q, st, gam, dg, db, hh, ww, cc, ph, pw, layer in reversed(bwd):
+                    lib.crnn_bn_bwd_ex(_ptr(q), _ptr(gA), _ptr(st), _ptr(gam), _ptr(gB), _ptr(dg), _ptr(db), _ptr(parts), _ptr(coef), B, hh, ww, cc, ph, pw,
+                                       rate, 1234, layer, 1, _stream())
+            e1.record(); torch.cuda.synchronize()
+            if it:
+                ts.append(e0.elapsed_time(e1) * 1e-3)
+        t = float(np.median(ts))
+        res[name] = {"achieved": round(nb / t / 1e9, 1), "frac": round(nb / t / 1e9 / PEAK_HBM_GBS, 4), "launches": nl, "ms": round(1e3 * t, 4),
+                     "algorithmic_bytes_per_launch_set": nb}
+    return {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "kernel": "bn_act_pool_drop_kernel (BatchNorm-2 + ReLU6 + MaxPooling + Dropout of the seven block outputs) and bn_bwd_kernel / bn_bwd_pool_kernel "
+                      "(its backward: statistics pass, finalize, apply pass); the gradient buffers are overwritten: run after the step's timing",
+            **res}
+
+
 def pointwise_gemm_roofline(eng, iters=5):
     """Secondary: the NN GEMM family (pointwise 1x1 convs b2..b7 fwd, dense1, RNN input projections) of one step on the
     live buffers: flops / time against the MFMA peak of the active mode."""
@@ -642,6 +688,9 @@ def main():
             lr = lstm_roofline(eng)
             if lr is not None:
                 res["lstm_roofline"] = lr
+            br = batchnorm_roofline(eng)
+            if br is not None:
+                res["bn_roofline"] = br
         if world == 1 and not args.no_secondary:
             adam = lambda: Adam(lr=1e-4, beta_1=0.5, beta_2=0.999, clipnorm=5)
 
