@@ -144,7 +144,12 @@ def depthwise_roofline(eng, iters=15):
     # What a plain COPY of the same bytes achieves here: the six (input, output) pairs copied back to back, same cold protocol and events.
     # "sweep" = grid-stride copy (the resident workgroups read one window of the buffer together); "banded" = every workgroup its own
     # contiguous band, the row-stream kernel's pattern (one image per workgroup).  Last: the copies overwrite the forward's outputs.
-    if bf16s and hasattr(lib, "crnn_debug_copy"):
+    try:
+        from crnn_mi355x import native as _native
+        hooks = _native.hooks()       # measurement hooks live in their own library (libcrnn_testhooks.so), not in the product's
+    except Exception:
+        hooks = None
+    if bf16s and hooks is not None:
         ref = {}
         for name, pattern in (("sweep", 0), ("banded", 1)):
             ts = []
@@ -152,7 +157,7 @@ def depthwise_roofline(eng, iters=15):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for (x, k, o, pt, hh, ww, cc, flip, st) in launches:
-                    lib.crnn_debug_copy(_ptr(x), _ptr(o), B * hh * ww * cc * esz, pattern, 256, _stream())
+                    hooks.crnn_debug_copy(_ptr(x), _ptr(o), B * hh * ww * cc * esz, pattern, 256, _stream())
                 e1.record()
                 torch.cuda.synchronize()
                 if it:
@@ -357,7 +362,115 @@ def synthetic_batch(B, seed, imgh=100, imgw=32, max_len=23, num_classes=38, T=52
     return x, labels, np.full(B, T - 2, dtype=np.int64), ll.astype(np.int64)
 
 
-def cpu_baseline():
+def parity_check(B, n=16, precisions=("fp32", "bf16s"), gru=False):
+    """BASELINE.json's metric is "images/sec + CTC-loss parity": the benchmarked configuration against the oracle (the checker, outside
+    every timed region).  Inference BatchNorm makes the images independent, so the first `n` images of the benchmarked synthetic batch
+    (seed 0, batch B) are run through the fp64 oracle alone and compared with rows 0..n-1 of the device's batch-B forward, per arithmetic
+    mode: max |d logit|, max |d posterior|, max |d CTC cost| per sample (HIP CTC kernel on the device's posteriors vs oracle CTC on the
+    oracle's; utils.py:98-103) absolute and relative, arg-max and greedy-decode agreement (utils.py:347-357 with beam_width 1).
+    Weights: the Keras-family initialisation with randomised biases / BatchNorm parameters / moving statistics (the untouched
+    initialisation decodes every image to "" -- agreement would be trivial)."""
+    from crnn_mi355x.engine import Engine, _ptr, _stream
+    from crnn_mi355x.init import initial_parameters
+    from oracle import model as OM, ctc as OC
+    cfg = OM.Config(gru=gru)
+    probe = None
+    out = {"images": n, "batch": B, "reference": "oracle/model.py forward (fp64 NumPy restatement of utils.py:58-96,247-258) + oracle/ctc.py on the first %d images "
+                                                  "of the benchmarked batch, inference mode" % n,
+           "tolerance": "north_star: fp32 logits within 1e-3, CTC loss within 1e-3, arg-max / greedy indices bit-exact"}
+    x, lab, il, ll = synthetic_batch(B, seed=0, T=cfg.T)
+    p64 = y_ref = None
+    for precision in precisions:
+        eng = Engine(B, dropout=False, precision=precision, gru=gru)
+        if p64 is None:
+            p = initial_parameters(eng.layout, eng.cfg.units, gru, seed=1)
+            rs = np.random.RandomState(2)
+            for k in p:
+                if k.endswith(("_b", "_g")) or k == "stn_d2_w":
+                    p[k] = (p[k] + rs.normal(size=p[k].shape) * (0.02 if k.startswith("stn_d2") else 0.3)).astype(np.float32)
+            bn = {}
+            for name, (off, ch, _) in eng.bn_layout.items():
+                bn[name + "_mean"] = (rs.normal(size=ch) * 0.1).astype(np.float32)
+                bn[name + "_var"] = (np.abs(rs.normal(size=ch)) * 0.5 + 0.5).astype(np.float32)
+            p64 = {k: v.astype(np.float64) for k, v in p.items()}
+            bn64 = {k: v.astype(np.float64) for k, v in bn.items()}
+            t0 = time.perf_counter()
+            y_ref, c_ref = OM.forward(cfg, p64, bn64, x[:n].astype(np.float64), train=False)
+            loss_ref, _ = OC.ctc_loss_and_grad(y_ref, lab[:n], il[:n], ll[:n])
+            g_ref, gl_ref = OC.ctc_greedy_decode(y_ref)
+            out["oracle_seconds"] = round(time.perf_counter() - t0, 2)
+        eng.set_params(p, bn)
+        y = eng.forward(x, train=False)
+        eng._ctc_inputs(lab, il, ll)
+        scratch = eng.ws_tensor("dlogits")
+        rc = eng.lib.crnn_ctc_loss_grad(_ptr(y), _ptr(eng._lab), _ptr(eng._il), _ptr(eng._ll), _ptr(eng.loss), _ptr(scratch), eng.B, eng.T, eng.C,
+                                        eng.cfg.max_len, 2, 0.0, _stream())
+        assert rc == 0, rc
+        go, gl = eng.greedy_decode(y)
+        eng.check_rnn_status()
+        yh = y.float().cpu().numpy()[:n].astype(np.float64)
+        logits = eng.ws_tensor("logits").float().cpu().numpy().reshape(B, eng.T, eng.C)[:n].astype(np.float64)
+        loss = eng.loss.cpu().numpy()[:n].astype(np.float64)
+        go, gl = go.cpu().numpy()[:n], gl.cpu().numpy()[:n]
+        same_seq = [bool(gl[i] == gl_ref[i] and np.array_equal(go[i, :gl[i]], g_ref[i, :gl_ref[i]])) for i in range(n)]
+        dl = np.abs(loss - loss_ref)
+        out[precision] = {"max_abs_dlogit": float(np.abs(logits - c_ref["logits"]).max()), "max_abs_dposterior": float(np.abs(yh - y_ref).max()),
+                          "max_abs_dctc_cost": float(dl.max()), "max_rel_dctc_cost": float((dl / np.abs(loss_ref)).max()),
+                          "mean_ctc_cost_device": float(loss.mean()), "mean_ctc_cost_oracle": float(loss_ref.mean()),
+                          "argmax_agreement": float((np.argmax(yh, -1) == np.argmax(y_ref, -1)).mean()),
+                          "greedy_decodes_equal": float(np.mean(same_seq)),
+                          "nonblank_argmax_fraction_oracle": float((np.argmax(y_ref, -1) != cfg.num_classes - 1).mean())}
+        o = out[precision]
+        o["within_tolerance"] = bool(o["max_abs_dlogit"] <= 1e-3 and o["max_abs_dctc_cost"] <= 1e-3 + 1e-5 * float(np.abs(loss_ref).max())
+                                     and o["argmax_agreement"] == 1.0 and o["greedy_decodes_equal"] == 1.0)
+        for k, v in list(o.items()):
+            if isinstance(v, float):
+                o[k] = float("%.4g" % v)
+        del eng
+        torch.cuda.empty_cache()
+    return out
+
+
+def fit_leg(B, steps, precision, warm=5):
+    """Host-inclusive rate through the reference's own surface (train.py:201-209): CRNN(...).get_model() -> compile(Adam) ->
+    Model.fit_generator over a Readf-style generator of HOST NumPy batches (float64 images as get_blank_matrices makes them, int64
+    labels / lengths, the generator keeps rewriting the arrays it yielded).  Includes the float64 -> float32 conversion, the PCIe
+    transfer (page-locked double-buffered staging, batch k+1 under step k), the per-step loss read-back and the callback plumbing."""
+    import utils as U
+    old = os.environ.get("CRNN_PRECISION")
+    os.environ["CRNN_PRECISION"] = precision
+    try:
+        x, lab, il, ll = synthetic_batch(B, seed=0)
+        X = x.astype(np.float64)
+        inputs = {"the_input": X, "the_labels": lab.astype(np.int64), "input_length": il.reshape(-1, 1).astype(np.int64),
+                  "label_length": ll.reshape(-1, 1).astype(np.int64), "source_str": np.array(["x"] * B)}
+        outputs = {"ctc": np.zeros([B])}
+
+        def gen():
+            while True:
+                np.add(X, 0.0, out=X)                   # the generator owns and rewrites these arrays between yields
+                yield inputs, outputs
+        model = U.CRNN(num_classes=38, shape=(100, 32, 1), GRU=False, time_dense_size=128, n_units=256, max_string_len=23).get_model()
+        model.compile(loss={"ctc": lambda y_true, y_pred: y_pred}, optimizer=U.optimizers.Adam(lr=1e-4, beta_1=0.5, beta_2=0.999, clipnorm=5))
+        g = gen()
+        model.fit_generator(g, steps_per_epoch=warm, epochs=1, verbose=0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        H = model.fit_generator(g, steps_per_epoch=steps, epochs=1, verbose=0)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"value": round(B * steps / dt, 1), "unit": "images/sec", "ms_per_step": round(1e3 * dt / steps, 3), "batch": B, "steps": steps,
+                "dtype": "f32" if precision == "fp32" else "bf16", "loss": round(float(H.history["loss"][-1]), 4),
+                "workload": "Model.fit_generator over host NumPy batches (float64 images, batch %d) through utils.CRNN / compile / fit_generator" % B}
+    finally:
+        if old is None:
+            os.environ.pop("CRNN_PRECISION", None)
+        else:
+            os.environ["CRNN_PRECISION"] = old
+        torch.cuda.empty_cache()
+
+
+def cpu_baseline(full=False):
     """The reference's CPU path is Keras-TF (train.py with --G 0), absent from this image; what IS timed here, on this box's host
     cores, is the torch-CPU fp32 restatement of the same graph (oracle/torch_port.py: training-mode forward, CTC cost, autograd
     backward, global-norm clip, Keras-form Adam) on the metric's literal batch: 64 synthetic 100x32 images (BASELINE configs[0]).
@@ -368,15 +481,18 @@ def cpu_baseline():
     # (2 x EPYC 9575F, 256 logical cores) 4 / 16 / 32 / 64 threads = 6.2 / 6.5 / 6.3 / 9.1 s per step, and minutes per step with all
     # 256 -- so "all cores" is capped at 16 threads and `cores` states the threads actually used
     cores = min(os.cpu_count() or 1, 16)
-    sall, _ = TP.train_step_benchmark(batch=64, threads=cores, steps=2, warmup=1)
-    s4, _ = TP.train_step_benchmark(batch=64, threads=4, steps=1, warmup=0)     # the allocator / thread pools are warm by now
+    nwarm, nsteps = (5, 20) if full else (1, 3)
+    sall, _ = TP.train_step_benchmark(batch=64, threads=cores, steps=nsteps, warmup=nwarm)
+    s4, _ = TP.train_step_benchmark(batch=64, threads=4, steps=nsteps if full else 1, warmup=0)     # the allocator / thread pools are warm by now
     return {"value": round(64 / sall, 2), "unit": "images/sec", "cores": int(cores), "kind": "port",
             "threads4": {"value": round(64 / s4, 2), "unit": "images/sec", "cores": 4, "sec_per_step": round(s4, 3)},
             "sec_per_step": round(sall, 3), "host_logical_cores": os.cpu_count(),
             "sample": "torch-CPU fp32 restatement of the Keras/TF graph (oracle/torch_port.py), full train step (fwd + CTC + bwd + clip + "
-                      "Adam) at batch 64, 100x32: 1 warm-up + 2 timed steps with %d threads (more threads are slower on this graph); then 1 timed "
-                      "step with 4 threads (the reference's CPU setting, predict.py:88-93); a bounded sample (BASELINE.md planned 5 + 20 steps: "
-                      "that is 2.5 minutes of CPU work); Keras-TF itself is not in the image" % cores}
+                      "Adam) at batch 64, 100x32: %d warm-up + %d timed steps (mean) with %d threads (more threads are slower on this graph); then %d timed "
+                      "step(s) with 4 threads (the reference's CPU setting, predict.py:88-93); %s; Keras-TF itself is not in the image"
+                      % (nwarm, nsteps, cores, nsteps if full else 1,
+                         "BASELINE.md's full protocol (--cpu-baseline-full)" if full else
+                         "a bounded sample (about 30 s of CPU work; --cpu-baseline-full runs BASELINE.md's 5 + 20 steps: 2.5 minutes)")}
 
 
 def predict_leg(batch=1024, iters=20, precision="bf16s", cpu_sample=32):
@@ -573,6 +689,8 @@ def main():
     ap.add_argument("--gru", action="store_true", help="GRU recurrence (what the reference's train.py really builds, SURVEY F3) instead of "
                     "the LSTM BASELINE.json names")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="BASELINE.md's protocol for the CPU leg: 5 warm-up + 20 timed steps (about 2.5 minutes)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity object (oracle forward of 16 images: a few seconds of CPU)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the fp32 parity-mode and batch-64 timings")
     args = ap.parse_args()
@@ -728,6 +846,12 @@ def main():
             if B != 64:
                 # the metric's literal batch size (BASELINE.json: "100x32 bs64"), same precision as the headline
                 res["bs64"] = leg(64, max(5, args.steps), 3, reps=3)
+                if args.precision != "fp32":   # ... and at the reference's own precision (the parity mode)
+                    res["bs64_fp32"] = leg(64, max(5, min(args.steps, 10)), 3, reps=3, precision="fp32")
+            if args.imgh == 100 and not args.gru:
+                # the same step driven through the reference's surface from host batches (train.py:201-209)
+                res["fit"] = fit_leg(B, max(10, args.steps), args.precision)
+                res["fit"]["vs_device_resident"] = round(res["fit"]["value"] / res["value"], 3)
             if args.imgh == 100 and not args.gru and args.precision == "bf16s":
                 # BASELINE configs[2]: the IAM shape (200x32 variable-width text, max_len 21, T = 102), STN on
                 res["iam"] = dict(leg(B, max(3, min(args.steps, 10)), 2, imgh=200, max_len=21),
@@ -738,8 +862,12 @@ def main():
                                   workload="configs[1] with the GRU recurrence the reference trains (train.py:119, utils.py:80-82)")
                 # BASELINE configs[4]: predict path (predict.py:166-171), batch 1024, beam width 10
                 res["predict"] = predict_leg(1024, iters=20, precision=args.precision, cpu_sample=0 if args.no_cpu_baseline else 32)
+        if world == 1 and not args.no_parity and args.imgh == 100:
+            # CTC-loss / logit / arg-max parity of the benchmarked configuration against the oracle (the metric's second half)
+            res["parity"] = parity_check(B, 16, ("fp32", "bf16s") if args.precision == "bf16s" else ("fp32", args.precision) if args.precision != "fp32" else ("fp32",),
+                                         gru=args.gru)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline()
+            res["cpu_baseline"] = cpu_baseline(args.cpu_baseline_full)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

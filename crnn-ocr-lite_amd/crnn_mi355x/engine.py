@@ -24,6 +24,15 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class StagedBatch:
+    """One training batch on its way to the device (Engine.stage): page-locked host buffers -> device buffers on the engine's copy
+    stream; `ready` is recorded behind the copies, the compute stream waits for it when the batch is used."""
+    __slots__ = ("x", "labels", "input_length", "label_length", "ready", "slot", "n")
+
+    def __len__(self):
+        return self.n
+
+
 class Engine:
     def __init__(self, batch, imgh=100, imgw=32, num_classes=38, max_len=23, time_dense_size=128, n_units=256,
                  gru=False, stn=True, dropout=True, device=None, precision="fp32", share=None, flags=None):
@@ -79,7 +88,8 @@ class Engine:
         # launch ever resets that word
         self.ws = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=dev)
         self._rnn_giveups = None          # 1-element int32 view of that counter (None: this configuration runs the per-step kernels)
-        self._rnn_giveups_seen = 0
+        self._rnn_giveups_seen = 0        # baseline of this rank's counter
+        self._rnn_giveups_seen_sum = 0    # baseline of the counter summed over data-parallel ranks (surface.fit_generator)
         off, cnt = ctypes.c_long(), ctypes.c_long()
         if self.lib.crnn_ws_tensor(self._c, b"rnnx", ctypes.byref(off), ctypes.byref(cnt)) == 0:
             self._rnn_giveups = self.ws[off.value:off.value + 1].view(torch.int32)
@@ -96,6 +106,91 @@ class Engine:
         # so also opt-in: CRNN_CONV_OVERLAP=1; bit-identical either way
         self.overlap_conv_wgrad = os.environ.get("CRNN_CONV_OVERLAP", "0") == "1"
         self._aux_stream = None
+        self._warn_schedule_fallbacks()
+        self._stage = None                # page-locked staging slots of stage() (built on first use)
+        self._stage_next = 0
+
+    _warned_shapes = set()
+
+    def _warn_schedule_fallbacks(self):
+        """The row-stream depthwise kernels (csrc/dwconv_stream.hip, dwconv_bwd_stream.hip) take maps whose rows (W * C * 2 bytes, or a
+        whole number of row bands) fill their 9 KiB step row -- every block at image width 32.  Other widths run the halo-tile kernels
+        at roughly half the depthwise rate: correct, but worth knowing about, so say it once per shape instead of silently."""
+        if self.precision != "bf16s" or (self.cfg.flags & native.FLAG_DW_TILE_KERNEL):
+            return
+        key = (self.cfg.imgh, self.cfg.imgw)
+        if key in Engine._warned_shapes:
+            return
+        h, w, cin = self.cfg.imgh + 4, self.cfg.imgw + 4, 1
+        slow = []
+        for i, (co, ph, pw) in enumerate(((64, 1, 1), (128, 1, 1), (256, 2, 2), (256, 1, 1), (512, 1, 2), (512, 1, 1), (512, 1, 1)), 1):
+            if i >= 2 and (self.lib.crnn_dwconv_fwd_stream_supported(self.B, h, w, cin) != 0 or self.lib.crnn_dwconv_bwd_stream_supported(self.B, h, w, cin) != 0):
+                slow.append("block %d (%dx%dx%d)" % (i, h, w, cin))
+            h, w, cin = h // ph, w // pw, co
+        if slow:
+            import warnings
+            Engine._warned_shapes.add(key)
+            warnings.warn("crnn_mi355x: image width %d: the row-stream depthwise kernels do not take %s (their step row is sized for width 32); "
+                          "these blocks run the halo-tile kernels at about half the depthwise rate" % (self.cfg.imgw, ", ".join(slow)), RuntimeWarning, stacklevel=3)
+
+    # ---- host -> device staging --------------------------------------------------------------------------
+    _STAGE_SLOTS = 2
+
+    def _stage_slots(self):
+        if self._stage is None:
+            B, c = self.B, self.cfg
+            slots = []
+            for _ in range(self._STAGE_SLOTS):
+                s = {"hx": torch.empty(B * c.imgh * c.imgw, dtype=torch.float32).pin_memory(),
+                     "hi": torch.empty(B * (c.max_len + 2), dtype=torch.int32).pin_memory(),
+                     "dx": torch.empty(B * c.imgh * c.imgw, dtype=torch.float32, device=self.device),
+                     "di": torch.empty(B * (c.max_len + 2), dtype=torch.int32, device=self.device),
+                     "copied": torch.cuda.Event(), "free": torch.cuda.Event()}
+                s["hx_np"], s["hi_np"] = s["hx"].numpy(), s["hi"].numpy()
+                slots.append(s)
+            self._stage = slots
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        return self._stage
+
+    def stage(self, x, labels, input_length, label_length):
+        """Host batch (Readf's NumPy arrays: float64 images, int64 labels / lengths) -> StagedBatch.  The images are converted to
+        fp32 straight into a page-locked buffer (one pass: the snapshot the generator contract asks for -- Readf keeps writing into the
+        arrays it yielded, utils.py:468,495-511 -- and the cast in one), labels and lengths into a second one, and both are copied to
+        the device asynchronously on a copy stream: staging batch k+1 while step k runs hides the PCIe transfer (train.py:201-209:
+        fit_generator over a host generator).  Two slots: a slot is rewritten only after the step that used it has finished."""
+        slots = self._stage_slots()
+        k = self._stage_next
+        self._stage_next = (k + 1) % len(slots)
+        s = slots[k]
+        B, c = self.B, self.cfg
+        xa = np.asarray(x)
+        if xa.size != s["hx_np"].size:
+            raise ValueError("batch shape mismatch: the_input has %d elements, the engine expects %d x %d x %d" % (xa.size, B, c.imgh, c.imgw))
+        s["copied"].synchronize()                      # the previous H->D copy out of this slot's host buffers is done
+        with np.errstate(over="ignore", invalid="ignore"):
+            np.copyto(s["hx_np"], xa.reshape(-1), casting="unsafe")
+        if not np.isfinite(s["hx_np"]).all():         # undefined rows of Readf's short tail batch (see _as_input)
+            s["hx_np"][~np.isfinite(s["hx_np"])] = 0.0
+        self._check_ctc_inputs(labels, input_length, label_length)
+        L = c.max_len
+        hi = s["hi_np"]
+        np.copyto(hi[:B * L], np.asarray(labels).reshape(-1), casting="unsafe")
+        np.copyto(hi[B * L:B * L + B], np.asarray(input_length).reshape(-1), casting="unsafe")
+        np.copyto(hi[B * L + B:], np.asarray(label_length).reshape(-1), casting="unsafe")
+        cs = self._copy_stream
+        cs.wait_event(s["free"])                      # the step that last read this slot's device buffers has finished
+        with torch.cuda.stream(cs):
+            s["dx"].copy_(s["hx"], non_blocking=True)
+            s["di"].copy_(s["hi"], non_blocking=True)
+            s["copied"].record(cs)
+        sb = StagedBatch()
+        sb.x, sb.ready, sb.slot, sb.n = s["dx"], s["copied"], s, B
+        sb.labels, sb.input_length, sb.label_length = s["di"][:B * L], s["di"][B * L:B * L + B], s["di"][B * L + B:]
+        return sb
+
+    def _release(self, sb):
+        """The compute stream has been handed every kernel that reads the staged batch: its slot may be rewritten after them."""
+        sb.slot["free"].record(torch.cuda.current_stream())
 
     # ---- parameters -------------------------------------------------------------------------------------
     def set_params(self, p, bn=None):
@@ -139,6 +234,9 @@ class Engine:
 
     # ---- hot path -----------------------------------------------------------------------------------------
     def _as_input(self, x):
+        if isinstance(x, StagedBatch):
+            torch.cuda.current_stream().wait_event(x.ready)
+            return x.x
         if not torch.is_tensor(x):
             # Readf's batches start as np.empty (utils.py:448) and the short tail batch of a pass is yielded with
             # whatever those unused rows contain: rows that are not finite in fp32 are zeroed instead of poisoning
@@ -167,6 +265,14 @@ class Engine:
         return a.to(self.device, dtype=torch.int32).contiguous()
 
     def _ctc_inputs(self, labels, input_length, label_length):
+        if isinstance(labels, StagedBatch):           # validated on the host by stage(); already on the device
+            torch.cuda.current_stream().wait_event(labels.ready)
+            self._lab, self._il, self._ll = labels.labels, labels.input_length, labels.label_length
+            return
+        self._check_ctc_inputs(labels, input_length, label_length)
+        self._lab = self._as_i32(labels); self._il = self._as_i32(input_length); self._ll = self._as_i32(label_length)
+
+    def _check_ctc_inputs(self, labels, input_length, label_length):
         """Host-side validation of the CTC inputs (the kernel indexes LDS with the label ids): labels (B, max_len) with
         0 <= id < num_classes, 0 <= label_length <= max_len, input_length <= T - 2.  Device tensors are trusted (checking
         them would force a synchronisation in the hot loop); NumPy batches from Readf are checked."""
@@ -184,7 +290,6 @@ class Engine:
             il = np.asarray(input_length)
             if il.size != self.B or (il.size and (il.min() < 0 or il.max() > self.T - 2)):
                 raise ValueError("input_length must be (batch,) with values in [0, T-2=%d]" % (self.T - 2))
-        self._lab = self._as_i32(labels); self._il = self._as_i32(input_length); self._ll = self._as_i32(label_length)
 
     def backward(self, labels, input_length, label_length, seed=0):
         """CTC + backward after forward(train=True).  Returns per-sample loss (device tensor, B)."""
@@ -245,8 +350,12 @@ class Engine:
                                      _ptr(self.norm), _stream()), "sgd")
 
     def train_step(self, x, labels, input_length, label_length, opt, iteration, seed=None, allreduce=None):
-        """forward(train) -> CTC -> backward -> [all-reduce] -> clip -> optimizer -> BN moving stats."""
+        """forward(train) -> CTC -> backward -> [all-reduce] -> clip -> optimizer -> BN moving stats.
+        x may be a StagedBatch (stage()): it then carries the labels and lengths too."""
         seed = iteration if seed is None else seed
+        staged = x if isinstance(x, StagedBatch) else None
+        if staged is not None:
+            labels = staged
         self.forward(x, train=True, seed=seed)
         if allreduce is not None and getattr(allreduce, "overlap", False):
             # the upper layers' gradients (tail of the flat buffer) are exchanged while the conv stack is still in backward
@@ -260,6 +369,8 @@ class Engine:
             loss = self.backward(labels, input_length, label_length, seed=seed)
             if allreduce is not None:
                 allreduce(self.grads)
+        if staged is not None:
+            self._release(staged)
         opt.apply(self, iteration)
         self.bn_update()
         return loss
@@ -271,14 +382,19 @@ class Engine:
         st = self._rnn_giveups.to(torch.float32) if self._rnn_giveups is not None else torch.zeros(1, device=self.device)
         return torch.cat([self.loss.mean().reshape(1), st])
 
-    def raise_if_rnn_gave_up(self, count):
+    def raise_if_rnn_gave_up(self, count, summed=False):
         """count: current value of the sticky give-up counter (from loss_and_status / check_rnn_status).  A persistent recurrence
         whose cluster was not co-resident (CUs held by another process / stream, a CU-masked device) stops waiting after a bounded
-        spin and free-runs on garbage; that must never pass silently."""
+        spin and free-runs on garbage; that must never pass silently.  summed: `count` is the SUM of the ranks' counters (data
+        parallel); it has its own baseline, so the rank-local checks of predict / test never see a value of the other kind."""
         count = int(count)
-        if count != self._rnn_giveups_seen:
-            new = count - self._rnn_giveups_seen
-            self._rnn_giveups_seen = count
+        seen = self._rnn_giveups_seen_sum if summed else self._rnn_giveups_seen
+        if count != seen:
+            new = count - seen
+            if summed:
+                self._rnn_giveups_seen_sum = count
+            else:
+                self._rnn_giveups_seen = count
             raise native.CrnnError("persistent LSTM/GRU recurrence gave up waiting for its workgroup cluster %d time(s): the launch was not "
                                    "co-resident on the GPU, so the results of this step (and weights updated from it) are invalid.  Free the GPU "
                                    "of other work, or run the per-step recurrence kernels: Engine(flags=native.FLAG_RNN_STEP_KERNELS) / "

@@ -14,6 +14,8 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 HEADER = os.path.join(REPO_ROOT, "include", "crnn_mi355x.h")
 CSRC = os.path.join(PKG_ROOT, "csrc")
 LIB_PATH = os.path.join(PKG_ROOT, "libcrnn_mi355x.so")
+HOOKS_HEADER = os.path.join(REPO_ROOT, "include", "crnn_testhooks.h")
+HOOKS_PATH = os.path.join(PKG_ROOT, "libcrnn_testhooks.so")     # measurement / test hooks: never loaded by the product path
 SOURCES = ["gemm.hip", "gemm_nt.hip", "gemm_wres.hip", "gemm_wgrad.hip", "conv.hip", "conv_bwd_fused.hip", "dwconv_stream.hip", "dwconv_bwd_stream.hip", "stn.hip", "rnn.hip", "rnn_persist.hip", "gru_persist.hip", "ctc.hip", "beam.hip", "optim.hip", "model.hip"]
 
 
@@ -84,6 +86,13 @@ def build(verbose=False):
             list(ex.map(run, jobs))
     if not os.path.exists(LIB_PATH) or any(os.path.getmtime(o) > os.path.getmtime(LIB_PATH) for o in objs):
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH])
+    hsrc = os.path.join(CSRC, "testhooks.hip")
+    hdeps = [hsrc, os.path.join(CSRC, "common.h"), HEADER, HOOKS_HEADER]
+    if not os.path.exists(HOOKS_PATH) or any(os.path.getmtime(d) > os.path.getmtime(HOOKS_PATH) for d in hdeps):
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", inc, hsrc, "-o", HOOKS_PATH]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     return LIB_PATH
 
 
@@ -108,6 +117,25 @@ def lib():
             fn.restype, fn.argtypes = ret, args
         _LIB = L
     return _LIB
+
+
+_HOOKS = None
+
+
+def hooks():
+    """libcrnn_testhooks.so (include/crnn_testhooks.h): crnn_debug_copy / crnn_debug_occupy for bench.py's copy reference, scripts/ and
+    tests/.  Separate from the product library on purpose; nothing under crnn_mi355x/ calls this."""
+    global _HOOKS
+    if _HOOKS is None:
+        if not os.path.exists(HOOKS_PATH):
+            raise RuntimeError("libcrnn_testhooks.so not built (%s); run `python __graft_entry__.py`" % HOOKS_PATH)
+        import torch  # noqa: F401  (same HIP runtime as PyTorch, see lib())
+        L = ctypes.CDLL(HOOKS_PATH)
+        for name, (ret, args) in parse_header(HOOKS_HEADER).items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = ret, args
+        _HOOKS = L
+    return _HOOKS
 
 
 class CrnnError(RuntimeError):

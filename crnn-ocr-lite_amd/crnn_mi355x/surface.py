@@ -160,6 +160,7 @@ class Model:
             if eng is None:
                 eng = self._engine(batch or 1)
             broadcast_state(eng, dist, world)
+            self._state["replicas_synced"] = True
 
     def _pull(self):
         """device -> host copies of weights and BN statistics."""
@@ -172,6 +173,7 @@ class Model:
         eng = self._state["engine"]
         if eng is not None:
             eng.set_params(self._state["params"], self._state["bn"])     # rank-local (see sync_replicas)
+        self._state["replicas_synced"] = False       # the next data-parallel train step (or fit_generator) re-broadcasts rank 0's
 
     # ---- Keras weight list (SURVEY A.9 order, 94 tensors for either cell) ---------------------------------------
     def _weight_index(self):
@@ -367,11 +369,15 @@ class Model:
             eng.opt_state.clear()            # a new optimizer starts from zero moments (shared dict: cleared for every engine)
 
     def _snapshot(self, batch):
-        """Readf re-yields the SAME arrays it keeps filling (utils.py:468,495-511): copy what a step needs before the
-        generator is advanced again."""
+        """Readf re-yields the SAME arrays it keeps filling (utils.py:468,495-511): what a step needs is taken out of them before
+        the generator is advanced again.  Host (NumPy) batches go straight into the engine's page-locked staging buffers and on to
+        the device on a copy stream (Engine.stage: the snapshot, the float64 -> float32 conversion and the H->D transfer of batch
+        k+1 all happen while step k runs); anything else (device tensors) is copied as before.  -> StagedBatch | (x, lab, il, ll)"""
         x, lab, il, ll = self._unpack(batch)
-        cp = lambda a: None if a is None else np.array(a, copy=True)
-        return np.asarray(x, dtype=np.float32).copy(), cp(lab), cp(il), cp(ll)
+        if lab is not None and il is not None and ll is not None and not any(hasattr(a, "is_cuda") for a in (x, lab, il, ll)):
+            return self._engine(len(x)).stage(x, lab, il, ll)
+        cp = lambda a: None if a is None else (a.clone() if hasattr(a, "is_cuda") else np.array(a, copy=True))
+        return (x.clone() if hasattr(x, "is_cuda") else np.asarray(x, dtype=np.float32).copy()), cp(lab), cp(il), cp(ll)
 
     @staticmethod
     def _unpack(batch):
@@ -389,8 +395,9 @@ class Model:
             pass
         return None, 1
 
-    def _train_on_batch_async(self, x, labels, input_length, label_length):
-        """Enqueue one train step; returns the batch-mean loss as a DEVICE scalar (no host synchronisation)."""
+    def _train_on_batch_async(self, x, labels=None, input_length=None, label_length=None):
+        """Enqueue one train step; returns the batch-mean loss as a DEVICE scalar (no host synchronisation).
+        x: the images, or a StagedBatch (then it carries labels and lengths)."""
         if self.optimizer is None:
             raise RuntimeError("compile(optimizer=...) first")
         eng = self._engine(len(x))
@@ -398,16 +405,26 @@ class Model:
         allreduce = None
         if world > 1:
             from .parallel import GradAllReduce
+            if not self._state.get("replicas_synced"):
+                # data parallel: a train step is a collective anyway (gradient all-reduce), so the first one after construction /
+                # set_weights / load_weights also makes every rank adopt rank 0's weights -- a loop driven by train_on_batch must not
+                # run on per-rank random initial weights with averaged gradients (the replicas would drift apart silently)
+                self.sync_replicas(len(x))
             allreduce = GradAllReduce(eng, dist, world)
         eng.train_step(x, labels, input_length, label_length, self.optimizer, self._iterations, allreduce=allreduce)
         self._iterations += 1
         return eng.loss_and_status(), eng       # [batch-mean loss, give-up counter of the persistent recurrences]
 
     @staticmethod
-    def _read_loss(ls_dev, eng):
-        """The one host synchronisation of a step: loss and recurrence status in one D2H copy; raises if a recurrence gave up."""
+    def _batch_len(b):
+        return len(b[0]) if isinstance(b, tuple) else len(b)
+
+    @staticmethod
+    def _read_loss(ls_dev, eng, summed=False):
+        """The one host synchronisation of a step: loss and recurrence status in one D2H copy; raises if a recurrence gave up.
+        summed: the counter was all-reduced (SUM) over the data-parallel ranks -- compared against its own baseline."""
         loss, giveups = ls_dev.tolist()
-        eng.raise_if_rnn_gave_up(giveups)
+        eng.raise_if_rnn_gave_up(giveups, summed=summed)
         return float(loss)
 
     def train_on_batch(self, x, labels, input_length, label_length):
@@ -446,7 +463,7 @@ class Model:
             # the documented collective point: replicas start from rank 0's weights (engine for the first batch's size built here)
             if self._prefetched is None or self._prefetched[0] is not generator:
                 self._prefetched = (generator, self._snapshot(next(generator)))
-            self.sync_replicas(len(self._prefetched[1][0]))
+            self.sync_replicas(self._batch_len(self._prefetched[1]))
         for epoch in range(epochs):
             t0 = time.time()
             run, nimg = 0.0, 0
@@ -455,18 +472,19 @@ class Model:
                 # while the GPU works, and only then is the loss read back (the one host sync per step Keras has too)
                 if self._prefetched is None or self._prefetched[0] is not generator:   # a batch drawn ahead belongs to ITS generator
                     self._prefetched = (generator, self._snapshot(next(generator)))
-                x, lab, il, ll = self._prefetched[1]
-                ls_dev, eng = self._train_on_batch_async(x, lab, il, ll)
+                cur = self._prefetched[1]
+                nb = self._batch_len(cur)
+                ls_dev, eng = self._train_on_batch_async(*((cur,) if not isinstance(cur, tuple) else cur))
                 self._prefetched = (generator, self._snapshot(next(generator)))
                 if world > 1:
                     # every rank logs (and EarlyStoppingIter monitors) the GLOBAL batch-mean loss, so all ranks take the same
                     # stop / restore decisions and keep issuing the same collectives; the give-up counters are summed, so a
-                    # recurrence that gave up on one rank stops every rank
+                    # recurrence that gave up on one rank stops every rank (the rank-local counter keeps its own baseline)
                     dist.all_reduce(ls_dev, op=dist.ReduceOp.SUM)
                     ls_dev[0] /= world
-                loss = self._read_loss(ls_dev, eng)
-                run += loss; nimg += len(x)
-                logs = {"loss": loss, "batch": step, "size": len(x)}
+                loss = self._read_loss(ls_dev, eng, summed=world > 1)
+                run += loss; nimg += nb
+                logs = {"loss": loss, "batch": step, "size": nb}
                 for cb in callbacks:
                     cb.on_batch_end(step, logs)
                 if verbose and (step + 1 == steps_per_epoch or (step + 1) % max(1, steps_per_epoch // 20) == 0):
@@ -642,7 +660,54 @@ def get_initial_weights(output_size):
     return [np.zeros((output_size, 6), dtype='float32'), b.flatten()]
 
 
-def STN(image, sampling_size=(100, 32)):
-    """utils.py:247-258 builds the localisation net + sampler as Keras layers; in this build the spatial
-    transformer is part of the fused model (csrc/stn.hip + model.hip) and cannot be instantiated stand-alone."""
-    raise NotImplementedError("STN is built into CRNN(...).get_model(); use BilinearInterpolation for the sampler alone")
+def STN(image, sampling_size=(100, 32), weights=None):
+    """utils.py:247-258 on arrays: MaxPool(2,2) -> Conv2D(20,5x5) -> MaxPool(2,2) -> Conv2D(20,5x5) -> Flatten -> Dense(50) ->
+    relu -> Dense(6, weights=get_initial_weights(50)) -> BilinearInterpolation(sampling_size), each stage a HIP kernel of the
+    fused model's spatial transformer (csrc/stn.hip) called through the C ABI.
+    image (B,H,W,1) ndarray -> (B,H,W,1) float32.  weights: the 8 arrays of the localisation net in Keras order
+    [conv2d_1 kernel (5,5,1,20), bias, conv2d_2 kernel (5,5,20,20), bias, dense_1 kernel (F,50), bias, dense_2 kernel (50,6), bias];
+    None = what the reference's freshly built layers hold: glorot-uniform convs / dense_1, zero biases and the identity transform
+    in dense_2 (get_initial_weights) -- with dense_2's kernel all zero theta is the identity whatever the other layers hold."""
+    import torch
+    from .engine import _ptr, _stream
+    X = np.ascontiguousarray(np.asarray(image, dtype=np.float32))
+    if X.ndim != 4 or X.shape[3] != 1:
+        raise ValueError("STN expects (B, H, W, 1) images, got %r" % (X.shape,))
+    B, H, W, _ = X.shape
+    if tuple(sampling_size) != (H, W):
+        raise native.CrnnError("the HIP sampler handles output_size == input size (the reference always calls STN(inputs, shape[:2]))")
+    Hs1, Ws1 = H // 2, W // 2
+    Ho1, Wo1 = Hs1 - 4, Ws1 - 4
+    Hs2, Ws2 = Ho1 // 2, Wo1 // 2
+    Ho2, Wo2 = Hs2 - 4, Ws2 - 4
+    if Ho2 < 1 or Wo2 < 1:
+        raise ValueError("image too small for the localisation net (two 2x2 pools and two 5x5 valid convs)")
+    F = Ho2 * Wo2 * 20
+    if weights is None:
+        rs = np.random.RandomState()
+        glorot = lambda shape, fi, fo: rs.uniform(-np.sqrt(6.0 / (fi + fo)), np.sqrt(6.0 / (fi + fo)), shape).astype(np.float32)
+        weights = [glorot((5, 5, 1, 20), 25, 500), np.zeros(20, np.float32), glorot((5, 5, 20, 20), 500, 500), np.zeros(20, np.float32),
+                   glorot((F, 50), F, 50), np.zeros(50, np.float32)] + get_initial_weights(50)
+    shapes = [(5, 5, 1, 20), (20,), (5, 5, 20, 20), (20,), (F, 50), (50,), (50, 6), (6,)]
+    if len(weights) != 8:
+        raise ValueError("expected the 8 weight arrays of the localisation net, got %d" % len(weights))
+    dev = []
+    for w, shp in zip(weights, shapes):
+        w = np.asarray(w, dtype=np.float32)
+        if w.shape != shp:
+            raise ValueError("localisation-net weight of shape %r, expected %r" % (w.shape, shp))
+        dev.append(torch.from_numpy(np.ascontiguousarray(w)).cuda())
+    k1, b1, k2, b2, w1, c1b, w2, c2b = dev
+    L = native.lib()
+    f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device="cuda")
+    xd = torch.from_numpy(X).cuda()
+    pool1, c1, pool2, flat = f32(B, Hs1, Ws1), f32(B, Ho1, Wo1, 20), f32(B, Hs2, Ws2, 20), f32(B, F)
+    fc1, theta, out = f32(B, 50), f32(B, 6), f32(B, H, W)
+    st = _stream()
+    native.check(L.crnn_maxpool_fwd(_ptr(xd), _ptr(pool1), B, H, W, 1, 2, 2, st), "maxpool")
+    native.check(L.crnn_loc_conv_fwd(_ptr(pool1), _ptr(k1), _ptr(b1), _ptr(c1), B, Hs1, Ws1, 1, st), "loc_conv 1")
+    native.check(L.crnn_maxpool_fwd(_ptr(c1), _ptr(pool2), B, Ho1, Wo1, 20, 2, 2, st), "maxpool")
+    native.check(L.crnn_loc_conv_fwd(_ptr(pool2), _ptr(k2), _ptr(b2), _ptr(flat), B, Hs2, Ws2, 20, st), "loc_conv 2")
+    native.check(L.crnn_loc_fc_fwd(_ptr(flat), _ptr(w1), _ptr(c1b), _ptr(w2), _ptr(c2b), _ptr(fc1), _ptr(theta), B, F, st), "loc_fc")
+    native.check(L.crnn_sampler_fwd(_ptr(xd), _ptr(theta), _ptr(out), B, H, W, 0, st), "sampler")
+    return out.cpu().numpy()[..., None]

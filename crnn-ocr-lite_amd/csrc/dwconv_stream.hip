@@ -298,32 +298,3 @@ extern "C" int crnn_dwconv3x3_fwd_stream(const void* x, const float* k, void* ou
                                          int C, int flip, hipStream_t stream) {
   return crnn_dwconv3x3_fwd_stream_ex(x, k, out, stat_partials, bnstate, B, H, W, C, flip, 0, stream);
 }
-
-// ---- measurement reference (bench.py depthwise_roofline "copy_reference"): what a plain copy of the same bytes achieves -----------------
-// pattern 0: grid-stride, the resident workgroups sweep ONE window of the buffer together (16 KiB per workgroup and iteration);
-// pattern 1: workgroup b copies its own contiguous 1/gridDim.x of the buffer front to back -- the access pattern of the row-stream kernels
-//            (one image band per workgroup: reads and writes at gridDim.x places far apart).
-namespace {
-template <int BANDED>
-__global__ __launch_bounds__(256) void debug_copy_kernel(const u32x4* __restrict__ s, u32x4* __restrict__ d, long n) {
-  long lo, hi, stride;
-  if (BANDED) { const long per = (n + gridDim.x - 1) / gridDim.x; lo = blockIdx.x * per; hi = lo + per < n ? lo + per : n; stride = 1024; }
-  else { lo = (long)blockIdx.x * 1024; hi = n; stride = (long)gridDim.x * 1024; }
-  for (long i = lo + threadIdx.x; i < hi; i += stride) {
-    u32x4 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) if (i + u * 256 < hi) v[u] = s[i + u * 256];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) if (i + u * 256 < hi) d[i + u * 256] = v[u];
-  }
-}
-}  // namespace
-extern "C" int crnn_debug_copy(const void* src, void* dst, size_t bytes, int pattern, int workgroups, hipStream_t stream) {
-  if (!src || !dst || (bytes & 15) || ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) || workgroups < 1 || pattern < 0 || pattern > 1) return CRNN_ERR_ARG;
-  const long n = (long)(bytes / 16);
-  if (n == 0) return CRNN_OK;
-  if (pattern) hipLaunchKernelGGL(debug_copy_kernel<1>, dim3(workgroups), dim3(256), 0, stream, (const u32x4*)src, (u32x4*)dst, n);
-  else hipLaunchKernelGGL(debug_copy_kernel<0>, dim3(workgroups), dim3(256), 0, stream, (const u32x4*)src, (u32x4*)dst, n);
-  CRNN_LAUNCH_CHECK();
-  return CRNN_OK;
-}

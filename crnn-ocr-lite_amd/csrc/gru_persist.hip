@@ -303,7 +303,7 @@ constexpr size_t gru_lds_bwd(int U, int UW, int ES) { return (size_t)16 * (2 * U
 template <bool WBF, int U, int UW>
 int gru_launch_fwd(const GruFwdDir& a, const GruFwdDir& b, int T, int B, void* xbuf, size_t xbuf_bytes, int xreq, hipStream_t stream) {
   constexpr int ES = WBF ? 2 : 4, NSW = U / (16 * UW);
-  const Chunking ck = chunking(T, B, U, 1, UW, ES, gru_lds_fwd(U, UW, ES), U);
+  const Chunking ck = chunking(T, B, U, 1, UW, ES, gru_lds_fwd(U, UW, ES), U, (const void*)gru_fwd_persist_kernel<WBF, U, UW>);
   for (int lo = 0; lo < B; lo += ck.rows_per_launch) {
     const int cnt = (B - lo < ck.rows_per_launch) ? B - lo : ck.rows_per_launch;
     CRNN_TRY(prep_xbuf(xbuf, xbuf_bytes, ck.xdata_bytes, stream));     // every slot is written per launch: poison first
@@ -316,7 +316,7 @@ int gru_launch_fwd(const GruFwdDir& a, const GruFwdDir& b, int T, int B, void* x
 template <bool WBF, int U, int UW>
 int gru_launch_bwd(const GruBwdDir& a, const GruBwdDir& b, int T, int B, void* xbuf, size_t xbuf_bytes, int xreq, hipStream_t stream) {
   constexpr int ES = WBF ? 2 : 4, NSW = U / (16 * UW);
-  const Chunking ck = chunking(T, B, U, 1, UW, ES, gru_lds_bwd(U, UW, ES), 2 * U);
+  const Chunking ck = chunking(T, B, U, 1, UW, ES, gru_lds_bwd(U, UW, ES), 2 * U, (const void*)gru_bwd_persist_kernel<WBF, U, UW>);
   for (int lo = 0; lo < B; lo += ck.rows_per_launch) {
     const int cnt = (B - lo < ck.rows_per_launch) ? B - lo : ck.rows_per_launch;
     CRNN_TRY(prep_xbuf(xbuf, xbuf_bytes, ck.xdata_bytes, stream));

@@ -258,6 +258,12 @@ bool fuse_dw_bn(const crnn_config* cfg, int dtd, int dtq, int ci) {
 bool fuse_dw_bn_x3(const crnn_config* cfg, int dtd, int dtq, int ci) {
   return !(cfg->flags & CRNN_FLAG_NO_DW_BN_FUSION) && pw_products(cfg) == 2 && dtd == CRNN_F32 && dtq == CRNN_F32 && ci % 4 == 0 && ci >= 16 && ci <= 512;
 }
+// The fused entry points taken on that decision have no fallback once the activated tensor was skipped: every pointer they are handed must
+// satisfy their 16-byte rule up front (workspace tensors are 256-byte aligned by make_plan; the caller's parameter / gradient / workspace
+// base pointers are what can break it)
+bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
+  return ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d)) & 15) == 0;
+}
 // always-fp32 GEMM (spatial-transformer localisation net: tiny, and theta is precision-sensitive)
 int gemm32(const Ctx& c, int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
            const float* bias = nullptr, int act = 0, int acc = 0, int perm = 0) {
@@ -439,6 +445,7 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
       // (2,2) window the depthwise kernel writes its rows in window-major order -- the un-pooled map q never exists
       int pool_rows = 1;
       if (ph * pw > 1 && cfg->mfma_bf16 && pwT_off[i] >= 0 && dtd == CRNN_BF16 && dtq == CRNN_BF16 && c.dt("x" + p) == CRNN_BF16 &&
+          aligned16(aa, xo, s2, c.w("pwT")) &&
           !(cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS) && crnn_pwconv_fwd_wres_folded_pool_supported(M, co, ci, ph * pw) == CRNN_OK &&
           ((ph == 1 && pw == 2 && W % 2 == 0) || (ph == 2 && pw == 2 && dws && H % 2 == 0 && W % 2 == 0)))
         pool_rows = ph * pw;
@@ -488,7 +495,7 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
     }
     bn_off += ci;
     const bool fuse_a = fuse_dw_bn(cfg, dtd, dtq, ci);                  // BN + ReLU6 applied while the GEMM stages its operand
-    const bool fuse_x3 = fuse_dw_bn_x3(cfg, dtd, dtq, ci);              // ... by the staging waves of the parity mode's three-plane kernel
+    const bool fuse_x3 = fuse_dw_bn_x3(cfg, dtd, dtq, ci) && aligned16(dd, qq, s1, c.p(bp + "_pw"));   // ... by the staging waves of the parity mode's three-plane kernel
     if (!fuse_a && !fuse_x3) CRNN_TRY(crnn_bn_act_pool_drop_ex(dd, s1, aa, 1, 1, (int)M, ci, 1, 1, 0.f, 0, 0, dtd, dtd, stream));
     int stat_rows = crnn_pwconv_stat_rows(M);
     {  // pointwise conv; its epilogue also produces the batch statistics of the BatchNorm that follows
@@ -865,7 +872,7 @@ int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t au
           rc = crnn_pwconv_bnrelu6_wgrad(c.w("d" + p), c.w("bn1s" + p), gB, c.g(bp + "_pw"), M, co, ci, cw.scratch(), kGemmScratchBytes, cw.s);
         CRNN_TRY(rc);
       }
-      else if (fuse_dw_bn_x3(cfg, dtd, dtq, ci))   // parity mode: likewise, in the three-plane kernel's staging waves
+      else if (fuse_dw_bn_x3(cfg, dtd, dtq, ci) && aligned16(c.w("d" + p), c.w("q" + p), c.w("bn1s" + p), c.p(bp + "_pw")))   // parity mode: likewise (the forward's own predicate)
         CRNN_TRY(crnn_pwconv_bnrelu6_wgrad_f32x3(c.w("d" + p), c.w("bn1s" + p), gB, c.g(bp + "_pw"), M, co, ci, cw.scratch(), kGemmScratchBytes, cw.s));
       else CRNN_TRY(gemm_t(cw, 2, c.w("a" + p), dtd, gB, dtq, c.g(bp + "_pw"), CRNN_F32, ci, co, (int)M, ci, co, co));
       if (side) CRNN_TRY(fj.mark(&gB_free));

@@ -140,20 +140,26 @@ __device__ __forceinline__ bool cluster_shares_xcd(unsigned char* xbuf, int cl, 
   return verdict > 0;
 }
 
-// Workgroups that are certainly co-resident on the device: per CU as many as the LDS footprint and the thread count
-// (2048 threads, and the registers of two 256-thread workgroups / one 1024-thread workgroup) admit, at most 2.
-inline int resident_cap(size_t lds_bytes, int threads) {
+// Workgroups that are certainly co-resident on the device: per CU as many as the LDS footprint and the thread count admit, at most
+// 2 -- and no more than the runtime's occupancy figure for THIS kernel (`fn`), which also knows its register allocation: two
+// 512-thread workgroups share a CU only below 128 VGPRs, and several instantiations (wide fp32 tiles) need more.  A grid sized past
+// what is resident would stall every cluster wait for its 2 s bound.
+inline int resident_cap(size_t lds_bytes, int threads, const void* fn) {
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
   int per_cu = (lds_bytes * 2 <= 160 * 1024) ? 2 : 1;
   if (threads * per_cu > 1024) per_cu = 1;
+  if (fn && per_cu > 1) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, 0) == hipSuccess && nb >= 1 && nb < per_cu) per_cu = nb;
+  }
   return cus * per_cu;
 }
 // rows of the batch one launch covers, and the exchange bytes that launch needs
 struct Chunking { int rows_per_launch; size_t xdata_bytes; };
-inline Chunking chunking(int T, int B, int u, int mt, int uw, int es, size_t lds, int per_row) {
+inline Chunking chunking(int T, int B, int u, int mt, int uw, int es, size_t lds, int per_row, const void* fn) {
   const int NSW = u / (16 * uw), BT = 16 * mt;
-  int tiles = resident_cap(lds, 256 * uw) / (2 * NSW);
+  int tiles = resident_cap(lds, 256 * uw, fn) / (2 * NSW);
   if (tiles < 1) tiles = 1;
   Chunking c;
   c.rows_per_launch = tiles * BT;

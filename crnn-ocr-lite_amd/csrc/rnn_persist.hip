@@ -391,7 +391,7 @@ int launch_fwd_v(const FwdDir& a, const FwdDir& b, int T, int B, void* xbuf, siz
     return CRNN_ERR_UNSUPPORTED;
   } else {
     constexpr int ES = WBF ? 2 : 4, NSW = U / (16 * UW), BT = 16 * MT;
-    const Chunking ck = chunking(T, B, U, MT, UW, ES, lds_fwd(U, MT, UW, ES), U);
+    const Chunking ck = chunking(T, B, U, MT, UW, ES, lds_fwd(U, MT, UW, ES), U, (const void*)lstm_fwd_persist_kernel<WBF, MT, U, UW>);
     for (int lo = 0; lo < B; lo += ck.rows_per_launch) {
       const int cnt = (B - lo < ck.rows_per_launch) ? B - lo : ck.rows_per_launch;
       CRNN_TRY(prep_xbuf(xbuf, xbuf_bytes, ck.xdata_bytes, stream));     // every slot is written once per launch: poison first
@@ -409,7 +409,7 @@ int launch_bwd_v(const BwdDir& a, const BwdDir& b, int T, int B, void* xbuf, siz
     return CRNN_ERR_UNSUPPORTED;
   } else {
     constexpr int ES = WBF ? 2 : 4, NSW = U / (16 * UW), BT = 16 * MT;
-    const Chunking ck = chunking(T, B, U, MT, UW, ES, lds_bwd(U, MT, UW, ES), 4 * U);
+    const Chunking ck = chunking(T, B, U, MT, UW, ES, lds_bwd(U, MT, UW, ES), 4 * U, (const void*)lstm_bwd_persist_kernel<WBF, MT, U, UW>);
     for (int lo = 0; lo < B; lo += ck.rows_per_launch) {
       const int cnt = (B - lo < ck.rows_per_launch) ? B - lo : ck.rows_per_launch;
       CRNN_TRY(prep_xbuf(xbuf, xbuf_bytes, ck.xdata_bytes, stream));
@@ -443,10 +443,19 @@ int with_fallback(int B, int u, int mt_req, int uw_req, Try attempt) {
 }
 }  // namespace
 
+// Zero the sticky give-up counter at the head of an exchange buffer (once after allocation; see crnn_lstm_fwd_persist).
+extern "C" int crnn_rnn_status_reset(void* xbuf, hipStream_t stream) {
+  if (!xbuf || ((uintptr_t)xbuf & 15)) return CRNN_ERR_ARG;
+  hipError_t e = hipMemsetAsync(xbuf, 0, 4, stream);
+  return e == hipSuccess ? CRNN_OK : (int)e;
+}
+
 // Forward recurrence of one Bidirectional(LSTM) layer in ONE launch.  Arguments as crnn_lstm_fwd_ex; `xbuf` is
-// caller-owned scratch of crnn_lstm_persist_xbuf_bytes() bytes (16-byte aligned); the unsigned xbuf[0] is 0xFFFFFFFF
-// 16-byte aligned, its first 4 bytes zeroed once by the caller after allocation); the unsigned at byte 16 is 0xFFFFFFFF after a clean launch,
-// anything else means a bounded wait gave up (results invalid), and the unsigned at byte 0 counts give-ups since the caller zeroed it.
+// caller-owned scratch of crnn_lstm_persist_xbuf_bytes() bytes (16-byte aligned, its first 4 bytes zeroed ONCE by the caller after
+// allocation).  Status words: the unsigned at byte 0 is a sticky counter of give-ups since the caller zeroed it (no launch resets it);
+// the unsigned at byte 16 is the per-launch status, 0xFFFFFFFF after a clean launch, anything else means a bounded wait gave up
+// (results invalid).  crnn_rnn_status_reset(xbuf) zeroes the counter for callers that do not allocate with a zero fill (the earlier
+// contract filled xbuf[0] with 0xFFFFFFFF per launch: such a buffer must be reset once before it is used with this version).
 // mt: batch rows per workgroup / 16 (1 | 2), uw: 16-unit groups per workgroup (1 | 2 | 4); 0 = automatic.  uw_req | CRNN_RNN_XCD_LOCAL
 // (0x100) asks for the XCD-local workgroup -> cluster map (same results).
 extern "C" int crnn_lstm_fwd_persist(const float* xw0, const float* xw1, const void* ut0, const void* ut1, float* h0, float* h1,
@@ -491,26 +500,6 @@ extern "C" int crnn_lstm_bwd_persist(const void* u0, const void* u1, const float
     return DISPATCH_MT_UW(launch_bwd_v, false, 256, a, b, T, B, xbuf, xbuf_bytes, xreq, stream);
   });
   CRNN_TRY(rc);
-  CRNN_LAUNCH_CHECK();
-  return CRNN_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Test hook: workgroups that pin LDS and spin on the constant 100 MHz clock (bounded) -- tests/test_gpu_ops.py uses it to
-// take the CUs away from a persistent recurrence and asserts that the give-up is reported instead of silently wrong numbers.
-// ---------------------------------------------------------------------------------------------------------------
-namespace {
-__global__ __launch_bounds__(64) void occupy_kernel(unsigned long long ticks, int lds_bytes) {
-  extern __shared__ unsigned char pin[];
-  if (threadIdx.x == 0) pin[lds_bytes - 1] = 1;    // the allocation is what matters
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
-}
-}  // namespace
-extern "C" int crnn_debug_occupy(int blocks, int lds_bytes, long microseconds, hipStream_t stream) {
-  if (blocks < 1 || lds_bytes < 1 || lds_bytes > 160 * 1024 || microseconds < 0 || microseconds > 30L * 1000 * 1000) return CRNN_ERR_ARG;
-  CRNN_LDS_ATTR(occupy_kernel, 160 * 1024);
-  hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(64), lds_bytes, stream, (unsigned long long)microseconds * 100ull, lds_bytes);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }

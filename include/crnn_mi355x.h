@@ -83,13 +83,6 @@ int  crnn_ws_tensor(const crnn_config* cfg, const char* name, long* offset, long
 /* same + storage type of the tensor (0 = fp32, 1 = bf16; offset stays in floats, count in elements) */
 int  crnn_ws_tensor_info(const crnn_config* cfg, const char* name, long* offset, long* count, int* dtype);
 
-/* Test hook (tests/test_gpu_ops.py: the give-up path of the persistent recurrences): `blocks` workgroups of 64 threads that each pin
- * `lds_bytes` of LDS (<= 160 KiB: nothing else fits next to one on its CU) and spin for `microseconds` of the constant 100 MHz clock. */
-int crnn_debug_occupy(int blocks, int lds_bytes, long microseconds, crnn_stream_t stream);
-/* Measurement reference (bench.py "copy_reference"): dst[0..bytes) = src[0..bytes) (16-byte aligned, bytes % 16 == 0) by `workgroups` workgroups
- * of 256 threads.  pattern 0: grid-stride (the resident workgroups sweep one window together); pattern 1: workgroup b copies its own
- * contiguous 1/workgroups of the buffer -- the access pattern of the row-stream depthwise kernels (one image band per workgroup). */
-int crnn_debug_copy(const void* src, void* dst, size_t bytes, int pattern, int workgroups, crnn_stream_t stream);
 
 /* ---- whole-path drivers ------------------------------------------------------------------------------------- */
 /* Forward of the predictor sub-model (utils.py:308-312; Model.predict_generator, predict.py:166):
@@ -471,6 +464,8 @@ int crnn_pwconv_bnrelu6_fwd_wres(const void* d, const float* in_bnstate, const v
                                               member for good -- the others wait their 2 s, give up and report it (status word, sticky counter) */
 size_t crnn_lstm_persist_xbuf_bytes(int T, int B, int u, int dt_u);
 int crnn_lstm_persist_supported(int u, int dt_u);
+/* zero the sticky give-up counter at the head of an exchange buffer: once after allocation, for callers that do not zero-fill it */
+int crnn_rnn_status_reset(void* xbuf, crnn_stream_t stream);
 int crnn_lstm_fwd_persist(const float* xw0, const float* xw1, const void* ut0, const void* ut1, float* h0, float* h1, int ldh,
                           float* c0, float* c1, float* g0, float* g1, int T, int B, int u, int dt_u, void* xbuf, size_t xbuf_bytes,
                           int mt, int uw, crnn_stream_t stream);

@@ -28,7 +28,7 @@ side = torch.cuda.Stream()
 for blocks, lds, secs in ((cus - 2, 150 * 1024, 6), (cus, 150 * 1024, 3), (cus - 2, 100 * 1024, 6), (2 * cus, 64 * 1024, 6)):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    rc = L.crnn_debug_occupy(blocks, lds, secs * 1000 * 1000, ctypes.c_void_p(side.cuda_stream))
+    rc = native.hooks().crnn_debug_occupy(blocks, lds, secs * 1000 * 1000, ctypes.c_void_p(side.cuda_stream))
     time.sleep(0.3)
     a = torch.ones(4, device="cuda") + 1; a.cpu()                      # does anything run beside the spinners?
     t1 = time.perf_counter()

@@ -12,6 +12,8 @@ from crnn_mi355x.engine import Engine
 
 pytestmark = pytest.mark.gpu
 
+GRAD_TOL_PURE = 2e-3      # device gradient vs the pure fp64 oracle's under the device's gate decisions, relative to the tensor's maximum
+
 
 def masks_from_engine(eng, cfg, seed):
     """Fetch the dropout multipliers the device RNG applies and convert them to the oracle's keep-masks."""
@@ -131,6 +133,68 @@ def device_cache(eng, cfg, p, x, B, c_ref):
     return c
 
 
+def hybrid_cache(cfg, c, cdev, stn, masks=None):
+    """The PURE fp64 oracle cache with the device's value substituted wherever a discontinuous decision differs between the two
+    forwards: ReLU6 gates of a_i / r_i (0 < y < 6), the first-maximum position of every pooling window (whole window substituted),
+    dense1's and the localisation net's ReLU (y > 0), the hard-sigmoid gates of the recurrent cells (0 < a < 1).  The oracle's
+    backward on this cache takes the DEVICE's decisions everywhere but keeps the oracle's own values elsewhere: the device's
+    gradients must agree with it to the parity tolerance -- no flip noise left to hide a backward bug behind.
+    -> (cache, number of differing decisions, number of decisions)"""
+    h = dict(c)
+    flips, total = 0, 0
+
+    def gate(ref, dev, lo, hi, where=None):
+        nonlocal flips, total
+        ref = np.array(ref, dtype=np.float64, copy=True)
+        dev = np.asarray(dev, dtype=np.float64).reshape(ref.shape)
+        dref = (ref > lo) if hi is None else ((ref > lo) & (ref < hi))
+        ddev = (dev > lo) if hi is None else ((dev > lo) & (dev < hi))
+        diff = dref != ddev
+        if where is not None:
+            diff &= np.asarray(where).reshape(ref.shape) > 0
+        flips += int(diff.sum()); total += ref.size
+        ref[diff] = dev[diff]
+        return ref
+
+    def windows(ref, dev, ph, pw):
+        """substitute every pooling window whose first-maximum position differs"""
+        nonlocal flips, total
+        B, H, W, C = ref.shape
+        Ho, Wo = H // ph, W // pw
+        view = lambda a: a[:, :Ho * ph, :Wo * pw, :].reshape(B, Ho, ph, Wo, pw, C).transpose(0, 1, 3, 2, 4, 5).reshape(B, Ho, Wo, ph * pw, C)
+        rv, dv = view(ref).copy(), view(np.asarray(dev, dtype=np.float64).reshape(ref.shape))
+        diff = rv.argmax(axis=3) != dv.argmax(axis=3)
+        flips += int(diff.sum()); total += diff.size
+        sel = np.broadcast_to(diff[:, :, :, None, :], rv.shape)
+        rv[sel] = dv[sel]
+        out = np.array(ref, copy=True)
+        out[:, :Ho * ph, :Wo * pw, :] = rv.reshape(B, Ho, Wo, ph, pw, C).transpose(0, 1, 3, 2, 4, 5).reshape(B, Ho * ph, Wo * pw, C)
+        return out
+
+    for i, (cout, pool) in enumerate(M.BLOCKS, 1):
+        h[f"a{i}"] = gate(c[f"a{i}"], cdev[f"a{i}"], 0.0, 6.0)
+        r = gate(c[f"r{i}"], cdev[f"r{i}"], 0.0, 6.0)
+        if pool:
+            r = windows(r, cdev[f"r{i}"], *pool)
+        h[f"r{i}"] = r
+    # (the device keeps dense1 with its dropout applied: entries the mask drops carry no gradient and are not decisions)
+    h["dense1"] = gate(c["dense1"], cdev["dense1"], 0.0, None, where=(masks or {}).get("dense1"))
+    gi = 4 if cfg.gru else 5          # position of the activated gates in the cell cache tuple
+    for name in ("rnn1f", "rnn1b", "rnn2f", "rnn2b"):
+        t = list(c[name])
+        t[gi] = gate(t[gi], cdev[name][gi], 0.0, 1.0)
+        h[name] = tuple(t)
+    if stn:
+        h["fc1"] = gate(c["fc1"], cdev["fc1"], 0.0, None)
+        h["c1"] = windows(np.asarray(c["c1"], dtype=np.float64), cdev["c1"], 2, 2)
+    return h, flips, total
+
+
+class Case(tuple):
+    """run_case's 13 results + .hybrid = (gradients of the oracle's backward on hybrid_cache, differing decisions, decisions)"""
+    hybrid = None
+
+
 def run_case(B, imgh, imgw, u, tds, max_len, stn, dropout, seed=3, num_classes=38, gru=False, variable_width=False):
     cfg = M.Config(imgh=imgh, imgw=imgw, num_classes=num_classes, max_len=max_len, time_dense_size=tds, n_units=u, gru=gru)
     p, bn = M.init_params(cfg, seed=7, dtype=np.float64)
@@ -154,7 +218,13 @@ def run_case(B, imgh, imgw, u, tds, max_len, stn, dropout, seed=3, num_classes=3
     else:
         masks_dev = None
     gdev = M.backward(cfg, p, cdev, gy / B, masks=masks_dev, stn=stn)
-    return cfg, eng, p, bn, (x, lab, il, ll), yd, loss_d, gd, c, loss_b, g, rep, gdev
+    # ---- pure oracle values, the device's gate decisions (hybrid_cache): the pure-oracle gradient check without flip noise
+    ch, flips, decisions = hybrid_cache(cfg, c, cdev, stn, masks)
+    _, gy_ref = ctc.ctc_loss_and_grad(c["y_pred"], lab, il, ll)
+    ghyb = M.backward(cfg, p, ch, gy_ref / B, masks=masks, stn=stn)
+    res = Case((cfg, eng, p, bn, (x, lab, il, ll), yd, loss_d, gd, c, loss_b, g, rep, gdev))
+    res.hybrid = (ghyb, flips, decisions)
+    return res
 
 
 def check_case(res, tag):
@@ -176,24 +246,23 @@ def check_case(res, tag):
         if err > 1e-3 * scale + 1e-7:
             worst[k] = (err / scale)
     assert not worst, f"{tag}: gradient mismatch vs oracle-on-device-state {worst}"
-    # pure fp64 oracle: identical up to a handful of ReLU6-threshold flips (counted below); each flip moves some
-    # per-channel sums by percents, so only a coarse bound on the typical entry of the larger tensors is asserted
-    flips = 0
-    for i in range(1, 8):
-        for key, dev_name in ((f"a{i}", f"a{i}"),):
-            a_ref = c[key]
-            a_dev = eng.ws_tensor(dev_name).float().cpu().numpy().reshape(a_ref.shape)
-            flips += int((((a_ref > 0) & (a_ref < 6)) != ((a_dev > 0) & (a_dev < 6))).sum())
-    loose = {}
+    # pure fp64 oracle.  The two forwards take a handful of different discontinuous decisions (ReLU6 / ReLU / hard-sigmoid gates,
+    # pooling arg-maxima: activations within fp32 round-off of a threshold): their number is bounded, and with the device's decisions
+    # substituted into the oracle's own fp64 cache (hybrid_cache) every gradient must agree to the parity tolerance
+    ghyb, flips, decisions = res.hybrid
+    print(f"[{tag}] discontinuous decisions differing between the fp32 device forward and the fp64 oracle: {flips} of {decisions}")
+    assert flips <= 4 + 2e-5 * decisions, f"{tag}: {flips} of {decisions} gate / arg-max decisions differ from the oracle's"
+    off = {}
     for k in p:
-        if g[k].size < 256:
-            continue
-        scale = max(np.abs(g[k]).max(), 1e-6)
-        med = np.median(np.abs(gd[k] - g[k])) / scale
-        if med > 5e-2:
-            loose[k] = med
-    print(f"[{tag}] ReLU6 gate decisions differing between the fp32 device forward and the fp64 oracle: {flips}")
-    assert not loose, f"{tag}: gradients far from the pure oracle {loose}"
+        scale = max(np.abs(ghyb[k]).max(), 1e-6)
+        if "_bn" in k:
+            scale = max(scale, np.abs(ghyb[k[:-1] + "g"]).max(), np.abs(ghyb[k[:-1] + "b"]).max())
+        err = np.abs(gd[k] - ghyb[k]).max()
+        if err > GRAD_TOL_PURE * scale + 1e-7:
+            off[k] = err / scale
+    print(f"[{tag}] worst gradient error vs the pure oracle under the device's decisions: "
+          f"{max((np.abs(gd[k] - ghyb[k]).max() / max(np.abs(ghyb[k]).max(), 1e-6)) for k in p):.3e}")
+    assert not off, f"{tag}: gradients differ from the pure oracle evaluated under the device's gate decisions {off}"
 
 
 def test_small_model_no_dropout():
@@ -712,3 +781,61 @@ def test_side_stream_weight_gradients_equal_the_serial_schedule():
                 eng.backward(lab, il, ll, seed=2)
             torch.cuda.synchronize()
             assert torch.equal(res[False][1], eng.grads), (gru, precision, "repeat")
+
+
+def test_staged_host_batches_train_like_device_resident_ones():
+    """Engine.stage (page-locked double-buffered H->D staging of Readf's float64 / int64 host batches, the path Model.fit_generator
+    takes, train.py:201-209): three train steps fed through it leave bit-identical weights to the same steps on device-resident tensors,
+    including a non-finite row of a short tail batch being zeroed the same way."""
+    from crnn_mi355x.init import initial_parameters
+    from crnn_mi355x.optimizers import Adam
+    cfg = M.Config(imgh=40, max_len=6, time_dense_size=32, n_units=64)
+    B = 8
+    engs = []
+    for _ in range(2):
+        e = Engine(B, 40, 32, 38, 6, 32, 64, dropout=True)
+        e.set_params(initial_parameters(e.layout, 64, False, seed=5))
+        engs.append(e)
+    opts = [Adam(lr=1e-3, beta_1=0.5, clipnorm=5), Adam(lr=1e-3, beta_1=0.5, clipnorm=5)]
+    X = np.empty((B, 40, 32, 1))                       # the generator's own array, rewritten between steps
+    for it in range(3):
+        x, lab, il, ll = M.synthetic_batch(cfg, B, seed=20 + it, dtype=np.float64)
+        X[...] = x
+        if it == 1:
+            X[B - 1] = np.nan                          # undefined rows of Readf's tail batch
+        sb = engs[0].stage(X, lab, il.reshape(-1, 1), ll.reshape(-1, 1))
+        X[...] = -7.0                                  # the generator moves on before the step runs
+        engs[0].train_step(sb, None, None, None, opts[0], it)
+        xr = x.astype(np.float32)
+        if it == 1:
+            xr[B - 1] = 0.0
+        engs[1].train_step(torch.from_numpy(xr).cuda(), lab, il, ll, opts[1], it)
+    torch.cuda.synchronize()
+    assert torch.equal(engs[0].params, engs[1].params) and torch.equal(engs[0].bn_mean, engs[1].bn_mean)
+    assert torch.equal(engs[0].loss, engs[1].loss)
+
+
+def test_stn_callable_matches_the_oracle_locnet_and_sampler():
+    """utils.STN(image, sampling_size) (utils.py:247-258) as a callable: localisation net + sampler through the C ABI against the oracle
+    ops, with given weights; with the reference's initial weights (dense_2 kernel zero, identity bias) it is the identity-theta sampler."""
+    from crnn_mi355x.surface import STN, BilinearInterpolation, get_initial_weights
+    rs = np.random.RandomState(3)
+    B, H, W = 3, 100, 32
+    x = rs.normal(size=(B, H, W, 1))
+    F = ((H // 2 - 4) // 2 - 4) * ((W // 2 - 4) // 2 - 4) * 20
+    ws = [rs.normal(size=(5, 5, 1, 20)) * 0.2, rs.normal(size=20) * 0.1, rs.normal(size=(5, 5, 20, 20)) * 0.05, rs.normal(size=20) * 0.1,
+          rs.normal(size=(F, 50)) * 0.05, rs.normal(size=50) * 0.1, rs.normal(size=(50, 6)) * 0.02, np.array([1, 0, 0, 0, 1, 0], np.float64)]
+    out = STN(x, (H, W), weights=ws)
+    p1 = ops.maxpool_fwd(x, 2, 2)
+    c1 = ops.conv_valid_fwd(p1, ws[0], ws[1])
+    c2 = ops.conv_valid_fwd(ops.maxpool_fwd(c1, 2, 2), ws[2], ws[3])
+    fc1 = ops.relu_fwd(ops.dense_fwd(c2.reshape(B, -1), ws[4], ws[5]))
+    theta = ops.dense_fwd(fc1, ws[6], ws[7])
+    ref = ops.sampler_fwd(x, theta)
+    # (the sampler truncates its source coordinates, utils.py:166-169: a coordinate within fp32 round-off of an integer may pick the
+    # neighbouring corner on one side only -- isolated pixels, so the bound is on all but a vanishing fraction of them)
+    close = np.abs(out - ref) < 1e-3 * max(1.0, np.abs(ref).max())
+    assert out.shape == (B, H, W, 1) and close.mean() > 0.998, close.mean()
+    ident = STN(x, (H, W))                              # fresh layers: theta = identity
+    same = BilinearInterpolation((H, W))([x, np.tile(get_initial_weights(50)[1], (B, 1))])
+    assert np.array_equal(ident, same)

@@ -9,6 +9,7 @@ import torch
 
 from oracle import ops, ctc, model as M
 from gpu_util import L, dev, zeros, P, S, ok, host, assert_close, gemm
+from crnn_mi355x import native
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -310,10 +311,10 @@ def test_measurement_reference_copy_is_a_copy(pattern):
     for nbytes, wgs in ((16, 1), (16 * 1000 + 16, 7), (9216 * 104, 256), (4 << 20, 1024)):
         src = torch.randint(0, 256, (nbytes + 64,), dtype=torch.uint8, device="cuda")
         dst = torch.zeros_like(src)
-        ok(L().crnn_debug_copy(P(src), P(dst), nbytes, pattern, wgs, S()))
+        ok(native.hooks().crnn_debug_copy(P(src), P(dst), nbytes, pattern, wgs, S()))
         assert torch.equal(dst[:nbytes], src[:nbytes]) and int(dst[nbytes:].sum()) == 0, (nbytes, wgs)
-    assert L().crnn_debug_copy(P(src), P(dst), 24, pattern, 4, S()) != 0
-    assert L().crnn_debug_copy(P(src), P(dst), 32, 2, 4, S()) != 0
+    assert native.hooks().crnn_debug_copy(P(src), P(dst), 24, pattern, 4, S()) != 0
+    assert native.hooks().crnn_debug_copy(P(src), P(dst), 32, 2, 4, S()) != 0
 
 
 def test_bn_inference_states_in_one_launch_equal_the_single_launches():

@@ -86,6 +86,11 @@ def test_library_exports_every_declared_symbol_and_layout_is_keras_order():
     lib = ctypes.CDLL(native.LIB_PATH)          # loads without a GPU
     missing = [n for n in decl if not hasattr(lib, n)]
     assert not missing, missing
+    # measurement / test hooks are NOT in the product library or its header: their own .so (include/crnn_testhooks.h)
+    assert not [n for n in decl if n.startswith("crnn_debug")]
+    hdecl = native.parse_header(native.HOOKS_HEADER)
+    hlib = ctypes.CDLL(native.HOOKS_PATH)
+    assert set(hdecl) == {"crnn_debug_copy", "crnn_debug_occupy"} and all(hasattr(hlib, n) and not hasattr(lib, n) for n in hdecl)
     cfg = _cfg_struct(64, (100, 32, 1), 38, 23, 128, 256, False)
     lay = param_layout(cfg)
     names = list(lay)
