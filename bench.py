@@ -49,7 +49,8 @@ def depthwise_roofline(eng, iters=15):
     esz = 2 if bf16s else 4          # storage bytes per element of the conv-stack tensors
     dtype = 1 if bf16s else 0
     parts = eng.ws_tensor("partials")
-    nstream = 0
+    nstream = npro = 0
+    rate = 0.1 if eng.cfg.dropout else 0.0
     producers = []       # bf16s: the launch that writes each forward launch's input in the step (previous block's BN + ReLU6 + pool + dropout)
     prev = None          # (h, w, c, ph, pw) of the previous block's pointwise output q
     for i, (co, ph, pw) in enumerate(blocks, 1):
@@ -60,16 +61,22 @@ def depthwise_roofline(eng, iters=15):
                 producers.append((eng.ws_tensor("q%d" % (i - 1)), eng.ws_tensor("bn2s%d" % (i - 1)), eng.ws_tensor("x%d" % (i - 1)), qh, qw, qc, qph, qpw, i - 1))
             st = bf16s and not (eng.cfg.flags & 32) and lib.crnn_dwconv_fwd_stream_supported(B, h, w, cin) == 0
             nstream += int(st)
-            launches.append((eng.ws_tensor("x%d" % (i - 1)), k, eng.ws_tensor("d%d" % i), parts, h, w, cin, 0, st))   # forward
+            # the step's own form: the previous block's BatchNorm-2 + ReLU6 + dropout applied inside the kernel (prologue form, reads q) where the
+            # forward does not materialise x (crnn_block_output_fused)
+            pro = (eng.ws_tensor("q%d" % (i - 1)), eng.ws_tensor("bn2s%d" % (i - 1)), i - 1) if (st and lib.crnn_block_output_fused(eng._c, i - 1)) else None
+            npro += int(pro is not None)
+            launches.append((eng.ws_tensor("x%d" % (i - 1)), k, eng.ws_tensor("d%d" % i), parts, h, w, cin, 0, st, pro))   # forward
             nbytes += 2.0 * B * h * w * cin * esz
             if not bf16s:
-                launches.append((eng.ws_tensor("gB"), k, eng.ws_tensor("gA"), None, h, w, cin, 1, False))            # data gradient
+                launches.append((eng.ws_tensor("gB"), k, eng.ws_tensor("gA"), None, h, w, cin, 1, False, None))            # data gradient
                 nbytes += 2.0 * B * h * w * cin * esz
         prev = (h, w, co, ph, pw)
         h, w, cin = h // ph, w // pw, co
 
-    def issue(x, k, o, pt, hh, ww, cc, flip, st):
-        if st:
+    def issue(x, k, o, pt, hh, ww, cc, flip, st, pro):
+        if pro is not None:
+            lib.crnn_dwconv3x3_fwd_stream_pro(_ptr(pro[0]), _ptr(pro[1]), rate, 1234, pro[2], _ptr(k), _ptr(o), _ptr(pt), B, hh, ww, cc, _stream())
+        elif st:
             lib.crnn_dwconv3x3_fwd_stream(_ptr(x), _ptr(k), _ptr(o), _ptr(pt), None, B, hh, ww, cc, flip, _stream())
         else:
             lib.crnn_dwconv3x3_fwd_ex(_ptr(x), _ptr(k), _ptr(o), _ptr(pt), B, hh, ww, cc, flip, dtype, _stream())
@@ -89,12 +96,12 @@ def depthwise_roofline(eng, iters=15):
     # last-level cache still holds part of it), one event pair per launch (their ~2 us of event latency counted against the kernel)
     in_step = None
     if bf16s and len(producers) == len(launches):
-        rate = 0.1 if eng.cfg.dropout else 0.0
         tot = []
         for it in range(iters + 1):
             evs = []
             for (q, st2, xo, qh, qw, qc, qph, qpw, layer), L in zip(producers, launches):
-                lib.crnn_bn_act_pool_drop_ex(_ptr(q), _ptr(st2), _ptr(xo), B, qh, qw, qc, qph, qpw, rate, 1234, layer, 1, 1, _stream())
+                if L[9] is None:       # (prologue form: the input q is the pointwise GEMM's output, not re-produced here)
+                    lib.crnn_bn_act_pool_drop_ex(_ptr(q), _ptr(st2), _ptr(xo), B, qh, qw, qc, qph, qpw, rate, 1234, layer, 1, 1, _stream())
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(); issue(*L); e1.record()
                 evs.append((e0, e1))
@@ -122,7 +129,8 @@ def depthwise_roofline(eng, iters=15):
                                  + 2 * sh["52x18x256"]["hbm_bytes_per_launch"] + 2 * sh["52x9x512"]["hbm_bytes_per_launch"])
     except Exception:
         pass
-    kname = ("dw_fwd_stream_kernel (depthwise 3x3 forward + BatchNorm statistics, blocks 2-7: rows streamed through an LDS ring by a loader wave)"
+    kname = ("dw_fwd_stream_kernel (depthwise 3x3 forward + BatchNorm statistics, blocks 2-7: rows streamed through an LDS ring by a loader wave; %d of the "
+             "%d launches in the prologue form: the previous block's BatchNorm-2 + ReLU6 + dropout applied to q in LDS by two transform waves)" % (npro, len(launches))
              if nstream == len(launches) else
              "dwconv_tile_kernel<0> (depthwise 3x3 fwd%s, blocks 2-7, LDS halo tiles)" % ("" if bf16s else " + data-gradient")
              if nstream == 0 else "dw_fwd_stream_kernel + dwconv_tile_kernel<0> (depthwise 3x3 forward, blocks 2-7)")
@@ -156,7 +164,7 @@ def depthwise_roofline(eng, iters=15):
             for it in range(iters + 1):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                for (x, k, o, pt, hh, ww, cc, flip, st) in launches:
+                for (x, k, o, pt, hh, ww, cc, flip, st, pro) in launches:
                     hooks.crnn_debug_copy(_ptr(x), _ptr(o), B * hh * ww * cc * esz, pattern, 256, _stream())
                 e1.record()
                 torch.cuda.synchronize()
@@ -181,7 +189,8 @@ def depthwise_bwd_roofline(eng, iters=5):
     lib = eng.lib; B = eng.B
     blocks = [(64, 1, 1), (128, 1, 1), (256, 2, 2), (256, 1, 1), (512, 1, 2), (512, 1, 1), (512, 1, 1)]
     h, w, cin = eng.cfg.imgh + 4, eng.cfg.imgw + 4, 1
-    launches, nbytes, nstream = [], 0.0, 0
+    launches, nbytes, nstream, npro = [], 0.0, 0, 0
+    rate = 0.1 if eng.cfg.dropout else 0.0
     parts, coef = eng.ws_tensor("partials"), eng.ws_tensor("coef")
     for i, (co, ph, pw) in enumerate(blocks, 1):
         if i >= 2:
@@ -190,15 +199,21 @@ def depthwise_bwd_roofline(eng, iters=5):
             k = eng.params[eng.layout["b%d_dw" % i][0]:]; gk = eng.grads[eng.layout["b%d_dw" % i][0]:]
             st = not (eng.cfg.flags & 32) and lib.crnn_dwconv_bwd_stream_supported(B, h, w, cin) == 0    # the step's own choice of kernel
             nstream += int(st)
+            pro = (eng.ws_tensor("q%d" % (i - 1)), eng.ws_tensor("bn2s%d" % (i - 1)), i - 1) if (st and lib.crnn_block_output_fused(eng._c, i - 1)) else None
+            npro += int(pro is not None)
             launches.append((eng.ws_tensor("d%d" % i), eng.ws_tensor("gA"), eng.ws_tensor("bn1s%d" % i), coef, eng.ws_tensor("x%d" % (i - 1)), k,
-                             eng.ws_tensor("gB"), gk, parts, h, w, cin, st))
+                             eng.ws_tensor("gB"), gk, parts, h, w, cin, st, pro))
             nbytes += 4 * (2.0 * B * h * w * cin)
         h, w, cin = h // ph, w // pw, co
     times = []
     for it in range(iters + 1):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for d, da, st, cf, x, k, dx, dk, pt, hh, ww, cc, strm in launches:
+        for d, da, st, cf, x, k, dx, dk, pt, hh, ww, cc, strm, pro in launches:
+            if pro is not None:     # the step's own form: x re-formed from the previous block's q in LDS
+                lib.crnn_dwconv3x3_bwd_stream_pro(_ptr(d), _ptr(da), _ptr(st), _ptr(cf), _ptr(pro[0]), _ptr(pro[1]), rate, 1234, pro[2], _ptr(k), _ptr(dx),
+                                                  _ptr(dk), _ptr(pt), B, hh, ww, cc, _stream())
+                continue
             fn = lib.crnn_dwconv3x3_bwd_stream if strm else lib.crnn_dwconv3x3_bwd_fused
             fn(_ptr(d), _ptr(da), _ptr(st), _ptr(cf), _ptr(x), _ptr(k), _ptr(dx), _ptr(dk), _ptr(pt), B, hh, ww, cc, _stream())
         e1.record(); torch.cuda.synchronize()
@@ -206,7 +221,8 @@ def depthwise_bwd_roofline(eng, iters=5):
             times.append(e0.elapsed_time(e1) * 1e-3)
     t = float(np.median(times)); ach = nbytes / t / 1e9
     kname = ("dw_bwd_stream_kernel (BatchNorm-backward pass 2 + depthwise weight and data gradients, blocks 2-7: rows of d, da, x streamed through an LDS ring, "
-             "weight-gradient and data-gradient wave groups; incl. the second-stage sum of the weight-gradient partials)" if nstream == len(launches) else
+             "weight-gradient and data-gradient wave groups; incl. the second-stage sum of the weight-gradient partials; %d of the %d launches re-form x from "
+             "the previous block's q in LDS)" % (npro, len(launches)) if nstream == len(launches) else
              "dw_bwd_fused_kernel (BatchNorm-backward pass 2 + depthwise weight and data gradients, blocks 2-7; VALU-issue-bound, DESIGN.md section 4)")
     return {"bound": "hbm", "kernel": kname,
             "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "launches": len(launches),
@@ -215,7 +231,7 @@ def depthwise_bwd_roofline(eng, iters=5):
 
 def batchnorm_roofline(eng, iters=5):
     """Secondary: the BatchNorm streaming passes of the conv stack that are kernels of their own in the bf16s step -- the block outputs' BatchNorm-2 +
-    ReLU6 + pool + dropout (forward, 7 launches) and BatchNorm-2's backward (statistics pass, finalize, apply pass: blocks 7..1) -- re-issued on the
+    ReLU6 + pool + dropout (forward; the un-pooled blocks 1, 2, 4, 6 have none where the next depthwise kernel applies it in LDS) and BatchNorm-2's backward (statistics pass, finalize, apply pass: blocks 7..1) -- re-issued on the
     live buffers.  Algorithmic bytes in the storage type: apply reads q and writes x; the backward's two passes read g and q twice and write dq."""
     from crnn_mi355x.engine import _ptr, _stream
     if eng.precision != "bf16s":
@@ -230,7 +246,8 @@ def batchnorm_roofline(eng, iters=5):
         q, st, x = eng.ws_tensor("q%d" % i), eng.ws_tensor("bn2s%d" % i), eng.ws_tensor("x%d" % i)
         M, Mo = B * h * w, B * (h // ph) * (w // pw)
         gam = eng.params[eng.layout["b%d_bn2_g" % i][0]:]; dg = eng.grads[eng.layout["b%d_bn2_g" % i][0]:]; db = eng.grads[eng.layout["b%d_bn2_b" % i][0]:]
-        fwd.append((q, st, x, h, w, co, ph, pw, i)); fb += 2.0 * (M + Mo) * co
+        if not lib.crnn_block_output_fused(eng._c, i):      # (else the next block's depthwise kernels form x from q in LDS: no pass of its own)
+            fwd.append((q, st, x, h, w, co, ph, pw, i)); fb += 2.0 * (M + Mo) * co
         bwd.append((q, st, gam, dg, db, h, w, co, ph, pw, i)); bb += 2.0 * (2 * (M + Mo) + M) * co
         h, w = h // ph, w // pw
     gA, gB = eng.ws_tensor("gA"), eng.ws_tensor("gB")

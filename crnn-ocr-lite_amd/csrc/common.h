@@ -74,23 +74,56 @@ __device__ __forceinline__ void bn_bwd_pq(float sc, float c1, float c2, float mu
 }
 __device__ __forceinline__ float bn_bwd_dx_pq(float x, float gy, float sc, float P, float Q) { return fmaf(x, P, fmaf(gy, sc, Q)); }
 
-// Counter-based dropout RNG: murmur3-style 64-bit finaliser of (step seed, dropout site, group), one hash
-// per group of 4 consecutive elements; element idx takes 16-bit lane (idx & 3) of the hash of group idx >> 2
-// and is kept when lane >= floor(rate * 65536).  The backward pass recomputes it (no mask tensor).
-__device__ __host__ __forceinline__ uint64_t crnn_hash(uint64_t seed, uint32_t layer, uint64_t group) {
-  uint64_t x = group + 0x9E3779B97F4A7C15ull * (seed + 1) + ((uint64_t)layer << 56);
-  x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
-  x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
-  x ^= x >> 33;
-  return x;
+// Counter-based dropout RNG (round 4): three ChaCha quarter-rounds (add / xor / rotate only -- every operation full-rate on the
+// vector ALU; the murmur3-style 64-bit finaliser it replaces spent 8 quarter-rate 32-bit multiplies per 4 elements, half the VALU
+// work of the kernels that re-derive the mask) over the state (group ^ k0, k1, k2, rotl(group, 16) ^ c) with the key (k0, k1, k2)
+// folded from (step seed, dropout site).  One evaluation serves a group of 8 consecutive elements: element idx takes 16-bit lane
+// (idx & 7) of the 128-bit result for group idx >> 3 and is kept when lane >= floor(rate * 65536).  The backward pass recomputes it
+// (no mask tensor).  Avalanche over group / seed / site bits, lane uniformity and lane / stride correlations measured at 2^20
+// groups: indistinguishable from ideal at that sample size (3 quarter-rounds; 2 leave 0.11-0.19 avalanche bias).
+struct crnn_rng_key { uint32_t k0, k1, k2; };
+__device__ __host__ __forceinline__ crnn_rng_key crnn_rng_make_key(uint64_t seed, uint32_t layer) {
+  crnn_rng_key k;
+  k.k0 = (uint32_t)seed ^ 0x243F6A88u; k.k1 = (uint32_t)(seed >> 32) ^ 0x85A308D3u; k.k2 = (layer * 0x9E3779B9u) ^ 0x13198A2Eu;
+  return k;
+}
+__device__ __host__ __forceinline__ uint32_t crnn_rotl(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+__device__ __host__ __forceinline__ void crnn_rng8(const crnn_rng_key& k, uint64_t group, uint32_t (&w)[4]) {
+  const uint32_t glo = (uint32_t)group, ghi = (uint32_t)(group >> 32);
+  uint32_t a = glo ^ k.k0, b = k.k1, c = ghi ^ k.k2, d = crnn_rotl(glo, 16) ^ 0x03707344u;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    a += b; d = crnn_rotl(d ^ a, 16);
+    c += d; b = crnn_rotl(b ^ c, 12);
+    a += b; d = crnn_rotl(d ^ a, 8);
+    c += d; b = crnn_rotl(b ^ c, 7);
+  }
+  w[0] = a; w[1] = b; w[2] = c; w[3] = d;
+}
+__device__ __host__ __forceinline__ uint32_t crnn_drop_threshold(float rate) { return (uint32_t)(rate * 65536.f); }
+// bit e of the result: element 8 * group + e is KEPT
+__device__ __forceinline__ uint32_t crnn_keep8(const crnn_rng_key& k, uint64_t group, uint32_t thr) {
+  uint32_t w[4];
+  crnn_rng8(k, group, w);
+  uint32_t m = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    m |= ((w[q] & 0xffffu) >= thr ? 1u : 0u) << (2 * q);
+    m |= ((w[q] >> 16) >= thr ? 1u : 0u) << (2 * q + 1);
+  }
+  return m;
 }
 // returns the multiplier applied to the activation: 0 or 1/(1-rate); rate<=0 => 1
 __device__ __forceinline__ float drop_scale(uint64_t seed, uint32_t layer, uint64_t idx, float rate, float inv_keep) {
   if (rate <= 0.f) return 1.f;
-  uint32_t lane = (uint32_t)(crnn_hash(seed, layer, idx >> 2) >> (16 * (idx & 3))) & 0xffffu;
-  return (lane >= (uint32_t)(rate * 65536.f)) ? inv_keep : 0.f;
+  uint32_t w[4];
+  crnn_rng8(crnn_rng_make_key(seed, layer), idx >> 3, w);
+  const uint32_t e = (uint32_t)idx & 7u;
+  const uint32_t lane = (w[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+  return (lane >= crnn_drop_threshold(rate)) ? inv_keep : 0.f;
 }
-// multipliers of N consecutive elements idx0 .. idx0+N-1; one hash per aligned group of 4 when idx0 % 4 == 0
+// multipliers of N consecutive elements idx0 .. idx0+N-1; one evaluation per aligned group of 8 when idx0 % 8 == 0 (N % 8 == 0), half of
+// one when idx0 % 4 == 0 (N == 4)
 template <int N>
 __device__ __forceinline__ void drop_scale_vec(uint64_t seed, uint32_t layer, uint64_t idx0, float rate, float inv_keep, float* out) {
   if (rate <= 0.f) {
@@ -98,17 +131,28 @@ __device__ __forceinline__ void drop_scale_vec(uint64_t seed, uint32_t layer, ui
     for (int e = 0; e < N; ++e) out[e] = 1.f;
     return;
   }
-  if (N % 4 == 0) {
-    const uint32_t thr = (uint32_t)(rate * 65536.f);
+  const uint32_t thr = crnn_drop_threshold(rate);
+  const crnn_rng_key key = crnn_rng_make_key(seed, layer);
+  if (N % 8 == 0) {
 #pragma unroll
-    for (int gq = 0; gq < N / 4; ++gq) {
-      uint64_t h = crnn_hash(seed, layer, (idx0 >> 2) + gq);
-      uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 32);
-      out[(4 * gq + 0) % N] = ((lo & 0xffffu) >= thr) ? inv_keep : 0.f;
-      out[(4 * gq + 1) % N] = ((lo >> 16) >= thr) ? inv_keep : 0.f;
-      out[(4 * gq + 2) % N] = ((hi & 0xffffu) >= thr) ? inv_keep : 0.f;
-      out[(4 * gq + 3) % N] = ((hi >> 16) >= thr) ? inv_keep : 0.f;
+    for (int gq = 0; gq < N / 8; ++gq) {
+      uint32_t w[4];
+      crnn_rng8(key, (idx0 >> 3) + gq, w);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        out[(8 * gq + 2 * q) % N] = ((w[q] & 0xffffu) >= thr) ? inv_keep : 0.f;
+        out[(8 * gq + 2 * q + 1) % N] = ((w[q] >> 16) >= thr) ? inv_keep : 0.f;
+      }
     }
+  } else if (N == 4) {
+    uint32_t w[4];
+    crnn_rng8(key, idx0 >> 3, w);
+    const bool hi = (idx0 >> 2) & 1;
+    const uint32_t w0 = hi ? w[2] : w[0], w1 = hi ? w[3] : w[1];
+    out[0] = ((w0 & 0xffffu) >= thr) ? inv_keep : 0.f;
+    out[1 % N] = ((w0 >> 16) >= thr) ? inv_keep : 0.f;
+    out[2 % N] = ((w1 & 0xffffu) >= thr) ? inv_keep : 0.f;
+    out[3 % N] = ((w1 >> 16) >= thr) ? inv_keep : 0.f;
   } else {
 #pragma unroll
     for (int e = 0; e < N; ++e) out[e] = drop_scale(seed, layer, idx0 + e, rate, inv_keep);

@@ -14,6 +14,10 @@
 // The two groups have different register sets (72 sums + 32 BatchNorm constants vs 72 taps + 24 running sums) -- one wave holding both
 // would need 260 registers -- and unequal work, so the roles are dealt over the wave slots such that every SIMD carries about the same
 // (wave w runs on SIMD w mod 4).  Nothing is re-read: 4 tensor passes of HBM traffic (+ 2 halo rows per band), one barrier per row.
+//
+// PROLOGUE form (round 4): `xin` is the previous block's pointwise output q -- the block output x = Dropout(ReLU6(BatchNorm-2(q)))
+// (utils.py:48-56) is not kept by the forward (dwconv_stream.hip) and is re-formed here, bit for bit, one row ahead by the DX waves
+// (the lighter group) into a two-row LDS buffer the DK waves take their weight-gradient operand from; one more stage in flight.
 #include "common.h"
 
 namespace {
@@ -31,6 +35,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 struct DbsParams {
   const unsigned char *d, *da, *xin; unsigned char* dx; const float *bnstate, *coef, *k; float* partials;
   int H, W, C, HB, nwgb, nsplit, cols, cppw, rowbytes;
+  // prologue form: xin = q of the previous block, its BatchNorm-2 state [mean|var|scale|shift] and dropout site
+  const float* pro_bn; uint64_t seed; uint32_t layer; float rate;
 };
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
@@ -47,12 +53,19 @@ constexpr int kCW = 5;                       // compute waves per group (320 col
 constexpr int kSub = 5 * 1024;               // one row of one tensor in a ring stage (5 DMA instructions)
 constexpr int kStageB = 3 * kSub;            // d | da | xin
 constexpr int kNI = 15;                      // DMA instructions per stage
-constexpr int kD = CRNN_DBS_D, kNR = kD + 1;
-static_assert((kD - 1) * kNI <= 63, "vmcnt is a 6-bit counter");
-constexpr int kDdOff = kNR * kStageB;        // two dd rows
-constexpr int kZOff = kDdOff + 2 * kSub;     // 16 zero bytes
-constexpr int kCstOff = kZOff + 64;          // BatchNorm constants of the workgroup's channels: scale | shift | P | Q, [4][<= 256] floats
-constexpr int kLds = kCstOff + 4 * 256 * 4;
+// LDS plan for KD stages in flight (prologue form: + two rows of re-formed x)
+template <int KD>
+struct DbsLds {
+  static constexpr int NR = KD + 1;
+  static constexpr int DdOff = NR * kStageB;        // two dd rows
+  static constexpr int ZOff = DdOff + 2 * kSub;     // 16 zero bytes
+  static constexpr int CstOff = ZOff + 64;          // BatchNorm constants of the workgroup's channels: scale | shift | P | Q, [4][<= 256] floats
+  static constexpr int XtOff = CstOff + 4 * 256 * 4;   // prologue form: two rows of x = Dropout(ReLU6(BatchNorm-2(q)))
+  static constexpr int PcOff = XtOff + 2 * kSub;       // prologue form: BatchNorm-2 scale | shift of the workgroup's channels, [2][<= 256] floats
+  static constexpr int Total = PcOff + 2 * 256 * 4;
+  static_assert((KD - 1) * kNI <= 63, "vmcnt is a 6-bit counter");
+};
+constexpr int kD = CRNN_DBS_D;
 
 // role of wave slot w (11 waves; SIMD = w mod 4): DK work is about twice DX work per step
 //   SIMD 3: w3 w7 = DK DK;  SIMD 0: w0 w4 w8 = DK DX DX;  SIMD 1: w1 w5 w9 = DK DX DX;  SIMD 2: w2 w6 w10 = DK DX loader
@@ -64,7 +77,10 @@ __device__ __forceinline__ int role_of(int w, int& idx) {   // 0 = DK, 1 = DX, 2
   return 1;
 }
 
+template <int KD, bool PRO, bool DROP>
 __global__ __launch_bounds__(704) void dw_bwd_stream_kernel(DbsParams p) {
+  typedef DbsLds<KD> LP;
+  constexpr int kNR = LP::NR, kDdOff = LP::DdOff, kZOff = LP::ZOff, kCstOff = LP::CstOff, kXtOff = LP::XtOff, kPcOff = LP::PcOff;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -105,12 +121,12 @@ __global__ __launch_bounds__(704) void dw_bwd_stream_kernel(DbsParams p) {
       }
     };
 #pragma unroll
-    for (int s = 0; s < kD; ++s) issue(s, s);
-    int slot = kD;
+    for (int s = 0; s < KD; ++s) issue(s, s);
+    int slot = KD;
     for (int s = 0; s < nsteps; ++s) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kD - 1) * kNI) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((KD - (PRO ? 2 : 1)) * kNI) : "memory");   // stage s (prologue form: s + 1) has landed
       __builtin_amdgcn_s_barrier();
-      issue(s + kD, slot);
+      issue(s + KD, slot);
       slot = slot + 1 == kNR ? 0 : slot + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -141,10 +157,50 @@ __global__ __launch_bounds__(704) void dw_bwd_stream_kernel(DbsParams p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) X0[e] = X1[e] = X2[e] = 0.f;
     unsigned char* orow = p.dx + imgoff + (long)r0 * p.rowbytes + px * p.C * 2 + ch0 * 2;
+    // prologue form: re-form x of the stage that arrived one step ahead (own column) into the two-row buffer the DK waves read
+    // (the 16 BatchNorm-2 constants of the lane's channels sit in LDS and are read per step: kw + the running rows fill the registers)
+    uint32_t pgrp = 0;                                // dropout group of this column's chunk in stage 0 (image row r0 - 2)
+    const uint32_t prow = (uint32_t)(p.W * (p.C >> 3));
+    const int pcw = p.cppw * 8;                       // channels of this workgroup
+    float* pct = reinterpret_cast<float*>(lds + kPcOff);
+    if (PRO) {
+      for (int i = gidx * 64 + lane; i < pcw; i += kCW * 64) { pct[i] = p.pro_bn[2 * p.C + c0 + i]; pct[pcw + i] = p.pro_bn[3 * p.C + c0 + i]; }
+      pgrp = (uint32_t)((((long)img * p.H + r0 - 2) * p.W + px) * (p.C >> 3) + (ch0 >> 3));
+    }
+    const float* pcl = pct + oct * 8;
+    const crnn_rng_key pkey = crnn_rng_make_key(p.seed, p.layer);
+    const uint32_t pthr = DROP ? crnn_drop_threshold(p.rate) : 0u;
+    const float pik = DROP ? 1.f / (1.f - p.rate) : 1.f;
+    int xslot = 1;                                    // ring slot of stage `st`
+    auto xform = [&](int st) {                        // stage st: xin row r0 - 2 + st  ->  xt[st & 1]
+      const u32x4 v = *reinterpret_cast<const u32x4*>(lds + xslot * kStageB + 2 * kSub + offC);
+      xslot = xslot + 1 == kNR ? 0 : xslot + 1;
+      const float4 s0 = *reinterpret_cast<const float4*>(pcl), s1 = *reinterpret_cast<const float4*>(pcl + 4);
+      const float4 h0 = *reinterpret_cast<const float4*>(pcl + pcw), h1 = *reinterpret_cast<const float4*>(pcl + pcw + 4);
+      const f32x2_t psc[4] = {{s0.x, s0.y}, {s0.z, s0.w}, {s1.x, s1.y}, {s1.z, s1.w}};
+      const f32x2_t psh[4] = {{h0.x, h0.y}, {h0.z, h0.w}, {h1.x, h1.y}, {h1.z, h1.w}};
+      uint32_t w[4] = {0u, 0u, 0u, 0u};
+      if (DROP) crnn_rng8(pkey, (uint64_t)(pgrp + (uint32_t)st * prow), w);
+      u32x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x2_t x2 = (f32x2_t){__uint_as_float(v[q] << 16), __uint_as_float(v[q] & 0xffff0000u)};
+        f32x2_t y = __builtin_elementwise_fma(x2, psc[q], psh[q]);
+        y = (f32x2_t){relu6f(y.x), relu6f(y.y)};
+        if (DROP) {
+          const f32x2_t ys = y * (f32x2_t){pik, pik};
+          y = (f32x2_t){(w[q] & 0xffffu) >= pthr ? ys.x : 0.f, (w[q] >> 16) >= pthr ? ys.y : 0.f};
+        }
+        o[q] = pack2_bf16(y.x, y.y);
+      }
+      if (act) *reinterpret_cast<u32x4*>(lds + kXtOff + (st & 1) * kSub + offC) = o;
+      __builtin_amdgcn_sched_barrier(0);              // its temporaries are dead before the correlation's operands are loaded
+    };
     // a = arriving dd row (relative: image row r0-1+a), read one step after the DK waves wrote it
     auto step = [&](int a, float (&A)[8], float (&Bc)[8], float (&Cn)[8]) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();                  // barrier of stage a + 1
+      if (PRO && a + 2 < nsteps) xform(a + 2);
       const unsigned char* sb = lds + kDdOff + (a & 1) * kSub;
       const u32x4 vL = *reinterpret_cast<const u32x4*>(hasL ? sb + offC - pitch : lds + kZOff);
       const u32x4 vC = *reinterpret_cast<const u32x4*>(sb + offC);
@@ -172,6 +228,7 @@ __global__ __launch_bounds__(704) void dw_bwd_stream_kernel(DbsParams p) {
     };
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                  // step 0: the first dd row is being formed
+    if (PRO) xform(1);
     step(0, X1, X2, X0);
     step(1, X2, X0, X1);
     const int last = p.HB + 1;                     // arriving rows 0 .. HB+1
@@ -249,7 +306,7 @@ __global__ __launch_bounds__(704) void dw_bwd_stream_kernel(DbsParams p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     if (!edge || s >= 1) {
-      const unsigned char* xb = sb + 2 * kSub;
+      const unsigned char* xb = PRO ? lds + kXtOff + (s & 1) * kSub : sb + 2 * kSub;
       u32x4 vL = *reinterpret_cast<const u32x4*>(hasL ? xb + offC - pitch : lds + kZOff);
       u32x4 vC = *reinterpret_cast<const u32x4*>(xb + offC);
       u32x4 vR = *reinterpret_cast<const u32x4*>(hasR ? xb + offC + pitch : lds + kZOff);
@@ -371,8 +428,39 @@ extern "C" int crnn_dwconv3x3_bwd_stream(const void* d, const void* da, const fl
   p.d = (const unsigned char*)d; p.da = (const unsigned char*)da; p.xin = (const unsigned char*)xin; p.dx = (unsigned char*)dx;
   p.bnstate = bnstate; p.coef = coef; p.k = k; p.partials = scratch;
   p.H = H; p.W = W; p.C = C; p.HB = g.HB; p.nwgb = g.nwgb; p.nsplit = g.nsplit; p.cols = g.cols; p.cppw = g.cppw; p.rowbytes = W * C * 2;
-  CRNN_LDS_ATTR(dw_bwd_stream_kernel, kLds);
-  hipLaunchKernelGGL(dw_bwd_stream_kernel, dim3(B * g.nwgb * g.nsplit), dim3(704), kLds, stream, p);
+  p.pro_bn = nullptr; p.seed = 0; p.layer = 0; p.rate = 0.f;
+  CRNN_LDS_ATTR((dw_bwd_stream_kernel<kD, false, false>), DbsLds<kD>::XtOff);
+  hipLaunchKernelGGL((dw_bwd_stream_kernel<kD, false, false>), dim3(B * g.nwgb * g.nsplit), dim3(704), DbsLds<kD>::XtOff, stream, p);
+  CRNN_LAUNCH_CHECK();
+  return crnn_partials_sum(scratch, B * g.nwgb, 9 * C, dk, 1.f, stream);
+}
+// Prologue form: xin = q of the previous block ([B,H,W,C] bf16), pro_bnstate = its BatchNorm-2 state, (rate, seed, layer) = the dropout site of
+// its output (crnn_bn_act_pool_drop_ex): x = Dropout(ReLU6(q * scale + shift)) is re-formed in LDS instead of read.  dx / dk bit-identical to
+// crnn_dwconv3x3_bwd_stream on the materialised x.  Same shape rule + fewer than 2^32 dropout groups (B*H*W*C/8).
+extern "C" int crnn_dwconv_bwd_stream_pro_supported(int B, int H, int W, int C) {
+  return (dbs_geom(B, H, W, C).ok && (long)B * H * W * (C / 8) < (1L << 32)) ? CRNN_OK : CRNN_ERR_UNSUPPORTED;
+}
+extern "C" int crnn_dwconv3x3_bwd_stream_pro(const void* d, const void* da, const float* bnstate, const float* coef, const void* q, const float* pro_bnstate,
+                                             float rate, uint64_t seed, uint32_t layer, const float* k, void* dx, float* dk, float* scratch, int B, int H,
+                                             int W, int C, hipStream_t stream) {
+  if (!d || !da || !bnstate || !coef || !q || !pro_bnstate || !k || !dx || !dk || !scratch || rate < 0.f || rate >= 1.f) return CRNN_ERR_ARG;
+  const DbsGeom g = dbs_geom(B, H, W, C);
+  if (!g.ok || (long)B * H * W * (C / 8) >= (1L << 32)) return CRNN_ERR_UNSUPPORTED;
+  if ((((uintptr_t)d | (uintptr_t)da | (uintptr_t)q | (uintptr_t)dx | (uintptr_t)bnstate | (uintptr_t)coef | (uintptr_t)k | (uintptr_t)pro_bnstate) & 15)) return CRNN_ERR_UNSUPPORTED;
+  if ((long)H * W * C * 2 >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;
+  DbsParams p;
+  p.d = (const unsigned char*)d; p.da = (const unsigned char*)da; p.xin = (const unsigned char*)q; p.dx = (unsigned char*)dx;
+  p.bnstate = bnstate; p.coef = coef; p.k = k; p.partials = scratch;
+  p.H = H; p.W = W; p.C = C; p.HB = g.HB; p.nwgb = g.nwgb; p.nsplit = g.nsplit; p.cols = g.cols; p.cppw = g.cppw; p.rowbytes = W * C * 2;
+  p.pro_bn = pro_bnstate; p.seed = seed; p.layer = layer; p.rate = rate;
+  constexpr int KD = kD + 1;
+  if (rate > 0.f) {
+    CRNN_LDS_ATTR((dw_bwd_stream_kernel<KD, true, true>), DbsLds<KD>::Total);
+    hipLaunchKernelGGL((dw_bwd_stream_kernel<KD, true, true>), dim3(B * g.nwgb * g.nsplit), dim3(704), DbsLds<KD>::Total, stream, p);
+  } else {
+    CRNN_LDS_ATTR((dw_bwd_stream_kernel<KD, true, false>), DbsLds<KD>::Total);
+    hipLaunchKernelGGL((dw_bwd_stream_kernel<KD, true, false>), dim3(B * g.nwgb * g.nsplit), dim3(704), DbsLds<KD>::Total, stream, p);
+  }
   CRNN_LAUNCH_CHECK();
   return crnn_partials_sum(scratch, B * g.nwgb, 9 * C, dk, 1.f, stream);
 }

@@ -15,6 +15,14 @@
 // workgroup so that the step row always fills the 9 waves (block 2: 2 x 36 px x 64 ch; blocks 3-7: W*C = 4608).
 // BatchNorm statistics: per-lane fp32 sums over the band, combined over the pixel columns through LDS in a fixed order: one
 // partial row [2][C] per workgroup.
+//
+// PROLOGUE form (round 4, training): the input is the PREVIOUS block's pointwise output q and the kernel applies that block's
+// BatchNorm-2 + ReLU6 + Dropout(.1) (utils.py:48-56: x = drop(relu6(q * scale + shift)), the arithmetic of bn_act_pool_drop_kernel
+// bit for bit, dropout mask re-derived from (seed, site, element index)) to every row after it has landed in LDS -- the block output x
+// is never written to or read from HBM (one read pass + one write pass of the largest tensors of the step less per un-pooled block).
+// Two TRANSFORM waves rewrite the row that arrived one step ahead in place (own 16-byte chunks, bf16 again) while the compute waves
+// work on the current row; the ring is one slot deeper so that as many rows stay in flight.  The 12 waves are dealt over the SIMDs
+// (wave w runs on SIMD w mod 4) so that the transform waves share theirs with fewer compute waves.
 #include "common.h"
 
 namespace {
@@ -28,6 +36,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 struct DwsParams {
   const unsigned char* x; const float* k; unsigned char* out; float* partials; const float* bnstate;
   int H, W, C, HB, NS, nwgb, flip, cols, rowbytes, wmaj;
+  // prologue form: BatchNorm state [mean|var|scale|shift] of the producer, dropout of its output
+  const float* pro_bn; uint64_t seed; uint32_t layer; float rate;
 };
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
@@ -42,22 +52,107 @@ __device__ __forceinline__ void widen8(const u32x4& u, float (&f)[8]) {
 
 constexpr int kDwsMaxWaves = 9;     // compute waves (576 columns of 16 bytes)
 
-// NI: 1 KiB DMA instructions per step row; D: rows in flight; EPI: out = ReLU6(conv * scale + shift) (inference), no statistics
-template <int NI, int D, bool EPI>
-__global__ __launch_bounds__((kDwsMaxWaves + 1) * 64) void dw_fwd_stream_kernel(DwsParams p) {
+// role of wave slot w in the prologue form (12 waves, SIMD = w mod 4): 9 compute waves, the loader, two transform waves --
+//   SIMD 0: w0 w4 w8 = C C C;  SIMD 1: w1 w5 w9 = C T L;  SIMD 2: w2 w6 w10 = C C C;  SIMD 3: w3 w7 w11 = C C T
+__device__ __forceinline__ int dws_pro_role(int w, int& idx) {   // 0 = compute, 1 = transform, 2 = loader
+  if (w == 9) { idx = 0; return 2; }
+  if (w == 5) { idx = 0; return 1; }
+  if (w == 11) { idx = 1; return 1; }
+  idx = w < 5 ? w : (w < 9 ? w - 1 : 8);                        // 0 1 2 3 4 | 6 7 8 -> 5 6 7 | 10 -> 8
+  return 0;
+}
+constexpr int kDwsProChunks = 5;     // 16-byte chunks per transform lane and row: chunks j * 128 + 64 * (transform wave) + lane
+
+// NI: 1 KiB DMA instructions per step row; D: rows in flight; EPI: out = ReLU6(conv * scale + shift) (inference), no statistics;
+// PRO: prologue form (the input is q of the previous block: BatchNorm-2 + ReLU6 [+ dropout: DROP] applied in LDS)
+template <int NI, int D, bool EPI, bool PRO, bool DROP = false>
+__global__ __launch_bounds__((kDwsMaxWaves + (PRO ? 3 : 1)) * 64) void dw_fwd_stream_kernel(DwsParams p) {
   constexpr int NR = D + 1, SLOT = NI * 1024;
   static_assert((D - 1) * NI <= 63, "vmcnt is a 6-bit counter");
+  static_assert(!(PRO && EPI), "the prologue form is the training form");
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ncw = (int)(blockDim.x >> 6) - 1;
+  const int wave0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ncw = PRO ? kDwsMaxWaves : (int)(blockDim.x >> 6) - 1;
+  int ridx = 0;
+  const int role = PRO ? dws_pro_role(wave0, ridx) : 0;
+  // `wave`: index of a compute wave among the compute waves; == ncw for the loader (the transform waves take their own branch first)
+  const int wave = PRO ? (role == 0 ? ridx : ncw) : wave0;
   const int img = blockIdx.x / p.nwgb, wb = blockIdx.x - img * p.nwgb;
   const int r0 = wb * p.NS * p.HB;                 // first output row of sub-band 0
   const int steps = p.HB + 2;                      // input rows r0-1 .. r0+HB of every sub-band
   const int zoff = NR * SLOT;                      // 16 zero bytes (the pixels left of x = 0 and right of x = W-1)
   if (tid < 4) reinterpret_cast<unsigned*>(lds + zoff)[tid] = 0u;
 
-  if (wave == ncw) {
+  if (PRO && role == 1) {
+    // ------------------------------------------------------------------ transform waves (prologue form)
+    const int cpp = p.C >> 3, rowcols = p.W * cpp;               // 16-byte chunks per pixel / per image row
+    int coff[kDwsProChunks]; bool cact[kDwsProChunks]; uint32_t grp[kDwsProChunks];
+#pragma unroll
+    for (int j = 0; j < kDwsProChunks; ++j) {
+      const int c = j * 128 + ridx * 64 + lane;
+      cact[j] = c < p.cols;
+      const int cc = cact[j] ? c : 0;
+      const int sub = cc / rowcols, within = cc - sub * rowcols;
+      coff[j] = cc * 16;
+      // dropout group (8 consecutive elements of x in NHWC order) of this chunk in step row 0: image row r0 + sub * HB - 1; 32-bit:
+      // the launcher takes maps of fewer than 2^32 groups (rows outside the image wrap around: their values are discarded)
+      grp[j] = (uint32_t)(((long)img * p.H + r0 + sub * p.HB - 1) * rowcols + within);
+    }
+    // 128 % cpp == 0 (launcher): every chunk of a lane holds the same channel octet
+    const int oct = (ridx * 64 + lane) % cpp;
+    f32x2_t sc[4], sh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sc[e] = (f32x2_t){p.pro_bn[2 * p.C + oct * 8 + 2 * e], p.pro_bn[2 * p.C + oct * 8 + 2 * e + 1]};
+      sh[e] = (f32x2_t){p.pro_bn[3 * p.C + oct * 8 + 2 * e], p.pro_bn[3 * p.C + oct * 8 + 2 * e + 1]};
+    }
+    const crnn_rng_key key = crnn_rng_make_key(p.seed, p.layer);
+    // (threshold and scale spelled as bn_act_pool_drop_kernel spells them: the same bits)
+    const uint32_t thr = DROP ? crnn_drop_threshold(p.rate) : 0u;
+    const float ik = DROP ? 1.f / (1.f - p.rate) : 1.f;
+    const f32x2_t ik2 = (f32x2_t){ik, ik};
+    uint32_t rowgrp = 0;                                         // t * rowcols (uniform)
+    // (DROP is a compile-time constant: with a run-time test inside, both forms are evaluated and selected per element)
+    auto xform = [&](int slot) {
+      unsigned char* sb = lds + slot * SLOT;
+      u32x4 v[kDwsProChunks];
+#pragma unroll
+      for (int j = 0; j < kDwsProChunks; ++j) v[j] = *reinterpret_cast<const u32x4*>(sb + coff[j]);
+#pragma unroll
+      for (int j = 0; j < kDwsProChunks; ++j) {
+        if (j * 128 + ridx * 64 >= p.cols) continue;             // (uniform) this wave has no chunk j
+        u32x4 o;
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        if (DROP) crnn_rng8(key, (uint64_t)(grp[j] + rowgrp), w);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x2_t x2 = (f32x2_t){__uint_as_float(v[j][q] << 16), __uint_as_float(v[j][q] & 0xffff0000u)};
+          f32x2_t y = __builtin_elementwise_fma(x2, sc[q], sh[q]);    // per element fmaf(x, scale, shift): v_pk_fma_f32
+          y = (f32x2_t){relu6f(y.x), relu6f(y.y)};
+          if (DROP) {
+            const f32x2_t ys = y * ik2;                            // per element y * inv_keep (v_pk_mul_f32), as the stand-alone pass
+            y = (f32x2_t){(w[q] & 0xffffu) >= thr ? ys.x : 0.f, (w[q] >> 16) >= thr ? ys.y : 0.f};
+          }
+          o[q] = pack2_bf16(y.x, y.y);
+        }
+        if (cact[j]) *reinterpret_cast<u32x4*>(sb + coff[j]) = o;
+      }
+      rowgrp += (uint32_t)rowcols;
+    };
+    __builtin_amdgcn_s_barrier();                                // P: row 0 has landed
+    xform(0);
+    int slot = 1;                                                // slot of row t + 1
+    for (int t = 0; t < steps; ++t) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                              // row t + 1 has landed; row t is transformed
+      if (t + 1 < steps) xform(slot);
+      slot = slot + 1 == NR ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (!EPI && p.partials) __builtin_amdgcn_s_barrier();
+  } else if (wave == ncw) {
     // ------------------------------------------------------------------ loader wave
     const unsigned char* gx = p.x + (long)img * p.H * p.rowbytes;
     int rowfirst[NI], within[NI];
@@ -80,8 +175,12 @@ __global__ __launch_bounds__((kDwsMaxWaves + 1) * 64) void dw_fwd_stream_kernel(
 #pragma unroll
     for (int t = 0; t < D; ++t) issue(t, t);
     int slot = D;                                              // slot of row t + D
+    if (PRO) {                                                 // the transform waves work one row ahead of the compute waves
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NI) : "memory");   // row 0 has landed
+      __builtin_amdgcn_s_barrier();
+    }
     for (int t = 0; t < steps; ++t) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NI) : "memory");   // row t has landed
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - (PRO ? 2 : 1)) * NI) : "memory");   // row t (prologue form: row t + 1) has landed
       __builtin_amdgcn_s_barrier();
       issue(t + D, slot);                                      // the slot row t-1 has just released
       slot = slot + 1 == NR ? 0 : slot + 1;
@@ -91,7 +190,7 @@ __global__ __launch_bounds__((kDwsMaxWaves + 1) * 64) void dw_fwd_stream_kernel(
     if (!EPI && p.partials) __builtin_amdgcn_s_barrier();
   } else {
     // ------------------------------------------------------------------ compute waves
-    const int col = wave * 64 + lane;
+    const int col = wave * 64 + lane;                          // also this thread's index among the compute threads
     const bool act = col < p.cols;
     const int ccol = act ? col : p.cols - 1;                   // idle lanes of the last wave shadow the last column
     const int cpp = p.C >> 3;                                  // 16-byte columns per pixel
@@ -114,6 +213,7 @@ __global__ __launch_bounds__((kDwsMaxWaves + 1) * 64) void dw_fwd_stream_kernel(
     float X0[8], X1[8], X2[8], s[8], ss[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { X0[e] = X1[e] = X2[e] = 0.f; s[e] = ss[e] = 0.f; }
+    if (PRO) __builtin_amdgcn_s_barrier();                     // P (the transform waves take row 0 now)
     const int rsub = r0 + sub * p.HB;                          // this lane's first output row
     unsigned char* orow = p.out + ((long)img * p.H + rsub) * p.rowbytes + px * pitch + oct * 16;
     // window-major output (EPI only; crnn_dwconv3x3_fwd_stream_ex out_order 1): pixel (y, x) is row ((y/2) (W/2) + x/2) 4 + (y&1) 2 + (x&1) of
@@ -200,7 +300,7 @@ __global__ __launch_bounds__((kDwsMaxWaves + 1) * 64) void dw_fwd_stream_kernel(
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         // wave w holds octets (64 w + lane) % cpp: with cpp < 64 every wave holds all of them, with cpp == 64 likewise (octet = lane)
-        for (int ch = tid; ch < 2 * p.C; ch += nthr) {
+        for (int ch = col; ch < 2 * p.C; ch += nthr) {
           const int c = ch < p.C ? ch : ch - p.C;
           const float* src = red + (c >> 3) * 16 + (ch < p.C ? 0 : 8) + (c & 7);
           float a = 0.f;
@@ -218,7 +318,7 @@ __global__ __launch_bounds__((kDwsMaxWaves + 1) * 64) void dw_fwd_stream_kernel(
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const int npx = p.NS * p.W;
-        for (int ch = tid; ch < 2 * p.C; ch += nthr) {            // ch < C: sum, else sum of squares; pixel columns in ascending order
+        for (int ch = col; ch < 2 * p.C; ch += nthr) {            // ch < C: sum, else sum of squares; pixel columns in ascending order
           const int c = ch < p.C ? ch : ch - p.C;
           const float* src = red + (c >> 3) * 16 + (ch < p.C ? 0 : 8) + (c & 7);
           float a = 0.f;
@@ -263,8 +363,23 @@ constexpr int kDwsD = CRNN_DWS_D;     // rows in flight per workgroup (2..7 meas
 template <bool EPI>
 int dws_launch(const DwsParams& p, const DwsGeom& g, int B, hipStream_t stream) {
   constexpr int lds = (kDwsD + 1) * 9 * 1024 + 64;
-  CRNN_LDS_ATTR((dw_fwd_stream_kernel<9, kDwsD, EPI>), lds);
-  hipLaunchKernelGGL((dw_fwd_stream_kernel<9, kDwsD, EPI>), dim3(B * g.nwgb), dim3((g.ncw + 1) * 64), lds, stream, p);
+  CRNN_LDS_ATTR((dw_fwd_stream_kernel<9, kDwsD, EPI, false>), lds);
+  hipLaunchKernelGGL((dw_fwd_stream_kernel<9, kDwsD, EPI, false>), dim3(B * g.nwgb), dim3((g.ncw + 1) * 64), lds, stream, p);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+// prologue form: one more row in flight (the transform waves need row t + 1 landed when the compute waves take row t)
+constexpr int kDwsProD = kDwsD + 1;
+bool dws_pro_ok(const DwsGeom& g, int B, int H, int W, int C) {
+  const int cpp = C / 8;
+  return g.ok && g.ncw == kDwsMaxWaves && cpp > 0 && 128 % cpp == 0 && g.cols <= kDwsProChunks * 128 &&
+         (long)B * H * W * cpp < (1L << 32);          // dropout groups counted in 32 bits
+}
+template <bool DROP>
+int dws_launch_pro(const DwsParams& p, const DwsGeom& g, int B, hipStream_t stream) {
+  constexpr int lds = (kDwsProD + 1) * 9 * 1024 + 64;
+  CRNN_LDS_ATTR((dw_fwd_stream_kernel<9, kDwsProD, false, true, DROP>), lds);
+  hipLaunchKernelGGL((dw_fwd_stream_kernel<9, kDwsProD, false, true, DROP>), dim3(B * g.nwgb), dim3((kDwsMaxWaves + 3) * 64), lds, stream, p);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
@@ -292,7 +407,27 @@ extern "C" int crnn_dwconv3x3_fwd_stream_ex(const void* x, const float* k, void*
   DwsParams p;
   p.x = (const unsigned char*)x; p.k = k; p.out = (unsigned char*)out; p.partials = bnstate ? nullptr : stat_partials; p.bnstate = bnstate;
   p.H = H; p.W = W; p.C = C; p.HB = g.HB; p.NS = g.NS; p.nwgb = g.nwgb; p.flip = flip; p.cols = g.cols; p.rowbytes = W * C * 2; p.wmaj = out_order;
+  p.pro_bn = nullptr; p.seed = 0; p.layer = 0; p.rate = 0.f;
   return bnstate ? dws_launch<true>(p, g, B, stream) : dws_launch<false>(p, g, B, stream);
+}
+// Prologue form (training): `q` is the previous block's pointwise output, pro_bnstate its BatchNorm-2 state [mean|var|scale|shift]; the
+// kernel convolves x = Dropout(ReLU6(q * scale + shift)) (rate, seed, layer: the dropout site of crnn_bn_act_pool_drop_ex) without x ever
+// existing in HBM.  out / stat_partials bit-identical to crnn_bn_act_pool_drop_ex(q -> x, ph = pw = 1) + crnn_dwconv3x3_fwd_stream(x).
+// CRNN_ERR_UNSUPPORTED where crnn_dwconv_fwd_stream_pro_supported says so (the caller materialises x).
+extern "C" int crnn_dwconv_fwd_stream_pro_supported(int B, int H, int W, int C) {
+  return dws_pro_ok(dws_geom(B, H, W, C), B, H, W, C) ? CRNN_OK : CRNN_ERR_UNSUPPORTED;
+}
+extern "C" int crnn_dwconv3x3_fwd_stream_pro(const void* q, const float* pro_bnstate, float rate, uint64_t seed, uint32_t layer, const float* k, void* out,
+                                             float* stat_partials, int B, int H, int W, int C, hipStream_t stream) {
+  if (!q || !pro_bnstate || !k || !out || rate < 0.f || rate >= 1.f) return CRNN_ERR_ARG;
+  DwsGeom g = dws_geom(B, H, W, C);
+  if (!dws_pro_ok(g, B, H, W, C) || (((uintptr_t)q | (uintptr_t)out | (uintptr_t)k | (uintptr_t)pro_bnstate) & 15)) return CRNN_ERR_UNSUPPORTED;
+  if ((long)H * W * C * 2 >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;
+  DwsParams p;
+  p.x = (const unsigned char*)q; p.k = k; p.out = (unsigned char*)out; p.partials = stat_partials; p.bnstate = nullptr;
+  p.H = H; p.W = W; p.C = C; p.HB = g.HB; p.NS = g.NS; p.nwgb = g.nwgb; p.flip = 0; p.cols = g.cols; p.rowbytes = W * C * 2; p.wmaj = 0;
+  p.pro_bn = pro_bnstate; p.seed = seed; p.layer = layer; p.rate = rate;
+  return rate > 0.f ? dws_launch_pro<true>(p, g, B, stream) : dws_launch_pro<false>(p, g, B, stream);
 }
 extern "C" int crnn_dwconv3x3_fwd_stream(const void* x, const float* k, void* out, float* stat_partials, const float* bnstate, int B, int H, int W,
                                          int C, int flip, hipStream_t stream) {

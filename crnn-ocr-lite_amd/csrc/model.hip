@@ -264,6 +264,26 @@ bool fuse_dw_bn_x3(const crnn_config* cfg, int dtd, int dtq, int ci) {
 bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
   return ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d)) & 15) == 0;
 }
+// Training with bf16 conv-stack tensors: the output x_i = Dropout(ReLU6(BatchNorm-2(q_i))) of an un-pooled block i (1, 2, 4, 6; utils.py:48-56) is
+// not materialised -- block i+1's depthwise row-stream kernels apply it to q_i after the rows have landed in LDS (forward:
+// crnn_dwconv3x3_fwd_stream_pro) and re-form it the same way for the depthwise weight gradient (backward: crnn_dwconv3x3_bwd_stream_pro): one write
+// and two read passes of x_i less per step.  ONE decision for both passes (the backward has no x_i to fall back to).
+// CRNN_FLAG_NO_BN2_DW_FUSION keeps crnn_bn_act_pool_drop_ex + the plain kernels; bit-identical.
+bool fuse_bn2_dw_shape(const crnn_config* cfg, const Dims& d, const Plan& P, int i) {
+  if (i < 1 || i > 6) return false;
+  if (cfg->flags & (CRNN_FLAG_NO_BN2_DW_FUSION | CRNN_FLAG_DW_TILE_KERNEL | CRNN_FLAG_NO_DW_BWD_FUSION)) return false;
+  if (cfg->mfma_bf16 != 2 || kBlocks[i - 1].ph * kBlocks[i - 1].pw != 1) return false;
+  const std::string p = std::to_string(i), n = std::to_string(i + 1);
+  if (P.dt("q" + p) != CRNN_BF16 || P.dt("x" + p) != CRNN_BF16 || P.dt("d" + n) != CRNN_BF16) return false;
+  const int H = d.bh[i + 1], W = d.bw[i + 1], C = d.bc[i];
+  return crnn_dwconv_fwd_stream_pro_supported(d.B, H, W, C) == CRNN_OK && crnn_dwconv_bwd_stream_pro_supported(d.B, H, W, C) == CRNN_OK &&
+         crnn_dwconv_bwd_fused_supported(H, W, C) == CRNN_OK;
+}
+bool fuse_bn2_dw(const Ctx& c, int i) {
+  if (!fuse_bn2_dw_shape(c.cfg, c.d, c.P, i)) return false;
+  const std::string p = std::to_string(i), n = std::to_string(i + 1);
+  return aligned16(c.w("q" + p), c.w("bn2s" + p), c.w("d" + n), c.p("b" + n + "_dw"));
+}
 // always-fp32 GEMM (spatial-transformer localisation net: tiny, and theta is precision-sensitive)
 int gemm32(const Ctx& c, int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
            const float* bias = nullptr, int act = 0, int acc = 0, int perm = 0) {
@@ -366,6 +386,13 @@ extern "C" int crnn_ws_tensor_info(const crnn_config* cfg, const char* name, lon
   if (dtype) *dtype = P.dt(name);
   return 0;
 }
+// 1 when training does not materialise the output x_block of conv block `block` (1..7): the next block's depthwise row-stream kernels form it
+// from q_block in LDS (CRNN_FLAG_NO_BN2_DW_FUSION; bf16-storage mode, un-pooled blocks, image width 32) -- the workspace tensor "x<block>" is
+// then never written by a training forward.  (16-byte aligned parameter / workspace base pointers assumed, as torch allocations are.)
+extern "C" int crnn_block_output_fused(const crnn_config* cfg, int block) {
+  if (check_cfg(cfg)) return 0;
+  return fuse_bn2_dw_shape(cfg, make_dims(cfg), make_plan(cfg), block) ? 1 : 0;
+}
 extern "C" int crnn_ws_tensor(const crnn_config* cfg, const char* name, long* offset, long* count) {
   Plan P = make_plan(cfg);
   long o = P.off(name);
@@ -411,6 +438,7 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
   }
   // ---- 7 depthwise-separable blocks (utils.py:43-56, 64-70)
   const float* in = c.w("x0");
+  const float* pro_q = nullptr; const float* pro_s2 = nullptr;   // pending BatchNorm-2 prologue of the next depthwise kernel (training, fuse_bn2_dw)
   int bn_off = 0;
   if (!train) {   // inference: every BatchNorm's [mean|var|scale|shift] is known before the first conv -- one launch for all 14
     const float *mm[14], *mv[14], *gg[14], *bb[14]; float* st[14]; int cc[14]; int n = 0, off = 0;
@@ -482,7 +510,11 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
       in = xo;
       continue;
     }
-    if (dws) {
+    if (pro_q) {   // the previous block's output was not materialised: its BatchNorm-2 + ReLU6 + dropout run inside this depthwise kernel (fuse_bn2_dw)
+      CRNN_TRY(crnn_dwconv3x3_fwd_stream_pro(pro_q, pro_s2, cfg->dropout ? kDropBlock : 0.f, seed, (uint32_t)(i - 1), c.p(bp + "_dw"), dd, parts, B, H, W, ci, stream));
+      CRNN_TRY(crnn_bn_finalize_folded(parts, crnn_dwconv_fwd_stream_rows(B, H, W, ci), ci, M, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), s1, c.w("fold"), stream));
+      pro_q = nullptr; pro_s2 = nullptr;
+    } else if (dws) {
       CRNN_TRY(crnn_dwconv3x3_fwd_stream(in, c.p(bp + "_dw"), dd, parts, nullptr, B, H, W, ci, 0, stream));
       CRNN_TRY(crnn_bn_finalize_folded(parts, crnn_dwconv_fwd_stream_rows(B, H, W, ci), ci, M, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), s1, c.w("fold"), stream));
     } else if (ci % 32 == 0 && ci % slab == 0) {
@@ -520,6 +552,10 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
     }
     CRNN_TRY(crnn_bn_finalize_folded(parts, stat_rows, co, M, c.p(bp + "_bn2_g"), c.p(bp + "_bn2_b"), s2, c.w("fold"), stream));
     bn_off += co;
+    if (fuse_bn2_dw(c, i)) {   // x_i is formed by block i+1's depthwise kernel from q_i (and again by its backward): not written
+      pro_q = qq; pro_s2 = s2; in = nullptr;
+      continue;
+    }
     CRNN_TRY(crnn_bn_act_pool_drop_ex(qq, s2, xo, B, H, W, co, ph, pw, cfg->dropout ? kDropBlock : 0.f, seed,
                                       (uint32_t)i, dtq, c.dt("x" + p), stream));
     in = xo;
@@ -911,7 +947,12 @@ int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t au
                                 c.w("coef"), B, H, W, ci, 1, 1, 0.f, 0, 0, dtd, stream));
       CRNN_TRY(fj.wait(gC_free)); gC_free = nullptr;      // gC is written next
       int rc = CRNN_ERR_UNSUPPORTED;
-      if (!(cfg->flags & CRNN_FLAG_DW_TILE_KERNEL))         // rows streamed through LDS where the shape rule holds (dwconv_bwd_stream.hip)
+      if (fuse_bn2_dw(c, i - 1)) {                           // the forward did not keep x_{i-1}: re-formed from q_{i-1} in LDS (no fallback: same decision)
+        const std::string pp = std::to_string(i - 1);
+        CRNN_TRY(crnn_dwconv3x3_bwd_stream_pro(c.w("d" + p), gA, c.w("bn1s" + p), c.w("coef"), c.w("q" + pp), c.w("bn2s" + pp), cfg->dropout ? kDropBlock : 0.f,
+                                               seed, (uint32_t)(i - 1), c.p(bp + "_dw"), gC, c.g(bp + "_dw"), c.w("partials"), B, H, W, ci, stream));
+        rc = CRNN_OK;
+      } else if (!(cfg->flags & CRNN_FLAG_DW_TILE_KERNEL))         // rows streamed through LDS where the shape rule holds (dwconv_bwd_stream.hip)
         rc = crnn_dwconv3x3_bwd_stream(c.w("d" + p), gA, c.w("bn1s" + p), c.w("coef"), xin, c.p(bp + "_dw"), gC, c.g(bp + "_dw"), c.w("partials"),
                                        B, H, W, ci, stream);
       if (rc == CRNN_ERR_UNSUPPORTED)

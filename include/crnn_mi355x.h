@@ -41,6 +41,9 @@ typedef struct {
                        conv-stack activations / gradients are stored as bf16 in HBM (statistics, RNN, CTC, optimizer fp32) */
   int flags;        /* bit set of CRNN_FLAG_* (0 = the default schedule); A/B switches: bit-identical results except where a flag says otherwise */
 } crnn_config;
+#define CRNN_FLAG_NO_BN2_DW_FUSION 1024 /* bf16-storage training: materialise every block output x = Dropout(ReLU6(BatchNorm-2(q))) (crnn_bn_act_pool_drop_ex) instead
+                                         * of letting the NEXT block's depthwise row-stream kernels apply it to q in LDS (crnn_dwconv3x3_fwd_stream_pro, forward;
+                                         * crnn_dwconv3x3_bwd_stream_pro re-forms it in backward) after the un-pooled blocks 1, 2, 4, 6; bit-identical */
 #define CRNN_FLAG_DW_TILE_KERNEL 32    /* bf16-storage modes: depthwise 3x3 forward and fused depthwise-stage backward on the halo-tile kernels
                                         * (crnn_dwconv3x3_fwd_ex, crnn_dwconv3x3_bwd_fused) instead of the row-stream kernels (crnn_dwconv3x3_fwd_stream,
                                         * crnn_dwconv3x3_bwd_stream); tensors bit-identical, BatchNorm statistics / depthwise weight gradients to
@@ -80,6 +83,9 @@ int  crnn_time_steps(const crnn_config* cfg);                 /* T = (imgh+4)/2 
 size_t crnn_workspace_bytes(const crnn_config* cfg);
 /* named view into the workspace (float offset, element count) -- for parity tests / debugging */
 int  crnn_ws_tensor(const crnn_config* cfg, const char* name, long* offset, long* count);
+/* 1 when a training forward does not materialise the output "x<block>" of conv block `block` (1..7): the next block's depthwise row-stream kernels
+ * form it from "q<block>" in LDS (see CRNN_FLAG_NO_BN2_DW_FUSION); else 0 */
+int  crnn_block_output_fused(const crnn_config* cfg, int block);
 /* same + storage type of the tensor (0 = fp32, 1 = bf16; offset stays in floats, count in elements) */
 int  crnn_ws_tensor_info(const crnn_config* cfg, const char* name, long* offset, long* count, int* dtype);
 
@@ -233,6 +239,14 @@ int crnn_dwconv3x3_fwd_stream(const void* x, const float* k, void* out, float* s
  * ((y/2) (W/2) + x/2) 4 + (y&1) 2 + (x&1) -- so that crnn_pwconv_fwd_wres_folded_pool(pool_rows = 4) can pool in its epilogue.  0: NHWC. */
 int crnn_dwconv3x3_fwd_stream_ex(const void* x, const float* k, void* out, float* stat_partials, const float* bnstate, int B, int H, int W, int C,
                                  int flip, int out_order, crnn_stream_t stream);
+/* Prologue form (training, round 4): `q` is the PREVIOUS block's pointwise output and pro_bnstate its BatchNorm-2 state [mean|var|scale|shift]; the
+ * kernel convolves x = Dropout(ReLU6(q * scale + shift)) (utils.py:48-56; rate / seed / layer = the dropout site of crnn_bn_act_pool_drop_ex), formed
+ * in LDS by two transform waves one row ahead of the compute waves -- the block output x never exists in HBM.  out / stat_partials bit-identical to
+ * crnn_bn_act_pool_drop_ex(q -> x, no pooling) + crnn_dwconv3x3_fwd_stream(x).  _supported: the stream shape rule, 128 % (C/8) == 0 and fewer than
+ * 2^32 dropout groups (B*H*W*C/8). */
+int crnn_dwconv_fwd_stream_pro_supported(int B, int H, int W, int C);
+int crnn_dwconv3x3_fwd_stream_pro(const void* q, const float* pro_bnstate, float rate, uint64_t seed, uint32_t layer, const float* k, void* out,
+                                  float* stat_partials, int B, int H, int W, int C, crnn_stream_t stream);
 /* n (<= 8) independent matrix transposes in one launch: out[i] [C_i][R_i] = in[i]^T, in[i] = src + in_off[i] (fp32
  * elements), out[i] = dst + out_off[i] (elements of dt_out: 0 fp32 | 1 bf16).  src / dst are device pointers; the four
  * descriptor arrays (in_off, out_off, R, C) are HOST arrays of n entries, copied into the kernel arguments. */
@@ -270,6 +284,13 @@ int crnn_dwconv_bwd_stream_supported(int B, int H, int W, int C);
 int crnn_dwconv_bwd_stream_rows(int B, int H, int W, int C);
 int crnn_dwconv3x3_bwd_stream(const void* d, const void* da, const float* bnstate, const float* coef, const void* xin, const float* k, void* dx,
                               float* dk, float* scratch, int B, int H, int W, int C, crnn_stream_t stream);
+/* Prologue form: `q` (in place of xin) is the previous block's pointwise output; x = Dropout(ReLU6(q * scale + shift)) is re-formed in LDS by the DX
+ * waves one row ahead (the forward did not keep it: crnn_dwconv3x3_fwd_stream_pro).  dx / dk bit-identical to crnn_dwconv3x3_bwd_stream on the
+ * materialised x. */
+int crnn_dwconv_bwd_stream_pro_supported(int B, int H, int W, int C);
+int crnn_dwconv3x3_bwd_stream_pro(const void* d, const void* da, const float* bnstate, const float* coef, const void* q, const float* pro_bnstate,
+                                  float rate, uint64_t seed, uint32_t layer, const float* k, void* dx, float* dk, float* scratch, int B, int H,
+                                  int W, int C, crnn_stream_t stream);
 int crnn_dwconv3x3_fwd(const float* x, const float* k, float* out, float* stat_partials, int B, int H, int W, int C,
                        int flip, crnn_stream_t stream);
 int crnn_dwconv3x3_wgrad(const float* x, const float* g, float* dk, float* scratch, int B, int H, int W, int C,

@@ -350,8 +350,8 @@ def test_bf16s_producer_fused_pointwise_convs_equal_the_two_pass_path(shape):
     x, lab, il, ll = M.synthetic_batch(cfg, B, seed=4, dtype=np.float64)
     out = {}
     T = native.FLAG_GEMM_TILE_KERNELS | native.FLAG_DW_TILE_KERNEL
-    for flags in (T, T | native.FLAG_NO_DW_BN_FUSION, T | native.FLAG_RNN_STEP_KERNELS, T | native.FLAG_NO_DW_BWD_FUSION, native.FLAG_DEFERRED_SUMS,
-                  native.FLAG_NO_BN_STATS_FUSION, 0):
+    for flags in (T, T | native.FLAG_NO_DW_BN_FUSION, T | native.FLAG_RNN_STEP_KERNELS, T | native.FLAG_NO_DW_BWD_FUSION, native.FLAG_NO_BN2_DW_FUSION,
+                  native.FLAG_DEFERRED_SUMS, native.FLAG_NO_BN_STATS_FUSION, 0):
         eng = Engine(B, imgh, imgw, ncls, max_len, tds, u, stn=True, dropout=True, precision="bf16s", flags=flags)
         eng.set_params(p, bn)
         eng.ws.fill_(float("nan")); eng.grads.zero_()
@@ -372,7 +372,11 @@ def test_bf16s_producer_fused_pointwise_convs_equal_the_two_pass_path(shape):
     # stage (CRNN_FLAG_DEFERRED_SUMS): the same sums in the same order
     yc, lc, gc = out[native.FLAG_DEFERRED_SUMS]
     assert torch.equal(yc, yb) and torch.equal(lc, lb) and torch.equal(gc, gb), "deferred second stages changed the gradients"
-    for flags in list(out)[1:-3]:
+    # block outputs formed inside the next block's depthwise row-stream kernels (default where the shape rules hold: image width 32) or
+    # materialised by crnn_bn_act_pool_drop_ex (CRNN_FLAG_NO_BN2_DW_FUSION): same arithmetic, same summation orders -- everything bit-identical
+    yd, ld, gd_ = out[native.FLAG_NO_BN2_DW_FUSION]
+    assert torch.equal(yd, yb) and torch.equal(ld, lb) and torch.equal(gd_, gb), "BatchNorm-2 prologue fusion changed the results"
+    for flags in list(out)[1:-4]:
         y1, l1, g1 = out[flags]
         assert torch.isfinite(g1).all() and torch.equal(y0, y1) and torch.equal(l0, l1), flags
         if flags != T | native.FLAG_NO_DW_BWD_FUSION:

@@ -848,6 +848,89 @@ def test_row_stream_depthwise_equals_the_halo_tile_kernel(B, H, W, C):
     assert torch.equal(o1.view(torch.int16), o2.view(torch.int16))
 
 
+@pytest.mark.parametrize("B,H,W,C", [(3, 104, 36, 64), (2, 104, 36, 128), (5, 52, 18, 256), (2, 52, 9, 512), (256, 52, 9, 512), (70, 104, 36, 64)])
+@pytest.mark.parametrize("rate", [0.1, 0.0])
+def test_row_stream_depthwise_with_the_batchnorm2_prologue_equals_the_two_pass_path(B, H, W, C, rate):
+    """crnn_dwconv3x3_fwd_stream_pro / crnn_dwconv3x3_bwd_stream_pro: the previous block's BatchNorm-2 + ReLU6 + Dropout(.1) (utils.py:48-56)
+    applied to its pointwise output q inside the depthwise row-stream kernels (LDS, one row ahead) instead of by crnn_bn_act_pool_drop_ex
+    writing x: depthwise outputs, BatchNorm-1 statistic partials, data gradient and depthwise weight gradient are bit-identical to the
+    two-pass path on the materialised x.  The CRNN's un-pooled block outputs (inputs of blocks 2, 3, 5, 7); one band per workgroup
+    (batch 256) and several; with and without dropout; memory around the outputs untouched."""
+    assert L().crnn_dwconv_fwd_stream_pro_supported(B, H, W, C) == 0 and L().crnn_dwconv_bwd_stream_pro_supported(B, H, W, C) == 0
+    rs = np.random.RandomState(B + H + W + C)
+    n = B * H * W * C
+    qd = (torch.randn(n, device="cuda", generator=torch.Generator("cuda").manual_seed(n % 1000)) * 1.5).to(torch.bfloat16)
+    k = rs.normal(size=(3, 3, C)); kd = dev(k)
+    st2 = dev(np.concatenate([rs.normal(size=C), 1 + rs.uniform(size=C), 1 + 0.5 * rs.normal(size=C), 1.5 * rs.normal(size=C) + 1.5]))
+    seed, layer = 77, 4
+    xd = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+    ok(L().crnn_bn_act_pool_drop_ex(P(qd), P(st2), P(xd), B, H, W, C, 1, 1, rate, seed, layer, 1, 1, S()))
+    xf = xd.float()
+    assert float((xf == 0).float().mean()) > (0.08 if rate > 0 else 0.0) and float((xf > 6.0).float().mean()) > (1e-3 if rate > 0 else -1)
+    # ---- forward
+    rows = L().crnn_dwconv_fwd_stream_rows(B, H, W, C)
+    o1 = torch.zeros(n, dtype=torch.bfloat16, device="cuda"); p1 = zeros(rows, 2, C)
+    ok(L().crnn_dwconv3x3_fwd_stream(P(xd), P(kd), P(o1), P(p1), None, B, H, W, C, 0, S()))
+    o2 = torch.full((n + 64,), 7.0, dtype=torch.bfloat16, device="cuda"); p2 = torch.full((rows + 1, 2, C), 3.0, device="cuda")
+    ok(L().crnn_dwconv3x3_fwd_stream_pro(P(qd), P(st2), rate, seed, layer, P(kd), P(o2), P(p2), B, H, W, C, S()))
+    assert torch.equal(o2[:-64].view(torch.int16), o1.view(torch.int16)), "d: max diff %g" % float((o2[:-64].float() - o1.float()).abs().max())
+    assert torch.equal(p2[:rows], p1) and bool((o2[-64:] == 7.0).all()) and bool((p2[rows] == 3.0).all())
+    o3 = torch.zeros(n, dtype=torch.bfloat16, device="cuda"); p3 = zeros(rows, 2, C)
+    ok(L().crnn_dwconv3x3_fwd_stream_pro(P(qd), P(st2), rate, seed, layer, P(kd), P(o3), P(p3), B, H, W, C, S()))
+    assert torch.equal(o3, o2[:-64]) and torch.equal(p3, p1), "repeat launches differ"
+    # another dropout site / seed gives another mask
+    if rate > 0:
+        ok(L().crnn_dwconv3x3_fwd_stream_pro(P(qd), P(st2), rate, seed + 1, layer, P(kd), P(o3), P(p3), B, H, W, C, S()))
+        assert not torch.equal(o3, o1)
+    # ---- backward of the consuming depthwise stage
+    dd = o1                                                     # d = dwconv(x)
+    dad = (torch.randn(n, device="cuda", generator=torch.Generator("cuda").manual_seed(5)) * 0.7).to(torch.bfloat16)
+    M = B * H * W
+    dh = dd.float().view(M, C).double()
+    mean, var = dh.mean(0).cpu().numpy(), dh.var(0, unbiased=False).cpu().numpy()
+    gamma, beta = rs.normal(size=C) * 0.3 + 1.0, rs.normal(size=C) * 0.5 + 1.0
+    scale = gamma / np.sqrt(var + 1e-3)
+    st1 = dev(np.concatenate([mean, var, scale, beta - mean * scale]))
+    coef = dev(np.concatenate([rs.normal(size=C) * 1e-3, rs.normal(size=C) * 1e-3]))
+    brow = L().crnn_dwconv_bwd_stream_rows(B, H, W, C)
+    dx1 = torch.zeros(n, dtype=torch.bfloat16, device="cuda"); dk1 = zeros(9, C); sc = zeros(brow * 9 * C)
+    ok(L().crnn_dwconv3x3_bwd_stream(P(dd), P(dad), P(st1), P(coef), P(xd), P(kd), P(dx1), P(dk1), P(sc), B, H, W, C, S()))
+    dx2 = torch.full((n + 64,), 9.0, dtype=torch.bfloat16, device="cuda"); dk2 = zeros(9, C); sc2 = torch.full((brow * 9 * C + 16,), 5.0, device="cuda")
+    ok(L().crnn_dwconv3x3_bwd_stream_pro(P(dd), P(dad), P(st1), P(coef), P(qd), P(st2), rate, seed, layer, P(kd), P(dx2), P(dk2), P(sc2), B, H, W, C, S()))
+    assert torch.equal(dx2[:-64].view(torch.int16), dx1.view(torch.int16)), "dx: max diff %g" % float((dx2[:-64].float() - dx1.float()).abs().max())
+    assert torch.equal(dk2, dk1), "dk: max diff %g" % float((dk2 - dk1).abs().max())
+    assert bool((dx2[-64:] == 9.0).all()) and bool((sc2[-16:] == 5.0).all())
+    assert float(dk1.abs().max()) > 0
+
+
+def test_dropout_rng_statistics():
+    """The counter-based dropout RNG (csrc/common.h: three ChaCha quarter-rounds per group of 8 elements): the kept fraction matches the
+    rate, masks of different seeds / dropout sites are independent, neighbouring elements and channel strides are uncorrelated."""
+    n = 1 << 22
+    rate = 0.1
+    ms = []
+    for seed, layer in ((1, 1), (1, 2), (2, 1), (2 ** 40 + 3, 7)):
+        m = zeros(n)
+        ok(L().crnn_dropout_mask(P(m), n, rate, seed, layer, S()))
+        vals = torch.unique(m)
+        assert vals.numel() == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1 / 0.9) < 1e-6
+        ms.append((m > 0).float())
+        frac = 1.0 - float(ms[-1].mean())
+        assert abs(frac - rate) < 4 * np.sqrt(rate * 0.9 / n) + 2e-5, (seed, layer, frac)     # floor(rate * 65536) / 65536 = 0.09999
+    sd = rate * 0.9
+    for a in range(len(ms)):
+        for b in range(a + 1, len(ms)):
+            cov = float(((ms[a] - 0.9) * (ms[b] - 0.9)).mean()) / sd
+            assert abs(cov) < 5 / np.sqrt(n), (a, b, cov)
+    d = ms[0] - 0.9
+    for stride in (1, 2, 3, 7, 8, 64, 128, 512, 4608, 36 * 512):
+        cov = float((d[:-stride] * d[stride:]).mean()) / sd
+        assert abs(cov) < 5 / np.sqrt(n), (stride, cov)
+    m0 = zeros(64)
+    ok(L().crnn_dropout_mask(P(m0), 64, 0.0, 1, 1, S()))
+    assert bool((m0 == 1).all())
+
+
 def test_row_stream_depthwise_refuses_other_shapes():
     for B, H, W, C in [(2, 104, 40, 128), (2, 13, 18, 64), (2, 52, 18, 252), (2, 51, 9, 256)]:
         assert L().crnn_dwconv_fwd_stream_supported(B, H, W, C) == -3 and L().crnn_dwconv_fwd_stream_rows(B, H, W, C) == 0
