@@ -1300,6 +1300,46 @@ extern "C" int crnn_dropout_mask(float* m, long n, float rate, uint64_t seed, ui
   return CRNN_OK;
 }
 
+// Keep bits of a dropout site, one BYTE per group of 8 consecutive elements (bit e: element 8 g + e is kept) -- what drop_scale /
+// drop_scale_vec decide, in the form the prologue row-stream depthwise kernels read (dwconv_stream.hip, dwconv_bwd_stream.hip): the mask
+// depends on (seed, site, index) only, so it is evaluated once per step here -- four groups per thread, their dropout words side by side --
+// instead of once per consumer pass inside kernels whose transform waves have no spare issue slots (36 of ~100 operations per group).
+__global__ __launch_bounds__(256) void dropout_keep_bytes_kernel(unsigned* __restrict__ out, long nwords, long ngroups, uint32_t thr, uint64_t seed, uint32_t layer) {
+  const crnn_rng_key key = crnn_rng_make_key(seed, layer);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nwords; i += (long)gridDim.x * blockDim.x) {
+    uint32_t w[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) crnn_rng8(key, (uint64_t)(4 * i + j), w[j]);
+    unsigned v = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned m = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        m |= ((w[j][q] & 0xffffu) >= thr ? 1u : 0u) << (2 * q);
+        m |= ((w[j][q] >> 16) >= thr ? 1u : 0u) << (2 * q + 1);
+      }
+      if (4 * i + j >= ngroups) m = 0;
+      v |= m << (8 * j);
+    }
+    out[i] = v;
+  }
+}
+// out: 4-byte aligned, (ngroups + 3) / 4 * 4 bytes are written (the tail bytes of the last word are zero); rate <= 0: every element kept (0xFF)
+extern "C" int crnn_dropout_keep_bytes(void* out, long ngroups, float rate, uint64_t seed, uint32_t layer, hipStream_t stream) {
+  if (!out || ngroups < 0 || rate >= 1.f || ((uintptr_t)out & 3)) return CRNN_ERR_ARG;
+  if (ngroups == 0) return CRNN_OK;
+  const long nwords = (ngroups + 3) / 4;
+  if (rate <= 0.f) {
+    hipError_t e = hipMemsetAsync(out, 0xFF, (size_t)nwords * 4, stream);
+    return e == hipSuccess ? CRNN_OK : (int)e;
+  }
+  long blocks = (nwords + 255) / 256; if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(dropout_keep_bytes_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (unsigned*)out, nwords, ngroups, crnn_drop_threshold(rate), seed, layer);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+
 // g_out[perm(r)][c] = g[r][c] * [y[r][c] > 0]      (backward of ReLU, and of Dropout∘ReLU when y is the
 // dropped activation: the 1/(1-p) factor is passed as `scale`).  permP as in the GEMM epilogue.
 __global__ void relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ g, float* __restrict__ go,

@@ -16,8 +16,11 @@
 // (wave w runs on SIMD w mod 4).  Nothing is re-read: 4 tensor passes of HBM traffic (+ 2 halo rows per band), one barrier per row.
 //
 // PROLOGUE form (round 4): `xin` is the previous block's pointwise output q -- the block output x = Dropout(ReLU6(BatchNorm-2(q)))
-// (utils.py:48-56) is not kept by the forward (dwconv_stream.hip) and is re-formed here, bit for bit, one row ahead by the DX waves
-// (the lighter group) into a two-row LDS buffer the DK waves take their weight-gradient operand from; one more stage in flight.
+// (utils.py:48-56) is not kept by the forward (dwconv_stream.hip) and is re-formed here, bit for bit, one row ahead into a two-row LDS
+// buffer the DK waves take their weight-gradient operand from; one more stage in flight.  The re-forming (~65 VALU operations per
+// 16-byte chunk; the dropout decisions come as keep bytes, crnn_dropout_keep_bytes, which the loader wave brings along) is done by
+// the DX waves, each for its own column: spread over five waves it fits next to their ~70 operations per step, where one dedicated
+// wave for all five column groups became the critical path (profiles/r04_*: + 23 % kernel time).
 #include "common.h"
 
 namespace {
@@ -36,7 +39,7 @@ struct DbsParams {
   const unsigned char *d, *da, *xin; unsigned char* dx; const float *bnstate, *coef, *k; float* partials;
   int H, W, C, HB, nwgb, nsplit, cols, cppw, rowbytes;
   // prologue form: xin = q of the previous block, its BatchNorm-2 state [mean|var|scale|shift] and dropout site
-  const float* pro_bn; uint64_t seed; uint32_t layer; float rate;
+  const float* pro_bn; const unsigned char* keep; float rate;
 };
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
@@ -62,7 +65,8 @@ struct DbsLds {
   static constexpr int CstOff = ZOff + 64;          // BatchNorm constants of the workgroup's channels: scale | shift | P | Q, [4][<= 256] floats
   static constexpr int XtOff = CstOff + 4 * 256 * 4;   // prologue form: two rows of x = Dropout(ReLU6(BatchNorm-2(q)))
   static constexpr int PcOff = XtOff + 2 * kSub;       // prologue form: BatchNorm-2 scale | shift of the workgroup's channels, [2][<= 256] floats
-  static constexpr int Total = PcOff + 2 * 256 * 4;
+  static constexpr int KeepOff = PcOff + 2 * 256 * 4;  // prologue form: NR x 512 bytes of keep bytes (one per 16-byte chunk of the stage's xin row)
+  static constexpr int Total = KeepOff + NR * 512;
   static_assert((KD - 1) * kNI <= 63, "vmcnt is a 6-bit counter");
 };
 constexpr int kD = CRNN_DBS_D;
@@ -80,7 +84,9 @@ __device__ __forceinline__ int role_of(int w, int& idx) {   // 0 = DK, 1 = DX, 2
 template <int KD, bool PRO, bool DROP>
 __global__ __launch_bounds__(704) void dw_bwd_stream_kernel(DbsParams p) {
   typedef DbsLds<KD> LP;
-  constexpr int kNR = LP::NR, kDdOff = LP::DdOff, kZOff = LP::ZOff, kCstOff = LP::CstOff, kXtOff = LP::XtOff, kPcOff = LP::PcOff;
+  constexpr int kNR = LP::NR, kDdOff = LP::DdOff, kZOff = LP::ZOff, kCstOff = LP::CstOff, kXtOff = LP::XtOff, kPcOff = LP::PcOff, kKeepOff = LP::KeepOff;
+  constexpr int kNIT = kNI + (DROP ? 2 : 0);           // DMA instructions per stage
+  static_assert((KD - 1) * kNIT <= 63, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -105,6 +111,18 @@ __global__ __launch_bounds__(704) void dw_bwd_stream_kernel(DbsParams p) {
       goff[i] = px * p.C * 2 + c0 * 2 + o * 16;
     }
     const unsigned char* gd = p.d + imgoff; const unsigned char* gg = p.da + imgoff; const unsigned char* gxx = p.xin + imgoff;
+    // prologue form with dropout: the keep bytes of the stage's xin row for this workgroup's columns, 4 bytes (4 columns of one pixel) per lane
+    const int cpp = p.C >> 3, rowcols = p.W * cpp;
+    int koff[2];
+    const unsigned char* gk = DROP ? p.keep + (long)img * p.H * rowcols : nullptr;
+    if (DROP) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int c4 = (i * 64 + lane) * 4; if (c4 >= p.cols) c4 = p.cols - 4;
+        const int px = c4 / p.cppw, o = c4 - px * p.cppw;
+        koff[i] = px * cpp + split * p.cppw + o;
+      }
+    }
     auto issue = [&](int s, int slot) {
       s = s < nsteps ? s : nsteps - 1;
       int rd = r0 - 1 + s; rd = rd < 0 ? 0 : (rd >= p.H ? p.H - 1 : rd);
@@ -119,12 +137,18 @@ __global__ __launch_bounds__(704) void dw_bwd_stream_kernel(DbsParams p) {
           glds16(gxx + ox + goff[i], dst + 2 * kSub + i * 1024);
         }
       }
+      if (DROP) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gk + (long)rx * rowcols + koff[i]),
+                                           (__attribute__((address_space(3))) void*)(lds + kKeepOff + slot * 512 + i * 256), 4, 0, 0);
+      }
     };
 #pragma unroll
     for (int s = 0; s < KD; ++s) issue(s, s);
     int slot = KD;
     for (int s = 0; s < nsteps; ++s) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((KD - (PRO ? 2 : 1)) * kNI) : "memory");   // stage s (prologue form: s + 1) has landed
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((KD - (PRO ? 2 : 1)) * kNIT) : "memory");   // stage s (prologue form: s + 1) has landed
       __builtin_amdgcn_s_barrier();
       issue(s + KD, slot);
       slot = slot + 1 == kNR ? 0 : slot + 1;
@@ -134,7 +158,6 @@ __global__ __launch_bounds__(704) void dw_bwd_stream_kernel(DbsParams p) {
     __builtin_amdgcn_s_barrier();
     return;
   }
-
   const int col = gidx * 64 + lane;
   const bool act = col < p.cols;
   const int ccol = act ? col : p.cols - 1;
@@ -157,41 +180,36 @@ __global__ __launch_bounds__(704) void dw_bwd_stream_kernel(DbsParams p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) X0[e] = X1[e] = X2[e] = 0.f;
     unsigned char* orow = p.dx + imgoff + (long)r0 * p.rowbytes + px * p.C * 2 + ch0 * 2;
-    // prologue form: re-form x of the stage that arrived one step ahead (own column) into the two-row buffer the DK waves read
-    // (the 16 BatchNorm-2 constants of the lane's channels sit in LDS and are read per step: kw + the running rows fill the registers)
-    uint32_t pgrp = 0;                                // dropout group of this column's chunk in stage 0 (image row r0 - 2)
-    const uint32_t prow = (uint32_t)(p.W * (p.C >> 3));
+    // prologue form: re-form x = Dropout(ReLU6(q * scale + shift)) of the stage that arrived one step ahead (own column) into the two-row
+    // buffer the DK waves read; bn_act_pool_drop_kernel's arithmetic bit for bit.  (The 16 BatchNorm-2 constants of the lane's channels
+    // sit in LDS and are read per step: kw and the running rows fill the registers.)
     const int pcw = p.cppw * 8;                       // channels of this workgroup
     float* pct = reinterpret_cast<float*>(lds + kPcOff);
-    if (PRO) {
+    if (PRO)
       for (int i = gidx * 64 + lane; i < pcw; i += kCW * 64) { pct[i] = p.pro_bn[2 * p.C + c0 + i]; pct[pcw + i] = p.pro_bn[3 * p.C + c0 + i]; }
-      pgrp = (uint32_t)((((long)img * p.H + r0 - 2) * p.W + px) * (p.C >> 3) + (ch0 >> 3));
-    }
     const float* pcl = pct + oct * 8;
-    const crnn_rng_key pkey = crnn_rng_make_key(p.seed, p.layer);
-    const uint32_t pthr = DROP ? crnn_drop_threshold(p.rate) : 0u;
     const float pik = DROP ? 1.f / (1.f - p.rate) : 1.f;
-    int xslot = 1;                                    // ring slot of stage `st`
+    int xslot = 1;                                    // ring slot of the next stage to re-form (stage 1 first)
     auto xform = [&](int st) {                        // stage st: xin row r0 - 2 + st  ->  xt[st & 1]
       const u32x4 v = *reinterpret_cast<const u32x4*>(lds + xslot * kStageB + 2 * kSub + offC);
+      uint32_t kc = 0xffu;
+      if (DROP) kc = lds[kKeepOff + xslot * 512 + ccol];
       xslot = xslot + 1 == kNR ? 0 : xslot + 1;
-      const float4 s0 = *reinterpret_cast<const float4*>(pcl), s1 = *reinterpret_cast<const float4*>(pcl + 4);
-      const float4 h0 = *reinterpret_cast<const float4*>(pcl + pcw), h1 = *reinterpret_cast<const float4*>(pcl + pcw + 4);
-      const f32x2_t psc[4] = {{s0.x, s0.y}, {s0.z, s0.w}, {s1.x, s1.y}, {s1.z, s1.w}};
-      const f32x2_t psh[4] = {{h0.x, h0.y}, {h0.z, h0.w}, {h1.x, h1.y}, {h1.z, h1.w}};
-      uint32_t w[4] = {0u, 0u, 0u, 0u};
-      if (DROP) crnn_rng8(pkey, (uint64_t)(pgrp + (uint32_t)st * prow), w);
       u32x4 o;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x2_t x2 = (f32x2_t){__uint_as_float(v[q] << 16), __uint_as_float(v[q] & 0xffff0000u)};
-        f32x2_t y = __builtin_elementwise_fma(x2, psc[q], psh[q]);
+        const f32x2_t psc = *reinterpret_cast<const f32x2_t*>(pcl + 2 * q), psh = *reinterpret_cast<const f32x2_t*>(pcl + pcw + 2 * q);
+        f32x2_t y = __builtin_elementwise_fma(x2, psc, psh);
         y = (f32x2_t){relu6f(y.x), relu6f(y.y)};
         if (DROP) {
-          const f32x2_t ys = y * (f32x2_t){pik, pik};
-          y = (f32x2_t){(w[q] & 0xffffu) >= pthr ? ys.x : 0.f, (w[q] >> 16) >= pthr ? ys.y : 0.f};
+          y = y * (f32x2_t){pik, pik};
+          // dropped elements as an AND mask on the packed pair (y >= 0: y * 0 and 0 are the same bits)
+          const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe((int)kc, 2 * q, 1), hi = (uint32_t)__builtin_amdgcn_sbfe((int)kc, 2 * q + 1, 1);
+          o[q] = pack2_bf16(y.x, y.y) & __builtin_amdgcn_perm(hi, lo, 0x07060100u);
+        } else {
+          o[q] = pack2_bf16(y.x, y.y);
         }
-        o[q] = pack2_bf16(y.x, y.y);
       }
       if (act) *reinterpret_cast<u32x4*>(lds + kXtOff + (st & 1) * kSub + offC) = o;
       __builtin_amdgcn_sched_barrier(0);              // its temporaries are dead before the correlation's operands are loaded
@@ -428,31 +446,32 @@ extern "C" int crnn_dwconv3x3_bwd_stream(const void* d, const void* da, const fl
   p.d = (const unsigned char*)d; p.da = (const unsigned char*)da; p.xin = (const unsigned char*)xin; p.dx = (unsigned char*)dx;
   p.bnstate = bnstate; p.coef = coef; p.k = k; p.partials = scratch;
   p.H = H; p.W = W; p.C = C; p.HB = g.HB; p.nwgb = g.nwgb; p.nsplit = g.nsplit; p.cols = g.cols; p.cppw = g.cppw; p.rowbytes = W * C * 2;
-  p.pro_bn = nullptr; p.seed = 0; p.layer = 0; p.rate = 0.f;
+  p.pro_bn = nullptr; p.keep = nullptr; p.rate = 0.f;
   CRNN_LDS_ATTR((dw_bwd_stream_kernel<kD, false, false>), DbsLds<kD>::XtOff);
   hipLaunchKernelGGL((dw_bwd_stream_kernel<kD, false, false>), dim3(B * g.nwgb * g.nsplit), dim3(704), DbsLds<kD>::XtOff, stream, p);
   CRNN_LAUNCH_CHECK();
   return crnn_partials_sum(scratch, B * g.nwgb, 9 * C, dk, 1.f, stream);
 }
-// Prologue form: xin = q of the previous block ([B,H,W,C] bf16), pro_bnstate = its BatchNorm-2 state, (rate, seed, layer) = the dropout site of
-// its output (crnn_bn_act_pool_drop_ex): x = Dropout(ReLU6(q * scale + shift)) is re-formed in LDS instead of read.  dx / dk bit-identical to
+// Prologue form: xin = q of the previous block ([B,H,W,C] bf16), pro_bnstate = its BatchNorm-2 state, keep = the keep bytes of the dropout site of
+// its output (crnn_dropout_keep_bytes; NULL allowed when rate == 0): x = Dropout(ReLU6(q * scale + shift)) is re-formed in LDS instead of read.  dx / dk bit-identical to
 // crnn_dwconv3x3_bwd_stream on the materialised x.  Same shape rule + fewer than 2^32 dropout groups (B*H*W*C/8).
 extern "C" int crnn_dwconv_bwd_stream_pro_supported(int B, int H, int W, int C) {
-  return (dbs_geom(B, H, W, C).ok && (long)B * H * W * (C / 8) < (1L << 32)) ? CRNN_OK : CRNN_ERR_UNSUPPORTED;
+  const DbsGeom g = dbs_geom(B, H, W, C);       // (+ the keep bytes of a stage travel as whole dwords: 4 columns of one pixel)
+  return (g.ok && g.cppw % 4 == 0 && g.cols % 4 == 0 && (W * (C / 8)) % 4 == 0 && (long)B * H * W * (C / 8) < (1L << 31)) ? CRNN_OK : CRNN_ERR_UNSUPPORTED;
 }
 extern "C" int crnn_dwconv3x3_bwd_stream_pro(const void* d, const void* da, const float* bnstate, const float* coef, const void* q, const float* pro_bnstate,
-                                             float rate, uint64_t seed, uint32_t layer, const float* k, void* dx, float* dk, float* scratch, int B, int H,
+                                             float rate, const void* keep, const float* k, void* dx, float* dk, float* scratch, int B, int H,
                                              int W, int C, hipStream_t stream) {
-  if (!d || !da || !bnstate || !coef || !q || !pro_bnstate || !k || !dx || !dk || !scratch || rate < 0.f || rate >= 1.f) return CRNN_ERR_ARG;
+  if (!d || !da || !bnstate || !coef || !q || !pro_bnstate || !k || !dx || !dk || !scratch || rate < 0.f || rate >= 1.f || (rate > 0.f && !keep)) return CRNN_ERR_ARG;
   const DbsGeom g = dbs_geom(B, H, W, C);
-  if (!g.ok || (long)B * H * W * (C / 8) >= (1L << 32)) return CRNN_ERR_UNSUPPORTED;
-  if ((((uintptr_t)d | (uintptr_t)da | (uintptr_t)q | (uintptr_t)dx | (uintptr_t)bnstate | (uintptr_t)coef | (uintptr_t)k | (uintptr_t)pro_bnstate) & 15)) return CRNN_ERR_UNSUPPORTED;
+  if (crnn_dwconv_bwd_stream_pro_supported(B, H, W, C) != CRNN_OK) return CRNN_ERR_UNSUPPORTED;
+  if ((((uintptr_t)d | (uintptr_t)da | (uintptr_t)q | (uintptr_t)dx | (uintptr_t)bnstate | (uintptr_t)coef | (uintptr_t)k | (uintptr_t)pro_bnstate) & 15) || ((uintptr_t)keep & 3)) return CRNN_ERR_UNSUPPORTED;
   if ((long)H * W * C * 2 >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;
   DbsParams p;
   p.d = (const unsigned char*)d; p.da = (const unsigned char*)da; p.xin = (const unsigned char*)q; p.dx = (unsigned char*)dx;
   p.bnstate = bnstate; p.coef = coef; p.k = k; p.partials = scratch;
   p.H = H; p.W = W; p.C = C; p.HB = g.HB; p.nwgb = g.nwgb; p.nsplit = g.nsplit; p.cols = g.cols; p.cppw = g.cppw; p.rowbytes = W * C * 2;
-  p.pro_bn = pro_bnstate; p.seed = seed; p.layer = layer; p.rate = rate;
+  p.pro_bn = pro_bnstate; p.keep = (const unsigned char*)keep; p.rate = rate;
   constexpr int KD = kD + 1;
   if (rate > 0.f) {
     CRNN_LDS_ATTR((dw_bwd_stream_kernel<KD, true, true>), DbsLds<KD>::Total);

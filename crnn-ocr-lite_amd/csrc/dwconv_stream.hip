@@ -18,11 +18,15 @@
 //
 // PROLOGUE form (round 4, training): the input is the PREVIOUS block's pointwise output q and the kernel applies that block's
 // BatchNorm-2 + ReLU6 + Dropout(.1) (utils.py:48-56: x = drop(relu6(q * scale + shift)), the arithmetic of bn_act_pool_drop_kernel
-// bit for bit, dropout mask re-derived from (seed, site, element index)) to every row after it has landed in LDS -- the block output x
-// is never written to or read from HBM (one read pass + one write pass of the largest tensors of the step less per un-pooled block).
-// Two TRANSFORM waves rewrite the row that arrived one step ahead in place (own 16-byte chunks, bf16 again) while the compute waves
-// work on the current row; the ring is one slot deeper so that as many rows stay in flight.  The 12 waves are dealt over the SIMDs
-// (wave w runs on SIMD w mod 4) so that the transform waves share theirs with fewer compute waves.
+// bit for bit) to every row after it has landed in LDS -- the block output x is never written to or read from HBM (one read pass +
+// one write pass of the largest tensors of the step less per un-pooled block).  Every compute wave rewrites ITS OWN 16-byte chunk of
+// the row that arrived one step ahead (in place, bf16 again) before it works on the current row; the ring is one slot deeper so
+// that as many rows stay in flight.  The dropout decisions arrive as one keep byte per chunk (crnn_dropout_keep_bytes), brought
+// into LDS by the loader wave next to the row.  How it got there (profiles/r04_*): two dedicated transform waves that also
+// evaluated the counter RNG: +60 % kernel time (a wave issues one VALU operation per 4 cycles: the ~100 operations per chunk x 5
+// chunks per lane outlast the row's 2400-cycle HBM budget; interleaving the five RNG chains changed nothing -- issue, not latency);
+// keep bytes instead of the RNG: +30 %; the same work spread over the nine compute waves (~65 operations more per wave and row): see
+// the bench.
 #include "common.h"
 
 namespace {
@@ -30,14 +34,14 @@ namespace {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef CRNN_DWS_EXP
-#define CRNN_DWS_EXP 0      // experiment builds: 1 = no DMA, 2 = no stores, 4 = no fmas, 8 = nontemporal stores, 16 = nontemporal loads
+#define CRNN_DWS_EXP 0      // experiment builds: 1 = no DMA, 2 = no stores, 4 = no fmas, 8 = nontemporal stores, 16 = nontemporal loads, 32 = no transform (prologue form)
 #endif
 
 struct DwsParams {
   const unsigned char* x; const float* k; unsigned char* out; float* partials; const float* bnstate;
   int H, W, C, HB, NS, nwgb, flip, cols, rowbytes, wmaj;
   // prologue form: BatchNorm state [mean|var|scale|shift] of the producer, dropout of its output
-  const float* pro_bn; uint64_t seed; uint32_t layer; float rate;
+  const float* pro_bn; const unsigned char* keep; float rate;
 };
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
@@ -52,107 +56,28 @@ __device__ __forceinline__ void widen8(const u32x4& u, float (&f)[8]) {
 
 constexpr int kDwsMaxWaves = 9;     // compute waves (576 columns of 16 bytes)
 
-// role of wave slot w in the prologue form (12 waves, SIMD = w mod 4): 9 compute waves, the loader, two transform waves --
-//   SIMD 0: w0 w4 w8 = C C C;  SIMD 1: w1 w5 w9 = C T L;  SIMD 2: w2 w6 w10 = C C C;  SIMD 3: w3 w7 w11 = C C T
-__device__ __forceinline__ int dws_pro_role(int w, int& idx) {   // 0 = compute, 1 = transform, 2 = loader
-  if (w == 9) { idx = 0; return 2; }
-  if (w == 5) { idx = 0; return 1; }
-  if (w == 11) { idx = 1; return 1; }
-  idx = w < 5 ? w : (w < 9 ? w - 1 : 8);                        // 0 1 2 3 4 | 6 7 8 -> 5 6 7 | 10 -> 8
-  return 0;
-}
-constexpr int kDwsProChunks = 5;     // 16-byte chunks per transform lane and row: chunks j * 128 + 64 * (transform wave) + lane
-
 // NI: 1 KiB DMA instructions per step row; D: rows in flight; EPI: out = ReLU6(conv * scale + shift) (inference), no statistics;
 // PRO: prologue form (the input is q of the previous block: BatchNorm-2 + ReLU6 [+ dropout: DROP] applied in LDS)
+constexpr int kDwsKeepNI = 3;        // prologue form with dropout: 4-byte DMA instructions per step row for the keep bytes (<= 768 chunks)
 template <int NI, int D, bool EPI, bool PRO, bool DROP = false>
-__global__ __launch_bounds__((kDwsMaxWaves + (PRO ? 3 : 1)) * 64) void dw_fwd_stream_kernel(DwsParams p) {
+__global__ __launch_bounds__((kDwsMaxWaves + 1) * 64) void dw_fwd_stream_kernel(DwsParams p) {
   constexpr int NR = D + 1, SLOT = NI * 1024;
-  static_assert((D - 1) * NI <= 63, "vmcnt is a 6-bit counter");
-  static_assert(!(PRO && EPI), "the prologue form is the training form");
+  constexpr int NIT = NI + (DROP ? kDwsKeepNI : 0);            // DMA instructions per step row
+  static_assert((D - 1) * NIT <= 63, "vmcnt is a 6-bit counter");
+  static_assert(!(PRO && EPI) && !(DROP && !PRO), "the prologue form is the training form");
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave0 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ncw = PRO ? kDwsMaxWaves : (int)(blockDim.x >> 6) - 1;
-  int ridx = 0;
-  const int role = PRO ? dws_pro_role(wave0, ridx) : 0;
-  // `wave`: index of a compute wave among the compute waves; == ncw for the loader (the transform waves take their own branch first)
-  const int wave = PRO ? (role == 0 ? ridx : ncw) : wave0;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ncw = (int)(blockDim.x >> 6) - 1;
+  constexpr int KOFF = NR * SLOT + 64;                         // prologue form: NR x 1 KiB of keep bytes behind the zero chunk,
+  constexpr int PCOFF = KOFF + NR * 1024;                      // then the producer's BatchNorm scale | shift, [2][C <= 512] floats
   const int img = blockIdx.x / p.nwgb, wb = blockIdx.x - img * p.nwgb;
   const int r0 = wb * p.NS * p.HB;                 // first output row of sub-band 0
   const int steps = p.HB + 2;                      // input rows r0-1 .. r0+HB of every sub-band
   const int zoff = NR * SLOT;                      // 16 zero bytes (the pixels left of x = 0 and right of x = W-1)
   if (tid < 4) reinterpret_cast<unsigned*>(lds + zoff)[tid] = 0u;
 
-  if (PRO && role == 1) {
-    // ------------------------------------------------------------------ transform waves (prologue form)
-    const int cpp = p.C >> 3, rowcols = p.W * cpp;               // 16-byte chunks per pixel / per image row
-    int coff[kDwsProChunks]; bool cact[kDwsProChunks]; uint32_t grp[kDwsProChunks];
-#pragma unroll
-    for (int j = 0; j < kDwsProChunks; ++j) {
-      const int c = j * 128 + ridx * 64 + lane;
-      cact[j] = c < p.cols;
-      const int cc = cact[j] ? c : 0;
-      const int sub = cc / rowcols, within = cc - sub * rowcols;
-      coff[j] = cc * 16;
-      // dropout group (8 consecutive elements of x in NHWC order) of this chunk in step row 0: image row r0 + sub * HB - 1; 32-bit:
-      // the launcher takes maps of fewer than 2^32 groups (rows outside the image wrap around: their values are discarded)
-      grp[j] = (uint32_t)(((long)img * p.H + r0 + sub * p.HB - 1) * rowcols + within);
-    }
-    // 128 % cpp == 0 (launcher): every chunk of a lane holds the same channel octet
-    const int oct = (ridx * 64 + lane) % cpp;
-    f32x2_t sc[4], sh[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      sc[e] = (f32x2_t){p.pro_bn[2 * p.C + oct * 8 + 2 * e], p.pro_bn[2 * p.C + oct * 8 + 2 * e + 1]};
-      sh[e] = (f32x2_t){p.pro_bn[3 * p.C + oct * 8 + 2 * e], p.pro_bn[3 * p.C + oct * 8 + 2 * e + 1]};
-    }
-    const crnn_rng_key key = crnn_rng_make_key(p.seed, p.layer);
-    // (threshold and scale spelled as bn_act_pool_drop_kernel spells them: the same bits)
-    const uint32_t thr = DROP ? crnn_drop_threshold(p.rate) : 0u;
-    const float ik = DROP ? 1.f / (1.f - p.rate) : 1.f;
-    const f32x2_t ik2 = (f32x2_t){ik, ik};
-    uint32_t rowgrp = 0;                                         // t * rowcols (uniform)
-    // (DROP is a compile-time constant: with a run-time test inside, both forms are evaluated and selected per element)
-    auto xform = [&](int slot) {
-      unsigned char* sb = lds + slot * SLOT;
-      u32x4 v[kDwsProChunks];
-#pragma unroll
-      for (int j = 0; j < kDwsProChunks; ++j) v[j] = *reinterpret_cast<const u32x4*>(sb + coff[j]);
-#pragma unroll
-      for (int j = 0; j < kDwsProChunks; ++j) {
-        if (j * 128 + ridx * 64 >= p.cols) continue;             // (uniform) this wave has no chunk j
-        u32x4 o;
-        uint32_t w[4] = {0u, 0u, 0u, 0u};
-        if (DROP) crnn_rng8(key, (uint64_t)(grp[j] + rowgrp), w);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x2_t x2 = (f32x2_t){__uint_as_float(v[j][q] << 16), __uint_as_float(v[j][q] & 0xffff0000u)};
-          f32x2_t y = __builtin_elementwise_fma(x2, sc[q], sh[q]);    // per element fmaf(x, scale, shift): v_pk_fma_f32
-          y = (f32x2_t){relu6f(y.x), relu6f(y.y)};
-          if (DROP) {
-            const f32x2_t ys = y * ik2;                            // per element y * inv_keep (v_pk_mul_f32), as the stand-alone pass
-            y = (f32x2_t){(w[q] & 0xffffu) >= thr ? ys.x : 0.f, (w[q] >> 16) >= thr ? ys.y : 0.f};
-          }
-          o[q] = pack2_bf16(y.x, y.y);
-        }
-        if (cact[j]) *reinterpret_cast<u32x4*>(sb + coff[j]) = o;
-      }
-      rowgrp += (uint32_t)rowcols;
-    };
-    __builtin_amdgcn_s_barrier();                                // P: row 0 has landed
-    xform(0);
-    int slot = 1;                                                // slot of row t + 1
-    for (int t = 0; t < steps; ++t) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                              // row t + 1 has landed; row t is transformed
-      if (t + 1 < steps) xform(slot);
-      slot = slot + 1 == NR ? 0 : slot + 1;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (!EPI && p.partials) __builtin_amdgcn_s_barrier();
-  } else if (wave == ncw) {
+  if (wave == ncw) {
     // ------------------------------------------------------------------ loader wave
     const unsigned char* gx = p.x + (long)img * p.H * p.rowbytes;
     int rowfirst[NI], within[NI];
@@ -163,6 +88,19 @@ __global__ __launch_bounds__((kDwsMaxWaves + (PRO ? 3 : 1)) * 64) void dw_fwd_st
       if (s >= p.NS) { s = p.NS - 1; w = p.rowbytes - 16; }     // past the step row: re-read its last chunk (lands in the slot's unused tail)
       rowfirst[i] = r0 + s * p.HB - 1; within[i] = w;
     }
+    // prologue form with dropout: the keep bytes of the step row (one per 16-byte chunk, same order), 4 bytes per lane and instruction
+    int krow[kDwsKeepNI], kwithin[kDwsKeepNI];
+    const int rowcols = p.W * (p.C >> 3);
+    const unsigned char* gk = DROP ? p.keep + (long)img * p.H * rowcols : nullptr;
+    if (DROP) {
+#pragma unroll
+      for (int i = 0; i < kDwsKeepNI; ++i) {
+        int b = (i * 64 + lane) * 4;
+        if (b >= p.cols) b = p.cols - 4;                       // past the step row: its last dword again (lands in the unused tail)
+        const int s2 = b / rowcols;
+        krow[i] = r0 + s2 * p.HB - 1; kwithin[i] = b - s2 * rowcols;
+      }
+    }
     auto issue = [&](int t, int slot) {
       t = t < steps ? t : steps - 1;                           // past the end: the last row again, into a slot nobody reads any more
 #pragma unroll
@@ -171,16 +109,25 @@ __global__ __launch_bounds__((kDwsMaxWaves + (PRO ? 3 : 1)) * 64) void dw_fwd_st
         row = row < 0 ? 0 : (row >= p.H ? p.H - 1 : row);      // rows outside the image: any valid row (the compute waves substitute zeros)
         if (!(CRNN_DWS_EXP & 1)) glds16(gx + (long)row * p.rowbytes + within[i], lds + slot * SLOT + i * 1024);
       }
+      if (DROP) {
+#pragma unroll
+        for (int i = 0; i < kDwsKeepNI; ++i) {
+          int row = krow[i] + t;
+          row = row < 0 ? 0 : (row >= p.H ? p.H - 1 : row);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gk + (long)row * rowcols + kwithin[i]),
+                                           (__attribute__((address_space(3))) void*)(lds + KOFF + slot * 1024 + i * 256), 4, 0, 0);
+        }
+      }
     };
 #pragma unroll
     for (int t = 0; t < D; ++t) issue(t, t);
     int slot = D;                                              // slot of row t + D
-    if (PRO) {                                                 // the transform waves work one row ahead of the compute waves
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NI) : "memory");   // row 0 has landed
+    if (PRO) {                                                 // the rows are re-formed one row ahead of their use
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NIT) : "memory");   // row 0 has landed
       __builtin_amdgcn_s_barrier();
     }
     for (int t = 0; t < steps; ++t) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - (PRO ? 2 : 1)) * NI) : "memory");   // row t (prologue form: row t + 1) has landed
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - (PRO ? 2 : 1)) * NIT) : "memory");   // row t (prologue form: row t + 1) has landed
       __builtin_amdgcn_s_barrier();
       issue(t + D, slot);                                      // the slot row t-1 has just released
       slot = slot + 1 == NR ? 0 : slot + 1;
@@ -213,8 +160,48 @@ __global__ __launch_bounds__((kDwsMaxWaves + (PRO ? 3 : 1)) * 64) void dw_fwd_st
     float X0[8], X1[8], X2[8], s[8], ss[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { X0[e] = X1[e] = X2[e] = 0.f; s[e] = ss[e] = 0.f; }
-    if (PRO) __builtin_amdgcn_s_barrier();                     // P (the transform waves take row 0 now)
     const int rsub = r0 + sub * p.HB;                          // this lane's first output row
+    // prologue form: x = Dropout(ReLU6(q * scale + shift)) of the lane's own chunk of a row, in place (bf16 -> bf16)
+    // (its 16 BatchNorm constants per lane live in an LDS table [scale | shift][C] and are read per row: the taps and the running
+    // rows fill the registers)
+    float* pct = reinterpret_cast<float*>(lds + PCOFF);
+    if (PRO) {
+      for (int i = col; i < 2 * p.C; i += ncw * 64) pct[i] = p.pro_bn[2 * p.C + i];   // scale then shift: contiguous in bnstate
+    }
+    const float* pcl = pct + oct * 8;
+    const int pC = p.C;
+    const float pik = DROP ? 1.f / (1.f - p.rate) : 1.f;       // (spelled as bn_act_pool_drop_kernel spells it: the same bits)
+    int xslot = 0;                                             // slot of the next row to re-form
+    auto xform = [&]() {
+      unsigned char* cp = lds + xslot * SLOT + offC;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(cp);
+      uint32_t kc = 0xffu;
+      if (DROP) kc = lds[KOFF + xslot * 1024 + ccol];
+      xslot = xslot + 1 == NR ? 0 : xslot + 1;
+      if (CRNN_DWS_EXP & 32) return;                           // experiment build: no re-forming
+      u32x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x2_t x2 = (f32x2_t){__uint_as_float(v[q] << 16), __uint_as_float(v[q] & 0xffff0000u)};
+        const f32x2_t psc = *reinterpret_cast<const f32x2_t*>(pcl + 2 * q), psh = *reinterpret_cast<const f32x2_t*>(pcl + pC + 2 * q);
+        f32x2_t y = __builtin_elementwise_fma(x2, psc, psh);         // per element fmaf(x, scale, shift)
+        y = (f32x2_t){relu6f(y.x), relu6f(y.y)};
+        if (DROP) {
+          y = y * (f32x2_t){pik, pik};                           // per element y * inv_keep, as the stand-alone pass
+          // dropped elements as an AND mask on the packed pair (y >= 0: y * 0 and 0 are the same bits): sign-extending 1-bit extracts
+          const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe((int)kc, 2 * q, 1), hi = (uint32_t)__builtin_amdgcn_sbfe((int)kc, 2 * q + 1, 1);
+          o[q] = pack2_bf16(y.x, y.y) & __builtin_amdgcn_perm(hi, lo, 0x07060100u);
+        } else {
+          o[q] = pack2_bf16(y.x, y.y);
+        }
+      }
+      if (act) *reinterpret_cast<u32x4*>(cp) = o;
+      __builtin_amdgcn_sched_barrier(0);                       // its temporaries are dead before the window of the current row is loaded
+    };
+    if (PRO) {
+      __builtin_amdgcn_s_barrier();                            // P: row 0 has landed
+      xform();
+    }
     unsigned char* orow = p.out + ((long)img * p.H + rsub) * p.rowbytes + px * pitch + oct * 16;
     // window-major output (EPI only; crnn_dwconv3x3_fwd_stream_ex out_order 1): pixel (y, x) is row ((y/2) (W/2) + x/2) 4 + (y&1) 2 + (x&1) of
     // the image -- the four pixels of a 2x2 pooling window are consecutive rows for the pointwise GEMM whose epilogue pools them
@@ -224,6 +211,7 @@ __global__ __launch_bounds__((kDwsMaxWaves + (PRO ? 3 : 1)) * 64) void dw_fwd_st
     auto step = [&](int t, float (&A)[8], float (&Bc)[8], float (&Cn)[8], bool edge) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      if (PRO && t + 1 < steps) xform();                         // row t + 1 has landed: re-form the own chunk of it; row t is complete
       const unsigned char* sb = lds + slot * SLOT;
       u32x4 vL = *reinterpret_cast<const u32x4*>(hasL ? sb + offC - pitch : lds + zoff);
       u32x4 vC = *reinterpret_cast<const u32x4*>(sb + offC);
@@ -372,14 +360,14 @@ int dws_launch(const DwsParams& p, const DwsGeom& g, int B, hipStream_t stream) 
 constexpr int kDwsProD = kDwsD + 1;
 bool dws_pro_ok(const DwsGeom& g, int B, int H, int W, int C) {
   const int cpp = C / 8;
-  return g.ok && g.ncw == kDwsMaxWaves && cpp > 0 && 128 % cpp == 0 && g.cols <= kDwsProChunks * 128 &&
-         (long)B * H * W * cpp < (1L << 32);          // dropout groups counted in 32 bits
+  // the keep bytes of a step row travel as 4-byte DMA pieces: whole dwords per sub-row, at most kDwsKeepNI * 256 of them
+  return g.ok && cpp > 0 && C <= 512 && (W * cpp) % 4 == 0 && g.cols % 4 == 0 && g.cols <= kDwsKeepNI * 256 && (long)B * H * W * cpp < (1L << 31);
 }
 template <bool DROP>
 int dws_launch_pro(const DwsParams& p, const DwsGeom& g, int B, hipStream_t stream) {
-  constexpr int lds = (kDwsProD + 1) * 9 * 1024 + 64;
+  constexpr int lds = (kDwsProD + 1) * (9 + 1) * 1024 + 64 + 2 * 512 * 4;     // rows + 1 KiB of keep bytes per slot + the BatchNorm table
   CRNN_LDS_ATTR((dw_fwd_stream_kernel<9, kDwsProD, false, true, DROP>), lds);
-  hipLaunchKernelGGL((dw_fwd_stream_kernel<9, kDwsProD, false, true, DROP>), dim3(B * g.nwgb), dim3((kDwsMaxWaves + 3) * 64), lds, stream, p);
+  hipLaunchKernelGGL((dw_fwd_stream_kernel<9, kDwsProD, false, true, DROP>), dim3(B * g.nwgb), dim3((g.ncw + 1) * 64), lds, stream, p);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
@@ -407,26 +395,27 @@ extern "C" int crnn_dwconv3x3_fwd_stream_ex(const void* x, const float* k, void*
   DwsParams p;
   p.x = (const unsigned char*)x; p.k = k; p.out = (unsigned char*)out; p.partials = bnstate ? nullptr : stat_partials; p.bnstate = bnstate;
   p.H = H; p.W = W; p.C = C; p.HB = g.HB; p.NS = g.NS; p.nwgb = g.nwgb; p.flip = flip; p.cols = g.cols; p.rowbytes = W * C * 2; p.wmaj = out_order;
-  p.pro_bn = nullptr; p.seed = 0; p.layer = 0; p.rate = 0.f;
+  p.pro_bn = nullptr; p.keep = nullptr; p.rate = 0.f;
   return bnstate ? dws_launch<true>(p, g, B, stream) : dws_launch<false>(p, g, B, stream);
 }
 // Prologue form (training): `q` is the previous block's pointwise output, pro_bnstate its BatchNorm-2 state [mean|var|scale|shift]; the
-// kernel convolves x = Dropout(ReLU6(q * scale + shift)) (rate, seed, layer: the dropout site of crnn_bn_act_pool_drop_ex) without x ever
-// existing in HBM.  out / stat_partials bit-identical to crnn_bn_act_pool_drop_ex(q -> x, ph = pw = 1) + crnn_dwconv3x3_fwd_stream(x).
+// kernel convolves x = Dropout(ReLU6(q * scale + shift)) without x ever existing in HBM.  rate > 0: `keep` = the site's keep bytes
+// (crnn_dropout_keep_bytes(keep, B*H*W*C/8, rate, seed, layer) for the dropout site of crnn_bn_act_pool_drop_ex); rate == 0: keep may be NULL.
+// out / stat_partials bit-identical to crnn_bn_act_pool_drop_ex(q -> x, ph = pw = 1) + crnn_dwconv3x3_fwd_stream(x).
 // CRNN_ERR_UNSUPPORTED where crnn_dwconv_fwd_stream_pro_supported says so (the caller materialises x).
 extern "C" int crnn_dwconv_fwd_stream_pro_supported(int B, int H, int W, int C) {
   return dws_pro_ok(dws_geom(B, H, W, C), B, H, W, C) ? CRNN_OK : CRNN_ERR_UNSUPPORTED;
 }
-extern "C" int crnn_dwconv3x3_fwd_stream_pro(const void* q, const float* pro_bnstate, float rate, uint64_t seed, uint32_t layer, const float* k, void* out,
+extern "C" int crnn_dwconv3x3_fwd_stream_pro(const void* q, const float* pro_bnstate, float rate, const void* keep, const float* k, void* out,
                                              float* stat_partials, int B, int H, int W, int C, hipStream_t stream) {
-  if (!q || !pro_bnstate || !k || !out || rate < 0.f || rate >= 1.f) return CRNN_ERR_ARG;
+  if (!q || !pro_bnstate || !k || !out || rate < 0.f || rate >= 1.f || (rate > 0.f && !keep)) return CRNN_ERR_ARG;
   DwsGeom g = dws_geom(B, H, W, C);
-  if (!dws_pro_ok(g, B, H, W, C) || (((uintptr_t)q | (uintptr_t)out | (uintptr_t)k | (uintptr_t)pro_bnstate) & 15)) return CRNN_ERR_UNSUPPORTED;
+  if (!dws_pro_ok(g, B, H, W, C) || (((uintptr_t)q | (uintptr_t)out | (uintptr_t)k | (uintptr_t)pro_bnstate) & 15) || ((uintptr_t)keep & 3)) return CRNN_ERR_UNSUPPORTED;
   if ((long)H * W * C * 2 >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;
   DwsParams p;
   p.x = (const unsigned char*)q; p.k = k; p.out = (unsigned char*)out; p.partials = stat_partials; p.bnstate = nullptr;
   p.H = H; p.W = W; p.C = C; p.HB = g.HB; p.NS = g.NS; p.nwgb = g.nwgb; p.flip = 0; p.cols = g.cols; p.rowbytes = W * C * 2; p.wmaj = 0;
-  p.pro_bn = pro_bnstate; p.seed = seed; p.layer = layer; p.rate = rate;
+  p.pro_bn = pro_bnstate; p.keep = (const unsigned char*)keep; p.rate = rate;
   return rate > 0.f ? dws_launch_pro<true>(p, g, B, stream) : dws_launch_pro<false>(p, g, B, stream);
 }
 extern "C" int crnn_dwconv3x3_fwd_stream(const void* x, const float* k, void* out, float* stat_partials, const float* bnstate, int B, int H, int W,

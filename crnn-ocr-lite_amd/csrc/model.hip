@@ -138,6 +138,8 @@ Plan make_plan(const crnn_config* c) {
     const int sdt_in = (c->mfma_bf16 == 2 && ci % 4 == 0) ? CRNN_BF16 : CRNN_F32;
     const int sdt_out = (c->mfma_bf16 == 2) ? CRNN_BF16 : CRNN_F32;
     P.add("d" + p, M * ci, sdt_in); P.add("a" + p, M * ci, sdt_in); P.add("q" + p, M * co, sdt_out); P.add("x" + p, Mo * co, sdt_out);
+    // dropout keep bytes of the block output (one per 8 elements) for the prologue depthwise kernels of block i+1 (fuse_bn2_dw)
+    if (c->mfma_bf16 == 2 && i < 7 && kBlocks[i - 1].ph * kBlocks[i - 1].pw == 1 && co % 8 == 0) P.add("dm" + p, (M * co / 8 + 3) / 4);
     maxact = lmax(maxact, M * co);
     long tiles = crnn_dwconv_num_tiles(d.B, d.bh[i], d.bw[i]);
     maxparts = lmax(maxparts, tiles * 9L * ci);
@@ -274,7 +276,7 @@ bool fuse_bn2_dw_shape(const crnn_config* cfg, const Dims& d, const Plan& P, int
   if (cfg->flags & (CRNN_FLAG_NO_BN2_DW_FUSION | CRNN_FLAG_DW_TILE_KERNEL | CRNN_FLAG_NO_DW_BWD_FUSION)) return false;
   if (cfg->mfma_bf16 != 2 || kBlocks[i - 1].ph * kBlocks[i - 1].pw != 1) return false;
   const std::string p = std::to_string(i), n = std::to_string(i + 1);
-  if (P.dt("q" + p) != CRNN_BF16 || P.dt("x" + p) != CRNN_BF16 || P.dt("d" + n) != CRNN_BF16) return false;
+  if (P.dt("q" + p) != CRNN_BF16 || P.dt("x" + p) != CRNN_BF16 || P.dt("d" + n) != CRNN_BF16 || P.off("dm" + p) < 0) return false;
   const int H = d.bh[i + 1], W = d.bw[i + 1], C = d.bc[i];
   return crnn_dwconv_fwd_stream_pro_supported(d.B, H, W, C) == CRNN_OK && crnn_dwconv_bwd_stream_pro_supported(d.B, H, W, C) == CRNN_OK &&
          crnn_dwconv_bwd_fused_supported(H, W, C) == CRNN_OK;
@@ -284,6 +286,7 @@ bool fuse_bn2_dw(const Ctx& c, int i) {
   const std::string p = std::to_string(i), n = std::to_string(i + 1);
   return aligned16(c.w("q" + p), c.w("bn2s" + p), c.w("d" + n), c.p("b" + n + "_dw"));
 }
+const float* keep_bytes(const Ctx& c, int i) { return c.cfg->dropout ? c.w("dm" + std::to_string(i)) : nullptr; }
 // always-fp32 GEMM (spatial-transformer localisation net: tiny, and theta is precision-sensitive)
 int gemm32(const Ctx& c, int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
            const float* bias = nullptr, int act = 0, int acc = 0, int perm = 0) {
@@ -452,6 +455,10 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
     }
     CRNN_TRY(crnn_bn_infer_state_batch(n, mm, mv, gg, bb, cc, st, stream));
   }
+  if (train && cfg->dropout)   // the dropout decisions of the block outputs that only exist inside the next depthwise kernels: a function of (seed, site, index)
+    for (int i = 1; i <= 6; ++i)
+      if (fuse_bn2_dw(c, i))
+        CRNN_TRY(crnn_dropout_keep_bytes(c.w("dm" + std::to_string(i)), (long)B * d.bh[i] * d.bw[i] * d.bc[i] / 8, kDropBlock, seed, (uint32_t)i, stream));
   for (int i = 1; i <= 7; ++i) {
     std::string p = std::to_string(i), bp = "b" + p;
     const int H = d.bh[i], W = d.bw[i], ci = d.bc[i - 1], co = d.bc[i];
@@ -511,7 +518,7 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
       continue;
     }
     if (pro_q) {   // the previous block's output was not materialised: its BatchNorm-2 + ReLU6 + dropout run inside this depthwise kernel (fuse_bn2_dw)
-      CRNN_TRY(crnn_dwconv3x3_fwd_stream_pro(pro_q, pro_s2, cfg->dropout ? kDropBlock : 0.f, seed, (uint32_t)(i - 1), c.p(bp + "_dw"), dd, parts, B, H, W, ci, stream));
+      CRNN_TRY(crnn_dwconv3x3_fwd_stream_pro(pro_q, pro_s2, cfg->dropout ? kDropBlock : 0.f, keep_bytes(c, i - 1), c.p(bp + "_dw"), dd, parts, B, H, W, ci, stream));
       CRNN_TRY(crnn_bn_finalize_folded(parts, crnn_dwconv_fwd_stream_rows(B, H, W, ci), ci, M, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), s1, c.w("fold"), stream));
       pro_q = nullptr; pro_s2 = nullptr;
     } else if (dws) {
@@ -949,8 +956,9 @@ int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t au
       int rc = CRNN_ERR_UNSUPPORTED;
       if (fuse_bn2_dw(c, i - 1)) {                           // the forward did not keep x_{i-1}: re-formed from q_{i-1} in LDS (no fallback: same decision)
         const std::string pp = std::to_string(i - 1);
+        // (its dropout decisions: the keep bytes the forward of this step left in the workspace -- same seed)
         CRNN_TRY(crnn_dwconv3x3_bwd_stream_pro(c.w("d" + p), gA, c.w("bn1s" + p), c.w("coef"), c.w("q" + pp), c.w("bn2s" + pp), cfg->dropout ? kDropBlock : 0.f,
-                                               seed, (uint32_t)(i - 1), c.p(bp + "_dw"), gC, c.g(bp + "_dw"), c.w("partials"), B, H, W, ci, stream));
+                                               keep_bytes(c, i - 1), c.p(bp + "_dw"), gC, c.g(bp + "_dw"), c.w("partials"), B, H, W, ci, stream));
         rc = CRNN_OK;
       } else if (!(cfg->flags & CRNN_FLAG_DW_TILE_KERNEL))         // rows streamed through LDS where the shape rule holds (dwconv_bwd_stream.hip)
         rc = crnn_dwconv3x3_bwd_stream(c.w("d" + p), gA, c.w("bn1s" + p), c.w("coef"), xin, c.p(bp + "_dw"), gC, c.g(bp + "_dw"), c.w("partials"),

@@ -240,12 +240,13 @@ int crnn_dwconv3x3_fwd_stream(const void* x, const float* k, void* out, float* s
 int crnn_dwconv3x3_fwd_stream_ex(const void* x, const float* k, void* out, float* stat_partials, const float* bnstate, int B, int H, int W, int C,
                                  int flip, int out_order, crnn_stream_t stream);
 /* Prologue form (training, round 4): `q` is the PREVIOUS block's pointwise output and pro_bnstate its BatchNorm-2 state [mean|var|scale|shift]; the
- * kernel convolves x = Dropout(ReLU6(q * scale + shift)) (utils.py:48-56; rate / seed / layer = the dropout site of crnn_bn_act_pool_drop_ex), formed
- * in LDS by two transform waves one row ahead of the compute waves -- the block output x never exists in HBM.  out / stat_partials bit-identical to
+ * kernel convolves x = Dropout(ReLU6(q * scale + shift)) (utils.py:48-56), formed in LDS by two transform waves one row ahead of the compute
+ * waves -- the block output x never exists in HBM.  rate > 0: `keep` = crnn_dropout_keep_bytes(B*H*W*C/8 groups, rate, seed, layer) of the dropout
+ * site crnn_bn_act_pool_drop_ex would use (one byte per 16-byte chunk); rate == 0: keep may be NULL.  out / stat_partials bit-identical to
  * crnn_bn_act_pool_drop_ex(q -> x, no pooling) + crnn_dwconv3x3_fwd_stream(x).  _supported: the stream shape rule, 128 % (C/8) == 0 and fewer than
  * 2^32 dropout groups (B*H*W*C/8). */
 int crnn_dwconv_fwd_stream_pro_supported(int B, int H, int W, int C);
-int crnn_dwconv3x3_fwd_stream_pro(const void* q, const float* pro_bnstate, float rate, uint64_t seed, uint32_t layer, const float* k, void* out,
+int crnn_dwconv3x3_fwd_stream_pro(const void* q, const float* pro_bnstate, float rate, const void* keep, const float* k, void* out,
                                   float* stat_partials, int B, int H, int W, int C, crnn_stream_t stream);
 /* n (<= 8) independent matrix transposes in one launch: out[i] [C_i][R_i] = in[i]^T, in[i] = src + in_off[i] (fp32
  * elements), out[i] = dst + out_off[i] (elements of dt_out: 0 fp32 | 1 bf16).  src / dst are device pointers; the four
@@ -284,12 +285,12 @@ int crnn_dwconv_bwd_stream_supported(int B, int H, int W, int C);
 int crnn_dwconv_bwd_stream_rows(int B, int H, int W, int C);
 int crnn_dwconv3x3_bwd_stream(const void* d, const void* da, const float* bnstate, const float* coef, const void* xin, const float* k, void* dx,
                               float* dk, float* scratch, int B, int H, int W, int C, crnn_stream_t stream);
-/* Prologue form: `q` (in place of xin) is the previous block's pointwise output; x = Dropout(ReLU6(q * scale + shift)) is re-formed in LDS by the DX
- * waves one row ahead (the forward did not keep it: crnn_dwconv3x3_fwd_stream_pro).  dx / dk bit-identical to crnn_dwconv3x3_bwd_stream on the
- * materialised x. */
+/* Prologue form: `q` (in place of xin) is the previous block's pointwise output; x = Dropout(ReLU6(q * scale + shift)) is re-formed in LDS by a
+ * twelfth wave one row ahead (the forward did not keep it: crnn_dwconv3x3_fwd_stream_pro; same `keep` bytes).  dx / dk bit-identical to
+ * crnn_dwconv3x3_bwd_stream on the materialised x. */
 int crnn_dwconv_bwd_stream_pro_supported(int B, int H, int W, int C);
 int crnn_dwconv3x3_bwd_stream_pro(const void* d, const void* da, const float* bnstate, const float* coef, const void* q, const float* pro_bnstate,
-                                  float rate, uint64_t seed, uint32_t layer, const float* k, void* dx, float* dk, float* scratch, int B, int H,
+                                  float rate, const void* keep, const float* k, void* dx, float* dk, float* scratch, int B, int H,
                                   int W, int C, crnn_stream_t stream);
 int crnn_dwconv3x3_fwd(const float* x, const float* k, float* out, float* stat_partials, int B, int H, int W, int C,
                        int flip, crnn_stream_t stream);
@@ -325,6 +326,9 @@ int crnn_add(const float* a, const float* b, float* o, long n, crnn_stream_t str
 int crnn_dropout(const float* x, float* y, long rows, int C, int ldx, int ldy, float rate, uint64_t seed,
                  uint32_t layer, crnn_stream_t stream);
 int crnn_dropout_mask(float* m, long n, float rate, uint64_t seed, uint32_t layer, crnn_stream_t stream);
+/* keep bits of the same dropout site, one byte per group of 8 consecutive elements (bit e: element 8 g + e is kept; rate <= 0: 0xFF) -- the form the
+ * prologue row-stream depthwise kernels read (crnn_dwconv3x3_fwd_stream_pro / _bwd_stream_pro).  out: 4-byte aligned, (ngroups + 3) / 4 * 4 bytes written */
+int crnn_dropout_keep_bytes(void* out, long ngroups, float rate, uint64_t seed, uint32_t layer, crnn_stream_t stream);
 int crnn_relu_bwd(const float* y, const float* g, float* go, long rows, int C, float scale, int permP,
                   crnn_stream_t stream);
 /* spatial transformer pieces (utils.py:116-258) */

@@ -38,6 +38,12 @@ def main():
     B, steps = 8, 3
     precision = os.environ.get("CRNN_PRECISION", "fp32")
     kw = dict(imgh=40, max_len=6, time_dense_size=32, n_units=64, dropout=False, precision=precision)
+    if world > max(torch.cuda.device_count(), 1):
+        # ranks SHARE a GPU here (a test arrangement; the product runs one process per GPU): the persistent recurrences need their
+        # workgroup clusters co-resident and several processes launching them at once can starve each other into the bounded give-up,
+        # so the shared-GPU check runs the per-step recurrence kernels (bit-identical results)
+        from crnn_mi355x import native
+        kw["flags"] = native.FLAG_RNN_STEP_KERNELS
     eng = Engine(B, **kw)
     eng.set_params(initial_parameters(eng.layout, 64, False, seed=100 + rank))       # DIFFERENT weights per rank ...
     broadcast_state(eng, dist, world)                                                # ... until rank 0's are adopted
@@ -50,6 +56,7 @@ def main():
         eng.train_step(x, lab, il, ll, opt, it, allreduce=ar)
     sync_bn_stats(eng, dist, world)
     torch.cuda.synchronize()
+    eng.check_rnn_status()          # a persistent recurrence that gave up would have produced garbage silently
 
     def gathered(t):
         out = [torch.empty_like(t) for _ in range(world)]
@@ -82,7 +89,13 @@ def main():
             assert torch.equal(ref.params, eng.params), "DP step != single-process step on the mean gradient (max diff %g)" % float(
                 (ref.params - eng.params).abs().max())
         else:
-            assert torch.allclose(ref.params, eng.params, rtol=1e-5, atol=1e-7)
+            # more than two ranks: the all-reduce adds the shard gradients in another order than this loop (fp32 round-off, ~1e-7 relative),
+            # and Adam's first steps move a weight by ~lr * g / |g| -- an element whose gradient is within that round-off of zero may move
+            # by a different fraction of lr.  So: almost every weight agrees to round-off, none differs by more than Adam can move it.
+            diff = (ref.params - eng.params).abs()
+            frac = float((diff > 1e-6).float().mean())
+            print("world %d vs single process: max |dp| %.3g, mean %.3g, fraction above 1e-6: %.3g" % (world, float(diff.max()), float(diff.mean()), frac), flush=True)
+            assert float(diff.max()) <= 1e-3 * steps * 1.01 and frac < 2e-2 and float(diff.mean()) < 1e-6
         print("DP_CHECK OK world=%d backend=%s precision=%s" % (world, backend, precision), flush=True)
     dist.barrier()
     dist.destroy_process_group()

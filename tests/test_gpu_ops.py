@@ -863,6 +863,17 @@ def test_row_stream_depthwise_with_the_batchnorm2_prologue_equals_the_two_pass_p
     k = rs.normal(size=(3, 3, C)); kd = dev(k)
     st2 = dev(np.concatenate([rs.normal(size=C), 1 + rs.uniform(size=C), 1 + 0.5 * rs.normal(size=C), 1.5 * rs.normal(size=C) + 1.5]))
     seed, layer = 77, 4
+    ng = n // 8
+    keep = torch.full((ng + 3 + 64,), 0x55, dtype=torch.uint8, device="cuda")
+    ok(L().crnn_dropout_keep_bytes(P(keep), ng, rate, seed, layer, S()))
+    assert bool((keep[(ng + 3) // 4 * 4:] == 0x55).all())
+    if rate > 0:     # the keep bytes are the decisions of crnn_dropout_mask, bit e of byte g = element 8 g + e
+        m = zeros(n)
+        ok(L().crnn_dropout_mask(P(m), n, rate, seed, layer, S()))
+        bits = ((keep[:ng].to(torch.int32).unsqueeze(1) >> torch.arange(8, device="cuda", dtype=torch.int32)) & 1).reshape(-1)
+        assert torch.equal(bits.bool(), m > 0)
+    else:
+        assert bool((keep[:ng] == 0xFF).all())
     xd = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
     ok(L().crnn_bn_act_pool_drop_ex(P(qd), P(st2), P(xd), B, H, W, C, 1, 1, rate, seed, layer, 1, 1, S()))
     xf = xd.float()
@@ -872,16 +883,19 @@ def test_row_stream_depthwise_with_the_batchnorm2_prologue_equals_the_two_pass_p
     o1 = torch.zeros(n, dtype=torch.bfloat16, device="cuda"); p1 = zeros(rows, 2, C)
     ok(L().crnn_dwconv3x3_fwd_stream(P(xd), P(kd), P(o1), P(p1), None, B, H, W, C, 0, S()))
     o2 = torch.full((n + 64,), 7.0, dtype=torch.bfloat16, device="cuda"); p2 = torch.full((rows + 1, 2, C), 3.0, device="cuda")
-    ok(L().crnn_dwconv3x3_fwd_stream_pro(P(qd), P(st2), rate, seed, layer, P(kd), P(o2), P(p2), B, H, W, C, S()))
+    ok(L().crnn_dwconv3x3_fwd_stream_pro(P(qd), P(st2), rate, P(keep), P(kd), P(o2), P(p2), B, H, W, C, S()))
     assert torch.equal(o2[:-64].view(torch.int16), o1.view(torch.int16)), "d: max diff %g" % float((o2[:-64].float() - o1.float()).abs().max())
     assert torch.equal(p2[:rows], p1) and bool((o2[-64:] == 7.0).all()) and bool((p2[rows] == 3.0).all())
     o3 = torch.zeros(n, dtype=torch.bfloat16, device="cuda"); p3 = zeros(rows, 2, C)
-    ok(L().crnn_dwconv3x3_fwd_stream_pro(P(qd), P(st2), rate, seed, layer, P(kd), P(o3), P(p3), B, H, W, C, S()))
+    ok(L().crnn_dwconv3x3_fwd_stream_pro(P(qd), P(st2), rate, P(keep), P(kd), P(o3), P(p3), B, H, W, C, S()))
     assert torch.equal(o3, o2[:-64]) and torch.equal(p3, p1), "repeat launches differ"
     # another dropout site / seed gives another mask
     if rate > 0:
-        ok(L().crnn_dwconv3x3_fwd_stream_pro(P(qd), P(st2), rate, seed + 1, layer, P(kd), P(o3), P(p3), B, H, W, C, S()))
+        keep2 = torch.zeros_like(keep)
+        ok(L().crnn_dropout_keep_bytes(P(keep2), ng, rate, seed + 1, layer, S()))
+        ok(L().crnn_dwconv3x3_fwd_stream_pro(P(qd), P(st2), rate, P(keep2), P(kd), P(o3), P(p3), B, H, W, C, S()))
         assert not torch.equal(o3, o1)
+        assert L().crnn_dwconv3x3_fwd_stream_pro(P(qd), P(st2), rate, None, P(kd), P(o3), P(p3), B, H, W, C, S()) == -2
     # ---- backward of the consuming depthwise stage
     dd = o1                                                     # d = dwconv(x)
     dad = (torch.randn(n, device="cuda", generator=torch.Generator("cuda").manual_seed(5)) * 0.7).to(torch.bfloat16)
@@ -896,7 +910,7 @@ def test_row_stream_depthwise_with_the_batchnorm2_prologue_equals_the_two_pass_p
     dx1 = torch.zeros(n, dtype=torch.bfloat16, device="cuda"); dk1 = zeros(9, C); sc = zeros(brow * 9 * C)
     ok(L().crnn_dwconv3x3_bwd_stream(P(dd), P(dad), P(st1), P(coef), P(xd), P(kd), P(dx1), P(dk1), P(sc), B, H, W, C, S()))
     dx2 = torch.full((n + 64,), 9.0, dtype=torch.bfloat16, device="cuda"); dk2 = zeros(9, C); sc2 = torch.full((brow * 9 * C + 16,), 5.0, device="cuda")
-    ok(L().crnn_dwconv3x3_bwd_stream_pro(P(dd), P(dad), P(st1), P(coef), P(qd), P(st2), rate, seed, layer, P(kd), P(dx2), P(dk2), P(sc2), B, H, W, C, S()))
+    ok(L().crnn_dwconv3x3_bwd_stream_pro(P(dd), P(dad), P(st1), P(coef), P(qd), P(st2), rate, P(keep), P(kd), P(dx2), P(dk2), P(sc2), B, H, W, C, S()))
     assert torch.equal(dx2[:-64].view(torch.int16), dx1.view(torch.int16)), "dx: max diff %g" % float((dx2[:-64].float() - dx1.float()).abs().max())
     assert torch.equal(dk2, dk1), "dk: max diff %g" % float((dk2 - dk1).abs().max())
     assert bool((dx2[-64:] == 9.0).all()) and bool((sc2[-16:] == 5.0).all())
