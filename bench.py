@@ -212,7 +212,8 @@ def depthwise_bwd_roofline(eng, iters=5):
         for d, da, st, cf, x, k, dx, dk, pt, hh, ww, cc, strm, pro in launches:
             if pro is not None:     # the step's own form: x re-formed from the previous block's q in LDS
                 lib.crnn_dwconv3x3_bwd_stream_pro(_ptr(d), _ptr(da), _ptr(st), _ptr(cf), _ptr(pro[0]), _ptr(pro[1]), rate,
-                                                  _ptr(eng.ws_tensor("dm%d" % pro[2])) if rate > 0 else None, _ptr(k), _ptr(dx), _ptr(dk), _ptr(pt), B, hh, ww, cc, _stream())
+                                                  _ptr(eng.ws_tensor("dm%d" % pro[2])) if rate > 0 else None, _ptr(k), _ptr(dx), _ptr(dk), _ptr(pt),
+                                                  _ptr(eng.ws_tensor("bn2parts")) if (eng.cfg.flags & 2048) else None, B, hh, ww, cc, _stream())
                 continue
             fn = lib.crnn_dwconv3x3_bwd_stream if strm else lib.crnn_dwconv3x3_bwd_fused
             fn(_ptr(d), _ptr(da), _ptr(st), _ptr(cf), _ptr(x), _ptr(k), _ptr(dx), _ptr(dk), _ptr(pt), B, hh, ww, cc, _stream())
@@ -868,6 +869,13 @@ def main():
                 res["bs64"] = leg(64, max(5, args.steps), 3, reps=3)
                 if args.precision != "fp32":   # ... and at the reference's own precision (the parity mode)
                     res["bs64_fp32"] = leg(64, max(5, min(args.steps, 10)), 3, reps=3, precision="fp32")
+            if args.imgh == 100 and not args.gru and args.precision == "bf16s" and not (eng.cfg.flags & 1024):
+                # opt-in schedules measured beside the default in the same run: block outputs formed inside the next block's depthwise kernels
+                # (CRNN_FLAG_BN2_DW_FUSION), and with the BatchNorm-2 backward statistics taken there too (| CRNN_FLAG_BN2_STATS_FUSION)
+                res["bn2_dw_fusion"] = dict(leg(B, max(5, min(args.steps, 20)), 3, flags=1024), flags=1024,
+                                            note="opt-in: 4 BatchNorm-apply launches and 3 tensor passes per un-pooled block less, paid in VALU work on the "
+                                                 "depthwise kernels' transform waves; bit-identical results")
+                res["bn2_dw_stats_fusion"] = dict(leg(B, max(5, min(args.steps, 20)), 3, flags=1024 | 2048), flags=3072)
             if args.imgh == 100 and not args.gru:
                 # the same step driven through the reference's surface from host batches (train.py:201-209)
                 res["fit"] = fit_leg(B, max(10, args.steps), args.precision)

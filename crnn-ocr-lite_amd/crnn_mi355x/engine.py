@@ -105,6 +105,7 @@ class Engine:
         # bandwidth-bound kernels -- measured neutral to 0.7 % slower at batch 256 (7.97 vs 7.91 ms: both sides already fill the CUs),
         # so also opt-in: CRNN_CONV_OVERLAP=1; bit-identical either way
         self.overlap_conv_wgrad = os.environ.get("CRNN_CONV_OVERLAP", "0") == "1"
+        self.overlap_keep_bytes = os.environ.get("CRNN_KEEP_OVERLAP", "1") == "1"
         self._aux_stream = None
         self._warn_schedule_fallbacks()
         self._stage = None                # page-locked staging slots of stage() (built on first use)
@@ -255,8 +256,9 @@ class Engine:
         """x (B,imgh,imgw,1) -> y_pred (B,T,C) device tensor (softmax)."""
         x = self._as_input(x)
         self._x = x
-        check(self.lib.crnn_forward(self._c, _ptr(self.params), _ptr(self.bn_mean), _ptr(self.bn_var), _ptr(x), _ptr(self.ws),
-                                    self.ws_bytes, _ptr(self.y_pred), int(train), int(seed), _stream()), "forward")
+        # (training: the dropout keep bytes of the fused block outputs are generated on the side stream next to the spatial transformer)
+        check(self.lib.crnn_forward_ex(self._c, _ptr(self.params), _ptr(self.bn_mean), _ptr(self.bn_var), _ptr(x), _ptr(self.ws),
+                                       self.ws_bytes, _ptr(self.y_pred), int(train), int(seed), _stream(), self._aux(bool(train) and self.overlap_keep_bytes)), "forward")
         return self.y_pred
 
     def _as_i32(self, a):

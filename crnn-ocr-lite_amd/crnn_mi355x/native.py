@@ -33,7 +33,8 @@ FLAG_RNN_LINEAR_CLUSTERS = 64  # CRNN_FLAG_RNN_LINEAR_CLUSTERS
 FLAG_NO_BN_STATS_FUSION = 128  # CRNN_FLAG_NO_BN_STATS_FUSION
 FLAG_F32_MFMA_GEMMS = 256      # CRNN_FLAG_F32_MFMA_GEMMS
 FLAG_DEFERRED_SUMS = 512       # CRNN_FLAG_DEFERRED_SUMS
-FLAG_NO_BN2_DW_FUSION = 1024   # CRNN_FLAG_NO_BN2_DW_FUSION
+FLAG_BN2_DW_FUSION = 1024      # CRNN_FLAG_BN2_DW_FUSION (opt-in)
+FLAG_BN2_STATS_FUSION = 2048   # CRNN_FLAG_BN2_STATS_FUSION (opt-in)
 RNN_XCD_LOCAL = 0x100          # CRNN_RNN_XCD_LOCAL (or-ed into the uw argument of crnn_lstm_*_persist)
 
 

@@ -1304,8 +1304,12 @@ extern "C" int crnn_dropout_mask(float* m, long n, float rate, uint64_t seed, ui
 // drop_scale_vec decide, in the form the prologue row-stream depthwise kernels read (dwconv_stream.hip, dwconv_bwd_stream.hip): the mask
 // depends on (seed, site, index) only, so it is evaluated once per step here -- four groups per thread, their dropout words side by side --
 // instead of once per consumer pass inside kernels whose transform waves have no spare issue slots (36 of ~100 operations per group).
-__global__ __launch_bounds__(256) void dropout_keep_bytes_kernel(unsigned* __restrict__ out, long nwords, long ngroups, uint32_t thr, uint64_t seed, uint32_t layer) {
-  const crnn_rng_key key = crnn_rng_make_key(seed, layer);
+struct KeepBatch { unsigned* out[CRNN_KEEP_BATCH_MAX]; long nwords[CRNN_KEEP_BATCH_MAX]; long ngroups[CRNN_KEEP_BATCH_MAX]; uint32_t layer[CRNN_KEEP_BATCH_MAX]; };
+__global__ __launch_bounds__(256) void dropout_keep_bytes_kernel(KeepBatch b, uint32_t thr, uint64_t seed) {
+  const int site = blockIdx.y;
+  const crnn_rng_key key = crnn_rng_make_key(seed, b.layer[site]);
+  unsigned* __restrict__ out = b.out[site];
+  const long nwords = b.nwords[site], ngroups = b.ngroups[site];
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nwords; i += (long)gridDim.x * blockDim.x) {
     uint32_t w[4][4];
 #pragma unroll
@@ -1326,18 +1330,29 @@ __global__ __launch_bounds__(256) void dropout_keep_bytes_kernel(unsigned* __res
   }
 }
 // out: 4-byte aligned, (ngroups + 3) / 4 * 4 bytes are written (the tail bytes of the last word are zero); rate <= 0: every element kept (0xFF)
-extern "C" int crnn_dropout_keep_bytes(void* out, long ngroups, float rate, uint64_t seed, uint32_t layer, hipStream_t stream) {
-  if (!out || ngroups < 0 || rate >= 1.f || ((uintptr_t)out & 3)) return CRNN_ERR_ARG;
-  if (ngroups == 0) return CRNN_OK;
-  const long nwords = (ngroups + 3) / 4;
-  if (rate <= 0.f) {
-    hipError_t e = hipMemsetAsync(out, 0xFF, (size_t)nwords * 4, stream);
-    return e == hipSuccess ? CRNN_OK : (int)e;
+extern "C" int crnn_dropout_keep_bytes_batch(int n, void* const* out, const long* ngroups, const uint32_t* layer, float rate, uint64_t seed, hipStream_t stream) {
+  if (n < 0 || n > CRNN_KEEP_BATCH_MAX || rate >= 1.f || (n && (!out || !ngroups || !layer))) return CRNN_ERR_ARG;
+  KeepBatch b; long maxw = 0; int m = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!out[i] || ngroups[i] < 0 || ((uintptr_t)out[i] & 3)) return CRNN_ERR_ARG;
+    if (ngroups[i] == 0) continue;
+    const long nw = (ngroups[i] + 3) / 4;
+    if (rate <= 0.f) {
+      hipError_t e = hipMemsetAsync(out[i], 0xFF, (size_t)nw * 4, stream);
+      if (e != hipSuccess) return (int)e;
+      continue;
+    }
+    b.out[m] = (unsigned*)out[i]; b.nwords[m] = nw; b.ngroups[m] = ngroups[i]; b.layer[m] = layer[i]; ++m;
+    if (nw > maxw) maxw = nw;
   }
-  long blocks = (nwords + 255) / 256; if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(dropout_keep_bytes_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (unsigned*)out, nwords, ngroups, crnn_drop_threshold(rate), seed, layer);
+  if (m == 0) return CRNN_OK;
+  long blocks = (maxw + 255) / 256; if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(dropout_keep_bytes_kernel, dim3((unsigned)blocks, m), dim3(256), 0, stream, b, crnn_drop_threshold(rate), seed);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
+}
+extern "C" int crnn_dropout_keep_bytes(void* out, long ngroups, float rate, uint64_t seed, uint32_t layer, hipStream_t stream) {
+  return crnn_dropout_keep_bytes_batch(1, &out, &ngroups, &layer, rate, seed, stream);
 }
 
 // g_out[perm(r)][c] = g[r][c] * [y[r][c] > 0]      (backward of ReLU, and of Dropout∘ReLU when y is the

@@ -39,7 +39,7 @@ struct DbsParams {
   const unsigned char *d, *da, *xin; unsigned char* dx; const float *bnstate, *coef, *k; float* partials;
   int H, W, C, HB, nwgb, nsplit, cols, cppw, rowbytes;
   // prologue form: xin = q of the previous block, its BatchNorm-2 state [mean|var|scale|shift] and dropout site
-  const float* pro_bn; const unsigned char* keep; float rate;
+  const float* pro_bn; const unsigned char* keep; float rate; float* bn2_partials;
 };
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
@@ -57,16 +57,17 @@ constexpr int kSub = 5 * 1024;               // one row of one tensor in a ring 
 constexpr int kStageB = 3 * kSub;            // d | da | xin
 constexpr int kNI = 15;                      // DMA instructions per stage
 // LDS plan for KD stages in flight (prologue form: + two rows of re-formed x)
-template <int KD>
+template <int KD, bool STATS = false>
 struct DbsLds {
-  static constexpr int NR = KD + 1;
+  static constexpr int NR = KD + (STATS ? 3 : 1);   // (the statistics form reads a stage's raw xin row once more, three steps after it landed)
   static constexpr int DdOff = NR * kStageB;        // two dd rows
   static constexpr int ZOff = DdOff + 2 * kSub;     // 16 zero bytes
   static constexpr int CstOff = ZOff + 64;          // BatchNorm constants of the workgroup's channels: scale | shift | P | Q, [4][<= 256] floats
   static constexpr int XtOff = CstOff + 4 * 256 * 4;   // prologue form: two rows of x = Dropout(ReLU6(BatchNorm-2(q)))
   static constexpr int PcOff = XtOff + 2 * kSub;       // prologue form: BatchNorm-2 scale | shift of the workgroup's channels, [2][<= 256] floats
   static constexpr int KeepOff = PcOff + 2 * 256 * 4;  // prologue form: NR x 512 bytes of keep bytes (one per 16-byte chunk of the stage's xin row)
-  static constexpr int Total = KeepOff + NR * 512;
+  static constexpr int DxrOff = KeepOff + NR * 512;    // statistics form: two rows of dx (bf16, as stored) for the statistics wave
+  static constexpr int Total = DxrOff + (STATS ? 2 * kSub : 0);
   static_assert((KD - 1) * kNI <= 63, "vmcnt is a 6-bit counter");
 };
 constexpr int kD = CRNN_DBS_D;
@@ -81,16 +82,34 @@ __device__ __forceinline__ int role_of(int w, int& idx) {   // 0 = DK, 1 = DX, 2
   return 1;
 }
 
-template <int KD, bool PRO, bool DROP>
-__global__ __launch_bounds__(704) void dw_bwd_stream_kernel(DbsParams p) {
-  typedef DbsLds<KD> LP;
-  constexpr int kNR = LP::NR, kDdOff = LP::DdOff, kZOff = LP::ZOff, kCstOff = LP::CstOff, kXtOff = LP::XtOff, kPcOff = LP::PcOff, kKeepOff = LP::KeepOff;
+// statistics form (12 waves): DK ~145 operations per step, DX ~135 (with the re-forming of x), the statistics wave ~400 --
+//   SIMD 0: w0 w4 w8 = DK DK DX;  SIMD 1: w1 w5 w9 = DK DK DX;  SIMD 2: w2 w6 w10 = DK DX DX;  SIMD 3: w3 w7 w11 = DX loader S
+__device__ __forceinline__ int role_of_stats(int w, int& idx) {   // 0 = DK, 1 = DX, 2 = loader, 3 = statistics
+  switch (w) {
+    case 0: idx = 0; return 0;  case 4: idx = 1; return 0;  case 1: idx = 2; return 0;  case 5: idx = 3; return 0;  case 2: idx = 4; return 0;
+    case 8: idx = 0; return 1;  case 9: idx = 1; return 1;  case 6: idx = 2; return 1;  case 10: idx = 3; return 1;  case 3: idx = 4; return 1;
+    case 7: idx = 0; return 2;
+    default: idx = 0; return 3;   // w11
+  }
+}
+
+// STATS (prologue form only, opt-in: CRNN_FLAG_BN2_STATS_FUSION): a twelfth wave takes the statistics pass of the producer's BatchNorm-2
+// backward -- per channel sum gy and sum gy * xhat with gy = dx * dropout * [0 < q * scale + shift < 6] (what bn_bwd_kernel<1> reads q and dx
+// again for) -- from the dx rows the DX waves leave in LDS beside their global stores and the raw q rows still in the ring (three stages
+// deeper); one partial row [2][C] per workgroup band.  Measured (profiles/r04_*, four launches at batch 256): the pass it replaces 0.28 ms;
+// this kernel + 0.24 ms (the one wave's ~400 operations per step are the critical path); done by the DX waves themselves + 0.65 (36
+// spilled registers); gating in the DX waves and sums in the twelfth + 0.35 -- so it is not the default schedule.
+template <int KD, bool PRO, bool DROP, bool STATS = false>
+__global__ __launch_bounds__(STATS ? 768 : 704) void dw_bwd_stream_kernel(DbsParams p) {
+  static_assert(!STATS || PRO, "the statistics form is a prologue form");
+  typedef DbsLds<KD, STATS> LP;
+  constexpr int kNR = LP::NR, kDdOff = LP::DdOff, kZOff = LP::ZOff, kCstOff = LP::CstOff, kXtOff = LP::XtOff, kPcOff = LP::PcOff, kKeepOff = LP::KeepOff, kDxrOff = LP::DxrOff;
   constexpr int kNIT = kNI + (DROP ? 2 : 0);           // DMA instructions per stage
   static_assert((KD - 1) * kNIT <= 63, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int gidx; const int role = role_of(wave, gidx);
+  int gidx; const int role = STATS ? role_of_stats(wave, gidx) : role_of(wave, gidx);
   int bid = blockIdx.x;
   const int split = bid % p.nsplit; bid /= p.nsplit;
   const int wb = bid % p.nwgb, img = bid / p.nwgb;
@@ -155,6 +174,83 @@ __global__ __launch_bounds__(704) void dw_bwd_stream_kernel(DbsParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (STATS) __builtin_amdgcn_s_barrier();         // (the statistics wave takes its last row before the ring is reused)
+    __builtin_amdgcn_s_barrier();
+    return;
+  }
+  if (STATS && role == 3) {
+    // ------------------------------------------------------------------ statistics wave: all five column groups, one step behind the DX waves
+    int offS[kCW]; bool actS[kCW];
+#pragma unroll
+    for (int g = 0; g < kCW; ++g) { const int c = g * 64 + lane; actS[g] = c < p.cols; offS[g] = actS[g] ? c : p.cols - 1; }
+    // 64 % cppw == 0 (cppw is a power of two <= 32): every group of a lane holds the same channel octet -- one set of constants and sums
+    const int chS = c0 + ((lane % p.cppw) << 3);
+    f32x2_t sc[4], sh[4], iv[4], nm[4], st_s[4], st_q[4];          // xhat = q * inv - mean * inv
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sc[e] = (f32x2_t){p.pro_bn[2 * p.C + chS + 2 * e], p.pro_bn[2 * p.C + chS + 2 * e + 1]};
+      sh[e] = (f32x2_t){p.pro_bn[3 * p.C + chS + 2 * e], p.pro_bn[3 * p.C + chS + 2 * e + 1]};
+      iv[e] = (f32x2_t){1.0f / sqrtf(p.pro_bn[p.C + chS + 2 * e] + BN_EPS_F), 1.0f / sqrtf(p.pro_bn[p.C + chS + 2 * e + 1] + BN_EPS_F)};
+      nm[e] = (f32x2_t){-p.pro_bn[chS + 2 * e] * iv[e].x, -p.pro_bn[chS + 2 * e + 1] * iv[e].y};
+      st_s[e] = (f32x2_t){0.f, 0.f}; st_q[e] = (f32x2_t){0.f, 0.f};
+    }
+    int qslot = 2;                                   // ring slot of stage b - 2 at barrier index b = 4
+    // barrier index b: dx row b - 4 (image row r0 + b - 4, left in LDS by the DX waves in their step b - 2) and the raw q row of stage b - 2:
+    // gy = the stored bf16 dx where the element was kept and 0 < q * scale + shift < 6 (bn_bwd_kernel's gy without the 1 / (1 - rate) factor)
+    auto take = [&](int b) {
+      const unsigned char* dr = lds + kDxrOff + (b & 1) * kSub;
+      const unsigned char* qr = lds + qslot * kStageB + 2 * kSub;
+      const unsigned char* kr = lds + kKeepOff + qslot * 512;
+      qslot = qslot + 1 == kNR ? 0 : qslot + 1;
+      u32x4 vg[kCW], vq[kCW]; uint32_t kq[kCW];
+#pragma unroll
+      for (int g = 0; g < kCW; ++g) {
+        vg[g] = *reinterpret_cast<const u32x4*>(dr + offS[g] * 16); vq[g] = *reinterpret_cast<const u32x4*>(qr + offS[g] * 16);
+        kq[g] = DROP ? (uint32_t)kr[offS[g]] : 0xffu;
+      }
+#pragma unroll
+      for (int g = 0; g < kCW; ++g) {
+        if (g * 64 >= p.cols) continue;              // (uniform)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x2_t x2 = (f32x2_t){__uint_as_float(vq[g][q] << 16), __uint_as_float(vq[g][q] & 0xffff0000u)};
+          const f32x2_t t = __builtin_elementwise_fma(x2, sc[q], sh[q]);
+          uint32_t gm = actS[g] ? vg[g][q] : 0u;
+          if (DROP) {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe((int)kq[g], 2 * q, 1), hi = (uint32_t)__builtin_amdgcn_sbfe((int)kq[g], 2 * q + 1, 1);
+            gm &= __builtin_amdgcn_perm(hi, lo, 0x07060100u);
+          }
+          f32x2_t gy = (f32x2_t){__uint_as_float(gm << 16), __uint_as_float(gm & 0xffff0000u)};
+          gy = (f32x2_t){(t.x > 0.f && t.x < 6.f) ? gy.x : 0.f, (t.y > 0.f && t.y < 6.f) ? gy.y : 0.f};
+          st_s[q] += gy;
+          st_q[q] = __builtin_elementwise_fma(gy, __builtin_elementwise_fma(x2, iv[q], nm[q]), st_q[q]);
+        }
+      }
+    };
+    for (int b = 0; b < nsteps; ++b) {
+      __builtin_amdgcn_s_barrier();
+      if (b >= 4) take(b);
+    }
+    __builtin_amdgcn_s_barrier();                    // ring free for everybody else ...
+    take(nsteps);                                    // ... after the last row (dx row HB - 1): barrier index HB + 3
+    __builtin_amdgcn_s_barrier();
+    // lanes l, l + cppw, ... hold the same channels -> xor shuffles; this one wave has seen every column of the workgroup
+    for (int o = p.cppw; o < 64; o <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        st_s[e].x += __shfl_xor(st_s[e].x, o, 64); st_s[e].y += __shfl_xor(st_s[e].y, o, 64);
+        st_q[e].x += __shfl_xor(st_q[e].x, o, 64); st_q[e].y += __shfl_xor(st_q[e].y, o, 64);
+      }
+    }
+    if (lane < p.cppw) {
+      const float ik = DROP ? 1.f / (1.f - p.rate) : 1.f;        // gy carries the dropout's 1 / (1 - rate): applied once here
+      float* prow = p.bn2_partials + (long)(blockIdx.x / p.nsplit) * 2 * p.C + chS;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        prow[2 * e] = st_s[e].x * ik; prow[2 * e + 1] = st_s[e].y * ik;
+        prow[p.C + 2 * e] = st_q[e].x * ik; prow[p.C + 2 * e + 1] = st_q[e].y * ik;
+      }
+    }
     __builtin_amdgcn_s_barrier();
     return;
   }
@@ -186,7 +282,9 @@ __global__ __launch_bounds__(704) void dw_bwd_stream_kernel(DbsParams p) {
     const int pcw = p.cppw * 8;                       // channels of this workgroup
     float* pct = reinterpret_cast<float*>(lds + kPcOff);
     if (PRO)
-      for (int i = gidx * 64 + lane; i < pcw; i += kCW * 64) { pct[i] = p.pro_bn[2 * p.C + c0 + i]; pct[pcw + i] = p.pro_bn[3 * p.C + c0 + i]; }
+      for (int i = gidx * 64 + lane; i < pcw; i += kCW * 64) {
+        pct[i] = p.pro_bn[2 * p.C + c0 + i]; pct[pcw + i] = p.pro_bn[3 * p.C + c0 + i];
+      }
     const float* pcl = pct + oct * 8;
     const float pik = DROP ? 1.f / (1.f - p.rate) : 1.f;
     int xslot = 1;                                    // ring slot of the next stage to re-form (stage 1 first)
@@ -242,6 +340,7 @@ __global__ __launch_bounds__(704) void dw_bwd_stream_kernel(DbsParams p) {
         u32x4 o;
         o.x = pack2_bf16(A[0], A[1]); o.y = pack2_bf16(A[2], A[3]); o.z = pack2_bf16(A[4], A[5]); o.w = pack2_bf16(A[6], A[7]);
         if (!(CRNN_DBS_EXP & 2)) *reinterpret_cast<u32x4*>(orow + (long)(a - 2) * p.rowbytes) = o;
+        if (STATS) *reinterpret_cast<u32x4*>(lds + kDxrOff + (a & 1) * kSub + offC) = o;   // (for the statistics wave, one step later)
       }
     };
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -262,6 +361,7 @@ __global__ __launch_bounds__(704) void dw_bwd_stream_kernel(DbsParams p) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (STATS) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
     return;
   }
@@ -366,6 +466,7 @@ __global__ __launch_bounds__(704) void dw_bwd_stream_kernel(DbsParams p) {
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                    // ring free
+  if (STATS) __builtin_amdgcn_s_barrier();         // (... once the statistics wave has taken its last row out of it)
   // weight-gradient partials of the workgroup: lanes l, l + cppw, ... of a wave hold the same channels -> xor shuffles; the five waves
   // through LDS in a fixed order
   float* red = reinterpret_cast<float*>(lds);       // [5 waves][9][cppw * 8]
@@ -446,7 +547,7 @@ extern "C" int crnn_dwconv3x3_bwd_stream(const void* d, const void* da, const fl
   p.d = (const unsigned char*)d; p.da = (const unsigned char*)da; p.xin = (const unsigned char*)xin; p.dx = (unsigned char*)dx;
   p.bnstate = bnstate; p.coef = coef; p.k = k; p.partials = scratch;
   p.H = H; p.W = W; p.C = C; p.HB = g.HB; p.nwgb = g.nwgb; p.nsplit = g.nsplit; p.cols = g.cols; p.cppw = g.cppw; p.rowbytes = W * C * 2;
-  p.pro_bn = nullptr; p.keep = nullptr; p.rate = 0.f;
+  p.pro_bn = nullptr; p.keep = nullptr; p.rate = 0.f; p.bn2_partials = nullptr;
   CRNN_LDS_ATTR((dw_bwd_stream_kernel<kD, false, false>), DbsLds<kD>::XtOff);
   hipLaunchKernelGGL((dw_bwd_stream_kernel<kD, false, false>), dim3(B * g.nwgb * g.nsplit), dim3(704), DbsLds<kD>::XtOff, stream, p);
   CRNN_LAUNCH_CHECK();
@@ -459,9 +560,12 @@ extern "C" int crnn_dwconv_bwd_stream_pro_supported(int B, int H, int W, int C) 
   const DbsGeom g = dbs_geom(B, H, W, C);       // (+ the keep bytes of a stage travel as whole dwords: 4 columns of one pixel)
   return (g.ok && g.cppw % 4 == 0 && g.cols % 4 == 0 && (W * (C / 8)) % 4 == 0 && (long)B * H * W * (C / 8) < (1L << 31)) ? CRNN_OK : CRNN_ERR_UNSUPPORTED;
 }
+// bn2_stat_partials != NULL: [crnn_dwconv_bwd_stream_rows][2][C] partial sums (sum gy | sum gy * xhat) of the PRODUCER's BatchNorm-2 backward, gy = dx routed
+// through the dropout mask and the ReLU6 gate of q -- the statistics pass of crnn_bn_bwd_ex(q, dx, pro_bnstate, ..., rate, seed, layer) (finish with
+// crnn_bn_bwd_finalize, then crnn_bn_bwd_apply_ex); the same sums in another order.
 extern "C" int crnn_dwconv3x3_bwd_stream_pro(const void* d, const void* da, const float* bnstate, const float* coef, const void* q, const float* pro_bnstate,
-                                             float rate, const void* keep, const float* k, void* dx, float* dk, float* scratch, int B, int H,
-                                             int W, int C, hipStream_t stream) {
+                                             float rate, const void* keep, const float* k, void* dx, float* dk, float* scratch, float* bn2_stat_partials,
+                                             int B, int H, int W, int C, hipStream_t stream) {
   if (!d || !da || !bnstate || !coef || !q || !pro_bnstate || !k || !dx || !dk || !scratch || rate < 0.f || rate >= 1.f || (rate > 0.f && !keep)) return CRNN_ERR_ARG;
   const DbsGeom g = dbs_geom(B, H, W, C);
   if (crnn_dwconv_bwd_stream_pro_supported(B, H, W, C) != CRNN_OK) return CRNN_ERR_UNSUPPORTED;
@@ -471,15 +575,17 @@ extern "C" int crnn_dwconv3x3_bwd_stream_pro(const void* d, const void* da, cons
   p.d = (const unsigned char*)d; p.da = (const unsigned char*)da; p.xin = (const unsigned char*)q; p.dx = (unsigned char*)dx;
   p.bnstate = bnstate; p.coef = coef; p.k = k; p.partials = scratch;
   p.H = H; p.W = W; p.C = C; p.HB = g.HB; p.nwgb = g.nwgb; p.nsplit = g.nsplit; p.cols = g.cols; p.cppw = g.cppw; p.rowbytes = W * C * 2;
-  p.pro_bn = pro_bnstate; p.keep = (const unsigned char*)keep; p.rate = rate;
+  p.pro_bn = pro_bnstate; p.keep = (const unsigned char*)keep; p.rate = rate; p.bn2_partials = bn2_stat_partials;
   constexpr int KD = kD + 1;
-  if (rate > 0.f) {
-    CRNN_LDS_ATTR((dw_bwd_stream_kernel<KD, true, true>), DbsLds<KD>::Total);
-    hipLaunchKernelGGL((dw_bwd_stream_kernel<KD, true, true>), dim3(B * g.nwgb * g.nsplit), dim3(704), DbsLds<KD>::Total, stream, p);
-  } else {
-    CRNN_LDS_ATTR((dw_bwd_stream_kernel<KD, true, false>), DbsLds<KD>::Total);
-    hipLaunchKernelGGL((dw_bwd_stream_kernel<KD, true, false>), dim3(B * g.nwgb * g.nsplit), dim3(704), DbsLds<KD>::Total, stream, p);
-  }
+  const dim3 grid(B * g.nwgb * g.nsplit);
+#define DBS_PRO_LAUNCH(DROP, STATS)                                                                                     \
+  do {                                                                                                                  \
+    CRNN_LDS_ATTR((dw_bwd_stream_kernel<KD, true, DROP, STATS>), (DbsLds<KD, STATS>::Total));                           \
+    hipLaunchKernelGGL((dw_bwd_stream_kernel<KD, true, DROP, STATS>), grid, dim3(STATS ? 768 : 704), (DbsLds<KD, STATS>::Total), stream, p); \
+  } while (0)
+  if (bn2_stat_partials) { if (rate > 0.f) DBS_PRO_LAUNCH(true, true); else DBS_PRO_LAUNCH(false, true); }
+  else { if (rate > 0.f) DBS_PRO_LAUNCH(true, false); else DBS_PRO_LAUNCH(false, false); }
+#undef DBS_PRO_LAUNCH
   CRNN_LAUNCH_CHECK();
   return crnn_partials_sum(scratch, B * g.nwgb, 9 * C, dk, 1.f, stream);
 }

@@ -19,14 +19,15 @@
 // PROLOGUE form (round 4, training): the input is the PREVIOUS block's pointwise output q and the kernel applies that block's
 // BatchNorm-2 + ReLU6 + Dropout(.1) (utils.py:48-56: x = drop(relu6(q * scale + shift)), the arithmetic of bn_act_pool_drop_kernel
 // bit for bit) to every row after it has landed in LDS -- the block output x is never written to or read from HBM (one read pass +
-// one write pass of the largest tensors of the step less per un-pooled block).  Every compute wave rewrites ITS OWN 16-byte chunk of
-// the row that arrived one step ahead (in place, bf16 again) before it works on the current row; the ring is one slot deeper so
-// that as many rows stay in flight.  The dropout decisions arrive as one keep byte per chunk (crnn_dropout_keep_bytes), brought
-// into LDS by the loader wave next to the row.  How it got there (profiles/r04_*): two dedicated transform waves that also
-// evaluated the counter RNG: +60 % kernel time (a wave issues one VALU operation per 4 cycles: the ~100 operations per chunk x 5
-// chunks per lane outlast the row's 2400-cycle HBM budget; interleaving the five RNG chains changed nothing -- issue, not latency);
-// keep bytes instead of the RNG: +30 %; the same work spread over the nine compute waves (~65 operations more per wave and row): see
-// the bench.
+// one write pass of the largest tensors of the step less per un-pooled block).  Two TRANSFORM waves rewrite the row that arrived one
+// step ahead in place (bf16 again) while the compute waves work on the current row; the ring is one slot deeper so that as many
+// rows stay in flight; the 12 waves are dealt over the SIMDs so that the transform waves share theirs with fewer compute waves.
+// The dropout decisions arrive as one keep byte per chunk (crnn_dropout_keep_bytes), brought into LDS by the loader wave next to
+// the row.  How it got there (profiles/r04_*, four forward launches, cold): two-pass path 0.51 ms; transform waves that also evaluate
+// the counter RNG 0.43 (a wave issues one VALU operation per 4 cycles: ~100 operations per chunk x 5 chunks per lane outlast the
+// row's 2400-cycle HBM budget; interleaving the five RNG chains changed nothing -- issue, not latency); keep bytes loaded by the
+// transform waves themselves 0.35 (a vmcnt wait per row); the re-forming done by the nine compute waves on their own chunks 0.50
+// (two dependent LDS round trips per row in every wave, register spills); keep bytes through the loader's DMA: this version.
 #include "common.h"
 
 namespace {
@@ -59,25 +60,112 @@ constexpr int kDwsMaxWaves = 9;     // compute waves (576 columns of 16 bytes)
 // NI: 1 KiB DMA instructions per step row; D: rows in flight; EPI: out = ReLU6(conv * scale + shift) (inference), no statistics;
 // PRO: prologue form (the input is q of the previous block: BatchNorm-2 + ReLU6 [+ dropout: DROP] applied in LDS)
 constexpr int kDwsKeepNI = 3;        // prologue form with dropout: 4-byte DMA instructions per step row for the keep bytes (<= 768 chunks)
+// role of wave slot w in the prologue form (12 waves, SIMD = w mod 4): 9 compute waves, the loader, two transform waves --
+//   SIMD 0: w0 w4 w8 = C C C;  SIMD 1: w1 w5 w9 = C T L;  SIMD 2: w2 w6 w10 = C C C;  SIMD 3: w3 w7 w11 = C C T
+// (the transform wave with five chunks per lane shares its SIMD with one compute wave, the one with four with two; letting the loader
+// re-form a third of the row between its issues was measured slower: 0.35 against 0.31 ms for the four launches -- its DMA issues slip)
+__device__ __forceinline__ int dws_pro_role(int w, int& idx) {   // 0 = compute, 1 = transform, 2 = loader; idx: compute index / transformer index
+  if (w == 9) { idx = 0; return 2; }
+  if (w == 5) { idx = 0; return 1; }
+  if (w == 11) { idx = 1; return 1; }
+  idx = w < 5 ? w : (w < 9 ? w - 1 : 8);                        // 0 1 2 3 4 | 6 7 8 -> 5 6 7 | 10 -> 8
+  return 0;
+}
+constexpr int kDwsProChunks = 5;     // 16-byte chunks per transforming lane and row: chunks j * 128 + 64 * (transformer index) + lane
+constexpr int kDwsProStride = 128;
+
+// Re-forming x = Dropout(ReLU6(q * scale + shift)) of a transformer's chunks of one row, in place (bf16 -> bf16): bn_act_pool_drop_kernel's
+// arithmetic bit for bit; dropout decisions from the row's keep bytes (one per chunk) next to it in LDS.
+template <bool DROP>
+struct DwsXform {
+  int coff[kDwsProChunks]; bool cact[kDwsProChunks]; int nj;
+  f32x2_t sc[4], sh[4]; float ik;
+  __device__ __forceinline__ void init(const DwsParams& p, int tw, int lane) {
+    nj = 0;
+#pragma unroll
+    for (int j = 0; j < kDwsProChunks; ++j) {
+      const int c = j * kDwsProStride + tw * 64 + lane;
+      cact[j] = c < p.cols;
+      coff[j] = cact[j] ? c : 0;
+      if (j * kDwsProStride + tw * 64 < p.cols) nj = j + 1;     // (uniform) chunks this wave has
+    }
+    // kDwsProStride % (C / 8) == 0 (launcher): every chunk of a lane holds the same channel octet
+    const int oct = (tw * 64 + lane) % (p.C >> 3);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sc[e] = (f32x2_t){p.pro_bn[2 * p.C + oct * 8 + 2 * e], p.pro_bn[2 * p.C + oct * 8 + 2 * e + 1]};
+      sh[e] = (f32x2_t){p.pro_bn[3 * p.C + oct * 8 + 2 * e], p.pro_bn[3 * p.C + oct * 8 + 2 * e + 1]};
+    }
+    ik = DROP ? 1.f / (1.f - p.rate) : 1.f;                     // (spelled as bn_act_pool_drop_kernel spells it: the same bits)
+  }
+  __device__ __forceinline__ void run(unsigned char* sb, const unsigned char* kbp) const {
+    if (CRNN_DWS_EXP & 32) return;                               // experiment build: no re-forming
+    u32x4 v[kDwsProChunks]; uint32_t kc[kDwsProChunks];
+#pragma unroll
+    for (int j = 0; j < kDwsProChunks; ++j) { v[j] = *reinterpret_cast<const u32x4*>(sb + coff[j] * 16); kc[j] = DROP ? (uint32_t)kbp[coff[j]] : 0xffu; }
+    const f32x2_t ik2 = (f32x2_t){ik, ik};
+#pragma unroll
+    for (int j = 0; j < kDwsProChunks; ++j) {
+      if (j >= nj) continue;
+      u32x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x2_t x2 = (f32x2_t){__uint_as_float(v[j][q] << 16), __uint_as_float(v[j][q] & 0xffff0000u)};
+        f32x2_t y = __builtin_elementwise_fma(x2, sc[q], sh[q]);      // per element fmaf(x, scale, shift): v_pk_fma_f32
+        y = (f32x2_t){relu6f(y.x), relu6f(y.y)};
+        if (DROP) {
+          y = y * ik2;                                             // per element y * inv_keep (v_pk_mul_f32), as the stand-alone pass
+          // dropped elements as an AND mask on the packed pair (y >= 0: y * 0 and 0 are the same bits): sign-extending 1-bit extracts
+          const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe((int)kc[j], 2 * q, 1), hi = (uint32_t)__builtin_amdgcn_sbfe((int)kc[j], 2 * q + 1, 1);
+          o[q] = pack2_bf16(y.x, y.y) & __builtin_amdgcn_perm(hi, lo, 0x07060100u);
+        } else {
+          o[q] = pack2_bf16(y.x, y.y);
+        }
+      }
+      if (cact[j]) *reinterpret_cast<u32x4*>(sb + coff[j] * 16) = o;
+    }
+  }
+};
+
 template <int NI, int D, bool EPI, bool PRO, bool DROP = false>
-__global__ __launch_bounds__((kDwsMaxWaves + 1) * 64) void dw_fwd_stream_kernel(DwsParams p) {
+__global__ __launch_bounds__((kDwsMaxWaves + (PRO ? 3 : 1)) * 64) void dw_fwd_stream_kernel(DwsParams p) {
   constexpr int NR = D + 1, SLOT = NI * 1024;
   constexpr int NIT = NI + (DROP ? kDwsKeepNI : 0);            // DMA instructions per step row
   static_assert((D - 1) * NIT <= 63, "vmcnt is a 6-bit counter");
   static_assert(!(PRO && EPI) && !(DROP && !PRO), "the prologue form is the training form");
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ncw = (int)(blockDim.x >> 6) - 1;
-  constexpr int KOFF = NR * SLOT + 64;                         // prologue form: NR x 1 KiB of keep bytes behind the zero chunk,
-  constexpr int PCOFF = KOFF + NR * 1024;                      // then the producer's BatchNorm scale | shift, [2][C <= 512] floats
+  const int wave0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ncw = PRO ? kDwsMaxWaves : (int)(blockDim.x >> 6) - 1;
+  int ridx = 0;
+  const int role = PRO ? dws_pro_role(wave0, ridx) : 0;
+  // `wave`: index of a compute wave among the compute waves; == ncw for the loader (the transform waves take their own branch first)
+  const int wave = PRO ? (role == 0 ? ridx : ncw) : wave0;
+  constexpr int KOFF = NR * SLOT + 64;                         // prologue form: NR x 1 KiB of keep bytes behind the zero chunk
   const int img = blockIdx.x / p.nwgb, wb = blockIdx.x - img * p.nwgb;
   const int r0 = wb * p.NS * p.HB;                 // first output row of sub-band 0
   const int steps = p.HB + 2;                      // input rows r0-1 .. r0+HB of every sub-band
   const int zoff = NR * SLOT;                      // 16 zero bytes (the pixels left of x = 0 and right of x = W-1)
   if (tid < 4) reinterpret_cast<unsigned*>(lds + zoff)[tid] = 0u;
 
-  if (wave == ncw) {
+  if (PRO && role == 1) {
+    // ------------------------------------------------------------------ transform waves (prologue form): half of every row each
+    DwsXform<DROP> xf;
+    xf.init(p, ridx, lane);
+    auto xform = [&](int slot) { xf.run(lds + slot * SLOT, lds + KOFF + slot * 1024); };
+    __builtin_amdgcn_s_barrier();                                // P: row 0 has landed
+    xform(0);
+    int slot = 1;                                                // slot of row t + 1
+    for (int t = 0; t < steps; ++t) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                              // row t + 1 has landed; row t is transformed
+      if (t + 1 < steps) xform(slot);
+      slot = slot + 1 == NR ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (!EPI && p.partials) __builtin_amdgcn_s_barrier();
+  } else if (wave == ncw) {
     // ------------------------------------------------------------------ loader wave
     const unsigned char* gx = p.x + (long)img * p.H * p.rowbytes;
     int rowfirst[NI], within[NI];
@@ -161,47 +249,7 @@ __global__ __launch_bounds__((kDwsMaxWaves + 1) * 64) void dw_fwd_stream_kernel(
 #pragma unroll
     for (int e = 0; e < 8; ++e) { X0[e] = X1[e] = X2[e] = 0.f; s[e] = ss[e] = 0.f; }
     const int rsub = r0 + sub * p.HB;                          // this lane's first output row
-    // prologue form: x = Dropout(ReLU6(q * scale + shift)) of the lane's own chunk of a row, in place (bf16 -> bf16)
-    // (its 16 BatchNorm constants per lane live in an LDS table [scale | shift][C] and are read per row: the taps and the running
-    // rows fill the registers)
-    float* pct = reinterpret_cast<float*>(lds + PCOFF);
-    if (PRO) {
-      for (int i = col; i < 2 * p.C; i += ncw * 64) pct[i] = p.pro_bn[2 * p.C + i];   // scale then shift: contiguous in bnstate
-    }
-    const float* pcl = pct + oct * 8;
-    const int pC = p.C;
-    const float pik = DROP ? 1.f / (1.f - p.rate) : 1.f;       // (spelled as bn_act_pool_drop_kernel spells it: the same bits)
-    int xslot = 0;                                             // slot of the next row to re-form
-    auto xform = [&]() {
-      unsigned char* cp = lds + xslot * SLOT + offC;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(cp);
-      uint32_t kc = 0xffu;
-      if (DROP) kc = lds[KOFF + xslot * 1024 + ccol];
-      xslot = xslot + 1 == NR ? 0 : xslot + 1;
-      if (CRNN_DWS_EXP & 32) return;                           // experiment build: no re-forming
-      u32x4 o;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x2_t x2 = (f32x2_t){__uint_as_float(v[q] << 16), __uint_as_float(v[q] & 0xffff0000u)};
-        const f32x2_t psc = *reinterpret_cast<const f32x2_t*>(pcl + 2 * q), psh = *reinterpret_cast<const f32x2_t*>(pcl + pC + 2 * q);
-        f32x2_t y = __builtin_elementwise_fma(x2, psc, psh);         // per element fmaf(x, scale, shift)
-        y = (f32x2_t){relu6f(y.x), relu6f(y.y)};
-        if (DROP) {
-          y = y * (f32x2_t){pik, pik};                           // per element y * inv_keep, as the stand-alone pass
-          // dropped elements as an AND mask on the packed pair (y >= 0: y * 0 and 0 are the same bits): sign-extending 1-bit extracts
-          const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe((int)kc, 2 * q, 1), hi = (uint32_t)__builtin_amdgcn_sbfe((int)kc, 2 * q + 1, 1);
-          o[q] = pack2_bf16(y.x, y.y) & __builtin_amdgcn_perm(hi, lo, 0x07060100u);
-        } else {
-          o[q] = pack2_bf16(y.x, y.y);
-        }
-      }
-      if (act) *reinterpret_cast<u32x4*>(cp) = o;
-      __builtin_amdgcn_sched_barrier(0);                       // its temporaries are dead before the window of the current row is loaded
-    };
-    if (PRO) {
-      __builtin_amdgcn_s_barrier();                            // P: row 0 has landed
-      xform();
-    }
+    if (PRO) __builtin_amdgcn_s_barrier();                     // P (the transform waves take row 0 now)
     unsigned char* orow = p.out + ((long)img * p.H + rsub) * p.rowbytes + px * pitch + oct * 16;
     // window-major output (EPI only; crnn_dwconv3x3_fwd_stream_ex out_order 1): pixel (y, x) is row ((y/2) (W/2) + x/2) 4 + (y&1) 2 + (x&1) of
     // the image -- the four pixels of a 2x2 pooling window are consecutive rows for the pointwise GEMM whose epilogue pools them
@@ -211,7 +259,6 @@ __global__ __launch_bounds__((kDwsMaxWaves + 1) * 64) void dw_fwd_stream_kernel(
     auto step = [&](int t, float (&A)[8], float (&Bc)[8], float (&Cn)[8], bool edge) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (PRO && t + 1 < steps) xform();                         // row t + 1 has landed: re-form the own chunk of it; row t is complete
       const unsigned char* sb = lds + slot * SLOT;
       u32x4 vL = *reinterpret_cast<const u32x4*>(hasL ? sb + offC - pitch : lds + zoff);
       u32x4 vC = *reinterpret_cast<const u32x4*>(sb + offC);
@@ -361,13 +408,13 @@ constexpr int kDwsProD = kDwsD + 1;
 bool dws_pro_ok(const DwsGeom& g, int B, int H, int W, int C) {
   const int cpp = C / 8;
   // the keep bytes of a step row travel as 4-byte DMA pieces: whole dwords per sub-row, at most kDwsKeepNI * 256 of them
-  return g.ok && cpp > 0 && C <= 512 && (W * cpp) % 4 == 0 && g.cols % 4 == 0 && g.cols <= kDwsKeepNI * 256 && (long)B * H * W * cpp < (1L << 31);
+  return g.ok && g.ncw == kDwsMaxWaves && cpp > 0 && kDwsProStride % cpp == 0 && g.cols <= kDwsProChunks * kDwsProStride && (W * cpp) % 4 == 0 && g.cols % 4 == 0 && g.cols <= kDwsKeepNI * 256 && (long)B * H * W * cpp < (1L << 31);
 }
 template <bool DROP>
 int dws_launch_pro(const DwsParams& p, const DwsGeom& g, int B, hipStream_t stream) {
-  constexpr int lds = (kDwsProD + 1) * (9 + 1) * 1024 + 64 + 2 * 512 * 4;     // rows + 1 KiB of keep bytes per slot + the BatchNorm table
+  constexpr int lds = (kDwsProD + 1) * (9 + 1) * 1024 + 64;     // rows + 1 KiB of keep bytes per slot
   CRNN_LDS_ATTR((dw_fwd_stream_kernel<9, kDwsProD, false, true, DROP>), lds);
-  hipLaunchKernelGGL((dw_fwd_stream_kernel<9, kDwsProD, false, true, DROP>), dim3(B * g.nwgb), dim3((g.ncw + 1) * 64), lds, stream, p);
+  hipLaunchKernelGGL((dw_fwd_stream_kernel<9, kDwsProD, false, true, DROP>), dim3(B * g.nwgb), dim3((kDwsMaxWaves + 3) * 64), lds, stream, p);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }

@@ -181,6 +181,9 @@ Plan make_plan(const crnn_config* c) {
     maxparts = lmax(maxparts, ((long)crnn_loc_conv_wgrad_chunks(d.B, d.Hs2, d.Ws2) + 1) * (25L * 20 * 20 + 20));
   }
   P.add("partials", maxparts);
+  { long n = 0;   // BatchNorm-2 backward statistics taken by the next block's depthwise-stage backward (fuse_bn2_dw): they outlive that block's other partials
+    for (int i = 1; i <= 6; ++i) n = lmax(n, (long)crnn_dwconv_bwd_stream_rows(d.B, d.bh[i + 1], d.bw[i + 1], d.bc[i]) * 2L * d.bc[i]);
+    if (c->mfma_bf16 == 2 && n) P.add("bn2parts", n); }
   { long pw = 0; for (int i = 2; i <= 7; ++i) pw += (long)d.bc[i - 1] * d.bc[i];
     P.add("pwT", pw, CRNN_BF16); }   // bf16 W^T copies of the pointwise-conv weights (bf16 modes)
   P.add("pbf", make_layout(c).total, CRNN_BF16);   // bf16 shadow of the parameter buffer (GEMM B operands in the bf16 modes)
@@ -270,10 +273,12 @@ bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr, 
 // not materialised -- block i+1's depthwise row-stream kernels apply it to q_i after the rows have landed in LDS (forward:
 // crnn_dwconv3x3_fwd_stream_pro) and re-form it the same way for the depthwise weight gradient (backward: crnn_dwconv3x3_bwd_stream_pro): one write
 // and two read passes of x_i less per step.  ONE decision for both passes (the backward has no x_i to fall back to).
-// CRNN_FLAG_NO_BN2_DW_FUSION keeps crnn_bn_act_pool_drop_ex + the plain kernels; bit-identical.
+// Opt-in (CRNN_FLAG_BN2_DW_FUSION; bit-identical to crnn_bn_act_pool_drop_ex + the plain kernels): the re-forming is VALU work on a few waves
+// of kernels that are otherwise bandwidth-bound, and what the step gains in bytes it loses in issue slots -- measured -1.5 % ... +2.5 % step
+// time depending on the box.
 bool fuse_bn2_dw_shape(const crnn_config* cfg, const Dims& d, const Plan& P, int i) {
   if (i < 1 || i > 6) return false;
-  if (cfg->flags & (CRNN_FLAG_NO_BN2_DW_FUSION | CRNN_FLAG_DW_TILE_KERNEL | CRNN_FLAG_NO_DW_BWD_FUSION)) return false;
+  if (!(cfg->flags & CRNN_FLAG_BN2_DW_FUSION) || (cfg->flags & (CRNN_FLAG_DW_TILE_KERNEL | CRNN_FLAG_NO_DW_BWD_FUSION))) return false;
   if (cfg->mfma_bf16 != 2 || kBlocks[i - 1].ph * kBlocks[i - 1].pw != 1) return false;
   const std::string p = std::to_string(i), n = std::to_string(i + 1);
   if (P.dt("q" + p) != CRNN_BF16 || P.dt("x" + p) != CRNN_BF16 || P.dt("d" + n) != CRNN_BF16 || P.off("dm" + p) < 0) return false;
@@ -390,7 +395,7 @@ extern "C" int crnn_ws_tensor_info(const crnn_config* cfg, const char* name, lon
   return 0;
 }
 // 1 when training does not materialise the output x_block of conv block `block` (1..7): the next block's depthwise row-stream kernels form it
-// from q_block in LDS (CRNN_FLAG_NO_BN2_DW_FUSION; bf16-storage mode, un-pooled blocks, image width 32) -- the workspace tensor "x<block>" is
+// from q_block in LDS (CRNN_FLAG_BN2_DW_FUSION; bf16-storage mode, un-pooled blocks, image width 32) -- the workspace tensor "x<block>" is
 // then never written by a training forward.  (16-byte aligned parameter / workspace base pointers assumed, as torch allocations are.)
 extern "C" int crnn_block_output_fused(const crnn_config* cfg, int block) {
   if (check_cfg(cfg)) return 0;
@@ -405,15 +410,72 @@ extern "C" int crnn_ws_tensor(const crnn_config* cfg, const char* name, long* of
   return 0;
 }
 
+namespace {
+// Two streams with event links (fork: the side stream continues after everything enqueued on the main stream so far; join: the reverse)
+struct ForkJoin {
+  // The events are created once per host thread and reused by every call (recording an event again while an earlier
+  // wait on it is still queued is well defined: the wait captured the earlier record); nothing is created or destroyed
+  // on the step's path.
+  hipStream_t main, aux; int n = 0; bool on;
+  ForkJoin(hipStream_t m, hipStream_t a) : main(m), aux(a), on(a != nullptr) {}
+  static int event(int i, hipEvent_t* out) {
+    static thread_local hipEvent_t ev[24] = {};
+    if (i >= 24) return CRNN_ERR_ARG;
+    if (!ev[i]) { hipError_t r = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming); if (r != hipSuccess) return (int)r; }
+    *out = ev[i];
+    return CRNN_OK;
+  }
+  int link(hipStream_t from, hipStream_t to) {   // `to` continues after everything enqueued on `from` so far
+    if (!on) return CRNN_OK;
+    hipEvent_t e; CRNN_TRY(event(n++, &e));
+    hipError_t r = hipEventRecord(e, from); if (r != hipSuccess) return (int)r;
+    r = hipStreamWaitEvent(to, e, 0); return r == hipSuccess ? CRNN_OK : (int)r;
+  }
+  int fork() { return link(main, aux); }
+  int join() { return link(aux, main); }
+  // split form of a join: mark the side stream's progress now, make the main stream wait for that point later
+  int mark(hipEvent_t* e) {
+    if (!on) return CRNN_OK;
+    CRNN_TRY(event(n++, e));
+    hipError_t r = hipEventRecord(*e, aux); return r == hipSuccess ? CRNN_OK : (int)r;
+  }
+  int wait(hipEvent_t e) {
+    if (!on || !e) return CRNN_OK;
+    hipError_t r = hipStreamWaitEvent(main, e, 0); return r == hipSuccess ? CRNN_OK : (int)r;
+  }
+};
+
+}  // namespace
+
 // ---------------------------------------------------------------------------------------------------
 extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const float* bn_mean, const float* bn_var,
                             const float* x, float* ws, size_t ws_bytes, float* y_pred, int train, uint64_t seed,
                             hipStream_t stream) {
+  return crnn_forward_ex(cfg, params, bn_mean, bn_var, x, ws, ws_bytes, y_pred, train, seed, stream, nullptr);
+}
+// aux_stream != NULL (and != stream): work that nothing at the head of the forward waits for runs there next to the spatial transformer's
+// small kernels -- today the dropout keep bytes of the block outputs that only exist inside the next depthwise kernels (a function of
+// (seed, site, index), 0.1 ms of VALU work at batch 256), joined before block 2's depthwise kernel.  Same results.
+extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, const float* bn_mean, const float* bn_var,
+                               const float* x, float* ws, size_t ws_bytes, float* y_pred, int train, uint64_t seed,
+                               hipStream_t stream, hipStream_t aux_stream) {
   CRNN_TRY(check_cfg(cfg));
   Ctx c{cfg, make_dims(cfg), make_layout(cfg), make_plan(cfg), params, nullptr, ws, stream};
   if (ws_bytes < (size_t)c.P.total * sizeof(float)) return CRNN_ERR_ARG;
   const Dims& d = c.d;
   const int B = d.B;
+  ForkJoin fj(stream, aux_stream == stream ? nullptr : aux_stream);
+  bool keep_pending = false;
+  if (train && cfg->dropout) {   // the dropout decisions of the block outputs that only exist inside the next depthwise kernels (fuse_bn2_dw)
+    void* outs[CRNN_KEEP_BATCH_MAX]; long ng[CRNN_KEEP_BATCH_MAX]; uint32_t lay[CRNN_KEEP_BATCH_MAX]; int n = 0;
+    for (int i = 1; i <= 6; ++i)
+      if (fuse_bn2_dw(c, i)) { outs[n] = c.w("dm" + std::to_string(i)); ng[n] = (long)B * d.bh[i] * d.bw[i] * d.bc[i] / 8; lay[n] = (uint32_t)i; ++n; }
+    if (n) {
+      CRNN_TRY(fj.fork());
+      CRNN_TRY(crnn_dropout_keep_bytes_batch(n, outs, ng, lay, kDropBlock, seed, fj.on ? aux_stream : stream));
+      keep_pending = fj.on;
+    }
+  }
   if (cfg->mfma_bf16) CRNN_TRY(crnn_convert_f32_to_bf16(params, c.ws + c.P.off("pbf"), c.L.total, stream));
   // ---- spatial transformer (utils.py:247-258) + ZeroPadding2D (utils.py:63)
   if (cfg->stn) {
@@ -455,10 +517,6 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
     }
     CRNN_TRY(crnn_bn_infer_state_batch(n, mm, mv, gg, bb, cc, st, stream));
   }
-  if (train && cfg->dropout)   // the dropout decisions of the block outputs that only exist inside the next depthwise kernels: a function of (seed, site, index)
-    for (int i = 1; i <= 6; ++i)
-      if (fuse_bn2_dw(c, i))
-        CRNN_TRY(crnn_dropout_keep_bytes(c.w("dm" + std::to_string(i)), (long)B * d.bh[i] * d.bw[i] * d.bc[i] / 8, kDropBlock, seed, (uint32_t)i, stream));
   for (int i = 1; i <= 7; ++i) {
     std::string p = std::to_string(i), bp = "b" + p;
     const int H = d.bh[i], W = d.bw[i], ci = d.bc[i - 1], co = d.bc[i];
@@ -518,6 +576,7 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
       continue;
     }
     if (pro_q) {   // the previous block's output was not materialised: its BatchNorm-2 + ReLU6 + dropout run inside this depthwise kernel (fuse_bn2_dw)
+      if (keep_pending) { CRNN_TRY(fj.join()); keep_pending = false; }   // the keep bytes are complete
       CRNN_TRY(crnn_dwconv3x3_fwd_stream_pro(pro_q, pro_s2, cfg->dropout ? kDropBlock : 0.f, keep_bytes(c, i - 1), c.p(bp + "_dw"), dd, parts, B, H, W, ci, stream));
       CRNN_TRY(crnn_bn_finalize_folded(parts, crnn_dwconv_fwd_stream_rows(B, H, W, ci), ci, M, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), s1, c.w("fold"), stream));
       pro_q = nullptr; pro_s2 = nullptr;
@@ -567,6 +626,7 @@ extern "C" int crnn_forward(const crnn_config* cfg, const float* params, const f
                                       (uint32_t)i, dtq, c.dt("x" + p), stream));
     in = xo;
   }
+  if (keep_pending) { CRNN_TRY(fj.join()); keep_pending = false; }
   // ---- Reshape + dense1 (relu) + Dropout(.4) (utils.py:72-75); output time-major [T][B][tds]
   const int T = d.T, TB = T * B, u = d.u, G = d.G;
   CRNN_TRY(gemm_t(c, 0, in, c.dt("x7"), c.p("dense1_w"), CRNN_F32, c.w("dn1"), CRNN_F32, TB, d.tds, d.feat, d.feat, d.tds, d.tds, c.p("dense1_b"), 1, 0, T));
@@ -786,39 +846,6 @@ namespace {
 // microseconds each and leave the GPU almost idle; the GEMMs fill it.  Only the aux stream touches the split-reduction
 // scratch and the reduction partials between the fork and the join, and every gradient tensor still has a single
 // writer in a fixed order, so the result is bit-identical to the serial schedule.
-struct ForkJoin {
-  // The events are created once per host thread and reused by every call (recording an event again while an earlier
-  // wait on it is still queued is well defined: the wait captured the earlier record); nothing is created or destroyed
-  // on the step's path.
-  hipStream_t main, aux; int n = 0; bool on;
-  ForkJoin(hipStream_t m, hipStream_t a) : main(m), aux(a), on(a != nullptr) {}
-  static int event(int i, hipEvent_t* out) {
-    static thread_local hipEvent_t ev[24] = {};
-    if (i >= 24) return CRNN_ERR_ARG;
-    if (!ev[i]) { hipError_t r = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming); if (r != hipSuccess) return (int)r; }
-    *out = ev[i];
-    return CRNN_OK;
-  }
-  int link(hipStream_t from, hipStream_t to) {   // `to` continues after everything enqueued on `from` so far
-    if (!on) return CRNN_OK;
-    hipEvent_t e; CRNN_TRY(event(n++, &e));
-    hipError_t r = hipEventRecord(e, from); if (r != hipSuccess) return (int)r;
-    r = hipStreamWaitEvent(to, e, 0); return r == hipSuccess ? CRNN_OK : (int)r;
-  }
-  int fork() { return link(main, aux); }
-  int join() { return link(aux, main); }
-  // split form of a join: mark the side stream's progress now, make the main stream wait for that point later
-  int mark(hipEvent_t* e) {
-    if (!on) return CRNN_OK;
-    CRNN_TRY(event(n++, e));
-    hipError_t r = hipEventRecord(*e, aux); return r == hipSuccess ? CRNN_OK : (int)r;
-  }
-  int wait(hipEvent_t e) {
-    if (!on || !e) return CRNN_OK;
-    hipError_t r = hipStreamWaitEvent(main, e, 0); return r == hipSuccess ? CRNN_OK : (int)r;
-  }
-};
-
 // deferred second stages: serial schedule only (a side stream's first stages could not share one flush), bf16 modes with the streaming kernels
 void deferred_setup(const Ctx& c0, Ctx& c, Deferred& def, hipStream_t aux) {
   c = c0;
@@ -879,6 +906,7 @@ int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t au
   Ctx ca = c; if (aux) { ca.s = aux; ca.side = true; }
   float* gA = c.w("gA"); float* gB = c.w("gB"); float* gC = c.w("gC");   // gA holds d loss / d x7 (written by backward_top)
   hipEvent_t gB_free = nullptr, gC_free = nullptr;     // side-stream GEMMs still reading gB / gC (null: none)
+  int bn2_stats_rows = 0;                              // > 0: block i+1's depthwise-stage backward left the statistics of block i's BatchNorm-2 backward in "bn2parts"
   // ---- conv stack
   for (int i = 7; i >= 1; --i) {
     std::string p = std::to_string(i), bp = "b" + p;
@@ -889,6 +917,12 @@ int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t au
                           crnn_dwconv_bwd_fused_supported(H, W, ci) == CRNN_OK;
     int bn1_stats_rows = 0;                               // > 0: the data-gradient GEMM left the BatchNorm-1 backward statistics in `partials`
     CRNN_TRY(fj.wait(gB_free)); gB_free = nullptr;        // gB is written next
+    if (bn2_stats_rows > 0) {   // the depthwise-stage backward of block i+1 took this BatchNorm's statistics pass: finalize, then pass 2 alone
+      CRNN_TRY(crnn_bn_bwd_finalize(c.w("bn2parts"), bn2_stats_rows, co, M, c.g(bp + "_bn2_g"), c.g(bp + "_bn2_b"), c.w("coef"), stream));
+      CRNN_TRY(crnn_bn_bwd_apply_ex(c.w("q" + p), gA, c.w("bn2s" + p), c.w("coef"), gB, B, H, W, co, kBlocks[i - 1].ph, kBlocks[i - 1].pw,
+                                    cfg->dropout ? kDropBlock : 0.f, seed, (uint32_t)i, dtq, stream));
+      bn2_stats_rows = 0;
+    } else
     CRNN_TRY(crnn_bn_bwd_ex(c.w("q" + p), gA, c.w("bn2s" + p), c.p(bp + "_bn2_g"), gB, c.g(bp + "_bn2_g"), c.g(bp + "_bn2_b"), c.w("partials"),
                             c.w("coef"), B, H, W, co, kBlocks[i - 1].ph, kBlocks[i - 1].pw, cfg->dropout ? kDropBlock : 0.f, seed, (uint32_t)i, dtq, stream));
     if (ci == 1 && dtd == CRNN_F32) {   // block 1: outer-product weight / data gradients
@@ -957,8 +991,10 @@ int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t au
       if (fuse_bn2_dw(c, i - 1)) {                           // the forward did not keep x_{i-1}: re-formed from q_{i-1} in LDS (no fallback: same decision)
         const std::string pp = std::to_string(i - 1);
         // (its dropout decisions: the keep bytes the forward of this step left in the workspace -- same seed)
+        float* st2 = (cfg->flags & CRNN_FLAG_BN2_STATS_FUSION) ? c.w("bn2parts") : nullptr;   // opt-in: measured neutral (include/crnn_mi355x.h)
         CRNN_TRY(crnn_dwconv3x3_bwd_stream_pro(c.w("d" + p), gA, c.w("bn1s" + p), c.w("coef"), c.w("q" + pp), c.w("bn2s" + pp), cfg->dropout ? kDropBlock : 0.f,
-                                               keep_bytes(c, i - 1), c.p(bp + "_dw"), gC, c.g(bp + "_dw"), c.w("partials"), B, H, W, ci, stream));
+                                               keep_bytes(c, i - 1), c.p(bp + "_dw"), gC, c.g(bp + "_dw"), c.w("partials"), st2, B, H, W, ci, stream));
+        if (st2) bn2_stats_rows = crnn_dwconv_bwd_stream_rows(B, H, W, ci);
         rc = CRNN_OK;
       } else if (!(cfg->flags & CRNN_FLAG_DW_TILE_KERNEL))         // rows streamed through LDS where the shape rule holds (dwconv_bwd_stream.hip)
         rc = crnn_dwconv3x3_bwd_stream(c.w("d" + p), gA, c.w("bn1s" + p), c.w("coef"), xin, c.p(bp + "_dw"), gC, c.g(bp + "_dw"), c.w("partials"),
@@ -1001,7 +1037,7 @@ extern "C" int crnn_train_step_adam(const crnn_config* cfg, float* params, float
                                     const float* x, const int* labels, const int* input_length, const int* label_length, float* ws,
                                     size_t ws_bytes, float* y_pred, float* loss, void* norm_scratch, float* norm_out, float lr_t,
                                     float beta1, float beta2, float eps, float clipnorm, uint64_t seed, hipStream_t stream) {
-  CRNN_TRY(crnn_forward(cfg, params, bn_mean, bn_var, x, ws, ws_bytes, y_pred, 1, seed, stream));
+  CRNN_TRY(crnn_forward_ex(cfg, params, bn_mean, bn_var, x, ws, ws_bytes, y_pred, 1, seed, stream, nullptr));
   CRNN_TRY(crnn_backward(cfg, params, grads, x, labels, input_length, label_length, ws, ws_bytes, loss, seed, stream));
   const long n = make_layout(cfg).total;
   CRNN_TRY(crnn_global_norm(grads, n, clipnorm, norm_scratch, norm_out, stream));

@@ -41,9 +41,16 @@ typedef struct {
                        conv-stack activations / gradients are stored as bf16 in HBM (statistics, RNN, CTC, optimizer fp32) */
   int flags;        /* bit set of CRNN_FLAG_* (0 = the default schedule); A/B switches: bit-identical results except where a flag says otherwise */
 } crnn_config;
-#define CRNN_FLAG_NO_BN2_DW_FUSION 1024 /* bf16-storage training: materialise every block output x = Dropout(ReLU6(BatchNorm-2(q))) (crnn_bn_act_pool_drop_ex) instead
-                                         * of letting the NEXT block's depthwise row-stream kernels apply it to q in LDS (crnn_dwconv3x3_fwd_stream_pro, forward;
-                                         * crnn_dwconv3x3_bwd_stream_pro re-forms it in backward) after the un-pooled blocks 1, 2, 4, 6; bit-identical */
+#define CRNN_FLAG_BN2_STATS_FUSION 2048 /* opt-in (with the fusion below): statistics pass of the block outputs' BatchNorm-2 backward inside the next block's
+                                         * depthwise-stage backward (crnn_dwconv3x3_bwd_stream_pro with bn2_stat_partials: a twelfth wave) instead of a kernel of
+                                         * its own (crnn_bn_bwd_ex); same data gradients bit for bit, BatchNorm-2 gradients / coefficients the same sums in another
+                                         * order.  Measured neutral (the pass it removes costs 0.28 ms, the depthwise-stage kernels grow by 0.24): not the default */
+#define CRNN_FLAG_BN2_DW_FUSION 1024  /* opt-in, bf16-storage training: the output x = Dropout(ReLU6(BatchNorm-2(q))) of the un-pooled blocks 1, 2, 4, 6 is not
+                                         * materialised (crnn_bn_act_pool_drop_ex); the NEXT block's depthwise row-stream kernels apply it to q in LDS
+                                         * (crnn_dwconv3x3_fwd_stream_pro, forward; crnn_dwconv3x3_bwd_stream_pro re-forms it in backward; the dropout decisions
+                                         * as keep bytes, crnn_dropout_keep_bytes_batch on the side stream).  Bit-identical.  4 of the 8 BatchNorm-apply launches
+                                         * and one write + two read passes of those tensors less per step -- but the re-forming is VALU work on a few waves of a
+                                         * bandwidth kernel: measured -1.5 % ... +2.5 % step time depending on the box's clocks: not the default */
 #define CRNN_FLAG_DW_TILE_KERNEL 32    /* bf16-storage modes: depthwise 3x3 forward and fused depthwise-stage backward on the halo-tile kernels
                                         * (crnn_dwconv3x3_fwd_ex, crnn_dwconv3x3_bwd_fused) instead of the row-stream kernels (crnn_dwconv3x3_fwd_stream,
                                         * crnn_dwconv3x3_bwd_stream); tensors bit-identical, BatchNorm statistics / depthwise weight gradients to
@@ -84,7 +91,7 @@ size_t crnn_workspace_bytes(const crnn_config* cfg);
 /* named view into the workspace (float offset, element count) -- for parity tests / debugging */
 int  crnn_ws_tensor(const crnn_config* cfg, const char* name, long* offset, long* count);
 /* 1 when a training forward does not materialise the output "x<block>" of conv block `block` (1..7): the next block's depthwise row-stream kernels
- * form it from "q<block>" in LDS (see CRNN_FLAG_NO_BN2_DW_FUSION); else 0 */
+ * form it from "q<block>" in LDS (CRNN_FLAG_BN2_DW_FUSION set and the shape rules hold); else 0 */
 int  crnn_block_output_fused(const crnn_config* cfg, int block);
 /* same + storage type of the tensor (0 = fp32, 1 = bf16; offset stays in floats, count in elements) */
 int  crnn_ws_tensor_info(const crnn_config* cfg, const char* name, long* offset, long* count, int* dtype);
@@ -97,6 +104,11 @@ int  crnn_ws_tensor_info(const crnn_config* cfg, const char* name, long* offset,
 int crnn_forward(const crnn_config* cfg, const float* params, const float* bn_mean, const float* bn_var,
                  const float* x, float* ws, size_t ws_bytes, float* y_pred, int train, uint64_t seed,
                  crnn_stream_t stream);
+/* the same with a side stream (NULL: none) for work nothing at the head of the forward waits for -- the dropout keep bytes of the training forward
+ * (crnn_dropout_keep_bytes_batch) next to the spatial transformer's small kernels; joined inside, same results */
+int crnn_forward_ex(const crnn_config* cfg, const float* params, const float* bn_mean, const float* bn_var,
+                 const float* x, float* ws, size_t ws_bytes, float* y_pred, int train, uint64_t seed,
+                 crnn_stream_t stream, crnn_stream_t aux_stream);
 /* CTC loss (utils.py:98-103) + full backward of the graph after a train=1 crnn_forward on the same ws.
  * labels [B,max_len] int32 (blank-padded), input_length/label_length [B] int32 (Readf batch contract,
  * utils.py:485-500).  loss [B] = per-sample CTC cost (the model's 'ctc' output); grads (flat, same layout as
@@ -286,12 +298,14 @@ int crnn_dwconv_bwd_stream_rows(int B, int H, int W, int C);
 int crnn_dwconv3x3_bwd_stream(const void* d, const void* da, const float* bnstate, const float* coef, const void* xin, const float* k, void* dx,
                               float* dk, float* scratch, int B, int H, int W, int C, crnn_stream_t stream);
 /* Prologue form: `q` (in place of xin) is the previous block's pointwise output; x = Dropout(ReLU6(q * scale + shift)) is re-formed in LDS by a
- * twelfth wave one row ahead (the forward did not keep it: crnn_dwconv3x3_fwd_stream_pro; same `keep` bytes).  dx / dk bit-identical to
- * crnn_dwconv3x3_bwd_stream on the materialised x. */
+ * DX waves one row ahead (the forward did not keep it: crnn_dwconv3x3_fwd_stream_pro; same `keep` bytes).  dx / dk bit-identical to
+ * crnn_dwconv3x3_bwd_stream on the materialised x.  bn2_stat_partials != NULL: the DX waves also take the statistics pass of the producer's BatchNorm-2
+ * backward -- [crnn_dwconv_bwd_stream_rows][2][C] partial sums (sum gy | sum gy * xhat), gy = dx through the dropout mask and the ReLU6 gate of q: what
+ * crnn_bn_bwd_ex(q, dx, pro_bnstate, ...) would read q and dx again for; finish with crnn_bn_bwd_finalize + crnn_bn_bwd_apply_ex. */
 int crnn_dwconv_bwd_stream_pro_supported(int B, int H, int W, int C);
 int crnn_dwconv3x3_bwd_stream_pro(const void* d, const void* da, const float* bnstate, const float* coef, const void* q, const float* pro_bnstate,
-                                  float rate, const void* keep, const float* k, void* dx, float* dk, float* scratch, int B, int H,
-                                  int W, int C, crnn_stream_t stream);
+                                  float rate, const void* keep, const float* k, void* dx, float* dk, float* scratch, float* bn2_stat_partials,
+                                  int B, int H, int W, int C, crnn_stream_t stream);
 int crnn_dwconv3x3_fwd(const float* x, const float* k, float* out, float* stat_partials, int B, int H, int W, int C,
                        int flip, crnn_stream_t stream);
 int crnn_dwconv3x3_wgrad(const float* x, const float* g, float* dk, float* scratch, int B, int H, int W, int C,
@@ -329,6 +343,9 @@ int crnn_dropout_mask(float* m, long n, float rate, uint64_t seed, uint32_t laye
 /* keep bits of the same dropout site, one byte per group of 8 consecutive elements (bit e: element 8 g + e is kept; rate <= 0: 0xFF) -- the form the
  * prologue row-stream depthwise kernels read (crnn_dwconv3x3_fwd_stream_pro / _bwd_stream_pro).  out: 4-byte aligned, (ngroups + 3) / 4 * 4 bytes written */
 int crnn_dropout_keep_bytes(void* out, long ngroups, float rate, uint64_t seed, uint32_t layer, crnn_stream_t stream);
+/* the same for n <= CRNN_KEEP_BATCH_MAX dropout sites of one step in one launch (host arrays of n entries) */
+#define CRNN_KEEP_BATCH_MAX 8
+int crnn_dropout_keep_bytes_batch(int n, void* const* out, const long* ngroups, const uint32_t* layer, float rate, uint64_t seed, crnn_stream_t stream);
 int crnn_relu_bwd(const float* y, const float* g, float* go, long rows, int C, float scale, int permP,
                   crnn_stream_t stream);
 /* spatial transformer pieces (utils.py:116-258) */

@@ -59,11 +59,16 @@ def f_pro(rate):
 def b_plain(L, sh, bf):
     h, w, c = sh; q, x, d, da, dx, k, dk, st1, st2, coef, pt, keep = bf
     return L.crnn_dwconv3x3_bwd_stream(P(d), P(da), P(st1), P(coef), P(x), P(k), P(dx), P(dk), P(pt), B, h, w, c, S())
-def b_pro(rate):
+stat_parts = torch.empty(4096 * 2 * 512, device="cuda")
+def b_pro(rate, stats=False):
     def f(L, sh, bf):
         h, w, c = sh; q, x, d, da, dx, k, dk, st1, st2, coef, pt, keep = bf
-        return L.crnn_dwconv3x3_bwd_stream_pro(P(d), P(da), P(st1), P(coef), P(q), P(st2), rate, P(keep), P(k), P(dx), P(dk), P(pt), B, h, w, c, S())
+        return L.crnn_dwconv3x3_bwd_stream_pro(P(d), P(da), P(st1), P(coef), P(q), P(st2), rate, P(keep), P(k), P(dx), P(dk), P(pt), P(stat_parts) if stats else None,
+                                               B, h, w, c, S())
     return f
+def b_bn1(L, sh, bf):
+    h, w, c = sh; q, x, d, da, dx, k, dk, st1, st2, coef, pt, keep = bf
+    return L.crnn_bn_bwd_ex(P(q), P(dx), P(st2), P(st2), None, P(dk), P(dk), P(pt), P(coef), B, h, w, c, 1, 1, 0.1, 7, 3, 1, S())
 def f_keep(L, sh, bf):
     h, w, c = sh; keep = bf[-1]
     return L.crnn_dropout_keep_bytes(P(keep), B * h * w * c // 8, 0.1, 7, 3, S())
@@ -76,6 +81,8 @@ run(L0, "fwd pro rate 0", f_pro(0.0))
 run(L0, "bwd stream", b_plain)
 run(L0, "bwd pro rate .1", b_pro(0.1))
 run(L0, "bwd pro rate 0", b_pro(0.0))
+run(L0, "bwd pro .1 + BN2 statistics", b_pro(0.1, True))
+run(L0, "BN2 bwd statistics pass alone", b_bn1)
 for pth in sorted(glob.glob(os.path.join(ROOT, "scripts/_trace/libdwsp_*.so"))):
     L = load(pth); nm = os.path.basename(pth)[8:-3]
     run(L, "fwd pro .1 [%s]" % nm, f_pro(0.1))

@@ -10,7 +10,7 @@ timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py -q -m
 echo "pytest_new exit $?" > $OUT/${TAG}_summary.txt
 tail -5 $OUT/${TAG}_pytest_new.log
 for i in 1 2; do
-CRNN_FLAGS=1024 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-roofline --no-parity > $OUT/${TAG}_bench_no_bn2_dw_fusion_$i.json 2>> $OUT/${TAG}_bench.err
+CRNN_FLAGS=1024 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-roofline --no-parity > $OUT/${TAG}_bench_bn2_dw_fusion_$i.json 2>> $OUT/${TAG}_bench.err
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-roofline --no-parity > $OUT/${TAG}_bench_bf16s_$i.json 2>> $OUT/${TAG}_bench.err
 done
 cd /tmp && export TMPDIR=/tmp
@@ -21,7 +21,7 @@ f=$(find $OUT/${TAG}_prof -name "*kernel_trace.csv" | head -1)
 python $ROOT/scripts/trace_step.py $f > $OUT/${TAG}_step_timeline.txt
 cd $ROOT
 find $OUT -name "*kernel_trace.csv" -size +30M -delete
-for f in bench_no_bn2_dw_fusion_1 bench_bf16s_1 bench_no_bn2_dw_fusion_2 bench_bf16s_2; do echo -n "$f: "; cut -c60-200 $OUT/${TAG}_$f.json; echo; done
+for f in bench_bn2_dw_fusion_1 bench_bf16s_1 bench_bn2_dw_fusion_2 bench_bf16s_2; do echo -n "$f: "; cut -c60-200 $OUT/${TAG}_$f.json; echo; done
 grep -v amdgpu $OUT/${TAG}_bench.err | tail -8
 grep -E "dw_fwd_stream|dw_bwd_stream" $OUT/${TAG}_step_timeline.txt | cut -c1-120
 grep "step span" $OUT/${TAG}_step_timeline.txt

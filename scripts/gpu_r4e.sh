@@ -2,6 +2,6 @@
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 export PYTHONPATH=$ROOT:$ROOT/crnn-ocr-lite_amd:$ROOT/tests
 cd $ROOT
-for n in 2 4; do
-CRNN_DIST_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 29777 scripts/dp_debug.py 2>&1 | grep -v "Gloo\|amdgpu\|OMP_NUM" | head -12
+for ovl in 1 0; do
+OVL=$ovl timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29777 scripts/dp_debug2.py 2>&1 | grep "^step" | head -12
 done

@@ -355,8 +355,8 @@ def test_bf16s_producer_fused_pointwise_convs_equal_the_two_pass_path(shape):
     x, lab, il, ll = M.synthetic_batch(cfg, B, seed=4, dtype=np.float64)
     out = {}
     T = native.FLAG_GEMM_TILE_KERNELS | native.FLAG_DW_TILE_KERNEL
-    for flags in (T, T | native.FLAG_NO_DW_BN_FUSION, T | native.FLAG_RNN_STEP_KERNELS, T | native.FLAG_NO_DW_BWD_FUSION, native.FLAG_NO_BN2_DW_FUSION,
-                  native.FLAG_DEFERRED_SUMS, native.FLAG_NO_BN_STATS_FUSION, 0):
+    for flags in (T, T | native.FLAG_NO_DW_BN_FUSION, T | native.FLAG_RNN_STEP_KERNELS, T | native.FLAG_NO_DW_BWD_FUSION, native.FLAG_BN2_DW_FUSION,
+                  native.FLAG_BN2_DW_FUSION | native.FLAG_BN2_STATS_FUSION, native.FLAG_DEFERRED_SUMS, native.FLAG_NO_BN_STATS_FUSION, 0):
         eng = Engine(B, imgh, imgw, ncls, max_len, tds, u, stn=True, dropout=True, precision="bf16s", flags=flags)
         eng.set_params(p, bn)
         eng.ws.fill_(float("nan")); eng.grads.zero_()
@@ -377,11 +377,17 @@ def test_bf16s_producer_fused_pointwise_convs_equal_the_two_pass_path(shape):
     # stage (CRNN_FLAG_DEFERRED_SUMS): the same sums in the same order
     yc, lc, gc = out[native.FLAG_DEFERRED_SUMS]
     assert torch.equal(yc, yb) and torch.equal(lc, lb) and torch.equal(gc, gb), "deferred second stages changed the gradients"
-    # block outputs formed inside the next block's depthwise row-stream kernels (default where the shape rules hold: image width 32) or
-    # materialised by crnn_bn_act_pool_drop_ex (CRNN_FLAG_NO_BN2_DW_FUSION): same arithmetic, same summation orders -- everything bit-identical
-    yd, ld, gd_ = out[native.FLAG_NO_BN2_DW_FUSION]
+    # block outputs formed inside the next block's depthwise row-stream kernels (opt-in CRNN_FLAG_BN2_DW_FUSION, where the shape rules hold: image
+    # width 32) or materialised by crnn_bn_act_pool_drop_ex (default): same arithmetic, same summation orders -- everything bit-identical
+    yd, ld, gd_ = out[native.FLAG_BN2_DW_FUSION]; ye, le, ge = out[native.FLAG_BN2_DW_FUSION | native.FLAG_BN2_STATS_FUSION]
     assert torch.equal(yd, yb) and torch.equal(ld, lb) and torch.equal(gd_, gb), "BatchNorm-2 prologue fusion changed the results"
-    for flags in list(out)[1:-4]:
+    # ... and the statistics pass of those BatchNorms' backward inside the next block's depthwise-stage backward (opt-in: CRNN_FLAG_BN2_STATS_FUSION)
+    # or as a kernel of its own (default): same forward, the statistics are the same sums in another order
+    assert torch.equal(ye, yb) and torch.equal(le, lb)
+    rel2 = float((ge.double() - gb.double()).norm() / ge.double().norm())
+    print("BatchNorm-2 statistics fusion on/off: gradient rel L2 %.3g" % rel2)
+    assert torch.isfinite(ge).all() and rel2 < 5e-2, rel2
+    for flags in list(out)[1:-5]:
         y1, l1, g1 = out[flags]
         assert torch.isfinite(g1).all() and torch.equal(y0, y1) and torch.equal(l0, l1), flags
         if flags != T | native.FLAG_NO_DW_BWD_FUSION:

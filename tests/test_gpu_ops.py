@@ -910,11 +910,27 @@ def test_row_stream_depthwise_with_the_batchnorm2_prologue_equals_the_two_pass_p
     dx1 = torch.zeros(n, dtype=torch.bfloat16, device="cuda"); dk1 = zeros(9, C); sc = zeros(brow * 9 * C)
     ok(L().crnn_dwconv3x3_bwd_stream(P(dd), P(dad), P(st1), P(coef), P(xd), P(kd), P(dx1), P(dk1), P(sc), B, H, W, C, S()))
     dx2 = torch.full((n + 64,), 9.0, dtype=torch.bfloat16, device="cuda"); dk2 = zeros(9, C); sc2 = torch.full((brow * 9 * C + 16,), 5.0, device="cuda")
-    ok(L().crnn_dwconv3x3_bwd_stream_pro(P(dd), P(dad), P(st1), P(coef), P(qd), P(st2), rate, P(keep), P(kd), P(dx2), P(dk2), P(sc2), B, H, W, C, S()))
+    ok(L().crnn_dwconv3x3_bwd_stream_pro(P(dd), P(dad), P(st1), P(coef), P(qd), P(st2), rate, P(keep), P(kd), P(dx2), P(dk2), P(sc2), None, B, H, W, C, S()))
     assert torch.equal(dx2[:-64].view(torch.int16), dx1.view(torch.int16)), "dx: max diff %g" % float((dx2[:-64].float() - dx1.float()).abs().max())
     assert torch.equal(dk2, dk1), "dk: max diff %g" % float((dk2 - dk1).abs().max())
     assert bool((dx2[-64:] == 9.0).all()) and bool((sc2[-16:] == 5.0).all())
     assert float(dk1.abs().max()) > 0
+    # ---- the same launch also taking the statistics pass of the producer's BatchNorm-2 backward (gy = dx through dropout and the ReLU6 gate of q):
+    # dx / dk unchanged bit for bit, sums = crnn_bn_bwd_ex's (pass 1 + finalize) to fp32 summation order
+    dx3 = torch.zeros(n, dtype=torch.bfloat16, device="cuda"); dk3 = zeros(9, C)
+    parts2 = torch.full((brow + 1, 2, C), 3.0, device="cuda")
+    ok(L().crnn_dwconv3x3_bwd_stream_pro(P(dd), P(dad), P(st1), P(coef), P(qd), P(st2), rate, P(keep), P(kd), P(dx3), P(dk3), P(sc2), P(parts2), B, H, W, C, S()))
+    assert torch.equal(dx3, dx1) and torch.equal(dk3, dk1) and bool((parts2[brow] == 3.0).all())
+    dg2, db2, coef2 = zeros(C), zeros(C), zeros(2 * C)
+    ok(L().crnn_bn_bwd_finalize(P(parts2), brow, C, M, P(dg2), P(db2), P(coef2), S()))
+    gq = torch.zeros(n, dtype=torch.bfloat16, device="cuda"); dg1, db1, coef1 = zeros(C), zeros(C), zeros(2 * C)
+    pp = zeros(max(L().crnn_bn_bwd_chunks(M), 1) * 2 * C + 64); gam = dev(np.ones(C))
+    ok(L().crnn_bn_bwd_ex(P(qd), P(dx1), P(st2), P(gam), P(gq), P(dg1), P(db1), P(pp), P(coef1), B, H, W, C, 1, 1, rate, seed, layer, 1, S()))
+    for a, b, what in ((db2, db1, "sum gy"), (dg2, dg1, "sum gy xhat"), (coef2, coef1, "coefficients")):
+        assert_close(host(a), host(b), rtol=2e-4, atol=2e-5 * max(1.0, float(b.abs().max())), what="BatchNorm-2 backward " + what)
+    gq2 = torch.zeros_like(gq)
+    ok(L().crnn_bn_bwd_apply_ex(P(qd), P(dx1), P(st2), P(coef1), P(gq2), B, H, W, C, 1, 1, rate, seed, layer, 1, S()))
+    assert torch.equal(gq2, gq)
 
 
 def test_dropout_rng_statistics():
