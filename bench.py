@@ -115,7 +115,7 @@ def depthwise_roofline(eng, iters=15):
     # and committed under profiles/; FETCH_SIZE x2 per the gfx950 note in MI355X_MICROARCH.md)
     traffic, pmc_file = None, None
     try:
-        pmc_file = [f for f in ("r03_pmc_dwconv.json", "r02_pmc_dwconv.json", "r01_pmc_dwconv.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+        pmc_file = [f for f in ("r04_pmc_dwconv.json", "r03_pmc_dwconv.json", "r02_pmc_dwconv.json", "r01_pmc_dwconv.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
         pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
         if B == pmc["batch"] and (eng.cfg.imgh, eng.cfg.imgw) == (100, 32):
             if nstream == len(launches):

@@ -442,7 +442,12 @@ __global__ __launch_bounds__(512) void gemm_wres_fwd_kernel(WresFwdParams p) {
   constexpr int CPL = PB;                                      // 16-byte stage chunks per IO lane and stage (PX rows x 8 chunks over 256 lanes)
   // stages in flight in the IO waves' registers: 64 KiB per CU for the deep-K shapes; the K <= 128 shapes are HBM-bound with a write
   // stream twice the read stream and run faster with 32 KiB (measured: 75 / 160 us against 85 / 178 us for blocks 2 / 3)
-  constexpr int D = (KCH >= 4 ? 16 : 8) / PB;
+#ifndef CRNN_WRESF_DEEP
+#define CRNN_WRESF_DEEP 1    // 1: stage depth trimmed for the deep-K shapes so that no register spills (round 4); 0: the round-2 depths
+#endif
+  // (deep-K: 64 KiB in flight asked for pf[4][4] / pf[8][2] and left the K = 512 and K = 256 instantiations 5 and 8 registers short of their
+  // 256-register ceiling -- scratch traffic in the IO waves' steady state; 48 KiB in flight fits)
+  constexpr int D = CRNN_WRESF_DEEP ? (KCH >= 8 ? 12 / PB : (KCH >= 4 ? (PB == 2 ? 6 : 4) : 8 / PB)) : (KCH >= 4 ? 16 : 8) / PB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // kRf stages | two staging tiles | scale[K] | shift[K]
   unsigned char* const outs = smem + kRf * stage;
   float* const tab = reinterpret_cast<float*>(outs + 2 * otile);
