@@ -34,6 +34,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef CRNN_DBS_D
 #define CRNN_DBS_D 3
 #endif
+#ifndef CRNN_DBS_F32_WGS
+#define CRNN_DBS_F32_WGS 1  // workgroups per CU the fp32 form is compiled for (2 = 6 waves per SIMD = 80 registers: the DK waves spill 81 -- not used)
+#endif
 
 struct DbsParams {
   const unsigned char *d, *da, *xin; unsigned char* dx; const float *bnstate, *coef, *k; float* partials;
@@ -50,6 +53,21 @@ __device__ __forceinline__ void widen8(const u32x4& u, float (&f)[8]) {
   f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
   f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
   f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+
+// element forms of a 16-byte chunk: 8 bf16 (EPC = 8) or 4 fp32 (EPC = 4) -- the fp32 form runs the same schedule on half as many channels
+// per lane and twice as many channel ranges per row (round 4: the parity mode's depthwise-stage backward)
+template <int EPC> __device__ __forceinline__ void widenE(const u32x4& u, float (&f)[EPC]);
+template <> __device__ __forceinline__ void widenE<8>(const u32x4& u, float (&f)[8]) { widen8(u, f); }
+template <> __device__ __forceinline__ void widenE<4>(const u32x4& u, float (&f)[4]) {
+  f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y); f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
+}
+template <int EPC> __device__ __forceinline__ u32x4 packE(const float (&f)[EPC]);
+template <> __device__ __forceinline__ u32x4 packE<8>(const float (&f)[8]) {
+  u32x4 o; o.x = pack2_bf16(f[0], f[1]); o.y = pack2_bf16(f[2], f[3]); o.z = pack2_bf16(f[4], f[5]); o.w = pack2_bf16(f[6], f[7]); return o;
+}
+template <> __device__ __forceinline__ u32x4 packE<4>(const float (&f)[4]) {
+  u32x4 o; o.x = __float_as_uint(f[0]); o.y = __float_as_uint(f[1]); o.z = __float_as_uint(f[2]); o.w = __float_as_uint(f[3]); return o;
 }
 
 constexpr int kCW = 5;                       // compute waves per group (320 columns)
@@ -99,9 +117,12 @@ __device__ __forceinline__ int role_of_stats(int w, int& idx) {   // 0 = DK, 1 =
 // deeper); one partial row [2][C] per workgroup band.  Measured (profiles/r04_*, four launches at batch 256): the pass it replaces 0.28 ms;
 // this kernel + 0.24 ms (the one wave's ~400 operations per step are the critical path); done by the DX waves themselves + 0.65 (36
 // spilled registers); gating in the DX waves and sums in the twelfth + 0.35 -- so it is not the default schedule.
-template <int KD, bool PRO, bool DROP, bool STATS = false>
-__global__ __launch_bounds__(STATS ? 768 : 704) void dw_bwd_stream_kernel(DbsParams p) {
+template <int KD, bool PRO, bool DROP, bool STATS = false, bool F32 = false>
+__global__ __launch_bounds__(STATS ? 768 : 704, (F32 && CRNN_DBS_F32_WGS > 1) ? 3 * CRNN_DBS_F32_WGS : 1) void dw_bwd_stream_kernel(DbsParams p) {
   static_assert(!STATS || PRO, "the statistics form is a prologue form");
+  static_assert(!F32 || !PRO, "the prologue forms exist for bf16 tensors");
+  constexpr int EPC = F32 ? 4 : 8;                   // elements per 16-byte chunk
+  constexpr int ES = F32 ? 4 : 2;                    // bytes per element
   typedef DbsLds<KD, STATS> LP;
   constexpr int kNR = LP::NR, kDdOff = LP::DdOff, kZOff = LP::ZOff, kCstOff = LP::CstOff, kXtOff = LP::XtOff, kPcOff = LP::PcOff, kKeepOff = LP::KeepOff, kDxrOff = LP::DxrOff;
   constexpr int kNIT = kNI + (DROP ? 2 : 0);           // DMA instructions per stage
@@ -115,7 +136,6 @@ __global__ __launch_bounds__(STATS ? 768 : 704) void dw_bwd_stream_kernel(DbsPar
   const int wb = bid % p.nwgb, img = bid / p.nwgb;
   const int r0 = wb * p.HB;                         // first row of the band
   const int nsteps = p.HB + 3;                      // step s: d/da row r0-1+s (s <= HB+1), xin row r0-2+s (s >= 1), dx row r0+s-3 (s >= 3)
-  const int CWb = p.C / p.nsplit * 2;               // bytes of this workgroup's channel range per pixel
   const int c0 = split * (p.C / p.nsplit);          // first channel
   if (tid < 4) reinterpret_cast<unsigned*>(lds + kZOff)[tid] = 0u;
   const long imgoff = (long)img * p.H * p.rowbytes;
@@ -127,7 +147,7 @@ __global__ __launch_bounds__(STATS ? 768 : 704) void dw_bwd_stream_kernel(DbsPar
     for (int i = 0; i < 5; ++i) {
       int f = i * 64 + lane; f = f < p.cols ? f : p.cols - 1;
       const int px = f / p.cppw, o = f - px * p.cppw;
-      goff[i] = px * p.C * 2 + c0 * 2 + o * 16;
+      goff[i] = (px * p.C + c0) * ES + o * 16;
     }
     const unsigned char* gd = p.d + imgoff; const unsigned char* gg = p.da + imgoff; const unsigned char* gxx = p.xin + imgoff;
     // prologue form with dropout: the keep bytes of the stage's xin row for this workgroup's columns, 4 bytes (4 columns of one pixel) per lane
@@ -261,21 +281,24 @@ __global__ __launch_bounds__(STATS ? 768 : 704) void dw_bwd_stream_kernel(DbsPar
   const int offC = ccol * 16;
   const bool hasL = px > 0, hasR = px < p.W - 1;
   const int pitch = p.cppw * 16;                    // LDS bytes between horizontally adjacent pixels
-  const int ch0 = c0 + oct * 8;
+  const int ch0 = c0 + oct * EPC;
 
   if (role == 1) {
     // ------------------------------------------------------------------ DX waves: dx = correlation of dd with the mirrored taps
-    float kw[9][8];
+    float kw[9][EPC];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const float* kp = p.k + (long)(8 - t) * p.C + ch0;
-      const float4 a = *reinterpret_cast<const float4*>(kp), b = *reinterpret_cast<const float4*>(kp + 4);
-      kw[t][0] = a.x; kw[t][1] = a.y; kw[t][2] = a.z; kw[t][3] = a.w; kw[t][4] = b.x; kw[t][5] = b.y; kw[t][6] = b.z; kw[t][7] = b.w;
-    }
-    float X0[8], X1[8], X2[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) X0[e] = X1[e] = X2[e] = 0.f;
-    unsigned char* orow = p.dx + imgoff + (long)r0 * p.rowbytes + px * p.C * 2 + ch0 * 2;
+      for (int h = 0; h < EPC / 4; ++h) {
+        const float4 a = *reinterpret_cast<const float4*>(kp + 4 * h);
+        kw[t][4 * h] = a.x; kw[t][4 * h + 1] = a.y; kw[t][4 * h + 2] = a.z; kw[t][4 * h + 3] = a.w;
+      }
+    }
+    float X0[EPC], X1[EPC], X2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) X0[e] = X1[e] = X2[e] = 0.f;
+    unsigned char* orow = p.dx + imgoff + (long)r0 * p.rowbytes + (px * p.C + ch0) * ES;
     // prologue form: re-form x = Dropout(ReLU6(q * scale + shift)) of the stage that arrived one step ahead (own column) into the two-row
     // buffer the DK waves read; bn_act_pool_drop_kernel's arithmetic bit for bit.  (The 16 BatchNorm-2 constants of the lane's channels
     // sit in LDS and are read per step: kw and the running rows fill the registers.)
@@ -313,7 +336,7 @@ __global__ __launch_bounds__(STATS ? 768 : 704) void dw_bwd_stream_kernel(DbsPar
       __builtin_amdgcn_sched_barrier(0);              // its temporaries are dead before the correlation's operands are loaded
     };
     // a = arriving dd row (relative: image row r0-1+a), read one step after the DK waves wrote it
-    auto step = [&](int a, float (&A)[8], float (&Bc)[8], float (&Cn)[8]) {
+    auto step = [&](int a, float (&A)[EPC], float (&Bc)[EPC], float (&Cn)[EPC]) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                  // barrier of stage a + 1
       if (PRO && a + 2 < nsteps) xform(a + 2);
@@ -322,23 +345,22 @@ __global__ __launch_bounds__(STATS ? 768 : 704) void dw_bwd_stream_kernel(DbsPar
       const u32x4 vC = *reinterpret_cast<const u32x4*>(sb + offC);
       const u32x4 vR = *reinterpret_cast<const u32x4*>(hasR ? sb + offC + pitch : lds + kZOff);
       if (!(CRNN_DBS_EXP & 8)) {
-        float f[8];
-        widen8(vL, f);
+        float f[EPC];
+        widenE<EPC>(vL, f);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { A[e] = fmaf(f[e], kw[6][e], A[e]); Bc[e] = fmaf(f[e], kw[3][e], Bc[e]); Cn[e] = fmaf(f[e], kw[0][e], 0.f); }
-        widen8(vC, f);
+        for (int e = 0; e < EPC; ++e) { A[e] = fmaf(f[e], kw[6][e], A[e]); Bc[e] = fmaf(f[e], kw[3][e], Bc[e]); Cn[e] = fmaf(f[e], kw[0][e], 0.f); }
+        widenE<EPC>(vC, f);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { A[e] = fmaf(f[e], kw[7][e], A[e]); Bc[e] = fmaf(f[e], kw[4][e], Bc[e]); Cn[e] = fmaf(f[e], kw[1][e], Cn[e]); }
-        widen8(vR, f);
+        for (int e = 0; e < EPC; ++e) { A[e] = fmaf(f[e], kw[7][e], A[e]); Bc[e] = fmaf(f[e], kw[4][e], Bc[e]); Cn[e] = fmaf(f[e], kw[1][e], Cn[e]); }
+        widenE<EPC>(vR, f);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { A[e] = fmaf(f[e], kw[8][e], A[e]); Bc[e] = fmaf(f[e], kw[5][e], Bc[e]); Cn[e] = fmaf(f[e], kw[2][e], Cn[e]); }
+        for (int e = 0; e < EPC; ++e) { A[e] = fmaf(f[e], kw[8][e], A[e]); Bc[e] = fmaf(f[e], kw[5][e], Bc[e]); Cn[e] = fmaf(f[e], kw[2][e], Cn[e]); }
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { A[e] += __uint_as_float(vL[e]); A[e + 4] += __uint_as_float(vC[e]); Bc[e] += __uint_as_float(vR[e]); }
+        for (int e = 0; e < 4; ++e) { A[e] += __uint_as_float(vL[e]); A[(e + 4) % EPC] += __uint_as_float(vC[e]); Bc[e] += __uint_as_float(vR[e]); }
       }
       if (a >= 2 && act) {
-        u32x4 o;
-        o.x = pack2_bf16(A[0], A[1]); o.y = pack2_bf16(A[2], A[3]); o.z = pack2_bf16(A[4], A[5]); o.w = pack2_bf16(A[6], A[7]);
+        const u32x4 o = packE<EPC>(A);
         if (!(CRNN_DBS_EXP & 2)) *reinterpret_cast<u32x4*>(orow + (long)(a - 2) * p.rowbytes) = o;
         if (STATS) *reinterpret_cast<u32x4*>(lds + kDxrOff + (a & 1) * kSub + offC) = o;   // (for the statistics wave, one step later)
       }
@@ -369,7 +391,7 @@ __global__ __launch_bounds__(STATS ? 768 : 704) void dw_bwd_stream_kernel(DbsPar
   // -------------------------------------------------------------------- DK waves: dd of the arriving row, weight-gradient sums
   // (the 72 sums leave no room for the 32 BatchNorm constants of the lane's channels: they sit in LDS and are read per step; the dd
   // history is kept as packed bf16)
-  const int cw = p.cppw * 8;                        // channels of this workgroup
+  const int cw = p.cppw * EPC;                      // channels of this workgroup
   float* cst = reinterpret_cast<float*>(lds + kCstOff);
   for (int i = gidx * 64 + lane; i < cw; i += kCW * 64) {
     const int ch = c0 + i;
@@ -378,13 +400,13 @@ __global__ __launch_bounds__(STATS ? 768 : 704) void dw_bwd_stream_kernel(DbsPar
     bn_bwd_pq(scv, p.coef[ch], p.coef[p.C + ch], p.bnstate[ch], 1.0f / sqrtf(p.bnstate[p.C + ch] + BN_EPS_F), P, Q);
     cst[i] = scv; cst[cw + i] = p.bnstate[3 * p.C + ch]; cst[2 * cw + i] = P; cst[3 * cw + i] = Q;
   }
-  const float* cl = cst + oct * 8;
-  float dk[9][8];
+  const float* cl = cst + oct * EPC;
+  float dk[9][EPC];
   u32x4 H0 = (u32x4)(0u), H1 = (u32x4)(0u), H2 = (u32x4)(0u);
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dk[t][e] = 0.f;
+    for (int e = 0; e < EPC; ++e) dk[t][e] = 0.f;
   int slot = 0;
   // step s: Dn <- dd of row s (relative: image row r0-1+s); xin row s-1 (image row r0-2+s) meets Dn (taps 0..2), Dm1 (3..5), Dm2 (6..8)
   auto step = [&](int s, u32x4& Dn, const u32x4& Dm1, const u32x4& Dm2, bool edge) {
@@ -395,10 +417,10 @@ __global__ __launch_bounds__(STATS ? 768 : 704) void dw_bwd_stream_kernel(DbsPar
     if (!edge || s <= p.HB + 1) {
       const u32x4 vd = *reinterpret_cast<const u32x4*>(sb + offC);
       const u32x4 vg = *reinterpret_cast<const u32x4*>(sb + kSub + offC);
-      float xv[8], gv[8], r[8];
-      widen8(vd, xv); widen8(vg, gv);
+      float xv[EPC], gv[EPC], r[EPC];
+      widenE<EPC>(vd, xv); widenE<EPC>(vg, gv);
 #pragma unroll
-      for (int hq = 0; hq < 2; ++hq) {
+      for (int hq = 0; hq < EPC / 4; ++hq) {
         const float4 s4 = *reinterpret_cast<const float4*>(cl + 4 * hq), h4 = *reinterpret_cast<const float4*>(cl + cw + 4 * hq);
         const float4 p4 = *reinterpret_cast<const float4*>(cl + 2 * cw + 4 * hq), q4 = *reinterpret_cast<const float4*>(cl + 3 * cw + 4 * hq);
         const float scq[4] = {s4.x, s4.y, s4.z, s4.w}, shq[4] = {h4.x, h4.y, h4.z, h4.w}, pq[4] = {p4.x, p4.y, p4.z, p4.w}, qq[4] = {q4.x, q4.y, q4.z, q4.w};
@@ -409,8 +431,7 @@ __global__ __launch_bounds__(STATS ? 768 : 704) void dw_bwd_stream_kernel(DbsPar
           r[4 * hq + e] = bn_bwd_dx_pq(xv[4 * hq + e], gy, scq[e], pq[e], qq[e]);
         }
       }
-      u32x4 w;
-      w.x = pack2_bf16(r[0], r[1]); w.y = pack2_bf16(r[2], r[3]); w.z = pack2_bf16(r[4], r[5]); w.w = pack2_bf16(r[6], r[7]);
+      u32x4 w = packE<EPC>(r);                               // (bf16: rounded as the stored tensor would be)
       bool band = act;
       if (edge) {
         const int g = r0 - 1 + s;
@@ -433,17 +454,17 @@ __global__ __launch_bounds__(STATS ? 768 : 704) void dw_bwd_stream_kernel(DbsPar
         if (g < 0 || g >= p.H) { vL = (u32x4)(0u); vC = (u32x4)(0u); vR = (u32x4)(0u); }
       }
       if (!(CRNN_DBS_EXP & 4)) {
-        float f[8], dn[8], dm1[8], dm2[8];
-        widen8(Dn, dn); widen8(Dm1, dm1); widen8(Dm2, dm2);
-        widen8(vL, f);
+        float f[EPC], dn[EPC], dm1[EPC], dm2[EPC];
+        widenE<EPC>(Dn, dn); widenE<EPC>(Dm1, dm1); widenE<EPC>(Dm2, dm2);
+        widenE<EPC>(vL, f);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { dk[0][e] = fmaf(f[e], dn[e], dk[0][e]); dk[3][e] = fmaf(f[e], dm1[e], dk[3][e]); dk[6][e] = fmaf(f[e], dm2[e], dk[6][e]); }
-        widen8(vC, f);
+        for (int e = 0; e < EPC; ++e) { dk[0][e] = fmaf(f[e], dn[e], dk[0][e]); dk[3][e] = fmaf(f[e], dm1[e], dk[3][e]); dk[6][e] = fmaf(f[e], dm2[e], dk[6][e]); }
+        widenE<EPC>(vC, f);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { dk[1][e] = fmaf(f[e], dn[e], dk[1][e]); dk[4][e] = fmaf(f[e], dm1[e], dk[4][e]); dk[7][e] = fmaf(f[e], dm2[e], dk[7][e]); }
-        widen8(vR, f);
+        for (int e = 0; e < EPC; ++e) { dk[1][e] = fmaf(f[e], dn[e], dk[1][e]); dk[4][e] = fmaf(f[e], dm1[e], dk[4][e]); dk[7][e] = fmaf(f[e], dm2[e], dk[7][e]); }
+        widenE<EPC>(vR, f);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { dk[2][e] = fmaf(f[e], dn[e], dk[2][e]); dk[5][e] = fmaf(f[e], dm1[e], dk[5][e]); dk[8][e] = fmaf(f[e], dm2[e], dk[8][e]); }
+        for (int e = 0; e < EPC; ++e) { dk[2][e] = fmaf(f[e], dn[e], dk[2][e]); dk[5][e] = fmaf(f[e], dm1[e], dk[5][e]); dk[8][e] = fmaf(f[e], dm2[e], dk[8][e]); }
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { dk[0][e] += __uint_as_float(vL[e] + Dn[e]); dk[1][e] += __uint_as_float(vC[e] + Dm1[e]); dk[2][e] += __uint_as_float(vR[e] + Dm2[e]); }
@@ -474,14 +495,14 @@ __global__ __launch_bounds__(STATS ? 768 : 704) void dw_bwd_stream_kernel(DbsPar
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) dk[t][e] += __shfl_xor(dk[t][e], o, 64);
+      for (int e = 0; e < EPC; ++e) dk[t][e] += __shfl_xor(dk[t][e], o, 64);
   }
   if (lane < p.cppw) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      float* dst = red + (gidx * 9 + t) * cw + lane * 8;
-      *reinterpret_cast<float4*>(dst) = make_float4(dk[t][0], dk[t][1], dk[t][2], dk[t][3]);
-      *reinterpret_cast<float4*>(dst + 4) = make_float4(dk[t][4], dk[t][5], dk[t][6], dk[t][7]);
+      float* dst = red + (gidx * 9 + t) * cw + lane * EPC;
+#pragma unroll
+      for (int h = 0; h < EPC / 4; ++h) *reinterpret_cast<float4*>(dst + 4 * h) = make_float4(dk[t][4 * h], dk[t][4 * h + 1], dk[t][4 * h + 2], dk[t][4 * h + 3]);
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -501,17 +522,17 @@ __global__ __launch_bounds__(STATS ? 768 : 704) void dw_bwd_stream_kernel(DbsPar
 }
 
 struct DbsGeom { int nsplit, nwgb, HB, cols, cppw; bool ok; };
-DbsGeom dbs_geom(int B, int H, int W, int C) {
+DbsGeom dbs_geom(int B, int H, int W, int C, int epc = 8) {   // epc: elements per 16-byte chunk (8 bf16 | 4 fp32)
   DbsGeom g; g.ok = false; g.nsplit = g.nwgb = g.HB = g.cols = g.cppw = 0;
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8) return g;
-  const long cols1 = (long)W * C / 8;
+  const long cols1 = (long)W * C / epc;
   int ns = 0;
-  for (int n = 1; n <= C / 8; ++n) {
-    if ((C / 8) % n) continue;
+  for (int n = 1; n <= C / epc; ++n) {
+    if ((C / epc) % n) continue;
     if (cols1 / n <= kCW * 64) { ns = n; break; }
   }
   if (!ns) return g;
-  const int cols = (int)(cols1 / ns), cppw = C / 8 / ns;
+  const int cols = (int)(cols1 / ns), cppw = C / epc / ns;
   if (cols <= 4 * 64 || (cppw & (cppw - 1)) || cppw > 32) return g;   // five full-ish waves; power-of-two columns per pixel below a wave (shuffle reduction)
   int nwgb = 1;
 #ifndef CRNN_DBS_WGS
@@ -550,6 +571,36 @@ extern "C" int crnn_dwconv3x3_bwd_stream(const void* d, const void* da, const fl
   p.pro_bn = nullptr; p.keep = nullptr; p.rate = 0.f; p.bn2_partials = nullptr;
   CRNN_LDS_ATTR((dw_bwd_stream_kernel<kD, false, false>), DbsLds<kD>::XtOff);
   hipLaunchKernelGGL((dw_bwd_stream_kernel<kD, false, false>), dim3(B * g.nwgb * g.nsplit), dim3(704), DbsLds<kD>::XtOff, stream, p);
+  CRNN_LAUNCH_CHECK();
+  return crnn_partials_sum(scratch, B * g.nwgb, 9 * C, dk, 1.f, stream);
+}
+// The same stage on fp32 tensors (dtype CRNN_F32; CRNN_BF16 = the entry points above): four channels per lane, W * C / 4 columns split into
+// workgroups of 257..320 -- the parity mode's crnn_bn_bwd_apply_ex + crnn_dwconv3x3_wgrad_ex + crnn_dwconv3x3_fwd_ex(flip) in one pass over
+// d, da, xin (4 tensor passes instead of 7); dx bit-identical to that sequence, dk to the summation order of its partial sums.
+extern "C" int crnn_dwconv_bwd_stream_supported_ex(int B, int H, int W, int C, int dtype) {
+  if (dtype == CRNN_BF16) return crnn_dwconv_bwd_stream_supported(B, H, W, C);
+  if (dtype != CRNN_F32) return CRNN_ERR_ARG;
+  return dbs_geom(B, H, W, C, 4).ok ? CRNN_OK : CRNN_ERR_UNSUPPORTED;
+}
+extern "C" int crnn_dwconv_bwd_stream_rows_ex(int B, int H, int W, int C, int dtype) {
+  if (dtype == CRNN_BF16) return crnn_dwconv_bwd_stream_rows(B, H, W, C);
+  DbsGeom g = dbs_geom(B, H, W, C, 4); return (dtype == CRNN_F32 && g.ok) ? B * g.nwgb : 0;
+}
+extern "C" int crnn_dwconv3x3_bwd_stream_ex(const void* d, const void* da, const float* bnstate, const float* coef, const void* xin, const float* k,
+                                            void* dx, float* dk, float* scratch, int B, int H, int W, int C, int dtype, hipStream_t stream) {
+  if (dtype == CRNN_BF16) return crnn_dwconv3x3_bwd_stream(d, da, bnstate, coef, xin, k, dx, dk, scratch, B, H, W, C, stream);
+  if (dtype != CRNN_F32 || !d || !da || !bnstate || !coef || !xin || !k || !dx || !dk || !scratch) return CRNN_ERR_ARG;
+  const DbsGeom g = dbs_geom(B, H, W, C, 4);
+  if (!g.ok) return CRNN_ERR_UNSUPPORTED;
+  if ((((uintptr_t)d | (uintptr_t)da | (uintptr_t)xin | (uintptr_t)dx | (uintptr_t)bnstate | (uintptr_t)coef | (uintptr_t)k) & 15)) return CRNN_ERR_UNSUPPORTED;
+  if ((long)H * W * C * 4 >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;
+  DbsParams p;
+  p.d = (const unsigned char*)d; p.da = (const unsigned char*)da; p.xin = (const unsigned char*)xin; p.dx = (unsigned char*)dx;
+  p.bnstate = bnstate; p.coef = coef; p.k = k; p.partials = scratch;
+  p.H = H; p.W = W; p.C = C; p.HB = g.HB; p.nwgb = g.nwgb; p.nsplit = g.nsplit; p.cols = g.cols; p.cppw = g.cppw; p.rowbytes = W * C * 4;
+  p.pro_bn = nullptr; p.keep = nullptr; p.rate = 0.f; p.bn2_partials = nullptr;
+  CRNN_LDS_ATTR((dw_bwd_stream_kernel<kD, false, false, false, true>), DbsLds<kD>::XtOff);
+  hipLaunchKernelGGL((dw_bwd_stream_kernel<kD, false, false, false, true>), dim3(B * g.nwgb * g.nsplit), dim3(704), DbsLds<kD>::XtOff, stream, p);
   CRNN_LAUNCH_CHECK();
   return crnn_partials_sum(scratch, B * g.nwgb, 9 * C, dk, 1.f, stream);
 }

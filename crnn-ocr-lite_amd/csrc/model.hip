@@ -146,6 +146,7 @@ Plan make_plan(const crnn_config* c) {
     maxparts = lmax(maxparts, (long)crnn_dwconv_bwd_fused_rows(d.B, d.bh[i], d.bw[i], ci) * 9L * ci);
     maxparts = lmax(maxparts, (long)crnn_dwconv_fwd_stream_rows(d.B, d.bh[i], d.bw[i], ci) * 2L * ci);
     maxparts = lmax(maxparts, (long)crnn_dwconv_bwd_stream_rows(d.B, d.bh[i], d.bw[i], ci) * 9L * ci);
+    maxparts = lmax(maxparts, (long)crnn_dwconv_bwd_stream_rows_ex(d.B, d.bh[i], d.bw[i], ci, CRNN_F32) * 9L * ci);
     maxparts = lmax(maxparts, (long)crnn_colreduce_chunks(M) * 2L * lmax(ci, co));
     maxparts = lmax(maxparts, (long)crnn_pwconv_stat_rows(M) * 2L * co);
     maxparts = lmax(maxparts, (long)crnn_pwconv_fwd_wres_rows(M, co, ci) * 2L * co);   // one row per IO wave and stripe lane: more rows than tiles at small batches
@@ -913,8 +914,14 @@ int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t au
     const int H = d.bh[i], W = d.bw[i], ci = d.bc[i - 1], co = d.bc[i];
     const long M = (long)B * H * W;
     const int dtd = c.dt("d" + p), dtq = c.dt("q" + p);   // dtq == storage of the incoming gradient (gdt)
-    const bool fused_dw = i > 1 && dtd == CRNN_BF16 && c.dt("x" + std::to_string(i - 1)) == CRNN_BF16 && !(cfg->flags & CRNN_FLAG_NO_DW_BWD_FUSION) &&
+    const bool fused_bf = i > 1 && dtd == CRNN_BF16 && c.dt("x" + std::to_string(i - 1)) == CRNN_BF16 && !(cfg->flags & CRNN_FLAG_NO_DW_BWD_FUSION) &&
                           crnn_dwconv_bwd_fused_supported(H, W, ci) == CRNN_OK;
+    // fp32 tensors (parity mode, round 4): the row-stream kernel's fp32 form where its shape rule holds (no halo-tile form: else the three-kernel sequence)
+    const bool fused_f32 = i > 1 && dtd == CRNN_F32 && dtq == CRNN_F32 && c.dt("x" + std::to_string(i - 1)) == CRNN_F32 &&
+                           !(cfg->flags & (CRNN_FLAG_NO_DW_BWD_FUSION | CRNN_FLAG_DW_TILE_KERNEL)) &&
+                           crnn_dwconv_bwd_stream_supported_ex(B, H, W, ci, CRNN_F32) == CRNN_OK &&
+                           aligned16(c.w("d" + p), c.w("x" + std::to_string(i - 1)), c.p(bp + "_dw"), c.w("coef")) && aligned16(gA, gB, gC, c.w("bn1s" + p));
+    const bool fused_dw = fused_bf || fused_f32;
     int bn1_stats_rows = 0;                               // > 0: the data-gradient GEMM left the BatchNorm-1 backward statistics in `partials`
     CRNN_TRY(fj.wait(gB_free)); gB_free = nullptr;        // gB is written next
     if (bn2_stats_rows > 0) {   // the depthwise-stage backward of block i+1 took this BatchNorm's statistics pass: finalize, then pass 2 alone
@@ -970,7 +977,7 @@ int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t au
         }
       }
       // parity mode: the three-plane GEMM's epilogue takes the statistics pass of the depthwise BatchNorm's backward (it holds the finished da tile)
-      if (rc == CRNN_ERR_UNSUPPORTED && !fused_dw && pw_products(cfg) == 2 && dtq == CRNN_F32 && dtd == CRNN_F32 &&
+      if (rc == CRNN_ERR_UNSUPPORTED && !fused_bf && pw_products(cfg) == 2 && dtq == CRNN_F32 && dtd == CRNN_F32 &&
           !(cfg->flags & CRNN_FLAG_NO_BN_STATS_FUSION) && crnn_gemm_f32x3_bnstats_supported(M, ci, co) == CRNN_OK) {
         rc = crnn_gemm_f32x3_bnstats(gB, c.p(bp + "_pw"), gA, M, ci, co, c.w("d" + p), c.w("bn1s" + p), c.w("partials"), stream);
         bn1_stats_rows = (rc == CRNN_OK) ? crnn_gemm_f32x3_bnstats_rows(M) : 0;
@@ -981,14 +988,20 @@ int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t au
     const float* xin = (i == 1) ? c.w("x0") : c.w("x" + std::to_string(i - 1));
     if (fused_dw) {
       // depthwise stage in one kernel: BatchNorm statistics pass, then BN-backward pass 2 + depthwise weight and data gradients together
-      if (bn1_stats_rows > 0)
+      if (bn1_stats_rows > 0 && fused_f32)     // (one row per GEMM tile row: folded first)
+        CRNN_TRY(crnn_bn_bwd_finalize_folded(c.w("partials"), bn1_stats_rows, ci, M, c.g(bp + "_bn1_g"), c.g(bp + "_bn1_b"), c.w("coef"), c.w("fold"), stream));
+      else if (bn1_stats_rows > 0)
         CRNN_TRY(crnn_bn_bwd_finalize(c.w("partials"), bn1_stats_rows, ci, M, c.g(bp + "_bn1_g"), c.g(bp + "_bn1_b"), c.w("coef"), stream));
       else
         CRNN_TRY(crnn_bn_bwd_ex(c.w("d" + p), gA, c.w("bn1s" + p), c.p(bp + "_bn1_g"), nullptr, c.g(bp + "_bn1_g"), c.g(bp + "_bn1_b"), c.w("partials"),
                                 c.w("coef"), B, H, W, ci, 1, 1, 0.f, 0, 0, dtd, stream));
       CRNN_TRY(fj.wait(gC_free)); gC_free = nullptr;      // gC is written next
       int rc = CRNN_ERR_UNSUPPORTED;
-      if (fuse_bn2_dw(c, i - 1)) {                           // the forward did not keep x_{i-1}: re-formed from q_{i-1} in LDS (no fallback: same decision)
+      if (fused_f32) {                                          // (no fallback: the predicate above is the kernel's own rule)
+        CRNN_TRY(crnn_dwconv3x3_bwd_stream_ex(c.w("d" + p), gA, c.w("bn1s" + p), c.w("coef"), xin, c.p(bp + "_dw"), gC, c.g(bp + "_dw"), c.w("partials"),
+                                              B, H, W, ci, CRNN_F32, stream));
+        rc = CRNN_OK;
+      } else if (fuse_bn2_dw(c, i - 1)) {                           // the forward did not keep x_{i-1}: re-formed from q_{i-1} in LDS (no fallback: same decision)
         const std::string pp = std::to_string(i - 1);
         // (its dropout decisions: the keep bytes the forward of this step left in the workspace -- same seed)
         float* st2 = (cfg->flags & CRNN_FLAG_BN2_STATS_FUSION) ? c.w("bn2parts") : nullptr;   // opt-in: measured neutral (include/crnn_mi355x.h)

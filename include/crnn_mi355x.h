@@ -297,6 +297,13 @@ int crnn_dwconv_bwd_stream_supported(int B, int H, int W, int C);
 int crnn_dwconv_bwd_stream_rows(int B, int H, int W, int C);
 int crnn_dwconv3x3_bwd_stream(const void* d, const void* da, const float* bnstate, const float* coef, const void* xin, const float* k, void* dx,
                               float* dk, float* scratch, int B, int H, int W, int C, crnn_stream_t stream);
+/* The same stage by storage type (dtype: CRNN_BF16 = the three entry points above; CRNN_F32, round 4: four channels per lane, W * C / 4 columns
+ * in workgroups of 257..320): the parity mode's crnn_bn_bwd_apply_ex + crnn_dwconv3x3_wgrad_ex + crnn_dwconv3x3_fwd_ex(flip = 1) in one pass over
+ * d, da, xin -- 4 tensor passes instead of 7; dx bit-identical to that sequence, dk to the order of its partial sums. */
+int crnn_dwconv_bwd_stream_supported_ex(int B, int H, int W, int C, int dtype);
+int crnn_dwconv_bwd_stream_rows_ex(int B, int H, int W, int C, int dtype);
+int crnn_dwconv3x3_bwd_stream_ex(const void* d, const void* da, const float* bnstate, const float* coef, const void* xin, const float* k, void* dx,
+                                 float* dk, float* scratch, int B, int H, int W, int C, int dtype, crnn_stream_t stream);
 /* Prologue form: `q` (in place of xin) is the previous block's pointwise output; x = Dropout(ReLU6(q * scale + shift)) is re-formed in LDS by a
  * DX waves one row ahead (the forward did not keep it: crnn_dwconv3x3_fwd_stream_pro; same `keep` bytes).  dx / dk bit-identical to
  * crnn_dwconv3x3_bwd_stream on the materialised x.  bn2_stat_partials != NULL: the DX waves also take the statistics pass of the producer's BatchNorm-2

@@ -251,6 +251,61 @@ def test_fused_depthwise_stage_backward_equals_the_three_kernel_sequence(shape):
         assert L().crnn_dwconv_bwd_stream_rows(B, H, W, C) == 0
 
 
+@pytest.mark.parametrize("shape", [(2, 104, 36, 128), (3, 52, 18, 256), (2, 52, 9, 512), (3, 104, 36, 64), (2, 204, 36, 128), (40, 52, 18, 256), (70, 52, 9, 512),
+                                   (1, 40, 36, 64), (2, 13, 7, 64), (1, 3, 18, 256)])
+def test_fp32_row_stream_depthwise_stage_backward_equals_the_three_kernel_sequence(shape):
+    """crnn_dwconv3x3_bwd_stream_ex(dtype = fp32) -- the parity mode's depthwise-stage backward in one pass (round 4) -- against
+    crnn_bn_bwd_ex + crnn_dwconv3x3_wgrad_ex + crnn_dwconv3x3_fwd_ex(flip = 1) on fp32 tensors: the data gradient bit for bit, the weight
+    gradient to fp32 summation-order round-off; both against the fp64 oracle at the fp32 kernels' tolerance.  Shapes the rule refuses report so."""
+    B, H, W, C = shape
+    rs = np.random.RandomState(sum(shape) + 1)
+    x = rs.normal(size=shape).astype(np.float32).astype(np.float64); k = rs.normal(size=(3, 3, C))
+    d = ops.dwconv_fwd(x, k).astype(np.float32).astype(np.float64)
+    gamma, beta = rs.normal(size=C) * 0.3 + 1.0, rs.normal(size=C) * 0.5 + 1.0
+    da = rs.normal(size=shape).astype(np.float32).astype(np.float64)
+    xd, dd, dad, kd = dev(x), dev(d), dev(da), dev(k)
+    M = B * H * W
+    mean = d.reshape(M, C).mean(0); var = d.reshape(M, C).var(0)
+    scale = gamma / np.sqrt(var + 1e-3); shift = beta - mean * scale
+    st = dev(np.concatenate([mean, var, scale, shift])); gd = dev(gamma)
+    sup = L().crnn_dwconv_bwd_stream_supported_ex(B, H, W, C, 0)
+    rows = L().crnn_dwconv_bwd_stream_rows_ex(B, H, W, C, 0)
+    if sup != 0:
+        assert sup == -3 and rows == 0
+        assert L().crnn_dwconv3x3_bwd_stream_ex(P(dd), P(dad), P(st), P(st), P(xd), P(kd), P(dd), P(kd), P(kd), B, H, W, C, 0, S()) == -3
+        return
+    assert rows >= B
+    nparts = max(L().crnn_bn_bwd_chunks(M), L().crnn_dwconv_num_tiles(B, H, W) * 9, rows * 9)
+    gin = zeros(B, H, W, C); dg1, db1 = zeros(C), zeros(C); parts = zeros(nparts * 2 * C + 9 * C * nparts); coef = zeros(2 * C)
+    ok(L().crnn_bn_bwd_ex(P(dd), P(dad), P(st), P(gd), P(gin), P(dg1), P(db1), P(parts), P(coef), B, H, W, C, 1, 1, 0.0, 0, 0, 0, S()))
+    dk1 = zeros(9, C)
+    ok(L().crnn_dwconv3x3_wgrad_ex(P(xd), P(gin), P(dk1), P(parts), B, H, W, C, 0, S()))
+    dx1 = zeros(B, H, W, C)
+    ok(L().crnn_dwconv3x3_fwd_ex(P(gin), P(kd), P(dx1), None, B, H, W, C, 1, 0, S()))
+    dx2 = torch.full((B * H * W * C + 64,), 9.0, device="cuda"); dk2 = zeros(9, C)
+    sc2 = torch.full((rows * 9 * C + 16,), 5.0, device="cuda")
+    ok(L().crnn_dwconv3x3_bwd_stream_ex(P(dd), P(dad), P(st), P(coef), P(xd), P(kd), P(dx2), P(dk2), P(sc2), B, H, W, C, 0, S()))
+    assert torch.equal(dx2[:-64].view(torch.int32), dx1.reshape(-1).view(torch.int32)), "stream dx: max diff %g" % float((dx1.reshape(-1) - dx2[:-64]).abs().max())
+    assert bool((dx2[-64:] == 9.0).all()) and bool((sc2[-16:] == 5.0).all())
+    assert_close(host(dk2), host(dk1), rtol=2e-5, atol=2e-5 * np.abs(host(dk1)).max(), what="dk stream vs sequence")
+    dx3 = torch.zeros_like(dx2); dk3 = zeros(9, C)
+    ok(L().crnn_dwconv3x3_bwd_stream_ex(P(dd), P(dad), P(st), P(coef), P(xd), P(kd), P(dx3), P(dk3), P(sc2), B, H, W, C, 0, S()))
+    assert torch.equal(dx3[:-64], dx2[:-64]) and torch.equal(dk2, dk3), "repeat launches differ"
+    # fp64 oracle of the same stage
+    xhat = (d - mean) / np.sqrt(var + 1e-3); y = xhat * gamma + beta
+    gy = da * ((y > 0) & (y < 6))
+    ddn = scale * (gy - gy.reshape(M, C).mean(0) - xhat * (gy * xhat).reshape(M, C).mean(0))
+    dx_ref, dk_ref = ops.dwconv_bwd(x, k, ddn)
+    near = np.minimum(np.abs(y), np.abs(y - 6)) < 1e-4          # (activations within round-off of a ReLU6 threshold may gate differently)
+    if not near.any():
+        assert_close(host(dx2[:-64]).reshape(shape), dx_ref, rtol=1e-4, atol=1e-4 * np.abs(dx_ref).max(), what="dx vs oracle")
+        assert_close(host(dk2).reshape(3, 3, C), dk_ref, rtol=1e-4, atol=1e-4 * np.abs(dk_ref).max(), what="dk vs oracle")
+    # the bf16 entry points through the same dispatcher
+    assert L().crnn_dwconv_bwd_stream_supported_ex(B, H, W, C, 1) == L().crnn_dwconv_bwd_stream_supported(B, H, W, C)
+    assert L().crnn_dwconv_bwd_stream_rows_ex(B, H, W, C, 1) == L().crnn_dwconv_bwd_stream_rows(B, H, W, C)
+    assert L().crnn_dwconv_bwd_stream_supported_ex(B, H, W, C, 7) == -2
+
+
 # ------------------------------------------------------------------------------------------------ BatchNorm chain
 def _bn_state(x, gamma, beta):
     Mrows = x.size // x.shape[-1]
