@@ -75,9 +75,10 @@ constexpr int kSub = 5 * 1024;               // one row of one tensor in a ring 
 constexpr int kStageB = 3 * kSub;            // d | da | xin
 constexpr int kNI = 15;                      // DMA instructions per stage
 // LDS plan for KD stages in flight (prologue form: + two rows of re-formed x)
-template <int KD, bool STATS = false>
+// STATS: statistics form; DXS: the statistics are taken by the DX waves themselves (fp32 tensors) instead of by a twelfth wave
+template <int KD, bool STATS = false, bool DXS = false>
 struct DbsLds {
-  static constexpr int NR = KD + (STATS ? 3 : 1);   // (the statistics form reads a stage's raw xin row once more, three steps after it landed)
+  static constexpr int NR = KD + (STATS ? (DXS ? 2 : 3) : 1);   // (the statistics form reads a stage's raw xin row once more, two | three steps after it landed)
   static constexpr int DdOff = NR * kStageB;        // two dd rows
   static constexpr int ZOff = DdOff + 2 * kSub;     // 16 zero bytes
   static constexpr int CstOff = ZOff + 64;          // BatchNorm constants of the workgroup's channels: scale | shift | P | Q, [4][<= 256] floats
@@ -85,7 +86,9 @@ struct DbsLds {
   static constexpr int PcOff = XtOff + 2 * kSub;       // prologue form: BatchNorm-2 scale | shift of the workgroup's channels, [2][<= 256] floats
   static constexpr int KeepOff = PcOff + 2 * 256 * 4;  // prologue form: NR x 512 bytes of keep bytes (one per 16-byte chunk of the stage's xin row)
   static constexpr int DxrOff = KeepOff + NR * 512;    // statistics form: two rows of dx (bf16, as stored) for the statistics wave
-  static constexpr int Total = DxrOff + (STATS ? 2 * kSub : 0);
+  static constexpr int Total = DxrOff + ((STATS && !DXS) ? 2 * kSub : 0);
+  static constexpr int SredOff = 64 * 1024;            // DXS: the DX waves' statistics records [5][2][<= 256] after the ring is free (behind the DK waves' 45 KiB)
+  static_assert(!DXS || NR * kStageB >= SredOff + 5 * 2 * 256 * 4, "statistics records inside the ring");
   static_assert((KD - 1) * kNI <= 63, "vmcnt is a 6-bit counter");
 };
 constexpr int kD = CRNN_DBS_D;
@@ -118,19 +121,22 @@ __device__ __forceinline__ int role_of_stats(int w, int& idx) {   // 0 = DK, 1 =
 // this kernel + 0.24 ms (the one wave's ~400 operations per step are the critical path); done by the DX waves themselves + 0.65 (36
 // spilled registers); gating in the DX waves and sums in the twelfth + 0.35 -- so it is not the default schedule.
 template <int KD, bool PRO, bool DROP, bool STATS = false, bool F32 = false>
-__global__ __launch_bounds__(STATS ? 768 : 704, (F32 && CRNN_DBS_F32_WGS > 1) ? 3 * CRNN_DBS_F32_WGS : 1) void dw_bwd_stream_kernel(DbsParams p) {
+__global__ __launch_bounds__((STATS && !F32) ? 768 : 704, (F32 && CRNN_DBS_F32_WGS > 1) ? 3 * CRNN_DBS_F32_WGS : 1) void dw_bwd_stream_kernel(DbsParams p) {
   static_assert(!STATS || PRO, "the statistics form is a prologue form");
-  static_assert(!F32 || !PRO, "the prologue forms exist for bf16 tensors");
+  // fp32 tensors: half the elements per step leave the DX waves the issue slots and registers to take the statistics themselves (their dx values are
+  // in registers: no LDS round trip, no twelfth wave whose ~250 operations per step were the critical path: + 0.25 ms over four launches at batch 256)
+  constexpr bool SW = STATS && !F32;                 // statistics wave present
+  constexpr bool DXS = STATS && F32;                 // statistics in the DX waves
   constexpr int EPC = F32 ? 4 : 8;                   // elements per 16-byte chunk
   constexpr int ES = F32 ? 4 : 2;                    // bytes per element
-  typedef DbsLds<KD, STATS> LP;
+  typedef DbsLds<KD, STATS, DXS> LP;
   constexpr int kNR = LP::NR, kDdOff = LP::DdOff, kZOff = LP::ZOff, kCstOff = LP::CstOff, kXtOff = LP::XtOff, kPcOff = LP::PcOff, kKeepOff = LP::KeepOff, kDxrOff = LP::DxrOff;
   constexpr int kNIT = kNI + (DROP ? 2 : 0);           // DMA instructions per stage
   static_assert((KD - 1) * kNIT <= 63, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int gidx; const int role = STATS ? role_of_stats(wave, gidx) : role_of(wave, gidx);
+  int gidx; const int role = SW ? role_of_stats(wave, gidx) : role_of(wave, gidx);
   int bid = blockIdx.x;
   const int split = bid % p.nsplit; bid /= p.nsplit;
   const int wb = bid % p.nwgb, img = bid / p.nwgb;
@@ -151,15 +157,17 @@ __global__ __launch_bounds__(STATS ? 768 : 704, (F32 && CRNN_DBS_F32_WGS > 1) ? 
     }
     const unsigned char* gd = p.d + imgoff; const unsigned char* gg = p.da + imgoff; const unsigned char* gxx = p.xin + imgoff;
     // prologue form with dropout: the keep bytes of the stage's xin row for this workgroup's columns, 4 bytes (4 columns of one pixel) per lane
+    // (one keep byte per 8 elements: per column for bf16 tensors, per pair of columns for fp32 ones)
     const int cpp = p.C >> 3, rowcols = p.W * cpp;
     int koff[2];
     const unsigned char* gk = DROP ? p.keep + (long)img * p.H * rowcols : nullptr;
     if (DROP) {
+      const int kpp = p.cppw * EPC / 8, kcols = p.cols * EPC / 8;   // keep bytes per pixel of the channel range, per stage row
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        int c4 = (i * 64 + lane) * 4; if (c4 >= p.cols) c4 = p.cols - 4;
-        const int px = c4 / p.cppw, o = c4 - px * p.cppw;
-        koff[i] = px * cpp + split * p.cppw + o;
+        int c4 = (i * 64 + lane) * 4; if (c4 >= kcols) c4 = kcols - 4;
+        const int px = c4 / kpp, o = c4 - px * kpp;
+        koff[i] = px * cpp + (c0 >> 3) + o;
       }
     }
     auto issue = [&](int s, int slot) {
@@ -194,20 +202,21 @@ __global__ __launch_bounds__(STATS ? 768 : 704, (F32 && CRNN_DBS_F32_WGS > 1) ? 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (STATS) __builtin_amdgcn_s_barrier();         // (the statistics wave takes its last row before the ring is reused)
+    if (SW) __builtin_amdgcn_s_barrier();            // (the statistics wave takes its last row before the ring is reused)
     __builtin_amdgcn_s_barrier();
     return;
   }
-  if (STATS && role == 3) {
+  if (SW && role == 3) {
     // ------------------------------------------------------------------ statistics wave: all five column groups, one step behind the DX waves
     int offS[kCW]; bool actS[kCW];
 #pragma unroll
     for (int g = 0; g < kCW; ++g) { const int c = g * 64 + lane; actS[g] = c < p.cols; offS[g] = actS[g] ? c : p.cols - 1; }
     // 64 % cppw == 0 (cppw is a power of two <= 32): every group of a lane holds the same channel octet -- one set of constants and sums
-    const int chS = c0 + ((lane % p.cppw) << 3);
-    f32x2_t sc[4], sh[4], iv[4], nm[4], st_s[4], st_q[4];          // xhat = q * inv - mean * inv
+    const int chS = c0 + (lane % p.cppw) * EPC;
+    constexpr int HP = EPC / 2;                                    // channel pairs per column
+    f32x2_t sc[HP], sh[HP], iv[HP], nm[HP], st_s[HP], st_q[HP];    // xhat = q * inv - mean * inv
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < HP; ++e) {
       sc[e] = (f32x2_t){p.pro_bn[2 * p.C + chS + 2 * e], p.pro_bn[2 * p.C + chS + 2 * e + 1]};
       sh[e] = (f32x2_t){p.pro_bn[3 * p.C + chS + 2 * e], p.pro_bn[3 * p.C + chS + 2 * e + 1]};
       iv[e] = (f32x2_t){1.0f / sqrtf(p.pro_bn[p.C + chS + 2 * e] + BN_EPS_F), 1.0f / sqrtf(p.pro_bn[p.C + chS + 2 * e + 1] + BN_EPS_F)};
@@ -226,15 +235,28 @@ __global__ __launch_bounds__(STATS ? 768 : 704, (F32 && CRNN_DBS_F32_WGS > 1) ? 
 #pragma unroll
       for (int g = 0; g < kCW; ++g) {
         vg[g] = *reinterpret_cast<const u32x4*>(dr + offS[g] * 16); vq[g] = *reinterpret_cast<const u32x4*>(qr + offS[g] * 16);
-        kq[g] = DROP ? (uint32_t)kr[offS[g]] : 0xffu;
+        kq[g] = DROP ? (F32 ? ((uint32_t)kr[offS[g] >> 1] >> ((offS[g] & 1) * 4)) : (uint32_t)kr[offS[g]]) : 0xffu;
       }
 #pragma unroll
       for (int g = 0; g < kCW; ++g) {
         if (g * 64 >= p.cols) continue;              // (uniform)
+        if (F32) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const f32x2_t x2 = (f32x2_t){__uint_as_float(vq[g][2 * q]), __uint_as_float(vq[g][2 * q + 1])};
+            const f32x2_t t = __builtin_elementwise_fma(x2, sc[q], sh[q]);
+            f32x2_t gy = actS[g] ? (f32x2_t){__uint_as_float(vg[g][2 * q]), __uint_as_float(vg[g][2 * q + 1])} : (f32x2_t){0.f, 0.f};
+            gy = (f32x2_t){(((kq[g] >> (2 * q)) & 1u) && t.x > 0.f && t.x < 6.f) ? gy.x : 0.f,
+                           (((kq[g] >> (2 * q + 1)) & 1u) && t.y > 0.f && t.y < 6.f) ? gy.y : 0.f};
+            st_s[q] += gy;
+            st_q[q] = __builtin_elementwise_fma(gy, __builtin_elementwise_fma(x2, iv[q], nm[q]), st_q[q]);
+          }
+          continue;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x2_t x2 = (f32x2_t){__uint_as_float(vq[g][q] << 16), __uint_as_float(vq[g][q] & 0xffff0000u)};
-          const f32x2_t t = __builtin_elementwise_fma(x2, sc[q], sh[q]);
+          const f32x2_t t = __builtin_elementwise_fma(x2, sc[q % HP], sh[q % HP]);
           uint32_t gm = actS[g] ? vg[g][q] : 0u;
           if (DROP) {
             const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe((int)kq[g], 2 * q, 1), hi = (uint32_t)__builtin_amdgcn_sbfe((int)kq[g], 2 * q + 1, 1);
@@ -242,8 +264,8 @@ __global__ __launch_bounds__(STATS ? 768 : 704, (F32 && CRNN_DBS_F32_WGS > 1) ? 
           }
           f32x2_t gy = (f32x2_t){__uint_as_float(gm << 16), __uint_as_float(gm & 0xffff0000u)};
           gy = (f32x2_t){(t.x > 0.f && t.x < 6.f) ? gy.x : 0.f, (t.y > 0.f && t.y < 6.f) ? gy.y : 0.f};
-          st_s[q] += gy;
-          st_q[q] = __builtin_elementwise_fma(gy, __builtin_elementwise_fma(x2, iv[q], nm[q]), st_q[q]);
+          st_s[q % HP] += gy;
+          st_q[q % HP] = __builtin_elementwise_fma(gy, __builtin_elementwise_fma(x2, iv[q % HP], nm[q % HP]), st_q[q % HP]);
         }
       }
     };
@@ -257,7 +279,7 @@ __global__ __launch_bounds__(STATS ? 768 : 704, (F32 && CRNN_DBS_F32_WGS > 1) ? 
     // lanes l, l + cppw, ... hold the same channels -> xor shuffles; this one wave has seen every column of the workgroup
     for (int o = p.cppw; o < 64; o <<= 1) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < HP; ++e) {
         st_s[e].x += __shfl_xor(st_s[e].x, o, 64); st_s[e].y += __shfl_xor(st_s[e].y, o, 64);
         st_q[e].x += __shfl_xor(st_q[e].x, o, 64); st_q[e].y += __shfl_xor(st_q[e].y, o, 64);
       }
@@ -266,7 +288,7 @@ __global__ __launch_bounds__(STATS ? 768 : 704, (F32 && CRNN_DBS_F32_WGS > 1) ? 
       const float ik = DROP ? 1.f / (1.f - p.rate) : 1.f;        // gy carries the dropout's 1 / (1 - rate): applied once here
       float* prow = p.bn2_partials + (long)(blockIdx.x / p.nsplit) * 2 * p.C + chS;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < HP; ++e) {
         prow[2 * e] = st_s[e].x * ik; prow[2 * e + 1] = st_s[e].y * ik;
         prow[p.C + 2 * e] = st_q[e].x * ik; prow[p.C + 2 * e + 1] = st_q[e].y * ik;
       }
@@ -302,25 +324,39 @@ __global__ __launch_bounds__(STATS ? 768 : 704, (F32 && CRNN_DBS_F32_WGS > 1) ? 
     // prologue form: re-form x = Dropout(ReLU6(q * scale + shift)) of the stage that arrived one step ahead (own column) into the two-row
     // buffer the DK waves read; bn_act_pool_drop_kernel's arithmetic bit for bit.  (The 16 BatchNorm-2 constants of the lane's channels
     // sit in LDS and are read per step: kw and the running rows fill the registers.)
-    const int pcw = p.cppw * 8;                       // channels of this workgroup
+    const int pcw = p.cppw * EPC;                     // channels of this workgroup
     float* pct = reinterpret_cast<float*>(lds + kPcOff);
     if (PRO)
       for (int i = gidx * 64 + lane; i < pcw; i += kCW * 64) {
         pct[i] = p.pro_bn[2 * p.C + c0 + i]; pct[pcw + i] = p.pro_bn[3 * p.C + c0 + i];
       }
-    const float* pcl = pct + oct * 8;
+    const float* pcl = pct + oct * EPC;
     const float pik = DROP ? 1.f / (1.f - p.rate) : 1.f;
     int xslot = 1;                                    // ring slot of the next stage to re-form (stage 1 first)
     auto xform = [&](int st) {                        // stage st: xin row r0 - 2 + st  ->  xt[st & 1]
       const u32x4 v = *reinterpret_cast<const u32x4*>(lds + xslot * kStageB + 2 * kSub + offC);
       uint32_t kc = 0xffu;
-      if (DROP) kc = lds[kKeepOff + xslot * 512 + ccol];
+      if (DROP) kc = F32 ? ((uint32_t)lds[kKeepOff + xslot * 512 + (ccol >> 1)] >> ((ccol & 1) * 4)) : (uint32_t)lds[kKeepOff + xslot * 512 + ccol];
       xslot = xslot + 1 == kNR ? 0 : xslot + 1;
       u32x4 o;
+      if (F32) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const f32x2_t x2 = (f32x2_t){__uint_as_float(v[2 * q]), __uint_as_float(v[2 * q + 1])};
+          const f32x2_t psc = *reinterpret_cast<const f32x2_t*>(pcl + 2 * q), psh = *reinterpret_cast<const f32x2_t*>(pcl + pcw + 2 * q);
+          f32x2_t y = __builtin_elementwise_fma(x2, psc, psh);
+          y = (f32x2_t){relu6f(y.x), relu6f(y.y)};
+          if (DROP) {
+            y = y * (f32x2_t){pik, pik};                // y >= 0: a dropped element is +0 like y * 0
+            y = (f32x2_t){(kc >> (2 * q)) & 1u ? y.x : 0.f, (kc >> (2 * q + 1)) & 1u ? y.y : 0.f};
+          }
+          o[2 * q] = __float_as_uint(y.x); o[2 * q + 1] = __float_as_uint(y.y);
+        }
+      } else
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x2_t x2 = (f32x2_t){__uint_as_float(v[q] << 16), __uint_as_float(v[q] & 0xffff0000u)};
-        const f32x2_t psc = *reinterpret_cast<const f32x2_t*>(pcl + 2 * q), psh = *reinterpret_cast<const f32x2_t*>(pcl + pcw + 2 * q);
+        const f32x2_t psc = *reinterpret_cast<const f32x2_t*>(pcl + (2 * q) % EPC), psh = *reinterpret_cast<const f32x2_t*>(pcl + pcw + (2 * q) % EPC);
         f32x2_t y = __builtin_elementwise_fma(x2, psc, psh);
         y = (f32x2_t){relu6f(y.x), relu6f(y.y)};
         if (DROP) {
@@ -334,6 +370,36 @@ __global__ __launch_bounds__(STATS ? 768 : 704, (F32 && CRNN_DBS_F32_WGS > 1) ? 
       }
       if (act) *reinterpret_cast<u32x4*>(lds + kXtOff + (st & 1) * kSub + offC) = o;
       __builtin_amdgcn_sched_barrier(0);              // its temporaries are dead before the correlation's operands are loaded
+    };
+    // DXS: the statistics pass of the producer's BatchNorm-2 backward on the finished dx row (A, image row r0 + a - 2) and the raw q row of the same
+    // image row (stage a, two stages behind the one being re-formed): gy = dx where the element was kept and 0 < q * scale + shift < 6
+    f32x2_t ds_s[EPC / 2], ds_q[EPC / 2], dsc[EPC / 2], dsh[EPC / 2], div_[EPC / 2], dnm[EPC / 2];
+    int sslot = 2;                                    // ring slot of stage a at the first statistics step (a = 2)
+    if (DXS) {
+#pragma unroll
+      for (int e = 0; e < EPC / 2; ++e) {
+        dsc[e] = (f32x2_t){p.pro_bn[2 * p.C + ch0 + 2 * e], p.pro_bn[2 * p.C + ch0 + 2 * e + 1]};
+        dsh[e] = (f32x2_t){p.pro_bn[3 * p.C + ch0 + 2 * e], p.pro_bn[3 * p.C + ch0 + 2 * e + 1]};
+        div_[e] = (f32x2_t){1.0f / sqrtf(p.pro_bn[p.C + ch0 + 2 * e] + BN_EPS_F), 1.0f / sqrtf(p.pro_bn[p.C + ch0 + 2 * e + 1] + BN_EPS_F)};
+        dnm[e] = (f32x2_t){-p.pro_bn[ch0 + 2 * e] * div_[e].x, -p.pro_bn[ch0 + 2 * e + 1] * div_[e].y};
+        ds_s[e] = (f32x2_t){0.f, 0.f}; ds_q[e] = (f32x2_t){0.f, 0.f};
+      }
+    }
+    auto dxstats = [&](const float (&A)[EPC]) {
+      if constexpr (DXS) {
+        const u32x4 vq = *reinterpret_cast<const u32x4*>(lds + sslot * kStageB + 2 * kSub + offC);
+        uint32_t kq = 0xfu;
+        if (DROP) kq = (uint32_t)lds[kKeepOff + sslot * 512 + (ccol >> 1)] >> ((ccol & 1) * 4);
+#pragma unroll
+        for (int q = 0; q < EPC / 2; ++q) {
+          const f32x2_t x2 = (f32x2_t){__uint_as_float(vq[2 * q]), __uint_as_float(vq[2 * q + 1])};
+          const f32x2_t t = __builtin_elementwise_fma(x2, dsc[q], dsh[q]);
+          const f32x2_t gy = (f32x2_t){(((kq >> (2 * q)) & 1u) && t.x > 0.f && t.x < 6.f) ? A[2 * q] : 0.f,
+                                       (((kq >> (2 * q + 1)) & 1u) && t.y > 0.f && t.y < 6.f) ? A[2 * q + 1] : 0.f};
+          ds_s[q] += gy;
+          ds_q[q] = __builtin_elementwise_fma(gy, __builtin_elementwise_fma(x2, div_[q], dnm[q]), ds_q[q]);
+        }
+      }
     };
     // a = arriving dd row (relative: image row r0-1+a), read one step after the DK waves wrote it
     auto step = [&](int a, float (&A)[EPC], float (&Bc)[EPC], float (&Cn)[EPC]) {
@@ -362,8 +428,10 @@ __global__ __launch_bounds__(STATS ? 768 : 704, (F32 && CRNN_DBS_F32_WGS > 1) ? 
       if (a >= 2 && act) {
         const u32x4 o = packE<EPC>(A);
         if (!(CRNN_DBS_EXP & 2)) *reinterpret_cast<u32x4*>(orow + (long)(a - 2) * p.rowbytes) = o;
-        if (STATS) *reinterpret_cast<u32x4*>(lds + kDxrOff + (a & 1) * kSub + offC) = o;   // (for the statistics wave, one step later)
+        if (SW) *reinterpret_cast<u32x4*>(lds + kDxrOff + (a & 1) * kSub + offC) = o;   // (for the statistics wave, one step later)
+        if (DXS) dxstats(A);
       }
+      if (DXS && a >= 2) sslot = sslot + 1 == kNR ? 0 : sslot + 1;
     };
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                  // step 0: the first dd row is being formed
@@ -382,9 +450,39 @@ __global__ __launch_bounds__(STATS ? 768 : 704, (F32 && CRNN_DBS_F32_WGS > 1) ? 
       else step(a, X1, X2, X0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                  // ring free
+    if (SW) __builtin_amdgcn_s_barrier();
+    if (DXS) {
+      // lanes l, l + cppw, ... of a wave hold the same channels -> xor shuffles; one record [2][channels] per DX wave in LDS
+      for (int o = p.cppw; o < 64; o <<= 1) {
+#pragma unroll
+        for (int e = 0; e < EPC / 2; ++e) {
+          ds_s[e].x += __shfl_xor(ds_s[e].x, o, 64); ds_s[e].y += __shfl_xor(ds_s[e].y, o, 64);
+          ds_q[e].x += __shfl_xor(ds_q[e].x, o, 64); ds_q[e].y += __shfl_xor(ds_q[e].y, o, 64);
+        }
+      }
+      float* sred = reinterpret_cast<float*>(lds + LP::SredOff);      // [5 waves][2][pcw]
+      if (lane < p.cppw) {
+#pragma unroll
+        for (int e = 0; e < EPC / 2; ++e) {
+          *reinterpret_cast<f32x2_t*>(sred + (gidx * 2) * pcw + lane * EPC + 2 * e) = ds_s[e];
+          *reinterpret_cast<f32x2_t*>(sred + (gidx * 2 + 1) * pcw + lane * EPC + 2 * e) = ds_q[e];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
-    if (STATS) __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_s_barrier();
+    if (DXS) {
+      const float ik = DROP ? 1.f / (1.f - p.rate) : 1.f;          // gy carries the dropout's 1 / (1 - rate): applied once here
+      const float* sred = reinterpret_cast<const float*>(lds + LP::SredOff);
+      float* prow = p.bn2_partials + (long)(blockIdx.x / p.nsplit) * 2 * p.C + c0;
+      for (int i = gidx * 64 + lane; i < 2 * pcw; i += kCW * 64) {   // i < pcw: sum gy, else sum gy * xhat; the five waves in a fixed order
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < kCW; ++w) a += sred[w * 2 * pcw + i];
+        prow[i < pcw ? i : p.C + i - pcw] = a * ik;
+      }
+    }
     return;
   }
 
@@ -487,7 +585,7 @@ __global__ __launch_bounds__(STATS ? 768 : 704, (F32 && CRNN_DBS_F32_WGS > 1) ? 
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                    // ring free
-  if (STATS) __builtin_amdgcn_s_barrier();         // (... once the statistics wave has taken its last row out of it)
+  if (SW) __builtin_amdgcn_s_barrier();            // (... once the statistics wave has taken its last row out of it)
   // weight-gradient partials of the workgroup: lanes l, l + cppw, ... of a wave hold the same channels -> xor shuffles; the five waves
   // through LDS in a fixed order
   float* red = reinterpret_cast<float*>(lds);       // [5 waves][9][cppw * 8]
@@ -633,6 +731,42 @@ extern "C" int crnn_dwconv3x3_bwd_stream_pro(const void* d, const void* da, cons
   do {                                                                                                                  \
     CRNN_LDS_ATTR((dw_bwd_stream_kernel<KD, true, DROP, STATS>), (DbsLds<KD, STATS>::Total));                           \
     hipLaunchKernelGGL((dw_bwd_stream_kernel<KD, true, DROP, STATS>), grid, dim3(STATS ? 768 : 704), (DbsLds<KD, STATS>::Total), stream, p); \
+  } while (0)
+  if (bn2_stat_partials) { if (rate > 0.f) DBS_PRO_LAUNCH(true, true); else DBS_PRO_LAUNCH(false, true); }
+  else { if (rate > 0.f) DBS_PRO_LAUNCH(true, false); else DBS_PRO_LAUNCH(false, false); }
+#undef DBS_PRO_LAUNCH
+  CRNN_LAUNCH_CHECK();
+  return crnn_partials_sum(scratch, B * g.nwgb, 9 * C, dk, 1.f, stream);
+}
+// The prologue form by storage type (CRNN_BF16 = the entry points above; CRNN_F32, round 4 -- the parity mode): d, da, q, dx fp32, four channels per
+// lane, the keep bytes (one per 8 elements) as nibbles.  dx / dk / the statistics partials as for the bf16 form, against the fp32 sequence
+// crnn_bn_act_pool_drop_ex(q -> x) + crnn_dwconv3x3_bwd_stream_ex(x) [+ crnn_bn_bwd_ex's statistics pass].
+extern "C" int crnn_dwconv_bwd_stream_pro_supported_ex(int B, int H, int W, int C, int dtype) {
+  if (dtype == CRNN_BF16) return crnn_dwconv_bwd_stream_pro_supported(B, H, W, C);
+  if (dtype != CRNN_F32) return CRNN_ERR_ARG;
+  const DbsGeom g = dbs_geom(B, H, W, C, 4);   // (+ the keep bytes of a stage travel as whole dwords: 8 columns of one pixel)
+  return (g.ok && g.cppw % 8 == 0 && g.cols % 8 == 0 && (long)B * H * W * (C / 8) < (1L << 31)) ? CRNN_OK : CRNN_ERR_UNSUPPORTED;
+}
+extern "C" int crnn_dwconv3x3_bwd_stream_pro_ex(const void* d, const void* da, const float* bnstate, const float* coef, const void* q, const float* pro_bnstate,
+                                                float rate, const void* keep, const float* k, void* dx, float* dk, float* scratch, float* bn2_stat_partials,
+                                                int B, int H, int W, int C, int dtype, hipStream_t stream) {
+  if (dtype == CRNN_BF16) return crnn_dwconv3x3_bwd_stream_pro(d, da, bnstate, coef, q, pro_bnstate, rate, keep, k, dx, dk, scratch, bn2_stat_partials, B, H, W, C, stream);
+  if (dtype != CRNN_F32 || !d || !da || !bnstate || !coef || !q || !pro_bnstate || !k || !dx || !dk || !scratch || rate < 0.f || rate >= 1.f || (rate > 0.f && !keep)) return CRNN_ERR_ARG;
+  const DbsGeom g = dbs_geom(B, H, W, C, 4);
+  if (crnn_dwconv_bwd_stream_pro_supported_ex(B, H, W, C, CRNN_F32) != CRNN_OK) return CRNN_ERR_UNSUPPORTED;
+  if ((((uintptr_t)d | (uintptr_t)da | (uintptr_t)q | (uintptr_t)dx | (uintptr_t)bnstate | (uintptr_t)coef | (uintptr_t)k | (uintptr_t)pro_bnstate) & 15) || ((uintptr_t)keep & 3)) return CRNN_ERR_UNSUPPORTED;
+  if ((long)H * W * C * 4 >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;
+  DbsParams p;
+  p.d = (const unsigned char*)d; p.da = (const unsigned char*)da; p.xin = (const unsigned char*)q; p.dx = (unsigned char*)dx;
+  p.bnstate = bnstate; p.coef = coef; p.k = k; p.partials = scratch;
+  p.H = H; p.W = W; p.C = C; p.HB = g.HB; p.nwgb = g.nwgb; p.nsplit = g.nsplit; p.cols = g.cols; p.cppw = g.cppw; p.rowbytes = W * C * 4;
+  p.pro_bn = pro_bnstate; p.keep = (const unsigned char*)keep; p.rate = rate; p.bn2_partials = bn2_stat_partials;
+  constexpr int KD = kD + 1;
+  const dim3 grid(B * g.nwgb * g.nsplit);
+#define DBS_PRO_LAUNCH(DROP, STATS)                                                                                     \
+  do {                                                                                                                  \
+    CRNN_LDS_ATTR((dw_bwd_stream_kernel<KD, true, DROP, STATS, true>), (DbsLds<KD, STATS, STATS>::Total));              \
+    hipLaunchKernelGGL((dw_bwd_stream_kernel<KD, true, DROP, STATS, true>), grid, dim3(704), (DbsLds<KD, STATS, STATS>::Total), stream, p); \
   } while (0)
   if (bn2_stat_partials) { if (rate > 0.f) DBS_PRO_LAUNCH(true, true); else DBS_PRO_LAUNCH(false, true); }
   else { if (rate > 0.f) DBS_PRO_LAUNCH(true, false); else DBS_PRO_LAUNCH(false, false); }

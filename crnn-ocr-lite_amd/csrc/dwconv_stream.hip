@@ -41,6 +41,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 struct DwsParams {
   const unsigned char* x; const float* k; unsigned char* out; float* partials; const float* bnstate;
   int H, W, C, HB, NS, nwgb, flip, cols, rowbytes, wmaj;
+  int nsplit, cppw;          // channel ranges per row (fp32 form: 2 for rows of 18 KiB), 16-byte columns per pixel of one range
   // prologue form: BatchNorm state [mean|var|scale|shift] of the producer, dropout of its output
   const float* pro_bn; const unsigned char* keep; float rate;
 };
@@ -53,6 +54,20 @@ __device__ __forceinline__ void widen8(const u32x4& u, float (&f)[8]) {
   f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
   f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
   f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+
+// element forms of a 16-byte chunk: 8 bf16 (EPC = 8) or 4 fp32 (EPC = 4; round 4, the parity mode's prologue form)
+template <int EPC> __device__ __forceinline__ void widenE(const u32x4& u, float (&f)[EPC]);
+template <> __device__ __forceinline__ void widenE<8>(const u32x4& u, float (&f)[8]) { widen8(u, f); }
+template <> __device__ __forceinline__ void widenE<4>(const u32x4& u, float (&f)[4]) {
+  f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y); f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
+}
+template <int EPC> __device__ __forceinline__ u32x4 packE(const float (&f)[EPC]);
+template <> __device__ __forceinline__ u32x4 packE<8>(const float (&f)[8]) {
+  u32x4 o; o.x = pack2_bf16(f[0], f[1]); o.y = pack2_bf16(f[2], f[3]); o.z = pack2_bf16(f[4], f[5]); o.w = pack2_bf16(f[6], f[7]); return o;
+}
+template <> __device__ __forceinline__ u32x4 packE<4>(const float (&f)[4]) {
+  u32x4 o; o.x = __float_as_uint(f[0]); o.y = __float_as_uint(f[1]); o.z = __float_as_uint(f[2]); o.w = __float_as_uint(f[3]); return o;
 }
 
 constexpr int kDwsMaxWaves = 9;     // compute waves (576 columns of 16 bytes)
@@ -76,11 +91,12 @@ constexpr int kDwsProStride = 128;
 
 // Re-forming x = Dropout(ReLU6(q * scale + shift)) of a transformer's chunks of one row, in place (bf16 -> bf16): bn_act_pool_drop_kernel's
 // arithmetic bit for bit; dropout decisions from the row's keep bytes (one per chunk) next to it in LDS.
-template <bool DROP>
+template <bool DROP, bool F32 = false>
 struct DwsXform {
+  static constexpr int EPC = F32 ? 4 : 8;
   int coff[kDwsProChunks]; bool cact[kDwsProChunks]; int nj;
-  f32x2_t sc[4], sh[4]; float ik;
-  __device__ __forceinline__ void init(const DwsParams& p, int tw, int lane) {
+  f32x2_t sc[EPC / 2], sh[EPC / 2]; float ik;
+  __device__ __forceinline__ void init(const DwsParams& p, int tw, int lane, int c0) {
     nj = 0;
 #pragma unroll
     for (int j = 0; j < kDwsProChunks; ++j) {
@@ -89,29 +105,48 @@ struct DwsXform {
       coff[j] = cact[j] ? c : 0;
       if (j * kDwsProStride + tw * 64 < p.cols) nj = j + 1;     // (uniform) chunks this wave has
     }
-    // kDwsProStride % (C / 8) == 0 (launcher): every chunk of a lane holds the same channel octet
-    const int oct = (tw * 64 + lane) % (p.C >> 3);
+    // kDwsProStride % cppw == 0 (launcher): every chunk of a lane holds the same channels
+    const int ch0 = c0 + ((tw * 64 + lane) % p.cppw) * EPC;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      sc[e] = (f32x2_t){p.pro_bn[2 * p.C + oct * 8 + 2 * e], p.pro_bn[2 * p.C + oct * 8 + 2 * e + 1]};
-      sh[e] = (f32x2_t){p.pro_bn[3 * p.C + oct * 8 + 2 * e], p.pro_bn[3 * p.C + oct * 8 + 2 * e + 1]};
+    for (int e = 0; e < EPC / 2; ++e) {
+      sc[e] = (f32x2_t){p.pro_bn[2 * p.C + ch0 + 2 * e], p.pro_bn[2 * p.C + ch0 + 2 * e + 1]};
+      sh[e] = (f32x2_t){p.pro_bn[3 * p.C + ch0 + 2 * e], p.pro_bn[3 * p.C + ch0 + 2 * e + 1]};
     }
     ik = DROP ? 1.f / (1.f - p.rate) : 1.f;                     // (spelled as bn_act_pool_drop_kernel spells it: the same bits)
   }
   __device__ __forceinline__ void run(unsigned char* sb, const unsigned char* kbp) const {
     if (CRNN_DWS_EXP & 32) return;                               // experiment build: no re-forming
     u32x4 v[kDwsProChunks]; uint32_t kc[kDwsProChunks];
+    // keep bytes: one per group of 8 elements = per chunk (bf16) | per pair of chunks (fp32: the chunk's nibble)
 #pragma unroll
-    for (int j = 0; j < kDwsProChunks; ++j) { v[j] = *reinterpret_cast<const u32x4*>(sb + coff[j] * 16); kc[j] = DROP ? (uint32_t)kbp[coff[j]] : 0xffu; }
+    for (int j = 0; j < kDwsProChunks; ++j) {
+      v[j] = *reinterpret_cast<const u32x4*>(sb + coff[j] * 16);
+      kc[j] = DROP ? (F32 ? ((uint32_t)kbp[coff[j] >> 1] >> ((coff[j] & 1) * 4)) : (uint32_t)kbp[coff[j]]) : 0xffu;
+    }
     const f32x2_t ik2 = (f32x2_t){ik, ik};
 #pragma unroll
     for (int j = 0; j < kDwsProChunks; ++j) {
       if (j >= nj) continue;
       u32x4 o;
+      if (F32) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const f32x2_t x2 = (f32x2_t){__uint_as_float(v[j][2 * q]), __uint_as_float(v[j][2 * q + 1])};
+          f32x2_t y = __builtin_elementwise_fma(x2, sc[q], sh[q]);
+          y = (f32x2_t){relu6f(y.x), relu6f(y.y)};
+          if (DROP) {
+            y = y * ik2;                                           // y >= 0: a dropped element is +0 like y * 0
+            y = (f32x2_t){(kc[j] >> (2 * q)) & 1u ? y.x : 0.f, (kc[j] >> (2 * q + 1)) & 1u ? y.y : 0.f};
+          }
+          o[2 * q] = __float_as_uint(y.x); o[2 * q + 1] = __float_as_uint(y.y);
+        }
+        if (cact[j]) *reinterpret_cast<u32x4*>(sb + coff[j] * 16) = o;
+        continue;
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x2_t x2 = (f32x2_t){__uint_as_float(v[j][q] << 16), __uint_as_float(v[j][q] & 0xffff0000u)};
-        f32x2_t y = __builtin_elementwise_fma(x2, sc[q], sh[q]);      // per element fmaf(x, scale, shift): v_pk_fma_f32
+        f32x2_t y = __builtin_elementwise_fma(x2, sc[q % (EPC / 2)], sh[q % (EPC / 2)]);   // per element fmaf(x, scale, shift): v_pk_fma_f32
         y = (f32x2_t){relu6f(y.x), relu6f(y.y)};
         if (DROP) {
           y = y * ik2;                                             // per element y * inv_keep (v_pk_mul_f32), as the stand-alone pass
@@ -127,8 +162,9 @@ struct DwsXform {
   }
 };
 
-template <int NI, int D, bool EPI, bool PRO, bool DROP = false>
+template <int NI, int D, bool EPI, bool PRO, bool DROP = false, bool F32 = false>
 __global__ __launch_bounds__((kDwsMaxWaves + (PRO ? 3 : 1)) * 64) void dw_fwd_stream_kernel(DwsParams p) {
+  constexpr int EPC = F32 ? 4 : 8, ES = F32 ? 4 : 2;            // elements per 16-byte chunk, bytes per element
   constexpr int NR = D + 1, SLOT = NI * 1024;
   constexpr int NIT = NI + (DROP ? kDwsKeepNI : 0);            // DMA instructions per step row
   static_assert((D - 1) * NIT <= 63, "vmcnt is a 6-bit counter");
@@ -142,7 +178,11 @@ __global__ __launch_bounds__((kDwsMaxWaves + (PRO ? 3 : 1)) * 64) void dw_fwd_st
   // `wave`: index of a compute wave among the compute waves; == ncw for the loader (the transform waves take their own branch first)
   const int wave = PRO ? (role == 0 ? ridx : ncw) : wave0;
   constexpr int KOFF = NR * SLOT + 64;                         // prologue form: NR x 1 KiB of keep bytes behind the zero chunk
-  const int img = blockIdx.x / p.nwgb, wb = blockIdx.x - img * p.nwgb;
+  // workgroup = (image, band, channel range); one range (nsplit = 1) for bf16 maps, whose rows are the 9 KiB step row
+  const int split = F32 ? (int)(blockIdx.x % p.nsplit) : 0;
+  const int bidx = F32 ? (int)(blockIdx.x / p.nsplit) : (int)blockIdx.x;      // statistics row of the workgroup's band
+  const int img = bidx / p.nwgb, wb = bidx - img * p.nwgb;
+  const int c0 = split * (p.C / p.nsplit);         // first channel of the range
   const int r0 = wb * p.NS * p.HB;                 // first output row of sub-band 0
   const int steps = p.HB + 2;                      // input rows r0-1 .. r0+HB of every sub-band
   const int zoff = NR * SLOT;                      // 16 zero bytes (the pixels left of x = 0 and right of x = W-1)
@@ -150,8 +190,8 @@ __global__ __launch_bounds__((kDwsMaxWaves + (PRO ? 3 : 1)) * 64) void dw_fwd_st
 
   if (PRO && role == 1) {
     // ------------------------------------------------------------------ transform waves (prologue form): half of every row each
-    DwsXform<DROP> xf;
-    xf.init(p, ridx, lane);
+    DwsXform<DROP, F32> xf;
+    xf.init(p, ridx, lane, c0);
     auto xform = [&](int slot) { xf.run(lds + slot * SLOT, lds + KOFF + slot * 1024); };
     __builtin_amdgcn_s_barrier();                                // P: row 0 has landed
     xform(0);
@@ -171,6 +211,12 @@ __global__ __launch_bounds__((kDwsMaxWaves + (PRO ? 3 : 1)) * 64) void dw_fwd_st
     int rowfirst[NI], within[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
+      if (F32) {   // chunk j of the step row: pixel j / cppw of the band, 16-byte column j % cppw of the channel range
+        int j = i * 64 + lane; j = j < p.cols ? j : p.cols - 1;  // past the step row: re-read its last chunk (lands in the slot's unused tail)
+        const int sw = p.W * p.cppw, s = j / sw, jj = j - s * sw, px = jj / p.cppw, o = jj - px * p.cppw;
+        rowfirst[i] = r0 + s * p.HB - 1; within[i] = (px * p.C + c0) * ES + o * 16;
+        continue;
+      }
       const int f = i * 1024 + lane * 16;
       int s = f / p.rowbytes, w = f - s * p.rowbytes;
       if (s >= p.NS) { s = p.NS - 1; w = p.rowbytes - 16; }     // past the step row: re-read its last chunk (lands in the slot's unused tail)
@@ -178,15 +224,16 @@ __global__ __launch_bounds__((kDwsMaxWaves + (PRO ? 3 : 1)) * 64) void dw_fwd_st
     }
     // prologue form with dropout: the keep bytes of the step row (one per 16-byte chunk, same order), 4 bytes per lane and instruction
     int krow[kDwsKeepNI], kwithin[kDwsKeepNI];
-    const int rowcols = p.W * (p.C >> 3);
+    const int rowcols = p.W * (p.C >> 3);                      // keep bytes per image row (one per 8 elements)
     const unsigned char* gk = DROP ? p.keep + (long)img * p.H * rowcols : nullptr;
     if (DROP) {
+      const int kpp = p.cppw * EPC / 8, kcols = p.cols * EPC / 8;   // keep bytes per pixel of the channel range, per step row
 #pragma unroll
       for (int i = 0; i < kDwsKeepNI; ++i) {
         int b = (i * 64 + lane) * 4;
-        if (b >= p.cols) b = p.cols - 4;                       // past the step row: its last dword again (lands in the unused tail)
-        const int s2 = b / rowcols;
-        krow[i] = r0 + s2 * p.HB - 1; kwithin[i] = b - s2 * rowcols;
+        if (b >= kcols) b = kcols - 4;                         // past the step row: its last dword again (lands in the unused tail)
+        const int sw = p.W * kpp, s2 = b / sw, bb = b - s2 * sw, px = bb / kpp, o = bb - px * kpp;
+        krow[i] = r0 + s2 * p.HB - 1; kwithin[i] = px * (p.C >> 3) + (c0 >> 3) + o;
       }
     }
     auto issue = [&](int t, int slot) {
@@ -228,35 +275,40 @@ __global__ __launch_bounds__((kDwsMaxWaves + (PRO ? 3 : 1)) * 64) void dw_fwd_st
     const int col = wave * 64 + lane;                          // also this thread's index among the compute threads
     const bool act = col < p.cols;
     const int ccol = act ? col : p.cols - 1;                   // idle lanes of the last wave shadow the last column
-    const int cpp = p.C >> 3;                                  // 16-byte columns per pixel
+    const int cpp = F32 ? p.cppw : (p.C >> 3);                 // 16-byte columns per pixel (of the channel range)
     const int pxs = ccol / cpp, oct = ccol - pxs * cpp;
     const int sub = pxs / p.W, px = pxs - sub * p.W;
-    const int offC = ccol * 16, pitch = p.C * 2;
+    const int offC = ccol * 16, pitch = cpp * 16;              // LDS bytes between horizontally adjacent pixels
+    const int gpitch = p.C * ES;                               // the same in global memory
+    const int ch0 = c0 + oct * EPC;                            // first channel of the lane
     const bool hasL = px > 0, hasR = px < p.W - 1;
-    float kw[9][8];
+    float kw[9][EPC];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const float* kp = p.k + (long)(p.flip ? 8 - t : t) * p.C + oct * 8;
-      const float4 a = *reinterpret_cast<const float4*>(kp), b = *reinterpret_cast<const float4*>(kp + 4);
-      kw[t][0] = a.x; kw[t][1] = a.y; kw[t][2] = a.z; kw[t][3] = a.w; kw[t][4] = b.x; kw[t][5] = b.y; kw[t][6] = b.z; kw[t][7] = b.w;
+      const float* kp = p.k + (long)(p.flip ? 8 - t : t) * p.C + ch0;
+#pragma unroll
+      for (int h = 0; h < EPC / 4; ++h) {
+        const float4 a = *reinterpret_cast<const float4*>(kp + 4 * h);
+        kw[t][4 * h] = a.x; kw[t][4 * h + 1] = a.y; kw[t][4 * h + 2] = a.z; kw[t][4 * h + 3] = a.w;
+      }
     }
-    float esc[8], esh[8];
+    float esc[EPC], esh[EPC];
     if (EPI) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { esc[e] = p.bnstate[2 * p.C + oct * 8 + e]; esh[e] = p.bnstate[3 * p.C + oct * 8 + e]; }
+      for (int e = 0; e < EPC; ++e) { esc[e] = p.bnstate[2 * p.C + ch0 + e]; esh[e] = p.bnstate[3 * p.C + ch0 + e]; }
     }
-    float X0[8], X1[8], X2[8], s[8], ss[8];
+    float X0[EPC], X1[EPC], X2[EPC], s[EPC], ss[EPC];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { X0[e] = X1[e] = X2[e] = 0.f; s[e] = ss[e] = 0.f; }
+    for (int e = 0; e < EPC; ++e) { X0[e] = X1[e] = X2[e] = 0.f; s[e] = ss[e] = 0.f; }
     const int rsub = r0 + sub * p.HB;                          // this lane's first output row
     if (PRO) __builtin_amdgcn_s_barrier();                     // P (the transform waves take row 0 now)
-    unsigned char* orow = p.out + ((long)img * p.H + rsub) * p.rowbytes + px * pitch + oct * 16;
+    unsigned char* orow = p.out + ((long)img * p.H + rsub) * p.rowbytes + px * gpitch + ch0 * ES;
     // window-major output (EPI only; crnn_dwconv3x3_fwd_stream_ex out_order 1): pixel (y, x) is row ((y/2) (W/2) + x/2) 4 + (y&1) 2 + (x&1) of
     // the image -- the four pixels of a 2x2 pooling window are consecutive rows for the pointwise GEMM whose epilogue pools them
-    unsigned char* const owin = p.out + (long)img * p.H * p.rowbytes + ((px >> 1) * 4 + (px & 1)) * pitch + oct * 16;
+    unsigned char* const owin = p.out + (long)img * p.H * p.rowbytes + ((px >> 1) * 4 + (px & 1)) * gpitch + ch0 * ES;
     int slot = 0;
     // one step: input row t of the band (image row rsub - 1 + t) -> taps 6..8 of output t-2 (A: complete), 3..5 of t-1 (Bc), 0..2 of t (Cn)
-    auto step = [&](int t, float (&A)[8], float (&Bc)[8], float (&Cn)[8], bool edge) {
+    auto step = [&](int t, float (&A)[EPC], float (&Bc)[EPC], float (&Cn)[EPC], bool edge) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       const unsigned char* sb = lds + slot * SLOT;
@@ -269,32 +321,31 @@ __global__ __launch_bounds__((kDwsMaxWaves + (PRO ? 3 : 1)) * 64) void dw_fwd_st
         if (g < 0 || g >= p.H) { vL = (u32x4)(0u); vC = (u32x4)(0u); vR = (u32x4)(0u); }
       }
       if (!(CRNN_DWS_EXP & 4)) {
-        float f[8];
-        widen8(vL, f);
+        float f[EPC];
+        widenE<EPC>(vL, f);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { A[e] = fmaf(f[e], kw[6][e], A[e]); Bc[e] = fmaf(f[e], kw[3][e], Bc[e]); Cn[e] = fmaf(f[e], kw[0][e], 0.f); }
-        widen8(vC, f);
+        for (int e = 0; e < EPC; ++e) { A[e] = fmaf(f[e], kw[6][e], A[e]); Bc[e] = fmaf(f[e], kw[3][e], Bc[e]); Cn[e] = fmaf(f[e], kw[0][e], 0.f); }
+        widenE<EPC>(vC, f);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { A[e] = fmaf(f[e], kw[7][e], A[e]); Bc[e] = fmaf(f[e], kw[4][e], Bc[e]); Cn[e] = fmaf(f[e], kw[1][e], Cn[e]); }
-        widen8(vR, f);
+        for (int e = 0; e < EPC; ++e) { A[e] = fmaf(f[e], kw[7][e], A[e]); Bc[e] = fmaf(f[e], kw[4][e], Bc[e]); Cn[e] = fmaf(f[e], kw[1][e], Cn[e]); }
+        widenE<EPC>(vR, f);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { A[e] = fmaf(f[e], kw[8][e], A[e]); Bc[e] = fmaf(f[e], kw[5][e], Bc[e]); Cn[e] = fmaf(f[e], kw[2][e], Cn[e]); }
+        for (int e = 0; e < EPC; ++e) { A[e] = fmaf(f[e], kw[8][e], A[e]); Bc[e] = fmaf(f[e], kw[5][e], Bc[e]); Cn[e] = fmaf(f[e], kw[2][e], Cn[e]); }
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { A[e] += __uint_as_float(vL[e]); A[e + 4] += __uint_as_float(vC[e]); Bc[e] += __uint_as_float(vR[e]); }
+        for (int e = 0; e < 4; ++e) { A[e] += __uint_as_float(vL[e]); A[(e + 4) % EPC] += __uint_as_float(vC[e]); Bc[e] += __uint_as_float(vR[e]); }
       }
       if (t >= 2 && act) {
         if (EPI) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) A[e] = relu6f(fmaf(A[e], esc[e], esh[e]));
+          for (int e = 0; e < EPC; ++e) A[e] = relu6f(fmaf(A[e], esc[e], esh[e]));
         } else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { s[e] += A[e]; ss[e] = fmaf(A[e], A[e], ss[e]); }
+          for (int e = 0; e < EPC; ++e) { s[e] += A[e]; ss[e] = fmaf(A[e], A[e], ss[e]); }
         }
-        u32x4 o;
-        o.x = pack2_bf16(A[0], A[1]); o.y = pack2_bf16(A[2], A[3]); o.z = pack2_bf16(A[4], A[5]); o.w = pack2_bf16(A[6], A[7]);
+        const u32x4 o = packE<EPC>(A);
         unsigned char* dst = orow + (long)(t - 2) * p.rowbytes;
-        if (EPI && p.wmaj) { const int y = rsub + t - 2; dst = owin + (long)(y >> 1) * 2 * p.rowbytes + (y & 1) * 2 * pitch; }
+        if (EPI && p.wmaj) { const int y = rsub + t - 2; dst = owin + (long)(y >> 1) * 2 * p.rowbytes + (y & 1) * 2 * gpitch; }
         if (CRNN_DWS_EXP & 8) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(dst));
         else if (!(CRNN_DWS_EXP & 2)) *reinterpret_cast<u32x4*>(dst) = o;
       }
@@ -322,58 +373,74 @@ __global__ __launch_bounds__((kDwsMaxWaves + (PRO ? 3 : 1)) * 64) void dw_fwd_st
         // record [wave][octet][sum 8 | sumsq 8] per wave in LDS and a fixed-order sum over the waves
         for (int o = cpp; o < 64; o <<= 1) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { s[e] += __shfl_xor(s[e], o, 64); ss[e] += __shfl_xor(ss[e], o, 64); }
+          for (int e = 0; e < EPC; ++e) { s[e] += __shfl_xor(s[e], o, 64); ss[e] += __shfl_xor(ss[e], o, 64); }
         }
+        constexpr int REC = 2 * EPC;                              // record per (wave, column of a pixel): sums | sums of squares
+        const int cw = cpp * EPC;                                 // channels of the workgroup's range (bf16: all C)
         if (lane < cpp) {
-          float* dst = red + (wave * cpp + lane) * 16;
+          float* dst = red + (wave * cpp + lane) * REC;
 #pragma unroll
-          for (int e = 0; e < 8; e += 4) {
+          for (int e = 0; e < EPC; e += 4) {
             *reinterpret_cast<float4*>(dst + e) = make_float4(s[e], s[e + 1], s[e + 2], s[e + 3]);
-            *reinterpret_cast<float4*>(dst + 8 + e) = make_float4(ss[e], ss[e + 1], ss[e + 2], ss[e + 3]);
+            *reinterpret_cast<float4*>(dst + EPC + e) = make_float4(ss[e], ss[e + 1], ss[e + 2], ss[e + 3]);
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        // wave w holds octets (64 w + lane) % cpp: with cpp < 64 every wave holds all of them, with cpp == 64 likewise (octet = lane)
-        for (int ch = col; ch < 2 * p.C; ch += nthr) {
-          const int c = ch < p.C ? ch : ch - p.C;
-          const float* src = red + (c >> 3) * 16 + (ch < p.C ? 0 : 8) + (c & 7);
+        // wave w holds columns (64 w + lane) % cpp: with cpp < 64 every wave holds all of them, with cpp == 64 likewise (column = lane)
+        for (int ch = col; ch < 2 * cw; ch += nthr) {
+          const int c = ch < cw ? ch : ch - cw;
+          const float* src = red + (c / EPC) * REC + (ch < cw ? 0 : EPC) + (c % EPC);
           float a = 0.f;
-          for (int w = 0; w < ncw; ++w) a += src[w * cpp * 16];
-          p.partials[(long)blockIdx.x * 2 * p.C + ch] = a;
+          for (int w = 0; w < ncw; ++w) a += src[w * cpp * REC];
+          p.partials[(long)bidx * 2 * p.C + (ch < cw ? 0 : p.C) + c0 + c] = a;
         }
       } else {
-        if (act) {   // [cols][16]
+        constexpr int REC = 2 * EPC;
+        const int cw = cpp * EPC;
+        if (act) {   // [cols][REC]
 #pragma unroll
-          for (int e = 0; e < 8; e += 4) {
-            *reinterpret_cast<float4*>(red + col * 16 + e) = make_float4(s[e], s[e + 1], s[e + 2], s[e + 3]);
-            *reinterpret_cast<float4*>(red + col * 16 + 8 + e) = make_float4(ss[e], ss[e + 1], ss[e + 2], ss[e + 3]);
+          for (int e = 0; e < EPC; e += 4) {
+            *reinterpret_cast<float4*>(red + col * REC + e) = make_float4(s[e], s[e + 1], s[e + 2], s[e + 3]);
+            *reinterpret_cast<float4*>(red + col * REC + EPC + e) = make_float4(ss[e], ss[e + 1], ss[e + 2], ss[e + 3]);
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const int npx = p.NS * p.W;
-        for (int ch = col; ch < 2 * p.C; ch += nthr) {            // ch < C: sum, else sum of squares; pixel columns in ascending order
-          const int c = ch < p.C ? ch : ch - p.C;
-          const float* src = red + (c >> 3) * 16 + (ch < p.C ? 0 : 8) + (c & 7);
+        for (int ch = col; ch < 2 * cw; ch += nthr) {             // ch < cw: sum, else sum of squares; pixel columns in ascending order
+          const int c = ch < cw ? ch : ch - cw;
+          const float* src = red + (c / EPC) * REC + (ch < cw ? 0 : EPC) + (c % EPC);
           float a = 0.f;
-          for (int q = 0; q < npx; ++q) a += src[(long)q * cpp * 16];
-          p.partials[(long)blockIdx.x * 2 * p.C + ch] = a;
+          for (int q = 0; q < npx; ++q) a += src[(long)q * cpp * REC];
+          p.partials[(long)bidx * 2 * p.C + (ch < cw ? 0 : p.C) + c0 + c] = a;
         }
       }
     }
   }
 }
 
-struct DwsGeom { int NS, nwgb, HB, cols, ncw; bool ok; };
-DwsGeom dws_geom(int B, int H, int W, int C) {
-  DwsGeom g; g.ok = false; g.NS = g.nwgb = g.HB = g.cols = g.ncw = 0;
+struct DwsGeom { int NS, nwgb, HB, cols, ncw, nsplit, cppw; bool ok; };
+// es: bytes per element (2: bf16 maps, one channel range per row; 4: fp32 maps, rows of 18 KiB as two channel ranges of 9 KiB)
+DwsGeom dws_geom(int B, int H, int W, int C, int es = 2) {
+  DwsGeom g; g.ok = false; g.NS = g.nwgb = g.HB = g.cols = g.ncw = g.cppw = 0; g.nsplit = 1;
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8) return g;
-  const long rowbytes = (long)W * C * 2, cols1 = (long)W * C / 8;
+  const int epc = 16 / es;
+  int ns = 1;
+  if (es == 4) {                                   // smallest number of channel ranges (whole groups of 8 channels) that fits the step row
+    ns = 0;
+    for (int n = 1; n <= C / 8; ++n) {
+      if ((C / 8) % n) continue;
+      if ((long)W * C / epc / n <= kDwsMaxWaves * 64) { ns = n; break; }
+    }
+    if (!ns) return g;
+  }
+  const long rowbytes = (long)W * C * es / ns, cols1 = (long)W * C / epc / ns;   // of one channel range
   if (cols1 > kDwsMaxWaves * 64) return g;
   int NS = (int)(kDwsMaxWaves * 64 / cols1);
   while (NS > 1 && H % NS) --NS;
   if (NS * rowbytes <= 8 * 1024 || NS * rowbytes > 9 * 1024) return g;     // the 9-instruction step row only (every block of the CRNN)
+  g.nsplit = ns; g.cppw = C / epc / ns;
   // bands per image over workgroups: enough workgroups for the chip, bands of at least 8 rows
   int nwgb = 1;
 #ifndef CRNN_DWS_WGS
@@ -383,7 +450,7 @@ DwsGeom dws_geom(int B, int H, int W, int C) {
   for (int n = 1; n <= H / NS; ++n) {
     if ((H / NS) % n || H / NS / n < 8) continue;
     nwgb = n;
-    if ((long)B * n >= want) break;
+    if ((long)B * n * ns >= want) break;
   }
   if (H % (NS * nwgb)) return g;
   g.NS = NS; g.nwgb = nwgb; g.HB = H / (NS * nwgb); g.cols = (int)(NS * cols1); g.ncw = (g.cols + 63) / 64; g.ok = true;
@@ -405,16 +472,17 @@ int dws_launch(const DwsParams& p, const DwsGeom& g, int B, hipStream_t stream) 
 }
 // prologue form: one more row in flight (the transform waves need row t + 1 landed when the compute waves take row t)
 constexpr int kDwsProD = kDwsD + 1;
-bool dws_pro_ok(const DwsGeom& g, int B, int H, int W, int C) {
-  const int cpp = C / 8;
-  // the keep bytes of a step row travel as 4-byte DMA pieces: whole dwords per sub-row, at most kDwsKeepNI * 256 of them
-  return g.ok && g.ncw == kDwsMaxWaves && cpp > 0 && kDwsProStride % cpp == 0 && g.cols <= kDwsProChunks * kDwsProStride && (W * cpp) % 4 == 0 && g.cols % 4 == 0 && g.cols <= kDwsKeepNI * 256 && (long)B * H * W * cpp < (1L << 31);
+bool dws_pro_ok(const DwsGeom& g, int B, int H, int W, int C, int es = 2) {
+  const int cpp = g.cppw, kpp = cpp * (16 / es) / 8, kcols = g.cols * (16 / es) / 8;   // keep bytes (one per 8 elements) per pixel of the range, per step row
+  // the keep bytes of a step row travel as 4-byte DMA pieces: whole dwords per pixel range, at most kDwsKeepNI * 256 of them
+  return g.ok && g.ncw == kDwsMaxWaves && cpp > 0 && kDwsProStride % cpp == 0 && g.cols <= kDwsProChunks * kDwsProStride &&
+         (es == 2 ? (W * cpp) % 4 == 0 : kpp % 4 == 0) && kcols % 4 == 0 && kcols <= kDwsKeepNI * 256 && (long)B * H * W * (C / 8) < (1L << 31);
 }
-template <bool DROP>
+template <bool DROP, bool F32 = false>
 int dws_launch_pro(const DwsParams& p, const DwsGeom& g, int B, hipStream_t stream) {
   constexpr int lds = (kDwsProD + 1) * (9 + 1) * 1024 + 64;     // rows + 1 KiB of keep bytes per slot
-  CRNN_LDS_ATTR((dw_fwd_stream_kernel<9, kDwsProD, false, true, DROP>), lds);
-  hipLaunchKernelGGL((dw_fwd_stream_kernel<9, kDwsProD, false, true, DROP>), dim3(B * g.nwgb), dim3((kDwsMaxWaves + 3) * 64), lds, stream, p);
+  CRNN_LDS_ATTR((dw_fwd_stream_kernel<9, kDwsProD, false, true, DROP, F32>), lds);
+  hipLaunchKernelGGL((dw_fwd_stream_kernel<9, kDwsProD, false, true, DROP, F32>), dim3(B * g.nwgb * g.nsplit), dim3((kDwsMaxWaves + 3) * 64), lds, stream, p);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
@@ -442,6 +510,7 @@ extern "C" int crnn_dwconv3x3_fwd_stream_ex(const void* x, const float* k, void*
   DwsParams p;
   p.x = (const unsigned char*)x; p.k = k; p.out = (unsigned char*)out; p.partials = bnstate ? nullptr : stat_partials; p.bnstate = bnstate;
   p.H = H; p.W = W; p.C = C; p.HB = g.HB; p.NS = g.NS; p.nwgb = g.nwgb; p.flip = flip; p.cols = g.cols; p.rowbytes = W * C * 2; p.wmaj = out_order;
+  p.nsplit = 1; p.cppw = C / 8;
   p.pro_bn = nullptr; p.keep = nullptr; p.rate = 0.f;
   return bnstate ? dws_launch<true>(p, g, B, stream) : dws_launch<false>(p, g, B, stream);
 }
@@ -462,8 +531,60 @@ extern "C" int crnn_dwconv3x3_fwd_stream_pro(const void* q, const float* pro_bns
   DwsParams p;
   p.x = (const unsigned char*)q; p.k = k; p.out = (unsigned char*)out; p.partials = stat_partials; p.bnstate = nullptr;
   p.H = H; p.W = W; p.C = C; p.HB = g.HB; p.NS = g.NS; p.nwgb = g.nwgb; p.flip = 0; p.cols = g.cols; p.rowbytes = W * C * 2; p.wmaj = 0;
+  p.nsplit = 1; p.cppw = C / 8;
   p.pro_bn = pro_bnstate; p.keep = (const unsigned char*)keep; p.rate = rate;
   return rate > 0.f ? dws_launch_pro<true>(p, g, B, stream) : dws_launch_pro<false>(p, g, B, stream);
+}
+// The training form on fp32 maps (dtype CRNN_F32; CRNN_BF16 = crnn_dwconv3x3_fwd_stream without bnstate): rows of 18 KiB as two channel ranges of
+// 9 KiB, four channels per lane.  out bit-identical to crnn_dwconv3x3_fwd_ex on fp32 tensors, the statistics one partial row per workgroup band.
+extern "C" int crnn_dwconv_fwd_stream_supported_ex(int B, int H, int W, int C, int dtype) {
+  if (dtype == CRNN_BF16) return crnn_dwconv_fwd_stream_supported(B, H, W, C);
+  if (dtype != CRNN_F32) return CRNN_ERR_ARG;
+  return dws_geom(B, H, W, C, 4).ok ? CRNN_OK : CRNN_ERR_UNSUPPORTED;
+}
+extern "C" int crnn_dwconv3x3_fwd_stream_dt(const void* x, const float* k, void* out, float* stat_partials, int B, int H, int W, int C, int flip, int dtype,
+                                            hipStream_t stream) {
+  if (dtype == CRNN_BF16) return crnn_dwconv3x3_fwd_stream_ex(x, k, out, stat_partials, nullptr, B, H, W, C, flip, 0, stream);
+  if (dtype != CRNN_F32 || !x || !k || !out) return CRNN_ERR_ARG;
+  DwsGeom g = dws_geom(B, H, W, C, 4);
+  if (!g.ok || (((uintptr_t)x | (uintptr_t)out | (uintptr_t)k) & 15)) return CRNN_ERR_UNSUPPORTED;
+  if ((long)H * W * C * 4 >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;
+  DwsParams p;
+  p.x = (const unsigned char*)x; p.k = k; p.out = (unsigned char*)out; p.partials = stat_partials; p.bnstate = nullptr;
+  p.H = H; p.W = W; p.C = C; p.HB = g.HB; p.NS = g.NS; p.nwgb = g.nwgb; p.flip = flip; p.cols = g.cols; p.rowbytes = W * C * 4; p.wmaj = 0;
+  p.nsplit = g.nsplit; p.cppw = g.cppw;
+  p.pro_bn = nullptr; p.keep = nullptr; p.rate = 0.f;
+  constexpr int lds = (kDwsD + 1) * 9 * 1024 + 64;
+  CRNN_LDS_ATTR((dw_fwd_stream_kernel<9, kDwsD, false, false, false, true>), lds);
+  hipLaunchKernelGGL((dw_fwd_stream_kernel<9, kDwsD, false, false, false, true>), dim3(B * g.nwgb * g.nsplit), dim3((g.ncw + 1) * 64), lds, stream, p);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+// The prologue form by storage type (dtype CRNN_BF16 = the entry points above; CRNN_F32, round 4 -- the parity mode): q, out fp32; rows of 18 KiB run as
+// two channel ranges of 9 KiB (one workgroup each), four channels per lane, the keep bytes (still one per 8 elements) as nibbles.  out / stat_partials
+// bit-identical to crnn_bn_act_pool_drop_ex(q -> x) + crnn_dwconv3x3_fwd_ex(x) on fp32 tensors (the statistics to the order of their partial sums).
+extern "C" int crnn_dwconv_fwd_stream_pro_supported_ex(int B, int H, int W, int C, int dtype) {
+  if (dtype == CRNN_BF16) return crnn_dwconv_fwd_stream_pro_supported(B, H, W, C);
+  if (dtype != CRNN_F32) return CRNN_ERR_ARG;
+  return dws_pro_ok(dws_geom(B, H, W, C, 4), B, H, W, C, 4) ? CRNN_OK : CRNN_ERR_UNSUPPORTED;
+}
+extern "C" int crnn_dwconv_fwd_stream_rows_ex(int B, int H, int W, int C, int dtype) {
+  if (dtype == CRNN_BF16) return crnn_dwconv_fwd_stream_rows(B, H, W, C);
+  DwsGeom g = dws_geom(B, H, W, C, 4); return (dtype == CRNN_F32 && g.ok) ? B * g.nwgb : 0;
+}
+extern "C" int crnn_dwconv3x3_fwd_stream_pro_ex(const void* q, const float* pro_bnstate, float rate, const void* keep, const float* k, void* out,
+                                                float* stat_partials, int B, int H, int W, int C, int dtype, hipStream_t stream) {
+  if (dtype == CRNN_BF16) return crnn_dwconv3x3_fwd_stream_pro(q, pro_bnstate, rate, keep, k, out, stat_partials, B, H, W, C, stream);
+  if (dtype != CRNN_F32 || !q || !pro_bnstate || !k || !out || rate < 0.f || rate >= 1.f || (rate > 0.f && !keep)) return CRNN_ERR_ARG;
+  DwsGeom g = dws_geom(B, H, W, C, 4);
+  if (!dws_pro_ok(g, B, H, W, C, 4) || (((uintptr_t)q | (uintptr_t)out | (uintptr_t)k | (uintptr_t)pro_bnstate) & 15) || ((uintptr_t)keep & 3)) return CRNN_ERR_UNSUPPORTED;
+  if ((long)H * W * C * 4 >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;
+  DwsParams p;
+  p.x = (const unsigned char*)q; p.k = k; p.out = (unsigned char*)out; p.partials = stat_partials; p.bnstate = nullptr;
+  p.H = H; p.W = W; p.C = C; p.HB = g.HB; p.NS = g.NS; p.nwgb = g.nwgb; p.flip = 0; p.cols = g.cols; p.rowbytes = W * C * 4; p.wmaj = 0;
+  p.nsplit = g.nsplit; p.cppw = g.cppw;
+  p.pro_bn = pro_bnstate; p.keep = (const unsigned char*)keep; p.rate = rate;
+  return rate > 0.f ? dws_launch_pro<true, true>(p, g, B, stream) : dws_launch_pro<false, true>(p, g, B, stream);
 }
 extern "C" int crnn_dwconv3x3_fwd_stream(const void* x, const float* k, void* out, float* stat_partials, const float* bnstate, int B, int H, int W,
                                          int C, int flip, hipStream_t stream) {

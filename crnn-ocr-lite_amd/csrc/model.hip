@@ -95,6 +95,15 @@ struct Plan {
 
 long lmax(long a, long b) { return a > b ? a : b; }
 
+// The BatchNorm-2 fusions into the depthwise row-stream kernels (fuse_bn2_dw below): opt-in flags for bf16 tensors (the re-forming is VALU work the bf16
+// kernels have no issue slots for: measured neutral), the default schedule for fp32 tensors since round 4 (half the elements per byte: -0.6 ms of 14.8 per
+// step), CRNN_FLAG_NO_BN2_DW_FUSION switches them off.
+bool bn2_dw_fusion_on(const crnn_config* c) {
+  if (c->flags & CRNN_FLAG_NO_BN2_DW_FUSION) return false;
+  return (c->flags & CRNN_FLAG_BN2_DW_FUSION) || c->mfma_bf16 != 2;
+}
+bool bn2_stats_fusion_on(const crnn_config* c) { return bn2_dw_fusion_on(c) && ((c->flags & CRNN_FLAG_BN2_STATS_FUSION) || c->mfma_bf16 != 2); }
+
 // storage of the recurrent weights the recurrences multiply with: bf16 copies in the bf16 modes (u % 128 == 0), else fp32
 int rnn_dtu(const crnn_config* c) { return (c->mfma_bf16 && c->units % 128 == 0) ? CRNN_BF16 : CRNN_F32; }
 // recurrences as persistent one-launch-per-layer kernels (rnn_persist.hip, gru_persist.hip) unless switched off or unsupported
@@ -139,12 +148,14 @@ Plan make_plan(const crnn_config* c) {
     const int sdt_out = (c->mfma_bf16 == 2) ? CRNN_BF16 : CRNN_F32;
     P.add("d" + p, M * ci, sdt_in); P.add("a" + p, M * ci, sdt_in); P.add("q" + p, M * co, sdt_out); P.add("x" + p, Mo * co, sdt_out);
     // dropout keep bytes of the block output (one per 8 elements) for the prologue depthwise kernels of block i+1 (fuse_bn2_dw)
-    if (c->mfma_bf16 == 2 && i < 7 && kBlocks[i - 1].ph * kBlocks[i - 1].pw == 1 && co % 8 == 0) P.add("dm" + p, (M * co / 8 + 3) / 4);
+    if (i < 7 && kBlocks[i - 1].ph * kBlocks[i - 1].pw == 1 && co % 8 == 0 && (c->mfma_bf16 == 2 || bn2_dw_fusion_on(c)))
+      P.add("dm" + p, (M * co / 8 + 3) / 4);
     maxact = lmax(maxact, M * co);
     long tiles = crnn_dwconv_num_tiles(d.B, d.bh[i], d.bw[i]);
     maxparts = lmax(maxparts, tiles * 9L * ci);
     maxparts = lmax(maxparts, (long)crnn_dwconv_bwd_fused_rows(d.B, d.bh[i], d.bw[i], ci) * 9L * ci);
     maxparts = lmax(maxparts, (long)crnn_dwconv_fwd_stream_rows(d.B, d.bh[i], d.bw[i], ci) * 2L * ci);
+    maxparts = lmax(maxparts, (long)crnn_dwconv_fwd_stream_rows_ex(d.B, d.bh[i], d.bw[i], ci, CRNN_F32) * 2L * ci);
     maxparts = lmax(maxparts, (long)crnn_dwconv_bwd_stream_rows(d.B, d.bh[i], d.bw[i], ci) * 9L * ci);
     maxparts = lmax(maxparts, (long)crnn_dwconv_bwd_stream_rows_ex(d.B, d.bh[i], d.bw[i], ci, CRNN_F32) * 9L * ci);
     maxparts = lmax(maxparts, (long)crnn_colreduce_chunks(M) * 2L * lmax(ci, co));
@@ -183,8 +194,9 @@ Plan make_plan(const crnn_config* c) {
   }
   P.add("partials", maxparts);
   { long n = 0;   // BatchNorm-2 backward statistics taken by the next block's depthwise-stage backward (fuse_bn2_dw): they outlive that block's other partials
-    for (int i = 1; i <= 6; ++i) n = lmax(n, (long)crnn_dwconv_bwd_stream_rows(d.B, d.bh[i + 1], d.bw[i + 1], d.bc[i]) * 2L * d.bc[i]);
-    if (c->mfma_bf16 == 2 && n) P.add("bn2parts", n); }
+    for (int i = 1; i <= 6; ++i)
+      n = lmax(n, (long)crnn_dwconv_bwd_stream_rows_ex(d.B, d.bh[i + 1], d.bw[i + 1], d.bc[i], c->mfma_bf16 == 2 ? CRNN_BF16 : CRNN_F32) * 2L * d.bc[i]);
+    if ((c->mfma_bf16 == 2 || bn2_stats_fusion_on(c)) && n) P.add("bn2parts", n); }
   { long pw = 0; for (int i = 2; i <= 7; ++i) pw += (long)d.bc[i - 1] * d.bc[i];
     P.add("pwT", pw, CRNN_BF16); }   // bf16 W^T copies of the pointwise-conv weights (bf16 modes)
   P.add("pbf", make_layout(c).total, CRNN_BF16);   // bf16 shadow of the parameter buffer (GEMM B operands in the bf16 modes)
@@ -274,18 +286,21 @@ bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr, 
 // not materialised -- block i+1's depthwise row-stream kernels apply it to q_i after the rows have landed in LDS (forward:
 // crnn_dwconv3x3_fwd_stream_pro) and re-form it the same way for the depthwise weight gradient (backward: crnn_dwconv3x3_bwd_stream_pro): one write
 // and two read passes of x_i less per step.  ONE decision for both passes (the backward has no x_i to fall back to).
-// Opt-in (CRNN_FLAG_BN2_DW_FUSION; bit-identical to crnn_bn_act_pool_drop_ex + the plain kernels): the re-forming is VALU work on a few waves
-// of kernels that are otherwise bandwidth-bound, and what the step gains in bytes it loses in issue slots -- measured -1.5 % ... +2.5 % step
-// time depending on the box.
+// bf16 tensors: opt-in (CRNN_FLAG_BN2_DW_FUSION; bit-identical to crnn_bn_act_pool_drop_ex + the plain kernels): the re-forming is VALU work on a few
+// waves of kernels that are otherwise bandwidth-bound, and what the step gains in bytes it loses in issue slots -- measured -1.5 % ... +2.5 % step
+// time depending on the box.  fp32 tensors (the parity mode): the default -- half the elements per byte, the same kernels stay
+// bandwidth-bound (bn2_dw_fusion_on above).
 bool fuse_bn2_dw_shape(const crnn_config* cfg, const Dims& d, const Plan& P, int i) {
   if (i < 1 || i > 6) return false;
-  if (!(cfg->flags & CRNN_FLAG_BN2_DW_FUSION) || (cfg->flags & (CRNN_FLAG_DW_TILE_KERNEL | CRNN_FLAG_NO_DW_BWD_FUSION))) return false;
-  if (cfg->mfma_bf16 != 2 || kBlocks[i - 1].ph * kBlocks[i - 1].pw != 1) return false;
+  if (!bn2_dw_fusion_on(cfg) || (cfg->flags & (CRNN_FLAG_DW_TILE_KERNEL | CRNN_FLAG_NO_DW_BWD_FUSION))) return false;
+  if (kBlocks[i - 1].ph * kBlocks[i - 1].pw != 1) return false;
   const std::string p = std::to_string(i), n = std::to_string(i + 1);
-  if (P.dt("q" + p) != CRNN_BF16 || P.dt("x" + p) != CRNN_BF16 || P.dt("d" + n) != CRNN_BF16 || P.off("dm" + p) < 0) return false;
+  const int dt = P.dt("q" + p);                       // bf16 tensors (throughput mode) or fp32 tensors (round 4: the parity mode's forms of the same kernels)
+  if (P.dt("x" + p) != dt || P.dt("d" + n) != dt || P.off("dm" + p) < 0) return false;
+  if (bn2_stats_fusion_on(cfg) && P.off("bn2parts") < 0) return false;
   const int H = d.bh[i + 1], W = d.bw[i + 1], C = d.bc[i];
-  return crnn_dwconv_fwd_stream_pro_supported(d.B, H, W, C) == CRNN_OK && crnn_dwconv_bwd_stream_pro_supported(d.B, H, W, C) == CRNN_OK &&
-         crnn_dwconv_bwd_fused_supported(H, W, C) == CRNN_OK;
+  return crnn_dwconv_fwd_stream_pro_supported_ex(d.B, H, W, C, dt) == CRNN_OK && crnn_dwconv_bwd_stream_pro_supported_ex(d.B, H, W, C, dt) == CRNN_OK &&
+         (dt == CRNN_F32 || crnn_dwconv_bwd_fused_supported(H, W, C) == CRNN_OK);
 }
 bool fuse_bn2_dw(const Ctx& c, int i) {
   if (!fuse_bn2_dw_shape(c.cfg, c.d, c.P, i)) return false;
@@ -396,7 +411,7 @@ extern "C" int crnn_ws_tensor_info(const crnn_config* cfg, const char* name, lon
   return 0;
 }
 // 1 when training does not materialise the output x_block of conv block `block` (1..7): the next block's depthwise row-stream kernels form it
-// from q_block in LDS (CRNN_FLAG_BN2_DW_FUSION; bf16-storage mode, un-pooled blocks, image width 32) -- the workspace tensor "x<block>" is
+// from q_block in LDS (fp32 tensors: the default; bf16 tensors: CRNN_FLAG_BN2_DW_FUSION; un-pooled blocks, image width 32) -- the workspace tensor "x<block>" is
 // then never written by a training forward.  (16-byte aligned parameter / workspace base pointers assumed, as torch allocations are.)
 extern "C" int crnn_block_output_fused(const crnn_config* cfg, int block) {
   if (check_cfg(cfg)) return 0;
@@ -578,12 +593,17 @@ extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, cons
     }
     if (pro_q) {   // the previous block's output was not materialised: its BatchNorm-2 + ReLU6 + dropout run inside this depthwise kernel (fuse_bn2_dw)
       if (keep_pending) { CRNN_TRY(fj.join()); keep_pending = false; }   // the keep bytes are complete
-      CRNN_TRY(crnn_dwconv3x3_fwd_stream_pro(pro_q, pro_s2, cfg->dropout ? kDropBlock : 0.f, keep_bytes(c, i - 1), c.p(bp + "_dw"), dd, parts, B, H, W, ci, stream));
-      CRNN_TRY(crnn_bn_finalize_folded(parts, crnn_dwconv_fwd_stream_rows(B, H, W, ci), ci, M, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), s1, c.w("fold"), stream));
+      CRNN_TRY(crnn_dwconv3x3_fwd_stream_pro_ex(pro_q, pro_s2, cfg->dropout ? kDropBlock : 0.f, keep_bytes(c, i - 1), c.p(bp + "_dw"), dd, parts, B, H, W, ci, dtd, stream));
+      CRNN_TRY(crnn_bn_finalize_folded(parts, crnn_dwconv_fwd_stream_rows_ex(B, H, W, ci, dtd), ci, M, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), s1, c.w("fold"), stream));
       pro_q = nullptr; pro_s2 = nullptr;
     } else if (dws) {
       CRNN_TRY(crnn_dwconv3x3_fwd_stream(in, c.p(bp + "_dw"), dd, parts, nullptr, B, H, W, ci, 0, stream));
       CRNN_TRY(crnn_bn_finalize_folded(parts, crnn_dwconv_fwd_stream_rows(B, H, W, ci), ci, M, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), s1, c.w("fold"), stream));
+    } else if (dtd == CRNN_F32 && i > 1 && !(cfg->flags & CRNN_FLAG_DW_TILE_KERNEL) && crnn_dwconv_fwd_stream_supported_ex(B, H, W, ci, CRNN_F32) == CRNN_OK &&
+               aligned16(in, dd, c.p(bp + "_dw"))) {
+      // fp32 maps (parity mode, round 4): the row-stream kernel's fp32 form -- same outputs as the halo-tile kernel, statistics per workgroup band
+      CRNN_TRY(crnn_dwconv3x3_fwd_stream_dt(in, c.p(bp + "_dw"), dd, parts, B, H, W, ci, 0, CRNN_F32, stream));
+      CRNN_TRY(crnn_bn_finalize_folded(parts, crnn_dwconv_fwd_stream_rows_ex(B, H, W, ci, CRNN_F32), ci, M, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), s1, c.w("fold"), stream));
     } else if (ci % 32 == 0 && ci % slab == 0) {
       CRNN_TRY(crnn_dwconv3x3_fwd_ex(in, c.p(bp + "_dw"), dd, parts, B, H, W, ci, 0, dtd, stream));
       CRNN_TRY(crnn_bn_finalize_folded(parts, crnn_dwconv_num_tiles(B, H, W), ci, M, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), s1, c.w("fold"), stream));
@@ -997,17 +1017,17 @@ int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t au
                                 c.w("coef"), B, H, W, ci, 1, 1, 0.f, 0, 0, dtd, stream));
       CRNN_TRY(fj.wait(gC_free)); gC_free = nullptr;      // gC is written next
       int rc = CRNN_ERR_UNSUPPORTED;
-      if (fused_f32) {                                          // (no fallback: the predicate above is the kernel's own rule)
-        CRNN_TRY(crnn_dwconv3x3_bwd_stream_ex(c.w("d" + p), gA, c.w("bn1s" + p), c.w("coef"), xin, c.p(bp + "_dw"), gC, c.g(bp + "_dw"), c.w("partials"),
-                                              B, H, W, ci, CRNN_F32, stream));
-        rc = CRNN_OK;
-      } else if (fuse_bn2_dw(c, i - 1)) {                           // the forward did not keep x_{i-1}: re-formed from q_{i-1} in LDS (no fallback: same decision)
+      if (fuse_bn2_dw(c, i - 1)) {                           // the forward did not keep x_{i-1}: re-formed from q_{i-1} in LDS (no fallback: same decision)
         const std::string pp = std::to_string(i - 1);
         // (its dropout decisions: the keep bytes the forward of this step left in the workspace -- same seed)
-        float* st2 = (cfg->flags & CRNN_FLAG_BN2_STATS_FUSION) ? c.w("bn2parts") : nullptr;   // opt-in: measured neutral (include/crnn_mi355x.h)
-        CRNN_TRY(crnn_dwconv3x3_bwd_stream_pro(c.w("d" + p), gA, c.w("bn1s" + p), c.w("coef"), c.w("q" + pp), c.w("bn2s" + pp), cfg->dropout ? kDropBlock : 0.f,
-                                               keep_bytes(c, i - 1), c.p(bp + "_dw"), gC, c.g(bp + "_dw"), c.w("partials"), st2, B, H, W, ci, stream));
-        if (st2) bn2_stats_rows = crnn_dwconv_bwd_stream_rows(B, H, W, ci);
+        float* st2 = bn2_stats_fusion_on(cfg) ? c.w("bn2parts") : nullptr;   // (bf16 tensors: opt-in, measured neutral -- include/crnn_mi355x.h)
+        CRNN_TRY(crnn_dwconv3x3_bwd_stream_pro_ex(c.w("d" + p), gA, c.w("bn1s" + p), c.w("coef"), c.w("q" + pp), c.w("bn2s" + pp), cfg->dropout ? kDropBlock : 0.f,
+                                                  keep_bytes(c, i - 1), c.p(bp + "_dw"), gC, c.g(bp + "_dw"), c.w("partials"), st2, B, H, W, ci, dtd, stream));
+        if (st2) bn2_stats_rows = crnn_dwconv_bwd_stream_rows_ex(B, H, W, ci, dtd);
+        rc = CRNN_OK;
+      } else if (fused_f32) {                                   // (no fallback: the predicate above is the kernel's own rule)
+        CRNN_TRY(crnn_dwconv3x3_bwd_stream_ex(c.w("d" + p), gA, c.w("bn1s" + p), c.w("coef"), xin, c.p(bp + "_dw"), gC, c.g(bp + "_dw"), c.w("partials"),
+                                              B, H, W, ci, CRNN_F32, stream));
         rc = CRNN_OK;
       } else if (!(cfg->flags & CRNN_FLAG_DW_TILE_KERNEL))         // rows streamed through LDS where the shape rule holds (dwconv_bwd_stream.hip)
         rc = crnn_dwconv3x3_bwd_stream(c.w("d" + p), gA, c.w("bn1s" + p), c.w("coef"), xin, c.p(bp + "_dw"), gC, c.g(bp + "_dw"), c.w("partials"),

@@ -41,6 +41,10 @@ typedef struct {
                        conv-stack activations / gradients are stored as bf16 in HBM (statistics, RNN, CTC, optimizer fp32) */
   int flags;        /* bit set of CRNN_FLAG_* (0 = the default schedule); A/B switches: bit-identical results except where a flag says otherwise */
 } crnn_config;
+#define CRNN_FLAG_NO_BN2_DW_FUSION 4096 /* fp32-storage training, where the two fusions below are the DEFAULT schedule since round 4 (fp32 forms of the same
+                                         * kernels; half the elements per byte leave them bandwidth-bound: -0.6 ms of 14.8 per step at batch 256): block outputs
+                                         * materialised, BatchNorm-2's backward statistics as a pass of their own.  Forward / data gradients bit-identical,
+                                         * BatchNorm-2 gradients the same sums in another order */
 #define CRNN_FLAG_BN2_STATS_FUSION 2048 /* opt-in (with the fusion below): statistics pass of the block outputs' BatchNorm-2 backward inside the next block's
                                          * depthwise-stage backward (crnn_dwconv3x3_bwd_stream_pro with bn2_stat_partials: a twelfth wave) instead of a kernel of
                                          * its own (crnn_bn_bwd_ex); same data gradients bit for bit, BatchNorm-2 gradients / coefficients the same sums in another
@@ -313,6 +317,21 @@ int crnn_dwconv_bwd_stream_pro_supported(int B, int H, int W, int C);
 int crnn_dwconv3x3_bwd_stream_pro(const void* d, const void* da, const float* bnstate, const float* coef, const void* q, const float* pro_bnstate,
                                   float rate, const void* keep, const float* k, void* dx, float* dk, float* scratch, float* bn2_stat_partials,
                                   int B, int H, int W, int C, crnn_stream_t stream);
+/* Round 4: the row-stream kernels on fp32 maps (the parity mode; dtype CRNN_F32, CRNN_BF16 = the entry points above).  Rows of 18 KiB run as two
+ * channel ranges of 9 KiB (one workgroup each), four channels per lane; the keep bytes (still one per 8 elements) are read as nibbles.
+ * crnn_dwconv3x3_fwd_stream_dt: training form (statistics, no folded BatchNorm); out bit-identical to crnn_dwconv3x3_fwd_ex on fp32 tensors.
+ * The prologue forms: bit-identical to crnn_bn_act_pool_drop_ex(q -> x) + the plain forms on the materialised x, as for bf16. */
+int crnn_dwconv_fwd_stream_supported_ex(int B, int H, int W, int C, int dtype);
+int crnn_dwconv_fwd_stream_rows_ex(int B, int H, int W, int C, int dtype);
+int crnn_dwconv3x3_fwd_stream_dt(const void* x, const float* k, void* out, float* stat_partials, int B, int H, int W, int C, int flip, int dtype,
+                                 crnn_stream_t stream);
+int crnn_dwconv_fwd_stream_pro_supported_ex(int B, int H, int W, int C, int dtype);
+int crnn_dwconv3x3_fwd_stream_pro_ex(const void* q, const float* pro_bnstate, float rate, const void* keep, const float* k, void* out,
+                                     float* stat_partials, int B, int H, int W, int C, int dtype, crnn_stream_t stream);
+int crnn_dwconv_bwd_stream_pro_supported_ex(int B, int H, int W, int C, int dtype);
+int crnn_dwconv3x3_bwd_stream_pro_ex(const void* d, const void* da, const float* bnstate, const float* coef, const void* q, const float* pro_bnstate,
+                                     float rate, const void* keep, const float* k, void* dx, float* dk, float* scratch, float* bn2_stat_partials,
+                                     int B, int H, int W, int C, int dtype, crnn_stream_t stream);
 int crnn_dwconv3x3_fwd(const float* x, const float* k, float* out, float* stat_partials, int B, int H, int W, int C,
                        int flip, crnn_stream_t stream);
 int crnn_dwconv3x3_wgrad(const float* x, const float* g, float* dk, float* scratch, int B, int H, int W, int C,

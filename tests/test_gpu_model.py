@@ -79,7 +79,7 @@ def layer_report(eng, cfg, c, B):
     return rep
 
 
-def device_cache(eng, cfg, p, x, B, c_ref):
+def device_cache(eng, cfg, p, x, B, c_ref, masks=None):
     """Oracle cache rebuilt from the DEVICE's forward state (fp32 -> fp64).
 
     ReLU6 / ReLU / hard-sigmoid gates and max-pool arg-maxima are discontinuous: with ~1e7 activations per
@@ -111,7 +111,15 @@ def device_cache(eng, cfg, p, x, B, c_ref):
         c[f"r{i}"] = np.minimum(np.maximum(y, 0), 6)
         if pool:
             h, w = h // pool[0], w // pool[1]
-        prev = f64(f"x{i}").reshape(B, h, w, cout)
+        if eng.lib.crnn_block_output_fused(eng._c, i):
+            # the block output exists only inside the next block's depthwise kernels (parity mode: the default schedule for the un-pooled blocks):
+            # x = Dropout(ReLU6(BatchNorm-2(q))) as those kernels form it -- r * 1/(1-rate) in fp32, dropped elements 0
+            prev = c[f"r{i}"]
+            if masks is not None:
+                ik = np.float32(1.0) / (np.float32(1.0) - np.float32(M.DROP_BLOCK))
+                prev = (prev.astype(np.float32) * ik).astype(np.float64) * masks[f"b{i}"]
+        else:
+            prev = f64(f"x{i}").reshape(B, h, w, cout)
         cin = cout
     c["conv_out"] = prev
     c["feat"] = prev.reshape(B, cfg.T, cfg.feat)
@@ -216,7 +224,7 @@ def run_case(B, imgh, imgw, u, tds, max_len, stn, dropout, seed=3, num_classes=3
     loss, loss_b, g, c = M.loss_and_grads(cfg, p, bn, x, lab, il, ll, masks=masks, stn=stn)
     rep = layer_report(eng, cfg, c, B)
     # ---- oracle backward on the device's forward state: exact gradient parity
-    cdev = device_cache(eng, cfg, p, x, B, c)
+    cdev = device_cache(eng, cfg, p, x, B, c, masks)
     _, gy = ctc.ctc_loss_and_grad(cdev["y_pred"], lab, il, ll)
     if masks is not None:   # dense1 holds the dropped activation on the device: its mask is already applied
         masks_dev = dict(masks)
@@ -333,6 +341,55 @@ def test_step_does_not_depend_on_workspace_contents(precision, shape):
         assert torch.equal(a, b)
     for a, b in zip(runs[0], runs[2]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dropout", [True, False])
+def test_fp32_row_stream_schedules_equal_the_tile_schedule(dropout):
+    """Parity mode (fp32 tensors), round 4: the depthwise stage runs on the fp32 forms of the row-stream kernels -- forward with the BatchNorm-1
+    statistics per workgroup band, backward as one kernel (BatchNorm-1 backward pass 2 + both depthwise gradients) -- and the un-pooled block
+    outputs are formed inside the next block's depthwise kernels, which also take BatchNorm-2's backward statistics (the default schedule).
+    Against the schedule switches: CRNN_FLAG_NO_BN2_DW_FUSION (block outputs materialised, statistics pass of its own) gives the same forward and
+    data gradients, the BatchNorm-2 backward statistics being the same sums in another order; on top of it CRNN_FLAG_NO_DW_BWD_FUSION (the
+    three-kernel backward) gives the same bits everywhere but the depthwise weight gradients (partial sums grouped differently);
+    CRNN_FLAG_DW_TILE_KERNEL (halo-tile kernels: statistics per tile) agrees to fp32 summation noise."""
+    from crnn_mi355x import native
+    B, imgh, imgw, ncls, max_len, tds, u = 4, 100, 32, 38, 23, 128, 256
+    cfg = M.Config(imgh=imgh, imgw=imgw, max_len=max_len, time_dense_size=tds, n_units=u, num_classes=ncls)
+    p, bn = M.init_params(cfg, seed=6, dtype=np.float64)
+    p = M.randomize_params(cfg, p)
+    x, lab, il, ll = M.synthetic_batch(cfg, B, seed=4, dtype=np.float64)
+    out = {}
+    N = native.FLAG_NO_BN2_DW_FUSION
+    for flags in (0, N, N | native.FLAG_NO_DW_BWD_FUSION, native.FLAG_DW_TILE_KERNEL):
+        eng = Engine(B, imgh, imgw, ncls, max_len, tds, u, stn=True, dropout=dropout, precision="fp32", flags=flags)
+        assert [eng.lib.crnn_block_output_fused(eng._c, i) for i in range(1, 8)] == ([1, 1, 0, 1, 0, 1, 0] if flags == 0 else [0] * 7)
+        eng.set_params(p, bn)
+        eng.ws.fill_(float("nan")); eng.grads.zero_()
+        y = eng.forward(x.astype(np.float32), train=True, seed=5).clone()
+        loss = eng.backward(lab, il, ll, seed=5).clone()
+        out[flags] = (y, loss, eng.grads.clone())
+        lay = eng.layout
+        del eng
+    y0, l0, g0 = out[N]
+    assert torch.isfinite(g0).all()
+    y1, l1, g1 = out[N | native.FLAG_NO_DW_BWD_FUSION]
+    assert torch.equal(y0, y1) and torch.equal(l0, l1)
+    dw = torch.zeros_like(g0, dtype=torch.bool)
+    for name, (off, size, _) in lay.items():
+        if name.endswith("_dw") and name != "b1_dw":
+            dw[off:off + size] = True
+            a, b = g0[off:off + size], g1[off:off + size]
+            assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-7, name
+    assert torch.equal(g0[~dw], g1[~dw]), "three-kernel depthwise-stage backward: a data gradient changed"
+    y3, l3, g3 = out[0]
+    assert torch.equal(y0, y3) and torch.equal(l0, l3) and torch.isfinite(g3).all(), "BatchNorm-2 prologue fusion changed the forward"
+    rel = float((g3.double() - g0.double()).norm() / g0.double().norm())
+    print("fp32 BatchNorm-2 fusion on/off: gradient rel L2 %.3g" % rel)
+    assert rel < 1e-4, rel
+    y4, l4, g4 = out[native.FLAG_DW_TILE_KERNEL]
+    rel4 = float((g4.double() - g0.double()).norm() / g0.double().norm())
+    print("fp32 row-stream vs tile schedule: max |dy| %.3g, gradient rel L2 %.3g" % (float((y0 - y4).abs().max()), rel4))
+    assert float((y0 - y4).abs().max()) < 1e-4 and rel4 < 5e-2      # (gate decisions next to a threshold may differ: the bf16 test's bound)
 
 
 @pytest.mark.parametrize("shape", [(5, 60, 48, 20, 10, 64, 128), (4, 100, 32, 38, 23, 128, 256)])

@@ -988,6 +988,81 @@ def test_row_stream_depthwise_with_the_batchnorm2_prologue_equals_the_two_pass_p
     assert torch.equal(gq2, gq)
 
 
+@pytest.mark.parametrize("B,H,W,C", [(3, 104, 36, 64), (2, 104, 36, 128), (5, 52, 18, 256), (2, 52, 9, 512), (256, 52, 9, 512), (70, 104, 36, 64)])
+@pytest.mark.parametrize("rate", [0.1, 0.0])
+def test_fp32_row_stream_depthwise_kernels_and_their_batchnorm2_prologue_forms(B, H, W, C, rate):
+    """The fp32 forms of the row-stream kernels (round 4, the parity mode): crnn_dwconv3x3_fwd_stream_dt against the halo-tile kernel (outputs
+    bit for bit, statistics to summation order); crnn_dwconv3x3_fwd_stream_pro_ex / crnn_dwconv3x3_bwd_stream_pro_ex (BatchNorm-2 + ReLU6 +
+    Dropout(.1) of the previous block applied to q in LDS; keep bytes read as nibbles) against crnn_bn_act_pool_drop_ex + the plain fp32 forms on
+    the materialised x: outputs, statistic partials, data and weight gradients bit for bit; the BatchNorm-2 backward statistics taken by the same
+    launch against crnn_bn_bwd_ex to summation order.  Memory around the outputs untouched."""
+    F32 = 0
+    assert L().crnn_dwconv_fwd_stream_supported_ex(B, H, W, C, F32) == 0
+    assert L().crnn_dwconv_fwd_stream_pro_supported_ex(B, H, W, C, F32) == 0 and L().crnn_dwconv_bwd_stream_pro_supported_ex(B, H, W, C, F32) == 0
+    rs = np.random.RandomState(B + H + W + C + 1)
+    n = B * H * W * C
+    qd = torch.randn(n, device="cuda", generator=torch.Generator("cuda").manual_seed(n % 1000 + 1)) * 1.5
+    k = rs.normal(size=(3, 3, C)); kd = dev(k)
+    st2 = dev(np.concatenate([rs.normal(size=C), 1 + rs.uniform(size=C), 1 + 0.5 * rs.normal(size=C), 1.5 * rs.normal(size=C) + 1.5]))
+    seed, layer = 78, 2
+    ng = n // 8
+    keep = torch.full((ng + 3 + 64,), 0x55, dtype=torch.uint8, device="cuda")
+    ok(L().crnn_dropout_keep_bytes(P(keep), ng, rate, seed, layer, S()))
+    xd = zeros(n)
+    ok(L().crnn_bn_act_pool_drop_ex(P(qd), P(st2), P(xd), B, H, W, C, 1, 1, rate, seed, layer, F32, F32, S()))
+    assert float((xd == 0).float().mean()) > (0.08 if rate > 0 else 0.0) and float((xd > 6.0).float().mean()) > (1e-3 if rate > 0 else -1)
+    # ---- forward: tile kernel, plain stream form, prologue form
+    ntiles = L().crnn_dwconv_num_tiles(B, H, W)
+    o0 = zeros(n); p0 = zeros(ntiles, 2, C)
+    ok(L().crnn_dwconv3x3_fwd_ex(P(xd), P(kd), P(o0), P(p0), B, H, W, C, 0, F32, S()))
+    rows = L().crnn_dwconv_fwd_stream_rows_ex(B, H, W, C, F32)
+    assert rows >= B
+    o1 = torch.full((n + 64,), 7.0, device="cuda"); p1 = torch.full((rows + 1, 2, C), 3.0, device="cuda")
+    ok(L().crnn_dwconv3x3_fwd_stream_dt(P(xd), P(kd), P(o1), P(p1), B, H, W, C, 0, F32, S()))
+    assert torch.equal(o1[:-64].view(torch.int32), o0.view(torch.int32)), "stream vs tile: max diff %g" % float((o1[:-64] - o0).abs().max())
+    assert bool((o1[-64:] == 7.0).all()) and bool((p1[rows] == 3.0).all())
+    t0, t1 = host(p0).sum(0), host(p1[:rows]).sum(0)
+    assert_close(t1, t0, rtol=1e-4, atol=1e-4 * np.abs(t0).max(), what="statistics stream vs tile")
+    o2 = torch.full((n + 64,), 7.0, device="cuda"); p2 = torch.full((rows + 1, 2, C), 3.0, device="cuda")
+    ok(L().crnn_dwconv3x3_fwd_stream_pro_ex(P(qd), P(st2), rate, P(keep), P(kd), P(o2), P(p2), B, H, W, C, F32, S()))
+    assert torch.equal(o2[:-64].view(torch.int32), o0.view(torch.int32)), "d: max diff %g" % float((o2[:-64] - o0).abs().max())
+    assert torch.equal(p2[:rows], p1[:rows]) and bool((o2[-64:] == 7.0).all()) and bool((p2[rows] == 3.0).all())
+    o3 = zeros(n); p3 = zeros(rows, 2, C)
+    ok(L().crnn_dwconv3x3_fwd_stream_pro_ex(P(qd), P(st2), rate, P(keep), P(kd), P(o3), P(p3), B, H, W, C, F32, S()))
+    assert torch.equal(o3, o2[:-64]) and torch.equal(p3, p1[:rows]), "repeat launches differ"
+    if rate > 0:
+        assert L().crnn_dwconv3x3_fwd_stream_pro_ex(P(qd), P(st2), rate, None, P(kd), P(o3), P(p3), B, H, W, C, F32, S()) == -2
+    # ---- backward of the consuming depthwise stage
+    dd = o0
+    dad = torch.randn(n, device="cuda", generator=torch.Generator("cuda").manual_seed(6)) * 0.7
+    M = B * H * W
+    dh = dd.view(M, C).double()
+    mean, var = dh.mean(0).cpu().numpy(), dh.var(0, unbiased=False).cpu().numpy()
+    gamma, beta = rs.normal(size=C) * 0.3 + 1.0, rs.normal(size=C) * 0.5 + 1.0
+    scale = gamma / np.sqrt(var + 1e-3)
+    st1 = dev(np.concatenate([mean, var, scale, beta - mean * scale]))
+    coef = dev(np.concatenate([rs.normal(size=C) * 1e-3, rs.normal(size=C) * 1e-3]))
+    brow = L().crnn_dwconv_bwd_stream_rows_ex(B, H, W, C, F32)
+    dx1 = zeros(n); dk1 = zeros(9, C); sc = zeros(brow * 9 * C)
+    ok(L().crnn_dwconv3x3_bwd_stream_ex(P(dd), P(dad), P(st1), P(coef), P(xd), P(kd), P(dx1), P(dk1), P(sc), B, H, W, C, F32, S()))
+    dx2 = torch.full((n + 64,), 9.0, device="cuda"); dk2 = zeros(9, C); sc2 = torch.full((brow * 9 * C + 16,), 5.0, device="cuda")
+    ok(L().crnn_dwconv3x3_bwd_stream_pro_ex(P(dd), P(dad), P(st1), P(coef), P(qd), P(st2), rate, P(keep), P(kd), P(dx2), P(dk2), P(sc2), None, B, H, W, C, F32, S()))
+    assert torch.equal(dx2[:-64].view(torch.int32), dx1.view(torch.int32)), "dx: max diff %g" % float((dx2[:-64] - dx1).abs().max())
+    assert torch.equal(dk2, dk1), "dk: max diff %g" % float((dk2 - dk1).abs().max())
+    assert bool((dx2[-64:] == 9.0).all()) and bool((sc2[-16:] == 5.0).all()) and float(dk1.abs().max()) > 0
+    dx3 = zeros(n); dk3 = zeros(9, C)
+    parts2 = torch.full((brow + 1, 2, C), 3.0, device="cuda")
+    ok(L().crnn_dwconv3x3_bwd_stream_pro_ex(P(dd), P(dad), P(st1), P(coef), P(qd), P(st2), rate, P(keep), P(kd), P(dx3), P(dk3), P(sc2), P(parts2), B, H, W, C, F32, S()))
+    assert torch.equal(dx3, dx1) and torch.equal(dk3, dk1) and bool((parts2[brow] == 3.0).all())
+    dg2, db2, coef2 = zeros(C), zeros(C), zeros(2 * C)
+    ok(L().crnn_bn_bwd_finalize(P(parts2), brow, C, M, P(dg2), P(db2), P(coef2), S()))
+    gq = zeros(n); dg1, db1, coef1 = zeros(C), zeros(C), zeros(2 * C)
+    pp = zeros(max(L().crnn_bn_bwd_chunks(M), 1) * 2 * C + 64); gam = dev(np.ones(C))
+    ok(L().crnn_bn_bwd_ex(P(qd), P(dx1), P(st2), P(gam), P(gq), P(dg1), P(db1), P(pp), P(coef1), B, H, W, C, 1, 1, rate, seed, layer, F32, S()))
+    for a, b, what in ((db2, db1, "sum gy"), (dg2, dg1, "sum gy xhat"), (coef2, coef1, "coefficients")):
+        assert_close(host(a), host(b), rtol=2e-4, atol=2e-5 * max(1.0, float(b.abs().max())), what="BatchNorm-2 backward " + what)
+
+
 def test_dropout_rng_statistics():
     """The counter-based dropout RNG (csrc/common.h: three ChaCha quarter-rounds per group of 8 elements): the kept fraction matches the
     rate, masks of different seeds / dropout sites are independent, neighbouring elements and channel strides are uncorrelated."""
