@@ -863,7 +863,11 @@ def main():
                                           note="fp32 tensors + fp32-accurate GEMMs (three bf16 planes per operand, six bf16 MFMAs per k-step; CRNN_FLAGS=256 = fp32 MFMA, 20.6 ms): "
                                                "the mode the 1e-3 logit / CTC-loss parity and bit-exact arg-max are asserted in; "
                                                "the headline bf16 line is outside that tolerance (bf16 conv-stack tensors: softmax within 2e-3, loss 2e-3 "
-                                               "relative of the fp64 oracle)")
+                                               "relative of the fp64 oracle).  Round 4: the depthwise stage on the fp32 forms of the row-stream kernels "
+                                               "(block outputs and BatchNorm-2 backward statistics formed inside them)")
+                # the same step on the round-3 schedule (halo-tile depthwise kernels, three-kernel depthwise-stage backward, every BatchNorm-2 pass on its own):
+                # CRNN_FLAG_DW_TILE_KERNEL; same forward to summation order
+                res["parity_mode"]["tile_schedule"] = dict(leg(B, max(3, min(args.steps, 10)), 2, precision="fp32", flags=32), flags=32)
             if B != 64:
                 # the metric's literal batch size (BASELINE.json: "100x32 bs64"), same precision as the headline
                 res["bs64"] = leg(64, max(5, args.steps), 3, reps=3)
