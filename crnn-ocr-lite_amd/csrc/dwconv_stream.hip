@@ -42,6 +42,9 @@ struct DwsParams {
   const unsigned char* x; const float* k; unsigned char* out; float* partials; const float* bnstate;
   int H, W, C, HB, NS, nwgb, flip, cols, rowbytes, wmaj;
   int nsplit, cppw;          // channel ranges per row (fp32 form: 2 for rows of 18 KiB), 16-byte columns per pixel of one range
+#ifdef CRNN_DWS_TRACE
+  unsigned long long* trace = nullptr; // timing build only: [workgroup][4] s_memrealtime stamps (entry, first row landed, last step done, statistics written)
+#endif
   // prologue form: BatchNorm state [mean|var|scale|shift] of the producer, dropout of its output
   const float* pro_bn; const unsigned char* keep; float rate;
 };
@@ -187,6 +190,13 @@ __global__ __launch_bounds__((kDwsMaxWaves + (PRO ? 3 : 1)) * 64) void dw_fwd_st
   const int steps = p.HB + 2;                      // input rows r0-1 .. r0+HB of every sub-band
   const int zoff = NR * SLOT;                      // 16 zero bytes (the pixels left of x = 0 and right of x = W-1)
   if (tid < 4) reinterpret_cast<unsigned*>(lds + zoff)[tid] = 0u;
+#ifdef CRNN_DWS_TRACE
+  unsigned long long* const trc = (p.trace && tid == 0) ? p.trace + (long)blockIdx.x * 4 : nullptr;
+  if (trc) trc[0] = __builtin_amdgcn_s_memrealtime();
+#define DWS_TRC(i) do { if (trc) trc[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define DWS_TRC(i) do {} while (0)
+#endif
 
   if (PRO && role == 1) {
     // ------------------------------------------------------------------ transform waves (prologue form): half of every row each
@@ -351,6 +361,7 @@ __global__ __launch_bounds__((kDwsMaxWaves + (PRO ? 3 : 1)) * 64) void dw_fwd_st
       }
     };
     step(0, X1, X2, X0, true);
+    DWS_TRC(1);
     step(1, X2, X0, X1, false);
     int t = 2;
     for (; t + 3 <= steps - 1; t += 3) {          // whole groups of three that do not contain the last step
@@ -363,6 +374,7 @@ __global__ __launch_bounds__((kDwsMaxWaves + (PRO ? 3 : 1)) * 64) void dw_fwd_st
       else if (r == 1) step(t, X1, X2, X0, true);
       else step(t, X2, X0, X1, true);
     }
+    DWS_TRC(2);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (!EPI && p.partials) {
@@ -417,6 +429,7 @@ __global__ __launch_bounds__((kDwsMaxWaves + (PRO ? 3 : 1)) * 64) void dw_fwd_st
         }
       }
     }
+    DWS_TRC(3);
   }
 }
 
@@ -512,6 +525,9 @@ extern "C" int crnn_dwconv3x3_fwd_stream_ex(const void* x, const float* k, void*
   p.H = H; p.W = W; p.C = C; p.HB = g.HB; p.NS = g.NS; p.nwgb = g.nwgb; p.flip = flip; p.cols = g.cols; p.rowbytes = W * C * 2; p.wmaj = out_order;
   p.nsplit = 1; p.cppw = C / 8;
   p.pro_bn = nullptr; p.keep = nullptr; p.rate = 0.f;
+#ifdef CRNN_DWS_TRACE
+  { const char* e = getenv("CRNN_DWS_TRACE_PTR"); p.trace = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
+#endif
   return bnstate ? dws_launch<true>(p, g, B, stream) : dws_launch<false>(p, g, B, stream);
 }
 // Prologue form (training): `q` is the previous block's pointwise output, pro_bnstate its BatchNorm-2 state [mean|var|scale|shift]; the

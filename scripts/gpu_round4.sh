@@ -14,6 +14,8 @@ timeout 1200 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_bf16s.jso
 echo "bench exit $?" >> $OUT/${TAG}_summary.txt
 B="timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-parity"
 $B --precision fp32 > $OUT/${TAG}_bench_fp32.json 2>> $OUT/${TAG}_bench.err
+CRNN_FLAGS=4096 $B --precision fp32 --no-roofline > $OUT/${TAG}_bench_fp32_no_bn2_fusion.json 2>> $OUT/${TAG}_bench.err
+CRNN_FLAGS=32 $B --precision fp32 --no-roofline > $OUT/${TAG}_bench_fp32_tile_schedule.json 2>> $OUT/${TAG}_bench.err
 $B --precision bf16 > $OUT/${TAG}_bench_bf16.json 2>> $OUT/${TAG}_bench.err
 $B --imgh 200 --max-len 21 > $OUT/${TAG}_bench_iam.json 2>> $OUT/${TAG}_bench.err
 $B --gru > $OUT/${TAG}_bench_gru.json 2>> $OUT/${TAG}_bench.err
@@ -24,6 +26,7 @@ CRNN_FLAGS=128 $B --no-roofline > $OUT/${TAG}_bench_no_bn_stats_fusion.json 2>> 
 $B --no-roofline > $OUT/${TAG}_bench_bf16s_again.json 2>> $OUT/${TAG}_bench.err
 timeout 300 python scripts/predict_bench.py > $OUT/${TAG}_predict.json 2> $OUT/${TAG}_predict.err
 timeout 200 python scripts/dws_pro_bench.py 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_dw_prologue_bench.txt
+timeout 200 python scripts/dws_f32_bench.py 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_dw_f32_bench.txt
 timeout 100 python scripts/dws_bench.py 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_dw_fwd_stream_bench.txt
 timeout 100 python scripts/dbs_bench.py 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_dw_bwd_stream_bench.txt
 timeout 200 python scripts/wres_fwd_ablate.py 0 1 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_wres_fwd_depth.txt
@@ -41,6 +44,7 @@ prof bf16s
 CRNN_FLAGS=1024 prof bn2_dw_fusion --no-roofline
 CRNN_FLAGS=3072 prof bn2_dw_stats_fusion --no-roofline
 prof fp32 --precision fp32 --no-roofline
+CRNN_FLAGS=32 prof fp32_tile_schedule --precision fp32 --no-roofline
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $OUT/${TAG}_pmc_bf16_$c
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_bf16_$c -o dw -- python $ROOT/scripts/dw_bench.py --bf16 > $OUT/${TAG}_pmc_bf16_$c.log 2>&1
@@ -49,7 +53,7 @@ done
 cd $ROOT
 find $OUT -name "*kernel_trace.csv" -size +30M -delete
 grep -E "passed|failed|error" $OUT/${TAG}_pytest_gpu.log | tail -3
-for f in bench_bf16s bench_fp32 bench_bf16 bench_iam bench_gru bench_bn2_dw_fusion bench_bn2_dw_stats_fusion bench_step_kernels bench_no_bn_stats_fusion bench_bf16s_again predict; do echo -n "$f: "; cut -c1-170 $OUT/${TAG}_$f.json; echo; done
+for f in bench_bf16s bench_fp32 bench_fp32_no_bn2_fusion bench_fp32_tile_schedule bench_bf16 bench_iam bench_gru bench_bn2_dw_fusion bench_bn2_dw_stats_fusion bench_step_kernels bench_no_bn_stats_fusion bench_bf16s_again predict; do echo -n "$f: "; cut -c1-170 $OUT/${TAG}_$f.json; echo; done
 grep -v amdgpu $OUT/${TAG}_bench.err | tail -5
 grep "step span" $OUT/${TAG}_step_timeline_*.txt
 cat $OUT/${TAG}_summary.txt
