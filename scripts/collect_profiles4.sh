@@ -9,4 +9,6 @@ cp $G/${T}_kernel_stats_bf16s.csv $P/r04_bench_bf16s_kernel_stats.csv
 cp $G/${T}_kernel_stats_bn2_dw_fusion.csv $P/r04_bench_bn2_dw_fusion_kernel_stats.csv
 tail -15 $G/${T}_pytest_gpu.log > $P/r04_pytest_gpu.txt
 python scripts/pmc_summary.py $T r04
+python scripts/pmc_f32_summary.py $T r04
+cp $G/${T}_kernel_stats_fp32.csv $P/r04_bench_fp32_kernel_stats.csv
 ls $P | grep "^r04_" | wc -l

@@ -50,6 +50,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_bf16_$c -o dw -- python $ROOT/scripts/dw_bench.py --bf16 > $OUT/${TAG}_pmc_bf16_$c.log 2>&1
   echo "pmc bf16 $c exit $?" >> $OUT/${TAG}_summary.txt
 done
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $OUT/${TAG}_pmc_f32_$c
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_f32_$c -o dw -- python $ROOT/scripts/dw_f32_pmc.py > $OUT/${TAG}_pmc_f32_$c.log 2>&1
+  echo "pmc f32 $c exit $?" >> $OUT/${TAG}_summary.txt
+done
 cd $ROOT
 find $OUT -name "*kernel_trace.csv" -size +30M -delete
 grep -E "passed|failed|error" $OUT/${TAG}_pytest_gpu.log | tail -3
