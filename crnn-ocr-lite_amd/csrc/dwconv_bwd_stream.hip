@@ -320,7 +320,9 @@ __global__ __launch_bounds__((STATS && !F32) ? 768 : 704, (F32 && CRNN_DBS_F32_W
     float X0[EPC], X1[EPC], X2[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) X0[e] = X1[e] = X2[e] = 0.f;
-    unsigned char* orow = p.dx + imgoff + (long)r0 * p.rowbytes + (px * p.C + ch0) * ES;
+    // (spelled as two products: with the factored form the register allocator of the bf16 instantiation spills a 16-byte value inside the DK waves'
+    // row loop -- the kernel ran 22 % slower; check with scripts/check_loop_spills.sh after touching this file)
+    unsigned char* orow = p.dx + imgoff + (long)r0 * p.rowbytes + px * p.C * ES + ch0 * ES;
     // prologue form: re-form x = Dropout(ReLU6(q * scale + shift)) of the stage that arrived one step ahead (own column) into the two-row
     // buffer the DK waves read; bn_act_pool_drop_kernel's arithmetic bit for bit.  (The 16 BatchNorm-2 constants of the lane's channels
     // sit in LDS and are read per step: kw and the running rows fill the registers.)
