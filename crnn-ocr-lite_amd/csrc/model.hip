@@ -98,6 +98,10 @@ long lmax(long a, long b) { return a > b ? a : b; }
 // The BatchNorm-2 fusions into the depthwise row-stream kernels (fuse_bn2_dw below): opt-in flags for bf16 tensors (the re-forming is VALU work the bf16
 // kernels have no issue slots for: measured neutral), the default schedule for fp32 tensors since round 4 (half the elements per byte: -0.6 ms of 14.8 per
 // step), CRNN_FLAG_NO_BN2_DW_FUSION switches them off.
+// spatial transformer: the localisation net as one workgroup per sample (crnn_loc_net_fwd / crnn_loc_net_bwd, stn.hip) where a sample's maps fit
+bool loc_net_fused(const crnn_config* c, const Dims& d) {
+  return !(c->flags & CRNN_FLAG_LOC_NET_KERNELS) && crnn_loc_net_fused_supported(d.H0, d.W0) == CRNN_OK;
+}
 bool bn2_dw_fusion_on(const crnn_config* c) {
   if (c->flags & CRNN_FLAG_NO_BN2_DW_FUSION) return false;
   return (c->flags & CRNN_FLAG_BN2_DW_FUSION) || c->mfma_bf16 != 2;
@@ -185,6 +189,7 @@ Plan make_plan(const crnn_config* c) {
   // gradient ping-pong buffers: sized for fp32, hold bf16 tensors in storage mode 2
   P.add("gA", maxact); P.add("gB", maxact); P.add("gC", maxact);   // conv-stack gradient buffers (three: a weight-gradient GEMM on the side stream may still read one)
   P.add("dtheta", B * 6); P.add("dfc1", B * 50); P.add("dflat", B * d.stn_flat);
+  if (c->stn && loc_net_fused(c, d)) P.add("locterms", crnn_loc_net_bwd_scratch((int)B));   // the samples' convolution weight-gradient terms (crnn_loc_net_bwd)
   P.add("dpool2", B * d.Hs2 * d.Ws2 * 20); P.add("dc1", B * d.Ho1 * d.Wo1 * 20);
   maxparts = lmax(maxparts, (long)crnn_colreduce_chunks(TB) * lmax(d.G, lmax(d.tds, d.C)));
   maxparts = lmax(maxparts, (long)crnn_colreduce_chunks(B * d.Ho1 * d.Wo1) * 64);
@@ -494,7 +499,12 @@ extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, cons
   }
   if (cfg->mfma_bf16) CRNN_TRY(crnn_convert_f32_to_bf16(params, c.ws + c.P.off("pbf"), c.L.total, stream));
   // ---- spatial transformer (utils.py:247-258) + ZeroPadding2D (utils.py:63)
-  if (cfg->stn) {
+  if (cfg->stn && loc_net_fused(cfg, d) && aligned16(c.p("stn_c1_k"), c.p("stn_c2_k"), c.p("stn_c1_b"), c.p("stn_c2_b")) &&
+      aligned16(c.w("c1"), c.w("pool2"), c.w("flat"))) {
+    CRNN_TRY(crnn_loc_net_fwd(x, c.p("stn_c1_k"), c.p("stn_c1_b"), c.p("stn_c2_k"), c.p("stn_c2_b"), c.p("stn_d1_w"), c.p("stn_d1_b"), c.p("stn_d2_w"),
+                              c.p("stn_d2_b"), c.w("pool1"), c.w("c1"), c.w("pool2"), c.w("flat"), c.w("fc1"), c.w("theta"), B, d.H0, d.W0, stream));
+    CRNN_TRY(crnn_sampler_fwd(x, c.w("theta"), c.w("x0"), B, d.H0, d.W0, 2, stream));
+  } else if (cfg->stn) {
     CRNN_TRY(crnn_maxpool_fwd(x, c.w("pool1"), B, d.H0, d.W0, 1, 2, 2, stream));
     CRNN_TRY(crnn_loc_conv_fwd(c.w("pool1"), c.p("stn_c1_k"), c.p("stn_c1_b"), c.w("c1"), B, d.Hs1, d.Ws1, 1, stream));
     CRNN_TRY(crnn_maxpool_fwd(c.w("c1"), c.w("pool2"), B, d.Ho1, d.Wo1, 20, 2, 2, stream));
@@ -1055,6 +1065,10 @@ int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t au
   // ---- spatial transformer
   if (cfg->stn) {
     CRNN_TRY(crnn_sampler_bwd(x, c.w("theta"), gA, c.w("dtheta"), B, d.H0, d.W0, 2, stream));
+    if (loc_net_fused(cfg, d) && c.P.off("locterms") >= 0 && aligned16(c.p("stn_c2_k"), c.w("pool2"), c.w("locterms"), c.p("stn_d1_w")) && aligned16(c.w("dfc1"), c.w("fc1"), c.w("dtheta")))
+      return crnn_loc_net_bwd(c.w("dtheta"), c.w("flat"), c.w("fc1"), c.w("pool1"), c.w("c1"), c.w("pool2"), c.p("stn_d1_w"), c.p("stn_d2_w"), c.p("stn_c2_k"),
+                              c.w("dfc1"), c.w("locterms"), c.g("stn_c1_k"), c.g("stn_c1_b"), c.g("stn_c2_k"), c.g("stn_c2_b"), c.g("stn_d1_w"), c.g("stn_d1_b"),
+                              c.g("stn_d2_w"), c.g("stn_d2_b"), B, d.H0, d.W0, stream);
     CRNN_TRY(crnn_loc_fc_bwd(c.w("flat"), c.w("fc1"), c.w("dtheta"), c.p("stn_d1_w"), c.p("stn_d2_w"), c.w("dfc1"), c.w("dflat"),
                              c.g("stn_d1_w"), c.g("stn_d1_b"), c.g("stn_d2_w"), c.g("stn_d2_b"), B, d.stn_flat, stream));
     CRNN_TRY(crnn_loc_conv_wgrad(c.w("pool2"), c.w("dflat"), c.g("stn_c2_k"), c.g("stn_c2_b"), c.w("partials"), B, d.Hs2, d.Ws2, 20, stream));

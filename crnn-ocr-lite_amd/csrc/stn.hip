@@ -515,3 +515,425 @@ extern "C" int crnn_loc_fc_bwd(const float* flat, const float* fc1, const float*
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
+
+// =====================================================================================================
+// The localisation net of one sample in ONE workgroup (round 4; utils.py:248-256): MaxPool -> Conv2D(20, 5x5) -> MaxPool -> Conv2D(20, 5x5)
+// -> Flatten -> Dense(50, relu) -> Dense(6), everything a sample needs (3 KB of pooled image, 11 KB of pooled features, the 40 KB of the second
+// convolution's kernel) in LDS.  The five launches it replaces are 5..15 us each of mostly dispatch and drain for 0.7 MFLOP per sample; the
+// arithmetic (fmaf chains, fmaxf scans, the dense layers' interleaved partial sums) is theirs, statement for statement: bit-identical outputs,
+// and the saved intermediates (pool1, c1, pool2, flat, fc1) are still written for the backward pass.
+// =====================================================================================================
+#define LOC_NT 512          // threads of the per-sample kernels: two waves per SIMD -- one workgroup per CU has nothing else to hide LDS latency behind
+struct LocDims { int H0, W0, Hs1, Ws1, Ho1, Wo1, Hs2, Ws2, Ho2, Wo2, F; };
+static LocDims loc_dims(int H0, int W0) {
+  LocDims d; d.H0 = H0; d.W0 = W0; d.Hs1 = H0 / 2; d.Ws1 = W0 / 2; d.Ho1 = d.Hs1 - 4; d.Wo1 = d.Ws1 - 4;
+  d.Hs2 = d.Ho1 / 2; d.Ws2 = d.Wo1 / 2; d.Ho2 = d.Hs2 - 4; d.Wo2 = d.Ws2 - 4; d.F = d.Ho2 * d.Wo2 * LOC_CO;
+  return d;
+}
+static size_t loc_fwd_lds(const LocDims& d) {
+  return sizeof(float) * ((size_t)d.Hs1 * d.Ws1 + (size_t)d.Hs2 * d.Ws2 * LOC_CO + LOC_K * LOC_K * LOC_CO * LOC_CO + LOC_K * LOC_K * LOC_CO + d.F +
+                          LOC_KP * LOC_H1 + LOC_H1 + 16);
+}
+static size_t loc_bwd_lds(const LocDims& d);
+__global__ __launch_bounds__(LOC_NT) void loc_net_fwd_kernel(const float* __restrict__ x, const float* __restrict__ k1, const float* __restrict__ bc1,
+                                                          const float* __restrict__ k2, const float* __restrict__ bc2, const float* __restrict__ w1,
+                                                          const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                          float* __restrict__ pool1, float* __restrict__ c1, float* __restrict__ pool2,
+                                                          float* __restrict__ flat, float* __restrict__ fc1, float* __restrict__ theta, LocDims d) {
+  extern __shared__ __attribute__((aligned(16))) float lsm[];
+  constexpr int NK2 = LOC_K * LOC_K * LOC_CO * LOC_CO, NK1 = LOC_K * LOC_K * LOC_CO;
+  float* const k2s = lsm;                                        // [5][5][20][20]
+  float* const k1s = k2s + NK2;                                  // [5][5][1][20]
+  float* const p2 = k1s + NK1;                                   // [Hs2][Ws2][20]
+  float* const fl = p2 + d.Hs2 * d.Ws2 * LOC_CO;                 // [F]
+  float* const ps = fl + d.F;                                    // [LOC_KP][LOC_H1]
+  float* const hs = ps + LOC_KP * LOC_H1;                        // [LOC_H1]
+  float* const p1 = hs + LOC_H1 + 2;                             // [Hs1][Ws1]   (+2: keeps p1 off the float4-aligned part; scalar reads only)
+  const int img = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < NK2 / 4; i += LOC_NT) reinterpret_cast<float4*>(k2s)[i] = reinterpret_cast<const float4*>(k2)[i];
+  for (int i = tid; i < NK1 / 4; i += LOC_NT) reinterpret_cast<float4*>(k1s)[i] = reinterpret_cast<const float4*>(k1)[i];
+  // ---- MaxPool2D(2,2) of the image (maxpool_fwd_kernel's scan)
+  const float* xi = x + (long)img * d.H0 * d.W0;
+  for (int i = tid; i < d.Hs1 * d.Ws1; i += LOC_NT) {
+    const int w = i % d.Ws1, h = i / d.Ws1;
+    float m = -INFINITY;
+    for (int ii = 0; ii < 2; ++ii)
+      for (int j = 0; j < 2; ++j) m = fmaxf(m, xi[(2 * h + ii) * d.W0 + 2 * w + j]);
+    p1[i] = m;
+    pool1[(long)img * d.Hs1 * d.Ws1 + i] = m;
+  }
+  __syncthreads();
+  // ---- Conv2D(20, 5x5, valid) on the pooled image + MaxPool2D(2,2): a thread owns one pooling window and 4 filters (loc_conv_fwd_kernel<1>'s chain)
+  for (int t = tid; t < d.Hs2 * d.Ws2 * (LOC_CO / 4); t += LOC_NT) {
+    const int g = t % (LOC_CO / 4), pix = t / (LOC_CO / 4);
+    const int pw = pix % d.Ws2, ph = pix / d.Ws2;
+    const float4 bias = *reinterpret_cast<const float4*>(bc1 + 4 * g);
+    float4 acc[4] = {bias, bias, bias, bias};
+    for (int i = 0; i < LOC_K; ++i)
+      for (int j = 0; j < LOC_K; ++j) {
+        const float4 kv = *reinterpret_cast<const float4*>(k1s + (i * LOC_K + j) * LOC_CO + 4 * g);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float xv = p1[(2 * ph + (q >> 1) + i) * d.Ws1 + 2 * pw + (q & 1) + j];
+          acc[q].x = fmaf(xv, kv.x, acc[q].x); acc[q].y = fmaf(xv, kv.y, acc[q].y); acc[q].z = fmaf(xv, kv.z, acc[q].z); acc[q].w = fmaf(xv, kv.w, acc[q].w);
+        }
+      }
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      *reinterpret_cast<float4*>(c1 + (((long)img * d.Ho1 + 2 * ph + (q >> 1)) * d.Wo1 + 2 * pw + (q & 1)) * LOC_CO + 4 * g) = acc[q];
+      m.x = fmaxf(m.x, acc[q].x); m.y = fmaxf(m.y, acc[q].y); m.z = fmaxf(m.z, acc[q].z); m.w = fmaxf(m.w, acc[q].w);
+    }
+    *reinterpret_cast<float4*>(p2 + pix * LOC_CO + 4 * g) = m;
+    *reinterpret_cast<float4*>(pool2 + ((long)img * d.Hs2 * d.Ws2 + pix) * LOC_CO + 4 * g) = m;
+  }
+  __syncthreads();
+  // ---- Conv2D(20, 5x5, valid) on the pooled features = the flattened input of the dense layers (loc_conv_fwd_kernel<20>'s chain)
+  for (int t = tid; t < d.Ho2 * d.Wo2 * (LOC_CO / 4); t += LOC_NT) {
+    const int g = t % (LOC_CO / 4), pix = t / (LOC_CO / 4);
+    const int wo = pix % d.Wo2, ho = pix / d.Wo2;
+    float4 acc = *reinterpret_cast<const float4*>(bc2 + 4 * g);
+    for (int i = 0; i < LOC_K; ++i)
+      for (int j = 0; j < LOC_K; ++j) {
+        const float* xp = p2 + ((ho + i) * d.Ws2 + wo + j) * LOC_CO;
+        const float* kp = k2s + ((i * LOC_K + j) * LOC_CO) * LOC_CO + 4 * g;
+#pragma unroll
+        for (int c = 0; c < LOC_CO; ++c) {
+          const float xv = xp[c];
+          const float4 kv = *reinterpret_cast<const float4*>(kp + c * LOC_CO);
+          acc.x = fmaf(xv, kv.x, acc.x); acc.y = fmaf(xv, kv.y, acc.y); acc.z = fmaf(xv, kv.z, acc.z); acc.w = fmaf(xv, kv.w, acc.w);
+        }
+      }
+    *reinterpret_cast<float4*>(fl + pix * LOC_CO + 4 * g) = acc;
+    *reinterpret_cast<float4*>(flat + (long)img * d.F + pix * LOC_CO + 4 * g) = acc;
+  }
+  __syncthreads();
+  // ---- Dense(50, relu), Dense(6) (loc_fc_fwd_kernel's partial sums)
+  const int F = d.F, part = tid / LOC_H1, j = tid % LOC_H1;
+  if (tid < LOC_KP * LOC_H1) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int k = part;
+#pragma unroll 8   // (one workgroup per CU: nothing else hides the weight loads' latency -- 32 of them in flight per thread)
+    for (; k + 3 * LOC_KP < F; k += 4 * LOC_KP) {
+      a0 = fmaf(fl[k], w1[(long)k * LOC_H1 + j], a0);
+      a1 = fmaf(fl[k + LOC_KP], w1[(long)(k + LOC_KP) * LOC_H1 + j], a1);
+      a2 = fmaf(fl[k + 2 * LOC_KP], w1[(long)(k + 2 * LOC_KP) * LOC_H1 + j], a2);
+      a3 = fmaf(fl[k + 3 * LOC_KP], w1[(long)(k + 3 * LOC_KP) * LOC_H1 + j], a3);
+    }
+    for (; k < F; k += LOC_KP) a0 = fmaf(fl[k], w1[(long)k * LOC_H1 + j], a0);
+    ps[part * LOC_H1 + j] = (a0 + a1) + (a2 + a3);
+  }
+  __syncthreads();
+  if (tid < LOC_H1) {
+    float a = b1[tid];
+#pragma unroll
+    for (int q = 0; q < LOC_KP; ++q) a += ps[q * LOC_H1 + tid];
+    a = fmaxf(a, 0.f);
+    hs[tid] = a;
+    fc1[(long)img * LOC_H1 + tid] = a;
+  }
+  __syncthreads();
+  if (tid < LOC_H2) {
+    float a = b2[tid];
+    for (int q = 0; q < LOC_H1; ++q) a = fmaf(hs[q], w2[q * LOC_H2 + tid], a);
+    theta[(long)img * LOC_H2 + tid] = a;
+  }
+}
+// CRNN_OK when the fused localisation-net kernels take an H0 x W0 image: whole pooling windows over the first convolution's map, everything in LDS
+extern "C" int crnn_loc_net_fused_supported(int H0, int W0) {
+  if (H0 < 2 || W0 < 2) return CRNN_ERR_UNSUPPORTED;
+  const LocDims d = loc_dims(H0, W0);
+  if (d.Ho1 < 2 || d.Wo1 < 2 || (d.Ho1 & 1) || (d.Wo1 & 1) || d.Ho2 < 1 || d.Wo2 < 1) return CRNN_ERR_UNSUPPORTED;
+  return (loc_fwd_lds(d) <= 120 * 1024 && loc_bwd_lds(d) <= 150 * 1024) ? CRNN_OK : CRNN_ERR_UNSUPPORTED;
+}
+// x [B][H0][W0] -> pool1 [B][H0/2][W0/2], c1 [B][Ho1][Wo1][20], pool2 [B][Hs2][Ws2][20], flat [B][F], fc1 [B][50], theta [B][6]: the outputs of
+// crnn_maxpool_fwd + crnn_loc_conv_fwd + crnn_maxpool_fwd + crnn_loc_conv_fwd + crnn_loc_fc_fwd, bit for bit, in one launch.
+extern "C" int crnn_loc_net_fwd(const float* x, const float* k1, const float* bc1, const float* k2, const float* bc2, const float* w1, const float* b1,
+                                const float* w2, const float* b2, float* pool1, float* c1, float* pool2, float* flat, float* fc1, float* theta,
+                                int B, int H0, int W0, hipStream_t s) {
+  if (!x || !k1 || !bc1 || !k2 || !bc2 || !w1 || !b1 || !w2 || !b2 || !pool1 || !c1 || !pool2 || !flat || !fc1 || !theta || B <= 0) return CRNN_ERR_ARG;
+  CRNN_TRY(crnn_loc_net_fused_supported(H0, W0));
+  if ((((uintptr_t)k1 | (uintptr_t)k2 | (uintptr_t)bc1 | (uintptr_t)bc2 | (uintptr_t)c1 | (uintptr_t)pool2 | (uintptr_t)flat) & 15)) return CRNN_ERR_UNSUPPORTED;
+  const LocDims d = loc_dims(H0, W0);
+  const size_t lds = loc_fwd_lds(d);
+  CRNN_LDS_ATTR(loc_net_fwd_kernel, 120 * 1024);
+  hipLaunchKernelGGL(loc_net_fwd_kernel, dim3(B), dim3(LOC_NT), lds, s, x, k1, bc1, k2, bc2, w1, b1, w2, b2, pool1, c1, pool2, flat, fc1, theta, d);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+
+// ---- backward of the localisation net: one workgroup per sample (data path + that sample's convolution weight-gradient terms), then one
+// launch that sums the samples' terms in a fixed order and forms the dense layers' weight gradients over the batch --------------------------------
+//   per sample:  dfc1 = (dtheta W2^T) [fc1 > 0];  dflat = dfc1 W1^T;  dpool2 = conv_dgrad(dflat, k2);  dc1 = MaxPool backward (first maximum);
+//                terms [dk2 10000 | db2 20 | dk1 500 | db1 20]: dk2[tap][c][o] = sum_pix pool2[pix + tap][c] dflat[pix][o], dk1[tap][o] = sum pool1[.] dc1[.]
+// Nothing but dfc1 and the terms goes to HBM (the stand-alone kernels wrote dflat, dpool2 and the mostly-zero dc1 and read them back).
+#define LOC_TERMS (LOC_K * LOC_K * LOC_CO * LOC_CO + LOC_CO + LOC_K * LOC_K * LOC_CO + LOC_CO)
+static size_t loc_bwd_lds(const LocDims& d) {
+  const size_t np2 = (size_t)d.Hs2 * d.Ws2 * LOC_CO;
+  return sizeof(float) * (LOC_K * LOC_K * LOC_CO * LOC_CO + 2 * np2 + d.F + 64 + (size_t)d.Hs1 * d.Ws1 + 16) + np2;   // k2 | pool2 | dpool2 | dflat | dfc1 | pool1 | arg bytes
+}
+#ifdef CRNN_LOC_TRACE   // timing build: s_memrealtime stamps of workgroup 0 after every phase, behind the samples' terms
+#define LOC_TRC(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(terms + (long)gridDim.x * LOC_TERMS)[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define LOC_TRC(i) do {} while (0)
+#endif
+__global__ __launch_bounds__(LOC_NT) void loc_net_bwd_kernel(const float* __restrict__ dtheta, const float* __restrict__ fc1, const float* __restrict__ w1,
+                                                          const float* __restrict__ w2, const float* __restrict__ k2, const float* __restrict__ pool1,
+                                                          const float* __restrict__ c1, const float* __restrict__ pool2, float* __restrict__ dfc1,
+                                                          float* __restrict__ terms, LocDims d) {
+  extern __shared__ __attribute__((aligned(16))) float lsm[];
+  constexpr int NK2 = LOC_K * LOC_K * LOC_CO * LOC_CO;
+  const int np2 = d.Hs2 * d.Ws2 * LOC_CO, F = d.F;
+  float* const k2s = lsm;                       // [5][5][20][20]
+  float* const p2 = k2s + NK2;                  // pool2 of the sample [Hs2][Ws2][20]
+  float* const dp2 = p2 + np2;                  // dpool2
+  float* const df = dp2 + np2;                  // dflat [Ho2][Wo2][20]
+  float* const ds = df + F;                     // dfc1 [50] (64 reserved)
+  float* const p1 = ds + 64;                    // pool1 of the sample [Hs1][Ws1]
+  unsigned char* const arg = reinterpret_cast<unsigned char*>(p1 + d.Hs1 * d.Ws1 + 16);   // first-maximum position (0..3) of every pooling window x channel
+  const int img = blockIdx.x, tid = threadIdx.x;
+  float* const tm = terms + (long)img * LOC_TERMS;
+  LOC_TRC(0);
+  for (int i = tid; i < NK2 / 4; i += LOC_NT) reinterpret_cast<float4*>(k2s)[i] = reinterpret_cast<const float4*>(k2)[i];
+  for (int i = tid; i < np2 / 4; i += LOC_NT) reinterpret_cast<float4*>(p2)[i] = reinterpret_cast<const float4*>(pool2 + (long)img * np2)[i];
+  for (int i = tid; i < d.Hs1 * d.Ws1; i += LOC_NT) p1[i] = pool1[(long)img * d.Hs1 * d.Ws1 + i];
+  // first maximum of every 2x2 window of c1 (maxpool_bwd_kernel's scan: strict '>' keeps the first)
+  for (int i = tid; i < np2; i += LOC_NT) {
+    const int c = i % LOC_CO, pix = i / LOC_CO, pw = pix % d.Ws2, ph = pix / d.Ws2;
+    const float* cb = c1 + (((long)img * d.Ho1 + 2 * ph) * d.Wo1 + 2 * pw) * LOC_CO + c;
+    float best = cb[0]; int a = 0;
+    for (int ii = 0; ii < 2; ++ii)
+      for (int j = 0; j < 2; ++j) {
+        const float v = cb[(ii * d.Wo1 + j) * LOC_CO];
+        if (v > best) { best = v; a = ii * 2 + j; }
+      }
+    arg[i] = (unsigned char)a;
+  }
+  // ---- dense layers backwards (loc_fc_bwd_data_kernel)
+  if (tid < LOC_H1) {
+    float a = 0.f;
+    for (int o = 0; o < LOC_H2; ++o) a = fmaf(dtheta[(long)img * LOC_H2 + o], w2[tid * LOC_H2 + o], a);
+    a = (fc1[(long)img * LOC_H1 + tid] > 0.f) ? a : 0.f;
+    ds[tid] = a;
+    dfc1[(long)img * LOC_H1 + tid] = a;
+  }
+  __syncthreads();
+  LOC_TRC(1);
+  for (int k = tid; k < F; k += LOC_NT) {
+    const float2* wr = reinterpret_cast<const float2*>(w1 + (long)k * LOC_H1);    // the row's 25 loads issued together (same sums, same order)
+    float2 wv[LOC_H1 / 2];
+#pragma unroll
+    for (int q = 0; q < LOC_H1 / 2; ++q) wv[q] = wr[q];
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < LOC_H1 / 2; ++q) { a0 = fmaf(ds[2 * q], wv[q].x, a0); a1 = fmaf(ds[2 * q + 1], wv[q].y, a1); }
+    df[k] = a0 + a1;
+  }
+  __syncthreads();
+  LOC_TRC(2);
+  // ---- second convolution: data gradient (loc_conv_dgrad_kernel's chain) into LDS ...
+  for (int t = tid; t < d.Hs2 * d.Ws2 * (LOC_CO / 4); t += LOC_NT) {
+    const int g = t % (LOC_CO / 4), pix = t / (LOC_CO / 4);
+    const int w = pix % d.Ws2, h = pix / d.Ws2;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < LOC_K; ++i) {
+      const int ho = h - i; if (ho < 0 || ho >= d.Ho2) continue;
+      for (int j = 0; j < LOC_K; ++j) {
+        const int wo = w - j; if (wo < 0 || wo >= d.Wo2) continue;
+        const float* gp = df + (ho * d.Wo2 + wo) * LOC_CO;
+        const float* kp = k2s + ((i * LOC_K + j) * LOC_CO + 4 * g) * LOC_CO;
+#pragma unroll
+        for (int o4 = 0; o4 < LOC_CO / 4; ++o4) {
+          const float4 gv = *reinterpret_cast<const float4*>(gp + 4 * o4);
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            const float4 kv = *reinterpret_cast<const float4*>(kp + cc * LOC_CO + 4 * o4);
+            acc[cc] = fmaf(gv.x, kv.x, fmaf(gv.y, kv.y, fmaf(gv.z, kv.z, fmaf(gv.w, kv.w, acc[cc]))));
+          }
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(dp2 + pix * LOC_CO + 4 * g) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+  // ... and this sample's term of its weight gradient: thread = (half of the taps, input channel c, 4 filters)
+  if (tid < LOC_K * LOC_CO * (LOC_CO / 4)) {                     // 500 threads: (tap row, input channel, 4 filters)
+    const int og = tid % (LOC_CO / 4), c = (tid / (LOC_CO / 4)) % LOC_CO, tg = tid / (LOC_CO * (LOC_CO / 4));
+    const int t0 = tg * LOC_K, t1 = t0 + LOC_K;
+    for (int tap = t0; tap < t1; ++tap) {
+      const int i = tap / LOC_K, j = tap % LOC_K;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int ho = 0; ho < d.Ho2; ++ho)
+        for (int wo = 0; wo < d.Wo2; ++wo) {
+          const float xv = p2[((ho + i) * d.Ws2 + wo + j) * LOC_CO + c];
+          const float4 gv = *reinterpret_cast<const float4*>(df + (ho * d.Wo2 + wo) * LOC_CO + 4 * og);
+          a.x = fmaf(xv, gv.x, a.x); a.y = fmaf(xv, gv.y, a.y); a.z = fmaf(xv, gv.z, a.z); a.w = fmaf(xv, gv.w, a.w);
+        }
+      *reinterpret_cast<float4*>(tm + (tap * LOC_CO + c) * LOC_CO + 4 * og) = a;
+    }
+  }
+  __syncthreads();
+  LOC_TRC(3);
+  // ---- first convolution: dc1 is dpool2 at the first maximum of each window, zero elsewhere -- its weight-gradient term straight from the windows
+  float* const t1p = tm + NK2 + LOC_CO;
+  float* const qs = k2s;                                           // (the kernel of the second convolution is not needed any more) [4][125][4] partial sums
+  constexpr int NT1 = LOC_K * LOC_K * (LOC_CO / 4);                // 125 (tap, 4 filters) pairs, each over four quarters of the windows
+  const int nwin = d.Hs2 * d.Ws2, wq = (nwin + 3) / 4;
+  if (tid < 4 * NT1) {
+    const int qd = tid / NT1, t = tid % NT1;
+    const int og = t % (LOC_CO / 4), tap = t / (LOC_CO / 4), i = tap / LOC_K, j = tap % LOC_K;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int pix = qd * wq; pix < min(nwin, (qd + 1) * wq); ++pix) {
+      const int pw = pix % d.Ws2, ph = pix / d.Ws2;
+      const float4 gv = *reinterpret_cast<const float4*>(dp2 + pix * LOC_CO + 4 * og);
+      const float g4[4] = {gv.x, gv.y, gv.z, gv.w};
+      const unsigned am = *reinterpret_cast<const unsigned*>(arg + pix * LOC_CO + 4 * og);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ar = (am >> (8 * q)) & 3;
+        a[q] = fmaf(p1[(2 * ph + (ar >> 1) + i) * d.Ws1 + 2 * pw + (ar & 1) + j], g4[q], a[q]);
+      }
+    }
+    *reinterpret_cast<float4*>(qs + (qd * NT1 + t) * 4) = make_float4(a[0], a[1], a[2], a[3]);
+  }
+  __syncthreads();
+  LOC_TRC(4);
+  if (tid < NT1) {                                                 // the four quarters in a fixed order
+    const int og = tid % (LOC_CO / 4), tap = tid / (LOC_CO / 4);
+    float4 v = *reinterpret_cast<const float4*>(qs + tid * 4);
+#pragma unroll
+    for (int qd = 1; qd < 4; ++qd) {
+      const float4 u = *reinterpret_cast<const float4*>(qs + (qd * NT1 + tid) * 4);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    *reinterpret_cast<float4*>(t1p + tap * LOC_CO + 4 * og) = v;
+  } else if (tid >= 128 && tid < 128 + LOC_CO) {                  // its bias: sum of dc1 = sum of dpool2
+    const int o = tid - 128;
+    float a = 0.f;
+    for (int pix = 0; pix < d.Hs2 * d.Ws2; ++pix) a += dp2[pix * LOC_CO + o];
+    t1p[LOC_K * LOC_K * LOC_CO + o] = a;
+  } else if (tid >= 192 && tid < 192 + LOC_CO) {                  // bias of the second convolution: sum of dflat over the pixels
+    const int o = tid - 192;
+    float a = 0.f;
+    for (int pix = 0; pix < d.Ho2 * d.Wo2; ++pix) a += df[pix * LOC_CO + o];
+    tm[NK2 + o] = a;
+  }
+  LOC_TRC(5);
+}
+// Second launch: blocks [0, nred): the samples' terms summed in sample order (4 interleaved chains) -> dk2 | db2c | dk1 | db1c;
+// blocks [nred, nred + nw1): rows of dW1 (+ db1) = flat^T dfc1 over the batch; last block: dW2, db2 = fc1^T dtheta.
+#define LOC_WROWS 8
+#define LOC_WIMG 128
+__global__ __launch_bounds__(256) void loc_net_bwd_reduce_kernel(const float* __restrict__ terms, const float* __restrict__ flat, const float* __restrict__ fc1,
+                                                                 const float* __restrict__ dfc1, const float* __restrict__ dtheta, float* __restrict__ dk2,
+                                                                 float* __restrict__ dbc2, float* __restrict__ dk1, float* __restrict__ dbc1,
+                                                                 float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
+                                                                 float* __restrict__ db2, int B, int F, int nred, int nw1) {
+  constexpr int NK2 = LOC_K * LOC_K * LOC_CO * LOC_CO, NK1 = LOC_K * LOC_K * LOC_CO;
+  __shared__ __attribute__((aligned(16))) float ls[LOC_WIMG][LOC_H1];   // left operand of a chunk: 8 columns of flat (dW1 blocks) | fc1 (the dW2 block)
+  __shared__ __attribute__((aligned(16))) float rs[LOC_WIMG][LOC_H1];   // right operand: dfc1 | dtheta
+  const int tid = threadIdx.x, bid = blockIdx.x;
+  if (bid < nred) {
+    const int o = bid * 256 + tid;
+    if (o >= LOC_TERMS) return;
+    float a[16];                                   // 16 interleaved chains: 16 loads in flight per thread, combined in a fixed tree
+#pragma unroll
+    for (int u = 0; u < 16; ++u) a[u] = 0.f;
+    int i = 0;
+    for (; i + 15 < B; i += 16) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a[u] += terms[(long)(i + u) * LOC_TERMS + o];
+    }
+    for (; i < B; ++i) a[0] += terms[(long)i * LOC_TERMS + o];
+#pragma unroll
+    for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+      for (int u = 0; u < w; ++u) a[u] += a[u + w];
+    const float v = a[0];
+    if (o < NK2) dk2[o] = v;
+    else if (o < NK2 + LOC_CO) dbc2[o - NK2] = v;
+    else if (o < NK2 + LOC_CO + NK1) dk1[o - NK2 - LOC_CO] = v;
+    else dbc1[o - NK2 - LOC_CO - NK1] = v;
+    return;
+  }
+  // dense layers' weight gradients over the batch, images staged through LDS in chunks of LOC_WIMG (contiguous float4 copies where the source is contiguous):
+  //   blocks nred .. nred + nw1 - 1: rows r0 .. r0 + 7 of dW1 = flat^T dfc1 (the first of them also db1 = column sums of dfc1);
+  //   last block: dW2 = fc1^T dtheta and db2 = column sums of dtheta
+  const bool second = bid == nred + nw1;
+  const int r0 = second ? 0 : (bid - nred) * LOC_WROWS;
+  const int nlr = second ? LOC_H1 : LOC_WROWS;                       // staged left columns per image
+  const int nc = second ? LOC_H2 : LOC_H1;
+  const float* Rm = second ? dtheta : dfc1;
+  float* const lsf = &ls[0][0]; float* const rsf = &rs[0][0];        // flat views: left [LOC_WIMG][nlr], right [LOC_WIMG][nc]
+  const int o0 = tid, o1 = tid + 256, nout = nlr * nc;              // this thread's outputs (8 * 50 = 400 | 50 * 6 = 300)
+  const bool v0 = o0 < nout, v1 = o1 < nout;
+  const int ra = v0 ? o0 / nc : 0, ca = v0 ? o0 % nc : 0, rb = v1 ? o1 / nc : 0, cb = v1 ? o1 % nc : 0;
+  float acc0 = 0.f, acc1 = 0.f, accb = 0.f;
+  for (int i0 = 0; i0 < B; i0 += LOC_WIMG) {
+    const int ni = min(LOC_WIMG, B - i0);
+    __syncthreads();
+    // contiguous source -> float4 copy, zero past the batch (the sources are 16-byte aligned: chunks start at multiples of 128 images)
+    auto stage = [&](float* dst, const float* src, int nvalid, int ntotal) {
+#pragma unroll 4
+      for (int t4 = tid; t4 < ntotal / 4; t4 += 256) {
+        const int e = 4 * t4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e + 3 < nvalid) v = *reinterpret_cast<const float4*>(src + e);
+        else { if (e < nvalid) v.x = src[e]; if (e + 1 < nvalid) v.y = src[e + 1]; if (e + 2 < nvalid) v.z = src[e + 2]; }
+        reinterpret_cast<float4*>(dst)[t4] = v;
+      }
+    };
+    if (second) {
+      stage(lsf, fc1 + (long)i0 * LOC_H1, ni * LOC_H1, LOC_WIMG * LOC_H1);
+    } else {
+      for (int t = tid; t < LOC_WIMG * LOC_WROWS; t += 256) {
+        const int i = t / LOC_WROWS, r = t % LOC_WROWS;
+        lsf[t] = (i < ni && r0 + r < F) ? flat[(long)(i0 + i) * F + r0 + r] : 0.f;
+      }
+    }
+    stage(rsf, Rm + (long)i0 * nc, ni * nc, LOC_WIMG * nc);
+    __syncthreads();
+    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+#pragma unroll 4
+    for (int i = 0; i < LOC_WIMG; i += 2) {          // both outputs side by side, eight images per trip: the LDS reads of a trip are in flight together
+      a0 = fmaf(lsf[i * nlr + ra], rsf[i * nc + ca], a0); a1 = fmaf(lsf[(i + 1) * nlr + ra], rsf[(i + 1) * nc + ca], a1);
+      b0 = fmaf(lsf[i * nlr + rb], rsf[i * nc + cb], b0); b1 = fmaf(lsf[(i + 1) * nlr + rb], rsf[(i + 1) * nc + cb], b1);
+    }
+    acc0 += a0 + a1; acc1 += b0 + b1;
+    if (tid < nc) {                                  // column sums of the right operand (rows past ni are zero)
+      float s0 = 0.f, s1 = 0.f;
+      for (int i = 0; i < LOC_WIMG; i += 2) { s0 += rsf[i * nc + tid]; s1 += rsf[(i + 1) * nc + tid]; }
+      accb += s0 + s1;
+    }
+  }
+  if (second) {
+    if (v0) dw2[o0] = acc0;
+    if (v1) dw2[o1] = acc1;
+    if (tid < LOC_H2) db2[tid] = accb;
+  } else {
+    if (v0 && r0 + ra < F) dw1[(long)(r0 + ra) * LOC_H1 + ca] = acc0;
+    if (v1 && r0 + rb < F) dw1[(long)(r0 + rb) * LOC_H1 + cb] = acc1;
+    if (bid == nred && tid < LOC_H1) db1[tid] = accb;
+  }
+}
+// floats of scratch crnn_loc_net_bwd needs (the samples' convolution weight-gradient terms)
+extern "C" long crnn_loc_net_bwd_scratch(int B) { return (long)B * LOC_TERMS; }
+// Backward of crnn_loc_net_fwd from dtheta [B][6]: every gradient of the eight localisation-net parameters (dk1 [5][5][1][20], dbc1 [20], dk2 [5][5][20][20],
+// dbc2 [20], dw1 [F][50], db1 [50], dw2 [50][6], db2 [6]); dfc1 [B][50] and `scratch` (crnn_loc_net_bwd_scratch floats) are work buffers.  The sums of
+// crnn_loc_fc_bwd + crnn_loc_conv_wgrad + crnn_loc_conv_dgrad + crnn_maxpool_bwd + crnn_loc_conv_wgrad in another order (fixed: deterministic).
+extern "C" int crnn_loc_net_bwd(const float* dtheta, const float* flat, const float* fc1, const float* pool1, const float* c1, const float* pool2,
+                                const float* w1, const float* w2, const float* k2, float* dfc1, float* scratch, float* dk1, float* dbc1, float* dk2,
+                                float* dbc2, float* dw1, float* db1, float* dw2, float* db2, int B, int H0, int W0, hipStream_t s) {
+  if (!dtheta || !flat || !fc1 || !pool1 || !c1 || !pool2 || !w1 || !w2 || !k2 || !dfc1 || !scratch || !dk1 || !dbc1 || !dk2 || !dbc2 || !dw1 || !db1 ||
+      !dw2 || !db2 || B <= 0) return CRNN_ERR_ARG;
+  CRNN_TRY(crnn_loc_net_fused_supported(H0, W0));
+  if ((((uintptr_t)k2 | (uintptr_t)pool2 | (uintptr_t)scratch | (uintptr_t)dfc1 | (uintptr_t)fc1 | (uintptr_t)dtheta) & 15) || ((uintptr_t)w1 & 7)) return CRNN_ERR_UNSUPPORTED;
+  const LocDims d = loc_dims(H0, W0);
+  CRNN_LDS_ATTR(loc_net_bwd_kernel, 150 * 1024);
+  hipLaunchKernelGGL(loc_net_bwd_kernel, dim3(B), dim3(LOC_NT), loc_bwd_lds(d), s, dtheta, fc1, w1, w2, k2, pool1, c1, pool2, dfc1, scratch, d);
+  CRNN_LAUNCH_CHECK();
+  const int nred = cdiv(LOC_TERMS, 256), nw1 = cdiv(d.F, LOC_WROWS);
+  hipLaunchKernelGGL(loc_net_bwd_reduce_kernel, dim3(nred + nw1 + 1), dim3(256), 0, s, scratch, flat, fc1, dfc1, dtheta, dk2, dbc2, dk1, dbc1, dw1, db1, dw2,
+                     db2, B, d.F, nred, nw1);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}

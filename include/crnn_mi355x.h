@@ -41,6 +41,9 @@ typedef struct {
                        conv-stack activations / gradients are stored as bf16 in HBM (statistics, RNN, CTC, optimizer fp32) */
   int flags;        /* bit set of CRNN_FLAG_* (0 = the default schedule); A/B switches: bit-identical results except where a flag says otherwise */
 } crnn_config;
+#define CRNN_FLAG_LOC_NET_KERNELS 8192  /* spatial transformer: the localisation net as its stand-alone kernels (five launches forward, about ten backward) instead of
+                                         * crnn_loc_net_fwd / crnn_loc_net_bwd (one workgroup per sample); forward bit-identical, the localisation net's weight
+                                         * gradients the same sums in another order */
 #define CRNN_FLAG_NO_BN2_DW_FUSION 4096 /* fp32-storage training, where the two fusions below are the DEFAULT schedule since round 4 (fp32 forms of the same
                                          * kernels; half the elements per byte leave them bandwidth-bound: -0.6 ms of 14.8 per step at batch 256): block outputs
                                          * materialised, BatchNorm-2's backward statistics as a pass of their own.  Forward / data gradients bit-identical,
@@ -400,6 +403,19 @@ int crnn_loc_fc_fwd(const float* flat, const float* w1, const float* b1, const f
                     int B, int F, crnn_stream_t stream);
 int crnn_loc_fc_bwd(const float* flat, const float* fc1, const float* dtheta, const float* w1, const float* w2, float* dfc1,
                     float* dflat, float* dw1, float* db1, float* dw2, float* db2, int B, int F, crnn_stream_t stream);
+/* Round 4: the localisation net of a sample in ONE workgroup (utils.py:248-256).  crnn_loc_net_fwd = crnn_maxpool_fwd + crnn_loc_conv_fwd + crnn_maxpool_fwd +
+ * crnn_loc_conv_fwd + crnn_loc_fc_fwd in one launch, every output (pool1, c1, pool2, flat, fc1, theta) bit-identical; crnn_loc_net_bwd = the whole backward from
+ * dtheta (crnn_loc_fc_bwd + crnn_loc_conv_wgrad + crnn_loc_conv_dgrad + crnn_maxpool_bwd + crnn_loc_conv_wgrad) in two launches: one workgroup per sample for the data
+ * path and the sample's convolution weight-gradient terms (scratch: crnn_loc_net_bwd_scratch(B) floats), then one launch summing the terms in sample order and forming
+ * the dense layers' weight gradients -- the same sums in another (fixed) order.  _supported: whole pooling windows over the first convolution's map (even Ho1, Wo1)
+ * and a sample's maps within LDS (images up to about 250 x 32); else CRNN_ERR_UNSUPPORTED and the caller runs the stand-alone kernels. */
+int crnn_loc_net_fused_supported(int H0, int W0);
+int crnn_loc_net_fwd(const float* x, const float* k1, const float* bc1, const float* k2, const float* bc2, const float* w1, const float* b1, const float* w2,
+                     const float* b2, float* pool1, float* c1, float* pool2, float* flat, float* fc1, float* theta, int B, int H0, int W0, crnn_stream_t stream);
+long crnn_loc_net_bwd_scratch(int B);
+int crnn_loc_net_bwd(const float* dtheta, const float* flat, const float* fc1, const float* pool1, const float* c1, const float* pool2, const float* w1,
+                     const float* w2, const float* k2, float* dfc1, float* scratch, float* dk1, float* dbc1, float* dk2, float* dbc2, float* dw1, float* db1,
+                     float* dw2, float* db2, int B, int H0, int W0, crnn_stream_t stream);
 /* Bidirectional LSTM recurrence (utils.py:78-79), time-major */
 int crnn_lstm_fwd(const float* xw0, const float* xw1, const float* ut0, const float* ut1, float* h0, float* h1, int ldh,
                   float* c0, float* c1, float* g0, float* g1, int T, int B, int u, crnn_stream_t stream);

@@ -343,6 +343,39 @@ def test_step_does_not_depend_on_workspace_contents(precision, shape):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16s"])
+def test_localisation_net_per_sample_kernels_equal_the_standalone_kernels(precision):
+    """The spatial transformer's localisation net as one workgroup per sample (default, round 4) against its stand-alone kernels
+    (CRNN_FLAG_LOC_NET_KERNELS): the same forward bit for bit -- hence the same posteriors, loss and every gradient outside the localisation net --
+    and the localisation net's eight parameter gradients to summation order."""
+    from crnn_mi355x import native
+    B, imgh, imgw, ncls, max_len, tds, u = 6, 100, 32, 38, 23, 128, 256
+    cfg = M.Config(imgh=imgh, imgw=imgw, max_len=max_len, time_dense_size=tds, n_units=u, num_classes=ncls)
+    p, bn = M.init_params(cfg, seed=6, dtype=np.float64)
+    p = M.randomize_params(cfg, p)
+    x, lab, il, ll = M.synthetic_batch(cfg, B, seed=4, dtype=np.float64)
+    out = {}
+    for flags in (0, native.FLAG_LOC_NET_KERNELS):
+        eng = Engine(B, imgh, imgw, ncls, max_len, tds, u, stn=True, dropout=True, precision=precision, flags=flags)
+        eng.set_params(p, bn)
+        eng.ws.fill_(float("nan")); eng.grads.zero_()
+        y = eng.forward(x.astype(np.float32), train=True, seed=5).clone()
+        loss = eng.backward(lab, il, ll, seed=5).clone()
+        out[flags] = (y, loss, eng.grads.clone(), eng.ws_tensor("theta").clone())
+        lay = eng.layout
+        del eng
+    (y0, l0, g0, t0), (y1, l1, g1, t1) = out[0], out[native.FLAG_LOC_NET_KERNELS]
+    assert torch.equal(t0, t1) and torch.equal(y0, y1) and torch.equal(l0, l1) and torch.isfinite(g0).all()
+    stn = torch.zeros_like(g0, dtype=torch.bool)
+    for name, (off, size, _) in lay.items():
+        if name.startswith("stn_"):
+            stn[off:off + size] = True
+            a, b = g0[off:off + size], g1[off:off + size]
+            assert float(b.abs().max()) > 0, name
+            assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-7, (name, float((a - b).abs().max()), float(b.abs().max()))
+    assert torch.equal(g0[~stn], g1[~stn])
+
+
 @pytest.mark.parametrize("dropout", [True, False])
 def test_fp32_row_stream_schedules_equal_the_tile_schedule(dropout):
     """Parity mode (fp32 tensors), round 4: the depthwise stage runs on the fp32 forms of the row-stream kernels -- forward with the BatchNorm-1

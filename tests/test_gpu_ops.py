@@ -1907,6 +1907,63 @@ def test_localisation_net_direct_conv_kernels(cin, H, W):
     assert L().crnn_loc_conv_fwd(P(dev(x)), P(dev(k)), P(dev(b)), P(y), B, H, W, 3, S()) == -3
 
 
+@pytest.mark.parametrize("B,H0,W0", [(7, 100, 32), (256, 100, 32), (3, 200, 32), (5, 40, 32), (2, 60, 48)])
+def test_localisation_net_in_one_workgroup_per_sample(B, H0, W0):
+    """crnn_loc_net_fwd / crnn_loc_net_bwd (round 4): the spatial transformer's localisation net (utils.py:248-256) with one workgroup per sample.
+    Forward: pool1, c1, pool2, flat, fc1, theta bit-identical to the five stand-alone kernels.  Backward from dtheta: all eight parameter gradients
+    against the stand-alone sequence (crnn_loc_fc_bwd, crnn_loc_conv_wgrad, crnn_loc_conv_dgrad, crnn_maxpool_bwd, crnn_loc_conv_wgrad) to summation
+    order, repeat launches bit-identical; shapes the kernels refuse say so."""
+    rs = np.random.RandomState(B + H0 + W0)
+    Hs1, Ws1 = H0 // 2, W0 // 2; Ho1, Wo1 = Hs1 - 4, Ws1 - 4; Hs2, Ws2 = Ho1 // 2, Wo1 // 2; Ho2, Wo2 = Hs2 - 4, Ws2 - 4; F = Ho2 * Wo2 * 20
+    sup = L().crnn_loc_net_fused_supported(H0, W0)
+    assert sup == (0 if (Ho1 % 2 == 0 and Wo1 % 2 == 0 and Ho2 >= 1 and Wo2 >= 1) else -3)
+    x = dev(rs.uniform(size=(B, H0, W0)))
+    k1 = dev(rs.normal(size=(5, 5, 1, 20)) * 0.3); bc1 = dev(rs.normal(size=20) * 0.1)
+    k2 = dev(rs.normal(size=(5, 5, 20, 20)) * 0.1); bc2 = dev(rs.normal(size=20) * 0.1)
+    w1 = dev(rs.normal(size=(max(F, 1), 50)) * 0.1); b1 = dev(rs.normal(size=50) * 0.1); w2 = dev(rs.normal(size=(50, 6)) * 0.3); b2 = dev(rs.normal(size=6))
+    if sup != 0:
+        z = zeros(16)
+        assert L().crnn_loc_net_fwd(P(x), P(k1), P(bc1), P(k2), P(bc2), P(w1), P(b1), P(w2), P(b2), P(z), P(z), P(z), P(z), P(z), P(z), B, H0, W0, S()) == -3
+        return
+    # stand-alone sequence
+    p1 = zeros(B, Hs1, Ws1); c1 = zeros(B, Ho1, Wo1, 20); p2 = zeros(B, Hs2, Ws2, 20); fl = zeros(B, F); f1 = zeros(B, 50); th = zeros(B, 6)
+    ok(L().crnn_maxpool_fwd(P(x), P(p1), B, H0, W0, 1, 2, 2, S()))
+    ok(L().crnn_loc_conv_fwd(P(p1), P(k1), P(bc1), P(c1), B, Hs1, Ws1, 1, S()))
+    ok(L().crnn_maxpool_fwd(P(c1), P(p2), B, Ho1, Wo1, 20, 2, 2, S()))
+    ok(L().crnn_loc_conv_fwd(P(p2), P(k2), P(bc2), P(fl), B, Hs2, Ws2, 20, S()))
+    ok(L().crnn_loc_fc_fwd(P(fl), P(w1), P(b1), P(w2), P(b2), P(f1), P(th), B, F, S()))
+    q = [torch.full((t.numel() + 8,), 7.0, device="cuda") for t in (p1, c1, p2, fl, f1, th)]
+    ok(L().crnn_loc_net_fwd(P(x), P(k1), P(bc1), P(k2), P(bc2), P(w1), P(b1), P(w2), P(b2), *[P(t) for t in q], B, H0, W0, S()))
+    for t, ref, nm in zip(q, (p1, c1, p2, fl, f1, th), ("pool1", "c1", "pool2", "flat", "fc1", "theta")):
+        assert torch.equal(t[:-8], ref.reshape(-1)), "%s: max diff %g" % (nm, float((t[:-8] - ref.reshape(-1)).abs().max()))
+        assert bool((t[-8:] == 7.0).all()), nm
+    assert float(f1.abs().max()) > 0 and float((f1 == 0).float().mean()) > 0.05
+    # backward from dtheta
+    dth = dev(rs.normal(size=(B, 6)))
+    g1 = dict(dfc1=zeros(B, 50), dflat=zeros(B, F), dw1=zeros(F, 50), db1=zeros(50), dw2=zeros(50, 6), db2=zeros(6), dk2=zeros(5, 5, 20, 20), dbc2=zeros(20),
+              dp2=zeros(B, Hs2, Ws2, 20), dc1=zeros(B, Ho1, Wo1, 20), dk1=zeros(5, 5, 1, 20), dbc1=zeros(20))
+    ok(L().crnn_loc_fc_bwd(P(fl), P(f1), P(dth), P(w1), P(w2), P(g1["dfc1"]), P(g1["dflat"]), P(g1["dw1"]), P(g1["db1"]), P(g1["dw2"]), P(g1["db2"]), B, F, S()))
+    scr = zeros((max(L().crnn_loc_conv_wgrad_chunks(B, Hs2, Ws2), L().crnn_loc_conv_wgrad_chunks(B, Hs1, Ws1)) + 2) * (25 * 20 * 20 + 20))
+    ok(L().crnn_loc_conv_wgrad(P(p2), P(g1["dflat"]), P(g1["dk2"]), P(g1["dbc2"]), P(scr), B, Hs2, Ws2, 20, S()))
+    ok(L().crnn_loc_conv_dgrad(P(g1["dflat"]), P(k2), P(g1["dp2"]), B, Hs2, Ws2, S()))
+    ok(L().crnn_maxpool_bwd(P(c1), P(g1["dp2"]), P(g1["dc1"]), B, Ho1, Wo1, 20, 2, 2, S()))
+    ok(L().crnn_loc_conv_wgrad(P(p1), P(g1["dc1"]), P(g1["dk1"]), P(g1["dbc1"]), P(scr), B, Hs1, Ws1, 1, S()))
+    names = ("dk1", "dbc1", "dk2", "dbc2", "dw1", "db1", "dw2", "db2")
+    def fused():
+        g = {n: torch.full((g1[n].numel() + 4,), 5.0, device="cuda") for n in names}
+        dfc1 = zeros(B, 50); terms = torch.full((L().crnn_loc_net_bwd_scratch(B) + 8,), 3.0, device="cuda")
+        ok(L().crnn_loc_net_bwd(P(dth), P(fl), P(f1), P(p1), P(c1), P(p2), P(w1), P(w2), P(k2), P(dfc1), P(terms), *[P(g[n]) for n in names], B, H0, W0, S()))
+        assert bool((terms[-8:] == 3.0).all()) and all(bool((g[n][-4:] == 5.0).all()) for n in names)
+        return g, dfc1
+    g2, dfc1 = fused()
+    assert torch.equal(dfc1, g1["dfc1"])
+    for n in names:
+        ref = host(g1[n]).reshape(-1)
+        assert_close(host(g2[n][:-4]), ref, rtol=1e-4, atol=1e-5 * max(1.0, float(np.abs(ref).max())), what=n)
+    g3, _ = fused()
+    assert all(torch.equal(g2[n], g3[n]) for n in names), "repeat launches differ"
+
+
 @pytest.mark.parametrize("B,F", [(12, 760), (3, 80)])
 def test_localisation_net_dense_kernels(B, F):
     """crnn_loc_fc_fwd / crnn_loc_fc_bwd: Dense(50, relu) -> Dense(6) (utils.py:254-255) and their gradients."""
