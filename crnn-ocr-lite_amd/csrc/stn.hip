@@ -523,7 +523,8 @@ extern "C" int crnn_loc_fc_bwd(const float* flat, const float* fc1, const float*
 // arithmetic (fmaf chains, fmaxf scans, the dense layers' interleaved partial sums) is theirs, statement for statement: bit-identical outputs,
 // and the saved intermediates (pool1, c1, pool2, flat, fc1) are still written for the backward pass.
 // =====================================================================================================
-#define LOC_NT 512          // threads of the per-sample kernels: two waves per SIMD -- one workgroup per CU has nothing else to hide LDS latency behind
+#define LOC_NT 512          // threads of the per-sample forward kernel: two waves per SIMD -- one workgroup per CU has nothing else to hide LDS latency behind
+#define LOC_NTB 1024        // ... of the backward kernel: the second convolution's data gradient and weight-gradient term run side by side on 512 threads each
 struct LocDims { int H0, W0, Hs1, Ws1, Ho1, Wo1, Hs2, Ws2, Ho2, Wo2, F; };
 static LocDims loc_dims(int H0, int W0) {
   LocDims d; d.H0 = H0; d.W0 = W0; d.Hs1 = H0 / 2; d.Ws1 = W0 / 2; d.Ho1 = d.Hs1 - 4; d.Wo1 = d.Ws1 - 4;
@@ -670,14 +671,15 @@ extern "C" int crnn_loc_net_fwd(const float* x, const float* k1, const float* bc
 #define LOC_TERMS (LOC_K * LOC_K * LOC_CO * LOC_CO + LOC_CO + LOC_K * LOC_K * LOC_CO + LOC_CO)
 static size_t loc_bwd_lds(const LocDims& d) {
   const size_t np2 = (size_t)d.Hs2 * d.Ws2 * LOC_CO;
-  return sizeof(float) * (LOC_K * LOC_K * LOC_CO * LOC_CO + 2 * np2 + d.F + 64 + (size_t)d.Hs1 * d.Ws1 + 16) + np2;   // k2 | pool2 | dpool2 | dflat | dfc1 | pool1 | arg bytes
+  return sizeof(float) * (LOC_K * LOC_K * LOC_CO * LOC_CO + 2 * np2 + d.F + 64 + (size_t)d.Hs1 * d.Ws1 + 16) + ((np2 + 15) & ~(size_t)15) +
+         sizeof(int) * ((size_t)d.Ho2 * d.Wo2 + 4);   // k2 | pool2 | dpool2 | dflat | dfc1 | pool1 | arg bytes | pixel offsets
 }
 #ifdef CRNN_LOC_TRACE   // timing build: s_memrealtime stamps of workgroup 0 after every phase, behind the samples' terms
 #define LOC_TRC(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(terms + (long)gridDim.x * LOC_TERMS)[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define LOC_TRC(i) do {} while (0)
 #endif
-__global__ __launch_bounds__(LOC_NT) void loc_net_bwd_kernel(const float* __restrict__ dtheta, const float* __restrict__ fc1, const float* __restrict__ w1,
+__global__ __launch_bounds__(LOC_NTB) void loc_net_bwd_kernel(const float* __restrict__ dtheta, const float* __restrict__ fc1, const float* __restrict__ w1,
                                                           const float* __restrict__ w2, const float* __restrict__ k2, const float* __restrict__ pool1,
                                                           const float* __restrict__ c1, const float* __restrict__ pool2, float* __restrict__ dfc1,
                                                           float* __restrict__ terms, LocDims d) {
@@ -691,14 +693,16 @@ __global__ __launch_bounds__(LOC_NT) void loc_net_bwd_kernel(const float* __rest
   float* const ds = df + F;                     // dfc1 [50] (64 reserved)
   float* const p1 = ds + 64;                    // pool1 of the sample [Hs1][Ws1]
   unsigned char* const arg = reinterpret_cast<unsigned char*>(p1 + d.Hs1 * d.Ws1 + 16);   // first-maximum position (0..3) of every pooling window x channel
+  int* const xo = reinterpret_cast<int*>(arg + ((np2 + 15) & ~15));   // offset of output pixel (ho, wo) of the second convolution inside pool2: (ho Ws2 + wo) 20
   const int img = blockIdx.x, tid = threadIdx.x;
   float* const tm = terms + (long)img * LOC_TERMS;
   LOC_TRC(0);
-  for (int i = tid; i < NK2 / 4; i += LOC_NT) reinterpret_cast<float4*>(k2s)[i] = reinterpret_cast<const float4*>(k2)[i];
-  for (int i = tid; i < np2 / 4; i += LOC_NT) reinterpret_cast<float4*>(p2)[i] = reinterpret_cast<const float4*>(pool2 + (long)img * np2)[i];
-  for (int i = tid; i < d.Hs1 * d.Ws1; i += LOC_NT) p1[i] = pool1[(long)img * d.Hs1 * d.Ws1 + i];
+  for (int i = tid; i < d.Ho2 * d.Wo2 + 4; i += LOC_NTB) xo[i] = (i < d.Ho2 * d.Wo2) ? ((i / d.Wo2) * d.Ws2 + i % d.Wo2) * LOC_CO : 0;
+  for (int i = tid; i < NK2 / 4; i += LOC_NTB) reinterpret_cast<float4*>(k2s)[i] = reinterpret_cast<const float4*>(k2)[i];
+  for (int i = tid; i < np2 / 4; i += LOC_NTB) reinterpret_cast<float4*>(p2)[i] = reinterpret_cast<const float4*>(pool2 + (long)img * np2)[i];
+  for (int i = tid; i < d.Hs1 * d.Ws1; i += LOC_NTB) p1[i] = pool1[(long)img * d.Hs1 * d.Ws1 + i];
   // first maximum of every 2x2 window of c1 (maxpool_bwd_kernel's scan: strict '>' keeps the first)
-  for (int i = tid; i < np2; i += LOC_NT) {
+  for (int i = tid; i < np2; i += LOC_NTB) {
     const int c = i % LOC_CO, pix = i / LOC_CO, pw = pix % d.Ws2, ph = pix / d.Ws2;
     const float* cb = c1 + (((long)img * d.Ho1 + 2 * ph) * d.Wo1 + 2 * pw) * LOC_CO + c;
     float best = cb[0]; int a = 0;
@@ -719,7 +723,7 @@ __global__ __launch_bounds__(LOC_NT) void loc_net_bwd_kernel(const float* __rest
   }
   __syncthreads();
   LOC_TRC(1);
-  for (int k = tid; k < F; k += LOC_NT) {
+  for (int k = tid; k < F; k += LOC_NTB) {
     const float2* wr = reinterpret_cast<const float2*>(w1 + (long)k * LOC_H1);    // the row's 25 loads issued together (same sums, same order)
     float2 wv[LOC_H1 / 2];
 #pragma unroll
@@ -732,7 +736,8 @@ __global__ __launch_bounds__(LOC_NT) void loc_net_bwd_kernel(const float* __rest
   __syncthreads();
   LOC_TRC(2);
   // ---- second convolution: data gradient (loc_conv_dgrad_kernel's chain) into LDS ...
-  for (int t = tid; t < d.Hs2 * d.Ws2 * (LOC_CO / 4); t += LOC_NT) {
+  // (threads 0..511: the data gradient; threads 512..1011: the weight-gradient term below -- independent work side by side)
+  for (int t = tid; t < d.Hs2 * d.Ws2 * (LOC_CO / 4) && tid < 512; t += 512) {
     const int g = t % (LOC_CO / 4), pix = t / (LOC_CO / 4);
     const int w = pix % d.Ws2, h = pix / d.Ws2;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -756,20 +761,35 @@ __global__ __launch_bounds__(LOC_NT) void loc_net_bwd_kernel(const float* __rest
     *reinterpret_cast<float4*>(dp2 + pix * LOC_CO + 4 * g) = make_float4(acc[0], acc[1], acc[2], acc[3]);
   }
   // ... and this sample's term of its weight gradient: thread = (half of the taps, input channel c, 4 filters)
-  if (tid < LOC_K * LOC_CO * (LOC_CO / 4)) {                     // 500 threads: (tap row, input channel, 4 filters)
-    const int og = tid % (LOC_CO / 4), c = (tid / (LOC_CO / 4)) % LOC_CO, tg = tid / (LOC_CO * (LOC_CO / 4));
-    const int t0 = tg * LOC_K, t1 = t0 + LOC_K;
-    for (int tap = t0; tap < t1; ++tap) {
-      const int i = tap / LOC_K, j = tap % LOC_K;
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int ho = 0; ho < d.Ho2; ++ho)
-        for (int wo = 0; wo < d.Wo2; ++wo) {
-          const float xv = p2[((ho + i) * d.Ws2 + wo + j) * LOC_CO + c];
-          const float4 gv = *reinterpret_cast<const float4*>(df + (ho * d.Wo2 + wo) * LOC_CO + 4 * og);
-          a.x = fmaf(xv, gv.x, a.x); a.y = fmaf(xv, gv.y, a.y); a.z = fmaf(xv, gv.z, a.z); a.w = fmaf(xv, gv.w, a.w);
+  if (tid >= 512 && tid < 512 + LOC_K * LOC_CO * (LOC_CO / 4)) {  // 500 threads: (tap row, input channel, 4 filters)
+    const int t5 = tid - 512;
+    const int og = t5 % (LOC_CO / 4), c = (t5 / (LOC_CO / 4)) % LOC_CO, tg = t5 / (LOC_CO * (LOC_CO / 4));
+    // the five taps of kernel row tg share a pixel's gradient: one read of it feeds 20 fmas (a tap at a time read it once per 4)
+    const int npx = d.Ho2 * d.Wo2;
+    const float* xb = p2 + (tg * d.Ws2) * LOC_CO + c;
+    float4 a[LOC_K];
+#pragma unroll
+    for (int j = 0; j < LOC_K; ++j) a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int pix = 0; pix < npx; pix += 2) {              // two pixels per trip (a pixel past the end: gradient 0 -> the sums unchanged)
+      float xv[2][LOC_K]; float4 gv[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const bool in = pix + u < npx;
+        const float* xp = xb + xo[pix + u];
+        gv[u] = in ? *reinterpret_cast<const float4*>(df + (pix + u) * LOC_CO + 4 * og) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < LOC_K; ++j) xv[u][j] = xp[j * LOC_CO];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < LOC_K; ++j) {
+          a[j].x = fmaf(xv[u][j], gv[u].x, a[j].x); a[j].y = fmaf(xv[u][j], gv[u].y, a[j].y);
+          a[j].z = fmaf(xv[u][j], gv[u].z, a[j].z); a[j].w = fmaf(xv[u][j], gv[u].w, a[j].w);
         }
-      *reinterpret_cast<float4*>(tm + (tap * LOC_CO + c) * LOC_CO + 4 * og) = a;
     }
+#pragma unroll
+    for (int j = 0; j < LOC_K; ++j) *reinterpret_cast<float4*>(tm + ((tg * LOC_K + j) * LOC_CO + c) * LOC_CO + 4 * og) = a[j];
   }
   __syncthreads();
   LOC_TRC(3);
@@ -782,16 +802,30 @@ __global__ __launch_bounds__(LOC_NT) void loc_net_bwd_kernel(const float* __rest
     const int qd = tid / NT1, t = tid % NT1;
     const int og = t % (LOC_CO / 4), tap = t / (LOC_CO / 4), i = tap / LOC_K, j = tap % LOC_K;
     float a[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int pix = qd * wq; pix < min(nwin, (qd + 1) * wq); ++pix) {
-      const int pw = pix % d.Ws2, ph = pix / d.Ws2;
-      const float4 gv = *reinterpret_cast<const float4*>(dp2 + pix * LOC_CO + 4 * og);
-      const float g4[4] = {gv.x, gv.y, gv.z, gv.w};
-      const unsigned am = *reinterpret_cast<const unsigned*>(arg + pix * LOC_CO + 4 * og);
+    const int pend = min(nwin, (qd + 1) * wq);
+    for (int pix = qd * wq; pix < pend; pix += 2) {       // two windows per trip: both rounds of LDS reads (positions, then the pooled image) in flight together
+      float g4[2][4]; float xv[2][4];
+      unsigned am[2]; int pb[2];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int ar = (am >> (8 * q)) & 3;
-        a[q] = fmaf(p1[(2 * ph + (ar >> 1) + i) * d.Ws1 + 2 * pw + (ar & 1) + j], g4[q], a[q]);
+      for (int u = 0; u < 2; ++u) {
+        const int px = min(pix + u, nwin - 1);
+        const float4 gv = *reinterpret_cast<const float4*>(dp2 + px * LOC_CO + 4 * og);
+        const bool in = pix + u < pend;
+        g4[u][0] = in ? gv.x : 0.f; g4[u][1] = in ? gv.y : 0.f; g4[u][2] = in ? gv.z : 0.f; g4[u][3] = in ? gv.w : 0.f;
+        am[u] = *reinterpret_cast<const unsigned*>(arg + px * LOC_CO + 4 * og);
+        pb[u] = (2 * (px / d.Ws2) + i) * d.Ws1 + 2 * (px % d.Ws2) + j;
       }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int ar = (am[u] >> (8 * q)) & 3;
+          xv[u][q] = p1[pb[u] + (ar >> 1) * d.Ws1 + (ar & 1)];
+        }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = fmaf(xv[u][q], g4[u][q], a[q]);
     }
     *reinterpret_cast<float4*>(qs + (qd * NT1 + t) * 4) = make_float4(a[0], a[1], a[2], a[3]);
   }
@@ -929,7 +963,7 @@ extern "C" int crnn_loc_net_bwd(const float* dtheta, const float* flat, const fl
   if ((((uintptr_t)k2 | (uintptr_t)pool2 | (uintptr_t)scratch | (uintptr_t)dfc1 | (uintptr_t)fc1 | (uintptr_t)dtheta) & 15) || ((uintptr_t)w1 & 7)) return CRNN_ERR_UNSUPPORTED;
   const LocDims d = loc_dims(H0, W0);
   CRNN_LDS_ATTR(loc_net_bwd_kernel, 150 * 1024);
-  hipLaunchKernelGGL(loc_net_bwd_kernel, dim3(B), dim3(LOC_NT), loc_bwd_lds(d), s, dtheta, fc1, w1, w2, k2, pool1, c1, pool2, dfc1, scratch, d);
+  hipLaunchKernelGGL(loc_net_bwd_kernel, dim3(B), dim3(LOC_NTB), loc_bwd_lds(d), s, dtheta, fc1, w1, w2, k2, pool1, c1, pool2, dfc1, scratch, d);
   CRNN_LAUNCH_CHECK();
   const int nred = cdiv(LOC_TERMS, 256), nw1 = cdiv(d.F, LOC_WROWS);
   hipLaunchKernelGGL(loc_net_bwd_reduce_kernel, dim3(nred + nw1 + 1), dim3(256), 0, s, scratch, flat, fc1, dfc1, dtheta, dk2, dbc2, dk1, dbc1, dw1, db1, dw2,
