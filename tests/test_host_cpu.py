@@ -131,6 +131,62 @@ def test_schedule_flags_of_the_binding_equal_the_header_and_row_stream_shape_rul
         assert L.crnn_dwconv_bwd_stream_supported(8, h, w, c) == -3 and L.crnn_dwconv_bwd_stream_rows(8, h, w, c) == 0
 
 
+def test_fp32_row_stream_and_localisation_net_shape_rules():
+    """Round 4, host arithmetic only: the fp32 forms of the row-stream kernels (rows of 18 KiB as channel ranges) take every block of the CRNN at the
+    100x32 and 200x32 shapes, with the same number of statistic rows per image band as the bf16 forms report bands; the one-workgroup-per-sample
+    localisation net takes images whose first convolution map pools into whole windows and fits LDS."""
+    L = ctypes.CDLL(native.LIB_PATH)
+    for fn in ("crnn_dwconv_fwd_stream_supported_ex", "crnn_dwconv_fwd_stream_rows_ex", "crnn_dwconv_bwd_stream_supported_ex", "crnn_dwconv_bwd_stream_rows_ex",
+               "crnn_dwconv_fwd_stream_pro_supported_ex", "crnn_dwconv_bwd_stream_pro_supported_ex", "crnn_loc_net_fused_supported"):
+        getattr(L, fn).restype = ctypes.c_int
+    L.crnn_loc_net_bwd_scratch.restype = ctypes.c_long
+    F32, BF16 = 0, 1
+    for B in (1, 64, 256):
+        for H in (104, 204):
+            for (h, w, c) in [(H, 36, 64), (H, 36, 128), (H // 2, 18, 256), (H // 2, 9, 512)]:
+                for dt in (F32, BF16):
+                    assert L.crnn_dwconv_fwd_stream_supported_ex(B, h, w, c, dt) == 0 and L.crnn_dwconv_bwd_stream_supported_ex(B, h, w, c, dt) == 0, (B, h, w, c, dt)
+                    assert L.crnn_dwconv_fwd_stream_pro_supported_ex(B, h, w, c, dt) == 0 and L.crnn_dwconv_bwd_stream_pro_supported_ex(B, h, w, c, dt) == 0
+                    for rows in (L.crnn_dwconv_fwd_stream_rows_ex(B, h, w, c, dt), L.crnn_dwconv_bwd_stream_rows_ex(B, h, w, c, dt)):
+                        assert rows >= B and rows % B == 0 and h % (rows // B) == 0
+                assert L.crnn_dwconv_fwd_stream_rows_ex(B, h, w, c, BF16) == L.crnn_dwconv_fwd_stream_rows(B, h, w, c)
+    assert L.crnn_dwconv_fwd_stream_supported_ex(8, 104, 52, 64, F32) == -3 and L.crnn_dwconv_bwd_stream_supported_ex(8, 104, 36, 1, F32) == -3
+    assert L.crnn_dwconv_fwd_stream_supported_ex(8, 104, 36, 64, 7) == -2
+    assert L.crnn_loc_net_fused_supported(100, 32) == 0 and L.crnn_loc_net_fused_supported(200, 32) == 0 and L.crnn_loc_net_fused_supported(40, 32) == 0
+    assert L.crnn_loc_net_fused_supported(60, 48) == 0
+    assert L.crnn_loc_net_fused_supported(30, 32) == -3          # first convolution map 11 x 12: an odd side, no whole pooling windows
+    assert L.crnn_loc_net_fused_supported(1000, 32) == -3        # a sample's maps beyond LDS
+    assert L.crnn_loc_net_bwd_scratch(256) == 256 * (25 * 20 * 20 + 20 + 25 * 20 + 20)
+
+
+def test_row_stream_kernels_keep_their_row_loops_spill_free():
+    """The bf16 row-stream kernels sit at their 168-register ceiling; a harmless-looking edit (an address spelled with one multiplication instead of two)
+    once put a 16-byte spill into the depthwise-stage backward's row loop and cost the kernel 22 %.  hipcc cross-compiles gfx950 without a GPU: no
+    instantiation of the two files may have scratch traffic inside a loop (scripts/check_loop_spills.sh is the same check by hand)."""
+    import re, shutil, subprocess, tempfile
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    csrc = os.path.join(os.path.dirname(native.LIB_PATH), "csrc")
+    inc = os.path.dirname(native.HEADER)
+    for src in ("dwconv_stream.hip", "dwconv_bwd_stream.hip"):
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "k.s")
+            subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", inc, "-S", "--cuda-device-only", os.path.join(csrc, src), "-o", out],
+                                  stderr=subprocess.DEVNULL)
+            text = open(out).read()
+        kernels = list(re.finditer(r"^(_ZN\S*dw_\w+_stream_kernel\S*):", text, re.M))
+        assert len(kernels) >= 7, (src, len(kernels))
+        for m in kernels:
+            body = text[m.start():text.index(".Lfunc_end", m.start())]
+            in_loop, bad = False, []
+            for line in body.split("\n"):
+                if re.match(r"^(\.LBB\S+:|; %bb\.\d+:)", line):
+                    in_loop = ("in Loop" in line) or ("Loop Header" in line)
+                if "scratch_" in line and in_loop:
+                    bad.append(line.strip())
+            assert not bad, "%s: %s spills inside a loop: %s" % (src, m.group(1), bad[:3])
+
+
 def test_model_surface_weights_roundtrip_without_gpu(tmp_path):
     init_model = U.CRNN(num_classes=38, shape=(100, 32, 1), max_string_len=23, time_dense_size=128, n_units=256)
     model = init_model.get_model()
