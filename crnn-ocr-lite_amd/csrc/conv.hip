@@ -1478,6 +1478,124 @@ __global__ __launch_bounds__(256) void pw1_wgrad_kernel(const float* __restrict_
     partials[(long)blockIdx.x * N + tid] = acc;
   }
 }
+// ---- block 1 with its depthwise BatchNorm folded into the neighbours (round 4) ---------------------------------------------------
+// The block's single-channel stage was nine launches of 5..12 us around 3.8 MB of data.  Training forward: the depthwise kernel takes its own
+// statistics (dwconv_c1_fwd_kernel), the outer product applies BatchNorm-1 + ReLU6 to d on the way in (a = relu6(fma(d, scale, shift)): the stand-alone
+// pass's arithmetic -- the activated tensor is never stored).  Backward: ONE pass over dq forms the weight gradient (from a re-formed the same way), the
+// data gradient and the statistics of BatchNorm-1's backward (sum gy, sum gy * xhat with gy = da [0 < BN(d) < 6]) -- the stand-alone kernels read dq twice
+// and d / da once more.
+template <typename T>
+__global__ __launch_bounds__(256) void pw1_bn_fwd_kernel(const float* __restrict__ d, const float* __restrict__ bn1, const float* __restrict__ w,
+                                                         T* __restrict__ q, float* __restrict__ stats, long M, int N) {
+  __shared__ float red[2][256 * 8];
+  const int CG = N / 8, RT = 256 / CG, tid = threadIdx.x, cg = tid % CG, rt = tid / CG;
+  const long r0 = (long)blockIdx.x * 128;
+  const float sc = bn1[2], sh = bn1[3];                      // [mean | var | scale | shift] of the one-channel BatchNorm
+  float wv[8], s[8], ss[8];
+  VecF<8> wl = vload<8>(w + 8 * cg);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { wv[e] = wl.v[e]; s[e] = 0.f; ss[e] = 0.f; }
+  if (rt < RT)
+    for (int r = rt; r < 128 && r0 + r < M; r += RT) {
+      const float av = relu6f(fmaf(d[r0 + r], sc, sh));
+      VecF<8> o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o.v[e] = av * wv[e];
+      vstore<8>(&q[(r0 + r) * N + 8 * cg], o);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = o.v[e];
+        if (sizeof(T) == 2) v = __uint_as_float(pack2_bf16(v, 0.f) << 16);   // the value the consumer reads back
+        s[e] += v; ss[e] = fmaf(v, v, ss[e]);
+      }
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[0][tid * 8 + e] = s[e]; red[1][tid * 8 + e] = ss[e]; }
+  __syncthreads();
+  if (tid < 2 * N) {
+    const int v = tid / N, c = tid % N;
+    float acc = 0.f;
+    for (int r = 0; r < RT; ++r) acc += red[v][(r * CG + c / 8) * 8 + (c & 7)];
+    stats[((long)blockIdx.x * 2 + v) * N + c] = acc;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void pw1_bn_bwd_kernel(const float* __restrict__ d, const float* __restrict__ bn1, const float* __restrict__ w,
+                                                         const T* __restrict__ dq, float* __restrict__ da, float* __restrict__ partials,
+                                                         float* __restrict__ bnparts, long M, int N, int rows_per_chunk) {
+  __shared__ float red[256 * 8];
+  __shared__ float sred[2][256];
+  const int CG = N / 8, RT = 256 / CG, tid = threadIdx.x, cg = tid % CG, rt = tid / CG;
+  const long r0 = (long)blockIdx.x * rows_per_chunk;
+  long r1 = r0 + rows_per_chunk; if (r1 > M) r1 = M;
+  const float mu = bn1[0], inv = 1.0f / sqrtf(bn1[1] + BN_EPS), sc = bn1[2], sh = bn1[3];
+  VecF<8> wl = vload<8>(w + 8 * cg);
+  float s[8], sg = 0.f, sq = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  if (rt < RT)
+    for (long r = r0 + rt; r < r1; r += RT) {
+      const float dv = d[r], t = fmaf(dv, sc, sh), av = relu6f(t);
+      VecF<8> g = vload<8>(&dq[r * N + 8 * cg]);
+      float acc = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] = fmaf(av, g.v[e], s[e]); acc = fmaf(g.v[e], wl.v[e], acc); }
+      for (int o = 1; o < CG; o <<= 1) acc += __shfl_xor(acc, o, 64);       // CG is a power of two <= 32: the lanes of a row (pw1_dgrad_kernel's sum)
+      if (cg == 0) {
+        da[r] = acc;
+        const float gy = (t > 0.f && t < 6.f) ? acc : 0.f;
+        sg += gy; sq = fmaf(gy, (dv - mu) * inv, sq);
+      }
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[tid * 8 + e] = s[e];
+  sred[0][tid] = sg; sred[1][tid] = sq;
+  __syncthreads();
+  if (tid < N) {
+    float acc = 0.f;
+    for (int r = 0; r < RT; ++r) acc += red[(r * CG + tid / 8) * 8 + (tid & 7)];
+    partials[(long)blockIdx.x * N + tid] = acc;
+  }
+  if (tid < 2) {                                                          // the chunk's two BatchNorm-backward sums, row lanes in order
+    float acc = 0.f;
+    for (int r = 0; r < RT; ++r) acc += sred[tid][r * CG];
+    bnparts[(long)blockIdx.x * 2 + tid] = acc;
+  }
+}
+// one-channel depthwise 3x3 forward with the statistics of its outputs: partial sums / sums of squares per block of 1024 pixels, [blocks][2]
+__global__ __launch_bounds__(256) void dwconv_c1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ k, float* __restrict__ out,
+                                                            float* __restrict__ stats, int B, int H, int W) {
+  __shared__ float red[2][256];
+  const long total = (long)B * H * W;
+  float kk[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) kk[t] = k[t];
+  float s = 0.f, ss = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long i = (long)blockIdx.x * 1024 + u * 256 + threadIdx.x;
+    if (i < total) {
+      const int w = (int)(i % W); const long r = i / W; const int h = (int)(r % H); const long b = r / H;
+      float a = 0.f;
+#pragma unroll
+      for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int gh = h + ii - 1, gw = w + j - 1;
+          if (gh >= 0 && gh < H && gw >= 0 && gw < W) a = fmaf(x[(b * H + gh) * W + gw], kk[ii * 3 + j], a);   // dwconv_naive_kernel's chain
+        }
+      out[i] = a;
+      s += a; ss = fmaf(a, a, ss);
+    }
+  }
+  red[0][threadIdx.x] = s; red[1][threadIdx.x] = ss;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) { red[0][threadIdx.x] += red[0][threadIdx.x + st]; red[1][threadIdx.x] += red[1][threadIdx.x + st]; }
+    __syncthreads();
+  }
+  if (threadIdx.x < 2) stats[(long)blockIdx.x * 2 + threadIdx.x] = red[threadIdx.x][0];
+}
 static bool pw1_ok(int N, const void* q) { return N % 8 == 0 && N <= 256 && (N & (N - 1)) == 0 && ((uintptr_t)q & 15) == 0; }
 // q [M][N] = a[M] (x) w[N]; stat_partials (may be NULL): [ceil(M/128)][2][N] like crnn_pwconv_fwd
 static int pw1_fwd_launch(const float* a, const float* w, void* q, long M, int N, float* stat_partials, const float* bn, int dt_q, hipStream_t stream) {
@@ -1512,4 +1630,38 @@ extern "C" int crnn_pw1_bwd(const float* a, const float* w, const void* dq, floa
     CRNN_LAUNCH_CHECK();
   }
   return CRNN_OK;
+}
+// Block 1's single-channel stage with BatchNorm-1 folded in (round 4; d, da fp32 [M]; in_bnstate = [mean|var|scale|shift] of the one-channel BatchNorm):
+//   crnn_dwconv3x3_c1_fwd: out = dwconv3x3(x, k[9]) on [B][H][W] and [crnn_dwconv_c1_stat_rows][2] partial sums / sums of squares of out;
+//   crnn_pw1_bn_fwd: q [M][N] = relu6(fma(d, scale, shift)) (x) w -- crnn_bn_act_pool_drop_ex + crnn_pw1_fwd without the activated tensor, same bits;
+//   crnn_pw1_bn_bwd: dw [N], da [M] as crnn_pw1_bwd on the re-formed a (same bits), and bn_stat_partials [crnn_pw1_bn_bwd_rows][2] = partial sums of gy and
+//                    gy * xhat for crnn_bn_bwd_finalize (C = 1), gy = da where 0 < BN(d) < 6; scratch: crnn_pw1_bn_bwd_rows(M) * N floats.
+extern "C" int crnn_dwconv_c1_stat_rows(int B, int H, int W) { return cdiv((long)B * H * W, 1024); }
+extern "C" int crnn_dwconv3x3_c1_fwd(const float* x, const float* k, float* out, float* stat_partials, int B, int H, int W, hipStream_t stream) {
+  if (!x || !k || !out || !stat_partials || B <= 0 || H <= 0 || W <= 0) return CRNN_ERR_ARG;
+  if ((long)B * H * W >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(dwconv_c1_fwd_kernel, dim3(crnn_dwconv_c1_stat_rows(B, H, W)), dim3(256), 0, stream, x, k, out, stat_partials, B, H, W);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+extern "C" int crnn_pw1_bn_fwd(const float* d, const float* in_bnstate, const float* w, void* q, long M, int N, float* stat_partials, int dt_q,
+                               hipStream_t stream) {
+  if (!d || !in_bnstate || !w || !q || !stat_partials) return CRNN_ERR_ARG;
+  if (!pw1_ok(N, q) || M <= 0) return CRNN_ERR_UNSUPPORTED;
+  const int blocks = cdiv(M, 128);
+  if (dt_q == CRNN_BF16) hipLaunchKernelGGL(pw1_bn_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, d, in_bnstate, w, (bf16_t*)q, stat_partials, M, N);
+  else hipLaunchKernelGGL(pw1_bn_fwd_kernel<float>, dim3(blocks), dim3(256), 0, stream, d, in_bnstate, w, (float*)q, stat_partials, M, N);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+extern "C" int crnn_pw1_bn_bwd_rows(long M) { return cdiv(M, colreduce_rpc(M)); }
+extern "C" int crnn_pw1_bn_bwd(const float* d, const float* in_bnstate, const float* w, const void* dq, float* da, float* dw, float* scratch,
+                               float* bn_stat_partials, long M, int N, int dt_q, hipStream_t stream) {
+  if (!d || !in_bnstate || !w || !dq || !da || !dw || !scratch || !bn_stat_partials) return CRNN_ERR_ARG;
+  if (!pw1_ok(N, dq) || M <= 0 || N < 8) return CRNN_ERR_UNSUPPORTED;
+  const int rpc = colreduce_rpc(M), chunks = cdiv(M, rpc);
+  if (dt_q == CRNN_BF16) hipLaunchKernelGGL(pw1_bn_bwd_kernel<bf16_t>, dim3(chunks), dim3(256), 0, stream, d, in_bnstate, w, (const bf16_t*)dq, da, scratch, bn_stat_partials, M, N, rpc);
+  else hipLaunchKernelGGL(pw1_bn_bwd_kernel<float>, dim3(chunks), dim3(256), 0, stream, d, in_bnstate, w, (const float*)dq, da, scratch, bn_stat_partials, M, N, rpc);
+  CRNN_LAUNCH_CHECK();
+  return crnn_partials_sum(scratch, chunks, N, dw, 1.f, stream);
 }

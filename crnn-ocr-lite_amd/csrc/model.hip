@@ -102,6 +102,8 @@ long lmax(long a, long b) { return a > b ? a : b; }
 bool loc_net_fused(const crnn_config* c, const Dims& d) {
   return !(c->flags & CRNN_FLAG_LOC_NET_KERNELS) && crnn_loc_net_fused_supported(d.H0, d.W0) == CRNN_OK;
 }
+// block 1's single-channel stage with BatchNorm-1 folded into the neighbouring kernels (conv.hip: crnn_dwconv3x3_c1_fwd, crnn_pw1_bn_fwd, crnn_pw1_bn_bwd)
+bool block1_fused(const crnn_config* c, int ci, int dtd) { return ci == 1 && dtd == CRNN_F32 && !(c->flags & CRNN_FLAG_BLOCK1_KERNELS); }
 bool bn2_dw_fusion_on(const crnn_config* c) {
   if (c->flags & CRNN_FLAG_NO_BN2_DW_FUSION) return false;
   return (c->flags & CRNN_FLAG_BN2_DW_FUSION) || c->mfma_bf16 != 2;
@@ -163,6 +165,7 @@ Plan make_plan(const crnn_config* c) {
     maxparts = lmax(maxparts, (long)crnn_dwconv_bwd_stream_rows(d.B, d.bh[i], d.bw[i], ci) * 9L * ci);
     maxparts = lmax(maxparts, (long)crnn_dwconv_bwd_stream_rows_ex(d.B, d.bh[i], d.bw[i], ci, CRNN_F32) * 9L * ci);
     maxparts = lmax(maxparts, (long)crnn_colreduce_chunks(M) * 2L * lmax(ci, co));
+    if (ci == 1) maxparts = lmax(maxparts, lmax((long)crnn_dwconv_c1_stat_rows(d.B, d.bh[i], d.bw[i]) * 2L, (long)crnn_pw1_bn_bwd_rows(M) * (co + 2L) + 64));
     maxparts = lmax(maxparts, (long)crnn_pwconv_stat_rows(M) * 2L * co);
     maxparts = lmax(maxparts, (long)crnn_pwconv_fwd_wres_rows(M, co, ci) * 2L * co);   // one row per IO wave and stripe lane: more rows than tiles at small batches
     maxparts = lmax(maxparts, (long)crnn_bn_bwd_chunks(M) * 2L * lmax(ci, co));
@@ -617,6 +620,9 @@ extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, cons
     } else if (ci % 32 == 0 && ci % slab == 0) {
       CRNN_TRY(crnn_dwconv3x3_fwd_ex(in, c.p(bp + "_dw"), dd, parts, B, H, W, ci, 0, dtd, stream));
       CRNN_TRY(crnn_bn_finalize_folded(parts, crnn_dwconv_num_tiles(B, H, W), ci, M, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), s1, c.w("fold"), stream));
+    } else if (block1_fused(cfg, ci, dtd)) {                           // block 1: the one-channel depthwise kernel takes its own statistics
+      CRNN_TRY(crnn_dwconv3x3_c1_fwd(in, c.p(bp + "_dw"), dd, parts, B, H, W, stream));
+      CRNN_TRY(crnn_bn_finalize(parts, crnn_dwconv_c1_stat_rows(B, H, W), ci, M, c.p(bp + "_bn1_g"), c.p(bp + "_bn1_b"), s1, stream));
     } else {
       CRNN_TRY(crnn_dwconv3x3_fwd_ex(in, c.p(bp + "_dw"), dd, nullptr, B, H, W, ci, 0, dtd, stream));
       CRNN_TRY(crnn_colreduce_ex(dd, parts, M, ci, ci, 2, dtd, stream));
@@ -625,7 +631,8 @@ extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, cons
     bn_off += ci;
     const bool fuse_a = fuse_dw_bn(cfg, dtd, dtq, ci);                  // BN + ReLU6 applied while the GEMM stages its operand
     const bool fuse_x3 = fuse_dw_bn_x3(cfg, dtd, dtq, ci) && aligned16(dd, qq, s1, c.p(bp + "_pw"));   // ... by the staging waves of the parity mode's three-plane kernel
-    if (!fuse_a && !fuse_x3) CRNN_TRY(crnn_bn_act_pool_drop_ex(dd, s1, aa, 1, 1, (int)M, ci, 1, 1, 0.f, 0, 0, dtd, dtd, stream));
+    const bool blk1 = block1_fused(cfg, ci, dtd);                       // ... by the outer product of block 1 (crnn_pw1_bn_fwd): no activated tensor either
+    if (!fuse_a && !fuse_x3 && !blk1) CRNN_TRY(crnn_bn_act_pool_drop_ex(dd, s1, aa, 1, 1, (int)M, ci, 1, 1, 0.f, 0, 0, dtd, dtd, stream));
     int stat_rows = crnn_pwconv_stat_rows(M);
     {  // pointwise conv; its epilogue also produces the batch statistics of the BatchNorm that follows
       int dtw = CRNN_F32, wt = 0;
@@ -634,7 +641,8 @@ extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, cons
         wq = reinterpret_cast<const float*>(reinterpret_cast<const bf16_t*>(c.w("pwT")) + pwT_off[i]);
         dtw = CRNN_BF16; wt = 1;
       }
-      if (ci == 1 && dtd == CRNN_F32) CRNN_TRY(crnn_pw1_fwd(aa, c.p(bp + "_pw"), qq, M, co, parts, dtq, stream));   // block 1: outer product
+      if (blk1) CRNN_TRY(crnn_pw1_bn_fwd(dd, s1, c.p(bp + "_pw"), qq, M, co, parts, dtq, stream));                      // block 1: outer product of relu6(BN(d))
+      else if (ci == 1 && dtd == CRNN_F32) CRNN_TRY(crnn_pw1_fwd(aa, c.p(bp + "_pw"), qq, M, co, parts, dtq, stream));
       else if (fuse_x3) CRNN_TRY(crnn_pwconv_bnrelu6_fwd_f32x3(dd, s1, c.p(bp + "_pw"), qq, M, co, ci, parts, stream));
       else if (fuse_a) {
         // weights resident in registers, IO waves transform / drain / take the statistics (gemm_wres.hip) where its shape rules hold
@@ -962,7 +970,12 @@ int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t au
     } else
     CRNN_TRY(crnn_bn_bwd_ex(c.w("q" + p), gA, c.w("bn2s" + p), c.p(bp + "_bn2_g"), gB, c.g(bp + "_bn2_g"), c.g(bp + "_bn2_b"), c.w("partials"),
                             c.w("coef"), B, H, W, co, kBlocks[i - 1].ph, kBlocks[i - 1].pw, cfg->dropout ? kDropBlock : 0.f, seed, (uint32_t)i, dtq, stream));
-    if (ci == 1 && dtd == CRNN_F32) {   // block 1: outer-product weight / data gradients
+    if (block1_fused(cfg, ci, dtd)) {   // block 1: weight gradient, data gradient and BatchNorm-1's backward statistics from one pass over dq
+      const int rows = crnn_pw1_bn_bwd_rows(M);
+      float* bnp = c.w("partials");       // [rows][2] for the finalize below; the weight-gradient partials behind them
+      CRNN_TRY(crnn_pw1_bn_bwd(c.w("d" + p), c.w("bn1s" + p), c.p(bp + "_pw"), gB, gA, c.g(bp + "_pw"), bnp + ((2L * rows + 63) & ~63L), bnp, M, co, dtq, stream));
+      bn1_stats_rows = rows;
+    } else if (ci == 1 && dtd == CRNN_F32) {   // block 1: outer-product weight / data gradients
       CRNN_TRY(crnn_pw1_bwd(c.w("a" + p), c.p(bp + "_pw"), gB, gA, c.g(bp + "_pw"), c.w("partials"), M, co, dtq, stream));
     } else {
       const bool side = fj.on && fused_dw;

@@ -41,6 +41,9 @@ typedef struct {
                        conv-stack activations / gradients are stored as bf16 in HBM (statistics, RNN, CTC, optimizer fp32) */
   int flags;        /* bit set of CRNN_FLAG_* (0 = the default schedule); A/B switches: bit-identical results except where a flag says otherwise */
 } crnn_config;
+#define CRNN_FLAG_BLOCK1_KERNELS 16384 /* training: block 1's single-channel stage as its stand-alone kernels (depthwise conv, column statistics, BatchNorm-1 apply,
+                                         * outer product; backward: weight gradient, data gradient and BatchNorm-1 statistics as three passes) instead of
+                                         * crnn_dwconv3x3_c1_fwd / crnn_pw1_bn_fwd / crnn_pw1_bn_bwd; the same values with BatchNorm-1's statistics summed in another order */
 #define CRNN_FLAG_LOC_NET_KERNELS 8192  /* spatial transformer: the localisation net as its stand-alone kernels (five launches forward, about ten backward) instead of
                                          * crnn_loc_net_fwd / crnn_loc_net_bwd (one workgroup per sample); forward bit-identical, the localisation net's weight
                                          * gradients the same sums in another order */
@@ -240,6 +243,17 @@ int crnn_pw1_fwd(const float* a, const float* w, void* q, long M, int N, float* 
 int crnn_pw1_fwd_folded(const float* a, const float* w, void* y, long M, int N, const float* out_bnstate, int dt_y, crnn_stream_t stream);
 int crnn_pw1_bwd(const float* a, const float* w, const void* dq, float* da, float* dw, float* scratch, long M, int N, int dt_q,
                  crnn_stream_t stream);
+/* Round 4: block 1's single-channel stage with its BatchNorm-1 folded into the neighbouring kernels (d, da fp32 [M]; in_bnstate = [mean|var|scale|shift] of the
+ * one-channel BatchNorm).  crnn_dwconv3x3_c1_fwd: out = dwconv3x3(x, k[9]) on [B][H][W] + [crnn_dwconv_c1_stat_rows][2] partial sums / sums of squares of out.
+ * crnn_pw1_bn_fwd: q [M][N] = relu6(fma(d, scale, shift)) (x) w -- crnn_bn_act_pool_drop_ex + crnn_pw1_fwd without the activated tensor, the same bits.
+ * crnn_pw1_bn_bwd: ONE pass over dq -> dw [N] and da [M] (crnn_pw1_bwd's bits on the re-formed activation) and bn_stat_partials [crnn_pw1_bn_bwd_rows(M)][2] =
+ * partial sums of gy and gy * xhat, gy = da where 0 < BN(d) < 6, for crnn_bn_bwd_finalize (C = 1); scratch: crnn_pw1_bn_bwd_rows(M) * N floats. */
+int crnn_dwconv_c1_stat_rows(int B, int H, int W);
+int crnn_dwconv3x3_c1_fwd(const float* x, const float* k, float* out, float* stat_partials, int B, int H, int W, crnn_stream_t stream);
+int crnn_pw1_bn_fwd(const float* d, const float* in_bnstate, const float* w, void* q, long M, int N, float* stat_partials, int dt_q, crnn_stream_t stream);
+int crnn_pw1_bn_bwd_rows(long M);
+int crnn_pw1_bn_bwd(const float* d, const float* in_bnstate, const float* w, const void* dq, float* da, float* dw, float* scratch, float* bn_stat_partials,
+                    long M, int N, int dt_q, crnn_stream_t stream);
 /* Depthwise 3x3 with the inference BatchNorm + ReLU6 after it (utils.py:44-46) folded into the epilogue:
  * out = ReLU6(dwconv3x3(x, k) * scale + shift); C must be a multiple of 32 (fp32 storage) / 64 (bf16 storage). */
 int crnn_dwconv3x3_bn_relu6_fwd(const void* x, const float* k, const float* bnstate, void* out, int B, int H, int W, int C,

@@ -38,13 +38,11 @@ def masks_from_engine(eng, cfg, seed):
 
 
 def device_activation(eng, i, cin):
-    """a_i = ReLU6(BatchNorm_1(d_i)) of block i as the device forms it.  Block 1 writes it; from block 2 on the pointwise GEMMs apply the
+    """a_i = ReLU6(BatchNorm_1(d_i)) of block i as the device forms it: the pointwise kernels apply the
     BatchNorm + ReLU6 while they stage d (no `a` tensor in HBM): relu6(fma(d, scale, shift)) -- exact product + one rounding -- from the
     device's own d and BatchNorm state, the arithmetic of the staging waves."""
     f64 = lambda name: eng.ws_tensor(name).float().cpu().numpy().astype(np.float64)
-    if i == 1:
-        return f64("a1")
-    s1 = f64(f"bn1s{i}")
+    s1 = f64(f"bn1s{i}")     # (block 1 too since round 4: its outer product applies the BatchNorm to d on the way in)
     y = (f64(f"d{i}").reshape(-1, cin) * s1[2 * cin:3 * cin] + s1[3 * cin:4 * cin]).astype(np.float32).astype(np.float64)
     return np.minimum(np.maximum(y, 0), 6)
 
@@ -341,6 +339,36 @@ def test_step_does_not_depend_on_workspace_contents(precision, shape):
         assert torch.equal(a, b)
     for a, b in zip(runs[0], runs[2]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16s"])
+def test_block1_folded_batchnorm_kernels_equal_the_standalone_kernels(precision):
+    """Block 1's single-channel stage with BatchNorm-1 folded into the neighbouring kernels (default, round 4) against its stand-alone kernels
+    (CRNN_FLAG_BLOCK1_KERNELS): the same arithmetic with BatchNorm-1's forward and backward statistics summed in another order -- posteriors, loss and
+    gradients agree to that round-off (re-rounded through bf16 tensors in the throughput mode)."""
+    from crnn_mi355x import native
+    B, imgh, imgw, ncls, max_len, tds, u = 6, 100, 32, 38, 23, 128, 256
+    cfg = M.Config(imgh=imgh, imgw=imgw, max_len=max_len, time_dense_size=tds, n_units=u, num_classes=ncls)
+    p, bn = M.init_params(cfg, seed=6, dtype=np.float64)
+    p = M.randomize_params(cfg, p)
+    x, lab, il, ll = M.synthetic_batch(cfg, B, seed=4, dtype=np.float64)
+    out = {}
+    for flags in (0, native.FLAG_BLOCK1_KERNELS):
+        eng = Engine(B, imgh, imgw, ncls, max_len, tds, u, stn=True, dropout=True, precision=precision, flags=flags)
+        eng.set_params(p, bn)
+        eng.ws.fill_(float("nan")); eng.grads.zero_()
+        y = eng.forward(x.astype(np.float32), train=True, seed=5).clone()
+        loss = eng.backward(lab, il, ll, seed=5).clone()
+        out[flags] = (y, loss, eng.grads.clone(), eng.ws_tensor("d1").clone(), eng.ws_tensor("bn1s1").clone())
+        del eng
+    (y0, l0, g0, d0, s0), (y1, l1, g1, d1, s1) = out[0], out[native.FLAG_BLOCK1_KERNELS]
+    assert torch.equal(d0, d1)                                            # the depthwise outputs: the same chain
+    assert float((s0 - s1).abs().max()) <= 1e-5 * float(s1.abs().max())  # BatchNorm-1 state: sums in another order
+    tol = 1e-5 if precision == "fp32" else 2e-2
+    assert torch.isfinite(g0).all() and float((y0 - y1).abs().max()) <= tol and float(((l0 - l1).abs() / l1.abs().clamp_min(1.0)).max()) <= tol
+    rel = float((g0.double() - g1.double()).norm() / g1.double().norm())
+    print("block 1 folded vs stand-alone (%s): max |dy| %.3g, gradient rel L2 %.3g" % (precision, float((y0 - y1).abs().max()), rel))
+    assert rel < (1e-3 if precision == "fp32" else 0.3), rel
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16s"])

@@ -1907,6 +1907,61 @@ def test_localisation_net_direct_conv_kernels(cin, H, W):
     assert L().crnn_loc_conv_fwd(P(dev(x)), P(dev(k)), P(dev(b)), P(y), B, H, W, 3, S()) == -3
 
 
+@pytest.mark.parametrize("B,H,W,N,bf", [(3, 104, 36, 64, True), (256, 104, 36, 64, True), (5, 44, 36, 64, False), (2, 204, 36, 64, False), (1, 7, 5, 64, True)])
+def test_block1_kernels_with_batchnorm1_folded_in(B, H, W, N, bf):
+    """crnn_dwconv3x3_c1_fwd, crnn_pw1_bn_fwd, crnn_pw1_bn_bwd (round 4): block 1's single-channel depthwise conv with its own statistics, the outer
+    product applying BatchNorm-1 + ReLU6 to d on the way in, and ONE backward pass over dq for weight gradient, data gradient and BatchNorm-1's backward
+    statistics -- against the stand-alone kernels (outputs bit for bit; the statistics the same sums in another order) and the fp64 oracle."""
+    rs = np.random.RandomState(B + H + W)
+    x = rs.normal(size=(B, H, W, 1)); k = rs.normal(size=(3, 3, 1)); w = rs.normal(size=N) * 0.3
+    xd, kd, wd = dev(x), dev(k), dev(w)
+    M = B * H * W
+    # depthwise conv + statistics
+    d_ref = zeros(B, H, W, 1)
+    ok(L().crnn_dwconv3x3_fwd_ex(P(xd), P(kd), P(d_ref), None, B, H, W, 1, 0, 0, S()))
+    rows = L().crnn_dwconv_c1_stat_rows(B, H, W)
+    d = torch.full((M + 8,), 7.0, device="cuda"); parts = torch.full((rows + 1, 2), 3.0, device="cuda")
+    ok(L().crnn_dwconv3x3_c1_fwd(P(xd), P(kd), P(d), P(parts), B, H, W, S()))
+    assert torch.equal(d[:-8], d_ref.reshape(-1)) and bool((d[-8:] == 7.0).all()) and bool((parts[rows] == 3.0).all())
+    dn = host(d_ref).reshape(-1)
+    assert_close(host(parts[:rows]).sum(0), np.array([dn.sum(), (dn ** 2).sum()]), rtol=1e-4, atol=1e-3, what="statistics")
+    assert_close(dn.reshape(B, H, W, 1), ops.dwconv_fwd(x, k), what="d vs oracle")
+    # outer product of relu6(BN(d))
+    mean, var = dn.mean(), dn.var(); gamma, beta = 1.3, 1.1
+    scale = gamma / np.sqrt(var + 1e-3); st = dev(np.array([mean, var, scale, beta - mean * scale]))
+    a = zeros(M)
+    ok(L().crnn_bn_act_pool_drop_ex(P(d_ref), P(st), P(a), 1, 1, M, 1, 1, 1, 0.0, 0, 0, 0, 0, S()))
+    dtq = 1 if bf else 0
+    mk = (lambda *sh: torch.zeros(*sh, dtype=torch.bfloat16, device="cuda")) if bf else zeros
+    srows = L().crnn_pwconv_stat_rows(M)
+    q1 = mk(M, N); p1 = zeros(srows, 2, N); q2 = mk(M, N); p2 = zeros(srows, 2, N)
+    ok(L().crnn_pw1_fwd(P(a), P(wd), P(q1), M, N, P(p1), dtq, S()))
+    ok(L().crnn_pw1_bn_fwd(P(d_ref), P(st), P(wd), P(q2), M, N, P(p2), dtq, S()))
+    assert torch.equal(q1.view(torch.int16 if bf else torch.int32), q2.view(torch.int16 if bf else torch.int32))
+    if bf:
+        assert torch.equal(p1, p2)                      # statistics of the values as stored (re-rounded): the same sums
+    else:                                               # fp32: the compiler may contract product + sum differently in the two kernels (last-bit differences)
+        assert_close(host(p2), host(p1), rtol=1e-5, atol=1e-5 * float(p1.abs().max()), what="BatchNorm-2 statistic partials")
+    # backward: one pass over dq
+    dq = (torch.randn(M, N, device="cuda", generator=torch.Generator("cuda").manual_seed(3)) * 0.5)
+    dq = dq.to(torch.bfloat16) if bf else dq
+    chunks = L().crnn_colreduce_chunks(M)
+    da1 = zeros(M); dw1 = zeros(N); sc1 = zeros(chunks * N)
+    ok(L().crnn_pw1_bwd(P(a), P(wd), P(dq), P(da1), P(dw1), P(sc1), M, N, dtq, S()))
+    brow = L().crnn_pw1_bn_bwd_rows(M)
+    assert brow == chunks
+    da2 = torch.full((M + 8,), 9.0, device="cuda"); dw2 = zeros(N); sc2 = zeros(brow * N); bp = torch.full((brow + 1, 2), 5.0, device="cuda")
+    ok(L().crnn_pw1_bn_bwd(P(d_ref), P(st), P(wd), P(dq), P(da2), P(dw2), P(sc2), P(bp), M, N, dtq, S()))
+    assert torch.equal(da2[:-8], da1) and torch.equal(dw2, dw1) and bool((da2[-8:] == 9.0).all()) and bool((bp[brow] == 5.0).all())
+    # ... and the BatchNorm-1 backward statistics against the stand-alone statistics pass
+    dg1, db1, coef1 = zeros(1), zeros(1), zeros(2); gin = zeros(M); pp = zeros(max(L().crnn_bn_bwd_chunks(M), 1) * 2 + 64); gam = dev(np.array([gamma]))
+    ok(L().crnn_bn_bwd_ex(P(d_ref), P(da1), P(st), P(gam), P(gin), P(dg1), P(db1), P(pp), P(coef1), B, H, W, 1, 1, 1, 0.0, 0, 0, 0, S()))
+    dg2, db2, coef2 = zeros(1), zeros(1), zeros(2)
+    ok(L().crnn_bn_bwd_finalize(P(bp), brow, 1, M, P(dg2), P(db2), P(coef2), S()))
+    for u, v, nm in ((db2, db1, "sum gy"), (dg2, dg1, "sum gy xhat"), (coef2, coef1, "coefficients")):
+        assert_close(host(u), host(v), rtol=2e-4, atol=2e-5 * max(1.0, float(v.abs().max())), what=nm)
+
+
 @pytest.mark.parametrize("B,H0,W0", [(7, 100, 32), (256, 100, 32), (3, 200, 32), (5, 40, 32), (2, 60, 48)])
 def test_localisation_net_in_one_workgroup_per_sample(B, H0, W0):
     """crnn_loc_net_fwd / crnn_loc_net_bwd (round 4): the spatial transformer's localisation net (utils.py:248-256) with one workgroup per sample.
