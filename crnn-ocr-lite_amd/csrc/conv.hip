@@ -1596,6 +1596,72 @@ __global__ __launch_bounds__(256) void dwconv_c1_fwd_kernel(const float* __restr
   }
   if (threadIdx.x < 2) stats[(long)blockIdx.x * 2 + threadIdx.x] = red[threadIdx.x][0];
 }
+// one-channel depthwise stage backwards in one kernel: dd = BatchNorm-1 backward pass 2 of (d, da) (bn_bwd_kernel<2>'s arithmetic) formed ONCE per pixel of the
+// block's 1024 pixels and a halo of W + 1 on either side into LDS, the input x beside it; dx = correlation of dd with the mirrored taps
+// (dwconv_naive_kernel<0>, flip: the same chain), dk partials per block
+#define C1B_PIX 1024
+#define C1B_MAXW 255
+__global__ __launch_bounds__(256) void dwconv_c1_bwd_kernel(const float* __restrict__ d, const float* __restrict__ da, const float* __restrict__ bn1,
+                                                            const float* __restrict__ coef, const float* __restrict__ x, const float* __restrict__ k,
+                                                            float* __restrict__ dx, float* __restrict__ partials, int B, int H, int W) {
+  __shared__ float ddl[C1B_PIX + 2 * (C1B_MAXW + 1)];
+  __shared__ float xl[C1B_PIX + 2 * (C1B_MAXW + 1)];
+  __shared__ float red[9][256];
+  const long total = (long)B * H * W;
+  const float mu = bn1[0], inv = 1.0f / sqrtf(bn1[1] + BN_EPS), sc = bn1[2], sh = bn1[3];
+  float P, Q;
+  bn_bwd_pq(sc, coef[0], coef[1], mu, inv, P, Q);
+  float kk[9], acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) { kk[t] = k[t]; acc[t] = 0.f; }
+  const long p0 = (long)blockIdx.x * C1B_PIX - (W + 1);            // first pixel of the staged range
+  const int nst = C1B_PIX + 2 * (W + 1);
+  for (int i = threadIdx.x; i < nst; i += 256) {
+    const long p = p0 + i;
+    float g = 0.f, xv = 0.f;
+    if (p >= 0 && p < total) {
+      const float dv = d[p], t = fmaf(dv, sc, sh);
+      const float gy = (t > 0.f && t < 6.f) ? da[p] : 0.f;
+      g = bn_bwd_dx_pq(dv, gy, sc, P, Q);
+      xv = x[p];
+    }
+    ddl[i] = g; xl[i] = xv;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int li = u * 256 + threadIdx.x;
+    const long p = (long)blockIdx.x * C1B_PIX + li;
+    if (p < total) {
+      const int w = (int)(p % W); const long r = p / W; const int h = (int)(r % H);
+      const int c = li + W + 1;                                      // this pixel inside the staged range
+      const float g0 = ddl[c];
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int gh = h + i - 1, gw = w + j - 1;
+          if (gh >= 0 && gh < H && gw >= 0 && gw < W) {
+            const int cn = c + (i - 1) * W + (j - 1);
+            acc[i * 3 + j] = fmaf(xl[cn], g0, acc[i * 3 + j]);        // dwconv_wgrad_c1_kernel's term
+            a = fmaf(ddl[cn], kk[8 - (i * 3 + j)], a);
+          }
+        }
+      if (dx) dx[p] = a;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) red[t][threadIdx.x] = acc[t];
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if (threadIdx.x < s2)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) red[t][threadIdx.x] += red[t][threadIdx.x + s2];
+    __syncthreads();
+  }
+  if (threadIdx.x < 9) partials[(long)blockIdx.x * 9 + threadIdx.x] = red[threadIdx.x][0];
+}
 static bool pw1_ok(int N, const void* q) { return N % 8 == 0 && N <= 256 && (N & (N - 1)) == 0 && ((uintptr_t)q & 15) == 0; }
 // q [M][N] = a[M] (x) w[N]; stat_partials (may be NULL): [ceil(M/128)][2][N] like crnn_pwconv_fwd
 static int pw1_fwd_launch(const float* a, const float* w, void* q, long M, int N, float* stat_partials, const float* bn, int dt_q, hipStream_t stream) {
@@ -1653,6 +1719,18 @@ extern "C" int crnn_pw1_bn_fwd(const float* d, const float* in_bnstate, const fl
   else hipLaunchKernelGGL(pw1_bn_fwd_kernel<float>, dim3(blocks), dim3(256), 0, stream, d, in_bnstate, w, (float*)q, stat_partials, M, N);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
+}
+//   crnn_dwconv3x3_c1_bwd: the one-channel depthwise stage backwards in one kernel -- crnn_bn_bwd_apply_ex (coef from crnn_bn_bwd_finalize) + crnn_dwconv3x3_wgrad_ex +
+//                    crnn_dwconv3x3_fwd_ex(flip = 1): dx [B][H][W] (NULL: not wanted) bit-identical, dk [9] to the order of its partial sums; scratch: rows * 9 floats.
+extern "C" int crnn_dwconv_c1_bwd_rows(int B, int H, int W) { return cdiv((long)B * H * W, 1024); }
+extern "C" int crnn_dwconv3x3_c1_bwd(const float* d, const float* da, const float* bnstate, const float* coef, const float* x, const float* k, float* dx, float* dk,
+                                     float* scratch, int B, int H, int W, hipStream_t stream) {
+  if (!d || !da || !bnstate || !coef || !x || !k || !dk || !scratch || B <= 0 || H <= 0 || W <= 0) return CRNN_ERR_ARG;
+  if ((long)B * H * W >= (1L << 31) || W > C1B_MAXW) return CRNN_ERR_UNSUPPORTED;
+  const int rows = crnn_dwconv_c1_bwd_rows(B, H, W);
+  hipLaunchKernelGGL(dwconv_c1_bwd_kernel, dim3(rows), dim3(256), 0, stream, d, da, bnstate, coef, x, k, dx, scratch, B, H, W);
+  CRNN_LAUNCH_CHECK();
+  return crnn_partials_sum(scratch, rows, 9, dk, 1.f, stream);
 }
 extern "C" int crnn_pw1_bn_bwd_rows(long M) { return cdiv(M, colreduce_rpc(M)); }
 extern "C" int crnn_pw1_bn_bwd(const float* d, const float* in_bnstate, const float* w, const void* dq, float* da, float* dw, float* scratch,

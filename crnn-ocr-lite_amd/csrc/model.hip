@@ -103,7 +103,7 @@ bool loc_net_fused(const crnn_config* c, const Dims& d) {
   return !(c->flags & CRNN_FLAG_LOC_NET_KERNELS) && crnn_loc_net_fused_supported(d.H0, d.W0) == CRNN_OK;
 }
 // block 1's single-channel stage with BatchNorm-1 folded into the neighbouring kernels (conv.hip: crnn_dwconv3x3_c1_fwd, crnn_pw1_bn_fwd, crnn_pw1_bn_bwd)
-bool block1_fused(const crnn_config* c, int ci, int dtd) { return ci == 1 && dtd == CRNN_F32 && !(c->flags & CRNN_FLAG_BLOCK1_KERNELS); }
+bool block1_fused(const crnn_config* c, int ci, int dtd) { return ci == 1 && dtd == CRNN_F32 && !(c->flags & CRNN_FLAG_BLOCK1_KERNELS) && c->imgw + 4 <= 255; }
 bool bn2_dw_fusion_on(const crnn_config* c) {
   if (c->flags & CRNN_FLAG_NO_BN2_DW_FUSION) return false;
   return (c->flags & CRNN_FLAG_BN2_DW_FUSION) || c->mfma_bf16 != 2;
@@ -1062,6 +1062,13 @@ int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t au
       // the block below finds its incoming gradient in gA, writes gB; this block's side-stream GEMM may still read the old gB
       float* t = gA; gA = gC; gC = gB; gB = t;
       gC_free = gB_free; gB_free = nullptr;
+      continue;
+    }
+    if (bn1_stats_rows > 0 && block1_fused(cfg, ci, dtd)) {   // block 1: finalize, then pass 2 + both depthwise gradients in one kernel
+      CRNN_TRY(crnn_bn_bwd_finalize_folded(c.w("partials"), bn1_stats_rows, ci, M, c.g(bp + "_bn1_g"), c.g(bp + "_bn1_b"), c.w("coef"), c.w("fold"), stream));
+      CRNN_TRY(crnn_dwconv3x3_c1_bwd(c.w("d" + p), gA, c.w("bn1s" + p), c.w("coef"), xin, c.p(bp + "_dw"), (i > 1 || cfg->stn) ? gB : nullptr, c.g(bp + "_dw"),
+                                     c.w("partials"), B, H, W, stream));
+      if (i > 1 || cfg->stn) { float* t = gA; gA = gB; gB = t; }   // (the spatial transformer's backward finds d loss / d x0 in gA)
       continue;
     }
     if (bn1_stats_rows > 0) {   // statistics from the data-gradient GEMM: finalize, then pass 2 alone

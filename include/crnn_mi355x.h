@@ -251,6 +251,11 @@ int crnn_pw1_bwd(const float* a, const float* w, const void* dq, float* da, floa
 int crnn_dwconv_c1_stat_rows(int B, int H, int W);
 int crnn_dwconv3x3_c1_fwd(const float* x, const float* k, float* out, float* stat_partials, int B, int H, int W, crnn_stream_t stream);
 int crnn_pw1_bn_fwd(const float* d, const float* in_bnstate, const float* w, void* q, long M, int N, float* stat_partials, int dt_q, crnn_stream_t stream);
+/* crnn_dwconv3x3_c1_bwd: the one-channel depthwise stage backwards in ONE kernel = crnn_bn_bwd_apply_ex (coef from crnn_bn_bwd_finalize) + crnn_dwconv3x3_wgrad_ex +
+ * crnn_dwconv3x3_fwd_ex(flip = 1); dx [B][H][W] (NULL: not wanted) bit-identical, dk [9] to the order of its partial sums; scratch: crnn_dwconv_c1_bwd_rows * 9 floats */
+int crnn_dwconv_c1_bwd_rows(int B, int H, int W);
+int crnn_dwconv3x3_c1_bwd(const float* d, const float* da, const float* bnstate, const float* coef, const float* x, const float* k, float* dx, float* dk,
+                          float* scratch, int B, int H, int W, crnn_stream_t stream);
 int crnn_pw1_bn_bwd_rows(long M);
 int crnn_pw1_bn_bwd(const float* d, const float* in_bnstate, const float* w, const void* dq, float* da, float* dw, float* scratch, float* bn_stat_partials,
                     long M, int N, int dt_q, crnn_stream_t stream);

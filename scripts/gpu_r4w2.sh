@@ -8,4 +8,4 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r4w2_pr
 f=$(find $OUT/r4w2_prof -name "*kernel_trace.csv" | head -1)
 python $ROOT/scripts/trace_step.py $f > $OUT/r4w2_step_timeline.txt
 rm -rf $OUT/r4w2_prof
-grep -n "loc_\|sampler\|maxpool\|step span" $OUT/r4w2_step_timeline.txt | head -20
+grep -n "loc_\|sampler\|c1_\|pw1_\|dwconv_naive\|step span" $OUT/r4w2_step_timeline.txt | head -20

@@ -1960,6 +1960,20 @@ def test_block1_kernels_with_batchnorm1_folded_in(B, H, W, N, bf):
     ok(L().crnn_bn_bwd_finalize(P(bp), brow, 1, M, P(dg2), P(db2), P(coef2), S()))
     for u, v, nm in ((db2, db1, "sum gy"), (dg2, dg1, "sum gy xhat"), (coef2, coef1, "coefficients")):
         assert_close(host(u), host(v), rtol=2e-4, atol=2e-5 * max(1.0, float(v.abs().max())), what=nm)
+    # the depthwise stage backwards in one kernel: BatchNorm-1 backward pass 2 (gin above) + weight gradient + data gradient
+    dk1 = zeros(9); scw = zeros(max(L().crnn_dwconv_num_tiles(B, H, W) * 9, 1024 * 9) + 64)
+    ok(L().crnn_dwconv3x3_wgrad_ex(P(xd), P(gin), P(dk1), P(scw), B, H, W, 1, 0, S()))
+    dx1 = zeros(M)
+    ok(L().crnn_dwconv3x3_fwd_ex(P(gin), P(kd), P(dx1), None, B, H, W, 1, 1, 0, S()))
+    crow = L().crnn_dwconv_c1_bwd_rows(B, H, W)
+    dx2 = torch.full((M + 8,), 9.0, device="cuda"); dk2 = zeros(9); sc3 = torch.full((crow * 9 + 8,), 5.0, device="cuda")
+    ok(L().crnn_dwconv3x3_c1_bwd(P(d_ref), P(da1), P(st), P(coef1), P(xd), P(kd), P(dx2), P(dk2), P(sc3), B, H, W, S()))
+    assert torch.equal(dx2[:-8], dx1), "dx: max diff %g" % float((dx2[:-8] - dx1).abs().max())
+    assert bool((dx2[-8:] == 9.0).all()) and bool((sc3[-8:] == 5.0).all())
+    assert_close(host(dk2), host(dk1), rtol=1e-4, atol=1e-5 * max(1.0, float(dk1.abs().max())), what="dk")
+    dk3 = zeros(9)
+    ok(L().crnn_dwconv3x3_c1_bwd(P(d_ref), P(da1), P(st), P(coef1), P(xd), P(kd), None, P(dk3), P(sc3), B, H, W, S()))
+    assert torch.equal(dk3, dk2)
 
 
 @pytest.mark.parametrize("B,H0,W0", [(7, 100, 32), (256, 100, 32), (3, 200, 32), (5, 40, 32), (2, 60, 48)])
