@@ -51,11 +51,11 @@ typedef struct {
                                          * kernels; half the elements per byte leave them bandwidth-bound: -0.6 ms of 14.8 per step at batch 256): block outputs
                                          * materialised, BatchNorm-2's backward statistics as a pass of their own.  Forward / data gradients bit-identical,
                                          * BatchNorm-2 gradients the same sums in another order */
-#define CRNN_FLAG_BN2_STATS_FUSION 2048 /* opt-in (with the fusion below): statistics pass of the block outputs' BatchNorm-2 backward inside the next block's
+#define CRNN_FLAG_BN2_STATS_FUSION 2048 /* bf16 tensors: opt-in (fp32 tensors: the default, see CRNN_FLAG_NO_BN2_DW_FUSION; the statistics in the DX waves) -- with the fusion below: statistics pass of the block outputs' BatchNorm-2 backward inside the next block's
                                          * depthwise-stage backward (crnn_dwconv3x3_bwd_stream_pro with bn2_stat_partials: a twelfth wave) instead of a kernel of
                                          * its own (crnn_bn_bwd_ex); same data gradients bit for bit, BatchNorm-2 gradients / coefficients the same sums in another
                                          * order.  Measured neutral (the pass it removes costs 0.28 ms, the depthwise-stage kernels grow by 0.24): not the default */
-#define CRNN_FLAG_BN2_DW_FUSION 1024  /* opt-in, bf16-storage training: the output x = Dropout(ReLU6(BatchNorm-2(q))) of the un-pooled blocks 1, 2, 4, 6 is not
+#define CRNN_FLAG_BN2_DW_FUSION 1024  /* bf16-storage training: opt-in (fp32 storage: the default schedule, CRNN_FLAG_NO_BN2_DW_FUSION switches it off): the output x = Dropout(ReLU6(BatchNorm-2(q))) of the un-pooled blocks 1, 2, 4, 6 is not
                                          * materialised (crnn_bn_act_pool_drop_ex); the NEXT block's depthwise row-stream kernels apply it to q in LDS
                                          * (crnn_dwconv3x3_fwd_stream_pro, forward; crnn_dwconv3x3_bwd_stream_pro re-forms it in backward; the dropout decisions
                                          * as keep bytes, crnn_dropout_keep_bytes_batch on the side stream).  Bit-identical.  4 of the 8 BatchNorm-apply launches
@@ -64,9 +64,11 @@ typedef struct {
 #define CRNN_FLAG_DW_TILE_KERNEL 32    /* bf16-storage modes: depthwise 3x3 forward and fused depthwise-stage backward on the halo-tile kernels
                                         * (crnn_dwconv3x3_fwd_ex, crnn_dwconv3x3_bwd_fused) instead of the row-stream kernels (crnn_dwconv3x3_fwd_stream,
                                         * crnn_dwconv3x3_bwd_stream); tensors bit-identical, BatchNorm statistics / depthwise weight gradients to
-                                        * summation round-off */
+                                        * summation round-off.  fp32 storage (round 4): the round-3 schedule -- halo-tile forward, three-kernel depthwise-stage
+                                        * backward, every BatchNorm-2 pass on its own -- instead of the fp32 forms of the row-stream kernels */
 #define CRNN_FLAG_NO_DW_BWD_FUSION 16 /* bf16-storage training: depthwise-stage backward as three kernels (BatchNorm backward pass 2, depthwise weight
-                                         gradient, depthwise data gradient) instead of crnn_dwconv3x3_bwd_fused; same data gradients bit for bit */
+                                         gradient, depthwise data gradient) instead of crnn_dwconv3x3_bwd_fused / crnn_dwconv3x3_bwd_stream[_ex] (either
+                                         storage type; also switches the BatchNorm-2 fusions off); same data gradients bit for bit */
 #define CRNN_FLAG_NO_DW_BN_FUSION 8   /* bf16-storage training: materialise a = ReLU6(BN(d)) in a pass of its own instead of applying it while the
                                          pointwise GEMMs stage their operand; bit-identical */
 #define CRNN_FLAG_GEMM_TILE_KERNELS 2 /* every pointwise conv of the conv stack (forward, data gradient, weight gradient) on the tile-per-workgroup
