@@ -178,6 +178,7 @@ Plan make_plan(const crnn_config* c) {
     for (const char* dir : {"f", "b"}) {
       P.add("xw" + p + dir, TB * d.G); P.add("cs" + p + dir, TB * d.u); P.add("gt" + p + dir, TB * d.G);
       P.add("ut" + p + dir, (long)d.G * d.u); P.add("dz" + p + dir, TB * d.G);
+      if (!c->gru) P.add("dbp" + p + dir, (long)crnn_rnn_db_rows((int)B) * d.G);   // bias-gradient partials of the persistent LSTM backward (one row per 16-row batch tile)
       P.add("wt" + p + dir, (long)d.G * (l == 1 ? d.tds : d.u));   // bf16 W^T of the input projection (streaming xw kernel), oversized by 2
     }
   }
@@ -749,6 +750,15 @@ extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, cons
 // One Bidirectional layer's backward in three pieces so that the caller can put the weight-gradient GEMMs on a second
 // stream: (1) the BPTT chain (T dependent step launches, latency-bound), (2) dW/dU/db from the finished dz (throughput
 // work nobody downstream of the chain waits for), (3) dX = dZ W^T (what the layer below needs).
+// the persistent LSTM backward of layer `layer` runs (and leaves the bias-gradient partials "dbp<layer>f/b"): one decision for rnn_bwd_chain and rnn_bwd_wgrads
+static bool lstm_bwd_persistent(const Ctx& c, int layer) {
+  if (c.cfg->gru || !rnn_persist(c.cfg)) return false;
+  std::string l = std::to_string(layer);
+  int dtu = CRNN_F32;
+  const float* uf = c.p("rnn" + l + "f_u"); const float* ub = c.p("rnn" + l + "b_u");
+  if (c.cfg->mfma_bf16 && c.d.u % 128 == 0) { uf = weight_operand(c, 0, uf, &dtu); ub = weight_operand(c, 0, ub, &dtu); }
+  return !(((uintptr_t)uf | (uintptr_t)ub) & 15) && c.P.off("dbp" + l + "f") >= 0;
+}
 static int rnn_bwd_chain(const Ctx& c, int layer, const float* hf, const float* hb, int ldh, const float* doutf, const float* doutb, int ldo) {
   const Dims& d = c.d;
   const int T = d.T, B = d.B, u = d.u;
@@ -764,6 +774,10 @@ static int rnn_bwd_chain(const Ctx& c, int layer, const float* hf, const float* 
   if (c.cfg->gru)
     return crnn_gru_bwd_ex(uf, ub, hf, hb, ldh, c.w("gt" + l + "f"), c.w("gt" + l + "b"), doutf, doutb,
                            ldo, dzf, dzb, c.w("dcf"), c.w("dcb"), c.w("dhpf"), c.w("dhpb"), T, B, u, dtu, c.s);
+  if (lstm_bwd_persistent(c, layer))      // (also leaves the bias-gradient partials: rnn_bwd_wgrads sums them instead of reading dz once more)
+    return crnn_lstm_bwd_persist_db(uf, ub, c.w("cs" + l + "f"), c.w("cs" + l + "b"), c.w("gt" + l + "f"), c.w("gt" + l + "b"), doutf, doutb, ldo,
+                                    dzf, dzb, c.w("dbp" + l + "f"), c.w("dbp" + l + "b"), T, B, u, dtu, c.w("rnnx"),
+                                    crnn_lstm_persist_xbuf_bytes(T, B, u, dtu), 0, rnn_uw(c.cfg), c.s);
   if (rnn_persist(c.cfg) && !(((uintptr_t)uf | (uintptr_t)ub) & 15))
     return crnn_lstm_bwd_persist(uf, ub, c.w("cs" + l + "f"), c.w("cs" + l + "b"), c.w("gt" + l + "f"), c.w("gt" + l + "b"), doutf, doutb, ldo,
                                  dzf, dzb, T, B, u, dtu, c.w("rnnx"), crnn_lstm_persist_xbuf_bytes(T, B, u, dtu), 0, rnn_uw(c.cfg), c.s);
@@ -804,6 +818,10 @@ static int rnn_bwd_wgrads(const Ctx& c, int layer, const float* xin, int ldx, in
   if (c.cfg->gru) {
     CRNN_TRY(gemm(c, 2, c.w("cs" + l + "f"), dzf + 2 * u, c.g("rnn" + l + "f_u") + 2 * u, u, u, TB, u, G, G));
     CRNN_TRY(gemm(c, 2, c.w("cs" + l + "b"), dzb + 2 * u, c.g("rnn" + l + "b_u") + 2 * u, u, u, TB, u, G, G));
+  }
+  if (lstm_bwd_persistent(c, layer)) {    // the persistent backward summed dz over time per 16-row batch tile: the tiles in a fixed order
+    CRNN_TRY(crnn_partials_sum(c.w("dbp" + l + "f"), crnn_rnn_db_rows(B), G, c.g("rnn" + l + "f_b"), 1.f, c.s));
+    return crnn_partials_sum(c.w("dbp" + l + "b"), crnn_rnn_db_rows(B), G, c.g("rnn" + l + "b_b"), 1.f, c.s);
   }
   CRNN_TRY(colsum(c, dzf, TB, G, G, c.g("rnn" + l + "f_b")));
   return colsum(c, dzb, TB, G, G, c.g("rnn" + l + "b_b"));

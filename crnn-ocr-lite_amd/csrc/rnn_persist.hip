@@ -53,6 +53,7 @@ struct BwdDir {
   const float* gates;
   const float* dout; int ldo;
   float* dz;         // [T][B][4u]
+  float* dbp;        // may be null: [ceil(B / 16)][4u] bias-gradient partials, the column sums of dz over t of every 16-row batch tile
 };
 
 // A workgroup has 4*UW waves = UW "unit groups" of 16 hidden units; wave w works for unit group w>>2 on gate (forward) /
@@ -241,9 +242,9 @@ __global__ __launch_bounds__(256 * UW) void lstm_bwd_persist_kernel(BwdDir d0, B
     }
   }
   const int tl = tid & 255, row = tl >> 4, col = tl & 15, j = j0 + col;
-  float dcin[MT];
+  float dcin[MT], bs[MT][4];                          // bs: this thread's (row, unit) share of the bias gradient, summed over the steps
 #pragma unroll
-  for (int m = 0; m < MT; ++m) dcin[m] = 0.f;
+  for (int m = 0; m < MT; ++m) { dcin[m] = 0.f; bs[m][0] = bs[m][1] = bs[m][2] = bs[m][3] = 0.f; }
 
 #pragma unroll 1
   for (int sb = 0; sb < T; ++sb) {
@@ -307,6 +308,8 @@ __global__ __launch_bounds__(256 * UW) void lstm_bwd_persist_kernel(BwdDir d0, B
       if (b >= b_end) { o[m].dz[0] = o[m].dz[1] = o[m].dz[2] = o[m].dz[3] = 0.f; o[m].dc = 0.f; }
       dcin[m] = o[m].dc;
 #pragma unroll
+      for (int g = 0; g < 4; ++g) bs[m][g] += o[m].dz[g];
+#pragma unroll
       for (int g = 0; g < 4; ++g) {
         if constexpr (WBF) zout[ug][((16 * m + row) * 4 + g) * 16 + col] = (bf16_t)(pack2_bf16(o[m].dz[g], 0.f) & 0xffffu);
         else zout[ug][((16 * m + row) * 4 + g) * 16 + col] = o[m].dz[g];
@@ -349,6 +352,28 @@ __global__ __launch_bounds__(256 * UW) void lstm_bwd_persist_kernel(BwdDir d0, B
           xstore((u32x4){kSentinel, kSentinel, kSentinel, kSentinel}, rp, eoff * ES, local);
         }
       }
+    }
+  }
+  // bias gradient of the layer (Keras' recurrent bias: db = column sums of dz over time and batch): the rows of a 16-row tile are 4 lanes apart in 4 waves --
+  // shuffles, then the waves through LDS in a fixed order; one partial row per 16-row batch tile (the stand-alone column reduction read dz again for it)
+  if (d.dbp) {
+    __syncthreads();                                 // (`red` is free: the last step's sums were consumed before the last barrier-free epilogue)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v = bs[m][g];
+        v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+        if (lane < 16) red[ug][kq][m][g * 16 + lane] = v;
+      }
+    __syncthreads();
+    if (kq == 0) {
+      const int g = lane >> 4, cc = lane & 15;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        if (b0 + 16 * m < b_end)
+          d.dbp[(long)((b0 + 16 * m) >> 4) * K + g * U + j0 + cc] =
+              (red[ug][0][m][g * 16 + cc] + red[ug][1][m][g * 16 + cc]) + (red[ug][2][m][g * 16 + cc] + red[ug][3][m][g * 16 + cc]);
     }
   }
 }
@@ -482,12 +507,25 @@ extern "C" int crnn_lstm_fwd_persist(const float* xw0, const float* xw1, const v
 
 // BPTT of one Bidirectional(LSTM) layer in ONE launch: fills dz[d] [T][B][4u] from dout[d].  Arguments as
 // crnn_lstm_bwd_ex without the dc scratch (the cell-gradient carry stays in registers).
+// crnn_lstm_bwd_persist_db: the same launch also leaves the layer's bias-gradient partials, db_partials0 / 1 [crnn_rnn_db_rows(B)][4u] = column sums of dz0 / dz1 over
+// time for every 16-row batch tile (finish with crnn_partials_sum over the rows) -- the stand-alone column reduction reads dz (54 MB per direction) once more.
+extern "C" int crnn_rnn_db_rows(int B) { return cdiv(B, 16); }
+extern "C" int crnn_lstm_bwd_persist_db(const void* u0, const void* u1, const float* c0, const float* c1, const float* g0,
+                                        const float* g1, const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1, float* db_partials0,
+                                        float* db_partials1, int T, int B, int u, int dt_u, void* xbuf, size_t xbuf_bytes, int mt_req, int uw_req,
+                                        hipStream_t stream);
 extern "C" int crnn_lstm_bwd_persist(const void* u0, const void* u1, const float* c0, const float* c1, const float* g0,
                                      const float* g1, const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1,
                                      int T, int B, int u, int dt_u, void* xbuf, size_t xbuf_bytes, int mt_req, int uw_req, hipStream_t stream) {
+  return crnn_lstm_bwd_persist_db(u0, u1, c0, c1, g0, g1, dout0, dout1, ldo, dz0, dz1, nullptr, nullptr, T, B, u, dt_u, xbuf, xbuf_bytes, mt_req, uw_req, stream);
+}
+extern "C" int crnn_lstm_bwd_persist_db(const void* u0, const void* u1, const float* c0, const float* c1, const float* g0,
+                                        const float* g1, const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1, float* db_partials0,
+                                        float* db_partials1, int T, int B, int u, int dt_u, void* xbuf, size_t xbuf_bytes, int mt_req, int uw_req,
+                                        hipStream_t stream) {
   CRNN_TRY(crnn_lstm_persist_supported(u, dt_u));
-  if (T < 1 || B < 1 || (((uintptr_t)u0 | (uintptr_t)u1) & 15)) return CRNN_ERR_ARG;
-  BwdDir a{u0, c0, g0, dout0, ldo, dz0}, b{u1, c1, g1, dout1, ldo, dz1};
+  if (T < 1 || B < 1 || (((uintptr_t)u0 | (uintptr_t)u1) & 15) || (!db_partials0) != (!db_partials1)) return CRNN_ERR_ARG;
+  BwdDir a{u0, c0, g0, dout0, ldo, dz0, db_partials0}, b{u1, c1, g1, dout1, ldo, dz1, db_partials1};
   const int xreq = (uw_req & CRNN_RNN_XCD_LOCAL) ? 1 : 0; uw_req &= 0xff;
   const int rc = with_fallback(B, u, mt_req, uw_req, [&](int mt, int uw) {
     if (dt_u == CRNN_BF16) {

@@ -577,6 +577,12 @@ int crnn_lstm_fwd_persist(const float* xw0, const float* xw1, const void* ut0, c
 int crnn_lstm_bwd_persist(const void* u0, const void* u1, const float* c0, const float* c1, const float* g0, const float* g1,
                           const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1, int T, int B, int u, int dt_u,
                           void* xbuf, size_t xbuf_bytes, int mt, int uw, crnn_stream_t stream);
+/* crnn_lstm_bwd_persist that also leaves the layer's bias-gradient partials (round 4): db_partials0 / 1 [crnn_rnn_db_rows(B)][4u] = the column sums of dz0 / dz1 over time
+ * for every 16-row batch tile -- finish with crnn_partials_sum over the rows (a fixed order); the stand-alone column reduction reads dz once more for the same sums */
+int crnn_rnn_db_rows(int B);
+int crnn_lstm_bwd_persist_db(const void* u0, const void* u1, const float* c0, const float* c1, const float* g0, const float* g1, const float* dout0,
+                             const float* dout1, int ldo, float* dz0, float* dz1, float* db_partials0, float* db_partials1, int T, int B, int u, int dt_u,
+                             void* xbuf, size_t xbuf_bytes, int mt_req, int uw_req, crnn_stream_t stream);
 /* Persistent Bidirectional(GRU) recurrences (utils.py:80-82, the cell train.py:119 really builds): ONE launch per layer and pass instead of
  * 2 T step launches, the cluster / sentinel-ring design of crnn_lstm_*_persist with two all-gathers per step (h_{t-1}, then r * h_{t-1}:
  * the candidate's recurrent product needs r of every unit; backward: [dz|dr]_{t+1}, then dhh_t).  Bit-identical to crnn_gru_*_ex.

@@ -508,7 +508,17 @@ def test_bf16s_producer_fused_pointwise_convs_equal_the_two_pass_path(shape):
     for flags in list(out)[1:-5]:
         y1, l1, g1 = out[flags]
         assert torch.isfinite(g1).all() and torch.equal(y0, y1) and torch.equal(l0, l1), flags
-        if flags != T | native.FLAG_NO_DW_BWD_FUSION:
+        if flags == T | native.FLAG_RNN_STEP_KERNELS:
+            # the persistent LSTM backward also sums its dz over time per 16-row batch tile for the recurrent biases (round 4); the step kernels' path
+            # sums the stored dz in column-reduction chunks: the four bias gradients to summation round-off, everything else exactly
+            rb = torch.zeros_like(g0, dtype=torch.bool)
+            for name, (off, size, _) in lay.items():
+                if name.startswith("rnn") and name.endswith("_b"):
+                    rb[off:off + size] = True
+                    a, b = g0[off:off + size], g1[off:off + size]
+                    assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-7, name
+            assert torch.equal(g0[~rb], g1[~rb]), flags
+        elif flags != T | native.FLAG_NO_DW_BWD_FUSION:
             assert torch.equal(g0, g1), flags
         else:
             # the fused depthwise-stage backward groups the partial sums of the depthwise weight gradients differently: those six
