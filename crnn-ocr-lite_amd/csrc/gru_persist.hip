@@ -35,6 +35,7 @@ struct GruBwdDir {
   const float* gates;
   const float* dout; int ldo;
   float* dz;         // [T][B][3u]
+  float* dbp;        // may be null: [ceil(B / 16)][3u] bias-gradient partials, the column sums of dz over t of every 16-row batch tile
 };
 
 template <bool WBF> __device__ __forceinline__ typename XE<WBF>::type to_e(float v);
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256 * UW) void gru_bwd_persist_kernel(GruBwdDir d0,
   const int b = b0 + row;
   const bool live = b < b_end;
   const long bbx = live ? b : b_lo;
-  float dhp = 0.f;
+  float dhp = 0.f, bsz = 0.f, bsr = 0.f, bsh = 0.f;       // bs*: this thread's (row, unit) share of the bias gradient (z | r | candidate), summed over the steps
 
 #pragma unroll 1
   for (int sb = 0; sb < T; ++sb) {
@@ -262,6 +263,7 @@ __global__ __launch_bounds__(256 * UW) void gru_bwd_persist_kernel(GruBwdDir d0,
     }
     GruBwdB ob = gru_cell_bwd_b(dh, zg, hh, hprev);
     if (!live) { ob.dzz = 0.f; ob.dhh = 0.f; }
+    bsz += ob.dzz; bsh += ob.dhh;
     // publish dhh_t of this unit group (exchange 2sb)
     pub[ug][row * 16 + col] = to_e<WBF>(ob.dhh);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -285,6 +287,7 @@ __global__ __launch_bounds__(256 * UW) void gru_bwd_persist_kernel(GruBwdDir d0,
     const float drh = (red[ug][0][tl] + red[ug][1][tl]) + (red[ug][2][tl] + red[ug][3][tl]);
     GruBwdA oa = gru_cell_bwd_a(drh, dh, zg, rg, hprev);
     if (!live) { oa.dzr = 0.f; oa.dhp = 0.f; }
+    bsr += oa.dzr;
     dhp = oa.dhp;
     if (sb + 1 < T) {
       pub[ug][(row * 2 + 0) * 16 + col] = to_e<WBF>(ob.dzz);         // exchange 2sb+1: [dz | dr]_t
@@ -294,6 +297,21 @@ __global__ __launch_bounds__(256 * UW) void gru_bwd_persist_kernel(GruBwdDir d0,
     }
     if (live) d.dz[((long)t * B + b) * G + U + j] = oa.dzr;
     if (sb + 1 < T) poison_rows<32>(slot_tile(2 * sb + 3) + (long)sg * BT * 32, kq, lane, local);
+  }
+  // bias gradient of the layer (db = column sums of dz over time and batch), as in the LSTM kernel: the 16 rows of the tile are 4 lanes apart in 4 waves
+  if (d.dbp) {
+    __syncthreads();
+    float v[3] = {bsz, bsr, bsh};
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      v[g] += __shfl_xor(v[g], 16, 64); v[g] += __shfl_xor(v[g], 32, 64);
+      if (lane < 16) red[ug][kq][g * 16 + lane] = v[g];
+    }
+    __syncthreads();
+    if (kq == 0 && lane < 48 && b0 < b_end) {
+      const int g = lane >> 4, cc = lane & 15;
+      d.dbp[(long)(b0 >> 4) * G + g * U + j0 + cc] = (red[ug][0][g * 16 + cc] + red[ug][1][g * 16 + cc]) + (red[ug][2][g * 16 + cc] + red[ug][3][g * 16 + cc]);
+    }
   }
 }
 
@@ -358,12 +376,21 @@ extern "C" int crnn_gru_fwd_persist(const float* xw0, const float* xw1, const vo
 
 // BPTT of one Bidirectional(GRU) layer in ONE launch: fills dz[d] [T][B][3u] from dout[d].  Arguments as crnn_gru_bwd_ex without
 // the dh / dhp scratch (both stay in registers).
+// crnn_gru_bwd_persist_db: the same launch also leaves the bias-gradient partials db_partials0 / 1 [crnn_rnn_db_rows(B)][3u] (column sums of dz over time per 16-row tile)
+extern "C" int crnn_gru_bwd_persist_db(const void* u0, const void* u1, const float* h0, const float* h1, int ldh, const float* g0, const float* g1,
+                                       const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1, float* db_partials0, float* db_partials1,
+                                       int T, int B, int u, int dt_u, void* xbuf, size_t xbuf_bytes, int flags, hipStream_t stream);
 extern "C" int crnn_gru_bwd_persist(const void* u0, const void* u1, const float* h0, const float* h1, int ldh, const float* g0, const float* g1,
                                     const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1, int T, int B, int u, int dt_u,
                                     void* xbuf, size_t xbuf_bytes, int flags, hipStream_t stream) {
+  return crnn_gru_bwd_persist_db(u0, u1, h0, h1, ldh, g0, g1, dout0, dout1, ldo, dz0, dz1, nullptr, nullptr, T, B, u, dt_u, xbuf, xbuf_bytes, flags, stream);
+}
+extern "C" int crnn_gru_bwd_persist_db(const void* u0, const void* u1, const float* h0, const float* h1, int ldh, const float* g0, const float* g1,
+                                       const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1, float* db_partials0, float* db_partials1,
+                                       int T, int B, int u, int dt_u, void* xbuf, size_t xbuf_bytes, int flags, hipStream_t stream) {
   CRNN_TRY(crnn_gru_persist_supported(u, dt_u));
-  if (T < 1 || B < 1 || (((uintptr_t)u0 | (uintptr_t)u1) & 15)) return CRNN_ERR_ARG;
-  GruBwdDir a{u0, h0, ldh, g0, dout0, ldo, dz0}, b{u1, h1, ldh, g1, dout1, ldo, dz1};
+  if (T < 1 || B < 1 || (((uintptr_t)u0 | (uintptr_t)u1) & 15) || (!db_partials0) != (!db_partials1)) return CRNN_ERR_ARG;
+  GruBwdDir a{u0, h0, ldh, g0, dout0, ldo, dz0, db_partials0}, b{u1, h1, ldh, g1, dout1, ldo, dz1, db_partials1};
   const int xreq = (flags & CRNN_RNN_XCD_LOCAL) ? 1 : 0;
   int rc;
   if (dt_u == CRNN_BF16) rc = u == 128 ? gru_launch_bwd<true, 128, 2>(a, b, T, B, xbuf, xbuf_bytes, xreq, stream)

@@ -178,7 +178,7 @@ Plan make_plan(const crnn_config* c) {
     for (const char* dir : {"f", "b"}) {
       P.add("xw" + p + dir, TB * d.G); P.add("cs" + p + dir, TB * d.u); P.add("gt" + p + dir, TB * d.G);
       P.add("ut" + p + dir, (long)d.G * d.u); P.add("dz" + p + dir, TB * d.G);
-      if (!c->gru) P.add("dbp" + p + dir, (long)crnn_rnn_db_rows((int)B) * d.G);   // bias-gradient partials of the persistent LSTM backward (one row per 16-row batch tile)
+      P.add("dbp" + p + dir, (long)crnn_rnn_db_rows((int)B) * d.G);   // bias-gradient partials of the persistent LSTM backward (one row per 16-row batch tile)
       P.add("wt" + p + dir, (long)d.G * (l == 1 ? d.tds : d.u));   // bf16 W^T of the input projection (streaming xw kernel), oversized by 2
     }
   }
@@ -751,8 +751,8 @@ extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, cons
 // stream: (1) the BPTT chain (T dependent step launches, latency-bound), (2) dW/dU/db from the finished dz (throughput
 // work nobody downstream of the chain waits for), (3) dX = dZ W^T (what the layer below needs).
 // the persistent LSTM backward of layer `layer` runs (and leaves the bias-gradient partials "dbp<layer>f/b"): one decision for rnn_bwd_chain and rnn_bwd_wgrads
-static bool lstm_bwd_persistent(const Ctx& c, int layer) {
-  if (c.cfg->gru || !rnn_persist(c.cfg)) return false;
+static bool lstm_bwd_persistent(const Ctx& c, int layer) {     // (LSTM or GRU: whichever cell the configuration has)
+  if (!rnn_persist(c.cfg)) return false;
   std::string l = std::to_string(layer);
   int dtu = CRNN_F32;
   const float* uf = c.p("rnn" + l + "f_u"); const float* ub = c.p("rnn" + l + "b_u");
@@ -768,13 +768,16 @@ static int rnn_bwd_chain(const Ctx& c, int layer, const float* hf, const float* 
   int dtu = CRNN_F32;
   const float* uf = c.p("rnn" + l + "f_u"); const float* ub = c.p("rnn" + l + "b_u");
   if (c.cfg->mfma_bf16 && u % 128 == 0) { uf = weight_operand(c, 0, uf, &dtu); ub = weight_operand(c, 0, ub, &dtu); }
+  if (c.cfg->gru && lstm_bwd_persistent(c, layer))
+    return crnn_gru_bwd_persist_db(uf, ub, hf, hb, ldh, c.w("gt" + l + "f"), c.w("gt" + l + "b"), doutf, doutb, ldo, dzf, dzb, c.w("dbp" + l + "f"),
+                                   c.w("dbp" + l + "b"), T, B, u, dtu, c.w("rnnx"), crnn_lstm_persist_xbuf_bytes(T, B, u, dtu), rnn_uw(c.cfg), c.s);
   if (c.cfg->gru && rnn_persist(c.cfg) && !(((uintptr_t)uf | (uintptr_t)ub) & 15))
     return crnn_gru_bwd_persist(uf, ub, hf, hb, ldh, c.w("gt" + l + "f"), c.w("gt" + l + "b"), doutf, doutb, ldo, dzf, dzb, T, B, u, dtu,
                                 c.w("rnnx"), crnn_lstm_persist_xbuf_bytes(T, B, u, dtu), rnn_uw(c.cfg), c.s);
   if (c.cfg->gru)
     return crnn_gru_bwd_ex(uf, ub, hf, hb, ldh, c.w("gt" + l + "f"), c.w("gt" + l + "b"), doutf, doutb,
                            ldo, dzf, dzb, c.w("dcf"), c.w("dcb"), c.w("dhpf"), c.w("dhpb"), T, B, u, dtu, c.s);
-  if (lstm_bwd_persistent(c, layer))      // (also leaves the bias-gradient partials: rnn_bwd_wgrads sums them instead of reading dz once more)
+  if (!c.cfg->gru && lstm_bwd_persistent(c, layer))      // (also leaves the bias-gradient partials: rnn_bwd_wgrads sums them instead of reading dz once more)
     return crnn_lstm_bwd_persist_db(uf, ub, c.w("cs" + l + "f"), c.w("cs" + l + "b"), c.w("gt" + l + "f"), c.w("gt" + l + "b"), doutf, doutb, ldo,
                                     dzf, dzb, c.w("dbp" + l + "f"), c.w("dbp" + l + "b"), T, B, u, dtu, c.w("rnnx"),
                                     crnn_lstm_persist_xbuf_bytes(T, B, u, dtu), 0, rnn_uw(c.cfg), c.s);

@@ -595,6 +595,10 @@ int crnn_gru_fwd_persist(const float* xw0, const float* xw1, const void* ut0, co
 int crnn_gru_bwd_persist(const void* u0, const void* u1, const float* h0, const float* h1, int ldh, const float* g0, const float* g1,
                          const float* dout0, const float* dout1, int ldo, float* dz0, float* dz1, int T, int B, int u, int dt_u,
                          void* xbuf, size_t xbuf_bytes, int flags, crnn_stream_t stream);
+/* ... and with the layer's bias-gradient partials, db_partials0 / 1 [crnn_rnn_db_rows(B)][3u] (crnn_lstm_bwd_persist_db's contract) */
+int crnn_gru_bwd_persist_db(const void* u0, const void* u1, const float* h0, const float* h1, int ldh, const float* g0, const float* g1, const float* dout0,
+                            const float* dout1, int ldo, float* dz0, float* dz1, float* db_partials0, float* db_partials1, int T, int B, int u, int dt_u,
+                            void* xbuf, size_t xbuf_bytes, int flags, crnn_stream_t stream);
 /* Bidirectional GRU recurrence (utils.py:81-82; reset_after=False), time-major; gates = z,r,hh; rh = r*h_prev */
 int crnn_gru_fwd(const float* xw0, const float* xw1, const float* ut0, const float* ut1, float* h0, float* h1, int ldh,
                  float* g0, float* g1, float* rh0, float* rh1, int T, int B, int u, crnn_stream_t stream);

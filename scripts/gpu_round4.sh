@@ -7,7 +7,7 @@ mkdir -p $OUT
 export PYTHONPATH=$ROOT:$ROOT/crnn-ocr-lite_amd:$ROOT/tests
 cd $ROOT
 rm -f $OUT/rccl_skip_reason.txt $OUT/dp_world4_failure.log
-timeout 900 python -m pytest tests -q -m gpu -n 4 --tb=short -p no:cacheprovider > $OUT/${TAG}_pytest_gpu.log 2>&1
+timeout 900 python -m pytest tests -q -m gpu --tb=short -p no:cacheprovider > $OUT/${TAG}_pytest_gpu.log 2>&1
 echo "pytest_gpu exit $?" > $OUT/${TAG}_summary.txt
 [ -f $OUT/rccl_skip_reason.txt ] && cat $OUT/rccl_skip_reason.txt >> $OUT/${TAG}_summary.txt
 timeout 1200 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_bf16s.json 2> $OUT/${TAG}_bench.err

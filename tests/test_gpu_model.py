@@ -550,7 +550,7 @@ def test_bf16s_producer_fused_pointwise_convs_equal_the_two_pass_path(shape):
 @pytest.mark.parametrize("precision", ["fp32", "bf16s"])
 def test_gru_model_persistent_recurrences_equal_the_step_kernels(precision):
     """GRU variant (what the reference's train.py builds): the whole train step with the persistent recurrences (default) must equal
-    the per-step-launch schedule (CRNN_FLAG_RNN_STEP_KERNELS) bit for bit -- posteriors, losses, every gradient -- and so must the
+    the per-step-launch schedule (CRNN_FLAG_RNN_STEP_KERNELS) bit for bit -- posteriors, losses, every gradient but the recurrent biases' -- and so must the
     BPTT launches on the linear workgroup -> cluster map (CRNN_FLAG_RNN_LINEAR_CLUSTERS)."""
     from crnn_mi355x import native
     B, imgh, imgw, ncls, max_len, tds, u = 20, 60, 32, 38, 10, 64, 256
@@ -571,9 +571,22 @@ def test_gru_model_persistent_recurrences_equal_the_step_kernels(precision):
         del eng
     y0, l0, g0 = out[0]
     assert torch.isfinite(g0).all() and float(g0.abs().max()) > 0
+    lay = Engine(B, imgh, imgw, ncls, max_len, tds, u, gru=True, precision=precision).layout
     for flags in list(out)[1:]:
         y1, l1, g1 = out[flags]
-        assert torch.equal(y0, y1) and torch.equal(l0, l1) and torch.equal(g0, g1), flags
+        assert torch.equal(y0, y1) and torch.equal(l0, l1), flags
+        if flags == native.FLAG_RNN_STEP_KERNELS:
+            # (round 4) the persistent backward sums its dz per 16-row batch tile for the recurrent biases, the step kernels' path reduces the stored dz
+            # in column chunks: those four gradients to summation round-off, everything else bit for bit
+            rb = torch.zeros_like(g0, dtype=torch.bool)
+            for name, (off, size, _) in lay.items():
+                if name.startswith("rnn") and name.endswith("_b"):
+                    rb[off:off + size] = True
+                    a, b = g0[off:off + size], g1[off:off + size]
+                    assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-7, name
+            assert torch.equal(g0[~rb], g1[~rb]), flags
+        else:
+            assert torch.equal(g0, g1), flags
 
 
 def test_parity_mode_three_plane_gemms_track_the_fp32_mfma_path():

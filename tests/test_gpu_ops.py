@@ -707,9 +707,13 @@ def _gru_persist_case(B, T, u, bf16, flags, seed, reps=1):
                 ok(L().crnn_gru_fwd_persist(P(xw[0]), P(xw[1]), P(ut[0]), P(ut[1]), P(hcat), hb, 2 * u, P(gt[0]), P(gt[1]), P(rh[0]), P(rh[1]), T, B, u, dt,
                                             P(xbuf), nbytes, flags, S()))
                 status |= int(xbuf[4].item()) != -1
-                ok(L().crnn_gru_bwd_persist(P(Ud[0]), P(Ud[1]), P(hcat), hb, 2 * u, P(gt[0]), P(gt[1]), P(gd), gb, 2 * u, P(dz[0]), P(dz[1]), T, B, u, dt,
-                                            P(xbuf), nbytes, flags, S()))
+                nrow = L().crnn_rnn_db_rows(B)      # (round 4: the launch also leaves the bias-gradient partials, one row per 16-row batch tile)
+                dbp = [torch.full((nrow + 1, G), 7.0, device="cuda") for _ in range(2)]
+                ok(L().crnn_gru_bwd_persist_db(P(Ud[0]), P(Ud[1]), P(hcat), hb, 2 * u, P(gt[0]), P(gt[1]), P(gd), gb, 2 * u, P(dz[0]), P(dz[1]), P(dbp[0]), P(dbp[1]),
+                                               T, B, u, dt, P(xbuf), nbytes, flags, S()))
                 status |= int(xbuf[4].item()) != -1
+                assert all(bool((t[nrow] == 7.0).all()) for t in dbp)
+                out["db"] = [host(t[:nrow]).sum(0) for t in dbp]
             status |= int(xbuf[0].item()) != 0
         out[kind] = dict(h=host(hcat), g=[host(t) for t in gt], rh=[host(t) for t in rh], dz=[host(t) for t in dz], status=status)
     return out
@@ -732,6 +736,9 @@ def test_persistent_gru_is_bit_identical_to_the_step_kernels(B, T, u, bf16, flag
         assert np.array_equal(a["rh"][d], b["rh"][d]), "r*h dir%d" % d
         assert np.array_equal(a["dz"][d], b["dz"][d]), "dz dir%d: max diff %g" % (d, np.abs(a["dz"][d] - b["dz"][d]).max())
     assert np.isfinite(b["h"]).all() and np.abs(b["dz"][0]).max() > 0 and np.abs(b["h"]).max() > 0
+    for d in range(2):        # the bias gradient the same launch leaves: column sums of dz over time and batch
+        ref = b["dz"][d].astype(np.float64).reshape(-1, 3 * u).sum(0)
+        assert_close(r["db"][d], ref, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(ref).max()), what="db dir%d" % d)
 
 
 def test_persistent_gru_repeated_launches_and_oracle():
