@@ -43,6 +43,9 @@ struct GemmParams {
   // a ReLU6(BatchNorm(d)); bnpart [tilesM][2][N] = per-tile column sums of gy and gy * xhat, gy = C where 0 < d * scale + shift < 6,
   // xhat = (d - mean) / sqrt(var + eps); bnD [M][ldd] fp32 = d, bnstate = [mean | var | scale | shift] x N
   const float* bnD; int ldd; const float* bnstate; float* bnpart;
+  // three-plane kernel: an operand handed over as its three bf16 planes (crnn_split3_planes; plane pl of element i at Xpl[pl * xpls + i], the leading
+  // dimension of the fp32 operand it stands for) -- null: split from fp32 while staging
+  const unsigned short* Apl; const unsigned short* Bpl; long apls, bpls;
 #ifdef CRNN_GEMM_EXP
   unsigned long long* trace;   // ablation build only: s_memrealtime stamps of workgroup 300, thread 0
   int exp;         // ablation build only (scripts/gemm_ablate.py): 1 no C stores, 2 no MFMA, 4 B loaded once, 8 A loaded once
@@ -474,6 +477,14 @@ extern "C" int crnn_pwconv_bnrelu6_fwd_f32x3(const float* d, const float* in_bns
   if (M <= 0 || M > 0x7fffffffL || !in_bnstate) return CRNN_ERR_ARG;
   return gemm_bf16_impl(0, d, w, q, (int)M, N, K, K, N, N, nullptr, 0, 0, 0, nullptr, 0, CRNN_F32, CRNN_F32, CRNN_F32, stat_partials, stream,
                         nullptr, nullptr, in_bnstate + 2L * K, in_bnstate + 3L * K, true);
+}
+// ... with the weights as planes (crnn_split3_planes of w, plane stride w_plane_stride elements; null: the entry point above)
+extern "C" int crnn_pwconv_bnrelu6_fwd_f32x3_pl(const float* d, const float* in_bnstate, const float* w, const void* w_planes, long w_plane_stride, float* q,
+                                                long M, int N, int K, float* stat_partials, hipStream_t stream) {
+  if (M <= 0 || M > 0x7fffffffL || !in_bnstate) return CRNN_ERR_ARG;
+  const X3Planes pl{nullptr, 0, (const unsigned short*)w_planes, w_plane_stride};
+  return gemm_bf16_impl(0, d, w, q, (int)M, N, K, K, N, N, nullptr, 0, 0, 0, nullptr, 0, CRNN_F32, CRNN_F32, CRNN_F32, stat_partials, stream,
+                        nullptr, nullptr, in_bnstate + 2L * K, in_bnstate + 3L * K, true, nullptr, w_planes ? &pl : nullptr);
 }
 extern "C" int crnn_pwconv_bnrelu6_wgrad_f32x3(const float* d, const float* in_bnstate, const float* g, float* dw, long M, int N, int K,
                                                float* scratch, size_t scratch_bytes, hipStream_t stream) {

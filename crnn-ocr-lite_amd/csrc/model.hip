@@ -209,6 +209,10 @@ Plan make_plan(const crnn_config* c) {
   { long pw = 0; for (int i = 2; i <= 7; ++i) pw += (long)d.bc[i - 1] * d.bc[i];
     P.add("pwT", pw, CRNN_BF16); }   // bf16 W^T copies of the pointwise-conv weights (bf16 modes)
   P.add("pbf", make_layout(c).total, CRNN_BF16);   // bf16 shadow of the parameter buffer (GEMM B operands in the bf16 modes)
+  if (!c->mfma_bf16) {   // parity mode: bf16 planes of the pointwise-conv weights (CRNN_FLAG_WEIGHT_PLANES, weight_planes below); 3 planes x the b2_pw .. b7_pw span
+    const Layout L = make_layout(c);
+    P.add("p3", 3 * (L.off("b7_pw") + pad4((long)d.bc[6] * d.bc[7]) - L.off("b2_pw")), CRNN_BF16);
+  }
   P.add("coef", 2 * 1024);
   P.add("fold", 32 * 2 * 1024);   // chunk sums of long BatchNorm partial lists (crnn_bn_finalize_folded)
   P.add("gemm_scratch", 16L * 1024 * 1024);   // 64 MiB of split-reduction partials (main stream)
@@ -265,6 +269,25 @@ int gemm(const Ctx& c, int mode, const float* A, const float* B, float* C, int M
 }
 // product selector of crnn_pwconv_fwd: 1 = bf16 products (bf16 modes), 2 = three-plane fp32-accurate products (parity mode), 0 = fp32 MFMA
 int pw_products(const crnn_config* cfg) { return cfg->mfma_bf16 ? 1 : ((cfg->flags & CRNN_FLAG_F32_MFMA_GEMMS) ? 0 : 2); }
+// Parity mode with three-plane GEMMs, CRNN_FLAG_WEIGHT_PLANES (opt-in): the pointwise weights of blocks 2..7 are split into their bf16 planes ONCE, at
+// the start of the forward pass (crnn_split3_planes over the b2_pw .. b7_pw span of the parameter buffer -> workspace tensor "p3"), instead of by
+// every tile of the forward and data-gradient GEMMs that stages them (a tile of 128 rows re-splits the whole weight matrix).  Same words in LDS:
+// bit-identical.  Not the default: the staging waves pay more for three 8-byte loads per item than for the split arithmetic (include/crnn_mi355x.h).
+// `stride` = elements between planes; null: no planes for this weight.
+struct WeightPlanes { long lo = 0, n = 0; };
+WeightPlanes weight_planes_span(const Ctx& c) {
+  WeightPlanes s;
+  if (pw_products(c.cfg) != 2 || !(c.cfg->flags & CRNN_FLAG_WEIGHT_PLANES) || c.P.off("p3") < 0) return s;
+  s.lo = c.L.off("b2_pw"); s.n = c.L.off("b7_pw") + pad4((long)c.d.bc[6] * c.d.bc[7]) - s.lo;
+  if (((uintptr_t)(c.params + s.lo) & 15) || (s.n & 3)) s.n = 0;
+  return s;
+}
+const void* weight_planes(const Ctx& c, const float* w, long* stride) {
+  const WeightPlanes s = weight_planes_span(c);
+  *stride = s.n;
+  if (!s.n || w < c.params + s.lo || w >= c.params + s.lo + s.n || ((w - c.params - s.lo) & 3)) return nullptr;
+  return reinterpret_cast<const bf16_t*>(c.ws + c.P.off("p3")) + (w - c.params - s.lo);
+}
 // GEMM with explicit operand / result storage types (storage mode 2); falls back to the plain entry points otherwise
 int gemm_t(const Ctx& c, int mode, const float* A, int dtA, const float* B, int dtB, float* C, int dtC, int M, int N, int K, int lda,
            int ldb, int ldc, const float* bias = nullptr, int act = 0, int acc = 0, int perm = 0) {
@@ -502,6 +525,8 @@ extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, cons
     }
   }
   if (cfg->mfma_bf16) CRNN_TRY(crnn_convert_f32_to_bf16(params, c.ws + c.P.off("pbf"), c.L.total, stream));
+  { const WeightPlanes wp = weight_planes_span(c);   // parity mode, opt-in: the pointwise weights' bf16 planes, once per step
+    if (wp.n) CRNN_TRY(crnn_split3_planes(params + wp.lo, c.ws + c.P.off("p3"), wp.n, wp.n, stream)); }
   // ---- spatial transformer (utils.py:247-258) + ZeroPadding2D (utils.py:63)
   if (cfg->stn && loc_net_fused(cfg, d) && aligned16(c.p("stn_c1_k"), c.p("stn_c2_k"), c.p("stn_c1_b"), c.p("stn_c2_b")) &&
       aligned16(c.w("c1"), c.w("pool2"), c.w("flat"))) {
@@ -644,7 +669,12 @@ extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, cons
       }
       if (blk1) CRNN_TRY(crnn_pw1_bn_fwd(dd, s1, c.p(bp + "_pw"), qq, M, co, parts, dtq, stream));                      // block 1: outer product of relu6(BN(d))
       else if (ci == 1 && dtd == CRNN_F32) CRNN_TRY(crnn_pw1_fwd(aa, c.p(bp + "_pw"), qq, M, co, parts, dtq, stream));
-      else if (fuse_x3) CRNN_TRY(crnn_pwconv_bnrelu6_fwd_f32x3(dd, s1, c.p(bp + "_pw"), qq, M, co, ci, parts, stream));
+      else if (fuse_x3) {
+        long wps = 0; const void* wpl = weight_planes(c, c.p(bp + "_pw"), &wps);
+        int rc = wpl ? crnn_pwconv_bnrelu6_fwd_f32x3_pl(dd, s1, c.p(bp + "_pw"), wpl, wps, qq, M, co, ci, parts, stream) : CRNN_ERR_UNSUPPORTED;
+        if (rc == CRNN_ERR_UNSUPPORTED) rc = crnn_pwconv_bnrelu6_fwd_f32x3(dd, s1, c.p(bp + "_pw"), qq, M, co, ci, parts, stream);   // (ragged tiles: split while staging)
+        CRNN_TRY(rc);
+      }
       else if (fuse_a) {
         // weights resident in registers, IO waves transform / drain / take the statistics (gemm_wres.hip) where its shape rules hold
         int rc = CRNN_ERR_UNSUPPORTED;
@@ -1043,7 +1073,9 @@ int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t au
       // parity mode: the three-plane GEMM's epilogue takes the statistics pass of the depthwise BatchNorm's backward (it holds the finished da tile)
       if (rc == CRNN_ERR_UNSUPPORTED && !fused_bf && pw_products(cfg) == 2 && dtq == CRNN_F32 && dtd == CRNN_F32 &&
           !(cfg->flags & CRNN_FLAG_NO_BN_STATS_FUSION) && crnn_gemm_f32x3_bnstats_supported(M, ci, co) == CRNN_OK) {
-        rc = crnn_gemm_f32x3_bnstats(gB, c.p(bp + "_pw"), gA, M, ci, co, c.w("d" + p), c.w("bn1s" + p), c.w("partials"), stream);
+        long wps = 0; const void* wpl = weight_planes(c, c.p(bp + "_pw"), &wps);
+        rc = crnn_gemm_f32x3_bnstats_pl(gB, nullptr, 0, c.p(bp + "_pw"), wpl, wps, gA, M, ci, co, c.w("d" + p), c.w("bn1s" + p), c.w("partials"), stream);
+        if (rc == CRNN_ERR_UNSUPPORTED && wpl) rc = crnn_gemm_f32x3_bnstats(gB, c.p(bp + "_pw"), gA, M, ci, co, c.w("d" + p), c.w("bn1s" + p), c.w("partials"), stream);
         bn1_stats_rows = (rc == CRNN_OK) ? crnn_gemm_f32x3_bnstats_rows(M) : 0;
       }
       if (rc == CRNN_ERR_UNSUPPORTED) rc = gemm_t(c, 1, gB, dtq, c.p(bp + "_pw"), CRNN_F32, gA, dtd, (int)M, ci, co, co, co, ci);

@@ -75,6 +75,10 @@ typedef struct {
                                          GEMM (crnn_gemm_bf16_ex / crnn_pwconv_bnrelu6_*) instead of the streaming kernels (crnn_pwconv_bnrelu6_fwd_wres,
                                          crnn_gemm_wres_bf16, crnn_pwconv_bnrelu6_wgrad_stream).  Same products and data gradients bit for bit; the
                                          BatchNorm-2 statistics and the weight gradients are the same sums in another order (fp32 round-off) */
+#define CRNN_FLAG_WEIGHT_PLANES 32768    /* opt-in, parity mode: the pointwise GEMMs read bf16 planes of their weights split once per step (crnn_split3_planes +
+                                         the *_pl entry points) instead of splitting the fp32 weights in every tile that stages them; bit-identical.
+                                         Measured (profiles/r04_x3_planes_bench.txt): forward -2 %, data gradient +12 % -- three 8-byte loads per item
+                                         cost the staging waves more than the split arithmetic they save; step time unchanged.  Not the default */
 #define CRNN_FLAG_DEFERRED_SUMS 512      /* opt-in: second stage of every streaming weight gradient batched at the end of its backward stage
                                          (crnn_wgrad_sum_batch: 2 launches instead of 13 per step) instead of right after its first stage;
                                          bit-identical; measured neutral (6.583 vs 6.584 ms: the second stages are bandwidth, not launch latency) */
@@ -234,6 +238,9 @@ int crnn_pwconv_bnrelu6_wgrad(const void* d, const float* in_bnstate, const void
  * tensor is never written.  w [K][N] fp32, K <= 512; results equal the unfused sequence bit for bit; -3 outside the kernel's shape rules. */
 int crnn_pwconv_bnrelu6_fwd_f32x3(const float* d, const float* in_bnstate, const float* w, float* q, long M, int N, int K, float* stat_partials,
                                   crnn_stream_t stream);
+/* ... with the weights as planes (crnn_split3_planes of w [K][N]; null: the entry point above).  Whole tiles only (-3 otherwise). */
+int crnn_pwconv_bnrelu6_fwd_f32x3_pl(const float* d, const float* in_bnstate, const float* w, const void* w_planes, long w_plane_stride, float* q, long M,
+                                     int N, int K, float* stat_partials, crnn_stream_t stream);
 int crnn_pwconv_bnrelu6_wgrad_f32x3(const float* d, const float* in_bnstate, const float* g, float* dw, long M, int N, int K, float* scratch,
                                     size_t scratch_bytes, crnn_stream_t stream);
 /* The same pointwise conv for ONE input channel (block 1: Conv2D(64, 1x1) on the single-channel depthwise output,
@@ -488,6 +495,15 @@ int crnn_gemm_f32x3_bnstats_supported(long M, int N, int K);
 int crnn_gemm_f32x3_bnstats_rows(long M);
 int crnn_gemm_f32x3_bnstats(const float* dq, const float* W, float* da, long M, int N, int K, const float* d, const float* bnstate, float* stat_partials,
                             crnn_stream_t stream);
+/* The three bf16 planes of n fp32 values, formed once instead of by every GEMM tile that stages them: plane pl of x[i] at planes[pl * plane_stride + i]
+ * (bf16 words; n % 4 == 0, plane_stride % 4 == 0 and >= n, x 16-byte and planes 8-byte aligned) -- the very words the three-plane kernel's staging waves
+ * form, so the *_pl entry points below return what their fp32-operand forms return, bit for bit.  With CRNN_FLAG_WEIGHT_PLANES the parity-mode step splits the
+ * pointwise-conv weights this way at the start of the forward pass. */
+int crnn_split3_planes(const float* x, void* planes, long n, long plane_stride, crnn_stream_t stream);
+/* crnn_gemm_f32x3_bnstats with operands given as planes (null planes: split from the fp32 operand while staging).  W_planes: planes of W [N][K];
+ * dq_planes: planes of dq [M][K] (only together with W_planes).  The fp32 pointers stay required (alignment rules, fallback). */
+int crnn_gemm_f32x3_bnstats_pl(const float* dq, const void* dq_planes, long dq_plane_stride, const float* W, const void* W_planes, long W_plane_stride,
+                               float* da, long M, int N, int K, const float* d, const float* bnstate, float* stat_partials, crnn_stream_t stream);
 /* Inference forward of a pointwise convolution on the same kernel with the BatchNorm + ReLU6 that follows folded into the MFMA waves'
  * epilogue: y[M][N] (bf16) = ReLU6((a . wT^T) * scale[n] + shift[n]), out_bnstate = [mean|var|scale|shift] (crnn_bn_infer_state).
  * Bit-identical to crnn_pwconv_fwd(..., out_bnstate, ...) on bf16 tensors.  Same shape rules as crnn_gemm_wres_bf16. */

@@ -454,6 +454,32 @@ def test_fp32_row_stream_schedules_equal_the_tile_schedule(dropout):
 
 
 @pytest.mark.parametrize("shape", [(5, 60, 48, 20, 10, 64, 128), (4, 100, 32, 38, 23, 128, 256)])
+def test_parity_mode_weight_planes_split_once_change_no_bit(shape):
+    """Parity mode, CRNN_FLAG_WEIGHT_PLANES (opt-in): the pointwise-conv weights of blocks 2..7 are split into their three bf16 planes once per step
+    (crnn_split3_planes at the start of the forward, workspace tensor p3) and the forward / data-gradient GEMMs read the planes instead of
+    splitting the fp32 weights in every tile that stages them.  The same words reach LDS: posteriors, loss and every gradient are bit-identical (shapes with
+    ragged tiles fall back per GEMM, whole-tile shapes take the plane form)."""
+    from crnn_mi355x import native
+    B, imgh, imgw, ncls, max_len, tds, u = shape
+    cfg = M.Config(imgh=imgh, imgw=imgw, max_len=max_len, time_dense_size=tds, n_units=u, num_classes=ncls)
+    p, bn = M.init_params(cfg, seed=8, dtype=np.float64)
+    p = M.randomize_params(cfg, p)
+    x, lab, il, ll = M.synthetic_batch(cfg, B, seed=2, dtype=np.float64)
+    out = {}
+    for flags in (0, native.FLAG_WEIGHT_PLANES):
+        eng = Engine(B, imgh, imgw, ncls, max_len, tds, u, stn=True, dropout=True, precision="fp32", flags=flags)
+        eng.set_params(p, bn)
+        eng.ws.fill_(float("nan")); eng.grads.zero_()
+        y = eng.forward(x.astype(np.float32), train=True, seed=9).clone()
+        loss = eng.backward(lab, il, ll, seed=9).clone()
+        out[flags] = (y, loss, eng.grads.clone())
+        del eng
+    (y0, l0, g0), (y1, l1, g1) = out[0], out[native.FLAG_WEIGHT_PLANES]
+    assert torch.isfinite(g0).all() and float(g0.abs().max()) > 0
+    assert torch.equal(y0, y1) and torch.equal(l0, l1) and torch.equal(g0, g1)
+
+
+@pytest.mark.parametrize("shape", [(5, 60, 48, 20, 10, 64, 128), (4, 100, 32, 38, 23, 128, 256)])
 def test_bf16s_producer_fused_pointwise_convs_equal_the_two_pass_path(shape):
     """bf16s training applies the depthwise BatchNorm + ReLU6 inside the pointwise GEMMs (forward and weight gradient);
     crnn_config.flags bit CRNN_FLAG_NO_DW_BN_FUSION materialises the activated tensor instead.  Same operands, same order of

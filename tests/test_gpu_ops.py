@@ -1589,6 +1589,70 @@ def test_three_plane_gemms_apply_batchnorm_relu6_while_staging(M, K, N):
     assert_close(host(dw1), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max() + 1e-6, what="weight gradient vs fp64")
 
 
+def _planes_of(x, stride=None):
+    """crnn_split3_planes of a device fp32 tensor -> (planes tensor [3 * stride] of bf16 words, stride)."""
+    n = x.numel(); stride = stride or n
+    pl = torch.full((3 * stride + 8,), -1, dtype=torch.int16, device="cuda")
+    ok(L().crnn_split3_planes(P(x), P(pl), n, stride, S()))
+    return pl, stride
+
+
+@pytest.mark.parametrize("n,extra", [(4, 0), (1028, 0), (128 * 512, 64), (1 << 20, 4)])
+def test_split3_planes_are_the_three_bf16_terms_of_each_value(n, extra):
+    """crnn_split3_planes: plane 0 = bf16(x) (round to nearest even), plane 1 = bf16(x - plane 0), plane 2 = bf16(x - plane 0 - plane 1); the three
+    terms add up to x to 2^-24 relative; words behind a plane's n values (the stride's slack) stay untouched; bad arguments refused."""
+    rs = np.random.RandomState(n % 977 + extra)
+    x = dev((rs.normal(size=n) * np.exp(rs.uniform(-6, 6, size=n))).astype(np.float32))
+    pl, st = _planes_of(x, n + extra)
+    w = pl[:3 * st].view(3, st)
+    if extra: assert bool((w[:, n:] == -1).all())
+    assert bool((pl[3 * st:] == -1).all())
+    planes = [(w[k, :n].int() << 16).view(torch.float32) for k in range(3)]
+    assert torch.equal(planes[0], x.bfloat16().float())
+    r1 = x - planes[0]
+    assert torch.equal(planes[1], r1.bfloat16().float())
+    assert torch.equal(planes[2], (r1 - planes[1]).bfloat16().float())
+    tot = planes[0].double() + planes[1].double() + planes[2].double()
+    assert float(((tot - x.double()).abs() / x.double().abs().clamp_min(1e-30)).max()) <= 2.0 ** -23
+    assert L().crnn_split3_planes(P(x), P(pl), n + 1, st + 4, S()) == -2 and L().crnn_split3_planes(P(x), P(pl), n, n - 4, S()) == -2
+    assert L().crnn_split3_planes(P(x), P(pl), n, st + 2, S()) == -2
+
+
+@pytest.mark.parametrize("M,K,N", [(128 * 40, 128, 256), (128 * 6, 512, 512), (128 * 3, 256, 64), (128 * 200, 64, 128), (128 * 9, 64, 64)])
+def test_three_plane_gemms_read_operands_split_beforehand(M, K, N):
+    """The *_pl entry points (weights -- and the incoming gradient -- handed over as bf16 planes from crnn_split3_planes instead of being split by
+    every tile that stages them) must return the very bits of their fp32-operand forms: forward product + BatchNorm statistics
+    (crnn_pwconv_bnrelu6_fwd_f32x3_pl), data gradient + BatchNorm-backward statistics (crnn_gemm_f32x3_bnstats_pl with the weight planes alone and
+    with both operands as planes).  Plane strides with slack, both tile widths; ragged shapes are refused (-3: the caller falls back)."""
+    rs = np.random.RandomState(M % 1000 + N + K + 11)
+    d = dev((rs.normal(size=(M, K)) * 1.5 + 0.4).astype(np.float32)); w = dev((rs.normal(size=(K, N)) * 0.1).astype(np.float32))
+    st = dev(np.concatenate([rs.normal(size=K), rs.uniform(0.5, 2.0, size=K), rs.normal(size=K) * 0.3 + 1.0, rs.normal(size=K) * 0.5 + 0.5]).astype(np.float32))
+    rows = L().crnn_pwconv_stat_rows(M)
+    q0, q1 = zeros(M, N), torch.full((M + 2, N), 7.0, device="cuda"); p0, p1 = zeros(rows, 2, N), zeros(rows, 2, N)
+    ok(L().crnn_pwconv_bnrelu6_fwd_f32x3(P(d), P(st), P(w), P(q0), M, N, K, P(p0), S()))
+    wpl, ws = _planes_of(w, K * N + 64)
+    for rep in range(2):
+        ok(L().crnn_pwconv_bnrelu6_fwd_f32x3_pl(P(d), P(st), P(w), P(wpl), ws, P(q1), M, N, K, P(p1), S()))
+    assert torch.equal(q1[:M], q0) and bool((q1[M:] == 7.0).all()), "forward differs: max %g" % float((q1[:M] - q0).abs().max())
+    assert torch.equal(p1, p0) and float(q0.abs().max()) > 0
+    if K % 64 == 0:
+        # data gradient of the same conv: da [M][K] = dq [M][N] . W [K][N]^T  (the entry point's N = conv K, its K = conv N)
+        dq = dev(rs.normal(size=(M, N)).astype(np.float32))
+        bnstate = st                                               # [mean | var | scale | shift] of the conv's K input channels
+        assert L().crnn_gemm_f32x3_bnstats_supported(M, K, N) == 0
+        r = L().crnn_gemm_f32x3_bnstats_rows(M)
+        da0, da1, da2 = zeros(M, K), zeros(M, K), zeros(M, K); s0, s1, s2 = zeros(r * 2 * K), zeros(r * 2 * K), zeros(r * 2 * K)
+        ok(L().crnn_gemm_f32x3_bnstats(P(dq), P(w), P(da0), M, K, N, P(d), P(bnstate), P(s0), S()))
+        ok(L().crnn_gemm_f32x3_bnstats_pl(P(dq), None, 0, P(w), P(wpl), ws, P(da1), M, K, N, P(d), P(bnstate), P(s1), S()))
+        assert torch.equal(da1, da0) and torch.equal(s1, s0), "weight planes: data gradient differs: max %g" % float((da1 - da0).abs().max())
+        qpl, qs = _planes_of(dq)
+        ok(L().crnn_gemm_f32x3_bnstats_pl(P(dq), P(qpl), qs, P(w), P(wpl), ws, P(da2), M, K, N, P(d), P(bnstate), P(s2), S()))
+        assert torch.equal(da2, da0) and torch.equal(s2, s0), "both operands as planes: data gradient differs: max %g" % float((da2 - da0).abs().max())
+        assert L().crnn_gemm_f32x3_bnstats_pl(P(dq), P(qpl), qs, P(w), None, 0, P(da2), M, K, N, P(d), P(bnstate), P(s2), S()) == -3
+    # ragged tiles: refused
+    assert L().crnn_pwconv_bnrelu6_fwd_f32x3_pl(P(d), P(st), P(w), P(wpl), ws, P(q1), M - 3, N, K, P(p1), S()) == -3
+
+
 def _window_major(t):
     """[B][H][W][C] -> rows in 2x2-window-major order: pixel (y, x) is row ((y/2)(W/2) + x/2) 4 + (y&1) 2 + (x&1) of its image."""
     B, H, W, C = t.shape
