@@ -399,7 +399,12 @@ def parity_check(B, n=16, precisions=("fp32", "bf16s"), gru=False):
     x, lab, il, ll = synthetic_batch(B, seed=0, T=cfg.T)
     p64 = y_ref = None
     for precision in precisions:
-        eng = Engine(B, dropout=False, precision=precision, gru=gru)
+        flags = None
+        if precision == "fp32_two_plane_forward":     # the parity mode with CRNN_FLAG_TWO_PLANE_FORWARD (opt-in)
+            precision, flags = "fp32", 131072 | int(os.environ.get("CRNN_FLAGS", "0"))
+        eng = Engine(B, dropout=False, precision=precision, gru=gru, flags=flags)
+        if flags is not None:
+            precision = "fp32_two_plane_forward"
         if p64 is None:
             p = initial_parameters(eng.layout, eng.cfg.units, gru, seed=1)
             rs = np.random.RandomState(2)
@@ -860,7 +865,8 @@ def main():
                 # the parity mode (fp32 storage + fp32-accurate three-plane GEMMs: the mode in which logits / CTC loss meet the 1e-3 tolerance and arg-max is
                 # bit-exact against the oracle, tests/test_gpu_model.py) timed in the same run on the same workload
                 res["parity_mode"] = dict(leg(B, max(3, min(args.steps, 10)), 2, precision="fp32"),
-                                          note="fp32 tensors + fp32-accurate GEMMs (three bf16 planes per operand, six bf16 MFMAs per k-step; CRNN_FLAGS=256 = fp32 MFMA, 20.6 ms): "
+                                          note="fp32 tensors + fp32-accurate forward GEMMs (three bf16 planes per operand, six bf16 MFMAs per k-step; CRNN_FLAGS=256 = fp32 MFMA, 20.6 ms; the conv "
+                                               "stack's backward GEMMs carry two planes = 16 significant bits per factor, `three_plane_backward` = three there too): "
                                                "the mode the 1e-3 logit / CTC-loss parity and bit-exact arg-max are asserted in; "
                                                "the headline bf16 line is outside that tolerance (bf16 conv-stack tensors: softmax within 2e-3, loss 2e-3 "
                                                "relative of the fp64 oracle).  Round 4: the depthwise stage on the fp32 forms of the row-stream kernels "
@@ -868,6 +874,11 @@ def main():
                 # the same step on the round-3 schedule (halo-tile depthwise kernels, three-kernel depthwise-stage backward, every BatchNorm-2 pass on its own):
                 # CRNN_FLAG_DW_TILE_KERNEL; same forward to summation order
                 res["parity_mode"]["tile_schedule"] = dict(leg(B, max(3, min(args.steps, 10)), 2, precision="fp32", flags=32), flags=32)
+                # plane counts of the conv stack's pointwise GEMMs (include/crnn_mi355x.h): default = three planes forward (fp32-accurate: what `parity`
+                # checks), two planes backward (16 significant bits per factor, gradients within 1e-5); strict = three everywhere; and two everywhere
+                # (its forward is checked against the oracle as parity["fp32_two_plane_forward"])
+                res["parity_mode"]["three_plane_backward"] = dict(leg(B, max(3, min(args.steps, 10)), 2, precision="fp32", flags=65536), flags=65536)
+                res["parity_mode"]["two_plane_forward"] = dict(leg(B, max(3, min(args.steps, 10)), 2, precision="fp32", flags=131072), flags=131072)
             if B != 64:
                 # the metric's literal batch size (BASELINE.json: "100x32 bs64"), same precision as the headline
                 res["bs64"] = leg(64, max(5, args.steps), 3, reps=3)
@@ -896,8 +907,8 @@ def main():
                 res["predict"] = predict_leg(1024, iters=20, precision=args.precision, cpu_sample=0 if args.no_cpu_baseline else 32)
         if world == 1 and not args.no_parity and args.imgh == 100:
             # CTC-loss / logit / arg-max parity of the benchmarked configuration against the oracle (the metric's second half)
-            res["parity"] = parity_check(B, 16, ("fp32", "bf16s") if args.precision == "bf16s" else ("fp32", args.precision) if args.precision != "fp32" else ("fp32",),
-                                         gru=args.gru)
+            res["parity"] = parity_check(B, 16, ("fp32", "fp32_two_plane_forward", "bf16s") if args.precision == "bf16s" else
+                                         ("fp32", args.precision) if args.precision != "fp32" else ("fp32", "fp32_two_plane_forward"), gru=args.gru)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_baseline_full)
         print(json.dumps(res), flush=True)

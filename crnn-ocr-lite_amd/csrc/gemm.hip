@@ -443,9 +443,9 @@ extern "C" int crnn_pwconv_fwd(const void* a, const void* w, void* q, long M, in
   const int mode = w_transposed ? 1 : 0, ldw = w_transposed ? K : N;
   // out_bnstate ([mean|var|scale|shift] of the BatchNorm after the conv, inference): q = ReLU6(product * scale + shift)
   const float* cs = out_bnstate ? out_bnstate + 2L * N : nullptr; const float* ch = out_bnstate ? out_bnstate + 3L * N : nullptr;
-  if (bf16_products == 2)   // fp32 tensors, fp32-accurate three-plane bf16 products (crnn_gemm_f32x3)
+  if (bf16_products == 2 || bf16_products == 3)   // fp32 tensors: 2 = fp32-accurate three-plane bf16 products (crnn_gemm_f32x3), 3 = two planes (crnn_gemm_f32x2)
     return gemm_bf16_impl(mode, a, w, q, (int)M, N, K, K, ldw, N, nullptr, 0, 0, 0, nullptr, 0, dt_a, dt_w, dt_q, stat_partials, stream, cs, ch,
-                          nullptr, nullptr, true);
+                          nullptr, nullptr, true, nullptr, nullptr, bf16_products == 2 ? 3 : 2);
   if (bf16_products)
     return gemm_bf16_impl(mode, a, w, q, (int)M, N, K, K, ldw, N, nullptr, 0, 0, 0, nullptr, 0, dt_a, dt_w, dt_q, stat_partials, stream, cs, ch);
   if (dt_a != CRNN_F32 || dt_w != CRNN_F32 || dt_q != CRNN_F32) return CRNN_ERR_ARG;
@@ -477,6 +477,19 @@ extern "C" int crnn_pwconv_bnrelu6_fwd_f32x3(const float* d, const float* in_bns
   if (M <= 0 || M > 0x7fffffffL || !in_bnstate) return CRNN_ERR_ARG;
   return gemm_bf16_impl(0, d, w, q, (int)M, N, K, K, N, N, nullptr, 0, 0, 0, nullptr, 0, CRNN_F32, CRNN_F32, CRNN_F32, stat_partials, stream,
                         nullptr, nullptr, in_bnstate + 2L * K, in_bnstate + 3L * K, true);
+}
+// Two-plane forms of the two entry points below / above (hi*hi + hi*mid + mid*hi: 16 significant bits per factor; crnn_gemm_f32x2_bnstats)
+extern "C" int crnn_pwconv_bnrelu6_fwd_f32x2(const float* d, const float* in_bnstate, const float* w, float* q, long M, int N, int K,
+                                             float* stat_partials, hipStream_t stream) {
+  if (M <= 0 || M > 0x7fffffffL || !in_bnstate) return CRNN_ERR_ARG;
+  return gemm_bf16_impl(0, d, w, q, (int)M, N, K, K, N, N, nullptr, 0, 0, 0, nullptr, 0, CRNN_F32, CRNN_F32, CRNN_F32, stat_partials, stream,
+                        nullptr, nullptr, in_bnstate + 2L * K, in_bnstate + 3L * K, true, nullptr, nullptr, 2);
+}
+extern "C" int crnn_pwconv_bnrelu6_wgrad_f32x2(const float* d, const float* in_bnstate, const float* g, float* dw, long M, int N, int K,
+                                               float* scratch, size_t scratch_bytes, hipStream_t stream) {
+  if (M <= 0 || M > 0x7fffffffL || !in_bnstate) return CRNN_ERR_ARG;
+  return gemm_bf16_impl(2, d, g, dw, K, N, (int)M, K, N, N, nullptr, 0, 0, 0, scratch, scratch_bytes, CRNN_F32, CRNN_F32, CRNN_F32, nullptr, stream,
+                        nullptr, nullptr, in_bnstate + 2L * K, in_bnstate + 3L * K, true, nullptr, nullptr, 2);
 }
 // ... with the weights as planes (crnn_split3_planes of w, plane stride w_plane_stride elements; null: the entry point above)
 extern "C" int crnn_pwconv_bnrelu6_fwd_f32x3_pl(const float* d, const float* in_bnstate, const float* w, const void* w_planes, long w_plane_stride, float* q,

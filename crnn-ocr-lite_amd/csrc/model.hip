@@ -254,8 +254,9 @@ const float* weight_operand(const Ctx& c, int mode, const float* B, int* dtB) {
   return B;
 }
 // GEMMs of the conv stack / dense layers / RNN input projections: bf16 products when cfg->mfma_bf16
+// planes: bf16 planes per operand of the parity mode's products (3 = fp32-accurate; 2 = 16 significant bits per factor, conv_planes below)
 int gemm(const Ctx& c, int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
-         const float* bias = nullptr, int act = 0, int acc = 0, int perm = 0) {
+         const float* bias = nullptr, int act = 0, int acc = 0, int perm = 0, int planes = 3) {
   if (c.cfg->mfma_bf16) {
     int dtB = CRNN_F32;
     B = weight_operand(c, mode, B, &dtB);
@@ -265,10 +266,20 @@ int gemm(const Ctx& c, int mode, const float* A, const float* B, float* C, int M
   // crnn_gemm_f32x3).  CRNN_FLAG_F32_MFMA_GEMMS: fp32 MFMA (an fmaf chain bit for bit)
   if (c.cfg->flags & CRNN_FLAG_F32_MFMA_GEMMS)
     return crnn_gemm_f32(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, c.scratch(), kGemmScratchBytes, c.s);
+  if (planes == 2) return crnn_gemm_f32x2(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, c.scratch(), kGemmScratchBytes, c.s);
   return crnn_gemm_f32x3(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, c.scratch(), kGemmScratchBytes, c.s);
 }
 // product selector of crnn_pwconv_fwd: 1 = bf16 products (bf16 modes), 2 = three-plane fp32-accurate products (parity mode), 0 = fp32 MFMA
 int pw_products(const crnn_config* cfg) { return cfg->mfma_bf16 ? 1 : ((cfg->flags & CRNN_FLAG_F32_MFMA_GEMMS) ? 0 : 2); }
+// Parity mode, pointwise GEMMs of the conv stack: bf16 planes per operand.  Forward: three (every kept partial product exact: fp32-level accuracy, the
+// 1e-3 logit / CTC / bit-exact arg-max parity is asserted on this path); CRNN_FLAG_TWO_PLANE_FORWARD (opt-in): two.  Backward (weight and data
+// gradients): two -- hi*hi + hi*mid + mid*hi, 16 significant bits per factor, relative error of a product <= 3 * 2^-18 (between TF32's 2^-11 and
+// fp32's 2^-24), half the MFMA work: gradients within 1e-5 of the three-plane ones; CRNN_FLAG_THREE_PLANE_BACKWARD: three there too.
+int conv_planes(const crnn_config* cfg, bool backward) {
+  return backward ? ((cfg->flags & CRNN_FLAG_THREE_PLANE_BACKWARD) ? 3 : 2) : ((cfg->flags & CRNN_FLAG_TWO_PLANE_FORWARD) ? 2 : 3);
+}
+// ... as crnn_pwconv_fwd's product selector for a forward conv of the stack (3 = two planes)
+int pw_products_fwd(const crnn_config* cfg) { return (pw_products(cfg) == 2 && conv_planes(cfg, false) == 2) ? 3 : pw_products(cfg); }
 // Parity mode with three-plane GEMMs, CRNN_FLAG_WEIGHT_PLANES (opt-in): the pointwise weights of blocks 2..7 are split into their bf16 planes ONCE, at
 // the start of the forward pass (crnn_split3_planes over the b2_pw .. b7_pw span of the parameter buffer -> workspace tensor "p3"), instead of by
 // every tile of the forward and data-gradient GEMMs that stages them (a tile of 128 rows re-splits the whole weight matrix).  Same words in LDS:
@@ -282,7 +293,9 @@ WeightPlanes weight_planes_span(const Ctx& c) {
   if (((uintptr_t)(c.params + s.lo) & 15) || (s.n & 3)) s.n = 0;
   return s;
 }
-const void* weight_planes(const Ctx& c, const float* w, long* stride) {
+const void* weight_planes(const Ctx& c, const float* w, long* stride, bool backward) {
+  *stride = 0;
+  if (conv_planes(c.cfg, backward) != 3) return nullptr;        // (the planes tensor holds three planes)
   const WeightPlanes s = weight_planes_span(c);
   *stride = s.n;
   if (!s.n || w < c.params + s.lo || w >= c.params + s.lo + s.n || ((w - c.params - s.lo) & 3)) return nullptr;
@@ -290,13 +303,13 @@ const void* weight_planes(const Ctx& c, const float* w, long* stride) {
 }
 // GEMM with explicit operand / result storage types (storage mode 2); falls back to the plain entry points otherwise
 int gemm_t(const Ctx& c, int mode, const float* A, int dtA, const float* B, int dtB, float* C, int dtC, int M, int N, int K, int lda,
-           int ldb, int ldc, const float* bias = nullptr, int act = 0, int acc = 0, int perm = 0) {
+           int ldb, int ldc, const float* bias = nullptr, int act = 0, int acc = 0, int perm = 0, int planes = 3) {
   if (c.cfg->mfma_bf16 == 2) {
     B = weight_operand(c, mode, B, &dtB);
     return crnn_gemm_bf16_ex(mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, c.scratch(), kGemmScratchBytes, dtA, dtB, dtC, c.s);
   }
   if (dtA != CRNN_F32 || dtB != CRNN_F32 || dtC != CRNN_F32) return CRNN_ERR_ARG;
-  return gemm(c, mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm);
+  return gemm(c, mode, A, B, C, M, N, K, lda, ldb, ldc, bias, act, acc, perm, planes);
 }
 // Training with bf16 conv-stack tensors: the BatchNorm + ReLU6 between a block's depthwise and pointwise convolutions is
 // applied by the pointwise GEMMs themselves (forward and weight gradient) while they stage the operand; the activated
@@ -623,7 +636,7 @@ extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, cons
                : fold ? crnn_pwconv_fwd_wres_folded(aa, wq, xo, M, co, ci, s2, stream) : crnn_gemm_wres_bf16(aa, wq, qq, (int)M, co, ci, stream);
         if (pool_rows > 1) { CRNN_TRY(rc); in = xo; continue; }        // (its shape rules were checked above: no fallback that could read window-major rows)
         if (rc == CRNN_ERR_UNSUPPORTED)
-          rc = crnn_pwconv_fwd(aa, wq, fold ? xo : qq, M, co, ci, nullptr, fold ? s2 : nullptr, pw_products(cfg), dtd, dtw, dtq, wt, stream);
+          rc = crnn_pwconv_fwd(aa, wq, fold ? xo : qq, M, co, ci, nullptr, fold ? s2 : nullptr, pw_products_fwd(cfg), dtd, dtw, dtq, wt, stream);
         CRNN_TRY(rc);
       }
       if (!fold) CRNN_TRY(crnn_bn_act_pool_drop_ex(qq, s2, xo, B, H, W, co, ph, pw, 0.f, seed, (uint32_t)i, dtq, c.dt("x" + p), stream));
@@ -670,9 +683,11 @@ extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, cons
       if (blk1) CRNN_TRY(crnn_pw1_bn_fwd(dd, s1, c.p(bp + "_pw"), qq, M, co, parts, dtq, stream));                      // block 1: outer product of relu6(BN(d))
       else if (ci == 1 && dtd == CRNN_F32) CRNN_TRY(crnn_pw1_fwd(aa, c.p(bp + "_pw"), qq, M, co, parts, dtq, stream));
       else if (fuse_x3) {
-        long wps = 0; const void* wpl = weight_planes(c, c.p(bp + "_pw"), &wps);
+        long wps = 0; const void* wpl = weight_planes(c, c.p(bp + "_pw"), &wps, false);
         int rc = wpl ? crnn_pwconv_bnrelu6_fwd_f32x3_pl(dd, s1, c.p(bp + "_pw"), wpl, wps, qq, M, co, ci, parts, stream) : CRNN_ERR_UNSUPPORTED;
-        if (rc == CRNN_ERR_UNSUPPORTED) rc = crnn_pwconv_bnrelu6_fwd_f32x3(dd, s1, c.p(bp + "_pw"), qq, M, co, ci, parts, stream);   // (ragged tiles: split while staging)
+        if (rc == CRNN_ERR_UNSUPPORTED)      // (no planes, or ragged tiles: split while staging)
+          rc = conv_planes(cfg, false) == 2 ? crnn_pwconv_bnrelu6_fwd_f32x2(dd, s1, c.p(bp + "_pw"), qq, M, co, ci, parts, stream)
+                                            : crnn_pwconv_bnrelu6_fwd_f32x3(dd, s1, c.p(bp + "_pw"), qq, M, co, ci, parts, stream);
         CRNN_TRY(rc);
       }
       else if (fuse_a) {
@@ -684,7 +699,8 @@ extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, cons
         }
         if (rc == CRNN_ERR_UNSUPPORTED) rc = crnn_pwconv_bnrelu6_fwd(dd, s1, wq, qq, M, co, ci, parts, dtq, wt, stream);
         CRNN_TRY(rc);
-      } else CRNN_TRY(crnn_pwconv_fwd(aa, wq, qq, M, co, ci, parts, nullptr, pw_products(cfg), dtd, dtw, dtq, wt, stream));
+      } else CRNN_TRY(crnn_pwconv_fwd(aa, wq, qq, M, co, ci, parts, nullptr, pw_products_fwd(cfg),
+                                      dtd, dtw, dtq, wt, stream));
     }
     CRNN_TRY(crnn_bn_finalize_folded(parts, stat_rows, co, M, c.p(bp + "_bn2_g"), c.p(bp + "_bn2_b"), s2, c.w("fold"), stream));
     bn_off += co;
@@ -1051,8 +1067,9 @@ int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t au
         CRNN_TRY(rc);
       }
       else if (fuse_dw_bn_x3(cfg, dtd, dtq, ci) && aligned16(c.w("d" + p), c.w("q" + p), c.w("bn1s" + p), c.p(bp + "_pw")))   // parity mode: likewise (the forward's own predicate)
-        CRNN_TRY(crnn_pwconv_bnrelu6_wgrad_f32x3(c.w("d" + p), c.w("bn1s" + p), gB, c.g(bp + "_pw"), M, co, ci, cw.scratch(), kGemmScratchBytes, cw.s));
-      else CRNN_TRY(gemm_t(cw, 2, c.w("a" + p), dtd, gB, dtq, c.g(bp + "_pw"), CRNN_F32, ci, co, (int)M, ci, co, co));
+        CRNN_TRY((conv_planes(cfg, true) == 2 ? crnn_pwconv_bnrelu6_wgrad_f32x2 : crnn_pwconv_bnrelu6_wgrad_f32x3)(
+            c.w("d" + p), c.w("bn1s" + p), gB, c.g(bp + "_pw"), M, co, ci, cw.scratch(), kGemmScratchBytes, cw.s));
+      else CRNN_TRY(gemm_t(cw, 2, c.w("a" + p), dtd, gB, dtq, c.g(bp + "_pw"), CRNN_F32, ci, co, (int)M, ci, co, co, nullptr, 0, 0, 0, conv_planes(cfg, true)));
       if (side) CRNN_TRY(fj.mark(&gB_free));
       // data gradient da[M][ci] = dq[M][co] . W[ci][co]^T: the persistent LDS-DMA kernels where their shape rules hold
       int rc = CRNN_ERR_UNSUPPORTED;
@@ -1073,12 +1090,13 @@ int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t au
       // parity mode: the three-plane GEMM's epilogue takes the statistics pass of the depthwise BatchNorm's backward (it holds the finished da tile)
       if (rc == CRNN_ERR_UNSUPPORTED && !fused_bf && pw_products(cfg) == 2 && dtq == CRNN_F32 && dtd == CRNN_F32 &&
           !(cfg->flags & CRNN_FLAG_NO_BN_STATS_FUSION) && crnn_gemm_f32x3_bnstats_supported(M, ci, co) == CRNN_OK) {
-        long wps = 0; const void* wpl = weight_planes(c, c.p(bp + "_pw"), &wps);
-        rc = crnn_gemm_f32x3_bnstats_pl(gB, nullptr, 0, c.p(bp + "_pw"), wpl, wps, gA, M, ci, co, c.w("d" + p), c.w("bn1s" + p), c.w("partials"), stream);
+        long wps = 0; const void* wpl = weight_planes(c, c.p(bp + "_pw"), &wps, true);
+        if (conv_planes(cfg, true) == 2) rc = crnn_gemm_f32x2_bnstats(gB, c.p(bp + "_pw"), gA, M, ci, co, c.w("d" + p), c.w("bn1s" + p), c.w("partials"), stream);
+        else rc = crnn_gemm_f32x3_bnstats_pl(gB, nullptr, 0, c.p(bp + "_pw"), wpl, wps, gA, M, ci, co, c.w("d" + p), c.w("bn1s" + p), c.w("partials"), stream);
         if (rc == CRNN_ERR_UNSUPPORTED && wpl) rc = crnn_gemm_f32x3_bnstats(gB, c.p(bp + "_pw"), gA, M, ci, co, c.w("d" + p), c.w("bn1s" + p), c.w("partials"), stream);
         bn1_stats_rows = (rc == CRNN_OK) ? crnn_gemm_f32x3_bnstats_rows(M) : 0;
       }
-      if (rc == CRNN_ERR_UNSUPPORTED) rc = gemm_t(c, 1, gB, dtq, c.p(bp + "_pw"), CRNN_F32, gA, dtd, (int)M, ci, co, co, co, ci);
+      if (rc == CRNN_ERR_UNSUPPORTED) rc = gemm_t(c, 1, gB, dtq, c.p(bp + "_pw"), CRNN_F32, gA, dtd, (int)M, ci, co, co, co, ci, nullptr, 0, 0, 0, conv_planes(cfg, true));
       CRNN_TRY(rc);
     }
     const float* xin = (i == 1) ? c.w("x0") : c.w("x" + std::to_string(i - 1));

@@ -16,6 +16,8 @@ B="timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-seco
 $B --precision fp32 > $OUT/${TAG}_bench_fp32.json 2>> $OUT/${TAG}_bench.err
 CRNN_FLAGS=4096 $B --precision fp32 --no-roofline > $OUT/${TAG}_bench_fp32_no_bn2_fusion.json 2>> $OUT/${TAG}_bench.err
 CRNN_FLAGS=32 $B --precision fp32 --no-roofline > $OUT/${TAG}_bench_fp32_tile_schedule.json 2>> $OUT/${TAG}_bench.err
+CRNN_FLAGS=65536 $B --precision fp32 --no-roofline > $OUT/${TAG}_bench_fp32_three_plane_backward.json 2>> $OUT/${TAG}_bench.err
+CRNN_FLAGS=131072 $B --precision fp32 --no-roofline > $OUT/${TAG}_bench_fp32_two_plane_forward.json 2>> $OUT/${TAG}_bench.err
 $B --precision bf16 > $OUT/${TAG}_bench_bf16.json 2>> $OUT/${TAG}_bench.err
 $B --imgh 200 --max-len 21 > $OUT/${TAG}_bench_iam.json 2>> $OUT/${TAG}_bench.err
 $B --gru > $OUT/${TAG}_bench_gru.json 2>> $OUT/${TAG}_bench.err
@@ -30,6 +32,7 @@ timeout 200 python scripts/dws_f32_bench.py 2>/dev/null | grep -v amdgpu > $OUT/
 timeout 100 python scripts/dws_bench.py 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_dw_fwd_stream_bench.txt
 timeout 100 python scripts/dbs_bench.py 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_dw_bwd_stream_bench.txt
 timeout 200 python scripts/wres_fwd_ablate.py 0 1 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_wres_fwd_depth.txt
+timeout 100 python scripts/x2_bench.py 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_x2_bench.txt
 cd /tmp && export TMPDIR=/tmp
 prof() {  # name, bench args...
   n=$1; shift
@@ -58,7 +61,7 @@ done
 cd $ROOT
 find $OUT -name "*kernel_trace.csv" -size +30M -delete
 grep -E "passed|failed|error" $OUT/${TAG}_pytest_gpu.log | tail -3
-for f in bench_bf16s bench_fp32 bench_fp32_no_bn2_fusion bench_fp32_tile_schedule bench_bf16 bench_iam bench_gru bench_bn2_dw_fusion bench_bn2_dw_stats_fusion bench_step_kernels bench_no_bn_stats_fusion bench_bf16s_again predict; do echo -n "$f: "; cut -c1-170 $OUT/${TAG}_$f.json; echo; done
+for f in bench_bf16s bench_fp32 bench_fp32_no_bn2_fusion bench_fp32_tile_schedule bench_fp32_three_plane_backward bench_fp32_two_plane_forward bench_bf16 bench_iam bench_gru bench_bn2_dw_fusion bench_bn2_dw_stats_fusion bench_step_kernels bench_no_bn_stats_fusion bench_bf16s_again predict; do echo -n "$f: "; cut -c1-170 $OUT/${TAG}_$f.json; echo; done
 grep -v amdgpu $OUT/${TAG}_bench.err | tail -5
 grep "step span" $OUT/${TAG}_step_timeline_*.txt
 cat $OUT/${TAG}_summary.txt

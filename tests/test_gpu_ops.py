@@ -1653,6 +1653,66 @@ def test_three_plane_gemms_read_operands_split_beforehand(M, K, N):
     assert L().crnn_pwconv_bnrelu6_fwd_f32x3_pl(P(d), P(st), P(w), P(wpl), ws, P(q1), M - 3, N, K, P(p1), S()) == -3
 
 
+@pytest.mark.parametrize("M,K,N", [(128 * 40, 128, 256), (128 * 6, 512, 512), (128 * 3 + 5, 256, 64), (128 * 200, 64, 128), (1000, 64, 128)])
+def test_two_plane_gemms_carry_sixteen_bits_per_factor(M, K, N):
+    """The f32x2 entry points (two bf16 planes per operand, products hi*hi + hi*mid + mid*hi, fp32 accumulation: the parity mode's backward GEMMs) against
+    their three-plane forms and an fp64 reference: every result within 2e-5 of the largest magnitude (a product's relative error is <= 3 * 2^-18;
+    measured 5e-6), i.e. two orders of magnitude tighter than single-plane bf16 products, with the three-plane result within 2e-6.  Forward with
+    statistics, data gradient with the BatchNorm-backward statistics (whole tiles), weight gradient (split reduction), the plain GEMM entry in all
+    three modes; whole and ragged tiles; run-to-run identical."""
+    rs = np.random.RandomState(M % 1000 + N + K + 5)
+    d = dev((rs.normal(size=(M, K)) * 1.5 + 0.4).astype(np.float32)); w = dev((rs.normal(size=(K, N)) * 0.1).astype(np.float32))
+    g = dev(rs.normal(size=(M, N)).astype(np.float32))
+    st = dev(np.concatenate([rs.normal(size=K), rs.uniform(0.5, 2.0, size=K), rs.normal(size=K) * 0.3 + 1.0, rs.normal(size=K) * 0.5 + 0.5]).astype(np.float32))
+    a = zeros(M, K)
+    ok(L().crnn_bn_act_pool_drop_ex(P(d), P(st), P(a), 1, 1, M, K, 1, 1, 0.0, 0, 0, 0, 0, S()))
+    a64, w64, g64 = host(a).astype(np.float64), host(w).astype(np.float64), host(g).astype(np.float64)
+    rows = L().crnn_pwconv_stat_rows(M)
+    scr = zeros(16 * 1024 * 1024); sb = ctypes.c_size_t(scr.numel() * 4)
+
+    def close(x2, x3, ref, what):
+        x2, x3 = host(x2).astype(np.float64), host(x3).astype(np.float64)
+        m = np.abs(ref).max()
+        e2, e3 = np.abs(x2 - ref).max() / m, np.abs(x3 - ref).max() / m
+        assert e3 <= 2e-6 and e2 <= 2e-5, (what, e2, e3)
+        return e2
+    # forward + statistics
+    q3, q2 = zeros(M, N), torch.full((M + 2, N), 7.0, device="cuda"); p3, p2 = zeros(rows, 2, N), zeros(rows, 2, N)
+    ok(L().crnn_pwconv_bnrelu6_fwd_f32x3(P(d), P(st), P(w), P(q3), M, N, K, P(p3), S()))
+    for rep in range(2):
+        ok(L().crnn_pwconv_bnrelu6_fwd_f32x2(P(d), P(st), P(w), P(q2), M, N, K, P(p2), S()))
+        if rep == 0: first = q2.clone()
+        else: assert torch.equal(first, q2)
+    assert bool((q2[M:] == 7.0).all())
+    e = close(q2[:M], q3, a64 @ w64, "forward")
+    s2, s3 = host(p2).astype(np.float64).sum(0), host(p3).astype(np.float64).sum(0)
+    assert np.abs(s2 - s3).max() <= 1e-4 * np.abs(s3).max(), "statistics"
+    # weight gradient (producer prologue, split reduction)
+    dw3, dw2 = zeros(K, N), zeros(K, N)
+    ok(L().crnn_pwconv_bnrelu6_wgrad_f32x3(P(d), P(st), P(g), P(dw3), M, N, K, P(scr), sb, S()))
+    ok(L().crnn_pwconv_bnrelu6_wgrad_f32x2(P(d), P(st), P(g), P(dw2), M, N, K, P(scr), sb, S()))
+    close(dw2, dw3, a64.T @ g64, "weight gradient")
+    # plain entry: the unfused forms of the same three products
+    for mode, (A, Bm, Cs, m_, n_, k_, lda, ldb) in {0: (a, w, (M, N), M, N, K, K, N), 1: (g, w, (M, K), M, K, N, N, N), 2: (a, g, (K, N), K, N, M, K, N)}.items():
+        c3, c2 = zeros(*Cs), zeros(*Cs)
+        ok(L().crnn_gemm_f32x3(mode, P(A), P(Bm), P(c3), m_, n_, k_, lda, ldb, n_, None, 0, 0, 0, P(scr), sb, S()))
+        ok(L().crnn_gemm_f32x2(mode, P(A), P(Bm), P(c2), m_, n_, k_, lda, ldb, n_, None, 0, 0, 0, P(scr), sb, S()))
+        ref = a64 @ w64 if mode == 0 else g64 @ w64.T if mode == 1 else a64.T @ g64
+        close(c2, c3, ref, "plain mode %d" % mode)
+    # data gradient with the BatchNorm-backward statistics (whole tiles only)
+    if L().crnn_gemm_f32x3_bnstats_supported(M, K, N) == 0:
+        r = L().crnn_gemm_f32x3_bnstats_rows(M)
+        da3, da2 = zeros(M, K), zeros(M, K); t3, t2 = zeros(r * 2 * K), zeros(r * 2 * K)
+        ok(L().crnn_gemm_f32x3_bnstats(P(g), P(w), P(da3), M, K, N, P(d), P(st), P(t3), S()))
+        ok(L().crnn_gemm_f32x2_bnstats(P(g), P(w), P(da2), M, K, N, P(d), P(st), P(t2), S()))
+        close(da2, da3, g64 @ w64.T, "data gradient")
+        b2, b3 = host(t2).astype(np.float64).reshape(r, 2, K).sum(0), host(t3).astype(np.float64).reshape(r, 2, K).sum(0)
+        assert np.abs(b2 - b3).max() <= 1e-4 * np.abs(b3).max() + 1e-6, "BatchNorm-backward statistics"
+    else:
+        assert L().crnn_gemm_f32x2_bnstats(P(g), P(w), P(zeros(M, K)), M, K, N, P(d), P(st), P(zeros(8)), S()) == -3
+    assert e > 1e-8, "the two-plane form returned the three-plane bits: not exercised"
+
+
 def _window_major(t):
     """[B][H][W][C] -> rows in 2x2-window-major order: pixel (y, x) is row ((y/2)(W/2) + x/2) 4 + (y&1) 2 + (x&1) of its image."""
     B, H, W, C = t.shape
