@@ -271,9 +271,10 @@ int gemm(const Ctx& c, int mode, const float* A, const float* B, float* C, int M
 }
 // product selector of crnn_pwconv_fwd: 1 = bf16 products (bf16 modes), 2 = three-plane fp32-accurate products (parity mode), 0 = fp32 MFMA
 int pw_products(const crnn_config* cfg) { return cfg->mfma_bf16 ? 1 : ((cfg->flags & CRNN_FLAG_F32_MFMA_GEMMS) ? 0 : 2); }
-// Parity mode, pointwise GEMMs of the conv stack: bf16 planes per operand.  Forward: three (every kept partial product exact: fp32-level accuracy, the
-// 1e-3 logit / CTC / bit-exact arg-max parity is asserted on this path); CRNN_FLAG_TWO_PLANE_FORWARD (opt-in): two.  Backward (weight and data
-// gradients): two -- hi*hi + hi*mid + mid*hi, 16 significant bits per factor, relative error of a product <= 3 * 2^-18 (between TF32's 2^-11 and
+// Parity mode: bf16 planes per operand of the step's GEMMs.  Forward: three (every kept partial product exact: fp32-level accuracy, the 1e-3 logit /
+// CTC / bit-exact arg-max parity is asserted on this path); CRNN_FLAG_TWO_PLANE_FORWARD (opt-in): two in the conv stack's pointwise convolutions.
+// Backward (every weight- and data-gradient GEMM: conv stack, dense layers, RNN projections; the recurrences themselves stay on the fp32 MFMA):
+// two -- hi*hi + hi*mid + mid*hi, 16 significant bits per factor, relative error of a product <= 3 * 2^-18 (between TF32's 2^-11 and
 // fp32's 2^-24), half the MFMA work: gradients within 1e-5 of the three-plane ones; CRNN_FLAG_THREE_PLANE_BACKWARD: three there too.
 int conv_planes(const crnn_config* cfg, bool backward) {
   return backward ? ((cfg->flags & CRNN_FLAG_THREE_PLANE_BACKWARD) ? 3 : 2) : ((cfg->flags & CRNN_FLAG_TWO_PLANE_FORWARD) ? 2 : 3);
@@ -849,7 +850,7 @@ static int gemm_tn(const Ctx& c, const float* A, const float* B, float* C, int M
     const int rc = crnn_gemm_tn_stream(A, lda, B, ldb, C, ldc, M, N, K, c.scratch(), kGemmScratchBytes, c.s);
     if (rc != CRNN_ERR_UNSUPPORTED) return rc;
   }
-  return gemm(c, 2, A, B, C, M, N, K, lda, ldb, ldc);
+  return gemm(c, 2, A, B, C, M, N, K, lda, ldb, ldc, nullptr, 0, 0, 0, conv_planes(c.cfg, true));
 }
 static int rnn_bwd_wgrads(const Ctx& c, int layer, const float* xin, int ldx, int din, const float* hf, const float* hb, int ldh) {
   const Dims& d = c.d;
@@ -865,8 +866,8 @@ static int rnn_bwd_wgrads(const Ctx& c, int layer, const float* xin, int ldx, in
   CRNN_TRY(gemm_tn(c, hf, dzf + (long)B * G, c.g("rnn" + l + "f_u"), u, Nh, K1, ldh, G, G));
   CRNN_TRY(gemm_tn(c, hb + (long)B * ldh, dzb, c.g("rnn" + l + "b_u"), u, Nh, K1, ldh, G, G));
   if (c.cfg->gru) {
-    CRNN_TRY(gemm(c, 2, c.w("cs" + l + "f"), dzf + 2 * u, c.g("rnn" + l + "f_u") + 2 * u, u, u, TB, u, G, G));
-    CRNN_TRY(gemm(c, 2, c.w("cs" + l + "b"), dzb + 2 * u, c.g("rnn" + l + "b_u") + 2 * u, u, u, TB, u, G, G));
+    CRNN_TRY(gemm(c, 2, c.w("cs" + l + "f"), dzf + 2 * u, c.g("rnn" + l + "f_u") + 2 * u, u, u, TB, u, G, G, nullptr, 0, 0, 0, conv_planes(c.cfg, true)));
+    CRNN_TRY(gemm(c, 2, c.w("cs" + l + "b"), dzb + 2 * u, c.g("rnn" + l + "b_u") + 2 * u, u, u, TB, u, G, G, nullptr, 0, 0, 0, conv_planes(c.cfg, true)));
   }
   if (lstm_bwd_persistent(c, layer)) {    // the persistent backward summed dz over time per 16-row batch tile: the tiles in a fixed order
     CRNN_TRY(crnn_partials_sum(c.w("dbp" + l + "f"), crnn_rnn_db_rows(B), G, c.g("rnn" + l + "f_b"), 1.f, c.s));
@@ -888,8 +889,8 @@ static int rnn_bwd_dx(const Ctx& c, int layer, int din, float* dxin) {
       if (rc != CRNN_ERR_UNSUPPORTED) return rc;
     }
   }
-  CRNN_TRY(gemm(c, 1, c.w("dz" + l + "f"), c.p("rnn" + l + "f_w"), dxin, TB, din, G, G, G, din));
-  return gemm(c, 1, c.w("dz" + l + "b"), c.p("rnn" + l + "b_w"), dxin, TB, din, G, G, G, din, nullptr, 0, 1);
+  CRNN_TRY(gemm(c, 1, c.w("dz" + l + "f"), c.p("rnn" + l + "f_w"), dxin, TB, din, G, G, G, din, nullptr, 0, 0, 0, conv_planes(c.cfg, true)));
+  return gemm(c, 1, c.w("dz" + l + "b"), c.p("rnn" + l + "b_w"), dxin, TB, din, G, G, G, din, nullptr, 0, 1, 0, conv_planes(c.cfg, true));
 }
 
 // The backward runs in two stages so that a data-parallel host can start the gradient all-reduce of the upper
@@ -975,9 +976,9 @@ int backward_top(const Ctx& c0, const int* labels, const int* input_length, cons
   // ---- dense2: weight / bias gradients on the side stream, the data gradient feeds the recurrent layers
   const float* r2 = c.w("r2d");
   CRNN_TRY(fj.fork());
-  CRNN_TRY(gemm(ca, 2, r2, c.w("dlogits"), c.g("dense2_w"), 2 * u, d.C, TB, 2 * u, d.C, d.C));
+  CRNN_TRY(gemm(ca, 2, r2, c.w("dlogits"), c.g("dense2_w"), 2 * u, d.C, TB, 2 * u, d.C, d.C, nullptr, 0, 0, 0, conv_planes(cfg, true)));
   CRNN_TRY(colsum(ca, c.w("dlogits"), TB, d.C, d.C, c.g("dense2_b")));
-  CRNN_TRY(gemm(c, 1, c.w("dlogits"), c.p("dense2_w"), c.w("dr2"), TB, 2 * u, d.C, d.C, d.C, 2 * u));
+  CRNN_TRY(gemm(c, 1, c.w("dlogits"), c.p("dense2_w"), c.w("dr2"), TB, 2 * u, d.C, d.C, d.C, 2 * u, nullptr, 0, 0, 0, conv_planes(cfg, true)));
   if (cfg->dropout) CRNN_TRY(crnn_dropout(c.w("dr2"), c.w("dr2"), TB, 2 * u, 2 * u, 2 * u, kDropRnn, seed, kLayerRnn, stream));
   // ---- Bidirectional LSTM / GRU x2
   CRNN_TRY(rnn_bwd_chain(c, 2, c.w("h2"), c.w("h2") + u, 2 * u, c.w("dr2"), c.w("dr2") + u, 2 * u));
@@ -991,10 +992,10 @@ int backward_top(const Ctx& c0, const int* labels, const int* input_length, cons
   // ---- Dropout(.4) + relu of dense1, rows back to batch-major
   CRNN_TRY(crnn_relu_bwd(c.w("dn1"), c.w("ddn1"), c.w("gbm"), TB, d.tds, cfg->dropout ? 1.0f / (1.0f - kDropDense1) : 1.0f, B, stream));
   const float* feat = c.w("x7");
-  CRNN_TRY(gemm_t(c, 2, feat, c.dt("x7"), c.w("gbm"), CRNN_F32, c.g("dense1_w"), CRNN_F32, d.feat, d.tds, TB, d.feat, d.tds, d.tds));
+  CRNN_TRY(gemm_t(c, 2, feat, c.dt("x7"), c.w("gbm"), CRNN_F32, c.g("dense1_w"), CRNN_F32, d.feat, d.tds, TB, d.feat, d.tds, d.tds, nullptr, 0, 0, 0, conv_planes(cfg, true)));
   CRNN_TRY(colsum(c, c.w("gbm"), TB, d.tds, d.tds, c.g("dense1_b")));
   float* gA = c.w("gA"); float* gB = c.w("gB");
-  CRNN_TRY(gemm_t(c, 1, c.w("gbm"), CRNN_F32, c.p("dense1_w"), CRNN_F32, gA, c.gdt(), TB, d.feat, d.tds, d.tds, d.tds, d.feat));
+  CRNN_TRY(gemm_t(c, 1, c.w("gbm"), CRNN_F32, c.p("dense1_w"), CRNN_F32, gA, c.gdt(), TB, d.feat, d.tds, d.tds, d.tds, d.feat, nullptr, 0, 0, 0, conv_planes(cfg, true)));
   return flush_deferred(c);                             // every gradient of this stage is final (a data-parallel host exchanges them now)
 }
 

@@ -75,9 +75,9 @@ typedef struct {
                                          GEMM (crnn_gemm_bf16_ex / crnn_pwconv_bnrelu6_*) instead of the streaming kernels (crnn_pwconv_bnrelu6_fwd_wres,
                                          crnn_gemm_wres_bf16, crnn_pwconv_bnrelu6_wgrad_stream).  Same products and data gradients bit for bit; the
                                          BatchNorm-2 statistics and the weight gradients are the same sums in another order (fp32 round-off) */
-#define CRNN_FLAG_THREE_PLANE_BACKWARD 65536 /* parity mode: the conv stack's weight- and data-gradient GEMMs with three bf16 planes per operand (fp32-accurate, as
-                                         the forward) instead of two (crnn_gemm_f32x2*: 16 significant bits per factor, gradients within 1e-5 of these, half the
-                                         MFMA work -- the default since round 4) */
+#define CRNN_FLAG_THREE_PLANE_BACKWARD 65536 /* parity mode: the backward GEMMs (weight and data gradients of the conv stack, the dense layers and the RNN projections)
+                                         with three bf16 planes per operand (fp32-accurate, as the forward) instead of two (crnn_gemm_f32x2*: 16 significant
+                                         bits per factor, gradients within 1e-5 of these, half the MFMA work -- the default since round 4) */
 #define CRNN_FLAG_TWO_PLANE_FORWARD 131072 /* opt-in, parity mode: the conv stack's forward pointwise GEMMs with two planes too (logits move by ~1e-5: inside
                                          north_star's 1e-3, outside "fp32-accurate") */
 #define CRNN_FLAG_WEIGHT_PLANES 32768    /* opt-in, parity mode: the pointwise GEMMs read bf16 planes of their weights split once per step (crnn_split3_planes +
@@ -503,7 +503,7 @@ int crnn_gemm_f32x3_bnstats(const float* dq, const float* W, float* da, long M, 
 /* Two-plane forms (f32x2) of crnn_gemm_f32x3_bnstats, crnn_pwconv_bnrelu6_fwd_f32x3 and crnn_pwconv_bnrelu6_wgrad_f32x3: every operand split into TWO bf16
  * planes (hi = bf16(x), mid = bf16(x - hi): 16 significant bits) and the three products hi*hi + hi*mid + mid*hi accumulated in fp32 -- relative error of
  * a product <= 3 * 2^-18 (fp32: 2^-24, TF32: 2^-11), half the MFMA work and two thirds of the LDS traffic of the three-plane forms.  Same arguments, shapes
- * and return codes.  The parity-mode step uses them for the BACKWARD GEMMs of the conv stack (CRNN_FLAG_THREE_PLANE_BACKWARD: three planes there too);
+ * and return codes.  The parity-mode step uses them for its BACKWARD GEMMs (CRNN_FLAG_THREE_PLANE_BACKWARD: three planes there too);
  * its forward keeps three planes. */
 int crnn_gemm_f32x2(int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* bias, int act,
                     int accumulate, int permP, float* scratch, size_t scratch_bytes, crnn_stream_t stream);   /* crnn_gemm_f32x3's contract */

@@ -483,10 +483,10 @@ def test_parity_mode_weight_planes_split_once_change_no_bit(shape):
 
 @pytest.mark.parametrize("shape", [(5, 60, 48, 20, 10, 64, 128), (4, 100, 32, 38, 23, 128, 256)])
 def test_parity_mode_two_plane_backward_gemms_stay_within_1e_5_of_three_planes(shape):
-    """Parity mode: the conv stack's backward GEMMs (weight and data gradients of the six pointwise convolutions) carry two bf16 planes per operand
-    by default (16 significant bits per factor, half the MFMA work), the forward three.  Against CRNN_FLAG_THREE_PLANE_BACKWARD: the same forward
-    bit for bit -- posteriors, loss, hence every gate decision -- and gradients within 1e-4 of the norm (measured 1e-5; tensor by tensor within
-    2e-4 of the tensor's largest element).  CRNN_FLAG_TWO_PLANE_FORWARD (opt-in) moves the posteriors by < 1e-4 and the CTC costs by < 1e-4
+    """Parity mode: the backward GEMMs (weight and data gradients of the six pointwise convolutions, the dense layers and the RNN projections) carry
+    two bf16 planes per operand by default (16 significant bits per factor, half the MFMA work), the forward three.  Against
+    CRNN_FLAG_THREE_PLANE_BACKWARD: the same forward bit for bit -- posteriors, loss, hence every gate decision -- and gradients within 1e-4 of
+    the norm (measured 1e-5; tensor by tensor within 1e-3 of the tensor's largest element, measured 1e-4 on the tensor with the most cancellation).  CRNN_FLAG_TWO_PLANE_FORWARD (opt-in) moves the posteriors by < 1e-4 and the CTC costs by < 1e-4
     relative, with identical greedy decodes."""
     from crnn_mi355x import native
     B, imgh, imgw, ncls, max_len, tds, u = shape
@@ -515,7 +515,7 @@ def test_parity_mode_two_plane_backward_gemms_stay_within_1e_5_of_three_planes(s
         if float(b.abs().max()) > 0:
             worst = max(worst, float((a - b).abs().max() / b.abs().max()))
     print("two-plane backward: gradient rel L2 %.3g, worst tensor max-rel %.3g" % (rel, worst))
-    assert worst < 2e-4, worst
+    assert worst < 1e-3, worst
     yf, lf, gf, df = out[native.FLAG_TWO_PLANE_FORWARD | native.FLAG_THREE_PLANE_BACKWARD]
     dy = float((yf - y3).abs().max()); dl = float(((lf - l3).abs() / l3.abs().clamp_min(1.0)).max())
     print("two-plane forward: max |dy| %.3g, max rel dloss %.3g" % (dy, dl))
