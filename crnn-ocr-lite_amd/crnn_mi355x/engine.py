@@ -38,7 +38,9 @@ class Engine:
                  gru=False, stn=True, dropout=True, device=None, precision="fp32", share=None, flags=None):
         """share: another Engine of the same architecture (any batch size) whose parameter / gradient / BatchNorm / optimizer-
         state tensors this one adopts (only the workspace and the batch-shaped outputs are its own).
-        flags: bit set of native.FLAG_* (schedule A/B switches with identical numerics; default: $CRNN_FLAGS or 0)."""
+        flags: bit set of native.FLAG_* (default: $CRNN_FLAGS or 0): schedule A/B switches -- same results bit for bit or to summation order, as
+        include/crnn_mi355x.h says per flag -- and the parity mode's product-precision switches FLAG_THREE_PLANE_BACKWARD / FLAG_TWO_PLANE_FORWARD /
+        FLAG_F32_MFMA_GEMMS."""
         if not torch.cuda.is_available():
             raise RuntimeError("the CRNN hot path needs an AMD GPU (gfx950); there is no CPU fallback")
         self.lib = native.lib()
