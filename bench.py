@@ -497,14 +497,14 @@ def cpu_baseline(full=False):
     """The reference's CPU path is Keras-TF (train.py with --G 0), absent from this image; what IS timed here, on this box's host
     cores, is the torch-CPU fp32 restatement of the same graph (oracle/torch_port.py: training-mode forward, CTC cost, autograd
     backward, global-norm clip, Keras-form Adam) on the metric's literal batch: 64 synthetic 100x32 images (BASELINE configs[0]).
-    Bounded sample (about 25-30 s of CPU work): one untimed warm-up step + two timed steps with 16 threads; one warm-up + one timed
-    step with 4 threads (the reference's own CPU setting, predict.py:88-93)."""
+    Bounded sample (about 40 s of CPU work): one untimed warm-up step + five timed steps with 16 threads; then one timed step with 4
+    threads (the reference's own CPU setting, predict.py:88-93)."""
     from oracle import torch_port as TP
     # this graph does not scale over cores on the CPU (52-step Python LSTM loops, small ops): measured on the MI355X box's host
     # (2 x EPYC 9575F, 256 logical cores) 4 / 16 / 32 / 64 threads = 6.2 / 6.5 / 6.3 / 9.1 s per step, and minutes per step with all
     # 256 -- so "all cores" is capped at 16 threads and `cores` states the threads actually used
     cores = min(os.cpu_count() or 1, 16)
-    nwarm, nsteps = (5, 20) if full else (1, 3)
+    nwarm, nsteps = (5, 20) if full else (1, 5)
     sall, _ = TP.train_step_benchmark(batch=64, threads=cores, steps=nsteps, warmup=nwarm)
     s4, _ = TP.train_step_benchmark(batch=64, threads=4, steps=nsteps if full else 1, warmup=0)     # the allocator / thread pools are warm by now
     return {"value": round(64 / sall, 2), "unit": "images/sec", "cores": int(cores), "kind": "port",
@@ -515,7 +515,7 @@ def cpu_baseline(full=False):
                       "step(s) with 4 threads (the reference's CPU setting, predict.py:88-93); %s; Keras-TF itself is not in the image"
                       % (nwarm, nsteps, cores, nsteps if full else 1,
                          "BASELINE.md's full protocol (--cpu-baseline-full)" if full else
-                         "a bounded sample (about 30 s of CPU work; --cpu-baseline-full runs BASELINE.md's 5 + 20 steps: 2.5 minutes)")}
+                         "a bounded sample (about 40 s of CPU work; --cpu-baseline-full runs BASELINE.md's 5 + 20 steps: 2.5 minutes)")}
 
 
 def predict_leg(batch=1024, iters=20, precision="bf16s", cpu_sample=32):
@@ -682,6 +682,25 @@ def timed_steps(eng, batch, opt, steps, warmup, it0=0):
     return time.perf_counter() - t0, float(loss.mean().item())
 
 
+def collective_transport_info(dist):
+    """What the gradient exchange ran over, for the record (rank 0): backend, RCCL version, the NCCL_* / RCCL_* / HSA_* environment, visible GPUs
+    and the number of xGMI links rocm-smi reports between them (0 on a single-GPU box or when the tool is missing).  Informational: never raises."""
+    info = {"backend": dist.get_backend(), "visible_gpus": torch.cuda.device_count()}
+    try:
+        if dist.get_backend() == "nccl":
+            info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:
+        info["rccl_version"] = "unavailable (%s)" % type(e).__name__
+    info["env"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_", "HSA_", "HIP_VISIBLE", "ROCR_VISIBLE", "CRNN_DIST"))}
+    try:
+        import subprocess
+        out = subprocess.run(["rocm-smi", "--showtopotype"], capture_output=True, text=True, timeout=20).stdout
+        info["xgmi_links_reported"] = out.count("XGMI") // 2 if "XGMI" in out else 0      # the type matrix lists each pair twice
+    except Exception as e:
+        info["xgmi_links_reported"] = "unavailable (%s)" % type(e).__name__
+    return info
+
+
 def self_launch(n):
     """Spawn n ranks of this script (same argv) under torch.distributed.run on this node and relay rank 0's JSON line."""
     import socket
@@ -800,6 +819,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         ms_no_ar = 1e3 * float(tt.item()) / k2
         dp_proof = {"dist_world_size": dist.get_world_size(), "dist_backend": dist.get_backend(), "ranks_reporting": int(allchk.shape[0]),
+                    "transport": collective_transport_info(dist),
                     "param_checksum_max_abs_diff_across_ranks": spread, "replicas_identical": spread == 0.0,
                     "bn_moving_mean_checksum_spread": bn_spread,
                     "allreduce_bytes_per_step": int(eng.n_total * 4), "ms_per_step_without_allreduce": round(ms_no_ar, 3),
@@ -911,6 +931,31 @@ def main():
                                          ("fp32", args.precision) if args.precision != "fp32" else ("fp32", "fp32_two_plane_forward"), gru=args.gru)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_baseline_full)
+        # The contract in the one object the driver's record keeps whole (`config`): whether the 1e-3 / bit-exact tolerance holds in the parity mode
+        # and in the benchmarked mode, and the rates of the modes / batches the metric string names beside the headline.  None = leg not run.
+        cf = res["config"]
+        par = res.get("parity", {})
+        pm = res.get("parity_mode") if args.precision != "fp32" else {"ms_per_step": res["ms_per_step"], "value": res["value"]}
+        get = lambda d, *ks: (get(d.get(ks[0]), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None
+        cf["parity_within_tolerance_fp32"] = get(par, "fp32", "within_tolerance")
+        cf["parity_within_tolerance_headline"] = get(par, args.precision, "within_tolerance")
+        cf["parity_max_abs_dlogit_fp32"] = get(par, "fp32", "max_abs_dlogit")
+        cf["parity_max_abs_dlogit_headline"] = get(par, args.precision, "max_abs_dlogit")
+        cf["parity_mode_ms_per_step"] = get(pm, "ms_per_step")
+        cf["parity_mode_images_per_sec"] = get(pm, "value")
+        cf["parity_mode_strict_ms_per_step"] = get(pm, "three_plane_backward", "ms_per_step")
+        cf["parity_mode_backward_planes"] = "2 (16 significant bits per factor; CRNN_FLAG_THREE_PLANE_BACKWARD = strict)"
+        b64 = res.get("bs64") if B != 64 else {"ms_per_step": res["ms_per_step"], "value": res["value"]}
+        cf["bs64_ms_per_step"] = get(b64, "ms_per_step")
+        cf["bs64_images_per_sec"] = get(b64, "value")
+        cf["bs64_fp32_ms_per_step"] = get(res, "bs64_fp32", "ms_per_step") if args.precision != "fp32" else get(b64, "ms_per_step")
+        cf["bs64_fp32_images_per_sec"] = get(res, "bs64_fp32", "value") if args.precision != "fp32" else get(b64, "value")
+        cf["dw_fwd_hbm_frac_cold"] = get(res, "roofline", "frac")
+        cf["dw_bwd_hbm_frac_cold"] = get(res, "dw_bwd_roofline", "frac")
+        cf["pointwise_gemm_hbm_frac"] = get(res, "gemm_roofline", "hbm_frac")
+        cf["lstm_gate_gemm_mfma_frac"] = get(res, "lstm_roofline", "frac")
+        cf["predict_b1024_beam10_us_per_image_p50"] = get(res, "predict", "latency_us_per_image_p50")
+        cf["fit_generator_images_per_sec"] = get(res, "fit", "value")
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

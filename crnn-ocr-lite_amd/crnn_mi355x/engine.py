@@ -163,18 +163,19 @@ class Engine:
         fit_generator over a host generator).  Two slots: a slot is rewritten only after the step that used it has finished."""
         slots = self._stage_slots()
         k = self._stage_next
-        self._stage_next = (k + 1) % len(slots)
         s = slots[k]
         B, c = self.B, self.cfg
         xa = np.asarray(x)
+        # validation first: a rejected batch leaves the slot ring and the staging buffers untouched
         if xa.size != s["hx_np"].size:
             raise ValueError("batch shape mismatch: the_input has %d elements, the engine expects %d x %d x %d" % (xa.size, B, c.imgh, c.imgw))
+        self._check_ctc_inputs(labels, input_length, label_length)
+        self._stage_next = (k + 1) % len(slots)
         s["copied"].synchronize()                      # the previous H->D copy out of this slot's host buffers is done
         with np.errstate(over="ignore", invalid="ignore"):
             np.copyto(s["hx_np"], xa.reshape(-1), casting="unsafe")
         if not np.isfinite(s["hx_np"]).all():         # undefined rows of Readf's short tail batch (see _as_input)
             s["hx_np"][~np.isfinite(s["hx_np"])] = 0.0
-        self._check_ctc_inputs(labels, input_length, label_length)
         L = c.max_len
         hi = s["hi_np"]
         np.copyto(hi[:B * L], np.asarray(labels).reshape(-1), casting="unsafe")
@@ -360,21 +361,25 @@ class Engine:
         staged = x if isinstance(x, StagedBatch) else None
         if staged is not None:
             labels = staged
-        self.forward(x, train=True, seed=seed)
-        if allreduce is not None and getattr(allreduce, "overlap", False):
-            # the upper layers' gradients (tail of the flat buffer) are exchanged while the conv stack is still in backward
-            loss = self.backward_top(labels, input_length, label_length, seed=seed)
-            split = self.grad_split
-            allreduce.start(self.grads[split:])
-            self.backward_bottom(seed=seed)
-            allreduce.start(self.grads[:split])
-            allreduce.finish(self.grads)
-        else:
-            loss = self.backward(labels, input_length, label_length, seed=seed)
-            if allreduce is not None:
-                allreduce(self.grads)
-        if staged is not None:
-            self._release(staged)
+        try:
+            self.forward(x, train=True, seed=seed)
+            if allreduce is not None and getattr(allreduce, "overlap", False):
+                # the upper layers' gradients (tail of the flat buffer) are exchanged while the conv stack is still in backward
+                loss = self.backward_top(labels, input_length, label_length, seed=seed)
+                split = self.grad_split
+                allreduce.start(self.grads[split:])
+                self.backward_bottom(seed=seed)
+                allreduce.start(self.grads[:split])
+                allreduce.finish(self.grads)
+            else:
+                loss = self.backward(labels, input_length, label_length, seed=seed)
+                if allreduce is not None:
+                    allreduce(self.grads)
+        finally:
+            if staged is not None:
+                # also when a launch raised: `free` must follow whatever was enqueued on the slot's buffers, or the next H->D copy
+                # into the slot would wait on a stale event and could race kernels still reading it
+                self._release(staged)
         opt.apply(self, iteration)
         self.bn_update()
         return loss

@@ -149,10 +149,14 @@ class Model:
     def sync_replicas(self, batch=None):
         """Data parallel, a COLLECTIVE (every rank must call it): all ranks adopt rank 0's weights / BatchNorm moving statistics
         (a fresh model is initialised from OS entropy per process; crnn_mi355x.parallel.broadcast_state).  fit_generator calls it once
-        when it starts; nothing else in this class issues a broadcast -- building an engine lazily (the first predict / test / train
-        call) and set_weights / load_weights are rank-local, so rank-conditional user code (`if rank == 0: model.predict_on_batch(...)`,
-        `if rank == 0: model.load_weights(...)`) cannot deadlock the other ranks.  After a rank-local load_weights, call this (or
-        fit_generator) on every rank to make the replicas identical again."""
+        when it starts.  set_weights / load_weights and the lazy building of an engine are rank-local and issue no collective, so
+        rank-conditional user code (`if rank == 0: model.predict_on_batch(...)`, `if rank == 0: model.load_weights(...)`) cannot
+        deadlock the other ranks by itself; they only mark THIS rank's replica as out of sync.  Whether a broadcast is needed is
+        then decided COLLECTIVELY, never from the rank-local mark alone: a data-parallel `train_on_batch` first all-reduces (MAX)
+        the ranks' marks (`_replicas_need_sync`, one 4-byte collective every rank takes part in) and all ranks broadcast, or none
+        does -- after `if rank == 0: model.load_weights(...)` every rank therefore adopts the loaded weights at the next train
+        step instead of rank 0 entering a broadcast the others never join.  fit_generator's pipelined loop skips that per-step
+        check (it would cost a host synchronisation per step) and relies on its own sync_replicas() at the start."""
         dist, world = self._dist()
         if world > 1:
             from .parallel import broadcast_state
@@ -161,6 +165,15 @@ class Model:
                 eng = self._engine(batch or 1)
             broadcast_state(eng, dist, world)
             self._state["replicas_synced"] = True
+
+    def _replicas_need_sync(self, eng, dist):
+        """COLLECTIVE: True on every rank iff any rank's replica is marked out of sync (fresh model, set_weights, load_weights).
+        The mark is rank-local; the decision to broadcast must not be (one rank in a broadcast, the others in the gradient
+        all-reduce = mismatched collectives)."""
+        import torch
+        flag = torch.tensor([0 if self._state.get("replicas_synced") else 1], dtype=torch.int32, device=eng.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return bool(int(flag.item()))
 
     def _pull(self):
         """device -> host copies of weights and BN statistics."""
@@ -395,9 +408,12 @@ class Model:
             pass
         return None, 1
 
-    def _train_on_batch_async(self, x, labels=None, input_length=None, label_length=None):
+    def _train_on_batch_async(self, x, labels=None, input_length=None, label_length=None, collective_sync_check=True):
         """Enqueue one train step; returns the batch-mean loss as a DEVICE scalar (no host synchronisation).
-        x: the images, or a StagedBatch (then it carries labels and lengths)."""
+        x: the images, or a StagedBatch (then it carries labels and lengths).
+        collective_sync_check (data parallel): agree over all ranks whether any replica is out of sync before the step
+        (`_replicas_need_sync`: a 4-byte all-reduce + read-back); fit_generator passes False -- it synchronised the replicas itself
+        and must not pay a host synchronisation per step."""
         if self.optimizer is None:
             raise RuntimeError("compile(optimizer=...) first")
         eng = self._engine(len(x))
@@ -405,10 +421,10 @@ class Model:
         allreduce = None
         if world > 1:
             from .parallel import GradAllReduce
-            if not self._state.get("replicas_synced"):
-                # data parallel: a train step is a collective anyway (gradient all-reduce), so the first one after construction /
-                # set_weights / load_weights also makes every rank adopt rank 0's weights -- a loop driven by train_on_batch must not
-                # run on per-rank random initial weights with averaged gradients (the replicas would drift apart silently)
+            # data parallel: a loop driven by train_on_batch must not run on per-rank random initial weights (or on weights only one
+            # rank loaded) with averaged gradients -- the replicas would drift apart silently.  The out-of-sync mark is rank-local, so
+            # the decision is taken by all ranks together: every rank broadcasts, or none does.
+            if collective_sync_check and self._replicas_need_sync(eng, dist):
                 self.sync_replicas(len(x))
             allreduce = GradAllReduce(eng, dist, world)
         eng.train_step(x, labels, input_length, label_length, self.optimizer, self._iterations, allreduce=allreduce)
@@ -473,9 +489,14 @@ class Model:
                 if self._prefetched is None or self._prefetched[0] is not generator:   # a batch drawn ahead belongs to ITS generator
                     self._prefetched = (generator, self._snapshot(next(generator)))
                 cur = self._prefetched[1]
+                self._prefetched = None        # consumed: if drawing / staging the next batch raises, this one is not trained twice on a retry
                 nb = self._batch_len(cur)
-                ls_dev, eng = self._train_on_batch_async(*((cur,) if not isinstance(cur, tuple) else cur))
-                self._prefetched = (generator, self._snapshot(next(generator)))
+                ls_dev, eng = self._train_on_batch_async(*((cur,) if not isinstance(cur, tuple) else cur), collective_sync_check=False)
+                pending = None
+                try:
+                    self._prefetched = (generator, self._snapshot(next(generator)))
+                except Exception as e:         # (a bad batch k+1 / an exhausted generator): step k is already enqueued -- read it back and
+                    pending = e                # run its callbacks first, then re-raise
                 if world > 1:
                     # every rank logs (and EarlyStoppingIter monitors) the GLOBAL batch-mean loss, so all ranks take the same
                     # stop / restore decisions and keep issuing the same collectives; the give-up counters are summed, so a
@@ -487,6 +508,8 @@ class Model:
                 logs = {"loss": loss, "batch": step, "size": nb}
                 for cb in callbacks:
                     cb.on_batch_end(step, logs)
+                if pending is not None:
+                    raise pending
                 if verbose and (step + 1 == steps_per_epoch or (step + 1) % max(1, steps_per_epoch // 20) == 0):
                     print("\r%d/%d - loss: %.4f - %.0f img/s" % (step + 1, steps_per_epoch, run / (step + 1), nimg / max(time.time() - t0, 1e-9)),
                           end="", flush=True)

@@ -475,16 +475,28 @@ extern "C" int crnn_ws_tensor(const crnn_config* cfg, const char* name, long* of
 namespace {
 // Two streams with event links (fork: the side stream continues after everything enqueued on the main stream so far; join: the reverse)
 struct ForkJoin {
-  // The events are created once per host thread and reused by every call (recording an event again while an earlier
+  // The events are created once per (host thread, device) and reused by every call (recording an event again while an earlier
   // wait on it is still queued is well defined: the wait captured the earlier record); nothing is created or destroyed
-  // on the step's path.
-  hipStream_t main, aux; int n = 0; bool on;
+  // on the step's path.  Keyed by the streams' device: an event belongs to the device it was created on, and a second engine on
+  // another GPU driven from the same host thread must not record the first one's events on its streams (invalid resource handle).
+  // The events live as long as the thread (a fixed pool of 24 per device, like the runtime's own per-device pools); they are never
+  // destroyed because a wait on one of them may still be queued when the thread exits.
+  hipStream_t main, aux; int n = 0; bool on; int dev = -1;
   ForkJoin(hipStream_t m, hipStream_t a) : main(m), aux(a), on(a != nullptr) {}
-  static int event(int i, hipEvent_t* out) {
-    static thread_local hipEvent_t ev[24] = {};
-    if (i >= 24) return CRNN_ERR_ARG;
-    if (!ev[i]) { hipError_t r = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming); if (r != hipSuccess) return (int)r; }
-    *out = ev[i];
+  static constexpr int kMaxDevices = 16, kEvents = 24;
+  int event(int i, hipEvent_t* out) {
+    static thread_local hipEvent_t ev[kMaxDevices][kEvents] = {};
+    if (i >= kEvents) return CRNN_ERR_ARG;
+    if (dev < 0) {   // the device the side stream lives on (the NULL stream: the current device)
+      hipDevice_t d = 0;
+      hipError_t r = aux ? hipStreamGetDevice(aux, &d) : hipGetDevice(&d);
+      if (r != hipSuccess) return (int)r;
+      if (d < 0 || d >= kMaxDevices) return CRNN_ERR_UNSUPPORTED;
+      dev = d;
+    }
+    hipEvent_t& e = ev[dev][i];
+    if (!e) { hipError_t r = hipEventCreateWithFlags(&e, hipEventDisableTiming); if (r != hipSuccess) return (int)r; }
+    *out = e;
     return CRNN_OK;
   }
   int link(hipStream_t from, hipStream_t to) {   // `to` continues after everything enqueued on `from` so far

@@ -98,7 +98,7 @@ def main():
             # step, where the two agree to round-off; the replicas themselves stayed bit-identical over all the steps (above).
             diff = (ref.params - after_first).abs()
             print("world %d vs single process after one step: max |dp| %.3g, mean %.3g" % (world, float(diff.max()), float(diff.mean())), flush=True)
-            assert float(diff.max()) <= 5e-7 and float(diff.mean()) < 1e-9
+            assert float(diff.max()) <= 5e-7 * max(1, world // 4) and float(diff.mean()) < 1e-9 * max(1, world // 4)
         print("DP_CHECK OK world=%d backend=%s precision=%s" % (world, backend, precision), flush=True)
     dist.barrier()
     dist.destroy_process_group()

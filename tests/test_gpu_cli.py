@@ -134,6 +134,60 @@ def test_data_parallel_step_equals_single_process_step_gloo_world4():
     assert out.returncode == 0 and "DP_CHECK OK world=4" in out.stdout, (out.stdout[-1500:], err[-3000:])
 
 
+def _dp_log(name, out):
+    try:      # keep the whole log where the round's evidence script collects it
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", name), "w") as f:
+            f.write(out.stdout + "\n==== stderr ====\n" + out.stderr)
+    except OSError:
+        pass
+
+
+def test_data_parallel_step_equals_single_process_step_gloo_world8():
+    """BASELINE configs[3]'s rank count -- eight ranks, here on this box's one GPU over gloo: shard seeds 0..7, broadcast from rank 0, the two-bucket
+    all-reduce split at crnn_grad_split_offset, replicas bit-identical after three steps and equal (to the summation order of the eight-term
+    all-reduce) to one process applying Adam to the mean of the eight shard gradients.  The first execution of world size 8 on any backend."""
+    out = _torchrun([os.path.join(ROOT, "tests", "dp_check.py")], "gloo", nproc=8, timeout=600)
+    if out.returncode != 0:
+        _dp_log("dp_world8_failure.log", out)
+    err = "\n".join(l for l in out.stderr.splitlines() if "Gloo" not in l and "amdgpu.ids" not in l)
+    assert out.returncode == 0 and "DP_CHECK OK world=8" in out.stdout, (out.stdout[-1500:], err[-3000:])
+
+
+def test_bench_eight_ranks_on_one_gpu_over_gloo():
+    """`bench.py --gpus 8 --batch 8` as the driver launches the 8-GPU line (torch.distributed.run, one process per rank), the eight ranks sharing
+    this box's GPU over gloo: the JSON line's `data_parallel` self-proof at configs[3]'s world size (world size from the process group, eight
+    ranks reporting, bit-identical replicas after the timed steps) and the transport record."""
+    import json
+    import subprocess
+    env = dict(os.environ, CRNN_DIST_BACKEND="gloo", CRNN_FLAGS="1", PYTHONPATH=os.pathsep.join([ROOT, PKG]), OMP_NUM_THREADS="2")
+    port = 29300 + os.getpid() % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--batch", "8",
+           "--no-roofline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    if out.returncode != 0:
+        _dp_log("bench_world8_failure.log", out)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 8 and res["config"]["global_batch"] == 64 and res["config"]["parallelism"] == "dp8" and res["scaling"] == "weak"
+    dp = res["data_parallel"]
+    assert dp["dist_world_size"] == 8 and dp["ranks_reporting"] == 8 and dp["dist_backend"] == "gloo"
+    assert dp["replicas_identical"] is True and dp["param_checksum_max_abs_diff_across_ranks"] == 0.0
+    assert dp["transport"]["backend"] == "gloo" and "env" in dp["transport"] and "xgmi_links_reported" in dp["transport"]
+
+
+def test_rank_conditional_set_weights_then_train_on_batch_does_not_mismatch_collectives():
+    """`if rank == 0: model.set_weights(...)` followed by a data-parallel train_on_batch on every rank.  The decision to
+    broadcast is collective (tests/dp_surface_check.py): the loop finishes, exactly one broadcast on every rank, replicas bit-identical."""
+    out = _torchrun([os.path.join(ROOT, "tests", "dp_surface_check.py")], "gloo", nproc=2, timeout=300)
+    if out.returncode != 0:
+        _dp_log("dp_surface_failure.log", out)
+    assert out.returncode == 0 and "DP_SURFACE OK world=2" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
 def test_data_parallel_step_equals_single_process_step_rccl():
     """The same over RCCL (backend "nccl"), one rank per GPU -- needs >= 2 visible GPUs."""
     import torch

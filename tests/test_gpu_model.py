@@ -206,12 +206,12 @@ class Case(tuple):
     hybrid = None
 
 
-def run_case(B, imgh, imgw, u, tds, max_len, stn, dropout, seed=3, num_classes=38, gru=False, variable_width=False):
+def run_case(B, imgh, imgw, u, tds, max_len, stn, dropout, seed=3, num_classes=38, gru=False, variable_width=False, flags=None):
     cfg = M.Config(imgh=imgh, imgw=imgw, num_classes=num_classes, max_len=max_len, time_dense_size=tds, n_units=u, gru=gru)
     p, bn = M.init_params(cfg, seed=7, dtype=np.float64)
     p = M.randomize_params(cfg, p)
     x, lab, il, ll = M.synthetic_batch(cfg, B, seed=1, dtype=np.float64, variable_width=variable_width)
-    eng = Engine(B, imgh, imgw, num_classes, max_len, tds, u, gru=gru, stn=stn, dropout=dropout)
+    eng = Engine(B, imgh, imgw, num_classes, max_len, tds, u, gru=gru, stn=stn, dropout=dropout, flags=flags)
     eng.set_params(p, bn)
     masks = masks_from_engine(eng, cfg, seed) if dropout else None
     # ---- device
@@ -291,6 +291,49 @@ def test_small_gru_model_with_dropout():
 
 def test_config1_shape_gru_model():
     check_case(run_case(B=4, imgh=100, imgw=32, u=256, tds=128, max_len=23, stn=True, dropout=False, gru=True), "config1-gru")
+
+
+_BS64 = {}
+
+
+def _bs64_case():
+    """BASELINE.json's metric names "100x32 bs64": the full-width model (n_units 256, time_dense_size 128, max_len 23, LSTM, spatial transformer)
+    in TRAINING mode (batch statistics, dropout on, gradients) at batch 64, parity mode with its default flags, against the fp64 oracle.  The oracle
+    pass (forward + three backwards over 64 images) is the expensive part (~1-2 min of host time), so it runs once per session and the
+    strict-backward test below re-uses its references: both flag sets take the same forward bit for bit, hence the same device state, the same
+    gate decisions and the same oracle gradients."""
+    if "res" not in _BS64:
+        _BS64["res"] = run_case(B=64, imgh=100, imgw=32, u=256, tds=128, max_len=23, stn=True, dropout=True, seed=11)
+    return _BS64["res"]
+
+
+def test_bs64_training_step_matches_the_oracle_default_flags():
+    """(utils.py:58-103 at the metric's literal batch; the backward GEMMs carry two bf16 planes per operand -- the parity mode's default.)"""
+    check_case(_bs64_case(), "bs64")
+
+
+def test_bs64_training_step_matches_the_oracle_three_plane_backward():
+    """The same batch-64 training step under CRNN_FLAG_THREE_PLANE_BACKWARD (every backward GEMM with fp32-accurate products): the forward is the
+    default flags' bit for bit (asserted), so the oracle references of the default-flags case apply unchanged; every gradient tensor within the
+    same tolerances."""
+    from crnn_mi355x import native
+    res = _bs64_case()
+    cfg, eng0, p, bn, (x, lab, il, ll), yd, loss_d, gd0, c, loss_b, g, rep, gdev = res
+    eng = Engine(64, 100, 32, 38, 23, 128, 256, stn=True, dropout=True, flags=native.FLAG_THREE_PLANE_BACKWARD)
+    eng.set_params(p, bn)
+    y = eng.forward(x.astype(np.float32), train=True, seed=11).cpu().numpy()
+    loss = eng.backward(lab, il, ll, seed=11).cpu().numpy()
+    assert np.array_equal(y, yd) and np.array_equal(loss, loss_d), "the backward's product precision changed the forward"
+    for name in ("q3", "q7", "dn1", "h2"):
+        assert torch.equal(eng.ws_tensor(name), eng0.ws_tensor(name)), name
+    strict = Case((cfg, eng, p, bn, (x, lab, il, ll), y, loss, eng.get_grads(), c, loss_b, g, rep, gdev))
+    strict.hybrid = res.hybrid
+    check_case(strict, "bs64 three-plane backward")
+    # and the two backward precisions against each other at this batch: within 1e-4 of each tensor's largest element
+    gs = strict[7]
+    worst = max(float(np.abs(gs[k] - gd0[k]).max() / max(np.abs(gs[k]).max(), 1e-12)) for k in gs)
+    print("bs64: two-plane vs three-plane backward, worst tensor %.3g of its maximum" % worst)
+    assert worst < 1e-3, worst
 
 
 def test_odd_shape_model_wide_image_small_alphabet():
@@ -482,7 +525,7 @@ def test_parity_mode_weight_planes_split_once_change_no_bit(shape):
 
 
 @pytest.mark.parametrize("shape", [(5, 60, 48, 20, 10, 64, 128), (4, 100, 32, 38, 23, 128, 256)])
-def test_parity_mode_two_plane_backward_gemms_stay_within_1e_5_of_three_planes(shape):
+def test_parity_mode_two_plane_backward_gemms_stay_within_1e_4_of_three_planes(shape):
     """Parity mode: the backward GEMMs (weight and data gradients of the six pointwise convolutions, the dense layers and the RNN projections) carry
     two bf16 planes per operand by default (16 significant bits per factor, half the MFMA work), the forward three.  Against
     CRNN_FLAG_THREE_PLANE_BACKWARD: the same forward bit for bit -- posteriors, loss, hence every gate decision -- and gradients within 1e-4 of
