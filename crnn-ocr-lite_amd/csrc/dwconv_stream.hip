@@ -42,6 +42,7 @@ struct DwsParams {
   const unsigned char* x; const float* k; unsigned char* out; float* partials; const float* bnstate;
   int H, W, C, HB, NS, nwgb, flip, cols, rowbytes, wmaj;
   int nsplit, cppw;          // channel ranges per row (fp32 form: 2 for rows of 18 KiB), 16-byte columns per pixel of one range
+  int xstride = 1;           // workgroup-id distance between the channel ranges of one band (see the kernel)
 #ifdef CRNN_DWS_TRACE
   unsigned long long* trace = nullptr; // timing build only: [workgroup][4] s_memrealtime stamps (entry, first row landed, last step done, statistics written)
 #endif
@@ -165,8 +166,11 @@ struct DwsXform {
   }
 };
 
+// NI = 9: the 9 KiB step row, one 10-wave workgroup per CU; NI = 5 (round 5): bf16 maps as two channel ranges of 4.5 KiB per row -- six-wave
+// workgroups (five compute waves + the loader), two of them per CU (3 waves per SIMD at the same 168 registers)
 template <int NI, int D, bool EPI, bool PRO, bool DROP = false, bool F32 = false>
-__global__ __launch_bounds__((kDwsMaxWaves + (PRO ? 3 : 1)) * 64) void dw_fwd_stream_kernel(DwsParams p) {
+__global__ __launch_bounds__(NI == 9 ? (kDwsMaxWaves + (PRO ? 3 : 1)) * 64 : (NI + 1) * 64, NI == 9 ? 1 : 3) void dw_fwd_stream_kernel(DwsParams p) {
+  static_assert(NI == 9 || !PRO, "the prologue form runs on the 9 KiB step row");
   constexpr int EPC = F32 ? 4 : 8, ES = F32 ? 4 : 2;            // elements per 16-byte chunk, bytes per element
   constexpr int NR = D + 1, SLOT = NI * 1024;
   constexpr int NIT = NI + (DROP ? kDwsKeepNI : 0);            // DMA instructions per step row
@@ -181,9 +185,12 @@ __global__ __launch_bounds__((kDwsMaxWaves + (PRO ? 3 : 1)) * 64) void dw_fwd_st
   // `wave`: index of a compute wave among the compute waves; == ncw for the loader (the transform waves take their own branch first)
   const int wave = PRO ? (role == 0 ? ridx : ncw) : wave0;
   constexpr int KOFF = NR * SLOT + 64;                         // prologue form: NR x 1 KiB of keep bytes behind the zero chunk
-  // workgroup = (image, band, channel range); one range (nsplit = 1) for bf16 maps, whose rows are the 9 KiB step row
-  const int split = F32 ? (int)(blockIdx.x % p.nsplit) : 0;
-  const int bidx = F32 ? (int)(blockIdx.x / p.nsplit) : (int)blockIdx.x;      // statistics row of the workgroup's band
+  // workgroup = (image, band, channel range).  The ranges of a band sit p.xstride workgroup ids apart (8 = the XCD count: workgroup i runs on
+  // XCD i mod 8, so the ranges of one image row share an XCD and its L2 / memory channel queue; 1 = adjacent ids)
+  const int xs = p.xstride, blk = (int)blockIdx.x;
+  const int grp = blk / (xs * p.nsplit), rem = blk - grp * (xs * p.nsplit);
+  const int split = rem / xs;
+  const int bidx = grp * xs + (rem - split * xs);                             // statistics row of the workgroup's band
   const int img = bidx / p.nwgb, wb = bidx - img * p.nwgb;
   const int c0 = split * (p.C / p.nsplit);         // first channel of the range
   const int r0 = wb * p.NS * p.HB;                 // first output row of sub-band 0
@@ -221,16 +228,10 @@ __global__ __launch_bounds__((kDwsMaxWaves + (PRO ? 3 : 1)) * 64) void dw_fwd_st
     int rowfirst[NI], within[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      if (F32) {   // chunk j of the step row: pixel j / cppw of the band, 16-byte column j % cppw of the channel range
-        int j = i * 64 + lane; j = j < p.cols ? j : p.cols - 1;  // past the step row: re-read its last chunk (lands in the slot's unused tail)
-        const int sw = p.W * p.cppw, s = j / sw, jj = j - s * sw, px = jj / p.cppw, o = jj - px * p.cppw;
-        rowfirst[i] = r0 + s * p.HB - 1; within[i] = (px * p.C + c0) * ES + o * 16;
-        continue;
-      }
-      const int f = i * 1024 + lane * 16;
-      int s = f / p.rowbytes, w = f - s * p.rowbytes;
-      if (s >= p.NS) { s = p.NS - 1; w = p.rowbytes - 16; }     // past the step row: re-read its last chunk (lands in the slot's unused tail)
-      rowfirst[i] = r0 + s * p.HB - 1; within[i] = w;
+      // chunk j of the step row: sub-band j / (W cppw), pixel (j / cppw) % W of it, 16-byte column j % cppw of the channel range
+      int j = i * 64 + lane; j = j < p.cols ? j : p.cols - 1;    // past the step row: re-read its last chunk (lands in the slot's unused tail)
+      const int sw = p.W * p.cppw, s = j / sw, jj = j - s * sw, px = jj / p.cppw, o = jj - px * p.cppw;
+      rowfirst[i] = r0 + s * p.HB - 1; within[i] = (px * p.C + c0) * ES + o * 16;
     }
     // prologue form with dropout: the keep bytes of the step row (one per 16-byte chunk, same order), 4 bytes per lane and instruction
     int krow[kDwsKeepNI], kwithin[kDwsKeepNI];
@@ -285,7 +286,7 @@ __global__ __launch_bounds__((kDwsMaxWaves + (PRO ? 3 : 1)) * 64) void dw_fwd_st
     const int col = wave * 64 + lane;                          // also this thread's index among the compute threads
     const bool act = col < p.cols;
     const int ccol = act ? col : p.cols - 1;                   // idle lanes of the last wave shadow the last column
-    const int cpp = F32 ? p.cppw : (p.C >> 3);                 // 16-byte columns per pixel (of the channel range)
+    const int cpp = p.cppw;                                    // 16-byte columns per pixel (of the channel range)
     const int pxs = ccol / cpp, oct = ccol - pxs * cpp;
     const int sub = pxs / p.W, px = pxs - sub * p.W;
     const int offC = ccol * 16, pitch = cpp * 16;              // LDS bytes between horizontally adjacent pixels
@@ -433,33 +434,43 @@ __global__ __launch_bounds__((kDwsMaxWaves + (PRO ? 3 : 1)) * 64) void dw_fwd_st
   }
 }
 
-struct DwsGeom { int NS, nwgb, HB, cols, ncw, nsplit, cppw; bool ok; };
+struct DwsGeom { int NS, nwgb, HB, cols, ncw, nsplit, cppw, maxw; bool ok; };
+#ifndef CRNN_DWS_BF16_SPLIT
+#define CRNN_DWS_BF16_SPLIT 1   // 2: bf16 training-form launches with C >= 128 run as two channel ranges per row on six-wave workgroups (experiment, round 5)
+#endif
+#ifndef CRNN_DWS_XSTRIDE
+#define CRNN_DWS_XSTRIDE 8      // workgroup-id distance between the channel ranges of a band (8: same XCD)
+#endif
 // es: bytes per element (2: bf16 maps, one channel range per row; 4: fp32 maps, rows of 18 KiB as two channel ranges of 9 KiB)
-DwsGeom dws_geom(int B, int H, int W, int C, int es = 2) {
-  DwsGeom g; g.ok = false; g.NS = g.nwgb = g.HB = g.cols = g.ncw = g.cppw = 0; g.nsplit = 1;
+// ns_req > 0: that many channel ranges per row; maxw: compute waves per workgroup (9: the 9 KiB step row | 5: 4.5 .. 5 KiB)
+DwsGeom dws_geom(int B, int H, int W, int C, int es = 2, int ns_req = 0, int maxw = kDwsMaxWaves) {
+  DwsGeom g; g.ok = false; g.NS = g.nwgb = g.HB = g.cols = g.ncw = g.cppw = 0; g.nsplit = 1; g.maxw = maxw;
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8) return g;
   const int epc = 16 / es;
   int ns = 1;
-  if (es == 4) {                                   // smallest number of channel ranges (whole groups of 8 channels) that fits the step row
+  if (ns_req > 0) {
+    if ((C / 8) % ns_req) return g;
+    ns = ns_req;
+  } else if (es == 4) {                            // smallest number of channel ranges (whole groups of 8 channels) that fits the step row
     ns = 0;
     for (int n = 1; n <= C / 8; ++n) {
       if ((C / 8) % n) continue;
-      if ((long)W * C / epc / n <= kDwsMaxWaves * 64) { ns = n; break; }
+      if ((long)W * C / epc / n <= maxw * 64) { ns = n; break; }
     }
     if (!ns) return g;
   }
   const long rowbytes = (long)W * C * es / ns, cols1 = (long)W * C / epc / ns;   // of one channel range
-  if (cols1 > kDwsMaxWaves * 64) return g;
-  int NS = (int)(kDwsMaxWaves * 64 / cols1);
+  if (cols1 > maxw * 64) return g;
+  int NS = (int)(maxw * 64 / cols1);
   while (NS > 1 && H % NS) --NS;
-  if (NS * rowbytes <= 8 * 1024 || NS * rowbytes > 9 * 1024) return g;     // the 9-instruction step row only (every block of the CRNN)
+  if (NS * rowbytes <= (maxw - 1) * 1024 || NS * rowbytes > maxw * 1024) return g;   // the maxw-instruction step row only (every block of the CRNN)
   g.nsplit = ns; g.cppw = C / epc / ns;
   // bands per image over workgroups: enough workgroups for the chip, bands of at least 8 rows
   int nwgb = 1;
 #ifndef CRNN_DWS_WGS
 #define CRNN_DWS_WGS 256
 #endif
-  const int want = CRNN_DWS_WGS;
+  const int want = maxw == kDwsMaxWaves ? CRNN_DWS_WGS : 2 * CRNN_DWS_WGS;
   for (int n = 1; n <= H / NS; ++n) {
     if ((H / NS) % n || H / NS / n < 8) continue;
     nwgb = n;
@@ -469,11 +480,23 @@ DwsGeom dws_geom(int B, int H, int W, int C, int es = 2) {
   g.NS = NS; g.nwgb = nwgb; g.HB = H / (NS * nwgb); g.cols = (int)(NS * cols1); g.ncw = (g.cols + 63) / 64; g.ok = true;
   return g;
 }
+// bf16 training form as two channel ranges on six-wave workgroups (CRNN_DWS_BF16_SPLIT): whole 128-byte pieces per pixel and range (C >= 128)
+DwsGeom dws_geom_split(int B, int H, int W, int C) {
+  DwsGeom g; g.ok = false;
+  if (CRNN_DWS_BF16_SPLIT < 2 || C < 64 * CRNN_DWS_BF16_SPLIT || (B * 1L) % CRNN_DWS_XSTRIDE) return g;
+  g = dws_geom(B, H, W, C, 2, CRNN_DWS_BF16_SPLIT, 5);
+  if (g.ok && ((long)B * g.nwgb) % CRNN_DWS_XSTRIDE) g.ok = false;
+  return g;
+}
 
 #ifndef CRNN_DWS_D
 #define CRNN_DWS_D 4
 #endif
 constexpr int kDwsD = CRNN_DWS_D;     // rows in flight per workgroup (2..7 measured: 4.4 / 4.6 / 4.6 / 4.5 TB/s at 2 / 3 / 4 / 7)
+#ifndef CRNN_DWS_D5
+#define CRNN_DWS_D5 4
+#endif
+constexpr int kDwsD5 = CRNN_DWS_D5;   // the same for the six-wave form (4.5 KiB rows)
 
 template <bool EPI>
 int dws_launch(const DwsParams& p, const DwsGeom& g, int B, hipStream_t stream) {
@@ -528,6 +551,17 @@ extern "C" int crnn_dwconv3x3_fwd_stream_ex(const void* x, const float* k, void*
 #ifdef CRNN_DWS_TRACE
   { const char* e = getenv("CRNN_DWS_TRACE_PTR"); p.trace = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
 #endif
+  if (!bnstate) {
+    const DwsGeom g2 = dws_geom_split(B, H, W, C);
+    if (g2.ok && g2.nwgb == g.nwgb) {                // (the same statistics rows: one per image band)
+      p.HB = g2.HB; p.NS = g2.NS; p.cols = g2.cols; p.nsplit = g2.nsplit; p.cppw = g2.cppw; p.xstride = CRNN_DWS_XSTRIDE;
+      constexpr int lds = (kDwsD5 + 1) * 5 * 1024 + 64;
+      CRNN_LDS_ATTR((dw_fwd_stream_kernel<5, kDwsD5, false, false>), lds);
+      hipLaunchKernelGGL((dw_fwd_stream_kernel<5, kDwsD5, false, false>), dim3(B * g2.nwgb * g2.nsplit), dim3((g2.ncw + 1) * 64), lds, stream, p);
+      CRNN_LAUNCH_CHECK();
+      return CRNN_OK;
+    }
+  }
   return bnstate ? dws_launch<true>(p, g, B, stream) : dws_launch<false>(p, g, B, stream);
 }
 // Prologue form (training): `q` is the previous block's pointwise output, pro_bnstate its BatchNorm-2 state [mean|var|scale|shift]; the

@@ -711,8 +711,10 @@ extern "C" int crnn_pwconv_fwd_wres_folded_pool(const void* a, const void* wT, v
 
 namespace {
 // two shapes of the forward kernel: (CB 1, PB 4) = 128 pixels x 128 channels per workgroup; (CB 2, PB 2) = 64 pixels x 256 channels,
-// where the doubled weight fragments still fit the registers (K <= 256): half as many channel slices transform / read every pixel
-bool wres_fwd_wide(int N, int K) { return N % 256 == 0 && K <= 256 && crnn_knob("CRNN_WRES_WIDE", 1); }
+// where the doubled weight fragments still fit the registers (K <= 256): half as many channel slices transform / read every pixel.
+// K = 64 stays on the narrow shape: its 8 drain pieces per stage beside the doubled accumulators left <1, 2, 2> at the 256-register
+// ceiling with 47 spilled registers (round 4's recompile), and no block of the CRNN has K = 64 with N a multiple of 256 (block 2: N = 128)
+bool wres_fwd_wide(int N, int K) { return N % 256 == 0 && K >= 128 && K <= 256 && crnn_knob("CRNN_WRES_WIDE", 1); }
 void wres_fwd_geom(long M, int N, int K, WresFwdParams& p, int& grid) {
   const bool wide = wres_fwd_wide(N, K);
   p.stripes = cdiv(M, wide ? 64 : 128); p.S = N / (wide ? 256 : 128);
@@ -761,11 +763,8 @@ extern "C" int crnn_pwconv_bnrelu6_fwd_wres(const void* d, const float* in_bnsta
   p.stats = stat_partials; p.M = (int)M; p.N = N; p.K = K;
   wres_fwd_geom(M, N, K, p, grid);
   if (wres_fwd_wide(N, K)) {
-    switch (K / 64) {
-      case 1: return launch_wres_fwd<1, 2, 2>(p, grid, stream);
-      case 2: return launch_wres_fwd<2, 2, 2>(p, grid, stream);
-      default: return launch_wres_fwd<4, 2, 2>(p, grid, stream);
-    }
+    if (K == 128) return launch_wres_fwd<2, 2, 2>(p, grid, stream);
+    return launch_wres_fwd<4, 2, 2>(p, grid, stream);
   }
   switch (K / 64) {
     case 1: return launch_wres_fwd<1, 1, 4>(p, grid, stream);

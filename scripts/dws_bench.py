@@ -22,7 +22,22 @@ variants = [("tile", L0, False), ("stream", L0, True)]
 for pth in sorted(glob.glob(os.path.join(ROOT, "scripts/_trace/libdws_*.so"))):
     variants.append((os.path.basename(pth)[7:-3], ctypes.CDLL(pth), True))
 iters = 8
+ref_out = {}
 for name, L, stream in variants:
+    if stream:   # every build of the row-stream kernel must give the product library's bits (outputs) and statistics (to summation order)
+        for si, ((h, w, c), (x, o, k, pt)) in enumerate(zip(shapes, bufs)):
+            o.zero_(); pt.zero_()
+            rc = L.crnn_dwconv3x3_fwd_stream(P(x), P(k), P(o), P(pt), None, B, h, w, c, 0, S())
+            assert rc == 0, rc
+            rows = L0.crnn_dwconv_fwd_stream_rows(B, h, w, c)
+            st = pt[:rows * 2 * c].view(rows, 2, c).double().sum(0)
+            if si not in ref_out:
+                ref_out[si] = (o.clone(), st.clone())
+            elif "exp" not in name:
+                same = torch.equal(o, ref_out[si][0]); rel = float(((st - ref_out[si][1]).abs() / (ref_out[si][1].abs() + 1e-3)).max())
+                if not same or rel > 1e-4:
+                    print("!! %s %dx%dx%d: outputs identical %s, statistics max rel diff %.3g" % (name, h, w, c, same, rel), flush=True)
+
     ms = np.zeros((iters, len(shapes)))
     for it in range(iters + 2):
         evs = []

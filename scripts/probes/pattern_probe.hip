@@ -1,0 +1,84 @@
+// Which access PATTERN does the memory system reward?  (round 5; companion of copy_probe.hip)  The row-stream depthwise kernels give every workgroup its
+// own image band: 256 read streams and 256 write streams far apart, each advancing 9 KiB per step -- a plain copy with that pattern reaches 0.60-0.64 of the
+// HBM peak where a copy in which the resident workgroups sweep ONE window together reaches 0.70 (nontemporal: 0.77).  This probe copies the same six tensor
+// pairs (cold protocol of bench.py's depthwise_roofline) with S streams far apart, G workgroups cooperating on each stream (adjacent bursts of one window),
+// `burst` bytes per workgroup and iteration, plain or nontemporal accesses, and two workgroup -> (stream, position) maps:
+//   map 0: wg = stream * G + g   (the G workgroups of a stream have consecutive ids: spread over the XCDs, wg % 8)
+//   map 1: wg = g * S + stream   (stream s stays on XCD s % 8 when S % 8 == 0)
+// S = 1 is the sweep copy, (S = wgs, G = 1) the banded copy.
+// build: hipcc --offload-arch=gfx950 -O3 -w -o scripts/probes/pattern_probe scripts/probes/pattern_probe.hip
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct Pat { long n; int S, G, burst16, map, nt, mode; };   // n in 16-byte units; burst16 = 16-byte units per workgroup and iteration; mode 0 copy | 1 read only | 2 write only
+template <int NT>
+__global__ __launch_bounds__(256) void pattern_kernel(const u32x4* __restrict__ s, u32x4* __restrict__ d, Pat p) {
+  const int wg = blockIdx.x;
+  const int stream = p.map ? wg % p.S : wg / p.G, g = p.map ? wg / p.S : wg % p.G;
+  const long per = (p.n + p.S - 1) / p.S;                       // units per stream
+  const long lo = stream * per, hi = lo + per < p.n ? lo + per : p.n;
+  const long step = (long)p.G * p.burst16;
+  u32x4 acc = {0u, 0u, 0u, 0u};
+  for (long w0 = lo + (long)g * p.burst16; w0 < hi; w0 += step) {
+    const long w1 = w0 + p.burst16 < hi ? w0 + p.burst16 : hi;
+    for (long i = w0 + threadIdx.x; i < w1; i += 1024) {
+      u32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (p.mode == 2) { v[u] = u32x4{(unsigned)i, 1u, 2u, 3u}; continue; }
+        if (i + u * 256 < w1) v[u] = NT ? __builtin_nontemporal_load(s + i + u * 256) : s[i + u * 256];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (p.mode == 1) { if (i + u * 256 < w1) { acc.x ^= v[u].x; acc.y += v[u].y; } continue; }
+        if (i + u * 256 < w1) { if (NT) __builtin_nontemporal_store(v[u], d + i + u * 256); else d[i + u * 256] = v[u]; }
+      }
+    }
+  }
+  if (p.mode == 1 && acc.x == 0x12345678u && acc.y == 0x9abcdef0u) d[0] = acc;   // keeps the loads alive
+}
+int main() {
+  const long B = 256;
+  const long shp[6][3] = {{104, 36, 64}, {104, 36, 128}, {52, 18, 256}, {52, 18, 256}, {52, 9, 512}, {52, 9, 512}};
+  void *src[6], *dst[6]; long bytes[6]; double total = 0;
+  for (int i = 0; i < 6; ++i) {
+    bytes[i] = B * shp[i][0] * shp[i][1] * shp[i][2] * 2;
+    if (hipMalloc(&src[i], bytes[i]) != hipSuccess || hipMalloc(&dst[i], bytes[i]) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    hipMemset(src[i], 1, bytes[i]); hipMemset(dst[i], 2, bytes[i]);
+    total += 2.0 * bytes[i];
+  }
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  auto run = [&](int S, int G, int burst, int map, int nt, int mode = 0) {
+    std::vector<float> ts;
+    for (int it = 0; it < 12; ++it) {
+      hipEventRecord(e0, 0);
+      for (int i = 0; i < 6; ++i) {
+        Pat p{bytes[i] / 16, S, G, burst / 16, map, nt, mode};
+        if (nt) hipLaunchKernelGGL(pattern_kernel<1>, dim3(S * G), dim3(256), 0, 0, (const u32x4*)src[i], (u32x4*)dst[i], p);
+        else hipLaunchKernelGGL(pattern_kernel<0>, dim3(S * G), dim3(256), 0, 0, (const u32x4*)src[i], (u32x4*)dst[i], p);
+      }
+      hipEventRecord(e1, 0); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      if (it) ts.push_back(ms);
+    }
+    std::sort(ts.begin(), ts.end());
+    const double t = ts[ts.size() / 2] * 1e-3, bytes_moved = mode ? total / 2 : total;
+    printf("S %4d  G %4d  wgs %5d  burst %6d  map %d  %s %-5s  %7.1f us per set  %6.0f GB/s  %.3f of 8 TB/s\n", S, G, S * G, burst, map, nt ? "nt   " : "plain",
+           mode == 0 ? "copy" : (mode == 1 ? "read" : "write"), t * 1e6, bytes_moved / t / 1e9, bytes_moved / t / 8e12);
+    fflush(stdout);
+  };
+  printf("six tensor pairs of the depthwise forward (%.0f MB read + written per set), median of 11 cold sets; S streams x G cooperating workgroups\n", total / 1e6);
+  for (int nt = 0; nt < 2; ++nt) {
+    run(1, 256, 16384, 0, nt);                                  // sweep
+    run(256, 1, 16384, 0, nt);                                  // banded
+    for (int S : {128, 64, 32, 16, 8}) { run(S, 256 / S, 16384, 0, nt); run(S, 256 / S, 16384, 1, nt); }
+  }
+  for (int burst : {4096, 8192, 9216, 32768, 65536}) run(256, 1, burst, 0, 0);            // banded: burst size
+  for (int S : {256, 128, 64, 32}) { run(S, 512 / S, 16384, 0, 0); run(S, 512 / S, 16384, 1, 0); }   // two workgroups per CU
+  for (int S : {256, 64, 16}) { run(S, 1024 / S, 16384, 1, 0); }                          // four per CU
+  run(64, 4, 36864, 0, 0); run(64, 4, 36864, 1, 0); run(32, 8, 18432, 1, 0);             // four (eight) CUs sharing an image band, 36 (18) KiB per step
+  for (int mode : {1, 2}) { run(1, 256, 16384, 0, 0, mode); run(256, 1, 16384, 0, 0, mode); run(64, 4, 16384, 1, 0, mode); }
+  return hipDeviceSynchronize() == hipSuccess ? 0 : 1;
+}
