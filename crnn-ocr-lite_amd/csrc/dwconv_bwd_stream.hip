@@ -633,7 +633,10 @@ DbsGeom dbs_geom(int B, int H, int W, int C, int epc = 8) {   // epc: elements p
   }
   if (!ns) return g;
   const int cols = (int)(cols1 / ns), cppw = C / epc / ns;
-  if (cols <= 4 * 64 || (cppw & (cppw - 1)) || cppw > 32) return g;   // five full-ish waves; power-of-two columns per pixel below a wave (shuffle reduction)
+  // more than two of the five waves of a group busy (round 5: was more than four -- image width 48 gives ranges of 208 columns, which used to send the
+  // whole depthwise stage back to the three-kernel tile path; 65 % of the lanes busy is still the faster schedule); power-of-two columns per pixel
+  // below a wave (shuffle reduction)
+  if (cols <= 2 * 64 || (cppw & (cppw - 1)) || cppw > 32) return g;
   int nwgb = 1;
 #ifndef CRNN_DBS_WGS
 #define CRNN_DBS_WGS 256
@@ -651,7 +654,7 @@ DbsGeom dbs_geom(int B, int H, int W, int C, int epc = 8) {   // epc: elements p
 }  // namespace
 
 // CRNN_OK when crnn_dwconv3x3_bwd_stream takes the shape (W * C / 8 sixteen-byte columns split over whole channel octets into
-// workgroups of 257..320 columns: every block of the CRNN), else CRNN_ERR_UNSUPPORTED -> crnn_dwconv3x3_bwd_fused.
+// workgroups of 129..320 columns: every block of the CRNN at image widths 32, 48, 64), else CRNN_ERR_UNSUPPORTED -> crnn_dwconv3x3_bwd_fused.
 extern "C" int crnn_dwconv_bwd_stream_supported(int B, int H, int W, int C) { return dbs_geom(B, H, W, C).ok ? CRNN_OK : CRNN_ERR_UNSUPPORTED; }
 // rows of [9][C] weight-gradient partials the launch writes (scratch = rows * 9 * C floats)
 extern "C" int crnn_dwconv_bwd_stream_rows(int B, int H, int W, int C) { DbsGeom g = dbs_geom(B, H, W, C); return g.ok ? B * g.nwgb : 0; }
@@ -675,7 +678,7 @@ extern "C" int crnn_dwconv3x3_bwd_stream(const void* d, const void* da, const fl
   return crnn_partials_sum(scratch, B * g.nwgb, 9 * C, dk, 1.f, stream);
 }
 // The same stage on fp32 tensors (dtype CRNN_F32; CRNN_BF16 = the entry points above): four channels per lane, W * C / 4 columns split into
-// workgroups of 257..320 -- the parity mode's crnn_bn_bwd_apply_ex + crnn_dwconv3x3_wgrad_ex + crnn_dwconv3x3_fwd_ex(flip) in one pass over
+// workgroups of 129..320 -- the parity mode's crnn_bn_bwd_apply_ex + crnn_dwconv3x3_wgrad_ex + crnn_dwconv3x3_fwd_ex(flip) in one pass over
 // d, da, xin (4 tensor passes instead of 7); dx bit-identical to that sequence, dk to the summation order of its partial sums.
 extern "C" int crnn_dwconv_bwd_stream_supported_ex(int B, int H, int W, int C, int dtype) {
   if (dtype == CRNN_BF16) return crnn_dwconv_bwd_stream_supported(B, H, W, C);

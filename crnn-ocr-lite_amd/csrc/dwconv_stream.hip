@@ -166,11 +166,11 @@ struct DwsXform {
   }
 };
 
-// NI = 9: the 9 KiB step row, one 10-wave workgroup per CU; NI = 5 (round 5): bf16 maps as two channel ranges of 4.5 KiB per row -- six-wave
-// workgroups (five compute waves + the loader), two of them per CU (3 waves per SIMD at the same 168 registers)
+// NI = compute waves = 1 KiB DMA instructions per step row: 9 for every block of the CRNN at image width 32 (the 9 KiB step row); 5..8 (round 5) for the
+// step rows of other image widths (e.g. width 48: 416 columns = 7 waves), which used to fall back to the halo-tile kernels
 template <int NI, int D, bool EPI, bool PRO, bool DROP = false, bool F32 = false>
-__global__ __launch_bounds__(NI == 9 ? (kDwsMaxWaves + (PRO ? 3 : 1)) * 64 : (NI + 1) * 64, NI == 9 ? 1 : 3) void dw_fwd_stream_kernel(DwsParams p) {
-  static_assert(NI == 9 || !PRO, "the prologue form runs on the 9 KiB step row");
+__global__ __launch_bounds__((NI + (PRO ? 3 : 1)) * 64) void dw_fwd_stream_kernel(DwsParams p) {
+  static_assert(NI == kDwsMaxWaves || !PRO, "the prologue form runs on the 9 KiB step row");
   constexpr int EPC = F32 ? 4 : 8, ES = F32 ? 4 : 2;            // elements per 16-byte chunk, bytes per element
   constexpr int NR = D + 1, SLOT = NI * 1024;
   constexpr int NIT = NI + (DROP ? kDwsKeepNI : 0);            // DMA instructions per step row
@@ -434,58 +434,43 @@ __global__ __launch_bounds__(NI == 9 ? (kDwsMaxWaves + (PRO ? 3 : 1)) * 64 : (NI
   }
 }
 
-struct DwsGeom { int NS, nwgb, HB, cols, ncw, nsplit, cppw, maxw; bool ok; };
-#ifndef CRNN_DWS_BF16_SPLIT
-#define CRNN_DWS_BF16_SPLIT 1   // 2: bf16 training-form launches with C >= 128 run as two channel ranges per row on six-wave workgroups (experiment, round 5)
-#endif
-#ifndef CRNN_DWS_XSTRIDE
-#define CRNN_DWS_XSTRIDE 8      // workgroup-id distance between the channel ranges of a band (8: same XCD)
-#endif
-// es: bytes per element (2: bf16 maps, one channel range per row; 4: fp32 maps, rows of 18 KiB as two channel ranges of 9 KiB)
-// ns_req > 0: that many channel ranges per row; maxw: compute waves per workgroup (9: the 9 KiB step row | 5: 4.5 .. 5 KiB)
-DwsGeom dws_geom(int B, int H, int W, int C, int es = 2, int ns_req = 0, int maxw = kDwsMaxWaves) {
-  DwsGeom g; g.ok = false; g.NS = g.nwgb = g.HB = g.cols = g.ncw = g.cppw = 0; g.nsplit = 1; g.maxw = maxw;
+struct DwsGeom { int NS, nwgb, HB, cols, ncw, nsplit, cppw, xstride; bool ok; };
+constexpr int kDwsMinWaves = 5;      // step rows that fill fewer compute waves stay with the halo-tile kernels
+// es: bytes per element (2: bf16 maps, 4: fp32 maps).  A row of W * C * es bytes is cut into the smallest number of channel ranges (whole groups of 8
+// channels) whose 16-byte columns fit the nine compute waves; narrow ranges run NS bands of the same image side by side.  Every block of the CRNN at image
+// width 32: bf16 one range of 576 columns, fp32 two.  Round 5: any step row of 257..576 columns (five to nine compute waves, NI = waves), e.g. image width
+// 48 (416 columns, bf16 blocks 3..7 as two ranges) or 64 (544) -- these shapes ran the halo-tile kernels at about half the rate.
+DwsGeom dws_geom(int B, int H, int W, int C, int es = 2) {
+  DwsGeom g; g.ok = false; g.NS = g.nwgb = g.HB = g.cols = g.ncw = g.cppw = 0; g.nsplit = 1; g.xstride = 1;
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8) return g;
   const int epc = 16 / es;
-  int ns = 1;
-  if (ns_req > 0) {
-    if ((C / 8) % ns_req) return g;
-    ns = ns_req;
-  } else if (es == 4) {                            // smallest number of channel ranges (whole groups of 8 channels) that fits the step row
-    ns = 0;
-    for (int n = 1; n <= C / 8; ++n) {
-      if ((C / 8) % n) continue;
-      if ((long)W * C / epc / n <= maxw * 64) { ns = n; break; }
-    }
-    if (!ns) return g;
+  int ns = 0;
+  for (int n = 1; n <= C / 8; ++n) {               // smallest number of channel ranges that fits the step row
+    if ((C / 8) % n) continue;
+    if ((long)W * C / epc / n <= kDwsMaxWaves * 64) { ns = n; break; }
   }
-  const long rowbytes = (long)W * C * es / ns, cols1 = (long)W * C / epc / ns;   // of one channel range
-  if (cols1 > maxw * 64) return g;
-  int NS = (int)(maxw * 64 / cols1);
+  if (!ns) return g;
+  const long cols1 = (long)W * C / epc / ns;       // 16-byte columns of one channel range
+  int NS = (int)(kDwsMaxWaves * 64 / cols1);
   while (NS > 1 && H % NS) --NS;
-  if (NS * rowbytes <= (maxw - 1) * 1024 || NS * rowbytes > maxw * 1024) return g;   // the maxw-instruction step row only (every block of the CRNN)
+  const int cols = (int)(NS * cols1), ncw = (cols + 63) / 64;
+  if (ncw < kDwsMinWaves) return g;
   g.nsplit = ns; g.cppw = C / epc / ns;
   // bands per image over workgroups: enough workgroups for the chip, bands of at least 8 rows
   int nwgb = 1;
 #ifndef CRNN_DWS_WGS
 #define CRNN_DWS_WGS 256
 #endif
-  const int want = maxw == kDwsMaxWaves ? CRNN_DWS_WGS : 2 * CRNN_DWS_WGS;
+  const int want = CRNN_DWS_WGS;
   for (int n = 1; n <= H / NS; ++n) {
     if ((H / NS) % n || H / NS / n < 8) continue;
     nwgb = n;
     if ((long)B * n * ns >= want) break;
   }
   if (H % (NS * nwgb)) return g;
-  g.NS = NS; g.nwgb = nwgb; g.HB = H / (NS * nwgb); g.cols = (int)(NS * cols1); g.ncw = (g.cols + 63) / 64; g.ok = true;
-  return g;
-}
-// bf16 training form as two channel ranges on six-wave workgroups (CRNN_DWS_BF16_SPLIT): whole 128-byte pieces per pixel and range (C >= 128)
-DwsGeom dws_geom_split(int B, int H, int W, int C) {
-  DwsGeom g; g.ok = false;
-  if (CRNN_DWS_BF16_SPLIT < 2 || C < 64 * CRNN_DWS_BF16_SPLIT || (B * 1L) % CRNN_DWS_XSTRIDE) return g;
-  g = dws_geom(B, H, W, C, 2, CRNN_DWS_BF16_SPLIT, 5);
-  if (g.ok && ((long)B * g.nwgb) % CRNN_DWS_XSTRIDE) g.ok = false;
+  g.NS = NS; g.nwgb = nwgb; g.HB = H / (NS * nwgb); g.cols = cols; g.ncw = ncw; g.ok = true;
+  // bf16 maps: the ranges of a band 8 workgroup ids apart (one XCD); fp32 maps keep round 4's adjacent ids (measured with them)
+  g.xstride = (es == 2 && ns > 1 && ((long)B * nwgb) % 8 == 0) ? 8 : 1;
   return g;
 }
 
@@ -493,25 +478,32 @@ DwsGeom dws_geom_split(int B, int H, int W, int C) {
 #define CRNN_DWS_D 4
 #endif
 constexpr int kDwsD = CRNN_DWS_D;     // rows in flight per workgroup (2..7 measured: 4.4 / 4.6 / 4.6 / 4.5 TB/s at 2 / 3 / 4 / 7)
-#ifndef CRNN_DWS_D5
-#define CRNN_DWS_D5 4
-#endif
-constexpr int kDwsD5 = CRNN_DWS_D5;   // the same for the six-wave form (4.5 KiB rows)
 
-template <bool EPI>
-int dws_launch(const DwsParams& p, const DwsGeom& g, int B, hipStream_t stream) {
-  constexpr int lds = (kDwsD + 1) * 9 * 1024 + 64;
-  CRNN_LDS_ATTR((dw_fwd_stream_kernel<9, kDwsD, EPI, false>), lds);
-  hipLaunchKernelGGL((dw_fwd_stream_kernel<9, kDwsD, EPI, false>), dim3(B * g.nwgb), dim3((g.ncw + 1) * 64), lds, stream, p);
+template <int NI, bool EPI, bool F32>
+int dws_launch_ni(const DwsParams& p, const DwsGeom& g, int B, hipStream_t stream) {
+  constexpr int lds = (kDwsD + 1) * NI * 1024 + 64;
+  CRNN_LDS_ATTR((dw_fwd_stream_kernel<NI, kDwsD, EPI, false, false, F32>), lds);
+  hipLaunchKernelGGL((dw_fwd_stream_kernel<NI, kDwsD, EPI, false, false, F32>), dim3(B * g.nwgb * g.nsplit), dim3((NI + 1) * 64), lds, stream, p);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
+}
+template <bool EPI, bool F32 = false>
+int dws_launch(const DwsParams& p, const DwsGeom& g, int B, hipStream_t stream) {
+  switch (g.ncw) {
+    case 9: return dws_launch_ni<9, EPI, F32>(p, g, B, stream);
+    case 8: return dws_launch_ni<8, EPI, F32>(p, g, B, stream);
+    case 7: return dws_launch_ni<7, EPI, F32>(p, g, B, stream);
+    case 6: return dws_launch_ni<6, EPI, F32>(p, g, B, stream);
+    case 5: return dws_launch_ni<5, EPI, F32>(p, g, B, stream);
+    default: return CRNN_ERR_UNSUPPORTED;
+  }
 }
 // prologue form: one more row in flight (the transform waves need row t + 1 landed when the compute waves take row t)
 constexpr int kDwsProD = kDwsD + 1;
 bool dws_pro_ok(const DwsGeom& g, int B, int H, int W, int C, int es = 2) {
   const int cpp = g.cppw, kpp = cpp * (16 / es) / 8, kcols = g.cols * (16 / es) / 8;   // keep bytes (one per 8 elements) per pixel of the range, per step row
   // the keep bytes of a step row travel as 4-byte DMA pieces: whole dwords per pixel range, at most kDwsKeepNI * 256 of them
-  return g.ok && g.ncw == kDwsMaxWaves && cpp > 0 && kDwsProStride % cpp == 0 && g.cols <= kDwsProChunks * kDwsProStride &&
+  return g.ok && g.ncw == kDwsMaxWaves && (es == 4 || g.nsplit == 1) && cpp > 0 && kDwsProStride % cpp == 0 && g.cols <= kDwsProChunks * kDwsProStride &&
          (es == 2 ? (W * cpp) % 4 == 0 : kpp % 4 == 0) && kcols % 4 == 0 && kcols <= kDwsKeepNI * 256 && (long)B * H * W * (C / 8) < (1L << 31);
 }
 template <bool DROP, bool F32 = false>
@@ -525,8 +517,8 @@ int dws_launch_pro(const DwsParams& p, const DwsGeom& g, int B, hipStream_t stre
 
 }  // namespace
 
-// CRNN_OK when crnn_dwconv3x3_fwd_stream takes the shape (bf16 storage; W*C*2 bytes per row such that a whole number of bands fills
-// the 9 KiB step row), else CRNN_ERR_UNSUPPORTED: the caller uses the halo-tile kernel (crnn_dwconv3x3_fwd_ex).
+// CRNN_OK when crnn_dwconv3x3_fwd_stream takes the shape (bf16 storage; dws_geom: 257..576 sixteen-byte columns per step row after cutting the row into
+// channel ranges / laying bands side by side), else CRNN_ERR_UNSUPPORTED: the caller uses the halo-tile kernel (crnn_dwconv3x3_fwd_ex).
 extern "C" int crnn_dwconv_fwd_stream_supported(int B, int H, int W, int C) { return dws_geom(B, H, W, C).ok ? CRNN_OK : CRNN_ERR_UNSUPPORTED; }
 // rows [2][C] of statistics partials the launch writes (one per workgroup)
 extern "C" int crnn_dwconv_fwd_stream_rows(int B, int H, int W, int C) { DwsGeom g = dws_geom(B, H, W, C); return g.ok ? B * g.nwgb : 0; }
@@ -546,22 +538,11 @@ extern "C" int crnn_dwconv3x3_fwd_stream_ex(const void* x, const float* k, void*
   DwsParams p;
   p.x = (const unsigned char*)x; p.k = k; p.out = (unsigned char*)out; p.partials = bnstate ? nullptr : stat_partials; p.bnstate = bnstate;
   p.H = H; p.W = W; p.C = C; p.HB = g.HB; p.NS = g.NS; p.nwgb = g.nwgb; p.flip = flip; p.cols = g.cols; p.rowbytes = W * C * 2; p.wmaj = out_order;
-  p.nsplit = 1; p.cppw = C / 8;
+  p.nsplit = g.nsplit; p.cppw = g.cppw; p.xstride = g.xstride;
   p.pro_bn = nullptr; p.keep = nullptr; p.rate = 0.f;
 #ifdef CRNN_DWS_TRACE
   { const char* e = getenv("CRNN_DWS_TRACE_PTR"); p.trace = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
 #endif
-  if (!bnstate) {
-    const DwsGeom g2 = dws_geom_split(B, H, W, C);
-    if (g2.ok && g2.nwgb == g.nwgb) {                // (the same statistics rows: one per image band)
-      p.HB = g2.HB; p.NS = g2.NS; p.cols = g2.cols; p.nsplit = g2.nsplit; p.cppw = g2.cppw; p.xstride = CRNN_DWS_XSTRIDE;
-      constexpr int lds = (kDwsD5 + 1) * 5 * 1024 + 64;
-      CRNN_LDS_ATTR((dw_fwd_stream_kernel<5, kDwsD5, false, false>), lds);
-      hipLaunchKernelGGL((dw_fwd_stream_kernel<5, kDwsD5, false, false>), dim3(B * g2.nwgb * g2.nsplit), dim3((g2.ncw + 1) * 64), lds, stream, p);
-      CRNN_LAUNCH_CHECK();
-      return CRNN_OK;
-    }
-  }
   return bnstate ? dws_launch<true>(p, g, B, stream) : dws_launch<false>(p, g, B, stream);
 }
 // Prologue form (training): `q` is the previous block's pointwise output, pro_bnstate its BatchNorm-2 state [mean|var|scale|shift]; the
@@ -602,13 +583,9 @@ extern "C" int crnn_dwconv3x3_fwd_stream_dt(const void* x, const float* k, void*
   DwsParams p;
   p.x = (const unsigned char*)x; p.k = k; p.out = (unsigned char*)out; p.partials = stat_partials; p.bnstate = nullptr;
   p.H = H; p.W = W; p.C = C; p.HB = g.HB; p.NS = g.NS; p.nwgb = g.nwgb; p.flip = flip; p.cols = g.cols; p.rowbytes = W * C * 4; p.wmaj = 0;
-  p.nsplit = g.nsplit; p.cppw = g.cppw;
+  p.nsplit = g.nsplit; p.cppw = g.cppw; p.xstride = g.xstride;
   p.pro_bn = nullptr; p.keep = nullptr; p.rate = 0.f;
-  constexpr int lds = (kDwsD + 1) * 9 * 1024 + 64;
-  CRNN_LDS_ATTR((dw_fwd_stream_kernel<9, kDwsD, false, false, false, true>), lds);
-  hipLaunchKernelGGL((dw_fwd_stream_kernel<9, kDwsD, false, false, false, true>), dim3(B * g.nwgb * g.nsplit), dim3((g.ncw + 1) * 64), lds, stream, p);
-  CRNN_LAUNCH_CHECK();
-  return CRNN_OK;
+  return dws_launch<false, true>(p, g, B, stream);
 }
 // The prologue form by storage type (dtype CRNN_BF16 = the entry points above; CRNN_F32, round 4 -- the parity mode): q, out fp32; rows of 18 KiB run as
 // two channel ranges of 9 KiB (one workgroup each), four channels per lane, the keep bytes (still one per 8 elements) as nibbles.  out / stat_partials

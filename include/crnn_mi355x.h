@@ -282,7 +282,9 @@ int crnn_dwconv3x3_bn_relu6_fwd(const void* x, const float* k, const float* bnst
  * rows (nothing is held or re-read).  stat_partials != NULL: [crnn_dwconv_fwd_stream_rows][2][C] BatchNorm partial sums of the fp32 results;
  * bnstate != NULL ([mean|var|scale|shift]): out = ReLU6(conv * scale + shift) (inference), no statistics; flip = 1: the data gradient.
  * Results bit-identical to crnn_dwconv3x3_fwd_ex / crnn_dwconv3x3_bn_relu6_fwd (reference utils.py:44-46).  _supported: CRNN_OK when the shape
- * is taken (a whole number of row bands fills the 9 KiB step row: every block of the CRNN), else CRNN_ERR_UNSUPPORTED. */
+ * is taken -- a row, cut into the smallest number of channel ranges (whole groups of 8 channels) that fit 576 sixteen-byte columns, with a whole number of
+ * row bands side by side, fills five to nine compute waves (257..576 columns): every block of the CRNN at image width 32 (576), 48 (416), 64 (544) --, else
+ * CRNN_ERR_UNSUPPORTED (the caller runs the halo-tile kernel). */
 int crnn_dwconv_fwd_stream_supported(int B, int H, int W, int C);
 int crnn_dwconv_fwd_stream_rows(int B, int H, int W, int C);
 int crnn_dwconv3x3_fwd_stream(const void* x, const float* k, void* out, float* stat_partials, const float* bnstate, int B, int H, int W, int C,
@@ -331,14 +333,14 @@ int crnn_dwconv3x3_bwd_fused(const void* d, const void* da, const float* bnstate
  * (global_load_lds); five "DK" waves form dd of the arriving row and keep the 72 weight-gradient sums of their 16-byte column, five "DX"
  * waves run the three running output rows of the data gradient on the dd row the others left in LDS.  Same contract and arithmetic as
  * crnn_dwconv3x3_bwd_fused (dx bit-identical, dk to the order of its partial sums); scratch: crnn_dwconv_bwd_stream_rows() * 9 * C floats.
- * _supported: CRNN_OK when W * C / 8 sixteen-byte columns split over whole channel octets into workgroups of 257..320 columns (every block
+ * _supported: CRNN_OK when W * C / 8 sixteen-byte columns split over whole channel octets into workgroups of 129..320 columns (every block
  * of the CRNN), else CRNN_ERR_UNSUPPORTED. */
 int crnn_dwconv_bwd_stream_supported(int B, int H, int W, int C);
 int crnn_dwconv_bwd_stream_rows(int B, int H, int W, int C);
 int crnn_dwconv3x3_bwd_stream(const void* d, const void* da, const float* bnstate, const float* coef, const void* xin, const float* k, void* dx,
                               float* dk, float* scratch, int B, int H, int W, int C, crnn_stream_t stream);
 /* The same stage by storage type (dtype: CRNN_BF16 = the three entry points above; CRNN_F32, round 4: four channels per lane, W * C / 4 columns
- * in workgroups of 257..320): the parity mode's crnn_bn_bwd_apply_ex + crnn_dwconv3x3_wgrad_ex + crnn_dwconv3x3_fwd_ex(flip = 1) in one pass over
+ * in workgroups of 129..320): the parity mode's crnn_bn_bwd_apply_ex + crnn_dwconv3x3_wgrad_ex + crnn_dwconv3x3_fwd_ex(flip = 1) in one pass over
  * d, da, xin -- 4 tensor passes instead of 7; dx bit-identical to that sequence, dk to the order of its partial sums. */
 int crnn_dwconv_bwd_stream_supported_ex(int B, int H, int W, int C, int dtype);
 int crnn_dwconv_bwd_stream_rows_ex(int B, int H, int W, int C, int dtype);

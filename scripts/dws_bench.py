@@ -11,7 +11,9 @@ from crnn_mi355x import native
 P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 S = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 256
-shapes = [(104, 36, 64), (104, 36, 128), (52, 18, 256), (52, 18, 256), (52, 9, 512), (52, 9, 512)]
+IMGW = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 32      # image width: 32 (every BASELINE config) | 48 | 64 (round 5: row-stream kernels too)
+w2, w4, w6 = IMGW + 4, (IMGW + 4) // 2, (IMGW + 4) // 4
+shapes = [(104, w2, 64), (104, w2, 128), (52, w4, 256), (52, w4, 256), (52, w6, 512), (52, w6, 512)]
 L0 = native.lib()
 bufs = []
 for (h, w, c) in shapes:
@@ -53,4 +55,4 @@ for name, L, stream in variants:
     med = np.median(ms, 0)
     tot_b = sum(2.0 * B * h * w * c * 2 for h, w, c in shapes)
     line = "%-8s" % name + "".join("  %dx%dx%d %.1f us (%.2f TB/s)" % (h, w, c, 1e3 * m, 2.0 * B * h * w * c * 2 / m / 1e9) for (h, w, c), m in zip(shapes, med))
-    print(line + "   six launches %.3f ms = %.2f TB/s" % (med.sum(), tot_b / med.sum() / 1e9), flush=True)
+    print(line + "   six launches %.3f ms = %.2f TB/s (image width %d, batch %d)" % (med.sum(), tot_b / med.sum() / 1e9, IMGW, B), flush=True)

@@ -8,6 +8,7 @@
 #   prof:name[:args]         rocprofv3 --kernel-trace --stats of bench.py (short run) -> step timeline + kernel stats
 #   pmc:name:COUNTERS[:args] rocprofv3 --pmc pass (counters comma separated, no trace domains beside --kernel-trace) of bench.py
 #   py:script[:args]         python scripts/<script> args
+#   ab:libs:args             bench.py headline with each of the comma-separated libraries (product | scripts/_trace/libcrnn_<name>.so)
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out
@@ -32,7 +33,7 @@ for step in "$@"; do
       n=$(echo "$rest" | tr -c 'a-zA-Z0-9' '_' | cut -c1-40)
       timeout 1500 python bench.py $(echo $rest | tr ':' ' ') > $OUT/${TAG}_bench_${n:-default}.json 2> $OUT/${TAG}_bench_${n:-default}.err
       echo "bench[$rest] exit $?: $(cut -c1-150 $OUT/${TAG}_bench_${n:-default}.json)" >> $SUM ;;
-    dws) timeout 300 python scripts/dws_bench.py 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_dw_fwd_stream_bench.txt; echo "dws exit $?" >> $SUM ;;
+    dws) for wd in ${rest:-32}; do timeout 300 python scripts/dws_bench.py 256 $wd 2>/dev/null | grep -v amdgpu; done > $OUT/${TAG}_dw_fwd_stream_bench.txt; echo "dws exit $?" >> $SUM ;;
     dbs) timeout 300 python scripts/dbs_bench.py 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_dw_bwd_stream_bench.txt; echo "dbs exit $?" >> $SUM ;;
     probe) timeout 300 scripts/probes/pattern_probe > $OUT/${TAG}_pattern_probe.txt 2>&1; echo "probe exit $?" >> $SUM ;;
     py)
@@ -46,13 +47,18 @@ for step in "$@"; do
       f=$(find $OUT/${TAG}_prof_$n -name "*kernel_trace.csv" | head -1)
       [ -n "$f" ] && python scripts/trace_step.py $f > $OUT/${TAG}_step_timeline_$n.txt
       k=$(find $OUT/${TAG}_prof_$n -name "*kernel_stats.csv" | head -1); [ -n "$k" ] && cp $k $OUT/${TAG}_kernel_stats_$n.csv
-      find $OUT/${TAG}_prof_$n -name "*kernel_trace.csv" -size +30M -delete ;;
+      find $OUT/${TAG}_prof_$n -name "*kernel_trace.csv" -size +40M -delete ;;
     pmc)
       n=${rest%%:*}; r2=${rest#*:}; c=${r2%%:*}; a=${r2#*:}; [ "$a" = "$r2" ] && a=""
       ( cd /tmp && export TMPDIR=/tmp && rm -rf $OUT/${TAG}_pmc_$n &&
         timeout 900 rocprofv3 --pmc $(echo $c | tr ',' ' ') --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$n -o pmc -- python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary --no-parity --no-roofline $(echo $a | tr ':' ' ') > $OUT/${TAG}_pmc_${n}.log 2>&1 )
       echo "pmc[$rest] exit $?" >> $SUM
       find $OUT/${TAG}_pmc_$n -name "*kernel_trace.csv" -delete ;;
+    ab)   # ab:lib1,lib2:bench args -- whole-library A/B (scripts/gpu_ab_libs.sh; "product" = the library as built, others scripts/_trace/libcrnn_<name>.so)
+      l=${rest%%:*}; a=${rest#*:}; [ "$a" = "$rest" ] && a=""
+      n=$(echo "$a" | tr -c 'a-zA-Z0-9' '_' | cut -c1-30)
+      BENCH_ARGS="--no-roofline --no-parity $(echo $a | tr ':' ' ')" bash scripts/gpu_ab_libs.sh $(echo $l | tr ',' ' ') > $OUT/${TAG}_ab_$n.txt 2>&1
+      echo "ab[$rest]: $(tr '\n' ' ' < $OUT/${TAG}_ab_$n.txt)" >> $SUM ;;
     *) echo "unknown step $step" >> $SUM ;;
   esac
   echo "  ($(( $(date +%s) - t0 )) s)" >> $SUM

@@ -21,6 +21,20 @@ __global__ __launch_bounds__(256) void pattern_kernel(const u32x4* __restrict__ 
   const long lo = stream * per, hi = lo + per < p.n ? lo + per : p.n;
   const long step = (long)p.G * p.burst16;
   u32x4 acc = {0u, 0u, 0u, 0u};
+  if (p.mode == 3) {                                            // descending sweep (whole bursts; the tail burst first)
+    const long nburst = (hi - lo + p.burst16 - 1) / p.burst16;
+    for (long b = nburst - 1 - g; b >= 0; b -= p.G) {
+      const long w0 = lo + b * p.burst16, w1 = w0 + p.burst16 < hi ? w0 + p.burst16 : hi;
+      for (long i = w0 + threadIdx.x; i < w1; i += 1024) {
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i + u * 256 < w1) v[u] = s[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i + u * 256 < w1) d[i + u * 256] = v[u];
+      }
+    }
+    return;
+  }
   for (long w0 = lo + (long)g * p.burst16; w0 < hi; w0 += step) {
     const long w1 = w0 + p.burst16 < hi ? w0 + p.burst16 : hi;
     for (long i = w0 + threadIdx.x; i < w1; i += 1024) {
@@ -80,5 +94,55 @@ int main() {
   for (int S : {256, 64, 16}) { run(S, 1024 / S, 16384, 1, 0); }                          // four per CU
   run(64, 4, 36864, 0, 0); run(64, 4, 36864, 1, 0); run(32, 8, 18432, 1, 0);             // four (eight) CUs sharing an image band, 36 (18) KiB per step
   for (int mode : {1, 2}) { run(1, 256, 16384, 0, 0, mode); run(256, 1, 16384, 0, 0, mode); run(64, 4, 16384, 1, 0, mode); }
+  // ---- (2) the same sweep / banded pair inside ONE big allocation (the engine's workspace is one 7 GB tensor; the six pairs above are 12 separate
+  //          hipMalloc regions): does the gap between the two patterns depend on where the buffers live?
+  {
+    void* big = nullptr; const size_t sz = 4ull << 30;
+    if (hipMalloc(&big, sz) == hipSuccess) {
+      hipMemset(big, 3, sz);
+      size_t off = 4096 * 37;                                   // (an offset that is not 2 MiB aligned, like the workspace's sub-tensors)
+      void *s2[6], *d2[6];
+      for (int i = 0; i < 6; ++i) { s2[i] = (char*)big + off; off += bytes[i] + 256 * 13; d2[i] = (char*)big + off; off += bytes[i] + 256 * 7; }
+      if (off <= sz) {
+        void* keep_s[6]; void* keep_d[6];
+        for (int i = 0; i < 6; ++i) { keep_s[i] = src[i]; keep_d[i] = dst[i]; src[i] = s2[i]; dst[i] = d2[i]; }
+        printf("the same inside one 4 GiB allocation (sub-buffers at odd offsets):\n");
+        run(1, 256, 16384, 0, 0); run(256, 1, 16384, 0, 0); run(1, 256, 16384, 0, 1); run(256, 1, 16384, 0, 1); run(128, 4, 16384, 1, 0);
+        for (int i = 0; i < 6; ++i) { src[i] = keep_s[i]; dst[i] = keep_d[i]; }
+      }
+      hipFree(big);
+    }
+  }
+  // ---- (3) producer -> consumer through the 256 MB last-level cache: a producer copy writes T (123 MB, ascending addresses); the consumer copy reads T
+  //          ascending (the producer's oldest lines first) or DESCENDING (its newest first).  Only the consumer is timed.  If the cache keeps the most
+  //          recently written half of T, the descending consumer finds it there.
+  {
+    const long nb = bytes[2];                                   // 122.7 MB
+    void *A = src[2], *T = dst[2], *O = src[3];
+    for (int desc = 0; desc < 2; ++desc)
+      for (int wgs : {256, 2048}) {
+        std::vector<float> ts;
+        for (int it = 0; it < 10; ++it) {
+          // evict: stream two other pairs through the cache
+          Pat pe{bytes[0] / 16, 1, 256, 1024, 0, 0, 0};
+          hipLaunchKernelGGL(pattern_kernel<0>, dim3(256), dim3(256), 0, 0, (const u32x4*)src[0], (u32x4*)dst[0], pe);
+          Pat pe1{bytes[1] / 16, 1, 256, 1024, 0, 0, 0};
+          hipLaunchKernelGGL(pattern_kernel<0>, dim3(256), dim3(256), 0, 0, (const u32x4*)src[1], (u32x4*)dst[1], pe1);
+          Pat pp{nb / 16, 1, wgs, 1024, 0, 0, 0};               // producer: A -> T, ascending sweep
+          hipLaunchKernelGGL(pattern_kernel<0>, dim3(wgs), dim3(256), 0, 0, (const u32x4*)A, (u32x4*)T, pp);
+          hipEventRecord(e0, 0);
+          Pat pc{nb / 16, 1, wgs, 1024, 0, 0, desc ? 3 : 0};    // consumer: T -> O
+          hipLaunchKernelGGL(pattern_kernel<0>, dim3(wgs), dim3(256), 0, 0, (const u32x4*)T, (u32x4*)O, pc);
+          hipEventRecord(e1, 0); hipEventSynchronize(e1);
+          float ms; hipEventElapsedTime(&ms, e0, e1);
+          if (it) ts.push_back(ms);
+        }
+        std::sort(ts.begin(), ts.end());
+        const double t = ts[ts.size() / 2] * 1e-3;
+        printf("consumer of a just-written 123 MB tensor, %4d workgroups, %s: %6.1f us  %6.0f GB/s (read + write)\n", wgs, desc ? "DESCENDING" : "ascending ", t * 1e6,
+               2.0 * nb / t / 1e9);
+        fflush(stdout);
+      }
+  }
   return hipDeviceSynchronize() == hipSuccess ? 0 : 1;
 }

@@ -344,7 +344,16 @@ def test_odd_shape_model_wide_image_small_alphabet():
     check_case(res, "odd-shape")
     # the throughput mode at the same shape: close to the fp32 engine's posteriors, finite deterministic gradients
     cfg, eng32, p, bn, (x, lab, il, ll), yd = res[0], res[1], res[2], res[3], res[4], res[5]
-    eng = Engine(5, 60, 48, 20, 10, 64, 128, stn=True, dropout=True, precision="bf16s")
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)      # round 5: image width 48 takes the row-stream depthwise kernels -- no half-rate fallback, no warning
+        Engine._warned_shapes.discard((60, 48))
+        eng = Engine(5, 60, 48, 20, 10, 64, 128, stn=True, dropout=True, precision="bf16s")
+    h, w, cin = 64, 52, 1
+    for i, (co, ph, pw) in enumerate(((64, 1, 1), (128, 1, 1), (256, 2, 2), (256, 1, 1), (512, 1, 2), (512, 1, 1), (512, 1, 1)), 1):
+        if i >= 2:
+            assert eng.lib.crnn_dwconv_fwd_stream_supported(5, h, w, cin) == 0 and eng.lib.crnn_dwconv_bwd_stream_supported(5, h, w, cin) == 0, (i, h, w, cin)
+        h, w, cin = h // ph, w // pw, co
     eng.set_params(p, bn)
     y16 = eng.forward(x.astype(np.float32), train=True, seed=3).cpu().numpy()
     assert np.abs(y16 - yd).max() < 5e-2

@@ -191,7 +191,9 @@ def test_dwconv_fwd_flip_wgrad_stats(shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 104, 36, 128), (3, 52, 18, 256), (2, 52, 9, 512), (2, 13, 7, 64), (1, 5, 61, 64), (5, 33, 20, 128), (1, 3, 100, 64), (2, 1, 1, 64), (1, 40, 25, 64),
-                                   (3, 104, 36, 64), (2, 204, 36, 128), (40, 52, 18, 256), (128, 52, 9, 512), (2, 7, 36, 64), (1, 3, 18, 256)])
+                                   (3, 104, 36, 64), (2, 204, 36, 128), (40, 52, 18, 256), (128, 52, 9, 512), (2, 7, 36, 64), (1, 3, 18, 256),
+                                   # round 5: image widths 48 (ranges of 208 columns: three and a quarter of the five waves busy) and 64 (272 columns) on the row-stream kernel
+                                   (3, 64, 52, 64), (2, 64, 52, 128), (4, 32, 26, 256), (40, 32, 13, 512), (2, 104, 68, 64), (2, 104, 68, 128), (3, 52, 34, 256), (2, 52, 17, 512)])
 def test_fused_depthwise_stage_backward_equals_the_three_kernel_sequence(shape):
     """crnn_dwconv3x3_bwd_fused (BatchNorm-backward pass 2 formed in the halo-tile fill, depthwise weight and data gradients from one
     pass over the tiles) against crnn_bn_bwd_ex + crnn_dwconv3x3_wgrad_ex + crnn_dwconv3x3_fwd_ex(flip=1) on bf16 tensors: the data
@@ -236,6 +238,8 @@ def test_fused_depthwise_stage_backward_equals_the_three_kernel_sequence(shape):
     assert_close(host(dk2).reshape(3, 3, C), dk_ref, rtol=1e-2, atol=1e-2 * np.abs(dk_ref).max(), what="dk vs oracle")
     assert L().crnn_dwconv_bwd_fused_supported(H, W, 32) == -3 and L().crnn_dwconv_bwd_fused_supported(H, W, 96) == -3
     # the row-stream kernel of the same stage, where its shape rule holds: dx bit for bit, dk to summation round-off
+    if W in (52, 26, 13, 68, 34, 17):
+        assert L().crnn_dwconv_bwd_stream_supported(B, H, W, C) == 0, "image widths 48 / 64 take the row-stream backward since round 5"
     if L().crnn_dwconv_bwd_stream_supported(B, H, W, C) == 0:
         rows = L().crnn_dwconv_bwd_stream_rows(B, H, W, C)
         dx3 = torch.full((B * H * W * C + 64,), 9.0, dtype=torch.bfloat16, device="cuda"); dk3 = zeros(9, C)
@@ -252,7 +256,7 @@ def test_fused_depthwise_stage_backward_equals_the_three_kernel_sequence(shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 104, 36, 128), (3, 52, 18, 256), (2, 52, 9, 512), (3, 104, 36, 64), (2, 204, 36, 128), (40, 52, 18, 256), (70, 52, 9, 512),
-                                   (1, 40, 36, 64), (2, 13, 7, 64), (1, 3, 18, 256)])
+                                   (1, 40, 36, 64), (2, 13, 7, 64), (1, 3, 18, 256), (3, 64, 52, 64), (4, 32, 26, 256), (2, 104, 68, 128), (2, 52, 17, 512)])
 def test_fp32_row_stream_depthwise_stage_backward_equals_the_three_kernel_sequence(shape):
     """crnn_dwconv3x3_bwd_stream_ex(dtype = fp32) -- the parity mode's depthwise-stage backward in one pass (round 4) -- against
     crnn_bn_bwd_ex + crnn_dwconv3x3_wgrad_ex + crnn_dwconv3x3_fwd_ex(flip = 1) on fp32 tensors: the data gradient bit for bit, the weight
@@ -875,7 +879,12 @@ def _f(t):
 
 
 @pytest.mark.parametrize("B,H,W,C", [(3, 104, 36, 64), (2, 104, 36, 128), (5, 52, 18, 256), (2, 52, 9, 512), (2, 204, 36, 128), (256, 52, 9, 512),
-                                     (70, 52, 18, 256)])
+                                     (70, 52, 18, 256),
+                                     # round 5 -- step rows of five to eight compute waves and bf16 rows cut into channel ranges: image width 48 (416 columns: blocks 2..7,
+                                     # blocks 3..7 as two ranges), width 64 (544 columns, two ranges from block 3 on), and 5 / 6 / 8-wave rows
+                                     (3, 64, 52, 64), (2, 64, 52, 128), (4, 32, 26, 256), (3, 32, 13, 512), (70, 32, 13, 512),
+                                     (2, 104, 68, 64), (2, 104, 68, 128), (3, 52, 34, 256), (2, 52, 17, 512),
+                                     (2, 40, 20, 128), (2, 24, 24, 128), (2, 16, 32, 128), (2, 104, 40, 128), (2, 51, 9, 256)])
 def test_row_stream_depthwise_equals_the_halo_tile_kernel(B, H, W, C):
     """crnn_dwconv3x3_fwd_stream (rows streamed through an LDS ring by a loader wave with global_load_lds; every compute lane owns a 16-byte
     column and adds an arriving row's taps to three running output rows) against crnn_dwconv3x3_fwd_ex / crnn_dwconv3x3_bn_relu6_fwd on the
@@ -1106,9 +1115,43 @@ def test_dropout_rng_statistics():
     assert bool((m0 == 1).all())
 
 
+@pytest.mark.parametrize("B,H,W,C", [(3, 64, 52, 64), (2, 64, 52, 128), (4, 32, 26, 256), (3, 32, 13, 512), (2, 104, 68, 64), (3, 52, 34, 256), (2, 40, 20, 64), (2, 51, 9, 128)])
+def test_fp32_row_stream_depthwise_on_step_rows_of_five_to_nine_waves(B, H, W, C):
+    """Round 5: crnn_dwconv3x3_fwd_stream_dt(fp32) on the step rows image widths 48 / 64 give (and 5-wave rows), forward and flipped taps, against the
+    halo-tile kernel: outputs bit for bit, statistics to summation order, memory around the outputs untouched, repeated launches the same bits."""
+    F32 = 0
+    assert L().crnn_dwconv_fwd_stream_supported_ex(B, H, W, C, F32) == 0
+    rs = np.random.RandomState(B + H + W + C + 5)
+    n = B * H * W * C
+    xd = torch.randn(n, device="cuda", generator=torch.Generator("cuda").manual_seed(n % 997 + 3))
+    kd = dev(rs.normal(size=(3, 3, C)))
+    ntiles = L().crnn_dwconv_num_tiles(B, H, W)
+    rows = L().crnn_dwconv_fwd_stream_rows_ex(B, H, W, C, F32)
+    assert rows >= B
+    for flip in (0, 1):
+        o0 = zeros(n); p0 = zeros(ntiles, 2, C)
+        ok(L().crnn_dwconv3x3_fwd_ex(P(xd), P(kd), P(o0), P(p0), B, H, W, C, flip, F32, S()))
+        o1 = torch.full((n + 64,), 7.0, device="cuda"); p1 = torch.full((rows + 1, 2, C), 3.0, device="cuda")
+        ok(L().crnn_dwconv3x3_fwd_stream_dt(P(xd), P(kd), P(o1), P(p1), B, H, W, C, flip, F32, S()))
+        assert torch.equal(o1[:-64].view(torch.int32), o0.view(torch.int32)), "flip %d: max diff %g" % (flip, float((o1[:-64] - o0).abs().max()))
+        assert bool((o1[-64:] == 7.0).all()) and bool((p1[rows] == 3.0).all())
+        t0, t1 = host(p0).sum(0), host(p1[:rows]).sum(0)
+        assert_close(t1, t0, rtol=1e-4, atol=1e-4 * np.abs(t0).max(), what="statistics stream vs tile")
+        o2 = zeros(n); p2 = zeros(rows, 2, C)
+        ok(L().crnn_dwconv3x3_fwd_stream_dt(P(xd), P(kd), P(o2), P(p2), B, H, W, C, flip, F32, S()))
+        assert torch.equal(o2, o1[:-64]) and torch.equal(p2, p1[:rows]), "repeat launches differ"
+
+
 def test_row_stream_depthwise_refuses_other_shapes():
-    for B, H, W, C in [(2, 104, 40, 128), (2, 13, 18, 64), (2, 52, 18, 252), (2, 51, 9, 256)]:
+    """Step rows that fill fewer than five compute waves, and channel counts that are no whole groups of 8, stay with the halo-tile kernels."""
+    for B, H, W, C in [(2, 13, 18, 64), (2, 52, 18, 252), (2, 13, 9, 128), (2, 13, 9, 64)]:
         assert L().crnn_dwconv_fwd_stream_supported(B, H, W, C) == -3 and L().crnn_dwconv_fwd_stream_rows(B, H, W, C) == 0
+    for B, H, W, C in [(2, 52, 18, 252), (2, 13, 9, 64)]:         # (fp32 rows have twice the columns: 13 x 18 x 64 fills five waves there)
+        assert L().crnn_dwconv_fwd_stream_supported_ex(B, H, W, C, 0) == -3 and L().crnn_dwconv_fwd_stream_rows_ex(B, H, W, C, 0) == 0
+    # round 5: shapes the 9 KiB step-row rule used to refuse (image widths 48 and 64, 5-wave rows)
+    for B, H, W, C in [(2, 104, 40, 128), (2, 51, 9, 256), (4, 64, 52, 64), (4, 32, 26, 256), (4, 104, 68, 128), (4, 52, 17, 512)]:
+        assert L().crnn_dwconv_fwd_stream_supported(B, H, W, C) == 0 and L().crnn_dwconv_fwd_stream_rows(B, H, W, C) >= B
+        assert L().crnn_dwconv_fwd_stream_supported_ex(B, H, W, C, 0) == 0
 
 
 def test_bf16_storage_dwconv_bn_chain():

@@ -125,9 +125,23 @@ def test_schedule_flags_of_the_binding_equal_the_header_and_row_stream_shape_rul
                 rows_f, rows_b = L.crnn_dwconv_fwd_stream_rows(B, h, w, c), L.crnn_dwconv_bwd_stream_rows(B, h, w, c)
                 assert rows_f >= B and rows_f % B == 0 and h % (rows_f // B) == 0          # whole row bands per image
                 assert rows_b >= B and rows_b % B == 0 and h % (rows_b // B) == 0
-    for (h, w, c) in [(104, 52, 64), (13, 18, 64), (52, 18, 252), (51, 9, 256), (104, 36, 1)]:
+    # round 5: image widths 48 and 64 (step rows of 416 / 544 columns, bf16 rows cut into channel ranges) take the row-stream kernels in both storage types
+    for fn in ("crnn_dwconv_fwd_stream_supported_ex", "crnn_dwconv_bwd_stream_supported_ex"):
+        getattr(L, fn).restype = ctypes.c_int
+    for imgw in (48, 64):
+        h, w, cin = 104, imgw + 4, 1
+        for i, (co, ph, pw) in enumerate(((64, 1, 1), (128, 1, 1), (256, 2, 2), (256, 1, 1), (512, 1, 2), (512, 1, 1), (512, 1, 1)), 1):
+            if i >= 2:
+                for B in (5, 64, 256):
+                    assert L.crnn_dwconv_fwd_stream_supported(B, h, w, cin) == 0 and L.crnn_dwconv_bwd_stream_supported(B, h, w, cin) == 0, (imgw, B, h, w, cin)
+                    assert L.crnn_dwconv_fwd_stream_supported_ex(B, h, w, cin, 0) == 0 and L.crnn_dwconv_bwd_stream_supported_ex(B, h, w, cin, 0) == 0, (imgw, B, h, w, cin)
+                    rows_f = L.crnn_dwconv_fwd_stream_rows(B, h, w, cin)
+                    assert rows_f >= B and rows_f % B == 0 and h % (rows_f // B) == 0
+            h, w, cin = h // ph, w // pw, co
+    # refused: step rows that fill fewer than five compute waves (forward) / no more than two (backward), channel counts that are no whole groups of 8
+    for (h, w, c) in [(13, 18, 64), (52, 18, 252), (13, 9, 128), (104, 36, 1)]:
         assert L.crnn_dwconv_fwd_stream_supported(8, h, w, c) == -3 and L.crnn_dwconv_fwd_stream_rows(8, h, w, c) == 0
-    for (h, w, c) in [(104, 52, 64), (52, 18, 252), (104, 36, 1), (8, 4, 64)]:
+    for (h, w, c) in [(52, 18, 252), (104, 36, 1), (8, 4, 64), (13, 9, 64)]:
         assert L.crnn_dwconv_bwd_stream_supported(8, h, w, c) == -3 and L.crnn_dwconv_bwd_stream_rows(8, h, w, c) == 0
 
 
@@ -150,7 +164,8 @@ def test_fp32_row_stream_and_localisation_net_shape_rules():
                     for rows in (L.crnn_dwconv_fwd_stream_rows_ex(B, h, w, c, dt), L.crnn_dwconv_bwd_stream_rows_ex(B, h, w, c, dt)):
                         assert rows >= B and rows % B == 0 and h % (rows // B) == 0
                 assert L.crnn_dwconv_fwd_stream_rows_ex(B, h, w, c, BF16) == L.crnn_dwconv_fwd_stream_rows(B, h, w, c)
-    assert L.crnn_dwconv_fwd_stream_supported_ex(8, 104, 52, 64, F32) == -3 and L.crnn_dwconv_bwd_stream_supported_ex(8, 104, 36, 1, F32) == -3
+    assert L.crnn_dwconv_fwd_stream_supported_ex(8, 13, 9, 64, F32) == -3 and L.crnn_dwconv_bwd_stream_supported_ex(8, 104, 36, 1, F32) == -3
+    assert L.crnn_dwconv_fwd_stream_supported_ex(8, 104, 52, 64, F32) == 0 and L.crnn_dwconv_fwd_stream_pro_supported_ex(8, 104, 52, 64, F32) == -3   # (round 5: width 48 streams; its prologue form stays with the 9 KiB step row)
     assert L.crnn_dwconv_fwd_stream_supported_ex(8, 104, 36, 64, 7) == -2
     assert L.crnn_loc_net_fused_supported(100, 32) == 0 and L.crnn_loc_net_fused_supported(200, 32) == 0 and L.crnn_loc_net_fused_supported(40, 32) == 0
     assert L.crnn_loc_net_fused_supported(60, 48) == 0
