@@ -32,6 +32,48 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (not the 2:1-sparsity fig
 PEAK_HBM_GBS = 8000.0
 
 
+def pmc_step_traffic(eng, prefixes, grids=None):
+    """Memory-side bytes per train step of the kernels whose (shortened) names start with one of `prefixes`, from the committed counter passes over this very
+    command (profiles/r05_pmc_step_<mode>.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate counter-only runs, FETCH_SIZE doubled per
+    MI355X_MICROARCH.md; scripts/gpu_visit.sh pmc: steps + scripts/pmc_step_summary.py).  Counted in the step's own order and cache state (the requests the
+    L2s send to the fabric: last-level-cache hits included).  None when the workload is not the one the passes ran (batch 256, 100x32, LSTM).
+    grids: optional {prefix: set of grid sizes in threads} to tell launches of one kernel apart.  -> (bytes per step, launches per step) | None"""
+    if eng.B != 256 or (eng.cfg.imgh, eng.cfg.imgw) != (100, 32) or eng.cfg.gru or eng.cfg.flags:
+        return None
+    path = os.path.join(ROOT, "profiles", "r05_pmc_step_%s.json" % eng.precision)
+    if not os.path.exists(path):
+        return None
+    ks = json.load(open(path))["kernels"]
+    tot, n = 0.0, 0.0
+    for key, v in ks.items():
+        name, grid = key.rsplit("|", 1)
+        for pfx in prefixes:
+            if name.startswith(pfx) and (not grids or pfx not in grids or int(grid) in grids[pfx]):
+                tot += v["bytes_per_launch"] * v["calls_per_step"]; n += v["calls_per_step"]
+                break
+    return (tot, n) if n else None
+
+
+def pmc_mfma_util(eng, prefixes):
+    """MFMA-pipe utilisation by the counters (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x average kernel time x 2.4 GHz)) of the step's launches of each prefix."""
+    if eng.B != 256 or (eng.cfg.imgh, eng.cfg.imgw) != (100, 32) or eng.cfg.gru or eng.cfg.flags:
+        return None
+    path = os.path.join(ROOT, "profiles", "r05_pmc_step_%s.json" % eng.precision)
+    if not os.path.exists(path):
+        return None
+    ks = json.load(open(path))["kernels"]
+    out = []
+    for pfx in prefixes:
+        v = [x for k, x in ks.items() if k.startswith(pfx) and x.get("mfma_util") is not None and x["calls_per_step"] >= 0.9]
+        out.append(round(sum(x["mfma_util"] * x["calls_per_step"] for x in v) / max(1e-9, sum(x["calls_per_step"] for x in v)), 4) if v else None)
+    return out
+
+
+PMC_NOTE = ("memory-side bytes of the same kernels in the train step, per launch set: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE passes over `bench.py "
+            "--steps 3 --warmup 2` (profiles/r05_pmc_step_%s.json, profiles/r05_pmc_sq_step_%s.txt); counted in the step's order and cache state -- the L2s' "
+            "requests to the fabric, last-level-cache hits included -- while `achieved` is timed on the re-issued launches")
+
+
 def depthwise_roofline(eng, iters=15):
     """The HBM-bound kernel north_star singles out: the depthwise 3x3 of blocks 2..7.  bf16s (the headline mode): the six forward
     launches of a step (each with the BatchNorm-statistics epilogue) exactly as the step issues them -- dw_fwd_stream_kernel where its
@@ -115,7 +157,7 @@ def depthwise_roofline(eng, iters=15):
     # and committed under profiles/; FETCH_SIZE x2 per the gfx950 note in MI355X_MICROARCH.md)
     traffic, pmc_file = None, None
     try:
-        pmc_file = [f for f in ("r04_pmc_dwconv.json", "r03_pmc_dwconv.json", "r02_pmc_dwconv.json", "r01_pmc_dwconv.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+        pmc_file = [f for f in ("r05_pmc_dwconv.json", "r04_pmc_dwconv.json", "r03_pmc_dwconv.json", "r02_pmc_dwconv.json", "r01_pmc_dwconv.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
         pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
         if B == pmc["batch"] and (eng.cfg.imgh, eng.cfg.imgw) == (100, 32):
             if nstream == len(launches):
@@ -225,9 +267,12 @@ def depthwise_bwd_roofline(eng, iters=5):
              "weight-gradient and data-gradient wave groups; incl. the second-stage sum of the weight-gradient partials; %d of the %d launches re-form x from "
              "the previous block's q in LDS)" % (npro, len(launches)) if nstream == len(launches) else
              "dw_bwd_fused_kernel (BatchNorm-backward pass 2 + depthwise weight and data gradients, blocks 2-7; VALU-issue-bound, DESIGN.md section 4)")
+    tr = pmc_step_traffic(eng, ["dw_bwd_stream_kernel"]) if nstream == len(launches) else None
     return {"bound": "hbm", "kernel": kname,
             "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "launches": len(launches),
-            "avg_launch_ms": round(1e3 * t / len(launches), 4), "algorithmic_bytes_per_launch_set": nbytes}
+            "avg_launch_ms": round(1e3 * t / len(launches), 4), "algorithmic_bytes_per_launch_set": nbytes,
+            "traffic": None if tr is None or tr[1] != len(launches) else tr[0],
+            "traffic_note": None if tr is None else PMC_NOTE % (eng.precision, eng.precision)}
 
 
 def batchnorm_roofline(eng, iters=5):
@@ -269,12 +314,14 @@ def batchnorm_roofline(eng, iters=5):
             if it:
                 ts.append(e0.elapsed_time(e1) * 1e-3)
         t = float(np.median(ts))
+        tr = pmc_step_traffic(eng, ["bn_act_pool_drop_kernel"] if name == "apply" else ["bn_bwd_kernel", "bn_bwd_pool_kernel"])
+        # (the step's BatchNorm-1 backward statistics of block 2 run bn_bwd_kernel<1> once more than this launch set: same kernel family)
         res[name] = {"achieved": round(nb / t / 1e9, 1), "frac": round(nb / t / 1e9 / PEAK_HBM_GBS, 4), "launches": nl, "ms": round(1e3 * t, 4),
-                     "algorithmic_bytes_per_launch_set": nb}
+                     "algorithmic_bytes_per_launch_set": nb, "traffic": None if tr is None else tr[0], "traffic_launches_in_step": None if tr is None else tr[1]}
     return {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "kernel": "bn_act_pool_drop_kernel (BatchNorm-2 + ReLU6 + MaxPooling + Dropout of the seven block outputs) and bn_bwd_kernel / bn_bwd_pool_kernel "
                       "(its backward: statistics pass, finalize, apply pass); the gradient buffers are overwritten: run after the step's timing",
-            **res}
+            "traffic_note": PMC_NOTE % (eng.precision, eng.precision), **res}
 
 
 def pointwise_gemm_roofline(eng, iters=5):
@@ -345,7 +392,13 @@ def pointwise_gemm_roofline(eng, iters=5):
              "gemm_nt_f32_stream_kernel (RNN input projections)"
              if any(isinstance(c[8], tuple) and c[8][0] == "pw" for c in cfgs) else
              "gemm_%s_kernel<128,false,true> (pointwise 1x1 convs fwd + dense1 + RNN input GEMMs)" % ("bf16" if bf else "f32"))
+    # memory-side bytes of the same launches in the step (bf16s: the six weights-resident pointwise forwards, dense1's tile GEMM, the four forward input projections)
+    tr = pmc_step_traffic(eng, ["gemm_wres_fwd_kernel", "gemm_bf16_kernel<128, false, true, true, true, false, true, false>", "gemm_nt_f32_stream_kernel<2>"],
+                          {"gemm_nt_f32_stream_kernel<2>": {638976}}) if eng.precision == "bf16s" else None
     return {"bound": "mfma", "kernel": kname,
+            "traffic": None if tr is None or tr[1] != len(cfgs) else tr[0], "traffic_note": None if tr is None else PMC_NOTE % (eng.precision, eng.precision),
+            "mfma_busy_counter": (lambda m: None if m is None else {"gemm_wres_fwd_kernel": m[0], "gemm_wres_kernel (data gradient)": m[1], "pw_wgrad_stream_kernel": m[2],
+                                                                    "gemm_x3p_kernel": m[3]})(pmc_mfma_util(eng, ["gemm_wres_fwd_kernel", "gemm_wres_kernel", "pw_wgrad_stream_kernel", "gemm_x3p_kernel"])),
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "launches": len(cfgs), "avg_launch_ms": round(1e3 * t / len(cfgs), 4), "flops_per_launch_set": flops,
             # with bf16 tensors every one of these GEMMs sits below the 312 FLOP/B ridge: the binding roof is HBM
@@ -658,6 +711,11 @@ def lstm_roofline(eng, iters=10):
                                         else "lstm_fwd/bwd_step_kernel (one launch per timestep)"),
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "launches": 4 if persist else 4 * T,
             "ms_per_train_step": round(1e3 * t, 4), "us_per_step": round(1e6 * t / (4 * T), 3), "flops_recurrent_gemm": flops,
+            "traffic": (lambda tr: None if tr is None else tr[0])(pmc_step_traffic(eng, ["lstm_fwd_persist_kernel", "lstm_bwd_persist_kernel"]) if persist else None),
+            "traffic_note": PMC_NOTE % (eng.precision, eng.precision),
+            "mfma_busy_counter": (lambda m: None if m is None else {"lstm_fwd_persist_kernel": m[0], "lstm_bwd_persist_kernel": m[1],
+                                  "note": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel time x 2.4 GHz) of the step's launches (profiles/r05_pmc_sq_step_%s.txt)" % eng.precision})(
+                                  pmc_mfma_util(eng, ["lstm_fwd_persist_kernel", "lstm_bwd_persist_kernel"])),
             "input_projections": {"achieved": round(pflops / tp / 1e12, 2), "unit": "TFLOP/s", "frac": round(pflops / tp / 1e12 / peak, 4), "launches": 4,
                                   "ms": round(1e3 * tp, 4), "flops": pflops,
                                   "note": "the hoisted half of the gate GEMM (x W + b over all T steps, forward): fp32 rows streamed once against a "

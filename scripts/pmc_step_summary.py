@@ -21,8 +21,9 @@ CLK = 2.4e9
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
-    m = re.match(r"([A-Za-z0-9_]+(<[^(]*>)?)", name)
+    m = re.match(r"([A-Za-z0-9_:]+(<[^(]*>)?)", name)
     s = m.group(1) if m else name
+    if len(s) > 90: s = s[:90]
     return s.replace("unsigned short", "bf16").replace("unsigned int", "u32")
 
 
