@@ -144,5 +144,36 @@ int main() {
         fflush(stdout);
       }
   }
+  // ---- (4) a second pass over a working set LARGER than the last-level cache: pass 1 reads X (491 MB = q2 + dx of block 2's BatchNorm-2 backward) ascending,
+  //          pass 2 reads X again and writes Y (245 MB), ascending or DESCENDING.  Only pass 2 is timed.
+  {
+    void *X = nullptr, *Y = nullptr; const long xb = 2 * bytes[1], yb = bytes[1];
+    if (hipMalloc(&X, xb) == hipSuccess && hipMalloc(&Y, yb) == hipSuccess) {
+      hipMemset(X, 5, xb); hipMemset(Y, 6, yb);
+      for (int desc = 0; desc < 2; ++desc) {
+        std::vector<float> ts;
+        for (int it = 0; it < 8; ++it) {
+          Pat p1{xb / 16, 1, 2048, 1024, 0, 0, 1};              // pass 1: read-only ascending sweep
+          hipLaunchKernelGGL(pattern_kernel<0>, dim3(2048), dim3(256), 0, 0, (const u32x4*)X, (u32x4*)Y, p1);
+          hipEventRecord(e0, 0);
+          Pat p2a{yb / 16, 1, 2048, 1024, 0, 0, desc ? 3 : 0};  // pass 2: the two halves of X -> Y (two launches: 2 x 245 MB read, 2 x 245 MB written)
+          if (desc) {
+            hipLaunchKernelGGL(pattern_kernel<0>, dim3(2048), dim3(256), 0, 0, (const u32x4*)((char*)X + yb), (u32x4*)Y, p2a);
+            hipLaunchKernelGGL(pattern_kernel<0>, dim3(2048), dim3(256), 0, 0, (const u32x4*)X, (u32x4*)Y, p2a);
+          } else {
+            hipLaunchKernelGGL(pattern_kernel<0>, dim3(2048), dim3(256), 0, 0, (const u32x4*)X, (u32x4*)Y, p2a);
+            hipLaunchKernelGGL(pattern_kernel<0>, dim3(2048), dim3(256), 0, 0, (const u32x4*)((char*)X + yb), (u32x4*)Y, p2a);
+          }
+          hipEventRecord(e1, 0); hipEventSynchronize(e1);
+          float ms; hipEventElapsedTime(&ms, e0, e1);
+          if (it) ts.push_back(ms);
+        }
+        std::sort(ts.begin(), ts.end());
+        const double t = ts[ts.size() / 2] * 1e-3;
+        printf("second pass over a 491 MB working set just read ascending, %s: %6.1f us  %6.0f GB/s (read + write)\n", desc ? "DESCENDING" : "ascending ", t * 1e6, 2.0 * xb / t / 1e9);
+        fflush(stdout);
+      }
+    }
+  }
   return hipDeviceSynchronize() == hipSuccess ? 0 : 1;
 }
