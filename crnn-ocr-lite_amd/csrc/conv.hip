@@ -18,6 +18,20 @@
 template <int VEC>
 struct VecF { float v[VEC]; };
 
+// Cache policy of the streaming passes (round 5).  The 256 MB last-level cache holds about two of the conv stack's 123 MB tensors; a pass that reads a
+// tensor for the LAST time in the step (or for the last time before the other half of the step) loads it nontemporally so that it does not push out what the
+// next kernel is about to read (its own output, the tensors still to be re-read).  Same values, same order: results bit-identical.  Measured on the bf16s step
+// (profiles/r05_nt_loads_ab.txt): BatchNorm-backward apply pass -0.03 ms, depthwise-stage backward -0.07 ms, together with the forward passes -0.2 ms.
+#ifndef CRNN_NT_BN_BWD2
+#define CRNN_NT_BN_BWD2 1   // BatchNorm backward, apply pass: q and g are read for the last time
+#endif
+#ifndef CRNN_NT_BN_ACT
+#define CRNN_NT_BN_ACT 1    // BatchNorm-2 + ReLU6 + pool + dropout (forward): q is not read again before the backward pass
+#endif
+template <int VEC, typename T>
+__device__ __forceinline__ VecF<VEC> vload_nt(const T* p);
+template <int VEC, bool NT, typename T>
+__device__ __forceinline__ VecF<VEC> vload_s(const T* p);
 template <int VEC, typename T>
 __device__ __forceinline__ VecF<VEC> vload(const T* p) {
   VecF<VEC> r;
@@ -742,7 +756,7 @@ __global__ void bn_act_pool_drop_kernel(const TI* __restrict__ x, const float* _
     const int cl = (int)(i % (IDX)CL); const IDX pix = i / (IDX)CL;
     VecF<VEC> m, s = vload<VEC>(sc + cl * VEC), t = vload<VEC>(sh + cl * VEC);
     if (ph * pw == 1) {
-      VecF<VEC> v = vload<VEC>(&x[(long)pix * C + cl * VEC]);
+      VecF<VEC> v = vload_s<VEC, (CRNN_NT_BN_ACT != 0)>(&x[(long)pix * C + cl * VEC]);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) m.v[e] = relu6f(fmaf(v.v[e], s.v[e], t.v[e]));
     } else {
@@ -755,14 +769,14 @@ __global__ void bn_act_pool_drop_kernel(const TI* __restrict__ x, const float* _
         for (int ii = 0; ii < (PHT ? PHT : 1); ++ii)
 #pragma unroll
           for (int j = 0; j < (PWT ? PWT : 1); ++j) {
-            VecF<VEC> v = vload<VEC>(&x[base + ((long)ii * W + j) * C]);
+            VecF<VEC> v = vload_s<VEC, (CRNN_NT_BN_ACT != 0)>(&x[base + ((long)ii * W + j) * C]);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) m.v[e] = fmaxf(m.v[e], relu6f(fmaf(v.v[e], s.v[e], t.v[e])));
           }
       } else {
         for (int ii = 0; ii < ph; ++ii)
           for (int j = 0; j < pw; ++j) {
-            VecF<VEC> v = vload<VEC>(&x[base + ((long)ii * W + j) * C]);
+            VecF<VEC> v = vload_s<VEC, (CRNN_NT_BN_ACT != 0)>(&x[base + ((long)ii * W + j) * C]);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) m.v[e] = fmaxf(m.v[e], relu6f(fmaf(v.v[e], s.v[e], t.v[e])));
           }
@@ -830,8 +844,33 @@ struct BnBwdArgsT {
   int B, H, W, C, ph, pw; float rate; uint64_t seed; uint32_t layer;
 };
 
+template <int VEC, typename T>
+__device__ __forceinline__ VecF<VEC> vload_nt(const T* p) {
+  typedef unsigned u32x4_nt __attribute__((ext_vector_type(4)));
+  VecF<VEC> r;
+  if constexpr (VEC == 8 && sizeof(T) == 2) {
+    const u32x4_nt u = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(p));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { r.v[2 * q] = __uint_as_float(u[q] << 16); r.v[2 * q + 1] = __uint_as_float(u[q] & 0xffff0000u); }
+    return r;
+  } else if constexpr (VEC % 4 == 0 && sizeof(T) == 4) {
+#pragma unroll
+    for (int h = 0; h < VEC / 4; ++h) {
+      const u32x4_nt u = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(p) + h);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r.v[4 * h + q] = __uint_as_float(u[q]);
+    }
+    return r;
+  } else {
+    return vload<VEC>(p);
+  }
+}
+template <int VEC, bool NT, typename T>
+__device__ __forceinline__ VecF<VEC> vload_s(const T* p) {
+  if constexpr (NT) return vload_nt<VEC>(p); else return vload<VEC>(p);
+}
 // gy for VEC consecutive channels starting at c0 of pixel row r
-template <int VEC, bool POOL, typename T>
+template <int VEC, bool POOL, typename T, bool NT = false>
 __device__ __forceinline__ VecF<VEC> bn_gy_vec(const BnBwdArgsT<T>& a, long r, int c0, const VecF<VEC>& xv, const VecF<VEC>& sc,
                                                const VecF<VEC>& sh, float inv_keep) {
   VecF<VEC> out, y;
@@ -857,7 +896,7 @@ __device__ __forceinline__ VecF<VEC> bn_gy_vec(const BnBwdArgsT<T>& a, long r, i
     for (int ii = 0; ii < a.ph; ++ii)
       for (int j = 0; j < a.pw; ++j) {
         if (ii == si && j == sj) continue;
-        VecF<VEC> o = vload<VEC>(&a.x[(((long)b * a.H + ho * a.ph + ii) * a.W + wo * a.pw + j) * a.C + c0]);
+        VecF<VEC> o = vload_s<VEC, NT>(&a.x[(((long)b * a.H + ho * a.ph + ii) * a.W + wo * a.pw + j) * a.C + c0]);
         bool earlier = (ii < si) || (ii == si && j < sj);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
@@ -867,7 +906,7 @@ __device__ __forceinline__ VecF<VEC> bn_gy_vec(const BnBwdArgsT<T>& a, long r, i
       }
     oidx = (((long)b * Ho + ho) * Wo + wo) * a.C + c0;
   }
-  VecF<VEC> gv = vload<VEC>(&a.g[oidx]);
+  VecF<VEC> gv = vload_s<VEC, NT>(&a.g[oidx]);
   float dm[VEC];
   drop_scale_vec<VEC>(a.seed, a.layer, (uint64_t)oidx, a.rate, inv_keep, dm);
 #pragma unroll
@@ -924,11 +963,12 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgsT<T> a, float* __r
         }
       }
 #endif
+      constexpr bool NT = CRNN_NT_BN_BWD2 && PASS == 2;
       for (; r + RT < r1; r += 2L * RT) {   // two rows in flight (independent loads)
-        VecF<VEC> xa = vload<VEC>(&a.x[r * a.C + c0]);
-        VecF<VEC> xb = vload<VEC>(&a.x[(r + RT) * a.C + c0]);
-        VecF<VEC> ga = bn_gy_vec<VEC, POOL, T>(a, r, c0, xa, sc, sh, inv_keep);
-        VecF<VEC> gb = bn_gy_vec<VEC, POOL, T>(a, r + RT, c0, xb, sc, sh, inv_keep);
+        VecF<VEC> xa = vload_s<VEC, NT>(&a.x[r * a.C + c0]);
+        VecF<VEC> xb = vload_s<VEC, NT>(&a.x[(r + RT) * a.C + c0]);
+        VecF<VEC> ga = bn_gy_vec<VEC, POOL, T, NT>(a, r, c0, xa, sc, sh, inv_keep);
+        VecF<VEC> gb = bn_gy_vec<VEC, POOL, T, NT>(a, r + RT, c0, xb, sc, sh, inv_keep);
         VecF<VEC> oa, ob;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
@@ -944,8 +984,8 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgsT<T> a, float* __r
         if (PASS == 2) { vstore<VEC>(&dx[r * a.C + c0], oa); vstore<VEC>(&dx[(r + RT) * a.C + c0], ob); }
       }
       for (; r < r1; r += RT) {
-        VecF<VEC> xv = vload<VEC>(&a.x[r * a.C + c0]);
-        VecF<VEC> gy = bn_gy_vec<VEC, POOL, T>(a, r, c0, xv, sc, sh, inv_keep);
+        VecF<VEC> xv = vload_s<VEC, NT>(&a.x[r * a.C + c0]);
+        VecF<VEC> gy = bn_gy_vec<VEC, POOL, T, NT>(a, r, c0, xv, sc, sh, inv_keep);
         VecF<VEC> o;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
@@ -1013,11 +1053,12 @@ __global__ __launch_bounds__(256) void bn_bwd_pool_kernel(BnBwdArgsT<T> a, float
       if (PASS == 2) { c1 = vload<VEC>(coef + c0i); c2 = vload<VEC>(coef + a.C + c0i); }
       // one pool window per step; pass 1 (reduce only) keeps two windows' loads in flight
       auto load_window = [&](long r, const Pos& p, VecF<VEC>& gv, VecF<VEC> (&xw)[4], long& xbase) {
-        gv = vload<VEC>(&a.g[r * a.C + c0i]);
+        constexpr bool NT = CRNN_NT_BN_BWD2 && PASS == 2;
+        gv = vload_s<VEC, NT>(&a.g[r * a.C + c0i]);
         xbase = (((long)p.b * a.H + p.ho * ph) * a.W + p.wo * pw) * a.C + c0i;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          if (k < nwin) { int ii = k / pw, j = k - ii * pw; xw[k] = vload<VEC>(&a.x[xbase + ((long)ii * a.W + j) * a.C]); }
+          if (k < nwin) { int ii = k / pw, j = k - ii * pw; xw[k] = vload_s<VEC, NT>(&a.x[xbase + ((long)ii * a.W + j) * a.C]); }
       };
       // These two kernels are VALU-bound (SQ counters: ~3 resident waves/SIMD each 27-34 % VALU-active), so the window is
       // processed with as few operations as the arithmetic allows: only the arg-max position carries gradient, hence

@@ -50,8 +50,11 @@ struct DwsParams {
   const float* pro_bn; const unsigned char* keep; float rate;
 };
 
+#ifndef CRNN_DWS_NT
+#define CRNN_DWS_NT 1       // round 5: the input map is not read again before the backward pass -> nontemporal LDS-DMA (cache policy only; see conv.hip)
+#endif
 __device__ __forceinline__ void glds16(const void* g, void* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, (CRNN_DWS_EXP & 16) ? 2 : 0);
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, (CRNN_DWS_NT != 0 || (CRNN_DWS_EXP & 16) != 0) ? 2 : 0);
 }
 __device__ __forceinline__ void widen8(const u32x4& u, float (&f)[8]) {
   f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);

@@ -61,8 +61,15 @@ constexpr int kStage = 128 * 128;           // 128 pixel rows x 64 k x 2 B
 constexpr int kR = 6;                       // ring stages
 constexpr int kOut = 128 * 256;             // one staging tile: 128 pixels x 128 channels x 2 B
 
+#ifndef CRNN_WRESF_NT
+#define CRNN_WRESF_NT 1    // round 5: the training forward reads d with nontemporal loads (not read again before the backward pass; cache policy only)
+#endif
+#ifndef CRNN_WRES_NT
+#define CRNN_WRES_NT 0     // experiment (round 5): 1 = the data-gradient form (BNS) reads dq with nontemporal LDS-DMA (its last use in the step)
+#endif
+template <bool NT = false>
 __device__ __forceinline__ void glds16(const void* g, void* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, NT ? 2 : 0);
 }
 
 // The MFMA role shared by the kernels below: wave `wave` (0..3) of a workgroup keeps rows n0 .. n0+31 of W [N][K] as A-operand
@@ -379,7 +386,7 @@ __global__ __launch_bounds__(384 + 64 * NLW) void gemm_wres_kernel(WresParams p)
         int row = r0 + 8 * jrow + rsub;
         row = row < p.M ? row : p.M - 1;
         const int c = pos ^ ((4 * jrow + (lane >> 4)) & 7);
-        if (!WRES_EXP(p, 1)) glds16(p.X + row * ldk + kc * 64 + c * 8, dst + jrow * 1024);
+        if (!WRES_EXP(p, 1)) glds16<(CRNN_WRES_NT && BNS)>(p.X + row * ldk + kc * 64 + c * 8, dst + jrow * 1024);
       }
     };
 #pragma unroll
@@ -487,7 +494,10 @@ __global__ __launch_bounds__(512) void gemm_wres_fwd_kernel(WresFwdParams p) {
     const int it = lin / KCH, kc = lin % KCH;
     const bf16_t* src = p.X + ((long)(first + it * step) * PX + 8 * PB * w + r8) * ldk + kc * 64 + c * 8;
 #pragma unroll
-    for (int u = 0; u < CPL; ++u) buf[u] = *reinterpret_cast<const u32x4*>(src + (long)(8 * u) * ldk);
+    for (int u = 0; u < CPL; ++u) {
+      if (CRNN_WRESF_NT) buf[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + (long)(8 * u) * ldk));
+      else buf[u] = *reinterpret_cast<const u32x4*>(src + (long)(8 * u) * ldk);
+    }
   };
   // (stages past the end are written too -- transformed junk from the clamped loads into a slot whose stage has been consumed:
   // keeping the steady-state loop free of branches is what lets the wait-count insertion count the outstanding loads exactly)
