@@ -57,7 +57,8 @@ for step in "$@"; do
     ab)   # ab:lib1,lib2:bench args -- whole-library A/B (scripts/gpu_ab_libs.sh; "product" = the library as built, others scripts/_trace/libcrnn_<name>.so)
       l=${rest%%:*}; a=${rest#*:}; [ "$a" = "$rest" ] && a=""
       n=$(echo "$a" | tr -c 'a-zA-Z0-9' '_' | cut -c1-30)
-      BENCH_ARGS="--no-roofline --no-parity $(echo $a | tr ':' ' ')" bash scripts/gpu_ab_libs.sh $(echo $l | tr ',' ' ') > $OUT/${TAG}_ab_$n.txt 2>&1
+      RF="--no-roofline"; case "$a" in *roofline*) RF=""; a=$(echo "$a" | sed 's/:*roofline//');; esac      # "roofline" among the args: keep the roofline objects (slower)
+      BENCH_ARGS="$RF --no-parity $(echo $a | tr ':' ' ')" bash scripts/gpu_ab_libs.sh $(echo $l | tr ',' ' ') > $OUT/${TAG}_ab_$n.txt 2>&1
       echo "ab[$rest]: $(tr '\n' ' ' < $OUT/${TAG}_ab_$n.txt)" >> $SUM ;;
     *) echo "unknown step $step" >> $SUM ;;
   esac
