@@ -7,6 +7,7 @@
 #   dws | dbs | probe        depthwise forward / backward micro-benchmarks (product library + scripts/_trace variants), access-pattern probe
 #   prof:name[:args]         rocprofv3 --kernel-trace --stats of bench.py (short run) -> step timeline + kernel stats
 #   pmc:name:COUNTERS[:args] rocprofv3 --pmc pass (counters comma separated, no trace domains beside --kernel-trace) of bench.py
+#   pmcdw                    FETCH_SIZE / WRITE_SIZE passes over scripts/dw_bench.py --bf16 (cold depthwise forward; fold with scripts/pmc_summary.py)
 #   py:script[:args]         python scripts/<script> args
 #   ab:libs:args             bench.py headline with each of the comma-separated libraries (product | scripts/_trace/libcrnn_<name>.so)
 TAG=$1; shift
@@ -54,6 +55,13 @@ for step in "$@"; do
         timeout 900 rocprofv3 --pmc $(echo $c | tr ',' ' ') --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$n -o pmc -- python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary --no-parity --no-roofline $(echo $a | tr ':' ' ') > $OUT/${TAG}_pmc_${n}.log 2>&1 )
       echo "pmc[$rest] exit $?" >> $SUM
       find $OUT/${TAG}_pmc_$n -name "*kernel_trace.csv" -delete ;;
+    pmcdw)   # HBM bytes per launch of the depthwise forward in the cold micro-benchmark (scripts/dw_bench.py --bf16): FETCH_SIZE and WRITE_SIZE passes -> scripts/pmc_summary.py TAG rNN
+      for c in FETCH_SIZE WRITE_SIZE; do
+        ( cd /tmp && export TMPDIR=/tmp && rm -rf $OUT/${TAG}_pmc_bf16_$c &&
+          timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_bf16_$c -o dw -- python $ROOT/scripts/dw_bench.py --bf16 > $OUT/${TAG}_pmc_bf16_$c.log 2>&1 )
+        echo "pmcdw $c exit $?" >> $SUM
+        find $OUT/${TAG}_pmc_bf16_$c -name "*kernel_trace.csv" -delete
+      done ;;
     ab)   # ab:lib1,lib2:bench args -- whole-library A/B (scripts/gpu_ab_libs.sh; "product" = the library as built, others scripts/_trace/libcrnn_<name>.so)
       l=${rest%%:*}; a=${rest#*:}; [ "$a" = "$rest" ] && a=""
       n=$(echo "$a" | tr -c 'a-zA-Z0-9' '_' | cut -c1-30)
