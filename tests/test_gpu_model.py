@@ -362,8 +362,33 @@ def test_odd_shape_model_wide_image_small_alphabet():
     assert torch.equal(l1, l2) and torch.equal(g1, eng.grads) and torch.isfinite(g1).all()
 
 
+def test_width64_model_matches_the_oracle_on_the_row_stream_kernels():
+    """Image width 64 (maps 44 x 68 -> 22 x 34 -> 22 x 17; round 5: its depthwise stages run the row-stream kernels -- step rows of 544 columns, bf16 / fp32 rows
+    cut into channel ranges from block 3 on): the parity-mode train step against the oracle like every other shape, and the throughput mode close to it."""
+    res = run_case(B=3, imgh=40, imgw=64, u=128, tds=32, max_len=6, stn=True, dropout=True)
+    check_case(res, "width-64")
+    cfg, eng32, p, bn, (x, lab, il, ll), yd = res[0], res[1], res[2], res[3], res[4], res[5]
+    h, w, cin = 44, 68, 1
+    for i, (co, ph, pw) in enumerate(((64, 1, 1), (128, 1, 1), (256, 2, 2), (256, 1, 1), (512, 1, 2), (512, 1, 1), (512, 1, 1)), 1):
+        if i >= 2:
+            for dt in (0, 1):
+                assert eng32.lib.crnn_dwconv_fwd_stream_supported_ex(3, h, w, cin, dt) == 0 and eng32.lib.crnn_dwconv_bwd_stream_supported_ex(3, h, w, cin, dt) == 0, (i, h, w, cin, dt)
+        h, w, cin = h // ph, w // pw, co
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        Engine._warned_shapes.discard((40, 64))
+        eng = Engine(3, 40, 64, 38, 6, 32, 128, stn=True, dropout=True, precision="bf16s")
+    eng.set_params(p, bn)
+    y16 = eng.forward(x.astype(np.float32), train=True, seed=3).cpu().numpy()
+    assert np.abs(y16 - yd).max() < 5e-2
+    l1 = eng.backward(lab, il, ll, seed=3).clone(); g1 = eng.grads.clone()
+    eng.forward(x.astype(np.float32), train=True, seed=3); l2 = eng.backward(lab, il, ll, seed=3)
+    assert torch.equal(l1, l2) and torch.equal(g1, eng.grads) and torch.isfinite(g1).all()
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16s"])
-@pytest.mark.parametrize("shape", [(5, 60, 48, 20, 10, 64, 128), (3, 40, 32, 38, 6, 32, 64), (4, 100, 32, 38, 23, 128, 256)])
+@pytest.mark.parametrize("shape", [(5, 60, 48, 20, 10, 64, 128), (3, 40, 32, 38, 6, 32, 64), (4, 100, 32, 38, 23, 128, 256), (3, 40, 64, 38, 6, 32, 128)])
 def test_step_does_not_depend_on_workspace_contents(precision, shape):
     """Every workspace region a kernel reads must have been written by this step: a train step on a NaN-filled workspace
     gives bit-identical posteriors, losses and gradients to one on a zero-filled workspace (catches 0 * garbage in tile
