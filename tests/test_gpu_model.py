@@ -683,14 +683,26 @@ def test_bf16s_producer_fused_pointwise_convs_equal_the_two_pass_path(shape):
     worst = ("", 0.0)
     for name, (off, size, _) in lay.items():
         a, b = g0[off:off + size].double(), g1[off:off + size].double()
-        e = float((a - b).norm() / (a.norm() + 1e-30))
+        scale = float(a.norm())
+        if "_bn" in name:
+            # d(gamma) and d(beta) of one BatchNorm layer are sums over the same B*H*W terms: a sum that cancels to a small value (block 1 has ONE channel: its
+            # d(beta) is a single cancelling number) is judged against the larger of the pair, as check_case does, not against itself
+            o2, s2, _ = lay[name[:-1] + ("b" if name.endswith("g") else "g")]
+            scale = max(scale, float(g0[o2:o2 + s2].double().norm()))
+        e = float((a - b).norm() / (scale + 1e-30))
+        if size < 4:
+            continue   # block 1's one-channel BatchNorm: d(gamma) and d(beta) are single sums of B*H*W terms that BOTH cancel (measured 1.57 relative: a
+            #            scalar judged against itself); they count in the whole-gradient figure below
         if e > worst[1]: worst = (name, e)
     glob = float((g0.double() - g1.double()).norm() / g0.double().norm())
     print("default vs tile schedule: max |dy| %.3g, max rel dloss %.3g, gradient rel L2 %.3g, worst tensor %s %.3g" % (dy, dl, glob, worst[0], worst[1]))
-    # measured: |dy| 5e-4, dloss 3.5e-4, whole gradient 7e-2, worst single tensor 0.14 (stn_c1_b, a cancelling bias sum at the far end
-    # of the backward chain): statistics that differ in the last fp32 bits re-round a few bf16 activations, and this random-weight
-    # 4..5-sample net amplifies that like it amplifies the bf16 storage itself (bf16s against the fp64 oracle: ~5e-2, test above)
-    assert dy < 5e-3 and dl < 2e-3 and glob < 0.3 and worst[1] < 2.0, (dy, dl, glob, worst)
+    # measured (round 5, both shapes): |dy| 6.5e-4 .. 7.3e-4, dloss 3.3e-4 .. 4.5e-4, whole gradient 0.18 .. 0.22, worst single tensor 0.20 (stn_d2_w) / 0.67 (b1_pw), at the far
+    # end of the backward chain, once a BatchNorm layer's cancelling d(beta) is judged against its d(gamma) and block 1's one-channel BatchNorm
+    # (two cancelling scalars, 1.57 relative) is left to the whole-gradient figure: statistics that differ in the last fp32 bits re-round a few bf16 activations, and this random-weight 4..5-sample net amplifies that like it
+    # amplifies the bf16 storage itself (bf16s against the fp64 oracle: ~5e-2, test above).  An uncorrelated or sign-flipped tensor would read >= 1.
+    # (the 100x32 shape: worst tensor b1_pw 0.67 -- 64 cancelling sums at the very end of the chain, cosine 0.75; an uncorrelated tensor reads 1.41, a
+    # sign-flipped one 2.0: the bound sits between)
+    assert dy < 5e-3 and dl < 2e-3 and glob < 0.3 and worst[1] < 1.0, (dy, dl, glob, worst)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16s"])
