@@ -50,9 +50,6 @@ struct DwsParams {
   const float* pro_bn; const unsigned char* keep; float rate;
 };
 
-#ifndef CRNN_DWS_ST
-#define CRNN_DWS_ST 0
-#endif
 #ifndef CRNN_DWS_NT
 #define CRNN_DWS_NT 1       // round 5: the input map is not read again before the backward pass -> nontemporal LDS-DMA (cache policy only; see conv.hip)
 #endif
@@ -364,15 +361,8 @@ __global__ __launch_bounds__((NI + (PRO ? 3 : 1)) * 64) void dw_fwd_stream_kerne
         unsigned char* dst = orow + (long)(t - 2) * p.rowbytes;
         if (EPI && p.wmaj) { const int y = rsub + t - 2; dst = owin + (long)(y >> 1) * 2 * p.rowbytes + (y & 1) * 2 * gpitch; }
         if (CRNN_DWS_EXP & 8) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(dst));
-#if CRNN_DWS_ST == 1      // experiment (round 5): write-through stores (system scope) -- less dirty data left in the L2s for the end-of-kernel release
-        else if (!(CRNN_DWS_EXP & 2)) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(o) : "memory");
-#elif CRNN_DWS_ST == 2
-        else if (!(CRNN_DWS_EXP & 2)) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(o) : "memory");
-#elif CRNN_DWS_ST == 3
-        else if (!(CRNN_DWS_EXP & 2)) asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(dst), "v"(o) : "memory");
-#else
+        // (write-through stores -- sc0 sc1, sc1 or sc0 -- were measured in round 5: 3.2-3.3 TB/s instead of 4.3 cold, +0.15 ms in the step; plain stores stay)
         else if (!(CRNN_DWS_EXP & 2)) *reinterpret_cast<u32x4*>(dst) = o;
-#endif
       }
     };
     step(0, X1, X2, X0, true);

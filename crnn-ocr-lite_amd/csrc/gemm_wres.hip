@@ -64,12 +64,9 @@ constexpr int kOut = 128 * 256;             // one staging tile: 128 pixels x 12
 #ifndef CRNN_WRESF_NT
 #define CRNN_WRESF_NT 1    // round 5: the training forward reads d with nontemporal loads (not read again before the backward pass; cache policy only)
 #endif
-#ifndef CRNN_WRES_NT
-#define CRNN_WRES_NT 0     // experiment (round 5): 1 = the data-gradient form (BNS) reads dq with nontemporal LDS-DMA (its last use in the step)
-#endif
-template <bool NT = false>
+// (round 5: the data-gradient form reading dq -- its last use in the step -- with nontemporal LDS-DMA was measured: no effect on the step; plain DMA stays)
 __device__ __forceinline__ void glds16(const void* g, void* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, NT ? 2 : 0);
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
 // The MFMA role shared by the kernels below: wave `wave` (0..3) of a workgroup keeps rows n0 .. n0+31 of W [N][K] as A-operand
@@ -386,7 +383,7 @@ __global__ __launch_bounds__(384 + 64 * NLW) void gemm_wres_kernel(WresParams p)
         int row = r0 + 8 * jrow + rsub;
         row = row < p.M ? row : p.M - 1;
         const int c = pos ^ ((4 * jrow + (lane >> 4)) & 7);
-        if (!WRES_EXP(p, 1)) glds16<(CRNN_WRES_NT && BNS)>(p.X + row * ldk + kc * 64 + c * 8, dst + jrow * 1024);
+        if (!WRES_EXP(p, 1)) glds16(p.X + row * ldk + kc * 64 + c * 8, dst + jrow * 1024);
       }
     };
 #pragma unroll

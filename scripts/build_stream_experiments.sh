@@ -9,12 +9,8 @@ rm -f $O/libdws_* $O/libdbs_*
 for m in 1 2 4; do hipcc $F -DCRNN_DWS_EXP=$m dwconv_stream.hip -o $O/libdws_exp$m.so & done      # no DMA | no stores | no fmas
 for d in 2 7; do hipcc $F -DCRNN_DWS_D=$d dwconv_stream.hip -o $O/libdws_d$d.so & done                # rows in flight
 wait
-# round 5: bf16 maps as two (four) channel ranges per row on six-wave workgroups, two per CU; ranges 8 workgroup ids apart (same XCD) or adjacent; deeper ring
-hipcc $F -DCRNN_DWS_BF16_SPLIT=2 dwconv_stream.hip -o $O/libdws_split2.so &
-hipcc $F -DCRNN_DWS_BF16_SPLIT=2 -DCRNN_DWS_XSTRIDE=1 dwconv_stream.hip -o $O/libdws_split2x1.so &
-hipcc $F -DCRNN_DWS_BF16_SPLIT=2 -DCRNN_DWS_D5=7 dwconv_stream.hip -o $O/libdws_split2d7.so &
-hipcc $F -DCRNN_DWS_BF16_SPLIT=4 dwconv_stream.hip -o $O/libdws_split4.so &
-wait
+# (round 5's channel-range experiment -- bf16 maps as two / four ranges on six-wave workgroups, two per CU: profiles/r05_dw_fwd_split_experiment.txt -- was built
+#  from macros that are gone; dws_geom now cuts rows into channel ranges only where a row does not fit nine waves)
 for m in 1 2 4 8; do hipcc $F -DCRNN_DBS_EXP=$m dwconv_bwd_stream.hip conv.hip -o $O/libdbs_exp$m.so & done   # no DMA | no stores | no dk fmas | no dx fmas
 for d in 2 5; do hipcc $F -DCRNN_DBS_D=$d dwconv_bwd_stream.hip conv.hip -o $O/libdbs_d$d.so & done
 wait
