@@ -5,6 +5,9 @@
 // wavefront shuffles for the s-1 / s-2 neighbours, log-space fp32 throughout.
 #include "common.h"
 
+#ifndef CRNN_CTC_EXP
+#define CRNN_CTC_EXP 0      // timing experiments (scripts/ctc_bench.py): 1 = stop after the log-softmax phase, 2 = after the recursions, 3 = before the log-softmax
+#endif
 #define CTC_EPS 1e-7f
 #define NEG_INF (-INFINITY)
 
@@ -13,6 +16,13 @@ __device__ __forceinline__ float lse2(float a, float b) {
   if (b == NEG_INF) return a;
   float m = fmaxf(a, b);
   return m + logf(expf(a - m) + expf(b - m));
+}
+// log(e^a + e^b + e^c) in one go, branch-free (absent terms are -inf: e^-inf = 0): three exponentials and one logarithm on the recursions' dependent chain
+// where two nested lse2 took four and two
+__device__ __forceinline__ float lse3(float a, float b, float c) {
+  const float m = fmaxf(a, fmaxf(b, c));
+  const float mm = (m == NEG_INF) ? 0.f : m;                  // (all three absent: the sum below is 0 and its logarithm -inf)
+  return mm + logf(expf(a - mm) + expf(b - mm) + expf(c - mm));
 }
 
 // ---- row softmax over C (<= 64) classes: one wave per row -------------------------------------------
@@ -37,13 +47,17 @@ extern "C" int crnn_softmax_rows(const float* z, float* p, long rows, int C, hip
 // y [B][T][C] softmax (batch-major), labels [B][Lmax] int32, lengths int32.
 // loss[b] = -log p(label | y[:, skip:skip+Tb]);  dlogits [T][B][C] TIME-major, = grad_scale * d loss_b / d logits
 // (through log(y+eps), TF's internal re-softmax, and the model's softmax); rows outside [skip, skip+Tb) are 0.
-// One workgroup of 4 wavefronts per sample; the extended label (S = 2L+1 <= 64 states) lives one state per lane:
-//   phase 1  all waves : posteriors -> LDS (coalesced), log-softmax of log(y+eps) (one time step per thread)
+// One workgroup of CTC_WAVES wavefronts per sample; the extended label (S = 2L+1 <= 64 states) lives one state per lane:
+//   phase 1  all waves : posteriors -> LDS (coalesced), log-softmax of log(y+eps) (a time step per wave, a class per lane)
 //   phase 2  wave 0    : alpha recursion (t ascending)   ||   wave 1 : beta recursion (t descending)  -> LDS
 //   phase 3  all waves : time steps dealt round-robin to the waves: w_s = exp(alpha+beta-lsm-ll) per state lane, then
-//                        class lane k adds the w_s of its states (bit mask, ascending s) and chains to the logits
+//                        class lane k adds the w_s of its states (bit mask, ascending s; the blank class by a wave reduction) and chains to the logits
+// Round 5 (scripts/ctc_bench.py, phase-ablation builds): 61 -> 28 us per launch at batch 256 -- the gradient phase was 30 us of it (the blank lane walking
+// its 24-state mask through LDS with the wave waiting, two workgroup barriers per time step), the log-softmax phase ran on 50 lanes of 256.
 // LDS: lsm [Tb][C], alpha [Tb][64], beta [Tb][64], ys [Tb][C], ab [4][64].
-#define CTC_WAVES 4
+#ifndef CTC_WAVES
+#define CTC_WAVES 16     // round 5: 4 -> 16 (phases 1 and 3 deal the time steps over the waves: 41 -> 28 us at batch 256; 8 waves: 31.5)
+#endif
 __global__ __launch_bounds__(64 * CTC_WAVES) void ctc_loss_grad_kernel(const float* __restrict__ y, const int* __restrict__ labels,
                                                                        const int* __restrict__ input_len, const int* __restrict__ label_len,
                                                                        float* __restrict__ loss, float* __restrict__ dlogits, int B, int T,
@@ -74,16 +88,22 @@ __global__ __launch_bounds__(64 * CTC_WAVES) void ctc_loss_grad_kernel(const flo
     return;
   }
   __syncthreads();
-  // phase 1: log-softmax of z = log(y + eps), one time step per thread
-  for (int t = tid; t < Tb; t += 64 * CTC_WAVES) {
-    float m = NEG_INF;
-    for (int k = 0; k < C; ++k) m = fmaxf(m, logf(ys[t * C + k] + CTC_EPS));
-    float sacc = 0.f;
-    for (int k = 0; k < C; ++k) sacc += expf(logf(ys[t * C + k] + CTC_EPS) - m);
-    float lz = m + logf(sacc);
-    for (int k = 0; k < C; ++k) lsm[t * C + k] = logf(ys[t * C + k] + CTC_EPS) - lz;
+#if CRNN_CTC_EXP == 3
+  return;
+#endif
+  // phase 1: log-softmax of z = log(y + eps): a time step per wave, a class per lane (round 5: was one time step per THREAD -- 50 busy lanes of 256, each
+  // evaluating 3 C logarithms and C exponentials in sequence: a fifth of the kernel)
+  for (int t = wave; t < Tb; t += CTC_WAVES) {
+    const float z = lane < C ? logf(ys[t * C + lane] + CTC_EPS) : NEG_INF;
+    const float m = wave_max(z);
+    const float e = lane < C ? expf(z - m) : 0.f;
+    const float lz = m + logf(wave_sum(e));
+    if (lane < C) lsm[t * C + lane] = z - lz;
   }
   __syncthreads();
+#if CRNN_CTC_EXP == 1
+  return;
+#endif
   // extended label of this lane (every wave holds its own copy)
   const int s = lane;
   int ext = blank;
@@ -97,11 +117,10 @@ __global__ __launch_bounds__(64 * CTC_WAVES) void ctc_loss_grad_kernel(const flo
     else if (s == 1 && S > 1) a = lsm[ext];
     alpha[s] = a;
     for (int t = 1; t < Tb; ++t) {
-      float a1 = __shfl_up(a, 1, 64), a2 = __shfl_up(a, 2, 64);
-      float v = a;
-      if (s >= 1) v = lse2(v, a1);
-      if (can_skip) v = lse2(v, a2);
-      a = (s < S && v != NEG_INF) ? v + lsm[t * C + ext] : NEG_INF;
+      const float em = lsm[t * C + ext];                        // (independent of the chain: issued ahead of it)
+      const float a1 = __shfl_up(a, 1, 64), a2 = __shfl_up(a, 2, 64);
+      const float v = lse3(a, s >= 1 ? a1 : NEG_INF, can_skip ? a2 : NEG_INF);
+      a = (s < S && v != NEG_INF) ? v + em : NEG_INF;
       alpha[t * 64 + s] = a;
     }
     float aL = __shfl(a, S - 1, 64);
@@ -116,52 +135,55 @@ __global__ __launch_bounds__(64 * CTC_WAVES) void ctc_loss_grad_kernel(const flo
       if (t == Tb - 1) {
         bt = (s == S - 1 || (s == S - 2 && S > 1)) ? lsm[t * C + ext] : NEG_INF;
       } else {
-        float b1 = __shfl_down(bt, 1, 64), b2 = __shfl_down(bt, 2, 64);
-        float v = bt;
-        if (s + 1 < S) v = lse2(v, b1);
-        if (can_skip_b) v = lse2(v, b2);
-        bt = (s < S && v != NEG_INF) ? v + lsm[t * C + ext] : NEG_INF;
+        const float em = lsm[t * C + ext];
+        const float b1 = __shfl_down(bt, 1, 64), b2 = __shfl_down(bt, 2, 64);
+        const float v = lse3(bt, s + 1 < S ? b1 : NEG_INF, can_skip_b ? b2 : NEG_INF);
+        bt = (s < S && v != NEG_INF) ? v + em : NEG_INF;
       }
       beta[t * 64 + s] = bt;
     }
   }
   __syncthreads();
+#if CRNN_CTC_EXP == 2
+  return;
+#endif
   const float ll = ll_sh;
   if (tid == 0) loss[b] = -ll;
   if (ll == NEG_INF) {  // no valid path: TF reports inf loss, zero gradient
     for (int t = skip + wave; t < skip + Tb; t += CTC_WAVES) if (lane < C) dlogits[((long)t * B + b) * C + lane] = 0.f;
     return;
   }
-  // which extended-label states carry class `lane` (bit s set <=> ext_s == lane)
+  // which extended-label states carry class `lane` (bit s set <=> ext_s == lane).  The BLANK class sits on every even state (L + 1 of them): its lane takes
+  // the sum from a wave reduction of the state lanes' own registers instead of walking its mask (round 5: 24 dependent LDS reads per time step on one lane
+  // -- with the whole wave waiting for it -- were 30 of the kernel's 55 us; phase timings in scripts/ctc_bench.py)
   unsigned long long occ_mask = 0ull;
   for (int s2 = 0; s2 < S; ++s2) {
     int e2 = __shfl(ext, s2, 64);
-    if (e2 == lane) occ_mask |= 1ull << s2;
+    if (e2 == lane && lane != blank) occ_mask |= 1ull << s2;
   }
-  // phase 3: gradient, time steps round-robin over the waves (each wave has its own ab row)
+  // phase 3: gradient, time steps round-robin over the waves.  A wave works on its own ab row only: the hand-over from the state lanes to the class lanes is
+  // inside the wave (LDS operations of one wave complete in order), no workgroup barrier.
   float* abw = ab + wave * 64;
-  for (int t0 = 0; t0 < Tb; t0 += CTC_WAVES) {
-    const int t = t0 + wave;
-    const bool act = t < Tb;
-    if (act) {
-      float v = (s < S) ? alpha[t * 64 + s] + beta[t * 64 + s] : NEG_INF;   // both contain lsm[t][ext] once
-      abw[s] = (v != NEG_INF) ? expf(v - lsm[t * C + ext] - ll) : 0.f;
+  for (int t = wave; t < Tb; t += CTC_WAVES) {
+    const float v = (s < S) ? alpha[t * 64 + s] + beta[t * 64 + s] : NEG_INF;   // both contain lsm[t][ext] once
+    const float w = (v != NEG_INF) ? expf(v - lsm[t * C + ext] - ll) : 0.f;
+    const float wblank = wave_sum((s < S && ext == blank) ? w : 0.f);
+    abw[s] = w;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    float gyk = 0.f, pk = 0.f;
+    if (lane < C) {
+      const float l = lsm[t * C + lane];
+      float occ = (lane == blank) ? wblank : 0.f;
+      for (unsigned long long m = occ_mask; m; m &= m - 1) occ += abw[__ffsll((long long)m) - 1];
+      const float gz = expf(l) - occ;
+      pk = ys[t * C + lane];
+      gyk = gz / (pk + CTC_EPS);          // d loss / d y_pred[t][k]
     }
-    __syncthreads();
-    if (act) {
-      float gyk = 0.f, pk = 0.f;
-      if (lane < C) {
-        float l = lsm[t * C + lane];
-        float occ = 0.f;
-        for (unsigned long long m = occ_mask; m; m &= m - 1) occ += abw[__ffsll((long long)m) - 1];
-        float gz = expf(l) - occ;
-        pk = ys[t * C + lane];
-        gyk = gz / (pk + CTC_EPS);          // d loss / d y_pred[t][k]
-      }
-      float dot = wave_sum(gyk * pk);
-      if (lane < C) dlogits[((long)(t + skip) * B + b) * C + lane] = grad_scale * pk * (gyk - dot);
-    }
-    __syncthreads();
+    const float dot = wave_sum(gyk * pk);
+    if (lane < C) dlogits[((long)(t + skip) * B + b) * C + lane] = grad_scale * pk * (gyk - dot);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();       // (the class lanes are done with this row before the state lanes overwrite it)
   }
 }
 
