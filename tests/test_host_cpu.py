@@ -224,6 +224,33 @@ def test_weights_resident_gemms_and_row_stream_kernels_have_no_spilled_vector_re
         assert not bad, "%s: instantiations with spilled vector registers: %s" % (src, bad)
 
 
+def test_bench_counter_traffic_lookup_and_contract_fields():
+    """bench.py, host logic only: `pmc_step_traffic` / `pmc_mfma_util` read the committed counter passes (profiles/r05_pmc_step_<mode>.json) for the workload they
+    were collected on -- batch 256, 100x32, LSTM, default flags -- and return None for any other (a `traffic` must never be quoted for a configuration it was
+    not counted on); the contract fields the driver's record keeps (`config.*`) are spelled in the source."""
+    import importlib.util, types
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(native.HEADER), "..", "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    def eng(B=256, imgh=100, imgw=32, gru=0, flags=0, precision="bf16s"):
+        return types.SimpleNamespace(B=B, precision=precision, cfg=types.SimpleNamespace(imgh=imgh, imgw=imgw, gru=gru, flags=flags))
+    tr = bench.pmc_step_traffic(eng(), ["dw_bwd_stream_kernel"])
+    assert tr is not None and tr[1] == 6 and 3.4e9 < tr[0] < 3.7e9          # six launches per step, 3.435 GB algorithmic
+    tr = bench.pmc_step_traffic(eng(), ["bn_act_pool_drop_kernel"])
+    assert tr is not None and tr[1] == 7 and 2.4e9 < tr[0] < 2.6e9
+    nt = bench.pmc_step_traffic(eng(), ["gemm_nt_f32_stream_kernel<2>"], {"gemm_nt_f32_stream_kernel<2>": {638976}})
+    assert nt is not None and nt[1] == 4                                      # the four forward input projections, not the backward launch of the same kernel
+    for other in (eng(B=64), eng(imgh=200), eng(gru=1), eng(flags=1024), eng(imgw=48)):
+        assert bench.pmc_step_traffic(other, ["dw_bwd_stream_kernel"]) is None and bench.pmc_mfma_util(other, ["gemm_wres_fwd_kernel"]) is None
+    mf = bench.pmc_mfma_util(eng(), ["gemm_wres_fwd_kernel", "lstm_fwd_persist_kernel", "no_such_kernel"])
+    assert 0.1 < mf[0] < 0.4 and 0.01 < mf[1] < 0.2 and mf[2] is None
+    fp = bench.pmc_mfma_util(eng(precision="fp32"), ["gemm_x3p_kernel"])
+    assert fp is not None and 0.1 < fp[0] < 0.6
+    src = open(bench.__file__).read()
+    for key in ("parity_within_tolerance_fp32", "parity_within_tolerance_headline", "parity_mode_ms_per_step", "parity_mode_strict_ms_per_step",
+                "bs64_ms_per_step", "bs64_fp32_ms_per_step", "dw_fwd_hbm_frac_cold", "dw_bwd_hbm_frac_cold"):
+        assert 'cf["%s"]' % key in src, key
+
+
 def test_model_surface_weights_roundtrip_without_gpu(tmp_path):
     init_model = U.CRNN(num_classes=38, shape=(100, 32, 1), max_string_len=23, time_dense_size=128, n_units=256)
     model = init_model.get_model()
