@@ -513,6 +513,155 @@ __global__ __launch_bounds__(768) void gemm_nt_f32_stream_kernel(NtsParams p) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Input projections of a Bidirectional recurrent layer, forward (utils.py:77-82: x W + b of both directions, hoisted out of the recurrences):
+//     Yd[M][N] (fp32) = X[M][K] . Wd[N][K]^T + bd[N]      d = forward | backward direction, M = T*B rows, K = 128 | 256, N = 4u (3u)
+// The stripe kernel above runs this as one workgroup per (64-row stripe, 256-column slab) and direction: with K this short a workgroup's life is one load
+// round trip, it re-stages its 64-128 KiB weight slab for 2-4 MFMA k-chunks, and 120 KiB of LDS leave one workgroup per CU -- 28-37 us per launch for
+// 61 MB of traffic (round 5 timeline), four launches per step.  Here BOTH directions are one launch of persistent workgroups: a workgroup owns a column slab
+// of one direction, keeps the slab's weights [256][K] in LDS for its whole life and walks the row stripes blockIdx.x, + gridDim.x, ...; the IO waves stream
+// only the X chunks (fp32 -> bf16) two stages ahead through the ring, the MFMA waves store a finished stripe while the next one's chunks are already landing.
+// Same products in the same order as the stripe kernel (bf16 operands, k ascending, bias added last): bit-identical results.
+namespace {
+struct NtpParams {
+  const float* X; const bf16_t* W[2]; float* Y[2]; const float* bias[2];
+  int M, N, K, lda, ldw, ldy;              // N = gate columns of ONE direction (a multiple of 256)
+};
+__global__ __launch_bounds__(768) void gemm_nt_f32_proj_kernel(NtpParams p) {
+  constexpr int CB = 2, NS = 128 * CB;                         // 256-column slabs
+  constexpr int kX = 64 * 128, kW = NS * 128;                  // bytes of an X stage (64 rows x 64 k bf16), of one 64-k chunk of the weight slab
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // weight slab [kch][NS rows][64 k] | ring of kNtsRing X stages
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kch = p.K / 64;
+  const int slabs = p.N / NS;                                  // per direction
+  const int dir = (int)blockIdx.y / slabs, n0 = ((int)blockIdx.y - dir * slabs) * NS;
+  const int stripes = p.M / 64;
+  const int mine = ((int)blockIdx.x < stripes) ? (stripes - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int total = mine * kch;
+  unsigned char* const ring = smem + kch * kW;
+  if (mine <= 0) return;
+
+  if (wave < 4) {
+    const int half = lane >> 5, l31 = lane & 31, sw = (l31 >> 1) & 7;
+    f32x16 acc[2][CB];
+    float* const Y = p.Y[dir]; const float* const bias = p.bias[dir];
+    int slot = 0, s = 0;
+    for (int it = 0; it < mine; ++it) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[b][cb][e] = 0.f;
+      for (int kc = 0; kc < kch; ++kc, ++s) {
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* Xs = ring + slot * kX + l31 * 128;
+        const unsigned char* Ws = smem + kc * kW + (wave * 32 * CB + l31) * 128;
+        slot = slot + 1 == kNtsRing ? 0 : slot + 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int off = ((2 * ks + half) ^ sw) * 16;
+          bf16x8_t fx[2], fw[CB];
+#pragma unroll
+          for (int b = 0; b < 2; ++b) fx[b] = *reinterpret_cast<const bf16x8_t*>(Xs + b * 32 * 128 + off);
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb) fw[cb] = *reinterpret_cast<const bf16x8_t*>(Ws + cb * 32 * 128 + off);
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) acc[b][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[cb], fx[b], acc[b][cb], 0, 0, 0);
+        }
+      }
+      // the stripe is finished: lane = one row; register group g of a block = columns 8 g + 4 half + 0..3 (the IO waves are already two stages into the next one)
+      const int m0 = ((int)blockIdx.x + it * (int)gridDim.x) * 64;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int col0 = n0 + wave * 32 * CB + 4 * half;
+        float* yrow = Y + (long)(m0 + 32 * b + l31) * p.ldy + col0;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float4 v = make_float4(acc[b][cb][4 * g], acc[b][cb][4 * g + 1], acc[b][cb][4 * g + 2], acc[b][cb][4 * g + 3]);
+            if (bias) { const float4 bv = *reinterpret_cast<const float4*>(bias + col0 + 32 * cb + 8 * g); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+            *reinterpret_cast<float4*>(yrow + 32 * cb + 8 * g) = v;
+          }
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+    return;
+  }
+  // ---------------------------------------------------------------------------- IO waves (8): lane il = 0..511
+  const int il = tid - 256;
+  const int xr = il >> 3, xc = il & 7;                          // piece: row xr (0..63), 8-k piece xc
+  {  // the weight slab, once: NS rows x kch chunks x 8 pieces of 16 bytes, swizzled like a stage
+    const bf16_t* W = p.W[dir];
+    for (int kc = 0; kc < kch; ++kc)
+#pragma unroll
+      for (int u = 0; u < NS / 64; ++u) {
+        const int r = xr + 64 * u;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(W + (long)(n0 + r) * p.ldw + kc * 64 + xc * 8);
+        *reinterpret_cast<u32x4*>(smem + kc * kW + r * 128 + ((xc ^ ((r >> 1) & 7)) * 16)) = v;
+      }
+  }
+  u32x4 rx[kNtsD][2];
+  auto load = [&](int s, u32x4 (&ax)[2]) {
+    s = s < total ? s : total - 1;
+    const int it = s / kch, kc = s - it * kch;
+    const float* a = p.X + (long)(((int)blockIdx.x + it * (int)gridDim.x) * 64 + xr) * p.lda + kc * 64 + xc * 8;
+    ax[0] = *reinterpret_cast<const u32x4*>(a); ax[1] = *reinterpret_cast<const u32x4*>(a + 4);
+  };
+  auto write = [&](int s, const u32x4 (&ax)[2]) {
+    unsigned char* st = ring + (s % kNtsRing) * kX;
+    const u32x4 o = {pack2_bf16(__uint_as_float(ax[0].x), __uint_as_float(ax[0].y)), pack2_bf16(__uint_as_float(ax[0].z), __uint_as_float(ax[0].w)),
+                     pack2_bf16(__uint_as_float(ax[1].x), __uint_as_float(ax[1].y)), pack2_bf16(__uint_as_float(ax[1].z), __uint_as_float(ax[1].w))};
+    *reinterpret_cast<u32x4*>(st + xr * 128 + ((xc ^ ((xr >> 1) & 7)) * 16)) = o;
+  };
+  // barrier s: stage s (and, at s = 0, the weight slab) is written before it; after it the slot of stage s-1 is free; stage s+1 goes into slot
+  // (s+1) % 3, which held stage s-2 -- released at barrier s-1
+  load(0, rx[0]); load(1, rx[1]);
+  write(0, rx[0]); load(2, rx[0]);
+  for (int s = 0; s < total; ++s) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (s + 1 < total) {
+      if ((s + 1) & 1) { write(s + 1, rx[1]); load(s + 3, rx[1]); } else { write(s + 1, rx[0]); load(s + 3, rx[0]); }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+}  // namespace
+
+// Both directions' input projections of a Bidirectional layer in one launch: Yf = X . Wf^T + bf, Yb = X . Wb^T + bb (fp32 X [M][K] row stride lda, bf16
+// W [N][K] row stride ldw, fp32 Y [M][N] row stride ldy; bias may be NULL for both).  Bit-identical to two crnn_gemm_nt_f32_stream_bias calls.
+// Supported (else -3): M % 64 == 0, N % 256 == 0, K = 64 | 128 | 192 | 256 (the weight slab stays in LDS), leading dimensions multiples of 8, 16-byte aligned pointers.
+extern "C" int crnn_rnn_input_proj_supported(int M, int N, int K) {
+  return (M > 0 && M % 64 == 0 && N > 0 && N % 256 == 0 && K >= 64 && K <= 256 && K % 64 == 0 && 2 * (N / 256) <= 65535) ? CRNN_OK : CRNN_ERR_UNSUPPORTED;
+}
+extern "C" int crnn_rnn_input_proj(const float* X, const void* Wf, const void* Wb, const float* bias_f, const float* bias_b, float* Yf, float* Yb, int M, int N,
+                                   int K, int lda, int ldw, int ldy, hipStream_t stream) {
+  if (!X || !Wf || !Wb || !Yf || !Yb || ((bias_f != nullptr) != (bias_b != nullptr))) return CRNN_ERR_ARG;
+  CRNN_TRY(crnn_rnn_input_proj_supported(M, N, K));
+  if (((lda | ldw | ldy) & 7) || lda < K || ldw < K || ldy < N) return CRNN_ERR_UNSUPPORTED;
+  if ((((uintptr_t)X | (uintptr_t)Wf | (uintptr_t)Wb | (uintptr_t)Yf | (uintptr_t)Yb | (uintptr_t)bias_f | (uintptr_t)bias_b) & 15)) return CRNN_ERR_UNSUPPORTED;
+  if ((long)M * (lda > ldy ? lda : ldy) >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;
+  NtpParams p;
+  p.X = X; p.W[0] = (const bf16_t*)Wf; p.W[1] = (const bf16_t*)Wb; p.Y[0] = Yf; p.Y[1] = Yb; p.bias[0] = bias_f; p.bias[1] = bias_b;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldy = ldy;
+  const int slabs2 = 2 * (N / 256);
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+  int groups = cus / slabs2; if (groups < 1) groups = 1;       // one workgroup per CU: (row groups) x (slabs of both directions)
+  if (groups > M / 64) groups = M / 64;
+  const int lds = (K / 64) * 256 * 128 + kNtsRing * 64 * 128;
+  CRNN_LDS_ATTR(gemm_nt_f32_proj_kernel, 4 * 256 * 128 + kNtsRing * 64 * 128);
+  hipLaunchKernelGGL(gemm_nt_f32_proj_kernel, dim3(groups, slabs2), dim3(768), lds, stream, p);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+
 // Y[M][N] (fp32, row stride ldy) = A0[M][K] . W0[N][K]^T (+ A1 . W1^T when A1 != NULL) (+ bias[N]); A fp32 (row stride lda), W bf16 (row stride
 // ldw).  Supported (else -3): M % 64 == 0, N % 128 == 0 (column slabs of 256, or of 128 when N % 256 != 0), K % 64 == 0, leading dimensions
 // multiples of 8, 16-byte aligned pointers.

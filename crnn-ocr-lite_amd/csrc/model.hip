@@ -761,8 +761,18 @@ extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, cons
       return crnn_gemm_nt_f32_stream_bias(xin, c.w("wt" + s), nullptr, nullptr, c.w("xw" + s), c.p("rnn" + s + "_b"), TB, G, din, din, din, G, stream);
     return gemm(c, 0, xin, c.p("rnn" + s + "_w"), c.w("xw" + s), TB, G, din, din, G, G, c.p("rnn" + s + "_b"));
   };
-  CRNN_TRY(xw(c.w("dn1"), d.tds, "1f"));
-  CRNN_TRY(xw(c.w("dn1"), d.tds, "1b"));
+  // both directions of a layer in one launch of persistent workgroups (round 5: crnn_rnn_input_proj; bit-identical to the two stripe launches)
+  auto xw2 = [&](const float* xin, int din, const char* l) -> int {
+    const std::string f = std::string(l) + "f", b = std::string(l) + "b";
+    if (xw_stream && crnn_rnn_input_proj_supported(TB, G, din) == CRNN_OK) {
+      const int rc = crnn_rnn_input_proj(xin, c.w("wt" + f), c.w("wt" + b), c.p("rnn" + f + "_b"), c.p("rnn" + b + "_b"), c.w("xw" + f), c.w("xw" + b), TB, G, din,
+                                         din, din, G, stream);
+      if (rc != CRNN_ERR_UNSUPPORTED) return rc;
+    }
+    CRNN_TRY(xw(xin, din, f.c_str()));
+    return xw(xin, din, b.c_str());
+  };
+  CRNN_TRY(xw2(c.w("dn1"), d.tds, "1"));
   if (cfg->gru && persist)   // "cs" holds r*h_prev for the GRU (cell state for the LSTM)
     CRNN_TRY(crnn_gru_fwd_persist(c.w("xw1f"), c.w("xw1b"), c.w("ut1f"), c.w("ut1b"), c.w("h1f"), c.w("h1b"), u, c.w("gt1f"), c.w("gt1b"),
                                   c.w("cs1f"), c.w("cs1b"), T, B, u, dtu, c.w("rnnx"), xbytes, rnn_uw(cfg), stream));
@@ -776,8 +786,7 @@ extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, cons
     CRNN_TRY(crnn_lstm_fwd_ex(c.w("xw1f"), c.w("xw1b"), c.w("ut1f"), c.w("ut1b"), c.w("h1f"), c.w("h1b"), u, c.w("cs1f"), c.w("cs1b"),
                               c.w("gt1f"), c.w("gt1b"), T, B, u, dtu, stream));
   CRNN_TRY(crnn_add(c.w("h1f"), c.w("h1b"), c.w("r1"), (long)TB * u, stream));  // merge_mode='sum'
-  CRNN_TRY(xw(c.w("r1"), u, "2f"));
-  CRNN_TRY(xw(c.w("r1"), u, "2b"));
+  CRNN_TRY(xw2(c.w("r1"), u, "2"));
   if (cfg->gru && persist)
     CRNN_TRY(crnn_gru_fwd_persist(c.w("xw2f"), c.w("xw2b"), c.w("ut2f"), c.w("ut2b"), c.w("h2"), c.w("h2") + u, 2 * u, c.w("gt2f"), c.w("gt2b"),
                                   c.w("cs2f"), c.w("cs2b"), T, B, u, dtu, c.w("rnnx"), xbytes, rnn_uw(cfg), stream));

@@ -580,6 +580,13 @@ int crnn_gemm_nt_f32_stream(const float* A0, const void* W0, const float* A1, co
  * (+ bias[N]); N % 128 == 0.  The recurrent layers' input projections xw = X W + b from the bf16 W^T copies. */
 int crnn_gemm_nt_f32_stream_bias(const float* A0, const void* W0, const float* A1, const void* W1, float* Y, const float* bias, int M, int N, int K,
                                  int lda, int ldw, int ldy, crnn_stream_t stream);
+/* Both directions' input projections of a Bidirectional recurrent layer in ONE launch (reference utils.py:77-82, x W + b hoisted out of the recurrence;
+ * gemm_wgrad.hip, round 5): Yf = X . Wf^T + bias_f, Yb = X . Wb^T + bias_b with fp32 X [M][K] (row stride lda), bf16 W [N][K] (row stride ldw: the W^T copies the
+ * forward keeps), fp32 Y [M][N] (row stride ldy).  Persistent workgroups keep a 256-column weight slab in LDS and walk the 64-row stripes.  Bit-identical to two
+ * crnn_gemm_nt_f32_stream_bias calls.  _supported: M % 64 == 0, N % 256 == 0, K in {64, 128, 192, 256}; else CRNN_ERR_UNSUPPORTED. */
+int crnn_rnn_input_proj_supported(int M, int N, int K);
+int crnn_rnn_input_proj(const float* X, const void* Wf, const void* Wb, const float* bias_f, const float* bias_b, float* Yf, float* Yb, int M, int N, int K,
+                        int lda, int ldw, int ldy, crnn_stream_t stream);
 int crnn_pwconv_fwd_wres_supported(long M, int N, int K);
 int crnn_pwconv_fwd_wres_rows(long M, int N, int K);
 int crnn_pwconv_bnrelu6_fwd_wres(const void* d, const float* in_bnstate, const void* wT, void* q, long M, int N, int K, float* stat_partials,

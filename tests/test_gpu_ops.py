@@ -1854,6 +1854,34 @@ def test_streaming_input_projection_equals_the_tile_kernel(M, N, K, bias):
     assert L().crnn_gemm_nt_f32_stream_bias(P(Ad), P(WTd), None, None, P(Y3), None, M, 192, K, K, K, 192, S()) == -3
 
 
+@pytest.mark.parametrize("M,N,K,bias", [(13312, 1024, 128, True), (13312, 1024, 256, True), (64 * 7, 768, 256, True), (64, 256, 64, False), (64 * 300, 512, 192, True),
+                                         (64 * 33, 1024, 128, False)])
+def test_both_directions_input_projection_equals_the_two_stripe_launches(M, N, K, bias):
+    """crnn_rnn_input_proj (round 5): x W + b of both directions of a Bidirectional layer in ONE launch of persistent workgroups (256-column weight slab resident in
+    LDS, 64-row stripes walked per workgroup) against two crnn_gemm_nt_f32_stream_bias launches: the same bf16 products in the same order -- bit for bit --, and
+    against the fp64 oracle at the bf16 operands' tolerance; memory around the outputs untouched; shapes outside the rule refused."""
+    rs = np.random.RandomState(M % 97 + N + K)
+    x = rs.normal(size=(M, K)).astype(np.float32)
+    wf, wb = (rs.normal(size=(N, K)) * 0.1).astype(np.float32), (rs.normal(size=(N, K)) * 0.1).astype(np.float32)
+    bf, bb = rs.normal(size=N).astype(np.float32), rs.normal(size=N).astype(np.float32)
+    xd = dev(x); wfd, wbd = _to_bf16_dev(wf), _to_bf16_dev(wb); bfd, bbd = dev(bf), dev(bb)
+    assert L().crnn_rnn_input_proj_supported(M, N, K) == 0
+    y1f, y1b = zeros(M, N), zeros(M, N)
+    ok(L().crnn_gemm_nt_f32_stream_bias(P(xd), P(wfd), None, None, P(y1f), P(bfd) if bias else None, M, N, K, K, K, N, S()))
+    ok(L().crnn_gemm_nt_f32_stream_bias(P(xd), P(wbd), None, None, P(y1b), P(bbd) if bias else None, M, N, K, K, K, N, S()))
+    y2f = torch.full((M * N + 64,), 7.0, device="cuda"); y2b = torch.full((M * N + 64,), 9.0, device="cuda")
+    ok(L().crnn_rnn_input_proj(P(xd), P(wfd), P(wbd), P(bfd) if bias else None, P(bbd) if bias else None, P(y2f), P(y2b), M, N, K, K, K, N, S()))
+    assert torch.equal(y2f[:-64].view(M, N), y1f) and torch.equal(y2b[:-64].view(M, N), y1b)
+    assert bool((y2f[-64:] == 7.0).all()) and bool((y2b[-64:] == 9.0).all())
+    ref = _bf16_round(x) @ _bf16_round(wf).T + (bf if bias else 0.0)
+    assert_close(host(y2f[:-64]).reshape(M, N), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max(), what="forward direction vs oracle on the bf16-rounded operands")
+    y3f = torch.zeros_like(y2f); y3b = torch.zeros_like(y2b)
+    ok(L().crnn_rnn_input_proj(P(xd), P(wfd), P(wbd), P(bfd) if bias else None, P(bbd) if bias else None, P(y3f), P(y3b), M, N, K, K, K, N, S()))
+    assert torch.equal(y3f[:-64], y2f[:-64]) and torch.equal(y3b[:-64], y2b[:-64]), "repeat launches differ"
+    assert L().crnn_rnn_input_proj_supported(M, N, 320) == -3 and L().crnn_rnn_input_proj_supported(M, 384, K) == -3 and L().crnn_rnn_input_proj_supported(M + 1, N, K) == -3
+    assert L().crnn_rnn_input_proj(P(xd), P(wfd), P(wbd), P(bfd), None, P(y3f), P(y3b), M, N, K, K, K, N, S()) == -2      # one bias without the other
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_streaming_pointwise_kernels_on_random_shapes(seed):
     """The three streaming pointwise-conv kernels on drawn shapes (stripe counts around the grid size, 1..8 channel slices, every K,
