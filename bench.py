@@ -358,10 +358,15 @@ def pointwise_gemm_roofline(eng, iters=5):
     scratch = eng.ws_tensor("gemm_scratch"); parts = eng.ws_tensor("partials")
     cfgs.append((eng.ws_tensor("x7"), W("dense1_w"), eng.ws_tensor("gA"), TB, eng.cfg.tds, feat, sdt, 0, 0))
     u, G = eng.cfg.units, (3 if eng.cfg.gru else 4) * eng.cfg.units
-    for n, src, k in (("rnn1f_w", "dn1", eng.cfg.tds), ("rnn1b_w", "dn1", eng.cfg.tds), ("rnn2f_w", "r1", u), ("rnn2b_w", "r1", u)):
-        # bf16 modes: the step's streaming kernel on the bf16 W^T copy the forward keeps (model.hip xw_stream), else the tile GEMM
-        xs = bf and u % 128 == 0 and not (eng.cfg.flags & 2) and TB % 64 == 0 and G % 128 == 0 and k % 64 == 0
-        cfgs.append((eng.ws_tensor(src), W(n), eng.ws_tensor("gB"), TB, G, k, 0, 0, ("xw", eng.ws_tensor("wt" + n[3:5])) if xs else 0))
+    for l, src, k in (("1", "dn1", eng.cfg.tds), ("2", "r1", u)):
+        # bf16 modes: the step's own kernel -- both directions of a layer in one launch of persistent workgroups on the bf16 W^T copies the forward keeps
+        # (model.hip xw2 / crnn_rnn_input_proj; round 5) --, else one tile GEMM per direction
+        xs = bf and u % 128 == 0 and not (eng.cfg.flags & 2) and TB % 64 == 0 and G % 128 == 0 and k % 64 == 0 and lib.crnn_rnn_input_proj_supported(TB, G, k) == 0
+        if xs:
+            cfgs.append((eng.ws_tensor(src), None, eng.ws_tensor("gB"), TB, 2 * G, k, 0, 0, ("xw2", eng.ws_tensor("wt" + l + "f"), eng.ws_tensor("wt" + l + "b"))))
+        else:
+            for dr in ("f", "b"):
+                cfgs.append((eng.ws_tensor(src), W("rnn" + l + dr + "_w"), eng.ws_tensor("gB"), TB, G, k, 0, 0, 0))
     flops = sum(2.0 * M * N * K for _, _, _, M, N, K, _, _, _ in cfgs)
     # algorithmic HBM bytes of the same launches: A read + C written once, in their storage types (weights negligible)
     hbm_bytes = sum(M * K * (2.0 if dta else 4.0) + M * N * (2.0 if dtc else 4.0) for _, _, _, M, N, K, dta, dtc, _ in cfgs)
@@ -370,8 +375,8 @@ def pointwise_gemm_roofline(eng, iters=5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for A, Bm, C, M, N, K, dta, dtc, wt in cfgs:
-            if isinstance(wt, tuple) and wt[0] == "xw":
-                lib.crnn_gemm_nt_f32_stream_bias(_ptr(A), _ptr(wt[1]), None, None, _ptr(C), None, M, N, K, K, K, N, _stream())
+            if isinstance(wt, tuple) and wt[0] == "xw2":      # (both outputs into the scratch tensor: G columns each, the second half behind the first's rows)
+                lib.crnn_rnn_input_proj(_ptr(A), _ptr(wt[1]), _ptr(wt[2]), None, None, _ptr(C), ctypes.c_void_p(C.data_ptr() + M * (N // 2) * 4), M, N // 2, K, K, K, N // 2, _stream())
             elif isinstance(wt, tuple):
                 if not (eng.cfg.flags & 2) and lib.crnn_pwconv_fwd_wres_supported(M, N, K) == 0:
                     lib.crnn_pwconv_bnrelu6_fwd_wres(_ptr(A), _ptr(wt[1]), _ptr(Bm), _ptr(C), M, N, K, _ptr(parts), _stream())
@@ -389,12 +394,12 @@ def pointwise_gemm_roofline(eng, iters=5):
     t = float(np.median(times))
     ach = flops / t / 1e12
     kname = ("gemm_wres_fwd_kernel (pointwise 1x1 convs fwd incl. BN+ReLU6 prologue and statistics) + gemm_bf16_kernel (dense1) + "
-             "gemm_nt_f32_stream_kernel (RNN input projections)"
+             "gemm_nt_f32_proj_kernel (RNN input projections, both directions of a layer per launch)"
              if any(isinstance(c[8], tuple) and c[8][0] == "pw" for c in cfgs) else
              "gemm_%s_kernel<128,false,true> (pointwise 1x1 convs fwd + dense1 + RNN input GEMMs)" % ("bf16" if bf else "f32"))
     # memory-side bytes of the same launches in the step (bf16s: the six weights-resident pointwise forwards, dense1's tile GEMM, the four forward input projections)
-    tr = pmc_step_traffic(eng, ["gemm_wres_fwd_kernel", "gemm_bf16_kernel<128, false, true, true, true, false, true, false>", "gemm_nt_f32_stream_kernel<2>"],
-                          {"gemm_nt_f32_stream_kernel<2>": {638976}}) if eng.precision == "bf16s" else None
+    tr = pmc_step_traffic(eng, ["gemm_wres_fwd_kernel", "gemm_bf16_kernel<128, false, true, true, true, false, true, false>", "gemm_nt_f32_proj_kernel"]) \
+        if eng.precision == "bf16s" else None
     return {"bound": "mfma", "kernel": kname,
             "traffic": None if tr is None or tr[1] != len(cfgs) else tr[0], "traffic_note": None if tr is None else PMC_NOTE % (eng.precision, eng.precision),
             "mfma_busy_counter": (lambda m: None if m is None else {"gemm_wres_fwd_kernel": m[0], "gemm_wres_kernel (data gradient)": m[1], "pw_wgrad_stream_kernel": m[2],

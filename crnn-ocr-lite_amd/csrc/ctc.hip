@@ -43,6 +43,35 @@ extern "C" int crnn_softmax_rows(const float* z, float* p, long rows, int C, hip
   return CRNN_OK;
 }
 
+// dense2's epilogue in one pass (round 5): z [rows][ldz] are the raw products of the streaming GEMM over a padded weight matrix (columns >= C are never read);
+// logits = z + bias go out in permuted row order (out row = (m % P) * (rows / P) + m / P: time-major rows back to batch-major, as the tile GEMM's epilogue
+// does) together with their softmax p1 (workspace) and p2 (the caller's y_pred, may be NULL) -- the softmax and copy launches of the unfused path.
+__global__ __launch_bounds__(256) void softmax_rows_perm_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ bias, float* __restrict__ logits,
+                                                                float* __restrict__ p1, float* __restrict__ p2, long rows, int C, int P) {
+  const long m = blockIdx.x * 4L + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (m >= rows) return;
+  const long orow = P ? (m % P) * (rows / P) + m / P : m;
+  const float v = lane < C ? z[m * ldz + lane] + (bias ? bias[lane] : 0.f) : NEG_INF;
+  const float mx = wave_max(v);
+  const float e = lane < C ? expf(v - mx) : 0.f;
+  const float sum = wave_sum(e);
+  if (lane < C) {
+    logits[orow * C + lane] = v;
+    const float pr = e / sum;
+    p1[orow * C + lane] = pr;
+    if (p2) p2[orow * C + lane] = pr;
+  }
+}
+extern "C" int crnn_softmax_rows_perm(const float* z, int ldz, const float* bias, float* logits, float* p1, float* p2, long rows, int C, int permP,
+                                      hipStream_t stream) {
+  if (!z || !logits || !p1 || rows <= 0 || C < 1 || ldz < C || permP < 0 || (permP && rows % permP)) return CRNN_ERR_ARG;
+  if (C > 64) return CRNN_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(softmax_rows_perm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, z, ldz, bias, logits, p1, p2, rows, C, permP);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+
 // ---- CTC loss + gradient w.r.t. the dense2 logits -------------------------------------------------------
 // y [B][T][C] softmax (batch-major), labels [B][Lmax] int32, lengths int32.
 // loss[b] = -log p(label | y[:, skip:skip+Tb]);  dlogits [T][B][C] TIME-major, = grad_scale * d loss_b / d logits

@@ -95,6 +95,11 @@ struct Plan {
 
 long lmax(long a, long b) { return a > b ? a : b; }
 
+// dense2 (+ softmax) on the streaming GEMM over a 128-row padded bf16 W^T (forward, round 5): bf16 modes, whole 64-row stripes, 2u a multiple of 64, at most
+// 64 classes (the softmax kernels' limit); CRNN_FLAG_GEMM_TILE_KERNELS keeps the tile GEMM
+static bool dense2_stream(const crnn_config* cfg, const Dims& d) {
+  return cfg->mfma_bf16 && !(cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS) && ((long)d.T * d.B) % 64 == 0 && (2 * d.u) % 64 == 0 && d.C <= 64;
+}
 // The BatchNorm-2 fusions into the depthwise row-stream kernels (fuse_bn2_dw below): opt-in flags for bf16 tensors (the re-forming is VALU work the bf16
 // kernels have no issue slots for: measured neutral), the default schedule for fp32 tensors since round 4 (half the elements per byte: -0.6 ms of 14.8 per
 // step), CRNN_FLAG_NO_BN2_DW_FUSION switches them off.
@@ -207,7 +212,10 @@ Plan make_plan(const crnn_config* c) {
       n = lmax(n, (long)crnn_dwconv_bwd_stream_rows_ex(d.B, d.bh[i + 1], d.bw[i + 1], d.bc[i], c->mfma_bf16 == 2 ? CRNN_BF16 : CRNN_F32) * 2L * d.bc[i]);
     if ((c->mfma_bf16 == 2 || bn2_stats_fusion_on(c)) && n) P.add("bn2parts", n); }
   { long pw = 0; for (int i = 2; i <= 7; ++i) pw += (long)d.bc[i - 1] * d.bc[i];
-    P.add("pwT", pw, CRNN_BF16); }   // bf16 W^T copies of the pointwise-conv weights (bf16 modes)
+    // bf16 W^T copies of the pointwise-conv weights (bf16 modes) + dense2's W^T as 128 rows of 2u (rows >= num_classes are never written: the streaming
+    // GEMM's columns for them are never read -- dense2_stream below)
+    P.add("pwT", pw + 128L * 2 * d.u, CRNN_BF16); }
+  if (c->mfma_bf16) P.add("lg128", TB * 128);   // dense2's raw products over the padded weight matrix
   P.add("pbf", make_layout(c).total, CRNN_BF16);   // bf16 shadow of the parameter buffer (GEMM B operands in the bf16 modes)
   if (!c->mfma_bf16) {   // parity mode: bf16 planes of the pointwise-conv weights (CRNN_FLAG_WEIGHT_PLANES, weight_planes below); 3 planes x the b2_pw .. b7_pw span
     const Layout L = make_layout(c);
@@ -572,6 +580,7 @@ extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, cons
   }
   // bf16 modes: W^T (bf16) copies of the pointwise weights of blocks 2..7, one launch
   long pwT_off[8]; for (int i = 0; i < 8; ++i) pwT_off[i] = -1;
+  long d2T_off = -1;                       // element offset of dense2's padded W^T inside "pwT" (dense2_stream)
   if (cfg->mfma_bf16) {
     long in_off[8], out_off[8]; int R[8], Cc[8]; int n = 0; long acc = 0;
     for (int i = 2; i <= 7; ++i) {
@@ -579,6 +588,9 @@ extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, cons
       if (ci % 8 || co % 8) continue;
       in_off[n] = c.L.off("b" + std::to_string(i) + "_pw"); out_off[n] = acc; R[n] = ci; Cc[n] = co;
       pwT_off[i] = acc; acc += (long)ci * co; ++n;
+    }
+    if (dense2_stream(cfg, d) && n < 8) {   // dense2's W [2u][C] -> W^T rows 0..C-1 of a 128-row matrix behind the pointwise copies
+      in_off[n] = c.L.off("dense2_w"); out_off[n] = acc; R[n] = 2 * d.u; Cc[n] = d.C; d2T_off = acc; ++n;
     }
     if (n) CRNN_TRY(crnn_transpose_batch(params, c.w("pwT"), n, in_off, out_off, R, Cc, CRNN_BF16, stream));
   }
@@ -805,9 +817,23 @@ extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, cons
     r2 = c.w("r2d");
   }
   // ---- dense2 + softmax (utils.py:85-86); back to batch-major [B][T][C]
-  CRNN_TRY(gemm(c, 0, r2, c.p("dense2_w"), c.w("logits"), TB, d.C, 2 * u, 2 * u, d.C, d.C, c.p("dense2_b"), 0, 0, B));
-  CRNN_TRY(crnn_softmax_rows(c.w("logits"), c.w("ypred"), TB, d.C, stream));
-  if (y_pred && y_pred != c.w("ypred")) {
+  bool ypred_out = false;                  // y_pred already written by the fused epilogue
+  if (d2T_off >= 0) {
+    // round 5: the product on the streaming kernel (64-row stripes against the bf16 W^T through LDS; the tile GEMM ran 104 workgroups for 35 us), bias + row
+    // permutation + softmax + the y_pred copy in one pass over its output: dropout aside, four launches (56 us) -> two (18 us)
+    const bf16_t* wT = reinterpret_cast<const bf16_t*>(c.w("pwT")) + d2T_off;
+    int rc = crnn_gemm_nt_f32_stream_bias(r2, wT, nullptr, nullptr, c.w("lg128"), nullptr, TB, 128, 2 * u, 2 * u, 2 * u, 128, stream);
+    if (rc == CRNN_OK) {
+      CRNN_TRY(crnn_softmax_rows_perm(c.w("lg128"), 128, c.p("dense2_b"), c.w("logits"), c.w("ypred"), y_pred, TB, d.C, B, stream));
+      ypred_out = y_pred != nullptr;
+    } else if (rc != CRNN_ERR_UNSUPPORTED) return rc;
+    else d2T_off = -1;
+  }
+  if (d2T_off < 0) {
+    CRNN_TRY(gemm(c, 0, r2, c.p("dense2_w"), c.w("logits"), TB, d.C, 2 * u, 2 * u, d.C, d.C, c.p("dense2_b"), 0, 0, B));
+    CRNN_TRY(crnn_softmax_rows(c.w("logits"), c.w("ypred"), TB, d.C, stream));
+  }
+  if (y_pred && y_pred != c.w("ypred") && !ypred_out) {
     hipError_t e = hipMemcpyAsync(y_pred, c.w("ypred"), (size_t)TB * d.C * sizeof(float), hipMemcpyDeviceToDevice, stream);
     if (e != hipSuccess) return (int)e;
   }

@@ -658,6 +658,10 @@ int crnn_transpose(const float* in, float* out, int R, int C, crnn_stream_t stre
 int crnn_transpose_ex(const float* in, void* out, int R, int C, int dt_out, crnn_stream_t stream);   /* dt_out 1: bf16 result */
 /* softmax + CTC (utils.py:86, 98-103) */
 int crnn_softmax_rows(const float* z, float* p, long rows, int C, crnn_stream_t stream);
+/* dense2's epilogue in one pass (round 5): logits = z[:, :C] + bias (z [rows][ldz]: the raw products of a GEMM over a padded weight matrix), written in permuted
+ * row order out_row = (m % permP) * (rows / permP) + m / permP (permP = 0: none; time-major rows back to batch-major as crnn_gemm_f32's permP), together with their row
+ * softmax in p1 and, when p2 != NULL, in p2 as well (reference utils.py:85-86).  Same arithmetic as crnn_softmax_rows.  C <= 64. */
+int crnn_softmax_rows_perm(const float* z, int ldz, const float* bias, float* logits, float* p1, float* p2, long rows, int C, int permP, crnn_stream_t stream);
 int crnn_ctc_loss_grad(const float* y, const int* labels, const int* input_len, const int* label_len, float* loss,
                        float* dlogits, int B, int T, int C, int Lmax, int skip, float grad_scale, crnn_stream_t stream);
 

@@ -808,6 +808,34 @@ def test_ctc_loss_and_logit_gradient(B, T, C, Lmax, short):
     assert_close(np.swapaxes(host(dl), 0, 1), gl_ref, rtol=1e-3, atol=2e-6, what="dlogits")
 
 
+@pytest.mark.parametrize("rows,C,ldz,P_,two", [(52 * 8, 38, 128, 8, True), (64, 64, 64, 0, False), (13312, 38, 128, 256, True), (12, 20, 32, 4, False)])
+def test_softmax_rows_with_bias_row_permutation_and_two_outputs(rows, C, ldz, P_, two):
+    """crnn_softmax_rows_perm (round 5: dense2's epilogue in one pass): logits = z[:, :C] + bias in permuted row order, their softmax in one or two outputs --
+    against crnn_softmax_rows on the permuted biased rows (the same arithmetic: bit for bit) and the oracle; padding columns (NaN here) are never read."""
+    rs = np.random.RandomState(rows + C)
+    z = rs.normal(size=(rows, ldz)).astype(np.float32) * 3; z[:, C:] = np.nan
+    bias = rs.normal(size=C).astype(np.float32)
+    zd, bd = dev(z), dev(bias)
+    lg = torch.full((rows * C + 16,), 5.0, device="cuda"); p1 = torch.full((rows * C + 16,), 6.0, device="cuda"); p2 = torch.full((rows * C + 16,), 7.0, device="cuda")
+    ok(L().crnn_softmax_rows_perm(P(zd), ldz, P(bd), P(lg), P(p1), P(p2) if two else None, rows, C, P_, S()))
+    want = z[:, :C] + bias
+    if P_:
+        m = np.arange(rows); orow = (m % P_) * (rows // P_) + m // P_
+        perm = np.empty_like(want); perm[orow] = want; want = perm
+    assert np.array_equal(host(lg[:-16]).reshape(rows, C), want)
+    ref = zeros(rows, C)
+    ok(L().crnn_softmax_rows(P(dev(want)), P(ref), rows, C, S()))
+    assert torch.equal(p1[:-16].view(rows, C), ref)
+    assert_close(host(p1[:-16]).reshape(rows, C), ops.softmax_fwd(want.astype(np.float64)), rtol=1e-5, atol=1e-7, what="softmax vs oracle")
+    if two:
+        assert torch.equal(p2[:-16], p1[:-16])
+    else:
+        assert bool((p2 == 7.0).all())
+    assert bool((lg[-16:] == 5.0).all()) and bool((p1[-16:] == 6.0).all()) and bool((p2[-16:] == 7.0).all())
+    assert L().crnn_softmax_rows_perm(P(zd), ldz, P(bd), P(lg), P(p1), None, rows, C, 7 if rows % 7 else 5, S()) == -2      # rows not a multiple of permP
+    assert L().crnn_softmax_rows_perm(P(zd), C - 1, P(bd), P(lg), P(p1), None, rows, C, 0, S()) == -2
+
+
 def test_ctc_impossible_and_greedy_bitexact():
     y = np.full((2, 7, 4), 0.25)
     labels = np.array([[1, 1, 1], [0, 3, 3]]); il = np.array([3, 5]); ll = np.array([3, 1])
