@@ -1328,6 +1328,35 @@ extern "C" int crnn_dropout(const float* x, float* y, long rows, int C, int ldx,
   return CRNN_OK;
 }
 
+// eight consecutive elements per thread: two 16-byte loads / stores, ONE hash, and the group's keep byte (bit e: element 8 g + e is kept -- the table
+// crnn_dropout_keep_bytes writes) next to the dropped activations: dense2's one-pass backward (dense.hip) reads the decisions instead of hashing again
+__global__ void dropout_vec8_keep_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ keep, unsigned ngroups, int C8,
+                                         int ldx, int ldy, float rate, uint64_t seed, uint32_t layer) {
+  const float inv_keep = rate > 0.f ? 1.f / (1.f - rate) : 1.f;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < ngroups; i += gridDim.x * blockDim.x) {
+    const unsigned r = i / (unsigned)C8, c8 = i - r * (unsigned)C8;
+    const float4 v0 = *reinterpret_cast<const float4*>(x + (long)r * ldx + 8 * c8), v1 = *reinterpret_cast<const float4*>(x + (long)r * ldx + 8 * c8 + 4);
+    float dm[8];
+    drop_scale_vec<8>(seed, layer, (uint64_t)i * 8, rate, inv_keep, dm);
+    *reinterpret_cast<float4*>(y + (long)r * ldy + 8 * c8) = make_float4(v0.x * dm[0], v0.y * dm[1], v0.z * dm[2], v0.w * dm[3]);
+    *reinterpret_cast<float4*>(y + (long)r * ldy + 8 * c8 + 4) = make_float4(v1.x * dm[4], v1.y * dm[5], v1.z * dm[6], v1.w * dm[7]);
+    unsigned m = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m |= (dm[e] != 0.f ? 1u : 0u) << e;
+    keep[i] = (unsigned char)m;
+  }
+}
+extern "C" int crnn_dropout_keep(const float* x, float* y, void* keep, long rows, int C, int ldx, int ldy, float rate, uint64_t seed, uint32_t layer,
+                                 hipStream_t stream) {
+  const long n = rows * C;
+  if (!x || !y || !keep || rate >= 1.f) return CRNN_ERR_ARG;
+  if (C % 8 || ldx % 4 || ldy % 4 || (((uintptr_t)x | (uintptr_t)y) & 15) || n <= 0 || n / 8 + 4096L * 256 >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;
+  int blocks = cdiv(n / 8, 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(dropout_vec8_keep_kernel, dim3(blocks), dim3(256), 0, stream, x, y, static_cast<unsigned char*>(keep), (unsigned)(n / 8), C / 8, ldx, ldy, rate, seed, layer);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+
 // materialise the multiplier (0 or 1/(1-rate)) that dropout site `layer` applies -- test hook
 __global__ void dropout_mask_kernel(float* __restrict__ m, long n, float rate, uint64_t seed, uint32_t layer) {
   float inv_keep = rate > 0.f ? 1.f / (1.f - rate) : 1.f;

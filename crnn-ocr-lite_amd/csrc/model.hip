@@ -100,6 +100,11 @@ long lmax(long a, long b) { return a > b ? a : b; }
 static bool dense2_stream(const crnn_config* cfg, const Dims& d) {
   return cfg->mfma_bf16 && !(cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS) && ((long)d.T * d.B) % 64 == 0 && (2 * d.u) % 64 == 0 && d.C <= 64;
 }
+// dense2's backward (both gradients, the bias gradient and the dropout multiplier of its input) as one fp32 kernel with the weights in registers
+// (dense.hip, round 5) in every precision mode; CRNN_FLAG_GEMM_TILE_KERNELS keeps the tile GEMMs + column reduce + dropout pass
+static bool dense2_bwd_fused(const crnn_config* cfg, const Dims& d) {
+  return !(cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS) && crnn_dense_bwd_small_supported((long)d.T * d.B, 2 * d.u, d.C) == CRNN_OK;
+}
 // The BatchNorm-2 fusions into the depthwise row-stream kernels (fuse_bn2_dw below): opt-in flags for bf16 tensors (the re-forming is VALU work the bf16
 // kernels have no issue slots for: measured neutral), the default schedule for fp32 tensors since round 4 (half the elements per byte: -0.6 ms of 14.8 per
 // step), CRNN_FLAG_NO_BN2_DW_FUSION switches them off.
@@ -216,6 +221,10 @@ Plan make_plan(const crnn_config* c) {
     // GEMM's columns for them are never read -- dense2_stream below)
     P.add("pwT", pw + 128L * 2 * d.u, CRNN_BF16); }
   if (c->mfma_bf16) P.add("lg128", TB * 128);   // dense2's raw products over the padded weight matrix
+  if (dense2_bwd_fused(c, d)) {
+    P.add("d2part", (long)(crnn_dense_bwd_small_scratch_bytes(TB, 2 * d.u, d.C) / sizeof(float)));   // per-workgroup partial gradients of dense2
+    P.add("keep9", (TB * 2 * d.u / 8 + 3) / 4);   // keep bytes of the Dropout(.2) under dense2 (written by the forward's dropout pass, read by the one-pass backward)
+  }
   P.add("pbf", make_layout(c).total, CRNN_BF16);   // bf16 shadow of the parameter buffer (GEMM B operands in the bf16 modes)
   if (!c->mfma_bf16) {   // parity mode: bf16 planes of the pointwise-conv weights (CRNN_FLAG_WEIGHT_PLANES, weight_planes below); 3 planes x the b2_pw .. b7_pw span
     const Layout L = make_layout(c);
@@ -813,7 +822,14 @@ extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, cons
                               c.w("gt2f"), c.w("gt2b"), T, B, u, dtu, stream));    // merge_mode='concat'
   const float* r2 = c.w("h2");
   if (train) {  // Dropout(.2) (utils.py:83)
-    CRNN_TRY(crnn_dropout(c.w("h2"), c.w("r2d"), TB, 2 * u, 2 * u, 2 * u, cfg->dropout ? kDropRnn : 0.f, seed, kLayerRnn, stream));
+    int rcd = CRNN_ERR_UNSUPPORTED;
+    if (cfg->dropout && dense2_bwd_fused(cfg, d))   // the dropped activations and the decisions as keep bytes in one pass (dense2's backward reads them)
+      rcd = crnn_dropout_keep(c.w("h2"), c.w("r2d"), c.w("keep9"), TB, 2 * u, 2 * u, 2 * u, kDropRnn, seed, kLayerRnn, stream);
+    if (rcd != CRNN_OK && rcd != CRNN_ERR_UNSUPPORTED) return rcd;
+    if (rcd != CRNN_OK) {
+      CRNN_TRY(crnn_dropout(c.w("h2"), c.w("r2d"), TB, 2 * u, 2 * u, 2 * u, cfg->dropout ? kDropRnn : 0.f, seed, kLayerRnn, stream));
+      if (cfg->dropout && dense2_bwd_fused(cfg, d)) CRNN_TRY(crnn_dropout_keep_bytes(c.w("keep9"), (long)TB * 2 * u / 8, kDropRnn, seed, kLayerRnn, stream));
+    }
     r2 = c.w("r2d");
   }
   // ---- dense2 + softmax (utils.py:85-86); back to batch-major [B][T][C]
@@ -1022,11 +1038,19 @@ int backward_top(const Ctx& c0, const int* labels, const int* input_length, cons
   CRNN_TRY(crnn_ctc_loss_grad(c.w("ypred"), labels, input_length, label_length, loss, c.w("dlogits"), B, T, d.C, d.L, 2, 1.0f / (float)B, stream));
   // ---- dense2: weight / bias gradients on the side stream, the data gradient feeds the recurrent layers
   const float* r2 = c.w("r2d");
+  int rc2 = CRNN_ERR_UNSUPPORTED;
+  if (dense2_bwd_fused(cfg, d))   // one pass over r2 / dlogits: dW, db, and the data gradient with the forward's dropout multiplier (dense.hip)
+    rc2 = crnn_dense_bwd_small(r2, c.w("dlogits"), c.p("dense2_w"), c.w("dr2"), c.g("dense2_w"), c.g("dense2_b"), c.w("d2part"),
+                               (size_t)c.P.cnt("d2part") * sizeof(float), TB, 2 * u, d.C, 2 * u, 2 * u, cfg->dropout ? c.w("keep9") : nullptr,
+                               cfg->dropout ? kDropRnn : 0.f, seed, kLayerRnn, stream);
+  if (rc2 != CRNN_OK && rc2 != CRNN_ERR_UNSUPPORTED) return rc2;
   CRNN_TRY(fj.fork());
-  CRNN_TRY(gemm(ca, 2, r2, c.w("dlogits"), c.g("dense2_w"), 2 * u, d.C, TB, 2 * u, d.C, d.C, nullptr, 0, 0, 0, conv_planes(cfg, true)));
-  CRNN_TRY(colsum(ca, c.w("dlogits"), TB, d.C, d.C, c.g("dense2_b")));
-  CRNN_TRY(gemm(c, 1, c.w("dlogits"), c.p("dense2_w"), c.w("dr2"), TB, 2 * u, d.C, d.C, d.C, 2 * u, nullptr, 0, 0, 0, conv_planes(cfg, true)));
-  if (cfg->dropout) CRNN_TRY(crnn_dropout(c.w("dr2"), c.w("dr2"), TB, 2 * u, 2 * u, 2 * u, kDropRnn, seed, kLayerRnn, stream));
+  if (rc2 != CRNN_OK) {
+    CRNN_TRY(gemm(ca, 2, r2, c.w("dlogits"), c.g("dense2_w"), 2 * u, d.C, TB, 2 * u, d.C, d.C, nullptr, 0, 0, 0, conv_planes(cfg, true)));
+    CRNN_TRY(colsum(ca, c.w("dlogits"), TB, d.C, d.C, c.g("dense2_b")));
+    CRNN_TRY(gemm(c, 1, c.w("dlogits"), c.p("dense2_w"), c.w("dr2"), TB, 2 * u, d.C, d.C, d.C, 2 * u, nullptr, 0, 0, 0, conv_planes(cfg, true)));
+    if (cfg->dropout) CRNN_TRY(crnn_dropout(c.w("dr2"), c.w("dr2"), TB, 2 * u, 2 * u, 2 * u, kDropRnn, seed, kLayerRnn, stream));
+  }
   // ---- Bidirectional LSTM / GRU x2
   CRNN_TRY(rnn_bwd_chain(c, 2, c.w("h2"), c.w("h2") + u, 2 * u, c.w("dr2"), c.w("dr2") + u, 2 * u));
   CRNN_TRY(fj.fork());                               // dz of layer 2 is complete: its weight gradients go to the side stream

@@ -403,6 +403,10 @@ int crnn_bn_bwd(const float* x, const float* g, const float* bnstate, const floa
 int crnn_add(const float* a, const float* b, float* o, long n, crnn_stream_t stream);
 int crnn_dropout(const float* x, float* y, long rows, int C, int ldx, int ldy, float rate, uint64_t seed,
                  uint32_t layer, crnn_stream_t stream);
+/* crnn_dropout that also writes the keep bytes of the site (the table of crnn_dropout_keep_bytes below: one byte per 8 consecutive elements of the compact
+ * [rows][C] index space) -- round 5: dense2's one-pass backward reads them (crnn_dense_bwd_small).  C % 8 == 0, ldx / ldy % 4 == 0, 16-byte aligned x / y;
+ * else CRNN_ERR_UNSUPPORTED.  keep: rows * C / 8 bytes. */
+int crnn_dropout_keep(const float* x, float* y, void* keep, long rows, int C, int ldx, int ldy, float rate, uint64_t seed, uint32_t layer, crnn_stream_t stream);
 int crnn_dropout_mask(float* m, long n, float rate, uint64_t seed, uint32_t layer, crnn_stream_t stream);
 /* keep bits of the same dropout site, one byte per group of 8 consecutive elements (bit e: element 8 g + e is kept; rate <= 0: 0xFF) -- the form the
  * prologue row-stream depthwise kernels read (crnn_dwconv3x3_fwd_stream_pro / _bwd_stream_pro).  out: 4-byte aligned, (ngroups + 3) / 4 * 4 bytes written */
@@ -662,6 +666,18 @@ int crnn_softmax_rows(const float* z, float* p, long rows, int C, crnn_stream_t 
  * row order out_row = (m % permP) * (rows / permP) + m / permP (permP = 0: none; time-major rows back to batch-major as crnn_gemm_f32's permP), together with their row
  * softmax in p1 and, when p2 != NULL, in p2 as well (reference utils.py:85-86).  Same arithmetic as crnn_softmax_rows.  C <= 64. */
 int crnn_softmax_rows_perm(const float* z, int ldz, const float* bias, float* logits, float* p1, float* p2, long rows, int C, int permP, crnn_stream_t stream);
+/* dense2's backward in one pass (round 5; dense.hip; reference utils.py:82-86 under the CTC loss of utils.py:98-103): for x [M][K] (the layer's
+ * dropped-out input, leading dimension ldx), dy [M][C] (compact) and W [K][C],
+ *   dW[k][c] = sum_m x[m][k] dy[m][c],  db[c] = sum_m dy[m][c],  dx[m][k] = (sum_c dy[m][c] W[k][c]) * (dropout multiplier of element m * K + k of site `layer`)
+ * in exact fp32, weights and weight-gradient accumulators in registers (thread = two input features), rows in ascending order per workgroup, the
+ * per-workgroup partial gradients (scratch) summed in workgroup order.  db must be dW + K * C (the two gradients are one span of the gradient
+ * buffer).  drop_rate 0: no dropout; keep: the site's keep bytes (crnn_dropout_keep / crnn_dropout_keep_bytes; M * K / 8 bytes, 4-byte aligned) or NULL
+ * (the kernel's loader wave evaluates the decisions itself: same results, 1.6 us per 8-row step slower).  x rows contiguous (ldx == K).
+ * _supported: K % 128 == 0, 128 <= K <= 512, C <= 40; else CRNN_ERR_UNSUPPORTED (the caller runs the GEMMs). */
+int crnn_dense_bwd_small_supported(long M, int K, int C);
+size_t crnn_dense_bwd_small_scratch_bytes(long M, int K, int C);
+int crnn_dense_bwd_small(const float* x, const float* dy, const float* W, float* dx, float* dW, float* db, float* scratch, size_t scratch_bytes,
+                         long M, int K, int C, int ldx, int lddx, const void* keep, float drop_rate, uint64_t seed, uint32_t layer, crnn_stream_t stream);
 int crnn_ctc_loss_grad(const float* y, const int* labels, const int* input_len, const int* label_len, float* loss,
                        float* dlogits, int B, int T, int C, int Lmax, int skip, float grad_scale, crnn_stream_t stream);
 

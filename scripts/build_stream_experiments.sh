@@ -15,3 +15,9 @@ for m in 1 2 4 8; do hipcc $F -DCRNN_DBS_EXP=$m dwconv_bwd_stream.hip conv.hip -
 for d in 2 5; do hipcc $F -DCRNN_DBS_D=$d dwconv_bwd_stream.hip conv.hip -o $O/libdbs_d$d.so & done
 wait
 ls $O | grep -E "dws|dbs"
+# dense2's one-pass backward (scripts/dense_bench.py): the timing build (per-workgroup stamps) and its ablations
+rm -f $O/libdense_*
+hipcc $F -DCRNN_DSB_TRACE dense.hip conv.hip -o $O/libdense_trace.so &
+for m in 1 2 8 10 24; do hipcc $F -DCRNN_DSB_TRACE -DCRNN_DSB_EXP=$m dense.hip conv.hip -o $O/libdense_trace_exp$m.so & done   # no multiply-adds | no LDS dy reads | no dx store | 2+8 | no stores, no x DMA
+wait
+ls $O | grep dense

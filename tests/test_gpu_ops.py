@@ -836,6 +836,71 @@ def test_softmax_rows_with_bias_row_permutation_and_two_outputs(rows, C, ldz, P_
     assert L().crnn_softmax_rows_perm(P(zd), C - 1, P(bd), P(lg), P(p1), None, rows, C, 0, S()) == -2
 
 
+@pytest.mark.parametrize("M,K,C,rate,lddx", [(52 * 256, 512, 38, 0.2, 512), (52 * 8, 128, 38, 0.2, 128), (203, 256, 40, 0.0, 320), (7, 128, 2, 0.5, 128), (52 * 64, 512, 11, 0.2, 512), (2049, 384, 37, 0.3, 384)])
+def test_dense_backward_in_one_pass_against_the_products(M, K, C, rate, lddx):
+    """crnn_dense_bwd_small (round 5: dense2's backward, dense.hip): weight gradient, bias gradient and the data gradient with the dropout multiplier of
+    the layer's input -- against fp64 products (exact fp32 kernel: 1e-5 of each tensor's scale) and crnn_dropout_mask's decisions (the zeros: exactly), with the
+    decisions read from the site's keep bytes and evaluated in the kernel;
+    rows are owned by workgroups in steps of 8, so ragged row counts (203, 7, 2049) exercise the tails; padding columns of dx (lddx > K) stay untouched."""
+    rs = np.random.RandomState(M + K + C)
+    x = rs.normal(size=(M, K)).astype(np.float32); dy = rs.normal(size=(M, C)).astype(np.float32) * 0.1; W = rs.normal(size=(K, C)).astype(np.float32)
+    seed, layer = 1234567 + M, 9
+    xd, dyd, Wd = dev(x), dev(dy), dev(W)
+    dx = torch.full((M, lddx), 3.0, device="cuda"); g = torch.full((K * C + C + 8,), 4.0, device="cuda")
+    assert L().crnn_dense_bwd_small_supported(M, K, C) == 0
+    nb = L().crnn_dense_bwd_small_scratch_bytes(M, K, C)
+    scratch = torch.empty(nb // 4, device="cuda")
+    gW, gb = g[:K * C], g[K * C:K * C + C]
+    keep = torch.zeros(M * K // 8 + 4, dtype=torch.uint8, device="cuda")       # the site's keep bytes, as the forward's dropout pass writes them
+    ok(L().crnn_dropout_keep_bytes(P(keep), M * K // 8, rate, seed, layer, S()))
+    keep_arg = P(keep) if rate > 0 else None
+    ok(L().crnn_dense_bwd_small(P(xd), P(dyd), P(Wd), P(dx), P(gW), P(gb), P(scratch), nb, M, K, C, K, lddx, keep_arg, rate, seed, layer, S()))
+    mask = torch.ones(M * K, device="cuda")
+    if rate > 0:
+        ok(L().crnn_dropout_mask(P(mask), M * K, rate, seed, layer, S()))
+    mask = host(mask).reshape(M, K).astype(np.float64)
+    x64, dy64, W64 = x[:, :K].astype(np.float64), dy.astype(np.float64), W.astype(np.float64)
+    want_dx = (dy64 @ W64.T) * mask
+    got_dx = host(dx)
+    assert_close(got_dx[:, :K], want_dx, rtol=1e-5, atol=1e-5 * np.abs(want_dx).max(), what="dx")
+    assert (got_dx[:, :K][mask == 0] == 0).all()          # dropped elements are exact zeros
+    assert (got_dx[:, K:] == 3.0).all()
+    want_W = x64.T @ dy64
+    assert_close(host(gW).reshape(K, C), want_W, rtol=1e-5, atol=2e-6 * np.abs(want_W).max() + 1e-6, what="dW")
+    assert_close(host(gb), dy64.sum(0), rtol=1e-5, atol=1e-6 * M ** 0.5, what="db")
+    assert bool((g[K * C + C:] == 4.0).all())
+    again = torch.full_like(g, 5.0); dx2 = torch.empty_like(dx)
+    ok(L().crnn_dense_bwd_small(P(xd), P(dyd), P(Wd), P(dx2), P(again[:K * C]), P(again[K * C:K * C + C]), P(scratch), nb, M, K, C, K, lddx, keep_arg, rate, seed, layer, S()))
+    assert torch.equal(again[:K * C + C], g[:K * C + C]) and torch.equal(dx2[:, :K], dx[:, :K])      # fixed summation order
+    if rate > 0:     # without the table the loader wave evaluates the decisions itself: the same bits
+        dx3 = torch.empty_like(dx); g3 = torch.full_like(g, 6.0)
+        ok(L().crnn_dense_bwd_small(P(xd), P(dyd), P(Wd), P(dx3), P(g3[:K * C]), P(g3[K * C:K * C + C]), P(scratch), nb, M, K, C, K, lddx, None, rate, seed, layer, S()))
+        assert torch.equal(g3[:K * C + C], g[:K * C + C]) and torch.equal(dx3[:, :K], dx[:, :K])
+    # refusals: bias gradient elsewhere, short scratch, x rows not contiguous, shapes outside the rule
+    assert L().crnn_dense_bwd_small(P(xd), P(dyd), P(Wd), P(dx), P(gW), P(gb), P(scratch), nb, M, K, C, K + 4, lddx, keep_arg, rate, seed, layer, S()) == -3
+    other = zeros(C)
+    assert L().crnn_dense_bwd_small(P(xd), P(dyd), P(Wd), P(dx), P(gW), P(other), P(scratch), nb, M, K, C, K, lddx, keep_arg, rate, seed, layer, S()) == -3
+    assert L().crnn_dense_bwd_small(P(xd), P(dyd), P(Wd), P(dx), P(gW), P(gb), P(scratch), nb - 4, M, K, C, K, lddx, keep_arg, rate, seed, layer, S()) == -2
+    for (m_, k_, c_) in [(64, 640, 38), (64, 192, 38), (64, 64, 38), (64, 512, 41), (0, 512, 38)]:
+        assert L().crnn_dense_bwd_small_supported(m_, k_, c_) == -3
+
+
+@pytest.mark.parametrize("rows,C,ldx,ldy,rate", [(52 * 256, 512, 512, 512, 0.2), (13, 64, 72, 64, 0.5), (7, 8, 8, 12, 0.1), (33, 128, 128, 128, 0.0)])
+def test_dropout_with_keep_bytes_is_dropout_plus_the_keep_table(rows, C, ldx, ldy, rate):
+    """crnn_dropout_keep (round 5): the same outputs as crnn_dropout bit for bit, and the keep bytes crnn_dropout_keep_bytes writes for the site."""
+    rs = np.random.RandomState(rows + C)
+    x = dev(rs.normal(size=(rows, ldx)).astype(np.float32))
+    seed, layer = 99 + rows, 9
+    y = torch.full((rows, ldy), 3.0, device="cuda"); want = torch.full((rows, ldy), 3.0, device="cuda")
+    keep = torch.full((rows * C // 8 + 8,), 7, dtype=torch.uint8, device="cuda"); kw = torch.zeros((rows * C // 8 + 3) // 4 * 4, dtype=torch.uint8, device="cuda")
+    ok(L().crnn_dropout_keep(P(x), P(y), P(keep), rows, C, ldx, ldy, rate, seed, layer, S()))
+    ok(L().crnn_dropout(P(x), P(want), rows, C, ldx, ldy, rate, seed, layer, S()))
+    ok(L().crnn_dropout_keep_bytes(P(kw), rows * C // 8, rate, seed, layer, S()))
+    assert torch.equal(y, want)
+    assert torch.equal(keep[:rows * C // 8], kw[:rows * C // 8]) and bool((keep[rows * C // 8:] == 7).all())
+    assert L().crnn_dropout_keep(P(x), P(y), P(keep), rows, C + 4, ldx, ldy, rate, seed, layer, S()) == -3      # whole groups of 8 only
+
+
 def test_ctc_impossible_and_greedy_bitexact():
     y = np.full((2, 7, 4), 0.25)
     labels = np.array([[1, 1, 1], [0, 3, 3]]); il = np.array([3, 5]); ll = np.array([3, 1])

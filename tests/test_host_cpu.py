@@ -174,6 +174,26 @@ def test_fp32_row_stream_and_localisation_net_shape_rules():
     assert L.crnn_loc_net_bwd_scratch(256) == 256 * (25 * 20 * 20 + 20 + 25 * 20 + 20)
 
 
+def test_dense_backward_shape_rule_and_scratch_size():
+    """Round 5, host arithmetic only: dense2's one-pass backward (dense.hip) takes 2 * units a multiple of 128 up to 512 (units is a multiple of 64) and at most 40 classes; its scratch is
+    one partial gradient ([K][C] + [C], rounded up to whole 16 bytes) per workgroup, at most 256 workgroups of at least one 8-row step."""
+    L = ctypes.CDLL(native.LIB_PATH)
+    L.crnn_dense_bwd_small_scratch_bytes.restype = ctypes.c_size_t
+    L.crnn_dense_bwd_small_scratch_bytes.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int]
+    L.crnn_dense_bwd_small_supported.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int]
+    for (M, K, C, want) in [(13312, 512, 38, 0), (3328, 512, 38, 0), (52 * 8, 128, 11, 0), (7, 128, 2, 0), (7, 64, 2, -3), (64, 192, 38, -3), (13312, 512, 40, 0), (13312, 512, 41, -3),
+                            (13312, 640, 38, -3), (13312, 1024, 38, -3), (13312, 96, 38, -3), (13312, 512, 64, -3), (0, 512, 38, -3)]:
+        assert L.crnn_dense_bwd_small_supported(M, K, C) == want, (M, K, C)
+        nb = L.crnn_dense_bwd_small_scratch_bytes(M, K, C)
+        if want:
+            assert nb == 0
+        else:
+            per = (K * C + C + 3) // 4 * 4 * 4
+            assert nb % per == 0 and 1 <= nb // per <= 256 and nb // per <= (M + 7) // 8
+    assert L.crnn_dense_bwd_small_scratch_bytes(13312, 512, 38) == 256 * (512 * 38 + 38 + 2) * 4        # 52 rows per workgroup
+    assert L.crnn_dense_bwd_small_scratch_bytes(3328, 512, 38) == 256 * (512 * 38 + 38 + 2) * 4         # batch 64: 13 rows per workgroup
+
+
 def test_row_stream_kernels_keep_their_row_loops_spill_free():
     """The bf16 row-stream kernels sit at their 168-register ceiling; a harmless-looking edit (an address spelled with one multiplication instead of two)
     once put a 16-byte spill into the depthwise-stage backward's row loop and cost the kernel 22 %.  hipcc cross-compiles gfx950 without a GPU: no
@@ -212,7 +232,7 @@ def test_weights_resident_gemms_and_row_stream_kernels_have_no_spilled_vector_re
         pytest.skip("hipcc not on PATH")
     csrc = os.path.join(os.path.dirname(native.LIB_PATH), "csrc")
     inc = os.path.dirname(native.HEADER)
-    for src, minimum, allowed in (("gemm_wres.hip", 15, 0), ("gemm_wgrad.hip", 2, 0), ("dwconv_stream.hip", 7, 4), ("dwconv_bwd_stream.hip", 7, 4)):
+    for src, minimum, allowed in (("gemm_wres.hip", 15, 0), ("gemm_wgrad.hip", 2, 0), ("dwconv_stream.hip", 7, 4), ("dwconv_bwd_stream.hip", 7, 4), ("dense.hip", 2, 0)):
         with tempfile.TemporaryDirectory() as td:
             r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", inc, "-c", os.path.join(csrc, src), "-o", os.path.join(td, "k.o"),
                                 "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
