@@ -1427,23 +1427,29 @@ extern "C" int crnn_dropout_keep_bytes(void* out, long ngroups, float rate, uint
 
 // g_out[perm(r)][c] = g[r][c] * [y[r][c] > 0]      (backward of ReLU, and of Dropout∘ReLU when y is the
 // dropped activation: the 1/(1-p) factor is passed as `scale`).  permP as in the GEMM epilogue.
-__global__ void relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ g, float* __restrict__ go,
+__global__ void relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ g, float* __restrict__ go, bf16_t* __restrict__ go16,
                                 long rows, int C, float scale, int permP) {
   long n = rows * C;
   long Q = permP ? rows / permP : 0;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     long r = i / C; int c = (int)(i % C);
     long orow = permP ? (r % permP) * Q + r / permP : r;
-    go[orow * C + c] = (y[i] > 0.f) ? g[i] * scale : 0.f;
+    const float v = (y[i] > 0.f) ? g[i] * scale : 0.f;
+    go[orow * C + c] = v;
+    if (go16) st1(go16 + orow * C + c, v);      // the same values rounded to bf16 (round to nearest even): the data-gradient GEMM's operand
   }
+}
+extern "C" int crnn_relu_bwd_ex(const float* y, const float* g, float* go, void* go_bf16, long rows, int C, float scale, int permP,
+                                hipStream_t stream) {
+  long n = rows * C;
+  int blocks = cdiv(n, 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks), dim3(256), 0, stream, y, g, go, static_cast<bf16_t*>(go_bf16), rows, C, scale, permP);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
 }
 extern "C" int crnn_relu_bwd(const float* y, const float* g, float* go, long rows, int C, float scale, int permP,
                              hipStream_t stream) {
-  long n = rows * C;
-  int blocks = cdiv(n, 256); if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks), dim3(256), 0, stream, y, g, go, rows, C, scale, permP);
-  CRNN_LAUNCH_CHECK();
-  return CRNN_OK;
+  return crnn_relu_bwd_ex(y, g, go, nullptr, rows, C, scale, permP, stream);
 }
 
 // a = ReLU6(x*scale+shift) (the pointwise conv's input; kept for its weight gradient)

@@ -605,7 +605,7 @@ int launch_wres(const WresParams& p, int grid, hipStream_t stream) {
 
 // 0 if crnn_gemm_wres_bf16 handles (N, K), else -3: N a multiple of 128 up to 1024, K in {64, 128, 256, 512}
 extern "C" int crnn_gemm_wres_supported(int N, int K) {
-  return (N >= 128 && N % 128 == 0 && N <= 1024 && (K == 64 || K == 128 || K == 256 || K == 512)) ? CRNN_OK : CRNN_ERR_UNSUPPORTED;
+  return (N >= 128 && N % 128 == 0 && (N <= 1024 || (K <= 128 && N <= 8192)) && (K == 64 || K == 128 || K == 256 || K == 512)) ? CRNN_OK : CRNN_ERR_UNSUPPORTED;
 }
 
 // Y[M][N] (bf16) = X[M][K] (bf16, row stride K) . W[N][K]^T (bf16, row stride K), weights resident in registers.
@@ -616,7 +616,12 @@ static int wres_geom(int M, int N, WresParams& p) {             // -> grid
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
   p.nxcd = 8;
   int per_xcd = cus / 8;                                       // workgroups per XCD: one per CU
-  if (per_xcd < p.S) per_xcd = p.S;
+  if (p.S > per_xcd) {                                         // more slices than an XCD has CUs (round 5: dense1's data gradient, 36 slices of a 3.4 MB operand):
+    p.nxcd = cus / p.S < 1 ? 1 : cus / p.S;                    // one workgroup per (slice, stripe lane), at most one per CU -- the stripe lanes no longer
+    p.Q = 1;                                                   // coincide with XCDs, which only matters for operands that do not fit the L2s
+    if (p.nxcd > p.stripes) p.nxcd = p.stripes;
+    return p.nxcd * p.S;
+  }
   p.Q = per_xcd / p.S;
   const int need = cdiv(p.stripes, p.nxcd);                    // stripe lanes that have any work
   if (p.Q > need) p.Q = need;
@@ -748,7 +753,7 @@ int launch_wres_fwd(const WresFwdParams& p, int grid, hipStream_t stream) {
 
 // 0 if crnn_pwconv_bnrelu6_fwd_wres handles the shape (whole 128-pixel stripes, N a multiple of 128 up to 1024, K in {64,128,256,512}), else -3
 extern "C" int crnn_pwconv_fwd_wres_supported(long M, int N, int K) {
-  return (M > 0 && M % 128 == 0 && M * (long)(K > N ? K : N) < (1L << 31) && crnn_gemm_wres_supported(N, K) == CRNN_OK) ? CRNN_OK : CRNN_ERR_UNSUPPORTED;
+  return (M > 0 && M % 128 == 0 && M * (long)(K > N ? K : N) < (1L << 31) && N <= 1024 && crnn_gemm_wres_supported(N, K) == CRNN_OK) ? CRNN_OK : CRNN_ERR_UNSUPPORTED;
 }
 // rows of the partial statistics [rows][2][N] the kernel writes (every row and column of that block is written)
 extern "C" int crnn_pwconv_fwd_wres_rows(long M, int N, int K) {

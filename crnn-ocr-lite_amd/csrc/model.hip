@@ -100,6 +100,13 @@ long lmax(long a, long b) { return a > b ? a : b; }
 static bool dense2_stream(const crnn_config* cfg, const Dims& d) {
   return cfg->mfma_bf16 && !(cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS) && ((long)d.T * d.B) % 64 == 0 && (2 * d.u) % 64 == 0 && d.C <= 64;
 }
+// dense1's data gradient gA [T*B][feat] = gbm [T*B][tds] . W1^T on the weights-resident GEMM (gemm_wres.hip: 36 slices of 128 features keep their
+// 128 x 128 weights in registers, the 3.4 MB operand streams; bf16 storage mode: both operands and the result are bf16 there anyway -- the same
+// products as the tile GEMM); CRNN_FLAG_GEMM_TILE_KERNELS off
+static bool dense1_dgrad_wres(const crnn_config* cfg, const Dims& d) {
+  return cfg->mfma_bf16 == 2 && !(cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS) && crnn_gemm_wres_supported(d.feat, d.tds) == CRNN_OK &&
+         (long)d.T * d.B * d.feat < (1L << 31);
+}
 // dense2's backward (both gradients, the bias gradient and the dropout multiplier of its input) as one fp32 kernel with the weights in registers
 // (dense.hip, round 5) in every precision mode; CRNN_FLAG_GEMM_TILE_KERNELS keeps the tile GEMMs + column reduce + dropout pass
 static bool dense2_bwd_fused(const crnn_config* cfg, const Dims& d) {
@@ -199,6 +206,7 @@ Plan make_plan(const crnn_config* c) {
   P.add("dlogits", TB * d.C); P.add("dr2", TB * 2 * d.u); P.add("dr1", TB * d.u);
   P.add("dcf", B * d.u); P.add("dcb", B * d.u); P.add("dhpf", B * d.u); P.add("dhpb", B * d.u);
   P.add("ddn1", TB * d.tds); P.add("gbm", TB * d.tds);
+  if (dense1_dgrad_wres(c, d)) P.add("gbm16", TB * d.tds, CRNN_BF16);   // bf16 copy of dense1's output gradient (operand of the weights-resident GEMM)
   maxact = lmax(maxact, TB * d.feat);
   // gradient ping-pong buffers: sized for fp32, hold bf16 tensors in storage mode 2
   P.add("gA", maxact); P.add("gB", maxact); P.add("gC", maxact);   // conv-stack gradient buffers (three: a weight-gradient GEMM on the side stream may still read one)
@@ -1061,12 +1069,17 @@ int backward_top(const Ctx& c0, const int* labels, const int* input_length, cons
   CRNN_TRY(rnn_bwd_wgrads(c, 1, c.w("dn1"), d.tds, d.tds, c.w("h1f"), c.w("h1b"), u));
   CRNN_TRY(rnn_bwd_dx(c, 1, d.tds, c.w("ddn1")));
   // ---- Dropout(.4) + relu of dense1, rows back to batch-major
-  CRNN_TRY(crnn_relu_bwd(c.w("dn1"), c.w("ddn1"), c.w("gbm"), TB, d.tds, cfg->dropout ? 1.0f / (1.0f - kDropDense1) : 1.0f, B, stream));
+  const bool wres1 = dense1_dgrad_wres(cfg, d);
+  CRNN_TRY(crnn_relu_bwd_ex(c.w("dn1"), c.w("ddn1"), c.w("gbm"), wres1 ? c.w("gbm16") : nullptr, TB, d.tds, cfg->dropout ? 1.0f / (1.0f - kDropDense1) : 1.0f, B, stream));
   const float* feat = c.w("x7");
   CRNN_TRY(gemm_t(c, 2, feat, c.dt("x7"), c.w("gbm"), CRNN_F32, c.g("dense1_w"), CRNN_F32, d.feat, d.tds, TB, d.feat, d.tds, d.tds, nullptr, 0, 0, 0, conv_planes(cfg, true)));
   CRNN_TRY(colsum(c, c.w("gbm"), TB, d.tds, d.tds, c.g("dense1_b")));
   float* gA = c.w("gA"); float* gB = c.w("gB");
-  CRNN_TRY(gemm_t(c, 1, c.w("gbm"), CRNN_F32, c.p("dense1_w"), CRNN_F32, gA, c.gdt(), TB, d.feat, d.tds, d.tds, d.tds, d.feat, nullptr, 0, 0, 0, conv_planes(cfg, true)));
+  int rc1 = CRNN_ERR_UNSUPPORTED;
+  if (wres1) rc1 = crnn_gemm_wres_bf16(c.w("gbm16"), reinterpret_cast<const bf16_t*>(c.w("pbf")) + c.L.off("dense1_w"), gA, TB, d.feat, d.tds, stream);
+  if (rc1 != CRNN_OK && rc1 != CRNN_ERR_UNSUPPORTED) return rc1;
+  if (rc1 != CRNN_OK)
+    CRNN_TRY(gemm_t(c, 1, c.w("gbm"), CRNN_F32, c.p("dense1_w"), CRNN_F32, gA, c.gdt(), TB, d.feat, d.tds, d.tds, d.tds, d.feat, nullptr, 0, 0, 0, conv_planes(cfg, true)));
   return flush_deferred(c);                             // every gradient of this stage is final (a data-parallel host exchanges them now)
 }
 

@@ -416,6 +416,8 @@ int crnn_dropout_keep_bytes(void* out, long ngroups, float rate, uint64_t seed, 
 int crnn_dropout_keep_bytes_batch(int n, void* const* out, const long* ngroups, const uint32_t* layer, float rate, uint64_t seed, crnn_stream_t stream);
 int crnn_relu_bwd(const float* y, const float* g, float* go, long rows, int C, float scale, int permP,
                   crnn_stream_t stream);
+/* the same with a bf16 copy of the result (go_bf16, may be NULL; round to nearest even) -- round 5: dense1's data gradient runs on the weights-resident GEMM */
+int crnn_relu_bwd_ex(const float* y, const float* g, float* go, void* go_bf16, long rows, int C, float scale, int permP, crnn_stream_t stream);
 /* spatial transformer pieces (utils.py:116-258) */
 int crnn_maxpool_fwd(const float* x, float* y, int B, int H, int W, int C, int ph, int pw, crnn_stream_t stream);
 int crnn_maxpool_bwd(const float* x, const float* gy, float* gx, int B, int H, int W, int C, int ph, int pw,
@@ -477,7 +479,8 @@ int crnn_gemm_nt_bf16(const void* X, const void* W, void* Y, int M, int N, int K
 /* The same product with the weights RESIDENT IN REGISTERS (gemm_wres.hip): a workgroup owns 128 output channels, each of its four MFMA
  * waves holds 32 channels x K of W as MFMA operand fragments for the whole launch, only the pixel rows stream (LDS-DMA ring of 8 x 16 KiB
  * per CU), the N/128 channel slices of a pixel stripe run on one XCD so HBM sees the stripe once.  Bit-identical to crnn_gemm_nt_bf16.
- * Supported (else -3): N % 128 == 0, N <= 1024, K in {64, 128, 256, 512}, 16-byte aligned pointers. */
+ * Supported (else -3): N % 128 == 0, N <= 1024 (K <= 128: N <= 8192 -- round 5, dense1's data gradient: more slices than an XCD has CUs, one workgroup per
+ * slice and stripe lane), K in {64, 128, 256, 512}, 16-byte aligned pointers. */
 int crnn_gemm_wres_supported(int N, int K);
 int crnn_gemm_wres_bf16(const void* X, const void* W, void* Y, int M, int N, int K, crnn_stream_t stream);
 /* The same product as the data gradient da = dq . W^T of a depthwise-separable block (utils.py:45-49 backwards), with the statistics pass of

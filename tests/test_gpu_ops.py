@@ -1453,12 +1453,13 @@ def test_persistent_nt_gemm_equals_the_tile_kernel(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 128, 64), (1000, 256, 128), (129, 512, 256), (4097, 256, 512), (128 * 300 + 5, 128, 256),
-                                   (128 * 2100 + 77, 512, 512), (70000, 384, 128), (5, 1024, 64)])
+                                   (128 * 2100 + 77, 512, 512), (70000, 384, 128), (5, 1024, 64), (52 * 256, 4608, 128), (52 * 64 + 3, 4608, 128), (900, 1152, 64)])
 def test_weights_resident_gemm_equals_the_tile_kernel(M, N, K):
     """crnn_gemm_wres_bf16 (weight fragments resident in registers, pixel rows through an LDS-DMA ring of 8 stages, channel
     slices of a stripe on one XCD, fragments of the next stage read ahead of the barrier) against crnn_gemm_bf16_ex mode 1:
     same MFMA, same k order -> the very same bf16 result; and against an fp64 product.  Ragged M, 1..8 channel slices, K of
-    1..8 stages, fewer stripes than workgroups, more stripes than the ring is deep times the grid (long persistent loops)."""
+    1..8 stages, fewer stripes than workgroups, more stripes than the ring is deep times the grid (long persistent loops); round 5: 36 and 9 slices
+    (more than an XCD has CUs: dense1's data gradient at K <= 128)."""
     rs = np.random.RandomState(M + N + K)
     X = _bf16_round(rs.normal(size=(M, K))); W = _bf16_round(rs.normal(size=(N, K)) * 0.2)
     Xd, Wd = _to_bf16_dev(X), _to_bf16_dev(W)
@@ -1474,7 +1475,7 @@ def test_weights_resident_gemm_equals_the_tile_kernel(M, N, K):
         ref = X @ W.T
         assert_close(Y[:M].float().cpu().numpy(), ref, rtol=1e-2, atol=1e-2 * np.abs(ref).max(), what="wres gemm vs fp64")
     assert L().crnn_gemm_wres_bf16(P(Xd), P(Wd), P(Y), M, 64, K, S()) == -3 and L().crnn_gemm_wres_supported(N, 192) == -3
-    assert L().crnn_gemm_wres_supported(1152, 64) == -3
+    assert L().crnn_gemm_wres_supported(1152, 256) == -3 and L().crnn_gemm_wres_supported(8320, 128) == -3 and L().crnn_gemm_wres_supported(1152, 64) == 0
 
 
 @pytest.mark.parametrize("M,N,K", [(128 * 3, 128, 256), (128 * 41, 256, 256), (128 * 300, 256, 512), (128 * 531, 512, 512), (128 * 936, 512, 512), (128 * 7488, 128, 256),
