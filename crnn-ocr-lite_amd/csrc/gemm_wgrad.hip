@@ -38,6 +38,8 @@ struct WgParams {
   int nsplit;        // reduction ranges; grid = 8 * ceil(TI * TJ * nsplit / 8) workgroups, id -> (xcd, tile, range) below
   int per;           // chunks per range (the last range may be shorter)
   int lda, ldg;      // row strides of D and G in elements (bf16 convs: K and N)
+  int flat;          // more tiles than an XCD has CUs (round 5, dense1: 36): grid = tiles * nsplit, id -> (tile = id % tiles, range = id / tiles) -- a range's
+                     // tiles spread over the XCDs (one XCD would run 32 of them and then the other 4: twice the time, measured)
 #ifdef CRNN_WG_TRACE
   unsigned long long* trace;   // [2][64][4] s_memrealtime stamps of workgroup 8: IO wave 4, MFMA wave 0
 #endif
@@ -68,7 +70,8 @@ __device__ __forceinline__ bf16x8_t wg_frag(const unsigned char* Xs, int r0, int
 
 // F32: both operands are fp32 tensors rounded to bf16 on the way in (v_cvt_pk_bf16_f32, RNE -- what the tile GEMM does while it stages
 // them), no BatchNorm transform: the weight gradients of the recurrent layers, dW = X^T dZ and dU = H^T dZ over the T*B rows
-template <int NIO, bool F32>   // IO waves (4 or 8): 16 / NIO 8-channel pieces of each operand per lane and chunk
+// XF = false (bf16 operands): no BatchNorm transform either -- round 5, dense1's weight gradient dW1 = x7^T gbm over bf16 tensors
+template <int NIO, bool F32, bool XF = true>   // IO waves (4 or 8): 16 / NIO 8-channel pieces of each operand per lane and chunk
 __global__ __launch_bounds__(256 + 64 * NIO) void pw_wgrad_stream_kernel(WgParams p) {
   constexpr int NP = 16 / NIO, RW = F32 ? 2 : 1;              // 16-byte registers per piece
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // kRing x (A stage | B stage)
@@ -77,8 +80,8 @@ __global__ __launch_bounds__(256 + 64 * NIO) void pw_wgrad_stream_kernel(WgParam
   // workgroup -> (xcd, local) -> (range, tile): the tiles of a range are neighbours on one XCD
   const int wg = blockIdx.x, x = wg & 7, loc = wg >> 3;
   const int tiles = p.TI * p.TJ;
-  const int lin = loc % tiles, rloc = loc / tiles;              // tile, range index within this XCD
-  const int split = rloc * 8 + x;
+  const int lin = p.flat ? wg % tiles : loc % tiles, rloc = loc / tiles;   // tile, range index within this XCD
+  const int split = p.flat ? wg / tiles : rloc * 8 + x;
   if (split >= p.nsplit) return;
   const int ti = lin / p.TJ, tj = lin % p.TJ;
   const int c0 = split * p.per;
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(256 + 64 * NIO) void pw_wgrad_stream_kernel(WgParam
   const int c16 = lane & 15;                                    // 16-byte piece of a 256-byte tile row: channels 8 c16 .. +7
   const int pxl = w * 4 + (lane >> 4);                          // pixel row within a group of 4 NIO (chunk = NP groups)
   f32x2_t sc[4], sh[4];
-  if constexpr (!F32) {
+  if constexpr (!F32 && XF) {
     const float* s = p.scale + ti * 128 + c16 * 8; const float* t = p.shift + ti * 128 + c16 * 8;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { sc[e] = f32x2_t{s[2 * e], s[2 * e + 1]}; sh[e] = f32x2_t{t[2 * e], t[2 * e + 1]}; }
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256 + 64 * NIO) void pw_wgrad_stream_kernel(WgParam
     if constexpr (F32) { o = round8(xa[0], xa[1]); og = round8(xg[0], xg[1]); }
     else {
       og = xg[0];
-      if (CRNN_WG_EXP & 1) o = xa[0]; else {
+      if ((CRNN_WG_EXP & 1) || !XF) o = xa[0]; else {
         o.x = wg_bnrelu6_pair(xa[0].x, sc[0], sh[0]); o.y = wg_bnrelu6_pair(xa[0].y, sc[1], sh[1]);
         o.z = wg_bnrelu6_pair(xa[0].z, sc[2], sh[2]); o.w = wg_bnrelu6_pair(xa[0].w, sc[3], sh[3]);
       }
@@ -285,13 +288,15 @@ void wg_geom(long M, int N, int K, WgParams& p, int& grid) {
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
   int ns = (cus / tiles) & ~7;                                  // one workgroup per CU, a multiple of 8 ranges (8 XCDs)
-  if (ns < 8) ns = 8;
+  p.flat = tiles > cus / 8;
+  if (p.flat) ns = cus / tiles < 1 ? 1 : cus / tiles;           // more tiles than an XCD has CUs (dense1: 36): cus / tiles ranges, one workgroup per CU
+  else if (ns < 8) ns = 8;
   while (ns > 8 && p.chunks / ns < 2 * kD) ns -= 8;             // a range is at least two pipeline depths long
   if (ns > p.chunks) ns = p.chunks;                             // (tiny inputs: ranges of one chunk; some of the 8 XCD lanes stay empty)
   p.nsplit = ns;
   p.per = cdiv(p.chunks, ns);
   p.nsplit = cdiv(p.chunks, p.per);                             // drop empty tail ranges
-  grid = 8 * cdiv(p.nsplit, 8) * tiles;
+  grid = p.flat ? p.nsplit * tiles : 8 * cdiv(p.nsplit, 8) * tiles;
 }
 
 }  // namespace
@@ -308,7 +313,7 @@ extern "C" size_t crnn_pwconv_wgrad_stream_scratch_bytes(long M, int N, int K) {
   return (size_t)p.nsplit * K * N * sizeof(float);
 }
 namespace {
-template <bool F32>
+template <bool F32, bool XF = true>
 int wg_launch(WgParams& p, long M, float* out, int ldc, float* scratch, size_t scratch_bytes, hipStream_t stream, crnn_sum_job* defer = nullptr) {
   int grid;
   wg_geom(M, p.N, p.K, p, grid);
@@ -317,10 +322,10 @@ int wg_launch(WgParams& p, long M, float* out, int ldc, float* scratch, size_t s
 #endif
   if ((size_t)p.nsplit * p.K * p.N * sizeof(float) > scratch_bytes) return CRNN_ERR_UNSUPPORTED;
   const int lds = kRing * 2 * kOp;
-  CRNN_LDS_ATTR((pw_wgrad_stream_kernel<4, F32>), lds);
-  CRNN_LDS_ATTR((pw_wgrad_stream_kernel<8, F32>), lds);
-  if (crnn_knob("CRNN_WG_NIO", 8) == 4) hipLaunchKernelGGL((pw_wgrad_stream_kernel<4, F32>), dim3(grid), dim3(512), lds, stream, p);
-  else hipLaunchKernelGGL((pw_wgrad_stream_kernel<8, F32>), dim3(grid), dim3(768), lds, stream, p);
+  CRNN_LDS_ATTR((pw_wgrad_stream_kernel<4, F32, XF>), lds);
+  CRNN_LDS_ATTR((pw_wgrad_stream_kernel<8, F32, XF>), lds);
+  if (crnn_knob("CRNN_WG_NIO", 8) == 4) hipLaunchKernelGGL((pw_wgrad_stream_kernel<4, F32, XF>), dim3(grid), dim3(512), lds, stream, p);
+  else hipLaunchKernelGGL((pw_wgrad_stream_kernel<8, F32, XF>), dim3(grid), dim3(768), lds, stream, p);
   CRNN_LAUNCH_CHECK();
   const long total = (long)p.K * p.N;
   if (defer) {   // the caller batches the second stage (crnn_wgrad_sum_batch); `scratch` must stay untouched until then
@@ -386,6 +391,32 @@ extern "C" int crnn_gemm_tn_stream_defer(const float* A, int lda, const float* B
 extern "C" int crnn_gemm_tn_stream(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, long K, float* scratch,
                                    size_t scratch_bytes, hipStream_t stream) {
   return crnn_gemm_tn_stream_defer(A, lda, B, ldb, C, ldc, M, N, K, scratch, scratch_bytes, nullptr, stream);
+}
+
+// The same stream for bf16 operands without a transform (round 5): C[M][N] (fp32, row stride ldc) = A^T . B, A [K][lda >= M] bf16, B [K][ldb >= N]
+// bf16, the reduction over the K rows -- dense1's weight gradient dW1 [feat][tds] = x7^T . gbm over T*B rows (M = feat = 4608: 36 tiles of 128
+// features, cus / 36 = 7 row ranges).  Supported (else -3): M % 128 == 0 up to 8192, N % 128 == 0 up to 1024, K % 64 == 0, leading dimensions
+// multiples of 8, 16-byte aligned pointers; scratch: crnn_gemm_tn_bf16_stream_scratch_bytes.
+extern "C" int crnn_gemm_tn_bf16_stream_supported(int M, int N, long K) {
+  return (K >= 64 && K % 64 == 0 && N >= 128 && N % 128 == 0 && M >= 128 && M % 128 == 0 && N <= 1024 && M <= 8192 &&
+          K * (long)(M > N ? M : N) < (1L << 31)) ? CRNN_OK : CRNN_ERR_UNSUPPORTED;
+}
+extern "C" size_t crnn_gemm_tn_bf16_stream_scratch_bytes(int M, int N, long K) {
+  if (crnn_gemm_tn_bf16_stream_supported(M, N, K) != CRNN_OK) return 0;
+  WgParams p; int grid; wg_geom(K, N, M, p, grid);
+  return (size_t)p.nsplit * M * N * sizeof(float);
+}
+extern "C" int crnn_gemm_tn_bf16_stream(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, long K, float* scratch,
+                                        size_t scratch_bytes, hipStream_t stream) {
+  if (!A || !B || !C || !scratch) return CRNN_ERR_ARG;
+  CRNN_TRY(crnn_gemm_tn_bf16_stream_supported(M, N, K));
+  if (lda < M || ldb < N || ldc < N || ((lda | ldb) & 7) || (ldc & 3)) return CRNN_ERR_UNSUPPORTED;
+  if ((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)scratch) & 15)) return CRNN_ERR_UNSUPPORTED;
+  if (K * (long)(lda > ldb ? lda : ldb) >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;
+  WgParams p;
+  p.D = (const bf16_t*)A; p.G = (const bf16_t*)B; p.part = scratch; p.scale = nullptr; p.shift = nullptr;
+  p.M = (int)K; p.N = N; p.K = M; p.lda = lda; p.ldg = ldb;
+  return wg_launch<false, false>(p, K, C, ldc, scratch, scratch_bytes, stream, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

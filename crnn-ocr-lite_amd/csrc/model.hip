@@ -1072,7 +1072,12 @@ int backward_top(const Ctx& c0, const int* labels, const int* input_length, cons
   const bool wres1 = dense1_dgrad_wres(cfg, d);
   CRNN_TRY(crnn_relu_bwd_ex(c.w("dn1"), c.w("ddn1"), c.w("gbm"), wres1 ? c.w("gbm16") : nullptr, TB, d.tds, cfg->dropout ? 1.0f / (1.0f - kDropDense1) : 1.0f, B, stream));
   const float* feat = c.w("x7");
-  CRNN_TRY(gemm_t(c, 2, feat, c.dt("x7"), c.w("gbm"), CRNN_F32, c.g("dense1_w"), CRNN_F32, d.feat, d.tds, TB, d.feat, d.tds, d.tds, nullptr, 0, 0, 0, conv_planes(cfg, true)));
+  int rcw = CRNN_ERR_UNSUPPORTED;
+  if (wres1 && c.dt("x7") == CRNN_BF16)   // both operands bf16: the pixel-streaming weight-gradient kernel, 36 feature tiles x 7 row ranges (gemm_wgrad.hip)
+    rcw = crnn_gemm_tn_bf16_stream(feat, d.feat, c.w("gbm16"), d.tds, c.g("dense1_w"), d.tds, d.feat, d.tds, TB, c.scratch(), kGemmScratchBytes, stream);
+  if (rcw != CRNN_OK && rcw != CRNN_ERR_UNSUPPORTED) return rcw;
+  if (rcw != CRNN_OK)
+    CRNN_TRY(gemm_t(c, 2, feat, c.dt("x7"), c.w("gbm"), CRNN_F32, c.g("dense1_w"), CRNN_F32, d.feat, d.tds, TB, d.feat, d.tds, d.tds, nullptr, 0, 0, 0, conv_planes(cfg, true)));
   CRNN_TRY(colsum(c, c.w("gbm"), TB, d.tds, d.tds, c.g("dense1_b")));
   float* gA = c.w("gA"); float* gB = c.w("gB");
   int rc1 = CRNN_ERR_UNSUPPORTED;

@@ -566,6 +566,14 @@ int crnn_pwconv_bnrelu6_wgrad_stream(const void* d, const float* in_bnstate, con
  * multiples of 4, 16-byte aligned pointers; scratch: crnn_pwconv_wgrad_stream_scratch_bytes(K, N, M). */
 int crnn_gemm_tn_stream(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, long K, float* scratch,
                         size_t scratch_bytes, crnn_stream_t stream);
+/* The same stream for bf16 operands without a transform (round 5): C[M][N] (fp32, row stride ldc) = A^T . B with A [K][lda >= M], B [K][ldb >= N] bf16
+ * and the reduction over the K rows -- dense1's weight gradient dW1 [feat][tds] = x7^T . gbm (utils.py:73-74 backwards; M = feat = 4608 is 36 tiles of
+ * 128 features: more tiles than an XCD has CUs, so the rows split into cus / 36 ranges).  Supported (else -3): M % 128 == 0 up to 8192, N % 128 == 0 up
+ * to 1024, K % 64 == 0, lda / ldb multiples of 8, ldc of 4, 16-byte aligned pointers. */
+int crnn_gemm_tn_bf16_stream_supported(int M, int N, long K);
+size_t crnn_gemm_tn_bf16_stream_scratch_bytes(int M, int N, long K);
+int crnn_gemm_tn_bf16_stream(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, long K, float* scratch,
+                             size_t scratch_bytes, crnn_stream_t stream);
 /* Deferred second stages.  The two streaming weight-gradient entries above are stage 1 (partial tiles into `scratch`) + stage 2 (a fixed-order
  * sum into the gradient, ~5 us of dependent launch each, 13 per train step).  The *_defer forms run stage 1 only and describe stage 2 in
  * *job; crnn_wgrad_sum_batch runs up to CRNN_SUM_BATCH_MAX of them in ONE launch -- the same sums in the same order, bit-identical

@@ -1626,6 +1626,36 @@ def test_streaming_tn_gemm_on_fp32_operands_equals_the_tile_kernel(M, N, K, lda,
     assert L().crnn_gemm_tn_stream(P(Ad), lda, P(Bd), ldb, P(C1), ldc, M, N, K - 32, P(scratch), ctypes.c_size_t(scratch.numel() * 4), S()) == -3
 
 
+@pytest.mark.parametrize("M,N,K,lda,ldb,ldc", [(4608, 128, 52 * 256, 4608, 128, 128), (4608, 128, 52 * 64, 4608, 128, 128), (1152, 128, 52 * 16, 1152, 128, 128),
+                                               (256, 256, 640, 264, 256, 260), (2304, 128, 64, 2304, 136, 128)])
+def test_streaming_tn_gemm_on_bf16_operands_equals_the_tile_kernel(M, N, K, lda, ldb, ldc):
+    """crnn_gemm_tn_bf16_stream (round 5: dense1's weight gradient dW1 = x7^T gbm on the weight-gradient stream, bf16 operands, no transform; 36 / 9 / 18
+    feature tiles -- more than an XCD has CUs -- over cus / tiles row ranges, a range's tiles spread over the XCDs) against crnn_gemm_bf16_ex
+    mode 2 on the same bf16 operands (other reduction ranges: fp32 summation round-off) and the fp64 product; repeated launches give the same bits;
+    columns of C beyond N stay untouched."""
+    rs = np.random.RandomState(M + N + K % 977)
+    A = _bf16_round(np.maximum(rs.normal(size=(K, lda)), 0) * 2.2); Bm = _bf16_round(rs.normal(size=(K, ldb)) * 0.05)
+    Ad, Bd = _to_bf16_dev(A), _to_bf16_dev(Bm)
+    assert L().crnn_gemm_tn_bf16_stream_supported(M, N, K) == 0
+    nb = L().crnn_gemm_tn_bf16_stream_scratch_bytes(M, N, K)
+    assert 0 < nb <= 64 << 20
+    scratch = torch.empty(nb // 4, dtype=torch.float32, device="cuda")
+    C1 = torch.full((M, ldc), 7.0, device="cuda"); C2 = torch.full((M, ldc), 7.0, device="cuda"); C3 = torch.full((M, ldc), 7.0, device="cuda")
+    ok(L().crnn_gemm_tn_bf16_stream(P(Ad), lda, P(Bd), ldb, P(C1), ldc, M, N, K, P(scratch), nb, S()))
+    scratch.fill_(float("nan"))
+    ok(L().crnn_gemm_tn_bf16_stream(P(Ad), lda, P(Bd), ldb, P(C3), ldc, M, N, K, P(scratch), nb, S()))
+    assert torch.equal(C1, C3)
+    big = torch.empty(16 << 20, dtype=torch.float32, device="cuda")
+    ok(L().crnn_gemm_bf16_ex(2, P(Ad), P(dev(Bm)), P(C2), M, N, K, lda, ldb, ldc, None, 0, 0, 0, P(big), ctypes.c_size_t(big.numel() * 4), 1, 0, 0, S()))      # (bf16 A, fp32 B holding bf16 values: dense1's former call)
+    ref = A[:, :M].T @ Bm[:, :N]
+    tol = (2e-5 + 6e-8 * K / 64) * np.abs(ref).max() + 1e-5 * np.sqrt(K)
+    assert_close(host(C1)[:, :N], host(C2)[:, :N], rtol=1e-4, atol=tol, what="stream vs tile kernel")
+    assert_close(host(C1)[:, :N], ref, rtol=1e-4, atol=tol, what="stream vs fp64")
+    if ldc > N: assert bool((C1[:, N:] == 7.0).all())
+    assert L().crnn_gemm_tn_bf16_stream(P(Ad), lda, P(Bd), ldb, P(C1), ldc, M, N, K, P(scratch), nb - 4, S()) == -3      # short scratch
+    assert L().crnn_gemm_tn_bf16_stream_supported(M + 64, N, K) == -3 and L().crnn_gemm_tn_bf16_stream_supported(8320, 128, 64) == -3
+
+
 @pytest.mark.parametrize("M,N,K", [(128 * 5, 128, 64), (128 * 300 + 17, 256, 256), (128 * 700, 512, 512), (100, 128, 128)])
 def test_weights_resident_inference_conv_with_folded_batchnorm_equals_the_tile_kernel(M, N, K):
     """crnn_pwconv_fwd_wres_folded (predict path: pointwise conv with the following BatchNorm + ReLU6 applied to the fp32 accumulators
