@@ -435,10 +435,14 @@ struct NtsParams {
   float* Y;
   const float* bias;                        // optional [N total]: added to the finished sums (fp32), as the tile GEMM's epilogue does
   int M, N, K, lda, ldw, ldy, npairs;       // N = columns per workgroup (128 CB); blockIdx.y selects the column slab
+  // dense1's epilogue (ABF instantiation, round 5): ReLU, the rows written in permuted order out_row = (m % permP) * (M / permP) + m / permP (batch-major
+  // rows to time-major, as crnn_gemm_f32's permP; 0: none), Dropout of site `layer` over the compact [M][ldy] index space of the OUTPUT rows
+  int relu = 0, permP = 0; float drop_rate = 0.f; uint64_t seed = 0; uint32_t layer = 0;
 };
 constexpr int kNtsRing = 3, kNtsD = 2;
 
-template <int CB>   // 32-channel blocks per MFMA wave: N = 128 CB
+// ABF: the A operand is a bf16 tensor (p.A reinterpreted; no rounding on the way in) and the epilogue is dense1's (bias, ReLU, row permutation, Dropout)
+template <int CB, bool ABF = false>   // 32-channel blocks per MFMA wave: N = 128 CB
 __global__ __launch_bounds__(768) void gemm_nt_f32_stream_kernel(NtsParams p) {
   constexpr int N = 128 * CB;
   constexpr int kX = 64 * 128, kW = N * 128, kSt = kX + kW;   // bytes of a stage: 64 rows x 64 k bf16 | N weight rows x 64 k bf16
@@ -448,6 +452,7 @@ __global__ __launch_bounds__(768) void gemm_nt_f32_stream_kernel(NtsParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m0 = blockIdx.x * 64, n0 = blockIdx.y * N;          // row stripe, column slab (weight rows n0 .. n0 + N - 1)
   const int kch = p.K / 64, total = kch * p.npairs;
+  constexpr int ND = ABF ? 4 : kNtsD;                           // stages a lane has in flight (dense1: 72 chunks per stripe, every one a load round trip of ~1.3 us at depth 2)
 
   if (wave < 4) {
     const int half = lane >> 5, l31 = lane & 31, sw = (l31 >> 1) & 7;
@@ -483,13 +488,24 @@ __global__ __launch_bounds__(768) void gemm_nt_f32_stream_kernel(NtsParams p) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const int col0 = n0 + wave * 32 * CB + 4 * half;
-      float* yrow = p.Y + (long)(m0 + 32 * b + l31) * p.ldy + col0;
+      long orow = m0 + 32 * b + l31;
+      if (ABF && p.permP) orow = (orow % p.permP) * (p.M / p.permP) + orow / p.permP;
+      float* yrow = p.Y + orow * p.ldy + col0;
+      const float inv_keep = (ABF && p.drop_rate > 0.f) ? 1.f / (1.f - p.drop_rate) : 1.f;
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           float4 v = make_float4(acc[b][cb][4 * g], acc[b][cb][4 * g + 1], acc[b][cb][4 * g + 2], acc[b][cb][4 * g + 3]);
           if (p.bias) { const float4 bv = *reinterpret_cast<const float4*>(p.bias + col0 + 32 * cb + 8 * g); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+          if constexpr (ABF) {
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (p.drop_rate > 0.f) {          // the multipliers crnn_dropout applies to elements orow * ldy + col .. + 3 (ldy == the row length there)
+              float dm[4];
+              drop_scale_vec<4>(p.seed, p.layer, (uint64_t)(orow * p.ldy + col0 + 32 * cb + 8 * g), p.drop_rate, inv_keep, dm);
+              v.x *= dm[0]; v.y *= dm[1]; v.z *= dm[2]; v.w *= dm[3];
+            }
+          }
           *reinterpret_cast<float4*>(yrow + 32 * cb + 8 * g) = v;
         }
     }
@@ -498,19 +514,24 @@ __global__ __launch_bounds__(768) void gemm_nt_f32_stream_kernel(NtsParams p) {
   // ---------------------------------------------------------------------------- IO waves (8): lane il = 0..511
   const int il = tid - 256;
   const int xr = il >> 3, xc = il & 7;                          // dZ piece: row xr (0..63), 8-k piece xc
-  u32x4 rx[kNtsD][2], rw[kNtsD][WP];
+  u32x4 rx[ND][2], rw[ND][WP];
   auto load = [&](int s, u32x4 (&ax)[2], u32x4 (&aw)[WP]) {
     s = s < total ? s : total - 1;
     const int pr = s / kch, kc = s - pr * kch;
+    if constexpr (ABF) {
+      ax[0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.A[pr]) + (long)(m0 + xr) * p.lda + kc * 64 + xc * 8));
+      ax[1] = ax[0];
+    } else {
     const float* a = p.A[pr] + (long)(m0 + xr) * p.lda + kc * 64 + xc * 8;
     ax[0] = *reinterpret_cast<const u32x4*>(a); ax[1] = *reinterpret_cast<const u32x4*>(a + 4);
+    }
     const bf16_t* w = p.W[pr] + kc * 64 + xc * 8;
 #pragma unroll
     for (int u = 0; u < WP; ++u) aw[u] = *reinterpret_cast<const u32x4*>(w + (long)(n0 + xr + 64 * u) * p.ldw);
   };
   auto write = [&](int s, const u32x4 (&ax)[2], const u32x4 (&aw)[WP]) {
     unsigned char* st = smem + (s % kNtsRing) * kSt;
-    const u32x4 o = {pack2_bf16(__uint_as_float(ax[0].x), __uint_as_float(ax[0].y)), pack2_bf16(__uint_as_float(ax[0].z), __uint_as_float(ax[0].w)),
+    const u32x4 o = ABF ? ax[0] : u32x4{pack2_bf16(__uint_as_float(ax[0].x), __uint_as_float(ax[0].y)), pack2_bf16(__uint_as_float(ax[0].z), __uint_as_float(ax[0].w)),
                      pack2_bf16(__uint_as_float(ax[1].x), __uint_as_float(ax[1].y)), pack2_bf16(__uint_as_float(ax[1].z), __uint_as_float(ax[1].w))};
     *reinterpret_cast<u32x4*>(st + xr * 128 + ((xc ^ ((xr >> 1) & 7)) * 16)) = o;
 #pragma unroll
@@ -522,23 +543,24 @@ __global__ __launch_bounds__(768) void gemm_nt_f32_stream_kernel(NtsParams p) {
   auto step = [&](int s, u32x4 (&ax)[2], u32x4 (&aw)[WP]) {     // buffer (s + 1) % kNtsD
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    write(s + 1, ax, aw); load(s + 1 + kNtsD, ax, aw);
+    write(s + 1, ax, aw); load(s + 1 + ND, ax, aw);
   };
   // barrier s: stage s is written before it; after it the slot of stage s-1 is free; stage s+1 goes into slot (s+1) % 3, which held
   // stage s-2 -- released at barrier s-1
-  load(0, rx[0], rw[0]); load(1, rx[1], rw[1]);
-  write(0, rx[0], rw[0]); load(2, rx[0], rw[0]);
-  int s = 0;
-  for (; s + kNtsD <= total; s += kNtsD) {
 #pragma unroll
-    for (int k = 0; k < kNtsD; ++k) step(s + k, rx[(k + 1) % kNtsD], rw[(k + 1) % kNtsD]);
+  for (int k = 0; k < ND; ++k) load(k, rx[k], rw[k]);
+  write(0, rx[0], rw[0]); load(ND, rx[0], rw[0]);
+  int s = 0;
+  for (; s + ND <= total; s += ND) {
+#pragma unroll
+    for (int k = 0; k < ND; ++k) step(s + k, rx[(k + 1) % ND], rw[(k + 1) % ND]);
   }
 #pragma unroll
-  for (int k = 0; k < kNtsD; ++k)
+  for (int k = 0; k < ND; ++k)
     if (s + k <= total) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (s + k < total) { write(s + k + 1, rx[(k + 1) % kNtsD], rw[(k + 1) % kNtsD]); load(s + k + 1 + kNtsD, rx[(k + 1) % kNtsD], rw[(k + 1) % kNtsD]); }
+      if (s + k < total) { write(s + k + 1, rx[(k + 1) % ND], rw[(k + 1) % ND]); load(s + k + 1 + ND, rx[(k + 1) % ND], rw[(k + 1) % ND]); }
     }
 }
 
@@ -711,6 +733,29 @@ extern "C" int crnn_gemm_nt_f32_stream_bias(const float* A0, const void* W0, con
   CRNN_LDS_ATTR(gemm_nt_f32_stream_kernel<2>, kNtsRing * (64 * 128 + 256 * 128));
   if (slab == 128) hipLaunchKernelGGL(gemm_nt_f32_stream_kernel<1>, dim3(M / 64, N / slab), dim3(768), lds, stream, p);
   else hipLaunchKernelGGL(gemm_nt_f32_stream_kernel<2>, dim3(M / 64, N / slab), dim3(768), lds, stream, p);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}
+// dense1's forward (round 5; utils.py:72-75): Y[perm(m)][N] (fp32) = Dropout(ReLU(X[M][K] . W[N][K]^T + bias)) with X bf16 (block 7's output rows, batch-major),
+// W the bf16 W^T copy, one workgroup per 64-row stripe over the whole K = 4608 reduction (the tile GEMM ran it as 8 reduction ranges + a second stage + a
+// dropout pass: 63 us for 122 MB).  permP / drop_rate / relu as in NtsParams.  Supported (else -3): M % 64 == 0 (and % permP), N = 128 | 256 = ldy,
+// K % 64 == 0, leading dimensions multiples of 8, 16-byte aligned pointers.
+extern "C" int crnn_dense_fwd_stream_supported(long M, int N, long K) {
+  return (M > 0 && M % 64 == 0 && (N == 128 || N == 256) && K >= 64 && K % 64 == 0 && M * (K > N ? K : (long)N) < (1L << 31)) ? CRNN_OK : CRNN_ERR_UNSUPPORTED;
+}
+extern "C" int crnn_dense_fwd_stream(const void* X, const void* WT, const float* bias, float* Y, long M, int N, long K, int lda, int ldw, int relu, int permP,
+                                     float drop_rate, uint64_t seed, uint32_t layer, hipStream_t stream) {
+  if (!X || !WT || !Y || permP < 0 || drop_rate < 0.f || drop_rate >= 1.f) return CRNN_ERR_ARG;
+  CRNN_TRY(crnn_dense_fwd_stream_supported(M, N, K));
+  if (((lda | ldw) & 7) || lda < K || ldw < K || (permP && M % permP)) return CRNN_ERR_UNSUPPORTED;
+  if ((((uintptr_t)X | (uintptr_t)WT | (uintptr_t)Y | (uintptr_t)bias) & 15)) return CRNN_ERR_UNSUPPORTED;
+  NtsParams p;
+  p.A[0] = p.A[1] = reinterpret_cast<const float*>(X); p.W[0] = p.W[1] = (const bf16_t*)WT; p.Y = Y; p.bias = bias;
+  p.M = (int)M; p.N = N; p.K = (int)K; p.lda = lda; p.ldw = ldw; p.ldy = N; p.npairs = 1;
+  p.relu = relu; p.permP = permP; p.drop_rate = drop_rate; p.seed = seed; p.layer = layer;
+  const int lds = kNtsRing * (64 * 128 + N * 128);
+  if (N == 128) { CRNN_LDS_ATTR((gemm_nt_f32_stream_kernel<1, true>), lds); hipLaunchKernelGGL((gemm_nt_f32_stream_kernel<1, true>), dim3((unsigned)(M / 64), 1), dim3(768), lds, stream, p); }
+  else { CRNN_LDS_ATTR((gemm_nt_f32_stream_kernel<2, true>), lds); hipLaunchKernelGGL((gemm_nt_f32_stream_kernel<2, true>), dim3((unsigned)(M / 64), 1), dim3(768), lds, stream, p); }
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }

@@ -100,6 +100,12 @@ long lmax(long a, long b) { return a > b ? a : b; }
 static bool dense2_stream(const crnn_config* cfg, const Dims& d) {
   return cfg->mfma_bf16 && !(cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS) && ((long)d.T * d.B) % 64 == 0 && (2 * d.u) % 64 == 0 && d.C <= 64;
 }
+// dense1's forward on the 64-row stripe stream (gemm_wgrad.hip, crnn_dense_fwd_stream: x7 bf16 against a bf16 W1^T, bias + ReLU + the rows to time-major +
+// Dropout(.4) in the epilogue): bf16 storage mode, whole stripes; CRNN_FLAG_GEMM_TILE_KERNELS keeps the tile GEMM + dropout pass
+static bool dense1_stream(const crnn_config* cfg, const Dims& d) {
+  return cfg->mfma_bf16 == 2 && !(cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS) && d.feat % 8 == 0 &&
+         crnn_dense_fwd_stream_supported((long)d.T * d.B, d.tds, d.feat) == CRNN_OK;
+}
 // dense1's data gradient gA [T*B][feat] = gbm [T*B][tds] . W1^T on the weights-resident GEMM (gemm_wres.hip: 36 slices of 128 features keep their
 // 128 x 128 weights in registers, the 3.4 MB operand streams; bf16 storage mode: both operands and the result are bf16 there anyway -- the same
 // products as the tile GEMM); CRNN_FLAG_GEMM_TILE_KERNELS off
@@ -227,7 +233,7 @@ Plan make_plan(const crnn_config* c) {
   { long pw = 0; for (int i = 2; i <= 7; ++i) pw += (long)d.bc[i - 1] * d.bc[i];
     // bf16 W^T copies of the pointwise-conv weights (bf16 modes) + dense2's W^T as 128 rows of 2u (rows >= num_classes are never written: the streaming
     // GEMM's columns for them are never read -- dense2_stream below)
-    P.add("pwT", pw + 128L * 2 * d.u, CRNN_BF16); }
+    P.add("pwT", pw + 128L * 2 * d.u + (dense1_stream(c, d) ? (long)d.feat * d.tds : 0), CRNN_BF16); }   // (+ dense1's W^T [tds][feat], dense1_stream)
   if (c->mfma_bf16) P.add("lg128", TB * 128);   // dense2's raw products over the padded weight matrix
   if (dense2_bwd_fused(c, d)) {
     P.add("d2part", (long)(crnn_dense_bwd_small_scratch_bytes(TB, 2 * d.u, d.C) / sizeof(float)));   // per-workgroup partial gradients of dense2
@@ -598,6 +604,7 @@ extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, cons
   // bf16 modes: W^T (bf16) copies of the pointwise weights of blocks 2..7, one launch
   long pwT_off[8]; for (int i = 0; i < 8; ++i) pwT_off[i] = -1;
   long d2T_off = -1;                       // element offset of dense2's padded W^T inside "pwT" (dense2_stream)
+  long d1T_off = -1;                       // ... of dense1's W^T (dense1_stream)
   if (cfg->mfma_bf16) {
     long in_off[8], out_off[8]; int R[8], Cc[8]; int n = 0; long acc = 0;
     for (int i = 2; i <= 7; ++i) {
@@ -608,6 +615,10 @@ extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, cons
     }
     if (dense2_stream(cfg, d) && n < 8) {   // dense2's W [2u][C] -> W^T rows 0..C-1 of a 128-row matrix behind the pointwise copies
       in_off[n] = c.L.off("dense2_w"); out_off[n] = acc; R[n] = 2 * d.u; Cc[n] = d.C; d2T_off = acc; ++n;
+    }
+    acc += 128L * 2 * d.u;
+    if (dense1_stream(cfg, d) && n < 8) {   // dense1's W [feat][tds] -> W^T [tds][feat] behind it
+      in_off[n] = c.L.off("dense1_w"); out_off[n] = acc; R[n] = d.feat; Cc[n] = d.tds; d1T_off = acc; ++n;
     }
     if (n) CRNN_TRY(crnn_transpose_batch(params, c.w("pwT"), n, in_off, out_off, R, Cc, CRNN_BF16, stream));
   }
@@ -757,8 +768,15 @@ extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, cons
   if (keep_pending) { CRNN_TRY(fj.join()); keep_pending = false; }
   // ---- Reshape + dense1 (relu) + Dropout(.4) (utils.py:72-75); output time-major [T][B][tds]
   const int T = d.T, TB = T * B, u = d.u, G = d.G;
-  CRNN_TRY(gemm_t(c, 0, in, c.dt("x7"), c.p("dense1_w"), CRNN_F32, c.w("dn1"), CRNN_F32, TB, d.tds, d.feat, d.feat, d.tds, d.tds, c.p("dense1_b"), 1, 0, T));
-  if (train && cfg->dropout) CRNN_TRY(crnn_dropout(c.w("dn1"), c.w("dn1"), TB, d.tds, d.tds, d.tds, kDropDense1, seed, kLayerDense1, stream));
+  int rc1 = CRNN_ERR_UNSUPPORTED;
+  if (d1T_off >= 0 && c.dt("x7") == CRNN_BF16)
+    rc1 = crnn_dense_fwd_stream(in, reinterpret_cast<const bf16_t*>(c.w("pwT")) + d1T_off, c.p("dense1_b"), c.w("dn1"), TB, d.tds, d.feat, d.feat, d.feat, 1, T,
+                                (train && cfg->dropout) ? kDropDense1 : 0.f, seed, kLayerDense1, stream);
+  if (rc1 != CRNN_OK && rc1 != CRNN_ERR_UNSUPPORTED) return rc1;
+  if (rc1 != CRNN_OK) {
+    CRNN_TRY(gemm_t(c, 0, in, c.dt("x7"), c.p("dense1_w"), CRNN_F32, c.w("dn1"), CRNN_F32, TB, d.tds, d.feat, d.feat, d.tds, d.tds, c.p("dense1_b"), 1, 0, T));
+    if (train && cfg->dropout) CRNN_TRY(crnn_dropout(c.w("dn1"), c.w("dn1"), TB, d.tds, d.tds, d.tds, kDropDense1, seed, kLayerDense1, stream));
+  }
   // ---- 2 x Bidirectional(LSTM) (utils.py:78-79)
   // bf16 modes: the recurrent products run on the bf16 MFMA from a bf16 U^T (u % 128 == 0); parity mode: fp32
   const int dtu = rnn_dtu(cfg);

@@ -574,6 +574,14 @@ int crnn_gemm_tn_bf16_stream_supported(int M, int N, long K);
 size_t crnn_gemm_tn_bf16_stream_scratch_bytes(int M, int N, long K);
 int crnn_gemm_tn_bf16_stream(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, long K, float* scratch,
                              size_t scratch_bytes, crnn_stream_t stream);
+/* dense1's forward (round 5; utils.py:72-75): Y[perm(m)][N] (fp32, row stride N) = Dropout(ReLU(X[M][K] . WT[N][K]^T + bias)) -- X bf16 (row stride lda), WT the
+ * bf16 W^T copy (row stride ldw), one workgroup per 64-row stripe over the whole reduction (the recurrent layers' stripe stream with a bf16 operand);
+ * relu 0 | 1; permP: rows written at (m % permP) * (M / permP) + m / permP (0: in place; batch-major rows to time-major as crnn_gemm_f32's permP);
+ * drop_rate > 0: the multipliers crnn_dropout applies to the compact [M][N] output for (seed, layer).  Supported (else -3): M % 64 == 0, N = 128 | 256,
+ * K % 64 == 0, lda / ldw multiples of 8, 16-byte aligned pointers. */
+int crnn_dense_fwd_stream_supported(long M, int N, long K);
+int crnn_dense_fwd_stream(const void* X, const void* WT, const float* bias, float* Y, long M, int N, long K, int lda, int ldw, int relu, int permP,
+                          float drop_rate, uint64_t seed, uint32_t layer, crnn_stream_t stream);
 /* Deferred second stages.  The two streaming weight-gradient entries above are stage 1 (partial tiles into `scratch`) + stage 2 (a fixed-order
  * sum into the gradient, ~5 us of dependent launch each, 13 per train step).  The *_defer forms run stage 1 only and describe stage 2 in
  * *job; crnn_wgrad_sum_batch runs up to CRNN_SUM_BATCH_MAX of them in ONE launch -- the same sums in the same order, bit-identical

@@ -1626,6 +1626,41 @@ def test_streaming_tn_gemm_on_fp32_operands_equals_the_tile_kernel(M, N, K, lda,
     assert L().crnn_gemm_tn_stream(P(Ad), lda, P(Bd), ldb, P(C1), ldc, M, N, K - 32, P(scratch), ctypes.c_size_t(scratch.numel() * 4), S()) == -3
 
 
+@pytest.mark.parametrize("M,N,K,T,rate", [(52 * 64, 128, 4608, 52, 0.4), (52 * 256, 128, 4608, 52, 0.4), (64 * 3, 256, 192, 0, 0.0), (26 * 64, 128, 1152, 26, 0.25)])
+def test_dense_forward_stream_with_relu_row_permutation_and_dropout(M, N, K, T, rate):
+    """crnn_dense_fwd_stream (round 5: dense1's forward on the 64-row stripe stream, bf16 x7 against a bf16 W^T; bias + ReLU + the rows batch-major ->
+    time-major + Dropout in the epilogue) against the fp64 evaluation of the bf16 operands (fp32 accumulation over K: 2e-5 of the scale) with the
+    multipliers crnn_dropout_mask gives the site; dropped and clamped elements are exact zeros; repeated launches give the same bits."""
+    rs = np.random.RandomState(M + N + K)
+    X = _bf16_round(np.maximum(rs.normal(size=(M, K)), 0) * 2.0); WT = _bf16_round(rs.normal(size=(N, K)) * 0.02); bias = rs.normal(size=N).astype(np.float32) * 0.5
+    Xd, Wd, bd = _to_bf16_dev(X), _to_bf16_dev(WT), dev(bias)
+    seed, layer = 4242 + M, 8
+    assert L().crnn_dense_fwd_stream_supported(M, N, K) == 0
+    Y = torch.full((M + 2, N), 9.0, device="cuda"); Y2 = torch.full((M + 2, N), 9.0, device="cuda")
+    ok(L().crnn_dense_fwd_stream(P(Xd), P(Wd), P(bd), P(Y), M, N, K, K, K, 1, T, rate, seed, layer, S()))
+    ok(L().crnn_dense_fwd_stream(P(Xd), P(Wd), P(bd), P(Y2), M, N, K, K, K, 1, T, rate, seed, layer, S()))
+    assert torch.equal(Y, Y2) and bool((Y[M:] == 9.0).all())
+    want = np.maximum(X @ WT.T + bias.astype(np.float64), 0.0)
+    if T:
+        m = np.arange(M); orow = (m % T) * (M // T) + m // T
+        perm = np.empty_like(want); perm[orow] = want; want = perm
+    mask = torch.ones(M * N, device="cuda")
+    if rate > 0:
+        ok(L().crnn_dropout_mask(P(mask), M * N, rate, seed, layer, S()))
+    mask = host(mask).reshape(M, N).astype(np.float64)
+    want = want * mask
+    got = host(Y[:M])
+    assert_close(got, want, rtol=2e-5, atol=2e-5 * np.abs(want).max(), what="dense forward stream")
+    assert (got[mask == 0] == 0).all() and (got >= 0).all()
+    Y3 = torch.empty(M, N, device="cuda")       # no ReLU, no permutation, no dropout: the plain product + bias
+    ok(L().crnn_dense_fwd_stream(P(Xd), P(Wd), P(bd), P(Y3), M, N, K, K, K, 0, 0, 0.0, seed, layer, S()))
+    plain = X @ WT.T + bias.astype(np.float64)
+    assert_close(host(Y3), plain, rtol=2e-5, atol=2e-5 * np.abs(plain).max(), what="plain product")
+    assert L().crnn_dense_fwd_stream_supported(M + 32, N, K) == -3 and L().crnn_dense_fwd_stream_supported(M, 384, K) == -3 and L().crnn_dense_fwd_stream_supported(M, N, K + 32) == -3
+    if T:
+        assert L().crnn_dense_fwd_stream(P(Xd), P(Wd), P(bd), P(Y), M, N, K, K, K, 1, T + 1 if M % (T + 1) else T + 7, rate, seed, layer, S()) == -3      # rows not a multiple of permP
+
+
 @pytest.mark.parametrize("M,N,K,lda,ldb,ldc", [(4608, 128, 52 * 256, 4608, 128, 128), (4608, 128, 52 * 64, 4608, 128, 128), (1152, 128, 52 * 16, 1152, 128, 128),
                                                (256, 256, 640, 264, 256, 260), (2304, 128, 64, 2304, 136, 128)])
 def test_streaming_tn_gemm_on_bf16_operands_equals_the_tile_kernel(M, N, K, lda, ldb, ldc):
