@@ -260,7 +260,7 @@ def test_bench_counter_traffic_lookup_and_contract_fields():
     nt = bench.pmc_step_traffic(eng(), ["gemm_nt_f32_proj_kernel"])
     assert nt is not None and nt[1] == 2                                      # the two layers' input projections (both directions per launch)
     one = bench.pmc_step_traffic(eng(), ["gemm_nt_f32_stream_kernel"], {"gemm_nt_f32_stream_kernel": {159744}})
-    assert one is not None and one[1] == 2                                    # (grid filter: the two backward launches of the stripe kernel, <1> and <2>)
+    assert one is not None and one[1] == 4                                    # (grid filter: the stripe kernel's four launches -- dense1 and dense2 forward, the two layers' input gradients)
     for other in (eng(B=64), eng(imgh=200), eng(gru=1), eng(flags=1024), eng(imgw=48)):
         assert bench.pmc_step_traffic(other, ["dw_bwd_stream_kernel"]) is None and bench.pmc_mfma_util(other, ["gemm_wres_fwd_kernel"]) is None
     mf = bench.pmc_mfma_util(eng(), ["gemm_wres_fwd_kernel", "lstm_fwd_persist_kernel", "no_such_kernel"])
