@@ -356,8 +356,14 @@ def pointwise_gemm_roofline(eng, iters=5):
     feat = w * cin
     TB = T * B
     scratch = eng.ws_tensor("gemm_scratch"); parts = eng.ws_tensor("partials")
-    cfgs.append((eng.ws_tensor("x7"), W("dense1_w"), eng.ws_tensor("gA"), TB, eng.cfg.tds, feat, sdt, 0, 0))
     u, G = eng.cfg.units, (3 if eng.cfg.gru else 4) * eng.cfg.units
+    # bf16s: dense1 on the step's own kernel (round 5: the 64-row stripe stream over the bf16 W1^T the forward keeps behind the pointwise copies and dense2's
+    # padded W^T in "pwT"; bias + ReLU + row permutation + Dropout(.4) in the epilogue), else the tile GEMM
+    d1s = eng.precision == "bf16s" and not (eng.cfg.flags & 2) and feat % 8 == 0 and lib.crnn_dense_fwd_stream_supported(TB, eng.cfg.tds, feat) == 0
+    if d1s:
+        cfgs.append((eng.ws_tensor("x7"), None, eng.ws_tensor("gA"), TB, eng.cfg.tds, feat, sdt, 0, ("d1", pwT[toff + 128 * 2 * u:])))
+    else:
+        cfgs.append((eng.ws_tensor("x7"), W("dense1_w"), eng.ws_tensor("gA"), TB, eng.cfg.tds, feat, sdt, 0, 0))
     for l, src, k in (("1", "dn1", eng.cfg.tds), ("2", "r1", u)):
         # bf16 modes: the step's own kernel -- both directions of a layer in one launch of persistent workgroups on the bf16 W^T copies the forward keeps
         # (model.hip xw2 / crnn_rnn_input_proj; round 5) --, else one tile GEMM per direction
@@ -377,6 +383,8 @@ def pointwise_gemm_roofline(eng, iters=5):
         for A, Bm, C, M, N, K, dta, dtc, wt in cfgs:
             if isinstance(wt, tuple) and wt[0] == "xw2":      # (both outputs into the scratch tensor: G columns each, the second half behind the first's rows)
                 lib.crnn_rnn_input_proj(_ptr(A), _ptr(wt[1]), _ptr(wt[2]), None, None, _ptr(C), ctypes.c_void_p(C.data_ptr() + M * (N // 2) * 4), M, N // 2, K, K, K, N // 2, _stream())
+            elif isinstance(wt, tuple) and wt[0] == "d1":
+                lib.crnn_dense_fwd_stream(_ptr(A), _ptr(wt[1]), None, _ptr(C), M, N, K, K, K, 1, T, 0.4, 0, 8, _stream())
             elif isinstance(wt, tuple):
                 if not (eng.cfg.flags & 2) and lib.crnn_pwconv_fwd_wres_supported(M, N, K) == 0:
                     lib.crnn_pwconv_bnrelu6_fwd_wres(_ptr(A), _ptr(wt[1]), _ptr(Bm), _ptr(C), M, N, K, _ptr(parts), _stream())
@@ -393,12 +401,12 @@ def pointwise_gemm_roofline(eng, iters=5):
             times.append(e0.elapsed_time(e1) * 1e-3)
     t = float(np.median(times))
     ach = flops / t / 1e12
-    kname = ("gemm_wres_fwd_kernel (pointwise 1x1 convs fwd incl. BN+ReLU6 prologue and statistics) + gemm_bf16_kernel (dense1) + "
+    kname = ("gemm_wres_fwd_kernel (pointwise 1x1 convs fwd incl. BN+ReLU6 prologue and statistics) + gemm_nt_f32_stream_kernel<1, true> (dense1 incl. its ReLU / dropout epilogue) + "
              "gemm_nt_f32_proj_kernel (RNN input projections, both directions of a layer per launch)"
              if any(isinstance(c[8], tuple) and c[8][0] == "pw" for c in cfgs) else
              "gemm_%s_kernel<128,false,true> (pointwise 1x1 convs fwd + dense1 + RNN input GEMMs)" % ("bf16" if bf else "f32"))
-    # memory-side bytes of the same launches in the step (bf16s: the six weights-resident pointwise forwards, dense1's tile GEMM, the four forward input projections)
-    tr = pmc_step_traffic(eng, ["gemm_wres_fwd_kernel", "gemm_bf16_kernel<128, false, true, true, true, false, true, false>", "gemm_nt_f32_proj_kernel"]) \
+    # memory-side bytes of the same launches in the step (bf16s: the six weights-resident pointwise forwards, dense1's stripe stream, the two layers' input projections)
+    tr = pmc_step_traffic(eng, ["gemm_wres_fwd_kernel", "gemm_nt_f32_stream_kernel<1, true>", "gemm_nt_f32_proj_kernel"]) \
         if eng.precision == "bf16s" else None
     return {"bound": "mfma", "kernel": kname,
             "traffic": None if tr is None or tr[1] != len(cfgs) else tr[0], "traffic_note": None if tr is None else PMC_NOTE % (eng.precision, eng.precision),
