@@ -438,21 +438,25 @@ struct NtsParams {
   // dense1's epilogue (ABF instantiation, round 5): ReLU, the rows written in permuted order out_row = (m % permP) * (M / permP) + m / permP (batch-major
   // rows to time-major, as crnn_gemm_f32's permP; 0: none), Dropout of site `layer` over the compact [M][ldy] index space of the OUTPUT rows
   int relu = 0, permP = 0; float drop_rate = 0.f; uint64_t seed = 0; uint32_t layer = 0;
+  // skew != 0: workgroup i walks the 64-k chunks of the reduction starting at chunk (skew * i) % (K / 64) -- see the kernel
+  int skew = 0;
 };
 constexpr int kNtsRing = 3, kNtsD = 2;
 
 // ABF: the A operand is a bf16 tensor (p.A reinterpreted; no rounding on the way in) and the epilogue is dense1's (bias, ReLU, row permutation, Dropout)
-template <int CB, bool ABF = false>   // 32-channel blocks per MFMA wave: N = 128 CB
+template <int CB, bool ABF = false, int KC = 1>   // 32-channel blocks per MFMA wave: N = 128 CB; KC 64-k chunks per stage (and barrier)
 __global__ __launch_bounds__(768) void gemm_nt_f32_stream_kernel(NtsParams p) {
   constexpr int N = 128 * CB;
-  constexpr int kX = 64 * 128, kW = N * 128, kSt = kX + kW;   // bytes of a stage: 64 rows x 64 k bf16 | N weight rows x 64 k bf16
-  constexpr int WP = N * 8 / 512;                              // 16-byte weight pieces per IO lane and stage (N rows x 8 pieces over 512 lanes)
+  constexpr int kX = 64 * 128, kW = N * 128, kCh = kX + kW, kSt = KC * kCh;   // bytes of a chunk: 64 rows x 64 k bf16 | N weight rows x 64 k bf16; a stage = KC chunks
+  constexpr int WP = N * 8 / 512;                              // 16-byte weight pieces per IO lane and chunk (N rows x 8 pieces over 512 lanes)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m0 = blockIdx.x * 64, n0 = blockIdx.y * N;          // row stripe, column slab (weight rows n0 .. n0 + N - 1)
-  const int kch = p.K / 64, total = kch * p.npairs;
-  constexpr int ND = ABF ? 4 : kNtsD;                           // stages a lane has in flight (dense1: 72 chunks per stripe, every one a load round trip of ~1.3 us at depth 2)
+  const int kch = p.K / 64, total = kch * p.npairs / KC;        // stages (the host picks KC = 2 only for an even number of chunks)
+  // stages a lane has in flight.  (dense1, 72 chunks per stripe: depth 4 instead of 2 changed nothing -- the chunk loop is bound by the barrier round
+  // trip of its twelve waves, 0.5-0.6 us per chunk whatever the number of busy CUs; two chunks per barrier, KC = 2, is what shortens it.)
+  constexpr int ND = KC > 1 ? 2 : (ABF ? 4 : kNtsD);
 
   if (wave < 4) {
     const int half = lane >> 5, l31 = lane & 31, sw = (l31 >> 1) & 7;
@@ -466,22 +470,25 @@ __global__ __launch_bounds__(768) void gemm_nt_f32_stream_kernel(NtsParams p) {
     int slot = 0;
     for (int s = 0; s < total; ++s) {
       __builtin_amdgcn_s_barrier();
-      const unsigned char* Xs = smem + slot * kSt + l31 * 128;
-      const unsigned char* Ws = smem + slot * kSt + kX + (wave * 32 * CB + l31) * 128;
-      slot = slot + 1 == kNtsRing ? 0 : slot + 1;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int off = ((2 * ks + half) ^ sw) * 16;
-        bf16x8_t fx[2], fw[CB];
+      for (int j = 0; j < KC; ++j) {
+        const unsigned char* Xs = smem + slot * kSt + j * kCh + l31 * 128;
+        const unsigned char* Ws = smem + slot * kSt + j * kCh + kX + (wave * 32 * CB + l31) * 128;
 #pragma unroll
-        for (int b = 0; b < 2; ++b) fx[b] = *reinterpret_cast<const bf16x8_t*>(Xs + b * 32 * 128 + off);
+        for (int ks = 0; ks < 4; ++ks) {
+          const int off = ((2 * ks + half) ^ sw) * 16;
+          bf16x8_t fx[2], fw[CB];
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) fw[cb] = *reinterpret_cast<const bf16x8_t*>(Ws + cb * 32 * 128 + off);
+          for (int b = 0; b < 2; ++b) fx[b] = *reinterpret_cast<const bf16x8_t*>(Xs + b * 32 * 128 + off);
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+          for (int cb = 0; cb < CB; ++cb) fw[cb] = *reinterpret_cast<const bf16x8_t*>(Ws + cb * 32 * 128 + off);
 #pragma unroll
-          for (int cb = 0; cb < CB; ++cb) acc[b][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[cb], fx[b], acc[b][cb], 0, 0, 0);
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) acc[b][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[cb], fx[b], acc[b][cb], 0, 0, 0);
+        }
       }
+      slot = slot + 1 == kNtsRing ? 0 : slot + 1;
     }
     __builtin_amdgcn_s_barrier();
     // lane = one row; register group g of a block = columns 8 g + 4 half + 0..3
@@ -514,33 +521,45 @@ __global__ __launch_bounds__(768) void gemm_nt_f32_stream_kernel(NtsParams p) {
   // ---------------------------------------------------------------------------- IO waves (8): lane il = 0..511
   const int il = tid - 256;
   const int xr = il >> 3, xc = il & 7;                          // dZ piece: row xr (0..63), 8-k piece xc
-  u32x4 rx[ND][2], rw[ND][WP];
-  auto load = [&](int s, u32x4 (&ax)[2], u32x4 (&aw)[WP]) {
+  // All workgroups start together and advance in step, and the rows of both operands are a multiple of 256 bytes apart (x7: 9216, W1^T: 9216, the
+  // recurrent weights: 2048): at any moment every workgroup asks the SAME few memory channels for chunk kc of its rows (0.6 us per chunk whatever the
+  // ring depth, the chunks per barrier or the number of busy CUs).  With a skew each workgroup starts its walk over the reduction at another chunk:
+  // the chip reads all chunks of the rows at once.  (The sums of a stripe then run in a rotated k order: deterministic, fp32 round-off apart.)
+  const int kc0 = p.skew ? (int)(((long)p.skew * blockIdx.x) % kch) : 0;
+  u32x4 rx[ND][KC][2], rw[ND][KC][WP];
+  auto load = [&](int s, u32x4 (&ax)[KC][2], u32x4 (&aw)[KC][WP]) {
     s = s < total ? s : total - 1;
-    const int pr = s / kch, kc = s - pr * kch;
-    if constexpr (ABF) {
-      ax[0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.A[pr]) + (long)(m0 + xr) * p.lda + kc * 64 + xc * 8));
-      ax[1] = ax[0];
-    } else {
-    const float* a = p.A[pr] + (long)(m0 + xr) * p.lda + kc * 64 + xc * 8;
-    ax[0] = *reinterpret_cast<const u32x4*>(a); ax[1] = *reinterpret_cast<const u32x4*>(a + 4);
-    }
-    const bf16_t* w = p.W[pr] + kc * 64 + xc * 8;
 #pragma unroll
-    for (int u = 0; u < WP; ++u) aw[u] = *reinterpret_cast<const u32x4*>(w + (long)(n0 + xr + 64 * u) * p.ldw);
-  };
-  auto write = [&](int s, const u32x4 (&ax)[2], const u32x4 (&aw)[WP]) {
-    unsigned char* st = smem + (s % kNtsRing) * kSt;
-    const u32x4 o = ABF ? ax[0] : u32x4{pack2_bf16(__uint_as_float(ax[0].x), __uint_as_float(ax[0].y)), pack2_bf16(__uint_as_float(ax[0].z), __uint_as_float(ax[0].w)),
-                     pack2_bf16(__uint_as_float(ax[1].x), __uint_as_float(ax[1].y)), pack2_bf16(__uint_as_float(ax[1].z), __uint_as_float(ax[1].w))};
-    *reinterpret_cast<u32x4*>(st + xr * 128 + ((xc ^ ((xr >> 1) & 7)) * 16)) = o;
+    for (int j = 0; j < KC; ++j) {
+      const int g = s * KC + j, pr = g / kch;
+      int kc = g - pr * kch + kc0; kc = kc >= kch ? kc - kch : kc;
+      if constexpr (ABF) {
+        ax[j][0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.A[pr]) + (long)(m0 + xr) * p.lda + kc * 64 + xc * 8));
+        ax[j][1] = ax[j][0];
+      } else {
+        const float* a = p.A[pr] + (long)(m0 + xr) * p.lda + kc * 64 + xc * 8;
+        ax[j][0] = *reinterpret_cast<const u32x4*>(a); ax[j][1] = *reinterpret_cast<const u32x4*>(a + 4);
+      }
+      const bf16_t* w = p.W[pr] + kc * 64 + xc * 8;
 #pragma unroll
-    for (int u = 0; u < WP; ++u) {
-      const int r = xr + 64 * u;
-      *reinterpret_cast<u32x4*>(st + kX + r * 128 + ((xc ^ ((r >> 1) & 7)) * 16)) = aw[u];
+      for (int u = 0; u < WP; ++u) aw[j][u] = *reinterpret_cast<const u32x4*>(w + (long)(n0 + xr + 64 * u) * p.ldw);
     }
   };
-  auto step = [&](int s, u32x4 (&ax)[2], u32x4 (&aw)[WP]) {     // buffer (s + 1) % kNtsD
+  auto write = [&](int s, const u32x4 (&ax)[KC][2], const u32x4 (&aw)[KC][WP]) {
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+      unsigned char* st = smem + (s % kNtsRing) * kSt + j * kCh;
+      const u32x4 o = ABF ? ax[j][0] : u32x4{pack2_bf16(__uint_as_float(ax[j][0].x), __uint_as_float(ax[j][0].y)), pack2_bf16(__uint_as_float(ax[j][0].z), __uint_as_float(ax[j][0].w)),
+                       pack2_bf16(__uint_as_float(ax[j][1].x), __uint_as_float(ax[j][1].y)), pack2_bf16(__uint_as_float(ax[j][1].z), __uint_as_float(ax[j][1].w))};
+      *reinterpret_cast<u32x4*>(st + xr * 128 + ((xc ^ ((xr >> 1) & 7)) * 16)) = o;
+#pragma unroll
+      for (int u = 0; u < WP; ++u) {
+        const int r = xr + 64 * u;
+        *reinterpret_cast<u32x4*>(st + kX + r * 128 + ((xc ^ ((r >> 1) & 7)) * 16)) = aw[j][u];
+      }
+    }
+  };
+  auto step = [&](int s, u32x4 (&ax)[KC][2], u32x4 (&aw)[KC][WP]) {     // buffer (s + 1) % ND
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     write(s + 1, ax, aw); load(s + 1 + ND, ax, aw);
@@ -718,8 +737,8 @@ extern "C" int crnn_rnn_input_proj(const float* X, const void* Wf, const void* W
 // Y[M][N] (fp32, row stride ldy) = A0[M][K] . W0[N][K]^T (+ A1 . W1^T when A1 != NULL) (+ bias[N]); A fp32 (row stride lda), W bf16 (row stride
 // ldw).  Supported (else -3): M % 64 == 0, N % 128 == 0 (column slabs of 256, or of 128 when N % 256 != 0), K % 64 == 0, leading dimensions
 // multiples of 8, 16-byte aligned pointers.
-extern "C" int crnn_gemm_nt_f32_stream_bias(const float* A0, const void* W0, const float* A1, const void* W1, float* Y, const float* bias, int M, int N,
-                                            int K, int lda, int ldw, int ldy, hipStream_t stream) {
+static int nts_launch(const float* A0, const void* W0, const float* A1, const void* W1, float* Y, const float* bias, int M, int N,
+                      int K, int lda, int ldw, int ldy, int skew, hipStream_t stream) {
   if (M <= 0 || K <= 0 || N <= 0 || !A0 || !W0 || !Y || ((A1 != nullptr) != (W1 != nullptr))) return CRNN_ERR_ARG;
   if (M % 64 || N % 128 || K % 64 || ((lda | ldw | ldy) & 7) || lda < K || ldw < K || ldy < N) return CRNN_ERR_UNSUPPORTED;
   if ((((uintptr_t)A0 | (uintptr_t)W0 | (uintptr_t)A1 | (uintptr_t)W1 | (uintptr_t)Y | (uintptr_t)bias) & 15)) return CRNN_ERR_UNSUPPORTED;
@@ -727,11 +746,15 @@ extern "C" int crnn_gemm_nt_f32_stream_bias(const float* A0, const void* W0, con
   const int slab = (N % 256 == 0) ? 256 : 128;
   NtsParams p;
   p.A[0] = A0; p.A[1] = A1 ? A1 : A0; p.W[0] = (const bf16_t*)W0; p.W[1] = (const bf16_t*)(W1 ? W1 : W0); p.Y = Y; p.bias = bias;
-  p.M = M; p.N = slab; p.K = K; p.lda = lda; p.ldw = ldw; p.ldy = ldy; p.npairs = A1 ? 2 : 1;
+  p.M = M; p.N = slab; p.K = K; p.lda = lda; p.ldw = ldw; p.ldy = ldy; p.npairs = A1 ? 2 : 1; p.skew = skew;
   const int lds = kNtsRing * (64 * 128 + slab * 128);
   CRNN_LDS_ATTR(gemm_nt_f32_stream_kernel<1>, kNtsRing * (64 * 128 + 128 * 128));
   CRNN_LDS_ATTR(gemm_nt_f32_stream_kernel<2>, kNtsRing * (64 * 128 + 256 * 128));
-  if (slab == 128) hipLaunchKernelGGL(gemm_nt_f32_stream_kernel<1>, dim3(M / 64, N / slab), dim3(768), lds, stream, p);
+  CRNN_LDS_ATTR((gemm_nt_f32_stream_kernel<1, false, 2>), 2 * kNtsRing * (64 * 128 + 128 * 128));
+  // 128-column slabs with an even number of chunks: two chunks per stage and barrier (144 KiB of ring; the 256-column slab's would not fit)
+  if (slab == 128 && ((K / 64) * p.npairs) % 2 == 0 && crnn_knob("CRNN_NTS_KC", 2) == 2)
+    hipLaunchKernelGGL((gemm_nt_f32_stream_kernel<1, false, 2>), dim3(M / 64, N / slab), dim3(768), 2 * lds, stream, p);
+  else if (slab == 128) hipLaunchKernelGGL(gemm_nt_f32_stream_kernel<1>, dim3(M / 64, N / slab), dim3(768), lds, stream, p);
   else hipLaunchKernelGGL(gemm_nt_f32_stream_kernel<2>, dim3(M / 64, N / slab), dim3(768), lds, stream, p);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
@@ -752,15 +775,24 @@ extern "C" int crnn_dense_fwd_stream(const void* X, const void* WT, const float*
   NtsParams p;
   p.A[0] = p.A[1] = reinterpret_cast<const float*>(X); p.W[0] = p.W[1] = (const bf16_t*)WT; p.Y = Y; p.bias = bias;
   p.M = (int)M; p.N = N; p.K = (int)K; p.lda = lda; p.ldw = ldw; p.ldy = N; p.npairs = 1;
-  p.relu = relu; p.permP = permP; p.drop_rate = drop_rate; p.seed = seed; p.layer = layer;
+  p.relu = relu; p.permP = permP; p.drop_rate = drop_rate; p.seed = seed; p.layer = layer; p.skew = 3;
   const int lds = kNtsRing * (64 * 128 + N * 128);
-  if (N == 128) { CRNN_LDS_ATTR((gemm_nt_f32_stream_kernel<1, true>), lds); hipLaunchKernelGGL((gemm_nt_f32_stream_kernel<1, true>), dim3((unsigned)(M / 64), 1), dim3(768), lds, stream, p); }
+  if (N == 128 && (K / 64) % 2 == 0 && crnn_knob("CRNN_NTS_KC", 2) == 2) {
+    CRNN_LDS_ATTR((gemm_nt_f32_stream_kernel<1, true, 2>), 2 * lds);
+    hipLaunchKernelGGL((gemm_nt_f32_stream_kernel<1, true, 2>), dim3((unsigned)(M / 64), 1), dim3(768), 2 * lds, stream, p);
+  } else if (N == 128) { CRNN_LDS_ATTR((gemm_nt_f32_stream_kernel<1, true>), lds); hipLaunchKernelGGL((gemm_nt_f32_stream_kernel<1, true>), dim3((unsigned)(M / 64), 1), dim3(768), lds, stream, p); }
   else { CRNN_LDS_ATTR((gemm_nt_f32_stream_kernel<2, true>), lds); hipLaunchKernelGGL((gemm_nt_f32_stream_kernel<2, true>), dim3((unsigned)(M / 64), 1), dim3(768), lds, stream, p); }
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
+// (the forward input projections and dense2: chunks in ascending order in every workgroup -- the persistent projection kernel's order, bit for bit)
+extern "C" int crnn_gemm_nt_f32_stream_bias(const float* A0, const void* W0, const float* A1, const void* W1, float* Y, const float* bias, int M, int N,
+                                            int K, int lda, int ldw, int ldy, hipStream_t stream) {
+  return nts_launch(A0, W0, A1, W1, Y, bias, M, N, K, lda, ldw, ldy, 0, stream);
+}
+// (the recurrent layers' input gradients: each workgroup starts its walk over the reduction three chunks after its neighbour's -- see the kernel)
 extern "C" int crnn_gemm_nt_f32_stream(const float* A0, const void* W0, const float* A1, const void* W1, float* Y, int M, int N, int K, int lda,
                                        int ldw, int ldy, hipStream_t stream) {
   if (N != 128 && N != 256) return (M <= 0 || K <= 0) ? CRNN_ERR_ARG : CRNN_ERR_UNSUPPORTED;
-  return crnn_gemm_nt_f32_stream_bias(A0, W0, A1, W1, Y, nullptr, M, N, K, lda, ldw, ldy, stream);
+  return nts_launch(A0, W0, A1, W1, Y, nullptr, M, N, K, lda, ldw, ldy, 3, stream);
 }
