@@ -563,30 +563,36 @@ extern "C" int crnn_transpose(const float* in, float* out, int R, int C, hipStre
 }
 
 // several small transposes in one launch (blockIdx.z = matrix): the W^T copies of the pointwise-conv weights
-struct TransTable { long in_off[8], out_off[8]; int R[8], C[8]; };
+// (one-dimensional grid: matrix z owns the blocks first[z] .. first[z + 1] - 1, cdiv(C, 32) per block row.  A grid sized by the largest matrix in every
+//  dimension launched 18 432 workgroups for the eight of the forward once dense1's 4608 x 128 weight joined them, seven eighths of them empty: 9 us)
+struct TransTable { long in_off[8], out_off[8]; int R[8], C[8]; int first[9]; };
 template <typename TO>
 __global__ void transpose_batch_kernel(const float* __restrict__ src, TO* __restrict__ dst, TransTable tab) {
   __shared__ float tile[32][33];
-  const int z = blockIdx.z, R = tab.R[z], C = tab.C[z];
+  int z = 0;
+  while (z < 7 && (int)blockIdx.x >= tab.first[z + 1]) ++z;
+  const int R = tab.R[z], C = tab.C[z];
   const float* in = src + tab.in_off[z]; TO* out = dst + tab.out_off[z];
-  if (blockIdx.x * 32 >= C || blockIdx.y * 32 >= R) return;
-  int c = blockIdx.x * 32 + threadIdx.x, r = blockIdx.y * 32 + threadIdx.y;
+  const int nbx = (C + 31) / 32, lb = blockIdx.x - tab.first[z], bx = lb % nbx, by = lb / nbx;
+  int c = bx * 32 + threadIdx.x, r = by * 32 + threadIdx.y;
   for (int k = 0; k < 32; k += 8) if (r + k < R && c < C) tile[threadIdx.y + k][threadIdx.x] = in[(long)(r + k) * C + c];
   __syncthreads();
-  int oc = blockIdx.y * 32 + threadIdx.x, orow = blockIdx.x * 32 + threadIdx.y;
+  int oc = by * 32 + threadIdx.x, orow = bx * 32 + threadIdx.y;
   for (int k = 0; k < 32; k += 8) if (orow + k < C && oc < R) st1(&out[(long)(orow + k) * R + oc], tile[threadIdx.x][threadIdx.y + k]);
 }
 extern "C" int crnn_transpose_batch(const float* src, void* dst, int n, const long* in_off, const long* out_off, const int* R, const int* C,
                                     int dt_out, hipStream_t stream) {
   if (n <= 0 || n > 8) return CRNN_ERR_ARG;
-  TransTable tab; int maxR = 0, maxC = 0;
+  TransTable tab; int blocks = 0;
   for (int i = 0; i < 8; ++i) {
     int j = i < n ? i : 0;
+    if (R[j] <= 0 || C[j] <= 0) return CRNN_ERR_ARG;
     tab.in_off[i] = in_off[j]; tab.out_off[i] = out_off[j]; tab.R[i] = R[j]; tab.C[i] = C[j];
-    if (R[j] > maxR) maxR = R[j];
-    if (C[j] > maxC) maxC = C[j];
+    tab.first[i] = blocks;
+    if (i < n) blocks += cdiv(C[j], 32) * cdiv(R[j], 32);
   }
-  dim3 grid(cdiv(maxC, 32), cdiv(maxR, 32), n);
+  tab.first[8] = blocks;
+  dim3 grid(blocks);
   if (dt_out == CRNN_BF16) hipLaunchKernelGGL(transpose_batch_kernel<bf16_t>, grid, dim3(32, 8), 0, stream, src, (bf16_t*)dst, tab);
   else hipLaunchKernelGGL(transpose_batch_kernel<float>, grid, dim3(32, 8), 0, stream, src, (float*)dst, tab);
   CRNN_LAUNCH_CHECK();

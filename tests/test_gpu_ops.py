@@ -1626,6 +1626,29 @@ def test_streaming_tn_gemm_on_fp32_operands_equals_the_tile_kernel(M, N, K, lda,
     assert L().crnn_gemm_tn_stream(P(Ad), lda, P(Bd), ldb, P(C1), ldc, M, N, K - 32, P(scratch), ctypes.c_size_t(scratch.numel() * 4), S()) == -3
 
 
+@pytest.mark.parametrize("dt", [0, 1])
+def test_transpose_batch_of_eight_matrices_of_very_different_sizes(dt):
+    """crnn_transpose_batch: eight transposes in one launch (a one-dimensional grid, every matrix owns its own block range -- round 5: dense1's 4608 x 128
+    weight joined the pointwise convolutions' in the forward's batch), fp32 and bf16 outputs, ragged sizes; elements outside the outputs stay untouched."""
+    rs = np.random.RandomState(17 + dt)
+    shapes = [(64, 128), (128, 256), (4608, 128), (1, 1), (33, 65), (512, 38), (100, 7), (31, 200)]
+    src = rs.normal(size=sum(r * c for r, c in shapes) + 5).astype(np.float32)
+    in_off, out_off, o = [], [], 0
+    for r, c in shapes:
+        in_off.append(o); out_off.append(o + 3); o += r * c
+    total = o + 16
+    dst = torch.full((total,), 9.0, device="cuda", dtype=torch.bfloat16 if dt else torch.float32)
+    arr = lambda v, t: (t * len(v))(*v)
+    ok(L().crnn_transpose_batch(P(dev(src)), P(dst), len(shapes), arr(in_off, ctypes.c_long), arr(out_off, ctypes.c_long), arr([r for r, _ in shapes], ctypes.c_int),
+                                arr([c for _, c in shapes], ctypes.c_int), dt, S()))
+    got = dst.float().cpu().numpy()
+    want = np.full(total, 9.0, dtype=np.float32)
+    for (r, c), i, j in zip(shapes, in_off, out_off):
+        m = src[i:i + r * c].reshape(r, c).T
+        want[j:j + r * c] = (_bf16_round(m) if dt else m).reshape(-1)
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("M,N,K,T,rate", [(52 * 64, 128, 4608, 52, 0.4), (52 * 256, 128, 4608, 52, 0.4), (64 * 3, 256, 192, 0, 0.0), (26 * 64, 128, 1152, 26, 0.25)])
 def test_dense_forward_stream_with_relu_row_permutation_and_dropout(M, N, K, T, rate):
     """crnn_dense_fwd_stream (round 5: dense1's forward on the 64-row stripe stream, bf16 x7 against a bf16 W^T; bias + ReLU + the rows batch-major ->
