@@ -406,7 +406,7 @@ def pointwise_gemm_roofline(eng, iters=5):
              if any(isinstance(c[8], tuple) and c[8][0] == "pw" for c in cfgs) else
              "gemm_%s_kernel<128,false,true> (pointwise 1x1 convs fwd + dense1 + RNN input GEMMs)" % ("bf16" if bf else "f32"))
     # memory-side bytes of the same launches in the step (bf16s: the six weights-resident pointwise forwards, dense1's stripe stream, the two layers' input projections)
-    tr = pmc_step_traffic(eng, ["gemm_wres_fwd_kernel", "gemm_nt_f32_stream_kernel<1, true>", "gemm_nt_f32_proj_kernel"]) \
+    tr = pmc_step_traffic(eng, ["gemm_wres_fwd_kernel", "gemm_nt_f32_stream_kernel<1, true", "gemm_nt_f32_proj_kernel"]) \
         if eng.precision == "bf16s" else None
     return {"bound": "mfma", "kernel": kname,
             "traffic": None if tr is None or tr[1] != len(cfgs) else tr[0], "traffic_note": None if tr is None else PMC_NOTE % (eng.precision, eng.precision),
