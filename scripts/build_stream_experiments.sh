@@ -21,3 +21,5 @@ hipcc $F -DCRNN_DSB_TRACE dense.hip conv.hip -o $O/libdense_trace.so &
 for m in 1 2 8 10 24; do hipcc $F -DCRNN_DSB_TRACE -DCRNN_DSB_EXP=$m dense.hip conv.hip -o $O/libdense_trace_exp$m.so & done   # no multiply-adds | no LDS dy reads | no dx store | 2+8 | no stores, no x DMA
 wait
 ls $O | grep dense
+# dense1's forward micro-benchmark (scripts/dense1_bench.py): the stripe-stream file with the tuning knobs live
+hipcc $F -DCRNN_EXPERIMENT_HOOKS gemm_wgrad.hip -o $O/libcrnn_hooks.so
