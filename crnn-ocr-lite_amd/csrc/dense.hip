@@ -9,8 +9,10 @@
 // keep bytes from the forward's dropout pass, crnn_dropout_keep).  Exact fp32 arithmetic in every precision mode.
 // Before: two tile GEMMs with a padded 38-wide dimension, a split-K reduce, a column reduce with its second stage and a dropout pass (six
 // launches, 77 us, x read twice and dx written twice).  Now 30 + 7 us (kernel + second-stage sum; profiles/r05_dense_bwd_bench.txt):
-//   * the multiply-adds bound it: 545 M of them on 256 CUs x 64 per clock = 14 us -- v_pk_fma_f32 issues at HALF rate on this part (80 packed
-//     instructions per row and wave measured at 8 clocks each: the same throughput as 160 scalar ones, fewer issue slots);
+//   * the row loop is vector-ALU work on ONE wave per SIMD (4 x 40 registers of weights and accumulators per thread leave room for no second one): 80
+//     packed multiply-adds (545 M in all: 7 us at the packed fp32 peak, 14 at the scalar rate) + ~35 other instructions per row and wave take ~600
+//     clocks = 13 us over a workgroup's 52 rows with the LDS reads and the stores compiled out; dy's LDS broadcasts add 5 us that the half-row
+//     pipelining does not hide, the dx stores 1.5: 20 us;
 //   * 5-7 us until the first rows and the weights have landed (256 workgroups ask for 13 MB at once), 3 us for the 20 MB of partial gradients;
 //   * what it was before each fix (the timing build's per-workgroup stamps, -DCRNN_DSB_TRACE): rows loaded into registers one step ahead -- 16 KB
 //     per CU in flight, 1.6 TB/s; W read as 38 strided words per thread -- 2.5 MB through the vector cache per workgroup; W staged by predicated
@@ -183,16 +185,18 @@ __global__ __launch_bounds__(kDsbMaxThreads / 2 + 64) void dense_bwd_small_kerne
         for (int j = 0; j < CP / 8; ++j)
           d[h][j] = (CRNN_DSB_EXP & 2) ? make_float4(1.f, 2.f, 3.f, (float)r) : *reinterpret_cast<const float4*>(dls + r * 64 + half * (CP / 2) + 4 * j);
       };
-      auto mac = [&](int h, int half, f32x2 x0, f32x2 x1, f32x2& s0, f32x2& s1) {
+      // (the row sums run as four independent chains -- two per feature -- interleaved with the accumulator updates: with one wave per SIMD a chain's
+      //  next link issued right behind the previous one waits out the multiply-add pipeline)
+      auto mac = [&](int h, int half, f32x2 x0, f32x2 x1, f32x2& s0, f32x2& s1, f32x2& t0, f32x2& t1) {
 #pragma unroll
         for (int j = 0; j < CP / 8; ++j) {
           const int c2 = half * (CP / 4) + 2 * j;          // index of the class pair
           const f32x2 dlo = f32x2{d[h][j].x, d[h][j].y}, dhi = f32x2{d[h][j].z, d[h][j].w};
           if (CRNN_DSB_EXP & 1) { s0 += dlo; a0[c2] += x0; continue; }
-          s0 = pk_fma(dlo, w0[c2], s0); s0 = pk_fma(dhi, w0[c2 + 1], s0);
-          s1 = pk_fma(dlo, w1[c2], s1); s1 = pk_fma(dhi, w1[c2 + 1], s1);
-          a0[c2] = pk_fma(x0, dlo, a0[c2]); a0[c2 + 1] = pk_fma(x0, dhi, a0[c2 + 1]);
-          a1[c2] = pk_fma(x1, dlo, a1[c2]); a1[c2 + 1] = pk_fma(x1, dhi, a1[c2 + 1]);
+          s0 = pk_fma(dlo, w0[c2], s0); a0[c2] = pk_fma(x0, dlo, a0[c2]);
+          s1 = pk_fma(dlo, w1[c2], s1); a1[c2] = pk_fma(x1, dlo, a1[c2]);
+          t0 = pk_fma(dhi, w0[c2 + 1], t0); a0[c2 + 1] = pk_fma(x0, dhi, a0[c2 + 1]);
+          t1 = pk_fma(dhi, w1[c2 + 1], t1); a1[c2 + 1] = pk_fma(x1, dhi, a1[c2 + 1]);
         }
       };
       float xn0 = xs[k], xn1 = xs[k + KH];
@@ -206,10 +210,10 @@ __global__ __launch_bounds__(kDsbMaxThreads / 2 + 64) void dense_bwd_small_kerne
         const unsigned kb0 = kn0, kb1 = kn1;
         db += dbn;
         const f32x2 x0 = f32x2{xv0, xv0}, x1 = f32x2{xv1, xv1};
-        f32x2 s0 = f32x2{0.f, 0.f}, s1 = f32x2{0.f, 0.f};
+        f32x2 s0 = f32x2{0.f, 0.f}, s1 = f32x2{0.f, 0.f}, t0 = f32x2{0.f, 0.f}, t1 = f32x2{0.f, 0.f};
         ld(1, r, 1);
         __builtin_amdgcn_sched_barrier(0);
-        mac(0, 0, x0, x1, s0, s1);
+        mac(0, 0, x0, x1, s0, s1, t0, t1);
         __builtin_amdgcn_sched_barrier(0);
         const int rn = r + 1 < RB ? r + 1 : RB - 1;         // the row after the step's last: the last again (unused)
         ld(0, rn, 0);
@@ -217,7 +221,8 @@ __global__ __launch_bounds__(kDsbMaxThreads / 2 + 64) void dense_bwd_small_kerne
         kn0 = kp[rn * gpr + (k >> 3)]; kn1 = kp[rn * gpr + ((k + KH) >> 3)];
         dbn = dls[rn * 64 + lane];
         __builtin_amdgcn_sched_barrier(0);
-        mac(1, 1, x0, x1, s0, s1);
+        mac(1, 1, x0, x1, s0, s1, t0, t1);
+        s0 += t0; s1 += t1;
         const float m0 = (((kb0 >> (k & 7)) & 1) | nodrop) ? inv_keep : 0.f, m1 = (((kb1 >> (k & 7)) & 1) | nodrop) ? inv_keep : 0.f;
         if (!(CRNN_DSB_EXP & 8) || s0.x == 1234.5f) {
           __builtin_nontemporal_store((s0.x + s0.y) * m0, dxr);
