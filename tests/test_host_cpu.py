@@ -194,6 +194,24 @@ def test_dense_backward_shape_rule_and_scratch_size():
     assert L.crnn_dense_bwd_small_scratch_bytes(3328, 512, 38) == 256 * (512 * 38 + 38 + 2) * 4         # batch 64: 13 rows per workgroup
 
 
+def test_dense1_stream_kernels_shape_rules():
+    """Round 5, host arithmetic only: dense1's forward on the stripe stream takes whole 64-row stripes, 128 or 256 output columns and whole 64-k chunks; its
+    weight gradient on the pixel stream takes up to 8192 output rows (64 tiles of 128) and sizes its scratch by cus / tiles row ranges when the tiles
+    outnumber an XCD's CUs (36 tiles -> 7 ranges); its data gradient on the weights-resident kernel takes up to 8192 output columns at K <= 128."""
+    L = ctypes.CDLL(native.LIB_PATH)
+    L.crnn_dense_fwd_stream_supported.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_long]
+    L.crnn_gemm_tn_bf16_stream_supported.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_long]
+    L.crnn_gemm_tn_bf16_stream_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_long]
+    L.crnn_gemm_tn_bf16_stream_scratch_bytes.restype = ctypes.c_size_t
+    for (M, N, K, want) in [(13312, 128, 4608, 0), (3328, 128, 4608, 0), (26112, 256, 4608, 0), (416, 128, 4608, -3), (13312, 64, 4608, -3), (13312, 128, 4600, -3), (0, 128, 4608, -3)]:
+        assert L.crnn_dense_fwd_stream_supported(M, N, K) == want, (M, N, K)
+    for (M, N, K, want) in [(4608, 128, 13312, 0), (4608, 128, 3328, 0), (9216, 128, 26112, -3), (4608, 128, 416, -3), (4600, 128, 13312, -3), (4608, 96, 13312, -3)]:
+        assert L.crnn_gemm_tn_bf16_stream_supported(M, N, K) == want, (M, N, K)
+    assert L.crnn_gemm_tn_bf16_stream_scratch_bytes(4608, 128, 13312) == 7 * 4608 * 128 * 4          # 36 tiles x 7 row ranges (256 CUs)
+    assert L.crnn_gemm_tn_bf16_stream_scratch_bytes(4600, 128, 13312) == 0
+    assert L.crnn_gemm_wres_supported(4608, 128) == 0 and L.crnn_gemm_wres_supported(4608, 256) == -3 and L.crnn_gemm_wres_supported(8320, 128) == -3
+
+
 def test_row_stream_kernels_keep_their_row_loops_spill_free():
     """The bf16 row-stream kernels sit at their 168-register ceiling; a harmless-looking edit (an address spelled with one multiplication instead of two)
     once put a 16-byte spill into the depthwise-stage backward's row loop and cost the kernel 22 %.  hipcc cross-compiles gfx950 without a GPU: no
