@@ -16,7 +16,7 @@ CSRC = os.path.join(PKG_ROOT, "csrc")
 LIB_PATH = os.path.join(PKG_ROOT, "libcrnn_mi355x.so")
 HOOKS_HEADER = os.path.join(REPO_ROOT, "include", "crnn_testhooks.h")
 HOOKS_PATH = os.path.join(PKG_ROOT, "libcrnn_testhooks.so")     # measurement / test hooks: never loaded by the product path
-SOURCES = ["gemm.hip", "gemm_nt.hip", "gemm_wres.hip", "gemm_wgrad.hip", "conv.hip", "conv_bwd_fused.hip", "dwconv_stream.hip", "dwconv_bwd_stream.hip", "stn.hip", "rnn.hip", "rnn_persist.hip", "gru_persist.hip", "ctc.hip", "dense.hip", "beam.hip", "optim.hip", "model.hip"]
+SOURCES = ["gemm.hip", "gemm_nt.hip", "gemm_wres.hip", "gemm_wres3.hip", "gemm_wgrad.hip", "conv.hip", "conv_bwd_fused.hip", "dwconv_stream.hip", "dwconv_bwd_stream.hip", "stn.hip", "rnn.hip", "rnn_persist.hip", "gru_persist.hip", "ctc.hip", "dense.hip", "beam.hip", "optim.hip", "model.hip"]
 
 
 class crnn_config(ctypes.Structure):

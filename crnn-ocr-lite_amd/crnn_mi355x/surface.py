@@ -156,7 +156,9 @@ class Model:
         the ranks' marks (`_replicas_need_sync`, one 4-byte collective every rank takes part in) and all ranks broadcast, or none
         does -- after `if rank == 0: model.load_weights(...)` every rank therefore adopts the loaded weights at the next train
         step instead of rank 0 entering a broadcast the others never join.  fit_generator's pipelined loop skips that per-step
-        check (it would cost a host synchronisation per step) and relies on its own sync_replicas() at the start."""
+        check (it would cost a host synchronisation per step): it synchronises once at the start, and carries every rank's mark in
+        a third slot of the loss all-reduce it issues anyway -- weights replaced on one rank by a callback are re-broadcast from
+        rank 0 after the following step (round 6)."""
         dist, world = self._dist()
         if world > 1:
             from .parallel import broadcast_state
@@ -439,7 +441,7 @@ class Model:
     def _read_loss(ls_dev, eng, summed=False):
         """The one host synchronisation of a step: loss and recurrence status in one D2H copy; raises if a recurrence gave up.
         summed: the counter was all-reduced (SUM) over the data-parallel ranks -- compared against its own baseline."""
-        loss, giveups = ls_dev.tolist()
+        loss, giveups = ls_dev.tolist()[:2]
         eng.raise_if_rnn_gave_up(giveups, summed=summed)
         return float(loss)
 
@@ -497,17 +499,29 @@ class Model:
                     self._prefetched = (generator, self._snapshot(next(generator)))
                 except Exception as e:         # (a bad batch k+1 / an exhausted generator): step k is already enqueued -- read it back and
                     pending = e                # run its callbacks first, then re-raise
+                resync = False
                 if world > 1:
                     # every rank logs (and EarlyStoppingIter monitors) the GLOBAL batch-mean loss, so all ranks take the same
                     # stop / restore decisions and keep issuing the same collectives; the give-up counters are summed, so a
-                    # recurrence that gave up on one rank stops every rank (the rank-local counter keeps its own baseline)
+                    # recurrence that gave up on one rank stops every rank (the rank-local counter keeps its own baseline).
+                    # Third slot (round 6, ADVICE): this rank's out-of-sync mark -- a callback that called set_weights / load_weights on ONE
+                    # rank since the last step -- rides on the same all-reduce and the same read-back, so the pipelined loop needs no
+                    # extra collective or host synchronisation to notice it; every rank then takes the broadcast below together.
+                    import torch
+                    mark = torch.full((1,), 0.0 if self._state.get("replicas_synced") else 1.0, dtype=ls_dev.dtype, device=ls_dev.device)
+                    ls_dev = torch.cat([ls_dev, mark])
                     dist.all_reduce(ls_dev, op=dist.ReduceOp.SUM)
                     ls_dev[0] /= world
-                loss = self._read_loss(ls_dev, eng, summed=world > 1)
+                vals = ls_dev.tolist()                # the one host synchronisation of the step
+                eng.raise_if_rnn_gave_up(vals[1], summed=world > 1)
+                loss = float(vals[0])
+                resync = world > 1 and vals[2] > 0
                 run += loss; nimg += nb
                 logs = {"loss": loss, "batch": step, "size": nb}
                 for cb in callbacks:
                     cb.on_batch_end(step, logs)
+                if resync:      # some rank's weights were replaced during the last step's callbacks: all ranks adopt rank 0's, one step late
+                    self.sync_replicas(nb)
                 if pending is not None:
                     raise pending
                 if verbose and (step + 1 == steps_per_epoch or (step + 1) % max(1, steps_per_epoch // 20) == 0):

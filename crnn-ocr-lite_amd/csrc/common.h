@@ -187,6 +187,18 @@ __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
   f32x2_t v = {lo, hi};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));   // v_cvt_pk_bf16_f32 (RNE)
 }
+// x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), round-to-nearest-even each (the differences are exact in
+// fp32): the three bf16 planes of the parity mode's products (gemm_bf16.inc: gemm_x3p_kernel; gemm_wres3.hip).  One spelling shared by every
+// kernel that forms planes, so that all of them produce the same words.  w0 / w1 / w2 = the packed pair (v0 low half, v1 high half) of each plane.
+// (scalar v_sub_f32: SLP-packed into v_pk_add_f32 these four subtractions cost ~25 cycles each beside running MFMAs)
+__device__ __forceinline__ void crnn_split3_pair(float v0, float v1, unsigned& w0, unsigned& w1, unsigned& w2) {
+#pragma clang fp contract(off)
+  w0 = pack2_bf16(v0, v1);
+  const float r0 = sub_unpacked(v0, __uint_as_float(w0 << 16)), r1 = sub_unpacked(v1, __uint_as_float(w0 & 0xffff0000u));
+  w1 = pack2_bf16(r0, r1);
+  const float s0 = sub_unpacked(r0, __uint_as_float(w1 << 16)), s1 = sub_unpacked(r1, __uint_as_float(w1 & 0xffff0000u));
+  w2 = pack2_bf16(s0, s1);
+}
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 ld4(const bf16_t* p) {
   uint2 u = *reinterpret_cast<const uint2*>(p);

@@ -314,7 +314,9 @@ extern "C" int crnn_dense_bwd_small(const float* x, const float* dy, const float
                                     uint32_t layer, hipStream_t stream) {
   if (crnn_dense_bwd_small_supported(M, K, C) != CRNN_OK || ldx != K || lddx < K) return CRNN_ERR_UNSUPPORTED;   // x rows are contiguous (whole steps are one DMA range)
   if (!x || !dy || !W || !dx || !dW || !db || !scratch) return CRNN_ERR_ARG;
-  if ((((uintptr_t)x | (uintptr_t)W | (uintptr_t)scratch) & 15) != 0 || ((uintptr_t)keep & 3) != 0) return CRNN_ERR_ARG;
+  // misaligned operands are a shape this kernel does not take, not a caller error: -3 sends crnn_backward_top to the GEMM + column-sum + dropout path
+  // (as the other stream entry points do; round 6, ADVICE)
+  if ((((uintptr_t)x | (uintptr_t)W | (uintptr_t)scratch) & 15) != 0 || ((uintptr_t)keep & 3) != 0) return CRNN_ERR_UNSUPPORTED;
   if (drop_rate < 0.f || drop_rate >= 1.f) return CRNN_ERR_ARG;
   if (scratch_bytes < crnn_dense_bwd_small_scratch_bytes(M, K, C)) return CRNN_ERR_ARG;
   if (db != dW + (long)K * C) return CRNN_ERR_UNSUPPORTED;   // the two gradients are one span of the gradient buffer (one second-stage sum)

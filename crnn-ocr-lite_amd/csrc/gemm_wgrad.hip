@@ -775,7 +775,11 @@ extern "C" int crnn_dense_fwd_stream(const void* X, const void* WT, const float*
   NtsParams p;
   p.A[0] = p.A[1] = reinterpret_cast<const float*>(X); p.W[0] = p.W[1] = (const bf16_t*)WT; p.Y = Y; p.bias = bias;
   p.M = (int)M; p.N = N; p.K = (int)K; p.lda = lda; p.ldw = ldw; p.ldy = N; p.npairs = 1;
-  p.relu = relu; p.permP = permP; p.drop_rate = drop_rate; p.seed = seed; p.layer = layer; p.skew = crnn_knob("CRNN_NTS_SKEW", 3);
+  // The rotated start of the reduction walk (p.skew, see the kernel) makes a row's fp32 sum depend on which 64-row stripe it sits in.  Training launches
+  // (drop_rate > 0: the dropout decision depends on the row index anyway) take it; inference launches walk the chunks in ascending order in every workgroup,
+  // so that a sample's activations do not depend on its position in the batch or on the batch size (round 6, ADVICE; test_dense1_stream_inference_rows_do_
+  // not_depend_on_their_position).
+  p.relu = relu; p.permP = permP; p.drop_rate = drop_rate; p.seed = seed; p.layer = layer; p.skew = drop_rate > 0.f ? crnn_knob("CRNN_NTS_SKEW", 3) : 0;
   const int lds = kNtsRing * (64 * 128 + N * 128);
   if (N == 128 && (K / 64) % 2 == 0 && crnn_knob("CRNN_NTS_KC", 2) == 2) {
     CRNN_LDS_ATTR((gemm_nt_f32_stream_kernel<1, true, 2>), 2 * lds);

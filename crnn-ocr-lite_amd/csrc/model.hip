@@ -193,6 +193,8 @@ Plan make_plan(const crnn_config* c) {
     maxparts = lmax(maxparts, (long)crnn_pwconv_fwd_wres_rows(M, co, ci) * 2L * co);   // one row per IO wave and stripe lane: more rows than tiles at small batches
     maxparts = lmax(maxparts, (long)crnn_bn_bwd_chunks(M) * 2L * lmax(ci, co));
     maxparts = lmax(maxparts, (long)crnn_gemm_wres_bnstats_rows(M, ci, co) * 2L * ci);
+    maxparts = lmax(maxparts, (long)crnn_gemm_wres3_stat_rows(M, co, ci) * 2L * co);   // parity mode, weights-resident plane kernels (gemm_wres3.hip): forward ...
+    maxparts = lmax(maxparts, (long)crnn_gemm_wres3_stat_rows(M, ci, co) * 2L * ci);   // ... and data gradient
   }
   const long TB = (long)d.T * B;
   P.add("dn1", TB * d.tds);
@@ -309,6 +311,12 @@ int pw_products(const crnn_config* cfg) { return cfg->mfma_bf16 ? 1 : ((cfg->fla
 // fp32's 2^-24), half the MFMA work: gradients within 1e-5 of the three-plane ones; CRNN_FLAG_THREE_PLANE_BACKWARD: three there too.
 int conv_planes(const crnn_config* cfg, bool backward) {
   return backward ? ((cfg->flags & CRNN_FLAG_THREE_PLANE_BACKWARD) ? 3 : 2) : ((cfg->flags & CRNN_FLAG_TWO_PLANE_FORWARD) ? 2 : 3);
+}
+// Parity mode, round 6: the pointwise convolutions' forward product and data gradient on the weights-resident plane kernels (gemm_wres3.hip) for reductions
+// of at most 256 channels; CRNN_FLAG_GEMM_TILE_KERNELS keeps the tile kernel (same planes and products, another accumulation order).  At a reduction of 512
+// the resident kernel is slower than the tile kernel (its 64-channel slices ingest and split every pixel row eight times: profiles/r06_wres3_bench.txt).
+bool wres3_on(const crnn_config* cfg, int reduction) {
+  return !(cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS) && reduction <= crnn_knob("CRNN_W3_MAXK", 256);
 }
 // ... as crnn_pwconv_fwd's product selector for a forward conv of the stack (3 = two planes)
 int pw_products_fwd(const crnn_config* cfg) { return (pw_products(cfg) == 2 && conv_planes(cfg, false) == 2) ? 3 : pw_products(cfg); }
@@ -504,6 +512,15 @@ extern "C" int crnn_ws_tensor(const crnn_config* cfg, const char* name, long* of
 }
 
 namespace {
+constexpr int kForkMaxDevices = 64;
+// The side stream an entry point may fork to: NULL (run everything on `stream`) when the caller passed none, the same stream, or a stream on a device ordinal
+// beyond the fork/join event table (round 6, ADVICE: such a box used to fail the whole step with -3)
+hipStream_t side_stream(hipStream_t stream, hipStream_t aux) {
+  if (!aux || aux == stream) return nullptr;
+  hipDevice_t d = 0;
+  if (hipStreamGetDevice(aux, &d) != hipSuccess || d < 0 || d >= kForkMaxDevices) return nullptr;
+  return aux;
+}
 // Two streams with event links (fork: the side stream continues after everything enqueued on the main stream so far; join: the reverse)
 struct ForkJoin {
   // The events are created once per (host thread, device) and reused by every call (recording an event again while an earlier
@@ -512,19 +529,19 @@ struct ForkJoin {
   // another GPU driven from the same host thread must not record the first one's events on its streams (invalid resource handle).
   // The events live as long as the thread (a fixed pool of 24 per device, like the runtime's own per-device pools); they are never
   // destroyed because a wait on one of them may still be queued when the thread exits.
+  // A device ordinal beyond the table (more than 64 GPUs / partitions visible to one process) does not fail the step: the fork is simply not taken
+  // and the side work runs on the main stream (same results; round 6, ADVICE).
   hipStream_t main, aux; int n = 0; bool on; int dev = -1;
-  ForkJoin(hipStream_t m, hipStream_t a) : main(m), aux(a), on(a != nullptr) {}
-  static constexpr int kMaxDevices = 16, kEvents = 24;
+  static constexpr int kMaxDevices = kForkMaxDevices, kEvents = 24;
+  ForkJoin(hipStream_t m, hipStream_t a) : main(m), aux(a), on(a != nullptr) {
+    if (on) {   // the device the side stream lives on
+      hipDevice_t d = 0;
+      if (hipStreamGetDevice(aux, &d) != hipSuccess || d < 0 || d >= kMaxDevices) on = false; else dev = d;
+    }
+  }
   int event(int i, hipEvent_t* out) {
     static thread_local hipEvent_t ev[kMaxDevices][kEvents] = {};
-    if (i >= kEvents) return CRNN_ERR_ARG;
-    if (dev < 0) {   // the device the side stream lives on (the NULL stream: the current device)
-      hipDevice_t d = 0;
-      hipError_t r = aux ? hipStreamGetDevice(aux, &d) : hipGetDevice(&d);
-      if (r != hipSuccess) return (int)r;
-      if (d < 0 || d >= kMaxDevices) return CRNN_ERR_UNSUPPORTED;
-      dev = d;
-    }
+    if (i >= kEvents || dev < 0) return CRNN_ERR_ARG;
     hipEvent_t& e = ev[dev][i];
     if (!e) { hipError_t r = hipEventCreateWithFlags(&e, hipEventDisableTiming); if (r != hipSuccess) return (int)r; }
     *out = e;
@@ -569,7 +586,8 @@ extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, cons
   if (ws_bytes < (size_t)c.P.total * sizeof(float)) return CRNN_ERR_ARG;
   const Dims& d = c.d;
   const int B = d.B;
-  ForkJoin fj(stream, aux_stream == stream ? nullptr : aux_stream);
+  aux_stream = side_stream(stream, aux_stream);
+  ForkJoin fj(stream, aux_stream);
   bool keep_pending = false;
   if (train && cfg->dropout) {   // the dropout decisions of the block outputs that only exist inside the next depthwise kernels (fuse_bn2_dw)
     void* outs[CRNN_KEEP_BATCH_MAX]; long ng[CRNN_KEEP_BATCH_MAX]; uint32_t lay[CRNN_KEEP_BATCH_MAX]; int n = 0;
@@ -738,6 +756,12 @@ extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, cons
       else if (fuse_x3) {
         long wps = 0; const void* wpl = weight_planes(c, c.p(bp + "_pw"), &wps, false);
         int rc = wpl ? crnn_pwconv_bnrelu6_fwd_f32x3_pl(dd, s1, c.p(bp + "_pw"), wpl, wps, qq, M, co, ci, parts, stream) : CRNN_ERR_UNSUPPORTED;
+        // round 6: the weights' planes resident in registers, the pixel rows streamed once (gemm_wres3.hip) where that kernel wins: K <= 256
+        // (at K = 512 the planes of a 128-channel slice do not fit a CU's registers next to the accumulators: the tile kernel stays)
+        if (rc == CRNN_ERR_UNSUPPORTED && wres3_on(cfg, ci) && crnn_gemm_wres3_supported(M, co, ci) == CRNN_OK) {
+          rc = crnn_pwconv_bnrelu6_fwd_wres3(dd, s1, c.p(bp + "_pw"), qq, M, co, ci, conv_planes(cfg, false), parts, stream);
+          if (rc == CRNN_OK) stat_rows = crnn_gemm_wres3_stat_rows(M, co, ci);
+        }
         if (rc == CRNN_ERR_UNSUPPORTED)      // (no planes, or ragged tiles: split while staging)
           rc = conv_planes(cfg, false) == 2 ? crnn_pwconv_bnrelu6_fwd_f32x2(dd, s1, c.p(bp + "_pw"), qq, M, co, ci, parts, stream)
                                             : crnn_pwconv_bnrelu6_fwd_f32x3(dd, s1, c.p(bp + "_pw"), qq, M, co, ci, parts, stream);
@@ -996,7 +1020,7 @@ extern "C" int crnn_backward_top_ex(const crnn_config* cfg, const float* params,
   CRNN_TRY(check_cfg(cfg));
   Ctx c{cfg, make_dims(cfg), make_layout(cfg), make_plan(cfg), params, grads, ws, stream};
   if (ws_bytes < (size_t)c.P.total * sizeof(float)) return CRNN_ERR_ARG;
-  return backward_top(c, labels, input_length, label_length, loss, seed, aux_stream == stream ? nullptr : aux_stream);
+  return backward_top(c, labels, input_length, label_length, loss, seed, side_stream(stream, aux_stream));
 }
 extern "C" int crnn_backward_top(const crnn_config* cfg, const float* params, float* grads, const int* labels,
                                  const int* input_length, const int* label_length, float* ws, size_t ws_bytes, float* loss,
@@ -1015,7 +1039,7 @@ extern "C" int crnn_backward_bottom_ex(const crnn_config* cfg, const float* para
   CRNN_TRY(check_cfg(cfg));
   Ctx c{cfg, make_dims(cfg), make_layout(cfg), make_plan(cfg), params, grads, ws, stream};
   if (ws_bytes < (size_t)c.P.total * sizeof(float)) return CRNN_ERR_ARG;
-  return backward_bottom(c, x, seed, aux_stream == stream ? nullptr : aux_stream);
+  return backward_bottom(c, x, seed, side_stream(stream, aux_stream));
 }
 extern "C" int crnn_backward(const crnn_config* cfg, const float* params, float* grads, const float* x, const int* labels,
                              const int* input_length, const int* label_length, float* ws, size_t ws_bytes, float* loss,
@@ -1032,8 +1056,8 @@ extern "C" int crnn_backward_ex(const crnn_config* cfg, const float* params, flo
   CRNN_TRY(check_cfg(cfg));
   Ctx c{cfg, make_dims(cfg), make_layout(cfg), make_plan(cfg), params, grads, ws, stream};
   if (ws_bytes < (size_t)c.P.total * sizeof(float)) return CRNN_ERR_ARG;
-  CRNN_TRY(backward_top(c, labels, input_length, label_length, loss, seed, aux_stream == stream ? nullptr : aux_stream));
-  return backward_bottom(c, x, seed, aux_stream == stream ? nullptr : aux_stream);
+  CRNN_TRY(backward_top(c, labels, input_length, label_length, loss, seed, side_stream(stream, aux_stream)));
+  return backward_bottom(c, x, seed, side_stream(stream, aux_stream));
 }
 
 namespace {
@@ -1199,10 +1223,16 @@ int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t au
       if (rc == CRNN_ERR_UNSUPPORTED && !fused_bf && pw_products(cfg) == 2 && dtq == CRNN_F32 && dtd == CRNN_F32 &&
           !(cfg->flags & CRNN_FLAG_NO_BN_STATS_FUSION) && crnn_gemm_f32x3_bnstats_supported(M, ci, co) == CRNN_OK) {
         long wps = 0; const void* wpl = weight_planes(c, c.p(bp + "_pw"), &wps, true);
-        if (conv_planes(cfg, true) == 2) rc = crnn_gemm_f32x2_bnstats(gB, c.p(bp + "_pw"), gA, M, ci, co, c.w("d" + p), c.w("bn1s" + p), c.w("partials"), stream);
+        int w3_rows = 0;
+        if (wres3_on(cfg, co) && !wpl && crnn_gemm_wres3_supported(M, ci, co) == CRNN_OK) {   // round 6: W^T planes resident, dq streamed once (gemm_wres3.hip)
+          rc = crnn_gemm_wres3_bnstats(gB, c.p(bp + "_pw"), gA, M, ci, co, conv_planes(cfg, true), c.w("d" + p), c.w("bn1s" + p), c.w("partials"), stream);
+          if (rc == CRNN_OK) { w3_rows = crnn_gemm_wres3_stat_rows(M, ci, co); }
+        }
+        if (rc != CRNN_ERR_UNSUPPORTED) {}
+        else if (conv_planes(cfg, true) == 2) rc = crnn_gemm_f32x2_bnstats(gB, c.p(bp + "_pw"), gA, M, ci, co, c.w("d" + p), c.w("bn1s" + p), c.w("partials"), stream);
         else rc = crnn_gemm_f32x3_bnstats_pl(gB, nullptr, 0, c.p(bp + "_pw"), wpl, wps, gA, M, ci, co, c.w("d" + p), c.w("bn1s" + p), c.w("partials"), stream);
         if (rc == CRNN_ERR_UNSUPPORTED && wpl) rc = crnn_gemm_f32x3_bnstats(gB, c.p(bp + "_pw"), gA, M, ci, co, c.w("d" + p), c.w("bn1s" + p), c.w("partials"), stream);
-        bn1_stats_rows = (rc == CRNN_OK) ? crnn_gemm_f32x3_bnstats_rows(M) : 0;
+        bn1_stats_rows = (rc == CRNN_OK) ? (w3_rows ? w3_rows : crnn_gemm_f32x3_bnstats_rows(M)) : 0;
       }
       if (rc == CRNN_ERR_UNSUPPORTED) rc = gemm_t(c, 1, gB, dtq, c.p(bp + "_pw"), CRNN_F32, gA, dtd, (int)M, ci, co, co, co, ci, nullptr, 0, 0, 0, conv_planes(cfg, true));
       CRNN_TRY(rc);

@@ -248,6 +248,23 @@ int crnn_pwconv_bnrelu6_fwd_f32x3_pl(const float* d, const float* in_bnstate, co
                                      int N, int K, float* stat_partials, crnn_stream_t stream);
 int crnn_pwconv_bnrelu6_wgrad_f32x3(const float* d, const float* in_bnstate, const float* g, float* dw, long M, int N, int K, float* scratch,
                                     size_t scratch_bytes, crnn_stream_t stream);
+/* Round 6: the same forward product and the data gradient with the WEIGHTS' PLANES RESIDENT IN REGISTERS (gemm_wres3.hip; replaces Keras' Conv2D(1x1)
+ * forward / backward of reference utils.py:48-49 in the parity mode): a workgroup owns a slice of 128 output channels (64 at K = 512, where the reduction
+ * runs as two halves on two waves each), splits its slice of w into planes once, and the pixel rows stream through it once -- IO waves load fp32 rows,
+ * apply BatchNorm-1 + ReLU6 (forward), split into planes into an LDS ring; the result leaves through LDS staging tiles whose drain also takes the
+ * statistics.  planes = 3 | 2.  Results: K <= 256 bit-identical to crnn_pwconv_bnrelu6_fwd_f32x3 / _f32x2 and crnn_gemm_f32x3_bnstats / _f32x2_bnstats;
+ * K = 512 equal up to the order of ONE addition (the two half-reduction chains are added at the end).  Statistics: the same sums in another order,
+ * [crnn_gemm_wres3_stat_rows(M, N, K)][2][N], every element written.  Shapes (crnn_gemm_wres3_supported, -3 otherwise): K in {64, 128, 256, 512}
+ * (data gradient: 256 | 512), N a multiple of 128 (64 at K = 512) up to 1024, M a multiple of 64 (32 at K >= 256), 16-byte aligned tensors. */
+int crnn_gemm_wres3_supported(long M, int N, int K);
+int crnn_gemm_wres3_stat_rows(long M, int N, int K);
+int crnn_pwconv_bnrelu6_fwd_wres3(const float* d, const float* in_bnstate, const float* w, float* q, long M, int N, int K, int planes,
+                                  float* stat_partials, crnn_stream_t stream);
+/* da[M][N] = dq[M][K] . w[N][K]^T (w = the convolution's kernel [N input channels][K output channels]) + BatchNorm-1 backward statistics:
+ * stat_partials = partial sums of gy and gy * xhat, gy = da where 0 < d * scale + shift < 6; d [M][N], bnstate = [mean|var|scale|shift] x N
+ * (as crnn_gemm_f32x3_bnstats; feed crnn_bn_bwd_finalize_folded). */
+int crnn_gemm_wres3_bnstats(const float* dq, const float* w, float* da, long M, int N, int K, int planes, const float* d, const float* bnstate,
+                            float* stat_partials, crnn_stream_t stream);
 /* The same pointwise conv for ONE input channel (block 1: Conv2D(64, 1x1) on the single-channel depthwise output,
  * utils.py:64 / 49): an outer product q[m][c] = a[m] * w[c], its data gradient da[m] = dq[m] . w and weight gradient
  * dw[c] = sum_m a[m] dq[m][c].  a / da fp32; q / dq fp32 (dt_q 0) or bf16 (1); N a power of two, 8 <= N <= 256.
@@ -578,7 +595,11 @@ int crnn_gemm_tn_bf16_stream(const void* A, int lda, const void* B, int ldb, flo
  * bf16 W^T copy (row stride ldw), one workgroup per 64-row stripe over the whole reduction (the recurrent layers' stripe stream with a bf16 operand);
  * relu 0 | 1; permP: rows written at (m % permP) * (M / permP) + m / permP (0: in place; batch-major rows to time-major as crnn_gemm_f32's permP);
  * drop_rate > 0: the multipliers crnn_dropout applies to the compact [M][N] output for (seed, layer).  Supported (else -3): M % 64 == 0, N = 128 | 256,
- * K % 64 == 0, lda / ldw multiples of 8, 16-byte aligned pointers. */
+ * K % 64 == 0, lda / ldw multiples of 8, 16-byte aligned pointers.
+ * Summation order (round 6): with drop_rate == 0 (inference) every 64-row stripe sums its 64-k chunks in ascending order -- a row's result does not depend on
+ * its position in the batch or on the batch size.  With drop_rate > 0 (training) stripe i starts its walk at chunk (3 i) mod (K / 64) (memory-channel skew):
+ * results differ between stripes at fp32 round-off level and are deterministic run to run only.  crnn_gemm_nt_f32_stream (the recurrent layers' input
+ * gradients, training only) always rotates. */
 int crnn_dense_fwd_stream_supported(long M, int N, long K);
 int crnn_dense_fwd_stream(const void* X, const void* WT, const float* bias, float* Y, long M, int N, long K, int lda, int ldw, int relu, int permP,
                           float drop_rate, uint64_t seed, uint32_t layer, crnn_stream_t stream);

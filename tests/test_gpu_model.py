@@ -544,7 +544,9 @@ def test_parity_mode_weight_planes_split_once_change_no_bit(shape):
     x, lab, il, ll = M.synthetic_batch(cfg, B, seed=2, dtype=np.float64)
     out = {}
     T3 = native.FLAG_THREE_PLANE_BACKWARD      # (the backward's data-gradient GEMMs read weight planes only in their three-plane form)
-    for flags in (0, native.FLAG_WEIGHT_PLANES, T3, T3 | native.FLAG_WEIGHT_PLANES):
+    TILE = native.FLAG_GEMM_TILE_KERNELS        # round 6: the plane form belongs to the tile kernel; the default schedule runs K <= 256 on the weights-resident kernels
+    T3 |= TILE
+    for flags in (TILE, TILE | native.FLAG_WEIGHT_PLANES, T3, T3 | native.FLAG_WEIGHT_PLANES):
         eng = Engine(B, imgh, imgw, ncls, max_len, tds, u, stn=True, dropout=True, precision="fp32", flags=flags)
         eng.set_params(p, bn)
         eng.ws.fill_(float("nan")); eng.grads.zero_()
@@ -552,7 +554,7 @@ def test_parity_mode_weight_planes_split_once_change_no_bit(shape):
         loss = eng.backward(lab, il, ll, seed=9).clone()
         out[flags] = (y, loss, eng.grads.clone())
         del eng
-    for base in (0, T3):
+    for base in (TILE, T3):
         (y0, l0, g0), (y1, l1, g1) = out[base], out[base | native.FLAG_WEIGHT_PLANES]
         assert torch.isfinite(g0).all() and float(g0.abs().max()) > 0
         assert torch.equal(y0, y1) and torch.equal(l0, l1) and torch.equal(g0, g1), base

@@ -1684,6 +1684,24 @@ def test_dense_forward_stream_with_relu_row_permutation_and_dropout(M, N, K, T, 
         assert L().crnn_dense_fwd_stream(P(Xd), P(Wd), P(bd), P(Y), M, N, K, K, K, 1, T + 1 if M % (T + 1) else T + 7, rate, seed, layer, S()) == -3      # rows not a multiple of permP
 
 
+def test_dense1_stream_inference_rows_do_not_depend_on_their_position():
+    """crnn_dense_fwd_stream without dropout (the inference launch: predict.py at any batch size): every workgroup walks the reduction in ascending order, so a
+    row's fp32 sum is the same bits wherever the row sits in the batch -- rows permuted on the way in come out permuted, and the first stripe of a long batch
+    equals a short batch of the same rows.  (Training launches, drop_rate > 0, rotate each stripe's start -- round 5's memory-channel skew -- and are only
+    deterministic run to run: the header says so.)"""
+    M, N, K = 64 * 12, 128, 4608
+    rs = np.random.RandomState(5)
+    X = _bf16_round(np.maximum(rs.normal(size=(M, K)), 0) * 2.0); WT = _bf16_round(rs.normal(size=(N, K)) * 0.02); bias = rs.normal(size=N).astype(np.float32) * 0.5
+    perm = rs.permutation(M)
+    Wd, bd = _to_bf16_dev(WT), dev(bias)
+    Y0, Y1, Y2 = zeros(M, N), zeros(M, N), zeros(64, N)
+    ok(L().crnn_dense_fwd_stream(P(_to_bf16_dev(X)), P(Wd), P(bd), P(Y0), M, N, K, K, K, 1, 0, 0.0, 1, 8, S()))
+    ok(L().crnn_dense_fwd_stream(P(_to_bf16_dev(X[perm])), P(Wd), P(bd), P(Y1), M, N, K, K, K, 1, 0, 0.0, 1, 8, S()))
+    ok(L().crnn_dense_fwd_stream(P(_to_bf16_dev(X[64 * 7:64 * 8])), P(Wd), P(bd), P(Y2), 64, N, K, K, K, 1, 0, 0.0, 1, 8, S()))
+    assert np.array_equal(host(Y1), host(Y0)[perm]), "a row's result depends on its position in the batch"
+    assert np.array_equal(host(Y2), host(Y0)[64 * 7:64 * 8]), "a row's result depends on the batch size"
+
+
 @pytest.mark.parametrize("M,N,K,lda,ldb,ldc", [(4608, 128, 52 * 256, 4608, 128, 128), (4608, 128, 52 * 64, 4608, 128, 128), (1152, 128, 52 * 16, 1152, 128, 128),
                                                (256, 256, 640, 264, 256, 260), (2304, 128, 64, 2304, 136, 128)])
 def test_streaming_tn_gemm_on_bf16_operands_equals_the_tile_kernel(M, N, K, lda, ldb, ldc):
@@ -1812,6 +1830,95 @@ def test_three_plane_gemms_apply_batchnorm_relu6_while_staging(M, K, N):
     assert torch.equal(dw1, dw0), "weight gradient differs: max %g" % float((dw1 - dw0).abs().max())
     ref = host(a).astype(np.float64).T @ host(g).astype(np.float64)
     assert_close(host(dw1), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max() + 1e-6, what="weight gradient vs fp64")
+
+
+def _bnstate(rs, C):
+    return dev(np.concatenate([rs.normal(size=C), rs.uniform(0.5, 2.0, size=C), rs.normal(size=C) * 0.3 + 1.0, rs.normal(size=C) * 0.5 + 0.5]).astype(np.float32))
+
+
+@pytest.mark.parametrize("planes", [3, 2])
+@pytest.mark.parametrize("M,K,N", [(64 * 5, 64, 128), (64 * 1100, 64, 128), (64 * 37, 128, 256), (64 * 700, 128, 256), (32 * 9, 256, 256), (32 * 333, 256, 512),
+                                   (32 * 40, 512, 512), (32 * 210, 512, 512), (32 * 70, 512, 64), (64 * 3, 128, 1024)])
+def test_resident_weight_plane_forward_equals_the_tile_kernel(M, K, N, planes):
+    """crnn_pwconv_bnrelu6_fwd_wres3 (round 6, gemm_wres3.hip): the parity mode's pointwise forward with the weights' planes resident in registers and the
+    pixel rows streamed once.  q must equal crnn_pwconv_bnrelu6_fwd_f32x3 / _f32x2 (same planes, same products) up to the ORDER of the fp32 accumulation
+    (four interleaved chains per output, two reduction halves at K = 512) and be as close to fp64 as the tile kernel.  The statistics
+    partials must give the tile kernel's column sums / sums of squares up to the order of the fp32 partial sums; rows behind M stay untouched; one to
+    many stripes per workgroup (the IO waves' prologue, steady state and tail all run)."""
+    rs = np.random.RandomState(M % 1000 + N + K + planes)
+    d = dev((rs.normal(size=(M, K)) * 1.5 + 0.4).astype(np.float32)); w = dev((rs.normal(size=(K, N)) * 0.1).astype(np.float32))
+    st = _bnstate(rs, K)
+    assert L().crnn_gemm_wres3_supported(M, N, K) == 0
+    rows0 = L().crnn_pwconv_stat_rows(M); rows1 = L().crnn_gemm_wres3_stat_rows(M, N, K)
+    assert rows1 > 0
+    q0 = zeros(M, N); q1 = torch.full((M + 2, N), 7.0, device="cuda"); p0 = zeros(rows0, 2, N); p1 = torch.full((rows1, 2, N), float("nan"), device="cuda")
+    ok((L().crnn_pwconv_bnrelu6_fwd_f32x3 if planes == 3 else L().crnn_pwconv_bnrelu6_fwd_f32x2)(P(d), P(st), P(w), P(q0), M, N, K, P(p0), S()))
+    for rep in range(2):
+        ok(L().crnn_pwconv_bnrelu6_fwd_wres3(P(d), P(st), P(w), P(q1), M, N, K, planes, P(p1), S()))
+    assert bool((q1[M:] == 7.0).all()), "rows behind M written"
+    assert bool(torch.isfinite(p1).all()), "a statistics row or column was not written"
+    a = np.clip(host(d).astype(np.float64) * host(st)[2 * K:3 * K] + host(st)[3 * K:], 0.0, 6.0)
+    ref = a @ host(w).astype(np.float64)
+    e0 = np.abs(host(q0) - ref).max(); e1 = np.abs(host(q1[:M]) - ref).max(); sc = np.abs(ref).max()
+    # the same planes and products as the tile kernel, summed as four interleaved chains (and two reduction halves at K = 512) instead of one: equal up to
+    # the order of the fp32 accumulation
+    assert float((q1[:M] - q0).abs().max()) <= 2e-6 * sc, (float((q1[:M] - q0).abs().max()), sc)
+    assert e1 <= max(1.5 * e0, 2e-6 * sc), (e0, e1, sc)
+    if planes == 3: assert e1 <= 3e-6 * sc
+    s0 = host(p0).astype(np.float64).sum(0); s1 = host(p1).astype(np.float64).sum(0)
+    qh = host(q1[:M]).astype(np.float64)
+    for k, exact in ((0, qh.sum(0)), (1, (qh * qh).sum(0))):
+        tol = 2e-6 * np.abs(qh if k == 0 else qh * qh).sum(0).max() + 1e-6
+        assert np.abs(s1[k] - exact).max() <= tol, ("statistics vs fp64", k, np.abs(s1[k] - exact).max(), tol)
+        assert np.abs(s1[k] - s0[k]).max() <= 2 * tol
+    # shape rules
+    assert L().crnn_gemm_wres3_supported(M + 8, N, K) == -3 and L().crnn_gemm_wres3_supported(M, N + 32, K) == -3 and L().crnn_gemm_wres3_supported(M, N, 96) == -3
+    assert L().crnn_pwconv_bnrelu6_fwd_wres3(P(d), P(st), P(w), P(q1), M, N, K, 4, P(p1), S()) == -2
+    assert L().crnn_pwconv_bnrelu6_fwd_wres3(P(d), None, P(w), P(q1), M, N, K, 3, P(p1), S()) == -2
+
+
+@pytest.mark.parametrize("planes", [2, 3])
+@pytest.mark.parametrize("M,N,K", [(32 * 9, 128, 256), (32 * 500, 128, 256), (32 * 41, 256, 256), (32 * 300, 256, 512), (32 * 40, 512, 512), (32 * 260, 512, 512), (32 * 8, 64, 512)])
+def test_resident_weight_plane_data_gradient_with_batchnorm_backward_statistics(M, N, K, planes):
+    """crnn_gemm_wres3_bnstats: da = dq . W^T with W's planes resident in registers, dq streamed once, and BatchNorm-1's backward statistics taken while the
+    result is drained.  da: crnn_gemm_f32x3_bnstats / _f32x2_bnstats up to the order of the fp32 accumulation; dgamma / dbeta / coef
+    after crnn_bn_bwd_finalize_folded equal the tile kernel's up to the order of the partial sums."""
+    rs = np.random.RandomState(M % 1000 + N + K + 11 * planes)
+    dq = dev(rs.normal(size=(M, K)).astype(np.float32)); W = dev((rs.normal(size=(N, K)) * 0.1).astype(np.float32))
+    dh = (rs.normal(size=(M, N)) * 1.5 + 0.3).astype(np.float32); d = dev(dh)
+    gamma = rs.uniform(0.5, 1.5, N); beta = rs.normal(size=N) * 0.5 + 1.0
+    mean = dh.astype(np.float64).mean(0); var = dh.astype(np.float64).var(0)
+    inv = 1.0 / np.sqrt(var.astype(np.float32) + np.float32(1e-3))
+    scale = (gamma * inv).astype(np.float32); shift = (beta - mean * gamma * inv).astype(np.float32)
+    bnstate = dev(np.concatenate([mean, var, scale, shift]).astype(np.float32))
+    assert L().crnn_gemm_wres3_supported(M, N, K) == 0
+    rows1 = L().crnn_gemm_wres3_stat_rows(M, N, K)
+    p1 = torch.full((rows1, 2, N), float("nan"), device="cuda"); da1 = torch.full((M + 2, N), 7.0, device="cuda")
+    for rep in range(2):
+        ok(L().crnn_gemm_wres3_bnstats(P(dq), P(W), P(da1), M, N, K, planes, P(d), P(bnstate), P(p1), S()))
+    assert bool((da1[M:] == 7.0).all()) and bool(torch.isfinite(p1).all())
+    da0 = zeros(M, N)
+    if M % 128 == 0 and L().crnn_gemm_f32x3_bnstats_supported(M, N, K) == 0:
+        p0 = zeros(L().crnn_gemm_f32x3_bnstats_rows(M), 2, N)
+        ok((L().crnn_gemm_f32x3_bnstats if planes == 3 else L().crnn_gemm_f32x2_bnstats)(P(dq), P(W), P(da0), M, N, K, P(d), P(bnstate), P(p0), S()))
+    else:
+        ok((L().crnn_gemm_f32x3 if planes == 3 else L().crnn_gemm_f32x2)(1, P(dq), P(W), P(da0), M, N, K, K, K, N, None, 0, 0, 0, None, 0, S()))
+    ref = host(dq).astype(np.float64) @ host(W).astype(np.float64).T
+    sc = np.abs(ref).max()
+    assert float((da1[:M] - da0).abs().max()) <= 2e-6 * sc, "da differs from the tile kernel by more than the accumulation order: %g" % float((da1[:M] - da0).abs().max())
+    assert np.abs(host(da1[:M]) - ref).max() <= (3e-6 if planes == 3 else 3e-5) * sc
+    g = host(da1[:M]).astype(np.float64)
+    t = dh * scale + shift
+    gy = np.where((t > 0) & (t < 6), g, 0.0)
+    xhat = (dh.astype(np.float64) - mean.astype(np.float32).astype(np.float64)) * inv.astype(np.float64)
+    s1 = host(p1).astype(np.float64).sum(0)
+    assert_close(s1[0], gy.sum(0), rtol=1e-4, atol=1e-4 * np.abs(gy).sum(0).max(), what="sum gy vs fp64")
+    assert_close(s1[1], (gy * xhat).sum(0), rtol=1e-4, atol=1e-4 * np.abs(gy * xhat).sum(0).max(), what="sum gy xhat vs fp64")
+    dg, db, coef = zeros(N), zeros(N), zeros(2 * N); fold = zeros(32 * 2 * N)
+    ok(L().crnn_bn_bwd_finalize_folded(P(p1), rows1, N, M, P(dg), P(db), P(coef), P(fold), S()))
+    assert_close(host(db), gy.sum(0), rtol=1e-4, atol=1e-4 * np.abs(gy).sum(0).max(), what="dbeta vs fp64")
+    assert L().crnn_gemm_wres3_bnstats(P(dq), P(W), P(da1), M, N, 128, planes, P(d), P(bnstate), P(p1), S()) == -3
+    assert L().crnn_gemm_wres3_bnstats(P(dq), P(W), P(da1), M, N, K, planes, None, P(bnstate), P(p1), S()) == -2
 
 
 def _planes_of(x, stride=None):
