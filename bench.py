@@ -153,7 +153,7 @@ def depthwise_roofline(eng, iters=15):
         ti = float(np.median(tot))
         in_step = {"achieved": round(nbytes / ti / 1e9, 1), "frac": round(nbytes / ti / 1e9 / PEAK_HBM_GBS, 4), "avg_launch_ms": round(1e3 * ti / len(launches), 4)}
     # HBM bytes of the same launch set from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE as separate
-    # counter-only runs over scripts/dw_bench.py at batch 256 -- scripts/gpu_round2.sh -- folded by scripts/pmc_summary.py
+    # counter-only runs over scripts/dw_bench.py at batch 256 -- scripts/gpu_visit.sh pmcdw -- folded by scripts/pmc_summary.py
     # and committed under profiles/; FETCH_SIZE x2 per the gfx950 note in MI355X_MICROARCH.md)
     traffic, pmc_file = None, None
     try:
@@ -563,25 +563,25 @@ def cpu_baseline(full=False):
     """The reference's CPU path is Keras-TF (train.py with --G 0), absent from this image; what IS timed here, on this box's host
     cores, is the torch-CPU fp32 restatement of the same graph (oracle/torch_port.py: training-mode forward, CTC cost, autograd
     backward, global-norm clip, Keras-form Adam) on the metric's literal batch: 64 synthetic 100x32 images (BASELINE configs[0]).
-    Bounded sample (about 40 s of CPU work): one untimed warm-up step + five timed steps with 16 threads; then one timed step with 4
-    threads (the reference's own CPU setting, predict.py:88-93)."""
+    Bounded sample (about 90 s of CPU work; round 6: 2 + 10 steps instead of 1 + 5): two untimed warm-up steps + ten timed steps with 16 threads;
+    then two timed steps with 4 threads (the reference's own CPU setting, predict.py:88-93)."""
     from oracle import torch_port as TP
     # this graph does not scale over cores on the CPU (52-step Python LSTM loops, small ops): measured on the MI355X box's host
     # (2 x EPYC 9575F, 256 logical cores) 4 / 16 / 32 / 64 threads = 6.2 / 6.5 / 6.3 / 9.1 s per step, and minutes per step with all
     # 256 -- so "all cores" is capped at 16 threads and `cores` states the threads actually used
     cores = min(os.cpu_count() or 1, 16)
-    nwarm, nsteps = (5, 20) if full else (1, 5)
+    nwarm, nsteps = (5, 20) if full else (2, 10)
     sall, _ = TP.train_step_benchmark(batch=64, threads=cores, steps=nsteps, warmup=nwarm)
-    s4, _ = TP.train_step_benchmark(batch=64, threads=4, steps=nsteps if full else 1, warmup=0)     # the allocator / thread pools are warm by now
+    s4, _ = TP.train_step_benchmark(batch=64, threads=4, steps=nsteps if full else 2, warmup=0)     # the allocator / thread pools are warm by now
     return {"value": round(64 / sall, 2), "unit": "images/sec", "cores": int(cores), "kind": "port",
             "threads4": {"value": round(64 / s4, 2), "unit": "images/sec", "cores": 4, "sec_per_step": round(s4, 3)},
             "sec_per_step": round(sall, 3), "host_logical_cores": os.cpu_count(),
             "sample": "torch-CPU fp32 restatement of the Keras/TF graph (oracle/torch_port.py), full train step (fwd + CTC + bwd + clip + "
                       "Adam) at batch 64, 100x32: %d warm-up + %d timed steps (mean) with %d threads (more threads are slower on this graph); then %d timed "
                       "step(s) with 4 threads (the reference's CPU setting, predict.py:88-93); %s; Keras-TF itself is not in the image"
-                      % (nwarm, nsteps, cores, nsteps if full else 1,
+                      % (nwarm, nsteps, cores, nsteps if full else 2,
                          "BASELINE.md's full protocol (--cpu-baseline-full)" if full else
-                         "a bounded sample (about 40 s of CPU work; --cpu-baseline-full runs BASELINE.md's 5 + 20 steps: 2.5 minutes)")}
+                         "a bounded sample (about 90 s of CPU work; --cpu-baseline-full runs BASELINE.md's 5 + 20 steps: 2.5 minutes)")}
 
 
 def predict_leg(batch=1024, iters=20, precision="bf16s", cpu_sample=32):
