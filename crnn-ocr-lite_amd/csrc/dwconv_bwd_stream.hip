@@ -325,7 +325,12 @@ __global__ __launch_bounds__((STATS && !F32) ? 768 : 704, (F32 && CRNN_DBS_F32_W
     for (int e = 0; e < EPC; ++e) X0[e] = X1[e] = X2[e] = 0.f;
     // (spelled as two products: with the factored form the register allocator of the bf16 instantiation spills a 16-byte value inside the DK waves'
     // row loop -- the kernel ran 22 % slower; check with scripts/check_loop_spills.sh after touching this file)
-    unsigned char* orow = p.dx + imgoff + (long)r0 * p.rowbytes + px * p.C * ES + ch0 * ES;
+    // (round 6) the lane's byte offset inside a row as ONE opaque 32-bit value beside a wave-uniform base: left as an expression of px and ch0 the allocator kept
+    // both alive across the row loop for this one address and spilled them (8 bytes of scratch per lane)
+    int ooff = px * p.C * ES + ch0 * ES;
+    if constexpr (!PRO) asm volatile("" : "+v"(ooff));     // (the prologue forms hold other values across the loop: opaque there costs them a register more)
+    unsigned char* const obase = p.dx + imgoff + (long)r0 * p.rowbytes;
+#define orow (obase + ooff)
     // prologue form: re-form x = Dropout(ReLU6(q * scale + shift)) of the stage that arrived one step ahead (own column) into the two-row
     // buffer the DK waves read; bn_act_pool_drop_kernel's arithmetic bit for bit.  (The 16 BatchNorm-2 constants of the lane's channels
     // sit in LDS and are read per step: kw and the running rows fill the registers.)
@@ -433,6 +438,7 @@ __global__ __launch_bounds__((STATS && !F32) ? 768 : 704, (F32 && CRNN_DBS_F32_W
       if (a >= 2 && act) {
         const u32x4 o = packE<EPC>(A);
         if (!(CRNN_DBS_EXP & 2)) *reinterpret_cast<u32x4*>(orow + (long)(a - 2) * p.rowbytes) = o;
+#undef orow
         if (SW) *reinterpret_cast<u32x4*>(lds + kDxrOff + (a & 1) * kSub + offC) = o;   // (for the statistics wave, one step later)
         if (DXS) dxstats(A);
       }
@@ -600,10 +606,15 @@ __global__ __launch_bounds__((STATS && !F32) ? 768 : 704, (F32 && CRNN_DBS_F32_W
 #pragma unroll
       for (int e = 0; e < EPC; ++e) dk[t][e] += __shfl_xor(dk[t][e], o, 64);
   }
-  if (lane < p.cppw) {
+  // the lane index is formed again HERE (round 6): kept live from the top of the kernel across the row loop -- whose 72 sums, taps and running rows sit at the
+  // 168-register ceiling -- it was one of three values the allocator spilled to scratch (16 bytes per lane) and reloaded for these few lines
+  // (the prologue forms keep other values across the loop; re-forming the index costs them a register more: measured with -Rpass-analysis)
+  int lane_e = lane;
+  if constexpr (!PRO) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+  if (lane_e < p.cppw) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      float* dst = red + (gidx * 9 + t) * cw + lane * EPC;
+      float* dst = red + (gidx * 9 + t) * cw + lane_e * EPC;
 #pragma unroll
       for (int h = 0; h < EPC / 4; ++h) *reinterpret_cast<float4*>(dst + 4 * h) = make_float4(dk[t][4 * h], dk[t][4 * h + 1], dk[t][4 * h + 2], dk[t][4 * h + 3]);
     }
@@ -612,7 +623,7 @@ __global__ __launch_bounds__((STATS && !F32) ? 768 : 704, (F32 && CRNN_DBS_F32_W
   __builtin_amdgcn_s_barrier();
   {
     // the DK waves' threads, numbered 0 .. 319 by (group index, lane)
-    const int t5 = gidx * 64 + lane;
+    const int t5 = gidx * 64 + lane_e;
     const long prow = (long)(blockIdx.x / p.nsplit) * 9 * p.C;
     for (int i = t5; i < 9 * cw; i += kCW * 64) {
       float a = 0.f;

@@ -52,18 +52,19 @@ __device__ __forceinline__ bf16x8_t w3_frag(const unsigned char* p) { return __b
 // wave (0..3) = (cb = wave % CBN, kh = wave / CBN): channels slice * NS + 32 cb .. + 31, reduction half kh.  Stage j of a stripe holds, per plane,
 // PX = 32 PB pixel rows x 8 chunks of 8 k; chunk c is k = 64 j + 8 c (KHN = 1) or k = (c >> 2) K / 2 + 32 j + 8 (c & 3) (KHN = 2).
 // Accumulator chains: a v_mfma_f32_32x32x16_bf16 that accumulates onto the result of the one before it issues every ~75-95 cycles, not every 32 (measured
-// with one chain per wave: profiles/r06_wres3_bench.txt, first form).  A wave therefore runs FOUR independent chains -- NC = 4 / PB per 32-pixel block,
-// consecutive 16-k steps dealt round-robin over them -- and adds them when the stripe ends: (c0 + c1) + (c2 + c3).
+// with one chain per wave: profiles/r06_wres3_bench.txt, first form).  Consecutive MFMAs of the instruction stream therefore go to DIFFERENT accumulators:
+// the products of a 16-k step are dealt round-robin over NC chains per 32-pixel block (product t -> chain (t - T0) % NC; NC = 3, or 2 with two pixel
+// blocks and six products), every k-step adds to the same NC chains, and the chains are added when the stripe ends: (c0 + c1) + c2 -- the two chains of
+// small terms first with three planes.  Same products, another order of the fp32 accumulation than gemm_x3p_kernel's single chain.
 // WL: with three planes of a 32 x 256 block of W a wave would hold 192 registers of fragments and have room for one chain; the LOW plane (one product of
 // six) then lives in LDS -- written once by the wave that reads it, lane-linear, one ds_read_b128 per k-step -- and hi / mid (128 registers) stay resident.
 template <int KST, int KHN, int NPL, int PB, bool WL>
 __device__ __forceinline__ void w3_compute(const unsigned char* ring, unsigned char* outs, unsigned char* exch, unsigned char* wlo, const W3Params& p,
                                            int slice, int wave, int lane, int mine) {
-  constexpr int CBN = 4 / KHN, KS = 4 / KHN, NS = 32 * CBN, NCH = NS / 4, NC = 4 / PB, NG = KST * KS;
+  constexpr int CBN = 4 / KHN, KS = 4 / KHN, NS = 32 * CBN, NCH = NS / 4, NC = (PB == 2 && NPL == 3) ? 2 : 3, NG = KST * KS;
   constexpr int PLANE = PB * 4096, STAGE = NPL * PLANE, OROW = NS * 4, OTILE = PB * 32 * OROW;
   constexpr int NR = WL ? NPL - 1 : NPL;                       // planes of W in registers
   static_assert(!WL || NPL == 3, "the plane in LDS is the third");
-  static_assert(NG >= NC, "every chain gets a first step");
   const int cb = wave % CBN, kh = wave / CBN;
   const int half = lane >> 5, l31 = lane & 31, sw = (l31 >> 1) & 7;
   unsigned char* const wl = wlo + wave * (NG * 1024) + lane * 16;   // WL: this wave's low-plane fragments, [k-step g][lane] x 16 B
@@ -110,7 +111,7 @@ __device__ __forceinline__ void w3_compute(const unsigned char* ring, unsigned c
       const unsigned char* An = ring + slot * STAGE + lrow;    // the next stage has landed (the IO waves run one stage ahead of the barrier)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const int g = j * KS + ks, ch = g % NC;                // (compile-time after unrolling)
+        const int g = j * KS + ks;                             // (compile-time after unrolling)
         bf16x8_t nx[NPL][PB], nwl = {};
         const unsigned char* src = ks + 1 < KS ? A + (((cbase + 2 * (ks + 1)) ^ sw) * 16) : An + ((cbase ^ sw) * 16);
 #pragma unroll
@@ -124,8 +125,9 @@ __device__ __forceinline__ void w3_compute(const unsigned char* ring, unsigned c
 #pragma unroll
           for (int b = 0; b < PB; ++b) {
             const bf16x8_t wa = (WL && PWp[t] == 2) ? wlf : wf[PWp[t] < NR ? PWp[t] : 0][j][ks];
-            if (W3_EXP & 2) { if (g < NC && t == T0) acc[b][ch] = zero16; continue; }
-            if (g < NC && t == T0) acc[b][ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, fx[PXp[t]][b], zero16, 0, 0, 0);   // C = 0: no clearing pass
+            if (W3_EXP & 2) { if (g == 0 && t - T0 < NC) acc[b][(t - T0) % NC] = zero16; continue; }
+            const int ch = (t - T0) % NC;
+            if (g == 0 && t - T0 < NC) acc[b][ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, fx[PXp[t]][b], zero16, 0, 0, 0);   // C = 0: no clearing pass
             else acc[b][ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, fx[PXp[t]][b], acc[b][ch], 0, 0, 0);
           }
         __builtin_amdgcn_sched_barrier(0);
@@ -142,9 +144,8 @@ __device__ __forceinline__ void w3_compute(const unsigned char* ring, unsigned c
     f32x16 res[PB];
 #pragma unroll
     for (int b = 0; b < PB; ++b) {
-      if constexpr (NC == 4) res[b] = (acc[b][0] + acc[b][1]) + (acc[b][2] + acc[b][3]);
-      else if constexpr (NC == 2) res[b] = acc[b][0] + acc[b][1];
-      else res[b] = acc[b][0];
+      if constexpr (NC == 3) res[b] = (acc[b][0] + acc[b][1]) + acc[b][2];
+      else res[b] = acc[b][0] + acc[b][1];
     }
     unsigned char* ob = outs + (it & 1) * OTILE;
     if constexpr (KHN == 2) {

@@ -250,7 +250,8 @@ def test_weights_resident_gemms_and_row_stream_kernels_have_no_spilled_vector_re
         pytest.skip("hipcc not on PATH")
     csrc = os.path.join(os.path.dirname(native.LIB_PATH), "csrc")
     inc = os.path.dirname(native.HEADER)
-    for src, minimum, allowed in (("gemm_wres.hip", 15, 0), ("gemm_wgrad.hip", 2, 0), ("dwconv_stream.hip", 7, 4), ("dwconv_bwd_stream.hip", 7, 4), ("dense.hip", 2, 0)):
+    for src, minimum, allowed in (("gemm_wres.hip", 15, 0), ("gemm_wres3.hip", 12, 0), ("gemm_wgrad.hip", 2, 0), ("dwconv_stream.hip", 7, 4), ("dwconv_bwd_stream.hip", 7, 4),
+                                  ("dense.hip", 2, 0)):
         with tempfile.TemporaryDirectory() as td:
             r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", inc, "-c", os.path.join(csrc, src), "-o", os.path.join(td, "k.o"),
                                 "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
@@ -260,6 +261,11 @@ def test_weights_resident_gemms_and_row_stream_kernels_have_no_spilled_vector_re
         assert len(names) == len(spills) and len(names) >= minimum, (src, len(names), len(spills))
         bad = {n: v for n, v in zip(names, spills) if v > allowed}
         assert not bad, "%s: instantiations with spilled vector registers: %s" % (src, bad)
+        if src == "dwconv_bwd_stream.hip":
+            # the step's own instantiation, whole kernel (round 6: 3 -> 2 spilled registers, 8 bytes of scratch per lane, none inside a loop: the lane index and the
+            # dx row offset are re-formed where they are used; what is left are two column constants of the DK waves the allocator parks across the row loop)
+            step = [v for n, v in zip(names, spills) if "dw_bwd_stream_kernelILi3ELb0ELb0ELb0ELb0E" in n]
+            assert step and step[0] <= 2, step
 
 
 def test_bench_counter_traffic_lookup_and_contract_fields():
