@@ -874,6 +874,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("CRNN_DIST_BACKEND", "nccl")     # "nccl" = RCCL; "gloo" only to exercise this path on one GPU
+        if backend == "nccl":
+            # (round 6) RCCL wants one GPU per rank: say so in one line instead of failing somewhere inside init_process_group / the first collective
+            ndev, lws = torch.cuda.device_count(), int(os.environ.get("LOCAL_WORLD_SIZE", world))
+            if ndev < lws:
+                if rank == 0:
+                    print(json.dumps({"error": "bench.py --gpus %d over RCCL needs %d GPUs on this node, torch.cuda.device_count() = %d "
+                                               "(HIP_VISIBLE_DEVICES=%r, ROCR_VISIBLE_DEVICES=%r); CRNN_DIST_BACKEND=gloo shares one GPU between the ranks"
+                                               % (args.gpus, lws, ndev, os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES"))}), flush=True)
+                sys.exit(3)
         local_rank %= max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
@@ -897,6 +906,47 @@ def main():
     lld = torch.from_numpy(ll.astype(np.int32)).cuda()
     opt = Adam(lr=1e-4, beta_1=0.5, beta_2=0.999, clipnorm=5)
     allreduce = GradAllReduce(eng, dist, world) if world > 1 else None
+    preflight = None
+    if world > 1:
+        # (round 6) Before anything is timed: the gradient exchange in its blocking form and in its overlapped two-bucket form must leave the same averaged gradient on
+        # every rank -- a transport or stream-ordering problem of the asynchronous schedule shows here, by name, instead of as a silently different loss curve.
+        def grads_after(ar):
+            eng.forward(xd, train=True, seed=0)
+            if getattr(ar, "overlap", False):
+                eng.backward_top(labd, ild, lld, seed=0)
+                split = eng.grad_split
+                ar.start(eng.grads[split:]); eng.backward_bottom(seed=0); ar.start(eng.grads[:split]); ar.finish(eng.grads)
+            else:
+                eng.backward(labd, ild, lld, seed=0); ar(eng.grads)
+            torch.cuda.synchronize()
+            return eng.grads.clone()
+        g_block = grads_after(GradAllReduce(eng, dist, world, overlap=False))
+        g_over = grads_after(allreduce)
+        gmax = float(g_block.abs().max().item()) + 1e-30
+        d_sched = float((g_block - g_over).abs().max().item()) / gmax            # blocking vs overlapped exchange, this rank
+        chk = torch.stack([g_block.double().sum(), g_block.double().abs().sum(), g_over.double().sum(), g_over.double().abs().sum(),
+                           torch.tensor(d_sched, dtype=torch.float64, device="cuda")])
+        allc = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(allc, chk)
+        allc = torch.stack(allc)
+        d_ranks = float((allc[:, :4].max(0).values - allc[:, :4].min(0).values).abs().max().item())   # the averaged gradient, across ranks (either schedule)
+        d_sched = float(allc[:, 4].max().item())
+        preflight = {"what": "one forward + backward from the initial state with the blocking exchange (one all-reduce of the whole gradient buffer) and with the "
+                             "overlapped two-bucket exchange: the averaged gradient buffers compared",
+                     "max_abs_diff_blocking_vs_overlapped_rel_to_max_gradient": d_sched, "gradient_checksum_max_abs_diff_across_ranks": d_ranks,
+                     # every rank must hold the same averaged gradient; the two schedules cut the buffer into different all-reduce calls, and a ring all-reduce adds
+                     # the ranks' terms of an element in an order that depends on its position in the call: fp32 round-off of a sum of `world` terms (bit-equal at
+                     # world size 2, where a + b has one order)
+                     "overlapped_schedule_equals_blocking": d_ranks == 0.0 and d_sched <= (0.0 if world == 2 else 1e-5)}
+        if rank == 0 and not preflight["overlapped_schedule_equals_blocking"]:
+            print("bench.py: PREFLIGHT FAILED: %s" % json.dumps(preflight), file=sys.stderr, flush=True)
+        del g_block, g_over
+        # (the timed run starts from the initial state again)
+        eng.set_params(initial_parameters(eng.layout, eng.cfg.units, args.gru, seed=1))
+        for k in ("m", "v"):
+            if k in eng.opt_state:
+                eng.opt_state[k].zero_()
+        opt = Adam(lr=1e-4, beta_1=0.5, beta_2=0.999, clipnorm=5)
 
     it = 0
     for _ in range(args.warmup):
@@ -912,8 +962,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    per_rank_ms = None
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)                  # every rank's own clock around the same barrier-bracketed region: a straggler is visible by rank
+        per_rank_ms = [round(1e3 * float(t.item()) / args.steps, 3) for t in allt]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     last_loss, giveups = eng.loss_and_status().tolist()
@@ -942,6 +996,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         ms_no_ar = 1e3 * float(tt.item()) / k2
         dp_proof = {"dist_world_size": dist.get_world_size(), "dist_backend": dist.get_backend(), "ranks_reporting": int(allchk.shape[0]),
+                    "visible_gpus": torch.cuda.device_count(), "preflight": preflight,
+                    "ms_per_step_per_rank": per_rank_ms, "ms_per_step_max_over_ranks": max(per_rank_ms),
                     "transport": collective_transport_info(dist),
                     "param_checksum_max_abs_diff_across_ranks": spread, "replicas_identical": spread == 0.0,
                     "bn_moving_mean_checksum_spread": bn_spread,

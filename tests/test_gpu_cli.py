@@ -8,6 +8,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 
@@ -100,6 +101,25 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert dp["dist_world_size"] == 2 and dp["ranks_reporting"] == 2 and dp["dist_backend"] == "gloo"
     assert dp["replicas_identical"] is True and dp["param_checksum_max_abs_diff_across_ranks"] == 0.0
     assert np.isfinite(dp["exposed_allreduce_ms"]) and dp["allreduce_bytes_per_step"] > 0
+    pf = dp["preflight"]       # two ranks: a + b has one order -- the overlapped exchange must reproduce the blocking one bit for bit
+    assert pf["overlapped_schedule_equals_blocking"] is True and pf["max_abs_diff_blocking_vs_overlapped_rel_to_max_gradient"] == 0.0, pf
+    assert len(dp["ms_per_step_per_rank"]) == 2
+
+
+def test_bench_over_rccl_without_enough_gpus_says_so_in_one_line():
+    """`bench.py --gpus 2` over RCCL (backend nccl) on a box with one GPU: every rank exits with code 3 before init_process_group and rank 0 prints ONE JSON line naming
+    the reason -- not a hang or a stack trace from inside the first collective (round 6)."""
+    import json
+    import subprocess
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has the GPUs")
+    env = dict(os.environ, CRNN_DIST_BACKEND="nccl", PYTHONPATH=os.pathsep.join([ROOT, PKG]))
+    port = 29650 + os.getpid() % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--no-roofline", "--no-secondary", "--no-parity", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode != 0 and len(lines) == 1 and "needs 2 GPUs" in json.loads(lines[0])["error"], (out.stdout[-1000:], out.stderr[-1500:])
 
 
 def _torchrun(script_args, backend, nproc=2, timeout=300):
@@ -176,6 +196,12 @@ def test_bench_eight_ranks_on_one_gpu_over_gloo():
     dp = res["data_parallel"]
     assert dp["dist_world_size"] == 8 and dp["ranks_reporting"] == 8 and dp["dist_backend"] == "gloo"
     assert dp["replicas_identical"] is True and dp["param_checksum_max_abs_diff_across_ranks"] == 0.0
+    # round 6: what makes the first RCCL run unable to fail silently -- the pre-flight comparison of the blocking and the overlapped exchange, every rank's own
+    # clock, the GPUs the ranks saw
+    pf = dp["preflight"]
+    assert pf["overlapped_schedule_equals_blocking"] is True and pf["gradient_checksum_max_abs_diff_across_ranks"] == 0.0, pf
+    assert len(dp["ms_per_step_per_rank"]) == 8 and dp["ms_per_step_max_over_ranks"] == max(dp["ms_per_step_per_rank"]) and dp["visible_gpus"] >= 1
+    assert abs(dp["ms_per_step_max_over_ranks"] - res["ms_per_step"]) < 0.01 * res["ms_per_step"] + 0.01
     assert dp["transport"]["backend"] == "gloo" and "env" in dp["transport"] and "xgmi_links_reported" in dp["transport"]
 
 

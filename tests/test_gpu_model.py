@@ -391,8 +391,10 @@ def _bf16s_gradient_case(tag, B, imgh, imgw, u, tds, max_len, seed, ref=None, fl
           + " ".join(f"{k}:{e_own[k]:.1e}" for k in BF16S_TOP))
     print(f"[bf16s {tag}] gradients vs the pure oracle under the device's decisions:   worst {w_hyb} {e_hyb[w_hyb]:.3e} of its maximum; "
           + " ".join(f"{k}:{e_hyb[k]:.1e}" for k in BF16S_TOP))
+    tile = tag.endswith("-tile")      # the tile schedule runs dense2's backward and the recurrent projections' gradients as bf16 tile GEMMs (measured 6e-4 / 3.5e-3)
     tag = tag.split("-")[0]
-    bad = {k: v for k, v in e_own.items() if v > min(BF16S_OWN_STATE_TOL[tag], BF16S_TOP.get(k, 1.0))}
+    cap = lambda k: BF16S_TOP.get(k, 1.0) if not tile else max(2 * BF16S_TOP.get(k, 1.0), 1.5e-3)
+    bad = {k: v for k, v in e_own.items() if v > min(BF16S_OWN_STATE_TOL[tag], cap(k))}
     assert not bad, f"bf16s {tag}: backward differs from the oracle's on the device's own forward state: {bad}"
     bad = {k: v for k, v in e_hyb.items() if v > BF16S_HYBRID_TOL[tag]}
     assert not bad, f"bf16s {tag}: gradients differ from the pure oracle's under the device's decisions: {bad}"
