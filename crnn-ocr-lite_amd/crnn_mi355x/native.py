@@ -16,7 +16,7 @@ CSRC = os.path.join(PKG_ROOT, "csrc")
 LIB_PATH = os.path.join(PKG_ROOT, "libcrnn_mi355x.so")
 HOOKS_HEADER = os.path.join(REPO_ROOT, "include", "crnn_testhooks.h")
 HOOKS_PATH = os.path.join(PKG_ROOT, "libcrnn_testhooks.so")     # measurement / test hooks: never loaded by the product path
-SOURCES = ["gemm.hip", "gemm_nt.hip", "gemm_wres.hip", "gemm_wres3.hip", "gemm_wgrad.hip", "conv.hip", "conv_bwd_fused.hip", "dwconv_stream.hip", "dwconv_bwd_stream.hip", "stn.hip", "rnn.hip", "rnn_persist.hip", "gru_persist.hip", "ctc.hip", "dense.hip", "beam.hip", "optim.hip", "model.hip"]
+SOURCES = ["gemm.hip", "gemm_nt.hip", "gemm_wres.hip", "gemm_wres3.hip", "gemm_wgrad.hip", "gemm_wgrad3.hip", "gemm_pres.hip", "conv.hip", "conv_bwd_fused.hip", "dwconv_stream.hip", "dwconv_bwd_stream.hip", "stn.hip", "rnn.hip", "rnn_persist.hip", "gru_persist.hip", "ctc.hip", "dense.hip", "beam.hip", "optim.hip", "model.hip"]
 
 
 class crnn_config(ctypes.Structure):
@@ -39,6 +39,7 @@ FLAG_BLOCK1_KERNELS = 16384    # CRNN_FLAG_BLOCK1_KERNELS
 FLAG_LOC_NET_KERNELS = 8192    # CRNN_FLAG_LOC_NET_KERNELS
 FLAG_THREE_PLANE_BACKWARD = 65536   # CRNN_FLAG_THREE_PLANE_BACKWARD (parity mode: strict backward GEMMs)
 FLAG_TWO_PLANE_FORWARD = 131072     # CRNN_FLAG_TWO_PLANE_FORWARD (parity mode, opt-in)
+FLAG_NO_GRADIENT_PLANES = 262144   # CRNN_FLAG_NO_GRADIENT_PLANES (parity mode: BatchNorm-2's input gradients stay fp32 tensors)
 FLAG_WEIGHT_PLANES = 32768     # CRNN_FLAG_WEIGHT_PLANES (parity mode, opt-in)
 FLAG_NO_BN2_DW_FUSION = 4096   # CRNN_FLAG_NO_BN2_DW_FUSION (fp32 tensors: the two fusions above are the default)
 RNN_XCD_LOCAL = 0x100          # CRNN_RNN_XCD_LOCAL (or-ed into the uw argument of crnn_lstm_*_persist)

@@ -174,6 +174,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // packed fp32 forms contend with the matrix pipe (MI355X_MICROARCH.md: "an anti-lever beside MFMAs"); same IEEE results.
 __device__ __forceinline__ float fma_unpacked(float a, float b, float c) { float d; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 __device__ __forceinline__ float add_unpacked(float a, float b) { float d; asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ float mul_unpacked(float a, float b) { float d; asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ float sub_unpacked(float a, float b) { float d; asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 
 // ---- storage types: fp32 or bf16 (bf16 = upper half of the fp32 bit pattern, round-to-nearest-even on store) ----

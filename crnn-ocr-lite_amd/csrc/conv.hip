@@ -842,7 +842,27 @@ template <typename T>
 struct BnBwdArgsT {
   const T* x; const T* g; const float* bnstate; const float* gamma;
   int B, H, W, C, ph, pw; float rate; uint64_t seed; uint32_t layer;
+  // round 6 (fp32 tensors): pass 2 writes dx as bf16 PLANES instead (plane pl of element i at dxp[pl * dxps + i]; the words of crnn_split3_pair) -- what the
+  // pointwise GEMMs that read dx (gemm_pres.hip, gemm_wgrad3.hip) stage, split once here instead of once per tile there.  Null: dx as T
+  unsigned short* dxp = nullptr; long dxps = 0; int dxpl = 0;
 };
+// dx (fp32 values) of VEC consecutive elements as planes (VEC = 4: two words per plane)
+template <int VEC, typename T>
+__device__ __forceinline__ void bn_store_dx(const BnBwdArgsT<T>& a, T* dx, long idx, const VecF<VEC>& o) {
+  if constexpr (VEC == 4 && sizeof(T) == 4) {
+    if (a.dxp) {
+      unsigned w0[3], w1[3];
+      crnn_split3_pair(o.v[0], o.v[1], w0[0], w0[1], w0[2]);
+      crnn_split3_pair(o.v[2 % VEC], o.v[3 % VEC], w1[0], w1[1], w1[2]);
+      unsigned short* q = a.dxp + idx;
+      *reinterpret_cast<uint2*>(q) = make_uint2(w0[0], w1[0]);
+      *reinterpret_cast<uint2*>(q + a.dxps) = make_uint2(w0[1], w1[1]);
+      if (a.dxpl == 3) *reinterpret_cast<uint2*>(q + 2 * a.dxps) = make_uint2(w0[2], w1[2]);
+      return;
+    }
+  }
+  vstore<VEC>(&dx[idx], o);
+}
 
 template <int VEC, typename T>
 __device__ __forceinline__ VecF<VEC> vload_nt(const T* p) {
@@ -981,7 +1001,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgsT<T> a, float* __r
             ob.v[e] = bn_bwd_dx_pq(xb.v[e], gb.v[e], sc.v[e], Pc.v[e], Qc.v[e]);
           }
         }
-        if (PASS == 2) { vstore<VEC>(&dx[r * a.C + c0], oa); vstore<VEC>(&dx[(r + RT) * a.C + c0], ob); }
+        if (PASS == 2) { bn_store_dx<VEC, T>(a, dx, r * a.C + c0, oa); bn_store_dx<VEC, T>(a, dx, (r + RT) * a.C + c0, ob); }
       }
       for (; r < r1; r += RT) {
         VecF<VEC> xv = vload_s<VEC, NT>(&a.x[r * a.C + c0]);
@@ -993,7 +1013,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgsT<T> a, float* __r
           if (PASS == 1) { s.v[e] += gy.v[e]; q.v[e] = fmaf(gy.v[e], xh, q.v[e]); }
           else o.v[e] = bn_bwd_dx_pq(xv.v[e], gy.v[e], sc.v[e], Pc.v[e], Qc.v[e]);
         }
-        if (PASS == 2) vstore<VEC>(&dx[r * a.C + c0], o);
+        if (PASS == 2) bn_store_dx<VEC, T>(a, dx, r * a.C + c0, o);
       }
     }
     if (PASS == 1) {
@@ -1111,7 +1131,7 @@ __global__ __launch_bounds__(256) void bn_bwd_pool_kernel(BnBwdArgsT<T> a, float
 #pragma unroll
               for (int e = 0; e < VEC; ++e) o.v[e] = fmaf(cx.v[e], xw[k].v[e], c0.v[e]) + ((arg[e] == k) ? gsel[e] : 0.f);
               int ii = k / pw, j = k - ii * pw;
-              vstore<VEC>(&dx[xbase + ((long)ii * a.W + j) * a.C], o);
+              bn_store_dx<VEC, T>(a, dx, xbase + ((long)ii * a.W + j) * a.C, o);
             }
           }
         }
@@ -1205,7 +1225,7 @@ static int bn_bwd_launch(const BnBwdArgsT<T>& a, T* dx, float* dgamma, float* db
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(a.C, RED_CH)), dim3(RED_CH, RED_PL), 0, stream, parts, chunks, a.C, 1.0 / (double)M, dgamma, dbeta, coef);
   CRNN_LAUNCH_CHECK();
   }
-  if (dx == nullptr) return CRNN_OK;   // statistics only: dgamma, dbeta and coef = [mean(gy) | mean(gy * xhat)]; the caller applies pass 2 itself
+  if (dx == nullptr && a.dxp == nullptr) return CRNN_OK;   // statistics only: dgamma, dbeta and coef = [mean(gy) | mean(gy * xhat)]; the caller applies pass 2 itself
   if (window && pk == 1) hipLaunchKernelGGL((bn_bwd_pool_kernel<2, VEC, T, 2, 2>), dim3(chunks), dim3(256), 0, stream, a, (float*)nullptr, coef, dx, CW, rpc);
   else if (window && pk == 2) hipLaunchKernelGGL((bn_bwd_pool_kernel<2, VEC, T, 1, 2>), dim3(chunks), dim3(256), 0, stream, a, (float*)nullptr, coef, dx, CW, rpc);
   else if (window) hipLaunchKernelGGL((bn_bwd_pool_kernel<2, VEC, T>), dim3(chunks), dim3(256), 0, stream, a, (float*)nullptr, coef, dx, CW, rpc);
@@ -1217,8 +1237,13 @@ static int bn_bwd_launch(const BnBwdArgsT<T>& a, T* dx, float* dgamma, float* db
 template <typename T>
 static int bn_bwd_typed(const T* x, const T* g, const float* bnstate, const float* gamma, T* dx, float* dgamma, float* dbeta,
                         float* scratch_partials, float* coef, int B, int H, int W, int C, int ph, int pw, float rate, uint64_t seed,
-                        uint32_t layer, hipStream_t stream, bool apply_only = false) {
+                        uint32_t layer, hipStream_t stream, bool apply_only = false, void* dx_planes = nullptr, long plane_stride = 0, int planes = 0) {
   BnBwdArgsT<T> a{x, g, bnstate, gamma, B, H, W, C, ph, pw, rate, seed, layer};
+  if (dx_planes) {   // fp32 tensors, four channels per thread, the planes 8-byte aligned
+    if (sizeof(T) != 4 || dx || (planes != 2 && planes != 3) || (C & 3) || ((uintptr_t)dx_planes & 7) || (plane_stride & 3) || plane_stride < (long)B * H * W * C ||
+        (((uintptr_t)x | (uintptr_t)g | (uintptr_t)bnstate | (uintptr_t)coef) & 15)) return CRNN_ERR_ARG;
+    a.dxp = reinterpret_cast<unsigned short*>(dx_planes); a.dxps = plane_stride; a.dxpl = planes;
+  }
   const bool pool = (ph * pw) > 1;
   const bool al = ((((uintptr_t)x | (uintptr_t)g | (uintptr_t)dx | (uintptr_t)bnstate | (uintptr_t)coef) & 15) == 0);   // (dx may be null: statistics only)
   const bool vec = (C % 4 == 0) && al;
@@ -1252,6 +1277,21 @@ extern "C" int crnn_bn_bwd_apply_ex(const void* x, const void* g, const float* b
                                 C, ph, pw, rate, seed, layer, stream, true);
   return bn_bwd_typed<float>((const float*)x, (const float*)g, bnstate, nullptr, (float*)dx, nullptr, nullptr, nullptr, const_cast<float*>(coef), B, H, W, C,
                              ph, pw, rate, seed, layer, stream, true);
+}
+// crnn_bn_bwd_ex / crnn_bn_bwd_apply_ex for fp32 tensors with dx written as bf16 planes (planes = 2 | 3; plane pl of dx[i] at dx_planes[pl * plane_stride + i], the
+// words of crnn_split3_planes of the fp32 dx the entry points above write) -- the operand format of crnn_gemm_pres_bnstats and crnn_pwconv_bnrelu6_wgrad_planes_stream_gp.
+extern "C" int crnn_bn_bwd_planes_ex(const float* x, const float* g, const float* bnstate, const float* gamma, void* dx_planes, long plane_stride, int planes,
+                                     float* dgamma, float* dbeta, float* scratch_partials, float* coef, int B, int H, int W, int C, int ph, int pw, float rate,
+                                     uint64_t seed, uint32_t layer, hipStream_t stream) {
+  if (!x || !g || !bnstate || !dx_planes || !coef) return CRNN_ERR_ARG;
+  return bn_bwd_typed<float>(x, g, bnstate, gamma, nullptr, dgamma, dbeta, scratch_partials, coef, B, H, W, C, ph, pw, rate, seed, layer, stream, false, dx_planes,
+                             plane_stride, planes);
+}
+extern "C" int crnn_bn_bwd_apply_planes_ex(const float* x, const float* g, const float* bnstate, const float* coef, void* dx_planes, long plane_stride, int planes,
+                                           int B, int H, int W, int C, int ph, int pw, float rate, uint64_t seed, uint32_t layer, hipStream_t stream) {
+  if (!x || !g || !bnstate || !coef || !dx_planes) return CRNN_ERR_ARG;
+  return bn_bwd_typed<float>(x, g, bnstate, nullptr, nullptr, nullptr, nullptr, nullptr, const_cast<float*>(coef), B, H, W, C, ph, pw, rate, seed, layer, stream, true,
+                             dx_planes, plane_stride, planes);
 }
 // Second stage of a BatchNorm backward whose statistics pass ran elsewhere (crnn_gemm_wres_bf16_bnstats): partials [nparts][2][C] = partial
 // sums of gy and gy * xhat over `count` elements per channel -> dgamma, dbeta and coef = [mean(gy) | mean(gy * xhat)] (what

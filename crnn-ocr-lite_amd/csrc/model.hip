@@ -1160,13 +1160,29 @@ int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t au
                            aligned16(c.w("d" + p), c.w("x" + std::to_string(i - 1)), c.p(bp + "_dw"), c.w("coef")) && aligned16(gA, gB, gC, c.w("bn1s" + p));
     const bool fused_dw = fused_bf || fused_f32;
     int bn1_stats_rows = 0;                               // > 0: the data-gradient GEMM left the BatchNorm-1 backward statistics in `partials`
+    // Parity mode, two-plane backward (round 6): dq -- BatchNorm-2's input gradient, read only by this block's two pointwise GEMMs -- is WRITTEN as its two bf16
+    // planes (the bytes of the fp32 tensor) by the BatchNorm backward, so that neither GEMM splits it: the data gradient runs from the planes by LDS-DMA
+    // with the weight planes resident (gemm_pres.hip), the weight gradient's IO waves copy them (gemm_wgrad3.hip).  Same words, same products.
+    const bool dq_planes = !fused_bf && pw_products(cfg) == 2 && conv_planes(cfg, true) == 2 && dtq == CRNN_F32 && dtd == CRNN_F32 && fuse_dw_bn_x3(cfg, dtd, dtq, ci) &&
+                           !(cfg->flags & (CRNN_FLAG_GEMM_TILE_KERNELS | CRNN_FLAG_NO_BN_STATS_FUSION | CRNN_FLAG_NO_GRADIENT_PLANES | CRNN_FLAG_WEIGHT_PLANES)) &&
+                           (kBlocks[i - 1].ph * kBlocks[i - 1].pw == 1 || crnn_knob("CRNN_DQPL_POOL", 1)) &&
+                           crnn_gemm_pres_supported(M, ci, co, 2) == CRNN_OK && crnn_pwconv_wgrad_planes_stream_supported(M, co, ci) == CRNN_OK &&
+                           crnn_pwconv_wgrad_planes_stream_scratch_bytes(M, co, ci) <= kGemmScratchBytes &&
+                           aligned16(c.w("d" + p), c.w("q" + p), c.w("bn1s" + p), c.p(bp + "_pw")) && aligned16(gA, gB, gC, c.w("partials"));
     CRNN_TRY(fj.wait(gB_free)); gB_free = nullptr;        // gB is written next
     if (bn2_stats_rows > 0) {   // the depthwise-stage backward of block i+1 took this BatchNorm's statistics pass: finalize, then pass 2 alone
       CRNN_TRY(crnn_bn_bwd_finalize(c.w("bn2parts"), bn2_stats_rows, co, M, c.g(bp + "_bn2_g"), c.g(bp + "_bn2_b"), c.w("coef"), stream));
+      if (dq_planes)
+        CRNN_TRY(crnn_bn_bwd_apply_planes_ex(c.w("q" + p), gA, c.w("bn2s" + p), c.w("coef"), gB, M * co, 2, B, H, W, co, kBlocks[i - 1].ph, kBlocks[i - 1].pw,
+                                             cfg->dropout ? kDropBlock : 0.f, seed, (uint32_t)i, stream));
+      else
       CRNN_TRY(crnn_bn_bwd_apply_ex(c.w("q" + p), gA, c.w("bn2s" + p), c.w("coef"), gB, B, H, W, co, kBlocks[i - 1].ph, kBlocks[i - 1].pw,
                                     cfg->dropout ? kDropBlock : 0.f, seed, (uint32_t)i, dtq, stream));
       bn2_stats_rows = 0;
-    } else
+    } else if (dq_planes)
+      CRNN_TRY(crnn_bn_bwd_planes_ex(c.w("q" + p), gA, c.w("bn2s" + p), c.p(bp + "_bn2_g"), gB, M * co, 2, c.g(bp + "_bn2_g"), c.g(bp + "_bn2_b"), c.w("partials"),
+                                     c.w("coef"), B, H, W, co, kBlocks[i - 1].ph, kBlocks[i - 1].pw, cfg->dropout ? kDropBlock : 0.f, seed, (uint32_t)i, stream));
+    else
     CRNN_TRY(crnn_bn_bwd_ex(c.w("q" + p), gA, c.w("bn2s" + p), c.p(bp + "_bn2_g"), gB, c.g(bp + "_bn2_g"), c.g(bp + "_bn2_b"), c.w("partials"),
                             c.w("coef"), B, H, W, co, kBlocks[i - 1].ph, kBlocks[i - 1].pw, cfg->dropout ? kDropBlock : 0.f, seed, (uint32_t)i, dtq, stream));
     if (block1_fused(cfg, ci, dtd)) {   // block 1: weight gradient, data gradient and BatchNorm-1's backward statistics from one pass over dq
@@ -1198,13 +1214,25 @@ int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t au
           rc = crnn_pwconv_bnrelu6_wgrad(c.w("d" + p), c.w("bn1s" + p), gB, c.g(bp + "_pw"), M, co, ci, cw.scratch(), kGemmScratchBytes, cw.s);
         CRNN_TRY(rc);
       }
-      else if (fuse_dw_bn_x3(cfg, dtd, dtq, ci) && aligned16(c.w("d" + p), c.w("q" + p), c.w("bn1s" + p), c.p(bp + "_pw")))   // parity mode: likewise (the forward's own predicate)
-        CRNN_TRY((conv_planes(cfg, true) == 2 ? crnn_pwconv_bnrelu6_wgrad_f32x2 : crnn_pwconv_bnrelu6_wgrad_f32x3)(
-            c.w("d" + p), c.w("bn1s" + p), gB, c.g(bp + "_pw"), M, co, ci, cw.scratch(), kGemmScratchBytes, cw.s));
+      else if (fuse_dw_bn_x3(cfg, dtd, dtq, ci) && aligned16(c.w("d" + p), c.w("q" + p), c.w("bn1s" + p), c.p(bp + "_pw"))) {   // parity mode: likewise (the forward's own predicate)
+        int rc = CRNN_ERR_UNSUPPORTED;
+        // round 6: two-plane operands on the pixel stream (gemm_wgrad3.hip): one workgroup per 128 x 128 tile and pixel range, the tile in registers; dq from
+        // its planes (no fallback: the planes are what gB holds -- the predicate above is the kernel's own rule)
+        if (dq_planes) { CRNN_TRY(crnn_pwconv_bnrelu6_wgrad_planes_stream_gp(c.w("d" + p), c.w("bn1s" + p), gB, M * co, c.g(bp + "_pw"), M, co, ci, cw.scratch(), kGemmScratchBytes, cw.s)); rc = CRNN_OK; }
+        if (rc == CRNN_ERR_UNSUPPORTED)
+          rc = (conv_planes(cfg, true) == 2 ? crnn_pwconv_bnrelu6_wgrad_f32x2 : crnn_pwconv_bnrelu6_wgrad_f32x3)(
+              c.w("d" + p), c.w("bn1s" + p), gB, c.g(bp + "_pw"), M, co, ci, cw.scratch(), kGemmScratchBytes, cw.s);
+        CRNN_TRY(rc);
+      }
       else CRNN_TRY(gemm_t(cw, 2, c.w("a" + p), dtd, gB, dtq, c.g(bp + "_pw"), CRNN_F32, ci, co, (int)M, ci, co, co, nullptr, 0, 0, 0, conv_planes(cfg, true)));
       if (side) CRNN_TRY(fj.mark(&gB_free));
       // data gradient da[M][ci] = dq[M][co] . W[ci][co]^T: the persistent LDS-DMA kernels where their shape rules hold
       int rc = CRNN_ERR_UNSUPPORTED;
+      if (dq_planes) {   // (no fallback either)
+        CRNN_TRY(crnn_gemm_pres_bnstats(gB, M * co, c.p(bp + "_pw"), gA, M, ci, co, 2, c.w("d" + p), c.w("bn1s" + p), c.w("partials"), nullptr, 0, 0, stream));
+        bn1_stats_rows = crnn_gemm_pres_stat_rows(M, ci, co, 2);
+        rc = CRNN_OK;
+      }
       if (cfg->mfma_bf16 == 2 && dtq == CRNN_BF16 && dtd == CRNN_BF16 && !(cfg->flags & CRNN_FLAG_GEMM_TILE_KERNELS)) {
         int dtw = CRNN_F32;
         const float* wsh = weight_operand(c, 1, c.p(bp + "_pw"), &dtw);

@@ -80,6 +80,10 @@ typedef struct {
                                          bits per factor, gradients within 1e-5 of these, half the MFMA work -- the default since round 4) */
 #define CRNN_FLAG_TWO_PLANE_FORWARD 131072 /* opt-in, parity mode: the conv stack's forward pointwise GEMMs with two planes too (logits move by ~1e-5: inside
                                          north_star's 1e-3, outside "fp32-accurate") */
+#define CRNN_FLAG_NO_GRADIENT_PLANES 262144 /* parity mode, two-plane backward: keep BatchNorm-2's input gradient of every block an fp32 tensor that both pointwise
+                                         GEMMs split while staging (rounds 4-5) instead of two bf16 planes written by the BatchNorm backward and read by
+                                         crnn_gemm_pres_bnstats / crnn_pwconv_bnrelu6_wgrad_planes_stream_gp (round 6: same words and products; the data gradient
+                                         bit-identical, the weight gradient and the statistics the same sums in another order) */
 #define CRNN_FLAG_WEIGHT_PLANES 32768    /* opt-in, parity mode: the pointwise GEMMs read bf16 planes of their weights split once per step (crnn_split3_planes +
                                          the *_pl entry points) instead of splitting the fp32 weights in every tile that stages them; bit-identical.
                                          Measured (profiles/r04_x3_planes_bench.txt): forward -2 %, data gradient +12 % -- three 8-byte loads per item
@@ -265,6 +269,31 @@ int crnn_pwconv_bnrelu6_fwd_wres3(const float* d, const float* in_bnstate, const
  * (as crnn_gemm_f32x3_bnstats; feed crnn_bn_bwd_finalize_folded). */
 int crnn_gemm_wres3_bnstats(const float* dq, const float* w, float* da, long M, int N, int K, int planes, const float* d, const float* bnstate,
                             float* stat_partials, crnn_stream_t stream);
+/* ... and the weight gradient dw[K][N] = ReLU6(d * scale + shift)^T [K][M] . g[M][N] of the same convolution with TWO bf16 planes per operand (the parity
+ * mode's default backward precision) on a pixel stream (gemm_wgrad3.hip): a workgroup keeps one 128 x 128 tile of dw in registers over a contiguous range of
+ * 32-pixel chunks, IO waves load the fp32 rows, apply BatchNorm-1 + ReLU6 (in_bnstate; NULL: dw = d^T . g), split both operands into planes and feed an LDS
+ * ring; fp32 partial tiles in `scratch` ([ranges][K][N], crnn_pwconv_wgrad_planes_stream_scratch_bytes), fixed-order second stage.  Same planes and products as
+ * crnn_pwconv_bnrelu6_wgrad_f32x2; other reduction ranges: equal to fp32 summation round-off.  Shapes (-3 otherwise): M % 32 == 0, K and N multiples of 128 up to
+ * 1024 with at most 32 tiles, 16-byte aligned tensors.  d [M][K], g [M][N] fp32. */
+int crnn_pwconv_wgrad_planes_stream_supported(long M, int N, int K);
+size_t crnn_pwconv_wgrad_planes_stream_scratch_bytes(long M, int N, int K);
+int crnn_pwconv_bnrelu6_wgrad_planes_stream(const float* d, const float* in_bnstate, const float* g, float* dw, long M, int N, int K, float* scratch,
+                                            size_t scratch_bytes, crnn_stream_t stream);
+/* ... with g given as its two bf16 planes (hi plane [M][N], the mid plane g_plane_stride elements behind it: crnn_bn_bwd_planes_ex's output); bit-identical. */
+int crnn_pwconv_bnrelu6_wgrad_planes_stream_gp(const float* d, const float* in_bnstate, const void* g_planes, long g_plane_stride, float* dw, long M, int N, int K,
+                                               float* scratch, size_t scratch_bytes, crnn_stream_t stream);
+/* The data gradient from PRE-SPLIT planes (round 6, gemm_pres.hip): da[M][N] = dq[M][K] . w[N][K]^T with dq given as bf16 planes
+ * (plane pl of dq[m][k] at dq_planes[pl * plane_stride + m * K + k]: the words of crnn_split3_planes; planes = 2 | 3) -- written once by the kernel that produces
+ * dq (crnn_bn_bwd_planes_ex) instead of being split by every slice of every GEMM that reads it.  Four waves per workgroup, one per SIMD, the planes of a
+ * 128-channel slice of w resident in up to 512 registers, the pixel planes and the rows of d by LDS-DMA.  stat_partials
+ * [crnn_gemm_pres_stat_rows][2][N]: partial sums of gy and gy * xhat (as crnn_gemm_wres3_bnstats; feed crnn_bn_bwd_finalize_folded).  a_planes (may be NULL):
+ * a_count (2 | 3) planes of a = ReLU6(d * scale + shift) [a_count][M][N] at element stride a_stride, the other operand of the same convolution's weight
+ * gradient (crnn_pwconv_wgrad_planes).  Same planes and products as crnn_gemm_f32x2_bnstats / crnn_gemm_f32x3_bnstats, three accumulator chains: fp32 summation
+ * order only.  Shapes (-3 otherwise): K in {256, 512} (three planes: 256), N a multiple of 128 up to 1024, M % 32 == 0, 16-byte aligned tensors. */
+int crnn_gemm_pres_supported(long M, int N, int K, int planes);
+int crnn_gemm_pres_stat_rows(long M, int N, int K, int planes);
+int crnn_gemm_pres_bnstats(const void* dq_planes, long plane_stride, const float* w, float* da, long M, int N, int K, int planes, const float* d,
+                           const float* bnstate, float* stat_partials, void* a_planes, long a_stride, int a_count, crnn_stream_t stream);
 /* The same pointwise conv for ONE input channel (block 1: Conv2D(64, 1x1) on the single-channel depthwise output,
  * utils.py:64 / 49): an outer product q[m][c] = a[m] * w[c], its data gradient da[m] = dq[m] . w and weight gradient
  * dw[c] = sum_m a[m] dq[m][c].  a / da fp32; q / dq fp32 (dt_q 0) or bf16 (1); N a power of two, 8 <= N <= 256.
@@ -515,6 +544,14 @@ int crnn_bn_bwd_finalize(const float* partials, int nparts, int C, long count, f
 /* ... for long partial lists (folded into 32 chunk rows first; scratch: 32 * 2 * C floats, may be NULL for nparts <= 1024) */
 int crnn_bn_bwd_finalize_folded(const float* partials, int nparts, int C, long count, float* dgamma, float* dbeta, float* coef, float* scratch,
                                 crnn_stream_t stream);
+/* crnn_bn_bwd_ex / crnn_bn_bwd_apply_ex for fp32 tensors with dx written as bf16 PLANES (planes = 2 | 3; plane pl of dx[i] at dx_planes[pl * plane_stride + i]:
+ * the words crnn_split3_planes forms from the fp32 dx those entry points write) -- the operand format of crnn_gemm_pres_bnstats and
+ * crnn_pwconv_bnrelu6_wgrad_planes_stream_gp, split once where dx is produced instead of once per tile where it is read.  C % 4 == 0, plane_stride % 4 == 0. */
+int crnn_bn_bwd_planes_ex(const float* x, const float* g, const float* bnstate, const float* gamma, void* dx_planes, long plane_stride, int planes,
+                          float* dgamma, float* dbeta, float* scratch_partials, float* coef, int B, int H, int W, int C, int ph, int pw, float rate,
+                          uint64_t seed, uint32_t layer, crnn_stream_t stream);
+int crnn_bn_bwd_apply_planes_ex(const float* x, const float* g, const float* bnstate, const float* coef, void* dx_planes, long plane_stride, int planes,
+                                int B, int H, int W, int C, int ph, int pw, float rate, uint64_t seed, uint32_t layer, crnn_stream_t stream);
 /* Pass 2 of crnn_bn_bwd_ex alone: dx from coef = [mean(gy) | mean(gy * xhat)] of a statistics pass that ran elsewhere (crnn_bn_bwd_finalize*). */
 int crnn_bn_bwd_apply_ex(const void* x, const void* g, const float* bnstate, const float* coef, void* dx, int B, int H, int W, int C, int ph, int pw,
                          float rate, uint64_t seed, uint32_t layer, int dtype, crnn_stream_t stream);

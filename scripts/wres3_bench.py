@@ -18,7 +18,8 @@ L = native.lib()
 R = L
 if os.environ.get('W3_LIB'):
     R = ctypes.CDLL(os.environ['W3_LIB'])
-    for n in ('crnn_pwconv_bnrelu6_fwd_wres3', 'crnn_gemm_wres3_bnstats', 'crnn_gemm_wres3_stat_rows'):
+    for n in ('crnn_pwconv_bnrelu6_fwd_wres3', 'crnn_gemm_wres3_bnstats', 'crnn_gemm_wres3_stat_rows', 'crnn_pwconv_bnrelu6_wgrad_planes_stream'):
+        if not hasattr(R, n): setattr(R, n, getattr(L, n)); continue
         getattr(R, n).argtypes = getattr(L, n).argtypes; getattr(R, n).restype = getattr(L, n).restype
 bufs = []
 for (px, ci, co) in shapes:
@@ -28,7 +29,8 @@ for (px, ci, co) in shapes:
     st = torch.cat([torch.randn(ci) * 0.1, 1 + torch.rand(ci), 1 + 0.3 * torch.randn(ci), 1.0 + 0.5 * torch.randn(ci)]).cuda()
     rows = max(L.crnn_pwconv_stat_rows(M), L.crnn_gemm_f32x3_bnstats_rows(M), 1024)
     parts = torch.empty(rows * 2 * max(ci, co) + 64, device="cuda")
-    bufs.append((M, d, q, dq, da, w, st, parts))
+    dw = torch.empty(ci, co, device="cuda")
+    bufs.append((M, d, q, dq, da, w, st, parts, dw))
 def run(name, fn, iters=6):
     ms = np.full((iters, len(shapes)), np.nan)
     for it in range(iters + 2):
@@ -43,7 +45,10 @@ def run(name, fn, iters=6):
     return med
 def mk(kind, planes, res):
     def f(sh, bf):
-        px, ci, co = sh; M, d, q, dq, da, w, st, parts = bf
+        px, ci, co = sh; M, d, q, dq, da, w, st, parts, dw = bf
+        if kind == "wgrad":
+            if res: return R.crnn_pwconv_bnrelu6_wgrad_planes_stream(P(d), P(st), P(dq), P(dw), M, co, ci, P(scr), sb, S()) if planes == 2 else -3
+            return (L.crnn_pwconv_bnrelu6_wgrad_f32x3 if planes == 3 else L.crnn_pwconv_bnrelu6_wgrad_f32x2)(P(d), P(st), P(dq), P(dw), M, co, ci, P(scr), sb, S())
         if kind == "fwd":
             if res: return R.crnn_pwconv_bnrelu6_fwd_wres3(P(d), P(st), P(w), P(q), M, co, ci, planes, P(parts), S())
             return (L.crnn_pwconv_bnrelu6_fwd_f32x3 if planes == 3 else L.crnn_pwconv_bnrelu6_fwd_f32x2)(P(d), P(st), P(w), P(q), M, co, ci, P(parts), S())
@@ -52,8 +57,9 @@ def mk(kind, planes, res):
     return f
 print("batch %d; bounds per block (us): " % B + "  ".join("%d>%d mfma6 %.0f mfma3 %.0f fwd-hbm %.0f dgrad-hbm %.0f" % (
     ci, co, 2e6 * B * px * ci * co * 6 / 2.5e15, 2e6 * B * px * ci * co * 3 / 2.5e15, 1e6 * B * px * (ci + co) * 4 / 8e12, 1e6 * B * px * (2 * ci + co) * 4 / 8e12) for px, ci, co in shapes))
-outs = {"fwd": 2, "dgrad": 4}
-kinds = (("fwd", 3), ("fwd", 2), ("dgrad", 2), ("dgrad", 3))
+outs = {"fwd": 2, "dgrad": 4, "wgrad": 8}
+scr = torch.empty(16 * 1024 * 1024, device="cuda"); sb = ctypes.c_size_t(scr.numel() * 4)
+kinds = (("fwd", 3), ("fwd", 2), ("dgrad", 2), ("dgrad", 3), ("wgrad", 2))
 if os.environ.get("W3_ONLY"): kinds = tuple((k.split(":")[0], int(k.split(":")[1])) for k in os.environ["W3_ONLY"].split(","))
 for kind, planes in kinds:
     t0 = run("%s, %d planes, tile kernel" % (kind, planes), mk(kind, planes, False)) if not os.environ.get("W3_LIB") else np.ones(len(shapes))

@@ -720,6 +720,42 @@ def test_parity_mode_two_plane_backward_gemms_stay_within_1e_4_of_three_planes(s
     assert 0 < dy < 1e-4 and dl < 1e-4 and torch.equal(df, d3), (dy, dl)
 
 
+@pytest.mark.parametrize("shape", [(4, 100, 32, 38, 23, 128, 256), (8, 100, 32, 38, 23, 128, 256), (3, 200, 32, 62, 21, 128, 256)])
+def test_parity_mode_gradient_planes_schedule_equals_the_fp32_gradient_schedule(shape):
+    """Parity mode, round 6: BatchNorm-2's input gradient of blocks 3-7 is written as two bf16 planes by the BatchNorm backward and read as such by the block's
+    data-gradient GEMM (crnn_gemm_pres_bnstats: LDS-DMA, weight planes resident) and weight-gradient GEMM (crnn_pwconv_bnrelu6_wgrad_planes_stream_gp).
+    CRNN_FLAG_NO_GRADIENT_PLANES keeps the fp32 tensor that both GEMMs split while staging (rounds 4-5).  Same planes, same products: the forward is untouched
+    (bit-identical posteriors / loss) and every gradient tensor agrees to the order of fp32 sums (the data gradients are the tile kernel's bit for bit, the
+    statistics and the weight gradients the same sums grouped differently) -- within 1e-4 of each tensor's maximum (measured 2e-6 .. 3e-5, on BatchNorm
+    shift gradients, the sums with the most cancellation): the level of the two-plane products themselves."""
+    from crnn_mi355x import native
+    B, imgh, imgw, ncls, max_len, tds, u = shape
+    cfg = M.Config(imgh=imgh, imgw=imgw, max_len=max_len, time_dense_size=tds, n_units=u, num_classes=ncls)
+    p, bn = M.init_params(cfg, seed=12, dtype=np.float64)
+    p = M.randomize_params(cfg, p)
+    x, lab, il, ll = M.synthetic_batch(cfg, B, seed=6, dtype=np.float64)
+    out = {}
+    for flags in (0, native.FLAG_NO_GRADIENT_PLANES):
+        eng = Engine(B, imgh, imgw, ncls, max_len, tds, u, stn=True, dropout=True, precision="fp32", flags=flags)
+        eng.set_params(p, bn)
+        eng.ws.fill_(float("nan")); eng.grads.zero_()
+        y = eng.forward(x.astype(np.float32), train=True, seed=3).clone()
+        loss = eng.backward(lab, il, ll, seed=3).clone()
+        out[flags] = (y, loss, eng.grads.clone())
+        lay = eng.layout
+        del eng
+    (y0, l0, g0), (y1, l1, g1) = out[0], out[native.FLAG_NO_GRADIENT_PLANES]
+    assert torch.isfinite(g0).all() and torch.equal(y0, y1) and torch.equal(l0, l1)
+    worst, wname = 0.0, ""
+    for name, (off, size, _) in lay.items():
+        a, b = g0[off:off + size].double(), g1[off:off + size].double()
+        if float(b.abs().max()) > 0:
+            r = float((a - b).abs().max() / b.abs().max())
+            if r > worst: worst, wname = r, name
+    print("gradient planes vs fp32 gradient tensors: worst tensor %s max-rel %.3g" % (wname, worst))
+    assert worst < 1e-4, (wname, worst)
+
+
 @pytest.mark.parametrize("shape", [(5, 60, 48, 20, 10, 64, 128), (4, 100, 32, 38, 23, 128, 256)])
 def test_bf16s_producer_fused_pointwise_convs_equal_the_two_pass_path(shape):
     """bf16s training applies the depthwise BatchNorm + ReLU6 inside the pointwise GEMMs (forward and weight gradient);

@@ -1921,6 +1921,39 @@ def test_resident_weight_plane_data_gradient_with_batchnorm_backward_statistics(
     assert L().crnn_gemm_wres3_bnstats(P(dq), P(W), P(da1), M, N, K, planes, None, P(bnstate), P(p1), S()) == -2
 
 
+@pytest.mark.parametrize("M,K,N,bn", [(32 * 7, 128, 128, True), (32 * 900, 128, 256, True), (32 * 64 * 3, 256, 256, True), (32 * 500, 256, 512, True), (32 * 1200, 512, 512, True),
+                                        (32 * 333, 512, 128, False), (32 * 2, 128, 128, False)])
+def test_two_plane_weight_gradient_on_the_pixel_stream_equals_the_tile_kernel(M, K, N, bn):
+    """crnn_pwconv_bnrelu6_wgrad_planes_stream (round 6, gemm_wgrad3.hip): the parity mode's pointwise weight gradient with two bf16 planes per operand on a pixel
+    stream -- against crnn_pwconv_bnrelu6_wgrad_f32x2 (same planes and products, other reduction ranges: fp32 summation round-off) and the fp64 product of the
+    activated operand (16 significant bits per factor: 3e-5 of the scale); ranges of one chunk to hundreds; without the BatchNorm transform too; repeated launches
+    give the same bits."""
+    rs = np.random.RandomState(M % 1000 + N + K)
+    d = dev((rs.normal(size=(M, K)) * 1.5 + 0.4).astype(np.float32)); g = dev(rs.normal(size=(M, N)).astype(np.float32))
+    st = _bnstate(rs, K)
+    assert L().crnn_pwconv_wgrad_planes_stream_supported(M, N, K) == 0
+    nb = L().crnn_pwconv_wgrad_planes_stream_scratch_bytes(M, N, K)
+    assert 0 < nb <= 64 << 20
+    scr = torch.empty(nb // 4, device="cuda"); scr2 = zeros(16 * 1024 * 1024); sb2 = ctypes.c_size_t(scr2.numel() * 4)
+    dw1 = torch.full((K + 1, N), 7.0, device="cuda"); dw2 = torch.full((K + 1, N), 7.0, device="cuda"); dw0 = zeros(K, N)
+    ok(L().crnn_pwconv_bnrelu6_wgrad_planes_stream(P(d), P(st) if bn else None, P(g), P(dw1), M, N, K, P(scr), ctypes.c_size_t(nb), S()))
+    ok(L().crnn_pwconv_bnrelu6_wgrad_planes_stream(P(d), P(st) if bn else None, P(g), P(dw2), M, N, K, P(scr), ctypes.c_size_t(nb), S()))
+    assert torch.equal(dw1, dw2) and bool((dw1[K:] == 7.0).all())
+    if bn:
+        a = zeros(M, K)
+        ok(L().crnn_bn_act_pool_drop_ex(P(d), P(st), P(a), 1, 1, M, K, 1, 1, 0.0, 0, 0, 0, 0, S()))
+        ok(L().crnn_pwconv_bnrelu6_wgrad_f32x2(P(d), P(st), P(g), P(dw0), M, N, K, P(scr2), sb2, S()))
+    else:
+        a = d
+        ok(L().crnn_gemm_f32x2(2, P(d), P(g), P(dw0), K, N, M, K, N, N, None, 0, 0, 0, P(scr2), sb2, S()))
+    ref = host(a).astype(np.float64).T @ host(g).astype(np.float64)
+    sc = np.abs(ref).max()
+    assert float((dw1[:K] - dw0).abs().max()) <= 2e-6 * sc + 1e-6, (float((dw1[:K] - dw0).abs().max()), sc)
+    assert np.abs(host(dw1[:K]) - ref).max() <= 3e-5 * sc + 1e-6
+    assert L().crnn_pwconv_wgrad_planes_stream_supported(M + 8, N, K) == -3 and L().crnn_pwconv_wgrad_planes_stream_supported(M, N, 64) == -3
+    assert L().crnn_pwconv_bnrelu6_wgrad_planes_stream(P(d), P(st), P(g), P(dw1), M, N, K, P(scr), ctypes.c_size_t(1024), S()) == -3
+
+
 def _planes_of(x, stride=None):
     """crnn_split3_planes of a device fp32 tensor -> (planes tensor [3 * stride] of bf16 words, stride)."""
     n = x.numel(); stride = stride or n
@@ -2550,3 +2583,119 @@ def test_localisation_net_dense_kernels(B, F):
     ok(L().crnn_loc_fc_bwd(P(dev(flat)), P(fc1), P(dev(dth)), P(dev(w1)), P(dev(w2)), P(dfc1), P(dflat), P(dw1), P(db1), P(dw2), P(db2), B, F, S()))
     for got, ref, nm in ((dfc1, dpre, "dfc1"), (dflat, dflat_ref, "dflat"), (dw1, dw1_ref, "dW1"), (db1, db1_ref, "db1"), (dw2, dw2_ref, "dW2"), (db2, db2_ref, "db2")):
         assert_close(host(got), ref, rtol=1e-4, atol=1e-5, what=nm)
+
+
+# ------------------------------------------------------------------------------------------------ round 6: gradients as planes
+def _split_planes(x, n_planes=3):
+    """crnn_split3_planes of a device fp32 tensor -> int16 tensor [3 * n] (plane stride n)."""
+    n = x.numel()
+    pl = torch.empty(3 * n, dtype=torch.int16, device="cuda")
+    ok(L().crnn_split3_planes(P(x), P(pl), n, n, S()))
+    return pl
+
+
+@pytest.mark.parametrize("planes", [2, 3])
+@pytest.mark.parametrize("M,N,K", [(64 * 9, 128, 256), (64 * 250, 128, 256), (64 * 41, 256, 256), (64 * 150, 256, 512), (64 * 20, 512, 512), (64 * 700, 512, 512),
+                                   (64 * 1, 128, 512), (64 * 66, 128, 512)])
+def test_data_gradient_from_planes_equals_the_tile_kernel_bit_for_bit(M, N, K, planes):
+    """crnn_gemm_pres_bnstats (round 6, gemm_pres.hip): da = dq . W^T with dq given as pre-split bf16 planes (LDS-DMA, no split in the GEMM), the planes of W
+    resident in up to 512 registers per wave, one wave per SIMD.  The same planes, products and single fp32 accumulation chain per result as the tile kernel:
+    da EQUALS crnn_gemm_f32x2 / _f32x3 (mode 1) bit for bit; the BatchNorm-1 backward statistics are the tile kernel's sums in another order (vs fp64);
+    the planes of a = ReLU6(d * scale + shift) the drain can write equal crnn_split3_planes of crnn_bn_act_pool_drop_ex's output word for word.  Workgroups
+    with no stripe, one stripe (prologue + final drain only), stripes below and above the ring's warm-up; repeated launches give the same bits; the memory
+    behind the outputs is untouched."""
+    if planes == 3 and K == 512:
+        assert L().crnn_gemm_pres_supported(M, N, K, 3) == -3
+        return
+    rs = np.random.RandomState(M % 1000 + N + K + 13 * planes)
+    dq = dev((rs.normal(size=(M, K)) * 1e-2).astype(np.float32)); W = dev((rs.normal(size=(N, K)) * 0.1).astype(np.float32))
+    dh = (rs.normal(size=(M, N)) * 1.5 + 0.3).astype(np.float32); d = dev(dh)
+    gamma = rs.uniform(0.5, 1.5, N); beta = rs.normal(size=N) * 0.5 + 1.0
+    mean = dh.astype(np.float64).mean(0); var = dh.astype(np.float64).var(0)
+    inv = 1.0 / np.sqrt(var.astype(np.float32) + np.float32(1e-3))
+    scale = (gamma * inv).astype(np.float32); shift = (beta - mean * gamma * inv).astype(np.float32)
+    bnstate = dev(np.concatenate([mean, var, scale, shift]).astype(np.float32))
+    assert L().crnn_gemm_pres_supported(M, N, K, planes) == 0
+    rows = L().crnn_gemm_pres_stat_rows(M, N, K, planes)
+    assert 0 < rows <= 512
+    pl = _split_planes(dq)
+    da0 = zeros(M, N)
+    ok((L().crnn_gemm_f32x3 if planes == 3 else L().crnn_gemm_f32x2)(1, P(dq), P(W), P(da0), M, N, K, K, K, N, None, 0, 0, 0, None, 0, S()))
+    for emit in (0, planes):
+        p1 = torch.full((rows + 1, 2, N), float("nan"), device="cuda"); da1 = torch.full((M + 2, N), 7.0, device="cuda")
+        ap = torch.full((emit * M * N + 8,), 0x1234, dtype=torch.int16, device="cuda") if emit else None
+        for rep in range(2):
+            ok(L().crnn_gemm_pres_bnstats(P(pl), M * K, P(W), P(da1), M, N, K, planes, P(d), P(bnstate), P(p1), P(ap), M * N, emit, S()))
+            if rep == 0: keep = (da1.clone(), p1.clone())
+        assert torch.equal(da1, keep[0]) and torch.equal(p1[:rows], keep[1][:rows])
+        assert bool((da1[M:] == 7.0).all()) and bool(torch.isfinite(p1[:rows]).all()) and bool(torch.isnan(p1[rows:]).all())
+        assert torch.equal(da1[:M], da0), "da differs from the tile kernel: %g" % float((da1[:M] - da0).abs().max())
+        g = host(da1[:M]).astype(np.float64)
+        t = dh * scale + shift
+        gy = np.where((t > 0) & (t < 6), g, 0.0)
+        xhat = (dh.astype(np.float64) - mean.astype(np.float32).astype(np.float64)) * inv.astype(np.float64)
+        s1 = host(p1[:rows]).astype(np.float64).sum(0)
+        assert_close(s1[0], gy.sum(0), rtol=1e-4, atol=1e-4 * np.abs(gy).sum(0).max(), what="sum gy vs fp64")
+        assert_close(s1[1], (gy * xhat).sum(0), rtol=1e-4, atol=1e-4 * np.abs(gy * xhat).sum(0).max(), what="sum gy xhat vs fp64")
+        if emit:
+            a = zeros(M, N)
+            ok(L().crnn_bn_act_pool_drop_ex(P(d), P(bnstate), P(a), 1, 1, M, N, 1, 1, 0.0, 0, 0, 0, 0, S()))
+            ref = _split_planes(a)
+            assert torch.equal(ap[:emit * M * N], ref[:emit * M * N]) and bool((ap[emit * M * N:] == 0x1234).all())
+    dg, db, coef = zeros(N), zeros(N), zeros(2 * N); fold = zeros(32 * 2 * N)
+    ok(L().crnn_bn_bwd_finalize_folded(P(p1), rows, N, M, P(dg), P(db), P(coef), P(fold), S()))
+    assert_close(host(db), gy.sum(0), rtol=1e-4, atol=1e-4 * np.abs(gy).sum(0).max(), what="dbeta vs fp64")
+    assert L().crnn_gemm_pres_supported(M, N, 128, planes) == -3 and L().crnn_gemm_pres_supported(M + 16, N, K, planes) == -3 and L().crnn_gemm_pres_supported(M, 64, K, planes) == -3
+    assert L().crnn_gemm_pres_bnstats(P(pl), M * K, P(W), P(da1), M, N, K, planes, None, P(bnstate), P(p1), None, 0, 0, S()) == -2
+    assert L().crnn_gemm_pres_bnstats(P(pl), M * K, P(W), P(da1), M, N, K, 4, P(d), P(bnstate), P(p1), None, 0, 0, S()) == -2
+
+
+@pytest.mark.parametrize("B,H,W,C,ph,pw,rate", [(2, 8, 12, 64, 1, 1, 0.0), (3, 8, 12, 128, 2, 2, 0.2), (2, 6, 20, 256, 1, 2, 0.2), (1, 9, 7, 32, 1, 1, 0.2), (2, 18, 52, 512, 1, 1, 0.0)])
+@pytest.mark.parametrize("planes", [2, 3])
+def test_batchnorm_backward_writes_its_input_gradient_as_planes(B, H, W, C, ph, pw, rate, planes):
+    """crnn_bn_bwd_planes_ex / crnn_bn_bwd_apply_planes_ex (round 6): the fp32 BatchNorm backward (through dropout, max-pool and ReLU6) with dx written as bf16
+    planes -- the words crnn_split3_planes forms from the dx crnn_bn_bwd_ex writes, bit for bit; dgamma, dbeta and coef unchanged; nothing written behind the
+    planes; bad arguments rejected."""
+    rs = np.random.RandomState(B * 131 + H * 17 + C + ph + 3 * pw)
+    Ho, Wo = H // ph, W // pw
+    x = dev((rs.normal(size=(B, H, W, C)) * 1.2 + 0.5).astype(np.float32)); g = dev(rs.normal(size=(B, Ho, Wo, C)).astype(np.float32))
+    st = _bnstate(rs, C); gamma = dev(rs.uniform(0.5, 1.5, C).astype(np.float32))
+    n = B * H * W * C
+    chunks = L().crnn_bn_bwd_chunks(B * H * W)
+    def run(planes_out):
+        dgm, dbt, coef, pp = zeros(C), zeros(C), zeros(2 * C), zeros(chunks * 2 * C + 64)
+        if planes_out is None:
+            dx = zeros(B, H, W, C)
+            ok(L().crnn_bn_bwd_ex(P(x), P(g), P(st), P(gamma), P(dx), P(dgm), P(dbt), P(pp), P(coef), B, H, W, C, ph, pw, rate, 77, 3, 0, S()))
+            return dx, dgm, dbt, coef
+        ok(L().crnn_bn_bwd_planes_ex(P(x), P(g), P(st), P(gamma), P(planes_out), n, planes, P(dgm), P(dbt), P(pp), P(coef), B, H, W, C, ph, pw, rate, 77, 3, S()))
+        return planes_out, dgm, dbt, coef
+    dx, dg0, db0, coef0 = run(None)
+    ref = _split_planes(dx)
+    out = torch.full((planes * n + 16,), 0x4321, dtype=torch.int16, device="cuda")
+    _, dg1, db1, coef1 = run(out)
+    assert torch.equal(out[:planes * n], ref[:planes * n]) and bool((out[planes * n:] == 0x4321).all())
+    assert torch.equal(dg0, dg1) and torch.equal(db0, db1) and torch.equal(coef0, coef1)
+    out2 = torch.full((planes * n + 16,), 0x4321, dtype=torch.int16, device="cuda")
+    ok(L().crnn_bn_bwd_apply_planes_ex(P(x), P(g), P(st), P(coef0), P(out2), n, planes, B, H, W, C, ph, pw, rate, 77, 3, S()))
+    assert torch.equal(out2, out)
+    assert L().crnn_bn_bwd_apply_planes_ex(P(x), P(g), P(st), P(coef0), P(out2), n, 4, B, H, W, C, ph, pw, rate, 77, 3, S()) == -2
+    assert L().crnn_bn_bwd_apply_planes_ex(P(x), P(g), P(st), P(coef0), P(out2), n - 4, planes, B, H, W, C, ph, pw, rate, 77, 3, S()) == -2
+    assert L().crnn_bn_bwd_apply_planes_ex(P(x), P(g), P(st), P(coef0), None, n, planes, B, H, W, C, ph, pw, rate, 77, 3, S()) == -2
+
+
+@pytest.mark.parametrize("M,K,N,bn", [(32 * 7, 128, 128, True), (32 * 900, 128, 256, True), (32 * 500, 256, 512, True), (32 * 1200, 512, 512, True), (32 * 333, 512, 128, False)])
+def test_weight_gradient_stream_reads_the_planes_of_g(M, K, N, bn):
+    """crnn_pwconv_bnrelu6_wgrad_planes_stream_gp: g given as the two planes crnn_bn_bwd_planes_ex writes -- the IO waves copy the words the fp32 form splits:
+    the same result bit for bit."""
+    rs = np.random.RandomState(M % 1000 + N + K + 5)
+    d = dev((rs.normal(size=(M, K)) * 1.5 + 0.4).astype(np.float32)); g = dev((rs.normal(size=(M, N)) * 1e-2).astype(np.float32))
+    st = _bnstate(rs, K)
+    nb = L().crnn_pwconv_wgrad_planes_stream_scratch_bytes(M, N, K)
+    scr = torch.empty(nb // 4, device="cuda")
+    dw0 = torch.full((K + 1, N), 7.0, device="cuda"); dw1 = torch.full((K + 1, N), 7.0, device="cuda")
+    ok(L().crnn_pwconv_bnrelu6_wgrad_planes_stream(P(d), P(st) if bn else None, P(g), P(dw0), M, N, K, P(scr), ctypes.c_size_t(nb), S()))
+    gp = _split_planes(g)
+    ok(L().crnn_pwconv_bnrelu6_wgrad_planes_stream_gp(P(d), P(st) if bn else None, P(gp), M * N, P(dw1), M, N, K, P(scr), ctypes.c_size_t(nb), S()))
+    assert torch.equal(dw0, dw1) and bool((dw1[K:] == 7.0).all())
+    assert L().crnn_pwconv_bnrelu6_wgrad_planes_stream_gp(P(d), None, None, M * N, P(dw1), M, N, K, P(scr), ctypes.c_size_t(nb), S()) == -2
