@@ -121,24 +121,41 @@ __global__ __launch_bounds__(256, OCC) void pres_dgrad_kernel(PresParams p) {
   const unsigned db_a = __builtin_amdgcn_readfirstlane(pr_lds_addr(Db));
   const int half = lane >> 5, l31 = lane & 31, sw = (l31 >> 1) & 7;
 
-  // ---- the slice's planes, once: lane (l31, half) holds k = 64 j + 16 ks + 8 half + 0..7 of channel slice * 128 + 32 wave + l31
+  // ---- the slice's planes, once: lane (l31, half) holds k = 64 j + 16 ks + 8 half + 0..7 of channel slice * 128 + 32 wave + l31.  The wave's 32 rows of W
+  // come through LDS (the ring is not in use yet) in halves of 256 k: one LDS-DMA piece = one 1-KiB half row, fully coalesced; 16-byte chunk c of row r at
+  // position c ^ (r & 15), so that the fragment reads (32 rows, the same chunk) spread over the banks.  (Read straight from memory -- two 16-byte loads per
+  // fragment and lane, every lane in another 2-KiB row -- the prologue took 15 us of a 230-us launch at K = 512: profiles/r06_pres_ablate.txt.)
   bf16x8_t wf[NPL][KST][4];
   {
-    const float* wrow = p.W + (long)(slice * 128 + 32 * wave + l31) * p.ldw + 8 * half;
+    constexpr int NH = KST / 4;                                 // halves of 256 k
+    unsigned char* const wst = smem + wave * 32768;             // this wave's staging area: 32 rows x 1 KiB
+    const unsigned wst_a = __builtin_amdgcn_readfirstlane(pr_lds_addr(wst));
 #pragma unroll
-    for (int j = 0; j < KST; ++j)
+    for (int H = 0; H < NH; ++H) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the previous half's fragment reads are done)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const float4 v0 = *reinterpret_cast<const float4*>(wrow + 64 * j + 16 * ks), v1 = *reinterpret_cast<const float4*>(wrow + 64 * j + 16 * ks + 4);
-        unsigned w[3][4];
-        crnn_split3_pair(v0.x, v0.y, w[0][0], w[1][0], w[2][0]); crnn_split3_pair(v0.z, v0.w, w[0][1], w[1][1], w[2][1]);
-        crnn_split3_pair(v1.x, v1.y, w[0][2], w[1][2], w[2][2]); crnn_split3_pair(v1.z, v1.w, w[0][3], w[1][3], w[2][3]);
+      for (int r = 0; r < 32; ++r) pr_dma16(p.W + (long)(slice * 128 + 32 * wave + r) * p.ldw + 256 * H + 4 * (lane ^ (r & 15)), wst_a + r * 1024);
+      pr_wait_vm<0>();
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) {   // the accumulator half of the file holds the result blocks and the first NFA fragments; the rest stay in VGPRs
-          const bf16x8_t f = __builtin_bit_cast(bf16x8_t, u32x4{w[pl][0], w[pl][1], w[pl][2], w[pl][3]});
-          wf[pl][j][ks] = ((pl * KST + j) * 4 + ks < NFA) ? pr_pin_a(f) : pr_pin_v(f);
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int j = 4 * H + jj;
+          const int c = (64 * jj + 16 * ks + 8 * half) >> 2;   // chunk of 4 floats within the half row
+          const float4 v0 = *reinterpret_cast<const float4*>(wst + l31 * 1024 + ((c ^ (l31 & 15)) << 4));
+          const float4 v1 = *reinterpret_cast<const float4*>(wst + l31 * 1024 + (((c + 1) ^ (l31 & 15)) << 4));
+          unsigned w[3][4];
+          crnn_split3_pair(v0.x, v0.y, w[0][0], w[1][0], w[2][0]); crnn_split3_pair(v0.z, v0.w, w[0][1], w[1][1], w[2][1]);
+          crnn_split3_pair(v1.x, v1.y, w[0][2], w[1][2], w[2][2]); crnn_split3_pair(v1.z, v1.w, w[0][3], w[1][3], w[2][3]);
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) {   // the accumulator half of the file holds the result blocks and the first NFA fragments; the rest stay in VGPRs
+            const bf16x8_t f = __builtin_bit_cast(bf16x8_t, u32x4{w[pl][0], w[pl][1], w[pl][2], w[pl][3]});
+            wf[pl][j][ks] = ((pl * KST + j) * 4 + ks < NFA) ? pr_pin_a(f) : pr_pin_v(f);
+          }
         }
-      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                              // every wave has its fragments: the ring may land on the staging areas
   }
   float bmu[8], binv[8], bsc[8], bsh[8];
 #pragma unroll
@@ -403,7 +420,7 @@ int pres_supported(long M, int N, int K, int planes) {
 template <int KST, int NPL, int PB, int R, int OCC, int NPA, int DB>
 int pres_launch(const PresParams& p, int grid, hipStream_t stream) {
   constexpr int lds = R * NPL * PB * 4096 + 4 * PB * 4096 + 4 * DB * PB * 4096;
-  static_assert(lds * OCC <= 160 * 1024, "LDS per CU");
+  static_assert(lds * OCC <= 160 * 1024 && lds >= 4 * 32768, "LDS per CU; the prologue stages 32 KiB of W per wave");
   CRNN_LDS_ATTR((pres_dgrad_kernel<KST, NPL, PB, R, OCC, NPA, DB>), lds);
   hipLaunchKernelGGL((pres_dgrad_kernel<KST, NPL, PB, R, OCC, NPA, DB>), dim3(grid), dim3(256), lds, stream, p);
   CRNN_LAUNCH_CHECK();
