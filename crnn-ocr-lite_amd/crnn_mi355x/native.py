@@ -40,6 +40,7 @@ FLAG_LOC_NET_KERNELS = 8192    # CRNN_FLAG_LOC_NET_KERNELS
 FLAG_THREE_PLANE_BACKWARD = 65536   # CRNN_FLAG_THREE_PLANE_BACKWARD (parity mode: strict backward GEMMs)
 FLAG_TWO_PLANE_FORWARD = 131072     # CRNN_FLAG_TWO_PLANE_FORWARD (parity mode, opt-in)
 FLAG_NO_GRADIENT_PLANES = 262144   # CRNN_FLAG_NO_GRADIENT_PLANES (parity mode: BatchNorm-2's input gradients stay fp32 tensors)
+FLAG_NO_POOL_ARGMAX_Q = 524288     # CRNN_FLAG_NO_POOL_ARGMAX_Q (pooled blocks: the backward's statistics pass scans the windows again)
 FLAG_WEIGHT_PLANES = 32768     # CRNN_FLAG_WEIGHT_PLANES (parity mode, opt-in)
 FLAG_NO_BN2_DW_FUSION = 4096   # CRNN_FLAG_NO_BN2_DW_FUSION (fp32 tensors: the two fusions above are the default)
 RNN_XCD_LOCAL = 0x100          # CRNN_RNN_XCD_LOCAL (or-ed into the uw argument of crnn_lstm_*_persist)

@@ -746,7 +746,7 @@ extern "C" int crnn_bn_infer_state_batch(int n, const float* const* mmean, const
 template <int VEC, typename TI, typename TO, typename IDX, int PHT, int PWT>
 __global__ void bn_act_pool_drop_kernel(const TI* __restrict__ x, const float* __restrict__ bnstate,
                                         TO* __restrict__ y, int B, int H, int W, int C, int ph_, int pw_, float rate,
-                                        uint64_t seed, uint32_t layer) {
+                                        uint64_t seed, uint32_t layer, TI* __restrict__ qmax = nullptr) {
   const int ph = PHT ? PHT : ph_, pw = PWT ? PWT : pw_;
   const int Ho = H / ph, Wo = W / pw, CL = C / VEC;
   const IDX total = (IDX)((long)B * Ho * Wo * CL);
@@ -764,7 +764,26 @@ __global__ void bn_act_pool_drop_kernel(const TI* __restrict__ x, const float* _
 #pragma unroll
       for (int e = 0; e < VEC; ++e) m.v[e] = -INFINITY;
       const long base = ((b * H + (long)ho * ph) * W + (long)wo * pw) * C + cl * VEC;
-      if (PHT) {
+      if (PHT && qmax) {   // training: also x at the window's FIRST maximum of the unclamped BatchNorm value (the backward's statistics pass reads it instead of the window)
+        VecF<VEC> bt, bq;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { bt.v[e] = -INFINITY; bq.v[e] = 0.f; }
+#pragma unroll
+        for (int ii = 0; ii < (PHT ? PHT : 1); ++ii)
+#pragma unroll
+          for (int j = 0; j < (PWT ? PWT : 1); ++j) {
+            VecF<VEC> v = vload_s<VEC, (CRNN_NT_BN_ACT != 0)>(&x[base + ((long)ii * W + j) * C]);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              const float tt = fmaf(v.v[e], s.v[e], t.v[e]);
+              bq.v[e] = tt > bt.v[e] ? v.v[e] : bq.v[e];        // strict '>': the first maximum in scan order (bn_bwd_pool_kernel's rule)
+              bt.v[e] = fmaxf(bt.v[e], tt);
+            }
+          }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) m.v[e] = relu6f(bt.v[e]);  // ReLU6 is monotone: the maximum of the clamped values is the clamped maximum, exactly
+        vstore<VEC>(&qmax[(long)pix * C + cl * VEC], bq);
+      } else if (PHT) {
 #pragma unroll
         for (int ii = 0; ii < (PHT ? PHT : 1); ++ii)
 #pragma unroll
@@ -782,6 +801,7 @@ __global__ void bn_act_pool_drop_kernel(const TI* __restrict__ x, const float* _
           }
       }
     }
+    if (!y) continue;                                          // (qmax only: the next depthwise kernel forms the block output from it)
     const long obase = (long)pix * C + cl * VEC;
     float dm[VEC];
     drop_scale_vec<VEC>(seed, layer, (uint64_t)obase, rate, inv_keep, dm);
@@ -793,12 +813,12 @@ __global__ void bn_act_pool_drop_kernel(const TI* __restrict__ x, const float* _
 
 template <int VEC, typename TI, typename TO>
 static void bn_act_go(const TI* x, const float* bnstate, TO* y, int B, int H, int W, int C, int ph, int pw, float rate, uint64_t seed,
-                      uint32_t layer, hipStream_t stream) {
+                      uint32_t layer, hipStream_t stream, TI* qmax = nullptr) {
   long total = (long)B * (H / ph) * (W / pw) * C;
   int blocks = cdiv(total / VEC, 256); if (blocks > 8192) blocks = 8192;
   const bool small = total / VEC + 8192L * 256 < (1L << 31);       // the grid-stride counter stays below 2^31 + one stride: fits unsigned
   const dim3 g(blocks), t(256);
-#define BN_ACT_LAUNCH(IDX, PHT, PWT) hipLaunchKernelGGL((bn_act_pool_drop_kernel<VEC, TI, TO, IDX, PHT, PWT>), g, t, 0, stream, x, bnstate, y, B, H, W, C, ph, pw, rate, seed, layer)
+#define BN_ACT_LAUNCH(IDX, PHT, PWT) hipLaunchKernelGGL((bn_act_pool_drop_kernel<VEC, TI, TO, IDX, PHT, PWT>), g, t, 0, stream, x, bnstate, y, B, H, W, C, ph, pw, rate, seed, layer, qmax)
   if (!small) BN_ACT_LAUNCH(long, 0, 0);
   else if (ph == 2 && pw == 2) BN_ACT_LAUNCH(unsigned, 2, 2);
   else if (ph == 1 && pw == 2) BN_ACT_LAUNCH(unsigned, 1, 2);
@@ -807,12 +827,14 @@ static void bn_act_go(const TI* x, const float* bnstate, TO* y, int B, int H, in
 }
 template <typename TI, typename TO>
 static int bn_act_launch(const TI* x, const float* bnstate, TO* y, int B, int H, int W, int C, int ph, int pw, float rate, uint64_t seed,
-                         uint32_t layer, hipStream_t stream) {
-  const bool al = ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)bnstate) & 15) == 0);
+                         uint32_t layer, hipStream_t stream, TI* qmax = nullptr) {
+  if (qmax && !((ph == 2 && pw == 2) || (ph == 1 && pw == 2))) return CRNN_ERR_UNSUPPORTED;   // (the compile-time windows)
+  if (qmax && (long)B * (H / ph) * (W / pw) * C + 8192L * 256 * 8 >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;
+  const bool al = ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)bnstate | (uintptr_t)qmax) & 15) == 0);
   const int VM = (VecMax<TI>::value == 8 && VecMax<TO>::value == 8) ? 8 : 4;
-  if (VM == 8 && al && C % 8 == 0) bn_act_go<(VecMax<TI>::value == 8 && VecMax<TO>::value == 8) ? 8 : 4>(x, bnstate, y, B, H, W, C, ph, pw, rate, seed, layer, stream);
-  else if (al && C % 4 == 0) bn_act_go<4>(x, bnstate, y, B, H, W, C, ph, pw, rate, seed, layer, stream);
-  else bn_act_go<1>(x, bnstate, y, B, H, W, C, ph, pw, rate, seed, layer, stream);
+  if (VM == 8 && al && C % 8 == 0) bn_act_go<(VecMax<TI>::value == 8 && VecMax<TO>::value == 8) ? 8 : 4>(x, bnstate, y, B, H, W, C, ph, pw, rate, seed, layer, stream, qmax);
+  else if (al && C % 4 == 0) bn_act_go<4>(x, bnstate, y, B, H, W, C, ph, pw, rate, seed, layer, stream, qmax);
+  else bn_act_go<1>(x, bnstate, y, B, H, W, C, ph, pw, rate, seed, layer, stream, qmax);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
@@ -823,6 +845,17 @@ extern "C" int crnn_bn_act_pool_drop_ex(const void* x, const float* bnstate, voi
   if (dt_in == CRNN_BF16) return bn_act_launch((const bf16_t*)x, bnstate, (float*)y, B, H, W, C, ph, pw, rate, seed, layer, stream);
   if (dt_out == CRNN_BF16) return bn_act_launch((const float*)x, bnstate, (bf16_t*)y, B, H, W, C, ph, pw, rate, seed, layer, stream);
   return bn_act_launch((const float*)x, bnstate, (float*)y, B, H, W, C, ph, pw, rate, seed, layer, stream);
+}
+// ... that also writes qmax [B][H/ph][W/pw][C] (storage dt_in): x at the first maximum of x * scale + shift over each pool window (2 x 2 or 1 x 2 only) --
+// what crnn_bn_bwd_qmax_ex's statistics pass reads instead of the whole window.  y as above, bit for bit; y NULL: qmax only (the block output is then
+// Dropout(ReLU6(qmax * scale + shift)) element by element -- what crnn_dwconv3x3_fwd_stream_pro_ex forms from it, bit for bit).
+extern "C" int crnn_bn_act_pool_drop_qmax_ex(const void* x, const float* bnstate, void* y, void* qmax, int B, int H, int W, int C, int ph, int pw, float rate,
+                                             uint64_t seed, uint32_t layer, int dt_in, int dt_out, hipStream_t stream) {
+  if (!x || !bnstate || !qmax) return CRNN_ERR_ARG;          // y may be NULL: qmax only
+  if (dt_in == CRNN_BF16 && dt_out == CRNN_BF16) return bn_act_launch((const bf16_t*)x, bnstate, (bf16_t*)y, B, H, W, C, ph, pw, rate, seed, layer, stream, (bf16_t*)qmax);
+  if (dt_in == CRNN_BF16) return bn_act_launch((const bf16_t*)x, bnstate, (float*)y, B, H, W, C, ph, pw, rate, seed, layer, stream, (bf16_t*)qmax);
+  if (dt_out == CRNN_BF16) return bn_act_launch((const float*)x, bnstate, (bf16_t*)y, B, H, W, C, ph, pw, rate, seed, layer, stream, (float*)qmax);
+  return bn_act_launch((const float*)x, bnstate, (float*)y, B, H, W, C, ph, pw, rate, seed, layer, stream, (float*)qmax);
 }
 extern "C" int crnn_bn_act_pool_drop(const float* x, const float* bnstate, float* y, int B, int H, int W, int C, int ph,
                                      int pw, float rate, uint64_t seed, uint32_t layer, hipStream_t stream) {
@@ -845,6 +878,9 @@ struct BnBwdArgsT {
   // round 6 (fp32 tensors): pass 2 writes dx as bf16 PLANES instead (plane pl of element i at dxp[pl * dxps + i]; the words of crnn_split3_pair) -- what the
   // pointwise GEMMs that read dx (gemm_pres.hip, gemm_wgrad3.hip) stage, split once here instead of once per tile there.  Null: dx as T
   unsigned short* dxp = nullptr; long dxps = 0; int dxpl = 0;
+  // round 6: x at each pool window's first maximum, written by the forward (crnn_bn_act_pool_drop_qmax_ex): the statistics pass of the pooled kernel reads it
+  // (one value per window) instead of the window -- the same sums bit for bit from a quarter (half) of the bytes
+  const T* qmax = nullptr;
 };
 // dx (fp32 values) of VEC consecutive elements as planes (VEC = 4: two words per plane)
 template <int VEC, typename T>
@@ -1138,6 +1174,31 @@ __global__ __launch_bounds__(256) void bn_bwd_pool_kernel(BnBwdArgsT<T> a, float
       };
       long r = r0 + rt;
       Pos pa = pos_of(r < r1 ? r : r0);
+      if (PASS == 1 && a.qmax) {   // the window's maximum is x * scale + shift of the saved x; four windows in flight
+        auto one = [&](long rr, const VecF<VEC>& gv, const VecF<VEC>& xs) {
+          float dm[VEC];
+          drop_scale_vec<VEC>(a.seed, a.layer, (uint64_t)(rr * a.C + c0i), a.rate, inv_keep, dm);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float best = fmaf(xs.v[e], sc.v[e], sh.v[e]);
+            const bool live = (best > 0.f) && (best < 6.f);
+            const float gsel = live ? gv.v[e] * dm[e] : 0.f;
+            s.v[e] += gsel;
+            q.v[e] = fmaf(gsel, (xs.v[e] - mu.v[e]) * inv.v[e], q.v[e]);
+          }
+        };
+        for (; r + 3L * RT < r1; r += 4L * RT) {
+          VecF<VEC> gv[4], xs[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { gv[u] = vload<VEC>(&a.g[(r + u * RT) * a.C + c0i]); xs[u] = vload<VEC>(&a.qmax[(r + u * RT) * a.C + c0i]); }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) one(r + u * RT, gv[u], xs[u]);
+        }
+        for (; r < r1; r += RT) {
+          const VecF<VEC> gv = vload<VEC>(&a.g[r * a.C + c0i]), xs = vload<VEC>(&a.qmax[r * a.C + c0i]);
+          one(r, gv, xs);
+        }
+      } else
       if (PASS == 1) {
         for (; r + RT < r1; r += 2L * RT) {
           VecF<VEC> ga, gb, xa[4], xb[4]; long ba, bb;
@@ -1237,8 +1298,12 @@ static int bn_bwd_launch(const BnBwdArgsT<T>& a, T* dx, float* dgamma, float* db
 template <typename T>
 static int bn_bwd_typed(const T* x, const T* g, const float* bnstate, const float* gamma, T* dx, float* dgamma, float* dbeta,
                         float* scratch_partials, float* coef, int B, int H, int W, int C, int ph, int pw, float rate, uint64_t seed,
-                        uint32_t layer, hipStream_t stream, bool apply_only = false, void* dx_planes = nullptr, long plane_stride = 0, int planes = 0) {
+                        uint32_t layer, hipStream_t stream, bool apply_only = false, void* dx_planes = nullptr, long plane_stride = 0, int planes = 0, const T* qmax = nullptr) {
   BnBwdArgsT<T> a{x, g, bnstate, gamma, B, H, W, C, ph, pw, rate, seed, layer};
+  if (qmax) {   // (the pooled kernel's compile-time windows only)
+    if (!((ph == 2 && pw == 2) || (ph == 1 && pw == 2)) || H % ph || W % pw || ((uintptr_t)qmax & 15)) return CRNN_ERR_ARG;
+    a.qmax = qmax;
+  }
   if (dx_planes) {   // fp32 tensors, four channels per thread, the planes 8-byte aligned
     if (sizeof(T) != 4 || dx || (planes != 2 && planes != 3) || (C & 3) || ((uintptr_t)dx_planes & 7) || (plane_stride & 3) || plane_stride < (long)B * H * W * C ||
         (((uintptr_t)x | (uintptr_t)g | (uintptr_t)bnstate | (uintptr_t)coef) & 15)) return CRNN_ERR_ARG;
@@ -1292,6 +1357,20 @@ extern "C" int crnn_bn_bwd_apply_planes_ex(const float* x, const float* g, const
   if (!x || !g || !bnstate || !coef || !dx_planes) return CRNN_ERR_ARG;
   return bn_bwd_typed<float>(x, g, bnstate, nullptr, nullptr, nullptr, nullptr, nullptr, const_cast<float*>(coef), B, H, W, C, ph, pw, rate, seed, layer, stream, true,
                              dx_planes, plane_stride, planes);
+}
+// The general form: crnn_bn_bwd_ex with qmax (may be NULL; storage `dtype` like x: the forward's crnn_bn_act_pool_drop_qmax_ex output -- the statistics pass of a
+// pooled BatchNorm then reads one value per window, same sums bit for bit) and dx either as a tensor of `dtype` or (fp32 only, dx NULL) as `planes` bf16 planes.
+extern "C" int crnn_bn_bwd_qmax_ex(const void* x, const void* qmax, const void* g, const float* bnstate, const float* gamma, void* dx, void* dx_planes, long plane_stride,
+                                   int planes, float* dgamma, float* dbeta, float* scratch_partials, float* coef, int B, int H, int W, int C, int ph, int pw, float rate,
+                                   uint64_t seed, uint32_t layer, int dtype, hipStream_t stream) {
+  if (!x || !g || !bnstate || !coef || (dx && dx_planes)) return CRNN_ERR_ARG;
+  if (dtype == CRNN_BF16) {
+    if (dx_planes) return CRNN_ERR_ARG;
+    return bn_bwd_typed<bf16_t>((const bf16_t*)x, (const bf16_t*)g, bnstate, gamma, (bf16_t*)dx, dgamma, dbeta, scratch_partials, coef, B, H, W, C, ph, pw, rate, seed,
+                                layer, stream, false, nullptr, 0, 0, (const bf16_t*)qmax);
+  }
+  return bn_bwd_typed<float>((const float*)x, (const float*)g, bnstate, gamma, (float*)dx, dgamma, dbeta, scratch_partials, coef, B, H, W, C, ph, pw, rate, seed, layer,
+                             stream, false, dx_planes, plane_stride, planes, (const float*)qmax);
 }
 // Second stage of a BatchNorm backward whose statistics pass ran elsewhere (crnn_gemm_wres_bf16_bnstats): partials [nparts][2][C] = partial
 // sums of gy and gy * xhat over `count` elements per channel -> dgamma, dbeta and coef = [mean(gy) | mean(gy * xhat)] (what

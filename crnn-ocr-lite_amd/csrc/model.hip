@@ -12,6 +12,13 @@ namespace {
 
 struct BlockSpec { int cout, ph, pw; };
 const BlockSpec kBlocks[7] = {{64, 1, 1}, {128, 1, 1}, {256, 2, 2}, {256, 1, 1}, {512, 1, 2}, {512, 1, 1}, {512, 1, 1}};
+// Pooled blocks (round 6): the training forward's BatchNorm-2 + ReLU6 + MaxPool pass also keeps q at each window's first maximum ("qm<i>"), and the statistics
+// pass of that BatchNorm's backward reads it instead of the four (two) values of the window: the arg-max carries the window's whole gradient, so the sums are
+// the same, bit for bit (crnn_bn_bwd_qmax_ex).  CRNN_FLAG_NO_POOL_ARGMAX_Q: the window scan of rounds 1-5.
+bool pool_argmax_q(const crnn_config* cfg, int block) {
+  const int ph = kBlocks[block - 1].ph, pw = kBlocks[block - 1].pw;
+  return !(cfg->flags & CRNN_FLAG_NO_POOL_ARGMAX_Q) && ((ph == 2 && pw == 2) || (ph == 1 && pw == 2));
+}
 const float kDropBlock = 0.1f, kDropDense1 = 0.4f, kDropRnn = 0.2f;  // utils.py:56,75,83
 const uint32_t kLayerDense1 = 8, kLayerRnn = 9;
 
@@ -90,6 +97,7 @@ struct Plan {
   }
   int dt(const std::string& n) const { for (auto& x : t) if (x.name == n) return x.dtype; return CRNN_F32; }
   long off(const std::string& n) const { for (auto& x : t) if (x.name == n) return x.off; return -1; }
+  bool has(const std::string& n) const { return off(n) >= 0; }
   long cnt(const std::string& n) const { for (auto& x : t) if (x.name == n) return x.size; return -1; }
 };
 
@@ -176,9 +184,10 @@ Plan make_plan(const crnn_config* c) {
     const int sdt_in = (c->mfma_bf16 == 2 && ci % 4 == 0) ? CRNN_BF16 : CRNN_F32;
     const int sdt_out = (c->mfma_bf16 == 2) ? CRNN_BF16 : CRNN_F32;
     P.add("d" + p, M * ci, sdt_in); P.add("a" + p, M * ci, sdt_in); P.add("q" + p, M * co, sdt_out); P.add("x" + p, Mo * co, sdt_out);
+    if (pool_argmax_q(c, i)) P.add("qm" + p, Mo * co, sdt_out);   // q at each pool window's arg-max (training forward -> the backward's statistics pass)
     // dropout keep bytes of the block output (one per 8 elements) for the prologue depthwise kernels of block i+1 (fuse_bn2_dw)
-    if (i < 7 && kBlocks[i - 1].ph * kBlocks[i - 1].pw == 1 && co % 8 == 0 && (c->mfma_bf16 == 2 || bn2_dw_fusion_on(c)))
-      P.add("dm" + p, (M * co / 8 + 3) / 4);
+    if (i < 7 && (kBlocks[i - 1].ph * kBlocks[i - 1].pw == 1 || pool_argmax_q(c, i)) && co % 8 == 0 && (c->mfma_bf16 == 2 || bn2_dw_fusion_on(c)))
+      P.add("dm" + p, (Mo * co / 8 + 3) / 4);
     maxact = lmax(maxact, M * co);
     long tiles = crnn_dwconv_num_tiles(d.B, d.bh[i], d.bw[i]);
     maxparts = lmax(maxparts, tiles * 9L * ci);
@@ -277,6 +286,16 @@ struct Ctx {
   float* partials() const { return ws + P.off(side ? "partials2" : "partials"); }
 };
 
+// ... and the shapes crnn_bn_act_pool_drop_qmax_ex / crnn_bn_bwd_qmax_ex take (whole windows, 32-bit element counter, 16-byte aligned tensors): the training
+// forward and the backward both decide with this
+bool use_qmax(const Ctx& c, int i) {
+  if (!pool_argmax_q(c.cfg, i) || !c.P.has("qm" + std::to_string(i))) return false;
+  const int ph = kBlocks[i - 1].ph, pw = kBlocks[i - 1].pw, H = c.d.bh[i], W = c.d.bw[i], co = c.d.bc[i];
+  const long Mo = (long)c.d.B * (H / ph) * (W / pw);
+  const std::string p = std::to_string(i);
+  return H % ph == 0 && W % pw == 0 && co % 4 == 0 && Mo * co + 8192L * 256 * 8 < (1L << 31) &&
+         ((((uintptr_t)c.w("q" + p) | (uintptr_t)c.w("x" + p) | (uintptr_t)c.w("qm" + p) | (uintptr_t)c.w("bn2s" + p)) & 15) == 0);
+}
 // In the bf16 modes a weight operand (B of the NN / NT GEMMs, i.e. a pointer into the parameter buffer) is read from
 // the bf16 shadow copy refreshed at the start of every forward: half the L2->LDS bytes, identical rounding (RNE).
 const float* weight_operand(const Ctx& c, int mode, const float* B, int* dtB) {
@@ -378,8 +397,12 @@ bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr, 
 bool fuse_bn2_dw_shape(const crnn_config* cfg, const Dims& d, const Plan& P, int i) {
   if (i < 1 || i > 6) return false;
   if (!bn2_dw_fusion_on(cfg) || (cfg->flags & (CRNN_FLAG_DW_TILE_KERNEL | CRNN_FLAG_NO_DW_BWD_FUSION))) return false;
-  if (kBlocks[i - 1].ph * kBlocks[i - 1].pw != 1) return false;
   const std::string p = std::to_string(i), n = std::to_string(i + 1);
+  // a pooled block (round 6): its output is Dropout(ReLU6(BatchNorm-2(.))) of q at each window's arg-max, element by element -- the tensor "qm<i>" the training
+  // forward keeps (pool_argmax_q) stands in for q_i in both prologue kernels, which then also take the statistics pass of that BatchNorm's backward
+  const bool pooled = kBlocks[i - 1].ph * kBlocks[i - 1].pw != 1;
+  if (pooled && (!pool_argmax_q(cfg, i) || !P.has("qm" + p) || d.bh[i] % kBlocks[i - 1].ph || d.bw[i] % kBlocks[i - 1].pw || d.bc[i] % 4 ||
+                 (long)d.B * d.bh[i + 1] * d.bw[i + 1] * d.bc[i] + 8192L * 256 * 8 >= (1L << 31))) return false;
   const int dt = P.dt("q" + p);                       // bf16 tensors (throughput mode) or fp32 tensors (round 4: the parity mode's forms of the same kernels)
   if (P.dt("x" + p) != dt || P.dt("d" + n) != dt || P.off("dm" + p) < 0) return false;
   if (bn2_stats_fusion_on(cfg) && P.off("bn2parts") < 0) return false;
@@ -387,10 +410,12 @@ bool fuse_bn2_dw_shape(const crnn_config* cfg, const Dims& d, const Plan& P, int
   return crnn_dwconv_fwd_stream_pro_supported_ex(d.B, H, W, C, dt) == CRNN_OK && crnn_dwconv_bwd_stream_pro_supported_ex(d.B, H, W, C, dt) == CRNN_OK &&
          (dt == CRNN_F32 || crnn_dwconv_bwd_fused_supported(H, W, C) == CRNN_OK);
 }
+// the tensor the prologue kernels of block i + 1 form x_i from: q_i, or q_i at the pool windows' arg-max
+float* pro_src(const Ctx& c, int i) { return c.w((kBlocks[i - 1].ph * kBlocks[i - 1].pw != 1 ? "qm" : "q") + std::to_string(i)); }
 bool fuse_bn2_dw(const Ctx& c, int i) {
   if (!fuse_bn2_dw_shape(c.cfg, c.d, c.P, i)) return false;
   const std::string p = std::to_string(i), n = std::to_string(i + 1);
-  return aligned16(c.w("q" + p), c.w("bn2s" + p), c.w("d" + n), c.p("b" + n + "_dw"));
+  return aligned16(c.w("q" + p), c.w("bn2s" + p), c.w("d" + n), c.p("b" + n + "_dw")) && aligned16(pro_src(c, i));
 }
 const float* keep_bytes(const Ctx& c, int i) { return c.cfg->dropout ? c.w("dm" + std::to_string(i)) : nullptr; }
 // always-fp32 GEMM (spatial-transformer localisation net: tiny, and theta is precision-sensitive)
@@ -592,7 +617,7 @@ extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, cons
   if (train && cfg->dropout) {   // the dropout decisions of the block outputs that only exist inside the next depthwise kernels (fuse_bn2_dw)
     void* outs[CRNN_KEEP_BATCH_MAX]; long ng[CRNN_KEEP_BATCH_MAX]; uint32_t lay[CRNN_KEEP_BATCH_MAX]; int n = 0;
     for (int i = 1; i <= 6; ++i)
-      if (fuse_bn2_dw(c, i)) { outs[n] = c.w("dm" + std::to_string(i)); ng[n] = (long)B * d.bh[i] * d.bw[i] * d.bc[i] / 8; lay[n] = (uint32_t)i; ++n; }
+      if (fuse_bn2_dw(c, i)) { outs[n] = c.w("dm" + std::to_string(i)); ng[n] = (long)B * d.bh[i + 1] * d.bw[i + 1] * d.bc[i] / 8; lay[n] = (uint32_t)i; ++n; }   // (block i + 1's map = block i's output, pooled or not)
     if (n) {
       CRNN_TRY(fj.fork());
       CRNN_TRY(crnn_dropout_keep_bytes_batch(n, outs, ng, lay, kDropBlock, seed, fj.on ? aux_stream : stream));
@@ -782,9 +807,14 @@ extern "C" int crnn_forward_ex(const crnn_config* cfg, const float* params, cons
     CRNN_TRY(crnn_bn_finalize_folded(parts, stat_rows, co, M, c.p(bp + "_bn2_g"), c.p(bp + "_bn2_b"), s2, c.w("fold"), stream));
     bn_off += co;
     if (fuse_bn2_dw(c, i)) {   // x_i is formed by block i+1's depthwise kernel from q_i (and again by its backward): not written
-      pro_q = qq; pro_s2 = s2; in = nullptr;
+      if (ph * pw != 1)          // pooled: from q at each window's arg-max, which one pass over q selects (no BatchNorm output is written)
+        CRNN_TRY(crnn_bn_act_pool_drop_qmax_ex(qq, s2, nullptr, pro_src(c, i), B, H, W, co, ph, pw, 0.f, seed, (uint32_t)i, dtq, dtq, stream));
+      pro_q = pro_src(c, i); pro_s2 = s2; in = nullptr;
       continue;
     }
+    if (use_qmax(c, i))   // (no fallback: the backward takes the same decision)
+      CRNN_TRY(crnn_bn_act_pool_drop_qmax_ex(qq, s2, xo, c.w("qm" + p), B, H, W, co, ph, pw, cfg->dropout ? kDropBlock : 0.f, seed, (uint32_t)i, dtq, c.dt("x" + p), stream));
+    else
     CRNN_TRY(crnn_bn_act_pool_drop_ex(qq, s2, xo, B, H, W, co, ph, pw, cfg->dropout ? kDropBlock : 0.f, seed,
                                       (uint32_t)i, dtq, c.dt("x" + p), stream));
     in = xo;
@@ -1179,7 +1209,11 @@ int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t au
       CRNN_TRY(crnn_bn_bwd_apply_ex(c.w("q" + p), gA, c.w("bn2s" + p), c.w("coef"), gB, B, H, W, co, kBlocks[i - 1].ph, kBlocks[i - 1].pw,
                                     cfg->dropout ? kDropBlock : 0.f, seed, (uint32_t)i, dtq, stream));
       bn2_stats_rows = 0;
-    } else if (dq_planes)
+    } else if (use_qmax(c, i))   // pooled block: the statistics pass reads the forward's arg-max values
+      CRNN_TRY(crnn_bn_bwd_qmax_ex(c.w("q" + p), c.w("qm" + p), gA, c.w("bn2s" + p), c.p(bp + "_bn2_g"), dq_planes ? nullptr : gB, dq_planes ? gB : nullptr, M * co,
+                                   dq_planes ? 2 : 0, c.g(bp + "_bn2_g"), c.g(bp + "_bn2_b"), c.w("partials"), c.w("coef"), B, H, W, co, kBlocks[i - 1].ph,
+                                   kBlocks[i - 1].pw, cfg->dropout ? kDropBlock : 0.f, seed, (uint32_t)i, dtq, stream));
+    else if (dq_planes)
       CRNN_TRY(crnn_bn_bwd_planes_ex(c.w("q" + p), gA, c.w("bn2s" + p), c.p(bp + "_bn2_g"), gB, M * co, 2, c.g(bp + "_bn2_g"), c.g(bp + "_bn2_b"), c.w("partials"),
                                      c.w("coef"), B, H, W, co, kBlocks[i - 1].ph, kBlocks[i - 1].pw, cfg->dropout ? kDropBlock : 0.f, seed, (uint32_t)i, stream));
     else
@@ -1281,7 +1315,7 @@ int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t au
         const std::string pp = std::to_string(i - 1);
         // (its dropout decisions: the keep bytes the forward of this step left in the workspace -- same seed)
         float* st2 = bn2_stats_fusion_on(cfg) ? c.w("bn2parts") : nullptr;   // (bf16 tensors: opt-in, measured neutral -- include/crnn_mi355x.h)
-        CRNN_TRY(crnn_dwconv3x3_bwd_stream_pro_ex(c.w("d" + p), gA, c.w("bn1s" + p), c.w("coef"), c.w("q" + pp), c.w("bn2s" + pp), cfg->dropout ? kDropBlock : 0.f,
+        CRNN_TRY(crnn_dwconv3x3_bwd_stream_pro_ex(c.w("d" + p), gA, c.w("bn1s" + p), c.w("coef"), pro_src(c, i - 1), c.w("bn2s" + pp), cfg->dropout ? kDropBlock : 0.f,
                                                   keep_bytes(c, i - 1), c.p(bp + "_dw"), gC, c.g(bp + "_dw"), c.w("partials"), st2, B, H, W, ci, dtd, stream));
         if (st2) bn2_stats_rows = crnn_dwconv_bwd_stream_rows_ex(B, H, W, ci, dtd);
         rc = CRNN_OK;

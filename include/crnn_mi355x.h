@@ -84,6 +84,8 @@ typedef struct {
                                          GEMMs split while staging (rounds 4-5) instead of two bf16 planes written by the BatchNorm backward and read by
                                          crnn_gemm_pres_bnstats / crnn_pwconv_bnrelu6_wgrad_planes_stream_gp (round 6: same words and products; the data gradient
                                          bit-identical, the weight gradient and the statistics the same sums in another order) */
+#define CRNN_FLAG_NO_POOL_ARGMAX_Q 524288 /* the pooled blocks (3, 5): the statistics pass of BatchNorm-2's backward re-reads the whole pre-BatchNorm tensor and finds each
+                                         window's arg-max again (rounds 1-5) instead of reading the value the forward saved per window (round 6: bit-identical sums) */
 #define CRNN_FLAG_WEIGHT_PLANES 32768    /* opt-in, parity mode: the pointwise GEMMs read bf16 planes of their weights split once per step (crnn_split3_planes +
                                          the *_pl entry points) instead of splitting the fp32 weights in every tile that stages them; bit-identical.
                                          Measured (profiles/r04_x3_planes_bench.txt): forward -2 %, data gradient +12 % -- three 8-byte loads per item
@@ -552,6 +554,15 @@ int crnn_bn_bwd_planes_ex(const float* x, const float* g, const float* bnstate, 
                           uint64_t seed, uint32_t layer, crnn_stream_t stream);
 int crnn_bn_bwd_apply_planes_ex(const float* x, const float* g, const float* bnstate, const float* coef, void* dx_planes, long plane_stride, int planes,
                                 int B, int H, int W, int C, int ph, int pw, float rate, uint64_t seed, uint32_t layer, crnn_stream_t stream);
+/* The pooled blocks' shortcut (round 6): crnn_bn_act_pool_drop_qmax_ex = crnn_bn_act_pool_drop_ex that also writes qmax [B][H/ph][W/pw][C] (storage dt_in), x at the
+ * FIRST maximum of x * scale + shift over each 2 x 2 / 1 x 2 pool window; crnn_bn_bwd_qmax_ex = crnn_bn_bwd_ex / crnn_bn_bwd_planes_ex (dx as a tensor of `dtype`, or --
+ * fp32, dx NULL -- as bf16 planes) whose statistics pass reads that one value per window instead of the window: the arg-max carries all of the window's gradient,
+ * so the sums are the same, bit for bit, from a quarter (half) of the bytes.  qmax NULL: the entry points above.  -3 for other windows. */
+int crnn_bn_act_pool_drop_qmax_ex(const void* x, const float* bnstate, void* y, void* qmax, int B, int H, int W, int C, int ph, int pw, float rate, uint64_t seed,
+                                  uint32_t layer, int dt_in, int dt_out, crnn_stream_t stream);
+int crnn_bn_bwd_qmax_ex(const void* x, const void* qmax, const void* g, const float* bnstate, const float* gamma, void* dx, void* dx_planes, long plane_stride, int planes,
+                        float* dgamma, float* dbeta, float* scratch_partials, float* coef, int B, int H, int W, int C, int ph, int pw, float rate, uint64_t seed,
+                        uint32_t layer, int dtype, crnn_stream_t stream);
 /* Pass 2 of crnn_bn_bwd_ex alone: dx from coef = [mean(gy) | mean(gy * xhat)] of a statistics pass that ran elsewhere (crnn_bn_bwd_finalize*). */
 int crnn_bn_bwd_apply_ex(const void* x, const void* g, const float* bnstate, const float* coef, void* dx, int B, int H, int W, int C, int ph, int pw,
                          float rate, uint64_t seed, uint32_t layer, int dtype, crnn_stream_t stream);

@@ -110,9 +110,11 @@ def device_cache(eng, cfg, p, x, B, c_ref, masks=None):
         if pool:
             h, w = h // pool[0], w // pool[1]
         if eng.lib.crnn_block_output_fused(eng._c, i):
-            # the block output exists only inside the next block's depthwise kernels (parity mode: the default schedule for the un-pooled blocks):
+            # the block output exists only inside the next block's depthwise kernels (parity mode: the default schedule):
             # x = Dropout(ReLU6(BatchNorm-2(q))) as those kernels form it -- r * 1/(1-rate) in fp32, dropped elements 0
             prev = c[f"r{i}"]
+            if pool:   # (round 6: a pooled block's output formed from q at the windows' arg-max = the window maximum of r)
+                prev = prev.reshape(B, h, pool[0], w, pool[1], cout).max(axis=(2, 4))
             if masks is not None:
                 ik = np.float32(1.0) / (np.float32(1.0) - np.float32(M.DROP_BLOCK))
                 prev = (prev.astype(np.float32) * ik).astype(np.float64) * masks[f"b{i}"]
@@ -566,8 +568,8 @@ def test_localisation_net_per_sample_kernels_equal_the_standalone_kernels(precis
 @pytest.mark.parametrize("dropout", [True, False])
 def test_fp32_row_stream_schedules_equal_the_tile_schedule(dropout):
     """Parity mode (fp32 tensors), round 4: the depthwise stage runs on the fp32 forms of the row-stream kernels -- forward with the BatchNorm-1
-    statistics per workgroup band, backward as one kernel (BatchNorm-1 backward pass 2 + both depthwise gradients) -- and the un-pooled block
-    outputs are formed inside the next block's depthwise kernels, which also take BatchNorm-2's backward statistics (the default schedule).
+    statistics per workgroup band, backward as one kernel (BatchNorm-1 backward pass 2 + both depthwise gradients) -- and the block
+    outputs (round 6: of the pooled blocks too, from q at each window's arg-max) are formed inside the next block's depthwise kernels, which also take BatchNorm-2's backward statistics (the default schedule).
     Against the schedule switches: CRNN_FLAG_NO_BN2_DW_FUSION (block outputs materialised, statistics pass of its own) gives the same forward and
     data gradients, the BatchNorm-2 backward statistics being the same sums in another order; on top of it CRNN_FLAG_NO_DW_BWD_FUSION (the
     three-kernel backward) gives the same bits everywhere but the depthwise weight gradients (partial sums grouped differently);
@@ -582,7 +584,7 @@ def test_fp32_row_stream_schedules_equal_the_tile_schedule(dropout):
     N = native.FLAG_NO_BN2_DW_FUSION
     for flags in (0, N, N | native.FLAG_NO_DW_BWD_FUSION, native.FLAG_DW_TILE_KERNEL):
         eng = Engine(B, imgh, imgw, ncls, max_len, tds, u, stn=True, dropout=dropout, precision="fp32", flags=flags)
-        assert [eng.lib.crnn_block_output_fused(eng._c, i) for i in range(1, 8)] == ([1, 1, 0, 1, 0, 1, 0] if flags == 0 else [0] * 7)
+        assert [eng.lib.crnn_block_output_fused(eng._c, i) for i in range(1, 8)] == ([1, 1, 1, 1, 1, 1, 0] if flags == 0 else [0] * 7)   # (round 6: the pooled blocks 3 and 5 too, from q at the windows' arg-max)
         eng.set_params(p, bn)
         eng.ws.fill_(float("nan")); eng.grads.zero_()
         y = eng.forward(x.astype(np.float32), train=True, seed=5).clone()
@@ -754,6 +756,40 @@ def test_parity_mode_gradient_planes_schedule_equals_the_fp32_gradient_schedule(
             if r > worst: worst, wname = r, name
     print("gradient planes vs fp32 gradient tensors: worst tensor %s max-rel %.3g" % (wname, worst))
     assert worst < 1e-4, (wname, worst)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16s"])
+@pytest.mark.parametrize("shape", [(4, 100, 32, 38, 23, 128, 256), (3, 200, 32, 62, 21, 128, 256)])
+def test_pooled_blocks_statistics_from_saved_window_maxima_are_bit_identical(shape, precision):
+    """Round 6: the training forward keeps q at each pool window's arg-max for blocks 3 and 5 and BatchNorm-2's backward takes its statistics from those values
+    (one read per window instead of the window).  CRNN_FLAG_NO_POOL_ARGMAX_Q scans the windows again (rounds 1-5).  bf16 tensors: same sums in the same order --
+    posteriors, losses and every gradient are bit-identical.  fp32 tensors (where the BatchNorm-2 prologue fusion is the default): the saved maxima also replace
+    the pooled block's OUTPUT -- block i + 1's depthwise kernels form it from them in LDS, forward and backward, and the backward one takes the statistics: the
+    forward is bit-identical, the gradients agree to the order of fp32 sums."""
+    from crnn_mi355x import native
+    B, imgh, imgw, ncls, max_len, tds, u = shape
+    cfg = M.Config(imgh=imgh, imgw=imgw, max_len=max_len, time_dense_size=tds, n_units=u, num_classes=ncls)
+    p, bn = M.init_params(cfg, seed=12, dtype=np.float64)
+    p = M.randomize_params(cfg, p)
+    x, lab, il, ll = M.synthetic_batch(cfg, B, seed=6, dtype=np.float64)
+    out = {}
+    for flags in (0, native.FLAG_NO_POOL_ARGMAX_Q):
+        eng = Engine(B, imgh, imgw, ncls, max_len, tds, u, stn=True, dropout=True, precision=precision, flags=flags)
+        eng.set_params(p, bn)
+        eng.ws.fill_(float("nan")); eng.grads.zero_()
+        y = eng.forward(x.astype(np.float32), train=True, seed=3).clone()
+        loss = eng.backward(lab, il, ll, seed=3).clone()
+        out[flags] = (y, loss, eng.grads.clone())
+        del eng
+    (y0, l0, g0), (y1, l1, g1) = out[0], out[native.FLAG_NO_POOL_ARGMAX_Q]
+    assert torch.isfinite(g0).all() and float(g0.abs().max()) > 0
+    assert torch.equal(y0, y1) and torch.equal(l0, l1)
+    if precision == "bf16s":
+        assert torch.equal(g0, g1)
+    else:   # fp32 tensors: the saved maxima also stand in for q in the next block's prologue kernels, whose backward takes the statistics (another order of the sums)
+        rel = float((g0.double() - g1.double()).norm() / g1.double().norm())
+        print("pooled blocks through the prologue kernels: gradient rel L2 %.3g" % rel)
+        assert rel < 1e-5, rel
 
 
 @pytest.mark.parametrize("shape", [(5, 60, 48, 20, 10, 64, 128), (4, 100, 32, 38, 23, 128, 256)])

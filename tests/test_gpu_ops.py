@@ -2699,3 +2699,49 @@ def test_weight_gradient_stream_reads_the_planes_of_g(M, K, N, bn):
     ok(L().crnn_pwconv_bnrelu6_wgrad_planes_stream_gp(P(d), P(st) if bn else None, P(gp), M * N, P(dw1), M, N, K, P(scr), ctypes.c_size_t(nb), S()))
     assert torch.equal(dw0, dw1) and bool((dw1[K:] == 7.0).all())
     assert L().crnn_pwconv_bnrelu6_wgrad_planes_stream_gp(P(d), None, None, M * N, P(dw1), M, N, K, P(scr), ctypes.c_size_t(nb), S()) == -2
+
+
+@pytest.mark.parametrize("B,H,W,C,ph,pw,rate", [(3, 8, 12, 128, 2, 2, 0.2), (2, 6, 20, 256, 1, 2, 0.2), (2, 36, 52, 64, 2, 2, 0.0), (5, 18, 26, 24, 1, 2, 0.3)])
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_pooled_batchnorm_backward_statistics_from_the_saved_window_maxima(B, H, W, C, ph, pw, rate, dtype):
+    """Pooled blocks, round 6: crnn_bn_act_pool_drop_qmax_ex writes the same y as crnn_bn_act_pool_drop_ex plus qmax = x at the first maximum of x * scale + shift
+    over each pool window (checked against a numpy scan of the window in the kernel's order); crnn_bn_bwd_qmax_ex's statistics pass then reads one value per
+    window instead of the window -- dgamma, dbeta, coef and dx equal crnn_bn_bwd_ex's BIT FOR BIT (fp32 and bf16 tensors, with the planes output too); other
+    windows are refused."""
+    rs = np.random.RandomState(B * 131 + H * 17 + C + ph + 3 * pw + dtype)
+    Ho, Wo = H // ph, W // pw
+    xh = (rs.normal(size=(B, H, W, C)) * 1.2 + 0.5).astype(np.float32)
+    if dtype == 1: xh = host(dev(xh).to(torch.bfloat16).float())           # bf16-representable values
+    st = _bnstate(rs, C); gamma = dev(rs.uniform(0.5, 1.5, C).astype(np.float32))
+    tdt = torch.bfloat16 if dtype == 1 else torch.float32
+    x = dev(xh).to(tdt); g = dev(rs.normal(size=(B, Ho, Wo, C)).astype(np.float32)).to(tdt)
+    y0 = torch.zeros(B, Ho, Wo, C, device="cuda", dtype=tdt); y1 = torch.zeros_like(y0); qm = torch.full((B * Ho * Wo * C + 16,), 9.0, device="cuda", dtype=tdt)
+    ok(L().crnn_bn_act_pool_drop_ex(P(x), P(st), P(y0), B, H, W, C, ph, pw, rate, 77, 3, dtype, dtype, S()))
+    ok(L().crnn_bn_act_pool_drop_qmax_ex(P(x), P(st), P(y1), P(qm), B, H, W, C, ph, pw, rate, 77, 3, dtype, dtype, S()))
+    assert torch.equal(y0, y1) and bool((qm[B * Ho * Wo * C:] == 9.0).all())
+    sth = host(st).reshape(4, C)
+    t = (xh.astype(np.float64) * sth[2].astype(np.float64) + sth[3].astype(np.float64)).astype(np.float32)   # (the comparison below only needs the arg-max)
+    tw = t.reshape(B, Ho, ph, Wo, pw, C).transpose(0, 1, 3, 2, 4, 5).reshape(B, Ho, Wo, ph * pw, C)
+    xw = xh.reshape(B, Ho, ph, Wo, pw, C).transpose(0, 1, 3, 2, 4, 5).reshape(B, Ho, Wo, ph * pw, C)
+    am = tw.argmax(axis=3)                                                   # first maximum
+    ref = np.take_along_axis(xw, am[:, :, :, None, :], axis=3)[:, :, :, 0, :]
+    got = host(qm[:B * Ho * Wo * C].float()).reshape(B, Ho, Wo, C)
+    srt = np.sort(tw, axis=3)
+    clear = (srt[..., -1, :] - srt[..., -2, :]) > 1e-5                        # windows whose maximum is not a near-tie of the float64 restatement
+    assert np.array_equal(got[clear], ref[clear]) and clear.mean() > 0.95
+    chunks = L().crnn_bn_bwd_chunks(B * H * W)
+    def run(qmax, planes):
+        dgm, dbt, coef, pp = zeros(C), zeros(C), zeros(2 * C), zeros(chunks * 2 * C + 64)
+        n = B * H * W * C
+        dx = torch.zeros(B, H, W, C, device="cuda", dtype=tdt) if not planes else torch.zeros(planes * n, dtype=torch.int16, device="cuda")
+        ok(L().crnn_bn_bwd_qmax_ex(P(x), P(qmax), P(g), P(st), P(gamma), None if planes else P(dx), P(dx) if planes else None, n, planes, P(dgm), P(dbt), P(pp), P(coef),
+                                   B, H, W, C, ph, pw, rate, 77, 3, dtype, S()))
+        return dx, dgm, dbt, coef
+    for planes in ((0, 2) if dtype == 0 else (0,)):
+        a = run(None, planes); b = run(qm, planes)
+        for u, v in zip(a, b): assert torch.equal(u, v)
+    dgm, dbt, coef, pp = zeros(C), zeros(C), zeros(2 * C), zeros(chunks * 2 * C + 64); dx0 = torch.zeros(B, H, W, C, device="cuda", dtype=tdt)
+    ok(L().crnn_bn_bwd_ex(P(x), P(g), P(st), P(gamma), P(dx0), P(dgm), P(dbt), P(pp), P(coef), B, H, W, C, ph, pw, rate, 77, 3, dtype, S()))
+    assert torch.equal(dx0, a[0] if dtype == 1 else run(qm, 0)[0]) and torch.equal(dgm, b[1]) and torch.equal(dbt, b[2])
+    assert L().crnn_bn_act_pool_drop_qmax_ex(P(x), P(st), P(y1), P(qm), B, H, W, C, 1, 1, rate, 77, 3, dtype, dtype, S()) == -3
+    assert L().crnn_bn_act_pool_drop_qmax_ex(P(x), P(st), P(y1), None, B, H, W, C, ph, pw, rate, 77, 3, dtype, dtype, S()) == -2
