@@ -140,6 +140,17 @@ bool bn2_dw_fusion_on(const crnn_config* c) {
   return (c->flags & CRNN_FLAG_BN2_DW_FUSION) || c->mfma_bf16 != 2;
 }
 bool bn2_stats_fusion_on(const crnn_config* c) { return bn2_dw_fusion_on(c) && ((c->flags & CRNN_FLAG_BN2_STATS_FUSION) || c->mfma_bf16 != 2); }
+#ifndef CRNN_BF16_POOL_FUSION
+#define CRNN_BF16_POOL_FUSION 0   // experiment (scripts/gpu_ab_libs.sh): bf16 tensors, the POOLED blocks' outputs through the prologue kernels (q at the windows' arg-max), statistics fused
+#endif
+// ... per block: bf16 tensors keep the fusion opt-in for the un-pooled blocks (measured neutral to slower); block = the block whose output it is
+bool bn2_dw_fusion_block(const crnn_config* c, int block) {
+  if (bn2_dw_fusion_on(c)) return true;
+  return CRNN_BF16_POOL_FUSION && !(c->flags & CRNN_FLAG_NO_BN2_DW_FUSION) && c->mfma_bf16 == 2 && kBlocks[block - 1].ph * kBlocks[block - 1].pw != 1;
+}
+bool bn2_stats_fusion_block(const crnn_config* c, int block) {
+  return bn2_stats_fusion_on(c) || (CRNN_BF16_POOL_FUSION && bn2_dw_fusion_block(c, block) && kBlocks[block - 1].ph * kBlocks[block - 1].pw != 1);
+}
 
 // storage of the recurrent weights the recurrences multiply with: bf16 copies in the bf16 modes (u % 128 == 0), else fp32
 int rnn_dtu(const crnn_config* c) { return (c->mfma_bf16 && c->units % 128 == 0) ? CRNN_BF16 : CRNN_F32; }
@@ -396,7 +407,7 @@ bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr, 
 // bandwidth-bound (bn2_dw_fusion_on above).
 bool fuse_bn2_dw_shape(const crnn_config* cfg, const Dims& d, const Plan& P, int i) {
   if (i < 1 || i > 6) return false;
-  if (!bn2_dw_fusion_on(cfg) || (cfg->flags & (CRNN_FLAG_DW_TILE_KERNEL | CRNN_FLAG_NO_DW_BWD_FUSION))) return false;
+  if (!bn2_dw_fusion_block(cfg, i) || (cfg->flags & (CRNN_FLAG_DW_TILE_KERNEL | CRNN_FLAG_NO_DW_BWD_FUSION))) return false;
   const std::string p = std::to_string(i), n = std::to_string(i + 1);
   // a pooled block (round 6): its output is Dropout(ReLU6(BatchNorm-2(.))) of q at each window's arg-max, element by element -- the tensor "qm<i>" the training
   // forward keeps (pool_argmax_q) stands in for q_i in both prologue kernels, which then also take the statistics pass of that BatchNorm's backward
@@ -405,7 +416,7 @@ bool fuse_bn2_dw_shape(const crnn_config* cfg, const Dims& d, const Plan& P, int
                  (long)d.B * d.bh[i + 1] * d.bw[i + 1] * d.bc[i] + 8192L * 256 * 8 >= (1L << 31))) return false;
   const int dt = P.dt("q" + p);                       // bf16 tensors (throughput mode) or fp32 tensors (round 4: the parity mode's forms of the same kernels)
   if (P.dt("x" + p) != dt || P.dt("d" + n) != dt || P.off("dm" + p) < 0) return false;
-  if (bn2_stats_fusion_on(cfg) && P.off("bn2parts") < 0) return false;
+  if (bn2_stats_fusion_block(cfg, i) && P.off("bn2parts") < 0) return false;
   const int H = d.bh[i + 1], W = d.bw[i + 1], C = d.bc[i];
   return crnn_dwconv_fwd_stream_pro_supported_ex(d.B, H, W, C, dt) == CRNN_OK && crnn_dwconv_bwd_stream_pro_supported_ex(d.B, H, W, C, dt) == CRNN_OK &&
          (dt == CRNN_F32 || crnn_dwconv_bwd_fused_supported(H, W, C) == CRNN_OK);
@@ -1314,7 +1325,7 @@ int backward_bottom(const Ctx& c0, const float* x, uint64_t seed, hipStream_t au
       if (fuse_bn2_dw(c, i - 1)) {                           // the forward did not keep x_{i-1}: re-formed from q_{i-1} in LDS (no fallback: same decision)
         const std::string pp = std::to_string(i - 1);
         // (its dropout decisions: the keep bytes the forward of this step left in the workspace -- same seed)
-        float* st2 = bn2_stats_fusion_on(cfg) ? c.w("bn2parts") : nullptr;   // (bf16 tensors: opt-in, measured neutral -- include/crnn_mi355x.h)
+        float* st2 = bn2_stats_fusion_block(cfg, i - 1) ? c.w("bn2parts") : nullptr;   // (bf16 tensors: opt-in, measured neutral -- include/crnn_mi355x.h)
         CRNN_TRY(crnn_dwconv3x3_bwd_stream_pro_ex(c.w("d" + p), gA, c.w("bn1s" + p), c.w("coef"), pro_src(c, i - 1), c.w("bn2s" + pp), cfg->dropout ? kDropBlock : 0.f,
                                                   keep_bytes(c, i - 1), c.p(bp + "_dw"), gC, c.g(bp + "_dw"), c.w("partials"), st2, B, H, W, ci, dtd, stream));
         if (st2) bn2_stats_rows = crnn_dwconv_bwd_stream_rows_ex(B, H, W, ci, dtd);
