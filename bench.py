@@ -30,17 +30,18 @@ import torch  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (not the 2:1-sparsity figure)
 PEAK_HBM_GBS = 8000.0
+PMC_ROUND = "r06"               # the committed counter passes the *_roofline objects quote (profiles/<PMC_ROUND>_pmc_step_<mode>.json, visit r06ap)
 
 
 def pmc_step_traffic(eng, prefixes, grids=None):
     """Memory-side bytes per train step of the kernels whose (shortened) names start with one of `prefixes`, from the committed counter passes over this very
-    command (profiles/r05_pmc_step_<mode>.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate counter-only runs, FETCH_SIZE doubled per
+    command (profiles/r06_pmc_step_<mode>.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate counter-only runs, FETCH_SIZE doubled per
     MI355X_MICROARCH.md; scripts/gpu_visit.sh pmc: steps + scripts/pmc_step_summary.py).  Counted in the step's own order and cache state (the requests the
     L2s send to the fabric: last-level-cache hits included).  None when the workload is not the one the passes ran (batch 256, 100x32, LSTM).
     grids: optional {prefix: set of grid sizes in threads} to tell launches of one kernel apart.  -> (bytes per step, launches per step) | None"""
     if eng.B != 256 or (eng.cfg.imgh, eng.cfg.imgw) != (100, 32) or eng.cfg.gru or eng.cfg.flags:
         return None
-    path = os.path.join(ROOT, "profiles", "r05_pmc_step_%s.json" % eng.precision)
+    path = os.path.join(ROOT, "profiles", "%s_pmc_step_%s.json" % (PMC_ROUND, eng.precision))
     if not os.path.exists(path):
         return None
     ks = json.load(open(path))["kernels"]
@@ -58,7 +59,7 @@ def pmc_mfma_util(eng, prefixes):
     """MFMA-pipe utilisation by the counters (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x average kernel time x 2.4 GHz)) of the step's launches of each prefix."""
     if eng.B != 256 or (eng.cfg.imgh, eng.cfg.imgw) != (100, 32) or eng.cfg.gru or eng.cfg.flags:
         return None
-    path = os.path.join(ROOT, "profiles", "r05_pmc_step_%s.json" % eng.precision)
+    path = os.path.join(ROOT, "profiles", "%s_pmc_step_%s.json" % (PMC_ROUND, eng.precision))
     if not os.path.exists(path):
         return None
     ks = json.load(open(path))["kernels"]
@@ -70,7 +71,7 @@ def pmc_mfma_util(eng, prefixes):
 
 
 PMC_NOTE = ("memory-side bytes of the same kernels in the train step, per launch set: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE passes over `bench.py "
-            "--steps 3 --warmup 2` (profiles/r05_pmc_step_%s.json, profiles/r05_pmc_sq_step_%s.txt); counted in the step's order and cache state -- the L2s' "
+            "--steps 3 --warmup 2` (profiles/r06_pmc_step_%s.json, profiles/r06_pmc_sq_step_%s.txt: committed constants of visit r06ap, not measured in this run); counted in the step's order and cache state -- the L2s' "
             "requests to the fabric, last-level-cache hits included -- while `achieved` is timed on the re-issued launches")
 
 
@@ -779,7 +780,7 @@ def lstm_roofline(eng, iters=10):
             "traffic": (lambda tr: None if tr is None else tr[0])(pmc_step_traffic(eng, ["lstm_fwd_persist_kernel", "lstm_bwd_persist_kernel"]) if persist else None),
             "traffic_note": PMC_NOTE % (eng.precision, eng.precision),
             "mfma_busy_counter": (lambda m: None if m is None else {"lstm_fwd_persist_kernel": m[0], "lstm_bwd_persist_kernel": m[1],
-                                  "note": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel time x 2.4 GHz) of the step's launches (profiles/r05_pmc_sq_step_%s.txt)" % eng.precision})(
+                                  "note": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel time x 2.4 GHz) of the step's launches (profiles/r06_pmc_sq_step_%s.txt)" % eng.precision})(
                                   pmc_mfma_util(eng, ["lstm_fwd_persist_kernel", "lstm_bwd_persist_kernel"])),
             "input_projections": {"achieved": round(pflops / tp / 1e12, 2), "unit": "TFLOP/s", "frac": round(pflops / tp / 1e12 / peak, 4), "launches": 4,
                                   "ms": round(1e3 * tp, 4), "flops": pflops,

@@ -122,28 +122,34 @@ __global__ __launch_bounds__(256, OCC) void pres_dgrad_kernel(PresParams p) {
   const int half = lane >> 5, l31 = lane & 31, sw = (l31 >> 1) & 7;
 
   // ---- the slice's planes, once: lane (l31, half) holds k = 64 j + 16 ks + 8 half + 0..7 of channel slice * 128 + 32 wave + l31.  The wave's 32 rows of W
-  // come through LDS (the ring is not in use yet) in halves of 256 k: one LDS-DMA piece = one 1-KiB half row, fully coalesced; 16-byte chunk c of row r at
+  // come through LDS (the ring is not in use yet) 256 (128) k at a time: one LDS-DMA piece = 1 KiB of one (two) rows, fully coalesced; 16-byte chunk c of row r at
   // position c ^ (r & 15), so that the fragment reads (32 rows, the same chunk) spread over the banks.  (Read straight from memory -- two 16-byte loads per
   // fragment and lane, every lane in another 2-KiB row -- the prologue took 15 us of a 230-us launch at K = 512: profiles/r06_pres_ablate.txt.)
   bf16x8_t wf[NPL][KST][4];
   {
-    constexpr int NH = KST / 4;                                 // halves of 256 k
-    unsigned char* const wst = smem + wave * 32768;             // this wave's staging area: 32 rows x 1 KiB
+    constexpr int LDSB = R * STAGE + 4 * PB * 4096 + 4 * DB * PB * 4096;   // the launch's LDS: a quarter of it per wave for the staging
+    constexpr int KH = LDSB >= 4 * 32768 ? 256 : 128, NH = 64 * KST / KH;  // k per pass (32 rows x KH floats per wave), passes
+    constexpr int ROWB = KH * 4, RPP = 1024 / ROWB, CPRW = ROWB / 16;      // bytes per staged row, rows per 1-KiB DMA piece, 16-byte chunks per row
+    static_assert(LDSB >= 4 * 32 * ROWB, "staging area");
+    unsigned char* const wst = smem + wave * (32 * ROWB);       // this wave's staging area
     const unsigned wst_a = __builtin_amdgcn_readfirstlane(pr_lds_addr(wst));
 #pragma unroll
     for (int H = 0; H < NH; ++H) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the previous half's fragment reads are done)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the previous pass's fragment reads are done)
 #pragma unroll
-      for (int r = 0; r < 32; ++r) pr_dma16(p.W + (long)(slice * 128 + 32 * wave + r) * p.ldw + 256 * H + 4 * (lane ^ (r & 15)), wst_a + r * 1024);
+      for (int pc = 0; pc < 32 / RPP; ++pc) {                   // piece pc = rows RPP pc .. : lane -> row RPP pc + lane / CPRW, chunk position lane % CPRW
+        const int row = RPP * pc + lane / CPRW;
+        pr_dma16(p.W + (long)(slice * 128 + 32 * wave + row) * p.ldw + KH * H + 4 * ((lane % CPRW) ^ (row & 15)), wst_a + pc * 1024);
+      }
       pr_wait_vm<0>();
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
+      for (int jj = 0; jj < KH / 64; ++jj)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          const int j = 4 * H + jj;
-          const int c = (64 * jj + 16 * ks + 8 * half) >> 2;   // chunk of 4 floats within the half row
-          const float4 v0 = *reinterpret_cast<const float4*>(wst + l31 * 1024 + ((c ^ (l31 & 15)) << 4));
-          const float4 v1 = *reinterpret_cast<const float4*>(wst + l31 * 1024 + (((c + 1) ^ (l31 & 15)) << 4));
+          const int j = (KH / 64) * H + jj;
+          const int c = (64 * jj + 16 * ks + 8 * half) >> 2;   // chunk of 4 floats within the staged row
+          const float4 v0 = *reinterpret_cast<const float4*>(wst + l31 * ROWB + ((c ^ (l31 & 15)) << 4));
+          const float4 v1 = *reinterpret_cast<const float4*>(wst + l31 * ROWB + (((c + 1) ^ (l31 & 15)) << 4));
           unsigned w[3][4];
           crnn_split3_pair(v0.x, v0.y, w[0][0], w[1][0], w[2][0]); crnn_split3_pair(v0.z, v0.w, w[0][1], w[1][1], w[2][1]);
           crnn_split3_pair(v1.x, v1.y, w[0][2], w[1][2], w[2][2]); crnn_split3_pair(v1.z, v1.w, w[0][3], w[1][3], w[2][3]);
@@ -420,7 +426,7 @@ int pres_supported(long M, int N, int K, int planes) {
 template <int KST, int NPL, int PB, int R, int OCC, int NPA, int DB>
 int pres_launch(const PresParams& p, int grid, hipStream_t stream) {
   constexpr int lds = R * NPL * PB * 4096 + 4 * PB * 4096 + 4 * DB * PB * 4096;
-  static_assert(lds * OCC <= 160 * 1024 && lds >= 4 * 32768, "LDS per CU; the prologue stages 32 KiB of W per wave");
+  static_assert(lds * OCC <= 160 * 1024, "LDS per CU");
   CRNN_LDS_ATTR((pres_dgrad_kernel<KST, NPL, PB, R, OCC, NPA, DB>), lds);
   hipLaunchKernelGGL((pres_dgrad_kernel<KST, NPL, PB, R, OCC, NPA, DB>), dim3(grid), dim3(256), lds, stream, p);
   CRNN_LAUNCH_CHECK();

@@ -72,7 +72,7 @@ for k, c in agg.items():
                                   "mfma_util": None if row["mfma_util"] is None else round(row["mfma_util"], 4)}
 rows.sort(key=lambda r: -(r["calls_per_step"] * (r["avg_us"] or 0)))
 pct = lambda v: "  -  " if v != v else "%4.1f%%" % (100 * v)
-lines = ["# %s step, batch 256: per-kernel counters of the final round-5 code (scripts/pmc_step_summary.py %s %s %s); kernels by time per step" % (mode, tag, pref, mode),
+lines = ["# %s step, batch 256: per-kernel counters of the final code of the round (scripts/pmc_step_summary.py %s %s %s); kernels by time per step" % (mode, tag, pref, mode),
          "# mfma = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x average duration x 2.4 GHz); parked / stall / issuing = SQ_WAIT_ANY / SQ_WAIT_INST_ANY / SQ_ACTIVE_INST_ANY over",
          "# SQ_WAVE_CYCLES (disjoint); valu, lds = the issuing share by pipe; lds-stall = SQ_WAIT_INST_LDS (inside stall); MB = memory-side bytes per launch (FETCH x 2, WRITE)",
          "%-64s %9s %5s %8s %6s %7s %6s %7s %6s %6s %9s %7s %9s %9s %8s" % ("kernel", "grid", "n/stp", "avg us", "mfma", "parked", "stall", "issuing", "valu", "lds", "lds-stall",

@@ -269,7 +269,7 @@ def test_weights_resident_gemms_and_row_stream_kernels_have_no_spilled_vector_re
 
 
 def test_bench_counter_traffic_lookup_and_contract_fields():
-    """bench.py, host logic only: `pmc_step_traffic` / `pmc_mfma_util` read the committed counter passes (profiles/r05_pmc_step_<mode>.json) for the workload they
+    """bench.py, host logic only: `pmc_step_traffic` / `pmc_mfma_util` read the committed counter passes (profiles/r06_pmc_step_<mode>.json) for the workload they
     were collected on -- batch 256, 100x32, LSTM, default flags -- and return None for any other (a `traffic` must never be quoted for a configuration it was
     not counted on); the contract fields the driver's record keeps (`config.*`) are spelled in the source."""
     import importlib.util, types
@@ -280,7 +280,7 @@ def test_bench_counter_traffic_lookup_and_contract_fields():
     tr = bench.pmc_step_traffic(eng(), ["dw_bwd_stream_kernel"])
     assert tr is not None and tr[1] == 6 and 3.4e9 < tr[0] < 3.7e9          # six launches per step, 3.435 GB algorithmic
     tr = bench.pmc_step_traffic(eng(), ["bn_act_pool_drop_kernel"])
-    assert tr is not None and tr[1] == 7 and 2.4e9 < tr[0] < 2.6e9
+    assert tr is not None and tr[1] == 7 and 2.6e9 < tr[0] < 2.8e9          # (round 6: + q at the pool windows' arg-max of blocks 3 and 5, 0.18 GB)
     nt = bench.pmc_step_traffic(eng(), ["gemm_nt_f32_proj_kernel"])
     assert nt is not None and nt[1] == 2                                      # the two layers' input projections (both directions per launch)
     one = bench.pmc_step_traffic(eng(), ["gemm_nt_f32_stream_kernel"], {"gemm_nt_f32_stream_kernel": {159744}})
