@@ -243,14 +243,15 @@ def test_row_stream_kernels_keep_their_row_loops_spill_free():
 def test_weights_resident_gemms_and_row_stream_kernels_have_no_spilled_vector_registers():
     """VERDICT round 4, hygiene: an instantiation of the weights-resident pointwise kernels (gemm_wres.hip; `gemm_wres_fwd_kernel<1, 2, 2>` sat at 256
     registers with 47 spilled and 192 bytes of scratch per lane until K = 64 was routed to the narrow shape) or of the streaming weight-gradient kernel
-    must not spill vector registers at all: their IO / storer waves' steady state has no slack for scratch traffic.  The row-stream depthwise kernels may keep
+    must not spill vector registers at all: their IO / storer waves' steady state has no slack for scratch traffic (round 6: the parity mode's plane GEMMs too --
+    gemm_pres.hip budgets up to 512 registers per wave and must stay clear of scratch).  The row-stream depthwise kernels may keep
     the handful of spills outside their row loops that the loop check above allows.  hipcc's resource remarks, cross-compiled without a GPU."""
     import re, shutil, subprocess, tempfile
     if shutil.which("hipcc") is None:
         pytest.skip("hipcc not on PATH")
     csrc = os.path.join(os.path.dirname(native.LIB_PATH), "csrc")
     inc = os.path.dirname(native.HEADER)
-    for src, minimum, allowed in (("gemm_wres.hip", 15, 0), ("gemm_wres3.hip", 12, 0), ("gemm_wgrad.hip", 2, 0), ("dwconv_stream.hip", 7, 4), ("dwconv_bwd_stream.hip", 7, 4),
+    for src, minimum, allowed in (("gemm_wres.hip", 15, 0), ("gemm_wres3.hip", 12, 0), ("gemm_pres.hip", 9, 0), ("gemm_wgrad3.hip", 4, 0), ("gemm_wgrad.hip", 2, 0), ("dwconv_stream.hip", 7, 4), ("dwconv_bwd_stream.hip", 7, 4),
                                   ("dense.hip", 2, 0)):
         with tempfile.TemporaryDirectory() as td:
             r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", inc, "-c", os.path.join(csrc, src), "-o", os.path.join(td, "k.o"),
