@@ -2596,7 +2596,7 @@ def _split_planes(x, n_planes=3):
 
 @pytest.mark.parametrize("planes", [2, 3])
 @pytest.mark.parametrize("M,N,K", [(64 * 9, 128, 256), (64 * 250, 128, 256), (64 * 41, 256, 256), (64 * 150, 256, 512), (64 * 20, 512, 512), (64 * 700, 512, 512),
-                                   (64 * 1, 128, 512), (64 * 66, 128, 512)])
+                                   (64 * 1, 128, 512), (64 * 66, 128, 512), (256 * 52 * 9, 512, 512), (256 * 52 * 18, 256, 256)])   # (the last two: blocks 6 / 7 and 4 at batch 256)
 def test_data_gradient_from_planes_equals_the_tile_kernel_bit_for_bit(M, N, K, planes):
     """crnn_gemm_pres_bnstats (round 6, gemm_pres.hip): da = dq . W^T with dq given as pre-split bf16 planes (LDS-DMA, no split in the GEMM), the planes of W
     resident in up to 512 registers per wave, one wave per SIMD.  The same planes, products and single fp32 accumulation chain per result as the tile kernel:
