@@ -52,8 +52,33 @@ __device__ __forceinline__ bf16x8_t wg3_frag(const unsigned char* Xs, int r0, in
   return __builtin_bit_cast(bf16x8_t, make_uint4(a.x, a.y, b.x, b.y));
 }
 
+// ---- GPL (g as planes): the planes of g come by LDS-DMA issued by two more waves that do nothing else (as gemm_wres.hip's loader waves; issued by the MFMA waves
+// themselves the 16 pieces of a chunk cost them as much as they saved the IO waves: 205 -> 188 us only, profiles/r06_wgrad3_ablate.txt), into a ring of
+// its own: a stage = 2 planes x 32 pixel rows x 256 B (128 channels, unpadded -- the DMA's LDS image is lane-linear), 16-byte chunk c of row r at position
+// c ^ ((r & 3) << 2) (on the source address): the eight rows a transposing fragment read touches fall two and two into the four 64-byte bank ranges.
+constexpr int kPlB3 = 32 * 256;               // bytes of one g plane of a stage
+constexpr int kStageB3 = 2 * kPlB3;           // hi | mid
+constexpr int kRingB3 = 6;                    // stages of the g ring (5 in flight per CU: 80 KiB)
+constexpr int kLoaders3 = 4;                  // loader waves (one sustains ~25 GB/s per CU -- MI355X_MICROARCH.md, measured here: 314 us with one)
+constexpr int kStageA3 = 2 * kPl3;            // GPL: the IO waves' stages hold the planes of a only
+__device__ __forceinline__ unsigned wg3_lds_addr(const void* p) { return (unsigned)(uintptr_t)((__attribute__((address_space(3))) const unsigned char*)p); }
+__device__ __forceinline__ void wg3_dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// fragment of tile row r0 + l31 from a swizzled, unpadded plane (row = pixel, 128 channels)
+__device__ __forceinline__ bf16x8_t wg3_frag_sw(const unsigned char* Xs, int r0, int ks, int half, int l31) {
+  const int li = l31 & 15;
+  const int row = ks * 16 + 8 * half + (li >> 2), col = r0 + (l31 & 16) + (li & 3) * 4;
+  const unsigned short* X = reinterpret_cast<const unsigned short*>(Xs) + row * 128 + ((((col >> 3) ^ ((row & 3) << 2)) << 3) | (col & 7));
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)X);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(X + 4 * 128));
+  const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
+  return __builtin_bit_cast(bf16x8_t, make_uint4(a.x, a.y, b.x, b.y));
+}
+
 template <bool XF, bool GPL>   // XF: the A operand is ReLU6(d * scale + shift); GPL: g arrives split (written as planes by the kernel that produced it)
-__global__ __launch_bounds__(512, 2 * W3G_WGS) void pw_wgrad_planes_kernel(Wg3Params p) {
+__global__ __launch_bounds__(GPL ? 512 + 64 * kLoaders3 : 512, GPL ? 1 : 2 * W3G_WGS) void pw_wgrad_planes_kernel(Wg3Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // kRing3 stages
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,6 +92,33 @@ __global__ __launch_bounds__(512, 2 * W3G_WGS) void pw_wgrad_planes_kernel(Wg3Pa
   const int c0 = split * p.per;
   const int total = min(p.per, p.chunks - c0);                  // chunks of this range (> 0 by the host's choice of nsplit)
 
+  if constexpr (GPL) {
+    if (wave >= 8) {
+      const int lw = wave - 8;                                    // this loader's share: pieces lw, lw + kLoaders3, ...
+      // ---------------------------------------------------------------------- loader wave: the 16 1-KiB pieces of a stage's g planes -- piece pi -> plane pi >> 3,
+      // rows 4 (pi & 7) + (lane >> 4), chunk position lane & 15 -- kRingB3 - 1 stages ahead, one counted wait and one barrier per chunk
+      const unsigned bring = __builtin_amdgcn_readfirstlane(wg3_lds_addr(smem + kRing3 * kStageA3));
+      const unsigned short* gl = p.GP + (long)(lane >> 4) * p.ldg + tj * 128 + 8 * ((lane & 15) ^ (((lane >> 4) & 3) << 2));
+      auto issue_b = [&](int st, int sb) __attribute__((always_inline)) {
+        const long uo = (long)(c0 + (st < total ? st : total - 1)) * 32 * p.ldg;   // (past the end: the last chunk again, into a slot whose stage has been consumed)
+#pragma unroll
+        for (int pi = lw; pi < 16; pi += kLoaders3)
+          wg3_dma16(gl + uo + (long)(pi >> 3) * p.gps + (long)(4 * (pi & 7)) * p.ldg, bring + sb * kStageB3 + (pi >> 3) * kPlB3 + (pi & 7) * 1024);
+      };
+#pragma unroll
+      for (int s0 = 0; s0 < kRingB3 - 1; ++s0) issue_b(s0, s0);
+      int sb = kRingB3 - 1;                                       // slot of the stage issued next = (s - 1) % kRingB3 at iteration s
+      for (int s = 0; s < total; ++s) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kRingB3 - 2) * 16 / kLoaders3) : "memory");   // this wave's pieces of stage s have landed (the later stages' may be in flight)
+        __builtin_amdgcn_s_barrier();
+        issue_b(s + kRingB3 - 1, sb);
+        sb = sb + 1 == kRingB3 ? 0 : sb + 1;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the clamped re-reads past the end: nothing may land after the workgroup has left)
+      __builtin_amdgcn_s_barrier();
+      return;
+    }
+  }
   if (wave < 4) {
     // ------------------------------------------------------------------------ MFMA waves
     const int half = lane >> 5, l31 = lane & 31;
@@ -78,12 +130,14 @@ __global__ __launch_bounds__(512, 2 * W3G_WGS) void pw_wgrad_planes_kernel(Wg3Pa
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    int slot = 0;
+    int slot = 0, slotb = 0;
+    constexpr int STG = GPL ? kStageA3 : kStage3;
     for (int s = 0; s < total; ++s) {
       __builtin_amdgcn_s_barrier();                             // stage s is in LDS; stage s-1's slot is released
-      const unsigned char* As = smem + slot * kStage3;
-      const unsigned char* Bs = As + 2 * kPl3;
+      const unsigned char* As = smem + slot * STG;
+      const unsigned char* Bs = GPL ? smem + kRing3 * kStageA3 + slotb * kStageB3 : As + 2 * kPl3;
       slot = slot + 1 == kRing3 ? 0 : slot + 1;
+      slotb = slotb + 1 == kRingB3 ? 0 : slotb + 1;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8_t fa[2][2], fb[2][2];                            // [plane][block]
@@ -92,7 +146,8 @@ __global__ __launch_bounds__(512, 2 * W3G_WGS) void pw_wgrad_planes_kernel(Wg3Pa
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
             fa[pl][i] = wg3_frag(As + pl * kPl3, wm * 64 + i * 32, ks, half, l31);
-            fb[pl][i] = wg3_frag(Bs + pl * kPl3, wn * 64 + i * 32, ks, half, l31);
+            if constexpr (GPL) fb[pl][i] = wg3_frag_sw(Bs + pl * kPlB3, wn * 64 + i * 32, ks, half, l31);
+            else fb[pl][i] = wg3_frag(Bs + pl * kPl3, wn * 64 + i * 32, ks, half, l31);
           }
         // a_mid g_hi, a_hi g_mid, a_hi g_hi (the tile kernel's order: small terms first); consecutive MFMAs on different accumulators
         constexpr int PA[3] = {1, 0, 0}, PG[3] = {0, 1, 0};
@@ -130,7 +185,6 @@ __global__ __launch_bounds__(512, 2 * W3G_WGS) void pw_wgrad_planes_kernel(Wg3Pa
   }
   const float* dbase = p.D + (long)ti * 128 + c16 * 8;
   const float* gbase = GPL ? nullptr : p.G + (long)tj * 128 + c16 * 8;
-  const unsigned short* gpbase = GPL ? p.GP + (long)tj * 128 + c16 * 8 : nullptr;
   float4 ra[kD3][2][2], rg[kD3][2][2];                          // [buffer][pixel u][half]
   auto load = [&](int s, float4 (&xa)[2][2], float4 (&xg)[2][2]) {
     s = s < total ? s : total - 1;                              // past the end: a valid address, the data lands in a consumed slot
@@ -139,9 +193,8 @@ __global__ __launch_bounds__(512, 2 * W3G_WGS) void pw_wgrad_planes_kernel(Wg3Pa
       const long row = (long)(c0 + s) * 32 + pxl + 16 * u;
       const float* pa = dbase + row * p.lda;
       xa[u][0] = *reinterpret_cast<const float4*>(pa); xa[u][1] = *reinterpret_cast<const float4*>(pa + 4);
-      if constexpr (GPL) {                                      // the 8 channels' hi words, then their mid words: the same 32 bytes per pixel
-        const unsigned short* pg = gpbase + row * p.ldg;
-        xg[u][0] = *reinterpret_cast<const float4*>(pg); xg[u][1] = *reinterpret_cast<const float4*>(pg + p.gps);
+      if constexpr (GPL) {                                      // (the MFMA waves bring the planes of g by LDS-DMA)
+        xg[u][0] = make_float4(0.f, 0.f, 0.f, 0.f); xg[u][1] = xg[u][0];
       } else {
         const float* pg = gbase + row * p.ldg;
         xg[u][0] = *reinterpret_cast<const float4*>(pg); xg[u][1] = *reinterpret_cast<const float4*>(pg + 4);
@@ -165,16 +218,16 @@ __global__ __launch_bounds__(512, 2 * W3G_WGS) void pw_wgrad_planes_kernel(Wg3Pa
         if constexpr (!GPL) crnn_split3_pair(vg[2 * pr], vg[2 * pr + 1], wb[0][pr], wb[1][pr], wb[2][pr]);
       }
       pw[u][0] = u32x4{wa[0][0], wa[0][1], wa[0][2], wa[0][3]}; pw[u][1] = u32x4{wa[1][0], wa[1][1], wa[1][2], wa[1][3]};
-      if constexpr (GPL) { pw[u][2] = __builtin_bit_cast(u32x4, xg[u][0]); pw[u][3] = __builtin_bit_cast(u32x4, xg[u][1]); }
+      if constexpr (GPL) { pw[u][2] = u32x4{0u, 0u, 0u, 0u}; pw[u][3] = pw[u][2]; }
       else { pw[u][2] = u32x4{wb[0][0], wb[0][1], wb[0][2], wb[0][3]}; pw[u][3] = u32x4{wb[1][0], wb[1][1], wb[1][2], wb[1][3]}; }
     }
   };
   auto store = [&](int s) {
-    unsigned char* st = smem + (s % kRing3) * kStage3 + c16 * 16;
+    unsigned char* st = smem + (s % kRing3) * (GPL ? kStageA3 : kStage3) + c16 * 16;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4*>(st + q * kPl3 + (pxl + 16 * u) * (kLd3 * 2)) = pw[u][q];
+      for (int q = 0; q < (GPL ? 2 : 4); ++q) *reinterpret_cast<u32x4*>(st + q * kPl3 + (pxl + 16 * u) * (kLd3 * 2)) = pw[u][q];
   };
   // barrier s (s = 0 .. total): before it stage s is written; after it the slot of stage s-1 is free -> stage s + kLead3 goes there (its planes were formed before
   // the barrier), then the planes of stage s + kLead3 + 1 are formed and its buffer refilled
@@ -253,7 +306,7 @@ namespace {
 template <bool XF, bool GPL>
 int wg3_launch_kernel(const Wg3Params& p, int grid, int lds, hipStream_t stream) {
   CRNN_LDS_ATTR((pw_wgrad_planes_kernel<XF, GPL>), lds);
-  hipLaunchKernelGGL((pw_wgrad_planes_kernel<XF, GPL>), dim3(grid), dim3(512), lds, stream, p);
+  hipLaunchKernelGGL((pw_wgrad_planes_kernel<XF, GPL>), dim3(grid), dim3(GPL ? 512 + 64 * kLoaders3 : 512), lds, stream, p);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
@@ -268,7 +321,7 @@ int wg3_run(const float* d, const float* in_bnstate, const float* g, const void*
   p.M = (int)M; p.N = N; p.K = K; p.lda = K; p.ldg = N;
   int grid; wg3_geom(M, N, K, p, grid);
   if ((size_t)p.nsplit * K * N * sizeof(float) > scratch_bytes) return CRNN_ERR_UNSUPPORTED;
-  const int lds = kRing3 * kStage3;
+  const int lds = g_planes ? kRing3 * kStageA3 + kRingB3 * kStageB3 : kRing3 * kStage3;
   if (in_bnstate) CRNN_TRY(g_planes ? (wg3_launch_kernel<true, true>(p, grid, lds, stream)) : (wg3_launch_kernel<true, false>(p, grid, lds, stream)));
   else CRNN_TRY(g_planes ? (wg3_launch_kernel<false, true>(p, grid, lds, stream)) : (wg3_launch_kernel<false, false>(p, grid, lds, stream)));
   const long total = (long)K * N;
