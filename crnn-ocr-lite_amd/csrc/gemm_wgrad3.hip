@@ -6,10 +6,13 @@
 // bf16 mode's stream (gemm_wgrad.hip: pw_wgrad_stream_kernel) is carried over to plane operands:
 //   * a workgroup (512 threads) owns one 128 x 128 output tile over a contiguous range of 32-pixel chunks; the 4 MFMA waves (2 x 2, 64 x 64 each: 4 accumulator
 //     blocks) keep the tile in registers for the whole range; per 16-pixel step 12 MFMAs on 4 independent accumulators;
-//   * the 4 IO waves load the fp32 d- and g-rows of the chunks kD chunks ahead into registers, apply ReLU6(d * scale + shift) (the arithmetic of
+//   * the 4 IO waves load the fp32 d- and g-rows of the chunks kD3 chunks ahead into registers, apply ReLU6(d * scale + shift) (the arithmetic of
 //     crnn_pwconv_bnrelu6_wgrad_f32x2's staging waves, bit for bit), split both operands into their planes (common.h crnn_split3_pair) and write them k-major
 //     into an LDS ring of 3 stages (2 operands x 2 planes x 32 pixels x 160 bf16: 40 KiB per stage), conflict-free transposing fragment reads
 //     (two ds_read_b64_tr_b16 per fragment); a chunk's planes are formed one stage interval before they are written (as gemm_wres3.hip);
+//   * g given as planes (crnn_pwconv_bnrelu6_wgrad_planes_stream_gp: what the step runs): the IO waves handle d only, and FOUR loader waves bring the planes of g
+//     by LDS-DMA into a ring of their own (6 stages of 2 planes x 32 pixel rows x 256 B, unpadded, 16-byte chunks swizzled on the source address) -- the IO side
+//     is this kernel's bound (profiles/r06_wgrad3_ablate.txt);
 //   * one raw s_barrier per chunk, branch-free steady state; all tiles of one reduction range sit on one XCD; the fp32 partial tiles go to scratch
 //     [range][K][N] and a fixed-order second stage sums them (deterministic).
 // Same planes and products as the tile kernel; the reduction is grouped differently (other range boundaries): equal to fp32 summation round-off.
