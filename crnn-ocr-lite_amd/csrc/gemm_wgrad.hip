@@ -68,11 +68,43 @@ __device__ __forceinline__ bf16x8_t wg_frag(const unsigned char* Xs, int r0, int
   return __builtin_bit_cast(bf16x8_t, make_uint4(a.x, a.y, b.x, b.y));
 }
 
+// ---- GDMA (round 6, bf16 operands): g is only copied -- its stages come by LDS-DMA from four loader waves into a ring of their own instead of through the IO waves'
+// registers (as gemm_wgrad3.hip, where taking g off the IO waves was worth 11 %): a stage = 64 pixel rows x 256 B (128 channels, unpadded: the DMA's LDS image is
+// lane-linear), 16-byte chunk c of row r at position c ^ ((r & 3) << 2) on the source address, so that the transposing fragment reads stay conflict-free.
+constexpr int kOpB = 64 * 256;                // bytes of one g stage
+#ifndef WG_RINGB
+#define WG_RINGB 6
+#endif
+#ifndef WG_LOADERS
+#define WG_LOADERS 4
+#endif
+#ifndef WG_GDMA
+#define WG_GDMA 1
+#endif
+constexpr int kRingB = WG_RINGB;                     // stages of the g ring (5 in flight per CU: 80 KiB)
+constexpr int kLoaders = WG_LOADERS;                   // loader waves (one sustains ~25 GB/s per CU)
+__device__ __forceinline__ unsigned wg_lds_addr(const void* p) { return (unsigned)(uintptr_t)((__attribute__((address_space(3))) const unsigned char*)p); }
+__device__ __forceinline__ void wg_dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ bf16x8_t wg_frag_sw(const unsigned char* Xs, int r0, int ks, int half, int l31) {
+  const int li = l31 & 15;
+  const int row = ks * 16 + 8 * half + (li >> 2), col = r0 + (l31 & 16) + (li & 3) * 4;
+  const unsigned short* X = reinterpret_cast<const unsigned short*>(Xs) + row * 128 + ((((col >> 3) ^ ((row & 3) << 2)) << 3) | (col & 7));
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)X);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(X + 4 * 128));
+  const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
+  return __builtin_bit_cast(bf16x8_t, make_uint4(a.x, a.y, b.x, b.y));
+}
+
 // F32: both operands are fp32 tensors rounded to bf16 on the way in (v_cvt_pk_bf16_f32, RNE -- what the tile GEMM does while it stages
 // them), no BatchNorm transform: the weight gradients of the recurrent layers, dW = X^T dZ and dU = H^T dZ over the T*B rows
 // XF = false (bf16 operands): no BatchNorm transform either -- round 5, dense1's weight gradient dW1 = x7^T gbm over bf16 tensors
-template <int NIO, bool F32, bool XF = true>   // IO waves (4 or 8): 16 / NIO 8-channel pieces of each operand per lane and chunk
-__global__ __launch_bounds__(256 + 64 * NIO) void pw_wgrad_stream_kernel(WgParams p) {
+template <int NIO, bool F32, bool XF = true, bool GDMA = false>   // IO waves (4 or 8): 16 / NIO 8-channel pieces of each operand per lane and chunk; GDMA: g by loader waves
+__global__ __launch_bounds__(256 + 64 * NIO + (GDMA ? 64 * kLoaders : 0)) void pw_wgrad_stream_kernel(WgParams p) {
+  static_assert(!GDMA || !F32, "the loader waves copy bf16 rows");
+  constexpr int STA = GDMA ? kOp : 2 * kOp;                     // bytes of an IO-wave stage (GDMA: the a operand only)
   constexpr int NP = 16 / NIO, RW = F32 ? 2 : 1;              // 16-byte registers per piece
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // kRing x (A stage | B stage)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -87,6 +119,32 @@ __global__ __launch_bounds__(256 + 64 * NIO) void pw_wgrad_stream_kernel(WgParam
   const int c0 = split * p.per;
   const int total = min(p.per, p.chunks - c0);                  // chunks of this range (> 0 by the host's choice of nsplit)
 
+  if constexpr (GDMA) {
+    if (wave >= 4 + NIO) {
+      // ---------------------------------------------------------------------- loader waves: the 16 1-KiB pieces of a g stage (piece pi = rows 4 pi + (lane >> 4), chunk
+      // position lane & 15), a quarter each, kRingB - 1 stages ahead; one counted wait and one barrier per chunk
+      const int lw = wave - (4 + NIO);
+      const unsigned bring = __builtin_amdgcn_readfirstlane(wg_lds_addr(smem + kRing * kOp));
+      const bf16_t* gl = p.G + (long)(lane >> 4) * p.ldg + tj * 128 + 8 * ((lane & 15) ^ (((lane >> 4) & 3) << 2));
+      auto issue_b = [&](int st, int sb) __attribute__((always_inline)) {
+        const long uo = (long)(c0 + (st < total ? st : total - 1)) * 64 * p.ldg;   // (past the end: the last chunk again, into a slot whose stage has been consumed)
+#pragma unroll
+        for (int q = 0; q < 16 / kLoaders; ++q) wg_dma16(gl + uo + (long)(4 * (lw + q * kLoaders)) * p.ldg, bring + sb * kOpB + (lw + q * kLoaders) * 1024);
+      };
+#pragma unroll
+      for (int s0 = 0; s0 < kRingB - 1; ++s0) issue_b(s0, s0);
+      int sb = kRingB - 1;
+      for (int s = 0; s < total; ++s) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kRingB - 2) * 16 / kLoaders) : "memory");   // this wave's pieces of stage s have landed
+        __builtin_amdgcn_s_barrier();
+        issue_b(s + kRingB - 1, sb);
+        sb = sb + 1 == kRingB ? 0 : sb + 1;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // nothing may land after the workgroup has left
+      __builtin_amdgcn_s_barrier();
+      return;
+    }
+  }
   if (wave < 4) {
     // ------------------------------------------------------------------------ MFMA waves
     const int half = lane >> 5, l31 = lane & 31;
@@ -98,7 +156,7 @@ __global__ __launch_bounds__(256 + 64 * NIO) void pw_wgrad_stream_kernel(WgParam
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    int slot = 0;
+    int slot = 0, slotb = 0;
     for (int s = 0; s < total; ++s) {
 #ifdef CRNN_WG_TRACE
       const bool tr = p.trace && wg == 8 && wave == 0 && lane == 0 && s < 64;
@@ -108,9 +166,10 @@ __global__ __launch_bounds__(256 + 64 * NIO) void pw_wgrad_stream_kernel(WgParam
 #ifdef CRNN_WG_TRACE
       if (tr) p.trace[256 + s * 4 + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
-      const unsigned char* As = smem + slot * (2 * kOp);
-      const unsigned char* Bs = As + kOp;
+      const unsigned char* As = smem + slot * STA;
+      const unsigned char* Bs = GDMA ? smem + kRing * kOp + slotb * kOpB : As + kOp;
       slot = slot + 1 == kRing ? 0 : slot + 1;
+      slotb = slotb + 1 == kRingB ? 0 : slotb + 1;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         if (CRNN_WG_EXP & 2) continue;
@@ -118,7 +177,7 @@ __global__ __launch_bounds__(256 + 64 * NIO) void pw_wgrad_stream_kernel(WgParam
 #pragma unroll
         for (int i = 0; i < 2; ++i) fa[i] = wg_frag(As, wm * 64 + i * 32, ks, half, l31);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) fb[j] = wg_frag(Bs, wn * 64 + j * 32, ks, half, l31);
+        for (int j = 0; j < 2; ++j) fb[j] = GDMA ? wg_frag_sw(Bs, wn * 64 + j * 32, ks, half, l31) : wg_frag(Bs, wn * 64 + j * 32, ks, half, l31);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -163,7 +222,7 @@ __global__ __launch_bounds__(256 + 64 * NIO) void pw_wgrad_stream_kernel(WgParam
       xg[0] = *reinterpret_cast<const u32x4*>(pg); xg[1] = *reinterpret_cast<const u32x4*>(pg + 4);
     } else {
       xa[0] = *reinterpret_cast<const u32x4*>(dbase + row * p.lda);
-      xg[0] = *reinterpret_cast<const u32x4*>(gbase + row * p.ldg);
+      if constexpr (GDMA) xg[0] = u32x4{0u, 0u, 0u, 0u}; else xg[0] = *reinterpret_cast<const u32x4*>(gbase + row * p.ldg);
     }
   };
   auto load = [&](int s, u32x4 (&xa)[NP * RW], u32x4 (&xg)[NP * RW]) {
@@ -175,7 +234,7 @@ __global__ __launch_bounds__(256 + 64 * NIO) void pw_wgrad_stream_kernel(WgParam
                  pack2_bf16(__uint_as_float(hi.x), __uint_as_float(hi.y)), pack2_bf16(__uint_as_float(hi.z), __uint_as_float(hi.w))};
   };
   auto write1 = [&](int s, int u, const u32x4* xa, const u32x4* xg) {
-    unsigned char* As = smem + (s % kRing) * (2 * kOp);
+    unsigned char* As = smem + (s % kRing) * STA;
     unsigned char* Bs = As + kOp;
     const int px = pxl + 4 * NIO * u;
     u32x4 o, og;
@@ -188,7 +247,7 @@ __global__ __launch_bounds__(256 + 64 * NIO) void pw_wgrad_stream_kernel(WgParam
       }
     }
     *reinterpret_cast<u32x4*>(As + px * (kLd * 2) + c16 * 16) = o;
-    *reinterpret_cast<u32x4*>(Bs + px * (kLd * 2) + c16 * 16) = og;
+    if constexpr (!GDMA) *reinterpret_cast<u32x4*>(Bs + px * (kLd * 2) + c16 * 16) = og;
   };
   auto write = [&](int s, const u32x4 (&xa)[NP * RW], const u32x4 (&xg)[NP * RW]) {
 #pragma unroll
@@ -322,10 +381,21 @@ int wg_launch(WgParams& p, long M, float* out, int ldc, float* scratch, size_t s
 #endif
   if ((size_t)p.nsplit * p.K * p.N * sizeof(float) > scratch_bytes) return CRNN_ERR_UNSUPPORTED;
   const int lds = kRing * 2 * kOp;
+  bool done = false;
+  if constexpr (!F32 && XF) {   // the pointwise convolutions' form (bf16 d with the BatchNorm transform, bf16 g): g by LDS-DMA from loader waves
+    if (crnn_knob("CRNN_WG_GDMA", WG_GDMA) && (p.ldg & 7) == 0 && (((uintptr_t)p.G) & 15) == 0) {
+      const int ldsd = kRing * kOp + kRingB * kOpB;
+      CRNN_LDS_ATTR((pw_wgrad_stream_kernel<8, false, true, true>), ldsd);
+      hipLaunchKernelGGL((pw_wgrad_stream_kernel<8, false, true, true>), dim3(grid), dim3(256 + 64 * 8 + 64 * kLoaders), ldsd, stream, p);
+      done = true;
+    }
+  }
+  if (!done) {
   CRNN_LDS_ATTR((pw_wgrad_stream_kernel<4, F32, XF>), lds);
   CRNN_LDS_ATTR((pw_wgrad_stream_kernel<8, F32, XF>), lds);
   if (crnn_knob("CRNN_WG_NIO", 8) == 4) hipLaunchKernelGGL((pw_wgrad_stream_kernel<4, F32, XF>), dim3(grid), dim3(512), lds, stream, p);
   else hipLaunchKernelGGL((pw_wgrad_stream_kernel<8, F32, XF>), dim3(grid), dim3(768), lds, stream, p);
+  }
   CRNN_LAUNCH_CHECK();
   const long total = (long)p.K * p.N;
   if (defer) {   // the caller batches the second stage (crnn_wgrad_sum_batch); `scratch` must stay untouched until then

@@ -15,6 +15,10 @@ for name, M, N, K in [("b3", 958464, 256, 128), ("b4", 239616, 256, 256), ("b5",
     st = torch.randn(4 * K, device="cuda").abs() + 0.5; dw = torch.empty(K, N, device="cuda")
     res = []
     fns = [L.crnn_pwconv_bnrelu6_wgrad_stream, L.crnn_pwconv_bnrelu6_wgrad]
+    for path in filter(None, os.environ.get("WG_LIBS", "").split(",")):   # variant builds of gemm_wgrad.hip alone (scripts/_trace/libwg_<name>.so)
+        lib = ctypes.CDLL(os.path.join(ROOT, "scripts/_trace/libwg_%s.so" % path))
+        lib.crnn_pwconv_bnrelu6_wgrad_stream.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        fns.append(lib.crnn_pwconv_bnrelu6_wgrad_stream)
     if "--ablate" in sys.argv:
         for m in (1, 2, 3, 4, 7):
             lib = ctypes.CDLL(os.path.join(ROOT, "scripts/_trace/libwg_exp%d.so" % m))
@@ -31,5 +35,5 @@ for name, M, N, K in [("b3", 958464, 256, 128), ("b4", 239616, 256, 256), ("b5",
     by = 2.0 * M * (N + K)
     tot[0] += res[0]; tot[1] += res[1]
     print("%s M=%7d N=%3d K=%3d: stream %6.1f us (%.2f TB/s)   tile %6.1f us (%.2f TB/s)  %s" % (name, M, N, K, res[0], by / res[0] / 1e6, res[1], by / res[1] / 1e6,
-          "  ".join("exp%d %.1f" % (m, t) for m, t in zip((1, 2, 3, 4, 7), res[2:]))), flush=True)
+          "  ".join("%s %.1f" % (m, t) for m, t in zip(list(filter(None, os.environ.get("WG_LIBS", "").split(","))) + ["exp%d" % m for m in (1, 2, 3, 4, 7)], res[2:]))), flush=True)
 print("sum: stream %.0f us, tile %.0f us" % tuple(tot))
