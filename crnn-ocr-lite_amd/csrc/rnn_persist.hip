@@ -38,6 +38,10 @@
 
 #include "rnn_exchange.h"
 
+#ifndef CRNN_RNN_EXP
+#define CRNN_RNN_EXP 0   // experiment builds (scripts/lstm_ablate.py; wrong numbers): 1 = the per-step operands (x W / gates, c, dout) are constants instead of loads
+#endif                   // -- what the loads cost and which re-schedulings did not recover it: profiles/r06_lstm_operand_ablation.txt
+
 namespace {
 
 struct FwdDir {
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_fwd_persist_kernel(FwdDir d0, F
       const int b = b0 + 16 * m + row;
       const float* xw = d.xw + ((long)t * B + (b < b_end ? b : b_lo)) * 4 * U;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) xwv[m][g] = xw[g * U + j];
+      for (int g = 0; g < 4; ++g) xwv[m][g] = (CRNN_RNN_EXP & 1) ? 0.01f * (float)(g + col) : xw[g * U + j];
     }
     if (s > 0) {
       const E* tile = xdata + (((long)dir * kRing + ((s - 1) & (kRing - 1))) * nbt + bt) * tile_elems;
@@ -259,10 +263,10 @@ __global__ __launch_bounds__(256 * UW) void lstm_bwd_persist_kernel(BwdDir d0, B
       const long bb = (b < b_end) ? b : b_lo;
       const float* gt = d.gates + ((long)t * B + bb) * K;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) gv[m][g] = gt[g * U + j];
-      ctv[m] = d.c[((long)t * B + bb) * U + j];
-      cpv[m] = (sp > 0) ? d.c[((long)tprev * B + bb) * U + j] : 0.f;
-      dov[m] = d.dout[((long)t * B + bb) * d.ldo + j];
+      for (int g = 0; g < 4; ++g) gv[m][g] = (CRNN_RNN_EXP & 1) ? 0.3f + 0.01f * (float)g : gt[g * U + j];
+      ctv[m] = (CRNN_RNN_EXP & 1) ? 0.2f : d.c[((long)t * B + bb) * U + j];
+      cpv[m] = (CRNN_RNN_EXP & 1) ? 0.1f : (sp > 0) ? d.c[((long)tprev * B + bb) * U + j] : 0.f;
+      dov[m] = (CRNN_RNN_EXP & 1) ? 0.01f * (float)col : d.dout[((long)t * B + bb) * d.ldo + j];
     }
     if (sb > 0) {
       const E* tile = xdata + (((long)dir * kRing + ((sb - 1) & (kRing - 1))) * nbt + bt) * tile_elems;
