@@ -314,21 +314,23 @@ int wg3_launch_kernel(const Wg3Params& p, int grid, int lds, hipStream_t stream)
   return CRNN_OK;
 }
 int wg3_run(const float* d, const float* in_bnstate, const float* g, const void* g_planes, long g_plane_stride, float* dw, long M, int N, int K, float* scratch,
-            size_t scratch_bytes, hipStream_t stream) {
+            size_t scratch_bytes, hipStream_t stream, int lda = 0, int ldg = 0, int ldc = 0) {
   if (!d || (!g && !g_planes) || !dw || !scratch) return CRNN_ERR_ARG;
   CRNN_TRY(crnn_pwconv_wgrad_planes_stream_supported(M, N, K));
   if ((((uintptr_t)d | (uintptr_t)g | (uintptr_t)g_planes | (uintptr_t)dw | (uintptr_t)scratch | (uintptr_t)in_bnstate) & 15) || (g_plane_stride & 7)) return CRNN_ERR_UNSUPPORTED;
+  lda = lda ? lda : K; ldg = ldg ? ldg : N; ldc = ldc ? ldc : N;
+  if (lda < K || ldg < N || ldc < N || ((lda | ldg | ldc) & 3) || M * (long)(lda > ldg ? lda : ldg) >= (1L << 31)) return CRNN_ERR_UNSUPPORTED;
   Wg3Params p;
   p.D = d; p.G = g; p.GP = reinterpret_cast<const unsigned short*>(g_planes); p.gps = g_plane_stride; p.part = scratch;
   p.scale = in_bnstate ? in_bnstate + 2L * K : nullptr; p.shift = in_bnstate ? in_bnstate + 3L * K : nullptr;
-  p.M = (int)M; p.N = N; p.K = K; p.lda = K; p.ldg = N;
+  p.M = (int)M; p.N = N; p.K = K; p.lda = lda; p.ldg = ldg;
   int grid; wg3_geom(M, N, K, p, grid);
   if ((size_t)p.nsplit * K * N * sizeof(float) > scratch_bytes) return CRNN_ERR_UNSUPPORTED;
   const int lds = g_planes ? kRing3 * kStageA3 + kRingB3 * kStageB3 : kRing3 * kStage3;
   if (in_bnstate) CRNN_TRY(g_planes ? (wg3_launch_kernel<true, true>(p, grid, lds, stream)) : (wg3_launch_kernel<true, false>(p, grid, lds, stream)));
   else CRNN_TRY(g_planes ? (wg3_launch_kernel<false, true>(p, grid, lds, stream)) : (wg3_launch_kernel<false, false>(p, grid, lds, stream)));
   const long total = (long)K * N;
-  hipLaunchKernelGGL(pw_wgrad3_sum_kernel, dim3(cdiv(total / 4, 256)), dim3(256), 0, stream, scratch, p.nsplit, total, dw, N, N);
+  hipLaunchKernelGGL(pw_wgrad3_sum_kernel, dim3(cdiv(total / 4, 256)), dim3(256), 0, stream, scratch, p.nsplit, total, dw, N, ldc);
   CRNN_LAUNCH_CHECK();
   return CRNN_OK;
 }
@@ -345,4 +347,13 @@ extern "C" int crnn_pwconv_bnrelu6_wgrad_planes_stream_gp(const float* d, const 
                                                           int K, float* scratch, size_t scratch_bytes, hipStream_t stream) {
   if (!g_planes) return CRNN_ERR_ARG;
   return wg3_run(d, in_bnstate, nullptr, g_planes, g_plane_stride, dw, M, N, K, scratch, scratch_bytes, stream);
+}
+// The same stream without a transform and with leading dimensions (round 6): C[M][N] (fp32, row stride ldc) = A^T . B over the K rows of A [K][lda >= M] and
+// B [K][ldb >= N], both fp32, two bf16 planes per operand (hi*hi + hi*mid + mid*hi: the precision of crnn_gemm_f32x2) -- the recurrent layers' weight
+// gradients dW = x^T dz, dU = h_prev^T dz of the parity mode (utils.py:77-82 backwards), which the tile kernel ran as 8-16 tiles x 32-64 K ranges plus a
+// 64-row reduction.  Supported (else -3): crnn_pwconv_wgrad_planes_stream_supported(K, N, M), leading dimensions multiples of 4, 16-byte aligned pointers;
+// scratch: crnn_pwconv_wgrad_planes_stream_scratch_bytes(K, N, M).  Same products as crnn_gemm_f32x2 mode 2, another summation order.
+extern "C" int crnn_gemm_tn_planes_stream(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, long K, float* scratch,
+                                          size_t scratch_bytes, hipStream_t stream) {
+  return wg3_run(A, nullptr, B, nullptr, 0, C, K, N, M, scratch, scratch_bytes, stream, lda, ldb, ldc);
 }

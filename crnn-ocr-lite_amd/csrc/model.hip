@@ -1004,6 +1004,11 @@ static int gemm_tn(const Ctx& c, const float* A, const float* B, float* C, int M
     const int rc = crnn_gemm_tn_stream(A, lda, B, ldb, C, ldc, M, N, K, c.scratch(), kGemmScratchBytes, c.s);
     if (rc != CRNN_ERR_UNSUPPORTED) return rc;
   }
+  // parity mode, two-plane backward: the pixel-stream form of the two-plane weight gradient (gemm_wgrad3.hip) where its shape rules hold
+  if (!c.cfg->mfma_bf16 && conv_planes(c.cfg, true) == 2 && !(c.cfg->flags & (CRNN_FLAG_GEMM_TILE_KERNELS | CRNN_FLAG_F32_MFMA_GEMMS))) {
+    const int rc = crnn_gemm_tn_planes_stream(A, lda, B, ldb, C, ldc, M, N, K, c.scratch(), kGemmScratchBytes, c.s);
+    if (rc != CRNN_ERR_UNSUPPORTED) return rc;
+  }
   return gemm(c, 2, A, B, C, M, N, K, lda, ldb, ldc, nullptr, 0, 0, 0, conv_planes(c.cfg, true));
 }
 static int rnn_bwd_wgrads(const Ctx& c, int layer, const float* xin, int ldx, int din, const float* hf, const float* hb, int ldh) {

@@ -284,6 +284,12 @@ int crnn_pwconv_bnrelu6_wgrad_planes_stream(const float* d, const float* in_bnst
 /* ... with g given as its two bf16 planes (hi plane [M][N], the mid plane g_plane_stride elements behind it: crnn_bn_bwd_planes_ex's output); bit-identical. */
 int crnn_pwconv_bnrelu6_wgrad_planes_stream_gp(const float* d, const float* in_bnstate, const void* g_planes, long g_plane_stride, float* dw, long M, int N, int K,
                                                float* scratch, size_t scratch_bytes, crnn_stream_t stream);
+/* The planes stream without a transform and with leading dimensions (round 6): C[M][N] (row stride ldc) = A^T . B over the K rows of A [K][lda] and B [K][ldb], fp32,
+ * two bf16 planes per operand (crnn_gemm_f32x2's precision, another summation order) -- the parity mode's recurrent weight gradients (utils.py:77-82 backwards).
+ * Supported (else -3): crnn_pwconv_wgrad_planes_stream_supported(K, N, M), leading dimensions % 4 == 0, 16-byte aligned pointers;
+ * scratch: crnn_pwconv_wgrad_planes_stream_scratch_bytes(K, N, M) */
+int crnn_gemm_tn_planes_stream(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, long K, float* scratch,
+                               size_t scratch_bytes, crnn_stream_t stream);
 /* The data gradient from PRE-SPLIT planes (round 6, gemm_pres.hip): da[M][N] = dq[M][K] . w[N][K]^T with dq given as bf16 planes
  * (plane pl of dq[m][k] at dq_planes[pl * plane_stride + m * K + k]: the words of crnn_split3_planes; planes = 2 | 3) -- written once by the kernel that produces
  * dq (crnn_bn_bwd_planes_ex) instead of being split by every slice of every GEMM that reads it.  Four waves per workgroup, one per SIMD, the planes of a

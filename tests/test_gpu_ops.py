@@ -1954,6 +1954,31 @@ def test_two_plane_weight_gradient_on_the_pixel_stream_equals_the_tile_kernel(M,
     assert L().crnn_pwconv_bnrelu6_wgrad_planes_stream(P(d), P(st), P(g), P(dw1), M, N, K, P(scr), ctypes.c_size_t(1024), S()) == -3
 
 
+@pytest.mark.parametrize("rows,M,N,lda,ldb,ldc", [(52 * 256, 128, 1024, 128, 1024, 1024), (51 * 256, 256, 1024, 512, 1024, 1024), (51 * 64, 256, 1024, 256, 1024, 1028),
+                                                    (32 * 3, 128, 128, 132, 136, 128)])
+def test_two_plane_transposed_product_with_leading_dimensions_on_the_pixel_stream(rows, M, N, lda, ldb, ldc):
+    """crnn_gemm_tn_planes_stream (round 6): C = A^T B over the rows of A [rows][lda >= M] and B [rows][ldb >= N] -- the recurrent layers' weight gradients of the
+    parity mode (x^T dz, h_prev^T dz; h_prev a column half of the concatenated hidden states: lda = 2u) -- against crnn_gemm_f32x2 mode 2 (same planes and
+    products, other reduction ranges) and the fp64 product; columns beyond M / N of the operands and beyond N of C's rows are not touched; repeats give the same bits."""
+    rs = np.random.RandomState(rows % 1000 + M + N)
+    A = dev(rs.normal(size=(rows, lda)).astype(np.float32)); B = dev((rs.normal(size=(rows, ldb)) * 0.3).astype(np.float32))
+    assert L().crnn_pwconv_wgrad_planes_stream_supported(rows, N, M) == 0
+    nb = L().crnn_pwconv_wgrad_planes_stream_scratch_bytes(rows, N, M)
+    scr = torch.empty(nb // 4, device="cuda"); scr2 = zeros(16 * 1024 * 1024); sb2 = ctypes.c_size_t(scr2.numel() * 4)
+    c1 = torch.full((M + 1, ldc), 7.0, device="cuda"); c2 = torch.full((M + 1, ldc), 7.0, device="cuda"); c0 = zeros(M, ldc)
+    ok(L().crnn_gemm_tn_planes_stream(P(A), lda, P(B), ldb, P(c1), ldc, M, N, rows, P(scr), ctypes.c_size_t(nb), S()))
+    ok(L().crnn_gemm_tn_planes_stream(P(A), lda, P(B), ldb, P(c2), ldc, M, N, rows, P(scr), ctypes.c_size_t(nb), S()))
+    assert torch.equal(c1, c2) and bool((c1[M:] == 7.0).all()) and bool((c1[:, N:] == 7.0).all())
+    ok(L().crnn_gemm_f32x2(2, P(A), P(B), P(c0), M, N, rows, lda, ldb, ldc, None, 0, 0, 0, P(scr2), sb2, S()))
+    ref = host(A)[:, :M].astype(np.float64).T @ host(B)[:, :N].astype(np.float64)
+    sc = np.abs(ref).max()
+    assert float((c1[:M, :N] - c0[:, :N]).abs().max()) <= 2e-6 * sc + 1e-6, (float((c1[:M, :N] - c0[:, :N]).abs().max()), sc)
+    assert np.abs(host(c1[:M, :N]) - ref).max() <= 3e-5 * sc + 1e-6
+    assert L().crnn_gemm_tn_planes_stream(P(A), M - 4, P(B), ldb, P(c1), ldc, M, N, rows, P(scr), ctypes.c_size_t(nb), S()) == -3
+    assert L().crnn_gemm_tn_planes_stream(P(A), lda, P(B), ldb, P(c1), ldc, M, N, rows, P(scr), ctypes.c_size_t(1024), S()) == -3
+    assert L().crnn_gemm_tn_planes_stream(P(A), lda, P(B), ldb, P(c1), ldc, 64, N, rows, P(scr), ctypes.c_size_t(nb), S()) == -3
+
+
 def _planes_of(x, stride=None):
     """crnn_split3_planes of a device fp32 tensor -> (planes tensor [3 * stride] of bf16 words, stride)."""
     n = x.numel(); stride = stride or n
