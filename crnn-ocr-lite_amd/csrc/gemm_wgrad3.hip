@@ -357,3 +357,149 @@ extern "C" int crnn_gemm_tn_planes_stream(const float* A, int lda, const float* 
                                           size_t scratch_bytes, hipStream_t stream) {
   return wg3_run(A, nullptr, B, nullptr, 0, C, K, N, M, scratch, scratch_bytes, stream, lda, ldb, ldc);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Input gradient of a Bidirectional recurrent layer's input projections in the parity mode (utils.py:77-82 backwards; round 6):
+//     dX[M][N] (fp32) = dZf[M][K] . Wf[N][K]^T + dZb[M][K] . Wb[N][K]^T      M = T*B rows, K = 4u (3u) gate columns, N = 128 | 256
+// with two bf16 planes per operand (hi*hi + hi*mid + mid*hi: the precision of crnn_gemm_f32x2) on the schedule of gemm_wgrad.hip's stripe stream
+// (gemm_nt_f32_stream_kernel): one workgroup per (64-row stripe, 128-column slab) keeps its [64][128] result in the MFMA waves' registers over the whole
+// reduction of both pairs; eight IO waves stage every 64-k chunk of the dZ rows and of the weight rows through registers, split each fp32 value into its
+// hi and mid words (crnn_split3_pair: the words every plane kernel forms) and leave both planes in an LDS ring (swizzled 128-byte rows per plane).  The tile
+// kernel ran this as two launches (the second accumulating) of 104-208 tiles with a serial chunk chain each: 41-47 us per launch at batch 256.
+// Same products as crnn_gemm_f32x2 mode 1, summed small terms first and in the stripe's (rotated) chunk order: fp32 round-off apart.
+namespace {
+struct Nts2Params {
+  const float* A[2]; const float* W[2];     // the (dZ, W) pairs: A [M][lda], W [N][ldw] fp32
+  float* Y;
+  int M, K, lda, ldw, ldy, npairs, skew;    // 128 columns per workgroup: blockIdx.y selects the slab
+};
+constexpr int kN2Ring = 3;
+__global__ __launch_bounds__(768) void gemm_nt_f32x2_stream_kernel(Nts2Params p) {
+  constexpr int N = 128, kX = 64 * 128, kW = N * 128, kPl = kX + kW, kSt = 2 * kPl;   // a stage: plane hi [X rows | W rows], plane mid [X rows | W rows], 64 k each
+  constexpr int WP = N * 8 / 512, ND = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * N;
+  const int kch = p.K / 64, total = kch * p.npairs;
+
+  if (wave < 4) {
+    const int half = lane >> 5, l31 = lane & 31, sw = (l31 >> 1) & 7;
+    f32x16 acc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+    int slot = 0;
+    for (int s = 0; s < total; ++s) {
+      __builtin_amdgcn_s_barrier();
+      const unsigned char* Xs = smem + slot * kSt + l31 * 128;
+      const unsigned char* Ws = smem + slot * kSt + kX + (wave * 32 + l31) * 128;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int off = ((2 * ks + half) ^ sw) * 16;
+        bf16x8_t fx[2][2], fw[2];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+          for (int b = 0; b < 2; ++b) fx[b][pl] = *reinterpret_cast<const bf16x8_t*>(Xs + pl * kPl + b * 32 * 128 + off);
+          fw[pl] = *reinterpret_cast<const bf16x8_t*>(Ws + pl * kPl + off);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[0], fx[b][1], acc[b], 0, 0, 0);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[1], fx[b][0], acc[b], 0, 0, 0);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[0], fx[b][0], acc[b], 0, 0, 0);
+        }
+      }
+      slot = slot + 1 == kN2Ring ? 0 : slot + 1;
+    }
+    __builtin_amdgcn_s_barrier();
+    // lane = one row; register group g of a block = columns 8 g + 4 half + 0..3
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float* yrow = p.Y + (long)(m0 + 32 * b + l31) * p.ldy + n0 + wave * 32 + 4 * half;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(yrow + 8 * g) = make_float4(acc[b][4 * g], acc[b][4 * g + 1], acc[b][4 * g + 2], acc[b][4 * g + 3]);
+    }
+    return;
+  }
+  // ---------------------------------------------------------------------------- IO waves (8): lane il = 0..511
+  const int il = tid - 256;
+  const int xr = il >> 3, xc = il & 7;                          // dZ piece: row xr (0..63), 8-k piece xc; weight pieces: rows xr, xr + 64
+  const int kc0 = p.skew ? (int)(((long)p.skew * blockIdx.x) % kch) : 0;   // (see gemm_nt_f32_stream_kernel: every workgroup starts its walk at another chunk)
+  u32x4 rx[ND][2], rw[ND][WP][2];
+  auto load = [&](int s, u32x4 (&ax)[2], u32x4 (&aw)[WP][2]) {
+    s = s < total ? s : total - 1;
+    const int pr = s / kch;
+    int kc = s - pr * kch + kc0; kc = kc >= kch ? kc - kch : kc;
+    const float* a = p.A[pr] + (long)(m0 + xr) * p.lda + kc * 64 + xc * 8;
+    ax[0] = *reinterpret_cast<const u32x4*>(a); ax[1] = *reinterpret_cast<const u32x4*>(a + 4);
+    const float* w = p.W[pr] + kc * 64 + xc * 8;
+#pragma unroll
+    for (int u = 0; u < WP; ++u) {
+      const float* wr = w + (long)(n0 + xr + 64 * u) * p.ldw;
+      aw[u][0] = *reinterpret_cast<const u32x4*>(wr); aw[u][1] = *reinterpret_cast<const u32x4*>(wr + 4);
+    }
+  };
+  auto split8 = [](const u32x4& lo4, const u32x4& hi4, u32x4& h, u32x4& m) __attribute__((always_inline)) {
+    unsigned a[4], b[4], w2;
+    crnn_split3_pair(__uint_as_float(lo4.x), __uint_as_float(lo4.y), a[0], b[0], w2); crnn_split3_pair(__uint_as_float(lo4.z), __uint_as_float(lo4.w), a[1], b[1], w2);
+    crnn_split3_pair(__uint_as_float(hi4.x), __uint_as_float(hi4.y), a[2], b[2], w2); crnn_split3_pair(__uint_as_float(hi4.z), __uint_as_float(hi4.w), a[3], b[3], w2);
+    h = u32x4{a[0], a[1], a[2], a[3]}; m = u32x4{b[0], b[1], b[2], b[3]};
+  };
+  auto write = [&](int s, const u32x4 (&ax)[2], const u32x4 (&aw)[WP][2]) {
+    unsigned char* st = smem + (s % kN2Ring) * kSt;
+    u32x4 h, m;
+    split8(ax[0], ax[1], h, m);
+    const int xo = xr * 128 + ((xc ^ ((xr >> 1) & 7)) * 16);
+    *reinterpret_cast<u32x4*>(st + xo) = h; *reinterpret_cast<u32x4*>(st + kPl + xo) = m;
+#pragma unroll
+    for (int u = 0; u < WP; ++u) {
+      const int r = xr + 64 * u;
+      split8(aw[u][0], aw[u][1], h, m);
+      const int wo = kX + r * 128 + ((xc ^ ((r >> 1) & 7)) * 16);
+      *reinterpret_cast<u32x4*>(st + wo) = h; *reinterpret_cast<u32x4*>(st + kPl + wo) = m;
+    }
+  };
+  auto step = [&](int s, u32x4 (&ax)[2], u32x4 (&aw)[WP][2]) {     // buffer (s + 1) % ND
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    write(s + 1, ax, aw); load(s + 1 + ND, ax, aw);
+  };
+  // barrier s: stage s is written before it; after it the slot of stage s-1 is free; stage s+1 goes into slot (s+1) % 3, which held stage s-2 -- released at barrier s-1
+#pragma unroll
+  for (int k = 0; k < ND; ++k) load(k, rx[k], rw[k]);
+  write(0, rx[0], rw[0]); load(ND, rx[0], rw[0]);
+  int s = 0;
+  for (; s + ND <= total; s += ND) {
+#pragma unroll
+    for (int k = 0; k < ND; ++k) step(s + k, rx[(k + 1) % ND], rw[(k + 1) % ND]);
+  }
+#pragma unroll
+  for (int k = 0; k < ND; ++k)
+    if (s + k <= total) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (s + k < total) { write(s + k + 1, rx[(k + 1) % ND], rw[(k + 1) % ND]); load(s + k + 1 + ND, rx[(k + 1) % ND], rw[(k + 1) % ND]); }
+    }
+}
+}  // namespace
+// Y[M][N] (fp32, row stride ldy) = A0[M][K] . W0[N][K]^T (+ A1 . W1^T when A1 != NULL), everything fp32, two bf16 planes per operand.  Supported (else -3):
+// M % 64 == 0, N % 128 == 0, K % 64 == 0, leading dimensions multiples of 4, 16-byte aligned pointers.
+extern "C" int crnn_gemm_nt_f32x2_stream(const float* A0, const float* W0, const float* A1, const float* W1, float* Y, int M, int N, int K, int lda, int ldw,
+                                         int ldy, hipStream_t stream) {
+  if (M <= 0 || K <= 0 || N <= 0 || !A0 || !W0 || !Y || ((A1 != nullptr) != (W1 != nullptr))) return CRNN_ERR_ARG;
+  if (M % 64 || N % 128 || K % 64 || ((lda | ldw | ldy) & 3) || lda < K || ldw < K || ldy < N) return CRNN_ERR_UNSUPPORTED;
+  if ((((uintptr_t)A0 | (uintptr_t)W0 | (uintptr_t)A1 | (uintptr_t)W1 | (uintptr_t)Y) & 15)) return CRNN_ERR_UNSUPPORTED;
+  if ((long)M * (lda > ldy ? lda : ldy) >= (1L << 31) || N > 65535 * 128) return CRNN_ERR_UNSUPPORTED;
+  Nts2Params p;
+  p.A[0] = A0; p.A[1] = A1 ? A1 : A0; p.W[0] = W0; p.W[1] = W1 ? W1 : W0; p.Y = Y;
+  p.M = M; p.K = K; p.lda = lda; p.ldw = ldw; p.ldy = ldy; p.npairs = A1 ? 2 : 1; p.skew = 3;
+  const int lds = kN2Ring * 2 * (64 * 128 + 128 * 128);
+  CRNN_LDS_ATTR(gemm_nt_f32x2_stream_kernel, lds);
+  hipLaunchKernelGGL(gemm_nt_f32x2_stream_kernel, dim3(M / 64, N / 128), dim3(768), lds, stream, p);
+  CRNN_LAUNCH_CHECK();
+  return CRNN_OK;
+}

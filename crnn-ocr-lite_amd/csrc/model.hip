@@ -1048,6 +1048,11 @@ static int rnn_bwd_dx(const Ctx& c, int layer, int din, float* dxin) {
       if (rc != CRNN_ERR_UNSUPPORTED) return rc;
     }
   }
+  // parity mode, two-plane backward: both directions in one stripe-stream launch (gemm_wgrad3.hip)
+  if (!c.cfg->mfma_bf16 && conv_planes(c.cfg, true) == 2 && !(c.cfg->flags & (CRNN_FLAG_GEMM_TILE_KERNELS | CRNN_FLAG_F32_MFMA_GEMMS))) {
+    const int rc = crnn_gemm_nt_f32x2_stream(c.w("dz" + l + "f"), c.p("rnn" + l + "f_w"), c.w("dz" + l + "b"), c.p("rnn" + l + "b_w"), dxin, TB, din, G, G, G, din, c.s);
+    if (rc != CRNN_ERR_UNSUPPORTED) return rc;
+  }
   CRNN_TRY(gemm(c, 1, c.w("dz" + l + "f"), c.p("rnn" + l + "f_w"), dxin, TB, din, G, G, G, din, nullptr, 0, 0, 0, conv_planes(c.cfg, true)));
   return gemm(c, 1, c.w("dz" + l + "b"), c.p("rnn" + l + "b_w"), dxin, TB, din, G, G, G, din, nullptr, 0, 1, 0, conv_planes(c.cfg, true));
 }

@@ -290,6 +290,12 @@ int crnn_pwconv_bnrelu6_wgrad_planes_stream_gp(const float* d, const float* in_b
  * scratch: crnn_pwconv_wgrad_planes_stream_scratch_bytes(K, N, M) */
 int crnn_gemm_tn_planes_stream(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, long K, float* scratch,
                                size_t scratch_bytes, crnn_stream_t stream);
+/* Input gradient of a Bidirectional recurrent layer's input projections in the parity mode (round 6; utils.py:77-82 backwards): Y[M][N] (row stride ldy) =
+ * A0[M][K] . W0[N][K]^T (+ A1 . W1^T when A1 != NULL), everything fp32, two bf16 planes per operand (crnn_gemm_f32x2's precision, another summation order), one
+ * workgroup per 64-row stripe and 128-column slab over the whole reduction of both pairs.  Supported (else -3): M % 64 == 0, N % 128 == 0, K % 64 == 0,
+ * leading dimensions % 4 == 0, 16-byte aligned pointers */
+int crnn_gemm_nt_f32x2_stream(const float* A0, const float* W0, const float* A1, const float* W1, float* Y, int M, int N, int K, int lda, int ldw, int ldy,
+                              crnn_stream_t stream);
 /* The data gradient from PRE-SPLIT planes (round 6, gemm_pres.hip): da[M][N] = dq[M][K] . w[N][K]^T with dq given as bf16 planes
  * (plane pl of dq[m][k] at dq_planes[pl * plane_stride + m * K + k]: the words of crnn_split3_planes; planes = 2 | 3) -- written once by the kernel that produces
  * dq (crnn_bn_bwd_planes_ex) instead of being split by every slice of every GEMM that reads it.  Four waves per workgroup, one per SIMD, the planes of a

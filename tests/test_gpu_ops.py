@@ -1979,6 +1979,32 @@ def test_two_plane_transposed_product_with_leading_dimensions_on_the_pixel_strea
     assert L().crnn_gemm_tn_planes_stream(P(A), lda, P(B), ldb, P(c1), ldc, 64, N, rows, P(scr), ctypes.c_size_t(nb), S()) == -3
 
 
+@pytest.mark.parametrize("M,N,K,pairs,lda,ldw,ldy", [(52 * 256, 128, 1024, 2, 1024, 1024, 128), (52 * 256, 256, 1024, 2, 1024, 1024, 256), (64 * 5, 128, 768, 2, 772, 768, 132),
+                                                      (64, 384, 64, 1, 64, 68, 384), (102 * 64, 256, 1024, 2, 1024, 1024, 256)])
+def test_two_plane_stripe_stream_of_the_recurrent_input_gradients(M, N, K, pairs, lda, ldw, ldy):
+    """crnn_gemm_nt_f32x2_stream (round 6): dX = dZf Wf^T + dZb Wb^T with two bf16 planes per operand in one stripe-stream launch -- against two accumulating
+    crnn_gemm_f32x2 launches (same planes and products, other summation order) and the fp64 sum; one pair alone; padded leading dimensions (columns beyond N
+    of Y's rows untouched); repeats give the same bits; shapes outside the rules are refused."""
+    rs = np.random.RandomState(M % 1000 + N + K)
+    A = [dev((rs.normal(size=(M, lda)) * 0.2).astype(np.float32)) for _ in range(2)]
+    W = [dev((rs.normal(size=(N, ldw)) * 0.1).astype(np.float32)) for _ in range(2)]
+    y1 = torch.full((M + 1, ldy), 7.0, device="cuda"); y2 = torch.full((M + 1, ldy), 7.0, device="cuda"); y0 = zeros(M, ldy)
+    a1 = P(A[1]) if pairs == 2 else None; w1 = P(W[1]) if pairs == 2 else None
+    ok(L().crnn_gemm_nt_f32x2_stream(P(A[0]), P(W[0]), a1, w1, P(y1), M, N, K, lda, ldw, ldy, S()))
+    ok(L().crnn_gemm_nt_f32x2_stream(P(A[0]), P(W[0]), a1, w1, P(y2), M, N, K, lda, ldw, ldy, S()))
+    assert torch.equal(y1, y2) and bool((y1[M:] == 7.0).all()) and bool((y1[:, N:] == 7.0).all())
+    scr = zeros(16 * 1024 * 1024); sb = ctypes.c_size_t(scr.numel() * 4)
+    ok(L().crnn_gemm_f32x2(1, P(A[0]), P(W[0]), P(y0), M, N, K, lda, ldw, ldy, None, 0, 0, 0, P(scr), sb, S()))
+    if pairs == 2: ok(L().crnn_gemm_f32x2(1, P(A[1]), P(W[1]), P(y0), M, N, K, lda, ldw, ldy, None, 0, 1, 0, P(scr), sb, S()))
+    ref = sum(host(A[i])[:, :K].astype(np.float64) @ host(W[i])[:, :K].astype(np.float64).T for i in range(pairs))
+    sc = np.abs(ref).max()
+    assert float((y1[:M, :N] - y0[:, :N]).abs().max()) <= 2e-6 * sc + 1e-6, (float((y1[:M, :N] - y0[:, :N]).abs().max()), sc)
+    assert np.abs(host(y1[:M, :N]) - ref).max() <= 3e-5 * sc + 1e-6
+    assert L().crnn_gemm_nt_f32x2_stream(P(A[0]), P(W[0]), a1, w1, P(y1), M + 32, N, K, lda, ldw, ldy, S()) == -3
+    assert L().crnn_gemm_nt_f32x2_stream(P(A[0]), P(W[0]), a1, w1, P(y1), M, 64, K, lda, ldw, ldy, S()) == -3
+    assert L().crnn_gemm_nt_f32x2_stream(P(A[0]), P(W[0]), P(A[1]), None, P(y1), M, N, K, lda, ldw, ldy, S()) == -2
+
+
 def _planes_of(x, stride=None):
     """crnn_split3_planes of a device fp32 tensor -> (planes tensor [3 * stride] of bf16 words, stride)."""
     n = x.numel(); stride = stride or n
