@@ -31,6 +31,7 @@ struct Wg3Params {
   int M, N, K;
   int chunks;        // M / 32
   int TI, TJ, nsplit, per, lda, ldg;
+  int flat;          // more tiles than an XCD has CUs (dense1's weight gradient: 36): grid = tiles * nsplit, id -> (tile = id % tiles, range = id / tiles), as gemm_wgrad.hip
 };
 
 constexpr int kLd3 = 128 + 32;                // bf16 row stride of a k-major operand plane (320 B)
@@ -88,8 +89,8 @@ __global__ __launch_bounds__(GPL ? 512 + 64 * kLoaders3 : 512, GPL ? 1 : 2 * W3G
   // workgroup -> (xcd, local) -> (range, tile): the tiles of a range are neighbours on one XCD
   const int wg = blockIdx.x, x = wg & 7, loc = wg >> 3;
   const int tiles = p.TI * p.TJ;
-  const int lin = loc % tiles, rloc = loc / tiles;
-  const int split = rloc * 8 + x;
+  const int lin = p.flat ? wg % tiles : loc % tiles, rloc = loc / tiles;
+  const int split = p.flat ? wg / tiles : rloc * 8 + x;
   if (split >= p.nsplit) return;
   const int ti = lin / p.TJ, tj = lin % p.TJ;
   const int c0 = split * p.per;
@@ -285,19 +286,21 @@ void wg3_geom(long M, int N, int K, Wg3Params& p, int& grid) {
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
   int ns = (W3G_WGS * cus / tiles) & ~7;                                  // one workgroup per CU, a multiple of 8 ranges (8 XCDs)
-  if (ns < 8) ns = 8;
+  p.flat = tiles > cus / 8;
+  if (p.flat) ns = cus / tiles < 1 ? 1 : cus / tiles;           // (round 6: dense1's 36 feature tiles -- cus / tiles ranges, one workgroup per CU)
+  else if (ns < 8) ns = 8;
   while (ns > 8 && p.chunks / ns < 2 * kD3) ns -= 8;            // a range is at least two pipeline depths long
   if (ns > p.chunks) ns = p.chunks;
   p.per = cdiv(p.chunks, ns);
   p.nsplit = cdiv(p.chunks, p.per);                             // drop empty tail ranges
-  grid = 8 * cdiv(p.nsplit, 8) * tiles;
+  grid = p.flat ? p.nsplit * tiles : 8 * cdiv(p.nsplit, 8) * tiles;
 }
 
 }  // namespace
 
-// 0 if crnn_pwconv_bnrelu6_wgrad_planes_stream handles the shape (whole 32-pixel chunks, K and N multiples of 128 up to 1024, at most 32 tiles), else -3
+// 0 if crnn_pwconv_bnrelu6_wgrad_planes_stream handles the shape (whole 32-pixel chunks, K a multiple of 128 up to 8192, N up to 1024, at most 64 tiles), else -3
 extern "C" int crnn_pwconv_wgrad_planes_stream_supported(long M, int N, int K) {
-  return (M >= 32 && M % 32 == 0 && N >= 128 && N % 128 == 0 && K >= 128 && K % 128 == 0 && N <= 1024 && K <= 1024 && (K / 128) * (N / 128) <= 32 &&
+  return (M >= 32 && M % 32 == 0 && N >= 128 && N % 128 == 0 && K >= 128 && K % 128 == 0 && N <= 1024 && K <= 8192 && (K / 128) * (N / 128) <= 64 &&
           M * (long)(K > N ? K : N) < (1L << 31)) ? CRNN_OK : CRNN_ERR_UNSUPPORTED;
 }
 extern "C" size_t crnn_pwconv_wgrad_planes_stream_scratch_bytes(long M, int N, int K) {

@@ -1169,6 +1169,11 @@ int backward_top(const Ctx& c0, const int* labels, const int* input_length, cons
   if (wres1 && c.dt("x7") == CRNN_BF16)   // both operands bf16: the pixel-streaming weight-gradient kernel, 36 feature tiles x 7 row ranges (gemm_wgrad.hip)
     rcw = crnn_gemm_tn_bf16_stream(feat, d.feat, c.w("gbm16"), d.tds, c.g("dense1_w"), d.tds, d.feat, d.tds, TB, c.scratch(), kGemmScratchBytes, stream);
   if (rcw != CRNN_OK && rcw != CRNN_ERR_UNSUPPORTED) return rcw;
+  // parity mode, two-plane backward: the pixel-stream form (gemm_wgrad3.hip; 36 feature tiles x 7 row ranges)
+  if (rcw != CRNN_OK && !cfg->mfma_bf16 && c.dt("x7") == CRNN_F32 && conv_planes(cfg, true) == 2 && !(cfg->flags & (CRNN_FLAG_GEMM_TILE_KERNELS | CRNN_FLAG_F32_MFMA_GEMMS))) {
+    rcw = crnn_gemm_tn_planes_stream(feat, d.feat, c.w("gbm"), d.tds, c.g("dense1_w"), d.tds, d.feat, d.tds, TB, c.scratch(), kGemmScratchBytes, stream);
+    if (rcw != CRNN_OK && rcw != CRNN_ERR_UNSUPPORTED) return rcw;
+  }
   if (rcw != CRNN_OK)
     CRNN_TRY(gemm_t(c, 2, feat, c.dt("x7"), c.w("gbm"), CRNN_F32, c.g("dense1_w"), CRNN_F32, d.feat, d.tds, TB, d.feat, d.tds, d.tds, nullptr, 0, 0, 0, conv_planes(cfg, true)));
   CRNN_TRY(colsum(c, c.w("gbm"), TB, d.tds, d.tds, c.g("dense1_b")));

@@ -1951,11 +1951,12 @@ def test_two_plane_weight_gradient_on_the_pixel_stream_equals_the_tile_kernel(M,
     assert float((dw1[:K] - dw0).abs().max()) <= 2e-6 * sc + 1e-6, (float((dw1[:K] - dw0).abs().max()), sc)
     assert np.abs(host(dw1[:K]) - ref).max() <= 3e-5 * sc + 1e-6
     assert L().crnn_pwconv_wgrad_planes_stream_supported(M + 8, N, K) == -3 and L().crnn_pwconv_wgrad_planes_stream_supported(M, N, 64) == -3
+    assert L().crnn_pwconv_wgrad_planes_stream_supported(M, 1024, 1152) == -3      # 72 tiles
     assert L().crnn_pwconv_bnrelu6_wgrad_planes_stream(P(d), P(st), P(g), P(dw1), M, N, K, P(scr), ctypes.c_size_t(1024), S()) == -3
 
 
 @pytest.mark.parametrize("rows,M,N,lda,ldb,ldc", [(52 * 256, 128, 1024, 128, 1024, 1024), (51 * 256, 256, 1024, 512, 1024, 1024), (51 * 64, 256, 1024, 256, 1024, 1028),
-                                                    (32 * 3, 128, 128, 132, 136, 128)])
+                                                    (32 * 3, 128, 128, 132, 136, 128), (52 * 256, 4608, 128, 4608, 128, 128), (52 * 16, 1152, 256, 1152, 256, 256)])
 def test_two_plane_transposed_product_with_leading_dimensions_on_the_pixel_stream(rows, M, N, lda, ldb, ldc):
     """crnn_gemm_tn_planes_stream (round 6): C = A^T B over the rows of A [rows][lda >= M] and B [rows][ldb >= N] -- the recurrent layers' weight gradients of the
     parity mode (x^T dz, h_prev^T dz; h_prev a column half of the concatenated hidden states: lda = 2u) -- against crnn_gemm_f32x2 mode 2 (same planes and
