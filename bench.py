@@ -30,7 +30,7 @@ import torch  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (not the 2:1-sparsity figure)
 PEAK_HBM_GBS = 8000.0
-PMC_ROUND = "r06"               # the committed counter passes the *_roofline objects quote (profiles/<PMC_ROUND>_pmc_step_<mode>.json, visit r06bn)
+PMC_ROUND = "r06"               # the committed counter passes the *_roofline objects quote (profiles/<PMC_ROUND>_pmc_step_<mode>.json, visit r06bo)
 
 
 def pmc_step_traffic(eng, prefixes, grids=None):
@@ -71,7 +71,7 @@ def pmc_mfma_util(eng, prefixes):
 
 
 PMC_NOTE = ("memory-side bytes of the same kernels in the train step, per launch set: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE passes over `bench.py "
-            "--steps 3 --warmup 2` (profiles/r06_pmc_step_%s.json, profiles/r06_pmc_sq_step_%s.txt: committed constants of visit r06bn, not measured in this run); counted in the step's order and cache state -- the L2s' "
+            "--steps 3 --warmup 2` (profiles/r06_pmc_step_%s.json, profiles/r06_pmc_sq_step_%s.txt: committed constants of visit r06bo, not measured in this run); counted in the step's order and cache state -- the L2s' "
             "requests to the fabric, last-level-cache hits included -- while `achieved` is timed on the re-issued launches")
 
 
