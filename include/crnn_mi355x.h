@@ -74,7 +74,9 @@ typedef struct {
 #define CRNN_FLAG_GEMM_TILE_KERNELS 2 /* every pointwise conv of the conv stack (forward, data gradient, weight gradient) on the tile-per-workgroup
                                          GEMM (crnn_gemm_bf16_ex / crnn_pwconv_bnrelu6_*) instead of the streaming kernels (crnn_pwconv_bnrelu6_fwd_wres,
                                          crnn_gemm_wres_bf16, crnn_pwconv_bnrelu6_wgrad_stream).  Same products and data gradients bit for bit; the
-                                         BatchNorm-2 statistics and the weight gradients are the same sums in another order (fp32 round-off) */
+                                         BatchNorm-2 statistics and the weight gradients are the same sums in another order (fp32 round-off).  In the parity mode it
+                                         also returns the recurrent layers' and dense1's gradients from the round-6 plane streams (crnn_gemm_tn_planes_stream,
+                                         crnn_gemm_nt_f32x2_stream) to the tile kernel: same planes and products, another summation order */
 #define CRNN_FLAG_THREE_PLANE_BACKWARD 65536 /* parity mode: the backward GEMMs (weight and data gradients of the conv stack, the dense layers and the RNN projections)
                                          with three bf16 planes per operand (fp32-accurate, as the forward) instead of two (crnn_gemm_f32x2*: 16 significant
                                          bits per factor, gradients within 1e-5 of these, half the MFMA work -- the default since round 4) */
